@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""bench.py -- GAN train frames/sec (one D-update + one G-update on the same minibatch).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json north_star / SURVEY.md 8d): synthetic [B=64, T=100, 257 -> 40] per GPU
+(weak scaling: the reference defines batch_size per tower, models/gan_rnn_placeholder.py:96),
+reference-true networks G = FC 257->280 + 3 x LSTMP(760, proj 280) + FC 280->40
+(models/lstm.py:43-45) and D = 2 x LSTMP(256, proj 40) + FC 40->1
+(models/discriminator_lstm.py:26-28), seed-1234 N(0,1) inputs, xavier-uniform seed-4321 weights,
+g_lr 8e-5, d_lr 1e-3, mse_lambda 10, clip 15, noise std 0 (run_gan_rnn_placeholder.sh:124-142).
+A step = disc_updates=1 D-run + gen_updates=1 G-run through the C ABI (the G-run reuses the D-run's
+generator forward: G does not change in between).  Inputs are resident in HBM when the timed region
+starts.  One JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic GEMM FLOP per frame of one (1 D + 1 G) step = 3*F_G + 8*F_D
+PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+
+
+def flop_per_frame(din, dout, g_type, gl, gh, gp, dl_, dh, dp):
+    lstmp = lambda i, h, p: 2 * ((i + p) * 4 * h + h * p)
+    fc = lambda i, o: 2 * i * o
+    if g_type == "lstm":
+        fg = fc(din, gp) + gl * lstmp(gp, gh, gp) + fc(gp, dout)
+    else:
+        fg = lstmp(din, gh, gp) + (gl - 1) * lstmp(gp, gh, gp) + fc(gp, dout)
+    fd = lstmp(dout, dh, dp) + (dl_ - 1) * lstmp(dp, dh, dp) + fc(dp, 1)
+    return 3 * fg + 8 * fd, fg, fd
+
+
+def synthetic(B, T, din, dout, seed=1234):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, T, din)).astype(np.float32)
+    lab = rng.standard_normal((B, T, dout)).astype(np.float32)
+    ln = np.full(B, T, np.int32)
+    return x, lab, ln
+
+
+def cpu_baseline(net, B, T, budget_s=20.0):
+    """The oracle's torch-CPU twin timed on this box's host cores on a bounded sample of the SAME
+    workload (kind 'port': the reference's TF-1.4 path cannot run here)."""
+    from oracle import rsrgan_oracle as O
+    from oracle import torch_twin as TT
+    cfg = O.NetCfg() if net == "lstm" else O.NetCfg.res_lstm_l()
+    g = O.xavier_init(O.g_param_specs(cfg), np.random.default_rng(4321), np.float32)
+    d = O.xavier_init(O.d_param_specs(cfg), np.random.default_rng(4322), np.float32)
+    tw = TT.GanRnnTorchTwin(cfg, g, d)
+    x, lab, ln = synthetic(B, T, cfg.input_dim, cfg.output_dim)
+    threads = torch.get_num_threads()
+    t0 = time.time(); n = 0
+    while True:
+        tw.d_step(x, lab, ln); tw.g_step(x, lab, ln); n += 1
+        if n >= 4 or time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    model_name = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model_name = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    return {"value": round(B * T * n / dt, 1), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "%d full (1D+1G) steps of the same [B=%d,T=%d] workload, oracle/torch_twin.py fp32, "
+                      "os.cpu_count=%s, cpu=%s" % (n, B, T, os.cpu_count(), model_name)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--frames", type=int, default=100)
+    ap.add_argument("--net", default="lstm", choices=["lstm", "res_lstm_l"])
+    ap.add_argument("--gen-updates", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    from rsrgan_amd import GAN_RNN, dist as rdist
+    rank, local, world = rdist.init_from_env("nccl")
+    if world != max(a.gpus, 1):
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from types import SimpleNamespace
+    B, T = a.batch, a.frames
+    args = SimpleNamespace(batch_size=B, input_dim=257, output_dim=40, left_context=0, right_context=0, g_type=a.net,
+                           keep_prob=1.0, batch_norm=False, num_gpu=world, save_dir=None, l2_scale=0.0,
+                           disc_updates=1, gen_updates=a.gen_updates, init_mse_weight=10.0, init_disc_noise_std=0.0,
+                           d_learning_rate=1e-3 * world, g_learning_rate=8e-5 * world)   # LR x num_gpu (:458-459)
+    model = GAN_RNN(None, args, ["gpu:%d" % local], max_frames=T, seed=4321)
+    x, lab, ln = synthetic(B, T, 257, 40, seed=1234 + rank)
+    x = torch.from_numpy(x).to(dev); lab = torch.from_numpy(lab).to(dev); ln = torch.from_numpy(ln).to(dev)
+
+    def step():
+        model.d_step(x, lab, ln, sync=False)
+        out = None
+        for i in range(a.gen_updates):
+            out = model.g_step(x, lab, ln, reuse_g_forward=(i == 0), sync=False)
+        return out
+
+    for _ in range(a.warmup):
+        step()
+    rdist.barrier(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(a.steps):
+        last = step()
+    e1.record()
+    torch.cuda.synchronize(); rdist.barrier()
+    dt = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        t = torch.tensor([dt, dev_ms], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt, dev_ms = float(t[0]), float(t[1])
+    losses = last.mean(0).cpu().numpy()
+    if not np.all(np.isfinite(losses)):
+        raise SystemExit("non-finite losses: %s" % losses)
+
+    if rank == 0:
+        c = model.engine.cfg
+        fpf, fg, fd = flop_per_frame(257, 40, a.net, c.g_layers, c.g_cells, c.g_proj, c.d_layers, c.d_cells, c.d_proj)
+        if a.gen_updates != 1:
+            fpf = None
+        frames = B * T * world * a.steps
+        value = frames / dt
+        step_dev_s = dev_ms * 1e-3 / a.steps
+        roof = None
+        if fpf:
+            ach = fpf * B * T / step_dev_s / 1e12          # per GPU, HIP-event time of the whole step's launches
+            roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "scope": "all launches of one (1D+1G) step on one GPU; algorithmic %d FLOP/frame x %d frames "
+                             "(SURVEY 8d: 3*F_G+8*F_D, F_G=%d, F_D=%d) / HIP-event step time" % (fpf, B * T, fg, fd)}
+        out = {"metric": "GAN train frames/sec (G+D step), 257-dim LPS->40-dim MFCC", "value": round(value, 1),
+               "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(dt * 1e3 / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "gan_rnn_placeholder 1D+%dG step, G=%s(%dx%d/p%d)+D=lstm(%dx%d/p%d), B=%d/GPU T=%d, "
+                                      "257->40" % (a.gen_updates, a.net, c.g_layers, c.g_cells, c.g_proj, c.d_layers,
+                                                   c.d_cells, c.d_proj, B, T),
+                          "global_batch": B * world, "frames_per_step": B * T * world, "parallelism": "dp%d" % world,
+                          "losses_last_step": [round(float(v), 6) for v in losses]},
+               "roofline": roof}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.net, B, T)
+        print(json.dumps(out), flush=True)
+    rdist.barrier()
+
+
+if __name__ == "__main__":
+    main()

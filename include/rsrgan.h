@@ -1,0 +1,196 @@
+/* rsrgan.h -- C ABI of librsrgan_hip.so: RSRGAN's sequence-level GAN training step
+ * (LSTMP generator + LSTMP discriminator, LSGAN losses, SGD(D)/Adam(G)) as
+ * hand-written HIP kernels for MI355X (gfx950).
+ *
+ * The reference (wangkenpu/rsrgan, Python 2.7 + TensorFlow 1.4) has no FFI; the
+ * de-facto boundary is the object surface that
+ *   scripts/train_gan_rnn_placeholder.py:train_one_iteration (:48-133),
+ *   eval_one_iteration (:136-201) and decode (:204-302)
+ * touch on models/gan_rnn_placeholder.py:GAN_RNN (:62-298).  Every entry point
+ * below names the reference interface it replaces.  The reference-side binding
+ * (a ctypes stub a maintainer would drop into models/gan_rnn_placeholder.py) is
+ * shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no torch types.  Every `const float*` / `float*` data pointer is a
+ *     DEVICE pointer owned by the caller (e.g. torch.Tensor.data_ptr()) and is
+ *     only borrowed for the duration of the call's stream work, exactly like a
+ *     TF feed_dict entry (gan_rnn_placeholder.py:94-104).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All
+ *     work is enqueued asynchronously on it; nothing synchronises the device.
+ *   - every function returns 0 on success or a negative rsrgan_status; nothing
+ *     throws across the ABI; rsrgan_last_error() returns a thread-local string.
+ *   - one handle per process/GPU, single caller thread
+ *     (train_gan_rnn_placeholder.py:463-478: all sess.run calls come from the
+ *     main thread).
+ *   - all arithmetic is IEEE fp32 (tf.float32 placeholders, :94-104).
+ */
+#ifndef RSRGAN_H_
+#define RSRGAN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rsrgan_status {
+  RSRGAN_OK = 0,
+  RSRGAN_ERR_INVALID = -1,     /* bad argument / unsupported configuration (ValueError in the reference, :131-132) */
+  RSRGAN_ERR_HIP = -2,         /* a HIP runtime call failed */
+  RSRGAN_ERR_NO_DEVICE = -3,   /* no gfx950 device visible */
+  RSRGAN_ERR_STATE = -4        /* call sequence error (e.g. apply without backward) */
+} rsrgan_status;
+
+/* args.g_type (gan_rnn_placeholder.py:125-132) */
+enum { RSRGAN_G_LSTM = 0, RSRGAN_G_RES_LSTM_L = 1, RSRGAN_G_RES_LSTM_BASE = 2 };
+/* self.discriminator (gan_rnn_placeholder.py:117) */
+enum { RSRGAN_D_LSTM = 0 };
+/* which network a call addresses */
+enum { RSRGAN_NET_G = 0, RSRGAN_NET_D = 1 };
+
+/* Mutable scalars that the reference changes with sess.run(tf.assign(...))
+ * between steps (train_gan_rnn_placeholder.py:63-64,460-461,531-533;
+ * gan_rnn_placeholder.py:112-123). */
+typedef enum rsrgan_scalar {
+  RSRGAN_G_LEARNING_RATE = 0,
+  RSRGAN_D_LEARNING_RATE = 1,
+  RSRGAN_MSE_LAMBDA = 2,
+  RSRGAN_D_REAL = 3,
+  RSRGAN_D_FAKE = 4,
+  RSRGAN_L2_SCALE = 5,
+  RSRGAN_CLIP_NORM = 6,
+  RSRGAN_ADAM_STEP = 7,       /* Adam's t (beta powers), for checkpoint/resume */
+  RSRGAN_SCALAR_COUNT_
+} rsrgan_scalar;
+
+/* Construction arguments: the fields GAN_RNN.__init__ reads from `args`
+ * (gan_rnn_placeholder.py:65-137) plus the layer sizes the reference
+ * hard-codes (models/lstm.py:43-45, models/res_lstm_l.py:43-45,
+ * models/discriminator_lstm.py:26-28) made runtime parameters. */
+typedef struct rsrgan_cfg {
+  int32_t batch_size;      /* per-GPU B (:96) */
+  int32_t max_frames;      /* capacity for the padded time axis T */
+  int32_t input_dim;       /* input_dim*(left_context+1+right_context) (:96-98) */
+  int32_t output_dim;      /* 40 */
+  int32_t g_type;          /* RSRGAN_G_* */
+  int32_t g_layers;        /* 3 (lstm) / 4 (res_lstm_*) */
+  int32_t g_cells;         /* 760 */
+  int32_t g_proj;          /* 280 (lstm) / 257 (res_lstm_*) */
+  int32_t d_type;          /* RSRGAN_D_LSTM */
+  int32_t d_layers;        /* 2 */
+  int32_t d_cells;         /* 256 */
+  int32_t d_proj;          /* 40 */
+  float   l2_scale;        /* args.l2_scale (:91) */
+  float   clip_norm;       /* self.max_grad_norm = 15 (:71) */
+  float   adam_beta1;      /* 0.9   (tf.train.AdamOptimizer defaults, :147) */
+  float   adam_beta2;      /* 0.999 */
+  float   adam_eps;        /* 1e-8  */
+  float   ema_decay;       /* MOVING_AVERAGE_DECAY 0.9999 (:70); 0 disables the shadow copy */
+  float   lrelu_alpha;     /* utils/ops.py:120 (0.3) */
+  float   forget_bias;     /* LSTMCell(forget_bias=1.0) (models/lstm.py:94) */
+  int32_t cross_validation;/* 1 = the cross_validation=True twin: no L2 term (:253) */
+  int32_t flags;           /* RSRGAN_FLAG_* */
+} rsrgan_cfg;
+
+enum {
+  RSRGAN_FLAG_WAVEFRONT = 1,   /* run the stacked LSTMs as one (layer,t) wavefront (default schedule when set) */
+  RSRGAN_FLAG_GRAPH = 2        /* capture the per-step launch sequence into a hipGraph and replay it */
+};
+
+typedef struct rsrgan_handle_s* rsrgan_handle;
+
+/* fills *cfg with the reference's hard-coded sizes for `g_type`. */
+int rsrgan_default_cfg(int32_t g_type, rsrgan_cfg* cfg);
+
+/* GAN_RNN(sess, args, devices, cross_validation, infer) (gan_rnn_placeholder.py:65-137).
+ * Allocates parameters (xavier-uniform / zero biases from `seed`, as
+ * xavier_initializer()/zeros_initializer(), models/lstm.py:86-87), optimizer
+ * state and all activation stashes for (batch_size, max_frames). */
+int rsrgan_create(const rsrgan_cfg* cfg, uint64_t seed, rsrgan_handle* out);
+int rsrgan_destroy(rsrgan_handle h);
+const char* rsrgan_last_error(void);
+
+/* sess.run(tf.assign(model.<scalar>, v)) (train_gan_rnn_placeholder.py:63-64,460-461,531-533) */
+int rsrgan_set_scalar(rsrgan_handle h, int32_t which, double v);
+int rsrgan_get_scalar(rsrgan_handle h, int32_t which, double* v);
+
+/* Variable table == tf.trainable_variables() split by the g_/d_ prefix
+ * (gan_rnn_placeholder.py:301-317), in graph-construction order. */
+int rsrgan_num_tensors(rsrgan_handle h, int32_t net);
+int rsrgan_tensor_info(rsrgan_handle h, int32_t net, int32_t idx,
+                       char* name, int32_t name_cap,
+                       int32_t* rows, int32_t* cols, int64_t* dense_offset);
+/* number of floats of the DENSE (TF-shaped, unpadded) flat parameter vector */
+int64_t rsrgan_param_count(rsrgan_handle h, int32_t net);
+
+/* tf.train.Saver save/restore payload (gan_rnn_placeholder.py:26-60) and parity
+ * injection: dense flat vectors in variable-table order, DEVICE pointers.
+ * `what`: 0 = variables, 1 = Adam m, 2 = Adam v (G only), 3 = EMA shadow. */
+int rsrgan_get_params(rsrgan_handle h, int32_t net, int32_t what, float* dense, void* stream);
+int rsrgan_set_params(rsrgan_handle h, int32_t net, int32_t what, const float* dense, void* stream);
+/* last computed (tower-local or all-reduced) gradients, dense, for tests */
+int rsrgan_get_grads(rsrgan_handle h, int32_t net, float* dense, void* stream);
+
+/* sess.run(model.g_outputs, {inputs, lengths}) (train_gan_rnn_placeholder.py:282-285)
+ *   x [B,T,Din] batch-major, lengths int32 [B], y [B,T,Dout]. */
+int rsrgan_forward_g(rsrgan_handle h, const float* x, const int32_t* lengths, int32_t T,
+                     float* y, void* stream);
+
+/* sess.run([model.d_opt, model.d_rl_losses, model.d_fk_losses, model.d_losses], feed)
+ * (train_gan_rnn_placeholder.py:77-82).  labels [B,T,Dout].  noise_real/noise_fake
+ * are the two gaussian_noise_layer draws ([B,Dout], broadcast over T,
+ * utils/ops.py:19-30) or NULL for disc_noise_std == 0.  out_losses: DEVICE
+ * float[3] = {d_rl, d_fk, d_loss}.  train=0 gives the eval fetch
+ * (train_gan_rnn_placeholder.py:154-160): losses only, no update. */
+int rsrgan_d_step(rsrgan_handle h, const float* x, const float* labels, const int32_t* lengths,
+                  int32_t T, const float* noise_real, const float* noise_fake,
+                  float* out_losses, int32_t train, void* stream);
+
+/* sess.run([model.g_opt, model.g_adv_losses, model.g_mse_losses, model.g_l2_losses,
+ *           model.g_losses], feed) (train_gan_rnn_placeholder.py:94-101).
+ * out_losses: DEVICE float[4] = {g_adv, g_mse, g_l2, g_loss}.
+ * reuse_g_forward=1: the generator forward of the immediately preceding
+ * rsrgan_d_step / rsrgan_d_backward on the SAME batch is still valid (G did not
+ * change in between) and is not recomputed. */
+int rsrgan_g_step(rsrgan_handle h, const float* x, const float* labels, const int32_t* lengths,
+                  int32_t T, const float* noise_fake, float* out_losses,
+                  int32_t train, int32_t reuse_g_forward, void* stream);
+
+/* Data-parallel split of the two steps (gan_rnn_placeholder.py:164-184):
+ *   *_backward  = per-tower compute_gradients (:169,:173) into the gradient
+ *                 buffer, losses as above;
+ *   caller      = average_gradients over towers (utils/ops.py:343-376) as an
+ *                 RCCL all-reduce(avg) of rsrgan_grad_buffer();
+ *   *_apply     = clip_by_norm per tensor (:178-182) then apply_gradients
+ *                 (:183-184) and the EMA (:185-186). */
+int rsrgan_d_backward(rsrgan_handle h, const float* x, const float* labels, const int32_t* lengths,
+                      int32_t T, const float* noise_real, const float* noise_fake,
+                      float* out_losses, void* stream);
+int rsrgan_g_backward(rsrgan_handle h, const float* x, const float* labels, const int32_t* lengths,
+                      int32_t T, const float* noise_fake, float* out_losses,
+                      int32_t reuse_g_forward, void* stream);
+int rsrgan_apply(rsrgan_handle h, int32_t net, void* stream);
+/* device pointer + float count of the (padded) flat gradient buffer of `net`;
+ * padding entries are always zero, so it can be all-reduced as one message. */
+int rsrgan_grad_buffer(rsrgan_handle h, int32_t net, float** ptr, int64_t* count);
+
+/* ---- low-level operator entry points (unit parity tests + micro-benchmarks) ----
+ * C[M,N] = op(A)*op(B) (+bias) with fp32 MFMA.  a_kcontig: A is [M,K] row-major
+ * (else stored [K,M]); b_kcontig: B is stored [N,K] (else [K,N] row-major).
+ * All leading dimensions must be multiples of 4 floats, pointers 16-byte aligned.
+ * act: 0 none, 1 leaky-relu(alpha).  accumulate: C += result. */
+int rsrgan_op_gemm(const float* A, int32_t lda, int32_t a_kcontig,
+                   const float* B, int32_t ldb, int32_t b_kcontig,
+                   float* C, int32_t ldc, int32_t M, int32_t N, int32_t K,
+                   const float* bias, int32_t act, float alpha, int32_t accumulate, void* stream);
+
+/* time (microseconds, averaged) of the dominant kernel classes of the last
+ * step, measured with HIP events on `stream`; used by bench.py's roofline. */
+int rsrgan_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSRGAN_H_ */

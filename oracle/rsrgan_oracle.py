@@ -486,6 +486,23 @@ class GanRnnOracle:
                 grads[k] = grads[k] + v
         return (g_adv, mse, g_l2, g_loss), grads, y
 
+    # -- clip_by_norm per tensor (:178-182) then apply_gradients (:183-184), EMA (:185-186) --
+    def apply_d(self, avg):
+        for k in self.d:                                          # SGD :144,183
+            self.d[k] = self.d[k] - self.d_learning_rate * clip_by_norm(avg[k], self.clip_norm)
+            self.d_ema[k] = self.ema_decay * self.d_ema[k] + (1 - self.ema_decay) * self.d[k]
+
+    def apply_g(self, avg):
+        self.adam_t += 1                                          # Adam :147,184
+        t = self.adam_t
+        lr_t = self.g_learning_rate * math.sqrt(1 - self.beta2 ** t) / (1 - self.beta1 ** t)
+        for k in self.g:
+            g = clip_by_norm(avg[k], self.clip_norm)
+            self.adam_m[k] = self.beta1 * self.adam_m[k] + (1 - self.beta1) * g
+            self.adam_v[k] = self.beta2 * self.adam_v[k] + (1 - self.beta2) * g * g
+            self.g[k] = self.g[k] - lr_t * self.adam_m[k] / (np.sqrt(self.adam_v[k]) + self.eps)
+            self.g_ema[k] = self.ema_decay * self.g_ema[k] + (1 - self.ema_decay) * self.g[k]
+
     # -- sess.run([model.d_opt, ...]) (train_gan_rnn_placeholder.py:77-82) -------
     def d_step(self, inputs, labels, lengths, noise_real=None, noise_fake=None, train=True):
         x = np.asarray(inputs, self.dtype); lab = np.asarray(labels, self.dtype)
@@ -496,10 +513,7 @@ class GanRnnOracle:
                                  self._slice(noise_real, k), self._slice(noise_fake, k), want_grads=train)
             losses.append(ls); tower_grads.append(g)
         if train:
-            avg = average_gradients(tower_grads)
-            for k in self.d:                                      # SGD :144,183
-                self.d[k] = self.d[k] - self.d_learning_rate * clip_by_norm(avg[k], self.clip_norm)
-                self.d_ema[k] = self.ema_decay * self.d_ema[k] + (1 - self.ema_decay) * self.d[k]
+            self.apply_d(average_gradients(tower_grads))
         rl, fk, dl = zip(*losses)
         return list(rl), list(fk), list(dl)
 
@@ -513,16 +527,7 @@ class GanRnnOracle:
                                     self._slice(noise_fake, k), want_grads=train)
             losses.append(ls); tower_grads.append(g)
         if train:
-            avg = average_gradients(tower_grads)
-            self.adam_t += 1                                       # Adam :147,184
-            t = self.adam_t
-            lr_t = self.g_learning_rate * math.sqrt(1 - self.beta2 ** t) / (1 - self.beta1 ** t)
-            for k in self.g:
-                g = clip_by_norm(avg[k], self.clip_norm)
-                self.adam_m[k] = self.beta1 * self.adam_m[k] + (1 - self.beta1) * g
-                self.adam_v[k] = self.beta2 * self.adam_v[k] + (1 - self.beta2) * g * g
-                self.g[k] = self.g[k] - lr_t * self.adam_m[k] / (np.sqrt(self.adam_v[k]) + self.eps)
-                self.g_ema[k] = self.ema_decay * self.g_ema[k] + (1 - self.ema_decay) * self.g[k]
+            self.apply_g(average_gradients(tower_grads))
         adv, mse, l2, gl = zip(*losses)
         return list(adv), list(mse), list(l2), list(gl)
 

@@ -1,0 +1,220 @@
+// capi.cpp -- extern "C" entry points declared in include/rsrgan.h.
+#include <cstring>
+#include <new>
+
+#include "model.h"
+
+using namespace rsr;
+
+struct rsrgan_handle_s { Model m; };
+
+#define CHECK_H(h)                                                    \
+  if (!(h)) { set_error("null handle"); return RSRGAN_ERR_INVALID; }
+
+extern "C" {
+
+const char* rsrgan_last_error(void) { return get_error(); }
+int rsrgan_version(void) { return 100; }
+
+int rsrgan_default_cfg(int32_t g_type, rsrgan_cfg* c) {
+  if (!c) { set_error("null cfg"); return RSRGAN_ERR_INVALID; }
+  std::memset(c, 0, sizeof(*c));
+  c->batch_size = 8; c->max_frames = 100; c->input_dim = 257; c->output_dim = 40;
+  c->g_type = g_type;
+  if (g_type == RSRGAN_G_LSTM) { c->g_layers = 3; c->g_cells = 760; c->g_proj = 280; }           // models/lstm.py:43-45
+  else if (g_type == RSRGAN_G_RES_LSTM_L || g_type == RSRGAN_G_RES_LSTM_BASE) { c->g_layers = 4; c->g_cells = 760; c->g_proj = 257; }  // models/res_lstm_l.py:43-45
+  else { set_error("Unrecognized G type %d", g_type); return RSRGAN_ERR_INVALID; }
+  c->d_type = RSRGAN_D_LSTM; c->d_layers = 2; c->d_cells = 256; c->d_proj = 40;                   // models/discriminator_lstm.py:26-28
+  c->l2_scale = 0.f; c->clip_norm = 15.f; c->adam_beta1 = 0.9f; c->adam_beta2 = 0.999f; c->adam_eps = 1e-8f;
+  c->ema_decay = 0.9999f; c->lrelu_alpha = 0.3f; c->forget_bias = 1.0f; c->cross_validation = 0; c->flags = 0;
+  return RSRGAN_OK;
+}
+
+int rsrgan_create(const rsrgan_cfg* cfg, uint64_t seed, rsrgan_handle* out) {
+  if (!cfg || !out) { set_error("null argument"); return RSRGAN_ERR_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("no HIP device visible: librsrgan_hip needs an MI355X (gfx950); there is no CPU fallback");
+    return RSRGAN_ERR_NO_DEVICE;
+  }
+  rsrgan_handle h = new (std::nothrow) rsrgan_handle_s();
+  if (!h) { set_error("out of host memory"); return RSRGAN_ERR_INVALID; }
+  int rc = h->m.init(*cfg, seed);
+  if (rc != RSRGAN_OK) { h->m.destroy(); delete h; return rc; }
+  *out = h;
+  return RSRGAN_OK;
+}
+
+int rsrgan_destroy(rsrgan_handle h) {
+  CHECK_H(h);
+  hipDeviceSynchronize();
+  h->m.destroy();
+  delete h;
+  return RSRGAN_OK;
+}
+
+int rsrgan_set_scalar(rsrgan_handle h, int32_t which, double v) {
+  CHECK_H(h);
+  Model& m = h->m;
+  int idx = -1;
+  switch (which) {
+    case RSRGAN_G_LEARNING_RATE: idx = DYN_G_LR; break;
+    case RSRGAN_D_LEARNING_RATE: idx = DYN_D_LR; break;
+    case RSRGAN_MSE_LAMBDA: idx = DYN_LAMBDA; break;
+    case RSRGAN_D_REAL: idx = DYN_D_REAL; break;
+    case RSRGAN_D_FAKE: idx = DYN_D_FAKE; break;
+    case RSRGAN_L2_SCALE: idx = DYN_L2; break;
+    case RSRGAN_CLIP_NORM: idx = DYN_CLIP; break;
+    case RSRGAN_ADAM_STEP: {
+      const int t = (int)v;
+      if (hipMemcpy(m.adam_t_dev, &t, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed"); return RSRGAN_ERR_HIP; }
+      m.scal[which] = t;
+      return RSRGAN_OK;
+    }
+    default: set_error("unknown scalar %d", which); return RSRGAN_ERR_INVALID;
+  }
+  const float f = (float)v;      // the reference keeps these as tf.float32 variables
+  if (hipMemcpy(m.dyn + idx, &f, sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed"); return RSRGAN_ERR_HIP; }
+  m.scal[which] = v;
+  return RSRGAN_OK;
+}
+
+int rsrgan_get_scalar(rsrgan_handle h, int32_t which, double* v) {
+  CHECK_H(h);
+  if (which < 0 || which >= RSRGAN_SCALAR_COUNT_ || !v) { set_error("unknown scalar %d", which); return RSRGAN_ERR_INVALID; }
+  *v = h->m.scal[which];
+  return RSRGAN_OK;
+}
+
+static ParamSet* pset(rsrgan_handle h, int net) {
+  if (net == RSRGAN_NET_G) return &h->m.G;
+  if (net == RSRGAN_NET_D) return &h->m.D;
+  return nullptr;
+}
+
+int rsrgan_num_tensors(rsrgan_handle h, int32_t net) {
+  CHECK_H(h);
+  ParamSet* p = pset(h, net);
+  if (!p) { set_error("bad net"); return RSRGAN_ERR_INVALID; }
+  return (int)p->t.size();
+}
+
+int rsrgan_tensor_info(rsrgan_handle h, int32_t net, int32_t idx, char* name, int32_t cap, int32_t* rows, int32_t* cols, int64_t* dense_offset) {
+  CHECK_H(h);
+  ParamSet* p = pset(h, net);
+  if (!p || idx < 0 || idx >= (int)p->t.size()) { set_error("bad net/index"); return RSRGAN_ERR_INVALID; }
+  const TensorDesc& t = p->t[idx];
+  if (name && cap > 0) { std::strncpy(name, t.name.c_str(), cap - 1); name[cap - 1] = 0; }
+  if (rows) *rows = t.is_vector ? t.cols : t.rows;
+  if (cols) *cols = t.is_vector ? 0 : t.cols;       // cols == 0 marks a 1-D variable
+  if (dense_offset) *dense_offset = t.dense_off;
+  return RSRGAN_OK;
+}
+
+int64_t rsrgan_param_count(rsrgan_handle h, int32_t net) {
+  if (!h) return RSRGAN_ERR_INVALID;
+  ParamSet* p = pset(h, net);
+  return p ? p->dense : (int64_t)RSRGAN_ERR_INVALID;
+}
+
+static float* which_buf(ParamSet* p, int what) {
+  switch (what) {
+    case 0: return p->w;
+    case 1: return p->m;
+    case 2: return p->v;
+    case 3: return p->ema;
+    case 4: return p->g;
+  }
+  return nullptr;
+}
+
+static int copy_params(rsrgan_handle h, int net, int what, float* dense, bool to_padded, void* stream) {
+  CHECK_H(h);
+  ParamSet* p = pset(h, net);
+  if (!p || !dense) { set_error("bad net / null pointer"); return RSRGAN_ERR_INVALID; }
+  float* buf = which_buf(p, what);
+  if (!buf) { set_error("buffer %d not present for net %d", what, net); return RSRGAN_ERR_INVALID; }
+  hipStream_t s = (hipStream_t)stream;
+  for (const TensorDesc& t : p->t) launch_pad_copy(dense + t.dense_off, buf + t.off, t.rows, t.cols, t.ld, to_padded, s);
+  if (to_padded && what == 0) {
+    h->m.refresh_transposes(net, s);
+    if (net == RSRGAN_NET_G) h->m.g_fwd_valid = false;
+  }
+  if (hipGetLastError() != hipSuccess) { set_error("kernel launch failed in copy_params"); return RSRGAN_ERR_HIP; }
+  return RSRGAN_OK;
+}
+
+int rsrgan_get_params(rsrgan_handle h, int32_t net, int32_t what, float* dense, void* stream) {
+  if (what < 0 || what > 3) { set_error("bad what"); return RSRGAN_ERR_INVALID; }
+  return copy_params(h, net, what, dense, false, stream);
+}
+int rsrgan_set_params(rsrgan_handle h, int32_t net, int32_t what, const float* dense, void* stream) {
+  if (what < 0 || what > 3) { set_error("bad what"); return RSRGAN_ERR_INVALID; }
+  return copy_params(h, net, what, const_cast<float*>(dense), true, stream);
+}
+int rsrgan_get_grads(rsrgan_handle h, int32_t net, float* dense, void* stream) {
+  return copy_params(h, net, 4, dense, false, stream);
+}
+
+int rsrgan_forward_g(rsrgan_handle h, const float* x, const int32_t* lengths, int32_t T, float* y, void* stream) {
+  CHECK_H(h);
+  Model& m = h->m;
+  hipStream_t s = (hipStream_t)stream;
+  if (!y) { set_error("null output"); return RSRGAN_ERR_INVALID; }
+  int rc = m.prepare_batch(x, nullptr, lengths, T, s);
+  if (rc) return rc;
+  m.g_forward(T, s);
+  m.g_fwd_valid = false;      // labels were not packed: the stash is not a valid training forward
+  launch_unpack_bm(m.y_tm, m.ldDout, y, m.B, T, m.Dout, s);
+  if (hipGetLastError() != hipSuccess) { set_error("kernel launch failed in forward_g"); return RSRGAN_ERR_HIP; }
+  return RSRGAN_OK;
+}
+
+int rsrgan_d_backward(rsrgan_handle h, const float* x, const float* labels, const int32_t* lengths, int32_t T,
+                      const float* nr, const float* nf, float* out_losses, void* stream) {
+  CHECK_H(h);
+  return h->m.d_backward(x, labels, lengths, T, nr, nf, out_losses, true, (hipStream_t)stream);
+}
+int rsrgan_g_backward(rsrgan_handle h, const float* x, const float* labels, const int32_t* lengths, int32_t T,
+                      const float* nf, float* out_losses, int32_t reuse, void* stream) {
+  CHECK_H(h);
+  return h->m.g_backward(x, labels, lengths, T, nf, out_losses, true, reuse != 0, (hipStream_t)stream);
+}
+int rsrgan_apply(rsrgan_handle h, int32_t net, void* stream) {
+  CHECK_H(h);
+  return h->m.apply(net, (hipStream_t)stream);
+}
+
+int rsrgan_d_step(rsrgan_handle h, const float* x, const float* labels, const int32_t* lengths, int32_t T,
+                  const float* nr, const float* nf, float* out_losses, int32_t train, void* stream) {
+  CHECK_H(h);
+  int rc = h->m.d_backward(x, labels, lengths, T, nr, nf, out_losses, train != 0, (hipStream_t)stream);
+  if (rc || !train) return rc;
+  return h->m.apply(RSRGAN_NET_D, (hipStream_t)stream);
+}
+int rsrgan_g_step(rsrgan_handle h, const float* x, const float* labels, const int32_t* lengths, int32_t T,
+                  const float* nf, float* out_losses, int32_t train, int32_t reuse, void* stream) {
+  CHECK_H(h);
+  int rc = h->m.g_backward(x, labels, lengths, T, nf, out_losses, train != 0, reuse != 0, (hipStream_t)stream);
+  if (rc || !train) return rc;
+  return h->m.apply(RSRGAN_NET_G, (hipStream_t)stream);
+}
+
+int rsrgan_grad_buffer(rsrgan_handle h, int32_t net, float** ptr, int64_t* count) {
+  CHECK_H(h);
+  ParamSet* p = pset(h, net);
+  if (!p || !ptr || !count) { set_error("bad argument"); return RSRGAN_ERR_INVALID; }
+  *ptr = p->g;
+  *count = p->padded;
+  return RSRGAN_OK;
+}
+
+int rsrgan_op_gemm(const float* A, int32_t lda, int32_t a_kc, const float* B, int32_t ldb, int32_t b_kc, float* C, int32_t ldc,
+                   int32_t M, int32_t N, int32_t K, const float* bias, int32_t act, float alpha, int32_t accumulate, void* stream) {
+  if (!A || !B || !C || (lda & 3) || (ldb & 3)) { set_error("op_gemm: null pointer or leading dimension not a multiple of 4"); return RSRGAN_ERR_INVALID; }
+  launch_gemm(A, lda, a_kc != 0, B, ldb, b_kc != 0, C, ldc, M, N, K, bias, act, alpha, accumulate != 0, (hipStream_t)stream);
+  if (hipGetLastError() != hipSuccess) { set_error("op_gemm launch failed"); return RSRGAN_ERR_HIP; }
+  return RSRGAN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,140 @@
+// gemm.hip -- time-batched fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF/s peak on
+// MI355X).  Used for everything that is NOT on the serial recurrence: the input/output
+// fully_connected layers (models/lstm.py:82-87,121-124), the x-part of every LSTM kernel
+// batched over all T*B frames, and all weight/data gradients batched over time.
+//
+// 128x128x16 block tile, 256 threads = 4 waves in 2x2, each wave 64x64 = 2x2 MFMA tiles.
+// Operands are staged global -> VGPR (prefetched one k-tile ahead) -> LDS in a k-major image
+// As[k][m], Bs[k][n] (row stride 132 floats: 16-B aligned rows, 4-bank shift per k) so that the
+// MFMA fragment reads (lane l: row/col = l&31, k = l>>5) are 32 consecutive floats per half-wave
+// = conflict-free ds_read_b32.
+#include "kernels.h"
+
+namespace rsr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;
+
+// Load a 128(x) x 16(k) operand tile into registers (2 float4 per thread).
+//  KC  (k contiguous): element(x,k) = P[x*ld + k]  -> thread: x = idx>>2, k4 = (idx&3)*4
+//  !KC (x contiguous): element(x,k) = P[k*ld + x]  -> thread: k = idx>>5, x4 = (idx&31)*4
+template <bool KC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int x0, int X, int k0, int K,
+                                          int tid, float4 (&r)[2]) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int idx = tid + 256 * u;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KC) {
+      const int x = x0 + (idx >> 2), k = k0 + (idx & 3) * 4;
+      if (x < X && k < K) v = *reinterpret_cast<const float4*>(P + (size_t)x * ld + k);   // k..k+3 < ld (zero pad)
+    } else {
+      const int k = k0 + (idx >> 5), x = x0 + (idx & 31) * 4;
+      if (k < K && x < X) v = *reinterpret_cast<const float4*>(P + (size_t)k * ld + x);   // x..x+3 < ld (zero pad)
+    }
+    r[u] = v;
+  }
+}
+template <bool KC>
+__device__ __forceinline__ void store_tile(float (*S)[LDT], int tid, const float4 (&r)[2]) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int idx = tid + 256 * u;
+    if (KC) {
+      const int x = idx >> 2, k = (idx & 3) * 4;
+      S[k + 0][x] = r[u].x; S[k + 1][x] = r[u].y; S[k + 2][x] = r[u].z; S[k + 3][x] = r[u].w;
+    } else {
+      const int k = idx >> 5, x = (idx & 31) * 4;
+      *reinterpret_cast<float4*>(&S[k][x]) = r[u];
+    }
+  }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                              float* __restrict__ C, int ldc, int M, int N, int K,
+                                              const float* __restrict__ bias, int act, float alpha, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float As[BK][LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // k-contiguous operands may be read up to their zero-padded width
+  const int KA = AKC ? ((K + 3) & ~3) : K;
+  const int KB = BKC ? ((K + 3) & ~3) : K;
+  const int MA = AKC ? M : ((M + 3) & ~3);
+  const int NB = BKC ? N : ((N + 3) & ~3);
+
+  float4 ra[2], rb[2];
+  load_tile<AKC>(A, lda, m0, MA, 0, KA, tid, ra);
+  load_tile<BKC>(B, ldb, n0, NB, 0, KB, tid, rb);
+  const int nk = (K + BK - 1) / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tile<AKC>(As, tid, ra);
+    store_tile<BKC>(Bs, tid, rb);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      load_tile<AKC>(A, lda, m0, MA, (kt + 1) * BK, KA, tid, ra);
+      load_tile<BKC>(B, ldb, n0, NB, (kt + 1) * BK, KB, tid, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int k = 2 * kk + lh;
+      const float a0 = As[k][wr * 64 + l31], a1 = As[k][wr * 64 + 32 + l31];
+      const float b0 = Bs[k][wc * 64 + l31], b1 = Bs[k][wc * 64 + 32 + l31];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wc * 64 + j * 32 + l31;
+      if (col >= N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= M) continue;
+        float v = acc[i][j][r] + bv;
+        if (act == 1) v = fmaxf(v, alpha * v);            // utils/ops.py:120-121 tf.maximum(x, alpha*x)
+        float* c = C + (size_t)row * ldc + col;
+        if (accumulate) v += *c;
+        *c = v;
+      }
+    }
+}
+
+void launch_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool b_kc, float* C, int ldc,
+                 int M, int N, int K, const float* bias, int act, float alpha, bool accumulate, hipStream_t s) {
+  if (M <= 0 || N <= 0) return;
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM), block(256);
+  const int acc = accumulate ? 1 : 0;
+  if (a_kc && !b_kc)
+    hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc);
+  else if (a_kc && b_kc)
+    hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc);
+  else if (!a_kc && !b_kc)
+    hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc);
+  else
+    hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc);
+}
+
+}  // namespace rsr

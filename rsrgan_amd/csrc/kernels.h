@@ -1,0 +1,143 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels (kernels.hip, gemm.hip).
+// Every matrix is row-major with a leading dimension that is a multiple of 4
+// floats, 16-byte aligned, and ZERO in its padding columns (the arena is
+// memset once and kernels only ever write valid columns).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rsr {
+
+constexpr int MAXJ = 8;   // (layer, t) jobs fused into one launch of a step kernel
+
+// device-resident scalars (model.dyn): what the reference changes with tf.assign between steps
+enum { DYN_G_LR = 0, DYN_D_LR = 1, DYN_LAMBDA = 2, DYN_D_REAL = 3, DYN_D_FAKE = 4, DYN_L2 = 5, DYN_CLIP = 6,
+       DYN_B1 = 7, DYN_B2 = 8, DYN_EPS = 9, DYN_EMA = 10, DYN_ADAM_LRT = 11, DYN_COUNT = 16 };
+
+// ---------------------------------------------------------------- step kernels
+// Forward phase 1: z = zx | bias  (+ x_t . Kx) + m_{t-1} . Kh ; gates; c_t ; h_t
+struct FwdGateJob {
+  const float* x;      // [N][ldx] layer input at t, or nullptr when zx holds the x-part
+  const float* KxT;    // [4H][ldx]   (k-contiguous transposed copy of kernel rows 0..I)
+  const float* m;      // [N][ldm] carried recurrent state m_{t-1}
+  const float* KhT;    // [4H][ldm]
+  const float* zx;     // [N][4H] precomputed x_t.Kx + bias, or nullptr
+  const float* bias;   // [4H] (used when zx == nullptr)
+  const float* wf; const float* wi; const float* wo;   // peepholes [H]
+  const float* c_prev; // [N][H]
+  float* c_out;        // [N][H]
+  float* gates;        // [N][4H]  out: sigma(i), tanh(j), sigma(f), sigma(o)   (may alias zx)
+  float* h;            // [N][ldh] out: sigma(o)*tanh(c)
+  const int* len;      // [N]
+  int ldx, ldm, ldh, t, N, H;
+  int nblk_c, blk_base;
+};
+struct FwdGateJobs { int n; float forget_bias; FwdGateJob j[MAXJ]; };
+
+// Forward phase 2: m_t = h_t . Wp ; dynamic_rnn masking ; optional residual add
+struct FwdProjJob {
+  const float* h;       // [N][ldh]
+  const float* WpT;     // [P][ldh]
+  const float* m_prev;  // [N][ldm]
+  float* m_out;         // [N][ldm] carried state
+  float* out;           // [N][ldm] masked output (0 for t >= len)
+  const float* res_in;  // [N][ldm] or nullptr
+  float* res_out;       // [N][ldm] = out + res_in
+  const int* len;
+  int ldh, ldm, P, t, N;
+  int nblk_c, blk_base;
+};
+struct FwdProjJobs { int n; FwdProjJob j[MAXJ]; };
+
+// Backward phase A: dm = mask*(dout_t + dm_state); dh = dm . Wp^T ; gate grads -> dz ; dc
+struct BwdAJob {
+  const float* dout;    // [N][ldm] grad of the masked output at t (nullptr = 0)
+  const float* dmst;    // [N][ldm] carried grad of the m state
+  const float* Wp;      // [H][ldm]
+  float* dmt;           // [N][ldm] out: total dm at t (0 on masked rows)
+  float* gates;         // [N][4H]  in: activations, out: dz = (dai, dj, daf, dao)
+  const float* c_prev;  // [N][H]   c_{t-1} (state before the step)
+  const float* c_cur;   // [N][H]   c_t
+  const float* wf; const float* wi; const float* wo;
+  float* dc;            // [N][H]   carried grad of c (in/out)
+  const int* len;
+  int ldm, P, t, N, H;
+  int nblk_c, blk_base;
+};
+struct BwdAJobs { int n; BwdAJob j[MAXJ]; };
+
+// Backward phase B: [dx_t | dm_rec] = dz_t . K^T restricted to kernel rows [n_begin, n_end)
+struct BwdBJob {
+  const float* dz;      // [N][4H]
+  const float* K;       // [(I+R)][4H] TF-layout kernel
+  float* dx;            // [N][lddx] receives columns n < I (nullptr if n_begin >= I)
+  float* dmst;          // [N][ldm]  columns n >= I:  dmst = (mask ? 0 : dmst) + value
+  const int* len;
+  int I, n_begin, n_end, lddx, ldm, t, N, H4;
+  int dx_accumulate;    // dx += instead of =
+  int nblk_c, blk_base;
+};
+struct BwdBJobs { int n; BwdBJob j[MAXJ]; };
+
+void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, hipStream_t s);
+void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, hipStream_t s);
+void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, hipStream_t s);
+void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, hipStream_t s);
+
+// ---------------------------------------------------------------- batched GEMM
+// C[M,N] (+)= A.B (+bias)(lrelu).  a_kc: A(m,k)=A[m*lda+k] else A[k*lda+m];
+// b_kc: B(k,n)=B[n*ldb+k] else B[k*ldb+n].
+void launch_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool b_kc,
+                 float* C, int ldc, int M, int N, int K,
+                 const float* bias, int act, float alpha, bool accumulate, hipStream_t s);
+
+// ---------------------------------------------------------------- layout / pointwise
+void launch_pack_tm(const float* src_bm, float* dst_tm, int B, int T, int D, int ld, hipStream_t s);      // [B,T,D] -> [T][B][ld]
+void launch_unpack_bm(const float* src_tm, int ld, float* dst_bm, int B, int T, int D, hipStream_t s);    // [T][B][ld] -> [B,T,D]
+// xd[t][b] = labels[t][b] + noise_r[b]   (b <  B)   (only when with_real)
+// xd[t][B+b or b] = y[t][b] + noise_f[b]
+void launch_build_d_input(const float* lab_tm, const float* y_tm, const float* noise_r, const float* noise_f,
+                          float* xd, int B, int T, int D, int ld, bool with_real, hipStream_t s);
+void launch_transpose(const float* src, int lds, float* dst, int ldd, int R, int C, hipStream_t s);        // dst[c][r] = src[r][c]
+void launch_fill(float* p, size_t n, float v, hipStream_t s);
+void launch_lrelu_bwd(const float* hval, float* d, size_t rows, int cols, int ld, float alpha, hipStream_t s); // d *= (h>0?1:alpha)
+// col sums over `rows` rows: out[c] = sum_r a[r*lda+c] * (b ? b[r*ldb+c] : 1)
+void launch_colsum(const float* a, int lda, const float* b, int ldb, float* out, int rows, int cols,
+                   float* scratch /* >= 64*cols floats */, hipStream_t s);
+
+// LSGAN: logits [T*Nd][ldl] col 0.  rows with (r % Nd) < n_real use target_real and go to
+// loss[0], the others target_fake and loss[1]; loss[2] = loss[0]+loss[1].  Means over T*n_real /
+// T*(Nd-n_real) entries.  dlogits[r][0] = 2*(l-target)/count  (nullptr = skip).
+void launch_lsgan(const float* logits, int ldl, float* dlogits, int T, int Nd, int n_real,
+                  const float* target_real, const float* target_fake, float* loss3, hipStream_t s);
+// g_mse = 0.5*D*mean((y-lab)^2) ; dy (+)= lambda*(y-lab)/(B*T)   (dy nullptr = loss only)
+void launch_mse(const float* y, const float* lab, int ld, float* dy, int rows, int D, const float* lambda,
+                bool accumulate, float* loss_out, float* scratch /* >= 1024 floats */, hipStream_t s);
+// losses[3] = adv + lambda*mse + l2
+void launch_g_total(float* l4 /* adv,mse,l2,total */, const float* lambda, hipStream_t s);
+void launch_copy_f(const float* src, float* dst, int n, hipStream_t s);
+
+// ---------------------------------------------------------------- optimizer
+struct ChunkTable {          // device arrays, one entry per 4096-float chunk of the flat buffer
+  const int* tensor;         // tensor index of the chunk
+  const int* off;            // float offset in the flat buffer
+  const int* len;            // valid floats in the chunk
+  const int* t_first;        // [n_tensors] first chunk of tensor
+  const int* t_count;        // [n_tensors] chunks of tensor
+  const int* t_l2;           // [n_tensors] 1 if the tensor takes the L2 term ("bias" not in name)
+  int n_chunks, n_tensors;
+};
+void launch_sumsq(const float* g, const ChunkTable& ct, float* partial, hipStream_t s);
+// l2: g += l2_scale*w on flagged tensors; partial[c] = sumsq(w) of flagged chunks (else 0)
+void launch_l2(const float* w, float* g, const ChunkTable& ct, const float* l2_scale, float* partial, hipStream_t s);
+void launch_l2_total(const float* partial, int n_chunks, const float* l2_scale, float* out, hipStream_t s);
+// dyn: device scalars {lr, clip, beta1, beta2, eps, lr_t(adam), ema_decay}
+void launch_apply_sgd(float* w, const float* g, float* ema, const ChunkTable& ct, const float* partial,
+                      const float* dyn, hipStream_t s);
+void launch_apply_adam(float* w, const float* g, float* m, float* v, float* ema, const ChunkTable& ct,
+                       const float* partial, const float* dyn, hipStream_t s);
+void launch_adam_tick(float* dyn, int* t, double b1, double b2, hipStream_t s);
+// dense <-> padded flat copies (checkpoint / parity injection)
+void launch_pad_copy(const float* dense, float* padded, int rows, int cols, int ld, bool to_padded, hipStream_t s);
+
+}  // namespace rsr

@@ -1,0 +1,627 @@
+// kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the RSRGAN GAN step, except the
+// time-batched GEMM (gemm.hip).
+//
+// Recurrent LSTMP step kernels.  The reference runs tf.nn.dynamic_rnn over
+// tf.contrib.rnn.LSTMCell (models/lstm.py:89-112, models/discriminator_lstm.py:70-91;
+// cell math as restated in models/BNLSTMCell.py:176-217), i.e. per time step one
+// [B,in+P]x[in+P,4H] GEMM, ~12 tiny elementwise kernels and one [B,H]x[H,P] GEMM.
+// Here one step is TWO launches ("gates" and "proj"), each able to carry up to
+// MAXJ (layer,t) jobs of a wavefront, because on MI355X a dependent kernel boundary
+// (~1.5 us) is cheaper than any in-kernel grid barrier (>=4 us).
+//
+// MFMA use: the per-step GEMMs have M = batch rows (<=64 per tile column), so they use
+// v_mfma_f32_16x16x4_f32 (exact fp32) with BOTH operands loaded k-contiguously as
+// float4 straight from L2 into VGPRs (no LDS round trip: each operand element is used
+// by one wave only).  Lane l holds A[row=l&15][k=4*(l>>4)+u] and B[k=4*(l>>4)+u][col=l&15]
+// for the u-th of four consecutive MFMAs, which is why the forward pass keeps
+// k-contiguous transposed copies of the kernels (KxT, KhT, WpT) while the backward pass
+// reads the TF-layout originals (already k-contiguous for dz.K^T and dm.Wp^T).
+#include "kernels.h"
+
+namespace rsr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <typename JobT>
+__device__ __forceinline__ int find_job(const JobT* j, int n, int bid) {
+  int ji = 0;
+#pragma unroll
+  for (int q = 1; q < MAXJ; ++q)
+    if (q < n && bid >= j[q].blk_base) ji = q;
+  return ji;
+}
+
+// acc[16x16] += A[16 rows][k] * W[16 cols][k] over k in [kbeg,kend) (multiples of 16),
+// both operands k-contiguous; `ld` bounds the (zero-padded) row.
+__device__ __forceinline__ void mfma_seg(f32x4& acc, const float* __restrict__ arow, bool aok,
+                                         const float* __restrict__ wrow, bool wok, int ld,
+                                         int kbeg, int kend, int q) {
+#pragma unroll 4
+  for (int kb = kbeg; kb < kend; kb += 16) {
+    const int k = kb + 4 * q;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (aok && k < ld) a = *reinterpret_cast<const float4*>(arow + k);
+    if (wok && k < ld) b = *reinterpret_cast<const float4*>(wrow + k);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ int round16(int x) { return (x + 15) & ~15; }
+
+// ---------------------------------------------------------------------------------------
+// forward phase 1: 4 waves = 4 gates of a 16-row x 16-cell tile
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fwd_gates(const FwdGateJobs jobs) {
+  __shared__ float zs[4][16][17];
+  const int bid = blockIdx.x;
+  const int ji = find_job(jobs.j, jobs.n, bid);
+  const FwdGateJob& J = jobs.j[ji];
+  const int lb = bid - J.blk_base;
+  const int cb = lb % J.nblk_c, rb = lb / J.nblk_c;
+  const int r0 = rb * 16, c0 = cb * 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, q = lane >> 4;
+  const int H = J.H, N = J.N, H4 = 4 * H;
+  const int col = c0 + lr;
+  const bool colok = col < H;
+  const int gcol = w * H + col;
+
+  f32x4 acc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = r0 + q * 4 + i;
+    float v = 0.f;
+    if (colok && row < N) v = J.zx ? J.zx[(size_t)row * H4 + gcol] : J.bias[gcol];
+    acc[i] = v;
+  }
+  const int arow = r0 + lr;
+  const bool aok = arow < N;
+  if (J.x)
+    mfma_seg(acc, J.x + (size_t)arow * J.ldx, aok, J.KxT + (size_t)gcol * J.ldx, colok, J.ldx, 0, round16(J.ldx), q);
+  mfma_seg(acc, J.m + (size_t)arow * J.ldm, aok, J.KhT + (size_t)gcol * J.ldm, colok, J.ldm, 0, round16(J.ldm), q);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) zs[w][q * 4 + i][lr] = acc[i];
+  __syncthreads();
+
+  const int er = tid >> 4, ec = tid & 15;
+  const int row = r0 + er, cell = c0 + ec;
+  if (row < N && cell < H) {
+    const float zi = zs[0][er][ec], zj = zs[1][er][ec], zf = zs[2][er][ec], zo = zs[3][er][ec];
+    const size_t ci = (size_t)row * H + cell;
+    const float cp = J.c_prev[ci];
+    float* g = J.gates + (size_t)row * H4 + cell;
+    if (J.t < J.len[row]) {
+      const float gi = sigmoid_(zi + J.wi[cell] * cp);
+      const float gf = sigmoid_(zf + jobs.forget_bias + J.wf[cell] * cp);
+      const float gj = tanhf(zj);
+      const float cn = gf * cp + gi * gj;
+      const float go = sigmoid_(zo + J.wo[cell] * cn);
+      J.c_out[ci] = cn;
+      g[0] = gi; g[H] = gj; g[2 * H] = gf; g[3 * H] = go;
+      J.h[(size_t)row * J.ldh + cell] = go * tanhf(cn);
+    } else {                       // dynamic_rnn: t >= len -> state copied through, no gradient
+      J.c_out[ci] = cp;
+      g[0] = 0.f; g[H] = 0.f; g[2 * H] = 0.f; g[3 * H] = 0.f;
+      J.h[(size_t)row * J.ldh + cell] = 0.f;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// forward phase 2: 16x16 tile of m_t = h_t.Wp, K (=H) split over the 4 waves
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fwd_proj(const FwdProjJobs jobs) {
+  __shared__ float zs[4][16][17];
+  const int bid = blockIdx.x;
+  const int ji = find_job(jobs.j, jobs.n, bid);
+  const FwdProjJob& J = jobs.j[ji];
+  const int lb = bid - J.blk_base;
+  const int cb = lb % J.nblk_c, rb = lb / J.nblk_c;
+  const int r0 = rb * 16, c0 = cb * 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, q = lane >> 4;
+  const int N = J.N, P = J.P;
+  const int p = c0 + lr;
+  const bool pok = p < P;
+  const int arow = r0 + lr;
+  const bool aok = arow < N;
+  const int kblocks = (J.ldh + 15) >> 4, per = (kblocks + 3) >> 2;
+  const int kbeg = w * per * 16;
+  const int kend = min((w + 1) * per, kblocks) * 16;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  mfma_seg(acc, J.h + (size_t)arow * J.ldh, aok, J.WpT + (size_t)p * J.ldh, pok, J.ldh, kbeg, kend, q);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) zs[w][q * 4 + i][lr] = acc[i];
+  __syncthreads();
+  const int er = tid >> 4, ec = tid & 15;
+  const int row = r0 + er, pp = c0 + ec;
+  if (row < N && pp < P) {
+    const float v = ((zs[0][er][ec] + zs[1][er][ec]) + zs[2][er][ec]) + zs[3][er][ec];
+    const size_t mi = (size_t)row * J.ldm + pp;
+    const bool live = J.t < J.len[row];
+    J.m_out[mi] = live ? v : J.m_prev[mi];
+    const float o = live ? v : 0.f;
+    J.out[mi] = o;
+    if (J.res_out) J.res_out[mi] = o + J.res_in[mi];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward phase A: dh = (mask*(dout+dm_state)).Wp^T, then the cell's gate gradients
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bwd_a(const BwdAJobs jobs) {
+  __shared__ float zs[4][16][17];
+  const int bid = blockIdx.x;
+  const int ji = find_job(jobs.j, jobs.n, bid);
+  const BwdAJob& J = jobs.j[ji];
+  const int lb = bid - J.blk_base;
+  const int cb = lb % J.nblk_c, rb = lb / J.nblk_c;
+  const int r0 = rb * 16, c0 = cb * 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, q = lane >> 4;
+  const int N = J.N, H = J.H, H4 = 4 * H, ldm = J.ldm;
+  const int wcell = c0 + lr;
+  const bool wok = wcell < H;
+  const int arow = r0 + lr;
+  const bool aok = arow < N;
+  const bool alive = aok && (J.t < J.len[aok ? arow : 0]);
+  const int kblocks = (ldm + 15) >> 4, per = (kblocks + 3) >> 2;
+  const int kbeg = w * per * 16;
+  const int kend = min((w + 1) * per, kblocks) * 16;
+  const float* wrow = J.Wp + (size_t)wcell * ldm;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int kb = kbeg; kb < kend; kb += 16) {
+    const int k = kb + 4 * q;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (aok && k < ldm) {
+      if (alive) {
+        a = *reinterpret_cast<const float4*>(J.dmst + (size_t)arow * ldm + k);
+        if (J.dout) {
+          const float4 d = *reinterpret_cast<const float4*>(J.dout + (size_t)arow * ldm + k);
+          a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+        }
+      }
+      if (cb == 0) *reinterpret_cast<float4*>(J.dmt + (size_t)arow * ldm + k) = a;
+    }
+    if (wok && k < ldm) b = *reinterpret_cast<const float4*>(wrow + k);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) zs[w][q * 4 + i][lr] = acc[i];
+  __syncthreads();
+  const int er = tid >> 4, ec = tid & 15;
+  const int row = r0 + er, cell = c0 + ec;
+  if (row < N && cell < H) {
+    float* g = J.gates + (size_t)row * H4 + cell;
+    if (J.t < J.len[row]) {
+      const float dh = ((zs[0][er][ec] + zs[1][er][ec]) + zs[2][er][ec]) + zs[3][er][ec];
+      const size_t ci = (size_t)row * H + cell;
+      const float gi = g[0], gj = g[H], gf = g[2 * H], go = g[3 * H];
+      const float cp = J.c_prev[ci], cn = J.c_cur[ci];
+      const float tc = tanhf(cn);
+      const float dao = dh * tc * go * (1.f - go);
+      const float dcn = J.dc[ci] + dh * go * (1.f - tc * tc) + dao * J.wo[cell];
+      const float daf = dcn * cp * gf * (1.f - gf);
+      const float dai = dcn * gj * gi * (1.f - gi);
+      const float dj = dcn * gi * (1.f - gj * gj);
+      J.dc[ci] = dcn * gf + dai * J.wi[cell] + daf * J.wf[cell];
+      g[0] = dai; g[H] = dj; g[2 * H] = daf; g[3 * H] = dao;
+    } else {
+      g[0] = 0.f; g[H] = 0.f; g[2 * H] = 0.f; g[3 * H] = 0.f;     // dc passes through unchanged
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward phase B: 16x16 tile of dz_t.K^T, K (=4H) split over NW waves
+// ---------------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_bwd_b(const BwdBJobs jobs) {
+  __shared__ float zs[NW][16][17];
+  const int bid = blockIdx.x;
+  const int ji = find_job(jobs.j, jobs.n, bid);
+  const BwdBJob& J = jobs.j[ji];
+  const int lb = bid - J.blk_base;
+  const int cb = lb % J.nblk_c, rb = lb / J.nblk_c;
+  const int r0 = rb * 16, n0 = J.n_begin + cb * 16;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, q = lane >> 4;
+  const int N = J.N, H4 = J.H4;
+  const int n = n0 + lr;
+  const bool nok = n < J.n_end;
+  const int arow = r0 + lr;
+  const bool aok = arow < N;
+  const int kblocks = (H4 + 15) >> 4, per = (kblocks + NW - 1) / NW;
+  const int kbeg = w * per * 16;
+  const int kend = min((w + 1) * per, kblocks) * 16;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  mfma_seg(acc, J.dz + (size_t)arow * H4, aok, J.K + (size_t)n * H4, nok, H4, kbeg, kend, q);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) zs[w][q * 4 + i][lr] = acc[i];
+  __syncthreads();
+  if (tid < 256) {
+    const int er = tid >> 4, ec = tid & 15;
+    const int row = r0 + er, nn = n0 + ec;
+    if (row < N && nn < J.n_end) {
+      float v = 0.f;
+#pragma unroll
+      for (int s = 0; s < NW; ++s) v += zs[s][er][ec];
+      if (nn < J.I) {
+        float* d = J.dx + (size_t)row * J.lddx + nn;
+        *d = J.dx_accumulate ? (*d + v) : v;
+      } else {
+        float* d = J.dmst + (size_t)row * J.ldm + (nn - J.I);
+        const bool live = J.t < J.len[row];
+        *d = (live ? 0.f : *d) + v;
+      }
+    }
+  }
+}
+
+void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_fwd_gates, dim3(total_blocks), dim3(256), 0, s, jobs);
+}
+void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_fwd_proj, dim3(total_blocks), dim3(256), 0, s, jobs);
+}
+void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_bwd_a, dim3(total_blocks), dim3(256), 0, s, jobs);
+}
+void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_bwd_b<8>, dim3(total_blocks), dim3(512), 0, s, jobs);
+}
+
+// ---------------------------------------------------------------------------------------
+// layout kernels: batch-major caller buffers <-> time-major padded internal buffers
+// ---------------------------------------------------------------------------------------
+__global__ void k_pack_tm(const float* __restrict__ src, float* __restrict__ dst, int B, int T, int D, int ld) {
+  // one block per (t, b): coalesced read of the 257-float frame, coalesced write
+  const int t = blockIdx.x, b = blockIdx.y;
+  const float* s = src + ((size_t)b * T + t) * D;
+  float* d = dst + ((size_t)t * B + b) * ld;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) d[i] = s[i];
+}
+__global__ void k_unpack_bm(const float* __restrict__ src, int ld, float* __restrict__ dst, int B, int T, int D) {
+  const int t = blockIdx.x, b = blockIdx.y;
+  const float* s = src + ((size_t)t * B + b) * ld;
+  float* d = dst + ((size_t)b * T + t) * D;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) d[i] = s[i];
+}
+void launch_pack_tm(const float* src, float* dst, int B, int T, int D, int ld, hipStream_t s) {
+  hipLaunchKernelGGL(k_pack_tm, dim3(T, B), dim3(D >= 128 ? 128 : 64), 0, s, src, dst, B, T, D, ld);
+}
+void launch_unpack_bm(const float* src, int ld, float* dst, int B, int T, int D, hipStream_t s) {
+  hipLaunchKernelGGL(k_unpack_bm, dim3(T, B), dim3(D >= 128 ? 128 : 64), 0, s, src, ld, dst, B, T, D);
+}
+
+// discriminator input (gan_rnn_placeholder.py:205-213 + utils/ops.py:19-30): rows [0,B) real
+// = labels + noise_r, rows [B,2B) (or [0,B) when !with_real) fake = G(x) + noise_f; the noise
+// is [B,D], broadcast over time.
+__global__ void k_build_d_input(const float* __restrict__ lab, const float* __restrict__ y,
+                                const float* __restrict__ nr, const float* __restrict__ nf,
+                                float* __restrict__ xd, int B, int T, int D, int ld, int with_real) {
+  const int Nd = with_real ? 2 * B : B;
+  const size_t total = (size_t)T * Nd * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const size_t r = i / D;
+    const int bb = (int)(r % Nd), t = (int)(r / Nd);
+    float v;
+    if (with_real && bb < B) {
+      v = lab[((size_t)t * B + bb) * ld + d] + (nr ? nr[bb * D + d] : 0.f);
+    } else {
+      const int b = with_real ? bb - B : bb;
+      v = y[((size_t)t * B + b) * ld + d] + (nf ? nf[b * D + d] : 0.f);
+    }
+    xd[r * ld + d] = v;
+  }
+}
+void launch_build_d_input(const float* lab, const float* y, const float* nr, const float* nf, float* xd,
+                          int B, int T, int D, int ld, bool with_real, hipStream_t s) {
+  const size_t total = (size_t)T * (with_real ? 2 * B : B) * D;
+  const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+  hipLaunchKernelGGL(k_build_d_input, dim3(blocks), dim3(256), 0, s, lab, y, nr, nf, xd, B, T, D, ld, with_real ? 1 : 0);
+}
+
+__global__ void k_transpose(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, int R, int C) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? src[(size_t)r * lds_ + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < R) dst[(size_t)c * ldd + r] = tile[tx][i];
+  }
+}
+void launch_transpose(const float* src, int lds_, float* dst, int ldd, int R, int C, hipStream_t s) {
+  hipLaunchKernelGGL(k_transpose, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s, src, lds_, dst, ldd, R, C);
+}
+
+__global__ void k_fill(float* p, size_t n, float v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+void launch_fill(float* p, size_t n, float v, hipStream_t s) {
+  if (n == 0) return;
+  const int blocks = (int)min((size_t)2048, (n + 255) / 256);
+  hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, s, p, n, v);
+}
+
+__global__ void k_lrelu_bwd(const float* __restrict__ hval, float* __restrict__ d, size_t rows, int cols, int ld, float alpha) {
+  const size_t total = rows * (size_t)cols;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / cols; const int c = (int)(i % cols);
+    const size_t o = r * ld + c;
+    if (!(hval[o] > 0.f)) d[o] *= alpha;
+  }
+}
+void launch_lrelu_bwd(const float* hval, float* d, size_t rows, int cols, int ld, float alpha, hipStream_t s) {
+  const size_t total = rows * cols;
+  const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+  hipLaunchKernelGGL(k_lrelu_bwd, dim3(blocks), dim3(256), 0, s, hval, d, rows, cols, ld, alpha);
+}
+
+// column sums in two deterministic stages (bias and peephole gradients)
+constexpr int CS_SLICES = 64;
+__global__ __launch_bounds__(256) void k_colsum1(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                 float* __restrict__ scratch, int rows, int cols) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int per = (rows + CS_SLICES - 1) / CS_SLICES;
+  const int rbeg = blockIdx.y * per, rend = min(rows, rbeg + per);
+  float s = 0.f;
+  if (c < cols) {
+    for (int r = rbeg + rl; r < rend; r += 4) {
+      const float v = a[(size_t)r * lda + c];
+      s += b ? v * b[(size_t)r * ldb + c] : v;
+    }
+  }
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols)
+    scratch[(size_t)blockIdx.y * cols + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+__global__ void k_colsum2(const float* __restrict__ scratch, float* __restrict__ out, int cols) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int i = 0; i < CS_SLICES; ++i) s += scratch[(size_t)i * cols + c];
+  out[c] = s;
+}
+void launch_colsum(const float* a, int lda, const float* b, int ldb, float* out, int rows, int cols, float* scratch, hipStream_t s) {
+  hipLaunchKernelGGL(k_colsum1, dim3((cols + 63) / 64, CS_SLICES), dim3(256), 0, s, a, lda, b, ldb, scratch, rows, cols);
+  hipLaunchKernelGGL(k_colsum2, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, out, cols);
+}
+
+// ---------------------------------------------------------------------------------------
+// losses (models/gan_rnn_placeholder.py:244-260)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+  // deterministic: fixed shuffle tree per wave, then fixed-order sum of the 16 wave totals
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float s = 0.f;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int i = 0; i < nw; ++i) s += red[i];
+  __syncthreads();
+  return s;
+}
+
+__global__ __launch_bounds__(1024) void k_lsgan(const float* __restrict__ logits, int ldl, float* __restrict__ dlogits,
+                                                int T, int Nd, int n_real, const float* __restrict__ t_real,
+                                                const float* __restrict__ t_fake, float* __restrict__ loss3) {
+  __shared__ float red[16];
+  const int rows = T * Nd;
+  const float tr = *t_real, tf = *t_fake;
+  const float cr = (float)T * (float)n_real, cf = (float)T * (float)(Nd - n_real);
+  float sr = 0.f, sf = 0.f;
+  for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+    const bool real = (r % Nd) < n_real;
+    const float d = logits[(size_t)r * ldl] - (real ? tr : tf);
+    if (real) sr += d * d; else sf += d * d;
+    if (dlogits) dlogits[(size_t)r * ldl] = 2.f * d / (real ? cr : cf);
+  }
+  sr = block_sum_1024(sr, red);
+  sf = block_sum_1024(sf, red);
+  if (threadIdx.x == 0) {
+    const float lr_ = n_real > 0 ? sr / cr : 0.f;
+    const float lf_ = (Nd - n_real) > 0 ? sf / cf : 0.f;
+    loss3[0] = lr_; loss3[1] = lf_; loss3[2] = lr_ + lf_;
+  }
+}
+void launch_lsgan(const float* logits, int ldl, float* dlogits, int T, int Nd, int n_real,
+                  const float* t_real, const float* t_fake, float* loss3, hipStream_t s) {
+  hipLaunchKernelGGL(k_lsgan, dim3(1), dim3(1024), 0, s, logits, ldl, dlogits, T, Nd, n_real, t_real, t_fake, loss3);
+}
+
+constexpr int MSE_BLOCKS = 256;
+__global__ __launch_bounds__(256) void k_mse1(const float* __restrict__ y, const float* __restrict__ lab, int ld,
+                                              float* __restrict__ dy, int rows, int D, const float* __restrict__ lambda,
+                                              int accumulate, float* __restrict__ scratch) {
+  __shared__ float red[16];
+  const size_t total = (size_t)rows * D;
+  const float scale = dy ? (*lambda) / (float)rows : 0.f;
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / D; const int c = (int)(i % D);
+    const size_t o = r * ld + c;
+    const float d = y[o] - lab[o];
+    s += d * d;
+    if (dy) dy[o] = (accumulate ? dy[o] : 0.f) + scale * d;
+  }
+  s = block_sum_1024(s, red);
+  if (threadIdx.x == 0) scratch[blockIdx.x] = s;
+}
+__global__ void k_mse2(const float* __restrict__ scratch, int rows, float* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < MSE_BLOCKS; ++i) s += scratch[i];
+    *out = 0.5f * s / (float)rows;       // 0.5 * D * sum / (rows * D)
+  }
+}
+void launch_mse(const float* y, const float* lab, int ld, float* dy, int rows, int D, const float* lambda,
+                bool accumulate, float* loss_out, float* scratch, hipStream_t s) {
+  hipLaunchKernelGGL(k_mse1, dim3(MSE_BLOCKS), dim3(256), 0, s, y, lab, ld, dy, rows, D, lambda, accumulate ? 1 : 0, scratch);
+  hipLaunchKernelGGL(k_mse2, dim3(1), dim3(64), 0, s, scratch, rows, loss_out);
+}
+
+__global__ void k_g_total(float* l4, const float* lambda) {
+  if (threadIdx.x == 0) l4[3] = l4[0] + (*lambda) * l4[1] + l4[2];
+}
+void launch_g_total(float* l4, const float* lambda, hipStream_t s) {
+  hipLaunchKernelGGL(k_g_total, dim3(1), dim3(64), 0, s, l4, lambda);
+}
+__global__ void k_copy_f(const float* src, float* dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+void launch_copy_f(const float* src, float* dst, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_copy_f, dim3((n + 255) / 256), dim3(256), 0, s, src, dst, n);
+}
+
+// ---------------------------------------------------------------------------------------
+// optimizer: per-tensor clip_by_norm (gan_rnn_placeholder.py:178-182), SGD (:144,183),
+// TF-form Adam (:147,184), EMA (:149-150,185-186).  One block per 4096-float chunk; a chunk
+// never straddles two tensors.
+// ---------------------------------------------------------------------------------------
+constexpr int CHUNK = 4096;
+
+__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, ChunkTable ct, float* __restrict__ partial) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const float* p = g + ct.off[c];
+  const int n = ct.len[c];
+  float s = 0.f;
+  for (int i = threadIdx.x * 4; i < n; i += 1024) {       // len and off are multiples of 4
+    const float4 v = *reinterpret_cast<const float4*>(p + i);
+    s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  s = block_sum_1024(s, red);
+  if (threadIdx.x == 0) partial[c] = s;
+}
+void launch_sumsq(const float* g, const ChunkTable& ct, float* partial, hipStream_t s) {
+  hipLaunchKernelGGL(k_sumsq, dim3(ct.n_chunks), dim3(256), 0, s, g, ct, partial);
+}
+
+__global__ __launch_bounds__(256) void k_l2(const float* __restrict__ w, float* __restrict__ g, ChunkTable ct,
+                                            const float* __restrict__ l2_scale, float* __restrict__ partial) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const bool on = ct.t_l2[ct.tensor[c]] != 0;
+  const int off = ct.off[c], n = ct.len[c];
+  const float sc = *l2_scale;
+  float s = 0.f;
+  if (on) {
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const float v = w[off + i];
+      s += v * v;
+      g[off + i] += sc * v;
+    }
+  }
+  s = block_sum_1024(s, red);
+  if (threadIdx.x == 0) partial[c] = s;
+}
+void launch_l2(const float* w, float* g, const ChunkTable& ct, const float* l2_scale, float* partial, hipStream_t s) {
+  hipLaunchKernelGGL(k_l2, dim3(ct.n_chunks), dim3(256), 0, s, w, g, ct, l2_scale, partial);
+}
+__global__ __launch_bounds__(1024) void k_l2_total(const float* __restrict__ partial, int n, const float* __restrict__ l2_scale, float* out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += partial[i];
+  s = block_sum_1024(s, red);
+  if (threadIdx.x == 0) *out = 0.5f * (*l2_scale) * s;
+}
+void launch_l2_total(const float* partial, int n, const float* l2_scale, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_l2_total, dim3(1), dim3(1024), 0, s, partial, n, l2_scale, out);
+}
+
+__device__ __forceinline__ float tensor_clip_scale(const ChunkTable& ct, const float* partial, int c, float clip, float* red) {
+  const int t = ct.tensor[c];
+  const int first = ct.t_first[t], cnt = ct.t_count[t];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) s += partial[first + i];
+  s = block_sum_1024(s, red);
+  // tf.clip_by_norm: t * clip * min(rsqrt(sum(t*t)), 1/clip)
+  const float inv = s > 0.f ? 1.0f / sqrtf(s) : __builtin_inff();
+  return clip * fminf(inv, 1.0f / clip);
+}
+
+__global__ __launch_bounds__(256) void k_apply_sgd(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ ema,
+                                                   ChunkTable ct, const float* __restrict__ partial, const float* __restrict__ dyn) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const float scale = tensor_clip_scale(ct, partial, c, dyn[DYN_CLIP], red);
+  const float lr = dyn[DYN_D_LR], dec = dyn[DYN_EMA];
+  const int off = ct.off[c], n = ct.len[c];
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float nw = w[off + i] - lr * (g[off + i] * scale);
+    w[off + i] = nw;
+    if (ema) ema[off + i] = dec * ema[off + i] + (1.f - dec) * nw;
+  }
+}
+void launch_apply_sgd(float* w, const float* g, float* ema, const ChunkTable& ct, const float* partial, const float* dyn, hipStream_t s) {
+  hipLaunchKernelGGL(k_apply_sgd, dim3(ct.n_chunks), dim3(256), 0, s, w, g, ema, ct, partial, dyn);
+}
+
+__global__ __launch_bounds__(256) void k_apply_adam(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, float* __restrict__ ema, ChunkTable ct,
+                                                    const float* __restrict__ partial, const float* __restrict__ dyn) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const float scale = tensor_clip_scale(ct, partial, c, dyn[DYN_CLIP], red);
+  const float b1 = dyn[DYN_B1], b2 = dyn[DYN_B2], eps = dyn[DYN_EPS], lrt = dyn[DYN_ADAM_LRT], dec = dyn[DYN_EMA];
+  const int off = ct.off[c], n = ct.len[c];
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float gg = g[off + i] * scale;
+    const float mm = b1 * m[off + i] + (1.f - b1) * gg;
+    const float vv = b2 * v[off + i] + (1.f - b2) * gg * gg;
+    m[off + i] = mm; v[off + i] = vv;
+    const float nw = w[off + i] - lrt * mm / (sqrtf(vv) + eps);      // eps outside the sqrt (TF form)
+    w[off + i] = nw;
+    if (ema) ema[off + i] = dec * ema[off + i] + (1.f - dec) * nw;
+  }
+}
+void launch_apply_adam(float* w, const float* g, float* m, float* v, float* ema, const ChunkTable& ct,
+                       const float* partial, const float* dyn, hipStream_t s) {
+  hipLaunchKernelGGL(k_apply_adam, dim3(ct.n_chunks), dim3(256), 0, s, w, g, m, v, ema, ct, partial, dyn);
+}
+
+// Adam's beta powers (tf.train.AdamOptimizer): t += 1; lr_t = lr*sqrt(1-b2^t)/(1-b1^t), on the
+// device so that a captured graph advances it on every replay.
+__global__ void k_adam_tick(float* dyn, int* t, double b1, double b2) {
+  if (threadIdx.x == 0) {
+    const int tt = *t + 1;
+    *t = tt;
+    dyn[DYN_ADAM_LRT] = (float)((double)dyn[DYN_G_LR] * sqrt(1.0 - pow(b2, (double)tt)) / (1.0 - pow(b1, (double)tt)));
+  }
+}
+void launch_adam_tick(float* dyn, int* t, double b1, double b2, hipStream_t s) {
+  hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(64), 0, s, dyn, t, b1, b2);
+}
+
+__global__ void k_pad_copy(const float* __restrict__ dense_c, float* __restrict__ dense_m, float* __restrict__ padded,
+                           int rows, int cols, int ld, int to_padded) {
+  const size_t total = (size_t)rows * cols;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / cols; const int c = (int)(i % cols);
+    if (to_padded) padded[r * ld + c] = dense_c[i];
+    else dense_m[i] = padded[r * ld + c];
+  }
+}
+void launch_pad_copy(const float* dense, float* padded, int rows, int cols, int ld, bool to_padded, hipStream_t s) {
+  const size_t total = (size_t)rows * cols;
+  const int blocks = (int)min((size_t)1024, (total + 255) / 256);
+  hipLaunchKernelGGL(k_pad_copy, dim3(blocks), dim3(256), 0, s, dense, const_cast<float*>(dense), padded, rows, cols, ld, to_padded ? 1 : 0);
+}
+
+}  // namespace rsr

@@ -1,0 +1,112 @@
+// model.h -- host-side state of one GAN_RNN replica on one MI355X: parameter tables in the
+// reference's variable order, padded device buffers, activation stashes and the launch
+// schedule of D-step / G-step (models/gan_rnn_placeholder.py:139-298).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rsrgan.h"
+#include "kernels.h"
+
+namespace rsr {
+
+inline int pad4(int x) { return (x + 3) & ~3; }
+
+struct TensorDesc {
+  std::string name;
+  int rows, cols, ld;       // [rows][ld] in the padded flat buffer; 1-D tensors have rows == 1
+  int64_t off;              // float offset in the padded flat buffer (multiple of 64)
+  int64_t dense_off;        // float offset in the dense (TF-shaped) flat vector
+  bool l2;                  // takes the L2 term: "bias" not in name (gan_rnn_placeholder.py:254)
+  bool is_vector;
+};
+
+struct ParamSet {
+  std::vector<TensorDesc> t;
+  int64_t padded = 0, dense = 0;
+  float *w = nullptr, *g = nullptr, *m = nullptr, *v = nullptr, *ema = nullptr;
+  ChunkTable ct{};
+  float* partial = nullptr;      // [n_chunks] sum of squares per chunk
+  int add(const std::string& name, int rows, int cols, bool is_vector);
+  float* W(int i) const { return w + t[i].off; }
+  float* Gd(int i) const { return g + t[i].off; }
+};
+
+struct LstmLayer {               // one tf.contrib.rnn.LSTMCell(H, use_peepholes, num_proj=P)
+  int I, H, P, ldI, ldP, ldH;
+  int tK, tb, twf, twi, two, tWp;        // indices into the ParamSet
+  float *KxT = nullptr, *KhT = nullptr, *WpT = nullptr;   // k-contiguous transposed copies (forward)
+};
+
+struct LstmStash {               // everything one dynamic_rnn keeps for BPTT, time-major
+  float *gates = nullptr;        // [T][N][4H]   zx -> gate activations -> dz (in place)
+  float *c = nullptr;            // [T+1][N][H]  c[0] = 0
+  float *h = nullptr;            // [T][N][ldH]
+  float *mst = nullptr;          // [T+1][N][ldP] carried m state, mst[0] = 0
+  float *out = nullptr;          // [T][N][ldP]  masked output
+  float *dmt = nullptr;          // [T][N][ldP]  total dm per step
+  float *dc = nullptr;           // [N][H]   carried during BPTT
+  float *dmst = nullptr;         // [N][ldP] carried during BPTT
+};
+
+struct Model {
+  rsrgan_cfg cfg{};
+  int B = 0, Tmax = 0, Din = 0, Dout = 0, ldDin = 0, ldDout = 0;
+  ParamSet G, D;
+  std::vector<LstmLayer> gl, dl;
+  int g_fc_in_w = -1, g_fc_in_b = -1, g_fc_out_w = -1, g_fc_out_b = -1, d_fc_w = -1, d_fc_b = -1;
+
+  // generator activations (N = B rows per frame)
+  float *x_tm = nullptr, *lab_tm = nullptr, *g_h0 = nullptr, *y_tm = nullptr;
+  std::vector<float*> g_ins;      // g_ins[l] = input of layer l, g_ins[L] = input of the output FC
+  std::vector<float*> g_res;      // res_lstm_l: out_l + in_l buffers (g_ins[l+1] aliases these)
+  std::vector<LstmStash> g_st;
+  float *g_dA = nullptr, *g_dB = nullptr;   // ping-pong gradient buffers [T*B][max ld]
+  // discriminator activations (N = 2B rows per frame)
+  float *xd = nullptr, *logits = nullptr, *dlogits = nullptr;
+  std::vector<LstmStash> d_st;
+  float *d_dA = nullptr, *d_dB = nullptr, *last_dx0 = nullptr;
+  int *len_dev = nullptr;        // [2B]: lengths duplicated for the real|fake stacked batch
+
+  float *dyn = nullptr;          // device scalars (see kernels.hip DYN_*)
+  int *adam_t_dev = nullptr;
+  float *losses = nullptr;       // [8]: d_rl d_fk d_loss | g_adv g_mse g_l2 g_loss | tmp
+  float *tmp3 = nullptr;
+  float *scratch = nullptr;      // colsum / mse partials
+  double scal[RSRGAN_SCALAR_COUNT_] = {0};
+  bool g_fwd_valid = false;
+  int cur_T = 0;
+  bool d_grads_ready = false, g_grads_ready = false;
+  std::vector<void*> allocs;
+
+  int init(const rsrgan_cfg& c, uint64_t seed);
+  void destroy();
+
+  // steps
+  int prepare_batch(const float* x, const float* labels, const int32_t* lengths, int T, hipStream_t s);
+  void g_forward(int T, hipStream_t s);
+  void d_forward(int N, int T, hipStream_t s);
+  void d_backward_pass(int N, int T, bool want_wgrads, bool need_dx0, const float* dlog, hipStream_t s);
+  void g_backward_pass(int T, float* dy, hipStream_t s);
+  int d_backward(const float* x, const float* labels, const int32_t* lengths, int T, const float* nr, const float* nf,
+                 float* out_losses, bool want_grads, hipStream_t s);
+  int g_backward(const float* x, const float* labels, const int32_t* lengths, int T, const float* nf,
+                 float* out_losses, bool want_grads, bool reuse, hipStream_t s);
+  int apply(int net, hipStream_t s);
+  void refresh_transposes(int net, hipStream_t s);
+
+  // building blocks
+  void lstm_forward(const ParamSet& ps, const LstmLayer& L, LstmStash& S, const float* in, int N, int T,
+                    const float* res_in, float* res_out, hipStream_t s);
+  void lstm_backward(const ParamSet& ps, const LstmLayer& L, LstmStash& S, const float* in, int N, int T,
+                     const float* dout, float* din, bool din_accumulate, bool want_wgrads, hipStream_t s);
+
+  template <typename T> T* alloc(size_t n);
+};
+
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+}  // namespace rsr

@@ -1,0 +1,69 @@
+"""Data parallelism for the GAN step: one process per GPU, torch.distributed (backend "nccl" is RCCL
+on ROCm, over xGMI; "gloo" on CPU for tests).
+
+The reference's only parallelism is in-graph tower replication: the fed batch is sliced per GPU
+(models/gan_rnn_placeholder.py:157-159), every variable's gradient is averaged over towers
+(utils/ops.py:343-376), THEN clipped per tensor and applied once (:177-184), with the learning
+rates multiplied by num_gpu (scripts/train_gan_rnn_placeholder.py:458-459).  Here the mean is one
+all-reduce of the flat, zero-padded gradient buffer: 23.4 MB (G) / 0.75 MB (D) fp32 per step.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if is_dist(group) else 1
+
+
+def rank(group=None) -> int:
+    return dist.get_rank(group) if is_dist(group) else 0
+
+
+def init_from_env(backend: Optional[str] = None):
+    """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws <= 1:
+        return 0, 0, 1
+    rk, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rk, world_size=ws)
+    return rk, local, ws
+
+
+def all_reduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
+    """average_gradients (utils/ops.py:343-376) over ranks, in place."""
+    ws = world_size(group)
+    if ws > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.mul_(1.0 / ws)
+    return flat
+
+
+def all_gather_rows(v: torch.Tensor, group=None) -> torch.Tensor:
+    """[k] -> [world, k]: the per-tower loss lists the reference fetches (:262-268)."""
+    ws = world_size(group)
+    if ws == 1:
+        return v.unsqueeze(0)
+    out = [torch.empty_like(v) for _ in range(ws)]
+    dist.all_gather(out, v.contiguous(), group=group)
+    return torch.stack(out, 0)
+
+
+def barrier(group=None):
+    if is_dist(group):
+        dist.barrier(group=group)

@@ -1,0 +1,186 @@
+"""HipEngine -- thin Python wrapper over the C ABI (include/rsrgan.h).
+
+PyTorch is only plumbing here: it owns the device buffers that are passed to the library as raw
+pointers (Tensor.data_ptr()) and the HIP stream the library enqueues on.  No arithmetic of the
+GAN step happens in torch."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import NET_D, NET_G, RsrganCfg, SCALARS, WHAT, check
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class _RawDeviceBuffer:
+    """Exposes a device pointer owned by librsrgan_hip through __cuda_array_interface__ so that
+    torch can alias it (zero copy) -- needed to all-reduce the gradient buffer with RCCL."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False),
+                                         "version": 2, "strides": None}
+
+
+class HipEngine:
+    def __init__(self, *, batch_size: int, max_frames: int, input_dim: int = 257, output_dim: int = 40,
+                 g_type: str = "lstm", g_layers: Optional[int] = None, g_cells: Optional[int] = None,
+                 g_proj: Optional[int] = None, d_layers: Optional[int] = None, d_cells: Optional[int] = None,
+                 d_proj: Optional[int] = None, l2_scale: float = 0.0, cross_validation: bool = False,
+                 ema_decay: float = 0.9999, seed: int = 4321, device: Optional[torch.device] = None, flags: int = 0):
+        if g_type not in _lib.G_TYPES:
+            raise ValueError("Unrecognized G type {}".format(g_type))      # gan_rnn_placeholder.py:131-132
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.RsrganError("no GPU visible: rsrgan_amd runs only on MI355X (gfx950); there is no CPU fallback")
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        torch.cuda.set_device(self.device)
+        cfg = RsrganCfg()
+        check(self.lib.rsrgan_default_cfg(_lib.G_TYPES[g_type], C.byref(cfg)))
+        cfg.batch_size, cfg.max_frames, cfg.input_dim, cfg.output_dim = batch_size, max_frames, input_dim, output_dim
+        for k, v in dict(g_layers=g_layers, g_cells=g_cells, g_proj=g_proj, d_layers=d_layers, d_cells=d_cells,
+                         d_proj=d_proj).items():
+            if v is not None:
+                setattr(cfg, k, int(v))
+        cfg.l2_scale = l2_scale
+        cfg.cross_validation = 1 if cross_validation else 0
+        cfg.ema_decay = ema_decay
+        cfg.flags = flags
+        self.cfg = cfg
+        self.batch_size, self.max_frames = batch_size, max_frames
+        self.input_dim, self.output_dim = input_dim, output_dim
+        self.h = C.c_void_p()
+        check(self.lib.rsrgan_create(C.byref(cfg), C.c_uint64(seed), C.byref(self.h)))
+        self._grad_views = {}
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            self.lib.rsrgan_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing ----------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _f32(self, a, shape=None) -> torch.Tensor:
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+        t = t.to(self.device, torch.float32, non_blocking=True).contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError("expected shape %s, got %s" % (tuple(shape), tuple(t.shape)))
+        return t
+
+    def _i32(self, a) -> torch.Tensor:
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(self.device).to(torch.int32).contiguous()       # placeholder is float32, cast like dynamic_rnn
+
+    def _noise(self, n):
+        if n is None:
+            return None
+        return self._f32(n).reshape(self.batch_size, self.output_dim)
+
+    # -- scalars -----------------------------------------------------------------------
+    def set_scalar(self, name: str, v: float):
+        check(self.lib.rsrgan_set_scalar(self.h, SCALARS[name], float(v)))
+
+    def get_scalar(self, name: str) -> float:
+        out = C.c_double()
+        check(self.lib.rsrgan_get_scalar(self.h, SCALARS[name], C.byref(out)))
+        return out.value
+
+    # -- variables ---------------------------------------------------------------------
+    def tensor_table(self, net: int) -> List[Tuple[str, Tuple[int, ...], int]]:
+        n = self.lib.rsrgan_num_tensors(self.h, net)
+        out = []
+        buf = C.create_string_buffer(256)
+        for i in range(n):
+            r, c, off = C.c_int32(), C.c_int32(), C.c_int64()
+            check(self.lib.rsrgan_tensor_info(self.h, net, i, buf, 256, C.byref(r), C.byref(c), C.byref(off)))
+            shape = (r.value,) if c.value == 0 else (r.value, c.value)
+            out.append((buf.value.decode(), shape, off.value))
+        return out
+
+    def param_count(self, net: int) -> int:
+        return int(self.lib.rsrgan_param_count(self.h, net))
+
+    def get_params(self, net: int, what: str = "variables") -> torch.Tensor:
+        out = torch.empty(self.param_count(net), dtype=torch.float32, device=self.device)
+        check(self.lib.rsrgan_get_params(self.h, net, WHAT[what], _ptr(out), self._stream()))
+        return out
+
+    def set_params(self, net: int, flat, what: str = "variables"):
+        t = self._f32(flat).reshape(-1)
+        if t.numel() != self.param_count(net):
+            raise ValueError("expected %d floats, got %d" % (self.param_count(net), t.numel()))
+        check(self.lib.rsrgan_set_params(self.h, net, WHAT[what], _ptr(t), self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()        # `t` may be a temporary
+
+    def get_grads(self, net: int) -> torch.Tensor:
+        out = torch.empty(self.param_count(net), dtype=torch.float32, device=self.device)
+        check(self.lib.rsrgan_get_grads(self.h, net, _ptr(out), self._stream()))
+        return out
+
+    def grad_view(self, net: int) -> torch.Tensor:
+        """Zero-copy torch view of the library's (padded, flat) gradient buffer."""
+        if net not in self._grad_views:
+            p, n = C.c_void_p(), C.c_int64()
+            check(self.lib.rsrgan_grad_buffer(self.h, net, C.byref(p), C.byref(n)))
+            self._grad_views[net] = torch.as_tensor(_RawDeviceBuffer(p.value, n.value), device=self.device)
+        return self._grad_views[net]
+
+    # -- the path ----------------------------------------------------------------------
+    def forward_g(self, x, lengths) -> torch.Tensor:
+        x = self._f32(x)
+        B, T, _ = x.shape
+        ln = self._i32(lengths)
+        y = torch.empty(B, T, self.output_dim, dtype=torch.float32, device=self.device)
+        check(self.lib.rsrgan_forward_g(self.h, _ptr(x), _ptr(ln), T, _ptr(y), self._stream()))
+        return y
+
+    def d_backward(self, x, lab, lengths, noise_real=None, noise_fake=None, train=True, apply=False) -> torch.Tensor:
+        x, lab, ln = self._f32(x), self._f32(lab), self._i32(lengths)
+        nr, nf = self._noise(noise_real), self._noise(noise_fake)
+        out = torch.empty(3, dtype=torch.float32, device=self.device)
+        T = x.shape[1]
+        if apply or not train:
+            check(self.lib.rsrgan_d_step(self.h, _ptr(x), _ptr(lab), _ptr(ln), T, _ptr(nr), _ptr(nf), _ptr(out),
+                                         1 if train else 0, self._stream()))
+        else:
+            check(self.lib.rsrgan_d_backward(self.h, _ptr(x), _ptr(lab), _ptr(ln), T, _ptr(nr), _ptr(nf), _ptr(out),
+                                             self._stream()))
+        self._keep = (x, lab, ln, nr, nf)       # borrowed until the stream has consumed them
+        return out
+
+    def g_backward(self, x, lab, lengths, noise_fake=None, train=True, reuse=False, apply=False) -> torch.Tensor:
+        x, lab, ln = self._f32(x), self._f32(lab), self._i32(lengths)
+        nf = self._noise(noise_fake)
+        out = torch.empty(4, dtype=torch.float32, device=self.device)
+        T = x.shape[1]
+        if apply or not train:
+            check(self.lib.rsrgan_g_step(self.h, _ptr(x), _ptr(lab), _ptr(ln), T, _ptr(nf), _ptr(out),
+                                         1 if train else 0, 1 if reuse else 0, self._stream()))
+        else:
+            check(self.lib.rsrgan_g_backward(self.h, _ptr(x), _ptr(lab), _ptr(ln), T, _ptr(nf), _ptr(out),
+                                             1 if reuse else 0, self._stream()))
+        self._keep2 = (x, lab, ln, nf)
+        return out
+
+    def apply(self, net: int):
+        check(self.lib.rsrgan_apply(self.h, net, self._stream()))
+
+    # -- low-level op (unit tests, micro-bench) ------------------------------------------
+    def op_gemm(self, A, a_kc, B, b_kc, C_, M, N, K, bias=None, act=0, alpha=0.3, accumulate=False):
+        check(self.lib.rsrgan_op_gemm(_ptr(A), A.stride(0), 1 if a_kc else 0, _ptr(B), B.stride(0), 1 if b_kc else 0,
+                                      _ptr(C_), C_.stride(0), M, N, K, _ptr(bias), act, alpha, 1 if accumulate else 0,
+                                      self._stream()))

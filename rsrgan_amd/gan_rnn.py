@@ -1,0 +1,277 @@
+"""GAN_RNN -- host-side mirror of the reference's model object for the sequence-level GAN step.
+
+Same constructor arguments, attributes, scalars and save/load as
+models/gan_rnn_placeholder.py:GAN_RNN (:62-298), but one *process* per GPU instead of in-graph
+towers: the per-tower gradient mean (utils/ops.py:343-376 average_gradients) becomes an RCCL
+all-reduce(avg) over xGMI, after which the per-tensor clip and the SGD/Adam update run exactly
+as in :177-184.  `sess.run([model.d_opt, ...], feed)` becomes `model.d_step(inputs, labels,
+lengths)`, `sess.run([model.g_opt, ...], feed)` becomes `model.g_step(...)`.
+
+The compute engine defaults to the HIP library; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import glob
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import dist as rdist
+
+NET_G, NET_D = 0, 1
+
+
+class Model(object):
+    """Base class (gan_rnn_placeholder.py:21-60): save / load with tf.train.Saver semantics
+    (max_to_keep=10, `checkpoint` state file naming the latest), stored as .npz keyed by the
+    reference's variable names."""
+
+    def __init__(self, name="BaseModel"):
+        self.name = name
+
+    def save(self, save_dir, step):
+        if not os.path.exists(save_dir):
+            os.makedirs(save_dir)
+        if rdist.rank(self.process_group) != 0:
+            return None
+        base = "%s-%d" % (self.name, int(step))
+        payload = {}
+        for net, tag in ((NET_G, ""), (NET_D, "")):
+            flat = self.engine.get_params(net, "variables").cpu().numpy()
+            ema = self.engine.get_params(net, "ema").cpu().numpy() if self.ema_enabled else None
+            for name, shape, off in self.engine.tensor_table(net):
+                n = int(np.prod(shape))
+                payload[name] = flat[off:off + n].reshape(shape)
+                if ema is not None:
+                    payload[name + "/ExponentialMovingAverage"] = ema[off:off + n].reshape(shape)
+        for what in ("adam_m", "adam_v"):
+            flat = self.engine.get_params(NET_G, what).cpu().numpy()
+            for name, shape, off in self.engine.tensor_table(NET_G):
+                n = int(np.prod(shape))
+                payload[name + ("/Adam" if what == "adam_m" else "/Adam_1")] = flat[off:off + n].reshape(shape)
+        payload["__adam_step__"] = np.asarray(self.engine.get_scalar("adam_step"))
+        path = os.path.join(save_dir, base + ".npz")
+        np.savez(path, **payload)
+        kept = sorted(glob.glob(os.path.join(save_dir, self.name + "-*.npz")), key=os.path.getmtime)
+        for old in kept[:-10]:                                     # Saver(max_to_keep=10)
+            os.remove(old)
+        with open(os.path.join(save_dir, "checkpoint"), "w") as f:
+            f.write('model_checkpoint_path: "%s"\n' % base)
+        return path
+
+    def load(self, save_dir, model_file=None, moving_average=False):
+        if not os.path.exists(save_dir):
+            print("[!] Checkpoints path does not exist...")
+            return False
+        print("[*] Reading checkpoints...")
+        if model_file is None:
+            state = os.path.join(save_dir, "checkpoint")
+            if not os.path.exists(state):
+                return False
+            with open(state) as f:
+                line = f.readline()
+            ckpt_name = line.split('"')[1] if '"' in line else ""
+            if not ckpt_name:
+                return False
+        else:
+            ckpt_name = model_file
+        path = os.path.join(save_dir, ckpt_name if ckpt_name.endswith(".npz") else ckpt_name + ".npz")
+        if not os.path.exists(path):
+            return False
+        data = np.load(path)
+        for net in (NET_G, NET_D):
+            table = self.engine.tensor_table(net)
+            flat = np.zeros(self.engine.param_count(net), np.float32)
+            for name, shape, off in table:
+                key = name + "/ExponentialMovingAverage" if moving_average else name
+                flat[off:off + int(np.prod(shape))] = data[key].reshape(-1)
+            self.engine.set_params(net, flat, "variables")
+            if not moving_average and self.ema_enabled and (table[0][0] + "/ExponentialMovingAverage") in data:
+                for name, shape, off in table:
+                    flat[off:off + int(np.prod(shape))] = data[name + "/ExponentialMovingAverage"].reshape(-1)
+                self.engine.set_params(net, flat, "ema")
+        if not moving_average:
+            table = self.engine.tensor_table(NET_G)
+            for what, suffix in (("adam_m", "/Adam"), ("adam_v", "/Adam_1")):
+                flat = np.zeros(self.engine.param_count(NET_G), np.float32)
+                for name, shape, off in table:
+                    flat[off:off + int(np.prod(shape))] = data[name + suffix].reshape(-1)
+                self.engine.set_params(NET_G, flat, what)
+            self.engine.set_scalar("adam_step", float(data["__adam_step__"]))
+        print("[*] Read {}".format(ckpt_name))
+        return True
+
+
+class GAN_RNN(Model):
+    """Generative Adversarial Network for Speech Enhancement (gan_rnn_placeholder.py:62).
+
+    `sess` is accepted and ignored (there is no session); `devices` is the list the reference
+    iterates over (:153) -- here exactly one entry per process.  Extra keyword-only arguments
+    are the knobs the reference hard-codes or has no notion of."""
+
+    def __init__(self, sess, args, devices, cross_validation=False, infer=False, name="GAN_RNN", *,
+                 max_frames: Optional[int] = None, engine=None, process_group=None, seed: int = 4321,
+                 net_overrides: Optional[dict] = None, share_engine_from: Optional["GAN_RNN"] = None):
+        super(GAN_RNN, self).__init__(name)
+        self.sess = sess
+        self.cross_validation = cross_validation
+        self.MOVING_AVERAGE_DECAY = 0.9999
+        self.max_grad_norm = 15
+        self.keep_prob = 1.0 if cross_validation else getattr(args, "keep_prob", 1.0)
+        self.batch_norm = getattr(args, "batch_norm", False)
+        if self.batch_norm or self.keep_prob < 1.0:
+            raise NotImplementedError("batch_norm / dropout are off on this path "
+                                      "(run_gan_rnn_placeholder.sh:131; train_gan_rnn_placeholder.py:723-728)")
+        self.batch_size = args.batch_size
+        self.devices = devices
+        self.num_gpu = getattr(args, "num_gpu", 1)
+        self.save_dir = getattr(args, "save_dir", None)
+        self.writer = None                                   # tf.summary.FileWriter: out of scope
+        self.summaries = None
+        self.l2_scale = getattr(args, "l2_scale", 0.0)
+        self.input_dim = args.input_dim
+        self.output_dim = args.output_dim
+        self.left_context = getattr(args, "left_context", 0)
+        self.right_context = getattr(args, "right_context", 0)
+        self.g_disturb_weights = False
+        self.disc_updates = getattr(args, "disc_updates", 1)
+        self.gen_updates = getattr(args, "gen_updates", 1)
+        self.d_clip_weights = False
+        self.g_type = args.g_type
+        if self.g_type not in ("lstm", "res_lstm_l", "res_lstm_base"):
+            raise ValueError("Unrecognized G type {}".format(self.g_type))      # :131-132
+        self.process_group = process_group
+        self.infer = infer
+        din = self.input_dim * (self.left_context + 1 + self.right_context)
+        if share_engine_from is not None:                    # the cross_validation twin shares variables (:436-437)
+            self.engine = share_engine_from.engine
+        elif engine is not None:
+            self.engine = engine
+        else:
+            from .engine_hip import HipEngine                # raises if the HIP library / GPU is missing
+            self.engine = HipEngine(batch_size=self.batch_size, max_frames=max_frames or 1000, input_dim=din,
+                                    output_dim=self.output_dim, g_type=self.g_type, l2_scale=self.l2_scale,
+                                    cross_validation=cross_validation, seed=seed, **(net_overrides or {}))
+        self.ema_enabled = getattr(self.engine, "ema_enabled", True)
+        self._scalars = {}
+        if share_engine_from is None:
+            self.mse_lambda = getattr(args, "init_mse_weight", 10.0)
+            self.d_learning_rate = getattr(args, "d_learning_rate", 1e-3)
+            self.g_learning_rate = getattr(args, "g_learning_rate", 8e-5)
+            self.d_real = 1.0
+            self.d_fake = 0.0
+        else:
+            self._scalars = share_engine_from._scalars
+        self.disc_noise_std = getattr(args, "init_disc_noise_std", 0.0)
+        self._noise_gen = None
+
+    # -- mutable scalars: sess.run(tf.assign(model.<x>, v)) --------------------------------
+    def _set(self, k, v):
+        self._scalars[k] = float(v)
+        self.engine.set_scalar(k, float(v))
+
+    d_learning_rate = property(lambda s: s._scalars["d_learning_rate"], lambda s, v: s._set("d_learning_rate", v))
+    g_learning_rate = property(lambda s: s._scalars["g_learning_rate"], lambda s, v: s._set("g_learning_rate", v))
+    mse_lambda = property(lambda s: s._scalars["mse_lambda"], lambda s, v: s._set("mse_lambda", v))
+    d_real = property(lambda s: s._scalars["d_real"], lambda s, v: s._set("d_real", v))
+    d_fake = property(lambda s: s._scalars["d_fake"], lambda s, v: s._set("d_fake", v))
+
+    def assign(self, name, value):
+        setattr(self, name, value)
+
+    # -- helpers -----------------------------------------------------------------------
+    def _draw_noise(self):
+        """gaussian_noise_layer (utils/ops.py:19-30): N(0, std^2) of shape [B,1,Dout]."""
+        if self.disc_noise_std <= 0.0:
+            return None
+        dev = self.engine.device
+        if self._noise_gen is None:
+            self._noise_gen = torch.Generator(device=dev)
+            self._noise_gen.manual_seed(1234 + rdist.rank(self.process_group))
+        return torch.randn(self.batch_size, 1, self.output_dim, generator=self._noise_gen, device=dev) * self.disc_noise_std
+
+    def _shard(self, a):
+        """per-GPU batch slicing (:157-159): a fed [B*num_gpu, ...] batch -> this rank's rows."""
+        if a is None:
+            return None
+        n = a.shape[0]
+        if n == self.batch_size:
+            return a
+        ws, r = rdist.world_size(self.process_group), rdist.rank(self.process_group)
+        if n != self.batch_size * ws:
+            raise ValueError("batch has %d rows, expected %d or %d" % (n, self.batch_size, self.batch_size * ws))
+        return a[self.batch_size * r:self.batch_size * (r + 1)]
+
+    def _towers(self, losses: torch.Tensor) -> torch.Tensor:
+        """[k] device tensor -> [world, k]: the per-tower loss lists of :262-268."""
+        return rdist.all_gather_rows(losses, self.process_group)
+
+    # -- the two sess.run calls ------------------------------------------------------------
+    def d_step(self, inputs, labels, lengths, noise_real=None, noise_fake=None, train=True, sync=True):
+        """sess.run([model.d_opt, model.d_rl_losses, model.d_fk_losses, model.d_losses], feed)
+        (train_gan_rnn_placeholder.py:77-82).  Returns three per-tower lists (or, with
+        sync=False, a [towers,3] device tensor)."""
+        x, lab, ln = self._shard(inputs), self._shard(labels), self._shard(lengths)
+        nr = self._shard(noise_real) if noise_real is not None else self._draw_noise()
+        nf = self._shard(noise_fake) if noise_fake is not None else self._draw_noise()
+        train = train and not self.cross_validation
+        ws = rdist.world_size(self.process_group)
+        if train and ws > 1:
+            losses = self.engine.d_backward(x, lab, ln, nr, nf, train=True, apply=False)
+            rdist.all_reduce_mean_(self.engine.grad_view(NET_D), self.process_group)     # average_gradients
+            self.engine.apply(NET_D)
+        else:
+            losses = self.engine.d_backward(x, lab, ln, nr, nf, train=train, apply=train)
+        tw = self._towers(losses)
+        if not sync:
+            return tw
+        tw = tw.cpu().numpy()
+        return list(tw[:, 0]), list(tw[:, 1]), list(tw[:, 2])
+
+    def g_step(self, inputs, labels, lengths, noise_fake=None, train=True, reuse_g_forward=False, sync=True):
+        """sess.run([model.g_opt, model.g_adv_losses, model.g_mse_losses, model.g_l2_losses,
+        model.g_losses], feed) (train_gan_rnn_placeholder.py:94-101)."""
+        x, lab, ln = self._shard(inputs), self._shard(labels), self._shard(lengths)
+        nf = self._shard(noise_fake) if noise_fake is not None else self._draw_noise()
+        train = train and not self.cross_validation
+        ws = rdist.world_size(self.process_group)
+        if train and ws > 1:
+            losses = self.engine.g_backward(x, lab, ln, nf, train=True, reuse=reuse_g_forward, apply=False)
+            rdist.all_reduce_mean_(self.engine.grad_view(NET_G), self.process_group)
+            self.engine.apply(NET_G)
+        else:
+            losses = self.engine.g_backward(x, lab, ln, nf, train=train, reuse=reuse_g_forward, apply=train)
+        tw = self._towers(losses)
+        if not sync:
+            return tw
+        tw = tw.cpu().numpy()
+        return list(tw[:, 0]), list(tw[:, 1]), list(tw[:, 2]), list(tw[:, 3])
+
+    def forward(self, inputs, lengths):
+        """sess.run(model.g_outputs, {inputs, lengths}) (train_gan_rnn_placeholder.py:282-285)."""
+        y = self.engine.forward_g(inputs, lengths)
+        return y.cpu().numpy() if not isinstance(inputs, torch.Tensor) else y
+
+    # -- variables ---------------------------------------------------------------------
+    def get_vars(self):
+        """d_vars / g_vars split by name prefix with the reference's asserts (:301-317)."""
+        self.g_vars_dict, self.d_vars_dict = {}, {}
+        for net, dst, pre in ((NET_G, self.g_vars_dict, "g_"), (NET_D, self.d_vars_dict, "d_")):
+            flat = self.engine.get_params(net, "variables").cpu().numpy()
+            for name, shape, off in self.engine.tensor_table(net):
+                assert name.startswith(pre), name
+                dst[name] = flat[off:off + int(np.prod(shape))].reshape(shape)
+        return self.g_vars_dict, self.d_vars_dict
+
+    def set_vars(self, g_vars=None, d_vars=None):
+        for net, vals in ((NET_G, g_vars), (NET_D, d_vars)):
+            if vals is None:
+                continue
+            flat = np.zeros(self.engine.param_count(net), np.float32)
+            for name, shape, off in self.engine.tensor_table(net):
+                v = np.asarray(vals[name], np.float32)
+                assert tuple(v.shape) == tuple(shape), (name, v.shape, shape)
+                flat[off:off + v.size] = v.reshape(-1)
+            self.engine.set_params(net, flat, "variables")

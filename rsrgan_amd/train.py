@@ -1,0 +1,100 @@
+"""The caller of the hot path: scripts/train_gan_rnn_placeholder.py:48-201 and utils/ops.py:378-391."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+
+def exponential_decay(iteration, num_jobs, num_ietrs, init_learning_rate, multiply_jobs=True):
+    """utils/ops.py:378-391 (argument names as in the reference)."""
+    final_learning_rate = 0.0001 * init_learning_rate
+    if iteration + 1 >= num_ietrs:
+        current_learning_rate = final_learning_rate
+    else:
+        current_learning_rate = init_learning_rate * math.exp(
+            iteration * math.log(final_learning_rate / init_learning_rate) / num_ietrs)
+    return num_jobs * current_learning_rate if multiply_jobs else current_learning_rate
+
+
+def _batches(train_queue):
+    if hasattr(train_queue, "get") and not isinstance(train_queue, (list, tuple)):
+        while True:
+            item = train_queue.get()
+            if item is None:
+                return
+            yield item
+    else:
+        for item in train_queue:
+            yield item
+
+
+def train_one_iteration(sess, model, tr_num_batch, iteration, train_queue, num_gpu=None, share_g_forward=True):
+    """Runs the model one iteration on given data (train_gan_rnn_placeholder.py:48-133).
+
+    `train_queue` yields [ids, inputs, labels, lengths] (a Queue like the reference's, or any
+    iterable).  Per batch: disc_updates D-runs then gen_updates G-runs on the same fed batch;
+    batches whose row count is not batch_size*num_gpu are skipped (:69-70).  The batch is
+    uploaded once (the reference feeds it 3x) and -- legal because G does not change between the
+    last D update and the first G update -- the first G-run reuses the generator forward of the
+    D-run unless share_g_forward=False.  Losses stay on the device until the end of the
+    iteration.  Returns the same 7 averages."""
+    num_gpu = num_gpu or model.num_gpu
+    model.d_real = 1.0                                            # :63-64
+    model.d_fake = 0.0
+    d_counter = g_counter = 0
+    d_acc = g_acc = None
+    n_batches = int(tr_num_batch / num_gpu)
+    it = _batches(train_queue)
+    dev = model.engine.device
+    for batch in range(n_batches):
+        try:
+            _, queue_inputs, queue_labels, queue_lengths = next(it)
+        except StopIteration:
+            break
+        if queue_inputs.shape[0] != model.batch_size * num_gpu:   # :69-70
+            continue
+        x = model._shard(queue_inputs); lab = model._shard(queue_labels); ln = model._shard(queue_lengths)
+        if not isinstance(x, torch.Tensor):
+            x = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+            lab = torch.from_numpy(np.ascontiguousarray(lab, np.float32)).to(dev)
+            ln = torch.from_numpy(np.ascontiguousarray(ln)).to(dev).to(torch.int32)
+        for d_step in range(model.disc_updates):
+            tw = model.d_step(x, lab, ln, sync=False)             # [towers, 3]
+            m = tw.mean(0)                                        # np.mean over towers (:85-87)
+            d_acc = m if d_acc is None else d_acc + m
+            d_counter += 1
+        for g_step in range(model.gen_updates):
+            reuse = share_g_forward and g_step == 0 and model.disc_updates > 0
+            tw = model.g_step(x, lab, ln, reuse_g_forward=reuse, sync=False)
+            m = tw.mean(0)
+            g_acc = m if g_acc is None else g_acc + m
+            g_counter += 1
+    d = (d_acc / max(d_counter, 1)).cpu().numpy() if d_acc is not None else np.zeros(3)
+    g = (g_acc / max(g_counter, 1)).cpu().numpy() if g_acc is not None else np.zeros(4)
+    return float(d[0]), float(d[1]), float(d[2]), float(g[0]), float(g[1]), float(g[2]), float(g[3])
+
+
+def eval_one_iteration(sess, model, cv_num_batch, iteration, valid_queue, num_gpu=None):
+    """Cross validate the model on given data (train_gan_rnn_placeholder.py:136-201): the same
+    fetches without the *_opt ops."""
+    num_gpu = num_gpu or model.num_gpu
+    model.d_real = 1.0
+    model.d_fake = 0.0
+    d_acc = g_acc = None
+    n = 0
+    it = _batches(valid_queue)
+    for batch in range(int(cv_num_batch / num_gpu)):
+        try:
+            _, x, lab, ln = next(it)
+        except StopIteration:
+            break
+        td = model.d_step(x, lab, ln, train=False, sync=False).mean(0)
+        tg = model.g_step(x, lab, ln, train=False, sync=False).mean(0)
+        d_acc = td if d_acc is None else d_acc + td
+        g_acc = tg if g_acc is None else g_acc + tg
+        n += 1
+    d = (d_acc / max(n, 1)).cpu().numpy() if d_acc is not None else np.zeros(3)
+    g = (g_acc / max(n, 1)).cpu().numpy() if g_acc is not None else np.zeros(4)
+    return float(d[0]), float(d[1]), float(d[2]), float(g[0]), float(g[1]), float(g[2]), float(g[3])

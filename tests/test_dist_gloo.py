@@ -1,0 +1,61 @@
+"""N>1 path on CPU: world_size-2 gloo.  Rank k takes batch rows [B*k, B*(k+1))
+(models/gan_rnn_placeholder.py:157-159), gradients are averaged with all-reduce
+(utils/ops.py:343-376), then clipped and applied -- must equal the oracle run as 2 in-graph towers."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import rsrgan_oracle as O
+from tests.helpers import OracleEngine, args_for, rand_batch, rand_params, small_cfg
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rsrgan_amd import GAN_RNN, train_one_iteration
+        cfg = small_cfg()
+        B, T = 2, 5
+        g, d = rand_params(cfg, 5)
+        lr_g, lr_d = 8e-5 * world, 1e-3 * world                    # LR x num_gpu (train...py:458-459)
+        m = GAN_RNN(None, args_for(cfg, B, num_gpu=world, g_learning_rate=lr_g, d_learning_rate=lr_d, gen_updates=2),
+                    ["cpu:%d" % rank], engine=OracleEngine(cfg, g, d, B))
+        batches = [rand_batch(cfg, B * world, T, 60 + i, ragged=True) for i in range(2)]
+        res = train_one_iteration(None, m, len(batches) * world, 0, [[None] + list(b) for b in batches])
+        flat = np.concatenate([m.engine.o.g[n].reshape(-1) for n, _ in O.g_param_specs(cfg)] +
+                              [m.engine.o.d[n].reshape(-1) for n, _ in O.d_param_specs(cfg)])
+        out[rank] = (res, flat)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_equals_two_tower_oracle():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    cfg = small_cfg()
+    B, T = 2, 5
+    g, d = rand_params(cfg, 5)
+    ref = O.GanRnnOracle(cfg, g, d, batch_size=B, num_towers=world,
+                         g_learning_rate=float(np.float32(8e-5 * world)), d_learning_rate=float(np.float32(1e-3 * world)))
+    batches = [rand_batch(cfg, B * world, T, 60 + i, ragged=True) for i in range(2)]
+    want = O.train_one_iteration(ref, batches, 1, 2)
+    want_flat = np.concatenate([ref.g[n].reshape(-1) for n, _ in O.g_param_specs(cfg)] +
+                               [ref.d[n].reshape(-1) for n, _ in O.d_param_specs(cfg)])
+    for r in range(world):
+        res, flat = out[r]
+        assert np.allclose(res, want, rtol=1e-6), (r, res, want)
+        assert np.allclose(flat, want_flat, rtol=1e-9, atol=1e-12), r
+    assert np.array_equal(out[0][1], out[1][1])                     # replicas stay bit-identical

@@ -1,0 +1,169 @@
+"""Parity of the HIP path (through the C ABI) against the fp64 CPU oracle on seeded inputs.
+
+Tolerances: the north star asks for <= 1e-3 relative on the G/D losses and on the enhanced-MFCC
+L1; fp32 kernels against the fp64 oracle are expected to land around 1e-6..1e-5, so the tests
+assert 1e-4 on losses/outputs and 2e-3 relative-L2 on every gradient / updated tensor."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rsrgan_oracle as O
+from tests.helpers import (NET_D, NET_G, build_hip_pair, rand_batch, rel_err, small_cfg, split_flat)
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-4
+GRAD_RTOL = 2e-3
+
+
+def _check_grads(model, net, want, tag):
+    got = split_flat(model.engine.get_grads(net).cpu().numpy(), model.engine.tensor_table(net))
+    bad = []
+    for k in want:
+        scale = max(np.abs(want[k]).max(), 1e-12)
+        e = rel_err(got[k], want[k])
+        if not (e < GRAD_RTOL or np.abs(got[k] - want[k]).max() < 1e-6 * max(scale, 1.0)):
+            bad.append((k, e))
+    assert not bad, "%s gradient mismatch: %s" % (tag, bad)
+
+
+@pytest.mark.parametrize("g_type", ["lstm", "res_lstm_l", "res_lstm_base"])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_forward_and_gradients_small(g_type, ragged):
+    cfg = small_cfg(g_type)
+    B, T = 5, 7
+    model, oracle = build_hip_pair(cfg, B, T, seed=3)
+    x, lab, ln = rand_batch(cfg, B, T, seed=11, ragged=ragged)
+    y = model.forward(x, ln)
+    y_ref = oracle.forward(x, ln)
+    assert np.abs(y - y_ref).mean() / np.abs(y_ref).mean() < LOSS_RTOL          # enhanced-MFCC L1
+    assert np.abs(y - y_ref).max() < 1e-4
+    rng = np.random.default_rng(5)
+    nr = rng.normal(0, 0.05, (B, 1, cfg.output_dim)).astype(np.float32)
+    nf = rng.normal(0, 0.05, (B, 1, cfg.output_dim)).astype(np.float32)
+    # D tower: losses + d_vars gradients
+    got = model.engine.d_backward(x, lab, ln, nr, nf, train=True, apply=False).cpu().numpy()
+    want, wg = oracle.d_tower(x.astype(np.float64), lab.astype(np.float64), ln, nr.astype(np.float64), nf.astype(np.float64))
+    assert np.allclose(got, want, rtol=LOSS_RTOL), (got, want)
+    _check_grads(model, NET_D, wg, "D")
+    # G tower
+    got = model.engine.g_backward(x, lab, ln, nf, train=True, reuse=False, apply=False).cpu().numpy()
+    want, wg, _ = oracle.g_tower(x.astype(np.float64), lab.astype(np.float64), ln, nf.astype(np.float64))
+    assert np.allclose(got, want, rtol=LOSS_RTOL, atol=1e-7), (got, want)
+    _check_grads(model, NET_G, wg, "G")
+
+
+def test_steps_update_weights_like_oracle():
+    """1 D-update + 2 G-updates (the shipped 1:2 schedule, run_gan_rnn_placeholder.sh:129-130),
+    first G-run reusing the D-run's generator forward; then compare every variable, Adam slot
+    and EMA shadow."""
+    cfg = small_cfg("lstm")
+    B, T = 6, 9
+    model, oracle = build_hip_pair(cfg, B, T, seed=4, l2_scale=1e-3, g_learning_rate=1e-3, d_learning_rate=5e-2)
+    x, lab, ln = rand_batch(cfg, B, T, seed=12, ragged=True)
+    a = model.d_step(x, lab, ln); b = oracle.d_step(x, lab, ln)
+    assert np.allclose(np.ravel(a), np.ravel(b), rtol=LOSS_RTOL)
+    for i in range(2):
+        a = model.g_step(x, lab, ln, reuse_g_forward=(i == 0)); b = oracle.g_step(x, lab, ln)
+        assert np.allclose(np.ravel(a), np.ravel(b), rtol=LOSS_RTOL), (i, a, b)
+    gv, dv = model.get_vars()
+    for k in oracle.g:
+        assert rel_err(gv[k], oracle.g[k]) < 1e-4, k
+    for k in oracle.d:
+        assert rel_err(dv[k], oracle.d[k]) < 1e-4, k
+    eng = model.engine
+    m = split_flat(eng.get_params(NET_G, "adam_m").cpu().numpy(), eng.tensor_table(NET_G))
+    v = split_flat(eng.get_params(NET_G, "adam_v").cpu().numpy(), eng.tensor_table(NET_G))
+    e = split_flat(eng.get_params(NET_G, "ema").cpu().numpy(), eng.tensor_table(NET_G))
+    for k in oracle.g:
+        assert rel_err(m[k], oracle.adam_m[k]) < GRAD_RTOL, k
+        assert rel_err(v[k], oracle.adam_v[k]) < 2 * GRAD_RTOL, k
+        assert rel_err(e[k], oracle.g_ema[k]) < 1e-4, k
+    assert eng.get_scalar("adam_step") == 2
+
+
+def test_clip_by_norm_engages():
+    """Large gradients: per-tensor clip at 15 must bound the SGD step (gan_rnn_placeholder.py:178-182)."""
+    cfg = small_cfg("lstm")
+    B, T = 4, 6
+    model, oracle = build_hip_pair(cfg, B, T, seed=8, d_learning_rate=1e-2)
+    x, lab, ln = rand_batch(cfg, B, T, seed=13)
+    lab = lab * 300.0                                   # huge logits error -> gradient norms >> 15
+    model.d_step(x, lab, ln); oracle.d_step(x, lab, ln)
+    _, dv = model.get_vars()
+    for k in oracle.d:
+        assert rel_err(dv[k], oracle.d[k]) < 1e-4, k
+
+
+def test_eval_fetch_does_not_update():
+    cfg = small_cfg("lstm")
+    model, oracle = build_hip_pair(cfg, 4, 6, seed=9)
+    x, lab, ln = rand_batch(cfg, 4, 6, seed=14)
+    g0, d0 = model.get_vars()
+    a = model.d_step(x, lab, ln, train=False); b = oracle.d_step(x, lab, ln, train=False)
+    assert np.allclose(np.ravel(a), np.ravel(b), rtol=LOSS_RTOL)
+    a = model.g_step(x, lab, ln, train=False); b = oracle.g_step(x, lab, ln, train=False)
+    assert np.allclose(np.ravel(a), np.ravel(b), rtol=LOSS_RTOL)
+    g1, d1 = model.get_vars()
+    assert all(np.array_equal(g0[k], g1[k]) for k in g0) and all(np.array_equal(d0[k], d1[k]) for k in d0)
+
+
+def test_edge_lengths_and_batch_sizes():
+    """B not a multiple of 16, T=1, a row of length 1 and full-length rows."""
+    cfg = small_cfg("lstm")
+    for B, T in ((1, 1), (17, 3), (33, 2)):
+        model, oracle = build_hip_pair(cfg, B, T, seed=B)
+        x, lab, ln = rand_batch(cfg, B, T, seed=15 + B)
+        ln[-1] = 1
+        got = model.engine.g_backward(x, lab, ln, None, train=True, reuse=False, apply=False).cpu().numpy()
+        want, wg, _ = oracle.g_tower(x.astype(np.float64), lab.astype(np.float64), ln)
+        assert np.allclose(got, want, rtol=LOSS_RTOL, atol=1e-7), (B, T, got, want)
+        _check_grads(model, NET_G, wg, "G B=%d T=%d" % (B, T))
+
+
+@pytest.mark.parametrize("g_type", ["lstm", "res_lstm_l"])
+def test_reference_true_shapes(g_type):
+    """The reference's hard-coded sizes (G 3x760/p280 or 4x760/p257, D 2x256/p40) at B=4, T=6."""
+    cfg = O.NetCfg() if g_type == "lstm" else O.NetCfg.res_lstm_l()
+    B, T = 4, 6
+    model, oracle = build_hip_pair(cfg, B, T, seed=21)
+    x, lab, ln = rand_batch(cfg, B, T, seed=22, ragged=True)
+    got = model.engine.d_backward(x, lab, ln, None, None, train=True, apply=False).cpu().numpy()
+    want, wg = oracle.d_tower(x.astype(np.float64), lab.astype(np.float64), ln)
+    assert np.allclose(got, want, rtol=LOSS_RTOL), (got, want)
+    _check_grads(model, NET_D, wg, "D")
+    got = model.engine.g_backward(x, lab, ln, None, train=True, reuse=True, apply=False).cpu().numpy()
+    want, wg, y_ref = oracle.g_tower(x.astype(np.float64), lab.astype(np.float64), ln)
+    assert np.allclose(got, want, rtol=LOSS_RTOL), (got, want)
+    _check_grads(model, NET_G, wg, "G")
+    y = model.forward(x, ln)
+    assert np.abs(y - y_ref).mean() / np.abs(y_ref).mean() < LOSS_RTOL
+
+
+def test_train_one_iteration_matches_oracle():
+    from rsrgan_amd import train_one_iteration
+    cfg = small_cfg("lstm")
+    B, T = 4, 5
+    model, oracle = build_hip_pair(cfg, B, T, seed=31, disc_updates=1, gen_updates=2)
+    batches = [rand_batch(cfg, B, T, seed=40), rand_batch(cfg, 3, T, seed=41), rand_batch(cfg, B, T, seed=42)]
+    queue = [[None, x, lab, ln] for x, lab, ln in batches]
+    got = train_one_iteration(None, model, len(queue), 0, queue)
+    want = O.train_one_iteration(oracle, batches, disc_updates=1, gen_updates=2)
+    assert np.allclose(got, want, rtol=LOSS_RTOL), (got, want)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    cfg = small_cfg("lstm")
+    model, _ = build_hip_pair(cfg, 4, 5, seed=51)
+    x, lab, ln = rand_batch(cfg, 4, 5, seed=52)
+    model.d_step(x, lab, ln); model.g_step(x, lab, ln)
+    model.save(str(tmp_path), 7)
+    g0, d0 = model.get_vars()
+    ref = model.g_step(x, lab, ln, train=False)
+    model2, _ = build_hip_pair(cfg, 4, 5, seed=99)
+    assert model2.load(str(tmp_path))
+    g1, d1 = model2.get_vars()
+    assert all(np.array_equal(g0[k], g1[k]) for k in g0) and all(np.array_equal(d0[k], d1[k]) for k in d0)
+    assert model2.engine.get_scalar("adam_step") == 1
+    assert np.allclose(np.ravel(model2.g_step(x, lab, ln, train=False)), np.ravel(ref), rtol=1e-6)
+    assert not model2.load(str(tmp_path / "missing"))
