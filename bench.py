@@ -62,11 +62,14 @@ def cpu_baseline(net, B, T, budget_s=20.0):
     d = O.xavier_init(O.d_param_specs(cfg), np.random.default_rng(4322), np.float32)
     tw = TT.GanRnnTorchTwin(cfg, g, d)
     x, lab, ln = synthetic(B, T, cfg.input_dim, cfg.output_dim)
-    threads = torch.get_num_threads()
+    # the per-step GEMMs are tiny (M = 64): all 128+ hardware threads oversubscribe (measured 284
+    # frames/s at 128 threads vs ~1.6k at 8), so the baseline uses min(16, cores) threads
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     t0 = time.time(); n = 0
     while True:
         tw.d_step(x, lab, ln); tw.g_step(x, lab, ln); n += 1
-        if n >= 4 or time.time() - t0 > budget_s:
+        if n >= 3 or time.time() - t0 > budget_s:
             break
     dt = time.time() - t0
     model_name = ""
@@ -91,6 +94,8 @@ def main():
     ap.add_argument("--net", default="lstm", choices=["lstm", "res_lstm_l"])
     ap.add_argument("--gen-updates", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--flags", type=int, default=int(os.environ.get("RSRGAN_FLAGS", "1")),
+                    help="library schedule flags: 1 = wavefront, 2 = hipGraph (include/rsrgan.h)")
     a = ap.parse_args()
 
     from rsrgan_amd import GAN_RNN, dist as rdist
@@ -107,7 +112,7 @@ def main():
                            keep_prob=1.0, batch_norm=False, num_gpu=world, save_dir=None, l2_scale=0.0,
                            disc_updates=1, gen_updates=a.gen_updates, init_mse_weight=10.0, init_disc_noise_std=0.0,
                            d_learning_rate=1e-3 * world, g_learning_rate=8e-5 * world)   # LR x num_gpu (:458-459)
-    model = GAN_RNN(None, args, ["gpu:%d" % local], max_frames=T, seed=4321)
+    model = GAN_RNN(None, args, ["gpu:%d" % local], max_frames=T, seed=4321, net_overrides=dict(flags=a.flags))
     x, lab, ln = synthetic(B, T, 257, 40, seed=1234 + rank)
     x = torch.from_numpy(x).to(dev); lab = torch.from_numpy(lab).to(dev); ln = torch.from_numpy(ln).to(dev)
 
@@ -160,7 +165,7 @@ def main():
                "config": {"workload": "gan_rnn_placeholder 1D+%dG step, G=%s(%dx%d/p%d)+D=lstm(%dx%d/p%d), B=%d/GPU T=%d, "
                                       "257->40" % (a.gen_updates, a.net, c.g_layers, c.g_cells, c.g_proj, c.d_layers,
                                                    c.d_cells, c.d_proj, B, T),
-                          "global_batch": B * world, "frames_per_step": B * T * world, "parallelism": "dp%d" % world,
+                          "schedule_flags": a.flags, "global_batch": B * world, "frames_per_step": B * T * world, "parallelism": "dp%d" % world,
                           "losses_last_step": [round(float(v), 6) for v in losses]},
                "roofline": roof}
         if world == 1 and not a.no_cpu_baseline:

@@ -212,7 +212,12 @@ int rsrgan_grad_buffer(rsrgan_handle h, int32_t net, float** ptr, int64_t* count
 int rsrgan_op_gemm(const float* A, int32_t lda, int32_t a_kc, const float* B, int32_t ldb, int32_t b_kc, float* C, int32_t ldc,
                    int32_t M, int32_t N, int32_t K, const float* bias, int32_t act, float alpha, int32_t accumulate, void* stream) {
   if (!A || !B || !C || (lda & 3) || (ldb & 3)) { set_error("op_gemm: null pointer or leading dimension not a multiple of 4"); return RSRGAN_ERR_INVALID; }
-  launch_gemm(A, lda, a_kc != 0, B, ldb, b_kc != 0, C, ldc, M, N, K, bias, act, alpha, accumulate != 0, (hipStream_t)stream);
+  // unit-test entry: a private split-K workspace so the same code path as the model is exercised
+  static float* ws = nullptr;
+  static const size_t ws_floats = (size_t)16 << 20;
+  if (!ws && hipMalloc((void**)&ws, ws_floats * sizeof(float)) != hipSuccess) ws = nullptr;
+  launch_gemm(A, lda, a_kc != 0, B, ldb, b_kc != 0, C, ldc, M, N, K, bias, act, alpha, accumulate != 0, (hipStream_t)stream,
+              ws, ws ? ws_floats : 0);
   if (hipGetLastError() != hipSuccess) { set_error("op_gemm launch failed"); return RSRGAN_ERR_HIP; }
   return RSRGAN_OK;
 }

@@ -8,6 +8,8 @@
 // As[k][m], Bs[k][n] (row stride 132 floats: 16-B aligned rows, 4-bank shift per k) so that the
 // MFMA fragment reads (lane l: row/col = l&31, k = l>>5) are 32 consecutive floats per half-wave
 // = conflict-free ds_read_b32.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace rsr {
@@ -54,7 +56,8 @@ __device__ __forceinline__ void store_tile(float (*S)[LDT], int tid, const float
 template <bool AKC, bool BKC>
 __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                               float* __restrict__ C, int ldc, int M, int N, int K,
-                                              const float* __restrict__ bias, int act, float alpha, int accumulate) {
+                                              const float* __restrict__ bias, int act, float alpha, int accumulate,
+                                              float* __restrict__ ws, int ldw, int kt_per_split) {
   __shared__ __attribute__((aligned(16))) float As[BK][LDT];
   __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -76,11 +79,15 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
   const int MA = AKC ? M : ((M + 3) & ~3);
   const int NB = BKC ? N : ((N + 3) & ~3);
 
+  // split-K: blockIdx.z owns k-tiles [kt0, kt1); partial tiles go to ws[z][M][ldw] and are summed in
+  // a fixed order by k_splitk_reduce (deterministic, unlike float atomics)
+  const int nk_all = (K + BK - 1) / BK;
+  const int kt0 = blockIdx.z * kt_per_split;
+  const int nk = min(nk_all, kt0 + kt_per_split);
   float4 ra[2], rb[2];
-  load_tile<AKC>(A, lda, m0, MA, 0, KA, tid, ra);
-  load_tile<BKC>(B, ldb, n0, NB, 0, KB, tid, rb);
-  const int nk = (K + BK - 1) / BK;
-  for (int kt = 0; kt < nk; ++kt) {
+  load_tile<AKC>(A, lda, m0, MA, kt0 * BK, KA, tid, ra);
+  load_tile<BKC>(B, ldb, n0, NB, kt0 * BK, KB, tid, rb);
+  for (int kt = kt0; kt < nk; ++kt) {
     store_tile<AKC>(As, tid, ra);
     store_tile<BKC>(Bs, tid, rb);
     __syncthreads();
@@ -113,6 +120,10 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row >= M) continue;
+        if (ws) {
+          ws[((size_t)blockIdx.z * M + row) * ldw + col] = acc[i][j][r];
+          continue;
+        }
         float v = acc[i][j][r] + bv;
         if (act == 1) v = fmaxf(v, alpha * v);            // utils/ops.py:120-121 tf.maximum(x, alpha*x)
         float* c = C + (size_t)row * ldc + col;
@@ -122,19 +133,53 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     }
 }
 
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ ws, int ldw, int splits, float* __restrict__ C,
+                                                       int ldc, int M, int N, const float* __restrict__ bias, int act,
+                                                       float alpha, int accumulate) {
+  const size_t total = (size_t)M * N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / N), col = (int)(i % N);
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += ws[((size_t)z * M + row) * ldw + col];
+    if (bias) v += bias[col];
+    if (act == 1) v = fmaxf(v, alpha * v);
+    float* c = C + (size_t)row * ldc + col;
+    if (accumulate) v += *c;
+    *c = v;
+  }
+}
+
 void launch_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool b_kc, float* C, int ldc,
-                 int M, int N, int K, const float* bias, int act, float alpha, bool accumulate, hipStream_t s) {
+                 int M, int N, int K, const float* bias, int act, float alpha, bool accumulate, hipStream_t s,
+                 float* ws, size_t ws_floats) {
   if (M <= 0 || N <= 0) return;
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM), block(256);
+  const int gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
+  const int nk = (K + BK - 1) / BK;
+  // fill the 256 CUs: under-filled output grids (weight gradients: few tiles, K = T*B) split K
+  int splits = 1;
+  const int ldw = (N + 3) & ~3;
+  if (ws && gx * gy < 192 && nk >= 8) {
+    splits = std::min(std::min((512 + gx * gy - 1) / (gx * gy), nk / 4), 64);
+    while (splits > 1 && (size_t)splits * M * ldw > ws_floats) --splits;
+  }
+  const int per = std::max(1, (nk + splits - 1) / splits);
+  splits = std::max(1, (nk + per - 1) / per);
+  float* w = splits > 1 ? ws : nullptr;
+  dim3 grid(gx, gy, splits), block(256);
   const int acc = accumulate ? 1 : 0;
   if (a_kc && !b_kc)
-    hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc);
+    hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per);
   else if (a_kc && b_kc)
-    hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc);
+    hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per);
   else if (!a_kc && !b_kc)
-    hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc);
+    hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per);
   else
-    hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc);
+    hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per);
+  if (splits > 1) {
+    const size_t total = (size_t)M * N;
+    const int blocks = (int)std::min<size_t>(2048, (total + 255) / 256);
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(blocks), dim3(256), 0, s, ws, ldw, splits, C, ldc, M, N, bias, act, alpha, acc);
+  }
 }
 
 }  // namespace rsr

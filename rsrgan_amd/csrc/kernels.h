@@ -79,17 +79,22 @@ struct BwdBJob {
 };
 struct BwdBJobs { int n; BwdBJob j[MAXJ]; };
 
-void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, hipStream_t s);
-void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, hipStream_t s);
-void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, hipStream_t s);
-void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, hipStream_t s);
+// A job covers nblk_r = ceil(N/32) row blocks x roundup8(nblk_c) virtual column blocks; blk_base is
+// the job's first block id in the launch.  kb_max = largest 16-float k-block count of any job in
+// the launch (selects how many waves split K).
+inline int job_blocks(int nblk_c, int N) { return ((nblk_c + 7) & ~7) * ((N + 31) / 32); }
+void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
+void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
+void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
+void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
 
 // ---------------------------------------------------------------- batched GEMM
 // C[M,N] (+)= A.B (+bias)(lrelu).  a_kc: A(m,k)=A[m*lda+k] else A[k*lda+m];
 // b_kc: B(k,n)=B[n*ldb+k] else B[k*ldb+n].
 void launch_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool b_kc,
                  float* C, int ldc, int M, int N, int K,
-                 const float* bias, int act, float alpha, bool accumulate, hipStream_t s);
+                 const float* bias, int act, float alpha, bool accumulate, hipStream_t s,
+                 float* splitk_ws = nullptr, size_t splitk_ws_floats = 0);
 
 // ---------------------------------------------------------------- layout / pointwise
 void launch_pack_tm(const float* src_bm, float* dst_tm, int B, int T, int D, int ld, hipStream_t s);      // [B,T,D] -> [T][B][ld]
@@ -98,6 +103,9 @@ void launch_unpack_bm(const float* src_tm, int ld, float* dst_bm, int B, int T, 
 // xd[t][B+b or b] = y[t][b] + noise_f[b]
 void launch_build_d_input(const float* lab_tm, const float* y_tm, const float* noise_r, const float* noise_f,
                           float* xd, int B, int T, int D, int ld, bool with_real, hipStream_t s);
+// dst[t][row0 + b] = src[t][b] + noise[b]   for b < B; dst has Ns rows per time step
+void launch_add_noise_rows(const float* src_tm, const float* noise, float* dst, int B, int T, int D, int ld,
+                           int Ns, int row0, hipStream_t s);
 void launch_transpose(const float* src, int lds, float* dst, int ldd, int R, int C, hipStream_t s);        // dst[c][r] = src[r][c]
 void launch_fill(float* p, size_t n, float v, hipStream_t s);
 void launch_lrelu_bwd(const float* hval, float* d, size_t rows, int cols, int ld, float alpha, hipStream_t s); // d *= (h>0?1:alpha)

@@ -33,73 +33,125 @@ __device__ __forceinline__ int find_job(const JobT* j, int n, int bid) {
   return ji;
 }
 
-// acc[16x16] += A[16 rows][k] * W[16 cols][k] over k in [kbeg,kend) (multiples of 16),
-// both operands k-contiguous; `ld` bounds the (zero-padded) row.
-__device__ __forceinline__ void mfma_seg(f32x4& acc, const float* __restrict__ arow, bool aok,
-                                         const float* __restrict__ wrow, bool wok, int ld,
-                                         int kbeg, int kend, int q) {
-#pragma unroll 4
-  for (int kb = kbeg; kb < kend; kb += 16) {
-    const int k = kb + 4 * q;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (aok && k < ld) a = *reinterpret_cast<const float4*>(arow + k);
-    if (wok && k < ld) b = *reinterpret_cast<const float4*>(wrow + k);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+// Column-block <-> XCD affinity: a job's blocks are laid out as nblk_r rows of nblk_c8 =
+// roundup8(nblk_c) virtual column blocks, so (block id % 8) == (column block % 8) for every row
+// block and every time step: the slice of a weight matrix a column block streams stays in ONE
+// XCD's 4 MiB L2 across the whole recurrence (block id -> XCD id%8 is observed behaviour and only
+// affects speed).
+__device__ __forceinline__ bool tile_of_block(int lb, int nblk_c, int& cb, int& rb) {
+  const int nblk_c8 = (nblk_c + 7) & ~7;
+  cb = lb % nblk_c8;
+  rb = lb / nblk_c8;
+  return cb < nblk_c;
+}
+
+// One K segment of a tile product: per-lane row pointers (nullptr = out of range -> zeros).
+template <int RT>
+struct Seg {
+  const float* a[RT];   // A rows of this lane (row = l&15 of each 16-row tile), k-contiguous
+  const float* w;       // W row of this lane (col = l&15), k-contiguous
+  int ld;               // zero-padded row length (multiple of 4)
+  int nkb;              // ceil(ld/16) k-blocks
+};
+
+// acc[i] (16x16, i < RT row tiles) += A_i[.,k] * W[.,k] over the k-blocks [jb,je) of the
+// concatenation of segments s0|s1.  All operand loads of a CH-k-block chunk are issued before the
+// first MFMA of the chunk, so a wave pays ~one L2 round trip per chunk instead of one per k-block.
+template <int RT, int CH>
+__device__ __forceinline__ void mma_2seg(f32x4 (&acc)[RT], const Seg<RT>& s0, const Seg<RT>& s1, int jb, int je, int q) {
+  for (int j0 = jb; j0 < je; j0 += CH) {
+    float4 av[CH][RT], bv[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int j = j0 + c;
+      const bool first = j < s0.nkb;
+      const int k = (first ? j : j - s0.nkb) * 16 + 4 * q;
+      const int ld = first ? s0.ld : s1.ld;
+      const bool ok = (j < je) && (k < ld);
+      const float* w = first ? s0.w : s1.w;
+      bv[c] = (ok && w) ? *reinterpret_cast<const float4*>(w + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const float* a = first ? s0.a[i] : s1.a[i];
+        av[c][i] = (ok && a) ? *reinterpret_cast<const float4*>(a + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].x, bv[c].x, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].y, bv[c].y, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].z, bv[c].z, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].w, bv[c].w, acc[i], 0, 0, 0);
+      }
+    }
   }
 }
 
-__device__ __forceinline__ int round16(int x) { return (x + 15) & ~15; }
+constexpr int RT = 2;          // 16-row tiles per wave: one W fragment feeds 2 x 4 MFMAs
 
 // ---------------------------------------------------------------------------------------
-// forward phase 1: 4 waves = 4 gates of a 16-row x 16-cell tile
+// forward phase 1: WG = 32 rows x 16 cells; waves = 4 gates x KS slices of K = [x_t | m_{t-1}]
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fwd_gates(const FwdGateJobs jobs) {
-  __shared__ float zs[4][16][17];
+template <int KS>
+__global__ __launch_bounds__(256 * KS) void k_fwd_gates(const FwdGateJobs jobs) {
+  __shared__ float zs[4 * KS][RT][16][17];
   const int bid = blockIdx.x;
   const int ji = find_job(jobs.j, jobs.n, bid);
   const FwdGateJob& J = jobs.j[ji];
-  const int lb = bid - J.blk_base;
-  const int cb = lb % J.nblk_c, rb = lb / J.nblk_c;
-  const int r0 = rb * 16, c0 = cb * 16;
+  int cb, rb;
+  if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
+  const int r0 = rb * 16 * RT, c0 = cb * 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, q = lane >> 4;
+  const int gate = w & 3, ks = w >> 2;
   const int H = J.H, N = J.N, H4 = 4 * H;
   const int col = c0 + lr;
-  const bool colok = col < H;
-  const int gcol = w * H + col;
+  const int gcol = gate * H + col;
 
-  f32x4 acc;
+  Seg<RT> sx, sm;
+  sx.ld = J.ldx; sx.nkb = J.x ? ((J.ldx + 15) >> 4) : 0;
+  sm.ld = J.ldm; sm.nkb = (J.ldm + 15) >> 4;
+  sx.w = (J.x && col < H) ? J.KxT + (size_t)gcol * J.ldx : nullptr;
+  sm.w = (col < H) ? J.KhT + (size_t)gcol * J.ldm : nullptr;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = r0 + q * 4 + i;
-    float v = 0.f;
-    if (colok && row < N) v = J.zx ? J.zx[(size_t)row * H4 + gcol] : J.bias[gcol];
-    acc[i] = v;
+  for (int i = 0; i < RT; ++i) {
+    const int arow = r0 + i * 16 + lr;
+    sx.a[i] = (J.x && arow < N) ? J.x + (size_t)arow * J.ldx : nullptr;
+    sm.a[i] = (arow < N) ? J.m + (size_t)arow * J.ldm : nullptr;
   }
-  const int arow = r0 + lr;
-  const bool aok = arow < N;
-  if (J.x)
-    mfma_seg(acc, J.x + (size_t)arow * J.ldx, aok, J.KxT + (size_t)gcol * J.ldx, colok, J.ldx, 0, round16(J.ldx), q);
-  mfma_seg(acc, J.m + (size_t)arow * J.ldm, aok, J.KhT + (size_t)gcol * J.ldm, colok, J.ldm, 0, round16(J.ldm), q);
+  const int total = sx.nkb + sm.nkb, per = (total + KS - 1) / KS;
+  f32x4 acc[RT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) zs[w][q * 4 + i][lr] = acc[i];
+  for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  mma_2seg<RT, 9>(acc, sx, sm, ks * per, min(total, (ks + 1) * per), q);
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zs[w][i][q * 4 + r][lr] = acc[i][r];
   __syncthreads();
 
-  const int er = tid >> 4, ec = tid & 15;
-  const int row = r0 + er, cell = c0 + ec;
-  if (row < N && cell < H) {
-    const float zi = zs[0][er][ec], zj = zs[1][er][ec], zf = zs[2][er][ec], zo = zs[3][er][ec];
+  for (int e = tid; e < RT * 256; e += 256 * KS) {
+    const int i = e >> 8, er = (e >> 4) & 15, ec = e & 15;
+    const int row = r0 + i * 16 + er, cell = c0 + ec;
+    if (row >= N || cell >= H) continue;
+    float z[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float v = J.zx ? J.zx[(size_t)row * H4 + g * H + cell] : J.bias[g * H + cell];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) v += zs[s * 4 + g][i][er][ec];
+      z[g] = v;
+    }
     const size_t ci = (size_t)row * H + cell;
     const float cp = J.c_prev[ci];
     float* g = J.gates + (size_t)row * H4 + cell;
     if (J.t < J.len[row]) {
-      const float gi = sigmoid_(zi + J.wi[cell] * cp);
-      const float gf = sigmoid_(zf + jobs.forget_bias + J.wf[cell] * cp);
-      const float gj = tanhf(zj);
+      const float gi = sigmoid_(z[0] + J.wi[cell] * cp);
+      const float gf = sigmoid_(z[2] + jobs.forget_bias + J.wf[cell] * cp);
+      const float gj = tanhf(z[1]);
       const float cn = gf * cp + gi * gj;
-      const float go = sigmoid_(zo + J.wo[cell] * cn);
+      const float go = sigmoid_(z[3] + J.wo[cell] * cn);
       J.c_out[ci] = cn;
       g[0] = gi; g[H] = gj; g[2 * H] = gf; g[3 * H] = go;
       J.h[(size_t)row * J.ldh + cell] = go * tanhf(cn);
@@ -112,34 +164,47 @@ __global__ __launch_bounds__(256) void k_fwd_gates(const FwdGateJobs jobs) {
 }
 
 // ---------------------------------------------------------------------------------------
-// forward phase 2: 16x16 tile of m_t = h_t.Wp, K (=H) split over the 4 waves
+// forward phase 2: 32x16 tile of m_t = h_t.Wp, K (=H) split over NW waves
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fwd_proj(const FwdProjJobs jobs) {
-  __shared__ float zs[4][16][17];
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_fwd_proj(const FwdProjJobs jobs) {
+  __shared__ float zs[NW][RT][16][17];
   const int bid = blockIdx.x;
   const int ji = find_job(jobs.j, jobs.n, bid);
   const FwdProjJob& J = jobs.j[ji];
-  const int lb = bid - J.blk_base;
-  const int cb = lb % J.nblk_c, rb = lb / J.nblk_c;
-  const int r0 = rb * 16, c0 = cb * 16;
+  int cb, rb;
+  if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
+  const int r0 = rb * 16 * RT, c0 = cb * 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, q = lane >> 4;
   const int N = J.N, P = J.P;
   const int p = c0 + lr;
-  const bool pok = p < P;
-  const int arow = r0 + lr;
-  const bool aok = arow < N;
-  const int kblocks = (J.ldh + 15) >> 4, per = (kblocks + 3) >> 2;
-  const int kbeg = w * per * 16;
-  const int kend = min((w + 1) * per, kblocks) * 16;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  mfma_seg(acc, J.h + (size_t)arow * J.ldh, aok, J.WpT + (size_t)p * J.ldh, pok, J.ldh, kbeg, kend, q);
+  Seg<RT> s0, s1;
+  s0.ld = J.ldh; s0.nkb = (J.ldh + 15) >> 4;
+  s0.w = p < P ? J.WpT + (size_t)p * J.ldh : nullptr;
+  s1.ld = 0; s1.nkb = 0; s1.w = nullptr;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) zs[w][q * 4 + i][lr] = acc[i];
+  for (int i = 0; i < RT; ++i) {
+    const int arow = r0 + i * 16 + lr;
+    s0.a[i] = arow < N ? J.h + (size_t)arow * J.ldh : nullptr;
+    s1.a[i] = nullptr;
+  }
+  const int per = (s0.nkb + NW - 1) / NW;
+  f32x4 acc[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  mma_2seg<RT, 6>(acc, s0, s1, w * per, min(s0.nkb, (w + 1) * per), q);
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zs[w][i][q * 4 + r][lr] = acc[i][r];
   __syncthreads();
-  const int er = tid >> 4, ec = tid & 15;
-  const int row = r0 + er, pp = c0 + ec;
-  if (row < N && pp < P) {
-    const float v = ((zs[0][er][ec] + zs[1][er][ec]) + zs[2][er][ec]) + zs[3][er][ec];
+  for (int e = tid; e < RT * 256; e += 64 * NW) {
+    const int i = e >> 8, er = (e >> 4) & 15, ec = e & 15;
+    const int row = r0 + i * 16 + er, pp = c0 + ec;
+    if (row >= N || pp >= P) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int s = 0; s < NW; ++s) v += zs[s][i][er][ec];
     const size_t mi = (size_t)row * J.ldm + pp;
     const bool live = J.t < J.len[row];
     J.m_out[mi] = live ? v : J.m_prev[mi];
@@ -150,57 +215,81 @@ __global__ __launch_bounds__(256) void k_fwd_proj(const FwdProjJobs jobs) {
 }
 
 // ---------------------------------------------------------------------------------------
-// backward phase A: dh = (mask*(dout+dm_state)).Wp^T, then the cell's gate gradients
+// backward phase A: dh = (mask*(dout+dm_state)).Wp^T over K = P split on NW waves, then the
+// cell's gate gradients
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bwd_a(const BwdAJobs jobs) {
-  __shared__ float zs[4][16][17];
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
+  __shared__ float zs[NW][RT][16][17];
   const int bid = blockIdx.x;
   const int ji = find_job(jobs.j, jobs.n, bid);
   const BwdAJob& J = jobs.j[ji];
-  const int lb = bid - J.blk_base;
-  const int cb = lb % J.nblk_c, rb = lb / J.nblk_c;
-  const int r0 = rb * 16, c0 = cb * 16;
+  int cb, rb;
+  if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
+  const int r0 = rb * 16 * RT, c0 = cb * 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, q = lane >> 4;
   const int N = J.N, H = J.H, H4 = 4 * H, ldm = J.ldm;
   const int wcell = c0 + lr;
-  const bool wok = wcell < H;
-  const int arow = r0 + lr;
-  const bool aok = arow < N;
-  const bool alive = aok && (J.t < J.len[aok ? arow : 0]);
-  const int kblocks = (ldm + 15) >> 4, per = (kblocks + 3) >> 2;
-  const int kbeg = w * per * 16;
-  const int kend = min((w + 1) * per, kblocks) * 16;
-  const float* wrow = J.Wp + (size_t)wcell * ldm;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-  for (int kb = kbeg; kb < kend; kb += 16) {
-    const int k = kb + 4 * q;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (aok && k < ldm) {
-      if (alive) {
-        a = *reinterpret_cast<const float4*>(J.dmst + (size_t)arow * ldm + k);
-        if (J.dout) {
-          const float4 d = *reinterpret_cast<const float4*>(J.dout + (size_t)arow * ldm + k);
-          a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+  const float* wrow = wcell < H ? J.Wp + (size_t)wcell * ldm : nullptr;
+  int arow[RT];
+  bool aok[RT], alive[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) {
+    arow[i] = r0 + i * 16 + lr;
+    aok[i] = arow[i] < N;
+    alive[i] = aok[i] && (J.t < J.len[aok[i] ? arow[i] : 0]);
+  }
+  const int nkb = (ldm + 15) >> 4, per = (nkb + NW - 1) / NW;
+  const int jb = w * per, je = min(nkb, (w + 1) * per);
+  constexpr int CH = 5;
+  f32x4 acc[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int j0 = jb; j0 < je; j0 += CH) {
+    float4 av[CH][RT], bv[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int k = (j0 + c) * 16 + 4 * q;
+      const bool ok = (j0 + c < je) && (k < ldm);
+      bv[c] = (ok && wrow) ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && alive[i]) {
+          a = *reinterpret_cast<const float4*>(J.dmst + (size_t)arow[i] * ldm + k);
+          if (J.dout) {
+            const float4 d = *reinterpret_cast<const float4*>(J.dout + (size_t)arow[i] * ldm + k);
+            a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+          }
         }
+        if (ok && aok[i] && cb == 0) *reinterpret_cast<float4*>(J.dmt + (size_t)arow[i] * ldm + k) = a;
+        av[c][i] = a;
       }
-      if (cb == 0) *reinterpret_cast<float4*>(J.dmt + (size_t)arow * ldm + k) = a;
     }
-    if (wok && k < ldm) b = *reinterpret_cast<const float4*>(wrow + k);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].x, bv[c].x, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].y, bv[c].y, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].z, bv[c].z, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].w, bv[c].w, acc[i], 0, 0, 0);
+      }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) zs[w][q * 4 + i][lr] = acc[i];
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zs[w][i][q * 4 + r][lr] = acc[i][r];
   __syncthreads();
-  const int er = tid >> 4, ec = tid & 15;
-  const int row = r0 + er, cell = c0 + ec;
-  if (row < N && cell < H) {
+  for (int e = tid; e < RT * 256; e += 64 * NW) {
+    const int i = e >> 8, er = (e >> 4) & 15, ec = e & 15;
+    const int row = r0 + i * 16 + er, cell = c0 + ec;
+    if (row >= N || cell >= H) continue;
     float* g = J.gates + (size_t)row * H4 + cell;
     if (J.t < J.len[row]) {
-      const float dh = ((zs[0][er][ec] + zs[1][er][ec]) + zs[2][er][ec]) + zs[3][er][ec];
+      float dh = 0.f;
+#pragma unroll
+      for (int s = 0; s < NW; ++s) dh += zs[s][i][er][ec];
       const size_t ci = (size_t)row * H + cell;
       const float gi = g[0], gj = g[H], gf = g[2 * H], go = g[3 * H];
       const float cp = J.c_prev[ci], cn = J.c_cur[ci];
@@ -219,61 +308,83 @@ __global__ __launch_bounds__(256) void k_bwd_a(const BwdAJobs jobs) {
 }
 
 // ---------------------------------------------------------------------------------------
-// backward phase B: 16x16 tile of dz_t.K^T, K (=4H) split over NW waves
+// backward phase B: 32x16 tile of dz_t.K^T, K (=4H) split over NW waves
 // ---------------------------------------------------------------------------------------
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_bwd_b(const BwdBJobs jobs) {
-  __shared__ float zs[NW][16][17];
+  __shared__ float zs[NW][RT][16][17];
   const int bid = blockIdx.x;
   const int ji = find_job(jobs.j, jobs.n, bid);
   const BwdBJob& J = jobs.j[ji];
-  const int lb = bid - J.blk_base;
-  const int cb = lb % J.nblk_c, rb = lb / J.nblk_c;
-  const int r0 = rb * 16, n0 = J.n_begin + cb * 16;
+  int cb, rb;
+  if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
+  const int r0 = rb * 16 * RT, n0 = J.n_begin + cb * 16;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, q = lane >> 4;
   const int N = J.N, H4 = J.H4;
   const int n = n0 + lr;
-  const bool nok = n < J.n_end;
-  const int arow = r0 + lr;
-  const bool aok = arow < N;
-  const int kblocks = (H4 + 15) >> 4, per = (kblocks + NW - 1) / NW;
-  const int kbeg = w * per * 16;
-  const int kend = min((w + 1) * per, kblocks) * 16;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  mfma_seg(acc, J.dz + (size_t)arow * H4, aok, J.K + (size_t)n * H4, nok, H4, kbeg, kend, q);
+  Seg<RT> s0, s1;
+  s0.ld = H4; s0.nkb = (H4 + 15) >> 4;
+  s0.w = n < J.n_end ? J.K + (size_t)n * H4 : nullptr;
+  s1.ld = 0; s1.nkb = 0; s1.w = nullptr;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) zs[w][q * 4 + i][lr] = acc[i];
+  for (int i = 0; i < RT; ++i) {
+    const int arow = r0 + i * 16 + lr;
+    s0.a[i] = arow < N ? J.dz + (size_t)arow * H4 : nullptr;
+    s1.a[i] = nullptr;
+  }
+  const int per = (s0.nkb + NW - 1) / NW;
+  f32x4 acc[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  mma_2seg<RT, 6>(acc, s0, s1, w * per, min(s0.nkb, (w + 1) * per), q);
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zs[w][i][q * 4 + r][lr] = acc[i][r];
   __syncthreads();
-  if (tid < 256) {
-    const int er = tid >> 4, ec = tid & 15;
-    const int row = r0 + er, nn = n0 + ec;
-    if (row < N && nn < J.n_end) {
-      float v = 0.f;
+  for (int e = tid; e < RT * 256; e += 64 * NW) {
+    const int i = e >> 8, er = (e >> 4) & 15, ec = e & 15;
+    const int row = r0 + i * 16 + er, nn = n0 + ec;
+    if (row >= N || nn >= J.n_end) continue;
+    float v = 0.f;
 #pragma unroll
-      for (int s = 0; s < NW; ++s) v += zs[s][er][ec];
-      if (nn < J.I) {
-        float* d = J.dx + (size_t)row * J.lddx + nn;
-        *d = J.dx_accumulate ? (*d + v) : v;
-      } else {
-        float* d = J.dmst + (size_t)row * J.ldm + (nn - J.I);
-        const bool live = J.t < J.len[row];
-        *d = (live ? 0.f : *d) + v;
-      }
+    for (int s = 0; s < NW; ++s) v += zs[s][i][er][ec];
+    if (nn < J.I) {
+      float* d = J.dx + (size_t)row * J.lddx + nn;
+      *d = J.dx_accumulate ? (*d + v) : v;
+    } else {
+      float* d = J.dmst + (size_t)row * J.ldm + (nn - J.I);
+      const bool live = J.t < J.len[row];
+      *d = (live ? 0.f : *d) + v;
     }
   }
 }
 
-void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, hipStream_t s) {
-  hipLaunchKernelGGL(k_fwd_gates, dim3(total_blocks), dim3(256), 0, s, jobs);
+// total blocks of a job list and blk_base assignment happen on the host (model.cpp); `kb_max` is
+// the largest k-block count over the jobs, which picks the K split.
+void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
+  if (kb_max <= 9)
+    hipLaunchKernelGGL(k_fwd_gates<1>, dim3(total_blocks), dim3(256), 0, s, jobs);
+  else if (kb_max <= 18)
+    hipLaunchKernelGGL(k_fwd_gates<2>, dim3(total_blocks), dim3(512), 0, s, jobs);
+  else
+    hipLaunchKernelGGL(k_fwd_gates<4>, dim3(total_blocks), dim3(1024), 0, s, jobs);
 }
-void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, hipStream_t s) {
-  hipLaunchKernelGGL(k_fwd_proj, dim3(total_blocks), dim3(256), 0, s, jobs);
+void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
+  if (kb_max <= 24)
+    hipLaunchKernelGGL(k_fwd_proj<4>, dim3(total_blocks), dim3(256), 0, s, jobs);
+  else
+    hipLaunchKernelGGL(k_fwd_proj<8>, dim3(total_blocks), dim3(512), 0, s, jobs);
 }
-void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, hipStream_t s) {
-  hipLaunchKernelGGL(k_bwd_a, dim3(total_blocks), dim3(256), 0, s, jobs);
+void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
+  (void)kb_max;
+  hipLaunchKernelGGL(k_bwd_a<4>, dim3(total_blocks), dim3(256), 0, s, jobs);
 }
-void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, hipStream_t s) {
-  hipLaunchKernelGGL(k_bwd_b<8>, dim3(total_blocks), dim3(512), 0, s, jobs);
+void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
+  if (kb_max <= 96)
+    hipLaunchKernelGGL(k_bwd_b<8>, dim3(total_blocks), dim3(512), 0, s, jobs);
+  else
+    hipLaunchKernelGGL(k_bwd_b<16>, dim3(total_blocks), dim3(1024), 0, s, jobs);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -326,6 +437,22 @@ void launch_build_d_input(const float* lab, const float* y, const float* nr, con
   const size_t total = (size_t)T * (with_real ? 2 * B : B) * D;
   const int blocks = (int)min((size_t)2048, (total + 255) / 256);
   hipLaunchKernelGGL(k_build_d_input, dim3(blocks), dim3(256), 0, s, lab, y, nr, nf, xd, B, T, D, ld, with_real ? 1 : 0);
+}
+
+__global__ void k_add_noise_rows(const float* __restrict__ src, const float* __restrict__ noise, float* __restrict__ dst,
+                                 int B, int T, int D, int ld, int Ns, int row0) {
+  const size_t total = (size_t)T * B * D;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D);
+    const size_t r = i / D;
+    const int b = (int)(r % B), t = (int)(r / B);
+    dst[((size_t)t * Ns + row0 + b) * ld + d] = src[r * ld + d] + (noise ? noise[b * D + d] : 0.f);
+  }
+}
+void launch_add_noise_rows(const float* src, const float* noise, float* dst, int B, int T, int D, int ld, int Ns, int row0, hipStream_t s) {
+  const size_t total = (size_t)T * B * D;
+  const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+  hipLaunchKernelGGL(k_add_noise_rows, dim3(blocks), dim3(256), 0, s, src, noise, dst, B, T, D, ld, Ns, row0);
 }
 
 __global__ void k_transpose(const float* __restrict__ src, int lds_, float* __restrict__ dst, int ldd, int R, int C) {

@@ -203,6 +203,9 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   size_t maxcols = 4 * (size_t)std::max(c.g_cells, c.d_cells);
   maxcols = std::max(maxcols, (size_t)std::max(ldP, ldDin));
   scratch = alloc<float>(std::max<size_t>(64 * maxcols, 1024));
+  gemm_ws_floats = (size_t)16 << 20;          // 64 MiB of split-K partial tiles
+  gemm_ws = alloc<float>(gemm_ws_floats);
+  if (!gemm_ws) gemm_ws_floats = 0;
   if (!scratch || !d_dB || !g_dB || !xd) { set_error("hipMalloc failed (activations)"); return RSRGAN_ERR_HIP; }
 
   // ---- initial values: xavier_initializer() uniform / zeros (models/lstm.py:86-87,93) ----
@@ -253,85 +256,193 @@ void Model::refresh_transposes(int net, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
-// one dynamic_rnn(LSTMCell) over [T][N][I]  (schedule v1: layer by layer, 2 launches per step)
+// stacks of dynamic_rnn(LSTMCell) layers.  Two schedules over the same kernels:
+//   layer-sequential: per layer one time-batched GEMM for the x-part, then 2 launches per step;
+//   wavefront (RSRGAN_FLAG_WAVEFRONT): launch d carries every (layer l, t = d - l) job of every
+//   co-scheduled chain, so a 3-layer stack over T steps costs 2*(T+2) launches instead of 6*T.
 // ------------------------------------------------------------------------------------------
-void Model::lstm_forward(const ParamSet& ps, const LstmLayer& L, LstmStash& S, const float* in, int N, int T,
-                         const float* res_in, float* res_out, hipStream_t s) {
-  const int H = L.H, H4 = 4 * H;
-  // x-part of every step in one time-batched GEMM: zx = in . K[0:I] + bias
-  launch_gemm(in, L.ldI, true, ps.W(L.tK), H4, false, S.gates, H4, T * N, H4, L.I, ps.W(L.tb), 0, 0.f, false, s);
-  const int nbr = (N + 15) / 16;
-  for (int t = 0; t < T; ++t) {
-    FwdGateJobs gj{};
-    gj.n = 1; gj.forget_bias = cfg.forget_bias;
-    FwdGateJob& a = gj.j[0];
-    a.x = nullptr; a.KxT = L.KxT; a.ldx = L.ldI;
-    a.m = S.mst + (size_t)t * N * L.ldP; a.KhT = L.KhT; a.ldm = L.ldP;
-    a.zx = S.gates + (size_t)t * N * H4; a.bias = ps.W(L.tb);
-    a.wf = ps.W(L.twf); a.wi = ps.W(L.twi); a.wo = ps.W(L.two);
-    a.c_prev = S.c + (size_t)t * N * H; a.c_out = S.c + (size_t)(t + 1) * N * H;
-    a.gates = S.gates + (size_t)t * N * H4;
-    a.h = S.h + (size_t)t * N * L.ldH; a.ldh = L.ldH;
-    a.len = len_dev; a.t = t; a.N = N; a.H = H;
-    a.nblk_c = (H + 15) / 16; a.blk_base = 0;
-    launch_fwd_gates(gj, a.nblk_c * nbr, s);
+static inline int kb16(int ld) { return (ld + 15) >> 4; }
 
+void Model::gemm(const float* A, int lda, bool a_kc, const float* B_, int ldb, bool b_kc, float* C, int ldc, int M, int N,
+                 int K, const float* bias, int act, float alpha, bool accumulate, hipStream_t s) {
+  launch_gemm(A, lda, a_kc, B_, ldb, b_kc, C, ldc, M, N, K, bias, act, alpha, accumulate, s, gemm_ws, gemm_ws_floats);
+}
+
+static void fill_gate(FwdGateJob& a, const LayerRun& R, int t, bool zx) {
+  const LstmLayer& L = *R.L; const LstmStash& S = *R.S; const ParamSet& ps = *R.ps;
+  const int H = L.H, H4 = 4 * H;
+  const size_t r = (size_t)t * R.Ns + R.row0, rn = (size_t)(t + 1) * R.Ns + R.row0;
+  a.x = zx ? nullptr : R.in + r * L.ldI;
+  a.KxT = L.KxT; a.ldx = L.ldI;
+  a.m = S.mst + r * L.ldP; a.KhT = L.KhT; a.ldm = L.ldP;
+  a.zx = zx ? S.gates + r * H4 : nullptr; a.bias = ps.W(L.tb);
+  a.wf = ps.W(L.twf); a.wi = ps.W(L.twi); a.wo = ps.W(L.two);
+  a.c_prev = S.c + r * H; a.c_out = S.c + rn * H;
+  a.gates = S.gates + r * H4;
+  a.h = S.h + r * L.ldH; a.ldh = L.ldH;
+  a.len = R.len; a.t = t; a.N = R.N; a.H = H;
+  a.nblk_c = (H + 15) / 16;
+}
+static void fill_proj(FwdProjJob& p, const LayerRun& R, int t) {
+  const LstmLayer& L = *R.L; const LstmStash& S = *R.S;
+  const size_t r = (size_t)t * R.Ns + R.row0, rn = (size_t)(t + 1) * R.Ns + R.row0;
+  p.h = S.h + r * L.ldH; p.WpT = L.WpT; p.ldh = L.ldH;
+  p.m_prev = S.mst + r * L.ldP; p.m_out = S.mst + rn * L.ldP; p.out = S.out + r * L.ldP;
+  p.res_in = R.res_in ? R.res_in + r * L.ldP : nullptr;
+  p.res_out = R.res_out ? R.res_out + r * L.ldP : nullptr;
+  p.len = R.len; p.ldm = L.ldP; p.P = L.P; p.t = t; p.N = R.N;
+  p.nblk_c = (L.P + 15) / 16;
+}
+static void fill_bwd_a(BwdAJob& a, const LayerRun& R, int t) {
+  const LstmLayer& L = *R.L; const LstmStash& S = *R.S; const ParamSet& ps = *R.ps;
+  const int H = L.H, H4 = 4 * H;
+  const size_t r = (size_t)t * R.Ns + R.row0, rn = (size_t)(t + 1) * R.Ns + R.row0;
+  a.dout = R.dout ? R.dout + r * L.ldP : nullptr;
+  a.dmst = S.dmst + (size_t)R.row0 * L.ldP; a.Wp = ps.W(L.tWp);
+  a.dmt = S.dmt + r * L.ldP;
+  a.gates = S.gates + r * H4;
+  a.c_prev = S.c + r * H; a.c_cur = S.c + rn * H;
+  a.wf = ps.W(L.twf); a.wi = ps.W(L.twi); a.wo = ps.W(L.two);
+  a.dc = S.dc + (size_t)R.row0 * H; a.len = R.len; a.ldm = L.ldP; a.P = L.P; a.t = t; a.N = R.N; a.H = H;
+  a.nblk_c = (H + 15) / 16;
+}
+static void fill_bwd_b(BwdBJob& b, const LayerRun& R, int t, bool with_dx) {
+  const LstmLayer& L = *R.L; const LstmStash& S = *R.S; const ParamSet& ps = *R.ps;
+  const int H4 = 4 * L.H;
+  const size_t r = (size_t)t * R.Ns + R.row0;
+  b.dz = S.gates + r * H4; b.K = ps.W(L.tK);
+  b.dx = with_dx ? R.din + r * L.ldI : nullptr;
+  b.dmst = S.dmst + (size_t)R.row0 * L.ldP; b.len = R.len;
+  b.I = L.I; b.n_begin = with_dx ? 0 : L.I; b.n_end = L.I + L.P; b.lddx = L.ldI; b.ldm = L.ldP; b.t = t; b.N = R.N; b.H4 = H4;
+  b.dx_accumulate = R.din_accumulate ? 1 : 0;
+  b.nblk_c = (b.n_end - b.n_begin + 15) / 16;
+}
+
+void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s) {
+  // zero initial state (cell.zero_state, models/lstm.py:107): slot 0 of c / m for the rows of each run
+  for (auto& ch : chains)
+    for (auto& R : ch) {
+      (void)hipMemsetAsync(R.S->c + (size_t)R.row0 * R.L->H, 0, (size_t)R.N * R.L->H * sizeof(float), s);
+      (void)hipMemsetAsync(R.S->mst + (size_t)R.row0 * R.L->ldP, 0, (size_t)R.N * R.L->ldP * sizeof(float), s);
+    }
+  auto zx_gemm = [&](const LayerRun& R) {     // x-part of every step: zx = in . K[0:I] + bias, batched over T*N frames
+    const int H4 = 4 * R.L->H;
+    gemm(R.in, R.L->ldI, true, R.ps->W(R.L->tK), H4, false, R.S->gates, H4, T * R.N, H4, R.L->I, R.ps->W(R.L->tb), 0, 0.f, false, s);
+  };
+  if (!wavefront()) {
+    for (auto& ch : chains)
+      for (auto& R : ch) {
+        const bool zx = R.Ns == R.N && R.row0 == 0;          // rows contiguous over time -> batch the x-part
+        if (zx) zx_gemm(R);
+        for (int t = 0; t < T; ++t) {
+          FwdGateJobs gj{}; gj.n = 1; gj.forget_bias = cfg.forget_bias;
+          fill_gate(gj.j[0], R, t, zx); gj.j[0].blk_base = 0;
+          launch_fwd_gates(gj, job_blocks(gj.j[0].nblk_c, R.N), (zx ? 0 : kb16(R.L->ldI)) + kb16(R.L->ldP), s);
+          FwdProjJobs pj{}; pj.n = 1;
+          fill_proj(pj.j[0], R, t); pj.j[0].blk_base = 0;
+          launch_fwd_proj(pj, job_blocks(pj.j[0].nblk_c, R.N), kb16(R.L->ldH), s);
+        }
+      }
+    return;
+  }
+  size_t maxL = 0;
+  for (auto& ch : chains) {
+    maxL = std::max(maxL, ch.size());
+    for (auto& R : ch)
+      if (R.zx_batched) zx_gemm(R);
+  }
+  for (int d = 0; d < T + (int)maxL - 1; ++d) {
+    FwdGateJobs gj{}; gj.forget_bias = cfg.forget_bias;
     FwdProjJobs pj{};
-    pj.n = 1;
-    FwdProjJob& p = pj.j[0];
-    p.h = a.h; p.WpT = L.WpT; p.ldh = L.ldH;
-    p.m_prev = a.m; p.m_out = S.mst + (size_t)(t + 1) * N * L.ldP; p.out = S.out + (size_t)t * N * L.ldP;
-    p.res_in = res_in ? res_in + (size_t)t * N * L.ldP : nullptr;
-    p.res_out = res_out ? res_out + (size_t)t * N * L.ldP : nullptr;
-    p.len = len_dev; p.ldm = L.ldP; p.P = L.P; p.t = t; p.N = N;
-    p.nblk_c = (L.P + 15) / 16; p.blk_base = 0;
-    launch_fwd_proj(pj, p.nblk_c * nbr, s);
+    int gb = 0, pb = 0, gk = 0, pk = 0;
+    auto flush = [&]() {
+      if (gj.n) { launch_fwd_gates(gj, gb, gk, s); launch_fwd_proj(pj, pb, pk, s); }
+      gj.n = pj.n = 0; gb = pb = gk = pk = 0;
+    };
+    for (auto& ch : chains)
+      for (size_t l = 0; l < ch.size(); ++l) {
+        const int t = d - (int)l;
+        if (t < 0 || t >= T) continue;
+        const LayerRun& R = ch[l];
+        if (gj.n == MAXJ) flush();      // (cannot overflow a dependency: jobs of one diagonal are independent)
+        FwdGateJob& a = gj.j[gj.n++]; fill_gate(a, R, t, R.zx_batched); a.blk_base = gb; gb += job_blocks(a.nblk_c, R.N);
+        gk = std::max(gk, (R.zx_batched ? 0 : kb16(R.L->ldI)) + kb16(R.L->ldP));
+        FwdProjJob& p = pj.j[pj.n++]; fill_proj(p, R, t); p.blk_base = pb; pb += job_blocks(p.nblk_c, R.N);
+        pk = std::max(pk, kb16(R.L->ldH));
+      }
+    // NOTE: with > MAXJ jobs per diagonal the gates of all jobs must precede the projections of
+    // none they depend on -- true, since a diagonal's jobs only depend on the previous diagonal.
+    flush();
   }
 }
 
-void Model::lstm_backward(const ParamSet& ps, const LstmLayer& L, LstmStash& S, const float* in, int N, int T,
-                          const float* dout, float* din, bool din_accumulate, bool want_wgrads, hipStream_t s) {
-  const int H = L.H, H4 = 4 * H;
-  const int nbr = (N + 15) / 16;
-  (void)hipMemsetAsync(S.dc, 0, (size_t)N * H * sizeof(float), s);
-  (void)hipMemsetAsync(S.dmst, 0, (size_t)N * L.ldP * sizeof(float), s);
-  for (int t = T - 1; t >= 0; --t) {
-    BwdAJobs aj{};
-    aj.n = 1;
-    BwdAJob& a = aj.j[0];
-    a.dout = dout + (size_t)t * N * L.ldP; a.dmst = S.dmst; a.Wp = ps.W(L.tWp);
-    a.dmt = S.dmt + (size_t)t * N * L.ldP;
-    a.gates = S.gates + (size_t)t * N * H4;
-    a.c_prev = S.c + (size_t)t * N * H; a.c_cur = S.c + (size_t)(t + 1) * N * H;
-    a.wf = ps.W(L.twf); a.wi = ps.W(L.twi); a.wo = ps.W(L.two);
-    a.dc = S.dc; a.len = len_dev; a.ldm = L.ldP; a.P = L.P; a.t = t; a.N = N; a.H = H;
-    a.nblk_c = (H + 15) / 16; a.blk_base = 0;
-    launch_bwd_a(aj, a.nblk_c * nbr, s);
+void Model::layer_wgrads(const LayerRun& R, int T, hipStream_t s) {
+  const LstmLayer& L = *R.L; const LstmStash& S = *R.S; const ParamSet& ps = *R.ps;
+  const int H = L.H, H4 = 4 * H, Rws = T * R.N;      // needs Ns == N (rows contiguous over time)
+  float* dK = ps.Gd(L.tK);
+  // dK[0:I] = in^T . dZ ; dK[I:I+P] = m_{t-1}^T . dZ ; dWp = h^T . dm
+  gemm(R.in, L.ldI, false, S.gates, H4, false, dK, H4, L.I, H4, Rws, nullptr, 0, 0.f, false, s);
+  gemm(S.mst, L.ldP, false, S.gates, H4, false, dK + (size_t)L.I * H4, H4, L.P, H4, Rws, nullptr, 0, 0.f, false, s);
+  gemm(S.h, L.ldH, false, S.dmt, L.ldP, false, ps.Gd(L.tWp), L.ldP, H, L.P, Rws, nullptr, 0, 0.f, false, s);
+  launch_colsum(S.gates, H4, nullptr, 0, ps.Gd(L.tb), Rws, H4, scratch, s);
+  // peepholes: dw_i = sum dai*c_{t-1}; dw_f = sum daf*c_{t-1}; dw_o = sum dao*c_t
+  launch_colsum(S.gates, H4, S.c, H, ps.Gd(L.twi), Rws, H, scratch, s);
+  launch_colsum(S.gates + 2 * H, H4, S.c, H, ps.Gd(L.twf), Rws, H, scratch, s);
+  launch_colsum(S.gates + 3 * H, H4, S.c + (size_t)R.N * H, H, ps.Gd(L.two), Rws, H, scratch, s);
+}
 
-    BwdBJobs bj{};
-    bj.n = 1;
-    BwdBJob& b = bj.j[0];
-    b.dz = a.gates; b.K = ps.W(L.tK); b.dx = nullptr; b.dmst = S.dmst; b.len = len_dev;
-    b.I = L.I; b.n_begin = L.I; b.n_end = L.I + L.P; b.lddx = L.ldI; b.ldm = L.ldP; b.t = t; b.N = N; b.H4 = H4;
-    b.dx_accumulate = 0;
-    b.nblk_c = (L.P + 15) / 16; b.blk_base = 0;
-    launch_bwd_b(bj, b.nblk_c * nbr, s);
+void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s) {
+  for (auto& ch : chains)
+    for (auto& R : ch) {
+      (void)hipMemsetAsync(R.S->dc + (size_t)R.row0 * R.L->H, 0, (size_t)R.N * R.L->H * sizeof(float), s);
+      (void)hipMemsetAsync(R.S->dmst + (size_t)R.row0 * R.L->ldP, 0, (size_t)R.N * R.L->ldP * sizeof(float), s);
+    }
+  if (!wavefront()) {
+    for (auto& ch : chains)
+      for (int l = (int)ch.size() - 1; l >= 0; --l) {
+        const LayerRun& R = ch[l];
+        for (int t = T - 1; t >= 0; --t) {
+          BwdAJobs aj{}; aj.n = 1; fill_bwd_a(aj.j[0], R, t); aj.j[0].blk_base = 0;
+          launch_bwd_a(aj, job_blocks(aj.j[0].nblk_c, R.N), kb16(R.L->ldP), s);
+          BwdBJobs bj{}; bj.n = 1; fill_bwd_b(bj.j[0], R, t, false); bj.j[0].blk_base = 0;
+          launch_bwd_b(bj, job_blocks(bj.j[0].nblk_c, R.N), kb16(4 * R.L->H), s);
+        }
+        if (R.want_wgrads) layer_wgrads(R, T, s);
+        if (R.din) {   // din (+)= dZ . K[0:I]^T, batched over time
+          const int H4 = 4 * R.L->H;
+          gemm(R.S->gates, H4, true, R.ps->W(R.L->tK), H4, true, R.din, R.L->ldI, T * R.N, R.L->I, H4, nullptr, 0, 0.f,
+               R.din_accumulate, s);
+        }
+      }
+    return;
   }
-  const int R = T * N;
-  if (want_wgrads) {
-    float* dK = ps.Gd(L.tK);
-    // dK[0:I] = in^T . dZ ; dK[I:I+P] = m_{t-1}^T . dZ ; dWp = h^T . dm
-    launch_gemm(in, L.ldI, false, S.gates, H4, false, dK, H4, L.I, H4, R, nullptr, 0, 0.f, false, s);
-    launch_gemm(S.mst, L.ldP, false, S.gates, H4, false, dK + (size_t)L.I * H4, H4, L.P, H4, R, nullptr, 0, 0.f, false, s);
-    launch_gemm(S.h, L.ldH, false, S.dmt, L.ldP, false, ps.Gd(L.tWp), L.ldP, H, L.P, R, nullptr, 0, 0.f, false, s);
-    launch_colsum(S.gates, H4, nullptr, 0, ps.Gd(L.tb), R, H4, scratch, s);
-    // peepholes: dw_i = sum dai*c_{t-1}; dw_f = sum daf*c_{t-1}; dw_o = sum dao*c_t
-    launch_colsum(S.gates, H4, S.c, H, ps.Gd(L.twi), R, H, scratch, s);
-    launch_colsum(S.gates + 2 * H, H4, S.c, H, ps.Gd(L.twf), R, H, scratch, s);
-    launch_colsum(S.gates + 3 * H, H4, S.c + (size_t)N * H, H, ps.Gd(L.two), R, H, scratch, s);
+  size_t maxL = 0;
+  for (auto& ch : chains) maxL = std::max(maxL, ch.size());
+  for (int d = 0; d < T + (int)maxL - 1; ++d) {
+    BwdAJobs aj{}; BwdBJobs bj{};
+    int ab = 0, bb = 0, ak = 0, bk = 0;
+    auto flush = [&]() {
+      if (aj.n) { launch_bwd_a(aj, ab, ak, s); launch_bwd_b(bj, bb, bk, s); }
+      aj.n = bj.n = 0; ab = bb = ak = bk = 0;
+    };
+    for (auto& ch : chains) {
+      const int Lc = (int)ch.size();
+      for (int l = Lc - 1; l >= 0; --l) {
+        const int t = T - 1 - (d - (Lc - 1 - l));
+        if (t < 0 || t >= T) continue;
+        const LayerRun& R = ch[l];
+        if (aj.n == MAXJ) flush();
+        BwdAJob& a = aj.j[aj.n++]; fill_bwd_a(a, R, t); a.blk_base = ab; ab += job_blocks(a.nblk_c, R.N);
+        ak = std::max(ak, kb16(R.L->ldP));
+        BwdBJob& b = bj.j[bj.n++]; fill_bwd_b(b, R, t, R.din != nullptr); b.blk_base = bb; bb += job_blocks(b.nblk_c, R.N);
+        bk = std::max(bk, kb16(4 * R.L->H));
+      }
+    }
+    flush();
   }
-  if (din)   // din (+)= dZ . K[0:I]^T
-    launch_gemm(S.gates, H4, true, ps.W(L.tK), H4, true, din, L.ldI, R, L.I, H4, nullptr, 0, 0.f, din_accumulate, s);
+  for (auto& ch : chains)
+    for (auto& R : ch)
+      if (R.want_wgrads) layer_wgrads(R, T, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -347,31 +458,56 @@ int Model::prepare_batch(const float* x, const float* labels, const int32_t* len
   return RSRGAN_OK;
 }
 
-void Model::g_forward(int T, hipStream_t s) {
-  const int R = T * B;
-  const int P = cfg.g_proj, ldP = pad4(P);
-  if (cfg.g_type == RSRGAN_G_LSTM) {
-    // h = leakyrelu(x.W + b)  (models/lstm.py:82-87)
-    launch_gemm(x_tm, ldDin, true, G.W(g_fc_in_w), ldP, false, g_h0, ldP, R, P, Din, G.W(g_fc_in_b), 1, cfg.lrelu_alpha, false, s);
-    for (size_t l = 0; l < gl.size(); ++l) lstm_forward(G, gl[l], g_st[l], g_ins[l], B, T, nullptr, nullptr, s);
-  } else {
-    const bool res = cfg.g_type == RSRGAN_G_RES_LSTM_L;
-    for (size_t l = 0; l < gl.size(); ++l)      // inputs_{l+1} = outputs_l + inputs_l (models/res_lstm_l.py:111,121,131,190)
-      lstm_forward(G, gl[l], g_st[l], g_ins[l], B, T, res ? g_ins[l] : nullptr, res ? g_res[l] : nullptr, s);
+Chain Model::g_chain(int T) {
+  (void)T;
+  Chain ch;
+  const bool res = cfg.g_type == RSRGAN_G_RES_LSTM_L;
+  for (size_t l = 0; l < gl.size(); ++l) {
+    LayerRun R;
+    R.ps = &G; R.L = &gl[l]; R.S = &g_st[l]; R.in = g_ins[l];
+    R.N = B; R.Ns = B; R.row0 = 0; R.len = len_dev;
+    R.zx_batched = (l == 0);                 // layer 0's input exists for all t before the wave starts
+    if (res) { R.res_in = g_ins[l]; R.res_out = g_res[l]; }   // inputs_{l+1} = outputs_l + inputs_l (res_lstm_l.py:111,121,131,190)
+    ch.push_back(R);
   }
-  // y = outputs.W + b (models/lstm.py:121-124)
-  launch_gemm(g_ins[gl.size()], ldP, true, G.W(g_fc_out_w), ldDout, false, y_tm, ldDout, R, Dout, P, G.W(g_fc_out_b), 0, 0.f, false, s);
-  g_fwd_valid = true;
+  return ch;
 }
 
-void Model::d_forward(int N, int T, hipStream_t s) {
-  const float* in = xd;
+Chain Model::d_chain(int N, int Ns, int row0) {
+  Chain ch;
   for (size_t l = 0; l < dl.size(); ++l) {
-    lstm_forward(D, dl[l], d_st[l], in, N, T, nullptr, nullptr, s);
-    in = d_st[l].out;
+    LayerRun R;
+    R.ps = &D; R.L = &dl[l]; R.S = &d_st[l]; R.in = l == 0 ? xd : d_st[l - 1].out;
+    R.N = N; R.Ns = Ns; R.row0 = row0; R.len = len_dev + row0;
+    R.zx_batched = false;
+    ch.push_back(R);
   }
+  return ch;
+}
+
+void Model::g_forward_head(int T, hipStream_t s) {
+  if (cfg.g_type == RSRGAN_G_LSTM) {   // h = leakyrelu(x.W + b)  (models/lstm.py:82-87)
+    const int P = cfg.g_proj, ldP = pad4(P);
+    gemm(x_tm, ldDin, true, G.W(g_fc_in_w), ldP, false, g_h0, ldP, T * B, P, Din, G.W(g_fc_in_b), 1, cfg.lrelu_alpha, false, s);
+  }
+}
+void Model::g_forward_tail(int T, hipStream_t s) {   // y = outputs.W + b (models/lstm.py:121-124)
+  const int P = cfg.g_proj, ldP = pad4(P);
+  gemm(g_ins[gl.size()], ldP, true, G.W(g_fc_out_w), ldDout, false, y_tm, ldDout, T * B, Dout, P, G.W(g_fc_out_b), 0, 0.f, false, s);
+  g_fwd_valid = true;
+}
+void Model::g_forward(int T, hipStream_t s, Chain* extra) {
+  g_forward_head(T, s);
+  std::vector<Chain> chains;
+  chains.push_back(g_chain(T));
+  if (extra) chains.push_back(*extra);
+  rnn_forward(chains, T, s);
+  g_forward_tail(T, s);
+}
+
+void Model::d_logits(int N, int T, hipStream_t s) {
   const int ldPd = pad4(cfg.d_proj);
-  launch_gemm(in, ldPd, true, D.W(d_fc_w), 4, false, logits, 4, T * N, 1, cfg.d_proj, D.W(d_fc_b), 0, 0.f, false, s);
+  gemm(d_st[dl.size() - 1].out, ldPd, true, D.W(d_fc_w), 4, false, logits, 4, T * N, 1, cfg.d_proj, D.W(d_fc_b), 0, 0.f, false, s);
 }
 
 // leaves in last_dx0 (d_dA or d_dB) the gradient w.r.t. the discriminator input when need_dx0
@@ -381,19 +517,23 @@ void Model::d_backward_pass(int N, int T, bool want_wgrads, bool need_dx0, const
   const size_t Ld = dl.size();
   const float* top = d_st[Ld - 1].out;
   if (want_wgrads) {
-    launch_gemm(top, ldPd, false, dlog, 4, false, D.Gd(d_fc_w), 4, cfg.d_proj, 1, R, nullptr, 0, 0.f, false, s);
+    gemm(top, ldPd, false, dlog, 4, false, D.Gd(d_fc_w), 4, cfg.d_proj, 1, R, nullptr, 0, 0.f, false, s);
     launch_colsum(dlog, 4, nullptr, 0, D.Gd(d_fc_b), R, 1, scratch, s);
   }
   float* cur = d_dB;
   float* other = d_dA;
   // d(outputs) = dlogits . W^T
-  launch_gemm(dlog, 4, true, D.W(d_fc_w), 4, true, cur, ldPd, R, cfg.d_proj, 1, nullptr, 0, 0.f, false, s);
+  gemm(dlog, 4, true, D.W(d_fc_w), 4, true, cur, ldPd, R, cfg.d_proj, 1, nullptr, 0, 0.f, false, s);
+  std::vector<Chain> chains(1, d_chain(N, N, 0));
+  Chain& ch = chains[0];
   for (int l = (int)Ld - 1; l >= 0; --l) {
-    const float* in = l == 0 ? xd : d_st[l - 1].out;
-    const bool need = l > 0 || need_dx0;
-    lstm_backward(D, dl[l], d_st[l], in, N, T, cur, need ? other : nullptr, false, want_wgrads, s);
+    ch[l].dout = cur;
+    ch[l].din = (l > 0 || need_dx0) ? other : nullptr;
+    ch[l].din_accumulate = false;
+    ch[l].want_wgrads = want_wgrads;
     std::swap(cur, other);
   }
+  rnn_backward(chains, T, s);
   last_dx0 = cur;
 }
 
@@ -402,29 +542,36 @@ void Model::g_backward_pass(int T, float* dy, hipStream_t s) {
   const int P = cfg.g_proj, ldP = pad4(P);
   const size_t Lg = gl.size();
   // output FC: dW = in^T . dy ; db = colsum(dy) ; d(in) = dy . W^T
-  launch_gemm(g_ins[Lg], ldP, false, dy, ldDout, false, G.Gd(g_fc_out_w), ldDout, P, Dout, R, nullptr, 0, 0.f, false, s);
+  gemm(g_ins[Lg], ldP, false, dy, ldDout, false, G.Gd(g_fc_out_w), ldDout, P, Dout, R, nullptr, 0, 0.f, false, s);
   launch_colsum(dy, ldDout, nullptr, 0, G.Gd(g_fc_out_b), R, Dout, scratch, s);
   float* cur = g_dA;
   float* other = g_dB;
-  launch_gemm(dy, ldDout, true, G.W(g_fc_out_w), ldDout, true, cur, ldP, R, P, Dout, nullptr, 0, 0.f, false, s);
+  gemm(dy, ldDout, true, G.W(g_fc_out_w), ldDout, true, cur, ldP, R, P, Dout, nullptr, 0, 0.f, false, s);
+  std::vector<Chain> chains(1, g_chain(T));
+  Chain& ch = chains[0];
+  for (auto& r : ch) r.want_wgrads = true;
   if (cfg.g_type == RSRGAN_G_LSTM) {
     for (int l = (int)Lg - 1; l >= 0; --l) {
-      lstm_backward(G, gl[l], g_st[l], g_ins[l], B, T, cur, other, false, true, s);
+      ch[l].dout = cur; ch[l].din = other; ch[l].din_accumulate = false;
       std::swap(cur, other);
     }
+    rnn_backward(chains, T, s);
     // through leakyrelu and the input FC (models/lstm.py:82-87)
     launch_lrelu_bwd(g_h0, cur, (size_t)R, P, ldP, cfg.lrelu_alpha, s);
-    launch_gemm(x_tm, ldDin, false, cur, ldP, false, G.Gd(g_fc_in_w), ldP, Din, P, R, nullptr, 0, 0.f, false, s);
+    gemm(x_tm, ldDin, false, cur, ldP, false, G.Gd(g_fc_in_w), ldP, Din, P, R, nullptr, 0, 0.f, false, s);
     launch_colsum(cur, ldP, nullptr, 0, G.Gd(g_fc_in_b), R, P, scratch, s);
   } else if (cfg.g_type == RSRGAN_G_RES_LSTM_L) {
-    // d(inputs_l) = dx_l + d(inputs_{l+1}): accumulate in place
-    for (int l = (int)Lg - 1; l >= 0; --l)
-      lstm_backward(G, gl[l], g_st[l], g_ins[l], B, T, cur, l > 0 ? cur : nullptr, true, true, s);
+    // d(inputs_l) = dx_l + d(inputs_{l+1}): accumulate in place in one buffer
+    for (int l = (int)Lg - 1; l >= 0; --l) {
+      ch[l].dout = cur; ch[l].din = l > 0 ? cur : nullptr; ch[l].din_accumulate = true;
+    }
+    rnn_backward(chains, T, s);
   } else {
     for (int l = (int)Lg - 1; l >= 0; --l) {
-      lstm_backward(G, gl[l], g_st[l], g_ins[l], B, T, cur, l > 0 ? other : nullptr, false, true, s);
+      ch[l].dout = cur; ch[l].din = l > 0 ? other : nullptr; ch[l].din_accumulate = false;
       std::swap(cur, other);
     }
+    rnn_backward(chains, T, s);
   }
 }
 
@@ -433,9 +580,21 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
   if (!labels) { set_error("labels required"); return RSRGAN_ERR_INVALID; }
   int rc = prepare_batch(x, labels, lengths, T, s);
   if (rc) return rc;
-  g_forward(T, s);
-  launch_build_d_input(lab_tm, y_tm, nr, nf, xd, B, T, Dout, ldDout, true, s);
-  d_forward(2 * B, T, s);
+  // discriminator input rows [0,B) = labels + noise_real (gan_rnn_placeholder.py:207,212; utils/ops.py:19-30)
+  launch_add_noise_rows(lab_tm, nr, xd, B, T, Dout, ldDout, 2 * B, 0, s);
+  if (wavefront()) {
+    Chain dreal = d_chain(B, 2 * B, 0);           // D(real) does not depend on G: ride G's forward wave
+    g_forward(T, s, &dreal);
+    launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, 2 * B, B, s);   // rows [B,2B) = G(x) + noise_fake
+    std::vector<Chain> chains(1, d_chain(B, 2 * B, B));
+    rnn_forward(chains, T, s);
+  } else {
+    g_forward(T, s);
+    launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, 2 * B, B, s);
+    std::vector<Chain> chains(1, d_chain(2 * B, 2 * B, 0));
+    rnn_forward(chains, T, s);
+  }
+  d_logits(2 * B, T, s);
   launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, 2 * B, B, dyn + DYN_D_REAL, dyn + DYN_D_FAKE, losses, s);
   if (want_grads) {
     d_backward_pass(2 * B, T, true, false, dlogits, s);
@@ -456,15 +615,19 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     if (rc) return rc;
     g_forward(T, s);
   }
-  launch_build_d_input(lab_tm, y_tm, nullptr, nf, xd, B, T, Dout, ldDout, false, s);
-  d_forward(B, T, s);
+  launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, B, 0, s);
+  {
+    std::vector<Chain> chains(1, d_chain(B, B, 0));
+    rnn_forward(chains, T, s);
+  }
+  d_logits(B, T, s);
   // g_adv = mean((D(G(x)) - d_real)^2)  (gan_rnn_placeholder.py:246): all rows "fake", target d_real
   launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, B, 0, dyn + DYN_D_REAL, dyn + DYN_D_REAL, tmp3, s);
   launch_copy_f(tmp3 + 1, losses + 3, 1, s);
   const bool l2_on = !cfg.cross_validation && scal[RSRGAN_L2_SCALE] > 0.0;
   if (want_grads) {
     d_backward_pass(B, T, false, true, dlogits, s);
-    float* dy = last_dx0;                      // d g_adv / d y
+    float* dy = last_dx0;                        // d g_adv / d y
     launch_mse(y_tm, lab_tm, ldDout, dy, T * B, Dout, dyn + DYN_LAMBDA, true, losses + 4, scratch, s);
     g_backward_pass(T, dy, s);
     if (l2_on) {

@@ -51,6 +51,26 @@ struct LstmStash {               // everything one dynamic_rnn keeps for BPTT, t
   float *dmst = nullptr;         // [N][ldP] carried during BPTT
 };
 
+// One dynamic_rnn layer applied to N rows of a (possibly row-stacked) time-major buffer set.
+// A chain = the layers of one stack, bottom first; independent chains can share launches.
+struct LayerRun {
+  const ParamSet* ps = nullptr;
+  const LstmLayer* L = nullptr;
+  LstmStash* S = nullptr;
+  const float* in = nullptr;      // [T][Ns][ldI] layer input (row 0 of the stacked buffer)
+  int N = 0, Ns = 0, row0 = 0;    // rows processed, rows per time step in every buffer, first row
+  const int* len = nullptr;       // lengths of the N rows
+  bool zx_batched = false;        // x-part precomputed for all t by one GEMM (needs Ns == N, row0 == 0)
+  const float* res_in = nullptr;  // forward: res_out[t] = out[t] + res_in[t]
+  float* res_out = nullptr;
+  // backward
+  const float* dout = nullptr;    // [T][Ns][ldP] gradient of the masked outputs
+  float* din = nullptr;           // [T][Ns][ldI] gradient w.r.t. the layer input (nullptr = not needed)
+  bool din_accumulate = false;
+  bool want_wgrads = false;
+};
+typedef std::vector<LayerRun> Chain;
+
 struct Model {
   rsrgan_cfg cfg{};
   int B = 0, Tmax = 0, Din = 0, Dout = 0, ldDin = 0, ldDout = 0;
@@ -86,8 +106,10 @@ struct Model {
 
   // steps
   int prepare_batch(const float* x, const float* labels, const int32_t* lengths, int T, hipStream_t s);
-  void g_forward(int T, hipStream_t s);
-  void d_forward(int N, int T, hipStream_t s);
+  void g_forward(int T, hipStream_t s, Chain* extra = nullptr);
+  void g_forward_head(int T, hipStream_t s);
+  void g_forward_tail(int T, hipStream_t s);
+  void d_logits(int N, int T, hipStream_t s);
   void d_backward_pass(int N, int T, bool want_wgrads, bool need_dx0, const float* dlog, hipStream_t s);
   void g_backward_pass(int T, float* dy, hipStream_t s);
   int d_backward(const float* x, const float* labels, const int32_t* lengths, int T, const float* nr, const float* nf,
@@ -97,11 +119,17 @@ struct Model {
   int apply(int net, hipStream_t s);
   void refresh_transposes(int net, hipStream_t s);
 
-  // building blocks
-  void lstm_forward(const ParamSet& ps, const LstmLayer& L, LstmStash& S, const float* in, int N, int T,
-                    const float* res_in, float* res_out, hipStream_t s);
-  void lstm_backward(const ParamSet& ps, const LstmLayer& L, LstmStash& S, const float* in, int N, int T,
-                     const float* dout, float* din, bool din_accumulate, bool want_wgrads, hipStream_t s);
+  // building blocks: run chains layer-by-layer (v1) or as one fused (layer,t) wavefront
+  void rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s);
+  void rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s);
+  void layer_wgrads(const LayerRun& R, int T, hipStream_t s);
+  Chain g_chain(int T);
+  Chain d_chain(int N, int Ns, int row0);
+  void gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool b_kc, float* C, int ldc, int M, int N,
+            int K, const float* bias, int act, float alpha, bool accumulate, hipStream_t s);
+  bool wavefront() const { return (cfg.flags & RSRGAN_FLAG_WAVEFRONT) != 0; }
+  float* gemm_ws = nullptr;
+  size_t gemm_ws_floats = 0;
 
   template <typename T> T* alloc(size_t n);
 };

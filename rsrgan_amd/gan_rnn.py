@@ -265,7 +265,10 @@ class GAN_RNN(Model):
                 dst[name] = flat[off:off + int(np.prod(shape))].reshape(shape)
         return self.g_vars_dict, self.d_vars_dict
 
-    def set_vars(self, g_vars=None, d_vars=None):
+    def set_vars(self, g_vars=None, d_vars=None, reset_ema=True):
+        """Inject variable values (parity tests / external initialisers).  reset_ema: the EMA shadow
+        restarts from the injected values, as ExponentialMovingAverage.apply initialises it from the
+        variable's initial value (:185-186)."""
         for net, vals in ((NET_G, g_vars), (NET_D, d_vars)):
             if vals is None:
                 continue
@@ -275,3 +278,5 @@ class GAN_RNN(Model):
                 assert tuple(v.shape) == tuple(shape), (name, v.shape, shape)
                 flat[off:off + v.size] = v.reshape(-1)
             self.engine.set_params(net, flat, "variables")
+            if reset_ema and self.ema_enabled:
+                self.engine.set_params(net, flat, "ema")

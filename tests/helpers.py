@@ -160,12 +160,12 @@ class OracleEngine:
         (self.o.apply_g if net == NET_G else self.o.apply_d)(g)
 
 
-def build_hip_pair(cfg, B, Tmax, seed=0, **argkw):
+def build_hip_pair(cfg, B, Tmax, seed=0, flags=0, **argkw):
     """(GAN_RNN on the HIP engine, fp64 oracle) with identical fp32-rounded weights."""
     from rsrgan_amd import GAN_RNN
     g, d = rand_params(cfg, seed)
     args = args_for(cfg, B, **argkw)
-    model = GAN_RNN(None, args, ["gpu:0"], max_frames=Tmax, net_overrides=overrides(cfg))
+    model = GAN_RNN(None, args, ["gpu:0"], max_frames=Tmax, net_overrides=dict(overrides(cfg), flags=flags))
     want_g = [(n, tuple(s)) for n, s in O.g_param_specs(cfg)]
     want_d = [(n, tuple(s)) for n, s in O.d_param_specs(cfg)]
     assert [(n, s) for n, s, _ in model.engine.tensor_table(NET_G)] == want_g

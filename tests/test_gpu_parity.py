@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 
 LOSS_RTOL = 1e-4
 GRAD_RTOL = 2e-3
+SCHEDULES = [0, 1]        # 0 = layer-sequential, 1 = RSRGAN_FLAG_WAVEFRONT
 
 
 def _check_grads(model, net, want, tag):
@@ -27,12 +28,13 @@ def _check_grads(model, net, want, tag):
     assert not bad, "%s gradient mismatch: %s" % (tag, bad)
 
 
+@pytest.mark.parametrize("flags", SCHEDULES)
 @pytest.mark.parametrize("g_type", ["lstm", "res_lstm_l", "res_lstm_base"])
 @pytest.mark.parametrize("ragged", [False, True])
-def test_forward_and_gradients_small(g_type, ragged):
+def test_forward_and_gradients_small(g_type, ragged, flags):
     cfg = small_cfg(g_type)
     B, T = 5, 7
-    model, oracle = build_hip_pair(cfg, B, T, seed=3)
+    model, oracle = build_hip_pair(cfg, B, T, seed=3, flags=flags)
     x, lab, ln = rand_batch(cfg, B, T, seed=11, ragged=ragged)
     y = model.forward(x, ln)
     y_ref = oracle.forward(x, ln)
@@ -53,13 +55,14 @@ def test_forward_and_gradients_small(g_type, ragged):
     _check_grads(model, NET_G, wg, "G")
 
 
-def test_steps_update_weights_like_oracle():
+@pytest.mark.parametrize("flags", SCHEDULES)
+def test_steps_update_weights_like_oracle(flags):
     """1 D-update + 2 G-updates (the shipped 1:2 schedule, run_gan_rnn_placeholder.sh:129-130),
     first G-run reusing the D-run's generator forward; then compare every variable, Adam slot
     and EMA shadow."""
     cfg = small_cfg("lstm")
     B, T = 6, 9
-    model, oracle = build_hip_pair(cfg, B, T, seed=4, l2_scale=1e-3, g_learning_rate=1e-3, d_learning_rate=5e-2)
+    model, oracle = build_hip_pair(cfg, B, T, seed=4, flags=flags, l2_scale=1e-3, g_learning_rate=1e-3, d_learning_rate=5e-2)
     x, lab, ln = rand_batch(cfg, B, T, seed=12, ragged=True)
     a = model.d_step(x, lab, ln); b = oracle.d_step(x, lab, ln)
     assert np.allclose(np.ravel(a), np.ravel(b), rtol=LOSS_RTOL)
@@ -108,11 +111,12 @@ def test_eval_fetch_does_not_update():
     assert all(np.array_equal(g0[k], g1[k]) for k in g0) and all(np.array_equal(d0[k], d1[k]) for k in d0)
 
 
-def test_edge_lengths_and_batch_sizes():
-    """B not a multiple of 16, T=1, a row of length 1 and full-length rows."""
+@pytest.mark.parametrize("flags", SCHEDULES)
+def test_edge_lengths_and_batch_sizes(flags):
+    """B not a multiple of 16/32, T=1, a row of length 1 and full-length rows."""
     cfg = small_cfg("lstm")
-    for B, T in ((1, 1), (17, 3), (33, 2)):
-        model, oracle = build_hip_pair(cfg, B, T, seed=B)
+    for B, T in ((1, 1), (17, 3), (33, 2), (70, 2)):
+        model, oracle = build_hip_pair(cfg, B, T, seed=B, flags=flags)
         x, lab, ln = rand_batch(cfg, B, T, seed=15 + B)
         ln[-1] = 1
         got = model.engine.g_backward(x, lab, ln, None, train=True, reuse=False, apply=False).cpu().numpy()
@@ -121,12 +125,13 @@ def test_edge_lengths_and_batch_sizes():
         _check_grads(model, NET_G, wg, "G B=%d T=%d" % (B, T))
 
 
+@pytest.mark.parametrize("flags", SCHEDULES)
 @pytest.mark.parametrize("g_type", ["lstm", "res_lstm_l"])
-def test_reference_true_shapes(g_type):
+def test_reference_true_shapes(g_type, flags):
     """The reference's hard-coded sizes (G 3x760/p280 or 4x760/p257, D 2x256/p40) at B=4, T=6."""
     cfg = O.NetCfg() if g_type == "lstm" else O.NetCfg.res_lstm_l()
     B, T = 4, 6
-    model, oracle = build_hip_pair(cfg, B, T, seed=21)
+    model, oracle = build_hip_pair(cfg, B, T, seed=21, flags=flags)
     x, lab, ln = rand_batch(cfg, B, T, seed=22, ragged=True)
     got = model.engine.d_backward(x, lab, ln, None, None, train=True, apply=False).cpu().numpy()
     want, wg = oracle.d_tower(x.astype(np.float64), lab.astype(np.float64), ln)
@@ -140,11 +145,12 @@ def test_reference_true_shapes(g_type):
     assert np.abs(y - y_ref).mean() / np.abs(y_ref).mean() < LOSS_RTOL
 
 
-def test_train_one_iteration_matches_oracle():
+@pytest.mark.parametrize("flags", SCHEDULES)
+def test_train_one_iteration_matches_oracle(flags):
     from rsrgan_amd import train_one_iteration
     cfg = small_cfg("lstm")
     B, T = 4, 5
-    model, oracle = build_hip_pair(cfg, B, T, seed=31, disc_updates=1, gen_updates=2)
+    model, oracle = build_hip_pair(cfg, B, T, seed=31, flags=flags, disc_updates=1, gen_updates=2)
     batches = [rand_batch(cfg, B, T, seed=40), rand_batch(cfg, 3, T, seed=41), rand_batch(cfg, B, T, seed=42)]
     queue = [[None, x, lab, ln] for x, lab, ln in batches]
     got = train_one_iteration(None, model, len(queue), 0, queue)
