@@ -43,8 +43,10 @@ struct FwdProjJob {
   float* out;           // [N][ldm] masked output (0 for t >= len)
   const float* res_in;  // [N][ldm] or nullptr
   float* res_out;       // [N][ldm] = out + res_in
-  const int* len;
-  int ldh, ldm, P, t, N;
+  const int* len;       // nullptr: every row is live (fully_connected stage)
+  const float* bias;    // [P] added to the product (fully_connected stage), or nullptr
+  const float* noise;   // [N][P] added to `out` only (gaussian_noise_layer on D's input), or nullptr
+  int ldh, ldm, ldo, P, t, N;     // ldm: stride of m_prev/m_out/res_*, ldo: stride of out
   int nblk_c, blk_base;
 };
 struct FwdProjJobs { int n; FwdProjJob j[MAXJ]; };

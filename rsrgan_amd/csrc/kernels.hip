@@ -79,12 +79,13 @@ __device__ __forceinline__ void mma_2seg(f32x4 (&acc)[RT], const Seg<RT>& s0, co
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
 #pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].x, bv[c].x, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].y, bv[c].y, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].z, bv[c].z, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].w, bv[c].w, acc[i], 0, 0, 0);
-      }
+      for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].x, bv[c].x, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].y, bv[c].y, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].z, bv[c].z, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].w, bv[c].w, acc[i], 0, 0, 0);
     }
   }
 }
@@ -92,73 +93,129 @@ __device__ __forceinline__ void mma_2seg(f32x4 (&acc)[RT], const Seg<RT>& s0, co
 constexpr int RT = 2;          // 16-row tiles per wave: one W fragment feeds 2 x 4 MFMAs
 
 // ---------------------------------------------------------------------------------------
-// forward phase 1: WG = 32 rows x 16 cells; waves = 4 gates x KS slices of K = [x_t | m_{t-1}]
+// forward phase 1: WG (512 threads) = 32 rows x 16 cells; waves = 4 gates x 2 slices of
+// K = [x_t | m_{t-1}].  One memory round trip per kernel:
+//   - the 32-row A tile [x_t | m_{t-1}] goes global -> LDS by DMA (global_load_lds, no VGPRs) once
+//     per WG and is shared by all 8 waves (it used to be re-loaded by every wave);
+//   - every wave prefetches its whole weight slice (<= CHB k-blocks) into VGPRs;
+//   - every thread prefetches the operands of the one (row, cell) it finishes in the epilogue.
+// LDS row stride SA = K + 4 (or + 8) floats with SA/4 odd: the ds_read_b128 fragment reads of 16
+// consecutive rows land on distinct 16-B slots.  72 KB at K = 560 -> 2 WGs per CU.
 // ---------------------------------------------------------------------------------------
-template <int KS>
-__global__ __launch_bounds__(256 * KS) void k_fwd_gates(const FwdGateJobs jobs) {
-  __shared__ float zs[4 * KS][RT][16][17];
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__host__ __device__ inline int gates_sa4(int ktot) { int s = ktot / 4 + 1; return (s & 1) ? s : s + 1; }
+
+template <int CHB>
+__global__ __launch_bounds__(512, 4) void k_fwd_gates(const FwdGateJobs jobs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = blockIdx.x;
   const int ji = find_job(jobs.j, jobs.n, bid);
   const FwdGateJob& J = jobs.j[ji];
   int cb, rb;
   if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
   const int r0 = rb * 16 * RT, c0 = cb * 16;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, q = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform -> scalar branches
   const int gate = w & 3, ks = w >> 2;
   const int H = J.H, N = J.N, H4 = 4 * H;
-  const int col = c0 + lr;
-  const int gcol = gate * H + col;
+  const int ldx = J.x ? J.ldx : 0, ldm = J.ldm, Ktot = ldx + ldm;
+  const int SA4 = gates_sa4(Ktot), SA = SA4 * 4;
 
-  Seg<RT> sx, sm;
-  sx.ld = J.ldx; sx.nkb = J.x ? ((J.ldx + 15) >> 4) : 0;
-  sm.ld = J.ldm; sm.nkb = (J.ldm + 15) >> 4;
-  sx.w = (J.x && col < H) ? J.KxT + (size_t)gcol * J.ldx : nullptr;
-  sm.w = (col < H) ? J.KhT + (size_t)gcol * J.ldm : nullptr;
+  // (1) this wave's weight slice -> VGPRs (host guarantees <= CHB k-blocks per wave)
+  const int col = c0 + lr;
+  const int nkb = (Ktot + 15) >> 4, per = (nkb + 1) >> 1;
+  const int jb = ks * per, je = min(nkb, jb + per);
+  const size_t gcol = (size_t)gate * H + min(col, H - 1);
+  const float* wx = J.KxT + gcol * ldx;
+  const float* wm = J.KhT + gcol * ldm - ldx;          // so that wm[k] is valid for k >= ldx
+  float4 bv[CHB];
 #pragma unroll
-  for (int i = 0; i < RT; ++i) {
-    const int arow = r0 + i * 16 + lr;
-    sx.a[i] = (J.x && arow < N) ? J.x + (size_t)arow * J.ldx : nullptr;
-    sm.a[i] = (arow < N) ? J.m + (size_t)arow * J.ldm : nullptr;
+  for (int c = 0; c < CHB; ++c) {
+    const int k = (jb + c) * 16 + 4 * q;
+    const bool ok = (jb + c < je) && (k < Ktot) && (col < H);
+    const float* src = (k < ldx) ? wx : wm;
+    bv[c] = ok ? *reinterpret_cast<const float4*>(src + k) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  const int total = sx.nkb + sm.nkb, per = (total + KS - 1) / KS;
+  // (2) A tile: lane p of the linear LDS image <- x / m element (rows >= N and pad columns get a
+  // harmless finite dummy; they only ever meet zero weights or unstored rows)
+  {
+    const int P4 = 16 * RT * SA4;
+    for (int p0 = w * 64; p0 < P4; p0 += 512) {
+      const int p = p0 + lane;
+      const int row = p / SA4, k = (p - row * SA4) * 4;
+      const int arow = r0 + row;
+      const float* src = J.m;
+      if (p < P4 && arow < N) {
+        if (k < ldx) src = J.x + (size_t)arow * ldx + k;
+        else if (k < Ktot) src = J.m + (size_t)arow * ldm + (k - ldx);
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (size_t)p0 * 4), 16, 0, 0);
+    }
+  }
+  // (3) epilogue operands of this thread's (row, cell), in flight together with (1) and (2)
+  const int er_i = tid >> 8, er = (tid >> 4) & 15, ec = tid & 15;
+  const int erow = r0 + er_i * 16 + er, ecell = c0 + ec;
+  const bool evalid = erow < N && ecell < H;
+  float zb[4] = {0.f, 0.f, 0.f, 0.f}, cp = 0.f, pwi = 0.f, pwf = 0.f, pwo = 0.f;
+  int elen = 0;
+  if (evalid) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) zb[g] = J.zx ? J.zx[(size_t)erow * H4 + g * H + ecell] : J.bias[g * H + ecell];
+    cp = J.c_prev[(size_t)erow * H + ecell];
+    pwi = J.wi[ecell]; pwf = J.wf[ecell]; pwo = J.wo[ecell];
+    elen = J.len[erow];
+  }
+  __syncthreads();
+  // (4) MFMAs: A fragments from LDS, B from registers
   f32x4 acc[RT];
 #pragma unroll
   for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  mma_2seg<RT, 9>(acc, sx, sm, ks * per, min(total, (ks + 1) * per), q);
+  const float* abase = smem + (size_t)lr * SA + jb * 16 + 4 * q;
+#pragma unroll
+  for (int c = 0; c < CHB; ++c) {
+    if (jb + c < je) {
+      const float4 a0 = *reinterpret_cast<const float4*>(abase + c * 16);
+      const float4 a1 = *reinterpret_cast<const float4*>(abase + (size_t)16 * SA + c * 16);
+      // two independent accumulators alternate: a 16x16x4 MFMA has a 40-cycle dependent latency
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bv[c].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bv[c].x, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bv[c].y, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bv[c].y, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bv[c].z, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bv[c].z, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bv[c].w, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bv[c].w, acc[1], 0, 0, 0);
+    }
+  }
+  __syncthreads();                                     // everyone is done reading the A tile
+  float (*zs)[RT][16][17] = reinterpret_cast<float (*)[RT][16][17]>(smem);      // zs[8][RT][16][17] aliases it
 #pragma unroll
   for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) zs[w][i][q * 4 + r][lr] = acc[i][r];
   __syncthreads();
 
-  for (int e = tid; e < RT * 256; e += 256 * KS) {
-    const int i = e >> 8, er = (e >> 4) & 15, ec = e & 15;
-    const int row = r0 + i * 16 + er, cell = c0 + ec;
-    if (row >= N || cell >= H) continue;
+  if (evalid) {
     float z[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float v = J.zx ? J.zx[(size_t)row * H4 + g * H + cell] : J.bias[g * H + cell];
-#pragma unroll
-      for (int s = 0; s < KS; ++s) v += zs[s * 4 + g][i][er][ec];
-      z[g] = v;
-    }
-    const size_t ci = (size_t)row * H + cell;
-    const float cp = J.c_prev[ci];
-    float* g = J.gates + (size_t)row * H4 + cell;
-    if (J.t < J.len[row]) {
-      const float gi = sigmoid_(z[0] + J.wi[cell] * cp);
-      const float gf = sigmoid_(z[2] + jobs.forget_bias + J.wf[cell] * cp);
+    for (int g = 0; g < 4; ++g) z[g] = (zb[g] + zs[g][er_i][er][ec]) + zs[4 + g][er_i][er][ec];
+    const size_t ci = (size_t)erow * H + ecell;
+    float* g = J.gates + (size_t)erow * H4 + ecell;
+    if (J.t < elen) {
+      const float gi = sigmoid_(z[0] + pwi * cp);
+      const float gf = sigmoid_(z[2] + jobs.forget_bias + pwf * cp);
       const float gj = tanhf(z[1]);
       const float cn = gf * cp + gi * gj;
-      const float go = sigmoid_(z[3] + J.wo[cell] * cn);
+      const float go = sigmoid_(z[3] + pwo * cn);
       J.c_out[ci] = cn;
       g[0] = gi; g[H] = gj; g[2 * H] = gf; g[3 * H] = go;
-      J.h[(size_t)row * J.ldh + cell] = go * tanhf(cn);
+      J.h[(size_t)erow * J.ldh + ecell] = go * tanhf(cn);
     } else {                       // dynamic_rnn: t >= len -> state copied through, no gradient
       J.c_out[ci] = cp;
       g[0] = 0.f; g[H] = 0.f; g[2 * H] = 0.f; g[3 * H] = 0.f;
-      J.h[(size_t)row * J.ldh + cell] = 0.f;
+      J.h[(size_t)erow * J.ldh + ecell] = 0.f;
     }
   }
 }
@@ -175,7 +232,8 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_proj(const FwdProjJobs jobs) {
   int cb, rb;
   if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
   const int r0 = rb * 16 * RT, c0 = cb * 16;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, q = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform -> scalar branches
   const int N = J.N, P = J.P;
   const int p = c0 + lr;
   Seg<RT> s0, s1;
@@ -206,11 +264,13 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_proj(const FwdProjJobs jobs) {
 #pragma unroll
     for (int s = 0; s < NW; ++s) v += zs[s][i][er][ec];
     const size_t mi = (size_t)row * J.ldm + pp;
-    const bool live = J.t < J.len[row];
+    if (J.bias) v += J.bias[pp];
+    const bool live = J.len ? (J.t < J.len[row]) : true;
     J.m_out[mi] = live ? v : J.m_prev[mi];
-    const float o = live ? v : 0.f;
-    J.out[mi] = o;
-    if (J.res_out) J.res_out[mi] = o + J.res_in[mi];
+    float o = live ? v : 0.f;
+    if (J.noise) o += J.noise[(size_t)row * P + pp];
+    J.out[(size_t)row * J.ldo + pp] = o;
+    if (J.res_out) J.res_out[mi] = (live ? v : 0.f) + J.res_in[mi];
   }
 }
 
@@ -227,7 +287,8 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
   int cb, rb;
   if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
   const int r0 = rb * 16 * RT, c0 = cb * 16;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, q = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform -> scalar branches
   const int N = J.N, H = J.H, H4 = 4 * H, ldm = J.ldm;
   const int wcell = c0 + lr;
   const float* wrow = wcell < H ? J.Wp + (size_t)wcell * ldm : nullptr;
@@ -319,7 +380,8 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_b(const BwdBJobs jobs) {
   int cb, rb;
   if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
   const int r0 = rb * 16 * RT, n0 = J.n_begin + cb * 16;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, q = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform -> scalar branches
   const int N = J.N, H4 = J.H4;
   const int n = n0 + lr;
   Seg<RT> s0, s1;
@@ -363,12 +425,18 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_b(const BwdBJobs jobs) {
 // total blocks of a job list and blk_base assignment happen on the host (model.cpp); `kb_max` is
 // the largest k-block count over the jobs, which picks the K split.
 void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
-  if (kb_max <= 9)
-    hipLaunchKernelGGL(k_fwd_gates<1>, dim3(total_blocks), dim3(256), 0, s, jobs);
-  else if (kb_max <= 18)
-    hipLaunchKernelGGL(k_fwd_gates<2>, dim3(total_blocks), dim3(512), 0, s, jobs);
-  else
-    hipLaunchKernelGGL(k_fwd_gates<4>, dim3(total_blocks), dim3(1024), 0, s, jobs);
+  // dynamic LDS: the widest job's A tile (32 rows x SA floats) rounded to the 8 KB DMA granule of the
+  // 8 waves, and at least the 17 KB reduction buffer
+  const int ktot = kb_max * 16;
+  size_t lds = (size_t)16 * RT * gates_sa4(ktot) * 16;
+  lds = (lds + 8191) / 8192 * 8192;
+  if (lds < 8 * RT * 16 * 17 * sizeof(float)) lds = 8 * RT * 16 * 17 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_gates<18>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_fwd_gates<18>, dim3(total_blocks), dim3(512), lds, s, jobs);
 }
 void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
   if (kb_max <= 24)

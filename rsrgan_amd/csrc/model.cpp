@@ -189,7 +189,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     }
   }
   const int gmaxld = std::max(ldP, ldDin);
-  g_dA = alloc<float>(TB * gmaxld); g_dB = alloc<float>(TB * gmaxld);
+  g_dA = alloc<float>(TB * gmaxld); g_dB = alloc<float>(TB * gmaxld); g_dC = alloc<float>(TB * gmaxld);
   const size_t TB2 = TB * 2;
   const int ldPd = pad4(c.d_proj);
   xd = alloc<float>(TB2 * ldDout); logits = alloc<float>(TB2 * 4); dlogits = alloc<float>(TB2 * 4);
@@ -203,6 +203,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   size_t maxcols = 4 * (size_t)std::max(c.g_cells, c.d_cells);
   maxcols = std::max(maxcols, (size_t)std::max(ldP, ldDin));
   scratch = alloc<float>(std::max<size_t>(64 * maxcols, 1024));
+  g_fc_out_wT = alloc<float>((size_t)Dout * ldP);
   gemm_ws_floats = (size_t)16 << 20;          // 64 MiB of split-K partial tiles
   gemm_ws = alloc<float>(gemm_ws_floats);
   if (!gemm_ws) gemm_ws_floats = 0;
@@ -253,6 +254,8 @@ void Model::refresh_transposes(int net, hipStream_t s) {
     launch_transpose(K + (size_t)L.I * H4, H4, L.KhT, L.ldP, L.P, H4, s);    // [P][4H] -> [4H][ldP]
     launch_transpose(ps.W(L.tWp), L.ldP, L.WpT, L.ldH, L.H, L.P, s);         // [H][ldP] -> [P][ldH]
   }
+  if (net == RSRGAN_NET_G && g_fc_out_wT)
+    launch_transpose(G.W(g_fc_out_w), ldDout, g_fc_out_wT, pad4(cfg.g_proj), cfg.g_proj, Dout, s);   // [P][ldDout] -> [Dout][ldP]
 }
 
 // ------------------------------------------------------------------------------------------
@@ -290,8 +293,24 @@ static void fill_proj(FwdProjJob& p, const LayerRun& R, int t) {
   p.m_prev = S.mst + r * L.ldP; p.m_out = S.mst + rn * L.ldP; p.out = S.out + r * L.ldP;
   p.res_in = R.res_in ? R.res_in + r * L.ldP : nullptr;
   p.res_out = R.res_out ? R.res_out + r * L.ldP : nullptr;
-  p.len = R.len; p.ldm = L.ldP; p.P = L.P; p.t = t; p.N = R.N;
+  p.len = R.len; p.bias = nullptr; p.noise = nullptr;
+  p.ldm = L.ldP; p.ldo = L.ldP; p.P = L.P; p.t = t; p.N = R.N;
   p.nblk_c = (L.P + 15) / 16;
+}
+static void fill_fc_fwd(FwdProjJob& p, const FcStage& F, int t) {
+  p.h = F.in + (size_t)t * F.N * F.ld_in; p.WpT = F.WT; p.ldh = F.ld_in;
+  p.m_prev = nullptr; p.m_out = F.y + (size_t)t * F.N * F.ldy; p.ldm = F.ldy;
+  p.out = F.out2 + ((size_t)t * F.Ns2 + F.row02) * F.ld2; p.ldo = F.ld2;
+  p.res_in = nullptr; p.res_out = nullptr; p.len = nullptr; p.bias = F.bias; p.noise = F.noise;
+  p.P = F.D; p.t = t; p.N = F.N;
+  p.nblk_c = (F.D + 15) / 16;
+}
+static void fill_fc_bwd(BwdBJob& b, const FcStage& F, int t) {   // y[t] (=|+=) in[t] . W^T, W = [D rows][ld_in]
+  b.dz = F.in + (size_t)t * F.N * F.ld_in; b.K = F.WT; b.H4 = F.ld_in;
+  b.dx = F.y + (size_t)t * F.N * F.ldy; b.lddx = F.ldy; b.dmst = nullptr; b.len = nullptr;
+  b.I = F.D; b.n_begin = 0; b.n_end = F.D; b.ldm = 0; b.t = t; b.N = F.N;
+  b.dx_accumulate = F.accumulate ? 1 : 0;
+  b.nblk_c = (F.D + 15) / 16;
 }
 static void fill_bwd_a(BwdAJob& a, const LayerRun& R, int t) {
   const LstmLayer& L = *R.L; const LstmStash& S = *R.S; const ParamSet& ps = *R.ps;
@@ -318,7 +337,8 @@ static void fill_bwd_b(BwdBJob& b, const LayerRun& R, int t, bool with_dx) {
   b.nblk_c = (b.n_end - b.n_begin + 15) / 16;
 }
 
-void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s) {
+void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const std::vector<int>* offsets,
+                        const std::vector<FcStage>* fcs) {
   // zero initial state (cell.zero_state, models/lstm.py:107): slot 0 of c / m for the rows of each run
   for (auto& ch : chains)
     for (auto& R : ch) {
@@ -345,34 +365,56 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s) {
       }
     return;
   }
-  size_t maxL = 0;
-  for (auto& ch : chains) {
-    maxL = std::max(maxL, ch.size());
-    for (auto& R : ch)
+  int last = 0;      // last diagonal with work
+  for (size_t c = 0; c < chains.size(); ++c) {
+    const int off = offsets ? (*offsets)[c] : 0;
+    last = std::max(last, off + (int)chains[c].size() - 1 + T - 1);
+    for (auto& R : chains[c])
       if (R.zx_batched) zx_gemm(R);
   }
-  for (int d = 0; d < T + (int)maxL - 1; ++d) {
+  if (fcs)
+    for (auto& F : *fcs) last = std::max(last, F.offset + T - 1);
+  for (int d = 0; d <= last; ++d) {
     FwdGateJobs gj{}; gj.forget_bias = cfg.forget_bias;
     FwdProjJobs pj{};
     int gb = 0, pb = 0, gk = 0, pk = 0;
-    auto flush = [&]() {
-      if (gj.n) { launch_fwd_gates(gj, gb, gk, s); launch_fwd_proj(pj, pb, pk, s); }
-      gj.n = pj.n = 0; gb = pb = gk = pk = 0;
-    };
-    for (auto& ch : chains)
-      for (size_t l = 0; l < ch.size(); ++l) {
-        const int t = d - (int)l;
+    // a diagonal's jobs only depend on earlier diagonals, so they may be split over several launches
+    auto flush_g = [&]() { if (gj.n) launch_fwd_gates(gj, gb, gk, s); gj.n = 0; gb = gk = 0; };
+    auto flush_p = [&]() { if (pj.n) launch_fwd_proj(pj, pb, pk, s); pj.n = 0; pb = pk = 0; };
+    for (size_t c = 0; c < chains.size(); ++c) {
+      Chain& ch = chains[c];
+      const int off = offsets ? (*offsets)[c] : 0;
+      for (int l = (int)ch.size() - 1; l >= 0; --l) {     // upper layers first: their K is twice layer 0's (heavy blocks dispatch first)
+        const int t = d - off - l;
         if (t < 0 || t >= T) continue;
         const LayerRun& R = ch[l];
-        if (gj.n == MAXJ) flush();      // (cannot overflow a dependency: jobs of one diagonal are independent)
+        if (gj.n == MAXJ) flush_g();
         FwdGateJob& a = gj.j[gj.n++]; fill_gate(a, R, t, R.zx_batched); a.blk_base = gb; gb += job_blocks(a.nblk_c, R.N);
         gk = std::max(gk, (R.zx_batched ? 0 : kb16(R.L->ldI)) + kb16(R.L->ldP));
+      }
+    }
+    flush_g();
+    for (size_t c = 0; c < chains.size(); ++c) {
+      Chain& ch = chains[c];
+      const int off = offsets ? (*offsets)[c] : 0;
+      for (int l = (int)ch.size() - 1; l >= 0; --l) {
+        const int t = d - off - l;
+        if (t < 0 || t >= T) continue;
+        const LayerRun& R = ch[l];
+        if (pj.n == MAXJ) flush_p();
         FwdProjJob& p = pj.j[pj.n++]; fill_proj(p, R, t); p.blk_base = pb; pb += job_blocks(p.nblk_c, R.N);
         pk = std::max(pk, kb16(R.L->ldH));
       }
-    // NOTE: with > MAXJ jobs per diagonal the gates of all jobs must precede the projections of
-    // none they depend on -- true, since a diagonal's jobs only depend on the previous diagonal.
-    flush();
+    }
+    if (fcs)
+      for (auto& F : *fcs) {
+        const int t = d - F.offset;
+        if (t < 0 || t >= T) continue;
+        if (pj.n == MAXJ) flush_p();
+        FwdProjJob& p = pj.j[pj.n++]; fill_fc_fwd(p, F, t); p.blk_base = pb; pb += job_blocks(p.nblk_c, F.N);
+        pk = std::max(pk, kb16(F.ld_in));
+      }
+    flush_p();
   }
 }
 
@@ -391,7 +433,8 @@ void Model::layer_wgrads(const LayerRun& R, int T, hipStream_t s) {
   launch_colsum(S.gates + 3 * H, H4, S.c + (size_t)R.N * H, H, ps.Gd(L.two), Rws, H, scratch, s);
 }
 
-void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s) {
+void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const std::vector<int>* offsets,
+                         const std::vector<FcStage>* fcs) {
   for (auto& ch : chains)
     for (auto& R : ch) {
       (void)hipMemsetAsync(R.S->dc + (size_t)R.row0 * R.L->H, 0, (size_t)R.N * R.L->H * sizeof(float), s);
@@ -416,29 +459,49 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s) {
       }
     return;
   }
-  size_t maxL = 0;
-  for (auto& ch : chains) maxL = std::max(maxL, ch.size());
-  for (int d = 0; d < T + (int)maxL - 1; ++d) {
+  int last = 0;
+  for (size_t c = 0; c < chains.size(); ++c)
+    last = std::max(last, (offsets ? (*offsets)[c] : 0) + (int)chains[c].size() - 1 + T - 1);
+  if (fcs)
+    for (auto& F : *fcs) last = std::max(last, F.offset + T - 1);
+  for (int d = 0; d <= last; ++d) {
     BwdAJobs aj{}; BwdBJobs bj{};
     int ab = 0, bb = 0, ak = 0, bk = 0;
-    auto flush = [&]() {
-      if (aj.n) { launch_bwd_a(aj, ab, ak, s); launch_bwd_b(bj, bb, bk, s); }
-      aj.n = bj.n = 0; ab = bb = ak = bk = 0;
-    };
-    for (auto& ch : chains) {
-      const int Lc = (int)ch.size();
+    auto flush_a = [&]() { if (aj.n) launch_bwd_a(aj, ab, ak, s); aj.n = 0; ab = ak = 0; };
+    auto flush_b = [&]() { if (bj.n) launch_bwd_b(bj, bb, bk, s); bj.n = 0; bb = bk = 0; };
+    for (size_t c = 0; c < chains.size(); ++c) {
+      Chain& ch = chains[c];
+      const int Lc = (int)ch.size(), off = offsets ? (*offsets)[c] : 0;
       for (int l = Lc - 1; l >= 0; --l) {
-        const int t = T - 1 - (d - (Lc - 1 - l));
+        const int t = T - 1 - (d - off - (Lc - 1 - l));
+        if (t < 0 || t >= T) continue;
+        if (aj.n == MAXJ) flush_a();
+        BwdAJob& a = aj.j[aj.n++]; fill_bwd_a(a, ch[l], t); a.blk_base = ab; ab += job_blocks(a.nblk_c, ch[l].N);
+        ak = std::max(ak, kb16(ch[l].L->ldP));
+      }
+    }
+    flush_a();
+    for (size_t c = 0; c < chains.size(); ++c) {
+      Chain& ch = chains[c];
+      const int Lc = (int)ch.size(), off = offsets ? (*offsets)[c] : 0;
+      for (int l = Lc - 1; l >= 0; --l) {
+        const int t = T - 1 - (d - off - (Lc - 1 - l));
         if (t < 0 || t >= T) continue;
         const LayerRun& R = ch[l];
-        if (aj.n == MAXJ) flush();
-        BwdAJob& a = aj.j[aj.n++]; fill_bwd_a(a, R, t); a.blk_base = ab; ab += job_blocks(a.nblk_c, R.N);
-        ak = std::max(ak, kb16(R.L->ldP));
+        if (bj.n == MAXJ) flush_b();
         BwdBJob& b = bj.j[bj.n++]; fill_bwd_b(b, R, t, R.din != nullptr); b.blk_base = bb; bb += job_blocks(b.nblk_c, R.N);
         bk = std::max(bk, kb16(4 * R.L->H));
       }
     }
-    flush();
+    if (fcs)
+      for (auto& F : *fcs) {
+        const int t = T - 1 - (d - F.offset);
+        if (t < 0 || t >= T) continue;
+        if (bj.n == MAXJ) flush_b();
+        BwdBJob& b = bj.j[bj.n++]; fill_fc_bwd(b, F, t); b.blk_base = bb; bb += job_blocks(b.nblk_c, F.N);
+        bk = std::max(bk, kb16(F.ld_in));
+      }
+    flush_b();
   }
   for (auto& ch : chains)
     for (auto& R : ch)
@@ -583,11 +646,19 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
   // discriminator input rows [0,B) = labels + noise_real (gan_rnn_placeholder.py:207,212; utils/ops.py:19-30)
   launch_add_noise_rows(lab_tm, nr, xd, B, T, Dout, ldDout, 2 * B, 0, s);
   if (wavefront()) {
-    Chain dreal = d_chain(B, 2 * B, 0);           // D(real) does not depend on G: ride G's forward wave
-    g_forward(T, s, &dreal);
-    launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, 2 * B, B, s);   // rows [B,2B) = G(x) + noise_fake
-    std::vector<Chain> chains(1, d_chain(B, 2 * B, B));
-    rnn_forward(chains, T, s);
+    // ONE wave: G's layers | D(real) (independent of G) | per-step output FC -> y_t, xd fake rows |
+    // D(fake) two diagonals behind G's top layer
+    g_forward_head(T, s);
+    const int Lg = (int)gl.size(), ldP = pad4(cfg.g_proj);
+    std::vector<Chain> chains{g_chain(T), d_chain(B, 2 * B, 0), d_chain(B, 2 * B, B)};
+    std::vector<int> offs{0, 0, Lg + 1};
+    FcStage F;
+    F.offset = Lg; F.N = B; F.K = cfg.g_proj; F.D = Dout;
+    F.in = g_ins[Lg]; F.ld_in = ldP; F.WT = g_fc_out_wT; F.bias = G.W(g_fc_out_b); F.noise = nf;
+    F.y = y_tm; F.ldy = ldDout; F.out2 = xd; F.ld2 = ldDout; F.Ns2 = 2 * B; F.row02 = B;
+    std::vector<FcStage> fcs{F};
+    rnn_forward(chains, T, s, &offs, &fcs);
+    g_fwd_valid = true;
   } else {
     g_forward(T, s);
     launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, 2 * B, B, s);
@@ -625,7 +696,49 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, B, 0, dyn + DYN_D_REAL, dyn + DYN_D_REAL, tmp3, s);
   launch_copy_f(tmp3 + 1, losses + 3, 1, s);
   const bool l2_on = !cfg.cross_validation && scal[RSRGAN_L2_SCALE] > 0.0;
-  if (want_grads) {
+  if (want_grads && wavefront() && cfg.g_type == RSRGAN_G_LSTM) {
+    // ONE backward wave: D's layers (data gradient only) | per-step output-FC backward | G's layers.
+    // dy[t] = lambda*(y-lab)/(B*T) (written first) + d g_adv/d y[t] (accumulated by D layer 0's phase B)
+    const int R = T * B, Ld = (int)dl.size(), Lg = (int)gl.size();
+    const int ldPd = pad4(cfg.d_proj), P = cfg.g_proj, ldP = pad4(P);
+    float* dtop = d_dB;                           // d(D outputs) = dlogits . W^T
+    gemm(dlogits, 4, true, D.W(d_fc_w), 4, true, dtop, ldPd, R, cfg.d_proj, 1, nullptr, 0, 0.f, false, s);
+    float* dy = g_dB;                             // [T*B][ldDout]
+    launch_mse(y_tm, lab_tm, ldDout, dy, R, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s);
+    Chain dch = d_chain(B, B, 0);
+    float* cur = dtop; float* other = d_dA;
+    for (int l = Ld - 1; l >= 0; --l) {
+      dch[l].dout = cur; dch[l].want_wgrads = false;
+      if (l == 0) { dch[l].din = dy; dch[l].din_accumulate = true; }
+      else { dch[l].din = other; dch[l].din_accumulate = false; std::swap(cur, other); }
+    }
+    Chain gch = g_chain(T);
+    float* bufA = g_dA; float* bufB = g_dC;        // G-side gradient ping-pong (dy itself lives in g_dB)
+    for (int l = Lg - 1; l >= 0; --l) {
+      gch[l].want_wgrads = true;
+      gch[l].dout = bufA; gch[l].din = bufB; gch[l].din_accumulate = false;
+      std::swap(bufA, bufB);
+    }
+    FcStage F;                                     // d(ins[L])[t] = dy[t] . W_out^T
+    F.offset = Ld; F.N = B; F.K = Dout; F.D = P;
+    F.in = dy; F.ld_in = ldDout; F.WT = G.W(g_fc_out_w); F.y = g_dA; F.ldy = ldP; F.accumulate = false;
+    std::vector<Chain> chains{dch, gch};
+    std::vector<int> offs{0, Ld + 1};
+    std::vector<FcStage> fcs{F};
+    rnn_backward(chains, T, s, &offs, &fcs);
+    // output FC parameter gradients (batched over time, dy is complete now)
+    gemm(g_ins[Lg], ldP, false, dy, ldDout, false, G.Gd(g_fc_out_w), ldDout, P, Dout, R, nullptr, 0, 0.f, false, s);
+    launch_colsum(dy, ldDout, nullptr, 0, G.Gd(g_fc_out_b), R, Dout, scratch, s);
+    // through leakyrelu and the input FC (models/lstm.py:82-87); bufA now holds d(h0)
+    launch_lrelu_bwd(g_h0, bufA, (size_t)R, P, ldP, cfg.lrelu_alpha, s);
+    gemm(x_tm, ldDin, false, bufA, ldP, false, G.Gd(g_fc_in_w), ldP, Din, P, R, nullptr, 0, 0.f, false, s);
+    launch_colsum(bufA, ldP, nullptr, 0, G.Gd(g_fc_in_b), R, P, scratch, s);
+    if (l2_on) {
+      launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
+      launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);
+    }
+    g_grads_ready = true;
+  } else if (want_grads) {
     d_backward_pass(B, T, false, true, dlogits, s);
     float* dy = last_dx0;                        // d g_adv / d y
     launch_mse(y_tm, lab_tm, ldDout, dy, T * B, Dout, dyn + DYN_LAMBDA, true, losses + 4, scratch, s);

@@ -71,6 +71,21 @@ struct LayerRun {
 };
 typedef std::vector<LayerRun> Chain;
 
+// A per-time-step fully_connected stage riding a wavefront (wave mode only).
+//  forward : y[t] = in[t] . W + b  -> y (stride ldy) and, with noise, -> out2 rows of a stacked buffer
+//  backward: dst[t] (=|+=) src[t] . W^T
+struct FcStage {
+  int offset = 0;                 // diagonal at which time step 0 (forward) / T-1 (backward) runs
+  int N = 0, K = 0, D = 0;        // rows, input width, output width
+  const float* in = nullptr; int ld_in = 0;
+  const float* WT = nullptr;      // forward: [D][ld_in] transposed weights ; backward: W [K'][ldk] TF layout
+  const float* bias = nullptr;
+  const float* noise = nullptr;
+  float* y = nullptr; int ldy = 0;
+  float* out2 = nullptr; int ld2 = 0, Ns2 = 0, row02 = 0;
+  bool accumulate = false;
+};
+
 struct Model {
   rsrgan_cfg cfg{};
   int B = 0, Tmax = 0, Din = 0, Dout = 0, ldDin = 0, ldDout = 0;
@@ -83,7 +98,7 @@ struct Model {
   std::vector<float*> g_ins;      // g_ins[l] = input of layer l, g_ins[L] = input of the output FC
   std::vector<float*> g_res;      // res_lstm_l: out_l + in_l buffers (g_ins[l+1] aliases these)
   std::vector<LstmStash> g_st;
-  float *g_dA = nullptr, *g_dB = nullptr;   // ping-pong gradient buffers [T*B][max ld]
+  float *g_dA = nullptr, *g_dB = nullptr, *g_dC = nullptr;   // ping-pong gradient buffers [T*B][max ld]
   // discriminator activations (N = 2B rows per frame)
   float *xd = nullptr, *logits = nullptr, *dlogits = nullptr;
   std::vector<LstmStash> d_st;
@@ -120,14 +135,17 @@ struct Model {
   void refresh_transposes(int net, hipStream_t s);
 
   // building blocks: run chains layer-by-layer (v1) or as one fused (layer,t) wavefront
-  void rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s);
-  void rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s);
+  void rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const std::vector<int>* offsets = nullptr,
+                   const std::vector<FcStage>* fcs = nullptr);
+  void rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const std::vector<int>* offsets = nullptr,
+                    const std::vector<FcStage>* fcs = nullptr);
   void layer_wgrads(const LayerRun& R, int T, hipStream_t s);
   Chain g_chain(int T);
   Chain d_chain(int N, int Ns, int row0);
   void gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool b_kc, float* C, int ldc, int M, int N,
             int K, const float* bias, int act, float alpha, bool accumulate, hipStream_t s);
   bool wavefront() const { return (cfg.flags & RSRGAN_FLAG_WAVEFRONT) != 0; }
+  float* g_fc_out_wT = nullptr;   // [Dout][ldP] transposed copy of the output FC weights (per-step FC stage)
   float* gemm_ws = nullptr;
   size_t gemm_ws_floats = 0;
 
