@@ -1,6 +1,7 @@
 // capi.cpp -- extern "C" entry points declared in include/rsrgan.h.
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "model.h"
 
@@ -219,6 +220,46 @@ int rsrgan_op_gemm(const float* A, int32_t lda, int32_t a_kc, const float* B, in
   launch_gemm(A, lda, a_kc != 0, B, ldb, b_kc != 0, C, ldc, M, N, K, bias, act, alpha, accumulate != 0, (hipStream_t)stream,
               ws, ws ? ws_floats : 0);
   if (hipGetLastError() != hipSuccess) { set_error("op_gemm launch failed"); return RSRGAN_ERR_HIP; }
+  return RSRGAN_OK;
+}
+
+// Micro-benchmark of one wavefront launch (within-probe A/B of kernel variants; not part of the
+// drop-in surface).  kind 3 = backward phase B with `layers` jobs of (N rows, H cells, I inputs, P
+// proj) on random data; returns the mean microseconds per launch over `reps` launches.
+int rsrgan_microbench(int32_t kind, int32_t variant, int32_t N, int32_t H, int32_t I, int32_t P, int32_t layers,
+                      int32_t reps, float* out_us) {
+  if (kind != 3 || layers < 1 || layers > MAXJ || !out_us) { set_error("microbench: unsupported"); return RSRGAN_ERR_INVALID; }
+  const int H4 = 4 * H, ldI = pad4(I), ldP = pad4(P);
+  std::vector<void*> bufs;
+  auto dal = [&](size_t n, float v) { float* p = nullptr; if (hipMalloc((void**)&p, n * sizeof(float)) != hipSuccess) return (float*)nullptr; launch_fill(p, n, v, nullptr); bufs.push_back(p); return p; };
+  int* len = nullptr;
+  if (hipMalloc((void**)&len, N * sizeof(int)) != hipSuccess) { set_error("hipMalloc"); return RSRGAN_ERR_HIP; }
+  std::vector<int> hl(N, 1 << 20);
+  (void)hipMemcpy(len, hl.data(), N * sizeof(int), hipMemcpyHostToDevice);
+  BwdBJobs bj{};
+  int bb = 0;
+  for (int l = 0; l < layers; ++l) {
+    BwdBJob& b = bj.j[bj.n++];
+    b.dz = dal((size_t)N * H4, 0.01f * (l + 1)); b.K = dal((size_t)(I + P) * H4, 0.003f);
+    b.dx = dal((size_t)N * ldI, 0.f); b.dmst = dal((size_t)N * ldP, 0.f); b.len = len;
+    b.I = I; b.n_begin = 0; b.n_end = I + P; b.lddx = ldI; b.ldm = ldP; b.t = 0; b.N = N; b.H4 = H4; b.dx_accumulate = 0;
+    b.nblk_c = (I + P + 15) / 16; b.blk_base = bb; bb += job_blocks(b.nblk_c, N);
+    if (!b.dz || !b.K || !b.dx || !b.dmst) { set_error("hipMalloc"); return RSRGAN_ERR_HIP; }
+  }
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) launch_bwd_b_variant(bj, bb, variant, nullptr);
+  (void)hipEventRecord(e0, nullptr);
+  for (int i = 0; i < reps; ++i) launch_bwd_b_variant(bj, bb, variant, nullptr);
+  (void)hipEventRecord(e1, nullptr);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *out_us = ms * 1000.f / reps;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  for (void* p : bufs) (void)hipFree(p);
+  (void)hipFree(len);
+  if (hipGetLastError() != hipSuccess) { set_error("microbench launch failed"); return RSRGAN_ERR_HIP; }
   return RSRGAN_OK;
 }
 

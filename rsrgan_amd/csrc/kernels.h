@@ -89,6 +89,7 @@ void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, int kb_max, hip
 void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
 void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
 void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
+void launch_bwd_b_variant(const BwdBJobs& jobs, int total_blocks, int variant, hipStream_t s);
 
 // ---------------------------------------------------------------- batched GEMM
 // C[M,N] (+)= A.B (+bias)(lrelu).  a_kc: A(m,k)=A[m*lda+k] else A[k*lda+m];

@@ -90,6 +90,70 @@ __device__ __forceinline__ void mma_2seg(f32x4 (&acc)[RT], const Seg<RT>& s0, co
   }
 }
 
+// Software-pipelined variant: two register sets; the loads of chunk c+1 are in flight while chunk c
+// feeds the matrix pipe (the compiler's counted vmcnt waits only for the set it is about to use).
+// VAR (ablation bits, micro-benchmarks only; production = 0): 1 = no A loads, 2 = no B loads, 4 = no MFMA
+template <int RT, int CH, int VAR = 0>
+__device__ __forceinline__ void load_chunk(float4 (&av)[CH][RT], float4 (&bv)[CH], const Seg<RT>& s0, const Seg<RT>& s1,
+                                           int j0, int je, int q) {
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int j = j0 + c;
+    const bool first = j < s0.nkb;
+    // VAR & 32: k-blocks are processed in pairs; lane q owns the 32 contiguous bytes [8q, 8q+8) of
+    // each 32-float super-block, so the 4 q-lanes of a row read one full 128-B line (single segment)
+    const int jj = first ? j : j - s0.nkb;
+    const int k = (VAR & 32) ? ((jj >> 1) * 32 + 8 * q + 4 * (jj & 1)) : (jj * 16 + 4 * q);
+    const int ld = first ? s0.ld : s1.ld;
+    const bool ok = (j < je) && (k < ld);
+    const float* w = first ? s0.w : s1.w;
+    if (VAR & 2) bv[c] = make_float4(1.f, 1.f, 1.f, 1.f);
+    else bv[c] = (ok && w) ? *reinterpret_cast<const float4*>(w + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const float* a = first ? s0.a[i] : s1.a[i];
+      if (VAR & 1) av[c][i] = make_float4(1.f, 1.f, 1.f, 1.f);
+      else av[c][i] = (ok && a) ? *reinterpret_cast<const float4*>(a + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+template <int RT, int CH, int VAR = 0>
+__device__ __forceinline__ void mma_chunk(f32x4 (&acc)[RT], const float4 (&av)[CH][RT], const float4 (&bv)[CH]) {
+  if (VAR & 4) {        // keep the loads alive without the matrix pipe
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int i = 0; i < RT; ++i) acc[i][0] += av[c][i].x + av[c][i].w + bv[c].x + bv[c].w;
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].x, bv[c].x, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].y, bv[c].y, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].z, bv[c].z, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].w, bv[c].w, acc[i], 0, 0, 0);
+  }
+}
+template <int RT, int CH, int VAR = 0>
+__device__ __forceinline__ void mma_2seg_pipe(f32x4 (&acc)[RT], const Seg<RT>& s0, const Seg<RT>& s1, int jb, int je, int q) {
+  float4 a0[CH][RT], b0[CH], a1[CH][RT], b1[CH];
+  if (jb >= je) return;                                   // (wave-uniform)
+  load_chunk<RT, CH, VAR>(a0, b0, s0, s1, jb, je, q);
+  for (int j0 = jb; j0 < je; j0 += 2 * CH) {
+    const bool more1 = j0 + CH < je, more2 = j0 + 2 * CH < je;
+    if (more1) load_chunk<RT, CH, VAR>(a1, b1, s0, s1, j0 + CH, je, q);
+    mma_chunk<RT, CH, VAR>(acc, a0, b0);
+    if (more1) {
+      if (more2) load_chunk<RT, CH, VAR>(a0, b0, s0, s1, j0 + 2 * CH, je, q);
+      mma_chunk<RT, CH, VAR>(acc, a1, b1);
+    }
+  }
+}
+
 constexpr int RT = 2;          // 16-row tiles per wave: one W fragment feeds 2 x 4 MFMAs
 
 // ---------------------------------------------------------------------------------------
@@ -371,7 +435,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
 // ---------------------------------------------------------------------------------------
 // backward phase B: 32x16 tile of dz_t.K^T, K (=4H) split over NW waves
 // ---------------------------------------------------------------------------------------
-template <int NW>
+template <int NW, int VAR = 0>
 __global__ __launch_bounds__(NW * 64) void k_bwd_b(const BwdBJobs jobs) {
   __shared__ float zs[NW][RT][16][17];
   const int bid = blockIdx.x;
@@ -398,7 +462,8 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_b(const BwdBJobs jobs) {
   f32x4 acc[RT];
 #pragma unroll
   for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  mma_2seg<RT, 6>(acc, s0, s1, w * per, min(s0.nkb, (w + 1) * per), q);
+  if (VAR & 8) mma_2seg<RT, 6>(acc, s0, s1, w * per, min(s0.nkb, (w + 1) * per), q);      // un-pipelined
+  else mma_2seg_pipe<RT, 6, VAR>(acc, s0, s1, w * per, min(s0.nkb, (w + 1) * per), q);
 #pragma unroll
   for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -449,10 +514,24 @@ void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, int kb_max, hipStream_
   hipLaunchKernelGGL(k_bwd_a<4>, dim3(total_blocks), dim3(256), 0, s, jobs);
 }
 void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
-  if (kb_max <= 96)
-    hipLaunchKernelGGL(k_bwd_b<8>, dim3(total_blocks), dim3(512), 0, s, jobs);
-  else
-    hipLaunchKernelGGL(k_bwd_b<16>, dim3(total_blocks), dim3(1024), 0, s, jobs);
+  (void)kb_max;      // 8 waves split K; each runs a double-buffered 6-k-block register pipeline
+  hipLaunchKernelGGL(k_bwd_b<8>, dim3(total_blocks), dim3(512), 0, s, jobs);
+}
+// micro-benchmark variants (rsrgan_microbench): see VAR above; 8 = un-pipelined, 16 = 16 waves
+void launch_bwd_b_variant(const BwdBJobs& jobs, int total_blocks, int variant, hipStream_t s) {
+  switch (variant) {
+    case 0: hipLaunchKernelGGL((k_bwd_b<8, 0>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
+    case 1: hipLaunchKernelGGL((k_bwd_b<8, 1>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
+    case 2: hipLaunchKernelGGL((k_bwd_b<8, 2>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
+    case 3: hipLaunchKernelGGL((k_bwd_b<8, 3>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
+    case 4: hipLaunchKernelGGL((k_bwd_b<8, 4>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
+    case 7: hipLaunchKernelGGL((k_bwd_b<8, 7>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
+    case 8: hipLaunchKernelGGL((k_bwd_b<8, 8>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
+    case 16: hipLaunchKernelGGL((k_bwd_b<16, 8>), dim3(total_blocks), dim3(1024), 0, s, jobs); break;
+    case 32: hipLaunchKernelGGL((k_bwd_b<8, 32>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
+    case 36: hipLaunchKernelGGL((k_bwd_b<8, 36>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
+    default: break;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
