@@ -84,7 +84,9 @@ struct BwdBJobs { int n; BwdBJob j[MAXJ]; };
 // A job covers nblk_r = ceil(N/32) row blocks x roundup8(nblk_c) virtual column blocks; blk_base is
 // the job's first block id in the launch.  kb_max = largest 16-float k-block count of any job in
 // the launch (selects how many waves split K).
-inline int job_blocks(int nblk_c, int N) { return ((nblk_c + 7) & ~7) * ((N + 31) / 32); }
+inline int job_blocks(int nblk_c, int N, int rows = 32) { return ((nblk_c + 7) & ~7) * ((N + rows - 1) / rows); }
+int fwd_gates_rows();
+void set_fwd_gates_rows(int r);
 void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
 void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
 void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, int kb_max, hipStream_t s);

@@ -171,15 +171,15 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 __host__ __device__ inline int gates_sa4(int ktot) { int s = ktot / 4 + 1; return (s & 1) ? s : s + 1; }
 
-template <int CHB>
-__global__ __launch_bounds__(512, 4) void k_fwd_gates(const FwdGateJobs jobs) {
+template <int CHB, int RTG>      // RTG 16-row tiles per WG: 2 -> 32 rows (2 WGs/CU), 4 -> 64 rows (weights streamed once)
+__global__ __launch_bounds__(512, RTG == 2 ? 4 : 2) void k_fwd_gates(const FwdGateJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = blockIdx.x;
   const int ji = find_job(jobs.j, jobs.n, bid);
   const FwdGateJob& J = jobs.j[ji];
   int cb, rb;
   if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
-  const int r0 = rb * 16 * RT, c0 = cb * 16;
+  const int r0 = rb * 16 * RTG, c0 = cb * 16;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform -> scalar branches
   const int gate = w & 3, ks = w >> 2;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(512, 4) void k_fwd_gates(const FwdGateJobs jobs) {
   // (2) A tile: lane p of the linear LDS image <- x / m element (rows >= N and pad columns get a
   // harmless finite dummy; they only ever meet zero weights or unstored rows)
   {
-    const int P4 = 16 * RT * SA4;
+    const int P4 = 16 * RTG * SA4;
     for (int p0 = w * 64; p0 < P4; p0 += 512) {
       const int p = p0 + lane;
       const int row = p / SA4, k = (p - row * SA4) * 4;
@@ -218,66 +218,79 @@ __global__ __launch_bounds__(512, 4) void k_fwd_gates(const FwdGateJobs jobs) {
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (size_t)p0 * 4), 16, 0, 0);
     }
   }
-  // (3) epilogue operands of this thread's (row, cell), in flight together with (1) and (2)
-  const int er_i = tid >> 8, er = (tid >> 4) & 15, ec = tid & 15;
-  const int erow = r0 + er_i * 16 + er, ecell = c0 + ec;
-  const bool evalid = erow < N && ecell < H;
-  float zb[4] = {0.f, 0.f, 0.f, 0.f}, cp = 0.f, pwi = 0.f, pwf = 0.f, pwo = 0.f;
-  int elen = 0;
-  if (evalid) {
+  // (3) epilogue operands of this thread's EPT (row, cell) elements, in flight together with (1) and (2)
+  constexpr int EPT = RTG / 2;
+  const int er = (tid >> 4) & 15, ec = tid & 15, ecell = c0 + ec;
+  float zb[EPT][4], cp[EPT], pwi = 0.f, pwf = 0.f, pwo = 0.f;
+  int elen[EPT];
+  bool evalid[EPT];
+  if (ecell < H) { pwi = J.wi[ecell]; pwf = J.wf[ecell]; pwo = J.wo[ecell]; }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) zb[g] = J.zx ? J.zx[(size_t)erow * H4 + g * H + ecell] : J.bias[g * H + ecell];
-    cp = J.c_prev[(size_t)erow * H + ecell];
-    pwi = J.wi[ecell]; pwf = J.wf[ecell]; pwo = J.wo[ecell];
-    elen = J.len[erow];
+  for (int u = 0; u < EPT; ++u) {
+    const int erow = r0 + ((tid >> 8) + 2 * u) * 16 + er;
+    evalid[u] = erow < N && ecell < H;
+    cp[u] = 0.f; elen[u] = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) zb[u][g] = 0.f;
+    if (evalid[u]) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) zb[u][g] = J.zx ? J.zx[(size_t)erow * H4 + g * H + ecell] : J.bias[g * H + ecell];
+      cp[u] = J.c_prev[(size_t)erow * H + ecell];
+      elen[u] = J.len[erow];
+    }
   }
   __syncthreads();
-  // (4) MFMAs: A fragments from LDS, B from registers
-  f32x4 acc[RT];
+  // (4) MFMAs: A fragments from LDS, B from registers; RTG independent accumulators interleave
+  f32x4 acc[RTG];
 #pragma unroll
-  for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < RTG; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* abase = smem + (size_t)lr * SA + jb * 16 + 4 * q;
 #pragma unroll
   for (int c = 0; c < CHB; ++c) {
     if (jb + c < je) {
-      const float4 a0 = *reinterpret_cast<const float4*>(abase + c * 16);
-      const float4 a1 = *reinterpret_cast<const float4*>(abase + (size_t)16 * SA + c * 16);
-      // two independent accumulators alternate: a 16x16x4 MFMA has a 40-cycle dependent latency
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bv[c].x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bv[c].x, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bv[c].y, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bv[c].y, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bv[c].z, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bv[c].z, acc[1], 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bv[c].w, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bv[c].w, acc[1], 0, 0, 0);
+      float4 a[RTG];
+#pragma unroll
+      for (int i = 0; i < RTG; ++i) a[i] = *reinterpret_cast<const float4*>(abase + (size_t)i * 16 * SA + c * 16);
+#pragma unroll
+      for (int i = 0; i < RTG; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, bv[c].x, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < RTG; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, bv[c].y, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < RTG; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, bv[c].z, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < RTG; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bv[c].w, acc[i], 0, 0, 0);
     }
   }
   __syncthreads();                                     // everyone is done reading the A tile
-  float (*zs)[RT][16][17] = reinterpret_cast<float (*)[RT][16][17]>(smem);      // zs[8][RT][16][17] aliases it
+  float (*zs)[RTG][16][17] = reinterpret_cast<float (*)[RTG][16][17]>(smem);      // zs[8][RTG][16][17] aliases it
 #pragma unroll
-  for (int i = 0; i < RT; ++i)
+  for (int i = 0; i < RTG; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) zs[w][i][q * 4 + r][lr] = acc[i][r];
   __syncthreads();
 
-  if (evalid) {
+#pragma unroll
+  for (int u = 0; u < EPT; ++u) {
+    if (!evalid[u]) continue;
+    const int ei = (tid >> 8) + 2 * u;
+    const int erow = r0 + ei * 16 + er;
     float z[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) z[g] = (zb[g] + zs[g][er_i][er][ec]) + zs[4 + g][er_i][er][ec];
+    for (int g = 0; g < 4; ++g) z[g] = (zb[u][g] + zs[g][ei][er][ec]) + zs[4 + g][ei][er][ec];
     const size_t ci = (size_t)erow * H + ecell;
     float* g = J.gates + (size_t)erow * H4 + ecell;
-    if (J.t < elen) {
-      const float gi = sigmoid_(z[0] + pwi * cp);
-      const float gf = sigmoid_(z[2] + jobs.forget_bias + pwf * cp);
+    if (J.t < elen[u]) {
+      const float cpv = cp[u];
+      const float gi = sigmoid_(z[0] + pwi * cpv);
+      const float gf = sigmoid_(z[2] + jobs.forget_bias + pwf * cpv);
       const float gj = tanhf(z[1]);
-      const float cn = gf * cp + gi * gj;
+      const float cn = gf * cpv + gi * gj;
       const float go = sigmoid_(z[3] + pwo * cn);
       J.c_out[ci] = cn;
       g[0] = gi; g[H] = gj; g[2 * H] = gf; g[3 * H] = go;
       J.h[(size_t)erow * J.ldh + ecell] = go * tanhf(cn);
     } else {                       // dynamic_rnn: t >= len -> state copied through, no gradient
-      J.c_out[ci] = cp;
+      J.c_out[ci] = cp[u];
       g[0] = 0.f; g[H] = 0.f; g[2 * H] = 0.f; g[3 * H] = 0.f;
       J.h[(size_t)erow * J.ldh + ecell] = 0.f;
     }
@@ -355,76 +368,95 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform -> scalar branches
   const int N = J.N, H = J.H, H4 = 4 * H, ldm = J.ldm;
   const int wcell = c0 + lr;
-  const float* wrow = wcell < H ? J.Wp + (size_t)wcell * ldm : nullptr;
-  int arow[RT];
-  bool aok[RT], alive[RT];
+  const float* wrow = J.Wp + (size_t)min(wcell, H - 1) * ldm;
+  const bool wok = wcell < H;
+  int arow[RT], alen[RT];
 #pragma unroll
   for (int i = 0; i < RT; ++i) {
-    arow[i] = r0 + i * 16 + lr;
-    aok[i] = arow[i] < N;
-    alive[i] = aok[i] && (J.t < J.len[aok[i] ? arow[i] : 0]);
+    arow[i] = min(r0 + i * 16 + lr, N - 1);        // clamped: loads are unconditional, masks apply after
+    alen[i] = J.len[arow[i]];
   }
   const int nkb = (ldm + 15) >> 4, per = (nkb + NW - 1) / NW;
   const int jb = w * per, je = min(nkb, (w + 1) * per);
-  constexpr int CH = 5;
+  constexpr int CH = 3;
+  // all operand loads of this wave's K slice are issued before anything is consumed
+  float4 av[CH][RT], dv[CH][RT], bv[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int k = min((jb + c) * 16 + 4 * q, ldm - 4);
+    bv[c] = *reinterpret_cast<const float4*>(wrow + k);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      av[c][i] = *reinterpret_cast<const float4*>(J.dmst + (size_t)arow[i] * ldm + k);
+      dv[c][i] = J.dout ? *reinterpret_cast<const float4*>(J.dout + (size_t)arow[i] * ldm + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  // epilogue operands (one (row, cell) per thread when NW == 8), in flight with the above
+  float eg[4] = {0.f, 0.f, 0.f, 0.f}, ecp = 0.f, ecn = 0.f, edc = 0.f, ewo = 0.f, ewi = 0.f, ewf = 0.f;
+  int elen = 0;
+  const int e_i = tid >> 8, e_r = (tid >> 4) & 15, e_c = tid & 15;
+  const int erow = r0 + e_i * 16 + e_r, ecell = c0 + e_c;
+  const bool evalid = (NW == 8) && erow < N && ecell < H;
+  if (evalid) {
+    const float* g = J.gates + (size_t)erow * H4 + ecell;
+    eg[0] = g[0]; eg[1] = g[H]; eg[2] = g[2 * H]; eg[3] = g[3 * H];
+    const size_t ci = (size_t)erow * H + ecell;
+    ecp = J.c_prev[ci]; ecn = J.c_cur[ci]; edc = J.dc[ci];
+    ewo = J.wo[ecell]; ewi = J.wi[ecell]; ewf = J.wf[ecell];
+    elen = J.len[erow];
+  }
   f32x4 acc[RT];
 #pragma unroll
   for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int j0 = jb; j0 < je; j0 += CH) {
-    float4 av[CH][RT], bv[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int k = (j0 + c) * 16 + 4 * q;
-      const bool ok = (j0 + c < je) && (k < ldm);
-      bv[c] = (ok && wrow) ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = 0; c < CH; ++c) {
+    const int k = (jb + c) * 16 + 4 * q;
+    const bool kok = (jb + c < je) && (k < ldm);
+    float4 b = bv[c];
+    if (!(kok && wok)) b = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok && alive[i]) {
-          a = *reinterpret_cast<const float4*>(J.dmst + (size_t)arow[i] * ldm + k);
-          if (J.dout) {
-            const float4 d = *reinterpret_cast<const float4*>(J.dout + (size_t)arow[i] * ldm + k);
-            a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
-          }
-        }
-        if (ok && aok[i] && cb == 0) *reinterpret_cast<float4*>(J.dmt + (size_t)arow[i] * ldm + k) = a;
-        av[c][i] = a;
-      }
+    for (int i = 0; i < RT; ++i) {
+      float4 a = av[c][i];
+      a.x += dv[c][i].x; a.y += dv[c][i].y; a.z += dv[c][i].z; a.w += dv[c][i].w;
+      const bool rowok = (r0 + i * 16 + lr) < N;
+      if (!(kok && rowok && J.t < alen[i])) a = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (kok && rowok && cb == 0) *reinterpret_cast<float4*>(J.dmt + (size_t)arow[i] * ldm + k) = a;
+      av[c][i] = a;
     }
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].x, bv[c].x, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].y, bv[c].y, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].z, bv[c].z, acc[i], 0, 0, 0);
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].w, bv[c].w, acc[i], 0, 0, 0);
-      }
+    bv[c] = b;
   }
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].x, bv[c].x, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].y, bv[c].y, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].z, bv[c].z, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].w, bv[c].w, acc[i], 0, 0, 0);
+  }
+  static_assert(NW == 8, "k_bwd_a: 8 waves x 3 k-blocks cover K <= 384 floats; one epilogue element per thread");
 #pragma unroll
   for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) zs[w][i][q * 4 + r][lr] = acc[i][r];
   __syncthreads();
-  for (int e = tid; e < RT * 256; e += 64 * NW) {
-    const int i = e >> 8, er = (e >> 4) & 15, ec = e & 15;
-    const int row = r0 + i * 16 + er, cell = c0 + ec;
-    if (row >= N || cell >= H) continue;
-    float* g = J.gates + (size_t)row * H4 + cell;
-    if (J.t < J.len[row]) {
+  if (evalid) {
+    float* g = J.gates + (size_t)erow * H4 + ecell;
+    if (J.t < elen) {
       float dh = 0.f;
 #pragma unroll
-      for (int s = 0; s < NW; ++s) dh += zs[s][i][er][ec];
-      const size_t ci = (size_t)row * H + cell;
-      const float gi = g[0], gj = g[H], gf = g[2 * H], go = g[3 * H];
-      const float cp = J.c_prev[ci], cn = J.c_cur[ci];
-      const float tc = tanhf(cn);
+      for (int s2 = 0; s2 < NW; ++s2) dh += zs[s2][e_i][e_r][e_c];
+      const size_t ci = (size_t)erow * H + ecell;
+      const float gi = eg[0], gj = eg[1], gf = eg[2], go = eg[3];
+      const float tc = tanhf(ecn);
       const float dao = dh * tc * go * (1.f - go);
-      const float dcn = J.dc[ci] + dh * go * (1.f - tc * tc) + dao * J.wo[cell];
-      const float daf = dcn * cp * gf * (1.f - gf);
+      const float dcn = edc + dh * go * (1.f - tc * tc) + dao * ewo;
+      const float daf = dcn * ecp * gf * (1.f - gf);
       const float dai = dcn * gj * gi * (1.f - gi);
       const float dj = dcn * gi * (1.f - gj * gj);
-      J.dc[ci] = dcn * gf + dai * J.wi[cell] + daf * J.wf[cell];
+      J.dc[ci] = dcn * gf + dai * ewi + daf * ewf;
       g[0] = dai; g[H] = dj; g[2 * H] = daf; g[3 * H] = dao;
     } else {
       g[0] = 0.f; g[H] = 0.f; g[2 * H] = 0.f; g[3 * H] = 0.f;     // dc passes through unchanged
@@ -435,7 +467,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
 // ---------------------------------------------------------------------------------------
 // backward phase B: 32x16 tile of dz_t.K^T, K (=4H) split over NW waves
 // ---------------------------------------------------------------------------------------
-template <int NW, int VAR = 0>
+template <int NW, int VAR = 0, int CH = 6>
 __global__ __launch_bounds__(NW * 64) void k_bwd_b(const BwdBJobs jobs) {
   __shared__ float zs[NW][RT][16][17];
   const int bid = blockIdx.x;
@@ -458,50 +490,61 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_b(const BwdBJobs jobs) {
     s0.a[i] = arow < N ? J.dz + (size_t)arow * H4 : nullptr;
     s1.a[i] = nullptr;
   }
+  // epilogue read-modify-write operands, prefetched (first RT*256 threads own one output each)
+  const int e_i = tid >> 8, e_r = (tid >> 4) & 15, e_c = tid & 15;
+  const int erow = r0 + e_i * 16 + e_r, enn = n0 + e_c;
+  const bool evalid = tid < RT * 256 && erow < N && enn < J.n_end;
+  float eold = 0.f;
+  float* edst = nullptr;
+  if (evalid) {
+    if (enn < J.I) {
+      edst = J.dx + (size_t)erow * J.lddx + enn;
+      if (J.dx_accumulate) eold = *edst;
+    } else {
+      edst = J.dmst + (size_t)erow * J.ldm + (enn - J.I);
+      if (!(J.t < J.len[erow])) eold = *edst;            // masked row: the carried gradient passes through
+    }
+  }
   const int per = (s0.nkb + NW - 1) / NW;
   f32x4 acc[RT];
 #pragma unroll
   for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (VAR & 8) mma_2seg<RT, 6>(acc, s0, s1, w * per, min(s0.nkb, (w + 1) * per), q);      // un-pipelined
-  else mma_2seg_pipe<RT, 6, VAR>(acc, s0, s1, w * per, min(s0.nkb, (w + 1) * per), q);
+  if (VAR & 8) mma_2seg<RT, CH>(acc, s0, s1, w * per, min(s0.nkb, (w + 1) * per), q);      // un-pipelined
+  else mma_2seg_pipe<RT, CH, VAR>(acc, s0, s1, w * per, min(s0.nkb, (w + 1) * per), q);
 #pragma unroll
   for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) zs[w][i][q * 4 + r][lr] = acc[i][r];
   __syncthreads();
-  for (int e = tid; e < RT * 256; e += 64 * NW) {
-    const int i = e >> 8, er = (e >> 4) & 15, ec = e & 15;
-    const int row = r0 + i * 16 + er, nn = n0 + ec;
-    if (row >= N || nn >= J.n_end) continue;
-    float v = 0.f;
+  if (evalid) {
+    float v = eold;
 #pragma unroll
-    for (int s = 0; s < NW; ++s) v += zs[s][i][er][ec];
-    if (nn < J.I) {
-      float* d = J.dx + (size_t)row * J.lddx + nn;
-      *d = J.dx_accumulate ? (*d + v) : v;
-    } else {
-      float* d = J.dmst + (size_t)row * J.ldm + (nn - J.I);
-      const bool live = J.t < J.len[row];
-      *d = (live ? 0.f : *d) + v;
-    }
+    for (int s2 = 0; s2 < NW; ++s2) v += zs[s2][e_i][e_r][e_c];
+    *edst = v;
   }
 }
 
 // total blocks of a job list and blk_base assignment happen on the host (model.cpp); `kb_max` is
 // the largest k-block count over the jobs, which picks the K split.
+int g_gates_rows = 32;       // rows per k_fwd_gates workgroup (32 or 64); set once from RSRGAN_GATES_ROWS
+int fwd_gates_rows() { return g_gates_rows; }
+void set_fwd_gates_rows(int r) { g_gates_rows = (r == 64) ? 64 : 32; }
 void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
-  // dynamic LDS: the widest job's A tile (32 rows x SA floats) rounded to the 8 KB DMA granule of the
-  // 8 waves, and at least the 17 KB reduction buffer
+  // dynamic LDS: the widest job's A tile (rows x SA floats) rounded to the 8 KB DMA granule of the
+  // 8 waves, and at least the reduction buffer
   const int ktot = kb_max * 16;
-  size_t lds = (size_t)16 * RT * gates_sa4(ktot) * 16;
+  const int rtg = g_gates_rows / 16;
+  size_t lds = (size_t)16 * rtg * gates_sa4(ktot) * 16;
   lds = (lds + 8191) / 8192 * 8192;
-  if (lds < 8 * RT * 16 * 17 * sizeof(float)) lds = 8 * RT * 16 * 17 * sizeof(float);
+  if (lds < 8 * rtg * 16 * 17 * sizeof(float)) lds = 8 * rtg * 16 * 17 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_gates<18>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_gates<18, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_gates<18, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_fwd_gates<18>, dim3(total_blocks), dim3(512), lds, s, jobs);
+  if (rtg == 2) hipLaunchKernelGGL((k_fwd_gates<18, 2>), dim3(total_blocks), dim3(512), lds, s, jobs);
+  else hipLaunchKernelGGL((k_fwd_gates<18, 4>), dim3(total_blocks), dim3(512), lds, s, jobs);
 }
 void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
   if (kb_max <= 24)
@@ -510,12 +553,14 @@ void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, int kb_max, hipS
     hipLaunchKernelGGL(k_fwd_proj<8>, dim3(total_blocks), dim3(512), 0, s, jobs);
 }
 void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
-  (void)kb_max;
-  hipLaunchKernelGGL(k_bwd_a<4>, dim3(total_blocks), dim3(256), 0, s, jobs);
+  (void)kb_max;      // host asserts kb_max <= 24 (proj width <= 384)
+  hipLaunchKernelGGL(k_bwd_a<8>, dim3(total_blocks), dim3(512), 0, s, jobs);
 }
 void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
-  (void)kb_max;      // 8 waves split K; each runs a double-buffered 6-k-block register pipeline
-  hipLaunchKernelGGL(k_bwd_b<8>, dim3(total_blocks), dim3(512), 0, s, jobs);
+  if (kb_max <= 64)  // small K (the discriminator alone): 8 waves x <= 8 k-blocks, one load round, no pipeline
+    hipLaunchKernelGGL((k_bwd_b<8, 8, 8>), dim3(total_blocks), dim3(512), 0, s, jobs);
+  else               // 8 waves split K; each runs a double-buffered 6-k-block register pipeline
+    hipLaunchKernelGGL((k_bwd_b<8, 0, 6>), dim3(total_blocks), dim3(512), 0, s, jobs);
 }
 // micro-benchmark variants (rsrgan_microbench): see VAR above; 8 = un-pipelined, 16 = 16 waves
 void launch_bwd_b_variant(const BwdBJobs& jobs, int total_blocks, int variant, hipStream_t s) {

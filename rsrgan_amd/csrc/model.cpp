@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 
@@ -107,6 +108,7 @@ static void alloc_stash(Model& M, LstmStash& S, const LstmLayer& L, int N, int T
 
 int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   cfg = c;
+  if (const char* e = getenv("RSRGAN_GATES_ROWS")) set_fwd_gates_rows(atoi(e));
   B = c.batch_size; Tmax = c.max_frames; Din = c.input_dim; Dout = c.output_dim;
   ldDin = pad4(Din); ldDout = pad4(Dout);
   if (B <= 0 || Tmax <= 0 || Din <= 0 || Dout <= 0 || c.g_layers <= 0 || c.d_layers <= 0 || c.g_cells <= 0 ||
@@ -118,6 +120,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     set_error("num_proj=None (proj <= 0) is not supported yet");
     return RSRGAN_ERR_INVALID;
   }
+  if (c.g_proj > 384 || c.d_proj > 384) { set_error("num_proj > 384 is not supported by k_bwd_a (8 waves x 3 k-blocks)"); return RSRGAN_ERR_INVALID; }
   if (c.d_type != RSRGAN_D_LSTM) { set_error("Unrecognized D type %d", c.d_type); return RSRGAN_ERR_INVALID; }
   const int P = c.g_proj, H = c.g_cells;
   // ---- variable tables in graph-construction order (gan_rnn_placeholder.py:301-317) ----
@@ -357,7 +360,7 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
         for (int t = 0; t < T; ++t) {
           FwdGateJobs gj{}; gj.n = 1; gj.forget_bias = cfg.forget_bias;
           fill_gate(gj.j[0], R, t, zx); gj.j[0].blk_base = 0;
-          launch_fwd_gates(gj, job_blocks(gj.j[0].nblk_c, R.N), (zx ? 0 : kb16(R.L->ldI)) + kb16(R.L->ldP), s);
+          launch_fwd_gates(gj, job_blocks(gj.j[0].nblk_c, R.N, fwd_gates_rows()), (zx ? 0 : kb16(R.L->ldI)) + kb16(R.L->ldP), s);
           FwdProjJobs pj{}; pj.n = 1;
           fill_proj(pj.j[0], R, t); pj.j[0].blk_base = 0;
           launch_fwd_proj(pj, job_blocks(pj.j[0].nblk_c, R.N), kb16(R.L->ldH), s);
@@ -389,7 +392,7 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
         if (t < 0 || t >= T) continue;
         const LayerRun& R = ch[l];
         if (gj.n == MAXJ) flush_g();
-        FwdGateJob& a = gj.j[gj.n++]; fill_gate(a, R, t, R.zx_batched); a.blk_base = gb; gb += job_blocks(a.nblk_c, R.N);
+        FwdGateJob& a = gj.j[gj.n++]; fill_gate(a, R, t, R.zx_batched); a.blk_base = gb; gb += job_blocks(a.nblk_c, R.N, fwd_gates_rows());
         gk = std::max(gk, (R.zx_batched ? 0 : kb16(R.L->ldI)) + kb16(R.L->ldP));
       }
     }
