@@ -1,0 +1,95 @@
+"""Feature pipeline between the ark reader and GAN_RNN.d_step/g_step: global CMVN
+(io_funcs/make_tfrecords.py:84-87), Kaldi-style splicing (io_funcs/tfrecords_io.py:177-203) and
+length-bucketed, zero-padded batches (io_funcs/tfrecords_dataset.py:139-175)."""
+from __future__ import annotations
+
+import random
+from typing import Iterator, List, Optional
+
+import numpy as np
+
+from .kaldi_ark import ArkReader
+
+
+def apply_cmvn(inputs, labels, cmvn):
+    """make_tfrecords.py:84-87: float64 arithmetic, (x - mean) / stddev."""
+    inputs = (np.asarray(inputs, np.float64) - cmvn["mean_inputs"]) / cmvn["stddev_inputs"]
+    if labels is not None:
+        labels = (np.asarray(labels, np.float64) - cmvn["mean_labels"]) / cmvn["stddev_labels"]
+    return inputs, labels
+
+
+def splice_feats(feats, left, right):
+    """tfrecords_io.py:177-203: [row, col] -> [row, col*(left+1+right)].  The i-th left context is
+    feats shifted down by i with the first row repeated (tf.pad SYMMETRIC one row at a time), the
+    i-th right context is feats shifted up by i with the last row repeated; order: left far..near,
+    centre, right near..far."""
+    feats = np.asarray(feats)
+    row = feats.shape[0]
+    idx = np.arange(row)
+    parts = [feats[np.maximum(idx - i, 0)] for i in range(left, 0, -1)]
+    parts.append(feats)
+    parts += [feats[np.minimum(idx + i, row - 1)] for i in range(1, right + 1)]
+    return np.concatenate(parts, 1)
+
+
+class PaddedBatchReader(object):
+    """get_padded_batch (tfrecords_dataset.py:53-180) without TFRecords: reads (inputs, labels)
+    utterance pairs from two scp files, applies CMVN and splicing, groups utterances into windows of
+    `batch_size` by length bucket (start 200 frames, width 50, ids clipped at num_buckets, :157-171),
+    pads each batch with zeros to its longest utterance and yields
+    [utt_ids, inputs [B,T,D*(L+1+R)] f32, labels [B,T,Dout] f32, lengths [B] i32] -- the items
+    train_one_iteration pops from its queue (train_gan_rnn_placeholder.py:67).  Partial windows are
+    emitted at the end of the data, like tf.contrib.data.group_by_window; the training loop skips them."""
+
+    def __init__(self, inputs_scp, labels_scp, batch_size, left_context=0, right_context=0, cmvn=None,
+                 num_buckets=20, shuffle=True, seed=None):
+        self.inputs, self.labels = ArkReader(), ArkReader()
+        self.inputs(inputs_scp)
+        self.labels(labels_scp)
+        assert self.inputs.utt_ids == self.labels.utt_ids, "inputs_utt_id == labels_utt_id (make_tfrecords.py:35)"
+        self.batch_size, self.left, self.right = batch_size, left_context, right_context
+        self.cmvn, self.num_buckets, self.shuffle = cmvn, num_buckets, shuffle
+        self.rng = random.Random(seed)
+
+    def __len__(self):
+        return len(self.inputs.utt_ids)
+
+    def _utt(self, i):
+        x = self.inputs.read_utt_data_from_index(i).astype(np.float64)
+        y = self.labels.read_utt_data_from_index(i).astype(np.float64)
+        if self.cmvn is not None:
+            x, y = apply_cmvn(x, y, self.cmvn)
+        return self.inputs.utt_ids[i], splice_feats(x, self.left, self.right).astype(np.float32), y.astype(np.float32)
+
+    def _pad(self, items):
+        T = max(x.shape[0] for _, x, _ in items)
+        ids = [u for u, _, _ in items]
+        X = np.zeros((len(items), T, items[0][1].shape[1]), np.float32)
+        Y = np.zeros((len(items), T, items[0][2].shape[1]), np.float32)
+        L = np.zeros(len(items), np.int32)
+        for b, (_, x, y) in enumerate(items):
+            X[b, :x.shape[0]] = x
+            Y[b, :y.shape[0]] = y
+            L[b] = x.shape[0]
+        return [ids, X, Y, L]
+
+    def __iter__(self) -> Iterator[List]:
+        order = list(range(len(self)))
+        if self.shuffle:
+            self.rng.shuffle(order)
+        windows = {}
+        for i in order:
+            item = self._utt(i)
+            if self.num_buckets > 1:
+                key = min(self.num_buckets, (item[1].shape[0] - 200) // 50)      # :157-165
+            else:
+                key = 0
+            w = windows.setdefault(key, [])
+            w.append(item)
+            if len(w) == self.batch_size:
+                yield self._pad(w)
+                windows[key] = []
+        for key in sorted(windows):
+            if windows[key]:
+                yield self._pad(windows[key])
