@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--gen-updates", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=int(os.environ.get("RSRGAN_FLAGS", "1")),
-                    help="library schedule flags: 1 = wavefront, 2 = hipGraph (include/rsrgan.h)")
+                    help="library schedule flags: 1 = wavefront, 4 = side-stream GEMM overlap (include/rsrgan.h)")
     a = ap.parse_args()
 
     from rsrgan_amd import GAN_RNN, dist as rdist

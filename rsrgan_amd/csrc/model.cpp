@@ -206,10 +206,18 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   size_t maxcols = 4 * (size_t)std::max(c.g_cells, c.d_cells);
   maxcols = std::max(maxcols, (size_t)std::max(ldP, ldDin));
   scratch = alloc<float>(std::max<size_t>(64 * maxcols, 1024));
+  scratch2 = alloc<float>(std::max<size_t>(64 * maxcols, 1024));
   g_fc_out_wT = alloc<float>((size_t)Dout * ldP);
+  if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) side = nullptr;
+  if (side) {
+    for (auto& e : ev_pool)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { side = nullptr; break; }
+  }
   gemm_ws_floats = (size_t)16 << 20;          // 64 MiB of split-K partial tiles
   gemm_ws = alloc<float>(gemm_ws_floats);
   if (!gemm_ws) gemm_ws_floats = 0;
+  gemm_ws2 = alloc<float>(gemm_ws_floats ? gemm_ws_floats : 1);
+  if (!gemm_ws2) side = nullptr;
   if (!scratch || !d_dB || !g_dB || !xd) { set_error("hipMalloc failed (activations)"); return RSRGAN_ERR_HIP; }
 
   // ---- initial values: xavier_initializer() uniform / zeros (models/lstm.py:86-87,93) ----
@@ -243,6 +251,12 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
 }
 
 void Model::destroy() {
+  if (side) {
+    (void)hipStreamSynchronize(side);
+    for (auto& e : ev_pool) if (e) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(side);
+    side = nullptr;
+  }
   for (void* p : allocs) (void)hipFree(p);
   allocs.clear();
 }
@@ -271,7 +285,8 @@ static inline int kb16(int ld) { return (ld + 15) >> 4; }
 
 void Model::gemm(const float* A, int lda, bool a_kc, const float* B_, int ldb, bool b_kc, float* C, int ldc, int M, int N,
                  int K, const float* bias, int act, float alpha, bool accumulate, hipStream_t s) {
-  launch_gemm(A, lda, a_kc, B_, ldb, b_kc, C, ldc, M, N, K, bias, act, alpha, accumulate, s, gemm_ws, gemm_ws_floats);
+  launch_gemm(A, lda, a_kc, B_, ldb, b_kc, C, ldc, M, N, K, bias, act, alpha, accumulate, s,
+              (side && s == side) ? gemm_ws2 : gemm_ws, gemm_ws_floats);
 }
 
 static void fill_gate(FwdGateJob& a, const LayerRun& R, int t, bool zx) {
@@ -421,19 +436,28 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
   }
 }
 
-void Model::layer_wgrads(const LayerRun& R, int T, hipStream_t s) {
+void Model::layer_wgrads_gemms(const LayerRun& R, int t0, int t1, bool accumulate, hipStream_t s) {
   const LstmLayer& L = *R.L; const LstmStash& S = *R.S; const ParamSet& ps = *R.ps;
-  const int H = L.H, H4 = 4 * H, Rws = T * R.N;      // needs Ns == N (rows contiguous over time)
+  const int H = L.H, H4 = 4 * H, Rws = (t1 - t0) * R.N;      // needs Ns == N (rows contiguous over time)
+  const size_t r0 = (size_t)t0 * R.N;
   float* dK = ps.Gd(L.tK);
-  // dK[0:I] = in^T . dZ ; dK[I:I+P] = m_{t-1}^T . dZ ; dWp = h^T . dm
-  gemm(R.in, L.ldI, false, S.gates, H4, false, dK, H4, L.I, H4, Rws, nullptr, 0, 0.f, false, s);
-  gemm(S.mst, L.ldP, false, S.gates, H4, false, dK + (size_t)L.I * H4, H4, L.P, H4, Rws, nullptr, 0, 0.f, false, s);
-  gemm(S.h, L.ldH, false, S.dmt, L.ldP, false, ps.Gd(L.tWp), L.ldP, H, L.P, Rws, nullptr, 0, 0.f, false, s);
-  launch_colsum(S.gates, H4, nullptr, 0, ps.Gd(L.tb), Rws, H4, scratch, s);
+  // dK[0:I] (+)= in^T . dZ ; dK[I:I+P] (+)= m_{t-1}^T . dZ ; dWp (+)= h^T . dm   over frames [t0, t1)
+  gemm(R.in + r0 * L.ldI, L.ldI, false, S.gates + r0 * H4, H4, false, dK, H4, L.I, H4, Rws, nullptr, 0, 0.f, accumulate, s);
+  gemm(S.mst + r0 * L.ldP, L.ldP, false, S.gates + r0 * H4, H4, false, dK + (size_t)L.I * H4, H4, L.P, H4, Rws, nullptr, 0, 0.f, accumulate, s);
+  gemm(S.h + r0 * L.ldH, L.ldH, false, S.dmt + r0 * L.ldP, L.ldP, false, ps.Gd(L.tWp), L.ldP, H, L.P, Rws, nullptr, 0, 0.f, accumulate, s);
+}
+void Model::layer_wgrads_colsums(const LayerRun& R, int T, hipStream_t s, float* scr) {
+  const LstmLayer& L = *R.L; const LstmStash& S = *R.S; const ParamSet& ps = *R.ps;
+  const int H = L.H, H4 = 4 * H, Rws = T * R.N;
+  launch_colsum(S.gates, H4, nullptr, 0, ps.Gd(L.tb), Rws, H4, scr, s);
   // peepholes: dw_i = sum dai*c_{t-1}; dw_f = sum daf*c_{t-1}; dw_o = sum dao*c_t
-  launch_colsum(S.gates, H4, S.c, H, ps.Gd(L.twi), Rws, H, scratch, s);
-  launch_colsum(S.gates + 2 * H, H4, S.c, H, ps.Gd(L.twf), Rws, H, scratch, s);
-  launch_colsum(S.gates + 3 * H, H4, S.c + (size_t)R.N * H, H, ps.Gd(L.two), Rws, H, scratch, s);
+  launch_colsum(S.gates, H4, S.c, H, ps.Gd(L.twi), Rws, H, scr, s);
+  launch_colsum(S.gates + 2 * H, H4, S.c, H, ps.Gd(L.twf), Rws, H, scr, s);
+  launch_colsum(S.gates + 3 * H, H4, S.c + (size_t)R.N * H, H, ps.Gd(L.two), Rws, H, scr, s);
+}
+void Model::layer_wgrads(const LayerRun& R, int T, hipStream_t s) {
+  layer_wgrads_gemms(R, 0, T, false, s);
+  layer_wgrads_colsums(R, T, s, (side && s == side) ? scratch2 : scratch);
 }
 
 void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const std::vector<int>* offsets,
@@ -467,6 +491,15 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
     last = std::max(last, (offsets ? (*offsets)[c] : 0) + (int)chains[c].size() - 1 + T - 1);
   if (fcs)
     for (auto& F : *fcs) last = std::max(last, F.offset + T - 1);
+  // Weight-gradient GEMMs ride a side stream in time chunks: a chunk [tb, te) of a chain is final once
+  // its bottom layer has passed time tb, i.e. after diagonal (T-1-tb) + off + Lc - 1.
+  const int nchunk = (overlap() && T >= 16) ? 4 : 1;
+  bool any_w = false;
+  for (auto& ch : chains) for (auto& R : ch) any_w |= R.want_wgrads;
+  const bool ovl = overlap() && any_w;
+  std::vector<int> chunk_done(chains.size(), 0);            // chunks already handed to the side stream
+  auto chunk_lo = [&](int c) { return T - ((c + 1) * T) / nchunk; };   // chunk c (c=0 = latest frames): [lo, hi)
+  auto chunk_hi = [&](int c) { return T - (c * T) / nchunk; };
   for (int d = 0; d <= last; ++d) {
     BwdAJobs aj{}; BwdBJobs bj{};
     int ab = 0, bb = 0, ak = 0, bk = 0;
@@ -505,10 +538,34 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
         bk = std::max(bk, kb16(F.ld_in));
       }
     flush_b();
+    if (ovl) {
+      for (size_t c = 0; c < chains.size(); ++c) {
+        Chain& ch = chains[c];
+        if (!ch[0].want_wgrads) continue;
+        const int off = offsets ? (*offsets)[c] : 0, Lc = (int)ch.size();
+        while (chunk_done[c] < nchunk && d >= (T - 1 - chunk_lo(chunk_done[c])) + off + Lc - 1) {
+          const int cc = chunk_done[c]++;
+          hipEvent_t ev = ev_pool[ev_next++ & 15];
+          (void)hipEventRecord(ev, s);
+          (void)hipStreamWaitEvent(side, ev, 0);
+          for (auto& R : ch)
+            if (R.want_wgrads) layer_wgrads_gemms(R, chunk_lo(cc), chunk_hi(cc), cc > 0, side);
+        }
+      }
+    }
   }
-  for (auto& ch : chains)
-    for (auto& R : ch)
-      if (R.want_wgrads) layer_wgrads(R, T, s);
+  if (ovl) {
+    for (auto& ch : chains)
+      for (auto& R : ch)
+        if (R.want_wgrads) layer_wgrads_colsums(R, T, side, scratch2);
+    hipEvent_t ev = ev_pool[ev_next++ & 15];
+    (void)hipEventRecord(ev, side);
+    (void)hipStreamWaitEvent(s, ev, 0);                     // join: the optimizer needs every gradient
+  } else {
+    for (auto& ch : chains)
+      for (auto& R : ch)
+        if (R.want_wgrads) layer_wgrads(R, T, s);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -687,10 +744,23 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   } else {
     int rc = prepare_batch(x, labels, lengths, T, s);
     if (rc) return rc;
-    g_forward(T, s);
+    if (!wavefront()) g_forward(T, s);
   }
-  launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, B, 0, s);
-  {
+  if (!reuse && wavefront()) {
+    // ONE forward wave: G's layers | per-step output FC (-> y_t and D's input rows, noise added) | D's layers
+    g_forward_head(T, s);
+    const int Lg = (int)gl.size();
+    std::vector<Chain> chains{g_chain(T), d_chain(B, B, 0)};
+    std::vector<int> offs{0, Lg + 1};
+    FcStage F;
+    F.offset = Lg; F.N = B; F.K = cfg.g_proj; F.D = Dout;
+    F.in = g_ins[Lg]; F.ld_in = pad4(cfg.g_proj); F.WT = g_fc_out_wT; F.bias = G.W(g_fc_out_b); F.noise = nf;
+    F.y = y_tm; F.ldy = ldDout; F.out2 = xd; F.ld2 = ldDout; F.Ns2 = B; F.row02 = 0;
+    std::vector<FcStage> fcs{F};
+    rnn_forward(chains, T, s, &offs, &fcs);
+    g_fwd_valid = true;
+  } else {
+    launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, B, 0, s);
     std::vector<Chain> chains(1, d_chain(B, B, 0));
     rnn_forward(chains, T, s);
   }
@@ -699,7 +769,7 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, B, 0, dyn + DYN_D_REAL, dyn + DYN_D_REAL, tmp3, s);
   launch_copy_f(tmp3 + 1, losses + 3, 1, s);
   const bool l2_on = !cfg.cross_validation && scal[RSRGAN_L2_SCALE] > 0.0;
-  if (want_grads && wavefront() && cfg.g_type == RSRGAN_G_LSTM) {
+  if (want_grads && wavefront()) {
     // ONE backward wave: D's layers (data gradient only) | per-step output-FC backward | G's layers.
     // dy[t] = lambda*(y-lab)/(B*T) (written first) + d g_adv/d y[t] (accumulated by D layer 0's phase B)
     const int R = T * B, Ld = (int)dl.size(), Lg = (int)gl.size();
@@ -719,8 +789,13 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     float* bufA = g_dA; float* bufB = g_dC;        // G-side gradient ping-pong (dy itself lives in g_dB)
     for (int l = Lg - 1; l >= 0; --l) {
       gch[l].want_wgrads = true;
-      gch[l].dout = bufA; gch[l].din = bufB; gch[l].din_accumulate = false;
-      std::swap(bufA, bufB);
+      if (cfg.g_type == RSRGAN_G_RES_LSTM_L) {     // d(inputs_l) = dx_l + d(inputs_{l+1}): one buffer, accumulated in place
+        gch[l].dout = g_dA; gch[l].din = l > 0 ? g_dA : nullptr; gch[l].din_accumulate = true;
+      } else {
+        const bool need = cfg.g_type == RSRGAN_G_LSTM || l > 0;      // lstm: d(h0) feeds the input FC
+        gch[l].dout = bufA; gch[l].din = need ? bufB : nullptr; gch[l].din_accumulate = false;
+        std::swap(bufA, bufB);
+      }
     }
     FcStage F;                                     // d(ins[L])[t] = dy[t] . W_out^T
     F.offset = Ld; F.N = B; F.K = Dout; F.D = P;
@@ -732,10 +807,12 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     // output FC parameter gradients (batched over time, dy is complete now)
     gemm(g_ins[Lg], ldP, false, dy, ldDout, false, G.Gd(g_fc_out_w), ldDout, P, Dout, R, nullptr, 0, 0.f, false, s);
     launch_colsum(dy, ldDout, nullptr, 0, G.Gd(g_fc_out_b), R, Dout, scratch, s);
-    // through leakyrelu and the input FC (models/lstm.py:82-87); bufA now holds d(h0)
-    launch_lrelu_bwd(g_h0, bufA, (size_t)R, P, ldP, cfg.lrelu_alpha, s);
-    gemm(x_tm, ldDin, false, bufA, ldP, false, G.Gd(g_fc_in_w), ldP, Din, P, R, nullptr, 0, 0.f, false, s);
-    launch_colsum(bufA, ldP, nullptr, 0, G.Gd(g_fc_in_b), R, P, scratch, s);
+    if (cfg.g_type == RSRGAN_G_LSTM) {
+      // through leakyrelu and the input FC (models/lstm.py:82-87); bufA now holds d(h0)
+      launch_lrelu_bwd(g_h0, bufA, (size_t)R, P, ldP, cfg.lrelu_alpha, s);
+      gemm(x_tm, ldDin, false, bufA, ldP, false, G.Gd(g_fc_in_w), ldP, Din, P, R, nullptr, 0, 0.f, false, s);
+      launch_colsum(bufA, ldP, nullptr, 0, G.Gd(g_fc_in_b), R, P, scratch, s);
+    }
     if (l2_on) {
       launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
       launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);

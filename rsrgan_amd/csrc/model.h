@@ -140,6 +140,15 @@ struct Model {
   void rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const std::vector<int>* offsets = nullptr,
                     const std::vector<FcStage>* fcs = nullptr);
   void layer_wgrads(const LayerRun& R, int T, hipStream_t s);
+  void layer_wgrads_gemms(const LayerRun& R, int t0, int t1, bool accumulate, hipStream_t s);
+  void layer_wgrads_colsums(const LayerRun& R, int T, hipStream_t s, float* scr);
+  // side stream: weight-gradient GEMMs (MFMA-bound) overlap the byte-bound backward wave
+  hipStream_t side = nullptr;
+  hipEvent_t ev_pool[16] = {};
+  int ev_next = 0;
+  float* gemm_ws2 = nullptr;
+  float* scratch2 = nullptr;
+  bool overlap() const { return side != nullptr && (cfg.flags & RSRGAN_FLAG_OVERLAP) != 0; }
   Chain g_chain(int T);
   Chain d_chain(int N, int Ns, int row0);
   void gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool b_kc, float* C, int ldc, int M, int N,
