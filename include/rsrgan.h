@@ -44,9 +44,10 @@ typedef enum rsrgan_status {
 } rsrgan_status;
 
 /* args.g_type (gan_rnn_placeholder.py:125-132) */
-enum { RSRGAN_G_LSTM = 0, RSRGAN_G_RES_LSTM_L = 1, RSRGAN_G_RES_LSTM_BASE = 2 };
-/* self.discriminator (gan_rnn_placeholder.py:117) */
-enum { RSRGAN_D_LSTM = 0 };
+enum { RSRGAN_G_LSTM = 0, RSRGAN_G_RES_LSTM_L = 1, RSRGAN_G_RES_LSTM_BASE = 2,
+       RSRGAN_G_DNN = 3 /* models/gan.py:109-110 + models/dnn.py: frame-level FC generator */ };
+/* self.discriminator (gan_rnn_placeholder.py:117; models/gan.py:104) */
+enum { RSRGAN_D_LSTM = 0, RSRGAN_D_DNN = 1 /* models/discriminator_dnn.py */ };
 /* which network a call addresses */
 enum { RSRGAN_NET_G = 0, RSRGAN_NET_D = 1 };
 
@@ -61,7 +62,8 @@ typedef enum rsrgan_scalar {
   RSRGAN_D_FAKE = 4,
   RSRGAN_L2_SCALE = 5,
   RSRGAN_CLIP_NORM = 6,
-  RSRGAN_ADAM_STEP = 7,       /* Adam's t (beta powers), for checkpoint/resume */
+  RSRGAN_ADAM_STEP = 7,       /* Adam's t (beta powers) of the generator, for checkpoint/resume */
+  RSRGAN_ADAM_STEP_D = 8,     /* Adam's t of the discriminator (frame-level GAN only: models/gan.py:125) */
   RSRGAN_SCALAR_COUNT_
 } rsrgan_scalar;
 
@@ -92,6 +94,10 @@ typedef struct rsrgan_cfg {
   float   forget_bias;     /* LSTMCell(forget_bias=1.0) (models/lstm.py:94) */
   int32_t cross_validation;/* 1 = the cross_validation=True twin: no L2 term (:253) */
   int32_t flags;           /* RSRGAN_FLAG_* */
+  /* frame-level GAN (models/gan.py:158-175): D sees concat(inputs[:, d_joint_off : +d_joint_dim], labels|G(x));
+   * d_joint_dim = 0 feeds D the 40-dim target only, as gan_rnn_placeholder.py:207-208 does */
+  int32_t d_joint_off;
+  int32_t d_joint_dim;
 } rsrgan_cfg;
 
 enum {
@@ -144,7 +150,9 @@ int rsrgan_forward_g(rsrgan_handle h, const float* x, const int32_t* lengths, in
  * (train_gan_rnn_placeholder.py:77-82).  labels [B,T,Dout].  noise_real/noise_fake
  * are the two gaussian_noise_layer draws ([B,Dout], broadcast over T,
  * utils/ops.py:19-30) or NULL for disc_noise_std == 0.  out_losses: DEVICE
- * float[3] = {d_rl, d_fk, d_loss}.  train=0 gives the eval fetch
+ * float[3] = {d_rl, d_fk, d_loss}.  For the frame-level GAN (g_type RSRGAN_G_DNN: models/gan.py,
+ * scripts/train_gan_dnn.py) the same entry points are used with T = 1, x [N,1,Din*(L+1+R)], labels
+ * [N,1,Dout]; lengths may be NULL there.  train=0 gives the eval fetch
  * (train_gan_rnn_placeholder.py:154-160): losses only, no update. */
 int rsrgan_d_step(rsrgan_handle h, const float* x, const float* labels, const int32_t* lengths,
                   int32_t T, const float* noise_real, const float* noise_fake,

@@ -58,6 +58,7 @@ class NetCfg:
     g_layers: int = 3
     g_cells: int = 760
     g_proj: int = 280
+    d_type: str = "lstm"              # "dnn" = models/discriminator_dnn.py applied per frame to the 40-dim target
     d_layers: int = 2
     d_cells: int = 256
     d_proj: int = 40
@@ -118,8 +119,14 @@ def g_param_specs(cfg: NetCfg) -> List[Tuple[str, Tuple[int, ...]]]:
 
 
 def d_param_specs(cfg: NetCfg) -> List[Tuple[str, Tuple[int, ...]]]:
-    """d_vars (models/discriminator_lstm.py:70-104)."""
+    """d_vars (models/discriminator_lstm.py:70-104 | models/discriminator_dnn.py:61-92)."""
     s: List[Tuple[str, Tuple[int, ...]]] = []
+    if cfg.d_type == "dnn":
+        dims = [cfg.output_dim] + [cfg.d_cells] * cfg.d_layers + [1]
+        for i in range(cfg.d_layers + 1):
+            n = "d_model/fully_connected" + ("" if i == 0 else "_%d" % i)
+            s += [(n + "/weights", (dims[i], dims[i + 1])), (n + "/biases", (dims[i + 1],))]
+        return s
     in_dim = cfg.output_dim
     r = _rec_dim(cfg.d_cells, cfg.d_proj)
     for l in range(cfg.d_layers):
@@ -329,8 +336,23 @@ def gaussian_noise_layer(x, noise):
     return x if noise is None else x + noise
 
 
+D_CLIP = (-0.5, 1.5)          # models/discriminator_dnn.py:93
+
+
+def _dnn_names(cfg):
+    return ["d_model/fully_connected" + ("" if i == 0 else "_%d" % i) for i in range(cfg.d_layers + 1)]
+
+
 def discriminator_fwd(cfg: NetCfg, params, x, lengths, noise=None):
-    """discriminator_lstm (models/discriminator_lstm.py:24-110)."""
+    """discriminator_lstm (models/discriminator_lstm.py:24-110), or discriminator_dnn
+    (models/discriminator_dnn.py:21-98: no noise layer, ReLU FC stack, clip_by_value(-0.5, 1.5))."""
+    if cfg.d_type == "dnn":
+        acts = [x]
+        names = _dnn_names(cfg)
+        for i, n in enumerate(names):
+            z = acts[-1] @ params[n + "/weights"] + params[n + "/biases"]
+            acts.append(np.maximum(z, 0.0) if i < len(names) - 1 else z)
+        return np.clip(acts[-1], *D_CLIP), {"acts": acts}
     hp = cfg.d_proj > 0
     cache = {}
     ins = [gaussian_noise_layer(x, noise)]
@@ -345,6 +367,18 @@ def discriminator_fwd(cfg: NetCfg, params, x, lengths, noise=None):
 
 
 def discriminator_bwd(cfg: NetCfg, params, cache, dlogits, want_param_grads=True):
+    if cfg.d_type == "dnn":
+        acts, names, grads = cache["acts"], _dnn_names(cfg), {}
+        raw = acts[-1]
+        d = dlogits * ((raw >= D_CLIP[0]) & (raw <= D_CLIP[1]))
+        for i in range(len(names) - 1, -1, -1):
+            if i < len(names) - 1:
+                d = d * (acts[i + 1] > 0)
+            a2 = acts[i].reshape(-1, acts[i].shape[-1]); d2 = d.reshape(-1, d.shape[-1])
+            grads[names[i] + "/weights"] = a2.T @ d2
+            grads[names[i] + "/biases"] = d2.sum(0)
+            d = d @ params[names[i] + "/weights"].T
+        return d, (grads if want_param_grads else None)
     hp = cfg.d_proj > 0
     grads = {}
     ins = cache["ins"]

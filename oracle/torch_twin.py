@@ -66,6 +66,14 @@ def generator(cfg: NetCfg, P, x, lengths):
 
 
 def discriminator(cfg: NetCfg, P, x, lengths, noise=None):
+    if cfg.d_type == "dnn":                      # models/discriminator_dnn.py:61-93 (no noise layer)
+        h = x
+        for i in range(cfg.d_layers + 1):
+            n = "d_model/fully_connected" + ("" if i == 0 else "_%d" % i)
+            h = h @ P[n + "/weights"] + P[n + "/biases"]
+            if i < cfg.d_layers:
+                h = torch.relu(h)
+        return torch.clamp(h, -0.5, 1.5)
     hp = cfg.d_proj > 0
     h = x if noise is None else x + noise
     for l in range(cfg.d_layers):

@@ -6,7 +6,8 @@ hand-written HIP kernels behind the C ABI of include/rsrgan.h (rsrgan_amd/lib/li
 there is NO CPU fallback: constructing a model without the library or without a GPU raises.
 """
 from .gan_rnn import GAN_RNN, Model                      # noqa: F401
+from .gan import GAN                                     # noqa: F401
 from .train import (train_one_iteration, eval_one_iteration,   # noqa: F401
                     exponential_decay)
 
-__all__ = ["GAN_RNN", "Model", "train_one_iteration", "eval_one_iteration", "exponential_decay"]
+__all__ = ["GAN_RNN", "GAN", "Model", "train_one_iteration", "eval_one_iteration", "exponential_decay"]

@@ -1,0 +1,120 @@
+// dnn.cpp -- fully-connected stacks: the frame-level DNN-GAN (models/gan.py:GAN, generator
+// models/dnn.py:DNN, discriminator models/discriminator_dnn.py) and discriminator_dnn as the D of the
+// sequence model.  Everything here is time-batched fp32-MFMA GEMM (gemm.hip) plus small epilogue kernels:
+//   forward  h_{l+1} = relu(h_l . W_l + b_l)            (last layer linear)              dnn.py:79-110
+//   backward dW_l = h_l^T . d ; db_l = colsum(d) ; d <- (d . W_l^T) * [h_l > 0]
+#include "model.h"
+
+namespace rsr {
+
+#define HIPC(expr)                                                                   \
+  do {                                                                               \
+    hipError_t e_ = (expr);                                                          \
+    if (e_ != hipSuccess) {                                                          \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return RSRGAN_ERR_HIP;                                                         \
+    }                                                                                \
+  } while (0)
+
+static const float kDClipLo = -0.5f, kDClipHi = 1.5f;     // discriminator_dnn.py:93 tf.clip_by_value(y, -0.5, 1.5)
+
+void Model::fc_forward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, hipStream_t s) {
+  for (size_t l = 0; l < L.size(); ++l)
+    gemm(act[l], L[l].ld_in, true, ps.W(L[l].tW), L[l].ld_out, false, act[l + 1], L[l].ld_out, rows, L[l].out, L[l].in,
+         ps.W(L[l].tb), l + 1 < L.size() ? 2 : 0, 0.f, false, s);
+}
+
+// dtop: gradient w.r.t. the stack's (linear) output, [rows][ld_out of the last layer].  Returns the gradient w.r.t.
+// the stack's input (in fc_dA or fc_dB, leading dimension = ld_in of layer 0) when want_din, else nullptr.
+float* Model::fc_backward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, float* dtop,
+                          bool want_wgrads, bool want_din, hipStream_t s) {
+  float* d = dtop;
+  float* bufs[2] = {fc_dA, fc_dB};
+  int nb = 0;
+  for (int l = (int)L.size() - 1; l >= 0; --l) {
+    const FcLayer& F = L[l];
+    if (l + 1 < (int)L.size()) launch_lrelu_bwd(act[l + 1], d, (size_t)rows, F.out, F.ld_out, 0.f, s);   // relu': d *= [h > 0]
+    if (want_wgrads) {
+      gemm(act[l], F.ld_in, false, d, F.ld_out, false, ps.Gd(F.tW), F.ld_out, F.in, F.out, rows, nullptr, 0, 0.f, false, s);
+      launch_colsum(d, F.ld_out, nullptr, 0, ps.Gd(F.tb), rows, F.out, scratch, s);
+    }
+    if (l > 0 || want_din) {
+      float* dn = bufs[nb]; nb ^= 1;
+      if (dn == d) { dn = bufs[nb]; nb ^= 1; }
+      gemm(d, F.ld_out, true, ps.W(F.tW), F.ld_out, true, dn, F.ld_in, rows, F.in, F.out, nullptr, 0, 0.f, false, s);
+      d = dn;
+    } else {
+      d = nullptr;
+    }
+  }
+  return d;
+}
+
+// D(.) on d_act[0] ([T][Nd] rows), clipped LSGAN losses, dlogits
+void Model::d_dnn_forward_loss(int T, int Nd, int n_real, bool want_grads, float* loss3, hipStream_t s) {
+  fc_forward(D, dfc, d_act, T * Nd, s);
+  launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, Nd, n_real, dyn + DYN_D_REAL,
+               n_real > 0 ? dyn + DYN_D_FAKE : dyn + DYN_D_REAL, loss3, s, true, kDClipLo, kDClipHi);
+}
+
+// ---- frame-level GAN: sess.run([model.d_opt, ...]) of scripts/train_gan_dnn.py on [N, Din*(L+1+R)] frames ----
+int Model::dnn_d_backward(const float* x, const float* labels, int T, float* out_losses, bool want_grads, hipStream_t s) {
+  const int R = T * B;
+  if (!x || !labels) { set_error("null input pointer"); return RSRGAN_ERR_INVALID; }
+  if (T <= 0 || T > Tmax) { set_error("T=%d outside (0, max_frames=%d]", T, Tmax); return RSRGAN_ERR_INVALID; }
+  launch_pack_tm(x, x_tm, B, T, Din, ldDin, s);
+  launch_pack_tm(labels, lab_tm, B, T, Dout, ldDout, s);
+  cur_T = T;
+  fc_forward(G, gfc, g_act, R, s);                       // g = self.generator(inputs, ...)  gan.py:171
+  g_fwd_valid = true;
+  // d_rl_joint = concat(d_inputs, labels) ; d_fk_joint = concat(d_inputs, g)   gan.py:173-174
+  launch_build_joint(x_tm, ldDin, cfg.d_joint_off, cfg.d_joint_dim, lab_tm, ldDout, Dout, joint, ldJ, 0, R, s);
+  launch_build_joint(x_tm, ldDin, cfg.d_joint_off, cfg.d_joint_dim, y_tm, ldDout, Dout, joint, ldJ, R, R, s);
+  d_dnn_forward_loss(1, 2 * R, R, want_grads, losses, s);
+  if (want_grads) {
+    fc_backward(D, dfc, d_act, 2 * R, dlogits, true, false, s);
+    d_grads_ready = true;
+  }
+  if (out_losses) launch_copy_f(losses, out_losses, 3, s);
+  HIPC(hipGetLastError());
+  return RSRGAN_OK;
+}
+
+int Model::dnn_g_backward(const float* x, const float* labels, int T, float* out_losses, bool want_grads, bool reuse, hipStream_t s) {
+  const int R = T * B;
+  if (reuse) {
+    if (!g_fwd_valid || T != cur_T) { set_error("reuse_g_forward without a valid generator forward"); return RSRGAN_ERR_STATE; }
+  } else {
+    if (!x || !labels) { set_error("null input pointer"); return RSRGAN_ERR_INVALID; }
+    if (T <= 0 || T > Tmax) { set_error("T=%d outside (0, max_frames=%d]", T, Tmax); return RSRGAN_ERR_INVALID; }
+    launch_pack_tm(x, x_tm, B, T, Din, ldDin, s);
+    launch_pack_tm(labels, lab_tm, B, T, Dout, ldDout, s);
+    cur_T = T;
+    fc_forward(G, gfc, g_act, R, s);
+    g_fwd_valid = true;
+  }
+  launch_build_joint(x_tm, ldDin, cfg.d_joint_off, cfg.d_joint_dim, y_tm, ldDout, Dout, joint, ldJ, 0, R, s);
+  d_dnn_forward_loss(1, R, 0, want_grads, tmp3, s);      // g_adv = mean((D(fake) - 1)^2)  gan.py:202
+  launch_copy_f(tmp3 + 1, losses + 3, 1, s);
+  const bool l2_on = !cfg.cross_validation && scal[RSRGAN_L2_SCALE] > 0.0;
+  if (want_grads) {
+    float* dj = fc_backward(D, dfc, d_act, R, dlogits, false, true, s);                 // d g_adv / d joint
+    launch_slice_cols(dj, ldJ, cfg.d_joint_dim, dy_buf, ldDout, R, Dout, s);            // ... / d g
+    launch_mse(y_tm, lab_tm, ldDout, dy_buf, R, Dout, dyn + DYN_LAMBDA, true, losses + 4, scratch, s);
+    fc_backward(G, gfc, g_act, R, dy_buf, true, false, s);
+    if (l2_on) {
+      launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
+      launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);
+    }
+    g_grads_ready = true;
+  } else {
+    launch_mse(y_tm, lab_tm, ldDout, nullptr, R, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s);
+  }
+  if (!(want_grads && l2_on)) HIPC(hipMemsetAsync(losses + 5, 0, sizeof(float), s));
+  launch_g_total(losses + 3, dyn + DYN_LAMBDA, s);
+  if (out_losses) launch_copy_f(losses + 3, out_losses, 4, s);
+  HIPC(hipGetLastError());
+  return RSRGAN_OK;
+}
+
+}  // namespace rsr

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
         }
         float v = acc[i][j][r] + bv;
         if (act == 1) v = fmaxf(v, alpha * v);            // utils/ops.py:120-121 tf.maximum(x, alpha*x)
+        else if (act == 2) v = fmaxf(v, 0.f);             // tf.nn.relu (models/dnn.py:36)
         float* c = C + (size_t)row * ldc + col;
         if (accumulate) v += *c;
         *c = v;
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
     for (int z = 0; z < splits; ++z) v += ws[((size_t)z * M + row) * ldw + col];
     if (bias) v += bias[col];
     if (act == 1) v = fmaxf(v, alpha * v);
+    else if (act == 2) v = fmaxf(v, 0.f);
     float* c = C + (size_t)row * ldc + col;
     if (accumulate) v += *c;
     *c = v;

@@ -12,7 +12,7 @@ constexpr int MAXJ = 8;   // (layer, t) jobs fused into one launch of a step ker
 
 // device-resident scalars (model.dyn): what the reference changes with tf.assign between steps
 enum { DYN_G_LR = 0, DYN_D_LR = 1, DYN_LAMBDA = 2, DYN_D_REAL = 3, DYN_D_FAKE = 4, DYN_L2 = 5, DYN_CLIP = 6,
-       DYN_B1 = 7, DYN_B2 = 8, DYN_EPS = 9, DYN_EMA = 10, DYN_ADAM_LRT = 11, DYN_COUNT = 16 };
+       DYN_B1 = 7, DYN_B2 = 8, DYN_EPS = 9, DYN_EMA = 10, DYN_ADAM_LRT = 11, DYN_ADAM_LRT_D = 12, DYN_COUNT = 16 };
 
 // ---------------------------------------------------------------- step kernels
 // Forward phase 1: z = zx | bias  (+ x_t . Kx) + m_{t-1} . Kh ; gates; c_t ; h_t
@@ -122,7 +122,11 @@ void launch_colsum(const float* a, int lda, const float* b, int ldb, float* out,
 // loss[0], the others target_fake and loss[1]; loss[2] = loss[0]+loss[1].  Means over T*n_real /
 // T*(Nd-n_real) entries.  dlogits[r][0] = 2*(l-target)/count  (nullptr = skip).
 void launch_lsgan(const float* logits, int ldl, float* dlogits, int T, int Nd, int n_real,
-                  const float* target_real, const float* target_fake, float* loss3, hipStream_t s);
+                  const float* target_real, const float* target_fake, float* loss3, hipStream_t s,
+                  bool clip_on = false, float clip_lo = 0.f, float clip_hi = 0.f);
+void launch_build_joint(const float* x, int ldx, int off, int dim, const float* tail, int ldt, int Dt, float* joint, int ldj,
+                        int row0, int R, hipStream_t s);
+void launch_slice_cols(const float* src, int lds, int off, float* dst, int ldd, int R, int C, hipStream_t s);
 // g_mse = 0.5*D*mean((y-lab)^2) ; dy (+)= lambda*(y-lab)/(B*T)   (dy nullptr = loss only)
 void launch_mse(const float* y, const float* lab, int ld, float* dy, int rows, int D, const float* lambda,
                 bool accumulate, float* loss_out, float* scratch /* >= 1024 floats */, hipStream_t s);
@@ -148,8 +152,8 @@ void launch_l2_total(const float* partial, int n_chunks, const float* l2_scale, 
 void launch_apply_sgd(float* w, const float* g, float* ema, const ChunkTable& ct, const float* partial,
                       const float* dyn, hipStream_t s);
 void launch_apply_adam(float* w, const float* g, float* m, float* v, float* ema, const ChunkTable& ct,
-                       const float* partial, const float* dyn, hipStream_t s);
-void launch_adam_tick(float* dyn, int* t, double b1, double b2, hipStream_t s);
+                       const float* partial, const float* dyn, hipStream_t s, int lrt_slot = DYN_ADAM_LRT);
+void launch_adam_tick(float* dyn, int* t, double b1, double b2, hipStream_t s, int lr_slot = DYN_G_LR, int lrt_slot = DYN_ADAM_LRT);
 // dense <-> padded flat copies (checkpoint / parity injection)
 void launch_pad_copy(const float* dense, float* padded, int rows, int cols, int ld, bool to_padded, hipStream_t s);
 

@@ -16,6 +16,8 @@
 // for the u-th of four consecutive MFMAs, which is why the forward pass keeps
 // k-contiguous transposed copies of the kernels (KxT, KhT, WpT) while the backward pass
 // reads the TF-layout originals (already k-contiguous for dz.K^T and dm.Wp^T).
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace rsr {
@@ -537,6 +539,12 @@ void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, int kb_max, hip
   size_t lds = (size_t)16 * rtg * gates_sa4(ktot) * 16;
   lds = (lds + 8191) / 8192 * 8192;
   if (lds < 8 * rtg * 16 * 17 * sizeof(float)) lds = 8 * rtg * 16 * 17 * sizeof(float);
+  // One WG per CU: a launch lasts as long as its most-loaded CU pulls operands (~12 B/clk/CU); with two
+  // resident WGs per CU some CUs get two heavy (K=560) WGs.  One slot per CU + heavy-first order makes
+  // the dispatcher list-schedule: light WGs (layer 0, D) finish early and pick up the leftovers.
+  static int one_per_cu = -1;
+  if (one_per_cu < 0) { const char* e = getenv("RSRGAN_GATES_ONE_PER_CU"); one_per_cu = e ? atoi(e) : 1; }
+  if (one_per_cu && total_blocks > 256 && lds < 84 * 1024) lds = 84 * 1024;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_gates<18, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -738,7 +746,8 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red) {
 
 __global__ __launch_bounds__(1024) void k_lsgan(const float* __restrict__ logits, int ldl, float* __restrict__ dlogits,
                                                 int T, int Nd, int n_real, const float* __restrict__ t_real,
-                                                const float* __restrict__ t_fake, float* __restrict__ loss3) {
+                                                const float* __restrict__ t_fake, float* __restrict__ loss3,
+                                                int clip_on, float clip_lo, float clip_hi) {
   __shared__ float red[16];
   const int rows = T * Nd;
   const float tr = *t_real, tf = *t_fake;
@@ -746,9 +755,12 @@ __global__ __launch_bounds__(1024) void k_lsgan(const float* __restrict__ logits
   float sr = 0.f, sf = 0.f;
   for (int r = threadIdx.x; r < rows; r += blockDim.x) {
     const bool real = (r % Nd) < n_real;
-    const float d = logits[(size_t)r * ldl] - (real ? tr : tf);
+    const float raw = logits[(size_t)r * ldl];
+    // discriminator_dnn.py:93 tf.clip_by_value(y, -0.5, 1.5): value clipped, gradient passes where lo <= y <= hi
+    const float val = clip_on ? fminf(fmaxf(raw, clip_lo), clip_hi) : raw;
+    const float d = val - (real ? tr : tf);
     if (real) sr += d * d; else sf += d * d;
-    if (dlogits) dlogits[(size_t)r * ldl] = 2.f * d / (real ? cr : cf);
+    if (dlogits) dlogits[(size_t)r * ldl] = (clip_on && (raw < clip_lo || raw > clip_hi)) ? 0.f : 2.f * d / (real ? cr : cf);
   }
   sr = block_sum_1024(sr, red);
   sf = block_sum_1024(sf, red);
@@ -759,8 +771,38 @@ __global__ __launch_bounds__(1024) void k_lsgan(const float* __restrict__ logits
   }
 }
 void launch_lsgan(const float* logits, int ldl, float* dlogits, int T, int Nd, int n_real,
-                  const float* t_real, const float* t_fake, float* loss3, hipStream_t s) {
-  hipLaunchKernelGGL(k_lsgan, dim3(1), dim3(1024), 0, s, logits, ldl, dlogits, T, Nd, n_real, t_real, t_fake, loss3);
+                  const float* t_real, const float* t_fake, float* loss3, hipStream_t s, bool clip_on, float clip_lo, float clip_hi) {
+  hipLaunchKernelGGL(k_lsgan, dim3(1), dim3(1024), 0, s, logits, ldl, dlogits, T, Nd, n_real, t_real, t_fake, loss3,
+                     clip_on ? 1 : 0, clip_lo, clip_hi);
+}
+
+// models/gan.py:158-175: joint[r] = concat(x[r][off : off+dim], tail[r][0 : Dt]); rows [row0, row0+R) of `joint`
+__global__ void k_build_joint(const float* __restrict__ x, int ldx, int off, int dim, const float* __restrict__ tail, int ldt, int Dt,
+                              float* __restrict__ joint, int ldj, int row0, int R) {
+  const int W = dim + Dt;
+  const size_t total = (size_t)R * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / W), c = (int)(i % W);
+    joint[(size_t)(row0 + r) * ldj + c] = c < dim ? x[(size_t)r * ldx + off + c] : tail[(size_t)r * ldt + (c - dim)];
+  }
+}
+void launch_build_joint(const float* x, int ldx, int off, int dim, const float* tail, int ldt, int Dt, float* joint, int ldj,
+                        int row0, int R, hipStream_t s) {
+  const size_t total = (size_t)R * (dim + Dt);
+  const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+  hipLaunchKernelGGL(k_build_joint, dim3(blocks), dim3(256), 0, s, x, ldx, off, dim, tail, ldt, Dt, joint, ldj, row0, R);
+}
+__global__ void k_slice_cols(const float* __restrict__ src, int lds_, int off, float* __restrict__ dst, int ldd, int R, int C) {
+  const size_t total = (size_t)R * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / C), c = (int)(i % C);
+    dst[(size_t)r * ldd + c] = src[(size_t)r * lds_ + off + c];
+  }
+}
+void launch_slice_cols(const float* src, int lds_, int off, float* dst, int ldd, int R, int C, hipStream_t s) {
+  const size_t total = (size_t)R * C;
+  const int blocks = (int)min((size_t)2048, (total + 255) / 256);
+  hipLaunchKernelGGL(k_slice_cols, dim3(blocks), dim3(256), 0, s, src, lds_, off, dst, ldd, R, C);
 }
 
 constexpr int MSE_BLOCKS = 256;
@@ -870,6 +912,7 @@ __device__ __forceinline__ float tensor_clip_scale(const ChunkTable& ct, const f
   float s = 0.f;
   for (int i = threadIdx.x; i < cnt; i += blockDim.x) s += partial[first + i];
   s = block_sum_1024(s, red);
+  if (!(clip > 0.f)) return 1.0f;       // models/gan.py:140-143 applies the averaged gradients unclipped
   // tf.clip_by_norm: t * clip * min(rsqrt(sum(t*t)), 1/clip)
   const float inv = s > 0.f ? 1.0f / sqrtf(s) : __builtin_inff();
   return clip * fminf(inv, 1.0f / clip);
@@ -894,11 +937,11 @@ void launch_apply_sgd(float* w, const float* g, float* ema, const ChunkTable& ct
 
 __global__ __launch_bounds__(256) void k_apply_adam(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, float* __restrict__ ema, ChunkTable ct,
-                                                    const float* __restrict__ partial, const float* __restrict__ dyn) {
+                                                    const float* __restrict__ partial, const float* __restrict__ dyn, int lrt_slot) {
   __shared__ float red[16];
   const int c = blockIdx.x;
   const float scale = tensor_clip_scale(ct, partial, c, dyn[DYN_CLIP], red);
-  const float b1 = dyn[DYN_B1], b2 = dyn[DYN_B2], eps = dyn[DYN_EPS], lrt = dyn[DYN_ADAM_LRT], dec = dyn[DYN_EMA];
+  const float b1 = dyn[DYN_B1], b2 = dyn[DYN_B2], eps = dyn[DYN_EPS], lrt = dyn[lrt_slot], dec = dyn[DYN_EMA];
   const int off = ct.off[c], n = ct.len[c];
   for (int i = threadIdx.x; i < n; i += 256) {
     const float gg = g[off + i] * scale;
@@ -911,21 +954,21 @@ __global__ __launch_bounds__(256) void k_apply_adam(float* __restrict__ w, const
   }
 }
 void launch_apply_adam(float* w, const float* g, float* m, float* v, float* ema, const ChunkTable& ct,
-                       const float* partial, const float* dyn, hipStream_t s) {
-  hipLaunchKernelGGL(k_apply_adam, dim3(ct.n_chunks), dim3(256), 0, s, w, g, m, v, ema, ct, partial, dyn);
+                       const float* partial, const float* dyn, hipStream_t s, int lrt_slot) {
+  hipLaunchKernelGGL(k_apply_adam, dim3(ct.n_chunks), dim3(256), 0, s, w, g, m, v, ema, ct, partial, dyn, lrt_slot);
 }
 
 // Adam's beta powers (tf.train.AdamOptimizer): t += 1; lr_t = lr*sqrt(1-b2^t)/(1-b1^t), on the
 // device so that a captured graph advances it on every replay.
-__global__ void k_adam_tick(float* dyn, int* t, double b1, double b2) {
+__global__ void k_adam_tick(float* dyn, int* t, double b1, double b2, int lr_slot, int lrt_slot) {
   if (threadIdx.x == 0) {
     const int tt = *t + 1;
     *t = tt;
-    dyn[DYN_ADAM_LRT] = (float)((double)dyn[DYN_G_LR] * sqrt(1.0 - pow(b2, (double)tt)) / (1.0 - pow(b1, (double)tt)));
+    dyn[lrt_slot] = (float)((double)dyn[lr_slot] * sqrt(1.0 - pow(b2, (double)tt)) / (1.0 - pow(b1, (double)tt)));
   }
 }
-void launch_adam_tick(float* dyn, int* t, double b1, double b2, hipStream_t s) {
-  hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(64), 0, s, dyn, t, b1, b2);
+void launch_adam_tick(float* dyn, int* t, double b1, double b2, hipStream_t s, int lr_slot, int lrt_slot) {
+  hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(64), 0, s, dyn, t, b1, b2, lr_slot, lrt_slot);
 }
 
 __global__ void k_pad_copy(const float* __restrict__ dense_c, float* __restrict__ dense_m, float* __restrict__ padded,

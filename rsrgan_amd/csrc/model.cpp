@@ -116,15 +116,24 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     set_error("invalid sizes in rsrgan_cfg");
     return RSRGAN_ERR_INVALID;
   }
-  if (c.g_proj <= 0 || c.d_proj <= 0) {
-    set_error("num_proj=None (proj <= 0) is not supported yet");
-    return RSRGAN_ERR_INVALID;
-  }
-  if (c.g_proj > 384 || c.d_proj > 384) { set_error("num_proj > 384 is not supported by k_bwd_a (8 waves x 3 k-blocks)"); return RSRGAN_ERR_INVALID; }
-  if (c.d_type != RSRGAN_D_LSTM) { set_error("Unrecognized D type %d", c.d_type); return RSRGAN_ERR_INVALID; }
+  if (c.d_type != RSRGAN_D_LSTM && c.d_type != RSRGAN_D_DNN) { set_error("Unrecognized D type %d", c.d_type); return RSRGAN_ERR_INVALID; }
+  if (g_dnn() && !d_dnn()) { set_error("the frame-level generator (dnn) needs discriminator_dnn (models/gan.py:104)"); return RSRGAN_ERR_INVALID; }
+  if (!g_dnn() && (c.g_proj <= 0 || c.g_proj > 384)) { set_error("generator num_proj must be in [1, 384] (num_proj=None is not supported)"); return RSRGAN_ERR_INVALID; }
+  if (!d_dnn() && (c.d_proj <= 0 || c.d_proj > 384)) { set_error("discriminator num_proj must be in [1, 384]"); return RSRGAN_ERR_INVALID; }
+  if (d_dnn() && (c.d_joint_dim < 0 || c.d_joint_off < 0 || c.d_joint_off + c.d_joint_dim > Din)) { set_error("bad d_joint slice"); return RSRGAN_ERR_INVALID; }
   const int P = c.g_proj, H = c.g_cells;
+  auto fc_name = [](const char* net, int i) { return std::string(net) + "/fully_connected" + (i == 0 ? "" : "_" + std::to_string(i)); };
+  auto add_fc = [&](ParamSet& ps, std::vector<FcLayer>& out, const std::string& nm, int in, int o) {
+    FcLayer F; F.in = in; F.out = o; F.ld_in = pad4(in); F.ld_out = pad4(o);
+    F.tW = ps.add(nm + "/weights", in, o, false); F.tb = ps.add(nm + "/biases", 1, o, true);
+    out.push_back(F);
+  };
   // ---- variable tables in graph-construction order (gan_rnn_placeholder.py:301-317) ----
-  if (c.g_type == RSRGAN_G_LSTM) {                                       // models/lstm.py:82-124
+  if (c.g_type == RSRGAN_G_DNN) {                                        // models/dnn.py:79-110: (1+3) x [FC units, ReLU], FC -> Dout
+    int in = Din;
+    for (int l = 0; l < c.g_layers; ++l) { add_fc(G, gfc, fc_name("g_model", l), in, c.g_cells); in = c.g_cells; }
+    add_fc(G, gfc, fc_name("g_model", c.g_layers), in, Dout);
+  } else if (c.g_type == RSRGAN_G_LSTM) {                                // models/lstm.py:82-124
     g_fc_in_w = G.add("g_model/fully_connected/weights", Din, P, false);
     g_fc_in_b = G.add("g_model/fully_connected/biases", 1, P, true);
     for (int l = 0; l < c.g_layers; ++l)
@@ -147,7 +156,11 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     set_error("Unrecognized G type %d", c.g_type);                       // gan_rnn_placeholder.py:131-132
     return RSRGAN_ERR_INVALID;
   }
-  {                                                                      // models/discriminator_lstm.py:70-104
+  if (d_dnn()) {                                                         // models/discriminator_dnn.py:61-92
+    int in = c.d_joint_dim + Dout;
+    for (int l = 0; l < c.d_layers; ++l) { add_fc(D, dfc, fc_name("d_model", l), in, c.d_cells); in = c.d_cells; }
+    add_fc(D, dfc, fc_name("d_model", c.d_layers), in, 1);
+  } else {                                                               // models/discriminator_lstm.py:70-104
     int in = Dout;
     for (int l = 0; l < c.d_layers; ++l) {
       add_lstm(D, dl, "d_model/rnn/multi_rnn_cell/cell_" + std::to_string(l) + "/lstm_cell", in, c.d_cells, c.d_proj);
@@ -161,6 +174,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   G.w = alloc<float>(G.padded); G.g = alloc<float>(G.padded); G.m = alloc<float>(G.padded); G.v = alloc<float>(G.padded);
   G.ema = ema_on ? alloc<float>(G.padded) : nullptr;
   D.w = alloc<float>(D.padded); D.g = alloc<float>(D.padded);
+  if (d_adam()) { D.m = alloc<float>(D.padded); D.v = alloc<float>(D.padded); }
   D.ema = ema_on ? alloc<float>(D.padded) : nullptr;
   if (!G.w || !G.g || !G.m || !G.v || !D.w || !D.g) { set_error("hipMalloc failed (parameters)"); return RSRGAN_ERR_HIP; }
   if (build_chunks(*this, G) || build_chunks(*this, D)) { set_error("hipMalloc failed (chunk tables)"); return RSRGAN_ERR_HIP; }
@@ -172,11 +186,15 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     }
   const size_t TB = (size_t)Tmax * B;
   x_tm = alloc<float>(TB * ldDin); lab_tm = alloc<float>(TB * ldDout); y_tm = alloc<float>(TB * ldDout);
-  const int ldP = pad4(P);
+  const int ldP = g_dnn() ? 4 : pad4(P);
   g_st.resize(gl.size());
   for (size_t l = 0; l < gl.size(); ++l) alloc_stash(*this, g_st[l], gl[l], B, Tmax);
   g_ins.resize(gl.size() + 1);
-  if (c.g_type == RSRGAN_G_LSTM) {
+  if (g_dnn()) {
+    g_act.push_back(x_tm);
+    for (size_t l = 0; l + 1 < gfc.size(); ++l) g_act.push_back(alloc<float>(TB * gfc[l].ld_out));
+    g_act.push_back(y_tm);
+  } else if (c.g_type == RSRGAN_G_LSTM) {
     g_h0 = alloc<float>(TB * ldP);
     g_ins[0] = g_h0;
     for (size_t l = 0; l < gl.size(); ++l) g_ins[l + 1] = g_st[l].out;
@@ -194,8 +212,23 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   const int gmaxld = std::max(ldP, ldDin);
   g_dA = alloc<float>(TB * gmaxld); g_dB = alloc<float>(TB * gmaxld); g_dC = alloc<float>(TB * gmaxld);
   const size_t TB2 = TB * 2;
-  const int ldPd = pad4(c.d_proj);
+  const int ldPd = d_dnn() ? 4 : pad4(c.d_proj);
   xd = alloc<float>(TB2 * ldDout); logits = alloc<float>(TB2 * 4); dlogits = alloc<float>(TB2 * 4);
+  if (d_dnn()) {
+    ldJ = pad4(c.d_joint_dim + Dout);
+    if (c.d_joint_dim > 0) joint = alloc<float>(TB2 * ldJ);
+    d_act.push_back(c.d_joint_dim > 0 ? joint : xd);
+    for (size_t l = 0; l + 1 < dfc.size(); ++l) d_act.push_back(alloc<float>(TB2 * dfc[l].ld_out));
+    d_act.push_back(logits);
+    dy_buf = alloc<float>(TB * ldDout);
+  }
+  if (g_dnn() || d_dnn()) {
+    int mx = std::max(ldJ, ldDin);
+    for (auto& F : gfc) mx = std::max(mx, std::max(F.ld_in, F.ld_out));
+    for (auto& F : dfc) mx = std::max(mx, std::max(F.ld_in, F.ld_out));
+    fc_dA = alloc<float>(TB2 * mx); fc_dB = alloc<float>(TB2 * mx);
+  }
+  adam_t_dev_d = alloc<int>(1);
   d_st.resize(dl.size());
   for (size_t l = 0; l < dl.size(); ++l) alloc_stash(*this, d_st[l], dl[l], 2 * B, Tmax);
   const int dmaxld = std::max(ldPd, ldDout);
@@ -204,10 +237,11 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   dyn = alloc<float>(DYN_COUNT); adam_t_dev = alloc<int>(1);
   losses = alloc<float>(8); tmp3 = alloc<float>(4);
   size_t maxcols = 4 * (size_t)std::max(c.g_cells, c.d_cells);
+  maxcols = std::max(maxcols, (size_t)Din + 4);
   maxcols = std::max(maxcols, (size_t)std::max(ldP, ldDin));
   scratch = alloc<float>(std::max<size_t>(64 * maxcols, 1024));
   scratch2 = alloc<float>(std::max<size_t>(64 * maxcols, 1024));
-  g_fc_out_wT = alloc<float>((size_t)Dout * ldP);
+  g_fc_out_wT = g_dnn() ? nullptr : alloc<float>((size_t)Dout * ldP);
   if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) side = nullptr;
   if (side) {
     for (auto& e : ev_pool)
@@ -271,7 +305,7 @@ void Model::refresh_transposes(int net, hipStream_t s) {
     launch_transpose(K + (size_t)L.I * H4, H4, L.KhT, L.ldP, L.P, H4, s);    // [P][4H] -> [4H][ldP]
     launch_transpose(ps.W(L.tWp), L.ldP, L.WpT, L.ldH, L.H, L.P, s);         // [H][ldP] -> [P][ldH]
   }
-  if (net == RSRGAN_NET_G && g_fc_out_wT)
+  if (net == RSRGAN_NET_G && g_fc_out_wT && g_fc_out_w >= 0)
     launch_transpose(G.W(g_fc_out_w), ldDout, g_fc_out_wT, pad4(cfg.g_proj), cfg.g_proj, Dout, s);   // [P][ldDout] -> [Dout][ldP]
 }
 
@@ -571,11 +605,13 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
 // ------------------------------------------------------------------------------------------
 int Model::prepare_batch(const float* x, const float* labels, const int32_t* lengths, int T, hipStream_t s) {
   if (T <= 0 || T > Tmax) { set_error("T=%d outside (0, max_frames=%d]", T, Tmax); return RSRGAN_ERR_INVALID; }
-  if (!x || !lengths) { set_error("null input pointer"); return RSRGAN_ERR_INVALID; }
+  if (!x || (!lengths && !g_dnn())) { set_error("null input pointer"); return RSRGAN_ERR_INVALID; }
   launch_pack_tm(x, x_tm, B, T, Din, ldDin, s);
   if (labels) launch_pack_tm(labels, lab_tm, B, T, Dout, ldDout, s);
-  HIPC(hipMemcpyAsync(len_dev, lengths, B * sizeof(int), hipMemcpyDeviceToDevice, s));
-  HIPC(hipMemcpyAsync(len_dev + B, lengths, B * sizeof(int), hipMemcpyDeviceToDevice, s));
+  if (lengths) {
+    HIPC(hipMemcpyAsync(len_dev, lengths, B * sizeof(int), hipMemcpyDeviceToDevice, s));
+    HIPC(hipMemcpyAsync(len_dev + B, lengths, B * sizeof(int), hipMemcpyDeviceToDevice, s));
+  }
   cur_T = T;
   g_fwd_valid = false;
   return RSRGAN_OK;
@@ -620,6 +656,7 @@ void Model::g_forward_tail(int T, hipStream_t s) {   // y = outputs.W + b (model
   g_fwd_valid = true;
 }
 void Model::g_forward(int T, hipStream_t s, Chain* extra) {
+  if (g_dnn()) { fc_forward(G, gfc, g_act, T * B, s); g_fwd_valid = true; return; }
   g_forward_head(T, s);
   std::vector<Chain> chains;
   chains.push_back(g_chain(T));
@@ -701,8 +738,10 @@ void Model::g_backward_pass(int T, float* dy, hipStream_t s) {
 int Model::d_backward(const float* x, const float* labels, const int32_t* lengths, int T, const float* nr, const float* nf,
                       float* out_losses, bool want_grads, hipStream_t s) {
   if (!labels) { set_error("labels required"); return RSRGAN_ERR_INVALID; }
+  if (g_dnn()) return dnn_d_backward(x, labels, T, out_losses, want_grads, s);
   int rc = prepare_batch(x, labels, lengths, T, s);
   if (rc) return rc;
+  if (d_dnn()) { nr = nullptr; nf = nullptr; }    // discriminator_dnn.py:58: the noise layer is commented out
   // discriminator input rows [0,B) = labels + noise_real (gan_rnn_placeholder.py:207,212; utils/ops.py:19-30)
   launch_add_noise_rows(lab_tm, nr, xd, B, T, Dout, ldDout, 2 * B, 0, s);
   if (wavefront()) {
@@ -710,8 +749,12 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
     // D(fake) two diagonals behind G's top layer
     g_forward_head(T, s);
     const int Lg = (int)gl.size(), ldP = pad4(cfg.g_proj);
-    std::vector<Chain> chains{g_chain(T), d_chain(B, 2 * B, 0), d_chain(B, 2 * B, B)};
-    std::vector<int> offs{0, 0, Lg + 1};
+    std::vector<Chain> chains{g_chain(T)};
+    std::vector<int> offs{0};
+    if (!d_dnn()) {
+      chains.push_back(d_chain(B, 2 * B, 0)); offs.push_back(0);
+      chains.push_back(d_chain(B, 2 * B, B)); offs.push_back(Lg + 1);
+    }
     FcStage F;
     F.offset = Lg; F.N = B; F.K = cfg.g_proj; F.D = Dout;
     F.in = g_ins[Lg]; F.ld_in = ldP; F.WT = g_fc_out_wT; F.bias = G.W(g_fc_out_b); F.noise = nf;
@@ -722,14 +765,21 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
   } else {
     g_forward(T, s);
     launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, 2 * B, B, s);
-    std::vector<Chain> chains(1, d_chain(2 * B, 2 * B, 0));
-    rnn_forward(chains, T, s);
+    if (!d_dnn()) {
+      std::vector<Chain> chains(1, d_chain(2 * B, 2 * B, 0));
+      rnn_forward(chains, T, s);
+    }
   }
-  d_logits(2 * B, T, s);
-  launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, 2 * B, B, dyn + DYN_D_REAL, dyn + DYN_D_FAKE, losses, s);
-  if (want_grads) {
-    d_backward_pass(2 * B, T, true, false, dlogits, s);
-    d_grads_ready = true;
+  if (d_dnn()) {
+    d_dnn_forward_loss(T, 2 * B, B, want_grads, losses, s);
+    if (want_grads) { fc_backward(D, dfc, d_act, T * 2 * B, dlogits, true, false, s); d_grads_ready = true; }
+  } else {
+    d_logits(2 * B, T, s);
+    launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, 2 * B, B, dyn + DYN_D_REAL, dyn + DYN_D_FAKE, losses, s);
+    if (want_grads) {
+      d_backward_pass(2 * B, T, true, false, dlogits, s);
+      d_grads_ready = true;
+    }
   }
   if (out_losses) launch_copy_f(losses, out_losses, 3, s);
   HIPC(hipGetLastError());
@@ -739,6 +789,8 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
 int Model::g_backward(const float* x, const float* labels, const int32_t* lengths, int T, const float* nf,
                       float* out_losses, bool want_grads, bool reuse, hipStream_t s) {
   if (!labels) { set_error("labels required"); return RSRGAN_ERR_INVALID; }
+  if (g_dnn()) return dnn_g_backward(x, labels, T, out_losses, want_grads, reuse, s);
+  if (d_dnn()) nf = nullptr;
   if (reuse) {
     if (!g_fwd_valid || T != cur_T) { set_error("reuse_g_forward without a valid generator forward"); return RSRGAN_ERR_STATE; }
   } else {
@@ -750,8 +802,9 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     // ONE forward wave: G's layers | per-step output FC (-> y_t and D's input rows, noise added) | D's layers
     g_forward_head(T, s);
     const int Lg = (int)gl.size();
-    std::vector<Chain> chains{g_chain(T), d_chain(B, B, 0)};
-    std::vector<int> offs{0, Lg + 1};
+    std::vector<Chain> chains{g_chain(T)};
+    std::vector<int> offs{0};
+    if (!d_dnn()) { chains.push_back(d_chain(B, B, 0)); offs.push_back(Lg + 1); }
     FcStage F;
     F.offset = Lg; F.N = B; F.K = cfg.g_proj; F.D = Dout;
     F.in = g_ins[Lg]; F.ld_in = pad4(cfg.g_proj); F.WT = g_fc_out_wT; F.bias = G.W(g_fc_out_b); F.noise = nf;
@@ -761,15 +814,31 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     g_fwd_valid = true;
   } else {
     launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, B, 0, s);
-    std::vector<Chain> chains(1, d_chain(B, B, 0));
-    rnn_forward(chains, T, s);
+    if (!d_dnn()) {
+      std::vector<Chain> chains(1, d_chain(B, B, 0));
+      rnn_forward(chains, T, s);
+    }
   }
-  d_logits(B, T, s);
   // g_adv = mean((D(G(x)) - d_real)^2)  (gan_rnn_placeholder.py:246): all rows "fake", target d_real
-  launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, B, 0, dyn + DYN_D_REAL, dyn + DYN_D_REAL, tmp3, s);
+  if (d_dnn()) {
+    d_dnn_forward_loss(T, B, 0, want_grads, tmp3, s);
+  } else {
+    d_logits(B, T, s);
+    launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, B, 0, dyn + DYN_D_REAL, dyn + DYN_D_REAL, tmp3, s);
+  }
   launch_copy_f(tmp3 + 1, losses + 3, 1, s);
   const bool l2_on = !cfg.cross_validation && scal[RSRGAN_L2_SCALE] > 0.0;
-  if (want_grads && wavefront()) {
+  if (want_grads && d_dnn()) {
+    // discriminator_dnn: data gradient through the FC stack (time-batched GEMMs), then the generator's BPTT wave
+    float* dy = fc_backward(D, dfc, d_act, T * B, dlogits, false, true, s);      // [T*B][ldDout] (d_joint_dim == 0)
+    launch_mse(y_tm, lab_tm, ldDout, dy, T * B, Dout, dyn + DYN_LAMBDA, true, losses + 4, scratch, s);
+    g_backward_pass(T, dy, s);
+    if (l2_on) {
+      launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
+      launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);
+    }
+    g_grads_ready = true;
+  } else if (want_grads && wavefront()) {
     // ONE backward wave: D's layers (data gradient only) | per-step output-FC backward | G's layers.
     // dy[t] = lambda*(y-lab)/(B*T) (written first) + d g_adv/d y[t] (accumulated by D layer 0's phase B)
     const int R = T * B, Ld = (int)dl.size(), Lg = (int)gl.size();
@@ -842,7 +911,13 @@ int Model::apply(int net, hipStream_t s) {
   if (net == RSRGAN_NET_D) {
     if (!d_grads_ready) { set_error("apply(D) without gradients"); return RSRGAN_ERR_STATE; }
     launch_sumsq(D.g, D.ct, D.partial, s);
-    launch_apply_sgd(D.w, D.g, D.ema, D.ct, D.partial, dyn, s);
+    if (d_adam()) {                              // models/gan.py:125: d_opt = AdamOptimizer(d_learning_rate)
+      launch_adam_tick(dyn, adam_t_dev_d, (double)cfg.adam_beta1, (double)cfg.adam_beta2, s, DYN_D_LR, DYN_ADAM_LRT_D);
+      scal[RSRGAN_ADAM_STEP_D] += 1;
+      launch_apply_adam(D.w, D.g, D.m, D.v, D.ema, D.ct, D.partial, dyn, s, DYN_ADAM_LRT_D);
+    } else {
+      launch_apply_sgd(D.w, D.g, D.ema, D.ct, D.partial, dyn, s);
+    }
     refresh_transposes(RSRGAN_NET_D, s);
     d_grads_ready = false;
   } else if (net == RSRGAN_NET_G) {

@@ -40,6 +40,8 @@ struct LstmLayer {               // one tf.contrib.rnn.LSTMCell(H, use_peepholes
   float *KxT = nullptr, *KhT = nullptr, *WpT = nullptr;   // k-contiguous transposed copies (forward)
 };
 
+struct FcLayer { int in, out, ld_in, ld_out, tW, tb; };   // contrib.layers.fully_connected: weights [in][out], biases [out]
+
 struct LstmStash {               // everything one dynamic_rnn keeps for BPTT, time-major
   float *gates = nullptr;        // [T][N][4H]   zx -> gate activations -> dz (in place)
   float *c = nullptr;            // [T+1][N][H]  c[0] = 0
@@ -104,6 +106,21 @@ struct Model {
   std::vector<LstmStash> d_st;
   float *d_dA = nullptr, *d_dB = nullptr, *last_dx0 = nullptr;
   int *len_dev = nullptr;        // [2B]: lengths duplicated for the real|fake stacked batch
+  // fully-connected stacks: models/dnn.py generator and models/discriminator_dnn.py discriminator
+  std::vector<FcLayer> gfc, dfc;
+  std::vector<float*> g_act, d_act;        // act[l] = input of FC layer l, act[L] = output of the stack
+  float *fc_dA = nullptr, *fc_dB = nullptr, *joint = nullptr, *dy_buf = nullptr;
+  int ldJ = 0;
+  int *adam_t_dev_d = nullptr;
+  bool g_dnn() const { return cfg.g_type == RSRGAN_G_DNN; }
+  bool d_dnn() const { return cfg.d_type == RSRGAN_D_DNN; }
+  bool d_adam() const { return cfg.g_type == RSRGAN_G_DNN; }     // models/gan.py:125 (Adam) vs gan_rnn_placeholder.py:144 (SGD)
+  void fc_forward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, hipStream_t s);
+  float* fc_backward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, float* dtop,
+                     bool want_wgrads, bool want_din, hipStream_t s);
+  void d_dnn_forward_loss(int T, int Nd, int n_real, bool want_grads, float* loss3, hipStream_t s);
+  int dnn_d_backward(const float* x, const float* labels, int T, float* out_losses, bool want_grads, hipStream_t s);
+  int dnn_g_backward(const float* x, const float* labels, int T, float* out_losses, bool want_grads, bool reuse, hipStream_t s);
 
   float *dyn = nullptr;          // device scalars (see kernels.hip DYN_*)
   int *adam_t_dev = nullptr;

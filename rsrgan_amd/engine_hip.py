@@ -32,7 +32,9 @@ class HipEngine:
     def __init__(self, *, batch_size: int, max_frames: int, input_dim: int = 257, output_dim: int = 40,
                  g_type: str = "lstm", g_layers: Optional[int] = None, g_cells: Optional[int] = None,
                  g_proj: Optional[int] = None, d_layers: Optional[int] = None, d_cells: Optional[int] = None,
-                 d_proj: Optional[int] = None, l2_scale: float = 0.0, cross_validation: bool = False,
+                 d_proj: Optional[int] = None, d_type: Optional[str] = None, d_joint_off: Optional[int] = None,
+                 d_joint_dim: Optional[int] = None, clip_norm: Optional[float] = None,
+                 l2_scale: float = 0.0, cross_validation: bool = False,
                  ema_decay: float = 0.9999, seed: int = 4321, device: Optional[torch.device] = None, flags: int = 0):
         if g_type not in _lib.G_TYPES:
             raise ValueError("Unrecognized G type {}".format(g_type))      # gan_rnn_placeholder.py:131-132
@@ -48,6 +50,20 @@ class HipEngine:
                          d_proj=d_proj).items():
             if v is not None:
                 setattr(cfg, k, int(v))
+        if d_type is not None:
+            if d_type not in _lib.D_TYPES:
+                raise ValueError("Unrecognized D type {}".format(d_type))
+            cfg.d_type = _lib.D_TYPES[d_type]
+            if d_type == "dnn" and g_type != "dnn":          # discriminator_dnn on the 40-dim target only
+                cfg.d_layers = d_layers or 4
+                cfg.d_cells = d_cells or 1024
+                cfg.d_joint_off, cfg.d_joint_dim = 0, 0
+        if d_joint_off is not None:
+            cfg.d_joint_off = int(d_joint_off)
+        if d_joint_dim is not None:
+            cfg.d_joint_dim = int(d_joint_dim)
+        if clip_norm is not None:
+            cfg.clip_norm = float(clip_norm)
         cfg.l2_scale = l2_scale
         cfg.cross_validation = 1 if cross_validation else 0
         cfg.ema_decay = ema_decay
@@ -58,6 +74,7 @@ class HipEngine:
         self.h = C.c_void_p()
         check(self.lib.rsrgan_create(C.byref(cfg), C.c_uint64(seed), C.byref(self.h)))
         self._grad_views = {}
+        self.d_has_adam = g_type == "dnn"
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
@@ -143,13 +160,14 @@ class HipEngine:
     def forward_g(self, x, lengths) -> torch.Tensor:
         x = self._f32(x)
         B, T, _ = x.shape
-        ln = self._i32(lengths)
+        ln = self._i32(lengths) if lengths is not None else None
         y = torch.empty(B, T, self.output_dim, dtype=torch.float32, device=self.device)
         check(self.lib.rsrgan_forward_g(self.h, _ptr(x), _ptr(ln), T, _ptr(y), self._stream()))
         return y
 
     def d_backward(self, x, lab, lengths, noise_real=None, noise_fake=None, train=True, apply=False) -> torch.Tensor:
-        x, lab, ln = self._f32(x), self._f32(lab), self._i32(lengths)
+        x, lab = self._f32(x), self._f32(lab)
+        ln = self._i32(lengths) if lengths is not None else None
         nr, nf = self._noise(noise_real), self._noise(noise_fake)
         out = torch.empty(3, dtype=torch.float32, device=self.device)
         T = x.shape[1]
@@ -163,7 +181,8 @@ class HipEngine:
         return out
 
     def g_backward(self, x, lab, lengths, noise_fake=None, train=True, reuse=False, apply=False) -> torch.Tensor:
-        x, lab, ln = self._f32(x), self._f32(lab), self._i32(lengths)
+        x, lab = self._f32(x), self._f32(lab)
+        ln = self._i32(lengths) if lengths is not None else None
         nf = self._noise(noise_fake)
         out = torch.empty(4, dtype=torch.float32, device=self.device)
         T = x.shape[1]

@@ -1,0 +1,128 @@
+"""GAN -- host-side mirror of the reference's frame-level GAN (models/gan.py:60-300): DNN generator
+(models/dnn.py) + discriminator_dnn on concat(centre noisy frame, clean|enhanced MFCC), LSGAN losses with
+constant targets 1/0, Adam for both nets, no gradient clipping (gan.py:125-143).  Frames are independent, so
+the C ABI is driven with T = 1 and batch_size = frames per step."""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import dist as rdist
+from .gan_rnn import Model, NET_D, NET_G
+
+
+class GAN(Model):
+    """Generative Adversarial Network for Speech Enhancement (models/gan.py:60).  `inputs`/`labels` of the
+    reference constructor are tf.data tensors; here batches are passed to d_step / g_step."""
+
+    def __init__(self, sess, args, devices, inputs=None, labels=None, cross_validation=False, name="GAN", *,
+                 engine=None, process_group=None, seed: int = 4321, net_overrides: Optional[dict] = None):
+        super(GAN, self).__init__(name)
+        self.sess, self.cross_validation = sess, cross_validation
+        self.MOVING_AVERAGE_DECAY = 0.9999
+        self.keep_prob = 1.0 if cross_validation else getattr(args, "keep_prob", 1.0)
+        self.batch_norm = getattr(args, "batch_norm", False)
+        if self.batch_norm or self.keep_prob < 1.0:
+            raise NotImplementedError("batch_norm / dropout variants are not built (DESIGN.md section 7)")
+        self.batch_size, self.devices = args.batch_size, devices
+        self.num_gpu = getattr(args, "num_gpu", 1)
+        self.save_dir = getattr(args, "save_dir", None)
+        self.writer = self.summaries = None
+        self.l2_scale = getattr(args, "l2_scale", 0.0)
+        self.input_dim, self.output_dim = args.input_dim, args.output_dim
+        self.left_context, self.right_context = getattr(args, "left_context", 0), getattr(args, "right_context", 0)
+        self.g_disturb_weights = self.d_clip_weights = False
+        self.disc_updates, self.gen_updates = getattr(args, "disc_updates", 1), getattr(args, "gen_updates", 1)
+        if args.g_type != "dnn":
+            raise ValueError("Unrecognized G type {}".format(args.g_type))          # gan.py:111-112
+        self.process_group = process_group
+        fed = self.input_dim * (self.left_context + 1 + self.right_context)
+        if engine is not None:
+            self.engine = engine
+        else:
+            from .engine_hip import HipEngine
+            self.engine = HipEngine(batch_size=self.batch_size, max_frames=1, input_dim=fed, output_dim=self.output_dim,
+                                    g_type="dnn", d_type="dnn", d_joint_off=self.input_dim * self.left_context,
+                                    d_joint_dim=self.input_dim, l2_scale=self.l2_scale, cross_validation=cross_validation,
+                                    seed=seed, **(net_overrides or {}))
+        self.ema_enabled = getattr(self.engine, "ema_enabled", True)
+        self._scalars = {}
+        self.mse_lambda = getattr(args, "init_mse_weight", 10.0)
+        self.d_learning_rate = getattr(args, "d_learning_rate", 1e-4)
+        self.g_learning_rate = getattr(args, "g_learning_rate", 1e-4)
+
+    def _set(self, k, v):
+        self._scalars[k] = float(v)
+        self.engine.set_scalar(k, float(v))
+
+    d_learning_rate = property(lambda s: s._scalars["d_learning_rate"], lambda s, v: s._set("d_learning_rate", v))
+    g_learning_rate = property(lambda s: s._scalars["g_learning_rate"], lambda s, v: s._set("g_learning_rate", v))
+    mse_lambda = property(lambda s: s._scalars["mse_lambda"], lambda s, v: s._set("mse_lambda", v))
+
+    @staticmethod
+    def _frames(a):
+        return a[:, None, :] if a.ndim == 2 else a
+
+    def d_step(self, inputs, labels, train=True, sync=True):
+        """sess.run([model.d_opt, model.d_rl_losses, model.d_fk_losses, model.d_losses])."""
+        train = train and not self.cross_validation
+        x, lab = self._frames(inputs), self._frames(labels)
+        if train and rdist.world_size(self.process_group) > 1:
+            losses = self.engine.d_backward(x, lab, None, train=True, apply=False)
+            rdist.all_reduce_mean_(self.engine.grad_view(NET_D), self.process_group)
+            self.engine.apply(NET_D)
+        else:
+            losses = self.engine.d_backward(x, lab, None, train=train, apply=train)
+        tw = rdist.all_gather_rows(losses, self.process_group)
+        if not sync:
+            return tw
+        tw = tw.cpu().numpy()
+        return list(tw[:, 0]), list(tw[:, 1]), list(tw[:, 2])
+
+    def g_step(self, inputs, labels, train=True, reuse_g_forward=False, sync=True):
+        """sess.run([model.g_opt, model.g_adv_losses, model.g_mse_losses, model.g_l2_losses, model.g_losses])."""
+        train = train and not self.cross_validation
+        x, lab = self._frames(inputs), self._frames(labels)
+        if train and rdist.world_size(self.process_group) > 1:
+            losses = self.engine.g_backward(x, lab, None, train=True, reuse=reuse_g_forward, apply=False)
+            rdist.all_reduce_mean_(self.engine.grad_view(NET_G), self.process_group)
+            self.engine.apply(NET_G)
+        else:
+            losses = self.engine.g_backward(x, lab, None, train=train, reuse=reuse_g_forward, apply=train)
+        tw = rdist.all_gather_rows(losses, self.process_group)
+        if not sync:
+            return tw
+        tw = tw.cpu().numpy()
+        return list(tw[:, 0]), list(tw[:, 1]), list(tw[:, 2]), list(tw[:, 3])
+
+    def forward(self, inputs):
+        """sess.run(model.generator outputs): enhanced MFCC frames [N, output_dim]."""
+        y = self.engine.forward_g(self._frames(inputs), None)
+        y = y[:, 0, :]
+        return y.cpu().numpy() if not isinstance(inputs, torch.Tensor) else y
+
+    def get_vars(self):
+        out = []
+        for net, pre in ((NET_G, "g_"), (NET_D, "d_")):
+            flat = self.engine.get_params(net, "variables").cpu().numpy()
+            d = {}
+            for name, shape, off in self.engine.tensor_table(net):
+                assert name.startswith(pre), name
+                d[name] = flat[off:off + int(np.prod(shape))].reshape(shape)
+            out.append(d)
+        return out[0], out[1]
+
+    def set_vars(self, g_vars=None, d_vars=None, reset_ema=True):
+        for net, vals in ((NET_G, g_vars), (NET_D, d_vars)):
+            if vals is None:
+                continue
+            flat = np.zeros(self.engine.param_count(net), np.float32)
+            for name, shape, off in self.engine.tensor_table(net):
+                v = np.asarray(vals[name], np.float32)
+                assert tuple(v.shape) == tuple(shape), (name, v.shape, shape)
+                flat[off:off + v.size] = v.reshape(-1)
+            self.engine.set_params(net, flat, "variables")
+            if reset_ema and self.ema_enabled:
+                self.engine.set_params(net, flat, "ema")

@@ -52,6 +52,12 @@ class Model(object):
                 n = int(np.prod(shape))
                 payload[name + ("/Adam" if what == "adam_m" else "/Adam_1")] = flat[off:off + n].reshape(shape)
         payload["__adam_step__"] = np.asarray(self.engine.get_scalar("adam_step"))
+        if getattr(self.engine, "d_has_adam", False):              # models/gan.py: Adam for D as well
+            for what in ("adam_m", "adam_v"):
+                flat = self.engine.get_params(NET_D, what).cpu().numpy()
+                for name, shape, off in self.engine.tensor_table(NET_D):
+                    payload[name + ("/Adam" if what == "adam_m" else "/Adam_1")] = flat[off:off + int(np.prod(shape))].reshape(shape)
+            payload["__adam_step_d__"] = np.asarray(self.engine.get_scalar("adam_step_d"))
         path = os.path.join(save_dir, base + ".npz")
         np.savez(path, **payload)
         kept = sorted(glob.glob(os.path.join(save_dir, self.name + "-*.npz")), key=os.path.getmtime)
@@ -100,6 +106,14 @@ class Model(object):
                     flat[off:off + int(np.prod(shape))] = data[name + suffix].reshape(-1)
                 self.engine.set_params(NET_G, flat, what)
             self.engine.set_scalar("adam_step", float(data["__adam_step__"]))
+            if getattr(self.engine, "d_has_adam", False) and "__adam_step_d__" in data:
+                table = self.engine.tensor_table(NET_D)
+                for what, suffix in (("adam_m", "/Adam"), ("adam_v", "/Adam_1")):
+                    flat = np.zeros(self.engine.param_count(NET_D), np.float32)
+                    for name, shape, off in table:
+                        flat[off:off + int(np.prod(shape))] = data[name + suffix].reshape(-1)
+                    self.engine.set_params(NET_D, flat, what)
+                self.engine.set_scalar("adam_step_d", float(data["__adam_step_d__"]))
         print("[*] Read {}".format(ckpt_name))
         return True
 

@@ -235,3 +235,26 @@ def test_train_one_iteration_skips_short_batches():
     r = O.train_one_iteration(om, batches, disc_updates=1, gen_updates=2)
     assert len(r) == 7 and om.adam_t == 4
     assert math.isclose(r[2], r[0] + r[1], rel_tol=1e-12)
+
+
+def test_sequence_model_with_discriminator_dnn_matches_autograd():
+    """models/discriminator_dnn.py as the D of the sequence model (the combination BASELINE.json names)."""
+    cfg = small_cfg(d_type="dnn", d_layers=2, d_cells=11)
+    g, d = rand_params(cfg, seed=21)
+    for k in d:
+        if k.endswith("weights"):
+            d[k] = d[k] * 3.0                       # push some logits outside [-0.5, 1.5]
+    rng = np.random.default_rng(22)
+    x = rng.normal(size=(3, 5, 9)); lab = rng.normal(size=(3, 5, 5)); ln = np.array([5, 3, 4])
+    om = O.GanRnnOracle(cfg, g, d, batch_size=3)
+    tm = TT.GanRnnTorchTwin(cfg, g, d, dtype=torch.float64)
+    ol, og = om.d_tower(x, lab, ln)
+    tl, tg = tm.d_losses_and_grads(x, lab, ln)
+    assert np.allclose(ol, tl, rtol=1e-12)
+    for k in og:
+        assert np.allclose(og[k], tg[k].numpy(), rtol=1e-9, atol=1e-13), k
+    ol, og, _ = om.g_tower(x, lab, ln)
+    tl, tg, _ = tm.g_losses_and_grads(x, lab, ln)
+    assert np.allclose(ol, tl, rtol=1e-12)
+    for k in og:
+        assert np.allclose(og[k], tg[k].numpy(), rtol=1e-9, atol=1e-13), k
