@@ -84,6 +84,56 @@ def cpu_baseline(net, B, T, budget_s=20.0):
                       "os.cpu_count=%s, cpu=%s" % (n, B, T, os.cpu_count(), model_name)}
 
 
+def bench_dnn_gan(a, rank, local, world, dev):
+    """Frame-level GAN (models/gan.py): G = DNN 2827 -> 4x1024 -> 40, D = discriminator_dnn 297 -> 4x1024 -> 1,
+    Adam/Adam.  One step = 1 D-run + 1 G-run on N = --batch frames per GPU."""
+    from types import SimpleNamespace
+    from rsrgan_amd import GAN, dist as rdist
+    N = a.batch
+    args = SimpleNamespace(batch_size=N, input_dim=257, output_dim=40, left_context=5, right_context=5, g_type="dnn",
+                           keep_prob=1.0, batch_norm=False, num_gpu=world, save_dir=None, l2_scale=0.0, disc_updates=1,
+                           gen_updates=1, init_mse_weight=10.0, d_learning_rate=1e-4 * world, g_learning_rate=1e-4 * world)
+    model = GAN(None, args, ["gpu:%d" % local], seed=4321)
+    rng = np.random.default_rng(1234 + rank)
+    x = torch.from_numpy(rng.standard_normal((N, 1, 2827)).astype(np.float32)).to(dev)
+    lab = torch.from_numpy(rng.standard_normal((N, 1, 40)).astype(np.float32)).to(dev)
+
+    def step():
+        model.d_step(x, lab, sync=False)
+        return model.g_step(x, lab, reuse_g_forward=True, sync=False)
+    for _ in range(a.warmup):
+        step()
+    rdist.barrier(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter(); e0.record()
+    for _ in range(a.steps):
+        last = step()
+    e1.record(); torch.cuda.synchronize(); rdist.barrier()
+    dt = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        t = torch.tensor([dt, dev_ms], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt, dev_ms = float(t[0]), float(t[1])
+    if rank == 0:
+        fg = 2 * (2827 * 1024 + 3 * 1024 * 1024 + 1024 * 40)
+        fd = 2 * (297 * 1024 + 3 * 1024 * 1024 + 1024)
+        fpf = 3 * fg + 8 * fd          # G fwd + 2x bwd (weights only: no input gradient... counted as 2x), D as SURVEY 8d
+        ach = fpf * N / (dev_ms * 1e-3 / a.steps) / 1e12
+        out = {"metric": "GAN train frames/sec (G+D step), frame-level DNN-GAN 2827->40 (SURVEY 8f-1)",
+               "value": round(N * world * a.steps / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(dt * 1e3 / a.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "models/gan.py 1D+1G step, G=dnn(2827-4x1024-40)+D=discriminator_dnn(297-4x1024-1), "
+                                      "N=%d frames/GPU" % N, "global_batch": N * world, "parallelism": "dp%d" % world,
+                          "losses_last_step": [round(float(v), 6) for v in last.mean(0).cpu().numpy()]},
+               "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                            "scope": "all launches of one step; algorithmic 3*F_G+8*F_D = %d FLOP/frame" % fpf}}
+        print(json.dumps(out), flush=True)
+    rdist.barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,7 +141,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--frames", type=int, default=100)
-    ap.add_argument("--net", default="lstm", choices=["lstm", "res_lstm_l"])
+    ap.add_argument("--net", default="lstm", choices=["lstm", "res_lstm_l", "dnn_gan"],
+                    help="dnn_gan = the frame-level GAN of models/gan.py (SURVEY 8f-1): --batch frames per step, T ignored")
+    ap.add_argument("--d-type", default="lstm", choices=["lstm", "dnn"],
+                    help="dnn = models/discriminator_dnn.py as the D of the sequence model (BASELINE.json's wording)")
     ap.add_argument("--gen-updates", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=int(os.environ.get("RSRGAN_FLAGS", "1")),
@@ -107,12 +160,17 @@ def main():
     dev = torch.device("cuda", local)
 
     from types import SimpleNamespace
+    if a.net == "dnn_gan":
+        return bench_dnn_gan(a, rank, local, world, dev)
     B, T = a.batch, a.frames
     args = SimpleNamespace(batch_size=B, input_dim=257, output_dim=40, left_context=0, right_context=0, g_type=a.net,
                            keep_prob=1.0, batch_norm=False, num_gpu=world, save_dir=None, l2_scale=0.0,
                            disc_updates=1, gen_updates=a.gen_updates, init_mse_weight=10.0, init_disc_noise_std=0.0,
                            d_learning_rate=1e-3 * world, g_learning_rate=8e-5 * world)   # LR x num_gpu (:458-459)
-    model = GAN_RNN(None, args, ["gpu:%d" % local], max_frames=T, seed=4321, net_overrides=dict(flags=a.flags))
+    ov = dict(flags=a.flags)
+    if a.d_type == "dnn":
+        ov["d_type"] = "dnn"
+    model = GAN_RNN(None, args, ["gpu:%d" % local], max_frames=T, seed=4321, net_overrides=ov)
     x, lab, ln = synthetic(B, T, 257, 40, seed=1234 + rank)
     x = torch.from_numpy(x).to(dev); lab = torch.from_numpy(lab).to(dev); ln = torch.from_numpy(ln).to(dev)
 
@@ -146,24 +204,32 @@ def main():
     if rank == 0:
         c = model.engine.cfg
         fpf, fg, fd = flop_per_frame(257, 40, a.net, c.g_layers, c.g_cells, c.g_proj, c.d_layers, c.d_cells, c.d_proj)
+        if a.d_type == "dnn":      # per-frame FC stack 40 -> d_layers x d_cells -> 1
+            fd = 2 * (40 * c.d_cells + (c.d_layers - 1) * c.d_cells * c.d_cells + c.d_cells)
+            fpf = 3 * fg + 8 * fd
         if a.gen_updates != 1:
             fpf = None
         frames = B * T * world * a.steps
         value = frames / dt
         step_dev_s = dev_ms * 1e-3 / a.steps
         roof = None
+        traffic = None
+        tf_path = os.path.join(ROOT, "profiles", "r1_final_traffic.json")
+        if os.path.exists(tf_path) and a.net == "lstm" and a.d_type == "lstm" and (B, T, a.gen_updates) == (64, 100, 1):
+            traffic = json.load(open(tf_path)).get("hbm_bytes_per_step")     # PMC FETCH_SIZE(x2)+WRITE_SIZE of this workload
         if fpf:
             ach = fpf * B * T / step_dev_s / 1e12          # per GPU, HIP-event time of the whole step's launches
             roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "scope": "all launches of one (1D+1G) step on one GPU; algorithmic %d FLOP/frame x %d frames "
-                             "(SURVEY 8d: 3*F_G+8*F_D, F_G=%d, F_D=%d) / HIP-event step time" % (fpf, B * T, fg, fd)}
+                             "(SURVEY 8d: 3*F_G+8*F_D, F_G=%d, F_D=%d) / HIP-event step time; traffic = HBM-side bytes "
+                             "per step from profiles/r1_final_traffic.json" % (fpf, B * T, fg, fd)}
         out = {"metric": "GAN train frames/sec (G+D step), 257-dim LPS->40-dim MFCC", "value": round(value, 1),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt * 1e3 / a.steps, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "gan_rnn_placeholder 1D+%dG step, G=%s(%dx%d/p%d)+D=lstm(%dx%d/p%d), B=%d/GPU T=%d, "
-                                      "257->40" % (a.gen_updates, a.net, c.g_layers, c.g_cells, c.g_proj, c.d_layers,
+               "config": {"workload": "gan_rnn_placeholder 1D+%dG step, G=%s(%dx%d/p%d)+D=%s(%dx%d/p%d), B=%d/GPU T=%d, "
+                                      "257->40" % (a.gen_updates, a.net, c.g_layers, c.g_cells, c.g_proj, a.d_type, c.d_layers,
                                                    c.d_cells, c.d_proj, B, T),
                           "schedule_flags": a.flags, "global_batch": B * world, "frames_per_step": B * T * world, "parallelism": "dp%d" % world,
                           "losses_last_step": [round(float(v), 6) for v in losses]},
