@@ -78,6 +78,9 @@ struct BwdBJob {
   int I, n_begin, n_end, lddx, ldm, t, N, H4;
   int dx_accumulate;    // dx += instead of =
   int nblk_c, blk_base;
+  // split-K form (k_bwd_bp + k_bwd_b_red): partial tiles ws[KG][N][ldw], KG groups of kpg k-blocks
+  float* ws;
+  int ldw, KG, kpg, ncg, nrg, blk_base_p, blk_base_r;
 };
 struct BwdBJobs { int n; BwdBJob j[MAXJ]; };
 
@@ -92,6 +95,9 @@ void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, int kb_max, hipS
 void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
 void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
 void launch_bwd_b_variant(const BwdBJobs& jobs, int total_blocks, int variant, hipStream_t s);
+// split-K phase B: fills ws/ldw/KG/... of every job (ws_base: >= bwd_b_ws_floats(jobs) floats) and launches both kernels
+size_t bwd_b_plan(BwdBJobs& jobs, float* ws_base);
+void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s);
 
 // ---------------------------------------------------------------- batched GEMM
 // C[M,N] (+)= A.B (+bias)(lrelu).  a_kc: A(m,k)=A[m*lda+k] else A[k*lda+m];

@@ -16,6 +16,7 @@
 // for the u-th of four consecutive MFMAs, which is why the forward pass keeps
 // k-contiguous transposed copies of the kernels (KxT, KhT, WpT) while the backward pass
 // reads the TF-layout originals (already k-contiguous for dz.K^T and dm.Wp^T).
+#include <algorithm>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -524,6 +525,169 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_b(const BwdBJobs jobs) {
     for (int s2 = 0; s2 < NW; ++s2) v += zs[s2][e_i][e_r][e_c];
     *edst = v;
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward phase B, split-K form.  The per-CU operand pull rate (~12 B/clk) bounds these launches, so the
+// tiling minimises bytes: a WG owns ALL 64 rows x 64 output columns x one of KG slices of K (=4H): every
+// weight byte is pulled by exactly one WG per launch, the dz slice [64 x kpg*16] goes global -> LDS by DMA
+// once and is shared by the 8 waves (4 column tiles x 2 K halves).  Partial tiles land in ws[KG][N][ldw];
+// the kernel boundary makes them coherent, and k_bwd_b_red sums them in a fixed order and applies the
+// masked epilogue.  123 MB -> ~42 MB of operand traffic per generator-wave launch.
+// ---------------------------------------------------------------------------------------
+constexpr int BP_RT = 4, BP_CHB = 12;
+__host__ __device__ inline int bp_sa4(int kpg) { return kpg * 4 + 1; }      // LDS row stride in float4 (odd)
+
+__global__ __launch_bounds__(512) void k_bwd_bp(const BwdBJobs jobs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int bid = blockIdx.x;
+  int ji = 0;
+#pragma unroll
+  for (int qq = 1; qq < MAXJ; ++qq)
+    if (qq < jobs.n && bid >= jobs.j[qq].blk_base_p) ji = qq;
+  const BwdBJob& J = jobs.j[ji];
+  const int lb = bid - J.blk_base_p;
+  const int per_kg = J.ncg * J.nrg;
+  const int kg = lb / per_kg, rem = lb - kg * per_kg;
+  const int rg = rem / J.ncg, cg = rem - rg * J.ncg;
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = w & 3, kh = w >> 2;
+  const int N = J.N, H4 = J.H4, kpg = J.kpg;
+  const int nkb = (H4 + 15) >> 4;
+  const int j_begin = kg * kpg, j_end = min(nkb, j_begin + kpg);
+  const int per = (kpg + 1) >> 1;
+  const int jb = j_begin + kh * per, je = min(j_end, jb + per);
+  const int r0 = rg * 64;
+  const int SA4 = bp_sa4(kpg), SA = SA4 * 4;
+
+  // (1) weight slice of this wave's column tile -> VGPRs
+  const int n = J.n_begin + cg * 64 + ct * 16 + lr;
+  const bool nok = n < J.n_end;
+  const float* wrow = J.K + (size_t)(nok ? n : J.n_begin) * H4;
+  float4 bv[BP_CHB];
+#pragma unroll
+  for (int c = 0; c < BP_CHB; ++c) {
+    const int k = (jb + c) * 16 + 4 * q;
+    bv[c] = (nok && jb + c < je && k < H4) ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // (2) dz slice [64 rows][kpg*16] -> LDS (rows >= N / columns past H4 get a finite dummy: they meet zero weights
+  //     or unstored rows only)
+  {
+    const int P4 = 64 * SA4;
+    for (int p0 = w * 64; p0 < P4; p0 += 512) {
+      const int p = p0 + lane;
+      const int row = p / SA4, c4 = p - row * SA4;
+      const int k = j_begin * 16 + c4 * 4;
+      const float* src = J.dz;
+      if (p < P4 && r0 + row < N && c4 < kpg * 4 && k < H4) src = J.dz + (size_t)(r0 + row) * H4 + k;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (size_t)p0 * 4), 16, 0, 0);
+    }
+  }
+  __syncthreads();
+  // (3) MFMAs
+  f32x4 acc[BP_RT];
+#pragma unroll
+  for (int i = 0; i < BP_RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* abase = smem + (size_t)lr * SA + (jb - j_begin) * 16 + 4 * q;
+#pragma unroll
+  for (int c = 0; c < BP_CHB; ++c) {
+    if (jb + c < je) {
+      float4 a[BP_RT];
+#pragma unroll
+      for (int i = 0; i < BP_RT; ++i) a[i] = *reinterpret_cast<const float4*>(abase + (size_t)i * 16 * SA + c * 16);
+#pragma unroll
+      for (int i = 0; i < BP_RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, bv[c].x, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < BP_RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, bv[c].y, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < BP_RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, bv[c].z, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < BP_RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bv[c].w, acc[i], 0, 0, 0);
+    }
+  }
+  __syncthreads();                                       // done reading the dz slice
+  float (*zs)[BP_RT][16][17] = reinterpret_cast<float (*)[BP_RT][16][17]>(smem);     // zs[8][4][16][17] aliases it
+#pragma unroll
+  for (int i = 0; i < BP_RT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zs[w][i][q * 4 + r][lr] = acc[i][r];
+  __syncthreads();
+  // (4) partial tile [64 x 64] = sum of the two K halves -> ws[kg]
+  const int ncols = J.n_end - J.n_begin;
+  for (int e = tid; e < 64 * 64; e += 512) {
+    const int row = e >> 6, col = e & 63;
+    const int grow = r0 + row, gcol = cg * 64 + col;
+    if (grow < N && gcol < ncols) {
+      const int i = row >> 4, rr = row & 15, t2 = col >> 4, cc = col & 15;
+      J.ws[((size_t)kg * N + grow) * J.ldw + gcol] = zs[t2][i][rr][cc] + zs[4 + t2][i][rr][cc];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bwd_b_red(const BwdBJobs jobs) {
+  const int bid = blockIdx.x;
+  int ji = 0;
+#pragma unroll
+  for (int qq = 1; qq < MAXJ; ++qq)
+    if (qq < jobs.n && bid >= jobs.j[qq].blk_base_r) ji = qq;
+  const BwdBJob& J = jobs.j[ji];
+  const int ncols = J.n_end - J.n_begin;
+  const int e = (bid - J.blk_base_r) * 256 + threadIdx.x;
+  if (e >= J.N * ncols) return;
+  const int row = e / ncols, col = e - row * ncols;
+  const int nn = J.n_begin + col;
+  float* dst;
+  float v = 0.f;
+  if (nn < J.I) {
+    dst = J.dx + (size_t)row * J.lddx + nn;
+    if (J.dx_accumulate) v = *dst;
+  } else {
+    dst = J.dmst + (size_t)row * J.ldm + (nn - J.I);
+    if (!(J.t < J.len[row])) v = *dst;                   // masked row: the carried gradient passes through
+  }
+  for (int g = 0; g < J.KG; ++g) v += J.ws[((size_t)g * J.N + row) * J.ldw + col];
+  *dst = v;
+}
+
+size_t bwd_b_plan(BwdBJobs& jobs, float* ws_base) {
+  size_t off = 0;
+  int bp = 0, br = 0;
+  for (int i = 0; i < jobs.n; ++i) {
+    BwdBJob& b = jobs.j[i];
+    const int nkb = (b.H4 + 15) >> 4, ncols = b.n_end - b.n_begin;
+    int KG = std::max((nkb + 2 * BP_CHB - 1) / (2 * BP_CHB), std::min(8, nkb / 8));
+    KG = std::max(1, KG);
+    b.kpg = (nkb + KG - 1) / KG;
+    b.KG = (nkb + b.kpg - 1) / b.kpg;
+    b.ncg = (ncols + 63) / 64; b.nrg = (b.N + 63) / 64;
+    b.ldw = (ncols + 3) & ~3;
+    b.ws = ws_base ? ws_base + off : nullptr;
+    off += (size_t)b.KG * b.N * b.ldw;
+    b.blk_base_p = bp; bp += b.KG * b.ncg * b.nrg;
+    b.blk_base_r = br; br += (b.N * ncols + 255) / 256;
+  }
+  return off;
+}
+
+void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s) {
+  int bp = 0, br = 0, kpg_max = 1;
+  for (int i = 0; i < jobs.n; ++i) {
+    const BwdBJob& b = jobs.j[i];
+    bp = std::max(bp, b.blk_base_p + b.KG * b.ncg * b.nrg);
+    br = std::max(br, b.blk_base_r + (b.N * (b.n_end - b.n_begin) + 255) / 256);
+    kpg_max = std::max(kpg_max, b.kpg);
+  }
+  size_t lds = (size_t)64 * bp_sa4(kpg_max) * 16;
+  lds = (lds + 8191) / 8192 * 8192;
+  lds = std::max(lds, (size_t)8 * BP_RT * 16 * 17 * sizeof(float));
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_bp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_bwd_bp, dim3(bp), dim3(512), lds, s, jobs);
+  hipLaunchKernelGGL(k_bwd_b_red, dim3(br), dim3(256), 0, s, jobs);
 }
 
 // total blocks of a job list and blk_base assignment happen on the host (model.cpp); `kb_max` is

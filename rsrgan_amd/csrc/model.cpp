@@ -250,6 +250,8 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   gemm_ws_floats = (size_t)16 << 20;          // 64 MiB of split-K partial tiles
   gemm_ws = alloc<float>(gemm_ws_floats);
   if (!gemm_ws) gemm_ws_floats = 0;
+  bwdb_ws_floats = (size_t)8 << 20;
+  bwdb_ws = alloc<float>(bwdb_ws_floats);
   gemm_ws2 = alloc<float>(gemm_ws_floats ? gemm_ws_floats : 1);
   if (!gemm_ws2) side = nullptr;
   if (!scratch || !d_dB || !g_dB || !xd) { set_error("hipMalloc failed (activations)"); return RSRGAN_ERR_HIP; }
@@ -316,6 +318,16 @@ void Model::refresh_transposes(int net, hipStream_t s) {
 //   co-scheduled chain, so a 3-layer stack over T steps costs 2*(T+2) launches instead of 6*T.
 // ------------------------------------------------------------------------------------------
 static inline int kb16(int ld) { return (ld + 15) >> 4; }
+
+bool Model::bwd_b_splitk_ok(const BwdBJobs& jobs) const {
+  if (!bwdb_ws || (cfg.flags & RSRGAN_FLAG_NO_SPLITK_B)) return false;
+  BwdBJobs tmp = jobs;
+  const size_t need = bwd_b_plan(tmp, nullptr);
+  if (need > bwdb_ws_floats) return false;
+  for (int i = 0; i < tmp.n; ++i)
+    if ((tmp.j[i].kpg + 1) / 2 > 12) return false;       // k_bwd_bp holds <= 12 k-blocks of weights per wave
+  return true;
+}
 
 void Model::gemm(const float* A, int lda, bool a_kc, const float* B_, int ldb, bool b_kc, float* C, int ldc, int M, int N,
                  int K, const float* bias, int act, float alpha, bool accumulate, hipStream_t s) {
@@ -509,7 +521,8 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
           BwdAJobs aj{}; aj.n = 1; fill_bwd_a(aj.j[0], R, t); aj.j[0].blk_base = 0;
           launch_bwd_a(aj, job_blocks(aj.j[0].nblk_c, R.N), kb16(R.L->ldP), s);
           BwdBJobs bj{}; bj.n = 1; fill_bwd_b(bj.j[0], R, t, false); bj.j[0].blk_base = 0;
-          launch_bwd_b(bj, job_blocks(bj.j[0].nblk_c, R.N), kb16(4 * R.L->H), s);
+          if (bwd_b_splitk_ok(bj)) { bwd_b_plan(bj, bwdb_ws); launch_bwd_b_splitk(bj, s); }
+          else launch_bwd_b(bj, job_blocks(bj.j[0].nblk_c, R.N), kb16(4 * R.L->H), s);
         }
         if (R.want_wgrads) layer_wgrads(R, T, s);
         if (R.din) {   // din (+)= dZ . K[0:I]^T, batched over time
@@ -538,7 +551,13 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
     BwdAJobs aj{}; BwdBJobs bj{};
     int ab = 0, bb = 0, ak = 0, bk = 0;
     auto flush_a = [&]() { if (aj.n) launch_bwd_a(aj, ab, ak, s); aj.n = 0; ab = ak = 0; };
-    auto flush_b = [&]() { if (bj.n) launch_bwd_b(bj, bb, bk, s); bj.n = 0; bb = bk = 0; };
+    auto flush_b = [&]() {
+      if (bj.n) {
+        if (bwd_b_splitk_ok(bj)) { bwd_b_plan(bj, bwdb_ws); launch_bwd_b_splitk(bj, s); }
+        else launch_bwd_b(bj, bb, bk, s);
+      }
+      bj.n = 0; bb = bk = 0;
+    };
     for (size_t c = 0; c < chains.size(); ++c) {
       Chain& ch = chains[c];
       const int Lc = (int)ch.size(), off = offsets ? (*offsets)[c] : 0;

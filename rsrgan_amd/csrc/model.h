@@ -172,6 +172,9 @@ struct Model {
             int K, const float* bias, int act, float alpha, bool accumulate, hipStream_t s);
   bool wavefront() const { return (cfg.flags & RSRGAN_FLAG_WAVEFRONT) != 0; }
   float* g_fc_out_wT = nullptr;   // [Dout][ldP] transposed copy of the output FC weights (per-step FC stage)
+  float* bwdb_ws = nullptr;        // split-K partial tiles of backward phase B
+  size_t bwdb_ws_floats = 0;
+  bool bwd_b_splitk_ok(const BwdBJobs& jobs) const;
   float* gemm_ws = nullptr;
   size_t gemm_ws_floats = 0;
 
