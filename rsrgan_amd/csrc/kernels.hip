@@ -656,7 +656,9 @@ size_t bwd_b_plan(BwdBJobs& jobs, float* ws_base) {
   for (int i = 0; i < jobs.n; ++i) {
     BwdBJob& b = jobs.j[i];
     const int nkb = (b.H4 + 15) >> 4, ncols = b.n_end - b.n_begin;
-    int KG = std::max((nkb + 2 * BP_CHB - 1) / (2 * BP_CHB), std::min(8, nkb / 8));
+    static int kpg_target = -1;        // k-blocks per K slice: 24 -> 99 KB LDS (1 WG/CU), 12 -> 50 KB (3 WGs/CU overlap load and MFMA phases)
+    if (kpg_target < 0) { const char* e = getenv("RSRGAN_BP_KPG"); kpg_target = e ? atoi(e) : 24; if (kpg_target < 2 || kpg_target > 2 * BP_CHB) kpg_target = 24; }
+    int KG = std::max((nkb + kpg_target - 1) / kpg_target, std::min(8, nkb / 8));
     KG = std::max(1, KG);
     b.kpg = (nkb + KG - 1) / KG;
     b.KG = (nkb + b.kpg - 1) / b.kpg;
