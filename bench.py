@@ -34,12 +34,13 @@ PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md (v_
 
 
 def flop_per_frame(din, dout, g_type, gl, gh, gp, dl_, dh, dp):
-    lstmp = lambda i, h, p: 2 * ((i + p) * 4 * h + h * p)
+    lstmp = lambda i, h, p: 2 * ((i + p) * 4 * h + h * p) if p > 0 else 2 * (i + h) * 4 * h     # p == 0: num_proj=None
+    gp_out = gp if gp > 0 else gh
     fc = lambda i, o: 2 * i * o
     if g_type == "lstm":
-        fg = fc(din, gp) + gl * lstmp(gp, gh, gp) + fc(gp, dout)
+        fg = fc(din, gp_out) + gl * lstmp(gp_out, gh, gp) + fc(gp_out, dout)
     else:
-        fg = lstmp(din, gh, gp) + (gl - 1) * lstmp(gp, gh, gp) + fc(gp, dout)
+        fg = lstmp(din, gh, gp) + (gl - 1) * lstmp(gp_out, gh, gp) + fc(gp_out, dout)
     fd = lstmp(dout, dh, dp) + (dl_ - 1) * lstmp(dp, dh, dp) + fc(dp, 1)
     return 3 * fg + 8 * fd, fg, fd
 
@@ -141,8 +142,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--frames", type=int, default=100)
-    ap.add_argument("--net", default="lstm", choices=["lstm", "res_lstm_l", "dnn_gan"],
-                    help="dnn_gan = the frame-level GAN of models/gan.py (SURVEY 8f-1): --batch frames per step, T ignored")
+    ap.add_argument("--net", default="lstm", choices=["lstm", "res_lstm_l", "dnn_gan", "baseline_named"],
+                    help="dnn_gan = the frame-level GAN of models/gan.py (SURVEY 8f-1): --batch frames per step, T ignored; "
+                         "baseline_named = BASELINE.json's wording: 2-layer 512-unit LSTM (no projection, SURVEY 8d-iii) + DNN D")
     ap.add_argument("--d-type", default="lstm", choices=["lstm", "dnn"],
                     help="dnn = models/discriminator_dnn.py as the D of the sequence model (BASELINE.json's wording)")
     ap.add_argument("--gen-updates", type=int, default=1)
@@ -163,13 +165,18 @@ def main():
     if a.net == "dnn_gan":
         return bench_dnn_gan(a, rank, local, world, dev)
     B, T = a.batch, a.frames
-    args = SimpleNamespace(batch_size=B, input_dim=257, output_dim=40, left_context=0, right_context=0, g_type=a.net,
+    g_type = "res_lstm_base" if a.net == "baseline_named" else a.net
+    if a.net == "baseline_named":
+        a.d_type = "dnn"
+    args = SimpleNamespace(batch_size=B, input_dim=257, output_dim=40, left_context=0, right_context=0, g_type=g_type,
                            keep_prob=1.0, batch_norm=False, num_gpu=world, save_dir=None, l2_scale=0.0,
                            disc_updates=1, gen_updates=a.gen_updates, init_mse_weight=10.0, init_disc_noise_std=0.0,
                            d_learning_rate=1e-3 * world, g_learning_rate=8e-5 * world)   # LR x num_gpu (:458-459)
     ov = dict(flags=a.flags)
     if a.d_type == "dnn":
         ov["d_type"] = "dnn"
+    if a.net == "baseline_named":
+        ov.update(g_layers=2, g_cells=512, g_proj=0)
     model = GAN_RNN(None, args, ["gpu:%d" % local], max_frames=T, seed=4321, net_overrides=ov)
     x, lab, ln = synthetic(B, T, 257, 40, seed=1234 + rank)
     x = torch.from_numpy(x).to(dev); lab = torch.from_numpy(lab).to(dev); ln = torch.from_numpy(ln).to(dev)
@@ -203,7 +210,7 @@ def main():
 
     if rank == 0:
         c = model.engine.cfg
-        fpf, fg, fd = flop_per_frame(257, 40, a.net, c.g_layers, c.g_cells, c.g_proj, c.d_layers, c.d_cells, c.d_proj)
+        fpf, fg, fd = flop_per_frame(257, 40, g_type, c.g_layers, c.g_cells, c.g_proj, c.d_layers, c.d_cells, c.d_proj)
         if a.d_type == "dnn":      # per-frame FC stack 40 -> d_layers x d_cells -> 1
             fd = 2 * (40 * c.d_cells + (c.d_layers - 1) * c.d_cells * c.d_cells + c.d_cells)
             fpf = 3 * fg + 8 * fd
@@ -229,7 +236,7 @@ def main():
                "ms_per_step": round(dt * 1e3 / a.steps, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "gan_rnn_placeholder 1D+%dG step, G=%s(%dx%d/p%d)+D=%s(%dx%d/p%d), B=%d/GPU T=%d, "
-                                      "257->40" % (a.gen_updates, a.net, c.g_layers, c.g_cells, c.g_proj, a.d_type, c.d_layers,
+                                      "257->40" % (a.gen_updates, g_type, c.g_layers, c.g_cells, c.g_proj, a.d_type, c.d_layers,
                                                    c.d_cells, c.d_proj, B, T),
                           "schedule_flags": a.flags, "global_batch": B * world, "frames_per_step": B * T * world, "parallelism": "dp%d" % world,
                           "losses_last_step": [round(float(v), 6) for v in losses]},

@@ -31,6 +31,8 @@ struct FwdGateJob {
   const int* len;      // [N]
   int ldx, ldm, ldh, t, N, H;
   int nblk_c, blk_base;
+  // num_proj=None layers (m = h): the epilogue also writes the carried state, the masked output and the residual sum
+  float* np_m_out; float* np_out; const float* np_res_in; float* np_res_out;
 };
 struct FwdGateJobs { int n; float forget_bias; FwdGateJob j[MAXJ]; };
 

@@ -175,7 +175,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 __host__ __device__ inline int gates_sa4(int ktot) { int s = ktot / 4 + 1; return (s & 1) ? s : s + 1; }
 
 template <int CHB, int RTG>      // RTG 16-row tiles per WG: 2 -> 32 rows (2 WGs/CU), 4 -> 64 rows (weights streamed once)
-__global__ __launch_bounds__(512, RTG == 2 ? 4 : 2) void k_fwd_gates(const FwdGateJobs jobs) {
+__global__ __launch_bounds__(512, (RTG == 2 && CHB <= 18) ? 4 : 2) void k_fwd_gates(const FwdGateJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = blockIdx.x;
   const int ji = find_job(jobs.j, jobs.n, bid);
@@ -291,11 +291,22 @@ __global__ __launch_bounds__(512, RTG == 2 ? 4 : 2) void k_fwd_gates(const FwdGa
       const float go = sigmoid_(z[3] + pwo * cn);
       J.c_out[ci] = cn;
       g[0] = gi; g[H] = gj; g[2 * H] = gf; g[3 * H] = go;
-      J.h[(size_t)erow * J.ldh + ecell] = go * tanhf(cn);
+      const float hh = go * tanhf(cn);
+      J.h[(size_t)erow * J.ldh + ecell] = hh;
+      if (J.np_m_out) {
+        const size_t mi = (size_t)erow * J.ldm + ecell;
+        J.np_m_out[mi] = hh; J.np_out[mi] = hh;
+        if (J.np_res_out) J.np_res_out[mi] = hh + J.np_res_in[mi];
+      }
     } else {                       // dynamic_rnn: t >= len -> state copied through, no gradient
       J.c_out[ci] = cp[u];
       g[0] = 0.f; g[H] = 0.f; g[2 * H] = 0.f; g[3 * H] = 0.f;
       J.h[(size_t)erow * J.ldh + ecell] = 0.f;
+      if (J.np_m_out) {
+        const size_t mi = (size_t)erow * J.ldm + ecell;
+        J.np_m_out[mi] = J.m[mi]; J.np_out[mi] = 0.f;
+        if (J.np_res_out) J.np_res_out[mi] = J.np_res_in[mi];
+      }
     }
   }
 }
@@ -371,8 +382,9 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform -> scalar branches
   const int N = J.N, H = J.H, H4 = 4 * H, ldm = J.ldm;
   const int wcell = c0 + lr;
-  const float* wrow = J.Wp + (size_t)min(wcell, H - 1) * ldm;
-  const bool wok = wcell < H;
+  const bool noproj = J.Wp == nullptr;          // num_proj=None: dh = mask*(dout + dm_state), no product
+  const float* wrow = (noproj ? J.dmst : J.Wp) + (size_t)(noproj ? 0 : min(wcell, H - 1)) * ldm;
+  const bool wok = wcell < H && !noproj;
   int arow[RT], alen[RT];
 #pragma unroll
   for (int i = 0; i < RT; ++i) {
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
       a.x += dv[c][i].x; a.y += dv[c][i].y; a.z += dv[c][i].z; a.w += dv[c][i].w;
       const bool rowok = (r0 + i * 16 + lr) < N;
       if (!(kok && rowok && J.t < alen[i])) a = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kok && rowok && cb == 0) *reinterpret_cast<float4*>(J.dmt + (size_t)arow[i] * ldm + k) = a;
+      if (kok && rowok && cb == 0 && !noproj) *reinterpret_cast<float4*>(J.dmt + (size_t)arow[i] * ldm + k) = a;
       av[c][i] = a;
     }
     bv[c] = b;
@@ -449,8 +461,13 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
     float* g = J.gates + (size_t)erow * H4 + ecell;
     if (J.t < elen) {
       float dh = 0.f;
+      if (noproj) {
+        const size_t mi = (size_t)erow * ldm + ecell;
+        dh = J.dmst[mi] + (J.dout ? J.dout[mi] : 0.f);
+      } else {
 #pragma unroll
-      for (int s2 = 0; s2 < NW; ++s2) dh += zs[s2][e_i][e_r][e_c];
+        for (int s2 = 0; s2 < NW; ++s2) dh += zs[s2][e_i][e_r][e_c];
+      }
       const size_t ci = (size_t)erow * H + ecell;
       const float gi = eg[0], gj = eg[1], gf = eg[2], go = eg[3];
       const float tc = tanhf(ecn);
@@ -717,7 +734,13 @@ void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, int kb_max, hip
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_gates<18, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  if (rtg == 2) hipLaunchKernelGGL((k_fwd_gates<18, 2>), dim3(total_blocks), dim3(512), lds, s, jobs);
+  if (kb_max > 36) {        // K = [x | m] wider than 576 floats (e.g. 512-cell layers without projection): 32 k-blocks per wave, 1 WG/CU
+    static bool attr2 = false;
+    if (!attr2) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_gates<32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
+    size_t l2 = (size_t)32 * gates_sa4(ktot) * 16;
+    l2 = (l2 + 8191) / 8192 * 8192;
+    hipLaunchKernelGGL((k_fwd_gates<32, 2>), dim3(total_blocks), dim3(512), l2, s, jobs);
+  } else if (rtg == 2) hipLaunchKernelGGL((k_fwd_gates<18, 2>), dim3(total_blocks), dim3(512), lds, s, jobs);
   else hipLaunchKernelGGL((k_fwd_gates<18, 4>), dim3(total_blocks), dim3(512), lds, s, jobs);
 }
 void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {

@@ -54,15 +54,17 @@ T* Model::alloc(size_t n) {
   return reinterpret_cast<T*>(p);
 }
 
-static void add_lstm(ParamSet& ps, std::vector<LstmLayer>& out, const std::string& prefix, int I, int H, int P) {
+static void add_lstm(ParamSet& ps, std::vector<LstmLayer>& out, const std::string& prefix, int I, int H, int proj) {
   LstmLayer L;
+  const int P = proj > 0 ? proj : H;
+  L.has_proj = proj > 0;
   L.I = I; L.H = H; L.P = P; L.ldI = pad4(I); L.ldP = pad4(P); L.ldH = pad4(H);
   L.tK = ps.add(prefix + "/kernel", I + P, 4 * H, false);
   L.tb = ps.add(prefix + "/bias", 1, 4 * H, true);
   L.twf = ps.add(prefix + "/w_f_diag", 1, H, true);
   L.twi = ps.add(prefix + "/w_i_diag", 1, H, true);
   L.two = ps.add(prefix + "/w_o_diag", 1, H, true);
-  L.tWp = ps.add(prefix + "/projection/kernel", H, P, false);
+  L.tWp = L.has_proj ? ps.add(prefix + "/projection/kernel", H, P, false) : -1;
   out.push_back(L);
 }
 
@@ -118,10 +120,15 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   }
   if (c.d_type != RSRGAN_D_LSTM && c.d_type != RSRGAN_D_DNN) { set_error("Unrecognized D type %d", c.d_type); return RSRGAN_ERR_INVALID; }
   if (g_dnn() && !d_dnn()) { set_error("the frame-level generator (dnn) needs discriminator_dnn (models/gan.py:104)"); return RSRGAN_ERR_INVALID; }
-  if (!g_dnn() && (c.g_proj <= 0 || c.g_proj > 384)) { set_error("generator num_proj must be in [1, 384] (num_proj=None is not supported)"); return RSRGAN_ERR_INVALID; }
-  if (!d_dnn() && (c.d_proj <= 0 || c.d_proj > 384)) { set_error("discriminator num_proj must be in [1, 384]"); return RSRGAN_ERR_INVALID; }
+  if (!g_dnn() && (c.g_proj < 0 || c.g_proj > 384)) { set_error("generator num_proj must be in [0, 384] (0 = num_proj=None)"); return RSRGAN_ERR_INVALID; }
+  if (!d_dnn() && (c.d_proj < 0 || c.d_proj > 384)) { set_error("discriminator num_proj must be in [0, 384] (0 = num_proj=None)"); return RSRGAN_ERR_INVALID; }
+  if (!g_dnn() && d_dnn() && c.d_joint_dim != 0) { set_error("discriminator_dnn on the sequence model is fed the target only (d_joint_dim must be 0)"); return RSRGAN_ERR_INVALID; }
+  gR = c.g_proj > 0 ? c.g_proj : c.g_cells;
+  dR = c.d_proj > 0 ? c.d_proj : c.d_cells;
+  if (!g_dnn() && 2 * pad4(gR) > 1024) { set_error("generator layer input+state wider than 1024 floats is not supported by k_fwd_gates"); return RSRGAN_ERR_INVALID; }
+  if (!d_dnn() && pad4(dR) + std::max(pad4(dR), pad4(c.output_dim)) > 1024) { set_error("discriminator layer too wide for k_fwd_gates"); return RSRGAN_ERR_INVALID; }
   if (d_dnn() && (c.d_joint_dim < 0 || c.d_joint_off < 0 || c.d_joint_off + c.d_joint_dim > Din)) { set_error("bad d_joint slice"); return RSRGAN_ERR_INVALID; }
-  const int P = c.g_proj, H = c.g_cells;
+  const int P = gR, H = c.g_cells;
   auto fc_name = [](const char* net, int i) { return std::string(net) + "/fully_connected" + (i == 0 ? "" : "_" + std::to_string(i)); };
   auto add_fc = [&](ParamSet& ps, std::vector<FcLayer>& out, const std::string& nm, int in, int o) {
     FcLayer F; F.in = in; F.out = o; F.ld_in = pad4(in); F.ld_out = pad4(o);
@@ -137,7 +144,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     g_fc_in_w = G.add("g_model/fully_connected/weights", Din, P, false);
     g_fc_in_b = G.add("g_model/fully_connected/biases", 1, P, true);
     for (int l = 0; l < c.g_layers; ++l)
-      add_lstm(G, gl, "g_model/rnn/multi_rnn_cell/cell_" + std::to_string(l) + "/lstm_cell", P, H, P);
+      add_lstm(G, gl, "g_model/rnn/multi_rnn_cell/cell_" + std::to_string(l) + "/lstm_cell", P, H, c.g_proj);
     g_fc_out_w = G.add("g_model/fully_connected_1/weights", P, Dout, false);
     g_fc_out_b = G.add("g_model/fully_connected_1/biases", 1, Dout, true);
   } else if (c.g_type == RSRGAN_G_RES_LSTM_L || c.g_type == RSRGAN_G_RES_LSTM_BASE) {   // models/res_lstm_l.py:101-194
@@ -147,7 +154,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     }
     int in = Din;
     for (int l = 0; l < c.g_layers; ++l) {
-      add_lstm(G, gl, "g_model/lstm_cell_" + std::to_string(l + 1) + "/rnn/lstm_cell", in, H, P);
+      add_lstm(G, gl, "g_model/lstm_cell_" + std::to_string(l + 1) + "/rnn/lstm_cell", in, H, c.g_proj);
       in = P;
     }
     g_fc_out_w = G.add("g_model/forward_out/fully_connected/weights", P, Dout, false);
@@ -164,9 +171,9 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     int in = Dout;
     for (int l = 0; l < c.d_layers; ++l) {
       add_lstm(D, dl, "d_model/rnn/multi_rnn_cell/cell_" + std::to_string(l) + "/lstm_cell", in, c.d_cells, c.d_proj);
-      in = c.d_proj;
+      in = dR;
     }
-    d_fc_w = D.add("d_model/fully_connected/weights", c.d_proj, 1, false);
+    d_fc_w = D.add("d_model/fully_connected/weights", dR, 1, false);
     d_fc_b = D.add("d_model/fully_connected/biases", 1, 1, true);
   }
   // ---- device buffers ----
@@ -182,7 +189,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     for (auto& L : *layers) {
       L.KxT = alloc<float>((size_t)4 * L.H * L.ldI);
       L.KhT = alloc<float>((size_t)4 * L.H * L.ldP);
-      L.WpT = alloc<float>((size_t)L.P * L.ldH);
+      L.WpT = L.has_proj ? alloc<float>((size_t)L.P * L.ldH) : nullptr;
     }
   const size_t TB = (size_t)Tmax * B;
   x_tm = alloc<float>(TB * ldDin); lab_tm = alloc<float>(TB * ldDout); y_tm = alloc<float>(TB * ldDout);
@@ -212,7 +219,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   const int gmaxld = std::max(ldP, ldDin);
   g_dA = alloc<float>(TB * gmaxld); g_dB = alloc<float>(TB * gmaxld); g_dC = alloc<float>(TB * gmaxld);
   const size_t TB2 = TB * 2;
-  const int ldPd = d_dnn() ? 4 : pad4(c.d_proj);
+  const int ldPd = d_dnn() ? 4 : pad4(dR);
   xd = alloc<float>(TB2 * ldDout); logits = alloc<float>(TB2 * 4); dlogits = alloc<float>(TB2 * 4);
   if (d_dnn()) {
     ldJ = pad4(c.d_joint_dim + Dout);
@@ -305,10 +312,10 @@ void Model::refresh_transposes(int net, hipStream_t s) {
     const int H4 = 4 * L.H;
     launch_transpose(K, H4, L.KxT, L.ldI, L.I, H4, s);                       // [I][4H] -> [4H][ldI]
     launch_transpose(K + (size_t)L.I * H4, H4, L.KhT, L.ldP, L.P, H4, s);    // [P][4H] -> [4H][ldP]
-    launch_transpose(ps.W(L.tWp), L.ldP, L.WpT, L.ldH, L.H, L.P, s);         // [H][ldP] -> [P][ldH]
+    if (L.has_proj) launch_transpose(ps.W(L.tWp), L.ldP, L.WpT, L.ldH, L.H, L.P, s);         // [H][ldP] -> [P][ldH]
   }
   if (net == RSRGAN_NET_G && g_fc_out_wT && g_fc_out_w >= 0)
-    launch_transpose(G.W(g_fc_out_w), ldDout, g_fc_out_wT, pad4(cfg.g_proj), cfg.g_proj, Dout, s);   // [P][ldDout] -> [Dout][ldP]
+    launch_transpose(G.W(g_fc_out_w), ldDout, g_fc_out_wT, pad4(gR), gR, Dout, s);   // [P][ldDout] -> [Dout][ldP]
 }
 
 // ------------------------------------------------------------------------------------------
@@ -352,6 +359,12 @@ static void fill_gate(FwdGateJob& a, const LayerRun& R, int t, bool zx) {
   a.h = S.h + r * L.ldH; a.ldh = L.ldH;
   a.len = R.len; a.t = t; a.N = R.N; a.H = H;
   a.nblk_c = (H + 15) / 16;
+  if (L.has_proj) { a.np_m_out = nullptr; a.np_out = nullptr; a.np_res_in = nullptr; a.np_res_out = nullptr; }
+  else {     // num_proj=None: m = h; the gates epilogue also does the dynamic_rnn masking and the residual add
+    a.np_m_out = S.mst + rn * L.ldP; a.np_out = S.out + r * L.ldP;
+    a.np_res_in = R.res_in ? R.res_in + r * L.ldP : nullptr;
+    a.np_res_out = R.res_out ? R.res_out + r * L.ldP : nullptr;
+  }
 }
 static void fill_proj(FwdProjJob& p, const LayerRun& R, int t) {
   const LstmLayer& L = *R.L; const LstmStash& S = *R.S;
@@ -384,7 +397,7 @@ static void fill_bwd_a(BwdAJob& a, const LayerRun& R, int t) {
   const int H = L.H, H4 = 4 * H;
   const size_t r = (size_t)t * R.Ns + R.row0, rn = (size_t)(t + 1) * R.Ns + R.row0;
   a.dout = R.dout ? R.dout + r * L.ldP : nullptr;
-  a.dmst = S.dmst + (size_t)R.row0 * L.ldP; a.Wp = ps.W(L.tWp);
+  a.dmst = S.dmst + (size_t)R.row0 * L.ldP; a.Wp = L.has_proj ? ps.W(L.tWp) : nullptr;
   a.dmt = S.dmt + r * L.ldP;
   a.gates = S.gates + r * H4;
   a.c_prev = S.c + r * H; a.c_cur = S.c + rn * H;
@@ -425,9 +438,11 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
           FwdGateJobs gj{}; gj.n = 1; gj.forget_bias = cfg.forget_bias;
           fill_gate(gj.j[0], R, t, zx); gj.j[0].blk_base = 0;
           launch_fwd_gates(gj, job_blocks(gj.j[0].nblk_c, R.N, fwd_gates_rows()), (zx ? 0 : kb16(R.L->ldI)) + kb16(R.L->ldP), s);
-          FwdProjJobs pj{}; pj.n = 1;
-          fill_proj(pj.j[0], R, t); pj.j[0].blk_base = 0;
-          launch_fwd_proj(pj, job_blocks(pj.j[0].nblk_c, R.N), kb16(R.L->ldH), s);
+          if (R.L->has_proj) {
+            FwdProjJobs pj{}; pj.n = 1;
+            fill_proj(pj.j[0], R, t); pj.j[0].blk_base = 0;
+            launch_fwd_proj(pj, job_blocks(pj.j[0].nblk_c, R.N), kb16(R.L->ldH), s);
+          }
         }
       }
     return;
@@ -468,6 +483,7 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
         const int t = d - off - l;
         if (t < 0 || t >= T) continue;
         const LayerRun& R = ch[l];
+        if (!R.L->has_proj) continue;
         if (pj.n == MAXJ) flush_p();
         FwdProjJob& p = pj.j[pj.n++]; fill_proj(p, R, t); p.blk_base = pb; pb += job_blocks(p.nblk_c, R.N);
         pk = std::max(pk, kb16(R.L->ldH));
@@ -493,7 +509,8 @@ void Model::layer_wgrads_gemms(const LayerRun& R, int t0, int t1, bool accumulat
   // dK[0:I] (+)= in^T . dZ ; dK[I:I+P] (+)= m_{t-1}^T . dZ ; dWp (+)= h^T . dm   over frames [t0, t1)
   gemm(R.in + r0 * L.ldI, L.ldI, false, S.gates + r0 * H4, H4, false, dK, H4, L.I, H4, Rws, nullptr, 0, 0.f, accumulate, s);
   gemm(S.mst + r0 * L.ldP, L.ldP, false, S.gates + r0 * H4, H4, false, dK + (size_t)L.I * H4, H4, L.P, H4, Rws, nullptr, 0, 0.f, accumulate, s);
-  gemm(S.h + r0 * L.ldH, L.ldH, false, S.dmt + r0 * L.ldP, L.ldP, false, ps.Gd(L.tWp), L.ldP, H, L.P, Rws, nullptr, 0, 0.f, accumulate, s);
+  if (L.has_proj)
+    gemm(S.h + r0 * L.ldH, L.ldH, false, S.dmt + r0 * L.ldP, L.ldP, false, ps.Gd(L.tWp), L.ldP, H, L.P, Rws, nullptr, 0, 0.f, accumulate, s);
 }
 void Model::layer_wgrads_colsums(const LayerRun& R, int T, hipStream_t s, float* scr) {
   const LstmLayer& L = *R.L; const LstmStash& S = *R.S; const ParamSet& ps = *R.ps;
@@ -668,12 +685,12 @@ Chain Model::d_chain(int N, int Ns, int row0) {
 
 void Model::g_forward_head(int T, hipStream_t s) {
   if (cfg.g_type == RSRGAN_G_LSTM) {   // h = leakyrelu(x.W + b)  (models/lstm.py:82-87)
-    const int P = cfg.g_proj, ldP = pad4(P);
+    const int P = gR, ldP = pad4(P);
     gemm(x_tm, ldDin, true, G.W(g_fc_in_w), ldP, false, g_h0, ldP, T * B, P, Din, G.W(g_fc_in_b), 1, cfg.lrelu_alpha, false, s);
   }
 }
 void Model::g_forward_tail(int T, hipStream_t s) {   // y = outputs.W + b (models/lstm.py:121-124)
-  const int P = cfg.g_proj, ldP = pad4(P);
+  const int P = gR, ldP = pad4(P);
   gemm(g_ins[gl.size()], ldP, true, G.W(g_fc_out_w), ldDout, false, y_tm, ldDout, T * B, Dout, P, G.W(g_fc_out_b), 0, 0.f, false, s);
   g_fwd_valid = true;
 }
@@ -688,24 +705,24 @@ void Model::g_forward(int T, hipStream_t s, Chain* extra) {
 }
 
 void Model::d_logits(int N, int T, hipStream_t s) {
-  const int ldPd = pad4(cfg.d_proj);
-  gemm(d_st[dl.size() - 1].out, ldPd, true, D.W(d_fc_w), 4, false, logits, 4, T * N, 1, cfg.d_proj, D.W(d_fc_b), 0, 0.f, false, s);
+  const int ldPd = pad4(dR);
+  gemm(d_st[dl.size() - 1].out, ldPd, true, D.W(d_fc_w), 4, false, logits, 4, T * N, 1, dR, D.W(d_fc_b), 0, 0.f, false, s);
 }
 
 // leaves in last_dx0 (d_dA or d_dB) the gradient w.r.t. the discriminator input when need_dx0
 void Model::d_backward_pass(int N, int T, bool want_wgrads, bool need_dx0, const float* dlog, hipStream_t s) {
   const int R = T * N;
-  const int ldPd = pad4(cfg.d_proj);
+  const int ldPd = pad4(dR);
   const size_t Ld = dl.size();
   const float* top = d_st[Ld - 1].out;
   if (want_wgrads) {
-    gemm(top, ldPd, false, dlog, 4, false, D.Gd(d_fc_w), 4, cfg.d_proj, 1, R, nullptr, 0, 0.f, false, s);
+    gemm(top, ldPd, false, dlog, 4, false, D.Gd(d_fc_w), 4, dR, 1, R, nullptr, 0, 0.f, false, s);
     launch_colsum(dlog, 4, nullptr, 0, D.Gd(d_fc_b), R, 1, scratch, s);
   }
   float* cur = d_dB;
   float* other = d_dA;
   // d(outputs) = dlogits . W^T
-  gemm(dlog, 4, true, D.W(d_fc_w), 4, true, cur, ldPd, R, cfg.d_proj, 1, nullptr, 0, 0.f, false, s);
+  gemm(dlog, 4, true, D.W(d_fc_w), 4, true, cur, ldPd, R, dR, 1, nullptr, 0, 0.f, false, s);
   std::vector<Chain> chains(1, d_chain(N, N, 0));
   Chain& ch = chains[0];
   for (int l = (int)Ld - 1; l >= 0; --l) {
@@ -721,7 +738,7 @@ void Model::d_backward_pass(int N, int T, bool want_wgrads, bool need_dx0, const
 
 void Model::g_backward_pass(int T, float* dy, hipStream_t s) {
   const int R = T * B;
-  const int P = cfg.g_proj, ldP = pad4(P);
+  const int P = gR, ldP = pad4(P);
   const size_t Lg = gl.size();
   // output FC: dW = in^T . dy ; db = colsum(dy) ; d(in) = dy . W^T
   gemm(g_ins[Lg], ldP, false, dy, ldDout, false, G.Gd(g_fc_out_w), ldDout, P, Dout, R, nullptr, 0, 0.f, false, s);
@@ -770,7 +787,7 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
     // ONE wave: G's layers | D(real) (independent of G) | per-step output FC -> y_t, xd fake rows |
     // D(fake) two diagonals behind G's top layer
     g_forward_head(T, s);
-    const int Lg = (int)gl.size(), ldP = pad4(cfg.g_proj);
+    const int Lg = (int)gl.size(), ldP = pad4(gR);
     std::vector<Chain> chains{g_chain(T)};
     std::vector<int> offs{0};
     if (!d_dnn()) {
@@ -778,7 +795,7 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
       chains.push_back(d_chain(B, 2 * B, B)); offs.push_back(Lg + 1);
     }
     FcStage F;
-    F.offset = Lg; F.N = B; F.K = cfg.g_proj; F.D = Dout;
+    F.offset = Lg; F.N = B; F.K = gR; F.D = Dout;
     F.in = g_ins[Lg]; F.ld_in = ldP; F.WT = g_fc_out_wT; F.bias = G.W(g_fc_out_b); F.noise = nf;
     F.y = y_tm; F.ldy = ldDout; F.out2 = xd; F.ld2 = ldDout; F.Ns2 = 2 * B; F.row02 = B;
     std::vector<FcStage> fcs{F};
@@ -828,8 +845,8 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     std::vector<int> offs{0};
     if (!d_dnn()) { chains.push_back(d_chain(B, B, 0)); offs.push_back(Lg + 1); }
     FcStage F;
-    F.offset = Lg; F.N = B; F.K = cfg.g_proj; F.D = Dout;
-    F.in = g_ins[Lg]; F.ld_in = pad4(cfg.g_proj); F.WT = g_fc_out_wT; F.bias = G.W(g_fc_out_b); F.noise = nf;
+    F.offset = Lg; F.N = B; F.K = gR; F.D = Dout;
+    F.in = g_ins[Lg]; F.ld_in = pad4(gR); F.WT = g_fc_out_wT; F.bias = G.W(g_fc_out_b); F.noise = nf;
     F.y = y_tm; F.ldy = ldDout; F.out2 = xd; F.ld2 = ldDout; F.Ns2 = B; F.row02 = 0;
     std::vector<FcStage> fcs{F};
     rnn_forward(chains, T, s, &offs, &fcs);
@@ -864,9 +881,9 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     // ONE backward wave: D's layers (data gradient only) | per-step output-FC backward | G's layers.
     // dy[t] = lambda*(y-lab)/(B*T) (written first) + d g_adv/d y[t] (accumulated by D layer 0's phase B)
     const int R = T * B, Ld = (int)dl.size(), Lg = (int)gl.size();
-    const int ldPd = pad4(cfg.d_proj), P = cfg.g_proj, ldP = pad4(P);
+    const int ldPd = pad4(dR), P = gR, ldP = pad4(P);
     float* dtop = d_dB;                           // d(D outputs) = dlogits . W^T
-    gemm(dlogits, 4, true, D.W(d_fc_w), 4, true, dtop, ldPd, R, cfg.d_proj, 1, nullptr, 0, 0.f, false, s);
+    gemm(dlogits, 4, true, D.W(d_fc_w), 4, true, dtop, ldPd, R, dR, 1, nullptr, 0, 0.f, false, s);
     float* dy = g_dB;                             // [T*B][ldDout]
     launch_mse(y_tm, lab_tm, ldDout, dy, R, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s);
     Chain dch = d_chain(B, B, 0);

@@ -34,7 +34,8 @@ struct ParamSet {
   float* Gd(int i) const { return g + t[i].off; }
 };
 
-struct LstmLayer {               // one tf.contrib.rnn.LSTMCell(H, use_peepholes, num_proj=P)
+struct LstmLayer {               // one tf.contrib.rnn.LSTMCell(H, use_peepholes, num_proj): P = output/recurrent width
+  bool has_proj = true;          // num_proj=None: m = h, P == H, no projection kernel (tWp = -1)
   int I, H, P, ldI, ldP, ldH;
   int tK, tb, twf, twi, two, tWp;        // indices into the ParamSet
   float *KxT = nullptr, *KhT = nullptr, *WpT = nullptr;   // k-contiguous transposed copies (forward)
@@ -91,6 +92,7 @@ struct FcStage {
 struct Model {
   rsrgan_cfg cfg{};
   int B = 0, Tmax = 0, Din = 0, Dout = 0, ldDin = 0, ldDout = 0;
+  int gR = 0, dR = 0;            // output width of the generator / discriminator LSTM stacks (num_proj, or cells when None)
   ParamSet G, D;
   std::vector<LstmLayer> gl, dl;
   int g_fc_in_w = -1, g_fc_in_b = -1, g_fc_out_w = -1, g_fc_out_b = -1, d_fc_w = -1, d_fc_b = -1;

@@ -173,3 +173,50 @@ def test_checkpoint_roundtrip(tmp_path):
     assert model2.engine.get_scalar("adam_step") == 1
     assert np.allclose(np.ravel(model2.g_step(x, lab, ln, train=False)), np.ravel(ref), rtol=1e-6)
     assert not model2.load(str(tmp_path / "missing"))
+
+
+@pytest.mark.parametrize("flags", SCHEDULES)
+@pytest.mark.parametrize("g_type", ["lstm", "res_lstm_base"])
+def test_num_proj_none_layers(g_type, flags):
+    """tf.contrib.rnn.LSTMCell(num_proj=None): m = h (BASELINE.json's '2x512' wording); no projection launch."""
+    cfg = small_cfg(g_type, g_proj=0, d_proj=0)
+    B, T = 6, 7
+    model, oracle = build_hip_pair(cfg, B, T, seed=71, flags=flags)
+    assert not any("projection" in n for n, _, _ in model.engine.tensor_table(NET_G))
+    x, lab, ln = rand_batch(cfg, B, T, seed=72, ragged=True)
+    y = model.forward(x, ln)
+    assert np.abs(y - oracle.forward(x, ln)).max() < 1e-4
+    got = model.engine.d_backward(x, lab, ln, None, None, train=True, apply=False).cpu().numpy()
+    want, wg = oracle.d_tower(x.astype(np.float64), lab.astype(np.float64), ln)
+    assert np.allclose(got, want, rtol=LOSS_RTOL), (got, want)
+    _check_grads(model, NET_D, wg, "D")
+    got = model.engine.g_backward(x, lab, ln, None, train=True, reuse=True, apply=False).cpu().numpy()
+    want, wg, _ = oracle.g_tower(x.astype(np.float64), lab.astype(np.float64), ln)
+    assert np.allclose(got, want, rtol=LOSS_RTOL, atol=1e-7), (got, want)
+    _check_grads(model, NET_G, wg, "G")
+    a = model.d_step(x, lab, ln); b = oracle.d_step(x, lab, ln)
+    assert np.allclose(np.ravel(a), np.ravel(b), rtol=LOSS_RTOL)
+    a = model.g_step(x, lab, ln); b = oracle.g_step(x, lab, ln)
+    assert np.allclose(np.ravel(a), np.ravel(b), rtol=LOSS_RTOL)
+
+
+def test_baseline_named_network():
+    """BASELINE.json configs[1]: 2-layer 512-unit LSTM generator (no projection) + DNN discriminator, B=4, T=6."""
+    from rsrgan_amd import GAN_RNN
+    from tests.helpers import args_for, rand_params
+    cfg = O.NetCfg(g_type="lstm", g_layers=2, g_cells=512, g_proj=0, d_type="dnn", d_layers=4, d_cells=1024)
+    B, T = 4, 6
+    g, d = rand_params(cfg, 81)
+    m = GAN_RNN(None, args_for(cfg, B), ["gpu:0"], max_frames=T,
+                net_overrides=dict(g_layers=2, g_cells=512, g_proj=0, d_type="dnn", d_layers=4, d_cells=1024, flags=1))
+    m.set_vars(g, d)
+    o = O.GanRnnOracle(cfg, g, d, batch_size=B, g_learning_rate=float(np.float32(8e-5)), d_learning_rate=float(np.float32(1e-3)))
+    x, lab, ln = rand_batch(cfg, B, T, 82, ragged=True)
+    got = m.engine.d_backward(x, lab, ln, train=True, apply=False).cpu().numpy()
+    want, wg = o.d_tower(x.astype(np.float64), lab.astype(np.float64), ln)
+    assert np.allclose(got, want, rtol=LOSS_RTOL), (got, want)
+    _check_grads(m, NET_D, wg, "D")
+    got = m.engine.g_backward(x, lab, ln, train=True, reuse=True, apply=False).cpu().numpy()
+    want, wg, _ = o.g_tower(x.astype(np.float64), lab.astype(np.float64), ln)
+    assert np.allclose(got, want, rtol=LOSS_RTOL), (got, want)
+    _check_grads(m, NET_G, wg, "G")
