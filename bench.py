@@ -85,6 +85,56 @@ def cpu_baseline(net, B, T, budget_s=20.0):
                       "os.cpu_count=%s, cpu=%s" % (n, B, T, os.cpu_count(), model_name)}
 
 
+def measure_sequence(a, net, d_type, B, T, steps, warmup, rank, local, world, dev):
+    """One timed run of the sequence-level GAN step: W untimed steps, then exactly `steps` steps between
+    barrier + synchronize on both sides; MAX over ranks."""
+    from types import SimpleNamespace
+    from rsrgan_amd import GAN_RNN, dist as rdist
+    g_type = "res_lstm_base" if net == "baseline_named" else net
+    if net == "baseline_named":
+        d_type = "dnn"
+    args = SimpleNamespace(batch_size=B, input_dim=257, output_dim=40, left_context=0, right_context=0, g_type=g_type,
+                           keep_prob=1.0, batch_norm=False, num_gpu=world, save_dir=None, l2_scale=0.0,
+                           disc_updates=1, gen_updates=a.gen_updates, init_mse_weight=10.0, init_disc_noise_std=0.0,
+                           d_learning_rate=1e-3 * world, g_learning_rate=8e-5 * world)   # LR x num_gpu (:458-459)
+    ov = dict(flags=a.flags)
+    if d_type == "dnn":
+        ov["d_type"] = "dnn"
+    if net == "baseline_named":
+        ov.update(g_layers=2, g_cells=512, g_proj=0)
+    model = GAN_RNN(None, args, ["gpu:%d" % local], max_frames=T, seed=4321, net_overrides=ov)
+    x, lab, ln = synthetic(B, T, 257, 40, seed=1234 + rank)
+    x = torch.from_numpy(x).to(dev); lab = torch.from_numpy(lab).to(dev); ln = torch.from_numpy(ln).to(dev)
+
+    def step():
+        model.d_step(x, lab, ln, sync=False)
+        out = None
+        for i in range(a.gen_updates):
+            out = model.g_step(x, lab, ln, reuse_g_forward=(i == 0), sync=False)
+        return out
+
+    for _ in range(warmup):
+        step()
+    rdist.barrier(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        last = step()
+    e1.record()
+    torch.cuda.synchronize(); rdist.barrier()
+    dt = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        t = torch.tensor([dt, dev_ms], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt, dev_ms = float(t[0]), float(t[1])
+    losses = last.mean(0).cpu().numpy()
+    if not np.all(np.isfinite(losses)):
+        raise SystemExit("non-finite losses: %s" % losses)
+    return dict(model=model, g_type=g_type, d_type=d_type, dt=dt, dev_ms=dev_ms, losses=losses)
+
+
 def bench_dnn_gan(a, rank, local, world, dev):
     """Frame-level GAN (models/gan.py): G = DNN 2827 -> 4x1024 -> 40, D = discriminator_dnn 297 -> 4x1024 -> 1,
     Adam/Adam.  One step = 1 D-run + 1 G-run on N = --batch frames per GPU."""
@@ -149,6 +199,7 @@ def main():
                     help="dnn = models/discriminator_dnn.py as the D of the sequence model (BASELINE.json's wording)")
     ap.add_argument("--gen-updates", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the BASELINE.json-named network variant at N=1")
     ap.add_argument("--flags", type=int, default=int(os.environ.get("RSRGAN_FLAGS", "1")),
                     help="library schedule flags: 1 = wavefront, 4 = side-stream GEMM overlap (include/rsrgan.h)")
     a = ap.parse_args()
@@ -164,50 +215,10 @@ def main():
     from types import SimpleNamespace
     if a.net == "dnn_gan":
         return bench_dnn_gan(a, rank, local, world, dev)
-    B, T = a.batch, a.frames
-    g_type = "res_lstm_base" if a.net == "baseline_named" else a.net
+    res = measure_sequence(a, a.net, a.d_type, a.batch, a.frames, a.steps, a.warmup, rank, local, world, dev)
+    model, g_type, dt, dev_ms, losses, B, T = res["model"], res["g_type"], res["dt"], res["dev_ms"], res["losses"], a.batch, a.frames
     if a.net == "baseline_named":
         a.d_type = "dnn"
-    args = SimpleNamespace(batch_size=B, input_dim=257, output_dim=40, left_context=0, right_context=0, g_type=g_type,
-                           keep_prob=1.0, batch_norm=False, num_gpu=world, save_dir=None, l2_scale=0.0,
-                           disc_updates=1, gen_updates=a.gen_updates, init_mse_weight=10.0, init_disc_noise_std=0.0,
-                           d_learning_rate=1e-3 * world, g_learning_rate=8e-5 * world)   # LR x num_gpu (:458-459)
-    ov = dict(flags=a.flags)
-    if a.d_type == "dnn":
-        ov["d_type"] = "dnn"
-    if a.net == "baseline_named":
-        ov.update(g_layers=2, g_cells=512, g_proj=0)
-    model = GAN_RNN(None, args, ["gpu:%d" % local], max_frames=T, seed=4321, net_overrides=ov)
-    x, lab, ln = synthetic(B, T, 257, 40, seed=1234 + rank)
-    x = torch.from_numpy(x).to(dev); lab = torch.from_numpy(lab).to(dev); ln = torch.from_numpy(ln).to(dev)
-
-    def step():
-        model.d_step(x, lab, ln, sync=False)
-        out = None
-        for i in range(a.gen_updates):
-            out = model.g_step(x, lab, ln, reuse_g_forward=(i == 0), sync=False)
-        return out
-
-    for _ in range(a.warmup):
-        step()
-    rdist.barrier(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(a.steps):
-        last = step()
-    e1.record()
-    torch.cuda.synchronize(); rdist.barrier()
-    dt = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1)
-    if world > 1:
-        t = torch.tensor([dt, dev_ms], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt, dev_ms = float(t[0]), float(t[1])
-    losses = last.mean(0).cpu().numpy()
-    if not np.all(np.isfinite(losses)):
-        raise SystemExit("non-finite losses: %s" % losses)
-
     if rank == 0:
         c = model.engine.cfg
         fpf, fg, fd = flop_per_frame(257, 40, g_type, c.g_layers, c.g_cells, c.g_proj, c.d_layers, c.d_cells, c.d_proj)
@@ -242,7 +253,23 @@ def main():
                           "losses_last_step": [round(float(v), 6) for v in losses]},
                "roofline": roof}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.net, B, T)
+            out["cpu_baseline"] = cpu_baseline(a.net if a.net in ("lstm", "res_lstm_l") else "lstm", B, T)
+    if world == 1 and a.net == "lstm" and a.d_type == "lstm" and not a.no_variants:
+        # BASELINE.json words its configs as "2-layer 512-unit LSTM generator + DNN discriminator" (no such network exists
+        # in the reference); the same kernels run it, reported beside the reference-true headline.
+        del model, res
+        torch.cuda.empty_cache()
+        v = measure_sequence(a, "baseline_named", "dnn", B, T, max(3, a.steps // 4), 2, rank, local, world, dev)
+        c2 = v["model"].engine.cfg
+        f2, fg2, fd2 = flop_per_frame(257, 40, "res_lstm_base", 2, 512, 0, c2.d_layers, c2.d_cells, 0)
+        fd2 = 2 * (40 * c2.d_cells + (c2.d_layers - 1) * c2.d_cells * c2.d_cells + c2.d_cells)
+        f2 = 3 * fg2 + 8 * fd2
+        n2 = max(3, a.steps // 4)
+        out["variants"] = [{"workload": "BASELINE.json-named: G=2x512 LSTM (num_proj=None) + D=discriminator_dnn(4x1024), B=%d T=%d" % (B, T),
+                            "value": round(B * T * n2 / v["dt"], 1), "unit": "frames/s", "ms_per_step": round(v["dt"] * 1e3 / n2, 4),
+                            "roofline_frac": round(f2 * B * T / (v["dev_ms"] * 1e-3 / n2) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                            "flop_per_frame": f2}]
+    if rank == 0:
         print(json.dumps(out), flush=True)
     rdist.barrier()
 
