@@ -220,3 +220,38 @@ def test_baseline_named_network():
     want, wg, _ = o.g_tower(x.astype(np.float64), lab.astype(np.float64), ln)
     assert np.allclose(got, want, rtol=LOSS_RTOL), (got, want)
     _check_grads(m, NET_G, wg, "G")
+
+
+def test_outer_loop_on_gpu(tmp_path):
+    """train() (decay, accept/reject checkpoint) then decode() -> ark on the HIP engine with scp/ark data."""
+    from rsrgan_amd import run_gan_rnn as R
+    from rsrgan_amd.io import ArkReader, ArkWriter
+    rng = np.random.default_rng(0)
+    din, dout = 5, 3
+
+    def data(n, tag):
+        wi, wl = ArkWriter(str(tmp_path / (tag + "_in.scp"))), ArkWriter(str(tmp_path / (tag + "_lab.scp")))
+        for i in range(n):
+            T = int(rng.integers(6, 10))
+            wi.write_next_utt(str(tmp_path / (tag + "_in.ark")), "%s%02d" % (tag, i), rng.standard_normal((T, din)))
+            wl.write_next_utt(str(tmp_path / (tag + "_lab.ark")), "%s%02d" % (tag, i), rng.standard_normal((T, dout)))
+        wi.close(); wl.close()
+        return str(tmp_path / (tag + "_in.scp")), str(tmp_path / (tag + "_lab.scp"))
+    tr, cv, te = data(8, "tr"), data(4, "cv"), data(2, "te")
+    np.savez(tmp_path / "train_cmvn.npz", mean_inputs=np.zeros(din), stddev_inputs=np.ones(din), mean_labels=np.zeros(dout), stddev_labels=np.ones(dout))
+    FLAGS, _ = R.build_parser().parse_known_args([
+        "--data_dir", str(tmp_path), "--tr_inputs_scp", tr[0], "--tr_labels_scp", tr[1], "--cv_inputs_scp", cv[0], "--cv_labels_scp", cv[1],
+        "--test_inputs_scp", te[0], "--input_dim", str(din), "--output_dim", str(dout), "--left_context", "1", "--right_context", "1",
+        "--batch_size", "2", "--min_epoches", "1", "--max_epoches", "2", "--save_dir", str(tmp_path / "exp"), "--max_frames", "16",
+        "--init_disc_noise_std", "0.05", "--g_learning_rate", "0.003"])
+    ov = dict(g_layers=1, g_cells=8, g_proj=4, d_layers=1, d_cells=8, d_proj=3, flags=1)
+    logs = []
+    hist = R.train(FLAGS, log=logs.append, net_overrides=ov)
+    assert len(hist) >= 1 and all(np.isfinite(hist)) and "Nnet Accepted" in "\n".join(logs)
+    FLAGS.decode = True
+    scp = R.decode(FLAGS, log=logs.append, net_overrides=ov)
+    r = ArkReader(); r(scp)
+    assert len(r.utt_ids) == 2
+    for i in range(2):
+        m = r.read_utt_data_from_index(i)
+        assert m.shape[1] == dout and np.all(np.isfinite(m))
