@@ -121,6 +121,10 @@ void launch_add_noise_rows(const float* src_tm, const float* noise, float* dst, 
                            int Ns, int row0, hipStream_t s);
 void launch_transpose(const float* src, int lds, float* dst, int ldd, int R, int C, hipStream_t s);        // dst[c][r] = src[r][c]
 void launch_fill(float* p, size_t n, float v, hipStream_t s);
+struct ZeroList { int n; float* p[32]; unsigned len[32]; };        // many small buffers zeroed by ONE launch
+void launch_zero_many(const ZeroList& zl, hipStream_t s);
+void launch_lstm_colsums(const float* dz, const float* cprev, const float* ccur, float* db, float* dwi, float* dwf, float* dwo,
+                         int rows, int H, float* scratch /* >= 64*7*H floats */, hipStream_t s);
 void launch_lrelu_bwd(const float* hval, float* d, size_t rows, int cols, int ld, float alpha, hipStream_t s); // d *= (h>0?1:alpha)
 // col sums over `rows` rows: out[c] = sum_r a[r*lda+c] * (b ? b[r*ldb+c] : 1)
 void launch_colsum(const float* a, int lda, const float* b, int ldb, float* out, int rows, int cols,

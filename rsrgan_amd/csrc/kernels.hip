@@ -487,25 +487,25 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
 // ---------------------------------------------------------------------------------------
 // backward phase B: 32x16 tile of dz_t.K^T, K (=4H) split over NW waves
 // ---------------------------------------------------------------------------------------
-template <int NW, int VAR = 0, int CH = 6>
+template <int NW, int VAR = 0, int CH = 6, int RTB = RT>
 __global__ __launch_bounds__(NW * 64) void k_bwd_b(const BwdBJobs jobs) {
-  __shared__ float zs[NW][RT][16][17];
+  __shared__ float zs[NW][RTB][16][17];
   const int bid = blockIdx.x;
   const int ji = find_job(jobs.j, jobs.n, bid);
   const BwdBJob& J = jobs.j[ji];
   int cb, rb;
   if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
-  const int r0 = rb * 16 * RT, n0 = J.n_begin + cb * 16;
+  const int r0 = rb * 16 * RTB, n0 = J.n_begin + cb * 16;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform -> scalar branches
   const int N = J.N, H4 = J.H4;
   const int n = n0 + lr;
-  Seg<RT> s0, s1;
+  Seg<RTB> s0, s1;
   s0.ld = H4; s0.nkb = (H4 + 15) >> 4;
   s0.w = n < J.n_end ? J.K + (size_t)n * H4 : nullptr;
   s1.ld = 0; s1.nkb = 0; s1.w = nullptr;
 #pragma unroll
-  for (int i = 0; i < RT; ++i) {
+  for (int i = 0; i < RTB; ++i) {
     const int arow = r0 + i * 16 + lr;
     s0.a[i] = arow < N ? J.dz + (size_t)arow * H4 : nullptr;
     s1.a[i] = nullptr;
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_b(const BwdBJobs jobs) {
   // epilogue read-modify-write operands, prefetched (first RT*256 threads own one output each)
   const int e_i = tid >> 8, e_r = (tid >> 4) & 15, e_c = tid & 15;
   const int erow = r0 + e_i * 16 + e_r, enn = n0 + e_c;
-  const bool evalid = tid < RT * 256 && erow < N && enn < J.n_end;
+  const bool evalid = tid < RTB * 256 && erow < N && enn < J.n_end;
   float eold = 0.f;
   float* edst = nullptr;
   if (evalid) {
@@ -526,13 +526,13 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_b(const BwdBJobs jobs) {
     }
   }
   const int per = (s0.nkb + NW - 1) / NW;
-  f32x4 acc[RT];
+  f32x4 acc[RTB];
 #pragma unroll
-  for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (VAR & 8) mma_2seg<RT, CH>(acc, s0, s1, w * per, min(s0.nkb, (w + 1) * per), q);      // un-pipelined
-  else mma_2seg_pipe<RT, CH, VAR>(acc, s0, s1, w * per, min(s0.nkb, (w + 1) * per), q);
+  for (int i = 0; i < RTB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (VAR & 8) mma_2seg<RTB, CH>(acc, s0, s1, w * per, min(s0.nkb, (w + 1) * per), q);      // un-pipelined
+  else mma_2seg_pipe<RTB, CH, VAR>(acc, s0, s1, w * per, min(s0.nkb, (w + 1) * per), q);
 #pragma unroll
-  for (int i = 0; i < RT; ++i)
+  for (int i = 0; i < RTB; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) zs[w][i][q * 4 + r][lr] = acc[i][r];
   __syncthreads();
@@ -754,8 +754,8 @@ void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, int kb_max, hipStream_
   hipLaunchKernelGGL(k_bwd_a<8>, dim3(total_blocks), dim3(512), 0, s, jobs);
 }
 void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
-  if (kb_max <= 64)  // small K (the discriminator alone): 8 waves x <= 8 k-blocks, one load round, no pipeline
-    hipLaunchKernelGGL((k_bwd_b<8, 8, 8>), dim3(total_blocks), dim3(512), 0, s, jobs);
+  if (kb_max <= 64)  // small K (the discriminator alone): 8 waves x <= 8 k-blocks, one load round, no pipeline, 16-row tiles
+    hipLaunchKernelGGL((k_bwd_b<8, 8, 8, 1>), dim3(total_blocks), dim3(512), 0, s, jobs);
   else               // 8 waves split K; each runs a double-buffered 6-k-block register pipeline
     hipLaunchKernelGGL((k_bwd_b<8, 0, 6>), dim3(total_blocks), dim3(512), 0, s, jobs);
 }
@@ -862,6 +862,18 @@ void launch_transpose(const float* src, int lds_, float* dst, int ldd, int R, in
   hipLaunchKernelGGL(k_transpose, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s, src, lds_, dst, ldd, R, C);
 }
 
+__global__ void k_zero_many(ZeroList zl) {
+  const int j = blockIdx.y;
+  if (j >= zl.n) return;
+  float* p = zl.p[j];
+  const size_t n = zl.len[j];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+void launch_zero_many(const ZeroList& zl, hipStream_t s) {
+  if (zl.n == 0) return;
+  hipLaunchKernelGGL(k_zero_many, dim3(32, zl.n), dim3(256), 0, s, zl);
+}
+
 __global__ void k_fill(float* p, size_t n, float v) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -912,6 +924,50 @@ __global__ void k_colsum2(const float* __restrict__ scratch, float* __restrict__
   for (int i = 0; i < CS_SLICES; ++i) s += scratch[(size_t)i * cols + c];
   out[c] = s;
 }
+// One pass over dZ [rows][4H] and the cell stash: db[4H] = colsum(dZ); dw_i = colsum(dai*c_prev); dw_f = colsum(daf*c_prev);
+// dw_o = colsum(dao*c_cur).  scratch: CS_SLICES x 7H floats.
+__global__ __launch_bounds__(256) void k_lstm_colsums1(const float* __restrict__ dz, const float* __restrict__ cprev,
+                                                       const float* __restrict__ ccur, float* __restrict__ scratch, int rows, int H) {
+  __shared__ float red[7][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int per = (rows + CS_SLICES - 1) / CS_SLICES;
+  const int rbeg = blockIdx.y * per, rend = min(rows, rbeg + per);
+  float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < H) {
+    for (int r = rbeg + rl; r < rend; r += 4) {
+      const float* z = dz + (size_t)r * 4 * H + c;
+      const float di = z[0], dj = z[H], df = z[2 * H], d_o = z[3 * H];
+      const float cp = cprev[(size_t)r * H + c], cc = ccur[(size_t)r * H + c];
+      s[0] += di; s[1] += dj; s[2] += df; s[3] += d_o; s[4] += di * cp; s[5] += df * cp; s[6] += d_o * cc;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) red[k][rl][threadIdx.x & 63] = s[k];
+  __syncthreads();
+  if (rl == 0 && c < H) {
+    const int x = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+      scratch[((size_t)blockIdx.y * 7 + k) * H + c] = ((red[k][0][x] + red[k][1][x]) + red[k][2][x]) + red[k][3][x];
+  }
+}
+__global__ void k_lstm_colsums2(const float* __restrict__ scratch, float* __restrict__ db, float* __restrict__ dwi,
+                                float* __restrict__ dwf, float* __restrict__ dwo, int H) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < CS_SLICES; ++i)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s[k] += scratch[((size_t)i * 7 + k) * H + c];
+  db[c] = s[0]; db[H + c] = s[1]; db[2 * H + c] = s[2]; db[3 * H + c] = s[3];
+  dwi[c] = s[4]; dwf[c] = s[5]; dwo[c] = s[6];
+}
+void launch_lstm_colsums(const float* dz, const float* cprev, const float* ccur, float* db, float* dwi, float* dwf, float* dwo,
+                         int rows, int H, float* scratch, hipStream_t s) {
+  hipLaunchKernelGGL(k_lstm_colsums1, dim3((H + 63) / 64, CS_SLICES), dim3(256), 0, s, dz, cprev, ccur, scratch, rows, H);
+  hipLaunchKernelGGL(k_lstm_colsums2, dim3((H + 255) / 256), dim3(256), 0, s, scratch, db, dwi, dwf, dwo, H);
+}
+
 void launch_colsum(const float* a, int lda, const float* b, int ldb, float* out, int rows, int cols, float* scratch, hipStream_t s) {
   hipLaunchKernelGGL(k_colsum1, dim3((cols + 63) / 64, CS_SLICES), dim3(256), 0, s, a, lda, b, ldb, scratch, rows, cols);
   hipLaunchKernelGGL(k_colsum2, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, out, cols);

@@ -243,7 +243,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   len_dev = alloc<int>(2 * B);
   dyn = alloc<float>(DYN_COUNT); adam_t_dev = alloc<int>(1);
   losses = alloc<float>(8); tmp3 = alloc<float>(4);
-  size_t maxcols = 4 * (size_t)std::max(c.g_cells, c.d_cells);
+  size_t maxcols = 7 * (size_t)std::max(c.g_cells, c.d_cells);
   maxcols = std::max(maxcols, (size_t)Din + 4);
   maxcols = std::max(maxcols, (size_t)std::max(ldP, ldDin));
   scratch = alloc<float>(std::max<size_t>(64 * maxcols, 1024));
@@ -420,11 +420,16 @@ static void fill_bwd_b(BwdBJob& b, const LayerRun& R, int t, bool with_dx) {
 void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const std::vector<int>* offsets,
                         const std::vector<FcStage>* fcs) {
   // zero initial state (cell.zero_state, models/lstm.py:107): slot 0 of c / m for the rows of each run
-  for (auto& ch : chains)
-    for (auto& R : ch) {
-      (void)hipMemsetAsync(R.S->c + (size_t)R.row0 * R.L->H, 0, (size_t)R.N * R.L->H * sizeof(float), s);
-      (void)hipMemsetAsync(R.S->mst + (size_t)R.row0 * R.L->ldP, 0, (size_t)R.N * R.L->ldP * sizeof(float), s);
-    }
+  {
+    ZeroList zl{};
+    for (auto& ch : chains)
+      for (auto& R : ch) {
+        if (zl.n + 2 > 32) { launch_zero_many(zl, s); zl.n = 0; }
+        zl.p[zl.n] = R.S->c + (size_t)R.row0 * R.L->H; zl.len[zl.n++] = (unsigned)((size_t)R.N * R.L->H);
+        zl.p[zl.n] = R.S->mst + (size_t)R.row0 * R.L->ldP; zl.len[zl.n++] = (unsigned)((size_t)R.N * R.L->ldP);
+      }
+    launch_zero_many(zl, s);
+  }
   auto zx_gemm = [&](const LayerRun& R) {     // x-part of every step: zx = in . K[0:I] + bias, batched over T*N frames
     const int H4 = 4 * R.L->H;
     gemm(R.in, R.L->ldI, true, R.ps->W(R.L->tK), H4, false, R.S->gates, H4, T * R.N, H4, R.L->I, R.ps->W(R.L->tb), 0, 0.f, false, s);
@@ -515,11 +520,9 @@ void Model::layer_wgrads_gemms(const LayerRun& R, int t0, int t1, bool accumulat
 void Model::layer_wgrads_colsums(const LayerRun& R, int T, hipStream_t s, float* scr) {
   const LstmLayer& L = *R.L; const LstmStash& S = *R.S; const ParamSet& ps = *R.ps;
   const int H = L.H, H4 = 4 * H, Rws = T * R.N;
-  launch_colsum(S.gates, H4, nullptr, 0, ps.Gd(L.tb), Rws, H4, scr, s);
-  // peepholes: dw_i = sum dai*c_{t-1}; dw_f = sum daf*c_{t-1}; dw_o = sum dao*c_t
-  launch_colsum(S.gates, H4, S.c, H, ps.Gd(L.twi), Rws, H, scr, s);
-  launch_colsum(S.gates + 2 * H, H4, S.c, H, ps.Gd(L.twf), Rws, H, scr, s);
-  launch_colsum(S.gates + 3 * H, H4, S.c + (size_t)R.N * H, H, ps.Gd(L.two), Rws, H, scr, s);
+  // bias: colsum(dZ); peepholes: dw_i = sum dai*c_{t-1}; dw_f = sum daf*c_{t-1}; dw_o = sum dao*c_t -- one pass over dZ
+  (void)H4;
+  launch_lstm_colsums(S.gates, S.c, S.c + (size_t)R.N * H, ps.Gd(L.tb), ps.Gd(L.twi), ps.Gd(L.twf), ps.Gd(L.two), Rws, H, scr, s);
 }
 void Model::layer_wgrads(const LayerRun& R, int T, hipStream_t s) {
   layer_wgrads_gemms(R, 0, T, false, s);
@@ -528,11 +531,16 @@ void Model::layer_wgrads(const LayerRun& R, int T, hipStream_t s) {
 
 void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const std::vector<int>* offsets,
                          const std::vector<FcStage>* fcs) {
-  for (auto& ch : chains)
-    for (auto& R : ch) {
-      (void)hipMemsetAsync(R.S->dc + (size_t)R.row0 * R.L->H, 0, (size_t)R.N * R.L->H * sizeof(float), s);
-      (void)hipMemsetAsync(R.S->dmst + (size_t)R.row0 * R.L->ldP, 0, (size_t)R.N * R.L->ldP * sizeof(float), s);
-    }
+  {
+    ZeroList zl{};
+    for (auto& ch : chains)
+      for (auto& R : ch) {
+        if (zl.n + 2 > 32) { launch_zero_many(zl, s); zl.n = 0; }
+        zl.p[zl.n] = R.S->dc + (size_t)R.row0 * R.L->H; zl.len[zl.n++] = (unsigned)((size_t)R.N * R.L->H);
+        zl.p[zl.n] = R.S->dmst + (size_t)R.row0 * R.L->ldP; zl.len[zl.n++] = (unsigned)((size_t)R.N * R.L->ldP);
+      }
+    launch_zero_many(zl, s);
+  }
   if (!wavefront()) {
     for (auto& ch : chains)
       for (int l = (int)ch.size() - 1; l >= 0; --l) {
@@ -542,7 +550,7 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
           launch_bwd_a(aj, job_blocks(aj.j[0].nblk_c, R.N), kb16(R.L->ldP), s);
           BwdBJobs bj{}; bj.n = 1; fill_bwd_b(bj.j[0], R, t, false); bj.j[0].blk_base = 0;
           if (bwd_b_splitk_ok(bj)) { bwd_b_plan(bj, bwdb_ws); launch_bwd_b_splitk(bj, s); }
-          else launch_bwd_b(bj, job_blocks(bj.j[0].nblk_c, R.N), kb16(4 * R.L->H), s);
+          else launch_bwd_b(bj, job_blocks(bj.j[0].nblk_c, R.N, kb16(4 * R.L->H) <= 64 ? 16 : 32), kb16(4 * R.L->H), s);
         }
         if (R.want_wgrads) layer_wgrads(R, T, s);
         if (R.din) {   // din (+)= dZ . K[0:I]^T, batched over time
@@ -574,7 +582,12 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
     auto flush_b = [&]() {
       if (bj.n) {
         if (bwd_b_splitk_ok(bj)) { bwd_b_plan(bj, bwdb_ws); launch_bwd_b_splitk(bj, s); }
-        else launch_bwd_b(bj, bb, bk, s);
+        else {
+          const int rows = bk <= 64 ? 16 : 32;        // small-K launches use 16-row tiles
+          int base = 0;
+          for (int i = 0; i < bj.n; ++i) { bj.j[i].blk_base = base; base += job_blocks(bj.j[i].nblk_c, bj.j[i].N, rows); }
+          launch_bwd_b(bj, base, bk, s);
+        }
       }
       bj.n = 0; bb = bk = 0;
     };
