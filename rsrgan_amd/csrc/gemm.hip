@@ -21,9 +21,12 @@ constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;
 // Load a 128(x) x 16(k) operand tile into registers (2 float4 per thread).
 //  KC  (k contiguous): element(x,k) = P[x*ld + k]  -> thread: x = idx>>2, k4 = (idx&3)*4
 //  !KC (x contiguous): element(x,k) = P[k*ld + x]  -> thread: k = idx>>5, x4 = (idx&31)*4
+// `P2`/`ld2`/`X1` (x-contiguous operands only): rows x >= X1 of the operand come from a second matrix P2 (column
+// x - X1); X1 % 4 == 0 so a float4 never straddles.  This is how dK = [x_t | m_{t-1}]^T dZ reads its two stashes.
 template <bool KC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int x0, int X, int k0, int K,
-                                          int tid, float4 (&r)[2]) {
+                                          int tid, float4 (&r)[2], const float* __restrict__ P2 = nullptr, int ld2 = 0,
+                                          int X1 = 0) {
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int idx = tid + 256 * u;
@@ -33,7 +36,9 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
       if (x < X && k < K) v = *reinterpret_cast<const float4*>(P + (size_t)x * ld + k);   // k..k+3 < ld (zero pad)
     } else {
       const int k = k0 + (idx >> 5), x = x0 + (idx & 31) * 4;
-      if (k < K && x < X) v = *reinterpret_cast<const float4*>(P + (size_t)k * ld + x);   // x..x+3 < ld (zero pad)
+      if (k < K && x < X)                                                                 // x..x+3 < ld (zero pad)
+        v = (P2 && x >= X1) ? *reinterpret_cast<const float4*>(P2 + (size_t)k * ld2 + (x - X1))
+                            : *reinterpret_cast<const float4*>(P + (size_t)k * ld + x);
     }
     r[u] = v;
   }
@@ -57,7 +62,8 @@ template <bool AKC, bool BKC>
 __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                               float* __restrict__ C, int ldc, int M, int N, int K,
                                               const float* __restrict__ bias, int act, float alpha, int accumulate,
-                                              float* __restrict__ ws, int ldw, int kt_per_split) {
+                                              float* __restrict__ ws, int ldw, int kt_per_split,
+                                              const float* __restrict__ A2, int lda2, int M1) {
   __shared__ __attribute__((aligned(16))) float As[BK][LDT];
   __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -85,14 +91,14 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
   const int kt0 = blockIdx.z * kt_per_split;
   const int nk = min(nk_all, kt0 + kt_per_split);
   float4 ra[2], rb[2];
-  load_tile<AKC>(A, lda, m0, MA, kt0 * BK, KA, tid, ra);
+  load_tile<AKC>(A, lda, m0, MA, kt0 * BK, KA, tid, ra, A2, lda2, M1);
   load_tile<BKC>(B, ldb, n0, NB, kt0 * BK, KB, tid, rb);
   for (int kt = kt0; kt < nk; ++kt) {
     store_tile<AKC>(As, tid, ra);
     store_tile<BKC>(Bs, tid, rb);
     __syncthreads();
     if (kt + 1 < nk) {
-      load_tile<AKC>(A, lda, m0, MA, (kt + 1) * BK, KA, tid, ra);
+      load_tile<AKC>(A, lda, m0, MA, (kt + 1) * BK, KA, tid, ra, A2, lda2, M1);
       load_tile<BKC>(B, ldb, n0, NB, (kt + 1) * BK, KB, tid, rb);
     }
 #pragma unroll
@@ -151,18 +157,35 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
   }
 }
 
-void launch_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool b_kc, float* C, int ldc,
-                 int M, int N, int K, const float* bias, int act, float alpha, bool accumulate, hipStream_t s,
-                 float* ws, size_t ws_floats) {
+// Split-K factor for an under-filled output grid (weight gradients: few tiles, K = T*B).  Model: the busiest CU runs
+// ceil(tiles*s/256) workgroups of ceil(nk/s) k-tiles (~1.2 us each; 25 % slower when fewer than two workgroups per CU
+// hide each other's latency), then the reduce streams s partial images at ~4 TB/s.
+static int pick_splits(int tiles, int nk, size_t out_bytes, int max_splits) {
+  int best = 1;
+  double best_cost = 1e30;
+  for (int sp = 1; sp <= max_splits; ++sp) {
+    const int per = (nk + sp - 1) / sp;
+    if (sp > 1 && per < 4) break;
+    const int wgs = tiles * sp;
+    double cost = (double)((wgs + 255) / 256) * per * 1.2 * (wgs < 512 ? 1.25 : 1.0);
+    if (sp > 1) cost += 2.8 + (double)(sp + 1) * out_bytes / 4.0e6;
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
+  }
+  return best;
+}
+
+void launch_gemm2(const float* A, int lda, const float* A2, int lda2, int M1, bool a_kc, const float* B, int ldb, bool b_kc,
+                  float* C, int ldc, int M, int N, int K, const float* bias, int act, float alpha, bool accumulate,
+                  hipStream_t s, float* ws, size_t ws_floats) {
   if (M <= 0 || N <= 0) return;
   const int gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
   const int nk = (K + BK - 1) / BK;
-  // fill the 256 CUs: under-filled output grids (weight gradients: few tiles, K = T*B) split K
   int splits = 1;
   const int ldw = (N + 3) & ~3;
   if (ws && gx * gy < 192 && nk >= 8) {
-    splits = std::min(std::min((512 + gx * gy - 1) / (gx * gy), nk / 4), 64);
-    while (splits > 1 && (size_t)splits * M * ldw > ws_floats) --splits;
+    int cap = 64;
+    while (cap > 1 && (size_t)cap * M * ldw > ws_floats) --cap;
+    splits = pick_splits(gx * gy, nk, (size_t)M * ldw * sizeof(float), cap);
   }
   const int per = std::max(1, (nk + splits - 1) / splits);
   splits = std::max(1, (nk + per - 1) / per);
@@ -170,18 +193,24 @@ void launch_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bo
   dim3 grid(gx, gy, splits), block(256);
   const int acc = accumulate ? 1 : 0;
   if (a_kc && !b_kc)
-    hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per);
+    hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per, nullptr, 0, 0);
   else if (a_kc && b_kc)
-    hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per);
+    hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per, nullptr, 0, 0);
   else if (!a_kc && !b_kc)
-    hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per);
+    hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per, A2, lda2, M1);
   else
-    hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per);
+    hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per, A2, lda2, M1);
   if (splits > 1) {
     const size_t total = (size_t)M * N;
     const int blocks = (int)std::min<size_t>(2048, (total + 255) / 256);
     hipLaunchKernelGGL(k_splitk_reduce, dim3(blocks), dim3(256), 0, s, ws, ldw, splits, C, ldc, M, N, bias, act, alpha, acc);
   }
+}
+
+void launch_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool b_kc, float* C, int ldc,
+                 int M, int N, int K, const float* bias, int act, float alpha, bool accumulate, hipStream_t s,
+                 float* ws, size_t ws_floats) {
+  launch_gemm2(A, lda, nullptr, 0, 0, a_kc, B, ldb, b_kc, C, ldc, M, N, K, bias, act, alpha, accumulate, s, ws, ws_floats);
 }
 
 }  // namespace rsr

@@ -104,6 +104,9 @@ void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s);
 // ---------------------------------------------------------------- batched GEMM
 // C[M,N] (+)= A.B (+bias)(lrelu).  a_kc: A(m,k)=A[m*lda+k] else A[k*lda+m];
 // b_kc: B(k,n)=B[n*ldb+k] else B[k*ldb+n].
+void launch_gemm2(const float* A, int lda, const float* A2, int lda2, int M1, bool a_kc, const float* B, int ldb, bool b_kc,
+                  float* C, int ldc, int M, int N, int K, const float* bias, int act, float alpha, bool accumulate,
+                  hipStream_t s, float* ws, size_t ws_floats);   // rows >= M1 of an m-contiguous A come from A2
 void launch_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool b_kc,
                  float* C, int ldc, int M, int N, int K,
                  const float* bias, int act, float alpha, bool accumulate, hipStream_t s,

@@ -512,8 +512,13 @@ void Model::layer_wgrads_gemms(const LayerRun& R, int t0, int t1, bool accumulat
   const size_t r0 = (size_t)t0 * R.N;
   float* dK = ps.Gd(L.tK);
   // dK[0:I] (+)= in^T . dZ ; dK[I:I+P] (+)= m_{t-1}^T . dZ ; dWp (+)= h^T . dm   over frames [t0, t1)
-  gemm(R.in + r0 * L.ldI, L.ldI, false, S.gates + r0 * H4, H4, false, dK, H4, L.I, H4, Rws, nullptr, 0, 0.f, accumulate, s);
-  gemm(S.mst + r0 * L.ldP, L.ldP, false, S.gates + r0 * H4, H4, false, dK + (size_t)L.I * H4, H4, L.P, H4, Rws, nullptr, 0, 0.f, accumulate, s);
+  if (L.I % 4 == 0) {        // one GEMM over the stacked operand [x_t | m_{t-1}] (two source stashes, one output tensor)
+    launch_gemm2(R.in + r0 * L.ldI, L.ldI, S.mst + r0 * L.ldP, L.ldP, L.I, false, S.gates + r0 * H4, H4, false, dK, H4,
+                 L.I + L.P, H4, Rws, nullptr, 0, 0.f, accumulate, s, (side && s == side) ? gemm_ws2 : gemm_ws, gemm_ws_floats);
+  } else {
+    gemm(R.in + r0 * L.ldI, L.ldI, false, S.gates + r0 * H4, H4, false, dK, H4, L.I, H4, Rws, nullptr, 0, 0.f, accumulate, s);
+    gemm(S.mst + r0 * L.ldP, L.ldP, false, S.gates + r0 * H4, H4, false, dK + (size_t)L.I * H4, H4, L.P, H4, Rws, nullptr, 0, 0.f, accumulate, s);
+  }
   if (L.has_proj)
     gemm(S.h + r0 * L.ldH, L.ldH, false, S.dmt + r0 * L.ldP, L.ldP, false, ps.Gd(L.tWp), L.ldP, H, L.P, Rws, nullptr, 0, 0.f, accumulate, s);
 }
