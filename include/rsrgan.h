@@ -104,6 +104,8 @@ enum {
   RSRGAN_FLAG_WAVEFRONT = 1,   /* run the stacked LSTMs as one (layer,t) wavefront (default schedule when set) */
   RSRGAN_FLAG_GRAPH = 2,       /* reserved (hipGraph replay; the step is GPU-bound, not launch-bound) */
   RSRGAN_FLAG_NO_SPLITK_B = 8, /* backward phase B as one launch of 32x16 tiles (round-1 first form) instead of split-K + reduce */
+  RSRGAN_FLAG_SUPERVISED = 16, /* generator-only trainer (models/rnn_trainer.py:66-156, models/dnn_trainer.py:64-148):
+                                  g_loss = mse_lambda*g_mse + g_l2, no discriminator pass; rsrgan_d_step is an error */
   RSRGAN_FLAG_OVERLAP = 4      /* weight-gradient GEMMs on a side stream, chunked over time, concurrent with the backward
                                   wave (measured SLOWER on MI355X: 12.77 vs 12.20 ms/step; off by default) */
 };

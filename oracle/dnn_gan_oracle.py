@@ -158,9 +158,13 @@ class GanDnnOracle:
         cfg = self.cfg
         x, lab = np.asarray(x, self.dtype), np.asarray(lab, self.dtype)
         y, gacts = fc_stack_fwd(self.g, "g_model", cfg.g_hidden + 1, x)
-        out, raw, dacts = d_forward(cfg, self.d, np.concatenate([self._d_inputs(x), y], 1))
-        diff = out - 1.0
-        g_adv = float(np.mean(diff * diff))
+        supervised = getattr(self, "supervised", False)          # models/dnn_trainer.py:139-148: g_loss = g_mse + g_l2
+        if supervised:
+            g_adv = 0.0
+        else:
+            out, raw, dacts = d_forward(cfg, self.d, np.concatenate([self._d_inputs(x), y], 1))
+            diff = out - 1.0
+            g_adv = float(np.mean(diff * diff))
         e = y - lab
         g_mse = float(0.5 * np.mean(e * e) * cfg.output_dim)
         if (not self.cross_validation) and self.l2_scale > 0:
@@ -170,9 +174,11 @@ class GanDnnOracle:
         g_loss = g_adv + self.mse_lambda * g_mse + g_l2
         grads = None
         if want_grads:
-            draw = 2.0 * diff / diff.size * clip_grad_mask(cfg, raw)
-            djoint, _ = fc_stack_bwd(self.d, "d_model", cfg.d_hidden + 1, dacts, draw, want_dx=True)
-            dy = djoint[:, cfg.input_dim:] + self.mse_lambda * cfg.output_dim * e / e.size
+            dy = self.mse_lambda * cfg.output_dim * e / e.size
+            if not supervised:
+                draw = 2.0 * diff / diff.size * clip_grad_mask(cfg, raw)
+                djoint, _ = fc_stack_bwd(self.d, "d_model", cfg.d_hidden + 1, dacts, draw, want_dx=True)
+                dy = dy + djoint[:, cfg.input_dim:]
             _, grads = fc_stack_bwd(self.g, "g_model", cfg.g_hidden + 1, gacts, dy, want_dx=False)
             if g_l2 != 0.0 or ((not self.cross_validation) and self.l2_scale > 0):
                 for k in grads:

@@ -504,9 +504,21 @@ class GanRnnOracle:
     def g_tower(self, x, lab, ln, noise_fake=None, want_grads=True):
         cfg = self.cfg
         y, cg = generator_fwd(cfg, self.g, x, ln)
+        mse, dy_mse = g_mse(y, lab, cfg.output_dim)
+        if getattr(self, "supervised", False):
+            # models/rnn_trainer.py:146-156 (RNNTrainer): g_loss = g_mse + g_l2, no discriminator in the graph
+            if (not self.cross_validation) and self.l2_scale > 0.0:
+                g_l2, l2g = l2_term(self.g, self.l2_scale)
+            else:
+                g_l2, l2g = 0.0, {}
+            grads = None
+            if want_grads:
+                grads = generator_bwd(cfg, self.g, cg, self.mse_lambda * dy_mse)
+                for k, v in l2g.items():
+                    grads[k] = grads[k] + v
+            return (0.0, mse, g_l2, self.mse_lambda * mse + g_l2), grads, y
         lf_, cf = discriminator_fwd(cfg, self.d, y, ln, noise_fake)
         g_adv, dlf = lsgan_mean_sq(lf_, self.d_real)
-        mse, dy_mse = g_mse(y, lab, cfg.output_dim)
         if (not self.cross_validation) and self.l2_scale > 0.0:
             g_l2, l2g = l2_term(self.g, self.l2_scale)
         else:

@@ -93,14 +93,21 @@ int Model::dnn_g_backward(const float* x, const float* labels, int T, float* out
     fc_forward(G, gfc, g_act, R, s);
     g_fwd_valid = true;
   }
-  launch_build_joint(x_tm, ldDin, cfg.d_joint_off, cfg.d_joint_dim, y_tm, ldDout, Dout, joint, ldJ, 0, R, s);
-  d_dnn_forward_loss(1, R, 0, want_grads, tmp3, s);      // g_adv = mean((D(fake) - 1)^2)  gan.py:202
-  launch_copy_f(tmp3 + 1, losses + 3, 1, s);
+  const bool sup = supervised();           // DNNTrainer (models/dnn_trainer.py:139-148): g_loss = g_mse + g_l2, no discriminator
+  if (sup) {
+    HIPC(hipMemsetAsync(losses + 3, 0, sizeof(float), s));
+  } else {
+    launch_build_joint(x_tm, ldDin, cfg.d_joint_off, cfg.d_joint_dim, y_tm, ldDout, Dout, joint, ldJ, 0, R, s);
+    d_dnn_forward_loss(1, R, 0, want_grads, tmp3, s);      // g_adv = mean((D(fake) - 1)^2)  gan.py:202
+    launch_copy_f(tmp3 + 1, losses + 3, 1, s);
+  }
   const bool l2_on = !cfg.cross_validation && scal[RSRGAN_L2_SCALE] > 0.0;
   if (want_grads) {
-    float* dj = fc_backward(D, dfc, d_act, R, dlogits, false, true, s);                 // d g_adv / d joint
-    launch_slice_cols(dj, ldJ, cfg.d_joint_dim, dy_buf, ldDout, R, Dout, s);            // ... / d g
-    launch_mse(y_tm, lab_tm, ldDout, dy_buf, R, Dout, dyn + DYN_LAMBDA, true, losses + 4, scratch, s);
+    if (!sup) {
+      float* dj = fc_backward(D, dfc, d_act, R, dlogits, false, true, s);                 // d g_adv / d joint
+      launch_slice_cols(dj, ldJ, cfg.d_joint_dim, dy_buf, ldDout, R, Dout, s);            // ... / d g
+    }
+    launch_mse(y_tm, lab_tm, ldDout, dy_buf, R, Dout, dyn + DYN_LAMBDA, !sup, losses + 4, scratch, s);
     fc_backward(G, gfc, g_act, R, dy_buf, true, false, s);
     if (l2_on) {
       launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);

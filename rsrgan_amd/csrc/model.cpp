@@ -795,6 +795,7 @@ void Model::g_backward_pass(int T, float* dy, hipStream_t s) {
 int Model::d_backward(const float* x, const float* labels, const int32_t* lengths, int T, const float* nr, const float* nf,
                       float* out_losses, bool want_grads, hipStream_t s) {
   if (!labels) { set_error("labels required"); return RSRGAN_ERR_INVALID; }
+  if (supervised()) { set_error("RSRGAN_FLAG_SUPERVISED: the trainer graph has no discriminator step"); return RSRGAN_ERR_STATE; }
   if (g_dnn()) return dnn_d_backward(x, labels, T, out_losses, want_grads, s);
   int rc = prepare_batch(x, labels, lengths, T, s);
   if (rc) return rc;
@@ -847,6 +848,31 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
                       float* out_losses, bool want_grads, bool reuse, hipStream_t s) {
   if (!labels) { set_error("labels required"); return RSRGAN_ERR_INVALID; }
   if (g_dnn()) return dnn_g_backward(x, labels, T, out_losses, want_grads, reuse, s);
+  if (supervised()) {
+    // RNNTrainer (models/rnn_trainer.py:131-156): g_loss = 0.5*Dout*mse(G(x), labels) + l2; no discriminator in the graph
+    int rc = prepare_batch(x, labels, lengths, T, s);
+    if (rc) return rc;
+    g_forward(T, s);
+    const bool l2s = !cfg.cross_validation && scal[RSRGAN_L2_SCALE] > 0.0;
+    HIPC(hipMemsetAsync(losses + 3, 0, sizeof(float), s));
+    if (want_grads) {
+      float* dy = g_dC;                            // g_backward_pass ping-pongs g_dA / g_dB
+      launch_mse(y_tm, lab_tm, ldDout, dy, T * B, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s);
+      g_backward_pass(T, dy, s);
+      if (l2s) {
+        launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
+        launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);
+      }
+      g_grads_ready = true;
+    } else {
+      launch_mse(y_tm, lab_tm, ldDout, nullptr, T * B, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s);
+    }
+    if (!(want_grads && l2s)) HIPC(hipMemsetAsync(losses + 5, 0, sizeof(float), s));
+    launch_g_total(losses + 3, dyn + DYN_LAMBDA, s);
+    if (out_losses) launch_copy_f(losses + 3, out_losses, 4, s);
+    HIPC(hipGetLastError());
+    return RSRGAN_OK;
+  }
   if (d_dnn()) nf = nullptr;
   if (reuse) {
     if (!g_fwd_valid || T != cur_T) { set_error("reuse_g_forward without a valid generator forward"); return RSRGAN_ERR_STATE; }

@@ -172,6 +172,7 @@ struct Model {
   Chain d_chain(int N, int Ns, int row0);
   void gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool b_kc, float* C, int ldc, int M, int N,
             int K, const float* bias, int act, float alpha, bool accumulate, hipStream_t s);
+  bool supervised() const { return (cfg.flags & RSRGAN_FLAG_SUPERVISED) != 0; }
   bool wavefront() const { return (cfg.flags & RSRGAN_FLAG_WAVEFRONT) != 0; }
   float* g_fc_out_wT = nullptr;   // [Dout][ldP] transposed copy of the output FC weights (per-step FC stage)
   float* bwdb_ws = nullptr;        // split-K partial tiles of backward phase B

@@ -35,7 +35,7 @@ class HipEngine:
                  d_proj: Optional[int] = None, d_type: Optional[str] = None, d_joint_off: Optional[int] = None,
                  d_joint_dim: Optional[int] = None, clip_norm: Optional[float] = None,
                  l2_scale: float = 0.0, cross_validation: bool = False,
-                 ema_decay: float = 0.9999, seed: int = 4321, device: Optional[torch.device] = None, flags: int = 0):
+                 ema_decay: float = 0.9999, seed: int = 4321, device: Optional[torch.device] = None, flags: int = 1):
         if g_type not in _lib.G_TYPES:
             raise ValueError("Unrecognized G type {}".format(g_type))      # gan_rnn_placeholder.py:131-132
         self.lib = _lib.load()

@@ -1,0 +1,82 @@
+"""Generator-only trainers (models/rnn_trainer.py, models/dnn_trainer.py) on the HIP path vs the fp64 oracles
+in supervised mode: g_loss = 0.5*Dout*mse + l2, Adam, clip 15 (RNN) / none (DNN)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+from oracle import dnn_gan_oracle as DO
+from oracle import rsrgan_oracle as O
+from tests.helpers import NET_G, args_for, overrides, rand_batch, rand_params, rel_err, small_cfg, split_flat
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("g_type", ["lstm", "res_lstm_l", "res_lstm_base"])
+def test_rnn_trainer_matches_oracle(g_type, flags):
+    from rsrgan_amd.trainer import RNNTrainer
+    cfg = small_cfg(g_type)
+    B, T = 5, 7
+    g, d = rand_params(cfg, 11)
+    args = args_for(cfg, B, l2_scale=1e-3, g_learning_rate=1e-3)
+    m = RNNTrainer(None, args, ["gpu:0"], max_frames=T, net_overrides=dict(overrides(cfg), flags=flags))
+    m.set_vars(g, d)
+    o = O.GanRnnOracle(cfg, g, d, batch_size=B, l2_scale=1e-3, g_learning_rate=float(np.float32(1e-3)), mse_lambda=1.0)
+    o.supervised = True
+    x, lab, ln = rand_batch(cfg, B, T, seed=5, ragged=True)
+    # tower: losses and gradients
+    got = m.engine.g_backward(x, lab, ln, None, train=True, apply=False).cpu().numpy()
+    want, wg, _ = o.g_tower(x, lab, ln)
+    assert got[0] == 0.0 and np.allclose(got[1:], want[1:], rtol=1e-4), (got, want)
+    gr = split_flat(m.engine.get_grads(NET_G).cpu().numpy(), m.engine.tensor_table(NET_G))
+    for k in wg:
+        assert rel_err(gr[k], wg[k]) < 2e-3, k
+    # three optimizer steps, then the variables
+    for i in range(3):
+        xs, ls, lns = rand_batch(cfg, B, T, seed=20 + i, ragged=i % 2 == 0)
+        got = np.ravel(m.step(xs, ls, lns))
+        w = o.g_step(xs, ls, lns)
+        assert np.allclose(got, np.ravel(w)[1:], rtol=2e-4), (i, got, w)
+    gv, _ = m.get_vars()
+    for k in o.g:
+        assert rel_err(gv[k], o.g[k]) < 1e-3, k
+    with pytest.raises(RuntimeError):
+        m.d_step(x, lab, ln)
+    from rsrgan_amd._lib import RsrganError
+    with pytest.raises(RsrganError):
+        m.engine.d_backward(x, lab, ln)
+    # eval fetch on the cross-validation twin: no l2 term
+    o.cross_validation = True
+    ev = np.ravel(RNNTrainer(None, args, ["gpu:0"], cross_validation=True, share_engine_from=m).step(x, lab, ln))
+    w = o.g_step(x, lab, ln, train=False)
+    assert np.allclose(ev, np.ravel(w)[1:], rtol=2e-4) and ev[1] == 0.0
+
+
+@pytest.mark.parametrize("N", [9, 200])
+def test_dnn_trainer_matches_oracle(N):
+    from rsrgan_amd.trainer import DNNTrainer
+    cfg = DO.DnnCfg(input_dim=6, output_dim=5, left_context=2, right_context=1, g_units=20, g_hidden=3, d_units=18, d_hidden=2)
+    rng = np.random.default_rng(N)
+    g = {k: v.astype(np.float32) for k, v in DO.init_params(DO.g_param_specs(cfg), rng).items()}
+    d = {k: v.astype(np.float32) for k, v in DO.init_params(DO.d_param_specs(cfg), rng, relu_init=True).items()}
+    args = SimpleNamespace(batch_size=N, input_dim=cfg.input_dim, output_dim=cfg.output_dim, left_context=cfg.left_context,
+                           right_context=cfg.right_context, g_type="dnn", keep_prob=1.0, batch_norm=False, num_gpu=1,
+                           save_dir=None, l2_scale=1e-3, g_learning_rate=1e-3)
+    m = DNNTrainer(None, args, ["gpu:0"], net_overrides=dict(g_layers=cfg.g_hidden, g_cells=cfg.g_units, d_layers=cfg.d_hidden, d_cells=cfg.d_units))
+    m.set_vars(g, d)
+    o = DO.GanDnnOracle(cfg, g, d, l2_scale=1e-3, g_learning_rate=float(np.float32(1e-3)), mse_lambda=1.0)
+    o.supervised = True
+    x = rng.standard_normal((N, cfg.fed_dim)).astype(np.float32); lab = rng.standard_normal((N, cfg.output_dim)).astype(np.float32)
+    got = m.engine.g_backward(x[:, None], lab[:, None], None, train=True, apply=False).cpu().numpy()
+    want, wg, _ = o.g_tower(x, lab)
+    assert got[0] == 0.0 and np.allclose(got[1:], want[1:], rtol=1e-4), (got, want)
+    gr = split_flat(m.engine.get_grads(NET_G).cpu().numpy(), m.engine.tensor_table(NET_G))
+    for k in wg:
+        assert rel_err(gr[k], wg[k]) < 2e-3, k
+    for i in range(3):
+        got = np.ravel(m.step(x, lab))
+        assert np.allclose(got, np.ravel(o.g_step(x, lab))[1:], rtol=2e-4)
+    gv, _ = m.get_vars()
+    for k in o.g:
+        assert rel_err(gv[k], o.g[k]) < 1e-3, k

@@ -258,3 +258,26 @@ def test_sequence_model_with_discriminator_dnn_matches_autograd():
     assert np.allclose(ol, tl, rtol=1e-12)
     for k in og:
         assert np.allclose(og[k], tg[k].numpy(), rtol=1e-9, atol=1e-13), k
+
+
+def test_supervised_tower_is_the_mse_gradient():
+    """RNNTrainer graph (models/rnn_trainer.py:146-156): with the discriminator dropped, the generator gradient is the
+    derivative of 0.5*Dout*mse alone -- central differences on a few coordinates of the fp64 oracle."""
+    from tests.helpers import rand_batch, rand_params, small_cfg
+    cfg = small_cfg("lstm")
+    g, d = rand_params(cfg, 2, dtype=np.float64)
+    o = O.GanRnnOracle(cfg, g, d, batch_size=3, mse_lambda=1.0)
+    o.supervised = True
+    x, lab, ln = rand_batch(cfg, 3, 5, seed=9, ragged=True)
+    losses, grads, _ = o.g_tower(x, lab, ln)
+    assert losses[0] == 0.0 and abs(losses[3] - losses[1]) < 1e-12
+    rng = np.random.default_rng(0)
+    for name in list(o.g)[::3]:
+        idx = tuple(rng.integers(0, s) for s in o.g[name].shape)
+        old = o.g[name][idx]
+        eps = 1e-6
+        o.g[name][idx] = old + eps; lp = o.g_tower(x, lab, ln, want_grads=False)[0][3]
+        o.g[name][idx] = old - eps; lm = o.g_tower(x, lab, ln, want_grads=False)[0][3]
+        o.g[name][idx] = old
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - grads[name][idx]) < 1e-6 * max(1.0, abs(fd)), (name, fd, grads[name][idx])
