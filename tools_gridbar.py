@@ -1,0 +1,16 @@
+"""Grid-barrier micro-benchmark driver (rsrgan_microbench kind 4)."""
+import ctypes as C
+import torch
+from rsrgan_amd import _lib
+lib = _lib.load()
+torch.zeros(1, device="cuda")
+us = C.c_float()
+A = 64 * 560            # floats of one layer's [x_t | m_{t-1}] for 64 rows
+for nwg in (256, 512):
+    for name, v, wr, rd in (("flat barrier", 0, 0, 0), ("2-level barrier", 1, 0, 0),
+                            ("flat + write 560 + read 143KB", 2, 560, A), ("2lvl + write 560 + read 143KB", 3, 560, A),
+                            ("2lvl + write 560 + read 36KB", 3, 560, A // 4)):
+        rc = lib.rsrgan_microbench(4, v, nwg, 0, wr, rd, 1, 2000, C.byref(us))
+        print("nwg=%d %-34s rc=%d  %.2f us / iteration" % (nwg, name, rc, us.value), flush=True)
+        if rc:
+            print(lib.rsrgan_last_error())
