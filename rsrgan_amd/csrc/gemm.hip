@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int row = (int)(i / N), col = (int)(i % N);
     float v = 0.f;
+#pragma unroll 8
     for (int z = 0; z < splits; ++z) v += ws[((size_t)z * M + row) * ldw + col];
     if (bias) v += bias[col];
     if (act == 1) v = fmaxf(v, alpha * v);

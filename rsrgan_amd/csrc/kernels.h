@@ -125,6 +125,9 @@ void launch_add_noise_rows(const float* src_tm, const float* noise, float* dst, 
                            int Ns, int row0, hipStream_t s);
 void launch_transpose(const float* src, int lds, float* dst, int ldd, int R, int C, hipStream_t s);        // dst[c][r] = src[r][c]
 void launch_fill(float* p, size_t n, float v, hipStream_t s);
+struct TransposeJob { const float* src; float* dst; int lds, ldd, R, C, blk_base; };   // dst[c][r] = src[r][c]
+struct TransposeList { int n; TransposeJob j[16]; };
+void launch_transpose_many(TransposeList& tl, hipStream_t s);
 struct ZeroList { int n; float* p[32]; unsigned len[32]; };        // many small buffers zeroed by ONE launch
 void launch_zero_many(const ZeroList& zl, hipStream_t s);
 void launch_lstm_colsums(const float* dz, const float* cprev, const float* ccur, float* db, float* dwi, float* dwf, float* dwo,

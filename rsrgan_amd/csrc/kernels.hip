@@ -861,6 +861,31 @@ __global__ void k_transpose(const float* __restrict__ src, int lds_, float* __re
 void launch_transpose(const float* src, int lds_, float* dst, int ldd, int R, int C, hipStream_t s) {
   hipLaunchKernelGGL(k_transpose, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s, src, lds_, dst, ldd, R, C);
 }
+// all transposed weight copies of a network in ONE launch (after every optimizer step)
+__global__ void k_transpose_many(TransposeList tl) {
+  __shared__ float tile[32][33];
+  int j = 0;
+  while (j + 1 < tl.n && (int)blockIdx.x >= tl.j[j + 1].blk_base) ++j;
+  const TransposeJob& J = tl.j[j];
+  const int b = blockIdx.x - J.blk_base, nbc = (J.C + 31) / 32;
+  const int c0 = (b % nbc) * 32, r0 = (b / nbc) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < J.R && c < J.C) ? J.src[(size_t)r * J.lds + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < J.C && r < J.R) J.dst[(size_t)c * J.ldd + r] = tile[tx][i];
+  }
+}
+void launch_transpose_many(TransposeList& tl, hipStream_t s) {
+  if (tl.n == 0) return;
+  int base = 0;
+  for (int i = 0; i < tl.n; ++i) { tl.j[i].blk_base = base; base += ((tl.j[i].C + 31) / 32) * ((tl.j[i].R + 31) / 32); }
+  hipLaunchKernelGGL(k_transpose_many, dim3(base), dim3(256), 0, s, tl);
+}
 
 __global__ void k_zero_many(ZeroList zl) {
   const int j = blockIdx.y;
@@ -934,6 +959,7 @@ __global__ __launch_bounds__(256) void k_lstm_colsums1(const float* __restrict__
   const int rbeg = blockIdx.y * per, rend = min(rows, rbeg + per);
   float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c < H) {
+#pragma unroll 4
     for (int r = rbeg + rl; r < rend; r += 4) {
       const float* z = dz + (size_t)r * 4 * H + c;
       const float di = z[0], dj = z[H], df = z[2 * H], d_o = z[3 * H];
@@ -956,6 +982,7 @@ __global__ void k_lstm_colsums2(const float* __restrict__ scratch, float* __rest
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= H) return;
   float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
   for (int i = 0; i < CS_SLICES; ++i)
 #pragma unroll
     for (int k = 0; k < 7; ++k) s[k] += scratch[((size_t)i * 7 + k) * H + c];

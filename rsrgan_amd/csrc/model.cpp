@@ -307,15 +307,21 @@ void Model::destroy() {
 void Model::refresh_transposes(int net, hipStream_t s) {
   const ParamSet& ps = net == RSRGAN_NET_G ? G : D;
   auto& layers = net == RSRGAN_NET_G ? gl : dl;
+  TransposeList tl{};
+  auto add = [&](const float* src, int lds_, float* dst, int ldd, int R, int C) {
+    if (tl.n == 16) { launch_transpose_many(tl, s); tl.n = 0; }
+    tl.j[tl.n++] = TransposeJob{src, dst, lds_, ldd, R, C, 0};
+  };
   for (auto& L : layers) {
     const float* K = ps.W(L.tK);
     const int H4 = 4 * L.H;
-    launch_transpose(K, H4, L.KxT, L.ldI, L.I, H4, s);                       // [I][4H] -> [4H][ldI]
-    launch_transpose(K + (size_t)L.I * H4, H4, L.KhT, L.ldP, L.P, H4, s);    // [P][4H] -> [4H][ldP]
-    if (L.has_proj) launch_transpose(ps.W(L.tWp), L.ldP, L.WpT, L.ldH, L.H, L.P, s);         // [H][ldP] -> [P][ldH]
+    add(K, H4, L.KxT, L.ldI, L.I, H4);                       // [I][4H] -> [4H][ldI]
+    add(K + (size_t)L.I * H4, H4, L.KhT, L.ldP, L.P, H4);    // [P][4H] -> [4H][ldP]
+    if (L.has_proj) add(ps.W(L.tWp), L.ldP, L.WpT, L.ldH, L.H, L.P);         // [H][ldP] -> [P][ldH]
   }
   if (net == RSRGAN_NET_G && g_fc_out_wT && g_fc_out_w >= 0)
-    launch_transpose(G.W(g_fc_out_w), ldDout, g_fc_out_wT, pad4(gR), gR, Dout, s);   // [P][ldDout] -> [Dout][ldP]
+    add(G.W(g_fc_out_w), ldDout, g_fc_out_wT, pad4(gR), gR, Dout);   // [P][ldDout] -> [Dout][ldP]
+  launch_transpose_many(tl, s);
 }
 
 // ------------------------------------------------------------------------------------------
