@@ -188,6 +188,15 @@ int rsrgan_apply(rsrgan_handle h, int32_t net, void* stream);
 /* device pointer + float count of the (padded) flat gradient buffer of `net`;
  * padding entries are always zero, so it can be all-reduced as one message. */
 int rsrgan_grad_buffer(rsrgan_handle h, int32_t net, float** ptr, int64_t* count);
+/* Gradient buckets (average_gradients iterates per variable, utils/ops.py:356-375): the flat buffer as
+ * contiguous float ranges [offset, offset+count) listed in the order the backward pass completes them (generator, merged
+ * wavefront backward: output FC, input FC, LSTM layer 0..L-1; otherwise one bucket = the whole buffer).  The ranges tile
+ * the buffer exactly.  rsrgan_grad_bucket_wait makes `stream` wait (hipStreamWaitEvent) until bucket i of the most recent
+ * *_backward on this handle is final, so the caller can all-reduce bucket i on a communication stream while the weight
+ * gradients of the later buckets are still being computed. */
+int rsrgan_grad_bucket_count(rsrgan_handle h, int32_t net);
+int rsrgan_grad_bucket_info(rsrgan_handle h, int32_t net, int32_t i, int64_t* offset, int64_t* count);
+int rsrgan_grad_bucket_wait(rsrgan_handle h, int32_t net, int32_t i, void* stream);
 
 /* ---- low-level operator entry points (unit parity tests + micro-benchmarks) ----
  * C[M,N] = op(A)*op(B) (+bias) with fp32 MFMA.  a_kcontig: A is [M,K] row-major

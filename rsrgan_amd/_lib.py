@@ -19,6 +19,7 @@ SYMBOLS = ["rsrgan_default_cfg", "rsrgan_create", "rsrgan_destroy", "rsrgan_last
            "rsrgan_get_scalar", "rsrgan_num_tensors", "rsrgan_tensor_info", "rsrgan_param_count",
            "rsrgan_get_params", "rsrgan_set_params", "rsrgan_get_grads", "rsrgan_forward_g", "rsrgan_d_step",
            "rsrgan_g_step", "rsrgan_d_backward", "rsrgan_g_backward", "rsrgan_apply", "rsrgan_grad_buffer",
+           "rsrgan_grad_bucket_count", "rsrgan_grad_bucket_info", "rsrgan_grad_bucket_wait",
            "rsrgan_op_gemm", "rsrgan_microbench", "rsrgan_version"]
 
 
@@ -69,6 +70,9 @@ def load():
     lib.rsrgan_g_backward.argtypes = [vp, p, p, p, i32, p, p, i32, vp]
     lib.rsrgan_apply.argtypes = [vp, i32, vp]
     lib.rsrgan_grad_buffer.argtypes = [vp, i32, C.POINTER(p), C.POINTER(i64)]
+    lib.rsrgan_grad_bucket_count.argtypes = [vp, i32]
+    lib.rsrgan_grad_bucket_info.argtypes = [vp, i32, i32, C.POINTER(i64), C.POINTER(i64)]
+    lib.rsrgan_grad_bucket_wait.argtypes = [vp, i32, i32, vp]
     lib.rsrgan_op_gemm.argtypes = [p, i32, i32, p, i32, i32, p, i32, i32, i32, i32, p, i32, f32, i32, vp]
     lib.rsrgan_microbench.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(f32)]
     _lib = lib

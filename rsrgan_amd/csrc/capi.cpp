@@ -217,6 +217,28 @@ int rsrgan_grad_buffer(rsrgan_handle h, int32_t net, float** ptr, int64_t* count
   return RSRGAN_OK;
 }
 
+int rsrgan_grad_bucket_count(rsrgan_handle h, int32_t net) {
+  if (!h || (net != RSRGAN_NET_G && net != RSRGAN_NET_D)) return 0;
+  return (int)h->m.gbk[net].size();
+}
+int rsrgan_grad_bucket_info(rsrgan_handle h, int32_t net, int32_t i, int64_t* offset, int64_t* count) {
+  CHECK_H(h);
+  Model* m = &h->m;
+  if ((net != RSRGAN_NET_G && net != RSRGAN_NET_D) || i < 0 || i >= (int)m->gbk[net].size() || !offset || !count) {
+    set_error("bad bucket index"); return RSRGAN_ERR_INVALID;
+  }
+  *offset = m->gbk[net][i].off;
+  *count = m->gbk[net][i].count;
+  return RSRGAN_OK;
+}
+int rsrgan_grad_bucket_wait(rsrgan_handle h, int32_t net, int32_t i, void* stream) {
+  CHECK_H(h);
+  Model* m = &h->m;
+  if ((net != RSRGAN_NET_G && net != RSRGAN_NET_D) || i < 0 || i >= (int)m->gbk[net].size()) { set_error("bad bucket index"); return RSRGAN_ERR_INVALID; }
+  if (hipStreamWaitEvent((hipStream_t)stream, m->gbk[net][i].ev, 0) != hipSuccess) { set_error("hipStreamWaitEvent failed"); return RSRGAN_ERR_HIP; }
+  return RSRGAN_OK;
+}
+
 int rsrgan_op_gemm(const float* A, int32_t lda, int32_t a_kc, const float* B, int32_t ldb, int32_t b_kc, float* C, int32_t ldc,
                    int32_t M, int32_t N, int32_t K, const float* bias, int32_t act, float alpha, int32_t accumulate, void* stream) {
   if (!A || !B || !C || (lda & 3) || (ldb & 3)) { set_error("op_gemm: null pointer or leading dimension not a multiple of 4"); return RSRGAN_ERR_INVALID; }

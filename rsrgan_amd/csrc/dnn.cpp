@@ -73,7 +73,7 @@ int Model::dnn_d_backward(const float* x, const float* labels, int T, float* out
   d_dnn_forward_loss(1, 2 * R, R, want_grads, losses, s);
   if (want_grads) {
     fc_backward(D, dfc, d_act, 2 * R, dlogits, true, false, s);
-    d_grads_ready = true;
+    { finish_buckets(RSRGAN_NET_D, s); d_grads_ready = true; }
   }
   if (out_losses) launch_copy_f(losses, out_losses, 3, s);
   HIPC(hipGetLastError());
@@ -113,7 +113,7 @@ int Model::dnn_g_backward(const float* x, const float* labels, int T, float* out
       launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
       launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);
     }
-    g_grads_ready = true;
+    { finish_buckets(RSRGAN_NET_G, s); g_grads_ready = true; }
   } else {
     launch_mse(y_tm, lab_tm, ldDout, nullptr, R, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s);
   }

@@ -288,6 +288,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   HIPC(hipMemcpy(dyn, hdyn, sizeof(hdyn), hipMemcpyHostToDevice));
   refresh_transposes(RSRGAN_NET_G, nullptr);
   refresh_transposes(RSRGAN_NET_D, nullptr);
+  { int rc = build_buckets(); if (rc) return rc; }
   HIPC(hipDeviceSynchronize());
   HIPC(hipGetLastError());
   return RSRGAN_OK;
@@ -300,8 +301,50 @@ void Model::destroy() {
     (void)hipStreamDestroy(side);
     side = nullptr;
   }
+  for (auto& v : gbk) { for (auto& b : v) if (b.ev) (void)hipEventDestroy(b.ev); v.clear(); }
   for (void* p : allocs) (void)hipFree(p);
   allocs.clear();
+}
+
+int Model::build_buckets() {
+  auto range = [](const ParamSet& ps, int lo, int hi, GradBucket& b) {      // tensors lo..hi inclusive
+    b.off = ps.t[lo].off;
+    b.count = (hi + 1 < (int)ps.t.size() ? ps.t[hi + 1].off : ps.padded) - b.off;
+  };
+  auto whole = [](const ParamSet& ps, std::vector<GradBucket>& v) { GradBucket b; b.off = 0; b.count = ps.padded; v.assign(1, b); };
+  whole(D, gbk[RSRGAN_NET_D]);
+  whole(G, gbk[RSRGAN_NET_G]);
+  if (!g_dnn() && wavefront()) {
+    // completion order of the merged generator backward: output FC, input FC (g_type lstm), then the LSTM layers
+    std::vector<GradBucket> v;
+    bool ok = true;
+    GradBucket b;
+    range(G, g_fc_out_w, g_fc_out_b, b); ok = ok && g_fc_out_b == g_fc_out_w + 1; v.push_back(b);
+    if (cfg.g_type == RSRGAN_G_LSTM) { range(G, g_fc_in_w, g_fc_in_b, b); ok = ok && g_fc_in_b == g_fc_in_w + 1; v.push_back(b); }
+    for (auto& L : gl) {
+      const int lo = L.tK, hi = L.has_proj ? L.tWp : L.two;
+      ok = ok && L.tb > lo && L.tb < hi && L.twf > lo && L.twi > lo && L.two <= hi && hi - lo == (L.has_proj ? 5 : 4);
+      range(G, lo, hi, b); v.push_back(b);
+    }
+    int64_t covered = 0;
+    for (auto& x : v) covered += x.count;
+    if (ok && covered == G.padded) gbk[RSRGAN_NET_G] = v;      // else: keep the single whole-buffer bucket
+  }
+  for (auto& v : gbk)
+    for (auto& b : v)
+      if (hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return RSRGAN_ERR_HIP; }
+  return RSRGAN_OK;
+}
+void Model::mark_bucket(int net, int i, hipStream_t s) {
+  GradBucket& b = gbk[net][i];
+  (void)hipEventRecord(b.ev, s);
+  b.marked = true;
+}
+void Model::finish_buckets(int net, hipStream_t s) {
+  for (auto& b : gbk[net]) {
+    if (!b.marked) (void)hipEventRecord(b.ev, s);
+    b.marked = false;
+  }
 }
 
 void Model::refresh_transposes(int net, hipStream_t s) {
@@ -658,7 +701,7 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
     hipEvent_t ev = ev_pool[ev_next++ & 15];
     (void)hipEventRecord(ev, side);
     (void)hipStreamWaitEvent(s, ev, 0);                     // join: the optimizer needs every gradient
-  } else {
+  } else if (!defer_wgrads) {
     for (auto& ch : chains)
       for (auto& R : ch)
         if (R.want_wgrads) layer_wgrads(R, T, s);
@@ -836,13 +879,13 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
   }
   if (d_dnn()) {
     d_dnn_forward_loss(T, 2 * B, B, want_grads, losses, s);
-    if (want_grads) { fc_backward(D, dfc, d_act, T * 2 * B, dlogits, true, false, s); d_grads_ready = true; }
+    if (want_grads) { fc_backward(D, dfc, d_act, T * 2 * B, dlogits, true, false, s); { finish_buckets(RSRGAN_NET_D, s); d_grads_ready = true; } }
   } else {
     d_logits(2 * B, T, s);
     launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, 2 * B, B, dyn + DYN_D_REAL, dyn + DYN_D_FAKE, losses, s);
     if (want_grads) {
       d_backward_pass(2 * B, T, true, false, dlogits, s);
-      d_grads_ready = true;
+      { finish_buckets(RSRGAN_NET_D, s); d_grads_ready = true; }
     }
   }
   if (out_losses) launch_copy_f(losses, out_losses, 3, s);
@@ -869,7 +912,7 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
         launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
         launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);
       }
-      g_grads_ready = true;
+      { finish_buckets(RSRGAN_NET_G, s); g_grads_ready = true; }
     } else {
       launch_mse(y_tm, lab_tm, ldDout, nullptr, T * B, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s);
     }
@@ -926,7 +969,7 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
       launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
       launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);
     }
-    g_grads_ready = true;
+    { finish_buckets(RSRGAN_NET_G, s); g_grads_ready = true; }
   } else if (want_grads && wavefront()) {
     // ONE backward wave: D's layers (data gradient only) | per-step output-FC backward | G's layers.
     // dy[t] = lambda*(y-lab)/(B*T) (written first) + d g_adv/d y[t] (accumulated by D layer 0's phase B)
@@ -961,20 +1004,30 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     std::vector<Chain> chains{dch, gch};
     std::vector<int> offs{0, Ld + 1};
     std::vector<FcStage> fcs{F};
+    const bool bucketed = gbk[RSRGAN_NET_G].size() > 1 && !overlap();
+    defer_wgrads = bucketed;
     rnn_backward(chains, T, s, &offs, &fcs);
+    defer_wgrads = false;
+    int bi = 0;
     // output FC parameter gradients (batched over time, dy is complete now)
     gemm(g_ins[Lg], ldP, false, dy, ldDout, false, G.Gd(g_fc_out_w), ldDout, P, Dout, R, nullptr, 0, 0.f, false, s);
     launch_colsum(dy, ldDout, nullptr, 0, G.Gd(g_fc_out_b), R, Dout, scratch, s);
+    if (bucketed) mark_bucket(RSRGAN_NET_G, bi++, s);
     if (cfg.g_type == RSRGAN_G_LSTM) {
       // through leakyrelu and the input FC (models/lstm.py:82-87); bufA now holds d(h0)
       launch_lrelu_bwd(g_h0, bufA, (size_t)R, P, ldP, cfg.lrelu_alpha, s);
       gemm(x_tm, ldDin, false, bufA, ldP, false, G.Gd(g_fc_in_w), ldP, Din, P, R, nullptr, 0, 0.f, false, s);
       launch_colsum(bufA, ldP, nullptr, 0, G.Gd(g_fc_in_b), R, P, scratch, s);
+      if (bucketed) mark_bucket(RSRGAN_NET_G, bi++, s);
     }
+    if (bucketed)          // LSTM weight gradients layer by layer: each completes one bucket (all-reduced while the next runs)
+      for (auto& Rr : chains[1]) { layer_wgrads(Rr, T, s); mark_bucket(RSRGAN_NET_G, bi++, s); }
     if (l2_on) {
       launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
       launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);
+      for (auto& b : gbk[RSRGAN_NET_G]) b.marked = false;      // the L2 term touches every tensor: all buckets final only now
     }
+    finish_buckets(RSRGAN_NET_G, s);
     g_grads_ready = true;
   } else if (want_grads) {
     d_backward_pass(B, T, false, true, dlogits, s);
@@ -985,7 +1038,7 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
       launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
       launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);
     }
-    g_grads_ready = true;
+    { finish_buckets(RSRGAN_NET_G, s); g_grads_ready = true; }
   } else {
     launch_mse(y_tm, lab_tm, ldDout, nullptr, T * B, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s);
   }

@@ -163,6 +163,15 @@ struct Model {
   void layer_wgrads_colsums(const LayerRun& R, int T, hipStream_t s, float* scr);
   // side stream: weight-gradient GEMMs (MFMA-bound) overlap the byte-bound backward wave
   hipStream_t side = nullptr;
+  // gradient buckets: contiguous ranges of the flat gradient buffer in the order the backward completes them,
+  // each with an event recorded on the compute stream when its range is final -> the caller all-reduces bucket i while the
+  // weight-gradient GEMMs of bucket i+1.. are still running.
+  struct GradBucket { int64_t off = 0, count = 0; hipEvent_t ev = nullptr; bool marked = false; };
+  std::vector<GradBucket> gbk[2];
+  bool defer_wgrads = false;       // rnn_backward leaves the weight-gradient launches of want_wgrads runs to its caller
+  int build_buckets();
+  void mark_bucket(int net, int i, hipStream_t s);
+  void finish_buckets(int net, hipStream_t s);     // record every bucket not marked by this backward, reset the marks
   hipEvent_t ev_pool[16] = {};
   int ev_next = 0;
   float* gemm_ws2 = nullptr;

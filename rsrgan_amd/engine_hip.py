@@ -6,6 +6,7 @@ GAN step happens in torch."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -74,6 +75,7 @@ class HipEngine:
         self.h = C.c_void_p()
         check(self.lib.rsrgan_create(C.byref(cfg), C.c_uint64(seed), C.byref(self.h)))
         self._grad_views = {}
+        self._comm_stream = None
         self.d_has_adam = g_type == "dnn"
 
     def close(self):
@@ -155,6 +157,38 @@ class HipEngine:
             check(self.lib.rsrgan_grad_buffer(self.h, net, C.byref(p), C.byref(n)))
             self._grad_views[net] = torch.as_tensor(_RawDeviceBuffer(p.value, n.value), device=self.device)
         return self._grad_views[net]
+
+    def grad_buckets(self, net: int) -> List[Tuple[int, int]]:
+        """(offset, count) float ranges of the gradient buffer in the order the backward completes them."""
+        out = []
+        for i in range(self.lib.rsrgan_grad_bucket_count(self.h, net)):
+            off, cnt = C.c_int64(), C.c_int64()
+            check(self.lib.rsrgan_grad_bucket_info(self.h, net, i, C.byref(off), C.byref(cnt)))
+            out.append((off.value, cnt.value))
+        return out
+
+    def all_reduce_grads(self, net: int, group=None, force: bool = False):
+        """average_gradients (utils/ops.py:343-376) over ranks: one all-reduce per gradient bucket, issued on a
+        communication stream that waits only for that bucket's completion event, so RCCL moves the first buckets over
+        xGMI while the weight-gradient GEMMs of the later ones still run.  RSRGAN_BUCKETED_ALLREDUCE=0 (or a single
+        bucket) falls back to one all-reduce of the whole buffer on the compute stream."""
+        from . import dist as rdist
+        ws = rdist.world_size(group)
+        if ws == 1 and not force:
+            return
+        view = self.grad_view(net)
+        buckets = self.grad_buckets(net)
+        if len(buckets) <= 1 or os.environ.get("RSRGAN_BUCKETED_ALLREDUCE", "1") == "0":
+            rdist.all_reduce_mean_(view, group)
+            return
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=self.device)
+        comm, cur = self._comm_stream, torch.cuda.current_stream(self.device)
+        for i, (off, cnt) in enumerate(buckets):
+            check(self.lib.rsrgan_grad_bucket_wait(self.h, net, i, C.c_void_p(comm.cuda_stream)))
+            with torch.cuda.stream(comm):
+                rdist.all_reduce_mean_(view[off:off + cnt], group)
+        cur.wait_stream(comm)           # rsrgan_apply (clip, update) needs every averaged bucket
 
     # -- the path ----------------------------------------------------------------------
     def forward_g(self, x, lengths) -> torch.Tensor:

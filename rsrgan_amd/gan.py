@@ -71,7 +71,7 @@ class GAN(Model):
         x, lab = self._frames(inputs), self._frames(labels)
         if train and rdist.world_size(self.process_group) > 1:
             losses = self.engine.d_backward(x, lab, None, train=True, apply=False)
-            rdist.all_reduce_mean_(self.engine.grad_view(NET_D), self.process_group)
+            self._average_gradients(NET_D)
             self.engine.apply(NET_D)
         else:
             losses = self.engine.d_backward(x, lab, None, train=train, apply=train)
@@ -87,7 +87,7 @@ class GAN(Model):
         x, lab = self._frames(inputs), self._frames(labels)
         if train and rdist.world_size(self.process_group) > 1:
             losses = self.engine.g_backward(x, lab, None, train=True, reuse=reuse_g_forward, apply=False)
-            rdist.all_reduce_mean_(self.engine.grad_view(NET_G), self.process_group)
+            self._average_gradients(NET_G)
             self.engine.apply(NET_G)
         else:
             losses = self.engine.g_backward(x, lab, None, train=train, reuse=reuse_g_forward, apply=train)

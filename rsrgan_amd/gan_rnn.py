@@ -118,6 +118,18 @@ class Model(object):
         return True
 
 
+def _average_gradients(self, net):
+    """average_gradients over towers (utils/ops.py:343-376) = all-reduce(mean) over ranks; the HIP engine does it bucket
+    by bucket overlapped with the rest of the backward, any other engine (tests) as one all-reduce of the buffer."""
+    if hasattr(self.engine, "all_reduce_grads"):
+        self.engine.all_reduce_grads(net, self.process_group)
+    else:
+        rdist.all_reduce_mean_(self.engine.grad_view(net), self.process_group)
+
+
+Model._average_gradients = _average_gradients
+
+
 class GAN_RNN(Model):
     """Generative Adversarial Network for Speech Enhancement (gan_rnn_placeholder.py:62).
 
@@ -234,7 +246,7 @@ class GAN_RNN(Model):
         ws = rdist.world_size(self.process_group)
         if train and ws > 1:
             losses = self.engine.d_backward(x, lab, ln, nr, nf, train=True, apply=False)
-            rdist.all_reduce_mean_(self.engine.grad_view(NET_D), self.process_group)     # average_gradients
+            self._average_gradients(NET_D)     # average_gradients
             self.engine.apply(NET_D)
         else:
             losses = self.engine.d_backward(x, lab, ln, nr, nf, train=train, apply=train)
@@ -253,7 +265,7 @@ class GAN_RNN(Model):
         ws = rdist.world_size(self.process_group)
         if train and ws > 1:
             losses = self.engine.g_backward(x, lab, ln, nf, train=True, reuse=reuse_g_forward, apply=False)
-            rdist.all_reduce_mean_(self.engine.grad_view(NET_G), self.process_group)
+            self._average_gradients(NET_G)
             self.engine.apply(NET_G)
         else:
             losses = self.engine.g_backward(x, lab, ln, nf, train=train, reuse=reuse_g_forward, apply=train)

@@ -53,5 +53,26 @@ def test_nccl_world1_dp_path_equals_fused_step():
                 assert np.array_equal(p[k], q[k]), k
         assert np.allclose(np.ravel(la), lb.cpu().numpy())
         assert rdist.all_gather_rows(lb).shape == (1, 3)
+        # bucketed path (wavefront schedule): per-bucket events + communication stream, forced at world size 1
+        for g_type in ("lstm", "res_lstm_l"):
+            cfg2 = small_cfg(g_type)
+            c, _ = build_hip_pair(cfg2, 4, 6, seed=65, flags=1)
+            d, _ = build_hip_pair(cfg2, 4, 6, seed=65, flags=1)
+            bk = c.engine.grad_buckets(NET_G)
+            assert len(bk) == cfg2.g_layers + (2 if g_type == "lstm" else 1)
+            assert sorted(bk)[0][0] == 0 and sum(n for _, n in bk) == c.engine.grad_view(NET_G).numel()
+            ends = sorted((o, o + n) for o, n in bk)
+            assert all(ends[i][1] == ends[i + 1][0] for i in range(len(ends) - 1))       # the ranges tile the buffer
+            assert c.engine.grad_buckets(NET_D) == [(0, c.engine.grad_view(NET_D).numel())]
+            for it in range(3):
+                xs, ls, lns = rand_batch(cfg2, 4, 6, seed=70 + it, ragged=True)
+                c.d_step(xs, ls, lns); d.d_step(xs, ls, lns)
+                c.g_step(xs, ls, lns, reuse_g_forward=True)                                # fused
+                d.engine.g_backward(xs, ls, lns, train=True, reuse=True, apply=False)     # DP, bucket by bucket
+                d.engine.all_reduce_grads(NET_G, force=True)
+                d.engine.apply(NET_G)
+            for p_, q_ in zip(c.get_vars(), d.get_vars()):
+                for k in p_:
+                    assert np.array_equal(p_[k], q_[k]), (g_type, k)
     finally:
         dist.destroy_process_group()
