@@ -132,7 +132,11 @@ def measure_sequence(a, net, d_type, B, T, steps, warmup, rank, local, world, de
     losses = last.mean(0).cpu().numpy()
     if not np.all(np.isfinite(losses)):
         raise SystemExit("non-finite losses: %s" % losses)
-    return dict(model=model, g_type=g_type, d_type=d_type, dt=dt, dev_ms=dev_ms, losses=losses)
+    # one more (untimed) step with every launch of the dominant kernel bracketed by HIP events on its stream
+    model.engine.profile_begin()
+    step()
+    prof = model.engine.profile_read()
+    return dict(model=model, g_type=g_type, d_type=d_type, dt=dt, dev_ms=dev_ms, losses=losses, prof=prof)
 
 
 def bench_dnn_gan(a, rank, local, world, dev):
@@ -242,6 +246,16 @@ def main():
                     "scope": "all launches of one (1D+1G) step on one GPU; algorithmic %d FLOP/frame x %d frames "
                              "(SURVEY 8d: 3*F_G+8*F_D, F_G=%d, F_D=%d) / HIP-event step time; traffic = HBM-side bytes "
                              "per step from profiles/r1_final_traffic.json" % (fpf, B * T, fg, fd)}
+            n_l, us_l, fl_l = res["prof"]
+            if n_l:
+                k_ach = fl_l / (us_l * 1e-6) / 1e12
+                roof["dominant_kernel"] = {
+                    "name": "k_fwd_gates", "launches_per_step": n_l, "avg_us": round(us_l / n_l, 3),
+                    "algorithmic_flop_per_launch": round(fl_l / n_l), "achieved": round(k_ach, 3), "unit": "TFLOP/s",
+                    "frac": round(k_ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "how": "every launch of one step bracketed by HIP events on its stream (rsrgan_profile_begin/read); "
+                           "the event-to-event time includes the ~2.7 us dispatch gap per launch that rocprofv3's kernel duration "
+                           "excludes: compare AverageNs of k_fwd_gates<18,2> in profiles/r1_final_rocprofv3_kernel_stats.csv (12.1 us)"}
         out = {"metric": "GAN train frames/sec (G+D step), 257-dim LPS->40-dim MFCC", "value": round(value, 1),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt * 1e3 / a.steps, 4), "higher_is_better": True, "scaling": "weak",

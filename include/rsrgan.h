@@ -198,6 +198,13 @@ int rsrgan_grad_bucket_count(rsrgan_handle h, int32_t net);
 int rsrgan_grad_bucket_info(rsrgan_handle h, int32_t net, int32_t i, int64_t* offset, int64_t* count);
 int rsrgan_grad_bucket_wait(rsrgan_handle h, int32_t net, int32_t i, void* stream);
 
+/* Live timing of the dominant kernel (k_fwd_gates: LSTMCell gates + cell update of every (layer, t) job of a wavefront
+ * diagonal) for bench.py's roofline object: between rsrgan_profile_begin and rsrgan_profile_read every launch of that
+ * kernel is bracketed by HIP events on the stream it runs on; read returns the launch count, the summed event time and
+ * the summed algorithmic FLOPs (2*N*(I+P)*4H per job; the layer-0 x-part is excluded when it was batched into a GEMM). */
+int rsrgan_profile_begin(rsrgan_handle h);
+int rsrgan_profile_read(rsrgan_handle h, int32_t* launches, double* total_us, double* alg_flops);
+
 /* ---- low-level operator entry points (unit parity tests + micro-benchmarks) ----
  * C[M,N] = op(A)*op(B) (+bias) with fp32 MFMA.  a_kcontig: A is [M,K] row-major
  * (else stored [K,M]); b_kcontig: B is stored [N,K] (else [K,N] row-major).

@@ -239,6 +239,27 @@ int rsrgan_grad_bucket_wait(rsrgan_handle h, int32_t net, int32_t i, void* strea
   return RSRGAN_OK;
 }
 
+int rsrgan_profile_begin(rsrgan_handle h) {
+  CHECK_H(h);
+  h->m.prof_on = true; h->m.prof_n = 0; h->m.prof_flops = 0.0;
+  return RSRGAN_OK;
+}
+int rsrgan_profile_read(rsrgan_handle h, int32_t* launches, double* total_us, double* alg_flops) {
+  CHECK_H(h);
+  Model& m = h->m;
+  if (!launches || !total_us || !alg_flops) { set_error("null output pointer"); return RSRGAN_ERR_INVALID; }
+  m.prof_on = false;
+  double us = 0.0;
+  for (int i = 0; i < m.prof_n; ++i) {
+    if (hipEventSynchronize(m.prof_ev[2 * i + 1]) != hipSuccess) { set_error("hipEventSynchronize failed"); return RSRGAN_ERR_HIP; }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, m.prof_ev[2 * i], m.prof_ev[2 * i + 1]) != hipSuccess) { set_error("hipEventElapsedTime failed"); return RSRGAN_ERR_HIP; }
+    us += 1e3 * ms;
+  }
+  *launches = m.prof_n; *total_us = us; *alg_flops = m.prof_flops;
+  return RSRGAN_OK;
+}
+
 int rsrgan_op_gemm(const float* A, int32_t lda, int32_t a_kc, const float* B, int32_t ldb, int32_t b_kc, float* C, int32_t ldc,
                    int32_t M, int32_t N, int32_t K, const float* bias, int32_t act, float alpha, int32_t accumulate, void* stream) {
   if (!A || !B || !C || (lda & 3) || (ldb & 3)) { set_error("op_gemm: null pointer or leading dimension not a multiple of 4"); return RSRGAN_ERR_INVALID; }

@@ -302,6 +302,8 @@ void Model::destroy() {
     side = nullptr;
   }
   for (auto& v : gbk) { for (auto& b : v) if (b.ev) (void)hipEventDestroy(b.ev); v.clear(); }
+  for (auto& e : prof_ev) if (e) (void)hipEventDestroy(e);
+  prof_ev.clear();
   for (void* p : allocs) (void)hipFree(p);
   allocs.clear();
 }
@@ -466,6 +468,23 @@ static void fill_bwd_b(BwdBJob& b, const LayerRun& R, int t, bool with_dx) {
   b.nblk_c = (b.n_end - b.n_begin + 15) / 16;
 }
 
+void Model::gates_launch(const FwdGateJobs& gj, int blocks, int kb, hipStream_t s) {
+  if (!prof_on) { launch_fwd_gates(gj, blocks, kb, s); return; }
+  if ((size_t)(2 * prof_n + 2) > prof_ev.size()) {
+    const size_t old = prof_ev.size();
+    prof_ev.resize(old + 128, nullptr);
+    for (size_t i = old; i < prof_ev.size(); ++i) (void)hipEventCreate(&prof_ev[i]);
+  }
+  for (int i = 0; i < gj.n; ++i) {
+    const FwdGateJob& J = gj.j[i];
+    prof_flops += 2.0 * J.N * ((J.x ? J.ldx : 0) + J.ldm) * 4.0 * J.H;
+  }
+  (void)hipEventRecord(prof_ev[2 * prof_n], s);
+  launch_fwd_gates(gj, blocks, kb, s);
+  (void)hipEventRecord(prof_ev[2 * prof_n + 1], s);
+  ++prof_n;
+}
+
 void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const std::vector<int>* offsets,
                         const std::vector<FcStage>* fcs) {
   // zero initial state (cell.zero_state, models/lstm.py:107): slot 0 of c / m for the rows of each run
@@ -491,7 +510,7 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
         for (int t = 0; t < T; ++t) {
           FwdGateJobs gj{}; gj.n = 1; gj.forget_bias = cfg.forget_bias;
           fill_gate(gj.j[0], R, t, zx); gj.j[0].blk_base = 0;
-          launch_fwd_gates(gj, job_blocks(gj.j[0].nblk_c, R.N, fwd_gates_rows()), (zx ? 0 : kb16(R.L->ldI)) + kb16(R.L->ldP), s);
+          gates_launch(gj, job_blocks(gj.j[0].nblk_c, R.N, fwd_gates_rows()), (zx ? 0 : kb16(R.L->ldI)) + kb16(R.L->ldP), s);
           if (R.L->has_proj) {
             FwdProjJobs pj{}; pj.n = 1;
             fill_proj(pj.j[0], R, t); pj.j[0].blk_base = 0;
@@ -515,7 +534,7 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
     FwdProjJobs pj{};
     int gb = 0, pb = 0, gk = 0, pk = 0;
     // a diagonal's jobs only depend on earlier diagonals, so they may be split over several launches
-    auto flush_g = [&]() { if (gj.n) launch_fwd_gates(gj, gb, gk, s); gj.n = 0; gb = gk = 0; };
+    auto flush_g = [&]() { if (gj.n) gates_launch(gj, gb, gk, s); gj.n = 0; gb = gk = 0; };
     auto flush_p = [&]() { if (pj.n) launch_fwd_proj(pj, pb, pk, s); pj.n = 0; pb = pk = 0; };
     for (size_t c = 0; c < chains.size(); ++c) {
       Chain& ch = chains[c];

@@ -172,6 +172,13 @@ struct Model {
   int build_buckets();
   void mark_bucket(int net, int i, hipStream_t s);
   void finish_buckets(int net, hipStream_t s);     // record every bucket not marked by this backward, reset the marks
+  // live per-kernel timing for bench.py's roofline object: when prof_on, every k_fwd_gates launch is bracketed by HIP events on
+  // the stream it runs on and its algorithmic FLOPs (2*N*(I+P)*4H per job) are summed; read back by rsrgan_profile_read.
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;
+  int prof_n = 0;
+  double prof_flops = 0.0;
+  void gates_launch(const FwdGateJobs& gj, int blocks, int kb, hipStream_t s);
   hipEvent_t ev_pool[16] = {};
   int ev_next = 0;
   float* gemm_ws2 = nullptr;

@@ -232,6 +232,15 @@ class HipEngine:
     def apply(self, net: int):
         check(self.lib.rsrgan_apply(self.h, net, self._stream()))
 
+    def profile_begin(self):
+        check(self.lib.rsrgan_profile_begin(self.h))
+
+    def profile_read(self):
+        """(launches, total_us, algorithmic_flops) of k_fwd_gates since profile_begin (synchronises)."""
+        n, us, fl = C.c_int32(), C.c_double(), C.c_double()
+        check(self.lib.rsrgan_profile_read(self.h, C.byref(n), C.byref(us), C.byref(fl)))
+        return n.value, us.value, fl.value
+
     # -- low-level op (unit tests, micro-bench) ------------------------------------------
     def op_gemm(self, A, a_kc, B, b_kc, C_, M, N, K, bias=None, act=0, alpha=0.3, accumulate=False):
         check(self.lib.rsrgan_op_gemm(_ptr(A), A.stride(0), 1 if a_kc else 0, _ptr(B), B.stride(0), 1 if b_kc else 0,
