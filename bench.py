@@ -206,6 +206,9 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the BASELINE.json-named network variant at N=1")
     ap.add_argument("--flags", type=int, default=int(os.environ.get("RSRGAN_FLAGS", "1")),
                     help="library schedule flags: 1 = wavefront, 4 = side-stream GEMM overlap (include/rsrgan.h)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling (SURVEY 8d): --batch is the GLOBAL batch, split evenly over the ranks (default: weak, "
+                         "--batch per GPU as the reference defines batch_size per tower)")
     a = ap.parse_args()
 
     from rsrgan_amd import GAN_RNN, dist as rdist
@@ -215,6 +218,10 @@ def main():
             print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if a.strong:
+        if a.batch % world:
+            raise SystemExit("--strong: global batch %d not divisible by %d ranks" % (a.batch, world))
+        a.batch //= world
 
     from types import SimpleNamespace
     if a.net == "dnn_gan":
@@ -258,7 +265,7 @@ def main():
                            "excludes: compare AverageNs of k_fwd_gates<18,2> in profiles/r1_final_rocprofv3_kernel_stats.csv (12.1 us)"}
         out = {"metric": "GAN train frames/sec (G+D step), 257-dim LPS->40-dim MFCC", "value": round(value, 1),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(dt * 1e3 / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(dt * 1e3 / a.steps, 4), "higher_is_better": True, "scaling": "strong" if a.strong else "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "gan_rnn_placeholder 1D+%dG step, G=%s(%dx%d/p%d)+D=%s(%dx%d/p%d), B=%d/GPU T=%d, "
                                       "257->40" % (a.gen_updates, g_type, c.g_layers, c.g_cells, c.g_proj, a.d_type, c.d_layers,

@@ -1127,7 +1127,6 @@ void launch_copy_f(const float* src, float* dst, int n, hipStream_t s) {
 // TF-form Adam (:147,184), EMA (:149-150,185-186).  One block per 4096-float chunk; a chunk
 // never straddles two tensors.
 // ---------------------------------------------------------------------------------------
-constexpr int CHUNK = 4096;
 
 __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, ChunkTable ct, float* __restrict__ partial) {
   __shared__ float red[16];

@@ -86,7 +86,7 @@ static int build_chunks(Model& M, ParamSet& ps) {
   }
   auto up = [&](const std::vector<int>& v) -> int* {
     int* d = M.alloc<int>(v.size());
-    if (d) hipMemcpy(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (d && hipMemcpy(d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) d = nullptr;
     return d;
   };
   ps.ct.tensor = up(tensor); ps.ct.off = up(off); ps.ct.len = up(len);

@@ -255,3 +255,27 @@ def test_outer_loop_on_gpu(tmp_path):
     for i in range(2):
         m = r.read_utt_data_from_index(i)
         assert m.shape[1] == dout and np.all(np.isfinite(m))
+
+
+def test_profile_api_counts_gates_launches():
+    """rsrgan_profile_begin/read (bench.py's live dominant-kernel timing): launch count, positive time, algorithmic FLOPs
+    = sum over (layer, t) jobs of 2*N*(I+P)*4H, and no effect on the results."""
+    cfg = small_cfg()
+    B, T = 4, 6
+    model, oracle = build_hip_pair(cfg, B, T, seed=5, flags=1)
+    x, lab, ln = rand_batch(cfg, B, T, seed=6)
+    ref = model.engine.d_backward(x, lab, ln, train=True, apply=False).cpu().numpy()
+    model.engine.profile_begin()
+    got = model.engine.d_backward(x, lab, ln, train=True, apply=False).cpu().numpy()
+    n, us, flops = model.engine.profile_read()
+    assert np.array_equal(ref, got)
+    assert n > 0 and us > 0
+    pad4 = lambda v: (v + 3) // 4 * 4
+    lst = lambda n_, i, h, p: 2.0 * n_ * (pad4(i) + pad4(p)) * 4 * h
+    # generator: layer 0's x-part is batched into a GEMM (not in this kernel); discriminator on 2B rows (real + fake)
+    want = T * (lst(B, 0, cfg.g_cells, cfg.g_proj) + (cfg.g_layers - 1) * lst(B, cfg.g_proj, cfg.g_cells, cfg.g_proj))
+    want += T * (lst(2 * B, cfg.output_dim, cfg.d_cells, cfg.d_proj) + (cfg.d_layers - 1) * lst(2 * B, cfg.d_proj, cfg.d_cells, cfg.d_proj))
+    assert abs(flops - want) <= 1e-6 * want, (flops, want)
+    n2, us2, _ = model.engine.profile_read()          # profiling is off again: nothing new recorded by a further step
+    model.engine.d_backward(x, lab, ln, train=True, apply=False)
+    assert model.engine.profile_read()[0] == n2
