@@ -278,6 +278,12 @@ int rsrgan_op_gemm(const float* A, int32_t lda, int32_t a_kc, const float* B, in
 // proj) on random data; returns the mean microseconds per launch over `reps` launches.
 int rsrgan_microbench(int32_t kind, int32_t variant, int32_t N, int32_t H, int32_t I, int32_t P, int32_t layers,
                       int32_t reps, float* out_us) {
+  if (kind == 5 && out_us) {     // flag exchange in groups: N = workgroups, H = group size, I = floats written per member, reps = iterations
+    const int rc = flagx_microbench(variant, N, reps, H, I, out_us);
+    if (rc == -2) { set_error("microbench: flag spin limit hit"); return RSRGAN_ERR_STATE; }
+    if (rc) { set_error("microbench: hipMalloc"); return RSRGAN_ERR_HIP; }
+    return RSRGAN_OK;
+  }
   if (kind == 4 && out_us) {     // grid-barrier cost: N = workgroups, reps = barriers per launch, I = floats written per WG, P = floats read per WG
     const int rc = gridbar_microbench(variant, N, reps, I, P, out_us);
     if (rc == -2) { set_error("microbench: grid barrier spin limit hit (workgroups not co-resident?)"); return RSRGAN_ERR_STATE; }

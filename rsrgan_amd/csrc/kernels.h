@@ -104,6 +104,7 @@ void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s);
 // ---------------------------------------------------------------- batched GEMM
 // C[M,N] (+)= A.B (+bias)(lrelu).  a_kc: A(m,k)=A[m*lda+k] else A[k*lda+m];
 // b_kc: B(k,n)=B[n*ldb+k] else B[k*ldb+n].
+int flagx_microbench(int variant, int nwg, int iters, int gsz, int wr_floats, float* out_us);          // persist.hip
 int gridbar_microbench(int variant, int nwg, int iters, int wr_floats, int rd_floats, float* out_us);   // persist.hip
 void launch_gemm2(const float* A, int lda, const float* A2, int lda2, int M1, bool a_kc, const float* B, int ldb, bool b_kc,
                   float* C, int ldc, int M, int N, int K, const float* bias, int act, float alpha, bool accumulate,

@@ -74,6 +74,76 @@ __global__ __launch_bounds__(512) void k_gridbar(unsigned* ctrs, float* buf, int
   if (acc == 123.456f) sink[blockIdx.x] = acc;
 }
 
+// kind 5: flag exchange inside small groups (no global barrier).  `gsz` workgroups form a group; per iteration each writes
+// `wr_floats` to its slot, release-stores its flag, acquire-spins on the flags of the other members, then reads all slots.
+// variant 0: a group = consecutive block ids (its members sit on different XCDs); variant 1: a group = ids with equal
+// id % 8 (same XCD under round-robin dispatch).  Two slot sets alternate so a fast member cannot overwrite unread data.
+__global__ __launch_bounds__(512) void k_flagx(unsigned* flags, float* slots, int iters, int variant, int gsz, int wr_floats,
+                                               float* sink, int* err) {
+  const int b = blockIdx.x;
+  int grp, mem;
+  if (variant == 0) { grp = b / gsz; mem = b % gsz; }
+  else { const int x = b & 7, i = b >> 3; grp = x * ((gridDim.x / 8 + gsz - 1) / gsz) + i / gsz; mem = i % gsz; }   // needs gridDim.x >= 8 * gsz
+  unsigned* gflags = flags + (size_t)grp * gsz * 32;            // one 128-B line per flag
+  float* gslots = slots + (size_t)grp * gsz * 2 * wr_floats;
+  float acc = 0.f;
+  __shared__ int bail;
+  if (threadIdx.x == 0) bail = 0;
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    float* mine = gslots + ((size_t)(it & 1) * gsz + mem) * wr_floats;
+    for (int i = threadIdx.x; i < wr_floats; i += blockDim.x) mine[i] = acc + (float)(it + mem);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __atomic_store_n(gflags + mem * 32, (unsigned)(it + 1), __ATOMIC_RELEASE);
+    }
+    if ((int)threadIdx.x < gsz && (int)threadIdx.x != mem) {
+      unsigned spins = 0;
+      while (__atomic_load_n(gflags + threadIdx.x * 32, __ATOMIC_ACQUIRE) < (unsigned)(it + 1)) {
+        if (++spins > SPIN_LIMIT) { *err = 1; bail = 1; break; }
+      }
+    }
+    __syncthreads();
+    if (bail) break;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const float* all = gslots + (size_t)(it & 1) * gsz * wr_floats;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < gsz * wr_floats; i += blockDim.x) s += all[i];
+    acc = acc * 0.5f + 1e-6f * s;
+  }
+  if (acc == 123.456f) sink[blockIdx.x] = acc;
+}
+
+int flagx_microbench(int variant, int nwg, int iters, int gsz, int wr_floats, float* out_us) {
+  unsigned* flags = nullptr; float* slots = nullptr; float* sink = nullptr; int* err = nullptr;
+  if (hipMalloc((void**)&flags, (size_t)nwg * 32 * sizeof(unsigned)) != hipSuccess) return -1;
+  if (hipMalloc((void**)&slots, (size_t)nwg * 2 * wr_floats * sizeof(float) + 64) != hipSuccess) return -1;
+  if (hipMalloc((void**)&sink, nwg * sizeof(float)) != hipSuccess) return -1;
+  if (hipMalloc((void**)&err, sizeof(int)) != hipSuccess) return -1;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  float best = 1e30f;
+  int herr = 0;
+  for (int rep = 0; rep < 3; ++rep) {
+    (void)hipMemset(flags, 0, (size_t)nwg * 32 * sizeof(unsigned));
+    (void)hipMemset(slots, 0, (size_t)nwg * 2 * wr_floats * sizeof(float));
+    (void)hipMemset(err, 0, sizeof(int));
+    (void)hipEventRecord(e0, nullptr);
+    hipLaunchKernelGGL(k_flagx, dim3(nwg), dim3(512), 0, nullptr, flags, slots, iters, variant, gsz, wr_floats, sink, err);
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    best = ms < best ? ms : best;
+    (void)hipMemcpy(&herr, err, sizeof(int), hipMemcpyDeviceToHost);
+    if (herr) break;
+  }
+  *out_us = best * 1000.f / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(flags); (void)hipFree(slots); (void)hipFree(sink); (void)hipFree(err);
+  return herr ? -2 : 0;
+}
+
 int gridbar_microbench(int variant, int nwg, int iters, int wr_floats, int rd_floats, float* out_us) {
   unsigned* ctrs = nullptr; float* buf = nullptr; float* sink = nullptr; int* err = nullptr;
   if (hipMalloc((void**)&ctrs, 32 * 9 * sizeof(unsigned)) != hipSuccess) return -1;

@@ -14,3 +14,14 @@ for nwg in (256, 512):
         print("nwg=%d %-34s rc=%d  %.2f us / iteration" % (nwg, name, rc, us.value), flush=True)
         if rc:
             print(lib.rsrgan_last_error())
+
+print("flag exchange in groups (kind 5): per-iteration time")
+for nwg, gsz in ((16, 4), (16, 8), (64, 8), (64, 4)):
+    for name, v in (("members on different XCDs", 0), ("members on one XCD (id % 8)", 1)):
+        for wr in (640, 2560):
+            if v == 1 and nwg < 8 * gsz:
+                continue
+            rc = lib.rsrgan_microbench(5, v, nwg, gsz, wr, 0, 1, 2000, C.byref(us))
+            print("nwg=%d group=%d wr=%d floats %-30s rc=%d  %.2f us / iteration" % (nwg, gsz, wr, name, rc, us.value), flush=True)
+            if rc:
+                print(lib.rsrgan_last_error())
