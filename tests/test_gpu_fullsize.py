@@ -1,0 +1,102 @@
+"""Parity at BASELINE.json's full sizes (configs[1]: B=32,T=50; configs[2] per GPU: B=64,T=100; reference-true networks):
+the HIP path against the fp64 oracle (losses, every gradient tensor, enhanced-MFCC L1; tolerance 1e-3 relative as the
+north_star states), plus oracle-free properties of the domain at the same size: the tower mean (the N-rank result equals
+the 1-rank result on the concatenated batch), schedule equivalence, frames beyond `lengths`."""
+import numpy as np
+import pytest
+
+from oracle import rsrgan_oracle as O
+from tests.helpers import NET_D, NET_G, build_hip_pair, rand_batch, rel_err, split_flat
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-3           # BASELINE.json north_star: <= 1e-3 relative on losses and enhanced-MFCC L1
+
+
+def _grads(model, net):
+    return split_flat(model.engine.get_grads(net).cpu().numpy(), model.engine.tensor_table(net))
+
+
+@pytest.mark.parametrize("B,T", [(32, 50), (64, 100)])
+def test_full_size_step_against_oracle(B, T):
+    cfg = O.NetCfg()
+    model, oracle = build_hip_pair(cfg, B, T, seed=100 + B, flags=1)
+    x, lab, ln = rand_batch(cfg, B, T, seed=200 + B, ragged=True)
+    x64, lab64 = x.astype(np.float64), lab.astype(np.float64)
+    got = model.engine.d_backward(x, lab, ln, None, None, train=True, apply=False).cpu().numpy()
+    want, wg = oracle.d_tower(x64, lab64, ln)
+    assert np.allclose(got, want, rtol=RTOL), (got, want)
+    gd = _grads(model, NET_D)
+    for k in wg:
+        assert rel_err(gd[k], wg[k]) < 2e-3, ("D", k, rel_err(gd[k], wg[k]))
+    got = model.engine.g_backward(x, lab, ln, None, train=True, reuse=True, apply=False).cpu().numpy()
+    want, wg, y_ref = oracle.g_tower(x64, lab64, ln)
+    assert np.allclose(got, want, rtol=RTOL), (got, want)
+    gg = _grads(model, NET_G)
+    for k in wg:
+        assert rel_err(gg[k], wg[k]) < 2e-3, ("G", k, rel_err(gg[k], wg[k]))
+    y = model.forward(x, ln)
+    assert np.abs(y - y_ref).mean() / np.abs(y_ref).mean() < RTOL          # enhanced-MFCC L1
+    # one full iteration (1 D + 1 G update), then the losses of the updated networks
+    a = model.d_step(x, lab, ln); b = oracle.d_step(x64, lab64, ln)
+    assert np.allclose(np.ravel(a), np.ravel(b), rtol=RTOL)
+    a = model.g_step(x, lab, ln, reuse_g_forward=True); b = oracle.g_step(x64, lab64, ln)
+    assert np.allclose(np.ravel(a), np.ravel(b), rtol=RTOL)
+    a = model.g_step(x, lab, ln, train=False); b = oracle.g_step(x64, lab64, ln, train=False)
+    assert np.allclose(np.ravel(a), np.ravel(b), rtol=RTOL), (a, b)
+
+
+def test_full_size_tower_mean_property():
+    """average_gradients: losses and gradients of the [64]-row batch are the means of those of its two [32]-row halves."""
+    cfg = O.NetCfg()
+    B, T = 64, 100
+    full, _ = build_hip_pair(cfg, B, T, seed=7, flags=1)
+    half, _ = build_hip_pair(cfg, B // 2, T, seed=7, flags=1)          # same seed -> identical variables
+    x, lab, ln = rand_batch(cfg, B, T, seed=8, ragged=True)
+    lf = full.engine.d_backward(x, lab, ln, None, None, train=True, apply=False).cpu().numpy()
+    gf = _grads(full, NET_D)
+    lg = full.engine.g_backward(x, lab, ln, None, train=True, reuse=True, apply=False).cpu().numpy()
+    gg = _grads(full, NET_G)
+    acc_l, acc_lg, acc_d, acc_g = 0.0, 0.0, None, None
+    for s in (slice(0, B // 2), slice(B // 2, B)):
+        l = half.engine.d_backward(x[s], lab[s], ln[s], None, None, train=True, apply=False).cpu().numpy()
+        gd = _grads(half, NET_D)
+        l2 = half.engine.g_backward(x[s], lab[s], ln[s], None, train=True, reuse=True, apply=False).cpu().numpy()
+        g2 = _grads(half, NET_G)
+        acc_l = acc_l + 0.5 * l; acc_lg = acc_lg + 0.5 * l2
+        acc_d = {k: 0.5 * v for k, v in gd.items()} if acc_d is None else {k: acc_d[k] + 0.5 * gd[k] for k in gd}
+        acc_g = {k: 0.5 * v for k, v in g2.items()} if acc_g is None else {k: acc_g[k] + 0.5 * g2[k] for k in g2}
+    assert np.allclose(lf, acc_l, rtol=1e-5) and np.allclose(lg, acc_lg, rtol=1e-5)
+    for k in gf:
+        assert rel_err(gf[k], acc_d[k]) < 1e-4, k
+    for k in gg:
+        assert rel_err(gg[k], acc_g[k]) < 1e-4, k
+
+
+def test_full_size_schedules_agree_and_padding_is_inert():
+    cfg = O.NetCfg()
+    B, T = 64, 100
+    a, _ = build_hip_pair(cfg, B, T, seed=9, flags=1)
+    b, _ = build_hip_pair(cfg, B, T, seed=9, flags=0)
+    x, lab, ln = rand_batch(cfg, B, T, seed=10, ragged=True)
+    for m in (a, b):
+        m.engine.d_backward(x, lab, ln, None, None, train=True, apply=False)
+    for k, v in _grads(a, NET_D).items():
+        assert rel_err(v, _grads(b, NET_D)[k]) < 1e-5, k
+    la = a.engine.g_backward(x, lab, ln, None, train=True, reuse=True, apply=False).cpu().numpy()
+    lb = b.engine.g_backward(x, lab, ln, None, train=True, reuse=True, apply=False).cpu().numpy()
+    assert np.allclose(la, lb, rtol=1e-6)
+    gb = _grads(b, NET_G)
+    for k, v in _grads(a, NET_G).items():
+        assert rel_err(v, gb[k]) < 1e-5, k
+    # frames at t >= length: G(x) = output-FC bias there, and garbage in the padded input frames changes nothing
+    y = a.forward(x, ln)
+    gv, _ = a.get_vars()
+    bias = gv["g_model/fully_connected_1/biases"]
+    x2 = x.copy()
+    for i in range(B):
+        assert np.allclose(y[i, ln[i]:], bias[None, :], atol=1e-6)
+        x2[i, ln[i]:] = 1e3
+    y2 = a.forward(x2, ln)
+    assert np.array_equal(y, y2)
+    l2 = a.engine.g_backward(x2, lab, ln, None, train=True, reuse=False, apply=False).cpu().numpy()
+    assert np.allclose(la, l2, rtol=1e-6)
