@@ -174,18 +174,21 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 __host__ __device__ inline int gates_sa4(int ktot) { int s = ktot / 4 + 1; return (s & 1) ? s : s + 1; }
 
-template <int CHB, int RTG>      // RTG 16-row tiles per WG: 2 -> 32 rows (2 WGs/CU), 4 -> 64 rows (weights streamed once)
-__global__ __launch_bounds__(512, (RTG == 2 && CHB <= 18) ? 4 : 2) void k_fwd_gates(const FwdGateJobs jobs) {
+// RTG 16-row tiles per wave, RH row halves per workgroup: <.,2,1> = 32 rows x 16 cells on 8 waves (gate x K-half);
+// <.,2,2> = 64 rows on 16 waves (gate x K-half x row-half): the two row halves request the same weight lines, so a column
+// block's weight slice enters the CU once for 64 rows.
+template <int CHB, int RTG, int RH = 1>
+__global__ __launch_bounds__(512 * RH, (RH == 1 && RTG == 2 && CHB <= 18) ? 4 : 2) void k_fwd_gates(const FwdGateJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = blockIdx.x;
   const int ji = find_job(jobs.j, jobs.n, bid);
   const FwdGateJob& J = jobs.j[ji];
   int cb, rb;
   if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
-  const int r0 = rb * 16 * RTG, c0 = cb * 16;
+  const int r0 = rb * 16 * RTG * RH, c0 = cb * 16;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform -> scalar branches
-  const int gate = w & 3, ks = w >> 2;
+  const int gate = w & 3, ks = (w >> 2) & 1, rh = w >> 3;
   const int H = J.H, N = J.N, H4 = 4 * H;
   const int ldx = J.x ? J.ldx : 0, ldm = J.ldm, Ktot = ldx + ldm;
   const int SA4 = gates_sa4(Ktot), SA = SA4 * 4;
@@ -208,8 +211,8 @@ __global__ __launch_bounds__(512, (RTG == 2 && CHB <= 18) ? 4 : 2) void k_fwd_ga
   // (2) A tile: lane p of the linear LDS image <- x / m element (rows >= N and pad columns get a
   // harmless finite dummy; they only ever meet zero weights or unstored rows)
   {
-    const int P4 = 16 * RTG * SA4;
-    for (int p0 = w * 64; p0 < P4; p0 += 512) {
+    const int P4 = 16 * RTG * RH * SA4;
+    for (int p0 = w * 64; p0 < P4; p0 += 512 * RH) {
       const int p = p0 + lane;
       const int row = p / SA4, k = (p - row * SA4) * 4;
       const int arow = r0 + row;
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(512, (RTG == 2 && CHB <= 18) ? 4 : 2) void k_fwd_ga
   if (ecell < H) { pwi = J.wi[ecell]; pwf = J.wf[ecell]; pwo = J.wo[ecell]; }
 #pragma unroll
   for (int u = 0; u < EPT; ++u) {
-    const int erow = r0 + ((tid >> 8) + 2 * u) * 16 + er;
+    const int erow = r0 + ((tid >> 8) + 2 * RH * u) * 16 + er;
     evalid[u] = erow < N && ecell < H;
     cp[u] = 0.f; elen[u] = 0;
 #pragma unroll
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(512, (RTG == 2 && CHB <= 18) ? 4 : 2) void k_fwd_ga
   f32x4 acc[RTG];
 #pragma unroll
   for (int i = 0; i < RTG; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* abase = smem + (size_t)lr * SA + jb * 16 + 4 * q;
+  const float* abase = smem + (size_t)(rh * 16 * RTG + lr) * SA + jb * 16 + 4 * q;
 #pragma unroll
   for (int c = 0; c < CHB; ++c) {
     if (jb + c < je) {
@@ -265,17 +268,17 @@ __global__ __launch_bounds__(512, (RTG == 2 && CHB <= 18) ? 4 : 2) void k_fwd_ga
     }
   }
   __syncthreads();                                     // everyone is done reading the A tile
-  float (*zs)[RTG][16][17] = reinterpret_cast<float (*)[RTG][16][17]>(smem);      // zs[8][RTG][16][17] aliases it
+  float (*zs)[RTG * RH][16][17] = reinterpret_cast<float (*)[RTG * RH][16][17]>(smem);      // zs[8][RTG*RH][16][17] aliases it
 #pragma unroll
   for (int i = 0; i < RTG; ++i)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) zs[w][i][q * 4 + r][lr] = acc[i][r];
+    for (int r = 0; r < 4; ++r) zs[w & 7][rh * RTG + i][q * 4 + r][lr] = acc[i][r];
   __syncthreads();
 
 #pragma unroll
   for (int u = 0; u < EPT; ++u) {
     if (!evalid[u]) continue;
-    const int ei = (tid >> 8) + 2 * u;
+    const int ei = (tid >> 8) + 2 * RH * u;
     const int erow = r0 + ei * 16 + er;
     float z[4];
 #pragma unroll
@@ -720,7 +723,8 @@ void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, int kb_max, hip
   const int ktot = kb_max * 16;
   const int rtg = g_gates_rows / 16;
   size_t lds = (size_t)16 * rtg * gates_sa4(ktot) * 16;
-  lds = (lds + 8191) / 8192 * 8192;
+  const size_t granule = rtg == 2 ? 8192 : 16384;          // one DMA round of all waves of the workgroup
+  lds = (lds + granule - 1) / granule * granule;
   if (lds < 8 * rtg * 16 * 17 * sizeof(float)) lds = 8 * rtg * 16 * 17 * sizeof(float);
   // One WG per CU: a launch lasts as long as its most-loaded CU pulls operands (~12 B/clk/CU); with two
   // resident WGs per CU some CUs get two heavy (K=560) WGs.  One slot per CU + heavy-first order makes
@@ -731,7 +735,7 @@ void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, int kb_max, hip
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_gates<18, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_gates<18, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_gates<18, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   if (kb_max > 36) {        // K = [x | m] wider than 576 floats (e.g. 512-cell layers without projection): 32 k-blocks per wave, 1 WG/CU
@@ -741,7 +745,7 @@ void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, int kb_max, hip
     l2 = (l2 + 8191) / 8192 * 8192;
     hipLaunchKernelGGL((k_fwd_gates<32, 2>), dim3(total_blocks), dim3(512), l2, s, jobs);
   } else if (rtg == 2) hipLaunchKernelGGL((k_fwd_gates<18, 2>), dim3(total_blocks), dim3(512), lds, s, jobs);
-  else hipLaunchKernelGGL((k_fwd_gates<18, 4>), dim3(total_blocks), dim3(512), lds, s, jobs);
+  else hipLaunchKernelGGL((k_fwd_gates<18, 2, 2>), dim3(total_blocks), dim3(1024), lds, s, jobs);
 }
 void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
   if (kb_max <= 24)
