@@ -54,6 +54,27 @@ def all_reduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
     return flat
 
 
+def all_reduce_mean_buckets_(flat: torch.Tensor, buckets, group=None, wait_bucket=None, comm_stream=None) -> torch.Tensor:
+    """average_gradients bucket by bucket: `buckets` = (offset, count) ranges of `flat` in the order the backward pass
+    completes them.  `wait_bucket(i, stream)` makes `stream` wait until range i is final (HipEngine: rsrgan_grad_bucket_wait);
+    with a `comm_stream` every all-reduce is issued there, so bucket i travels while the later buckets are still being
+    computed on the caller's stream, which joins the communication stream at the end."""
+    if comm_stream is None:
+        for i, (off, cnt) in enumerate(buckets):
+            if wait_bucket is not None:
+                wait_bucket(i, None)
+            all_reduce_mean_(flat[off:off + cnt], group)
+        return flat
+    cur = torch.cuda.current_stream(flat.device)
+    for i, (off, cnt) in enumerate(buckets):
+        if wait_bucket is not None:
+            wait_bucket(i, comm_stream)
+        with torch.cuda.stream(comm_stream):
+            all_reduce_mean_(flat[off:off + cnt], group)
+    cur.wait_stream(comm_stream)
+    return flat
+
+
 def all_gather_rows(v: torch.Tensor, group=None) -> torch.Tensor:
     """[k] -> [world, k]: the per-tower loss lists the reference fetches (:262-268)."""
     ws = world_size(group)

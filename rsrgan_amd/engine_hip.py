@@ -183,12 +183,11 @@ class HipEngine:
             return
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=self.device)
-        comm, cur = self._comm_stream, torch.cuda.current_stream(self.device)
-        for i, (off, cnt) in enumerate(buckets):
-            check(self.lib.rsrgan_grad_bucket_wait(self.h, net, i, C.c_void_p(comm.cuda_stream)))
-            with torch.cuda.stream(comm):
-                rdist.all_reduce_mean_(view[off:off + cnt], group)
-        cur.wait_stream(comm)           # rsrgan_apply (clip, update) needs every averaged bucket
+
+        def wait_bucket(i, stream):
+            check(self.lib.rsrgan_grad_bucket_wait(self.h, net, i, C.c_void_p(stream.cuda_stream)))
+
+        rdist.all_reduce_mean_buckets_(view, buckets, group, wait_bucket, self._comm_stream)   # joins before rsrgan_apply
 
     # -- the path ----------------------------------------------------------------------
     def forward_g(self, x, lengths) -> torch.Tensor:

@@ -128,6 +128,22 @@ class OracleEngine:
     def grad_view(self, net):
         return self._grads[net]
 
+    bucketed = False            # True: expose the HipEngine bucket protocol (per-tensor ranges, last tensor first)
+
+    def grad_buckets(self, net):
+        tt = self.tensor_table(net)
+        ends = [off for _, _, off in tt][1:] + [self.param_count(net)]
+        return [(off, end - off) for (_, _, off), end in zip(tt, ends)][::-1]
+
+    def all_reduce_grads(self, net, group=None):
+        from rsrgan_amd import dist as rdist
+        if self.bucketed:
+            self.waited = getattr(self, "waited", [])
+            rdist.all_reduce_mean_buckets_(self._grads[net], self.grad_buckets(net), group,
+                                           wait_bucket=lambda i, stream: self.waited.append((net, i)))
+        else:
+            rdist.all_reduce_mean_(self._grads[net], group)
+
     def _np(self, a, dt=np.float64):
         return None if a is None else np.asarray(a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a, dt)
 

@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, bucketed=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -31,20 +31,25 @@ def _worker(rank, world, port, out):
         lr_g, lr_d = 8e-5 * world, 1e-3 * world                    # LR x num_gpu (train...py:458-459)
         m = GAN_RNN(None, args_for(cfg, B, num_gpu=world, g_learning_rate=lr_g, d_learning_rate=lr_d, gen_updates=2),
                     ["cpu:%d" % rank], engine=OracleEngine(cfg, g, d, B))
+        m.engine.bucketed = bucketed
         batches = [rand_batch(cfg, B * world, T, 60 + i, ragged=True) for i in range(2)]
         res = train_one_iteration(None, m, len(batches) * world, 0, [[None] + list(b) for b in batches])
         flat = np.concatenate([m.engine.o.g[n].reshape(-1) for n, _ in O.g_param_specs(cfg)] +
                               [m.engine.o.d[n].reshape(-1) for n, _ in O.d_param_specs(cfg)])
         out[rank] = (res, flat)
+        if bucketed:          # every bucket of every averaged backward was waited for, in completion order
+            nb = len(m.engine.grad_buckets(0))
+            assert m.engine.waited[:nb] != [] and [i for n, i in m.engine.waited if n == 0][:nb] == list(range(nb))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_gloo_equals_two_tower_oracle():
+@pytest.mark.parametrize("bucketed", [False, True])
+def test_two_rank_gloo_equals_two_tower_oracle(bucketed):
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, bucketed), nprocs=world, join=True)
     cfg = small_cfg()
     B, T = 2, 5
     g, d = rand_params(cfg, 5)
