@@ -45,7 +45,8 @@ typedef enum rsrgan_status {
 
 /* args.g_type (gan_rnn_placeholder.py:125-132) */
 enum { RSRGAN_G_LSTM = 0, RSRGAN_G_RES_LSTM_L = 1, RSRGAN_G_RES_LSTM_BASE = 2,
-       RSRGAN_G_DNN = 3 /* models/gan.py:109-110 + models/dnn.py: frame-level FC generator */ };
+       RSRGAN_G_DNN = 3, /* models/gan.py:109-110 + models/dnn.py: frame-level FC generator */
+       RSRGAN_G_RCED = 4 /* models/rced.py: frame-level 9 x conv2d + FC generator (dnn_trainer.py:98-99), batch_norm=False */ };
 /* self.discriminator (gan_rnn_placeholder.py:117; models/gan.py:104) */
 enum { RSRGAN_D_LSTM = 0, RSRGAN_D_DNN = 1 /* models/discriminator_dnn.py */ };
 /* which network a call addresses */
@@ -98,6 +99,9 @@ typedef struct rsrgan_cfg {
    * d_joint_dim = 0 feeds D the 40-dim target only, as gan_rnn_placeholder.py:207-208 does */
   int32_t d_joint_off;
   int32_t d_joint_dim;
+  /* R-CED generator (models/rced.py:36-52): the fed frame is reshaped to [g_splice, input_dim / g_splice, 1]
+   * (g_splice = left_context + 1 + right_context); 9 conv2d layers 12,16,20,24,32,24,20,16,12 x [g_splice, 13..7..13] */
+  int32_t g_splice;
 } rsrgan_cfg;
 
 enum {

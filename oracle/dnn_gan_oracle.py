@@ -134,9 +134,15 @@ class GanDnnOracle:
         c = self.cfg
         return x[:, c.input_dim * c.left_context: c.input_dim * (c.left_context + 1)]     # gan.py:158-160
 
+    # generator hooks (overridden by oracle/rced_oracle.py for the R-CED generator)
+    def _g_fwd(self, x):
+        return fc_stack_fwd(self.g, "g_model", self.cfg.g_hidden + 1, x)
+
+    def _g_bwd(self, cache, dy):
+        return fc_stack_bwd(self.g, "g_model", self.cfg.g_hidden + 1, cache, dy, want_dx=False)[1]
+
     def forward(self, x):
-        y, _ = fc_stack_fwd(self.g, "g_model", self.cfg.g_hidden + 1, np.asarray(x, self.dtype))
-        return y
+        return self._g_fwd(np.asarray(x, self.dtype))[0]
 
     def d_tower(self, x, lab, want_grads=True):
         cfg = self.cfg
@@ -157,7 +163,7 @@ class GanDnnOracle:
     def g_tower(self, x, lab, want_grads=True):
         cfg = self.cfg
         x, lab = np.asarray(x, self.dtype), np.asarray(lab, self.dtype)
-        y, gacts = fc_stack_fwd(self.g, "g_model", cfg.g_hidden + 1, x)
+        y, gacts = self._g_fwd(x)
         supervised = getattr(self, "supervised", False)          # models/dnn_trainer.py:139-148: g_loss = g_mse + g_l2
         if supervised:
             g_adv = 0.0
@@ -179,7 +185,7 @@ class GanDnnOracle:
                 draw = 2.0 * diff / diff.size * clip_grad_mask(cfg, raw)
                 djoint, _ = fc_stack_bwd(self.d, "d_model", cfg.d_hidden + 1, dacts, draw, want_dx=True)
                 dy = dy + djoint[:, cfg.input_dim:]
-            _, grads = fc_stack_bwd(self.g, "g_model", cfg.g_hidden + 1, gacts, dy, want_dx=False)
+            grads = self._g_bwd(gacts, dy)
             if g_l2 != 0.0 or ((not self.cross_validation) and self.l2_scale > 0):
                 for k in grads:
                     if k.endswith("weights"):

@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librsrgan_hip.so")
 
-G_TYPES = {"lstm": 0, "res_lstm_l": 1, "res_lstm_base": 2, "dnn": 3}
+G_TYPES = {"lstm": 0, "res_lstm_l": 1, "res_lstm_base": 2, "dnn": 3, "rced": 4}
 D_TYPES = {"lstm": 0, "dnn": 1}
 NET_G, NET_D = 0, 1
 SCALARS = {"g_learning_rate": 0, "d_learning_rate": 1, "mse_lambda": 2, "d_real": 3, "d_fake": 4,
@@ -31,7 +31,7 @@ class RsrganCfg(C.Structure):
                 ("d_proj", C.c_int32), ("l2_scale", C.c_float), ("clip_norm", C.c_float), ("adam_beta1", C.c_float),
                 ("adam_beta2", C.c_float), ("adam_eps", C.c_float), ("ema_decay", C.c_float),
                 ("lrelu_alpha", C.c_float), ("forget_bias", C.c_float), ("cross_validation", C.c_int32),
-                ("flags", C.c_int32), ("d_joint_off", C.c_int32), ("d_joint_dim", C.c_int32)]
+                ("flags", C.c_int32), ("d_joint_off", C.c_int32), ("d_joint_dim", C.c_int32), ("g_splice", C.c_int32)]
 
 
 class RsrganError(RuntimeError):

@@ -25,10 +25,11 @@ int rsrgan_default_cfg(int32_t g_type, rsrgan_cfg* c) {
   if (g_type == RSRGAN_G_LSTM) { c->g_layers = 3; c->g_cells = 760; c->g_proj = 280; }           // models/lstm.py:43-45
   else if (g_type == RSRGAN_G_RES_LSTM_L || g_type == RSRGAN_G_RES_LSTM_BASE) { c->g_layers = 4; c->g_cells = 760; c->g_proj = 257; }  // models/res_lstm_l.py:43-45
   else if (g_type == RSRGAN_G_DNN) { c->g_layers = 4; c->g_cells = 1024; c->g_proj = 0; }        // models/dnn.py:34-35 (1+3 hidden layers)
+  else if (g_type == RSRGAN_G_RCED) { c->g_layers = 9; c->g_cells = 32; c->g_proj = 0; c->g_splice = 11; }   // models/rced.py:92-93 (fixed filter table)
   else { set_error("Unrecognized G type %d", g_type); return RSRGAN_ERR_INVALID; }
   c->d_type = RSRGAN_D_LSTM; c->d_layers = 2; c->d_cells = 256; c->d_proj = 40;                   // models/discriminator_lstm.py:26-28
   c->l2_scale = 0.f; c->clip_norm = 15.f;
-  if (g_type == RSRGAN_G_DNN) {        // models/gan.py: discriminator_dnn on concat(centre frame, target), Adam/Adam, no clipping
+  if (g_type == RSRGAN_G_DNN || g_type == RSRGAN_G_RCED) {        // models/gan.py: discriminator_dnn on concat(centre frame, target), Adam/Adam, no clipping
     c->input_dim = 257 * 11; c->d_type = RSRGAN_D_DNN; c->d_layers = 4; c->d_cells = 1024; c->d_proj = 0;
     c->d_joint_off = 257 * 5; c->d_joint_dim = 257; c->clip_norm = 0.f; c->batch_size = 1024; c->max_frames = 1;
   } c->adam_beta1 = 0.9f; c->adam_beta2 = 0.999f; c->adam_eps = 1e-8f;

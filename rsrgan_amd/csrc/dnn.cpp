@@ -50,6 +50,50 @@ float* Model::fc_backward(const ParamSet& ps, const std::vector<FcLayer>& L, con
   return d;
 }
 
+// ---- R-CED generator (models/rced.py): every conv2d is patch matrix -> GEMM (+bias, ReLU); the patch matrix of a layer is
+// rebuilt in the backward pass instead of being kept (it is S*fw times the size of the activation it comes from) ----
+void Model::rced_forward(int rows, hipStream_t s) {
+  const size_t M = (size_t)rows * rcS * rcW;
+  for (size_t l = 0; l < gconv.size(); ++l) {
+    const ConvLayer& L = gconv[l];
+    launch_im2col(rc_act[l], l == 0 ? (size_t)ldDin : (size_t)rcS * rcW * L.ldCin, L.ldCin, L.Cin, rcS, rcW, rcS, L.fw, rc_col, L.ldK, M, s);
+    gemm(rc_col, L.ldK, true, G.W(L.tW), L.ldCout, false, rc_act[l + 1], L.ldCout, (int)M, L.Cout, L.K, G.W(L.tb), 2, 0.f, false, s);
+  }
+  // reshape [rows, S*W*C] (rced.py:110: contiguous because C % 4 == 0) -> linear FC
+  gemm(rc_act[gconv.size()], rc_fc.ld_in, true, G.W(rc_fc.tW), ldDout, false, y_tm, ldDout, rows, Dout, rc_fc.in, G.W(rc_fc.tb), 0, 0.f, false, s);
+}
+
+void Model::rced_backward(int rows, float* dy, hipStream_t s) {
+  const size_t M = (size_t)rows * rcS * rcW;
+  const int Lc = (int)gconv.size();
+  gemm(rc_act[Lc], rc_fc.ld_in, false, dy, ldDout, false, G.Gd(rc_fc.tW), ldDout, rc_fc.in, Dout, rows, nullptr, 0, 0.f, false, s);
+  launch_colsum(dy, ldDout, nullptr, 0, G.Gd(rc_fc.tb), rows, Dout, scratch, s);
+  float* d = rc_dA;
+  float* other = rc_dB;
+  gemm(dy, ldDout, true, G.W(rc_fc.tW), ldDout, true, d, rc_fc.ld_in, rows, rc_fc.in, Dout, nullptr, 0, 0.f, false, s);   // = [M][Cout_last]
+  for (int l = Lc - 1; l >= 0; --l) {
+    const ConvLayer& L = gconv[l];
+    launch_lrelu_bwd(rc_act[l + 1], d, M, L.Cout, L.ldCout, 0.f, s);                      // relu': d *= [a > 0]
+    launch_im2col(rc_act[l], l == 0 ? (size_t)ldDin : (size_t)rcS * rcW * L.ldCin, L.ldCin, L.Cin, rcS, rcW, rcS, L.fw, rc_col, L.ldK, M, s);
+    gemm(rc_col, L.ldK, false, d, L.ldCout, false, G.Gd(L.tW), L.ldCout, L.K, L.Cout, (int)M, nullptr, 0, 0.f, false, s);
+    launch_colsum(d, L.ldCout, nullptr, 0, G.Gd(L.tb), (int)M, L.Cout, scratch, s);
+    if (l > 0) {
+      gemm(d, L.ldCout, true, G.W(L.tW), L.ldCout, true, rc_dcol, L.ldK, (int)M, L.K, L.Cout, nullptr, 0, 0.f, false, s);
+      launch_col2im(rc_dcol, L.ldK, L.Cin, rcS, rcW, rcS, L.fw, other, L.ldCin, M, s);
+      std::swap(d, other);
+    }
+  }
+}
+
+void Model::g_frame_forward(int rows, hipStream_t s) {
+  if (g_rced()) rced_forward(rows, s);
+  else fc_forward(G, gfc, g_act, rows, s);
+}
+void Model::g_frame_backward(int rows, float* dy, hipStream_t s) {
+  if (g_rced()) rced_backward(rows, dy, s);
+  else fc_backward(G, gfc, g_act, rows, dy, true, false, s);
+}
+
 // D(.) on d_act[0] ([T][Nd] rows), clipped LSGAN losses, dlogits
 void Model::d_dnn_forward_loss(int T, int Nd, int n_real, bool want_grads, float* loss3, hipStream_t s) {
   fc_forward(D, dfc, d_act, T * Nd, s);
@@ -65,7 +109,7 @@ int Model::dnn_d_backward(const float* x, const float* labels, int T, float* out
   launch_pack_tm(x, x_tm, B, T, Din, ldDin, s);
   launch_pack_tm(labels, lab_tm, B, T, Dout, ldDout, s);
   cur_T = T;
-  fc_forward(G, gfc, g_act, R, s);                       // g = self.generator(inputs, ...)  gan.py:171
+  g_frame_forward(R, s);                                 // g = self.generator(inputs, ...)  gan.py:171
   g_fwd_valid = true;
   // d_rl_joint = concat(d_inputs, labels) ; d_fk_joint = concat(d_inputs, g)   gan.py:173-174
   launch_build_joint(x_tm, ldDin, cfg.d_joint_off, cfg.d_joint_dim, lab_tm, ldDout, Dout, joint, ldJ, 0, R, s);
@@ -90,7 +134,7 @@ int Model::dnn_g_backward(const float* x, const float* labels, int T, float* out
     launch_pack_tm(x, x_tm, B, T, Din, ldDin, s);
     launch_pack_tm(labels, lab_tm, B, T, Dout, ldDout, s);
     cur_T = T;
-    fc_forward(G, gfc, g_act, R, s);
+    g_frame_forward(R, s);
     g_fwd_valid = true;
   }
   const bool sup = supervised();           // DNNTrainer (models/dnn_trainer.py:139-148): g_loss = g_mse + g_l2, no discriminator
@@ -108,7 +152,7 @@ int Model::dnn_g_backward(const float* x, const float* labels, int T, float* out
       launch_slice_cols(dj, ldJ, cfg.d_joint_dim, dy_buf, ldDout, R, Dout, s);            // ... / d g
     }
     launch_mse(y_tm, lab_tm, ldDout, dy_buf, R, Dout, dyn + DYN_LAMBDA, !sup, losses + 4, scratch, s);
-    fc_backward(G, gfc, g_act, R, dy_buf, true, false, s);
+    g_frame_backward(R, dy_buf, s);
     if (l2_on) {
       launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
       launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);

@@ -129,6 +129,10 @@ void launch_fill(float* p, size_t n, float v, hipStream_t s);
 struct TransposeJob { const float* src; float* dst; int lds, ldd, R, C, blk_base; };   // dst[c][r] = src[r][c]
 struct TransposeList { int n; TransposeJob j[16]; };
 void launch_transpose_many(TransposeList& tl, hipStream_t s);
+// R-CED patch matrix (conv2d SAME as GEMM) and its adjoint; col2im needs C % 4 == 0
+void launch_im2col(const float* src, size_t row_stride, int ldc, int C, int S, int W, int kh, int kw, float* col, int ldk, size_t M,
+                   hipStream_t s);
+void launch_col2im(const float* dcol, int ldk, int C, int S, int W, int kh, int kw, float* dst, int ldc, size_t M, hipStream_t s);
 struct ZeroList { int n; float* p[32]; unsigned len[32]; };        // many small buffers zeroed by ONE launch
 void launch_zero_many(const ZeroList& zl, hipStream_t s);
 void launch_lstm_colsums(const float* dz, const float* cprev, const float* ccur, float* db, float* dwi, float* dwf, float* dwo,

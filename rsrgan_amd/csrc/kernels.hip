@@ -891,6 +891,91 @@ void launch_transpose_many(TransposeList& tl, hipStream_t s) {
   hipLaunchKernelGGL(k_transpose_many, dim3(base), dim3(256), 0, s, tl);
 }
 
+// ---------------------------------------------------------------------------------------
+// R-CED (models/rced.py:90-102): tf.contrib.layers.conv2d([S, fw], SAME, stride 1) on NHWC [R, S, W, C] as a GEMM over
+// the patch matrix.  Positions p = (r*S + h)*W + w; patch column k = (dh*fw + dw)*C + c = the row-major order of the
+// filter tensor [S, fw, C, Cout].  SAME padding: (k-1)/2 leading zeros per axis (TF pads the extra element of an even
+// extent at the end).  Element (r, h, w, c) of the source lives at src[r*row_stride + (h*W + w)*ldc + c] (layer 0 reads
+// the fed [R][S*W] rows directly with ldc = 1).
+// ---------------------------------------------------------------------------------------
+template <int V>      // V = 4: C % 4 == 0 (aligned float4 along c), V = 1: any C
+__global__ __launch_bounds__(256) void k_im2col(const float* __restrict__ src, size_t row_stride, int ldc, int C, int S, int W,
+                                                int kh, int kw, float* __restrict__ col, int ldk, size_t M) {
+  const int K = kh * kw * C, nv = ldk / V;
+  const size_t total = M * (size_t)nv;
+  const int pt = (kh - 1) / 2, pl = (kw - 1) / 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i / nv;
+    const int k = (int)(i - p * nv) * V;
+    const int w = (int)(p % W);
+    const size_t rh = p / W;
+    const int h = (int)(rh % S);
+    const size_t r = rh / S;
+    float v[V];
+#pragma unroll
+    for (int u = 0; u < V; ++u) v[u] = 0.f;
+    if (k < K) {
+      const int c = k % C, dd = k / C, dw = dd % kw, dh = dd / kw;
+      const int hh = h + dh - pt, ww = w + dw - pl;
+      if (hh >= 0 && hh < S && ww >= 0 && ww < W) {
+        const float* q = src + r * row_stride + ((size_t)hh * W + ww) * ldc + c;
+        if (V == 4) { const float4 t = *reinterpret_cast<const float4*>(q); v[0] = t.x; v[1 % V] = t.y; v[2 % V] = t.z; v[3 % V] = t.w; }
+        else v[0] = *q;
+      }
+    }
+    float* o = col + p * ldk + k;
+    if (V == 4) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1 % V], v[2 % V], v[3 % V]);
+    else *o = v[0];
+  }
+}
+void launch_im2col(const float* src, size_t row_stride, int ldc, int C, int S, int W, int kh, int kw, float* col, int ldk, size_t M,
+                   hipStream_t s) {
+  if (C % 4 == 0 && ldc % 4 == 0) {
+    const size_t total = M * (size_t)(ldk / 4);
+    hipLaunchKernelGGL(k_im2col<4>, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, s, src, row_stride, ldc, C,
+                       S, W, kh, kw, col, ldk, M);
+  } else {
+    const size_t total = M * (size_t)ldk;
+    hipLaunchKernelGGL(k_im2col<1>, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, s, src, row_stride, ldc, C,
+                       S, W, kh, kw, col, ldk, M);
+  }
+}
+// adjoint of the patch matrix, as a gather (deterministic): dst[p][c] = sum over (dh, dw) of dcol[p'][(dh*kw+dw)*C + c] with
+// p' = the output position whose patch element (dh, dw) is p.  dst is [M][ldc] (pad columns written as 0).
+__global__ __launch_bounds__(256) void k_col2im(const float* __restrict__ dcol, int ldk, int C, int S, int W, int kh, int kw,
+                                                float* __restrict__ dst, int ldc, size_t M) {
+  const int nv = ldc / 4;
+  const size_t total = M * (size_t)nv;
+  const int pt = (kh - 1) / 2, pl = (kw - 1) / 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = i / nv;
+    const int c = (int)(i - p * nv) * 4;
+    const int w = (int)(p % W);
+    const size_t rh = p / W;
+    const int h = (int)(rh % S);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+      for (int dh = 0; dh < kh; ++dh) {
+        const int ho = h - dh + pt;                  // output row whose patch row dh is h
+        if (ho < 0 || ho >= S) continue;
+        for (int dw = 0; dw < kw; ++dw) {
+          const int wo = w - dw + pl;
+          if (wo < 0 || wo >= W) continue;
+          const size_t po = (rh - h + ho) * W + wo;
+          const float4 t = *reinterpret_cast<const float4*>(dcol + po * ldk + (size_t)(dh * kw + dw) * C + c);
+          acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(dst + p * ldc + c) = acc;
+  }
+}
+void launch_col2im(const float* dcol, int ldk, int C, int S, int W, int kh, int kw, float* dst, int ldc, size_t M, hipStream_t s) {
+  const size_t total = M * (size_t)(ldc / 4);
+  hipLaunchKernelGGL(k_col2im, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, s, dcol, ldk, C, S, W, kh, kw,
+                     dst, ldc, M);
+}
+
 __global__ void k_zero_many(ZeroList zl) {
   const int j = blockIdx.y;
   if (j >= zl.n) return;

@@ -114,7 +114,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   B = c.batch_size; Tmax = c.max_frames; Din = c.input_dim; Dout = c.output_dim;
   ldDin = pad4(Din); ldDout = pad4(Dout);
   if (B <= 0 || Tmax <= 0 || Din <= 0 || Dout <= 0 || c.g_layers <= 0 || c.d_layers <= 0 || c.g_cells <= 0 ||
-      c.d_cells <= 0 || c.g_layers > MAXJ || c.d_layers > MAXJ) {
+      c.d_cells <= 0 || (c.g_layers > MAXJ && !g_dnn()) || c.d_layers > MAXJ) {
     set_error("invalid sizes in rsrgan_cfg");
     return RSRGAN_ERR_INVALID;
   }
@@ -136,7 +136,29 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     out.push_back(F);
   };
   // ---- variable tables in graph-construction order (gan_rnn_placeholder.py:301-317) ----
-  if (c.g_type == RSRGAN_G_DNN) {                                        // models/dnn.py:79-110: (1+3) x [FC units, ReLU], FC -> Dout
+  if (c.g_type == RSRGAN_G_RCED) {                                       // models/rced.py:90-116
+    static const int kNum[9] = {12, 16, 20, 24, 32, 24, 20, 16, 12}, kWidth[9] = {13, 11, 9, 7, 7, 7, 9, 11, 13};
+    if (c.g_splice <= 0 || Din % c.g_splice) { set_error("R-CED: input_dim must be g_splice x frame width"); return RSRGAN_ERR_INVALID; }
+    if (c.g_layers < 1 || c.g_layers > 9) { set_error("R-CED: g_layers must be in [1, 9]"); return RSRGAN_ERR_INVALID; }
+    rcS = c.g_splice; rcW = Din / c.g_splice;
+    int cin = 1;
+    for (int l = 0; l < c.g_layers; ++l) {
+      // the reference's table; g_cells < 32 scales it down for tests (every width stays a multiple of 4, col2im needs that)
+      const int co = c.g_cells >= 32 ? kNum[l] : std::max(4, kNum[l] * c.g_cells / 32 / 4 * 4);
+      ConvLayer L; L.fw = kWidth[l]; L.Cin = cin; L.Cout = co; L.K = rcS * L.fw * cin; L.ldK = pad4(L.K);
+      L.ldCin = l == 0 ? 1 : pad4(cin); L.ldCout = pad4(co);
+      const std::string nm = std::string("g_model/Conv") + (l == 0 ? "" : "_" + std::to_string(l));
+      L.tW = G.add(nm + "/weights", L.K, co, false); L.tb = G.add(nm + "/biases", 1, co, true);
+      G.t[L.tW].xavier_fan_out = rcS * L.fw * co;           // xavier for conv: receptive field x channels on both sides
+      gconv.push_back(L);
+      cin = co;
+    }
+    const int flat = rcS * rcW * cin;
+    rc_fc.in = flat; rc_fc.out = Dout; rc_fc.ld_in = flat; rc_fc.ld_out = ldDout;
+    rc_fc.tW = G.add("g_model/fully_connected/weights", flat, Dout, false);
+    rc_fc.tb = G.add("g_model/fully_connected/biases", 1, Dout, true);
+    G.t[rc_fc.tb].bias_init = 0.1f;
+  } else if (c.g_type == RSRGAN_G_DNN) {                                 // models/dnn.py:79-110: (1+3) x [FC units, ReLU], FC -> Dout
     int in = Din;
     for (int l = 0; l < c.g_layers; ++l) { add_fc(G, gfc, fc_name("g_model", l), in, c.g_cells); in = c.g_cells; }
     add_fc(G, gfc, fc_name("g_model", c.g_layers), in, Dout);
@@ -197,7 +219,18 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   g_st.resize(gl.size());
   for (size_t l = 0; l < gl.size(); ++l) alloc_stash(*this, g_st[l], gl[l], B, Tmax);
   g_ins.resize(gl.size() + 1);
-  if (g_dnn()) {
+  if (g_rced()) {
+    const size_t M = TB * rcS * rcW;
+    int maxK = 4, maxC = 4;
+    rc_act.push_back(x_tm);
+    for (auto& L : gconv) {
+      rc_act.push_back(alloc<float>(M * L.ldCout));
+      maxK = std::max(maxK, L.ldK); maxC = std::max(maxC, L.ldCout);
+    }
+    rc_col = alloc<float>(M * maxK); rc_dcol = alloc<float>(M * maxK);
+    rc_dA = alloc<float>(M * maxC); rc_dB = alloc<float>(M * maxC);
+    if (!rc_col || !rc_dcol || !rc_dA || !rc_dB) { set_error("hipMalloc failed (R-CED patch matrices: %zu floats)", M * maxK); return RSRGAN_ERR_HIP; }
+  } else if (g_dnn()) {
     g_act.push_back(x_tm);
     for (size_t l = 0; l + 1 < gfc.size(); ++l) g_act.push_back(alloc<float>(TB * gfc[l].ld_out));
     g_act.push_back(y_tm);
@@ -268,8 +301,12 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   for (ParamSet* ps : {&G, &D}) {
     std::vector<float> host((size_t)ps->padded, 0.f);
     for (auto& t : ps->t) {
-      if (!t.l2) continue;                                   // biases stay zero
-      const double fan_in = t.is_vector ? t.cols : t.rows, fan_out = t.cols;
+      if (!t.l2) {                                           // biases: zero, except R-CED's output FC (rced.py:116: 0.1)
+        if (t.bias_init != 0.f)
+          for (int cc = 0; cc < t.cols; ++cc) host[(size_t)t.off + cc] = t.bias_init;
+        continue;
+      }
+      const double fan_in = t.is_vector ? t.cols : t.rows, fan_out = t.xavier_fan_out > 0 ? t.xavier_fan_out : t.cols;
       const double lim = std::sqrt(6.0 / (fan_in + fan_out));
       std::uniform_real_distribution<double> u(-lim, lim);
       for (int r = 0; r < t.rows; ++r)
@@ -781,7 +818,7 @@ void Model::g_forward_tail(int T, hipStream_t s) {   // y = outputs.W + b (model
   g_fwd_valid = true;
 }
 void Model::g_forward(int T, hipStream_t s, Chain* extra) {
-  if (g_dnn()) { fc_forward(G, gfc, g_act, T * B, s); g_fwd_valid = true; return; }
+  if (g_dnn()) { g_frame_forward(T * B, s); g_fwd_valid = true; return; }
   g_forward_head(T, s);
   std::vector<Chain> chains;
   chains.push_back(g_chain(T));

@@ -21,6 +21,8 @@ struct TensorDesc {
   int64_t dense_off;        // float offset in the dense (TF-shaped) flat vector
   bool l2;                  // takes the L2 term: "bias" not in name (gan_rnn_placeholder.py:254)
   bool is_vector;
+  int xavier_fan_out = 0;   // > 0: fan_out of the xavier limit (conv: receptive field x Cout) instead of cols
+  float bias_init = 0.f;    // constant initial value of a bias vector
 };
 
 struct ParamSet {
@@ -39,6 +41,10 @@ struct LstmLayer {               // one tf.contrib.rnn.LSTMCell(H, use_peepholes
   int I, H, P, ldI, ldP, ldH;
   int tK, tb, twf, twi, two, tWp;        // indices into the ParamSet
   float *KxT = nullptr, *KhT = nullptr, *WpT = nullptr;   // k-contiguous transposed copies (forward)
+};
+
+struct ConvLayer {               // tf.contrib.layers.conv2d([S, fw], SAME) of models/rced.py: weights [S*fw*Cin][Cout] (= [S, fw, Cin, Cout])
+  int fw, Cin, Cout, K, ldK, ldCin, ldCout, tW, tb;
 };
 
 struct FcLayer { int in, out, ld_in, ld_out, tW, tb; };   // contrib.layers.fully_connected: weights [in][out], biases [out]
@@ -114,9 +120,20 @@ struct Model {
   float *fc_dA = nullptr, *fc_dB = nullptr, *joint = nullptr, *dy_buf = nullptr;
   int ldJ = 0;
   int *adam_t_dev_d = nullptr;
-  bool g_dnn() const { return cfg.g_type == RSRGAN_G_DNN; }
+  bool g_dnn() const { return cfg.g_type == RSRGAN_G_DNN || cfg.g_type == RSRGAN_G_RCED; }   // frame-level generator
+  bool g_rced() const { return cfg.g_type == RSRGAN_G_RCED; }
+  // R-CED generator (dnn.cpp): rc_act[l] = input of conv layer l as [M][ldCin] positions x channels, rc_act[L] = its output
+  std::vector<ConvLayer> gconv;
+  FcLayer rc_fc{};
+  std::vector<float*> rc_act;
+  float *rc_col = nullptr, *rc_dcol = nullptr, *rc_dA = nullptr, *rc_dB = nullptr;
+  int rcS = 0, rcW = 0;
+  void g_frame_forward(int rows, hipStream_t s);                        // DNN or R-CED generator on `rows` frames
+  void g_frame_backward(int rows, float* dy, hipStream_t s);            // parameter gradients from d(output)
+  void rced_forward(int rows, hipStream_t s);
+  void rced_backward(int rows, float* dy, hipStream_t s);
   bool d_dnn() const { return cfg.d_type == RSRGAN_D_DNN; }
-  bool d_adam() const { return cfg.g_type == RSRGAN_G_DNN; }     // models/gan.py:125 (Adam) vs gan_rnn_placeholder.py:144 (SGD)
+  bool d_adam() const { return g_dnn(); }     // models/gan.py:125 (Adam) vs gan_rnn_placeholder.py:144 (SGD)
   void fc_forward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, hipStream_t s);
   float* fc_backward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, float* dtop,
                      bool want_wgrads, bool want_din, hipStream_t s);

@@ -34,7 +34,7 @@ class HipEngine:
                  g_type: str = "lstm", g_layers: Optional[int] = None, g_cells: Optional[int] = None,
                  g_proj: Optional[int] = None, d_layers: Optional[int] = None, d_cells: Optional[int] = None,
                  d_proj: Optional[int] = None, d_type: Optional[str] = None, d_joint_off: Optional[int] = None,
-                 d_joint_dim: Optional[int] = None, clip_norm: Optional[float] = None,
+                 d_joint_dim: Optional[int] = None, clip_norm: Optional[float] = None, g_splice: Optional[int] = None,
                  l2_scale: float = 0.0, cross_validation: bool = False,
                  ema_decay: float = 0.9999, seed: int = 4321, device: Optional[torch.device] = None, flags: int = 1):
         if g_type not in _lib.G_TYPES:
@@ -55,7 +55,7 @@ class HipEngine:
             if d_type not in _lib.D_TYPES:
                 raise ValueError("Unrecognized D type {}".format(d_type))
             cfg.d_type = _lib.D_TYPES[d_type]
-            if d_type == "dnn" and g_type != "dnn":          # discriminator_dnn on the 40-dim target only
+            if d_type == "dnn" and g_type not in ("dnn", "rced"):          # discriminator_dnn on the 40-dim target only
                 cfg.d_layers = d_layers or 4
                 cfg.d_cells = d_cells or 1024
                 cfg.d_joint_off, cfg.d_joint_dim = 0, 0
@@ -65,6 +65,8 @@ class HipEngine:
             cfg.d_joint_dim = int(d_joint_dim)
         if clip_norm is not None:
             cfg.clip_norm = float(clip_norm)
+        if g_splice is not None:
+            cfg.g_splice = int(g_splice)
         cfg.l2_scale = l2_scale
         cfg.cross_validation = 1 if cross_validation else 0
         cfg.ema_decay = ema_decay
@@ -76,7 +78,7 @@ class HipEngine:
         check(self.lib.rsrgan_create(C.byref(cfg), C.c_uint64(seed), C.byref(self.h)))
         self._grad_views = {}
         self._comm_stream = None
-        self.d_has_adam = g_type == "dnn"
+        self.d_has_adam = g_type in ("dnn", "rced")
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:

@@ -14,6 +14,8 @@ from .gan_rnn import Model, NET_D, NET_G
 
 
 class GAN(Model):
+    G_TYPES = ("dnn",)            # models/gan.py:109-112; DNNTrainer widens this (dnn_trainer.py:94-101)
+
     """Generative Adversarial Network for Speech Enhancement (models/gan.py:60).  `inputs`/`labels` of the
     reference constructor are tf.data tensors; here batches are passed to d_step / g_step."""
 
@@ -35,7 +37,7 @@ class GAN(Model):
         self.left_context, self.right_context = getattr(args, "left_context", 0), getattr(args, "right_context", 0)
         self.g_disturb_weights = self.d_clip_weights = False
         self.disc_updates, self.gen_updates = getattr(args, "disc_updates", 1), getattr(args, "gen_updates", 1)
-        if args.g_type != "dnn":
+        if args.g_type not in self.G_TYPES:
             raise ValueError("Unrecognized G type {}".format(args.g_type))          # gan.py:111-112
         self.process_group = process_group
         fed = self.input_dim * (self.left_context + 1 + self.right_context)
@@ -44,7 +46,8 @@ class GAN(Model):
         else:
             from .engine_hip import HipEngine
             self.engine = HipEngine(batch_size=self.batch_size, max_frames=1, input_dim=fed, output_dim=self.output_dim,
-                                    g_type="dnn", d_type="dnn", d_joint_off=self.input_dim * self.left_context,
+                                    g_type=args.g_type, d_type="dnn", d_joint_off=self.input_dim * self.left_context,
+                                    g_splice=self.left_context + 1 + self.right_context,
                                     d_joint_dim=self.input_dim, l2_scale=self.l2_scale, cross_validation=cross_validation,
                                     seed=seed, **(net_overrides or {}))
         self.ema_enabled = getattr(self.engine, "ema_enabled", True)
@@ -103,6 +106,17 @@ class GAN(Model):
         y = y[:, 0, :]
         return y.cpu().numpy() if not isinstance(inputs, torch.Tensor) else y
 
+    _RCED_WIDTHS = (13, 11, 9, 7, 7, 7, 9, 11, 13)                     # models/rced.py:93
+
+    def _tf_shape(self, name, shape):
+        """The library keeps a conv2d kernel as the [S*fw*Cin, Cout] GEMM operand; TF's variable is [S, fw, Cin, Cout]."""
+        if "/Conv" in name and name.endswith("/weights"):
+            idx = name.split("/Conv")[1].split("/")[0]
+            fw = self._RCED_WIDTHS[int(idx[1:]) if idx else 0]
+            S = self.left_context + 1 + self.right_context
+            return (S, fw, shape[0] // (S * fw), shape[1])
+        return tuple(shape)
+
     def get_vars(self):
         out = []
         for net, pre in ((NET_G, "g_"), (NET_D, "d_")):
@@ -110,7 +124,7 @@ class GAN(Model):
             d = {}
             for name, shape, off in self.engine.tensor_table(net):
                 assert name.startswith(pre), name
-                d[name] = flat[off:off + int(np.prod(shape))].reshape(shape)
+                d[name] = flat[off:off + int(np.prod(shape))].reshape(self._tf_shape(name, shape))
             out.append(d)
         return out[0], out[1]
 
@@ -121,7 +135,7 @@ class GAN(Model):
             flat = np.zeros(self.engine.param_count(net), np.float32)
             for name, shape, off in self.engine.tensor_table(net):
                 v = np.asarray(vals[name], np.float32)
-                assert tuple(v.shape) == tuple(shape), (name, v.shape, shape)
+                assert tuple(v.shape) == self._tf_shape(name, shape), (name, v.shape, shape)
                 flat[off:off + v.size] = v.reshape(-1)
             self.engine.set_params(net, flat, "variables")
             if reset_ema and self.ema_enabled:

@@ -45,7 +45,9 @@ class RNNTrainer(GAN_RNN):
 
 
 class DNNTrainer(GAN):
-    """models/dnn_trainer.py:64 -- g_type 'dnn' (cnn / rced are not built); no gradient clipping (dnn_trainer.py:124-126)."""
+    """models/dnn_trainer.py:64 -- g_type 'dnn' or 'rced' (models/rced.py, batch_norm=False; 'cnn' is not built); no gradient
+    clipping (dnn_trainer.py:124-126).  Conv kernels are exposed in TF's [S, fw, Cin, Cout] shape by get_vars/set_vars."""
+    G_TYPES = ("dnn", "rced")
 
     def __init__(self, sess, args, devices, inputs=None, labels=None, cross_validation=False, name="DNNTrainer", *,
                  process_group=None, seed: int = 4321, net_overrides: Optional[dict] = None):

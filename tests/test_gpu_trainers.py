@@ -118,3 +118,57 @@ def test_training_converges_on_a_learnable_task():
     hist = np.asarray(hist)                       # columns: d_rl, d_fk, d, g_adv, g_mse, g_l2, g
     assert np.all(np.isfinite(hist))
     assert hist[-1, 4] < 0.6 * hist[0, 4], hist[:, 4]
+
+
+@pytest.mark.parametrize("N,gan", [(6, False), (37, False), (6, True)])
+def test_rced_generator_matches_oracle(N, gan):
+    """models/rced.py under DNNTrainer (and, as BASELINE.json's config 4 words it, paired with discriminator_dnn): conv2d SAME as
+    patch-matrix GEMMs on the HIP path vs the fp64 oracle (tower losses, every gradient tensor, Adam steps, variables)."""
+    from oracle import rced_oracle as R
+    from rsrgan_amd import GAN
+    from rsrgan_amd.trainer import DNNTrainer
+    cfg = R.RcedCfg(input_dim=9, output_dim=5, left_context=2, right_context=1, d_units=18, d_hidden=2,
+                    filters_num=(4, 4, 4, 4, 4, 4, 4, 4, 4))            # the library scales the reference table 12..32..12 by g_cells/32
+    rng = np.random.default_rng(N)
+    g = {k: v.astype(np.float32) for k, v in R.init_params(R.g_param_specs(cfg), rng).items()}
+    for k in g:
+        if k.endswith("biases"):
+            g[k] = rng.normal(0.05, 0.1, g[k].shape).astype(np.float32)
+    d = {k: (2.0 * v).astype(np.float32) for k, v in DO.init_params(DO.d_param_specs(cfg), rng, relu_init=True).items()}
+    args = SimpleNamespace(batch_size=N, input_dim=cfg.input_dim, output_dim=cfg.output_dim, left_context=cfg.left_context,
+                           right_context=cfg.right_context, g_type="rced", keep_prob=1.0, batch_norm=False, num_gpu=1, save_dir=None,
+                           l2_scale=1e-3, g_learning_rate=1e-3, d_learning_rate=2e-3, init_mse_weight=10.0, disc_updates=1, gen_updates=1)
+    ov = dict(g_layers=9, g_cells=4, d_layers=cfg.d_hidden, d_cells=cfg.d_units)
+    if gan:
+        class RcedGan(GAN):
+            G_TYPES = ("dnn", "rced")
+        m = RcedGan(None, args, ["gpu:0"], net_overrides=ov)
+        o = R.GanRcedOracle(cfg, g, d, l2_scale=1e-3, g_learning_rate=float(np.float32(1e-3)), d_learning_rate=float(np.float32(2e-3)))
+    else:
+        m = DNNTrainer(None, args, ["gpu:0"], net_overrides=ov)
+        o = R.GanRcedOracle(cfg, g, d, l2_scale=1e-3, g_learning_rate=float(np.float32(1e-3)), mse_lambda=1.0)
+        o.supervised = True
+    table = [(n, m._tf_shape(n, s)) for n, s, _ in m.engine.tensor_table(NET_G)]
+    assert table == [(n, tuple(s)) for n, s in R.g_param_specs(cfg)], table
+    m.set_vars(g, d)
+    x = rng.standard_normal((N, cfg.fed_dim)).astype(np.float32); lab = rng.standard_normal((N, cfg.output_dim)).astype(np.float32)
+    assert np.abs(m.forward(x) - o.forward(x)).max() < 1e-4
+    if gan:
+        got = m.engine.d_backward(x[:, None], lab[:, None], None, train=True, apply=False).cpu().numpy()
+        want, _ = o.d_tower(x, lab)
+        assert np.allclose(got, want, rtol=1e-4), (got, want)
+    got = m.engine.g_backward(x[:, None], lab[:, None], None, train=True, reuse=gan, apply=False).cpu().numpy()
+    want, wg, _ = o.g_tower(x, lab)
+    assert np.allclose(got, want, rtol=1e-4, atol=1e-7), (got, want)
+    gr = split_flat(m.engine.get_grads(NET_G).cpu().numpy(), m.engine.tensor_table(NET_G))
+    for k in wg:
+        assert rel_err(gr[k].reshape(wg[k].shape), wg[k]) < 2e-3, k
+    for i in range(3):
+        if gan:
+            assert np.allclose(np.ravel(m.d_step(x, lab)), o.d_step(x, lab), rtol=2e-4)
+            assert np.allclose(np.ravel(m.g_step(x, lab, reuse_g_forward=True)), o.g_step(x, lab), rtol=2e-4)
+        else:
+            assert np.allclose(np.ravel(m.step(x, lab)), np.ravel(o.g_step(x, lab))[1:], rtol=2e-4)
+    gv, _ = m.get_vars()
+    for k in o.g:
+        assert gv[k].shape == o.g[k].shape and rel_err(gv[k], o.g[k]) < 1e-3, k
