@@ -189,6 +189,54 @@ def bench_dnn_gan(a, rank, local, world, dev):
     rdist.barrier()
 
 
+def bench_rced(a, rank, local, world, dev):
+    """R-CED under DNNTrainer (models/rced.py + dnn_trainer.py; run_dnn.sh:124-140 without batch_norm): input_dim 40 spliced
+    +-5 (fed 440) -> 9 x conv2d -> FC -> 40, batch --batch frames per GPU, one Adam step per batch."""
+    from types import SimpleNamespace
+    from rsrgan_amd import dist as rdist
+    from rsrgan_amd.trainer import DNNTrainer
+    N, W, S = a.batch, a.rced_width, 11
+    args = SimpleNamespace(batch_size=N, input_dim=W, output_dim=40, left_context=5, right_context=5, g_type="rced", keep_prob=1.0,
+                           batch_norm=False, num_gpu=world, save_dir=None, l2_scale=0.0, g_learning_rate=1e-3 * world)
+    model = DNNTrainer(None, args, ["gpu:%d" % local], seed=4321)
+    rng = np.random.default_rng(1234 + rank)
+    x = torch.from_numpy(rng.standard_normal((N, 1, S * W)).astype(np.float32)).to(dev)
+    lab = torch.from_numpy(rng.standard_normal((N, 1, 40)).astype(np.float32)).to(dev)
+    for _ in range(a.warmup):
+        model.step(x, lab, sync=False)
+    rdist.barrier(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter(); e0.record()
+    for _ in range(a.steps):
+        last = model.step(x, lab, sync=False)
+    e1.record(); torch.cuda.synchronize(); rdist.barrier()
+    dt = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        t = torch.tensor([dt, dev_ms], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt, dev_ms = float(t[0]), float(t[1])
+    if rank == 0:
+        num, wid, cin, fl = (12, 16, 20, 24, 32, 24, 20, 16, 12), (13, 11, 9, 7, 7, 7, 9, 11, 13), 1, 0
+        for co, fw in zip(num, wid):
+            fl += 2 * S * W * (S * fw * cin) * co          # per frame: positions x patch size x filters
+            cin = co
+        fl += 2 * S * W * cin * 40
+        fpf = 3 * fl                                      # forward + data gradient + weight gradient
+        ach = fpf * N / (dev_ms * 1e-3 / a.steps) / 1e12
+        out = {"metric": "supervised train frames/sec, R-CED generator (SURVEY 8f-2)", "value": round(N * world * a.steps / dt, 1),
+               "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt * 1e3 / a.steps, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "models/rced.py under DNNTrainer (batch_norm=False), frame width %d x splice 11, N=%d frames/GPU" % (W, N),
+                          "global_batch": N * world, "parallelism": "dp%d" % world,
+                          "losses_last_step": [round(float(v), 6) for v in last.mean(0).cpu().numpy()]},
+               "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                            "scope": "all launches of one step; algorithmic 3 x %d FLOP/frame (conv + FC GEMM terms)" % fl}}
+        print(json.dumps(out), flush=True)
+    rdist.barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,7 +244,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--frames", type=int, default=100)
-    ap.add_argument("--net", default="lstm", choices=["lstm", "res_lstm_l", "dnn_gan", "baseline_named"],
+    ap.add_argument("--net", default="lstm", choices=["lstm", "res_lstm_l", "dnn_gan", "baseline_named", "rced"],
                     help="dnn_gan = the frame-level GAN of models/gan.py (SURVEY 8f-1): --batch frames per step, T ignored; "
                          "baseline_named = BASELINE.json's wording: 2-layer 512-unit LSTM (no projection, SURVEY 8d-iii) + DNN D")
     ap.add_argument("--d-type", default="lstm", choices=["lstm", "dnn"],
@@ -206,6 +254,7 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the BASELINE.json-named network variant at N=1")
     ap.add_argument("--flags", type=int, default=int(os.environ.get("RSRGAN_FLAGS", "1")),
                     help="library schedule flags: 1 = wavefront, 4 = side-stream GEMM overlap (include/rsrgan.h)")
+    ap.add_argument("--rced-width", type=int, default=40, help="--net rced: frame width (run_dnn.sh:137 uses 40-dim MFCC input)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling (SURVEY 8d): --batch is the GLOBAL batch, split evenly over the ranks (default: weak, "
                          "--batch per GPU as the reference defines batch_size per tower)")
@@ -226,6 +275,8 @@ def main():
     from types import SimpleNamespace
     if a.net == "dnn_gan":
         return bench_dnn_gan(a, rank, local, world, dev)
+    if a.net == "rced":
+        return bench_rced(a, rank, local, world, dev)
     res = measure_sequence(a, a.net, a.d_type, a.batch, a.frames, a.steps, a.warmup, rank, local, world, dev)
     model, g_type, dt, dev_ms, losses, B, T = res["model"], res["g_type"], res["dt"], res["dev_ms"], res["losses"], a.batch, a.frames
     if a.net == "baseline_named":

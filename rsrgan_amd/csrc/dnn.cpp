@@ -56,8 +56,9 @@ void Model::rced_forward(int rows, hipStream_t s) {
   const size_t M = (size_t)rows * rcS * rcW;
   for (size_t l = 0; l < gconv.size(); ++l) {
     const ConvLayer& L = gconv[l];
-    launch_im2col(rc_act[l], l == 0 ? (size_t)ldDin : (size_t)rcS * rcW * L.ldCin, L.ldCin, L.Cin, rcS, rcW, rcS, L.fw, rc_col, L.ldK, M, s);
-    gemm(rc_col, L.ldK, true, G.W(L.tW), L.ldCout, false, rc_act[l + 1], L.ldCout, (int)M, L.Cout, L.K, G.W(L.tb), 2, 0.f, false, s);
+    float* col = rc_keep_cols ? rc_cols[l] : rc_col;
+    launch_im2col(rc_act[l], l == 0 ? (size_t)ldDin : (size_t)rcS * rcW * L.ldCin, L.ldCin, L.Cin, rcS, rcW, rcS, L.fw, col, L.ldK, M, s);
+    gemm(col, L.ldK, true, G.W(L.tW), L.ldCout, false, rc_act[l + 1], L.ldCout, (int)M, L.Cout, L.K, G.W(L.tb), 2, 0.f, false, s);
   }
   // reshape [rows, S*W*C] (rced.py:110: contiguous because C % 4 == 0) -> linear FC
   gemm(rc_act[gconv.size()], rc_fc.ld_in, true, G.W(rc_fc.tW), ldDout, false, y_tm, ldDout, rows, Dout, rc_fc.in, G.W(rc_fc.tb), 0, 0.f, false, s);
@@ -74,9 +75,11 @@ void Model::rced_backward(int rows, float* dy, hipStream_t s) {
   for (int l = Lc - 1; l >= 0; --l) {
     const ConvLayer& L = gconv[l];
     launch_lrelu_bwd(rc_act[l + 1], d, M, L.Cout, L.ldCout, 0.f, s);                      // relu': d *= [a > 0]
-    launch_im2col(rc_act[l], l == 0 ? (size_t)ldDin : (size_t)rcS * rcW * L.ldCin, L.ldCin, L.Cin, rcS, rcW, rcS, L.fw, rc_col, L.ldK, M, s);
-    gemm(rc_col, L.ldK, false, d, L.ldCout, false, G.Gd(L.tW), L.ldCout, L.K, L.Cout, (int)M, nullptr, 0, 0.f, false, s);
-    launch_colsum(d, L.ldCout, nullptr, 0, G.Gd(L.tb), (int)M, L.Cout, scratch, s);
+    float* col = rc_keep_cols ? rc_cols[l] : rc_col;          // kept from the forward pass of the same batch, or rebuilt
+    if (!rc_keep_cols)
+      launch_im2col(rc_act[l], l == 0 ? (size_t)ldDin : (size_t)rcS * rcW * L.ldCin, L.ldCin, L.Cin, rcS, rcW, rcS, L.fw, col, L.ldK, M, s);
+    gemm(col, L.ldK, false, d, L.ldCout, false, G.Gd(L.tW), L.ldCout, L.K, L.Cout, (int)M, nullptr, 0, 0.f, false, s);
+    launch_colsum_tall(d, L.ldCout, G.Gd(L.tb), (int)M, L.Cout, scratch, scratch_floats, s);
     if (l > 0) {
       gemm(d, L.ldCout, true, G.W(L.tW), L.ldCout, true, rc_dcol, L.ldK, (int)M, L.K, L.Cout, nullptr, 0, 0.f, false, s);
       launch_col2im(rc_dcol, L.ldK, L.Cin, rcS, rcW, rcS, L.fw, other, L.ldCin, M, s);

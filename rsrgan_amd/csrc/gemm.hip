@@ -158,6 +158,101 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
   }
 }
 
+// Narrow-N variant for outputs with N <= 32 columns (R-CED: a conv2d has 12..32 filters; 128-wide tiles would spend 75-90 %
+// of the MFMA work on padding): 256 x 32 x 16 block tile, 4 waves each 64 rows x 32 columns = 2 MFMA tiles.  B is [K][N]
+// (n contiguous) only.  Same k-major LDS image, register prefetch and deterministic split-K as k_gemm.
+constexpr int NBM = 256, NBN = 32, NLDA = 260, NLDB = 36;
+template <bool AKC>
+__global__ __launch_bounds__(256) void k_gemm_n32(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                  float* __restrict__ C, int ldc, int M, int N, int K,
+                                                  const float* __restrict__ bias, int act, float alpha, int accumulate,
+                                                  float* __restrict__ ws, int ldw, int kt_per_split) {
+  __shared__ __attribute__((aligned(16))) float As[BK][NLDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK][NLDB];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int m0 = blockIdx.y * NBM;
+  const int l31 = lane & 31, lh = lane >> 5;
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const int KA = AKC ? ((K + 3) & ~3) : K;
+  const int MA = AKC ? M : ((M + 3) & ~3);
+  const int NB = (N + 3) & ~3;
+  const int nk_all = (K + BK - 1) / BK;
+  const int kt0 = blockIdx.z * kt_per_split;
+  const int nk = min(nk_all, kt0 + kt_per_split);
+  float4 ra[4], rb;
+  auto load = [&](int kt) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + 256 * u;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (AKC) {
+        const int x = m0 + (idx >> 2), k = k0 + (idx & 3) * 4;
+        if (x < MA && k < KA) v = *reinterpret_cast<const float4*>(A + (size_t)x * lda + k);
+      } else {
+        const int k = k0 + (idx >> 6), x = m0 + (idx & 63) * 4;
+        if (k < K && x < MA) v = *reinterpret_cast<const float4*>(A + (size_t)k * lda + x);
+      }
+      ra[u] = v;
+    }
+    rb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 128) {
+      const int k = k0 + (tid >> 3), x = (tid & 7) * 4;
+      if (k < K && x < NB) rb = *reinterpret_cast<const float4*>(B + (size_t)k * ldb + x);
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + 256 * u;
+      if (AKC) {
+        const int x = idx >> 2, k = (idx & 3) * 4;
+        As[k + 0][x] = ra[u].x; As[k + 1][x] = ra[u].y; As[k + 2][x] = ra[u].z; As[k + 3][x] = ra[u].w;
+      } else {
+        const int k = idx >> 6, x = (idx & 63) * 4;
+        *reinterpret_cast<float4*>(&As[k][x]) = ra[u];
+      }
+    }
+    if (tid < 128) *reinterpret_cast<float4*>(&Bs[tid >> 3][(tid & 7) * 4]) = rb;
+  };
+  load(kt0);
+  for (int kt = kt0; kt < nk; ++kt) {
+    store();
+    __syncthreads();
+    if (kt + 1 < nk) load(kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int k = 2 * kk + lh;
+      const float a0 = As[k][w * 64 + l31], a1 = As[k][w * 64 + 32 + l31];
+      const float b0 = Bs[k][l31];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int col = l31;
+  if (col >= N) return;
+  const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + w * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row >= M) continue;
+      if (ws) { ws[((size_t)blockIdx.z * M + row) * ldw + col] = acc[i][r]; continue; }
+      float v = acc[i][r] + bv;
+      if (act == 1) v = fmaxf(v, alpha * v);
+      else if (act == 2) v = fmaxf(v, 0.f);
+      float* c = C + (size_t)row * ldc + col;
+      if (accumulate) v += *c;
+      *c = v;
+    }
+}
+
 // Split-K factor for an under-filled output grid (weight gradients: few tiles, K = T*B).  Model: the busiest CU runs
 // ceil(tiles*s/256) workgroups of ceil(nk/s) k-tiles (~1.2 us each; 25 % slower when fewer than two workgroups per CU
 // hide each other's latency), then the reduce streams s partial images at ~4 TB/s.
@@ -179,6 +274,28 @@ void launch_gemm2(const float* A, int lda, const float* A2, int lda2, int M1, bo
                   float* C, int ldc, int M, int N, int K, const float* bias, int act, float alpha, bool accumulate,
                   hipStream_t s, float* ws, size_t ws_floats) {
   if (M <= 0 || N <= 0) return;
+  if (N <= NBN && !b_kc && !A2 && M >= NBM) {         // narrow output: 256 x 32 tiles
+    const int gy = (M + NBM - 1) / NBM, nk = (K + BK - 1) / BK, ldw = (N + 3) & ~3;
+    int splits = 1;
+    if (ws && gy < 192 && nk >= 8) {
+      int cap = 64;
+      while (cap > 1 && (size_t)cap * M * ldw > ws_floats) --cap;
+      splits = pick_splits(gy, nk, (size_t)M * ldw * sizeof(float), cap);
+    }
+    const int per = std::max(1, (nk + splits - 1) / splits);
+    splits = std::max(1, (nk + per - 1) / per);
+    float* w = splits > 1 ? ws : nullptr;
+    dim3 grid(1, gy, splits), block(256);
+    const int acc = accumulate ? 1 : 0;
+    if (a_kc) hipLaunchKernelGGL((k_gemm_n32<true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per);
+    else hipLaunchKernelGGL((k_gemm_n32<false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per);
+    if (splits > 1) {
+      const size_t total = (size_t)M * N;
+      const int blocks = (int)std::min<size_t>(2048, (total + 255) / 256);
+      hipLaunchKernelGGL(k_splitk_reduce, dim3(blocks), dim3(256), 0, s, ws, ldw, splits, C, ldc, M, N, bias, act, alpha, acc);
+    }
+    return;
+  }
   const int gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
   const int nk = (K + BK - 1) / BK;
   int splits = 1;

@@ -139,6 +139,7 @@ void launch_lstm_colsums(const float* dz, const float* cprev, const float* ccur,
                          int rows, int H, float* scratch /* >= 64*7*H floats */, hipStream_t s);
 void launch_lrelu_bwd(const float* hval, float* d, size_t rows, int cols, int ld, float alpha, hipStream_t s); // d *= (h>0?1:alpha)
 // col sums over `rows` rows: out[c] = sum_r a[r*lda+c] * (b ? b[r*ldb+c] : 1)
+void launch_colsum_tall(const float* a, int lda, float* out, int rows, int cols, float* scratch, size_t scratch_floats, hipStream_t s);
 void launch_colsum(const float* a, int lda, const float* b, int ldb, float* out, int rows, int cols,
                    float* scratch /* >= 64*cols floats */, hipStream_t s);
 

@@ -1038,6 +1038,44 @@ __global__ void k_colsum2(const float* __restrict__ scratch, float* __restrict__
   for (int i = 0; i < CS_SLICES; ++i) s += scratch[(size_t)i * cols + c];
   out[c] = s;
 }
+// Tall, narrow matrices (R-CED bias gradients: 10^5..10^6 rows x <= 32 columns): more row slices, and a second stage that
+// splits the slices over four thread groups (fixed summation order: slice-group partials, then groups 0..3).
+__global__ __launch_bounds__(256) void k_colsum1_n(const float* __restrict__ a, int lda, float* __restrict__ scratch, int rows, int cols,
+                                                   int per) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int rbeg = blockIdx.y * per, rend = min(rows, rbeg + per);
+  float s = 0.f;
+  if (c < cols) {
+#pragma unroll 4
+    for (int r = rbeg + rl; r < rend; r += 4) s += a[(size_t)r * lda + c];
+  }
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols)
+    scratch[(size_t)blockIdx.y * cols + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void k_colsum2_n(const float* __restrict__ scratch, float* __restrict__ out, int cols, int slices) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < cols) {
+#pragma unroll 4
+    for (int i = g; i < slices; i += 4) s += scratch[(size_t)i * cols + c];
+  }
+  red[g][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (g == 0 && c < cols) out[c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+void launch_colsum_tall(const float* a, int lda, float* out, int rows, int cols, float* scratch, size_t scratch_floats, hipStream_t s) {
+  int slices = (int)std::min<size_t>(512, scratch_floats / (size_t)std::max(cols, 1));
+  slices = std::max(1, std::min(slices, (rows + 63) / 64));
+  const int per = (rows + slices - 1) / slices;
+  slices = (rows + per - 1) / per;
+  hipLaunchKernelGGL(k_colsum1_n, dim3((cols + 63) / 64, slices), dim3(256), 0, s, a, lda, scratch, rows, cols, per);
+  hipLaunchKernelGGL(k_colsum2_n, dim3((cols + 63) / 64), dim3(256), 0, s, scratch, out, cols, slices);
+}
+
 // One pass over dZ [rows][4H] and the cell stash: db[4H] = colsum(dZ); dw_i = colsum(dai*c_prev); dw_f = colsum(daf*c_prev);
 // dw_o = colsum(dao*c_cur).  scratch: CS_SLICES x 7H floats.
 __global__ __launch_bounds__(256) void k_lstm_colsums1(const float* __restrict__ dz, const float* __restrict__ cprev,

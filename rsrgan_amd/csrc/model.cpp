@@ -227,7 +227,17 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
       rc_act.push_back(alloc<float>(M * L.ldCout));
       maxK = std::max(maxK, L.ldK); maxC = std::max(maxC, L.ldCout);
     }
-    rc_col = alloc<float>(M * maxK); rc_dcol = alloc<float>(M * maxK);
+    // patch matrices: kept per layer from the forward pass when they fit a 96 GB budget (288 GB HBM3E), else one shared
+    // buffer that the backward pass refills
+    size_t keep = 0;
+    for (auto& L : gconv) keep += M * L.ldK;
+    rc_keep_cols = keep * sizeof(float) <= ((size_t)96 << 30) && !cfg.cross_validation;
+    if (rc_keep_cols) {
+      for (auto& L : gconv) { rc_cols.push_back(alloc<float>(M * L.ldK)); if (!rc_cols.back()) rc_keep_cols = false; }
+      if (!rc_keep_cols) rc_cols.clear();
+    }
+    rc_col = rc_keep_cols ? rc_cols[0] : alloc<float>(M * maxK);
+    rc_dcol = alloc<float>(M * maxK);
     rc_dA = alloc<float>(M * maxC); rc_dB = alloc<float>(M * maxC);
     if (!rc_col || !rc_dcol || !rc_dA || !rc_dB) { set_error("hipMalloc failed (R-CED patch matrices: %zu floats)", M * maxK); return RSRGAN_ERR_HIP; }
   } else if (g_dnn()) {
@@ -279,7 +289,8 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   size_t maxcols = 7 * (size_t)std::max(c.g_cells, c.d_cells);
   maxcols = std::max(maxcols, (size_t)Din + 4);
   maxcols = std::max(maxcols, (size_t)std::max(ldP, ldDin));
-  scratch = alloc<float>(std::max<size_t>(64 * maxcols, 1024));
+  scratch_floats = std::max<size_t>(64 * maxcols, 16384);
+  scratch = alloc<float>(scratch_floats);
   scratch2 = alloc<float>(std::max<size_t>(64 * maxcols, 1024));
   g_fc_out_wT = g_dnn() ? nullptr : alloc<float>((size_t)Dout * ldP);
   if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) side = nullptr;

@@ -127,6 +127,9 @@ struct Model {
   FcLayer rc_fc{};
   std::vector<float*> rc_act;
   float *rc_col = nullptr, *rc_dcol = nullptr, *rc_dA = nullptr, *rc_dB = nullptr;
+  std::vector<float*> rc_cols;     // per-layer patch matrices kept from the forward pass (rc_keep_cols)
+  bool rc_keep_cols = false;
+  size_t scratch_floats = 0;
   int rcS = 0, rcW = 0;
   void g_frame_forward(int rows, hipStream_t s);                        // DNN or R-CED generator on `rows` frames
   void g_frame_backward(int rows, float* dy, hipStream_t s);            // parameter gradients from d(output)
