@@ -1,0 +1,186 @@
+// conv.hip -- implicit-GEMM conv2d for the R-CED generator (models/rced.py:90-102): kernel [S, fw] with S = the whole height,
+// stride 1, SAME, NHWC.  No patch matrix is materialised: a workgroup keeps all S rows of a TW-column strip of one frame
+// (plus the fw-1 halo columns) in LDS, and because the channel axis is innermost, the (dw, ci) part of a patch is a CONTIGUOUS
+// window of an image row: A[m][k] = row[h_m + dh - pt][(wl_m)*C' + k], k in [0, fw*C').  C' = C rounded so that C'/4 is odd:
+// the 16 lanes of an MFMA operand then start 4*odd floats apart and their float4 reads hit 16 disjoint bank groups.  The filter is
+// pre-arranged by k_conv_prep as Ft[dh][co][k'] (k' = dw*C' + ci, zero rows at the pads), so both MFMA operands are k-contiguous
+// float4 (v_mfma_f32_16x16x4_f32, four MFMAs per float4 pair) exactly as in the recurrence kernels.
+// The same kernel computes the data gradient: d(in) = conv_SAME(d(out), flipped filter with in/out channels swapped).
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace rsr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int conv_cpad(int C) { return ((C / 4) & 1) ? C : C + 4; }          // C % 4 == 0 -> C'/4 odd
+__host__ __device__ inline int conv_kp(int fw, int C) { return (fw * conv_cpad(C) + 15) / 16 * 16; }   // k' extent, whole k-blocks
+__host__ __device__ inline int conv_ldf(int fw, int C) { const int k = conv_kp(fw, C) + 4; return ((k / 4) & 1) ? k : k + 4; }
+
+// Ft[dh][n][k'] for n < 32: n = output channel, k' = dw*C' + c.  flip = 0: Ft = F[dh][dw][c][n] (forward, C = Cin, N = Cout);
+// flip = 1: Ft = F[S-1-dh][fw-1-dw][n][c] (data gradient: C = Cout of the layer, N = Cin).  F is the [S*fw*Cin][ldf_src] operand.
+__global__ void k_conv_prep(const float* __restrict__ F, int ldf_src, int S, int fw, int Cin, int Cout, int flip, float* __restrict__ Ft) {
+  const int C = flip ? Cout : Cin, N = flip ? Cin : Cout;
+  const int Cp = conv_cpad(C), ldf = conv_ldf(fw, C);
+  const size_t total = (size_t)S * 32 * ldf;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int kp = (int)(i % ldf);
+    const int n = (int)((i / ldf) % 32);
+    const int dh = (int)(i / ((size_t)ldf * 32));
+    const int dw = kp / Cp, c = kp - dw * Cp;
+    float v = 0.f;
+    if (n < N && dw < fw && c < C) {
+      if (!flip) v = F[((size_t)(dh * fw + dw) * Cin + c) * ldf_src + n];
+      else v = F[((size_t)((S - 1 - dh) * fw + (fw - 1 - dw)) * Cin + n) * ldf_src + c];
+    }
+    Ft[i] = v;
+  }
+}
+
+// grid: (strips per frame, frames).  512 threads = 8 waves; wave w owns the 16-position tiles w*RT .. w*RT+RT-1 of the strip's
+// S*TW positions and both 16-column halves of the (<= 32) output channels.
+template <int RT>
+__global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, int ldc_in, int C, const float* __restrict__ Ft,
+                                                  const float* __restrict__ bias, int relu, float* __restrict__ out, int ldc_out, int N,
+                                                  int S, int W, int fw, int TW) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Cp = conv_cpad(C), nkb = conv_kp(fw, C) / 16, ldf = conv_ldf(fw, C);
+  const int pt = (S - 1) / 2, pl = (fw - 1) / 2;
+  const int rowlen = (TW + fw - 1) * Cp + 16;             // +16: the last k-block of the last position may run past its window
+  float* img = smem;                                      // [S + 1][rowlen], row S = zeros
+  float* fts = smem + (size_t)(S + 1) * rowlen;           // [32][ldf] filter slice of one dh
+  const int r = blockIdx.y, w0 = blockIdx.x * TW;
+  const int tw = min(TW, W - w0);
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // image strip -> LDS: position x of a row is image column w0 - pl + x; every slot (halo, channel pads, zero row) is written
+  {
+    const int cp4 = Cp / 4, row4 = rowlen / 4;
+    const int total4 = (S + 1) * row4;
+    for (int i = tid; i < total4; i += 512) {
+      const int h = i / row4, e = i - h * row4;
+      const int x = e / cp4, c = (e - x * cp4) * 4;
+      const int wcol = w0 - pl + x;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (h < S && x < TW + fw - 1 && wcol >= 0 && wcol < W && c < C)
+        v = *reinterpret_cast<const float4*>(in + ((size_t)(r * S + h) * W + wcol) * ldc_in + c);
+      *reinterpret_cast<float4*>(img + (size_t)h * rowlen + (size_t)e * 4) = v;
+    }
+  }
+  // per-lane position of each row tile: m = (wv*RT + i)*16 + lr -> (h, wl); positions >= S*tw are parked on the zero row
+  const int M = S * TW;
+  int ph[RT], pofs[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) {
+    const int m = (wv * RT + i) * 16 + lr;
+    const int h = m / TW, wl = m - h * TW;
+    const bool ok = m < M && wl < tw;
+    ph[i] = ok ? h : -1000;
+    pofs[i] = wl * Cp + 4 * q;
+  }
+  f32x4 acc[RT][2];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int dh = 0; dh < S; ++dh) {
+    __syncthreads();                                      // image ready (first pass) / previous filter slice consumed
+    {
+      const float4* src = reinterpret_cast<const float4*>(Ft + (size_t)dh * 32 * ldf);
+      float4* dst = reinterpret_cast<float4*>(fts);
+      for (int i = tid; i < 32 * ldf / 4; i += 512) dst[i] = src[i];
+    }
+    __syncthreads();
+    const float* arow[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const int hh = ph[i] + dh - pt;
+      arow[i] = img + (size_t)((hh >= 0 && hh < S) ? hh : S) * rowlen + pofs[i];
+    }
+    const float* b0 = fts + (size_t)lr * ldf + 4 * q;
+    const float* b1 = b0 + (size_t)16 * ldf;
+    for (int kb = 0; kb < nkb; ++kb) {
+      const float4 bv0 = *reinterpret_cast<const float4*>(b0 + kb * 16);
+      const float4 bv1 = *reinterpret_cast<const float4*>(b1 + kb * 16);
+      float4 av[RT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) av[i] = *reinterpret_cast<const float4*>(arow[i] + kb * 16);
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv0.x, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv1.x, acc[i][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv0.y, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv1.y, acc[i][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv0.z, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv1.z, acc[i][1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv0.w, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv1.w, acc[i][1], 0, 0, 0);
+      }
+    }
+  }
+  // epilogue: C/D map of the 16x16 MFMA: row = 4*(lane>>4) + e, col = lane&15
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int co = j * 16 + lr;
+      if (co >= N) continue;
+      const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = (wv * RT + i) * 16 + 4 * q + e;
+        const int h = m / TW, wl = m - h * TW;
+        if (m >= M || wl >= tw) continue;
+        float v = acc[i][j][e] + bv;
+        if (relu) v = fmaxf(v, 0.f);
+        out[((size_t)(r * S + h) * W + w0 + wl) * ldc_out + co] = v;
+      }
+    }
+}
+
+size_t conv_prep_floats(int S, int fw, int C) { return (size_t)S * 32 * conv_ldf(fw, C); }
+
+void launch_conv_prep(const float* F, int ldf_src, int S, int fw, int Cin, int Cout, bool flip, float* Ft, hipStream_t s) {
+  const size_t total = conv_prep_floats(S, fw, flip ? Cout : Cin);
+  hipLaunchKernelGGL(k_conv_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, F, ldf_src, S, fw, Cin, Cout, flip ? 1 : 0, Ft);
+}
+
+// true if the implicit kernel covers this shape (else the caller uses the patch-matrix path)
+bool conv_fwd_supported(int C, int N, int S, int W, int fw) {
+  if (C % 4 || C < 4 || N > 32 || !(S & 1) || !(fw & 1)) return false;
+  const int TW = (S * W <= 8 * 4 * 16) ? W : 64;
+  const int RT = (S * W <= 8 * 4 * 16) ? 4 : 6;
+  if (S * TW > 8 * RT * 16) return false;
+  const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)32 * conv_ldf(fw, C)) * sizeof(float);
+  return lds <= 160 * 1024;
+}
+
+void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const float* bias, bool relu, float* out, int ldc_out, int N,
+                     int R, int S, int W, int fw, hipStream_t s) {
+  const bool small = S * W <= 8 * 4 * 16;
+  const int TW = small ? W : 64;
+  const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)32 * conv_ldf(fw, C)) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  dim3 grid((W + TW - 1) / TW, R);
+  if (small) hipLaunchKernelGGL(k_conv_fwd<4>, grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, relu ? 1 : 0, out, ldc_out, N, S, W, fw, TW);
+  else hipLaunchKernelGGL(k_conv_fwd<6>, grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, relu ? 1 : 0, out, ldc_out, N, S, W, fw, TW);
+}
+
+}  // namespace rsr

@@ -56,6 +56,10 @@ void Model::rced_forward(int rows, hipStream_t s) {
   const size_t M = (size_t)rows * rcS * rcW;
   for (size_t l = 0; l < gconv.size(); ++l) {
     const ConvLayer& L = gconv[l];
+    if (rc_ft_fwd[l]) {                          // implicit GEMM: no patch matrix
+      launch_conv_fwd(rc_act[l], L.ldCin, L.Cin, rc_ft_fwd[l], G.W(L.tb), true, rc_act[l + 1], L.ldCout, L.Cout, rows, rcS, rcW, L.fw, s);
+      continue;
+    }
     float* col = rc_keep_cols ? rc_cols[l] : rc_col;
     launch_im2col(rc_act[l], l == 0 ? (size_t)ldDin : (size_t)rcS * rcW * L.ldCin, L.ldCin, L.Cin, rcS, rcW, rcS, L.fw, col, L.ldK, M, s);
     gemm(col, L.ldK, true, G.W(L.tW), L.ldCout, false, rc_act[l + 1], L.ldCout, (int)M, L.Cout, L.K, G.W(L.tb), 2, 0.f, false, s);
@@ -81,8 +85,12 @@ void Model::rced_backward(int rows, float* dy, hipStream_t s) {
     gemm(col, L.ldK, false, d, L.ldCout, false, G.Gd(L.tW), L.ldCout, L.K, L.Cout, (int)M, nullptr, 0, 0.f, false, s);
     launch_colsum_tall(d, L.ldCout, G.Gd(L.tb), (int)M, L.Cout, scratch, scratch_floats, s);
     if (l > 0) {
-      gemm(d, L.ldCout, true, G.W(L.tW), L.ldCout, true, rc_dcol, L.ldK, (int)M, L.K, L.Cout, nullptr, 0, 0.f, false, s);
-      launch_col2im(rc_dcol, L.ldK, L.Cin, rcS, rcW, rcS, L.fw, other, L.ldCin, M, s);
+      if (rc_ft_bwd[l]) {                        // d(in) = conv_SAME(d, flipped filter): the same implicit-GEMM kernel
+        launch_conv_fwd(d, L.ldCout, L.Cout, rc_ft_bwd[l], nullptr, false, other, L.ldCin, L.Cin, rows, rcS, rcW, L.fw, s);
+      } else {
+        gemm(d, L.ldCout, true, G.W(L.tW), L.ldCout, true, rc_dcol, L.ldK, (int)M, L.K, L.Cout, nullptr, 0, 0.f, false, s);
+        launch_col2im(rc_dcol, L.ldK, L.Cin, rcS, rcW, rcS, L.fw, other, L.ldCin, M, s);
+      }
       std::swap(d, other);
     }
   }

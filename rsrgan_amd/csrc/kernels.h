@@ -129,6 +129,12 @@ void launch_fill(float* p, size_t n, float v, hipStream_t s);
 struct TransposeJob { const float* src; float* dst; int lds, ldd, R, C, blk_base; };   // dst[c][r] = src[r][c]
 struct TransposeList { int n; TransposeJob j[16]; };
 void launch_transpose_many(TransposeList& tl, hipStream_t s);
+// implicit-GEMM conv2d (conv.hip): Ft = prepared filter (launch_conv_prep), forward or data gradient (flip)
+size_t conv_prep_floats(int S, int fw, int C);
+void launch_conv_prep(const float* F, int ldf_src, int S, int fw, int Cin, int Cout, bool flip, float* Ft, hipStream_t s);
+bool conv_fwd_supported(int C, int N, int S, int W, int fw);
+void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const float* bias, bool relu, float* out, int ldc_out, int N,
+                     int R, int S, int W, int fw, hipStream_t s);
 // R-CED patch matrix (conv2d SAME as GEMM) and its adjoint; col2im needs C % 4 == 0
 void launch_im2col(const float* src, size_t row_stride, int ldc, int C, int S, int W, int kh, int kw, float* col, int ldk, size_t M,
                    hipStream_t s);

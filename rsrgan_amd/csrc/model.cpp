@@ -227,11 +227,20 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
       rc_act.push_back(alloc<float>(M * L.ldCout));
       maxK = std::max(maxK, L.ldK); maxC = std::max(maxC, L.ldCout);
     }
+    // implicit-GEMM convolution (conv.hip) for every layer it covers: forward and data gradient never build a patch matrix
+    if (const char* e = getenv("RSRGAN_RCED_IMPLICIT")) rc_implicit = atoi(e) != 0;
+    rc_ft_fwd.assign(gconv.size(), nullptr); rc_ft_bwd.assign(gconv.size(), nullptr);
+    bool any_implicit = false;
+    for (size_t l = 0; l < gconv.size() && rc_implicit; ++l) {
+      const ConvLayer& L = gconv[l];
+      if (conv_fwd_supported(L.Cin, L.Cout, rcS, rcW, L.fw)) { rc_ft_fwd[l] = alloc<float>(conv_prep_floats(rcS, L.fw, L.Cin)); any_implicit = true; }
+      if (l > 0 && conv_fwd_supported(L.Cout, L.Cin, rcS, rcW, L.fw)) rc_ft_bwd[l] = alloc<float>(conv_prep_floats(rcS, L.fw, L.Cout));
+    }
     // patch matrices: kept per layer from the forward pass when they fit a 96 GB budget (288 GB HBM3E), else one shared
     // buffer that the backward pass refills
     size_t keep = 0;
     for (auto& L : gconv) keep += M * L.ldK;
-    rc_keep_cols = keep * sizeof(float) <= ((size_t)96 << 30) && !cfg.cross_validation;
+    rc_keep_cols = !any_implicit && keep * sizeof(float) <= ((size_t)96 << 30) && !cfg.cross_validation;
     if (rc_keep_cols) {
       for (auto& L : gconv) { rc_cols.push_back(alloc<float>(M * L.ldK)); if (!rc_cols.back()) rc_keep_cols = false; }
       if (!rc_keep_cols) rc_cols.clear();
@@ -415,6 +424,12 @@ void Model::refresh_transposes(int net, hipStream_t s) {
   if (net == RSRGAN_NET_G && g_fc_out_wT && g_fc_out_w >= 0)
     add(G.W(g_fc_out_w), ldDout, g_fc_out_wT, pad4(gR), gR, Dout);   // [P][ldDout] -> [Dout][ldP]
   launch_transpose_many(tl, s);
+  if (net == RSRGAN_NET_G)
+    for (size_t l = 0; l < gconv.size(); ++l) {                       // R-CED: re-arranged filters of the implicit-GEMM conv
+      const ConvLayer& L = gconv[l];
+      if (rc_ft_fwd[l]) launch_conv_prep(G.W(L.tW), L.ldCout, rcS, L.fw, L.Cin, L.Cout, false, rc_ft_fwd[l], s);
+      if (rc_ft_bwd[l]) launch_conv_prep(G.W(L.tW), L.ldCout, rcS, L.fw, L.Cin, L.Cout, true, rc_ft_bwd[l], s);
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -120,15 +120,20 @@ def test_training_converges_on_a_learnable_task():
     assert hist[-1, 4] < 0.6 * hist[0, 4], hist[:, 4]
 
 
-@pytest.mark.parametrize("N,gan", [(6, False), (37, False), (6, True)])
-def test_rced_generator_matches_oracle(N, gan):
+@pytest.mark.parametrize("N,gan,ctx,width", [(6, False, (2, 1), 9), (37, False, (2, 1), 9), (6, True, (2, 1), 9),
+                                              (5, False, (1, 1), 9), (5, True, (2, 2), 21), (3, False, (1, 1), 200),
+                                              (3, False, (1, 1), -11), (2, True, (5, 5), -40)])     # width < 0: the reference's filter table
+def test_rced_generator_matches_oracle(N, gan, ctx, width):
     """models/rced.py under DNNTrainer (and, as BASELINE.json's config 4 words it, paired with discriminator_dnn): conv2d SAME as
     patch-matrix GEMMs on the HIP path vs the fp64 oracle (tower losses, every gradient tensor, Adam steps, variables)."""
     from oracle import rced_oracle as R
     from rsrgan_amd import GAN
     from rsrgan_amd.trainer import DNNTrainer
-    cfg = R.RcedCfg(input_dim=9, output_dim=5, left_context=2, right_context=1, d_units=18, d_hidden=2,
-                    filters_num=(4, 4, 4, 4, 4, 4, 4, 4, 4))            # the library scales the reference table 12..32..12 by g_cells/32
+    # even splice (2,1): patch-matrix GEMMs; odd splice: the implicit-GEMM conv (one strip per frame, or 64-column strips at width 200)
+    full = width < 0
+    width = abs(width)
+    cfg = R.RcedCfg(input_dim=width, output_dim=5, left_context=ctx[0], right_context=ctx[1], d_units=18, d_hidden=2,
+                    filters_num=R.FILTERS_NUM if full else (4,) * 9)   # the library scales the reference table 12..32..12 by g_cells/32
     rng = np.random.default_rng(N)
     g = {k: v.astype(np.float32) for k, v in R.init_params(R.g_param_specs(cfg), rng).items()}
     for k in g:
@@ -138,7 +143,7 @@ def test_rced_generator_matches_oracle(N, gan):
     args = SimpleNamespace(batch_size=N, input_dim=cfg.input_dim, output_dim=cfg.output_dim, left_context=cfg.left_context,
                            right_context=cfg.right_context, g_type="rced", keep_prob=1.0, batch_norm=False, num_gpu=1, save_dir=None,
                            l2_scale=1e-3, g_learning_rate=1e-3, d_learning_rate=2e-3, init_mse_weight=10.0, disc_updates=1, gen_updates=1)
-    ov = dict(g_layers=9, g_cells=4, d_layers=cfg.d_hidden, d_cells=cfg.d_units)
+    ov = dict(g_layers=9, g_cells=32 if full else 4, d_layers=cfg.d_hidden, d_cells=cfg.d_units)
     if gan:
         class RcedGan(GAN):
             G_TYPES = ("dnn", "rced")
