@@ -40,7 +40,7 @@ __global__ void k_conv_prep(const float* __restrict__ F, int ldf_src, int S, int
 
 // grid: (strips per frame, frames).  512 threads = 8 waves; wave w owns the 16-position tiles w*RT .. w*RT+RT-1 of the strip's
 // S*TW positions and both 16-column halves of the (<= 32) output channels.
-template <int RT>
+template <int RT, int NT>
 __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, int ldc_in, int C, const float* __restrict__ Ft,
                                                   const float* __restrict__ bias, int relu, float* __restrict__ out, int ldc_out, int N,
                                                   int S, int W, int fw, int TW) {
@@ -80,18 +80,18 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
     ph[i] = ok ? h : -1000;
     pofs[i] = wl * Cp + 4 * q;
   }
-  f32x4 acc[RT][2];
+  f32x4 acc[RT][NT];
 #pragma unroll
   for (int i = 0; i < RT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int dh = 0; dh < S; ++dh) {
     __syncthreads();                                      // image ready (first pass) / previous filter slice consumed
     {
       const float4* src = reinterpret_cast<const float4*>(Ft + (size_t)dh * 32 * ldf);
       float4* dst = reinterpret_cast<float4*>(fts);
-      for (int i = tid; i < 32 * ldf / 4; i += 512) dst[i] = src[i];
+      for (int i = tid; i < NT * 16 * ldf / 4; i += 512) dst[i] = src[i];
     }
     __syncthreads();
     const float* arow[RT];
@@ -103,38 +103,35 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
     const float* b0 = fts + (size_t)lr * ldf + 4 * q;
     const float* b1 = b0 + (size_t)16 * ldf;
     for (int kb = 0; kb < nkb; ++kb) {
-      const float4 bv0 = *reinterpret_cast<const float4*>(b0 + kb * 16);
-      const float4 bv1 = *reinterpret_cast<const float4*>(b1 + kb * 16);
+      float4 bv[NT];
+      bv[0] = *reinterpret_cast<const float4*>(b0 + kb * 16);
+      if (NT == 2) bv[NT - 1] = *reinterpret_cast<const float4*>(b1 + kb * 16);
       float4 av[RT];
 #pragma unroll
       for (int i = 0; i < RT; ++i) av[i] = *reinterpret_cast<const float4*>(arow[i] + kb * 16);
 #pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv0.x, acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv1.x, acc[i][1], 0, 0, 0);
-      }
+      for (int i = 0; i < RT; ++i)
 #pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv0.y, acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv1.y, acc[i][1], 0, 0, 0);
-      }
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv0.z, acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv1.z, acc[i][1], 0, 0, 0);
-      }
+      for (int i = 0; i < RT; ++i)
 #pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv0.w, acc[i][0], 0, 0, 0);
-        acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv1.w, acc[i][1], 0, 0, 0);
-      }
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
     }
   }
   // epilogue: C/D map of the 16x16 MFMA: row = 4*(lane>>4) + e, col = lane&15
 #pragma unroll
   for (int i = 0; i < RT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NT; ++j) {
       const int co = j * 16 + lr;
       if (co >= N) continue;
       const float bv = bias ? bias[co] : 0.f;
@@ -148,6 +145,100 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
         out[((size_t)(r * S + h) * W + w0 + wl) * ldc_out + co] = v;
       }
     }
+}
+
+// Weight gradient without a patch matrix: dF[dh][k'][co] = sum over positions of A[m][dh, k'] * d[m][co].  One workgroup owns one
+// filter row dh for a group of frames (and one column strip): per frame it stages the image strip and the d strip in LDS and
+// accumulates its [K' x 32] tile in registers (wave w: k'-tiles w*KT.., both output-channel halves; the MFMA k axis runs over
+// positions).  Partials [group][strip][dh][K'][32] are summed in a fixed order by k_conv_wgrad_red, which also undoes the k' padding.
+template <int KT>
+__global__ __launch_bounds__(512) void k_conv_wgrad(const float* __restrict__ in, int ldc_in, int C, const float* __restrict__ d, int ldc_d,
+                                                    int N, float* __restrict__ part, int S, int W, int fw, int TW, int R, int fpg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Cp = conv_cpad(C), KP = conv_kp(fw, C);
+  const int pt = (S - 1) / 2, pl = (fw - 1) / 2;
+  const int rowlen = (TW + fw - 1) * Cp + 16;
+  const int MP = (S * TW + 15) / 16 * 16;                 // positions padded to whole 16-blocks
+  float* img = smem;                                      // [S + 1][rowlen], row S = zeros
+  float* ds = smem + (size_t)(S + 1) * rowlen;            // [MP][33] gradient strip (33: consecutive positions on different banks)
+  const int dh = blockIdx.x, grp = blockIdx.y, strip = blockIdx.z;
+  const int w0 = strip * TW, tw = min(TW, W - w0);
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  f32x4 acc[KT][2];
+#pragma unroll
+  for (int i = 0; i < KT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int M = S * TW;
+  for (int f = 0; f < fpg; ++f) {
+    const int r = grp * fpg + f;
+    if (r >= R) break;
+    __syncthreads();
+    {
+      const int cp4 = Cp / 4, row4 = rowlen / 4, total4 = (S + 1) * row4;
+      for (int i = tid; i < total4; i += 512) {
+        const int h = i / row4, e = i - h * row4;
+        const int x = e / cp4, c = (e - x * cp4) * 4;
+        const int wcol = w0 - pl + x;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h < S && x < TW + fw - 1 && wcol >= 0 && wcol < W && c < C)
+          v = *reinterpret_cast<const float4*>(in + ((size_t)(r * S + h) * W + wcol) * ldc_in + c);
+        *reinterpret_cast<float4*>(img + (size_t)h * rowlen + (size_t)e * 4) = v;
+      }
+      for (int i = tid; i < MP * 8; i += 512) {            // 8 float4 = 32 channels per position
+        const int m = i >> 3, c = (i & 7) * 4;
+        const int h = m / TW, wl = m - h * TW;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M && wl < tw && c < N) v = *reinterpret_cast<const float4*>(d + ((size_t)(r * S + h) * W + w0 + wl) * ldc_d + c);
+        float* o = ds + (size_t)m * 33 + c;
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+      }
+    }
+    __syncthreads();
+    for (int mb = 0; mb < MP / 16; ++mb) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = mb * 16 + 4 * q + j;                 // this lane's position on the MFMA k axis
+        const int h = m / TW, wl = m - h * TW;
+        const int hh = h + dh - pt;
+        const float* arow = img + (size_t)((m < M && hh >= 0 && hh < S) ? hh : S) * rowlen + wl * Cp;
+        const float b0 = ds[(size_t)m * 33 + lr], b1 = ds[(size_t)m * 33 + 16 + lr];
+#pragma unroll
+        for (int i = 0; i < KT; ++i) {
+          const int kt = wv * KT + i;
+          const float a = (kt * 16 < KP) ? arow[kt * 16 + lr] : 0.f;
+          acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[i][0], 0, 0, 0);
+          acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[i][1], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // partial tile -> part[((grp*nstrips + strip)*S + dh)][k'][32]
+  float* po = part + ((size_t)(grp * gridDim.z + strip) * S + dh) * (size_t)KP * 32;
+#pragma unroll
+  for (int i = 0; i < KT; ++i) {
+    const int kt = wv * KT + i;
+    if (kt * 16 >= KP) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) po[(size_t)(kt * 16 + 4 * q + e) * 32 + j * 16 + lr] = acc[i][j][e];
+  }
+}
+// dW[(dh*fw + dw)*C + c][co] = sum over partial tiles p of part[p][dh][dw*C' + c][co]   (fixed order)
+__global__ void k_conv_wgrad_red(const float* __restrict__ part, int nparts, int S, int fw, int C, int N, float* __restrict__ dW, int ldw) {
+  const int Cp = conv_cpad(C), KP = conv_kp(fw, C);
+  const int total = S * fw * C * N;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int co = i % N, k = i / N;
+  const int c = k % C, dd = k / C, dw = dd % fw, dh = dd / fw;
+  const size_t off = ((size_t)dh * KP + dw * Cp + c) * 32 + co, stride = (size_t)S * KP * 32;
+  float s = 0.f;
+#pragma unroll 8
+  for (int p = 0; p < nparts; ++p) s += part[p * stride + off];
+  dW[(size_t)k * ldw + co] = s;
 }
 
 size_t conv_prep_floats(int S, int fw, int C) { return (size_t)S * 32 * conv_ldf(fw, C); }
@@ -174,13 +265,51 @@ void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const 
   const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)32 * conv_ldf(fw, C)) * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd<6, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd<6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   dim3 grid((W + TW - 1) / TW, R);
-  if (small) hipLaunchKernelGGL(k_conv_fwd<4>, grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, relu ? 1 : 0, out, ldc_out, N, S, W, fw, TW);
-  else hipLaunchKernelGGL(k_conv_fwd<6>, grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, relu ? 1 : 0, out, ldc_out, N, S, W, fw, TW);
+  const int rl = relu ? 1 : 0;
+  if (small && N <= 16) hipLaunchKernelGGL((k_conv_fwd<4, 1>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW);
+  else if (small) hipLaunchKernelGGL((k_conv_fwd<4, 2>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW);
+  else if (N <= 16) hipLaunchKernelGGL((k_conv_fwd<6, 1>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW);
+  else hipLaunchKernelGGL((k_conv_fwd<6, 2>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW);
+}
+
+// frames per workgroup of the weight-gradient kernel: ~256 workgroups in flight (S filter rows x groups x strips)
+static int wgrad_fpg(int R, int S, int nstrips) { return std::max(1, (R * S * nstrips + 255) / 256); }
+size_t conv_wgrad_ws_floats(int C, int R, int S, int W, int fw) {
+  const int TW = (S * W <= 8 * 4 * 16) ? W : 64, nstrips = (W + TW - 1) / TW;
+  const int fpg = wgrad_fpg(R, S, nstrips), groups = (R + fpg - 1) / fpg;
+  return (size_t)groups * nstrips * S * conv_kp(fw, C) * 32;
+}
+bool conv_wgrad_supported(int C, int N, int S, int W, int fw) {
+  if (!conv_fwd_supported(C, N, S, W, fw)) return false;
+  const int TW = (S * W <= 8 * 4 * 16) ? W : 64;
+  const int MP = (S * TW + 15) / 16 * 16;
+  const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 33) * sizeof(float);
+  return lds <= 160 * 1024 && conv_kp(fw, C) <= 8 * 2 * 16;
+}
+void launch_conv_wgrad(const float* in, int ldc_in, int C, const float* d, int ldc_d, int N, float* dW, int ldw, float* ws, int R, int S,
+                       int W, int fw, hipStream_t s) {
+  const int TW = (S * W <= 8 * 4 * 16) ? W : 64, nstrips = (W + TW - 1) / TW;
+  const int fpg = wgrad_fpg(R, S, nstrips), groups = (R + fpg - 1) / fpg;
+  const int MP = (S * TW + 15) / 16 * 16, KP = conv_kp(fw, C);
+  const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 33) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  dim3 grid(S, groups, nstrips);
+  if (KP <= 8 * 16) hipLaunchKernelGGL(k_conv_wgrad<1>, grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  else hipLaunchKernelGGL(k_conv_wgrad<2>, grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  const int total = S * fw * C * N;
+  hipLaunchKernelGGL(k_conv_wgrad_red, dim3((total + 255) / 256), dim3(256), 0, s, ws, groups * nstrips, S, fw, C, N, dW, ldw);
 }
 
 }  // namespace rsr

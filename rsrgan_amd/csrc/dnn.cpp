@@ -79,10 +79,14 @@ void Model::rced_backward(int rows, float* dy, hipStream_t s) {
   for (int l = Lc - 1; l >= 0; --l) {
     const ConvLayer& L = gconv[l];
     launch_lrelu_bwd(rc_act[l + 1], d, M, L.Cout, L.ldCout, 0.f, s);                      // relu': d *= [a > 0]
-    float* col = rc_keep_cols ? rc_cols[l] : rc_col;          // kept from the forward pass of the same batch, or rebuilt
-    if (!rc_keep_cols)
-      launch_im2col(rc_act[l], l == 0 ? (size_t)ldDin : (size_t)rcS * rcW * L.ldCin, L.ldCin, L.Cin, rcS, rcW, rcS, L.fw, col, L.ldK, M, s);
-    gemm(col, L.ldK, false, d, L.ldCout, false, G.Gd(L.tW), L.ldCout, L.K, L.Cout, (int)M, nullptr, 0, 0.f, false, s);
+    if (rc_wgrad_implicit[l] && rc_wg_ws) {
+      launch_conv_wgrad(rc_act[l], L.ldCin, L.Cin, d, L.ldCout, L.Cout, G.Gd(L.tW), L.ldCout, rc_wg_ws, rows, rcS, rcW, L.fw, s);
+    } else {
+      float* col = rc_keep_cols ? rc_cols[l] : rc_col;          // kept from the forward pass of the same batch, or rebuilt
+      if (!rc_keep_cols)
+        launch_im2col(rc_act[l], l == 0 ? (size_t)ldDin : (size_t)rcS * rcW * L.ldCin, L.ldCin, L.Cin, rcS, rcW, rcS, L.fw, col, L.ldK, M, s);
+      gemm(col, L.ldK, false, d, L.ldCout, false, G.Gd(L.tW), L.ldCout, L.K, L.Cout, (int)M, nullptr, 0, 0.f, false, s);
+    }
     launch_colsum_tall(d, L.ldCout, G.Gd(L.tb), (int)M, L.Cout, scratch, scratch_floats, s);
     if (l > 0) {
       if (rc_ft_bwd[l]) {                        // d(in) = conv_SAME(d, flipped filter): the same implicit-GEMM kernel

@@ -230,12 +230,19 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     // implicit-GEMM convolution (conv.hip) for every layer it covers: forward and data gradient never build a patch matrix
     if (const char* e = getenv("RSRGAN_RCED_IMPLICIT")) rc_implicit = atoi(e) != 0;
     rc_ft_fwd.assign(gconv.size(), nullptr); rc_ft_bwd.assign(gconv.size(), nullptr);
+    rc_wgrad_implicit.assign(gconv.size(), 0);
     bool any_implicit = false;
+    size_t wg_ws = 0;
     for (size_t l = 0; l < gconv.size() && rc_implicit; ++l) {
       const ConvLayer& L = gconv[l];
       if (conv_fwd_supported(L.Cin, L.Cout, rcS, rcW, L.fw)) { rc_ft_fwd[l] = alloc<float>(conv_prep_floats(rcS, L.fw, L.Cin)); any_implicit = true; }
       if (l > 0 && conv_fwd_supported(L.Cout, L.Cin, rcS, rcW, L.fw)) rc_ft_bwd[l] = alloc<float>(conv_prep_floats(rcS, L.fw, L.Cout));
+      if (conv_wgrad_supported(L.Cin, L.Cout, rcS, rcW, L.fw)) {
+        rc_wgrad_implicit[l] = 1;
+        wg_ws = std::max(wg_ws, conv_wgrad_ws_floats(L.Cin, (int)TB, rcS, rcW, L.fw));
+      }
     }
+    if (wg_ws) rc_wg_ws = alloc<float>(wg_ws);
     // patch matrices: kept per layer from the forward pass when they fit a 96 GB budget (288 GB HBM3E), else one shared
     // buffer that the backward pass refills
     size_t keep = 0;

@@ -129,6 +129,8 @@ struct Model {
   float *rc_col = nullptr, *rc_dcol = nullptr, *rc_dA = nullptr, *rc_dB = nullptr;
   std::vector<float*> rc_cols;     // per-layer patch matrices kept from the forward pass (rc_keep_cols)
   std::vector<float*> rc_ft_fwd, rc_ft_bwd;   // prepared filters of the implicit-GEMM conv (conv.hip); nullptr = patch-matrix path
+  std::vector<char> rc_wgrad_implicit;        // per layer: weight gradient by k_conv_wgrad
+  float* rc_wg_ws = nullptr;                  // its partial tiles
   bool rc_implicit = true;         // RSRGAN_RCED_IMPLICIT=0: patch-matrix GEMMs everywhere (the first correct path, kept for A/B)
   bool rc_keep_cols = false;
   size_t scratch_floats = 0;
