@@ -151,7 +151,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
 // filter row dh for a group of frames (and one column strip): per frame it stages the image strip and the d strip in LDS and
 // accumulates its [K' x 32] tile in registers (wave w: k'-tiles w*KT.., both output-channel halves; the MFMA k axis runs over
 // positions).  Partials [group][strip][dh][K'][32] are summed in a fixed order by k_conv_wgrad_red, which also undoes the k' padding.
-template <int KT>
+template <int KT, int NT>
 __global__ __launch_bounds__(512) void k_conv_wgrad(const float* __restrict__ in, int ldc_in, int C, const float* __restrict__ d, int ldc_d,
                                                     int N, float* __restrict__ part, int S, int W, int fw, int TW, int R, int fpg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -161,16 +161,24 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(const float* __restrict__ in
   const int MP = (S * TW + 15) / 16 * 16;                 // positions padded to whole 16-blocks
   float* img = smem;                                      // [S + 1][rowlen], row S = zeros
   float* ds = smem + (size_t)(S + 1) * rowlen;            // [MP][33] gradient strip (33: consecutive positions on different banks)
+  int* tab = reinterpret_cast<int*>(ds + (size_t)MP * 33); // [MP] LDS offset of position m's patch window for THIS filter row dh
   const int dh = blockIdx.x, grp = blockIdx.y, strip = blockIdx.z;
   const int w0 = strip * TW, tw = min(TW, W - w0);
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  f32x4 acc[KT][2];
+  f32x4 acc[KT][NT];
 #pragma unroll
   for (int i = 0; i < KT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int M = S * TW;
+  for (int m = tid; m < MP; m += 512) {                    // the window of position m (zero row when the patch row is padding)
+    const int h = m / TW, wl = m - h * TW, hh = h + dh - pt;
+    tab[m] = ((m < M && hh >= 0 && hh < S) ? hh : S) * rowlen + wl * Cp;
+  }
+  bool kt_ok[KT];
+#pragma unroll
+  for (int i = 0; i < KT; ++i) kt_ok[i] = (wv * KT + i) * 16 < KP;
   for (int f = 0; f < fpg; ++f) {
     const int r = grp * fpg + f;
     if (r >= R) break;
@@ -197,21 +205,25 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(const float* __restrict__ in
     }
     __syncthreads();
     for (int mb = 0; mb < MP / 16; ++mb) {
+      // this lane's four positions on the MFMA k axis: m = mb*16 + 4q + j
+      const int m0 = mb * 16 + 4 * q;
+      int off[4];
+      float b[4][NT], a[4][KT];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) off[j] = tab[m0 + j];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int m = mb * 16 + 4 * q + j;                 // this lane's position on the MFMA k axis
-        const int h = m / TW, wl = m - h * TW;
-        const int hh = h + dh - pt;
-        const float* arow = img + (size_t)((m < M && hh >= 0 && hh < S) ? hh : S) * rowlen + wl * Cp;
-        const float b0 = ds[(size_t)m * 33 + lr], b1 = ds[(size_t)m * 33 + 16 + lr];
 #pragma unroll
-        for (int i = 0; i < KT; ++i) {
-          const int kt = wv * KT + i;
-          const float a = (kt * 16 < KP) ? arow[kt * 16 + lr] : 0.f;
-          acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[i][0], 0, 0, 0);
-          acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[i][1], 0, 0, 0);
-        }
+        for (int n = 0; n < NT; ++n) b[j][n] = ds[(size_t)(m0 + j) * 33 + n * 16 + lr];
+#pragma unroll
+        for (int i = 0; i < KT; ++i) a[j][i] = kt_ok[i] ? img[off[j] + (wv * KT + i) * 16 + lr] : 0.f;
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < KT; ++i)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][i], b[j][n], acc[i][n], 0, 0, 0);
     }
   }
   // partial tile -> part[((grp*nstrips + strip)*S + dh)][k'][32]
@@ -223,7 +235,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(const float* __restrict__ in
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) po[(size_t)(kt * 16 + 4 * q + e) * 32 + j * 16 + lr] = acc[i][j][e];
+      for (int e = 0; e < 4; ++e) po[(size_t)(kt * 16 + 4 * q + e) * 32 + j * 16 + lr] = j < NT ? acc[i][j < NT ? j : 0][e] : 0.f;
   }
 }
 // dW[(dh*fw + dw)*C + c][co] = sum over partial tiles p of part[p][dh][dw*C' + c][co]   (fixed order)
@@ -281,33 +293,43 @@ void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const 
 
 // frames per workgroup of the weight-gradient kernel: ~256 workgroups in flight (S filter rows x groups x strips)
 static int wgrad_fpg(int R, int S, int nstrips) { return std::max(1, (R * S * nstrips + 255) / 256); }
+static int wgrad_tw(int S, int W) { return (S * W <= 8 * 4 * 16) ? W : 32; }      // narrower strips than the forward kernel: the d strip is in LDS too
 size_t conv_wgrad_ws_floats(int C, int R, int S, int W, int fw) {
-  const int TW = (S * W <= 8 * 4 * 16) ? W : 64, nstrips = (W + TW - 1) / TW;
+  const int TW = wgrad_tw(S, W), nstrips = (W + TW - 1) / TW;
   const int fpg = wgrad_fpg(R, S, nstrips), groups = (R + fpg - 1) / fpg;
   return (size_t)groups * nstrips * S * conv_kp(fw, C) * 32;
 }
 bool conv_wgrad_supported(int C, int N, int S, int W, int fw) {
   if (!conv_fwd_supported(C, N, S, W, fw)) return false;
-  const int TW = (S * W <= 8 * 4 * 16) ? W : 64;
+  const int TW = wgrad_tw(S, W);
   const int MP = (S * TW + 15) / 16 * 16;
-  const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 33) * sizeof(float);
-  return lds <= 160 * 1024 && conv_kp(fw, C) <= 8 * 2 * 16;
+  const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 34) * sizeof(float);
+  return lds <= 160 * 1024 && conv_kp(fw, C) <= 8 * 3 * 16;
 }
 void launch_conv_wgrad(const float* in, int ldc_in, int C, const float* d, int ldc_d, int N, float* dW, int ldw, float* ws, int R, int S,
                        int W, int fw, hipStream_t s) {
-  const int TW = (S * W <= 8 * 4 * 16) ? W : 64, nstrips = (W + TW - 1) / TW;
+  const int TW = wgrad_tw(S, W), nstrips = (W + TW - 1) / TW;
   const int fpg = wgrad_fpg(R, S, nstrips), groups = (R + fpg - 1) / fpg;
   const int MP = (S * TW + 15) / 16 * 16, KP = conv_kp(fw, C);
-  const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 33) * sizeof(float);
+  const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 34) * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   dim3 grid(S, groups, nstrips);
-  if (KP <= 8 * 16) hipLaunchKernelGGL(k_conv_wgrad<1>, grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
-  else hipLaunchKernelGGL(k_conv_wgrad<2>, grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  const bool k1 = KP <= 8 * 16, k3 = KP > 8 * 2 * 16, n1 = N <= 16;
+  if (k3 && n1) hipLaunchKernelGGL((k_conv_wgrad<3, 1>), grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  else if (k3) hipLaunchKernelGGL((k_conv_wgrad<3, 2>), grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  else if (k1 && n1) hipLaunchKernelGGL((k_conv_wgrad<1, 1>), grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  else if (k1) hipLaunchKernelGGL((k_conv_wgrad<1, 2>), grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  else if (n1) hipLaunchKernelGGL((k_conv_wgrad<2, 1>), grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  else hipLaunchKernelGGL((k_conv_wgrad<2, 2>), grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
   const int total = S * fw * C * N;
   hipLaunchKernelGGL(k_conv_wgrad_red, dim3((total + 255) / 256), dim3(256), 0, s, ws, groups * nstrips, S, fw, C, N, dW, ldw);
 }
