@@ -160,8 +160,9 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(const float* __restrict__ in
   const int rowlen = (TW + fw - 1) * Cp + 16;
   const int MP = (S * TW + 15) / 16 * 16;                 // positions padded to whole 16-blocks
   float* img = smem;                                      // [S + 1][rowlen], row S = zeros
-  float* ds = smem + (size_t)(S + 1) * rowlen;            // [MP][33] gradient strip (33: consecutive positions on different banks)
-  int* tab = reinterpret_cast<int*>(ds + (size_t)MP * 33); // [MP] LDS offset of position m's patch window for THIS filter row dh
+  float* ds = smem + (size_t)(S + 1) * rowlen;            // [MP][36] gradient strip (4 positions = 144 floats apart: 16-bank steps)
+  int* tab = reinterpret_cast<int*>(ds + (size_t)MP * 36); // [MP] LDS offset of position m's patch window for THIS filter row dh
+  int* gtab = tab + MP;                                   // [MP] offset of position m in one frame of d (-1: outside the strip)
   const int dh = blockIdx.x, grp = blockIdx.y, strip = blockIdx.z;
   const int w0 = strip * TW, tw = min(TW, W - w0);
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
@@ -175,7 +176,15 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(const float* __restrict__ in
   for (int m = tid; m < MP; m += 512) {                    // the window of position m (zero row when the patch row is padding)
     const int h = m / TW, wl = m - h * TW, hh = h + dh - pt;
     tab[m] = ((m < M && hh >= 0 && hh < S) ? hh : S) * rowlen + wl * Cp;
+    gtab[m] = (m < M && wl < tw) ? (h * W + w0 + wl) * ldc_d : -1;
   }
+  // staging map of this thread, frame independent: float4 slot e of every image row (x = strip column, c = channel)
+  const int cp4 = Cp / 4, row4 = rowlen / 4;
+  const int e0 = tid < row4 ? tid : -1;
+  const int sx = e0 >= 0 ? e0 / cp4 : 0, sc = e0 >= 0 ? (e0 - sx * cp4) * 4 : 0;
+  const int swcol = w0 - pl + sx;
+  const bool s_in = e0 >= 0 && sx < TW + fw - 1 && swcol >= 0 && swcol < W && sc < C;
+  __syncthreads();                                        // tab / gtab visible
   bool kt_ok[KT];
 #pragma unroll
   for (int i = 0; i < KT; ++i) kt_ok[i] = (wv * KT + i) * 16 < KP;
@@ -184,46 +193,68 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(const float* __restrict__ in
     if (r >= R) break;
     __syncthreads();
     {
-      const int cp4 = Cp / 4, row4 = rowlen / 4, total4 = (S + 1) * row4;
-      for (int i = tid; i < total4; i += 512) {
-        const int h = i / row4, e = i - h * row4;
-        const int x = e / cp4, c = (e - x * cp4) * 4;
-        const int wcol = w0 - pl + x;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (h < S && x < TW + fw - 1 && wcol >= 0 && wcol < W && c < C)
-          v = *reinterpret_cast<const float4*>(in + ((size_t)(r * S + h) * W + wcol) * ldc_in + c);
-        *reinterpret_cast<float4*>(img + (size_t)h * rowlen + (size_t)e * 4) = v;
+      // image strip: thread e0 owns float4 slot e0 of every row (row4 <= 512 is checked on the host); rows are independent loads
+      if (e0 >= 0) {
+        const float* src = in + ((size_t)r * S * W + swcol) * ldc_in + sc;
+        for (int h = 0; h <= S; ++h) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (s_in && h < S) v = *reinterpret_cast<const float4*>(src + (size_t)h * W * ldc_in);
+          *reinterpret_cast<float4*>(img + (size_t)h * rowlen + (size_t)e0 * 4) = v;
+        }
       }
+      const float* dsrc = d + (size_t)r * S * W * ldc_d;
       for (int i = tid; i < MP * 8; i += 512) {            // 8 float4 = 32 channels per position
         const int m = i >> 3, c = (i & 7) * 4;
-        const int h = m / TW, wl = m - h * TW;
+        const int go = gtab[m];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < M && wl < tw && c < N) v = *reinterpret_cast<const float4*>(d + ((size_t)(r * S + h) * W + w0 + wl) * ldc_d + c);
-        float* o = ds + (size_t)m * 33 + c;
-        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        if (go >= 0 && c < N) v = *reinterpret_cast<const float4*>(dsrc + go + c);
+        *reinterpret_cast<float4*>(ds + (size_t)m * 36 + c) = v;
       }
     }
     __syncthreads();
-    for (int mb = 0; mb < MP / 16; ++mb) {
-      // this lane's four positions on the MFMA k axis: m = mb*16 + 4q + j
-      const int m0 = mb * 16 + 4 * q;
-      int off[4];
-      float b[4][NT], a[4][KT];
+    // software pipeline over the 16-position blocks: window offsets two blocks ahead, operands one block ahead, MFMAs now
+    // (this lane's four positions on the MFMA k axis are m = mb*16 + 4q + j)
+    const int nmb = MP / 16;
+    int off_n[4];
+    float a_c[4][KT], b_c[4][NT], a_n[4][KT], b_n[4][NT];
+    auto load_off = [&](int mb, int (&off)[4]) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) off[j] = tab[m0 + j];
+      for (int j = 0; j < 4; ++j) off[j] = tab[min(mb, nmb - 1) * 16 + 4 * q + j];
+    };
+    auto load_ops = [&](int mb, const int (&off)[4], float (&a)[4][KT], float (&b)[4][NT]) {
+      const int m0 = min(mb, nmb - 1) * 16 + 4 * q;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) b[j][n] = ds[(size_t)(m0 + j) * 33 + n * 16 + lr];
+        for (int n = 0; n < NT; ++n) b[j][n] = ds[(size_t)(m0 + j) * 36 + n * 16 + lr];
 #pragma unroll
         for (int i = 0; i < KT; ++i) a[j][i] = kt_ok[i] ? img[off[j] + (wv * KT + i) * 16 + lr] : 0.f;
       }
+    };
+    auto mma = [&](const float (&a)[4][KT], const float (&b)[4][NT]) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < KT; ++i)
 #pragma unroll
           for (int n = 0; n < NT; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][i], b[j][n], acc[i][n], 0, 0, 0);
+    };
+    {
+      int off0[4];
+      load_off(0, off0);
+      load_ops(0, off0, a_c, b_c);
+      load_off(1, off_n);
+    }
+    for (int mb = 0; mb < nmb; mb += 2) {
+      int off_nn[4];
+      load_ops(mb + 1, off_n, a_n, b_n);
+      load_off(mb + 2, off_nn);
+      mma(a_c, b_c);
+      if (mb + 1 < nmb) {
+        load_ops(mb + 2, off_nn, a_c, b_c);
+        load_off(mb + 3, off_n);
+        mma(a_n, b_n);
+      }
     }
   }
   // partial tile -> part[((grp*nstrips + strip)*S + dh)][k'][32]
@@ -291,8 +322,11 @@ void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const 
   else hipLaunchKernelGGL((k_conv_fwd<6, 2>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW);
 }
 
-// frames per workgroup of the weight-gradient kernel: ~256 workgroups in flight (S filter rows x groups x strips)
-static int wgrad_fpg(int R, int S, int nstrips) { return std::max(1, (R * S * nstrips + 255) / 256); }
+// frames per workgroup of the weight-gradient kernel (S filter rows x groups x strips workgroups)
+static int wgrad_fpg(int R, int S, int nstrips) {           // at most 256 workgroups: one round on the 256 CUs
+  const int groups_max = std::max(1, 256 / (S * nstrips));
+  return std::max(1, (R + groups_max - 1) / groups_max);
+}
 static int wgrad_tw(int S, int W) { return (S * W <= 8 * 4 * 16) ? W : 32; }      // narrower strips than the forward kernel: the d strip is in LDS too
 size_t conv_wgrad_ws_floats(int C, int R, int S, int W, int fw) {
   const int TW = wgrad_tw(S, W), nstrips = (W + TW - 1) / TW;
@@ -303,15 +337,15 @@ bool conv_wgrad_supported(int C, int N, int S, int W, int fw) {
   if (!conv_fwd_supported(C, N, S, W, fw)) return false;
   const int TW = wgrad_tw(S, W);
   const int MP = (S * TW + 15) / 16 * 16;
-  const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 34) * sizeof(float);
-  return lds <= 160 * 1024 && conv_kp(fw, C) <= 8 * 3 * 16;
+  const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 38) * sizeof(float);
+  return lds <= 160 * 1024 && conv_kp(fw, C) <= 8 * 3 * 16 && ((TW + fw - 1) * conv_cpad(C) + 16) / 4 <= 512;
 }
 void launch_conv_wgrad(const float* in, int ldc_in, int C, const float* d, int ldc_d, int N, float* dW, int ldw, float* ws, int R, int S,
                        int W, int fw, hipStream_t s) {
   const int TW = wgrad_tw(S, W), nstrips = (W + TW - 1) / TW;
   const int fpg = wgrad_fpg(R, S, nstrips), groups = (R + fpg - 1) / fpg;
   const int MP = (S * TW + 15) / 16 * 16, KP = conv_kp(fw, C);
-  const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 34) * sizeof(float);
+  const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 38) * sizeof(float);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
