@@ -194,11 +194,19 @@ def bench_rced(a, rank, local, world, dev):
     +-5 (fed 440) -> 9 x conv2d -> FC -> 40, batch --batch frames per GPU, one Adam step per batch."""
     from types import SimpleNamespace
     from rsrgan_amd import dist as rdist
+    from rsrgan_amd import GAN
     from rsrgan_amd.trainer import DNNTrainer
     N, W, S = a.batch, a.rced_width, 11
     args = SimpleNamespace(batch_size=N, input_dim=W, output_dim=40, left_context=5, right_context=5, g_type="rced", keep_prob=1.0,
-                           batch_norm=False, num_gpu=world, save_dir=None, l2_scale=0.0, g_learning_rate=1e-3 * world)
-    model = DNNTrainer(None, args, ["gpu:%d" % local], seed=4321)
+                           batch_norm=False, num_gpu=world, save_dir=None, l2_scale=0.0, g_learning_rate=1e-3 * world,
+                           d_learning_rate=1e-4 * world, init_mse_weight=10.0, disc_updates=1, gen_updates=1)
+    if a.rced_gan:          # BASELINE.json configs[3]: R-CED generator + discriminator_dnn (the reference's gan.py only accepts 'dnn')
+        class RcedGan(GAN):
+            G_TYPES = ("dnn", "rced")
+        model = RcedGan(None, args, ["gpu:%d" % local], seed=4321)
+        model.step = lambda x_, l_, sync=False: (model.d_step(x_, l_, sync=False), model.g_step(x_, l_, reuse_g_forward=True, sync=False))[1]
+    else:
+        model = DNNTrainer(None, args, ["gpu:%d" % local], seed=4321)
     rng = np.random.default_rng(1234 + rank)
     x = torch.from_numpy(rng.standard_normal((N, 1, S * W)).astype(np.float32)).to(dev)
     lab = torch.from_numpy(rng.standard_normal((N, 1, 40)).astype(np.float32)).to(dev)
@@ -223,11 +231,15 @@ def bench_rced(a, rank, local, world, dev):
             cin = co
         fl += 2 * S * W * cin * 40
         fpf = 3 * fl                                      # forward + data gradient + weight gradient
+        if a.rced_gan:
+            fpf += 8 * 2 * ((W + 40) * 1024 + 3 * 1024 * 1024 + 1024)      # discriminator_dnn terms as in SURVEY 8d
         ach = fpf * N / (dev_ms * 1e-3 / a.steps) / 1e12
-        out = {"metric": "supervised train frames/sec, R-CED generator (SURVEY 8f-2)", "value": round(N * world * a.steps / dt, 1),
+        out = {"metric": ("GAN train frames/sec (G+D step), R-CED generator + discriminator_dnn (BASELINE configs[3])" if a.rced_gan
+                          else "supervised train frames/sec, R-CED generator (SURVEY 8f-2)"), "value": round(N * world * a.steps / dt, 1),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt * 1e3 / a.steps, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "models/rced.py under DNNTrainer (batch_norm=False), frame width %d x splice 11, N=%d frames/GPU" % (W, N),
+               "config": {"workload": ("models/rced.py + discriminator_dnn, 1D+1G step" if a.rced_gan else "models/rced.py under DNNTrainer") +
+                                      " (batch_norm=False), frame width %d x splice 11, N=%d frames/GPU" % (W, N),
                           "global_batch": N * world, "parallelism": "dp%d" % world,
                           "losses_last_step": [round(float(v), 6) for v in last.mean(0).cpu().numpy()]},
                "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -254,6 +266,7 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the BASELINE.json-named network variant at N=1")
     ap.add_argument("--flags", type=int, default=int(os.environ.get("RSRGAN_FLAGS", "1")),
                     help="library schedule flags: 1 = wavefront, 4 = side-stream GEMM overlap (include/rsrgan.h)")
+    ap.add_argument("--rced-gan", action="store_true", help="--net rced: 1 D + 1 G step with discriminator_dnn instead of the supervised trainer")
     ap.add_argument("--rced-width", type=int, default=40, help="--net rced: frame width (run_dnn.sh:137 uses 40-dim MFCC input)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling (SURVEY 8d): --batch is the GLOBAL batch, split evenly over the ranks (default: weak, "

@@ -252,10 +252,17 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
       for (auto& L : gconv) { rc_cols.push_back(alloc<float>(M * L.ldK)); if (!rc_cols.back()) rc_keep_cols = false; }
       if (!rc_keep_cols) rc_cols.clear();
     }
-    rc_col = rc_keep_cols ? rc_cols[0] : alloc<float>(M * maxK);
-    rc_dcol = alloc<float>(M * maxK);
+    // shared patch-matrix buffers only as wide as the layers that still take the patch-matrix path need them
+    int colK = 4, dcolK = 4;
+    for (size_t l = 0; l < gconv.size(); ++l) {
+      if (!rc_ft_fwd[l] || !rc_wgrad_implicit[l]) colK = std::max(colK, gconv[l].ldK);
+      if (l > 0 && !rc_ft_bwd[l]) dcolK = std::max(dcolK, gconv[l].ldK);
+    }
+    (void)maxK;
+    rc_col = rc_keep_cols ? rc_cols[0] : alloc<float>(M * colK);
+    rc_dcol = alloc<float>(M * dcolK);
     rc_dA = alloc<float>(M * maxC); rc_dB = alloc<float>(M * maxC);
-    if (!rc_col || !rc_dcol || !rc_dA || !rc_dB) { set_error("hipMalloc failed (R-CED patch matrices: %zu floats)", M * maxK); return RSRGAN_ERR_HIP; }
+    if (!rc_col || !rc_dcol || !rc_dA || !rc_dB) { set_error("hipMalloc failed (R-CED buffers: %zu positions)", M); return RSRGAN_ERR_HIP; }
   } else if (g_dnn()) {
     g_act.push_back(x_tm);
     for (size_t l = 0; l + 1 < gfc.size(); ++l) g_act.push_back(alloc<float>(TB * gfc[l].ld_out));
