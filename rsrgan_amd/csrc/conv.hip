@@ -291,21 +291,36 @@ void launch_conv_prep(const float* F, int ldf_src, int S, int fw, int Cin, int C
   hipLaunchKernelGGL(k_conv_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, F, ldf_src, S, fw, Cin, Cout, flip ? 1 : 0, Ft);
 }
 
+// Strip width TW and row tiles per wave RT (4 or 6: 512 / 768 positions per workgroup) of the forward kernel: even strips
+// (W / nstrips, not a fixed 64: a 257-wide frame is 4 x 65, not 5 x 64), the fewest strips whose workgroup fits the LDS.
+static bool conv_fwd_plan(int C, int S, int W, int fw, int& TW, int& RT, size_t& lds) {
+  double best = 0.0;
+  for (int rt : {4, 6}) {
+    const int twmax = 8 * rt * 16 / S;
+    if (twmax < 1) continue;
+    for (int ns = (W + twmax - 1) / twmax; ns <= W; ++ns) {
+      const int tw = (W + ns - 1) / ns;
+      const size_t l = ((size_t)(S + 1) * ((tw + fw - 1) * conv_cpad(C) + 16) + (size_t)32 * conv_ldf(fw, C)) * sizeof(float);
+      if (l > 160 * 1024) continue;
+      const double eff = (double)W * S / ((double)ns * 8 * rt * 16);       // useful share of the MFMA row slots
+      if (eff > best + 1e-9) { best = eff; TW = tw; RT = rt; lds = l; }
+      break;
+    }
+  }
+  return best > 0.0;
+}
 // true if the implicit kernel covers this shape (else the caller uses the patch-matrix path)
 bool conv_fwd_supported(int C, int N, int S, int W, int fw) {
   if (C % 4 || C < 4 || N > 32 || !(S & 1) || !(fw & 1)) return false;
-  const int TW = (S * W <= 8 * 4 * 16) ? W : 64;
-  const int RT = (S * W <= 8 * 4 * 16) ? 4 : 6;
-  if (S * TW > 8 * RT * 16) return false;
-  const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)32 * conv_ldf(fw, C)) * sizeof(float);
-  return lds <= 160 * 1024;
+  int TW, RT; size_t lds;
+  return conv_fwd_plan(C, S, W, fw, TW, RT, lds);
 }
 
 void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const float* bias, bool relu, float* out, int ldc_out, int N,
                      int R, int S, int W, int fw, hipStream_t s) {
-  const bool small = S * W <= 8 * 4 * 16;
-  const int TW = small ? W : 64;
-  const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)32 * conv_ldf(fw, C)) * sizeof(float);
+  int TW = W, RT = 4; size_t lds = 0;
+  if (!conv_fwd_plan(C, S, W, fw, TW, RT, lds)) return;
+  const bool small = RT == 4;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -327,7 +342,11 @@ static int wgrad_fpg(int R, int S, int nstrips) {           // at most 256 workg
   const int groups_max = std::max(1, 256 / (S * nstrips));
   return std::max(1, (R + groups_max - 1) / groups_max);
 }
-static int wgrad_tw(int S, int W) { return (S * W <= 8 * 4 * 16) ? W : 32; }      // narrower strips than the forward kernel: the d strip is in LDS too
+static int wgrad_tw(int S, int W) {          // narrower strips than the forward kernel (the d strip is in LDS too), evenly split
+  if (S * W <= 8 * 4 * 16) return W;
+  const int ns = (W + 31) / 32;
+  return (W + ns - 1) / ns;
+}
 size_t conv_wgrad_ws_floats(int C, int R, int S, int W, int fw) {
   const int TW = wgrad_tw(S, W), nstrips = (W + TW - 1) / TW;
   const int fpg = wgrad_fpg(R, S, nstrips), groups = (R + fpg - 1) / fpg;
