@@ -148,12 +148,19 @@ def bench_dnn_gan(a, rank, local, world, dev):
     args = SimpleNamespace(batch_size=N, input_dim=257, output_dim=40, left_context=5, right_context=5, g_type="dnn",
                            keep_prob=1.0, batch_norm=False, num_gpu=world, save_dir=None, l2_scale=0.0, disc_updates=1,
                            gen_updates=1, init_mse_weight=10.0, d_learning_rate=1e-4 * world, g_learning_rate=1e-4 * world)
-    model = GAN(None, args, ["gpu:%d" % local], seed=4321)
+    trainer = a.net == "dnn_trainer"          # BASELINE.json configs[0]: the DNN generator alone under DNNTrainer (supervised)
+    if trainer:
+        from rsrgan_amd.trainer import DNNTrainer
+        model = DNNTrainer(None, args, ["gpu:%d" % local], seed=4321)
+    else:
+        model = GAN(None, args, ["gpu:%d" % local], seed=4321)
     rng = np.random.default_rng(1234 + rank)
     x = torch.from_numpy(rng.standard_normal((N, 1, 2827)).astype(np.float32)).to(dev)
     lab = torch.from_numpy(rng.standard_normal((N, 1, 40)).astype(np.float32)).to(dev)
 
     def step():
+        if trainer:
+            return model.step(x, lab, sync=False)
         model.d_step(x, lab, sync=False)
         return model.g_step(x, lab, reuse_g_forward=True, sync=False)
     for _ in range(a.warmup):
@@ -173,13 +180,15 @@ def bench_dnn_gan(a, rank, local, world, dev):
     if rank == 0:
         fg = 2 * (2827 * 1024 + 3 * 1024 * 1024 + 1024 * 40)
         fd = 2 * (297 * 1024 + 3 * 1024 * 1024 + 1024)
-        fpf = 3 * fg + 8 * fd          # G fwd + 2x bwd (weights only: no input gradient... counted as 2x), D as SURVEY 8d
+        fpf = 3 * fg + (0 if trainer else 8 * fd)          # G fwd + 2x bwd (weights only: no input gradient... counted as 2x), D as SURVEY 8d
         ach = fpf * N / (dev_ms * 1e-3 / a.steps) / 1e12
-        out = {"metric": "GAN train frames/sec (G+D step), frame-level DNN-GAN 2827->40 (SURVEY 8f-1)",
+        out = {"metric": ("supervised train frames/sec, DNN generator 2827->40 under DNNTrainer (BASELINE configs[0])" if trainer else
+                          "GAN train frames/sec (G+D step), frame-level DNN-GAN 2827->40 (SURVEY 8f-1)"),
                "value": round(N * world * a.steps / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt * 1e3 / a.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "models/gan.py 1D+1G step, G=dnn(2827-4x1024-40)+D=discriminator_dnn(297-4x1024-1), "
+               "config": {"workload": ("models/dnn_trainer.py step, G=dnn(2827-4x1024-40), " if trainer else
+                                       "models/gan.py 1D+1G step, G=dnn(2827-4x1024-40)+D=discriminator_dnn(297-4x1024-1), ") +
                                       "N=%d frames/GPU" % N, "global_batch": N * world, "parallelism": "dp%d" % world,
                           "losses_last_step": [round(float(v), 6) for v in last.mean(0).cpu().numpy()]},
                "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -256,7 +265,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--frames", type=int, default=100)
-    ap.add_argument("--net", default="lstm", choices=["lstm", "res_lstm_l", "dnn_gan", "baseline_named", "rced"],
+    ap.add_argument("--net", default="lstm", choices=["lstm", "res_lstm_l", "dnn_gan", "dnn_trainer", "baseline_named", "rced"],
                     help="dnn_gan = the frame-level GAN of models/gan.py (SURVEY 8f-1): --batch frames per step, T ignored; "
                          "baseline_named = BASELINE.json's wording: 2-layer 512-unit LSTM (no projection, SURVEY 8d-iii) + DNN D")
     ap.add_argument("--d-type", default="lstm", choices=["lstm", "dnn"],
@@ -286,7 +295,7 @@ def main():
         a.batch //= world
 
     from types import SimpleNamespace
-    if a.net == "dnn_gan":
+    if a.net in ("dnn_gan", "dnn_trainer"):
         return bench_dnn_gan(a, rank, local, world, dev)
     if a.net == "rced":
         return bench_rced(a, rank, local, world, dev)
