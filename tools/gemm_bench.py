@@ -1,5 +1,6 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys, time
-sys.path.insert(0, ".")
 import torch
 from rsrgan_amd.engine_hip import HipEngine
 eng = HipEngine(batch_size=2, max_frames=4, input_dim=9, output_dim=5, g_layers=1, g_cells=8, g_proj=8, d_layers=1, d_cells=8, d_proj=4)

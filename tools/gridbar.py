@@ -1,4 +1,6 @@
 """Grid-barrier micro-benchmark driver (rsrgan_microbench kind 4)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
 import torch
 from rsrgan_amd import _lib

@@ -1,5 +1,7 @@
 """k_fwd_gates launch time of the merged forward wave vs number of generator layers (is a launch as long as its
 busiest CU? 48 column blocks x 2 row blocks per 760-cell layer: 1 layer = 96 WGs, 2 = 192, 3 = 288, 4 = 384)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys
 from types import SimpleNamespace
 import numpy as np

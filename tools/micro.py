@@ -1,5 +1,6 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C, sys
-sys.path.insert(0, ".")
 from rsrgan_amd import _lib
 lib = _lib.load()
 names = {0: "production (pipelined, 8 waves)", 1: "no A loads", 2: "no B loads", 3: "no loads at all", 4: "no MFMA (loads only)",

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> "<counters>" <bench args...>  : one rocprofv3 --pmc pass (no other tracing domains)
+# usage: tools/pmc.sh <tag> "<counters>" <bench args...>  : one rocprofv3 --pmc pass (no other tracing domains)
 tag=$1; shift; ctrs=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 mkdir -p $out

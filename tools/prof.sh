@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof.sh <tag> <bench args...> : rocprofv3 kernel trace -> gpurun_out/prof_<tag>/ (csv stats only)
+# usage: tools/prof.sh <tag> <bench args...> : rocprofv3 kernel trace -> gpurun_out/prof_<tag>/ (csv stats only)
 tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 mkdir -p $out

@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic of one bench step from PMC counters, separate passes (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE in KB,
-# FETCH_SIZE under-counts wide streaming reads by 2x on gfx950).  usage: tools_traffic.sh <tag> <bench args...>
+# FETCH_SIZE under-counts wide streaming reads by 2x on gfx950).  usage: tools/traffic.sh <tag> <bench args...>
 tag=$1; shift
 for c in FETCH_SIZE WRITE_SIZE; do
   out=$GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$c
