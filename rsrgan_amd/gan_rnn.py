@@ -31,6 +31,14 @@ class Model(object):
     def __init__(self, name="BaseModel"):
         self.name = name
 
+    def _average_gradients(self, net):
+        """average_gradients over towers (utils/ops.py:343-376) = all-reduce(mean) over ranks; the HIP engine does it bucket
+        by bucket overlapped with the rest of the backward, any other engine (tests) as one all-reduce of the buffer."""
+        if hasattr(self.engine, "all_reduce_grads"):
+            self.engine.all_reduce_grads(net, self.process_group)
+        else:
+            rdist.all_reduce_mean_(self.engine.grad_view(net), self.process_group)
+
     def save(self, save_dir, step):
         if not os.path.exists(save_dir):
             os.makedirs(save_dir)
@@ -116,18 +124,6 @@ class Model(object):
                 self.engine.set_scalar("adam_step_d", float(data["__adam_step_d__"]))
         print("[*] Read {}".format(ckpt_name))
         return True
-
-
-def _average_gradients(self, net):
-    """average_gradients over towers (utils/ops.py:343-376) = all-reduce(mean) over ranks; the HIP engine does it bucket
-    by bucket overlapped with the rest of the backward, any other engine (tests) as one all-reduce of the buffer."""
-    if hasattr(self.engine, "all_reduce_grads"):
-        self.engine.all_reduce_grads(net, self.process_group)
-    else:
-        rdist.all_reduce_mean_(self.engine.grad_view(net), self.process_group)
-
-
-Model._average_gradients = _average_gradients
 
 
 class GAN_RNN(Model):
