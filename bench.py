@@ -107,10 +107,11 @@ def measure_sequence(a, net, d_type, B, T, steps, warmup, rank, local, world, de
     x = torch.from_numpy(x).to(dev); lab = torch.from_numpy(lab).to(dev); ln = torch.from_numpy(ln).to(dev)
 
     def step():
-        model.d_step(x, lab, ln, sync=False)
+        # gather=False: like train_one_iteration, the tower mean of the loss scalars is taken once per iteration, not per step
+        model.d_step(x, lab, ln, sync=False, gather=False)
         out = None
         for i in range(a.gen_updates):
-            out = model.g_step(x, lab, ln, reuse_g_forward=(i == 0), sync=False)
+            out = model.g_step(x, lab, ln, reuse_g_forward=(i == 0), sync=False, gather=False)
         return out
 
     for _ in range(warmup):

@@ -226,12 +226,15 @@ class GAN_RNN(Model):
             raise ValueError("batch has %d rows, expected %d or %d" % (n, self.batch_size, self.batch_size * ws))
         return a[self.batch_size * r:self.batch_size * (r + 1)]
 
-    def _towers(self, losses: torch.Tensor) -> torch.Tensor:
-        """[k] device tensor -> [world, k]: the per-tower loss lists of :262-268."""
+    def _towers(self, losses: torch.Tensor, gather: bool = True) -> torch.Tensor:
+        """[k] device tensor -> [world, k]: the per-tower loss lists of :262-268.  gather=False keeps this rank's row only
+        ([1, k], no collective): train_one_iteration averages over towers once per iteration instead of once per step."""
+        if not gather:
+            return losses.unsqueeze(0)
         return rdist.all_gather_rows(losses, self.process_group)
 
     # -- the two sess.run calls ------------------------------------------------------------
-    def d_step(self, inputs, labels, lengths, noise_real=None, noise_fake=None, train=True, sync=True):
+    def d_step(self, inputs, labels, lengths, noise_real=None, noise_fake=None, train=True, sync=True, gather=True):
         """sess.run([model.d_opt, model.d_rl_losses, model.d_fk_losses, model.d_losses], feed)
         (train_gan_rnn_placeholder.py:77-82).  Returns three per-tower lists (or, with
         sync=False, a [towers,3] device tensor)."""
@@ -246,13 +249,13 @@ class GAN_RNN(Model):
             self.engine.apply(NET_D)
         else:
             losses = self.engine.d_backward(x, lab, ln, nr, nf, train=train, apply=train)
-        tw = self._towers(losses)
+        tw = self._towers(losses, gather or sync)
         if not sync:
             return tw
         tw = tw.cpu().numpy()
         return list(tw[:, 0]), list(tw[:, 1]), list(tw[:, 2])
 
-    def g_step(self, inputs, labels, lengths, noise_fake=None, train=True, reuse_g_forward=False, sync=True):
+    def g_step(self, inputs, labels, lengths, noise_fake=None, train=True, reuse_g_forward=False, sync=True, gather=True):
         """sess.run([model.g_opt, model.g_adv_losses, model.g_mse_losses, model.g_l2_losses,
         model.g_losses], feed) (train_gan_rnn_placeholder.py:94-101)."""
         x, lab, ln = self._shard(inputs), self._shard(labels), self._shard(lengths)
@@ -265,7 +268,7 @@ class GAN_RNN(Model):
             self.engine.apply(NET_G)
         else:
             losses = self.engine.g_backward(x, lab, ln, nf, train=train, reuse=reuse_g_forward, apply=train)
-        tw = self._towers(losses)
+        tw = self._towers(losses, gather or sync)
         if not sync:
             return tw
         tw = tw.cpu().numpy()

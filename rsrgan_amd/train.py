@@ -6,6 +6,8 @@ import math
 import numpy as np
 import torch
 
+from . import dist as rdist
+
 
 def exponential_decay(iteration, num_jobs, num_ietrs, init_learning_rate, multiply_jobs=True):
     """utils/ops.py:378-391 (argument names as in the reference)."""
@@ -61,16 +63,21 @@ def train_one_iteration(sess, model, tr_num_batch, iteration, train_queue, num_g
             lab = torch.from_numpy(np.ascontiguousarray(lab, np.float32)).to(dev)
             ln = torch.from_numpy(np.ascontiguousarray(ln)).to(dev).to(torch.int32)
         for d_step in range(model.disc_updates):
-            tw = model.d_step(x, lab, ln, sync=False)             # [towers, 3]
+            tw = model.d_step(x, lab, ln, sync=False, gather=False)   # this tower's [1, 3]; towers are averaged once, below
             m = tw.mean(0)                                        # np.mean over towers (:85-87)
             d_acc = m if d_acc is None else d_acc + m
             d_counter += 1
         for g_step in range(model.gen_updates):
             reuse = share_g_forward and g_step == 0 and model.disc_updates > 0
-            tw = model.g_step(x, lab, ln, reuse_g_forward=reuse, sync=False)
+            tw = model.g_step(x, lab, ln, reuse_g_forward=reuse, sync=False, gather=False)
             m = tw.mean(0)
             g_acc = m if g_acc is None else g_acc + m
             g_counter += 1
+    # np.mean over towers (:85-87,104-107) commutes with the mean over steps: one all-reduce of the 7 sums per iteration
+    if d_acc is not None:
+        d_acc = rdist.all_reduce_mean_(d_acc.clone(), getattr(model, "process_group", None))
+    if g_acc is not None:
+        g_acc = rdist.all_reduce_mean_(g_acc.clone(), getattr(model, "process_group", None))
     d = (d_acc / max(d_counter, 1)).cpu().numpy() if d_acc is not None else np.zeros(3)
     g = (g_acc / max(g_counter, 1)).cpu().numpy() if g_acc is not None else np.zeros(4)
     return float(d[0]), float(d[1]), float(d[2]), float(g[0]), float(g[1]), float(g[2]), float(g[3])
