@@ -14,7 +14,7 @@ namespace rsr {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__host__ __device__ inline int conv_cpad(int C) { return ((C / 4) & 1) ? C : C + 4; }          // C % 4 == 0 -> C'/4 odd
+__host__ __device__ inline int conv_cpad(int C) { const int c4 = (C + 3) & ~3; return ((c4 / 4) & 1) ? c4 : c4 + 4; }   // C'/4 odd (C = 1: one real channel + 3 zero ones)
 __host__ __device__ inline int conv_kp(int fw, int C) { return (fw * conv_cpad(C) + 15) / 16 * 16; }   // k' extent, whole k-blocks
 __host__ __device__ inline int conv_ldf(int fw, int C) { const int k = conv_kp(fw, C) + 4; return ((k / 4) & 1) ? k : k + 4; }
 
@@ -311,7 +311,7 @@ static bool conv_fwd_plan(int C, int S, int W, int fw, int& TW, int& RT, size_t&
 }
 // true if the implicit kernel covers this shape (else the caller uses the patch-matrix path)
 bool conv_fwd_supported(int C, int N, int S, int W, int fw) {
-  if (C % 4 || C < 4 || N > 32 || !(S & 1) || !(fw & 1)) return false;
+  if ((C % 4 && C != 1) || N > 32 || !(S & 1) || !(fw & 1)) return false;      // C == 1: the caller pads the input to [positions][4]
   int TW, RT; size_t lds;
   return conv_fwd_plan(C, S, W, fw, TW, RT, lds);
 }

@@ -57,7 +57,10 @@ void Model::rced_forward(int rows, hipStream_t s) {
   for (size_t l = 0; l < gconv.size(); ++l) {
     const ConvLayer& L = gconv[l];
     if (rc_ft_fwd[l]) {                          // implicit GEMM: no patch matrix
-      launch_conv_fwd(rc_act[l], L.ldCin, L.Cin, rc_ft_fwd[l], G.W(L.tb), true, rc_act[l + 1], L.ldCout, L.Cout, rows, rcS, rcW, L.fw, s);
+      const float* src = rc_act[l];
+      int ldc = L.ldCin;
+      if (l == 0) { launch_expand_c4(x_tm, ldDin, rcS * rcW, rc_x4, (size_t)rows, s); src = rc_x4; ldc = 4; }
+      launch_conv_fwd(src, ldc, L.Cin, rc_ft_fwd[l], G.W(L.tb), true, rc_act[l + 1], L.ldCout, L.Cout, rows, rcS, rcW, L.fw, s);
       continue;
     }
     float* col = rc_keep_cols ? rc_cols[l] : rc_col;
@@ -80,7 +83,8 @@ void Model::rced_backward(int rows, float* dy, hipStream_t s) {
     const ConvLayer& L = gconv[l];
     launch_lrelu_bwd(rc_act[l + 1], d, M, L.Cout, L.ldCout, 0.f, s);                      // relu': d *= [a > 0]
     if (rc_wgrad_implicit[l] && rc_wg_ws) {
-      launch_conv_wgrad(rc_act[l], L.ldCin, L.Cin, d, L.ldCout, L.Cout, G.Gd(L.tW), L.ldCout, rc_wg_ws, rows, rcS, rcW, L.fw, s);
+      launch_conv_wgrad(l == 0 ? rc_x4 : rc_act[l], l == 0 ? 4 : L.ldCin, L.Cin, d, L.ldCout, L.Cout, G.Gd(L.tW), L.ldCout, rc_wg_ws, rows,
+                        rcS, rcW, L.fw, s);
     } else {
       float* col = rc_keep_cols ? rc_cols[l] : rc_col;          // kept from the forward pass of the same batch, or rebuilt
       if (!rc_keep_cols)

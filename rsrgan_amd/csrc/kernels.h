@@ -142,6 +142,7 @@ void launch_conv_wgrad(const float* in, int ldc_in, int C, const float* d, int l
 // R-CED patch matrix (conv2d SAME as GEMM) and its adjoint; col2im needs C % 4 == 0
 void launch_im2col(const float* src, size_t row_stride, int ldc, int C, int S, int W, int kh, int kw, float* col, int ldk, size_t M,
                    hipStream_t s);
+void launch_expand_c4(const float* src, int ld_src, int n, float* dst, size_t rows, hipStream_t s);
 void launch_col2im(const float* dcol, int ldk, int C, int S, int W, int kh, int kw, float* dst, int ldc, size_t M, hipStream_t s);
 struct ZeroList { int n; float* p[32]; unsigned len[32]; };        // many small buffers zeroed by ONE launch
 void launch_zero_many(const ZeroList& zl, hipStream_t s);

@@ -970,6 +970,18 @@ __global__ __launch_bounds__(256) void k_col2im(const float* __restrict__ dcol, 
     *reinterpret_cast<float4*>(dst + p * ldc + c) = acc;
   }
 }
+// [R][ld_src] rows of n scalars -> [R*n][4] positions x (value, 0, 0, 0): the single-channel input of R-CED's first conv2d as NHWC with C' = 4
+__global__ void k_expand_c4(const float* __restrict__ src, int ld_src, int n, float4* __restrict__ dst, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / n;
+    dst[i] = make_float4(src[r * ld_src + (i - r * n)], 0.f, 0.f, 0.f);
+  }
+}
+void launch_expand_c4(const float* src, int ld_src, int n, float* dst, size_t rows, hipStream_t s) {
+  const size_t total = rows * (size_t)n;
+  hipLaunchKernelGGL(k_expand_c4, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, s, src, ld_src, n,
+                     reinterpret_cast<float4*>(dst), total);
+}
 void launch_col2im(const float* dcol, int ldk, int C, int S, int W, int kh, int kw, float* dst, int ldc, size_t M, hipStream_t s) {
   const size_t total = M * (size_t)(ldc / 4);
   hipLaunchKernelGGL(k_col2im, dim3((unsigned)std::min<size_t>((total + 255) / 256, 1u << 20)), dim3(256), 0, s, dcol, ldk, C, S, W, kh, kw,

