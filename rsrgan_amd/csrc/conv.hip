@@ -7,6 +7,7 @@
 // float4 (v_mfma_f32_16x16x4_f32, four MFMAs per float4 pair) exactly as in the recurrence kernels.
 // The same kernel computes the data gradient: d(in) = conv_SAME(d(out), flipped filter with in/out channels swapped).
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -151,8 +152,8 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
 // filter row dh for a group of frames (and one column strip): per frame it stages the image strip and the d strip in LDS and
 // accumulates its [K' x 32] tile in registers (wave w: k'-tiles w*KT.., both output-channel halves; the MFMA k axis runs over
 // positions).  Partials [group][strip][dh][K'][32] are summed in a fixed order by k_conv_wgrad_red, which also undoes the k' padding.
-template <int KT, int NT>
-__global__ __launch_bounds__(512) void k_conv_wgrad(const float* __restrict__ in, int ldc_in, int C, const float* __restrict__ d, int ldc_d,
+template <int KT, int NT, int NWV = 8>
+__global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict__ in, int ldc_in, int C, const float* __restrict__ d, int ldc_d,
                                                     int N, float* __restrict__ part, int S, int W, int fw, int TW, int R, int fpg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Cp = conv_cpad(C), KP = conv_kp(fw, C);
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(const float* __restrict__ in
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int M = S * TW;
-  for (int m = tid; m < MP; m += 512) {                    // the window of position m (zero row when the patch row is padding)
+  for (int m = tid; m < MP; m += 64 * NWV) {                    // the window of position m (zero row when the patch row is padding)
     const int h = m / TW, wl = m - h * TW, hh = h + dh - pt;
     tab[m] = ((m < M && hh >= 0 && hh < S) ? hh : S) * rowlen + wl * Cp;
     gtab[m] = (m < M && wl < tw) ? (h * W + w0 + wl) * ldc_d : -1;
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(512) void k_conv_wgrad(const float* __restrict__ in
         }
       }
       const float* dsrc = d + (size_t)r * S * W * ldc_d;
-      for (int i = tid; i < MP * 8; i += 512) {            // 8 float4 = 32 channels per position
+      for (int i = tid; i < MP * 8; i += 64 * NWV) {            // 8 float4 = 32 channels per position
         const int m = i >> 3, c = (i & 7) * 4;
         const int go = gtab[m];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -376,7 +377,23 @@ void launch_conv_wgrad(const float* in, int ldc_in, int C, const float* d, int l
     attr = true;
   }
   dim3 grid(S, groups, nstrips);
+  static int wide = -1;            // RSRGAN_WGRAD_WAVES=8: always 8 waves (A/B knob); default: 16 waves when a wave would own two k'-tiles
+  if (wide < 0) { const char* e = getenv("RSRGAN_WGRAD_WAVES"); wide = (e && atoi(e) == 8) ? 0 : 1; }
   const bool k1 = KP <= 8 * 16, k3 = KP > 8 * 2 * 16, n1 = N <= 16;
+  static bool attr2 = false;
+  if (!attr2) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<1, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<1, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<2, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<2, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr2 = true;
+  }
+  if (wide && !k1) {
+    if (k3 && n1) hipLaunchKernelGGL((k_conv_wgrad<2, 1, 16>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+    else if (k3) hipLaunchKernelGGL((k_conv_wgrad<2, 2, 16>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+    else if (n1) hipLaunchKernelGGL((k_conv_wgrad<1, 1, 16>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+    else hipLaunchKernelGGL((k_conv_wgrad<1, 2, 16>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  } else
   if (k3 && n1) hipLaunchKernelGGL((k_conv_wgrad<3, 1>), grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
   else if (k3) hipLaunchKernelGGL((k_conv_wgrad<3, 2>), grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
   else if (k1 && n1) hipLaunchKernelGGL((k_conv_wgrad<1, 1>), grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
