@@ -39,7 +39,8 @@ __global__ void k_conv_prep(const float* __restrict__ F, int ldf_src, int S, int
   }
 }
 
-// grid: (strips per frame, frames).  512 threads = 8 waves; wave w owns the 16-position tiles w*RT .. w*RT+RT-1 of the strip's
+// grid: (strips per frame, frames).  512 threads = 8 waves; wave w owns the 16-position tiles w, w+8, w+16, .. (interleaved, so every
+// wave gets its share of the edge rows whose padding tiles are skipped) of the strip's
 // S*TW positions and both 16-column halves of the (<= 32) output channels.
 template <int RT, int NT>
 __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, int ldc_in, int C, const float* __restrict__ Ft,
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
   int ph[RT], pofs[RT];
 #pragma unroll
   for (int i = 0; i < RT; ++i) {
-    const int m = (wv * RT + i) * 16 + lr;
+    const int m = (i * 8 + wv) * 16 + lr;
     const int h = m / TW, wl = m - h * TW;
     const bool ok = m < M && wl < tw;
     ph[i] = ok ? h : -1000;
@@ -95,11 +96,17 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
       for (int i = tid; i < NT * 16 * ldf / 4; i += 512) dst[i] = src[i];
     }
     __syncthreads();
+    // image rows h with 0 <= h + dh - pt < S take part in this filter row: positions [vlo, vhi) of the strip; a 16-position tile
+    // outside that range only multiplies the zero row -- skipped (wave-uniform: 25 % of the MFMAs at S = 11)
+    const int vlo = max(0, pt - dh) * TW, vhi = min(S, S + pt - dh) * TW;
     const float* arow[RT];
+    bool live[RT];
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
       const int hh = ph[i] + dh - pt;
       arow[i] = img + (size_t)((hh >= 0 && hh < S) ? hh : S) * rowlen + pofs[i];
+      const int t0 = (i * 8 + wv) * 16;
+      live[i] = t0 + 15 >= vlo && t0 < vhi;
     }
     const float* b0 = fts + (size_t)lr * ldf + 4 * q;
     const float* b1 = b0 + (size_t)16 * ldf;
@@ -107,25 +114,19 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
       float4 bv[NT];
       bv[0] = *reinterpret_cast<const float4*>(b0 + kb * 16);
       if (NT == 2) bv[NT - 1] = *reinterpret_cast<const float4*>(b1 + kb * 16);
-      float4 av[RT];
 #pragma unroll
-      for (int i = 0; i < RT; ++i) av[i] = *reinterpret_cast<const float4*>(arow[i] + kb * 16);
+      for (int i = 0; i < RT; ++i) {
+        if (!live[i]) continue;
+        const float4 av = *reinterpret_cast<const float4*>(arow[i] + kb * 16);
 #pragma unroll
-      for (int i = 0; i < RT; ++i)
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[j].x, acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[j].y, acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < RT; ++i)
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[j].z, acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < RT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < RT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[j].w, acc[i][j], 0, 0, 0);
+      }
     }
   }
   // epilogue: C/D map of the 16x16 MFMA: row = 4*(lane>>4) + e, col = lane&15
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
       const float bv = bias ? bias[co] : 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int m = (wv * RT + i) * 16 + 4 * q + e;
+        const int m = (i * 8 + wv) * 16 + 4 * q + e;
         const int h = m / TW, wl = m - h * TW;
         if (m >= M || wl >= tw) continue;
         float v = acc[i][j][e] + bv;
@@ -215,7 +216,9 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict
     __syncthreads();
     // software pipeline over the 16-position blocks: window offsets two blocks ahead, operands one block ahead, MFMAs now
     // (this lane's four positions on the MFMA k axis are m = mb*16 + 4q + j)
-    const int nmb = MP / 16;
+    // positions whose patch row dh is not padding: [vlo, vhi) -> blocks [mb_lo, mb_hi); the rest would add zeros
+    const int vlo = max(0, pt - dh) * TW, vhi = min(S, S + pt - dh) * TW;
+    const int mb_lo = vlo / 16, nmb = min(MP / 16, (vhi + 15) / 16);
     int off_n[4];
     float a_c[4][KT], b_c[4][NT], a_n[4][KT], b_n[4][NT];
     auto load_off = [&](int mb, int (&off)[4]) {
@@ -242,11 +245,11 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict
     };
     {
       int off0[4];
-      load_off(0, off0);
-      load_ops(0, off0, a_c, b_c);
-      load_off(1, off_n);
+      load_off(mb_lo, off0);
+      load_ops(mb_lo, off0, a_c, b_c);
+      load_off(mb_lo + 1, off_n);
     }
-    for (int mb = 0; mb < nmb; mb += 2) {
+    for (int mb = mb_lo; mb < nmb; mb += 2) {
       int off_nn[4];
       load_ops(mb + 1, off_n, a_n, b_n);
       load_off(mb + 2, off_nn);
