@@ -149,13 +149,14 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
     }
 }
 
-// Weight gradient without a patch matrix: dF[dh][k'][co] = sum over positions of A[m][dh, k'] * d[m][co].  One workgroup owns one
-// filter row dh for a group of frames (and one column strip): per frame it stages the image strip and the d strip in LDS and
-// accumulates its [K' x 32] tile in registers (wave w: k'-tiles w*KT.., both output-channel halves; the MFMA k axis runs over
-// positions).  Partials [group][strip][dh][K'][32] are summed in a fixed order by k_conv_wgrad_red, which also undoes the k' padding.
-template <int KT, int NT, int NWV = 8>
+// Weight gradient without a patch matrix: dF[dh][k'][co] = sum over positions of A[m][dh, k'] * d[m][co].  One workgroup owns DH
+// consecutive filter rows for a group of frames (and one column strip): per frame it stages the image strip and the d strip in
+// LDS ONCE and accumulates its DH [K' x 32] tiles in registers (wave w: k'-tiles w*KT.., both output-channel halves; the MFMA k
+// axis runs over positions; per filter row only the 16-position blocks that touch non-padding rows).  Partials
+// [group][strip][dh][K'][32] are summed in a fixed order by k_conv_wgrad_red, which also undoes the k' padding.
+template <int KT, int NT, int NWV, int DH>
 __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict__ in, int ldc_in, int C, const float* __restrict__ d, int ldc_d,
-                                                    int N, float* __restrict__ part, int S, int W, int fw, int TW, int R, int fpg) {
+                                                         int N, float* __restrict__ part, int S, int W, int fw, int TW, int R, int fpg) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Cp = conv_cpad(C), KP = conv_kp(fw, C);
   const int pt = (S - 1) / 2, pl = (fw - 1) / 2;
@@ -163,21 +164,28 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict
   const int MP = (S * TW + 15) / 16 * 16;                 // positions padded to whole 16-blocks
   float* img = smem;                                      // [S + 1][rowlen], row S = zeros
   float* ds = smem + (size_t)(S + 1) * rowlen;            // [MP][36] gradient strip (4 positions = 144 floats apart: 16-bank steps)
-  int* tab = reinterpret_cast<int*>(ds + (size_t)MP * 36); // [MP] LDS offset of position m's patch window for THIS filter row dh
+  int* tab = reinterpret_cast<int*>(ds + (size_t)MP * 36); // [MP] h*rowlen + wl*C': LDS offset of position m's window in its own image row
   int* gtab = tab + MP;                                   // [MP] offset of position m in one frame of d (-1: outside the strip)
-  const int dh = blockIdx.x, grp = blockIdx.y, strip = blockIdx.z;
+  const int dh0 = blockIdx.x * DH, grp = blockIdx.y, strip = blockIdx.z;
   const int w0 = strip * TW, tw = min(TW, W - w0);
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  f32x4 acc[KT][NT];
+  f32x4 acc[DH][KT][NT];
 #pragma unroll
-  for (int i = 0; i < KT; ++i)
+  for (int dd = 0; dd < DH; ++dd)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < KT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[dd][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int M = S * TW;
-  for (int m = tid; m < MP; m += 64 * NWV) {                    // the window of position m (zero row when the patch row is padding)
-    const int h = m / TW, wl = m - h * TW, hh = h + dh - pt;
-    tab[m] = ((m < M && hh >= 0 && hh < S) ? hh : S) * rowlen + wl * Cp;
+  for (int m = tid; m < MP; m += 64 * NWV) {
+    const int h = m / TW, wl = m - h * TW;
+    if constexpr (DH == 1) {        // one filter row per workgroup: the final window offset (zero row for padding) is tabulated once
+      const int hh = h + dh0 - pt;
+      tab[m] = ((m < M && hh >= 0 && hh < S) ? hh : S) * rowlen + wl * Cp;
+    } else {
+      tab[m] = (m < M ? h : 0) * rowlen + wl * Cp;
+    }
     gtab[m] = (m < M && wl < tw) ? (h * W + w0 + wl) * ldc_d : -1;
   }
   // staging map of this thread, frame independent: float4 slot e of every image row (x = strip column, c = channel)
@@ -205,7 +213,7 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict
         }
       }
       const float* dsrc = d + (size_t)r * S * W * ldc_d;
-      for (int i = tid; i < MP * 8; i += 64 * NWV) {            // 8 float4 = 32 channels per position
+      for (int i = tid; i < MP * 8; i += 64 * NWV) {       // 8 float4 = 32 channels per position
         const int m = i >> 3, c = (i & 7) * 4;
         const int go = gtab[m];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -214,63 +222,84 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict
       }
     }
     __syncthreads();
-    // software pipeline over the 16-position blocks: window offsets two blocks ahead, operands one block ahead, MFMAs now
-    // (this lane's four positions on the MFMA k axis are m = mb*16 + 4q + j)
-    // positions whose patch row dh is not padding: [vlo, vhi) -> blocks [mb_lo, mb_hi); the rest would add zeros
-    const int vlo = max(0, pt - dh) * TW, vhi = min(S, S + pt - dh) * TW;
-    const int mb_lo = vlo / 16, nmb = min(MP / 16, (vhi + 15) / 16);
-    int off_n[4];
-    float a_c[4][KT], b_c[4][NT], a_n[4][KT], b_n[4][NT];
-    auto load_off = [&](int mb, int (&off)[4]) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) off[j] = tab[min(mb, nmb - 1) * 16 + 4 * q + j];
-    };
-    auto load_ops = [&](int mb, const int (&off)[4], float (&a)[4][KT], float (&b)[4][NT]) {
-      const int m0 = min(mb, nmb - 1) * 16 + 4 * q;
+    for (int dd = 0; dd < DH; ++dd) {
+      const int dh = dh0 + dd;
+      if (dh >= S) break;
+      // positions whose patch row dh is not padding: [vlo, vhi) -> blocks [mb_lo, nmb); the rest would add zeros
+      const int vlo = max(0, pt - dh) * TW, vhi = min(S, S + pt - dh) * TW;
+      const int mb_lo = vlo / 16, nmb = min(MP / 16, (vhi + 15) / 16);
+      // software pipeline over the 16-position blocks: window offsets two blocks ahead, operands one block ahead, MFMAs now
+      // (this lane's four positions on the MFMA k axis are m = mb*16 + 4q + j)
+      // address arithmetic is kept to a handful of 32-bit VALU ops per block (the loop is VALU-, not MFMA-bound otherwise):
+      // lane constants + block-linear terms; a position outside [vlo, vhi) reads the zero row
+      int off_n[4];
+      float a_c[4][KT], b_c[4][NT], a_n[4][KT], b_n[4][NT];
+      const int shift = (dh - pt) * rowlen, zoff = S * rowlen;
+      const int a_lane = wv * KT * 16 + lr, b_lane = 4 * q * 36 + lr, t_lane = 4 * q;
+      const float* dsl = ds + b_lane;
+      const float* imgl = img + a_lane;
+      auto load_off = [&](int mb, int (&off)[4]) {
+        const int m0 = min(mb, nmb - 1) * 16 + t_lane;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j) {
+          const int m = m0 + j;
+          if constexpr (DH == 1) off[j] = tab[m];
+          else off[j] = (m >= vlo && m < vhi) ? tab[m] + shift : zoff;
+        }
+      };
+      auto load_ops = [&](int mb, const int (&off)[4], float (&a)[4][KT], float (&b)[4][NT]) {
+        const float* dp = dsl + min(mb, nmb - 1) * (16 * 36);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) b[j][n] = ds[(size_t)(m0 + j) * 36 + n * 16 + lr];
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int i = 0; i < KT; ++i) a[j][i] = kt_ok[i] ? img[off[j] + (wv * KT + i) * 16 + lr] : 0.f;
+          for (int n = 0; n < NT; ++n) b[j][n] = dp[j * 36 + n * 16];
+#pragma unroll
+          for (int i = 0; i < KT; ++i) a[j][i] = kt_ok[i] ? imgl[off[j] + i * 16] : 0.f;
+        }
+      };
+      auto mma = [&](const float (&a)[4][KT], const float (&b)[4][NT]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < KT; ++i)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[dd][i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][i], b[j][n], acc[dd][i][n], 0, 0, 0);
+      };
+      {
+        int off0[4];
+        load_off(mb_lo, off0);
+        load_ops(mb_lo, off0, a_c, b_c);
+        load_off(mb_lo + 1, off_n);
       }
-    };
-    auto mma = [&](const float (&a)[4][KT], const float (&b)[4][NT]) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < KT; ++i)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][i], b[j][n], acc[i][n], 0, 0, 0);
-    };
-    {
-      int off0[4];
-      load_off(mb_lo, off0);
-      load_ops(mb_lo, off0, a_c, b_c);
-      load_off(mb_lo + 1, off_n);
-    }
-    for (int mb = mb_lo; mb < nmb; mb += 2) {
-      int off_nn[4];
-      load_ops(mb + 1, off_n, a_n, b_n);
-      load_off(mb + 2, off_nn);
-      mma(a_c, b_c);
-      if (mb + 1 < nmb) {
-        load_ops(mb + 2, off_nn, a_c, b_c);
-        load_off(mb + 3, off_n);
-        mma(a_n, b_n);
+      for (int mb = mb_lo; mb < nmb; mb += 2) {
+        int off_nn[4];
+        load_ops(mb + 1, off_n, a_n, b_n);
+        load_off(mb + 2, off_nn);
+        mma(a_c, b_c);
+        if (mb + 1 < nmb) {
+          load_ops(mb + 2, off_nn, a_c, b_c);
+          load_off(mb + 3, off_n);
+          mma(a_n, b_n);
+        }
       }
     }
   }
-  // partial tile -> part[((grp*nstrips + strip)*S + dh)][k'][32]
-  float* po = part + ((size_t)(grp * gridDim.z + strip) * S + dh) * (size_t)KP * 32;
+  // partial tiles -> part[((grp*nstrips + strip)*S + dh)][k'][32]
 #pragma unroll
-  for (int i = 0; i < KT; ++i) {
-    const int kt = wv * KT + i;
-    if (kt * 16 >= KP) continue;
+  for (int dd = 0; dd < DH; ++dd) {
+    const int dh = dh0 + dd;
+    if (dh >= S) break;
+    float* po = part + ((size_t)(grp * gridDim.z + strip) * S + dh) * (size_t)KP * 32;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < KT; ++i) {
+      const int kt = wv * KT + i;
+      if (kt * 16 >= KP) continue;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) po[(size_t)(kt * 16 + 4 * q + e) * 32 + j * 16 + lr] = j < NT ? acc[i][j < NT ? j : 0][e] : 0.f;
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) po[(size_t)(kt * 16 + 4 * q + e) * 32 + j * 16 + lr] = j < NT ? acc[dd][i][j < NT ? j : 0][e] : 0.f;
+    }
   }
 }
 // dW[(dh*fw + dw)*C + c][co] = sum over partial tiles p of part[p][dh][dw*C' + c][co]   (fixed order)
@@ -341,19 +370,29 @@ void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const 
   else hipLaunchKernelGGL((k_conv_fwd<6, 2>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW);
 }
 
-// frames per workgroup of the weight-gradient kernel (S filter rows x groups x strips workgroups)
-static int wgrad_fpg(int R, int S, int nstrips) {           // at most 256 workgroups: one round on the 256 CUs
-  const int groups_max = std::max(1, 256 / (S * nstrips));
-  return std::max(1, (R + groups_max - 1) / groups_max);
-}
+// Grid of the weight-gradient kernel: ceil(S / DH) filter-row groups x frame groups x strips, at most 256 workgroups (one round
+// on the 256 CUs); DH (filter rows per workgroup, 1..3) is chosen to minimise the frames a workgroup has to stage.
 static int wgrad_tw(int S, int W) {          // narrower strips than the forward kernel (the d strip is in LDS too), evenly split
   if (S * W <= 8 * 4 * 16) return W;
   const int ns = (W + 31) / 32;
   return (W + ns - 1) / ns;
 }
+static void wgrad_plan(int R, int S, int nstrips, int& DH, int& fpg, int& groups) {
+  int best = 1 << 30;
+  DH = 1; fpg = R; groups = 1;
+  // measured: with one strip per frame (W = 40) one filter row per workgroup is faster (4.20 vs 4.39 ms/step) although it stages
+  // three times as many frames; with 9 strips (W = 257) three rows per workgroup win (26.2 vs 28.0 ms/step)
+  for (int dhc = 1; dhc <= (nstrips > 1 ? 3 : 1); ++dhc) {
+    const int ng = (S + dhc - 1) / dhc;
+    const int gmax = std::max(1, 256 / (ng * nstrips));
+    const int f = std::max(1, (R + gmax - 1) / gmax);
+    if (f < best) { best = f; DH = dhc; fpg = f; groups = (R + f - 1) / f; }
+  }
+}
 size_t conv_wgrad_ws_floats(int C, int R, int S, int W, int fw) {
   const int TW = wgrad_tw(S, W), nstrips = (W + TW - 1) / TW;
-  const int fpg = wgrad_fpg(R, S, nstrips), groups = (R + fpg - 1) / fpg;
+  int DH, fpg, groups;
+  wgrad_plan(R, S, nstrips, DH, fpg, groups);
   return (size_t)groups * nstrips * S * conv_kp(fw, C) * 32;
 }
 bool conv_wgrad_supported(int C, int N, int S, int W, int fw) {
@@ -361,48 +400,35 @@ bool conv_wgrad_supported(int C, int N, int S, int W, int fw) {
   const int TW = wgrad_tw(S, W);
   const int MP = (S * TW + 15) / 16 * 16;
   const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 38) * sizeof(float);
-  return lds <= 160 * 1024 && conv_kp(fw, C) <= 8 * 3 * 16 && ((TW + fw - 1) * conv_cpad(C) + 16) / 4 <= 512;
+  return lds <= 160 * 1024 && conv_kp(fw, C) <= 16 * 2 * 16 && ((TW + fw - 1) * conv_cpad(C) + 16) / 4 <= 512 && (TW + fw) * conv_cpad(C) < (1 << 20);
+}
+template <int KT, int NT>
+static void wgrad_launch_dh(int DH, dim3 grid, size_t lds, hipStream_t s, const float* in, int ldc_in, int C, const float* d, int ldc_d, int N,
+                            float* ws, int S, int W, int fw, int TW, int R, int fpg) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<KT, NT, 16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<KT, NT, 16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<KT, NT, 16, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  if (DH == 1) hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 1>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  else if (DH == 2) hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 2>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  else hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 3>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
 }
 void launch_conv_wgrad(const float* in, int ldc_in, int C, const float* d, int ldc_d, int N, float* dW, int ldw, float* ws, int R, int S,
                        int W, int fw, hipStream_t s) {
   const int TW = wgrad_tw(S, W), nstrips = (W + TW - 1) / TW;
-  const int fpg = wgrad_fpg(R, S, nstrips), groups = (R + fpg - 1) / fpg;
+  int DH, fpg, groups;
+  wgrad_plan(R, S, nstrips, DH, fpg, groups);
   const int MP = (S * TW + 15) / 16 * 16, KP = conv_kp(fw, C);
   const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 38) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
-  dim3 grid(S, groups, nstrips);
-  static int wide = -1;            // RSRGAN_WGRAD_WAVES=8: always 8 waves (A/B knob); default: 16 waves when a wave would own two k'-tiles
-  if (wide < 0) { const char* e = getenv("RSRGAN_WGRAD_WAVES"); wide = (e && atoi(e) == 8) ? 0 : 1; }
-  const bool k1 = KP <= 8 * 16, k3 = KP > 8 * 2 * 16, n1 = N <= 16;
-  static bool attr2 = false;
-  if (!attr2) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<1, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<1, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<2, 1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<2, 2, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr2 = true;
-  }
-  if (wide && !k1) {
-    if (k3 && n1) hipLaunchKernelGGL((k_conv_wgrad<2, 1, 16>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
-    else if (k3) hipLaunchKernelGGL((k_conv_wgrad<2, 2, 16>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
-    else if (n1) hipLaunchKernelGGL((k_conv_wgrad<1, 1, 16>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
-    else hipLaunchKernelGGL((k_conv_wgrad<1, 2, 16>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
-  } else
-  if (k3 && n1) hipLaunchKernelGGL((k_conv_wgrad<3, 1>), grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
-  else if (k3) hipLaunchKernelGGL((k_conv_wgrad<3, 2>), grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
-  else if (k1 && n1) hipLaunchKernelGGL((k_conv_wgrad<1, 1>), grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
-  else if (k1) hipLaunchKernelGGL((k_conv_wgrad<1, 2>), grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
-  else if (n1) hipLaunchKernelGGL((k_conv_wgrad<2, 1>), grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
-  else hipLaunchKernelGGL((k_conv_wgrad<2, 2>), grid, dim3(512), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  dim3 grid((S + DH - 1) / DH, groups, nstrips);
+  const bool k2 = KP > 16 * 16, n1 = N <= 16;          // 16 waves: one k'-tile per wave up to K' = 256, two beyond
+  if (k2 && n1) wgrad_launch_dh<2, 1>(DH, grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  else if (k2) wgrad_launch_dh<2, 2>(DH, grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  else if (n1) wgrad_launch_dh<1, 1>(DH, grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  else wgrad_launch_dh<1, 2>(DH, grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
   const int total = S * fw * C * N;
   hipLaunchKernelGGL(k_conv_wgrad_red, dim3((total + 255) / 256), dim3(256), 0, s, ws, groups * nstrips, S, fw, C, N, dW, ldw);
 }
