@@ -158,12 +158,15 @@ def bench_dnn_gan(a, rank, local, world, dev):
     rng = np.random.default_rng(1234 + rank)
     x = torch.from_numpy(rng.standard_normal((N, 1, 2827)).astype(np.float32)).to(dev)
     lab = torch.from_numpy(rng.standard_normal((N, 1, 40)).astype(np.float32)).to(dev)
+    x2 = torch.from_numpy(rng.standard_normal((N, 1, 2827)).astype(np.float32)).to(dev)
+    lab2 = torch.from_numpy(rng.standard_normal((N, 1, 40)).astype(np.float32)).to(dev)
 
     def step():
         if trainer:
             return model.step(x, lab, sync=False)
+        # scripts/train_gan_dnn.py:50-96: the D-run and the G-run each dequeue their own batch -> no shared generator forward
         model.d_step(x, lab, sync=False)
-        return model.g_step(x, lab, reuse_g_forward=True, sync=False)
+        return model.g_step(x2, lab2, sync=False)
     for _ in range(a.warmup):
         step()
     rdist.barrier(); torch.cuda.synchronize()
@@ -181,7 +184,7 @@ def bench_dnn_gan(a, rank, local, world, dev):
     if rank == 0:
         fg = 2 * (2827 * 1024 + 3 * 1024 * 1024 + 1024 * 40)
         fd = 2 * (297 * 1024 + 3 * 1024 * 1024 + 1024)
-        fpf = 3 * fg + (0 if trainer else 8 * fd)          # G fwd + 2x bwd (weights only: no input gradient... counted as 2x), D as SURVEY 8d
+        fpf = (3 * fg) if trainer else (4 * fg + 8 * fd)   # trainer: G fwd + 2x bwd; GAN: + the D-run's own G fwd, D terms as SURVEY 8d
         ach = fpf * N / (dev_ms * 1e-3 / a.steps) / 1e12
         out = {"metric": ("supervised train frames/sec, DNN generator 2827->40 under DNNTrainer (BASELINE configs[0])" if trainer else
                           "GAN train frames/sec (G+D step), frame-level DNN-GAN 2827->40 (SURVEY 8f-1)"),
@@ -194,7 +197,7 @@ def bench_dnn_gan(a, rank, local, world, dev):
                           "losses_last_step": [round(float(v), 6) for v in last.mean(0).cpu().numpy()]},
                "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                            "scope": "all launches of one step; algorithmic 3*F_G+8*F_D = %d FLOP/frame" % fpf}}
+                            "scope": "all launches of one step; algorithmic %s = %d FLOP/frame" % ("3*F_G" if trainer else "4*F_G+8*F_D", fpf)}}
         print(json.dumps(out), flush=True)
     rdist.barrier()
 
@@ -214,12 +217,15 @@ def bench_rced(a, rank, local, world, dev):
         class RcedGan(GAN):
             G_TYPES = ("dnn", "rced")
         model = RcedGan(None, args, ["gpu:%d" % local], seed=4321)
-        model.step = lambda x_, l_, sync=False: (model.d_step(x_, l_, sync=False), model.g_step(x_, l_, reuse_g_forward=True, sync=False))[1]
+        # the frame-level scripts feed the D-run and the G-run different batches (train_gan_dnn.py:50-96): no forward reuse
+        model.step = lambda x_, l_, sync=False: (model.d_step(x_, l_, sync=False), model.g_step(x2, lab2, sync=False))[1]
     else:
         model = DNNTrainer(None, args, ["gpu:%d" % local], seed=4321)
     rng = np.random.default_rng(1234 + rank)
     x = torch.from_numpy(rng.standard_normal((N, 1, S * W)).astype(np.float32)).to(dev)
     lab = torch.from_numpy(rng.standard_normal((N, 1, 40)).astype(np.float32)).to(dev)
+    x2 = torch.from_numpy(rng.standard_normal((N, 1, S * W)).astype(np.float32)).to(dev)
+    lab2 = torch.from_numpy(rng.standard_normal((N, 1, 40)).astype(np.float32)).to(dev)
     for _ in range(a.warmup):
         model.step(x, lab, sync=False)
     rdist.barrier(); torch.cuda.synchronize()
@@ -241,8 +247,8 @@ def bench_rced(a, rank, local, world, dev):
             cin = co
         fl += 2 * S * W * cin * 40
         fpf = 3 * fl                                      # forward + data gradient + weight gradient
-        if a.rced_gan:
-            fpf += 8 * 2 * ((W + 40) * 1024 + 3 * 1024 * 1024 + 1024)      # discriminator_dnn terms as in SURVEY 8d
+        if a.rced_gan:                                    # + the D-run's own generator forward, discriminator_dnn terms as SURVEY 8d
+            fpf += fl + 8 * 2 * ((W + 40) * 1024 + 3 * 1024 * 1024 + 1024)
         ach = fpf * N / (dev_ms * 1e-3 / a.steps) / 1e12
         out = {"metric": ("GAN train frames/sec (G+D step), R-CED generator + discriminator_dnn (BASELINE configs[3])" if a.rced_gan
                           else "supervised train frames/sec, R-CED generator (SURVEY 8f-2)"), "value": round(N * world * a.steps / dt, 1),
@@ -254,7 +260,8 @@ def bench_rced(a, rank, local, world, dev):
                           "losses_last_step": [round(float(v), 6) for v in last.mean(0).cpu().numpy()]},
                "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                            "scope": "all launches of one step; algorithmic 3 x %d FLOP/frame (conv + FC GEMM terms)" % fl}}
+                            "scope": "all launches of one step; algorithmic %d FLOP/frame (%s x %d conv + FC GEMM terms%s)" % (
+                                fpf, "4" if a.rced_gan else "3", fl, " + 8 F_D" if a.rced_gan else "")}}
         print(json.dumps(out), flush=True)
     rdist.barrier()
 
