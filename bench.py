@@ -343,7 +343,7 @@ def main():
                     "frac": round(k_ach / PEAK_FP32_MFMA_TFLOPS, 4),
                     "how": "every launch of one step bracketed by HIP events on its stream (rsrgan_profile_begin/read); "
                            "the event-to-event time includes the ~2.7 us dispatch gap per launch that rocprofv3's kernel duration "
-                           "excludes: compare AverageNs of k_fwd_gates<18,2> in profiles/r1_final_rocprofv3_kernel_stats.csv (12.1 us)"}
+                           "excludes: compare AverageNs of k_fwd_gates<18,2,1> in profiles/r1_final_rocprofv3_kernel_stats.csv (11.8 us)"}
         out = {"metric": "GAN train frames/sec (G+D step), 257-dim LPS->40-dim MFCC", "value": round(value, 1),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt * 1e3 / a.steps, 4), "higher_is_better": True, "scaling": "strong" if a.strong else "weak",
