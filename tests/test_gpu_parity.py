@@ -279,3 +279,24 @@ def test_profile_api_counts_gates_launches():
     n2, us2, _ = model.engine.profile_read()          # profiling is off again: nothing new recorded by a further step
     model.engine.d_backward(x, lab, ln, train=True, apply=False)
     assert model.engine.profile_read()[0] == n2
+
+
+@pytest.mark.parametrize("g_type", ["lstm", "res_lstm_l"])
+def test_long_sequences(g_type):
+    """T = 300 padded frames (the reference buckets utterances up to ~1000 frames): BPTT over hundreds of steps stays within the
+    tolerances of the short cases; lengths ragged, one row a single frame long."""
+    cfg = small_cfg(g_type)
+    B, T = 3, 300
+    model, oracle = build_hip_pair(cfg, B, T, seed=41, flags=1)
+    x, lab, ln = rand_batch(cfg, B, T, seed=42, ragged=True)
+    ln[1] = 1
+    got = model.engine.d_backward(x, lab, ln, None, None, train=True, apply=False).cpu().numpy()
+    want, wg = oracle.d_tower(x.astype(np.float64), lab.astype(np.float64), ln)
+    assert np.allclose(got, want, rtol=LOSS_RTOL), (got, want)
+    _check_grads(model, NET_D, wg, "D long")
+    got = model.engine.g_backward(x, lab, ln, None, train=True, reuse=True, apply=False).cpu().numpy()
+    want, wg, y_ref = oracle.g_tower(x.astype(np.float64), lab.astype(np.float64), ln)
+    assert np.allclose(got, want, rtol=LOSS_RTOL), (got, want)
+    _check_grads(model, NET_G, wg, "G long")
+    y = model.forward(x, ln)
+    assert np.abs(y - y_ref).max() < 1e-4
