@@ -1,0 +1,61 @@
+"""Background batch producer: the reference fills a `Queue.Queue(maxsize=32)` from daemon reader threads while the main thread
+trains (scripts/train_gan_rnn_placeholder.py:463-478, :304-343), so ark reading, CMVN, splicing and padding overlap the GPU
+step.  `prefetch(batches)` does the same for any iterable of `[ids, inputs, labels, lengths]` items: one daemon thread (the
+order of the batches is kept; NumPy releases the GIL in the heavy parts) and, when a GPU is present, page-locked staging
+tensors so that the host-to-device copy in train_one_iteration is a plain asynchronous DMA."""
+from __future__ import annotations
+
+import queue
+import threading
+from typing import Iterable, Iterator
+
+import numpy as np
+import torch
+
+_END = object()
+
+
+def _pin(a):
+    if isinstance(a, np.ndarray) and a.dtype in (np.float32, np.int32) and torch.cuda.is_available():
+        return torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
+    return a
+
+
+def prefetch(batches: Iterable, capacity: int = 32, pin: bool = True) -> Iterator:
+    """Yield the items of `batches` in order, produced `capacity` ahead by a daemon thread.  An exception in the producer is
+    re-raised in the consumer at the position where it happened; abandoning the generator stops the producer."""
+    q: "queue.Queue" = queue.Queue(maxsize=max(1, capacity))
+    stop = threading.Event()
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def work():
+        try:
+            for item in batches:
+                if pin and isinstance(item, (list, tuple)) and len(item) == 4:
+                    item = [item[0], _pin(item[1]), _pin(item[2]), _pin(item[3])]
+                if not put(item):
+                    return
+            put(_END)
+        except BaseException as e:          # noqa: BLE001 -- handed to the consumer
+            put(e)
+
+    t = threading.Thread(target=work, name="rsrgan-batch-reader", daemon=True)
+    t.start()
+    try:
+        while True:
+            item = q.get()
+            if item is _END:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+    finally:
+        stop.set()

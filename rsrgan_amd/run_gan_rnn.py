@@ -21,7 +21,7 @@ import numpy as np
 
 from . import dist as rdist
 from .gan_rnn import GAN_RNN
-from .io import ArkReader, ArkWriter, PaddedBatchReader, splice_feats
+from .io import ArkReader, ArkWriter, PaddedBatchReader, prefetch, splice_feats
 from .train import eval_one_iteration, exponential_decay, train_one_iteration
 
 
@@ -110,9 +110,10 @@ def train(FLAGS, model_factory=None, log=print, net_overrides=None):
     iteration = -1
     for iteration in range(max_iters):
         start = datetime.datetime.now()
-        tr = train_one_iteration(None, tr_model, train_batch_per_iter * FLAGS.num_gpu, iteration + 1, iter(tr_reader), FLAGS.num_gpu)
+        # reader thread + Queue(32) as :463-478: reading, CMVN, splicing and padding overlap the GPU steps
+        tr = train_one_iteration(None, tr_model, train_batch_per_iter * FLAGS.num_gpu, iteration + 1, prefetch(tr_reader), FLAGS.num_gpu)
         cv = eval_one_iteration(None, cv_model, valdi_batch_per_iter * FLAGS.num_gpu, iteration + 1,
-                                (b for b in cv_reader if len(b[0]) == full), FLAGS.num_gpu)
+                                prefetch(b for b in cv_reader if len(b[0]) == full), FLAGS.num_gpu)
         end = datetime.datetime.now()
         log("{}/{} (INFO): d_learning_rate = {:.5e}, g_learning_rate = {:.5e}, time = {:.3f} h\n"
             "{}/{} (TRAIN AVG.LOSS): d_rl_loss = {:.5f}, d_fk_loss = {:.5f}, d_loss = {:.5f}, g_adv_loss = {:.5f}, "

@@ -62,6 +62,9 @@ def train_one_iteration(sess, model, tr_num_batch, iteration, train_queue, num_g
             x = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
             lab = torch.from_numpy(np.ascontiguousarray(lab, np.float32)).to(dev)
             ln = torch.from_numpy(np.ascontiguousarray(ln)).to(dev).to(torch.int32)
+        elif x.device != dev:                                     # page-locked staging tensors from io.prefetch: asynchronous DMA
+            x = x.to(dev, non_blocking=True); lab = lab.to(dev, non_blocking=True)
+            ln = ln.to(dev, non_blocking=True).to(torch.int32)
         for d_step in range(model.disc_updates):
             tw = model.d_step(x, lab, ln, sync=False, gather=False)   # this tower's [1, 3]; towers are averaged once, below
             m = tw.mean(0)                                        # np.mean over towers (:85-87)

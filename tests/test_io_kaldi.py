@@ -136,3 +136,30 @@ def test_padded_batches_bucket_by_length_and_feed_the_training_loop(tmp_path):
     short = [[ids, X[:, :6], Y[:, :6], np.minimum(L, 6)] for ids, X, Y, L in batches]
     res = train_one_iteration(None, m, len(short), 0, short)
     assert len(res) == 7 and m.engine.o.adam_t == 4                # the two partial batches were skipped (:69-70)
+
+
+def test_prefetch_keeps_order_propagates_errors_and_stops():
+    from rsrgan_amd.io import prefetch
+    items = [[["u%d" % i], np.full((1, 2, 3), i, np.float32), np.zeros((1, 2, 1), np.float32), np.array([2], np.int32)] for i in range(50)]
+    got = list(prefetch(iter(items), capacity=4))
+    assert [g[0] for g in got] == [it[0] for it in items]
+    assert all(float(np.asarray(g[1]).ravel()[0]) == i for i, g in enumerate(got))
+
+    def bad():
+        yield items[0]
+        raise ValueError("boom")
+    it = prefetch(bad(), capacity=2)
+    assert next(it)[0] == ["u0"]
+    with pytest.raises(ValueError):
+        next(it)
+    # abandoning the consumer must not leave the producer blocked on a full queue
+    import threading
+    n0 = threading.active_count()
+    g = prefetch(iter(items), capacity=1)
+    next(g); g.close()
+    import time
+    for _ in range(50):
+        if threading.active_count() <= n0:
+            break
+        time.sleep(0.05)
+    assert threading.active_count() <= n0
