@@ -13,9 +13,11 @@ from .kaldi_ark import ArkReader
 
 def apply_cmvn(inputs, labels, cmvn):
     """make_tfrecords.py:84-87: float64 arithmetic, (x - mean) / stddev."""
-    inputs = (np.asarray(inputs, np.float64) - cmvn["mean_inputs"]) / cmvn["stddev_inputs"]
+    inputs = np.array(inputs, np.float64)                 # private float64 copy, then in place (no temporaries)
+    inputs -= cmvn["mean_inputs"]; inputs /= cmvn["stddev_inputs"]
     if labels is not None:
-        labels = (np.asarray(labels, np.float64) - cmvn["mean_labels"]) / cmvn["stddev_labels"]
+        labels = np.array(labels, np.float64)
+        labels -= cmvn["mean_labels"]; labels /= cmvn["stddev_labels"]
     return inputs, labels
 
 
@@ -65,13 +67,14 @@ class PaddedBatchReader(object):
     def _pad(self, items):
         T = max(x.shape[0] for _, x, _ in items)
         ids = [u for u, _, _ in items]
-        X = np.zeros((len(items), T, items[0][1].shape[1]), np.float32)
-        Y = np.zeros((len(items), T, items[0][2].shape[1]), np.float32)
+        X = np.empty((len(items), T, items[0][1].shape[1]), np.float32)       # every element is written exactly once below
+        Y = np.empty((len(items), T, items[0][2].shape[1]), np.float32)
         L = np.zeros(len(items), np.int32)
         for b, (_, x, y) in enumerate(items):
-            X[b, :x.shape[0]] = x
-            Y[b, :y.shape[0]] = y
-            L[b] = x.shape[0]
+            n = x.shape[0]
+            X[b, :n] = x; X[b, n:] = 0.0
+            Y[b, :n] = y; Y[b, n:] = 0.0
+            L[b] = n
         return [ids, X, Y, L]
 
     def __iter__(self) -> Iterator[List]:
