@@ -53,6 +53,7 @@ class PaddedBatchReader(object):
         self.batch_size, self.left, self.right = batch_size, left_context, right_context
         self.cmvn, self.num_buckets, self.shuffle = cmvn, num_buckets, shuffle
         self.rng = random.Random(seed)
+        self._nframes = None
 
     def __len__(self):
         return len(self.inputs.utt_ids)
@@ -77,22 +78,32 @@ class PaddedBatchReader(object):
             L[b] = n
         return [ids, X, Y, L]
 
-    def __iter__(self) -> Iterator[List]:
+    def plan(self) -> Iterator[List[int]]:
+        """The utterance indices of every batch, in the order __iter__ yields them -- from the matrix headers alone, so the
+        expensive part (materialize) can run on several threads (io.prefetch)."""
+        if self._nframes is None:
+            self._nframes = [self.inputs.utt_shape_from_index(i)[0] for i in range(len(self))]
         order = list(range(len(self)))
         if self.shuffle:
             self.rng.shuffle(order)
         windows = {}
         for i in order:
-            item = self._utt(i)
             if self.num_buckets > 1:
-                key = min(self.num_buckets, (item[1].shape[0] - 200) // 50)      # :157-165
+                key = min(self.num_buckets, (self._nframes[i] - 200) // 50)      # :157-165
             else:
                 key = 0
             w = windows.setdefault(key, [])
-            w.append(item)
+            w.append(i)
             if len(w) == self.batch_size:
-                yield self._pad(w)
+                yield w
                 windows[key] = []
         for key in sorted(windows):
             if windows[key]:
-                yield self._pad(windows[key])
+                yield windows[key]
+
+    def materialize(self, indices: List[int]) -> List:
+        return self._pad([self._utt(i) for i in indices])
+
+    def __iter__(self) -> Iterator[List]:
+        for indices in self.plan():
+            yield self.materialize(indices)

@@ -68,6 +68,23 @@ class ArkReader(object):
                 raise ValueError("unknown matrix type %r" % (header[1],))
             return np.reshape(mat, (rows, cols))
 
+    def read_shape(self, ark_file, ark_offset=0):
+        """(rows, cols) of the matrix at `ark_offset` from its header alone (length bucketing without reading the data)."""
+        with open(ark_file, "rb") as buf:
+            buf.seek(int(ark_offset), 0)
+            header = struct.unpack("<xcccc", buf.read(5))
+            if header[0] != b"B":
+                raise ValueError("%s: input .ark file is not binary" % ark_file)
+            if header[1] == b"C":
+                _, _, rows, cols = struct.unpack("<ffii", buf.read(16))
+                return rows, cols
+            _, rows = struct.unpack("<bi", buf.read(5))
+            _, cols = struct.unpack("<bi", buf.read(5))
+            return rows, cols
+
+    def utt_shape_from_index(self, index):
+        return self.read_shape(self.scp_data[index][0], self.scp_data[index][1])
+
     @staticmethod
     def uint16_to_float(min_value, rng, value):
         """:120-125 (the constant is 1/65535)."""

@@ -16,15 +16,34 @@ import torch
 _END = object()
 
 
+def _parallel(reader, threads, capacity):
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=threads, thread_name_prefix="rsrgan-batch-reader") as pool:
+        pending = deque()
+        for indices in reader.plan():
+            pending.append(pool.submit(reader.materialize, indices))
+            if len(pending) >= min(capacity, 2 * threads):
+                yield pending.popleft().result()
+        while pending:
+            yield pending.popleft().result()
+
+
 def _pin(a):
     if isinstance(a, np.ndarray) and a.dtype in (np.float32, np.int32) and torch.cuda.is_available():
         return torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
     return a
 
 
-def prefetch(batches: Iterable, capacity: int = 32, pin: bool = False) -> Iterator:
+def prefetch(batches: Iterable, capacity: int = 32, pin: bool = False, threads: int = 1) -> Iterator:
     """Yield the items of `batches` in order, produced `capacity` ahead by a daemon thread.  An exception in the producer is
-    re-raised in the consumer at the position where it happened; abandoning the generator stops the producer."""
+    re-raised in the consumer at the position where it happened; abandoning the generator stops the producer.  A reader that
+    separates planning from reading (`plan()` / `materialize(indices)`, io.features.PaddedBatchReader) is materialised by
+    `threads` workers with the batch order preserved (the reference starts two reader threads, train...py:463-478; measured here
+    one producer thread is fastest -- 0.39 vs 0.28 / 0.24 M frames/s with 1 / 2 / 4 workers: the work is page-fault and
+    interpreter bound, not NumPy-kernel bound -- hence the default)."""
+    if threads > 1 and hasattr(batches, "plan") and hasattr(batches, "materialize"):
+        batches = _parallel(batches, threads, max(1, capacity))
     q: "queue.Queue" = queue.Queue(maxsize=max(1, capacity))
     stop = threading.Event()
 

@@ -163,3 +163,24 @@ def test_prefetch_keeps_order_propagates_errors_and_stops():
             break
         time.sleep(0.05)
     assert threading.active_count() <= n0
+
+
+def test_threaded_reader_equals_direct_iteration(tmp_path):
+    from rsrgan_amd.io import ArkWriter, PaddedBatchReader, prefetch
+    rng = np.random.default_rng(3)
+    wi, wl = ArkWriter(str(tmp_path / "in.scp")), ArkWriter(str(tmp_path / "lab.scp"))
+    for i in range(37):
+        t = int(rng.integers(190, 330))
+        wi.write_next_utt(str(tmp_path / "in.ark"), "u%03d" % i, rng.standard_normal((t, 6)).astype(np.float32))
+        wl.write_next_utt(str(tmp_path / "lab.ark"), "u%03d" % i, rng.standard_normal((t, 3)).astype(np.float32))
+    wi.close(); wl.close()
+    cmvn = dict(mean_inputs=rng.standard_normal(6), stddev_inputs=1 + rng.random(6), mean_labels=rng.standard_normal(3), stddev_labels=1 + rng.random(3))
+    mk = lambda: PaddedBatchReader(str(tmp_path / "in.scp"), str(tmp_path / "lab.scp"), 4, left_context=1, right_context=2, cmvn=cmvn, shuffle=True, seed=5)
+    a = list(mk())
+    b = list(prefetch(mk(), capacity=3, threads=3))
+    assert len(a) == len(b) and len(a) >= 9
+    for x, y in zip(a, b):
+        assert x[0] == y[0]
+        for u, v in zip(x[1:], y[1:]):
+            assert np.array_equal(u, v)
+    assert mk().inputs.utt_shape_from_index(0) == mk().inputs.read_utt_data_from_index(0).shape
