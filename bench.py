@@ -53,7 +53,7 @@ def synthetic(B, T, din, dout, seed=1234):
     return x, lab, ln
 
 
-def cpu_baseline(net, B, T, budget_s=20.0):
+def cpu_baseline(net, B, T, budget_s=12.0):
     """The oracle's torch-CPU twin timed on this box's host cores on a bounded sample of the SAME
     workload (kind 'port': the reference's TF-1.4 path cannot run here)."""
     from oracle import rsrgan_oracle as O
@@ -70,7 +70,7 @@ def cpu_baseline(net, B, T, budget_s=20.0):
     t0 = time.time(); n = 0
     while True:
         tw.d_step(x, lab, ln); tw.g_step(x, lab, ln); n += 1
-        if n >= 3 or time.time() - t0 > budget_s:
+        if n >= 12 or time.time() - t0 > budget_s:        # a bounded sample: about 10-15 s of CPU work
             break
     dt = time.time() - t0
     model_name = ""
