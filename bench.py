@@ -335,12 +335,19 @@ def main():
                              "(SURVEY 8d: 3*F_G+8*F_D, F_G=%d, F_D=%d) / HIP-event step time; traffic = HBM-side bytes "
                              "per step from profiles/r1_final_traffic.json" % (fpf, B * T, fg, fd)}
             n_l, us_l, fl_l = res["prof"]
+            k_traffic = None
+            if traffic is not None:        # per-launch HBM-side bytes of the same kernel from the committed PMC passes
+                tj = json.load(open(tf_path))
+                f = [v for v in tj.get("top_fetch", []) if "k_fwd_gates" in v[0]]
+                w = [v for v in tj.get("top_write", []) if "k_fwd_gates" in v[0]]
+                if f and w and f[0][2] == w[0][2]:
+                    k_traffic = int((2 * f[0][1] + w[0][1]) * 1024 / f[0][2])
             if n_l:
                 k_ach = fl_l / (us_l * 1e-6) / 1e12
                 roof["dominant_kernel"] = {
                     "name": "k_fwd_gates", "launches_per_step": n_l, "avg_us": round(us_l / n_l, 3),
                     "algorithmic_flop_per_launch": round(fl_l / n_l), "achieved": round(k_ach, 3), "unit": "TFLOP/s",
-                    "frac": round(k_ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "frac": round(k_ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": k_traffic,
                     "how": "every launch of one step bracketed by HIP events on its stream (rsrgan_profile_begin/read); "
                            "the event-to-event time includes the ~2.7 us dispatch gap per launch that rocprofv3's kernel duration "
                            "excludes: compare AverageNs of k_fwd_gates<18,2,1> in profiles/r1_final_rocprofv3_kernel_stats.csv (11.8 us)"}
