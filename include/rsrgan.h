@@ -106,7 +106,8 @@ typedef struct rsrgan_cfg {
 
 enum {
   RSRGAN_FLAG_WAVEFRONT = 1,   /* run the stacked LSTMs as one (layer,t) wavefront (default schedule when set) */
-  /* 2: unused (a hipGraph replay was measured pointless: the step is GPU-bound, the host runs ahead of the queue) */
+  RSRGAN_FLAG_GRAPH = 2,       /* replay the (static, per T) launch sequences of the wavefront schedule as hipGraphs: 1.6 us per
+                                  dependent kernel on the GPU vs 3.1-4.6 us host-bound per eager launch (measured, round 2) */
   RSRGAN_FLAG_NO_SPLITK_B = 8, /* backward phase B as one launch of 32x16 tiles (round-1 first form) instead of split-K + reduce */
   RSRGAN_FLAG_SUPERVISED = 16, /* generator-only trainer (models/rnn_trainer.py:66-156, models/dnn_trainer.py:64-148):
                                   g_loss = mse_lambda*g_mse + g_l2, no discriminator pass; rsrgan_d_step is an error */

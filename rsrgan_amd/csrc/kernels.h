@@ -34,7 +34,7 @@ struct FwdGateJob {
   // num_proj=None layers (m = h): the epilogue also writes the carried state, the masked output and the residual sum
   float* np_m_out; float* np_out; const float* np_res_in; float* np_res_out;
 };
-struct FwdGateJobs { int n; float forget_bias; FwdGateJob j[MAXJ]; };
+struct FwdGateJobs { int n; float forget_bias; const float* zeros; FwdGateJob j[MAXJ]; };   // zeros: >= 16 B of device zeros (panel.hip)
 
 // Forward phase 2: m_t = h_t . Wp ; dynamic_rnn masking ; optional residual add
 struct FwdProjJob {
@@ -51,7 +51,7 @@ struct FwdProjJob {
   int ldh, ldm, ldo, P, t, N;     // ldm: stride of m_prev/m_out/res_*, ldo: stride of out
   int nblk_c, blk_base;
 };
-struct FwdProjJobs { int n; FwdProjJob j[MAXJ]; };
+struct FwdProjJobs { int n; const float* zeros; FwdProjJob j[MAXJ]; };
 
 // Backward phase A: dm = mask*(dout_t + dm_state); dh = dm . Wp^T ; gate grads -> dz ; dc
 struct BwdAJob {
@@ -68,7 +68,7 @@ struct BwdAJob {
   int ldm, P, t, N, H;
   int nblk_c, blk_base;
 };
-struct BwdAJobs { int n; BwdAJob j[MAXJ]; };
+struct BwdAJobs { int n; const float* zeros; BwdAJob j[MAXJ]; };
 
 // Backward phase B: [dx_t | dm_rec] = dz_t . K^T restricted to kernel rows [n_begin, n_end)
 struct BwdBJob {
@@ -84,7 +84,7 @@ struct BwdBJob {
   float* ws;
   int ldw, KG, kpg, ncg, nrg, blk_base_p, blk_base_r;
 };
-struct BwdBJobs { int n; BwdBJob j[MAXJ]; };
+struct BwdBJobs { int n; const float* zeros; BwdBJob j[MAXJ]; };
 
 // A job covers nblk_r = ceil(N/32) row blocks x roundup8(nblk_c) virtual column blocks; blk_base is
 // the job's first block id in the launch.  kb_max = largest 16-float k-block count of any job in
@@ -100,6 +100,21 @@ void launch_bwd_b_variant(const BwdBJobs& jobs, int total_blocks, int variant, h
 // split-K phase B: fills ws/ldw/KG/... of every job (ws_base: >= bwd_b_ws_floats(jobs) floats) and launches both kernels
 size_t bwd_b_plan(BwdBJobs& jobs, float* ws_base);
 void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s);
+void launch_bwd_b_red(const BwdBJobs& jobs, hipStream_t s);       // fixed-order sum of the split-K partials + masked epilogue
+
+// ---------------------------------------------------------------- panel step kernels (panel.hip, round 2)
+// 64-row x NC-column workgroups, A and W streamed through an LDS-DMA ring; same job structs, different block decomposition:
+// a job owns ceil(N/64) row groups x roundup8(ceil(cols / per_wg)) column groups.
+bool panel_kernels();                        // RSRGAN_PANEL=0 -> round 1's kernels
+int pn_gates_blocks(int H, int N);           // 12 cells per workgroup
+int pn_proj_blocks(int P, int N);            // 16 outputs
+int pn_bwd_a_blocks(int H, int N);           // 16 cells
+void launch_pn_gates(const FwdGateJobs& jobs, int total_blocks, hipStream_t s);
+void launch_pn_proj(const FwdProjJobs& jobs, int total_blocks, hipStream_t s);
+void launch_pn_bwd_a(const BwdAJobs& jobs, int total_blocks, hipStream_t s);
+size_t pn_bwd_b_plan(BwdBJobs& jobs, float* ws_base);        // fills ws/ldw/KG/kpg (chunks per slice)/ncg/nrg/blk_base_p/blk_base_r
+int pn_bwd_b_blocks(const BwdBJobs& jobs);
+void launch_pn_bwd_b(const BwdBJobs& jobs, hipStream_t s);   // partial tiles + k_bwd_b_red
 
 // ---------------------------------------------------------------- batched GEMM
 // C[M,N] (+)= A.B (+bias)(lrelu).  a_kc: A(m,k)=A[m*lda+k] else A[k*lda+m];

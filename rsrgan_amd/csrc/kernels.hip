@@ -711,6 +711,11 @@ void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s) {
   hipLaunchKernelGGL(k_bwd_bp, dim3(bp), dim3(512), lds, s, jobs);
   hipLaunchKernelGGL(k_bwd_b_red, dim3(br), dim3(256), 0, s, jobs);
 }
+void launch_bwd_b_red(const BwdBJobs& jobs, hipStream_t s) {
+  int br = 0;
+  for (int i = 0; i < jobs.n; ++i) br = std::max(br, jobs.j[i].blk_base_r + (jobs.j[i].N * (jobs.j[i].n_end - jobs.j[i].n_begin) + 255) / 256);
+  hipLaunchKernelGGL(k_bwd_b_red, dim3(br), dim3(256), 0, s, jobs);
+}
 
 // total blocks of a job list and blk_base assignment happen on the host (model.cpp); `kb_max` is
 // the largest k-block count over the jobs, which picks the K split.

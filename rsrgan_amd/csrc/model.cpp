@@ -44,6 +44,49 @@ int ParamSet::add(const std::string& name, int rows, int cols, bool is_vector) {
   return (int)t.size() - 1;
 }
 
+// ------------------------------------------------------------------------------------------ hipGraph segments
+static inline uint64_t seg_key(int seg, int T, unsigned bits) { return ((uint64_t)seg << 48) | ((uint64_t)(unsigned)T << 16) | (bits & 0xffffu); }
+enum { SEG_D = 1, SEG_G_MAIN = 2, SEG_G_FCIN = 3, SEG_G_LAYER0 = 4 /* .. + MAXJ */, SEG_G_L2 = 20, SEG_G_TAIL = 21, SEG_APPLY_D = 22, SEG_APPLY_G = 23 };
+
+template <class F>
+void Model::run_seg(uint64_t key, hipStream_t s, F&& body) {
+  if (!graphs_on() || s == nullptr) { body(); return; }
+  if (graphs.size() > 96) drop_graphs();                   // many distinct T (length-bucketed training): start over
+  GraphSlot& g = graphs[key];
+  if (g.exec) { if (hipGraphLaunch(g.exec, s) != hipSuccess) { (void)hipGetLastError(); g.exec = nullptr; g.uses = -1; body(); } return; }
+  if (g.uses < 0) { body(); return; }                       // capture failed once: eager from then on
+  if (g.uses++ == 0) { body(); return; }                    // first use: eager (also runs every lazy one-time setup)
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); g.uses = -1; body(); return; }
+  body();
+  hipGraph_t gr = nullptr;
+  if (hipStreamEndCapture(s, &gr) != hipSuccess || !gr) { (void)hipGetLastError(); g.uses = -1; body(); return; }
+  hipGraphExec_t ex = nullptr;
+  if (hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0) != hipSuccess || !ex) { (void)hipGetLastError(); (void)hipGraphDestroy(gr); g.uses = -1; body(); return; }
+  (void)hipGraphDestroy(gr);
+  g.exec = ex;
+  if (hipGraphLaunch(g.exec, s) != hipSuccess) { (void)hipGetLastError(); (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; g.uses = -1; body(); }
+}
+void Model::drop_graphs() {
+  for (auto& kv : graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+  graphs.clear();
+}
+hipStream_t Model::enter(hipStream_t caller) {
+  if (caller != nullptr || !main_s) return caller;
+  (void)hipEventRecord(ev_in, caller);
+  (void)hipStreamWaitEvent(main_s, ev_in, 0);
+  return main_s;
+}
+void Model::leave(hipStream_t caller, hipStream_t work) {
+  if (work == caller) return;
+  (void)hipEventRecord(ev_out, work);
+  (void)hipStreamWaitEvent(caller, ev_out, 0);
+}
+const float* Model::stage_noise(const float* src, float* buf, hipStream_t s) {
+  if (!src) return nullptr;
+  (void)hipMemcpyAsync(buf, src, (size_t)B * Dout * sizeof(float), hipMemcpyDeviceToDevice, s);
+  return buf;
+}
+
 template <typename T>
 T* Model::alloc(size_t n) {
   void* p = nullptr;
@@ -309,6 +352,12 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   const int dmaxld = std::max(ldPd, ldDout);
   d_dA = alloc<float>(TB2 * dmaxld); d_dB = alloc<float>(TB2 * dmaxld);
   len_dev = alloc<int>(2 * B);
+  zeros = alloc<float>(64);
+  noise_r_buf = alloc<float>((size_t)B * Dout); noise_f_buf = alloc<float>((size_t)B * Dout);
+  if (const char* e = getenv("RSRGAN_GRAPHS")) graphs_env = atoi(e) != 0;
+  if (hipStreamCreateWithFlags(&main_s, hipStreamNonBlocking) != hipSuccess) main_s = nullptr;
+  if (main_s && (hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) != hipSuccess ||
+                 hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) != hipSuccess)) { (void)hipStreamDestroy(main_s); main_s = nullptr; }
   dyn = alloc<float>(DYN_COUNT); adam_t_dev = alloc<int>(1);
   losses = alloc<float>(8); tmp3 = alloc<float>(4);
   size_t maxcols = 7 * (size_t)std::max(c.g_cells, c.d_cells);
@@ -368,6 +417,14 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
 }
 
 void Model::destroy() {
+  drop_graphs();
+  if (main_s) {
+    (void)hipStreamSynchronize(main_s);
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_out) (void)hipEventDestroy(ev_out);
+    (void)hipStreamDestroy(main_s);
+    main_s = nullptr;
+  }
   if (side) {
     (void)hipStreamSynchronize(side);
     for (auto& e : ev_pool) if (e) (void)hipEventDestroy(e);
@@ -466,6 +523,7 @@ bool Model::bwd_b_splitk_ok(const BwdBJobs& jobs) const {
     if ((tmp.j[i].kpg + 1) / 2 > 12) return false;       // k_bwd_bp holds <= 12 k-blocks of weights per wave
     blocks += tmp.j[i].KG * tmp.j[i].ncg * tmp.j[i].nrg;
   }
+  if (panel_kernels() && pn_bwd_b_plan(tmp, nullptr) > bwdb_ws_floats) return false;
   return blocks >= 96;          // small launches (the discriminator alone): one 32x16-tile launch is faster (9.3 vs 10.4 us)
 }
 
@@ -547,8 +605,26 @@ static void fill_bwd_b(BwdBJob& b, const LayerRun& R, int t, bool with_dx) {
   b.nblk_c = (b.n_end - b.n_begin + 15) / 16;
 }
 
+// round 2: the panel kernels (panel.hip) unless RSRGAN_PANEL=0; same job structs, different block decomposition
+int Model::gates_blocks(int H, int N) const { return panel_kernels() ? pn_gates_blocks(H, N) : job_blocks((H + 15) / 16, N, fwd_gates_rows()); }
+int Model::proj_blocks(int P, int N) const { return panel_kernels() ? pn_proj_blocks(P, N) : job_blocks((P + 15) / 16, N); }
+int Model::bwd_a_blocks(int H, int N) const { return panel_kernels() ? pn_bwd_a_blocks(H, N) : job_blocks((H + 15) / 16, N); }
+static void run_gates(const FwdGateJobs& gj, int blocks, int kb, hipStream_t s) {
+  if (panel_kernels()) launch_pn_gates(gj, blocks, s); else launch_fwd_gates(gj, blocks, kb, s);
+}
+static void run_proj(const FwdProjJobs& pj, int blocks, int kb, hipStream_t s) {
+  if (panel_kernels()) launch_pn_proj(pj, blocks, s); else launch_fwd_proj(pj, blocks, kb, s);
+}
+static void run_bwd_a(const BwdAJobs& aj, int blocks, int kb, hipStream_t s) {
+  if (panel_kernels()) launch_pn_bwd_a(aj, blocks, s); else launch_bwd_a(aj, blocks, kb, s);
+}
+void Model::run_bwd_b_splitk(BwdBJobs& bj, hipStream_t s) {
+  if (panel_kernels()) { pn_bwd_b_plan(bj, bwdb_ws); launch_pn_bwd_b(bj, s); }
+  else { bwd_b_plan(bj, bwdb_ws); launch_bwd_b_splitk(bj, s); }
+}
+
 void Model::gates_launch(const FwdGateJobs& gj, int blocks, int kb, hipStream_t s) {
-  if (!prof_on) { launch_fwd_gates(gj, blocks, kb, s); return; }
+  if (!prof_on) { run_gates(gj, blocks, kb, s); return; }
   if ((size_t)(2 * prof_n + 2) > prof_ev.size()) {
     const size_t old = prof_ev.size();
     prof_ev.resize(old + 128, nullptr);
@@ -559,7 +635,7 @@ void Model::gates_launch(const FwdGateJobs& gj, int blocks, int kb, hipStream_t 
     prof_flops += 2.0 * J.N * ((J.x ? J.ldx : 0) + J.ldm) * 4.0 * J.H;
   }
   (void)hipEventRecord(prof_ev[2 * prof_n], s);
-  launch_fwd_gates(gj, blocks, kb, s);
+  run_gates(gj, blocks, kb, s);
   (void)hipEventRecord(prof_ev[2 * prof_n + 1], s);
   ++prof_n;
 }
@@ -587,13 +663,13 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
         const bool zx = R.Ns == R.N && R.row0 == 0;          // rows contiguous over time -> batch the x-part
         if (zx) zx_gemm(R);
         for (int t = 0; t < T; ++t) {
-          FwdGateJobs gj{}; gj.n = 1; gj.forget_bias = cfg.forget_bias;
+          FwdGateJobs gj{}; gj.n = 1; gj.forget_bias = cfg.forget_bias; gj.zeros = zeros;
           fill_gate(gj.j[0], R, t, zx); gj.j[0].blk_base = 0;
-          gates_launch(gj, job_blocks(gj.j[0].nblk_c, R.N, fwd_gates_rows()), (zx ? 0 : kb16(R.L->ldI)) + kb16(R.L->ldP), s);
+          gates_launch(gj, gates_blocks(R.L->H, R.N), (zx ? 0 : kb16(R.L->ldI)) + kb16(R.L->ldP), s);
           if (R.L->has_proj) {
-            FwdProjJobs pj{}; pj.n = 1;
+            FwdProjJobs pj{}; pj.n = 1; pj.zeros = zeros;
             fill_proj(pj.j[0], R, t); pj.j[0].blk_base = 0;
-            launch_fwd_proj(pj, job_blocks(pj.j[0].nblk_c, R.N), kb16(R.L->ldH), s);
+            run_proj(pj, proj_blocks(R.L->P, R.N), kb16(R.L->ldH), s);
           }
         }
       }
@@ -609,12 +685,12 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
   if (fcs)
     for (auto& F : *fcs) last = std::max(last, F.offset + T - 1);
   for (int d = 0; d <= last; ++d) {
-    FwdGateJobs gj{}; gj.forget_bias = cfg.forget_bias;
-    FwdProjJobs pj{};
+    FwdGateJobs gj{}; gj.forget_bias = cfg.forget_bias; gj.zeros = zeros;
+    FwdProjJobs pj{}; pj.zeros = zeros;
     int gb = 0, pb = 0, gk = 0, pk = 0;
     // a diagonal's jobs only depend on earlier diagonals, so they may be split over several launches
     auto flush_g = [&]() { if (gj.n) gates_launch(gj, gb, gk, s); gj.n = 0; gb = gk = 0; };
-    auto flush_p = [&]() { if (pj.n) launch_fwd_proj(pj, pb, pk, s); pj.n = 0; pb = pk = 0; };
+    auto flush_p = [&]() { if (pj.n) run_proj(pj, pb, pk, s); pj.n = 0; pb = pk = 0; };
     for (size_t c = 0; c < chains.size(); ++c) {
       Chain& ch = chains[c];
       const int off = offsets ? (*offsets)[c] : 0;
@@ -623,7 +699,7 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
         if (t < 0 || t >= T) continue;
         const LayerRun& R = ch[l];
         if (gj.n == MAXJ) flush_g();
-        FwdGateJob& a = gj.j[gj.n++]; fill_gate(a, R, t, R.zx_batched); a.blk_base = gb; gb += job_blocks(a.nblk_c, R.N, fwd_gates_rows());
+        FwdGateJob& a = gj.j[gj.n++]; fill_gate(a, R, t, R.zx_batched); a.blk_base = gb; gb += gates_blocks(R.L->H, R.N);
         gk = std::max(gk, (R.zx_batched ? 0 : kb16(R.L->ldI)) + kb16(R.L->ldP));
       }
     }
@@ -637,7 +713,7 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
         const LayerRun& R = ch[l];
         if (!R.L->has_proj) continue;
         if (pj.n == MAXJ) flush_p();
-        FwdProjJob& p = pj.j[pj.n++]; fill_proj(p, R, t); p.blk_base = pb; pb += job_blocks(p.nblk_c, R.N);
+        FwdProjJob& p = pj.j[pj.n++]; fill_proj(p, R, t); p.blk_base = pb; pb += proj_blocks(R.L->P, R.N);
         pk = std::max(pk, kb16(R.L->ldH));
       }
     }
@@ -646,7 +722,7 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
         const int t = d - F.offset;
         if (t < 0 || t >= T) continue;
         if (pj.n == MAXJ) flush_p();
-        FwdProjJob& p = pj.j[pj.n++]; fill_fc_fwd(p, F, t); p.blk_base = pb; pb += job_blocks(p.nblk_c, F.N);
+        FwdProjJob& p = pj.j[pj.n++]; fill_fc_fwd(p, F, t); p.blk_base = pb; pb += proj_blocks(F.D, F.N);
         pk = std::max(pk, kb16(F.ld_in));
       }
     flush_p();
@@ -698,10 +774,10 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
       for (int l = (int)ch.size() - 1; l >= 0; --l) {
         const LayerRun& R = ch[l];
         for (int t = T - 1; t >= 0; --t) {
-          BwdAJobs aj{}; aj.n = 1; fill_bwd_a(aj.j[0], R, t); aj.j[0].blk_base = 0;
-          launch_bwd_a(aj, job_blocks(aj.j[0].nblk_c, R.N), kb16(R.L->ldP), s);
-          BwdBJobs bj{}; bj.n = 1; fill_bwd_b(bj.j[0], R, t, false); bj.j[0].blk_base = 0;
-          if (bwd_b_splitk_ok(bj)) { bwd_b_plan(bj, bwdb_ws); launch_bwd_b_splitk(bj, s); }
+          BwdAJobs aj{}; aj.n = 1; aj.zeros = zeros; fill_bwd_a(aj.j[0], R, t); aj.j[0].blk_base = 0;
+          run_bwd_a(aj, bwd_a_blocks(R.L->H, R.N), kb16(R.L->ldP), s);
+          BwdBJobs bj{}; bj.n = 1; bj.zeros = zeros; fill_bwd_b(bj.j[0], R, t, false); bj.j[0].blk_base = 0;
+          if (bwd_b_splitk_ok(bj)) run_bwd_b_splitk(bj, s);
           else launch_bwd_b(bj, job_blocks(bj.j[0].nblk_c, R.N, kb16(4 * R.L->H) <= 64 ? 16 : 32), kb16(4 * R.L->H), s);
         }
         if (R.want_wgrads) layer_wgrads(R, T, s);
@@ -729,11 +805,12 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
   auto chunk_hi = [&](int c) { return T - (c * T) / nchunk; };
   for (int d = 0; d <= last; ++d) {
     BwdAJobs aj{}; BwdBJobs bj{};
+    aj.zeros = zeros; bj.zeros = zeros;
     int ab = 0, bb = 0, ak = 0, bk = 0;
-    auto flush_a = [&]() { if (aj.n) launch_bwd_a(aj, ab, ak, s); aj.n = 0; ab = ak = 0; };
+    auto flush_a = [&]() { if (aj.n) run_bwd_a(aj, ab, ak, s); aj.n = 0; ab = ak = 0; };
     auto flush_b = [&]() {
       if (bj.n) {
-        if (bwd_b_splitk_ok(bj)) { bwd_b_plan(bj, bwdb_ws); launch_bwd_b_splitk(bj, s); }
+        if (bwd_b_splitk_ok(bj)) run_bwd_b_splitk(bj, s);
         else {
           const int rows = bk <= 64 ? 16 : 32;        // small-K launches use 16-row tiles
           int base = 0;
@@ -750,7 +827,7 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
         const int t = T - 1 - (d - off - (Lc - 1 - l));
         if (t < 0 || t >= T) continue;
         if (aj.n == MAXJ) flush_a();
-        BwdAJob& a = aj.j[aj.n++]; fill_bwd_a(a, ch[l], t); a.blk_base = ab; ab += job_blocks(a.nblk_c, ch[l].N);
+        BwdAJob& a = aj.j[aj.n++]; fill_bwd_a(a, ch[l], t); a.blk_base = ab; ab += bwd_a_blocks(ch[l].L->H, ch[l].N);
         ak = std::max(ak, kb16(ch[l].L->ldP));
       }
     }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/rsrgan.h"
@@ -114,6 +115,7 @@ struct Model {
   std::vector<LstmStash> d_st;
   float *d_dA = nullptr, *d_dB = nullptr, *last_dx0 = nullptr;
   int *len_dev = nullptr;        // [2B]: lengths duplicated for the real|fake stacked batch
+  float *zeros = nullptr;        // 256 B of zeros: DMA source of the panel kernels for padding / masked rows
   // fully-connected stacks: models/dnn.py generator and models/discriminator_dnn.py discriminator
   std::vector<FcLayer> gfc, dfc;
   std::vector<float*> g_act, d_act;        // act[l] = input of FC layer l, act[L] = output of the stack
@@ -204,6 +206,10 @@ struct Model {
   int prof_n = 0;
   double prof_flops = 0.0;
   void gates_launch(const FwdGateJobs& gj, int blocks, int kb, hipStream_t s);
+  int gates_blocks(int H, int N) const;
+  int proj_blocks(int P, int N) const;
+  int bwd_a_blocks(int H, int N) const;
+  void run_bwd_b_splitk(BwdBJobs& bj, hipStream_t s);
   hipEvent_t ev_pool[16] = {};
   int ev_next = 0;
   float* gemm_ws2 = nullptr;
@@ -221,6 +227,25 @@ struct Model {
   bool bwd_b_splitk_ok(const BwdBJobs& jobs) const;
   float* gemm_ws = nullptr;
   size_t gemm_ws_floats = 0;
+
+  // ---- hipGraph replay (RSRGAN_FLAG_GRAPH): for a given T the launch sequence of a step is static (device pointers of the
+  // model's own buffers, job tables by value, scalars read from device memory), so each segment is run eagerly once, captured
+  // on its second use and replayed afterwards: ~1.6 us per dependent kernel on the GPU instead of a host-bound 3-4.6 us per
+  // eager launch (profiles/r2_ubench_launch_l2_barrier.txt).  Caller-owned pointers never enter a graph: inputs are packed
+  // into the model's buffers before, losses are copied out after.  The legacy null stream cannot be captured: work handed
+  // to it runs on an internal stream, ordered against the caller's stream by events (enter / leave).
+  struct GraphSlot { int uses = 0; hipGraphExec_t exec = nullptr; };
+  std::unordered_map<uint64_t, GraphSlot> graphs;
+  hipStream_t main_s = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  float *noise_r_buf = nullptr, *noise_f_buf = nullptr;      // staged gaussian_noise_layer draws [B][Dout]
+  bool graphs_on() const { return (cfg.flags & RSRGAN_FLAG_GRAPH) != 0 && wavefront() && !overlap() && !prof_on && !g_dnn() && graphs_env; }
+  bool graphs_env = true;
+  template <class F> void run_seg(uint64_t key, hipStream_t s, F&& body);
+  void drop_graphs();
+  hipStream_t enter(hipStream_t caller);
+  void leave(hipStream_t caller, hipStream_t work);
+  const float* stage_noise(const float* src, float* buf, hipStream_t s);
 
   template <typename T> T* alloc(size_t n);
 };

@@ -79,6 +79,7 @@ class HipEngine:
         self._grad_views = {}
         self._comm_stream = None
         self.d_has_adam = g_type in ("dnn", "rced")
+        self.ema_enabled = ema_decay > 0          # no EMA shadow buffers in the library otherwise (WHAT['ema'] is absent)
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:
@@ -192,10 +193,25 @@ class HipEngine:
         rdist.all_reduce_mean_buckets_(view, buckets, group, wait_bucket, self._comm_stream)   # joins before rsrgan_apply
 
     # -- the path ----------------------------------------------------------------------
+    def _check_batch(self, x, lab=None, ln=None):
+        """The library reads and writes exactly batch_size x T x input_dim / output_dim elements behind the raw pointers:
+        refuse anything else here (the reference's placeholders have these static shapes, gan_rnn_placeholder.py:94-104)."""
+        if x.dim() != 3 or x.shape[0] != self.batch_size or x.shape[2] != self.input_dim:
+            raise ValueError("inputs must be [batch_size=%d, T, input_dim=%d], got %s" % (self.batch_size, self.input_dim, tuple(x.shape)))
+        T = x.shape[1]
+        if not 0 < T <= self.max_frames:
+            raise ValueError("T=%d outside (0, max_frames=%d]" % (T, self.max_frames))
+        if lab is not None and tuple(lab.shape) != (self.batch_size, T, self.output_dim):
+            raise ValueError("labels must be [%d, %d, %d], got %s" % (self.batch_size, T, self.output_dim, tuple(lab.shape)))
+        if ln is not None and ln.numel() != self.batch_size:
+            raise ValueError("lengths must hold batch_size=%d entries, got %d" % (self.batch_size, ln.numel()))
+        return T
+
     def forward_g(self, x, lengths) -> torch.Tensor:
         x = self._f32(x)
-        B, T, _ = x.shape
         ln = self._i32(lengths) if lengths is not None else None
+        T = self._check_batch(x, None, ln)
+        B = self.batch_size
         y = torch.empty(B, T, self.output_dim, dtype=torch.float32, device=self.device)
         check(self.lib.rsrgan_forward_g(self.h, _ptr(x), _ptr(ln), T, _ptr(y), self._stream()))
         return y
@@ -205,7 +221,7 @@ class HipEngine:
         ln = self._i32(lengths) if lengths is not None else None
         nr, nf = self._noise(noise_real), self._noise(noise_fake)
         out = torch.empty(3, dtype=torch.float32, device=self.device)
-        T = x.shape[1]
+        T = self._check_batch(x, lab, ln)
         if apply or not train:
             check(self.lib.rsrgan_d_step(self.h, _ptr(x), _ptr(lab), _ptr(ln), T, _ptr(nr), _ptr(nf), _ptr(out),
                                          1 if train else 0, self._stream()))
@@ -220,7 +236,7 @@ class HipEngine:
         ln = self._i32(lengths) if lengths is not None else None
         nf = self._noise(noise_fake)
         out = torch.empty(4, dtype=torch.float32, device=self.device)
-        T = x.shape[1]
+        T = self._check_batch(x, lab, ln)
         if apply or not train:
             check(self.lib.rsrgan_g_step(self.h, _ptr(x), _ptr(lab), _ptr(ln), T, _ptr(nf), _ptr(out),
                                          1 if train else 0, 1 if reuse else 0, self._stream()))

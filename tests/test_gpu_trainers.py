@@ -122,7 +122,10 @@ def test_training_converges_on_a_learnable_task():
 
 @pytest.mark.parametrize("N,gan,ctx,width", [(6, False, (2, 1), 9), (37, False, (2, 1), 9), (6, True, (2, 1), 9),
                                               (5, False, (1, 1), 9), (5, True, (2, 2), 21), (3, False, (1, 1), 200),
-                                              (3, False, (1, 1), -11), (2, True, (5, 5), -40)])     # width < 0: the reference's filter table
+                                              (3, False, (1, 1), -11), (2, True, (5, 5), -40),
+                                              # BASELINE.json configs[3]'s own frame shape: 257-dim LPS x splice 11 (4 strips of 65 columns),
+                                              # the reference's filter table (models/rced.py:90-114), supervised and with discriminator_dnn
+                                              (2, False, (5, 5), -257), (3, True, (5, 5), -257)])     # width < 0: the reference's filter table
 def test_rced_generator_matches_oracle(N, gan, ctx, width):
     """models/rced.py under DNNTrainer (and, as BASELINE.json's config 4 words it, paired with discriminator_dnn): conv2d SAME as
     patch-matrix GEMMs on the HIP path vs the fp64 oracle (tower losses, every gradient tensor, Adam steps, variables)."""
@@ -177,3 +180,51 @@ def test_rced_generator_matches_oracle(N, gan, ctx, width):
     gv, _ = m.get_vars()
     for k in o.g:
         assert gv[k].shape == o.g[k].shape and rel_err(gv[k], o.g[k]) < 1e-3, k
+
+
+def test_rced_gan_full_size_properties():
+    """BASELINE.json configs[3] at its full size (R-CED on 257-dim LPS +-5 frames + discriminator_dnn 297-4x1024-1, N = 6400 frames =
+    B 64 x T 100): too big for the fp64 oracle, so size-independent properties: finite losses, tower-mean linearity (the gradient
+    of a batch of 6400 frames is the mean of the gradients of its two halves of 3200; models/gan.py:158-175 means
+    over frames), and permutation invariance of the frame order."""
+    import torch
+    from rsrgan_amd import GAN
+
+    class RcedGan(GAN):
+        G_TYPES = ("dnn", "rced")
+
+    def model(n):
+        args = SimpleNamespace(batch_size=n, input_dim=257, output_dim=40, left_context=5, right_context=5, g_type="rced", keep_prob=1.0,
+                               batch_norm=False, num_gpu=1, save_dir=None, l2_scale=0.0, g_learning_rate=1e-3, d_learning_rate=1e-4,
+                               init_mse_weight=10.0, disc_updates=1, gen_updates=1)
+        return RcedGan(None, args, ["gpu:0"], seed=4321)
+
+    N = 6400
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((N, 1, 257 * 11)).astype(np.float32); lab = rng.standard_normal((N, 1, 40)).astype(np.float32)
+    big = model(N)
+    dl = big.engine.d_backward(x, lab, None, train=True, apply=False).cpu().numpy()
+    gd = big.engine.get_grads(1).cpu().numpy().copy()
+    gl = big.engine.g_backward(x, lab, None, train=True, reuse=True, apply=False).cpu().numpy()
+    gg = big.engine.get_grads(NET_G).cpu().numpy().copy()
+    assert np.all(np.isfinite(dl)) and np.all(np.isfinite(gl)) and np.all(np.isfinite(gg)) and np.all(np.isfinite(gd))
+    # permutation of the frames: same losses and gradients up to fp32 summation order
+    perm = rng.permutation(N)
+    dl_p = big.engine.d_backward(x[perm], lab[perm], None, train=True, apply=False).cpu().numpy()
+    gl_p = big.engine.g_backward(x[perm], lab[perm], None, train=True, reuse=True, apply=False).cpu().numpy()
+    gg_p = big.engine.get_grads(NET_G).cpu().numpy()
+    assert np.allclose(dl, dl_p, rtol=1e-4) and np.allclose(gl, gl_p, rtol=1e-4), (dl, dl_p, gl, gl_p)
+    assert rel_err(gg_p, gg) < 1e-3
+    gv, dv = big.get_vars()
+    del big
+    torch.cuda.empty_cache()
+    half = model(N // 2)
+    half.set_vars(gv, dv)
+    acc_l = np.zeros(4); acc_g = np.zeros_like(gg, dtype=np.float64); acc_dl = np.zeros(3)
+    for k in range(2):
+        sl = slice(k * N // 2, (k + 1) * N // 2)
+        acc_dl += half.engine.d_backward(x[sl], lab[sl], None, train=True, apply=False).cpu().numpy() / 2
+        acc_l += half.engine.g_backward(x[sl], lab[sl], None, train=True, reuse=True, apply=False).cpu().numpy() / 2
+        acc_g += half.engine.get_grads(NET_G).cpu().numpy() / 2
+    assert np.allclose(acc_dl, dl, rtol=1e-4) and np.allclose(acc_l, gl, rtol=1e-4), (acc_dl, dl, acc_l, gl)
+    assert rel_err(acc_g, gg) < 1e-3
