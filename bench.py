@@ -53,26 +53,60 @@ def synthetic(B, T, din, dout, seed=1234):
     return x, lab, ln
 
 
-def cpu_baseline(net, B, T, budget_s=12.0):
-    """The oracle's torch-CPU twin timed on this box's host cores on a bounded sample of the SAME
-    workload (kind 'port': the reference's TF-1.4 path cannot run here)."""
+def _usable_cpus():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (os.cpu_count() reports the
+    host's cores even inside a quota-limited container, and one torch thread per reported core then oversubscribes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _cpu_run(net, B, T, threads, budget_s, max_steps):
+    """`max_steps` (or as many as fit `budget_s`, at least one) full (1D+1G) steps of the oracle's torch-CPU twin."""
     from oracle import rsrgan_oracle as O
     from oracle import torch_twin as TT
+    torch.set_num_threads(threads)
     cfg = O.NetCfg() if net == "lstm" else O.NetCfg.res_lstm_l()
     g = O.xavier_init(O.g_param_specs(cfg), np.random.default_rng(4321), np.float32)
     d = O.xavier_init(O.d_param_specs(cfg), np.random.default_rng(4322), np.float32)
     tw = TT.GanRnnTorchTwin(cfg, g, d)
     x, lab, ln = synthetic(B, T, cfg.input_dim, cfg.output_dim)
-    # the per-step GEMMs are tiny (M = 64): all 128+ hardware threads oversubscribe (measured 284
-    # frames/s at 128 threads vs ~1.6k at 8), so the baseline uses min(16, cores) threads
-    threads = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
     t0 = time.time(); n = 0
     while True:
         tw.d_step(x, lab, ln); tw.g_step(x, lab, ln); n += 1
-        if n >= 12 or time.time() - t0 > budget_s:        # a bounded sample: about 10-15 s of CPU work
+        if n >= max_steps or time.time() - t0 > budget_s:
             break
-    dt = time.time() - t0
+    return n, time.time() - t0
+
+
+def cpu_baseline(net, B, T, budget_s=9.0):
+    """The oracle's torch-CPU twin timed on this box's host cores on a bounded sample of the SAME workload (kind 'port': the
+    reference's TF-1.4 path cannot run here), at min(16, cores) threads (the headline: the per-step GEMMs have M = 64 rows and
+    stop scaling there), at 1 thread and at all usable cores.  The 1-thread and all-core legs run in child
+    processes with a hard time limit (one thread per core on M = 64 GEMMs can take minutes per step on a many-core host)."""
+    import subprocess
+    ncpu = _usable_cpus()
+    head = min(16, ncpu)
+    n, dt = _cpu_run(net, B, T, head, budget_s, 12)
+
+    def child(threads, limit_s):
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "%s,%d,%d,%d" % (net, B, T, threads)]
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=limit_s, env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
+            r = json.loads(out.stdout.strip().splitlines()[-1])
+            return {"value": round(B * T * r["steps"] / r["seconds"], 1), "cores": threads, "sample": "%d step(s)" % r["steps"]}
+        except subprocess.TimeoutExpired:
+            return {"value": None, "cores": threads, "sample": "one step did not finish within %d s" % limit_s}
+        except Exception as e:           # never lose the bench line to a baseline leg
+            return {"value": None, "cores": threads, "sample": "failed: %s" % str(e)[:120]}
+
+    one = child(1, 75)
+    allc = ({"value": round(B * T * n / dt, 1), "cores": ncpu, "sample": "%d steps" % n} if ncpu == head else child(ncpu, 45))
     model_name = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -80,9 +114,10 @@ def cpu_baseline(net, B, T, budget_s=12.0):
                 model_name = line.split(":", 1)[1].strip(); break
     except OSError:
         pass
-    return {"value": round(B * T * n / dt, 1), "unit": "frames/s", "cores": threads, "kind": "port",
+    return {"value": round(B * T * n / dt, 1), "unit": "frames/s", "cores": head, "kind": "port",
             "sample": "%d full (1D+1G) steps of the same [B=%d,T=%d] workload, oracle/torch_twin.py fp32, "
-                      "os.cpu_count=%s, cpu=%s" % (n, B, T, os.cpu_count(), model_name)}
+                      "os.cpu_count=%s, usable=%d, cpu=%s" % (n, B, T, os.cpu_count(), ncpu, model_name),
+            "one_core": one, "all_cores": allc}
 
 
 def measure_sequence(a, net, d_type, B, T, steps, warmup, rank, local, world, dev):
@@ -114,30 +149,33 @@ def measure_sequence(a, net, d_type, B, T, steps, warmup, rank, local, world, de
             out = model.g_step(x, lab, ln, reuse_g_forward=(i == 0), sync=False, gather=False)
         return out
 
-    for _ in range(warmup):
+    with model.engine.on_stream():             # one real stream for the whole loop (hipGraph replay; no null-stream hops)
+        for _ in range(warmup):
+            step()
+        rdist.barrier(); torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        ev[0].record()
+        for i in range(steps):
+            last = step()
+            ev[i + 1].record()
+        torch.cuda.synchronize(); rdist.barrier()
+        dt = time.perf_counter() - t0
+        dev_ms = ev[0].elapsed_time(ev[steps])
+        per_step = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+        med_ms = per_step[steps // 2]
+        if world > 1:
+            t = torch.tensor([dt, dev_ms], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt, dev_ms = float(t[0]), float(t[1])
+        losses = last.mean(0).cpu().numpy()
+        if not np.all(np.isfinite(losses)):
+            raise SystemExit("non-finite losses: %s" % losses)
+        # one more (untimed) step with every launch of the dominant kernel bracketed by HIP events on its stream
+        model.engine.profile_begin()
         step()
-    rdist.barrier(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(steps):
-        last = step()
-    e1.record()
-    torch.cuda.synchronize(); rdist.barrier()
-    dt = time.perf_counter() - t0
-    dev_ms = e0.elapsed_time(e1)
-    if world > 1:
-        t = torch.tensor([dt, dev_ms], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt, dev_ms = float(t[0]), float(t[1])
-    losses = last.mean(0).cpu().numpy()
-    if not np.all(np.isfinite(losses)):
-        raise SystemExit("non-finite losses: %s" % losses)
-    # one more (untimed) step with every launch of the dominant kernel bracketed by HIP events on its stream
-    model.engine.profile_begin()
-    step()
-    prof = model.engine.profile_read()
-    return dict(model=model, g_type=g_type, d_type=d_type, dt=dt, dev_ms=dev_ms, losses=losses, prof=prof)
+        prof = model.engine.profile_read()
+    return dict(model=model, g_type=g_type, d_type=d_type, dt=dt, dev_ms=dev_ms, med_ms=med_ms, losses=losses, prof=prof)
 
 
 def bench_dnn_gan(a, rank, local, world, dev):
@@ -160,6 +198,9 @@ def bench_dnn_gan(a, rank, local, world, dev):
     lab = torch.from_numpy(rng.standard_normal((N, 1, 40)).astype(np.float32)).to(dev)
     x2 = torch.from_numpy(rng.standard_normal((N, 1, 2827)).astype(np.float32)).to(dev)
     lab2 = torch.from_numpy(rng.standard_normal((N, 1, 40)).astype(np.float32)).to(dev)
+
+    import contextlib
+    stack = contextlib.ExitStack(); stack.enter_context(model.engine.on_stream())     # one real stream for every call below
 
     def step():
         if trainer:
@@ -199,6 +240,7 @@ def bench_dnn_gan(a, rank, local, world, dev):
                             "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
                             "scope": "all launches of one step; algorithmic %s = %d FLOP/frame" % ("3*F_G" if trainer else "4*F_G+8*F_D", fpf)}}
         print(json.dumps(out), flush=True)
+    stack.close()
     rdist.barrier()
 
 
@@ -226,6 +268,8 @@ def bench_rced(a, rank, local, world, dev):
     lab = torch.from_numpy(rng.standard_normal((N, 1, 40)).astype(np.float32)).to(dev)
     x2 = torch.from_numpy(rng.standard_normal((N, 1, S * W)).astype(np.float32)).to(dev)
     lab2 = torch.from_numpy(rng.standard_normal((N, 1, 40)).astype(np.float32)).to(dev)
+    import contextlib
+    stack = contextlib.ExitStack(); stack.enter_context(model.engine.on_stream())
     for _ in range(a.warmup):
         model.step(x, lab, sync=False)
     rdist.barrier(); torch.cuda.synchronize()
@@ -263,14 +307,15 @@ def bench_rced(a, rank, local, world, dev):
                             "scope": "all launches of one step; algorithmic %d FLOP/frame (%s x %d conv + FC GEMM terms%s)" % (
                                 fpf, "4" if a.rced_gan else "3", fl, " + 8 F_D" if a.rced_gan else "")}}
         print(json.dumps(out), flush=True)
+    stack.close()
     rdist.barrier()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--frames", type=int, default=100)
     ap.add_argument("--net", default="lstm", choices=["lstm", "res_lstm_l", "dnn_gan", "dnn_trainer", "baseline_named", "rced"],
@@ -281,14 +326,20 @@ def main():
     ap.add_argument("--gen-updates", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the BASELINE.json-named network variant at N=1")
-    ap.add_argument("--flags", type=int, default=int(os.environ.get("RSRGAN_FLAGS", "1")),
-                    help="library schedule flags: 1 = wavefront, 4 = side-stream GEMM overlap (include/rsrgan.h)")
+    ap.add_argument("--flags", type=int, default=int(os.environ.get("RSRGAN_FLAGS", "3")),
+                    help="library schedule flags: 1 = wavefront, 2 = hipGraph replay, 4 = side-stream GEMM overlap (include/rsrgan.h)")
     ap.add_argument("--rced-gan", action="store_true", help="--net rced: 1 D + 1 G step with discriminator_dnn instead of the supervised trainer")
     ap.add_argument("--rced-width", type=int, default=40, help="--net rced: frame width (run_dnn.sh:137 uses 40-dim MFCC input)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling (SURVEY 8d): --batch is the GLOBAL batch, split evenly over the ranks (default: weak, "
                          "--batch per GPU as the reference defines batch_size per tower)")
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)      # internal: net,B,T,threads -> one timed CPU-baseline leg
     a = ap.parse_args()
+    if a.cpu_worker:
+        net, B, T, th = a.cpu_worker.split(",")
+        n, dt = _cpu_run(net, int(B), int(T), int(th), 5.0, 2)
+        print(json.dumps({"steps": n, "seconds": dt}), flush=True)
+        return
 
     from rsrgan_amd import GAN_RNN, dist as rdist
     rank, local, world = rdist.init_from_env("nccl")
@@ -324,36 +375,55 @@ def main():
         step_dev_s = dev_ms * 1e-3 / a.steps
         roof = None
         traffic = None
-        tf_path = os.path.join(ROOT, "profiles", "r1_final_traffic.json")
-        if os.path.exists(tf_path) and a.net == "lstm" and a.d_type == "lstm" and (B, T, a.gen_updates) == (64, 100, 1):
-            traffic = json.load(open(tf_path)).get("hbm_bytes_per_step")     # PMC FETCH_SIZE(x2)+WRITE_SIZE of this workload
+        k_traffic = None
+        k_rocprof_us = None
+        headline = a.net == "lstm" and a.d_type == "lstm" and (B, T, a.gen_updates) == (64, 100, 1)
+        tf_path = os.path.join(ROOT, "profiles", "r2_final_traffic.json")
+        if headline and os.path.exists(tf_path):
+            # HBM-side bytes from the committed PMC passes of this workload (tools/traffic.sh: separate FETCH_SIZE / WRITE_SIZE
+            # passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); refused when the kernels have changed
+            # since (recorded ms/step more than 10 % away from this run)
+            tj = json.load(open(tf_path))
+            rec = tj.get("ms_per_step")
+            if rec and abs(rec - step_dev_s * 1e3) <= 0.10 * step_dev_s * 1e3:
+                traffic = tj.get("hbm_bytes_per_step")
+                f = [v for v in tj.get("top_fetch", []) if "k_fwd_gates" in v[0]]
+                w = [v for v in tj.get("top_write", []) if "k_fwd_gates" in v[0]]
+                if f and w and f[0][2] == w[0][2]:
+                    k_traffic = int((2 * f[0][1] + w[0][1]) * 1024 / f[0][2])
+        cs_path = os.path.join(ROOT, "profiles", "r2_final_rocprofv3_kernel_stats.csv")
+        if headline and os.path.exists(cs_path):
+            import csv
+            for row in csv.DictReader(open(cs_path)):
+                if "k_fwd_gates" in row["Name"]:
+                    k_rocprof_us = round(float(row["AverageNs"]) / 1e3, 3); break
         if fpf:
             ach = fpf * B * T / step_dev_s / 1e12          # per GPU, HIP-event time of the whole step's launches
             roof = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "scope": "all launches of one (1D+1G) step on one GPU; algorithmic %d FLOP/frame x %d frames "
                              "(SURVEY 8d: 3*F_G+8*F_D, F_G=%d, F_D=%d) / HIP-event step time; traffic = HBM-side bytes "
-                             "per step from profiles/r1_final_traffic.json" % (fpf, B * T, fg, fd)}
+                             "per step from profiles/r2_final_traffic.json (null when that file is stale)" % (fpf, B * T, fg, fd)}
             n_l, us_l, fl_l = res["prof"]
-            k_traffic = None
-            if traffic is not None:        # per-launch HBM-side bytes of the same kernel from the committed PMC passes
-                tj = json.load(open(tf_path))
-                f = [v for v in tj.get("top_fetch", []) if "k_fwd_gates" in v[0]]
-                w = [v for v in tj.get("top_write", []) if "k_fwd_gates" in v[0]]
-                if f and w and f[0][2] == w[0][2]:
-                    k_traffic = int((2 * f[0][1] + w[0][1]) * 1024 / f[0][2])
             if n_l:
+                # the step is GPU-bound (sum of rocprof kernel durations = wall, profiles/r2_gap_summary.txt), so the kernel's
+                # duration is what rocprofv3 reports; the live HIP-event bracket also contains the two event records and is
+                # an upper bound -- both are given, the roofline fraction uses the live one measured in THIS run
                 k_ach = fl_l / (us_l * 1e-6) / 1e12
                 roof["dominant_kernel"] = {
                     "name": "k_fwd_gates", "launches_per_step": n_l, "avg_us": round(us_l / n_l, 3),
+                    "rocprofv3_avg_us": k_rocprof_us,
                     "algorithmic_flop_per_launch": round(fl_l / n_l), "achieved": round(k_ach, 3), "unit": "TFLOP/s",
                     "frac": round(k_ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": k_traffic,
-                    "how": "every launch of one step bracketed by HIP events on its stream (rsrgan_profile_begin/read); "
-                           "the event-to-event time includes the ~2.7 us dispatch gap per launch that rocprofv3's kernel duration "
-                           "excludes: compare AverageNs of k_fwd_gates<18,2,1> in profiles/r1_final_rocprofv3_kernel_stats.csv (11.8 us)"}
+                    "frac_at_rocprofv3_duration": (round(fl_l / n_l / (k_rocprof_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
+                                                   if k_rocprof_us else None),
+                    "how": "avg_us: every launch of one extra step bracketed by HIP events on its stream (rsrgan_profile_begin/"
+                           "read; includes the event records, an upper bound); rocprofv3_avg_us: AverageNs of the same kernel in "
+                           "the committed profiles/r2_final_rocprofv3_kernel_stats.csv of this command"}
         out = {"metric": "GAN train frames/sec (G+D step), 257-dim LPS->40-dim MFCC", "value": round(value, 1),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(dt * 1e3 / a.steps, 4), "higher_is_better": True, "scaling": "strong" if a.strong else "weak",
+               "ms_per_step": round(dt * 1e3 / a.steps, 4), "ms_per_step_median": round(res["med_ms"], 4),
+               "higher_is_better": True, "scaling": "strong" if a.strong else "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "gan_rnn_placeholder 1D+%dG step, G=%s(%dx%d/p%d)+D=%s(%dx%d/p%d), B=%d/GPU T=%d, "
                                       "257->40" % (a.gen_updates, g_type, c.g_layers, c.g_cells, c.g_proj, a.d_type, c.d_layers,
@@ -378,6 +448,26 @@ def main():
                             "value": round(B * T * n2 / v["dt"], 1), "unit": "frames/s", "ms_per_step": round(v["dt"] * 1e3 / n2, 4),
                             "roofline_frac": round(f2 * B * T / (v["dev_ms"] * 1e-3 / n2) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                             "flop_per_frame": f2}]
+        # the shipped schedule: 1 D-run + 2 G-runs per batch (run_gan_rnn_placeholder.sh:129-130), reference-true networks
+        del v
+        torch.cuda.empty_cache()
+        a2 = argparse.Namespace(**vars(a)); a2.gen_updates = 2
+        v2 = measure_sequence(a2, "lstm", "lstm", B, T, n2, 2, rank, local, world, dev)
+        out["variants"].append({"workload": "shipped schedule 1D+2G per batch, reference-true networks, B=%d T=%d" % (B, T),
+                                "value": round(B * T * n2 / v2["dt"], 1), "unit": "frames/s", "ms_per_step": round(v2["dt"] * 1e3 / n2, 4)})
+        del v2
+        torch.cuda.empty_cache()
+        try:           # BASELINE.json configs[3]: R-CED (257 x 11) + discriminator_dnn, N = 6400 frames (bench.py --net rced --rced-gan)
+            import contextlib, io
+            a3 = argparse.Namespace(**vars(a)); a3.net = "rced"; a3.rced_gan = True; a3.rced_width = 257; a3.batch = 6400; a3.steps = 3; a3.warmup = 1
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                bench_rced(a3, rank, local, world, dev)
+            r3 = json.loads(buf.getvalue().strip().splitlines()[-1])
+            out["variants"].append({"workload": r3["config"]["workload"], "value": r3["value"], "unit": "frames/s",
+                                    "ms_per_step": r3["ms_per_step"], "roofline_frac": r3["roofline"]["frac"]})
+        except Exception as e:          # never lose the headline line to a variant
+            out["variants"].append({"workload": "R-CED + discriminator_dnn (configs[3])", "error": str(e)[:200]})
     if rank == 0:
         print(json.dumps(out), flush=True)
     rdist.barrier()

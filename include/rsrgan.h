@@ -220,10 +220,6 @@ int rsrgan_op_gemm(const float* A, int32_t lda, int32_t a_kcontig,
                    float* C, int32_t ldc, int32_t M, int32_t N, int32_t K,
                    const float* bias, int32_t act, float alpha, int32_t accumulate, void* stream);
 
-/* Micro-benchmark of one wavefront launch on random data (kernel-variant A/B; test tooling, not a
- * reference interface).  kind 3 = backward phase B; returns mean microseconds per launch. */
-int rsrgan_microbench(int32_t kind, int32_t variant, int32_t N, int32_t H, int32_t I, int32_t P, int32_t layers,
-                      int32_t reps, float* out_us);
 int rsrgan_version(void);
 
 #ifdef __cplusplus

@@ -21,7 +21,7 @@ SYMBOLS = ["rsrgan_default_cfg", "rsrgan_create", "rsrgan_destroy", "rsrgan_last
            "rsrgan_g_step", "rsrgan_d_backward", "rsrgan_g_backward", "rsrgan_apply", "rsrgan_grad_buffer",
            "rsrgan_grad_bucket_count", "rsrgan_grad_bucket_info", "rsrgan_grad_bucket_wait",
            "rsrgan_profile_begin", "rsrgan_profile_read",
-           "rsrgan_op_gemm", "rsrgan_microbench", "rsrgan_version"]
+           "rsrgan_op_gemm", "rsrgan_version"]
 
 
 class RsrganCfg(C.Structure):
@@ -77,7 +77,6 @@ def load():
     lib.rsrgan_profile_begin.argtypes = [vp]
     lib.rsrgan_profile_read.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.rsrgan_op_gemm.argtypes = [p, i32, i32, p, i32, i32, p, i32, i32, i32, i32, p, i32, f32, i32, vp]
-    lib.rsrgan_microbench.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(f32)]
     _lib = lib
     return lib
 

@@ -1,5 +1,6 @@
 // capi.cpp -- extern "C" entry points declared in include/rsrgan.h.
 #include <cstring>
+#include <exception>
 #include <new>
 #include <vector>
 
@@ -11,6 +12,29 @@ struct rsrgan_handle_s { Model m; };
 
 #define CHECK_H(h)                                                    \
   if (!(h)) { set_error("null handle"); return RSRGAN_ERR_INVALID; }
+
+// Nothing may throw across the C ABI (include/rsrgan.h): every entry point that can allocate host memory runs its body
+// through guard(), which turns std::bad_alloc / any other exception into RSRGAN_ERR_INVALID with a message.
+template <class F>
+static int guard(const char* what, F&& body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    set_error("%s: out of host memory", what);
+  } catch (const std::exception& e) {
+    set_error("%s: %s", what, e.what());
+  } catch (...) {
+    set_error("%s: unknown C++ exception", what);
+  }
+  return RSRGAN_ERR_INVALID;
+}
+// Work handed to the legacy null stream runs on the model's own stream (hipGraph capture needs a real stream), ordered
+// against the caller's stream by events on both sides.
+struct StreamScope {
+  Model& m; hipStream_t caller, work;
+  StreamScope(Model& m_, void* s) : m(m_), caller((hipStream_t)s), work(m_.enter((hipStream_t)s)) {}
+  ~StreamScope() { m.leave(caller, work); }
+};
 
 extern "C" {
 
@@ -44,25 +68,33 @@ int rsrgan_create(const rsrgan_cfg* cfg, uint64_t seed, rsrgan_handle* out) {
     set_error("no HIP device visible: librsrgan_hip needs an MI355X (gfx950); there is no CPU fallback");
     return RSRGAN_ERR_NO_DEVICE;
   }
-  rsrgan_handle h = new (std::nothrow) rsrgan_handle_s();
-  if (!h) { set_error("out of host memory"); return RSRGAN_ERR_INVALID; }
-  int rc = h->m.init(*cfg, seed);
-  if (rc != RSRGAN_OK) { h->m.destroy(); delete h; return rc; }
-  *out = h;
-  return RSRGAN_OK;
+  return guard("rsrgan_create", [&]() -> int {
+    rsrgan_handle h = new (std::nothrow) rsrgan_handle_s();
+    if (!h) { set_error("out of host memory"); return RSRGAN_ERR_INVALID; }
+    int rc = RSRGAN_ERR_INVALID;
+    try { rc = h->m.init(*cfg, seed); } catch (...) { h->m.destroy(); delete h; throw; }
+    if (rc != RSRGAN_OK) { h->m.destroy(); delete h; return rc; }
+    *out = h;
+    return RSRGAN_OK;
+  });
 }
 
 int rsrgan_destroy(rsrgan_handle h) {
   CHECK_H(h);
-  hipDeviceSynchronize();
-  h->m.destroy();
-  delete h;
-  return RSRGAN_OK;
+  return guard("rsrgan_destroy", [&]() -> int {
+    (void)hipDeviceSynchronize();
+    h->m.destroy();
+    delete h;
+    return RSRGAN_OK;
+  });
 }
 
 int rsrgan_set_scalar(rsrgan_handle h, int32_t which, double v) {
   CHECK_H(h);
   Model& m = h->m;
+  // the copies below are synchronous on the null stream; the step kernels that read these device scalars may still be queued on
+  // the model's own stream, so drain it first (scalars change once per iteration: train_gan_rnn_placeholder.py:63-64,525-533)
+  if (m.main_s && hipStreamSynchronize(m.main_s) != hipSuccess) { set_error("hipStreamSynchronize failed"); return RSRGAN_ERR_HIP; }
   int idx = -1;
   switch (which) {
     case RSRGAN_G_LEARNING_RATE: idx = DYN_G_LR; break;
@@ -143,7 +175,8 @@ static int copy_params(rsrgan_handle h, int net, int what, float* dense, bool to
   if (!p || !dense) { set_error("bad net / null pointer"); return RSRGAN_ERR_INVALID; }
   float* buf = which_buf(p, what);
   if (!buf) { set_error("buffer %d not present for net %d", what, net); return RSRGAN_ERR_INVALID; }
-  hipStream_t s = (hipStream_t)stream;
+  StreamScope sc(h->m, stream);
+  hipStream_t s = sc.work;
   for (const TensorDesc& t : p->t) launch_pad_copy(dense + t.dense_off, buf + t.off, t.rows, t.cols, t.ld, to_padded, s);
   if (to_padded && what == 0) {
     h->m.refresh_transposes(net, s);
@@ -167,46 +200,64 @@ int rsrgan_get_grads(rsrgan_handle h, int32_t net, float* dense, void* stream) {
 
 int rsrgan_forward_g(rsrgan_handle h, const float* x, const int32_t* lengths, int32_t T, float* y, void* stream) {
   CHECK_H(h);
-  Model& m = h->m;
-  hipStream_t s = (hipStream_t)stream;
-  if (!y) { set_error("null output"); return RSRGAN_ERR_INVALID; }
-  int rc = m.prepare_batch(x, nullptr, lengths, T, s);
-  if (rc) return rc;
-  m.g_forward(T, s);
-  m.g_fwd_valid = false;      // labels were not packed: the stash is not a valid training forward
-  launch_unpack_bm(m.y_tm, m.ldDout, y, m.B, T, m.Dout, s);
-  if (hipGetLastError() != hipSuccess) { set_error("kernel launch failed in forward_g"); return RSRGAN_ERR_HIP; }
-  return RSRGAN_OK;
+  return guard("rsrgan_forward_g", [&]() -> int {
+    Model& m = h->m;
+    if (!y) { set_error("null output"); return RSRGAN_ERR_INVALID; }
+    StreamScope sc(m, stream);
+    hipStream_t s = sc.work;
+    int rc = m.prepare_batch(x, nullptr, lengths, T, s);
+    if (rc) return rc;
+    m.g_forward(T, s);
+    m.g_fwd_valid = false;      // labels were not packed: the stash is not a valid training forward
+    launch_unpack_bm(m.y_tm, m.ldDout, y, m.B, T, m.Dout, s);
+    if (hipGetLastError() != hipSuccess) { set_error("kernel launch failed in forward_g"); return RSRGAN_ERR_HIP; }
+    return RSRGAN_OK;
+  });
 }
 
 int rsrgan_d_backward(rsrgan_handle h, const float* x, const float* labels, const int32_t* lengths, int32_t T,
                       const float* nr, const float* nf, float* out_losses, void* stream) {
   CHECK_H(h);
-  return h->m.d_backward(x, labels, lengths, T, nr, nf, out_losses, true, (hipStream_t)stream);
+  return guard("rsrgan_d_backward", [&]() -> int {
+    StreamScope sc(h->m, stream);
+    return h->m.d_backward(x, labels, lengths, T, nr, nf, out_losses, true, sc.work);
+  });
 }
 int rsrgan_g_backward(rsrgan_handle h, const float* x, const float* labels, const int32_t* lengths, int32_t T,
                       const float* nf, float* out_losses, int32_t reuse, void* stream) {
   CHECK_H(h);
-  return h->m.g_backward(x, labels, lengths, T, nf, out_losses, true, reuse != 0, (hipStream_t)stream);
+  return guard("rsrgan_g_backward", [&]() -> int {
+    StreamScope sc(h->m, stream);
+    return h->m.g_backward(x, labels, lengths, T, nf, out_losses, true, reuse != 0, sc.work);
+  });
 }
 int rsrgan_apply(rsrgan_handle h, int32_t net, void* stream) {
   CHECK_H(h);
-  return h->m.apply(net, (hipStream_t)stream);
+  return guard("rsrgan_apply", [&]() -> int {
+    StreamScope sc(h->m, stream);
+    return h->m.apply(net, sc.work);
+  });
 }
 
 int rsrgan_d_step(rsrgan_handle h, const float* x, const float* labels, const int32_t* lengths, int32_t T,
                   const float* nr, const float* nf, float* out_losses, int32_t train, void* stream) {
   CHECK_H(h);
-  int rc = h->m.d_backward(x, labels, lengths, T, nr, nf, out_losses, train != 0, (hipStream_t)stream);
-  if (rc || !train) return rc;
-  return h->m.apply(RSRGAN_NET_D, (hipStream_t)stream);
+  return guard("rsrgan_d_step", [&]() -> int {
+    StreamScope sc(h->m, stream);
+    int rc = h->m.d_backward(x, labels, lengths, T, nr, nf, out_losses, train != 0, sc.work);
+    if (rc || !train) return rc;
+    return h->m.apply(RSRGAN_NET_D, sc.work);
+  });
 }
 int rsrgan_g_step(rsrgan_handle h, const float* x, const float* labels, const int32_t* lengths, int32_t T,
                   const float* nf, float* out_losses, int32_t train, int32_t reuse, void* stream) {
   CHECK_H(h);
-  int rc = h->m.g_backward(x, labels, lengths, T, nf, out_losses, train != 0, reuse != 0, (hipStream_t)stream);
-  if (rc || !train) return rc;
-  return h->m.apply(RSRGAN_NET_G, (hipStream_t)stream);
+  return guard("rsrgan_g_step", [&]() -> int {
+    StreamScope sc(h->m, stream);
+    int rc = h->m.g_backward(x, labels, lengths, T, nf, out_losses, train != 0, reuse != 0, sc.work);
+    if (rc || !train) return rc;
+    return h->m.apply(RSRGAN_NET_G, sc.work);
+  });
 }
 
 int rsrgan_grad_buffer(rsrgan_handle h, int32_t net, float** ptr, int64_t* count) {
@@ -271,58 +322,6 @@ int rsrgan_op_gemm(const float* A, int32_t lda, int32_t a_kc, const float* B, in
   launch_gemm(A, lda, a_kc != 0, B, ldb, b_kc != 0, C, ldc, M, N, K, bias, act, alpha, accumulate != 0, (hipStream_t)stream,
               ws, ws ? ws_floats : 0);
   if (hipGetLastError() != hipSuccess) { set_error("op_gemm launch failed"); return RSRGAN_ERR_HIP; }
-  return RSRGAN_OK;
-}
-
-// Micro-benchmark of one wavefront launch (within-probe A/B of kernel variants; not part of the
-// drop-in surface).  kind 3 = backward phase B with `layers` jobs of (N rows, H cells, I inputs, P
-// proj) on random data; returns the mean microseconds per launch over `reps` launches.
-int rsrgan_microbench(int32_t kind, int32_t variant, int32_t N, int32_t H, int32_t I, int32_t P, int32_t layers,
-                      int32_t reps, float* out_us) {
-  if (kind == 5 && out_us) {     // flag exchange in groups: N = workgroups, H = group size, I = floats written per member, reps = iterations
-    const int rc = flagx_microbench(variant, N, reps, H, I, out_us);
-    if (rc == -2) { set_error("microbench: flag spin limit hit"); return RSRGAN_ERR_STATE; }
-    if (rc) { set_error("microbench: hipMalloc"); return RSRGAN_ERR_HIP; }
-    return RSRGAN_OK;
-  }
-  if (kind == 4 && out_us) {     // grid-barrier cost: N = workgroups, reps = barriers per launch, I = floats written per WG, P = floats read per WG
-    const int rc = gridbar_microbench(variant, N, reps, I, P, out_us);
-    if (rc == -2) { set_error("microbench: grid barrier spin limit hit (workgroups not co-resident?)"); return RSRGAN_ERR_STATE; }
-    if (rc) { set_error("microbench: hipMalloc"); return RSRGAN_ERR_HIP; }
-    return RSRGAN_OK;
-  }
-  if (kind != 3 || layers < 1 || layers > MAXJ || !out_us) { set_error("microbench: unsupported"); return RSRGAN_ERR_INVALID; }
-  const int H4 = 4 * H, ldI = pad4(I), ldP = pad4(P);
-  std::vector<void*> bufs;
-  auto dal = [&](size_t n, float v) { float* p = nullptr; if (hipMalloc((void**)&p, n * sizeof(float)) != hipSuccess) return (float*)nullptr; launch_fill(p, n, v, nullptr); bufs.push_back(p); return p; };
-  int* len = nullptr;
-  if (hipMalloc((void**)&len, N * sizeof(int)) != hipSuccess) { set_error("hipMalloc"); return RSRGAN_ERR_HIP; }
-  std::vector<int> hl(N, 1 << 20);
-  (void)hipMemcpy(len, hl.data(), N * sizeof(int), hipMemcpyHostToDevice);
-  BwdBJobs bj{};
-  int bb = 0;
-  for (int l = 0; l < layers; ++l) {
-    BwdBJob& b = bj.j[bj.n++];
-    b.dz = dal((size_t)N * H4, 0.01f * (l + 1)); b.K = dal((size_t)(I + P) * H4, 0.003f);
-    b.dx = dal((size_t)N * ldI, 0.f); b.dmst = dal((size_t)N * ldP, 0.f); b.len = len;
-    b.I = I; b.n_begin = 0; b.n_end = I + P; b.lddx = ldI; b.ldm = ldP; b.t = 0; b.N = N; b.H4 = H4; b.dx_accumulate = 0;
-    b.nblk_c = (I + P + 15) / 16; b.blk_base = bb; bb += job_blocks(b.nblk_c, N);
-    if (!b.dz || !b.K || !b.dx || !b.dmst) { set_error("hipMalloc"); return RSRGAN_ERR_HIP; }
-  }
-  hipEvent_t e0, e1;
-  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) launch_bwd_b_variant(bj, bb, variant, nullptr);
-  (void)hipEventRecord(e0, nullptr);
-  for (int i = 0; i < reps; ++i) launch_bwd_b_variant(bj, bb, variant, nullptr);
-  (void)hipEventRecord(e1, nullptr);
-  (void)hipEventSynchronize(e1);
-  float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, e0, e1);
-  *out_us = ms * 1000.f / reps;
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  for (void* p : bufs) (void)hipFree(p);
-  (void)hipFree(len);
-  if (hipGetLastError() != hipSuccess) { set_error("microbench launch failed"); return RSRGAN_ERR_HIP; }
   return RSRGAN_OK;
 }
 

@@ -34,7 +34,7 @@ struct FwdGateJob {
   // num_proj=None layers (m = h): the epilogue also writes the carried state, the masked output and the residual sum
   float* np_m_out; float* np_out; const float* np_res_in; float* np_res_out;
 };
-struct FwdGateJobs { int n; float forget_bias; const float* zeros; FwdGateJob j[MAXJ]; };   // zeros: >= 16 B of device zeros (panel.hip)
+struct FwdGateJobs { int n; float forget_bias; FwdGateJob j[MAXJ]; };
 
 // Forward phase 2: m_t = h_t . Wp ; dynamic_rnn masking ; optional residual add
 struct FwdProjJob {
@@ -51,7 +51,7 @@ struct FwdProjJob {
   int ldh, ldm, ldo, P, t, N;     // ldm: stride of m_prev/m_out/res_*, ldo: stride of out
   int nblk_c, blk_base;
 };
-struct FwdProjJobs { int n; const float* zeros; FwdProjJob j[MAXJ]; };
+struct FwdProjJobs { int n; FwdProjJob j[MAXJ]; };
 
 // Backward phase A: dm = mask*(dout_t + dm_state); dh = dm . Wp^T ; gate grads -> dz ; dc
 struct BwdAJob {
@@ -68,7 +68,7 @@ struct BwdAJob {
   int ldm, P, t, N, H;
   int nblk_c, blk_base;
 };
-struct BwdAJobs { int n; const float* zeros; BwdAJob j[MAXJ]; };
+struct BwdAJobs { int n; BwdAJob j[MAXJ]; };
 
 // Backward phase B: [dx_t | dm_rec] = dz_t . K^T restricted to kernel rows [n_begin, n_end)
 struct BwdBJob {
@@ -84,7 +84,7 @@ struct BwdBJob {
   float* ws;
   int ldw, KG, kpg, ncg, nrg, blk_base_p, blk_base_r;
 };
-struct BwdBJobs { int n; const float* zeros; BwdBJob j[MAXJ]; };
+struct BwdBJobs { int n; BwdBJob j[MAXJ]; };
 
 // A job covers nblk_r = ceil(N/32) row blocks x roundup8(nblk_c) virtual column blocks; blk_base is
 // the job's first block id in the launch.  kb_max = largest 16-float k-block count of any job in
@@ -96,31 +96,38 @@ void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, int kb_max, hip
 void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
 void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
 void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
-void launch_bwd_b_variant(const BwdBJobs& jobs, int total_blocks, int variant, hipStream_t s);
 // split-K phase B: fills ws/ldw/KG/... of every job (ws_base: >= bwd_b_ws_floats(jobs) floats) and launches both kernels
 size_t bwd_b_plan(BwdBJobs& jobs, float* ws_base);
 void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s);
 void launch_bwd_b_red(const BwdBJobs& jobs, hipStream_t s);       // fixed-order sum of the split-K partials + masked epilogue
 
-// ---------------------------------------------------------------- panel step kernels (panel.hip, round 2)
-// 64-row x NC-column workgroups, A and W streamed through an LDS-DMA ring; same job structs, different block decomposition:
-// a job owns ceil(N/64) row groups x roundup8(ceil(cols / per_wg)) column groups.
-bool panel_kernels();                        // RSRGAN_PANEL=0 -> round 1's kernels
-int pn_gates_blocks(int H, int N);           // 12 cells per workgroup
-int pn_proj_blocks(int P, int N);            // 16 outputs
-int pn_bwd_a_blocks(int H, int N);           // 16 cells
-void launch_pn_gates(const FwdGateJobs& jobs, int total_blocks, hipStream_t s);
-void launch_pn_proj(const FwdProjJobs& jobs, int total_blocks, hipStream_t s);
-void launch_pn_bwd_a(const BwdAJobs& jobs, int total_blocks, hipStream_t s);
-size_t pn_bwd_b_plan(BwdBJobs& jobs, float* ws_base);        // fills ws/ldw/KG/kpg (chunks per slice)/ncg/nrg/blk_base_p/blk_base_r
-int pn_bwd_b_blocks(const BwdBJobs& jobs);
-void launch_pn_bwd_b(const BwdBJobs& jobs, hipStream_t s);   // partial tiles + k_bwd_b_red
+// ---------------------------------------------------------------- persistent small-cell recurrence (dlstm.hip)
+// One workgroup per (16-row tile, layer) walks all T steps of a stack of dynamic_rnn(LSTMCell) layers with the layer's weights in
+// VGPRs; layer l+1 follows layer l through flags in `flags` ([L][ceil(N/16)] words, zeroed by the launcher).  Pointers are already
+// offset to the first row of the run; a time step is Ns rows apart in every buffer.
+constexpr int DL_MAXL = 4;
+struct DlLayer {
+  const float* in;      // [T][Ns][ldI] layer input (layer l > 0: the masked output of layer l-1)
+  const float* KxT; const float* KhT; const float* WpT;      // [4H][ldI], [4H][ldP], [P][ldH]
+  const float* K; const float* Wp;                           // TF layouts [(I+P)][4H], [H][ldP] (backward)
+  const float* bias; const float* wf; const float* wi; const float* wo;
+  float* gates; float* c; float* h; float* mst; float* out;  // stashes: [T][..][4H], [T+1][..][H], [T][..][ldH], [T+1][..][ldP], [T][..][ldP]
+  int I, H, P, ldI, ldP, ldH;
+};
+struct DlFwdArgs {
+  DlLayer layer[DL_MAXL];
+  const int* len;
+  unsigned* flags; unsigned* err;
+  float* dump;          // >= 384 floats: lanes without a real (row, cell) store here instead of branching
+  int L, N, Ns, T;
+  float forget_bias;
+};
+bool dl_fwd_supported(const DlFwdArgs& a);
+void launch_dl_fwd(const DlFwdArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- batched GEMM
 // C[M,N] (+)= A.B (+bias)(lrelu).  a_kc: A(m,k)=A[m*lda+k] else A[k*lda+m];
 // b_kc: B(k,n)=B[n*ldb+k] else B[k*ldb+n].
-int flagx_microbench(int variant, int nwg, int iters, int gsz, int wr_floats, float* out_us);          // persist.hip
-int gridbar_microbench(int variant, int nwg, int iters, int wr_floats, int rd_floats, float* out_us);   // persist.hip
 void launch_gemm2(const float* A, int lda, const float* A2, int lda2, int M1, bool a_kc, const float* B, int ldb, bool b_kc,
                   float* C, int ldc, int M, int N, int K, const float* bias, int act, float alpha, bool accumulate,
                   hipStream_t s, float* ws, size_t ws_floats);   // rows >= M1 of an m-contiguous A come from A2

@@ -372,10 +372,22 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_proj(const FwdProjJobs jobs) {
 // backward phase A: dh = (mask*(dout+dm_state)).Wp^T over K = P split on NW waves, then the
 // cell's gate gradients
 // ---------------------------------------------------------------------------------------
+// tools/ubench compiles this file with KA_ABLATE to time k_bwd_a with parts switched off (bit 1: no MFMA, 2: no operand loads,
+// 4: no epilogue loads, 8: no epilogue stores, 16: no dmt store, 32: return at entry); the product build has no such code
+#ifdef KA_ABLATE
+__device__ int g_ka_ablate = 0;
+#define KA_ON(bit) (!(ka_ab & (bit)))
+#else
+#define KA_ON(bit) true
+#endif
 template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
   __shared__ float zs[NW][RT][16][17];
   const int bid = blockIdx.x;
+#ifdef KA_ABLATE
+  const int ka_ab = g_ka_ablate;
+  if (!KA_ON(32)) return;
+#endif
   const int ji = find_job(jobs.j, jobs.n, bid);
   const BwdAJob& J = jobs.j[ji];
   int cb, rb;
@@ -402,11 +414,15 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int k = min((jb + c) * 16 + 4 * q, ldm - 4);
-    bv[c] = *reinterpret_cast<const float4*>(wrow + k);
+    bv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (KA_ON(2)) bv[c] = *reinterpret_cast<const float4*>(wrow + k);
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
-      av[c][i] = *reinterpret_cast<const float4*>(J.dmst + (size_t)arow[i] * ldm + k);
-      dv[c][i] = J.dout ? *reinterpret_cast<const float4*>(J.dout + (size_t)arow[i] * ldm + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      av[c][i] = make_float4(0.f, 0.f, 0.f, 0.f); dv[c][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (KA_ON(2)) {
+        av[c][i] = *reinterpret_cast<const float4*>(J.dmst + (size_t)arow[i] * ldm + k);
+        dv[c][i] = J.dout ? *reinterpret_cast<const float4*>(J.dout + (size_t)arow[i] * ldm + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   }
   // epilogue operands (one (row, cell) per thread when NW == 8), in flight with the above
@@ -415,7 +431,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
   const int e_i = tid >> 8, e_r = (tid >> 4) & 15, e_c = tid & 15;
   const int erow = r0 + e_i * 16 + e_r, ecell = c0 + e_c;
   const bool evalid = (NW == 8) && erow < N && ecell < H;
-  if (evalid) {
+  if (evalid && KA_ON(4)) {
     const float* g = J.gates + (size_t)erow * H4 + ecell;
     eg[0] = g[0]; eg[1] = g[H]; eg[2] = g[2 * H]; eg[3] = g[3 * H];
     const size_t ci = (size_t)erow * H + ecell;
@@ -438,11 +454,12 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
       a.x += dv[c][i].x; a.y += dv[c][i].y; a.z += dv[c][i].z; a.w += dv[c][i].w;
       const bool rowok = (r0 + i * 16 + lr) < N;
       if (!(kok && rowok && J.t < alen[i])) a = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kok && rowok && cb == 0 && !noproj) *reinterpret_cast<float4*>(J.dmt + (size_t)arow[i] * ldm + k) = a;
+      if (kok && rowok && cb == 0 && !noproj && KA_ON(16)) *reinterpret_cast<float4*>(J.dmt + (size_t)arow[i] * ldm + k) = a;
       av[c][i] = a;
     }
     bv[c] = b;
   }
+  if (KA_ON(1)) {
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
 #pragma unroll
@@ -454,13 +471,14 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
 #pragma unroll
     for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].w, bv[c].w, acc[i], 0, 0, 0);
   }
+  }
   static_assert(NW == 8, "k_bwd_a: 8 waves x 3 k-blocks cover K <= 384 floats; one epilogue element per thread");
 #pragma unroll
   for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) zs[w][i][q * 4 + r][lr] = acc[i][r];
   __syncthreads();
-  if (evalid) {
+  if (evalid && KA_ON(8)) {
     float* g = J.gates + (size_t)erow * H4 + ecell;
     if (J.t < elen) {
       float dh = 0.f;
@@ -768,23 +786,6 @@ void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, int kb_max, hipStream_
   else               // 8 waves split K; each runs a double-buffered 6-k-block register pipeline
     hipLaunchKernelGGL((k_bwd_b<8, 0, 6>), dim3(total_blocks), dim3(512), 0, s, jobs);
 }
-// micro-benchmark variants (rsrgan_microbench): see VAR above; 8 = un-pipelined, 16 = 16 waves
-void launch_bwd_b_variant(const BwdBJobs& jobs, int total_blocks, int variant, hipStream_t s) {
-  switch (variant) {
-    case 0: hipLaunchKernelGGL((k_bwd_b<8, 0>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
-    case 1: hipLaunchKernelGGL((k_bwd_b<8, 1>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
-    case 2: hipLaunchKernelGGL((k_bwd_b<8, 2>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
-    case 3: hipLaunchKernelGGL((k_bwd_b<8, 3>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
-    case 4: hipLaunchKernelGGL((k_bwd_b<8, 4>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
-    case 7: hipLaunchKernelGGL((k_bwd_b<8, 7>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
-    case 8: hipLaunchKernelGGL((k_bwd_b<8, 8>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
-    case 16: hipLaunchKernelGGL((k_bwd_b<16, 8>), dim3(total_blocks), dim3(1024), 0, s, jobs); break;
-    case 32: hipLaunchKernelGGL((k_bwd_b<8, 32>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
-    case 36: hipLaunchKernelGGL((k_bwd_b<8, 36>), dim3(total_blocks), dim3(512), 0, s, jobs); break;
-    default: break;
-  }
-}
-
 // ---------------------------------------------------------------------------------------
 // layout kernels: batch-major caller buffers <-> time-major padded internal buffers
 // ---------------------------------------------------------------------------------------

@@ -353,6 +353,9 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   d_dA = alloc<float>(TB2 * dmaxld); d_dB = alloc<float>(TB2 * dmaxld);
   len_dev = alloc<int>(2 * B);
   zeros = alloc<float>(64);
+  dl_flags = alloc<unsigned>(DL_MAXL * 64 + 64);
+  dl_dump = alloc<float>(512);
+  if (const char* e = getenv("RSRGAN_DLSTM")) dl_env = atoi(e) != 0;
   noise_r_buf = alloc<float>((size_t)B * Dout); noise_f_buf = alloc<float>((size_t)B * Dout);
   if (const char* e = getenv("RSRGAN_GRAPHS")) graphs_env = atoi(e) != 0;
   if (hipStreamCreateWithFlags(&main_s, hipStreamNonBlocking) != hipSuccess) main_s = nullptr;
@@ -523,7 +526,6 @@ bool Model::bwd_b_splitk_ok(const BwdBJobs& jobs) const {
     if ((tmp.j[i].kpg + 1) / 2 > 12) return false;       // k_bwd_bp holds <= 12 k-blocks of weights per wave
     blocks += tmp.j[i].KG * tmp.j[i].ncg * tmp.j[i].nrg;
   }
-  if (panel_kernels() && pn_bwd_b_plan(tmp, nullptr) > bwdb_ws_floats) return false;
   return blocks >= 96;          // small launches (the discriminator alone): one 32x16-tile launch is faster (9.3 vs 10.4 us)
 }
 
@@ -605,23 +607,13 @@ static void fill_bwd_b(BwdBJob& b, const LayerRun& R, int t, bool with_dx) {
   b.nblk_c = (b.n_end - b.n_begin + 15) / 16;
 }
 
-// round 2: the panel kernels (panel.hip) unless RSRGAN_PANEL=0; same job structs, different block decomposition
-int Model::gates_blocks(int H, int N) const { return panel_kernels() ? pn_gates_blocks(H, N) : job_blocks((H + 15) / 16, N, fwd_gates_rows()); }
-int Model::proj_blocks(int P, int N) const { return panel_kernels() ? pn_proj_blocks(P, N) : job_blocks((P + 15) / 16, N); }
-int Model::bwd_a_blocks(int H, int N) const { return panel_kernels() ? pn_bwd_a_blocks(H, N) : job_blocks((H + 15) / 16, N); }
-static void run_gates(const FwdGateJobs& gj, int blocks, int kb, hipStream_t s) {
-  if (panel_kernels()) launch_pn_gates(gj, blocks, s); else launch_fwd_gates(gj, blocks, kb, s);
-}
-static void run_proj(const FwdProjJobs& pj, int blocks, int kb, hipStream_t s) {
-  if (panel_kernels()) launch_pn_proj(pj, blocks, s); else launch_fwd_proj(pj, blocks, kb, s);
-}
-static void run_bwd_a(const BwdAJobs& aj, int blocks, int kb, hipStream_t s) {
-  if (panel_kernels()) launch_pn_bwd_a(aj, blocks, s); else launch_bwd_a(aj, blocks, kb, s);
-}
-void Model::run_bwd_b_splitk(BwdBJobs& bj, hipStream_t s) {
-  if (panel_kernels()) { pn_bwd_b_plan(bj, bwdb_ws); launch_pn_bwd_b(bj, s); }
-  else { bwd_b_plan(bj, bwdb_ws); launch_bwd_b_splitk(bj, s); }
-}
+int Model::gates_blocks(int H, int N) const { return job_blocks((H + 15) / 16, N, fwd_gates_rows()); }
+int Model::proj_blocks(int P, int N) const { return job_blocks((P + 15) / 16, N); }
+int Model::bwd_a_blocks(int H, int N) const { return job_blocks((H + 15) / 16, N); }
+static void run_gates(const FwdGateJobs& gj, int blocks, int kb, hipStream_t s) { launch_fwd_gates(gj, blocks, kb, s); }
+static void run_proj(const FwdProjJobs& pj, int blocks, int kb, hipStream_t s) { launch_fwd_proj(pj, blocks, kb, s); }
+static void run_bwd_a(const BwdAJobs& aj, int blocks, int kb, hipStream_t s) { launch_bwd_a(aj, blocks, kb, s); }
+void Model::run_bwd_b_splitk(BwdBJobs& bj, hipStream_t s) { bwd_b_plan(bj, bwdb_ws); launch_bwd_b_splitk(bj, s); }
 
 void Model::gates_launch(const FwdGateJobs& gj, int blocks, int kb, hipStream_t s) {
   if (!prof_on) { run_gates(gj, blocks, kb, s); return; }
@@ -663,11 +655,11 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
         const bool zx = R.Ns == R.N && R.row0 == 0;          // rows contiguous over time -> batch the x-part
         if (zx) zx_gemm(R);
         for (int t = 0; t < T; ++t) {
-          FwdGateJobs gj{}; gj.n = 1; gj.forget_bias = cfg.forget_bias; gj.zeros = zeros;
+          FwdGateJobs gj{}; gj.n = 1; gj.forget_bias = cfg.forget_bias;
           fill_gate(gj.j[0], R, t, zx); gj.j[0].blk_base = 0;
           gates_launch(gj, gates_blocks(R.L->H, R.N), (zx ? 0 : kb16(R.L->ldI)) + kb16(R.L->ldP), s);
           if (R.L->has_proj) {
-            FwdProjJobs pj{}; pj.n = 1; pj.zeros = zeros;
+            FwdProjJobs pj{}; pj.n = 1;
             fill_proj(pj.j[0], R, t); pj.j[0].blk_base = 0;
             run_proj(pj, proj_blocks(R.L->P, R.N), kb16(R.L->ldH), s);
           }
@@ -685,8 +677,8 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
   if (fcs)
     for (auto& F : *fcs) last = std::max(last, F.offset + T - 1);
   for (int d = 0; d <= last; ++d) {
-    FwdGateJobs gj{}; gj.forget_bias = cfg.forget_bias; gj.zeros = zeros;
-    FwdProjJobs pj{}; pj.zeros = zeros;
+    FwdGateJobs gj{}; gj.forget_bias = cfg.forget_bias;
+    FwdProjJobs pj{};
     int gb = 0, pb = 0, gk = 0, pk = 0;
     // a diagonal's jobs only depend on earlier diagonals, so they may be split over several launches
     auto flush_g = [&]() { if (gj.n) gates_launch(gj, gb, gk, s); gj.n = 0; gb = gk = 0; };
@@ -727,6 +719,29 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
       }
     flush_p();
   }
+}
+
+// The whole forward recurrence of a small-cell chain (the discriminator running alone) as ONE persistent launch (dlstm.hip).
+bool Model::dl_forward(Chain& ch, int T, hipStream_t s) {
+  if (!dl_env || !wavefront() || ch.empty() || (int)ch.size() > DL_MAXL) return false;
+  DlFwdArgs a{};
+  a.L = (int)ch.size(); a.N = ch[0].N; a.Ns = ch[0].Ns; a.T = T; a.len = ch[0].len; a.forget_bias = cfg.forget_bias;
+  a.flags = dl_flags; a.err = dl_flags + DL_MAXL * 64; a.dump = dl_dump;
+  for (int l = 0; l < a.L; ++l) {
+    const LayerRun& R = ch[l];
+    const LstmLayer& L = *R.L; const LstmStash& S = *R.S; const ParamSet& ps = *R.ps;
+    if (!L.has_proj || R.res_in || R.res_out || R.zx_batched || R.N != a.N || R.Ns != a.Ns || R.row0 != ch[0].row0 || R.len != a.len) return false;
+    if (l > 0 && R.in != ch[l - 1].S->out) return false;
+    const size_t r0 = (size_t)R.row0;
+    DlLayer& y = a.layer[l];
+    y.in = R.in + r0 * L.ldI; y.KxT = L.KxT; y.KhT = L.KhT; y.WpT = L.WpT; y.K = ps.W(L.tK); y.Wp = ps.W(L.tWp);
+    y.bias = ps.W(L.tb); y.wf = ps.W(L.twf); y.wi = ps.W(L.twi); y.wo = ps.W(L.two);
+    y.gates = S.gates + r0 * 4 * L.H; y.c = S.c + r0 * L.H; y.h = S.h + r0 * L.ldH; y.mst = S.mst + r0 * L.ldP; y.out = S.out + r0 * L.ldP;
+    y.I = L.I; y.H = L.H; y.P = L.P; y.ldI = L.ldI; y.ldP = L.ldP; y.ldH = L.ldH;
+  }
+  if (!dl_fwd_supported(a)) return false;
+  launch_dl_fwd(a, s);
+  return true;
 }
 
 void Model::layer_wgrads_gemms(const LayerRun& R, int t0, int t1, bool accumulate, hipStream_t s) {
@@ -774,9 +789,9 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
       for (int l = (int)ch.size() - 1; l >= 0; --l) {
         const LayerRun& R = ch[l];
         for (int t = T - 1; t >= 0; --t) {
-          BwdAJobs aj{}; aj.n = 1; aj.zeros = zeros; fill_bwd_a(aj.j[0], R, t); aj.j[0].blk_base = 0;
+          BwdAJobs aj{}; aj.n = 1; fill_bwd_a(aj.j[0], R, t); aj.j[0].blk_base = 0;
           run_bwd_a(aj, bwd_a_blocks(R.L->H, R.N), kb16(R.L->ldP), s);
-          BwdBJobs bj{}; bj.n = 1; bj.zeros = zeros; fill_bwd_b(bj.j[0], R, t, false); bj.j[0].blk_base = 0;
+          BwdBJobs bj{}; bj.n = 1; fill_bwd_b(bj.j[0], R, t, false); bj.j[0].blk_base = 0;
           if (bwd_b_splitk_ok(bj)) run_bwd_b_splitk(bj, s);
           else launch_bwd_b(bj, job_blocks(bj.j[0].nblk_c, R.N, kb16(4 * R.L->H) <= 64 ? 16 : 32), kb16(4 * R.L->H), s);
         }
@@ -805,7 +820,7 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
   auto chunk_hi = [&](int c) { return T - (c * T) / nchunk; };
   for (int d = 0; d <= last; ++d) {
     BwdAJobs aj{}; BwdBJobs bj{};
-    aj.zeros = zeros; bj.zeros = zeros;
+   
     int ab = 0, bb = 0, ak = 0, bk = 0;
     auto flush_a = [&]() { if (aj.n) run_bwd_a(aj, ab, ak, s); aj.n = 0; ab = ak = 0; };
     auto flush_b = [&]() {
@@ -1024,6 +1039,9 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
   int rc = prepare_batch(x, labels, lengths, T, s);
   if (rc) return rc;
   if (d_dnn()) { nr = nullptr; nf = nullptr; }    // discriminator_dnn.py:58: the noise layer is commented out
+  nr = stage_noise(nr, noise_r_buf, s); nf = stage_noise(nf, noise_f_buf, s);     // caller pointers never enter a graph
+  const unsigned kbits = (want_grads ? 1u : 0u) | (nr ? 2u : 0u) | (nf ? 4u : 0u);
+  run_seg(seg_key(SEG_D, T, kbits), s, [&]() {
   // discriminator input rows [0,B) = labels + noise_real (gan_rnn_placeholder.py:207,212; utils/ops.py:19-30)
   launch_add_noise_rows(lab_tm, nr, xd, B, T, Dout, ldDout, 2 * B, 0, s);
   if (wavefront()) {
@@ -1043,7 +1061,6 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
     F.y = y_tm; F.ldy = ldDout; F.out2 = xd; F.ld2 = ldDout; F.Ns2 = 2 * B; F.row02 = B;
     std::vector<FcStage> fcs{F};
     rnn_forward(chains, T, s, &offs, &fcs);
-    g_fwd_valid = true;
   } else {
     g_forward(T, s);
     launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, 2 * B, B, s);
@@ -1054,15 +1071,15 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
   }
   if (d_dnn()) {
     d_dnn_forward_loss(T, 2 * B, B, want_grads, losses, s);
-    if (want_grads) { fc_backward(D, dfc, d_act, T * 2 * B, dlogits, true, false, s); { finish_buckets(RSRGAN_NET_D, s); d_grads_ready = true; } }
+    if (want_grads) fc_backward(D, dfc, d_act, T * 2 * B, dlogits, true, false, s);
   } else {
     d_logits(2 * B, T, s);
     launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, 2 * B, B, dyn + DYN_D_REAL, dyn + DYN_D_FAKE, losses, s);
-    if (want_grads) {
-      d_backward_pass(2 * B, T, true, false, dlogits, s);
-      { finish_buckets(RSRGAN_NET_D, s); d_grads_ready = true; }
-    }
+    if (want_grads) d_backward_pass(2 * B, T, true, false, dlogits, s);
   }
+  });
+  g_fwd_valid = true;
+  if (want_grads) { finish_buckets(RSRGAN_NET_D, s); d_grads_ready = true; }
   if (out_losses) launch_copy_f(losses, out_losses, 3, s);
   HIPC(hipGetLastError());
   return RSRGAN_OK;
@@ -1103,66 +1120,28 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   } else {
     int rc = prepare_batch(x, labels, lengths, T, s);
     if (rc) return rc;
-    if (!wavefront()) g_forward(T, s);
   }
-  if (!reuse && wavefront()) {
-    // ONE forward wave: G's layers | per-step output FC (-> y_t and D's input rows, noise added) | D's layers
-    g_forward_head(T, s);
-    const int Lg = (int)gl.size();
-    std::vector<Chain> chains{g_chain(T)};
-    std::vector<int> offs{0};
-    if (!d_dnn()) { chains.push_back(d_chain(B, B, 0)); offs.push_back(Lg + 1); }
-    FcStage F;
-    F.offset = Lg; F.N = B; F.K = gR; F.D = Dout;
-    F.in = g_ins[Lg]; F.ld_in = pad4(gR); F.WT = g_fc_out_wT; F.bias = G.W(g_fc_out_b); F.noise = nf;
-    F.y = y_tm; F.ldy = ldDout; F.out2 = xd; F.ld2 = ldDout; F.Ns2 = B; F.row02 = 0;
-    std::vector<FcStage> fcs{F};
-    rnn_forward(chains, T, s, &offs, &fcs);
-    g_fwd_valid = true;
-  } else {
-    launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, B, 0, s);
-    if (!d_dnn()) {
-      std::vector<Chain> chains(1, d_chain(B, B, 0));
-      rnn_forward(chains, T, s);
-    }
-  }
-  // g_adv = mean((D(G(x)) - d_real)^2)  (gan_rnn_placeholder.py:246): all rows "fake", target d_real
-  if (d_dnn()) {
-    d_dnn_forward_loss(T, B, 0, want_grads, tmp3, s);
-  } else {
-    d_logits(B, T, s);
-    launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, B, 0, dyn + DYN_D_REAL, dyn + DYN_D_REAL, tmp3, s);
-  }
-  launch_copy_f(tmp3 + 1, losses + 3, 1, s);
+  nf = stage_noise(nf, noise_f_buf, s);
   const bool l2_on = !cfg.cross_validation && scal[RSRGAN_L2_SCALE] > 0.0;
-  if (want_grads && d_dnn()) {
-    // discriminator_dnn: data gradient through the FC stack (time-batched GEMMs), then the generator's BPTT wave
-    float* dy = fc_backward(D, dfc, d_act, T * B, dlogits, false, true, s);      // [T*B][ldDout] (d_joint_dim == 0)
-    launch_mse(y_tm, lab_tm, ldDout, dy, T * B, Dout, dyn + DYN_LAMBDA, true, losses + 4, scratch, s);
-    g_backward_pass(T, dy, s);
-    if (l2_on) {
-      launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
-      launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);
-    }
-    { finish_buckets(RSRGAN_NET_G, s); g_grads_ready = true; }
-  } else if (want_grads && wavefront()) {
-    // ONE backward wave: D's layers (data gradient only) | per-step output-FC backward | G's layers.
-    // dy[t] = lambda*(y-lab)/(B*T) (written first) + d g_adv/d y[t] (accumulated by D layer 0's phase B)
-    const int R = T * B, Ld = (int)dl.size(), Lg = (int)gl.size();
-    const int ldPd = pad4(dR), P = gR, ldP = pad4(P);
-    float* dtop = d_dB;                           // d(D outputs) = dlogits . W^T
-    gemm(dlogits, 4, true, D.W(d_fc_w), 4, true, dtop, ldPd, R, dR, 1, nullptr, 0, 0.f, false, s);
-    float* dy = g_dB;                             // [T*B][ldDout]
-    launch_mse(y_tm, lab_tm, ldDout, dy, R, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s);
+  const bool wave_bwd = want_grads && !d_dnn() && wavefront();
+  const bool bucketed = wave_bwd && gbk[RSRGAN_NET_G].size() > 1 && !overlap();
+  const unsigned kbits = (want_grads ? 1u : 0u) | (nf ? 2u : 0u) | (reuse ? 4u : 0u) | (l2_on ? 8u : 0u) | (bucketed ? 16u : 0u);
+  const int R = T * B, Ld = (int)dl.size(), Lg = (int)gl.size();
+  const int ldPd = pad4(dR), P = gR, ldP = pad4(P);
+  float* dy = g_dB;                               // [T*B][ldDout] (wavefront backward)
+  float* bufA = g_dA; float* bufB = g_dC;         // G-side gradient ping-pong of the wavefront backward (dy itself lives in g_dB)
+  std::vector<Chain> bw_chains;                   // filled by the main segment's body; the bucketed weight-gradient segments read
+                                                  // only pointers that are the same on every call, so they rebuild it themselves
+  auto build_bw_chains = [&]() {
     Chain dch = d_chain(B, B, 0);
-    float* cur = dtop; float* other = d_dA;
+    float* cur = d_dB; float* other = d_dA;
     for (int l = Ld - 1; l >= 0; --l) {
       dch[l].dout = cur; dch[l].want_wgrads = false;
       if (l == 0) { dch[l].din = dy; dch[l].din_accumulate = true; }
       else { dch[l].din = other; dch[l].din_accumulate = false; std::swap(cur, other); }
     }
     Chain gch = g_chain(T);
-    float* bufA = g_dA; float* bufB = g_dC;        // G-side gradient ping-pong (dy itself lives in g_dB)
+    bufA = g_dA; bufB = g_dC;
     for (int l = Lg - 1; l >= 0; --l) {
       gch[l].want_wgrads = true;
       if (cfg.g_type == RSRGAN_G_RES_LSTM_L) {     // d(inputs_l) = dx_l + d(inputs_{l+1}): one buffer, accumulated in place
@@ -1173,52 +1152,105 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
         std::swap(bufA, bufB);
       }
     }
+    bw_chains = std::vector<Chain>{dch, gch};
+  };
+  if (wave_bwd) build_bw_chains();                // host-only bookkeeping (bufA after the loop = d(h0))
+
+  run_seg(seg_key(SEG_G_MAIN, T, kbits), s, [&]() {
+  if (!reuse && !wavefront()) g_forward(T, s);
+  if (!reuse && wavefront()) {
+    // ONE forward wave: G's layers | per-step output FC (-> y_t and D's input rows, noise added) | D's layers
+    g_forward_head(T, s);
+    std::vector<Chain> chains{g_chain(T)};
+    std::vector<int> offs{0};
+    if (!d_dnn()) { chains.push_back(d_chain(B, B, 0)); offs.push_back(Lg + 1); }
+    FcStage F;
+    F.offset = Lg; F.N = B; F.K = gR; F.D = Dout;
+    F.in = g_ins[Lg]; F.ld_in = pad4(gR); F.WT = g_fc_out_wT; F.bias = G.W(g_fc_out_b); F.noise = nf;
+    F.y = y_tm; F.ldy = ldDout; F.out2 = xd; F.ld2 = ldDout; F.Ns2 = B; F.row02 = 0;
+    std::vector<FcStage> fcs{F};
+    rnn_forward(chains, T, s, &offs, &fcs);
+  } else {
+    launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, B, 0, s);
+    if (!d_dnn()) {
+      std::vector<Chain> chains(1, d_chain(B, B, 0));
+      if (!dl_forward(chains[0], T, s)) rnn_forward(chains, T, s);
+    }
+  }
+  // g_adv = mean((D(G(x)) - d_real)^2)  (gan_rnn_placeholder.py:246): all rows "fake", target d_real
+  if (d_dnn()) {
+    d_dnn_forward_loss(T, B, 0, want_grads, tmp3, s);
+  } else {
+    d_logits(B, T, s);
+    launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, B, 0, dyn + DYN_D_REAL, dyn + DYN_D_REAL, tmp3, s);
+  }
+  launch_copy_f(tmp3 + 1, losses + 3, 1, s);
+  if (want_grads && d_dnn()) {
+    // discriminator_dnn: data gradient through the FC stack (time-batched GEMMs), then the generator's BPTT wave
+    float* dyd = fc_backward(D, dfc, d_act, T * B, dlogits, false, true, s);      // [T*B][ldDout] (d_joint_dim == 0)
+    launch_mse(y_tm, lab_tm, ldDout, dyd, T * B, Dout, dyn + DYN_LAMBDA, true, losses + 4, scratch, s);
+    g_backward_pass(T, dyd, s);
+  } else if (wave_bwd) {
+    // ONE backward wave: D's layers (data gradient only) | per-step output-FC backward | G's layers.
+    // dy[t] = lambda*(y-lab)/(B*T) (written first) + d g_adv/d y[t] (accumulated by D layer 0's phase B)
+    gemm(dlogits, 4, true, D.W(d_fc_w), 4, true, d_dB, ldPd, R, dR, 1, nullptr, 0, 0.f, false, s);      // d(D outputs) = dlogits . W^T
+    launch_mse(y_tm, lab_tm, ldDout, dy, R, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s);
     FcStage F;                                     // d(ins[L])[t] = dy[t] . W_out^T
     F.offset = Ld; F.N = B; F.K = Dout; F.D = P;
     F.in = dy; F.ld_in = ldDout; F.WT = G.W(g_fc_out_w); F.y = g_dA; F.ldy = ldP; F.accumulate = false;
-    std::vector<Chain> chains{dch, gch};
     std::vector<int> offs{0, Ld + 1};
     std::vector<FcStage> fcs{F};
-    const bool bucketed = gbk[RSRGAN_NET_G].size() > 1 && !overlap();
     defer_wgrads = bucketed;
-    rnn_backward(chains, T, s, &offs, &fcs);
+    rnn_backward(bw_chains, T, s, &offs, &fcs);
     defer_wgrads = false;
-    int bi = 0;
     // output FC parameter gradients (batched over time, dy is complete now)
     gemm(g_ins[Lg], ldP, false, dy, ldDout, false, G.Gd(g_fc_out_w), ldDout, P, Dout, R, nullptr, 0, 0.f, false, s);
     launch_colsum(dy, ldDout, nullptr, 0, G.Gd(g_fc_out_b), R, Dout, scratch, s);
-    if (bucketed) mark_bucket(RSRGAN_NET_G, bi++, s);
-    if (cfg.g_type == RSRGAN_G_LSTM) {
-      // through leakyrelu and the input FC (models/lstm.py:82-87); bufA now holds d(h0)
-      launch_lrelu_bwd(g_h0, bufA, (size_t)R, P, ldP, cfg.lrelu_alpha, s);
-      gemm(x_tm, ldDin, false, bufA, ldP, false, G.Gd(g_fc_in_w), ldP, Din, P, R, nullptr, 0, 0.f, false, s);
-      launch_colsum(bufA, ldP, nullptr, 0, G.Gd(g_fc_in_b), R, P, scratch, s);
-      if (bucketed) mark_bucket(RSRGAN_NET_G, bi++, s);
-    }
-    if (bucketed)          // LSTM weight gradients layer by layer: each completes one bucket (all-reduced while the next runs)
-      for (auto& Rr : chains[1]) { layer_wgrads(Rr, T, s); mark_bucket(RSRGAN_NET_G, bi++, s); }
-    if (l2_on) {
-      launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
-      launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);
-      for (auto& b : gbk[RSRGAN_NET_G]) b.marked = false;      // the L2 term touches every tensor: all buckets final only now
-    }
-    finish_buckets(RSRGAN_NET_G, s);
-    g_grads_ready = true;
   } else if (want_grads) {
     d_backward_pass(B, T, false, true, dlogits, s);
-    float* dy = last_dx0;                        // d g_adv / d y
-    launch_mse(y_tm, lab_tm, ldDout, dy, T * B, Dout, dyn + DYN_LAMBDA, true, losses + 4, scratch, s);
-    g_backward_pass(T, dy, s);
-    if (l2_on) {
-      launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
-      launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);
-    }
-    { finish_buckets(RSRGAN_NET_G, s); g_grads_ready = true; }
+    float* dyd = last_dx0;                        // d g_adv / d y
+    launch_mse(y_tm, lab_tm, ldDout, dyd, T * B, Dout, dyn + DYN_LAMBDA, true, losses + 4, scratch, s);
+    g_backward_pass(T, dyd, s);
   } else {
     launch_mse(y_tm, lab_tm, ldDout, nullptr, T * B, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s);
   }
-  if (!(want_grads && l2_on)) HIPC(hipMemsetAsync(losses + 5, 0, sizeof(float), s));
-  launch_g_total(losses + 3, dyn + DYN_LAMBDA, s);
+  });
+  if (!reuse) g_fwd_valid = true;
+  if (wave_bwd) {
+    int bi = 0;
+    if (bucketed) mark_bucket(RSRGAN_NET_G, bi++, s);
+    if (cfg.g_type == RSRGAN_G_LSTM) {
+      run_seg(seg_key(SEG_G_FCIN, T, kbits), s, [&]() {
+        // through leakyrelu and the input FC (models/lstm.py:82-87); bufA holds d(h0)
+        launch_lrelu_bwd(g_h0, bufA, (size_t)R, P, ldP, cfg.lrelu_alpha, s);
+        gemm(x_tm, ldDin, false, bufA, ldP, false, G.Gd(g_fc_in_w), ldP, Din, P, R, nullptr, 0, 0.f, false, s);
+        launch_colsum(bufA, ldP, nullptr, 0, G.Gd(g_fc_in_b), R, P, scratch, s);
+      });
+      if (bucketed) mark_bucket(RSRGAN_NET_G, bi++, s);
+    }
+    if (bucketed) {        // LSTM weight gradients layer by layer: each completes one bucket (all-reduced while the next runs)
+      int li = 0;
+      for (auto& Rr : bw_chains[1]) {
+        run_seg(seg_key(SEG_G_LAYER0 + li, T, kbits), s, [&]() { layer_wgrads(Rr, T, s); });
+        mark_bucket(RSRGAN_NET_G, bi++, s);
+        ++li;
+      }
+    }
+  }
+  run_seg(seg_key(SEG_G_TAIL, T, kbits), s, [&]() {
+    if (want_grads && l2_on) {
+      launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
+      launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);
+    } else {
+      (void)hipMemsetAsync(losses + 5, 0, sizeof(float), s);
+    }
+    launch_g_total(losses + 3, dyn + DYN_LAMBDA, s);
+  });
+  if (want_grads) {
+    if (l2_on) for (auto& bk : gbk[RSRGAN_NET_G]) bk.marked = false;      // the L2 term touches every tensor: all buckets final only now
+    finish_buckets(RSRGAN_NET_G, s);
+    g_grads_ready = true;
+  }
   if (out_losses) launch_copy_f(losses + 3, out_losses, 4, s);
   HIPC(hipGetLastError());
   return RSRGAN_OK;
@@ -1227,23 +1259,27 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
 int Model::apply(int net, hipStream_t s) {
   if (net == RSRGAN_NET_D) {
     if (!d_grads_ready) { set_error("apply(D) without gradients"); return RSRGAN_ERR_STATE; }
-    launch_sumsq(D.g, D.ct, D.partial, s);
-    if (d_adam()) {                              // models/gan.py:125: d_opt = AdamOptimizer(d_learning_rate)
-      launch_adam_tick(dyn, adam_t_dev_d, (double)cfg.adam_beta1, (double)cfg.adam_beta2, s, DYN_D_LR, DYN_ADAM_LRT_D);
-      scal[RSRGAN_ADAM_STEP_D] += 1;
-      launch_apply_adam(D.w, D.g, D.m, D.v, D.ema, D.ct, D.partial, dyn, s, DYN_ADAM_LRT_D);
-    } else {
-      launch_apply_sgd(D.w, D.g, D.ema, D.ct, D.partial, dyn, s);
-    }
-    refresh_transposes(RSRGAN_NET_D, s);
+    run_seg(seg_key(SEG_APPLY_D, 0, 0), s, [&]() {
+      launch_sumsq(D.g, D.ct, D.partial, s);
+      if (d_adam()) {                              // models/gan.py:125: d_opt = AdamOptimizer(d_learning_rate)
+        launch_adam_tick(dyn, adam_t_dev_d, (double)cfg.adam_beta1, (double)cfg.adam_beta2, s, DYN_D_LR, DYN_ADAM_LRT_D);
+        launch_apply_adam(D.w, D.g, D.m, D.v, D.ema, D.ct, D.partial, dyn, s, DYN_ADAM_LRT_D);
+      } else {
+        launch_apply_sgd(D.w, D.g, D.ema, D.ct, D.partial, dyn, s);
+      }
+      refresh_transposes(RSRGAN_NET_D, s);
+    });
+    if (d_adam()) scal[RSRGAN_ADAM_STEP_D] += 1;
     d_grads_ready = false;
   } else if (net == RSRGAN_NET_G) {
     if (!g_grads_ready) { set_error("apply(G) without gradients"); return RSRGAN_ERR_STATE; }
-    launch_sumsq(G.g, G.ct, G.partial, s);
-    launch_adam_tick(dyn, adam_t_dev, (double)cfg.adam_beta1, (double)cfg.adam_beta2, s);
+    run_seg(seg_key(SEG_APPLY_G, 0, 0), s, [&]() {
+      launch_sumsq(G.g, G.ct, G.partial, s);
+      launch_adam_tick(dyn, adam_t_dev, (double)cfg.adam_beta1, (double)cfg.adam_beta2, s);
+      launch_apply_adam(G.w, G.g, G.m, G.v, G.ema, G.ct, G.partial, dyn, s);
+      refresh_transposes(RSRGAN_NET_G, s);
+    });
     scal[RSRGAN_ADAM_STEP] += 1;
-    launch_apply_adam(G.w, G.g, G.m, G.v, G.ema, G.ct, G.partial, dyn, s);
-    refresh_transposes(RSRGAN_NET_G, s);
     g_grads_ready = false;
     g_fwd_valid = false;
   } else {

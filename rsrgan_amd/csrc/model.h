@@ -115,7 +115,11 @@ struct Model {
   std::vector<LstmStash> d_st;
   float *d_dA = nullptr, *d_dB = nullptr, *last_dx0 = nullptr;
   int *len_dev = nullptr;        // [2B]: lengths duplicated for the real|fake stacked batch
-  float *zeros = nullptr;        // 256 B of zeros: DMA source of the panel kernels for padding / masked rows
+  float *zeros = nullptr;        // 256 B of zeros
+  float *dl_dump = nullptr;
+  unsigned *dl_flags = nullptr;  // persistent small-cell recurrence (dlstm.hip): [DL_MAXL][64] progress words + 1 error word
+  bool dl_env = true;            // RSRGAN_DLSTM=0: launch-per-phase discriminator waves (round 1)
+  bool dl_forward(Chain& ch, int T, hipStream_t s);      // false: not supported for this chain -> caller falls back to rnn_forward
   // fully-connected stacks: models/dnn.py generator and models/discriminator_dnn.py discriminator
   std::vector<FcLayer> gfc, dfc;
   std::vector<float*> g_act, d_act;        // act[l] = input of FC layer l, act[L] = output of the stack

@@ -5,6 +5,7 @@ pointers (Tensor.data_ptr()) and the HIP stream the library enqueues on.  No ari
 GAN step happens in torch."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from typing import List, Optional, Tuple
@@ -36,7 +37,7 @@ class HipEngine:
                  d_proj: Optional[int] = None, d_type: Optional[str] = None, d_joint_off: Optional[int] = None,
                  d_joint_dim: Optional[int] = None, clip_norm: Optional[float] = None, g_splice: Optional[int] = None,
                  l2_scale: float = 0.0, cross_validation: bool = False,
-                 ema_decay: float = 0.9999, seed: int = 4321, device: Optional[torch.device] = None, flags: int = 1):
+                 ema_decay: float = 0.9999, seed: int = 4321, device: Optional[torch.device] = None, flags: int = 3):
         if g_type not in _lib.G_TYPES:
             raise ValueError("Unrecognized G type {}".format(g_type))      # gan_rnn_placeholder.py:131-132
         self.lib = _lib.load()
@@ -78,6 +79,10 @@ class HipEngine:
         check(self.lib.rsrgan_create(C.byref(cfg), C.c_uint64(seed), C.byref(self.h)))
         self._grad_views = {}
         self._comm_stream = None
+        # hipGraph capture needs a real stream: the library moves work handed to the legacy null stream onto its own stream
+        # with an event hop on both sides of EVERY call (measured ~0.2 ms per call); loops that run under on_stream() hand it
+        # this stream instead and pay nothing
+        self.stream = torch.cuda.Stream(device=self.device)
         self.d_has_adam = g_type in ("dnn", "rced")
         self.ema_enabled = ema_decay > 0          # no EMA shadow buffers in the library otherwise (WHAT['ema'] is absent)
 
@@ -93,6 +98,19 @@ class HipEngine:
             pass
 
     # -- plumbing ----------------------------------------------------------------------
+    @contextlib.contextmanager
+    def on_stream(self):
+        """Make the engine's stream the current torch stream for the block (ordered after the previous current stream on
+        entry, and the previous stream after it on exit).  Nested use is free."""
+        prev = torch.cuda.current_stream(self.device)
+        if prev == self.stream:
+            yield
+            return
+        self.stream.wait_stream(prev)
+        with torch.cuda.stream(self.stream):
+            yield
+        prev.wait_stream(self.stream)
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 

@@ -11,6 +11,7 @@ The compute engine defaults to the HIP library; there is no CPU fallback.
 """
 from __future__ import annotations
 
+import contextlib
 import glob
 import os
 from typing import List, Optional, Sequence
@@ -40,9 +41,9 @@ class Model(object):
             rdist.all_reduce_mean_(self.engine.grad_view(net), self.process_group)
 
     def save(self, save_dir, step):
-        if not os.path.exists(save_dir):
-            os.makedirs(save_dir)
+        os.makedirs(save_dir, exist_ok=True)
         if rdist.rank(self.process_group) != 0:
+            rdist.barrier(self.process_group)                      # rank 0 has written the checkpoint when this returns
             return None
         base = "%s-%d" % (self.name, int(step))
         payload = {}
@@ -73,6 +74,7 @@ class Model(object):
             os.remove(old)
         with open(os.path.join(save_dir, "checkpoint"), "w") as f:
             f.write('model_checkpoint_path: "%s"\n' % base)
+        rdist.barrier(self.process_group)
         return path
 
     def load(self, save_dir, model_file=None, moving_average=False):
@@ -95,6 +97,10 @@ class Model(object):
         if not os.path.exists(path):
             return False
         data = np.load(path)
+        if moving_average and not all((name + "/ExponentialMovingAverage") in data
+                                      for net in (NET_G, NET_D) for name, _, _ in self.engine.tensor_table(net)):
+            print("[!] {} holds no ExponentialMovingAverage variables".format(ckpt_name))
+            return False
         for net in (NET_G, NET_D):
             table = self.engine.tensor_table(net)
             flat = np.zeros(self.engine.param_count(net), np.float32)
@@ -226,6 +232,12 @@ class GAN_RNN(Model):
             raise ValueError("batch has %d rows, expected %d or %d" % (n, self.batch_size, self.batch_size * ws))
         return a[self.batch_size * r:self.batch_size * (r + 1)]
 
+    def on_stream(self):
+        """The engine's own HIP stream as the current torch stream (hipGraph replay needs a real stream; a loop that stays
+        under this context pays no null-stream hand-over per call).  A CPU test engine has no stream: no-op."""
+        f = getattr(self.engine, "on_stream", None)
+        return f() if f is not None else contextlib.nullcontext()
+
     def _towers(self, losses: torch.Tensor, gather: bool = True) -> torch.Tensor:
         """[k] device tensor -> [world, k]: the per-tower loss lists of :262-268.  gather=False keeps this rank's row only
         ([1, k], no collective): train_one_iteration averages over towers once per iteration instead of once per step."""
@@ -238,6 +250,10 @@ class GAN_RNN(Model):
         """sess.run([model.d_opt, model.d_rl_losses, model.d_fk_losses, model.d_losses], feed)
         (train_gan_rnn_placeholder.py:77-82).  Returns three per-tower lists (or, with
         sync=False, a [towers,3] device tensor)."""
+        with self.on_stream():
+            return self._d_step(inputs, labels, lengths, noise_real, noise_fake, train, sync, gather)
+
+    def _d_step(self, inputs, labels, lengths, noise_real, noise_fake, train, sync, gather):
         x, lab, ln = self._shard(inputs), self._shard(labels), self._shard(lengths)
         nr = self._shard(noise_real) if noise_real is not None else self._draw_noise()
         nf = self._shard(noise_fake) if noise_fake is not None else self._draw_noise()
@@ -258,6 +274,10 @@ class GAN_RNN(Model):
     def g_step(self, inputs, labels, lengths, noise_fake=None, train=True, reuse_g_forward=False, sync=True, gather=True):
         """sess.run([model.g_opt, model.g_adv_losses, model.g_mse_losses, model.g_l2_losses,
         model.g_losses], feed) (train_gan_rnn_placeholder.py:94-101)."""
+        with self.on_stream():
+            return self._g_step(inputs, labels, lengths, noise_fake, train, reuse_g_forward, sync, gather)
+
+    def _g_step(self, inputs, labels, lengths, noise_fake, train, reuse_g_forward, sync, gather):
         x, lab, ln = self._shard(inputs), self._shard(labels), self._shard(lengths)
         nf = self._shard(noise_fake) if noise_fake is not None else self._draw_noise()
         train = train and not self.cross_validation

@@ -77,8 +77,9 @@ def _reader(FLAGS, inputs_scp, labels_scp, cmvn, shuffle, seed):
 
 
 def get_num_batch(reader, full):
-    """get_num_batch (:346-385): a full pass that counts the batches the reader yields."""
-    return sum(1 for b in reader if len(b[0]) == full or True)
+    """get_num_batch (:346-385) counts the batches of a full pass; the reader's plan() gives the same count from the archive
+    headers alone (no utterance is read, normalised, spliced or padded just to be counted)."""
+    return sum(1 for _ in reader.plan())
 
 
 def train(FLAGS, model_factory=None, log=print, net_overrides=None):
@@ -194,7 +195,9 @@ def main(argv=None):
     if world > 1:
         FLAGS.num_gpu = world
     if FLAGS.decode:
-        decode(FLAGS)
+        if rank == 0:                                                      # one writer for <save_dir>/test/feats.{ark,scp}
+            decode(FLAGS)
+        rdist.barrier()
     else:
         train(FLAGS)
 

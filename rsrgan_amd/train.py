@@ -32,7 +32,18 @@ def _batches(train_queue):
             yield item
 
 
+def _on_stream(model):
+    import contextlib
+    f = getattr(model, "on_stream", None)
+    return f() if f is not None else contextlib.nullcontext()
+
+
 def train_one_iteration(sess, model, tr_num_batch, iteration, train_queue, num_gpu=None, share_g_forward=True):
+    with _on_stream(model):          # the whole iteration on the engine's stream: no per-call stream hand-over
+        return _train_one_iteration(sess, model, tr_num_batch, iteration, train_queue, num_gpu, share_g_forward)
+
+
+def _train_one_iteration(sess, model, tr_num_batch, iteration, train_queue, num_gpu=None, share_g_forward=True):
     """Runs the model one iteration on given data (train_gan_rnn_placeholder.py:48-133).
 
     `train_queue` yields [ids, inputs, labels, lengths] (a Queue like the reference's, or any
@@ -87,6 +98,11 @@ def train_one_iteration(sess, model, tr_num_batch, iteration, train_queue, num_g
 
 
 def eval_one_iteration(sess, model, cv_num_batch, iteration, valid_queue, num_gpu=None):
+    with _on_stream(model):
+        return _eval_one_iteration(sess, model, cv_num_batch, iteration, valid_queue, num_gpu)
+
+
+def _eval_one_iteration(sess, model, cv_num_batch, iteration, valid_queue, num_gpu=None):
     """Cross validate the model on given data (train_gan_rnn_placeholder.py:136-201): the same
     fetches without the *_opt ops."""
     num_gpu = num_gpu or model.num_gpu

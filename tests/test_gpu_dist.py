@@ -76,3 +76,69 @@ def test_nccl_world1_dp_path_equals_fused_step():
                     assert np.array_equal(p_[k], q_[k]), (g_type, k)
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, out):
+    """Two processes share cuda:0; gradients travel through gloo (RCCL refuses two ranks on one device), everything else is the
+    real HIP engine: sharding, per-bucket events + communication stream, average, clip, apply."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rsrgan_amd import GAN_RNN, train_one_iteration
+        from tests.helpers import args_for, overrides, rand_params
+        cfg = small_cfg("lstm")
+        B, T = 3, 7
+        g, d = rand_params(cfg, 5)
+        m = GAN_RNN(None, args_for(cfg, B, num_gpu=world, g_learning_rate=8e-5 * world, d_learning_rate=1e-3 * world, gen_updates=2),
+                    ["gpu:0"], max_frames=T, net_overrides=dict(overrides(cfg), flags=3))
+        m.set_vars(g, d)
+        assert len(m.engine.grad_buckets(NET_G)) > 1                 # the bucketed path is the one under test
+        batches = [rand_batch(cfg, B * world, T, 60 + i, ragged=True) for i in range(3)]
+        res = train_one_iteration(None, m, len(batches) * world, 0, [[None] + list(b) for b in batches])
+        gv, dv = m.get_vars()
+        out[rank] = (res, {k: v.copy() for k, v in gv.items()}, {k: v.copy() for k, v in dv.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_two_towers():
+    """SURVEY 8e determinism check on the HIP engine with world_size 2: must equal the oracle run as 2 in-graph towers and the
+    1-rank HIP run on the concatenated batch (tower mean of tower-mean gradients = gradient of the overall mean), replicas
+    bit-identical (models/gan_rnn_placeholder.py:157-184)."""
+    import torch.multiprocessing as mp
+    from oracle import rsrgan_oracle as O
+    from rsrgan_amd import GAN_RNN, train_one_iteration
+    from tests.helpers import args_for, overrides, rand_params
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_two_rank_worker, args=(world, port, out), nprocs=world, join=True)
+    cfg = small_cfg("lstm")
+    B, T = 3, 7
+    g, d = rand_params(cfg, 5)
+    batches = [rand_batch(cfg, B * world, T, 60 + i, ragged=True) for i in range(3)]
+    ref = O.GanRnnOracle(cfg, g, d, batch_size=B, num_towers=world,
+                         g_learning_rate=float(np.float32(8e-5 * world)), d_learning_rate=float(np.float32(1e-3 * world)))
+    want = O.train_one_iteration(ref, batches, 1, 2)
+    for r in range(world):
+        res, gv, dv = out[r]
+        assert np.allclose(res, want, rtol=1e-4), (r, res, want)
+        for k in ref.g:
+            assert np.abs(gv[k] - ref.g[k]).max() <= 1e-5 * max(1.0, np.abs(ref.g[k]).max()), k
+        for k in ref.d:
+            assert np.abs(dv[k] - ref.d[k]).max() <= 1e-5 * max(1.0, np.abs(ref.d[k]).max()), k
+    for k in out[0][1]:
+        assert np.array_equal(out[0][1][k], out[1][1][k]), k                   # replicas stay bit-identical
+    # one rank, concatenated batch, same learning rates
+    one = GAN_RNN(None, args_for(cfg, B * world, num_gpu=1, g_learning_rate=8e-5 * world, d_learning_rate=1e-3 * world, gen_updates=2),
+                  ["gpu:0"], max_frames=T, net_overrides=dict(overrides(cfg), flags=3))
+    one.set_vars(g, d)
+    res1 = train_one_iteration(None, one, len(batches), 0, [[None] + list(b) for b in batches])
+    assert np.allclose(res1, out[0][0], rtol=1e-4)
+    gv1, dv1 = one.get_vars()
+    for k in gv1:
+        assert np.abs(gv1[k] - out[0][1][k]).max() <= 2e-6 * max(1.0, np.abs(gv1[k]).max()), k

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 LOSS_RTOL = 1e-4
 GRAD_RTOL = 2e-3
-SCHEDULES = [0, 1]        # 0 = layer-sequential, 1 = RSRGAN_FLAG_WAVEFRONT
+SCHEDULES = [0, 1, 3]     # 0 = layer-sequential, 1 = RSRGAN_FLAG_WAVEFRONT, 3 = wavefront replayed as hipGraphs
 
 
 def _check_grads(model, net, want, tag):
@@ -300,3 +300,36 @@ def test_long_sequences(g_type):
     _check_grads(model, NET_G, wg, "G long")
     y = model.forward(x, ln)
     assert np.abs(y - y_ref).max() < 1e-4
+
+
+@pytest.mark.parametrize("g_type", ["lstm", "res_lstm_l"])
+def test_graph_replay_is_bit_identical_to_eager(g_type):
+    """RSRGAN_FLAG_GRAPH: a segment runs eagerly on its first use, is captured on the second and replayed from the third; the
+    kernels and their order are the same, so six iterations of the shipped 1 D + 2 G schedule (alternating T, with and without
+    noise, changing scalars in between) must give bit-identical losses and variables with and without graphs."""
+    cfg = small_cfg(g_type)
+    B = 6
+    eager, _ = build_hip_pair(cfg, B, 9, seed=21, flags=1, l2_scale=1e-3)
+    graph, _ = build_hip_pair(cfg, B, 9, seed=21, flags=3, l2_scale=1e-3)
+    rng = np.random.default_rng(2)
+    for it in range(8):
+        T = 9 if it % 3 else 7                      # two graph sets, each one used at least three times
+        x, lab, ln = rand_batch(cfg, B, T, seed=50 + it, ragged=it % 2 == 1)
+        nr = nf = None
+        if it % 4 >= 2:
+            nr = rng.normal(0, 0.05, (B, 1, cfg.output_dim)).astype(np.float32)
+            nf = rng.normal(0, 0.05, (B, 1, cfg.output_dim)).astype(np.float32)
+        for m in (eager, graph):
+            m.engine.set_scalar("g_learning_rate", 1e-3 * (1 + it))
+        outs = []
+        for m in (eager, graph):
+            d = np.ravel(m.engine.d_backward(x, lab, ln, nr, nf, train=True, apply=True).cpu().numpy())
+            g1 = np.ravel(m.engine.g_backward(x, lab, ln, nf, train=True, reuse=True, apply=True).cpu().numpy())
+            g2 = np.ravel(m.engine.g_backward(x, lab, ln, nf, train=True, reuse=False, apply=True).cpu().numpy())
+            ev = np.ravel(m.engine.g_backward(x, lab, ln, nf, train=False, reuse=False).cpu().numpy())
+            outs.append(np.concatenate([d, g1, g2, ev]))
+        assert np.array_equal(outs[0], outs[1]), (it, outs[0], outs[1])
+    for net in (NET_G, NET_D):
+        a = eager.engine.get_params(net).cpu().numpy(); b = graph.engine.get_params(net).cpu().numpy()
+        assert np.array_equal(a, b)
+    assert np.array_equal(eager.forward(x, ln), graph.forward(x, ln))

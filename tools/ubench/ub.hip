@@ -21,9 +21,15 @@
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#define KA_ABLATE 1
+#include "../../rsrgan_amd/csrc/kernels.hip"
+#ifndef DL_PROF_BLOCK
+#define DL_PROF_BLOCK 0
+#endif
+#define DL_PROF 1
+#include "../../rsrgan_amd/csrc/dlstm.hip"
 #define PN_ABLATE 1
-#include "../../rsrgan_amd/csrc/panel.hip"
-namespace rsr { void launch_bwd_b_red(const BwdBJobs&, hipStream_t) {} }
+#include "panel_experiment.hip"
 
 // ------------------------------------------------------------------------------------------------ t1
 struct BigJob { const float* p[20]; int v[12]; int nblk_c, blk_base; };      // ~216 B, like FwdGateJob
@@ -381,33 +387,151 @@ static void t4(hipStream_t s) {
     a.h = dal((size_t)N * ((H + 3) & ~3), 0.f); a.ldh = (H + 3) & ~3; a.len = len; a.t = 0; a.N = N; a.H = H;
   };
   auto build = [&](FwdGateJobs& gj, int ng, int nd, int N) {
-    gj = FwdGateJobs{}; gj.forget_bias = 1.f; gj.zeros = zeros;
+    gj = FwdGateJobs{}; gj.forget_bias = 1.f;
     int base = 0;
     for (int l = ng - 1; l >= 0; --l) { FwdGateJob& a = gj.j[gj.n++]; mk(a, N, 760, 280, 280, l == 0); a.blk_base = base; base += pn_gates_blocks(760, N); }
     for (int l = 0; l < nd; ++l) { FwdGateJob& a = gj.j[gj.n++]; mk(a, N, 256, 40, 40, false); a.blk_base = base; base += pn_gates_blocks(256, N); }
     return base;
   };
   struct Cfg { const char* name; int ng, nd, N; };
-  for (const Cfg& c : {Cfg{"3 G layers + 4 D jobs", 3, 4, 64}, Cfg{"3 G layers", 3, 0, 64}, Cfg{"1 G layer", 1, 0, 64}, Cfg{"4 D jobs only", 0, 4, 64}}) {
+  for (int tile : {34, 13, 12})
+  for (const Cfg& c : {Cfg{"3 G layers + 4 D jobs", 3, 4, 64}, Cfg{"3 G layers", 3, 0, 64}, Cfg{"4 D jobs only", 0, 4, 64}}) {
+    pn_set_gates_cfg(tile / 10, tile % 10);
+    printf("-- tile config (nct,s) = (%d,%d)\n", tile / 10, tile % 10);
     FwdGateJobs gj; const int blocks = build(gj, c.ng, c.nd, c.N);
-    for (int ab : {0, 1, 2, 1 | 4, 1 | 2 | 4, 8, 16, 8 | 16, 1 | 2 | 4 | 8 | 16, 32, 64, 128, 128 | 16}) {
+    for (int ab : {0, 1, 2, 1 | 4, 1 | 2 | 4, 8 | 16, 1 | 2 | 4 | 8 | 16, 128 | 16}) {
       CK(hipMemcpyToSymbol(HIP_SYMBOL(rsr::g_pn_ablate), &ab, sizeof(int)));
       launch_pn_gates(gj, blocks, s); CK(hipStreamSynchronize(s));
       float us = time_graph(s, 50, 6, [&] { launch_pn_gates(gj, blocks, s); });
       printf("%-24s blocks %3d  ablate %3d (%s%s%s%s%s%s%s%s) : %6.2f us\n", c.name, blocks, ab, ab & 1 ? "noMFMA " : "", ab & 2 ? "noDMA " : "", ab & 4 ? "noLDSread " : "",
              ab & 8 ? "noEpilogue " : "", ab & 16 ? "noPrefetch " : "", ab & 32 ? "return-at-entry " : "", ab & 64 ? "return-after-job-lookup " : "",
              ab & 128 ? "return-before-product " : "", us);
+      if (ab >= 256) printf("      (256 = no k-block guards, 512 = unchecked DMA sources, 1024 = broadcast fragment reads)\n");
     }
     {   // the same grid with a small LDS request / fewer threads, returning at entry: what does dispatching the workgroups cost?
       int ab = 32; CK(hipMemcpyToSymbol(HIP_SYMBOL(rsr::g_pn_ablate), &ab, sizeof(int)));
       for (int lds : {0, 64 * 1024, 147456}) {
-        float us = time_graph(s, 50, 6, [&] { hipLaunchKernelGGL(k_pn_gates, dim3(blocks), dim3(768), lds, s, gj); });
+        float us = time_graph(s, 50, 6, [&] { hipLaunchKernelGGL((k_pn_gates<3, 4>), dim3(blocks), dim3(768), lds, s, gj); });
         printf("%-24s blocks %3d  return-at-entry, 768 threads, dynamic LDS %6d B : %6.2f us\n", c.name, blocks, lds, us);
       }
     }
   }
   int z = 0; CK(hipMemcpyToSymbol(HIP_SYMBOL(rsr::g_pn_ablate), &z, sizeof(int)));
   for (void* p : bufs) CK(hipFree(p));
+}
+
+// ------------------------------------------------------------------------------------------------ t5
+// what does one s_barrier cost in a 4 / 8 / 12-wave workgroup, alone and with a little VALU work between barriers?
+template <int NT>
+__global__ __launch_bounds__(NT) void k_barloop(int iters, int work, float* sink) {
+  float x = (float)threadIdx.x;
+  for (int i = 0; i < iters; ++i) {
+    for (int j = 0; j < work; ++j) x = x * 1.0001f + 0.5f;
+    asm volatile("" : "+v"(x));
+    __builtin_amdgcn_s_barrier();
+  }
+  if (x == 123.456f) sink[blockIdx.x] = x;
+}
+static void t5(hipStream_t s) {
+  printf("== t5: s_barrier cost: us per launch (192 workgroups, hipGraph), iters barriers with `work` dependent FMAs in between\n");
+  float* sink; CK(hipMalloc(&sink, 4096 * 4));
+  for (int work : {0, 32, 128}) {
+    for (int iters : {0, 10, 100}) {
+      float a = time_graph(s, 50, 6, [&] { hipLaunchKernelGGL(k_barloop<256>, dim3(192), dim3(256), 0, s, iters, work, sink); });
+      float b = time_graph(s, 50, 6, [&] { hipLaunchKernelGGL(k_barloop<512>, dim3(192), dim3(512), 0, s, iters, work, sink); });
+      float c = time_graph(s, 50, 6, [&] { hipLaunchKernelGGL(k_barloop<768>, dim3(192), dim3(768), 0, s, iters, work, sink); });
+      printf("work %3d iters %3d : 256 thr %6.2f  512 thr %6.2f  768 thr %6.2f us\n", work, iters, a, b, c);
+    }
+  }
+  CK(hipFree(sink));
+}
+
+// ------------------------------------------------------------------------------------------------ t6
+// the persistent discriminator recurrence (rsrgan_amd/csrc/dlstm.hip) at BASELINE's size, with per-phase shader-cycle counters
+static void t6(hipStream_t s) {
+  using namespace rsr;
+  const int N = 64, T = 100, H = 256, P = 40, I = 40, L = 2;
+  printf("== t6: k_dl_fwd, N=%d rows, %d layers LSTMP(%d, proj %d), T=%d (profiled workgroup: block %d)\n", N, L, H, P, T, DL_PROF_BLOCK);
+  auto dal = [&](size_t n, float v) { float* p; CK(hipMalloc(&p, n * 4)); std::vector<float> h(n); for (size_t i = 0; i < n; ++i) h[i] = v * ((float)((i * 2654435761u >> 20) & 255) / 128.f - 1.f);
+                                       CK(hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice)); return p; };
+  DlFwdArgs a{};
+  a.L = L; a.N = N; a.Ns = N; a.T = T; a.forget_bias = 1.f;
+  int* len; CK(hipMalloc(&len, N * 4)); { std::vector<int> h(N, T); CK(hipMemcpy(len, h.data(), N * 4, hipMemcpyHostToDevice)); }
+  a.len = len;
+  unsigned* flags; CK(hipMalloc(&flags, (DL_MAXL * 64 + 64) * 4)); a.flags = flags; a.err = flags + DL_MAXL * 64;
+  CK(hipMalloc(&a.dump, 512 * 4));
+  float* prev_out = nullptr;
+  for (int l = 0; l < L; ++l) {
+    DlLayer& y = a.layer[l];
+    y.I = I; y.H = H; y.P = P; y.ldI = 40; y.ldP = 40; y.ldH = 256;
+    y.in = l == 0 ? dal((size_t)T * N * 40, 1.f) : prev_out;
+    y.KxT = dal((size_t)4 * H * 40, 0.1f); y.KhT = dal((size_t)4 * H * 40, 0.1f); y.WpT = dal((size_t)P * 256, 0.1f);
+    y.bias = dal(4 * H, 0.1f); y.wf = dal(H, 0.1f); y.wi = dal(H, 0.1f); y.wo = dal(H, 0.1f);
+    y.gates = dal((size_t)T * N * 4 * H, 0.f); y.c = dal((size_t)(T + 1) * N * H, 0.f); y.h = dal((size_t)T * N * 256, 0.f);
+    y.mst = dal((size_t)(T + 1) * N * 40, 0.f); y.out = dal((size_t)T * N * 40, 0.f);
+    prev_out = y.out;
+  }
+  if (!dl_fwd_supported(a)) { printf("not supported\n"); return; }
+  for (int i = 0; i < 3; ++i) launch_dl_fwd(a, s);
+  CK(hipStreamSynchronize(s));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0, s));
+  for (int i = 0; i < 10; ++i) launch_dl_fwd(a, s);
+  CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  unsigned long long prof[16]; CK(hipMemcpyFromSymbol(prof, HIP_SYMBOL(rsr::g_dl_prof), sizeof(prof)));
+  unsigned err; CK(hipMemcpy(&err, a.err, 4, hipMemcpyDeviceToHost));
+  printf("k_dl_fwd: %.1f us per launch = %.2f us per step (err flag %u)\n", ms * 100.f, ms * 100.f / T, err);
+  const char* nm[8] = {"x wait + issue", "gates MFMA", "cell update + stash stores", "projection MFMA + partial store", "barrier 1", "reduce + m_t + x commit", "drain + barrier 2 + flag", "loop top"};
+  unsigned long long tot = 0; for (int i = 0; i < 8; ++i) tot += prof[i];
+  for (int i = 0; i < 8; ++i) printf("  phase %-34s %8.0f cycles per step (%4.1f %%)\n", nm[i], (double)prof[i] / T, 100.0 * prof[i] / (double)tot);
+  printf("  total %.0f cycles per step\n", (double)tot / T);
+}
+
+// ------------------------------------------------------------------------------------------------ t7
+// round 1's backward phase A kernel on one generator diagonal (3 layers, N=64, H=760, P=280), parts switched off
+static void t7(hipStream_t s) {
+  using namespace rsr;
+  printf("== t7: k_bwd_a<8> on one diagonal (3 generator layers N=64 H=760 P=280 [+ 2 discriminator jobs]), us per launch in a hipGraph\n");
+  auto dal = [&](size_t n, float v) { float* p; CK(hipMalloc(&p, n * 4)); std::vector<float> h(n); for (size_t i = 0; i < n; ++i) h[i] = v * ((float)((i * 2654435761u >> 20) & 255) / 256.f);
+                                       CK(hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice)); return p; };
+  int* len; CK(hipMalloc(&len, 128 * 4)); { std::vector<int> h(128, 1000); CK(hipMemcpy(len, h.data(), 128 * 4, hipMemcpyHostToDevice)); }
+  // a stash big enough to be cold in every cache: 40 time steps per layer, one launch reads a different step each time
+  const int NT = 40;
+  auto mk = [&](BwdAJob& a, int N, int H, int P, int tstep, float* gates, float* cbuf, float* dcb, float* dm, float* dout, float* dmt, float* Wp, float* pe) {
+    a = BwdAJob{};
+    a.dout = dout; a.dmst = dm; a.Wp = Wp; a.dmt = dmt;
+    a.gates = gates + (size_t)tstep * N * 4 * H; a.c_prev = cbuf + (size_t)tstep * N * H; a.c_cur = cbuf + (size_t)(tstep + 1) * N * H;
+    a.wf = pe; a.wi = pe + H; a.wo = pe + 2 * H; a.dc = dcb; a.len = len; a.ldm = (P + 3) & ~3; a.P = P; a.t = 0; a.N = N; a.H = H;
+    a.nblk_c = (H + 15) / 16;
+  };
+  struct L { float *gates, *c, *dc, *dm, *dout, *dmt, *Wp, *pe; int N, H, P; };
+  std::vector<L> Ls;
+  for (int i = 0; i < 5; ++i) {
+    L l; l.N = 64; l.H = i < 3 ? 760 : 256; l.P = i < 3 ? 280 : 40;
+    l.gates = dal((size_t)NT * l.N * 4 * l.H, 0.5f); l.c = dal((size_t)(NT + 1) * l.N * l.H, 0.5f); l.dc = dal((size_t)l.N * l.H, 0.1f);
+    l.dm = dal((size_t)l.N * l.P, 0.1f); l.dout = dal((size_t)l.N * l.P, 0.1f); l.dmt = dal((size_t)l.N * l.P, 0.f);
+    l.Wp = dal((size_t)l.H * l.P, 0.05f); l.pe = dal(3 * l.H, 0.1f);
+    Ls.push_back(l);
+  }
+  for (int nd : {2, 0}) {
+    for (int ab : {0, 1, 2, 4, 8, 16, 4 | 8, 2 | 4 | 8 | 16, 1 | 2 | 4 | 8 | 16, 32}) {
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(rsr::g_ka_ablate), &ab, sizeof(int)));
+      int tstep = 0;
+      auto launch = [&] {
+        BwdAJobs aj{}; int base = 0;
+        for (int i = 0; i < 3 + nd; ++i) { BwdAJob& a = aj.j[aj.n++]; const L& l = Ls[i]; mk(a, l.N, l.H, l.P, tstep, l.gates, l.c, l.dc, l.dm, l.dout, l.dmt, l.Wp, l.pe);
+                                             a.blk_base = base; base += job_blocks(a.nblk_c, l.N); }
+        launch_bwd_a(aj, base, 0, s);
+        tstep = (tstep + 7) % NT;
+      };
+      launch(); CK(hipStreamSynchronize(s));
+      float us = time_graph(s, 40, 6, launch);
+      printf("3 G layers + %d D jobs  ablate %2d (%s%s%s%s%s%s) : %6.2f us\n", nd, ab, ab & 1 ? "noMFMA " : "", ab & 2 ? "noOperandLoads " : "", ab & 4 ? "noEpilogueLoads " : "",
+             ab & 8 ? "noEpilogueStores " : "", ab & 16 ? "noDmtStore " : "", ab & 32 ? "return-at-entry" : "", us);
+    }
+  }
+  int z = 0; CK(hipMemcpyToSymbol(HIP_SYMBOL(rsr::g_ka_ablate), &z, sizeof(int)));
 }
 
 int main(int argc, char** argv) {
@@ -419,6 +543,9 @@ int main(int argc, char** argv) {
   if (!strcmp(what, "t2") || !strcmp(what, "all")) t2(s);
   if (!strcmp(what, "t3") || !strcmp(what, "all")) t3(s);
   if (!strcmp(what, "t4") || !strcmp(what, "all")) t4(s);
+  if (!strcmp(what, "t5") || !strcmp(what, "all")) t5(s);
+  if (!strcmp(what, "t6") || !strcmp(what, "all")) t6(s);
+  if (!strcmp(what, "t7") || !strcmp(what, "all")) t7(s);
   CK(hipStreamDestroy(s));
   return 0;
 }
