@@ -21,6 +21,7 @@ struct FwdGateJob {
   const float* KxT;    // [4H][ldx]   (k-contiguous transposed copy of kernel rows 0..I)
   const float* m;      // [N][ldm] carried recurrent state m_{t-1}
   const float* KhT;    // [4H][ldm]
+  const float* Wsw;    // fragment-tiled copy of [KxT | KhT] (or of KhT alone when zx holds the x-part): tiles [gate][cell block][k-block][256], see SwizzleJob
   const float* zx;     // [N][4H] precomputed x_t.Kx + bias, or nullptr
   const float* bias;   // [4H] (used when zx == nullptr)
   const float* wf; const float* wi; const float* wo;   // peepholes [H]
@@ -40,6 +41,7 @@ struct FwdGateJobs { int n; float forget_bias; FwdGateJob j[MAXJ]; };
 struct FwdProjJob {
   const float* h;       // [N][ldh]
   const float* WpT;     // [P][ldh]
+  const float* WpT_sw;  // fragment-tiled copy of WpT: tiles [column block][k-block][256], or nullptr (fully_connected stages)
   const float* m_prev;  // [N][ldm]
   float* m_out;         // [N][ldm] carried state
   float* out;           // [N][ldm] masked output (0 for t >= len)
@@ -58,6 +60,7 @@ struct BwdAJob {
   const float* dout;    // [N][ldm] grad of the masked output at t (nullptr = 0)
   const float* dmst;    // [N][ldm] carried grad of the m state
   const float* Wp;      // [H][ldm]
+  const float* Wp_sw;   // fragment-tiled copy of Wp: tiles [cell block][k-block][256], or nullptr
   float* dmt;           // [N][ldm] out: total dm at t (0 on masked rows)
   float* gates;         // [N][4H]  in: activations, out: dz = (dai, dj, daf, dao)
   const float* c_prev;  // [N][H]   c_{t-1} (state before the step)
@@ -74,6 +77,7 @@ struct BwdAJobs { int n; BwdAJob j[MAXJ]; };
 struct BwdBJob {
   const float* dz;      // [N][4H]
   const float* K;       // [(I+R)][4H] TF-layout kernel
+  const float* Ksw;     // fragment-tiled copy of rows [n_begin, n_end) of K: tiles [row block from n_begin][k-block][256], or nullptr
   float* dx;            // [N][lddx] receives columns n < I (nullptr if n_begin >= I)
   float* dmst;          // [N][ldm]  columns n >= I:  dmst = (mask ? 0 : dmst) + value
   const int* len;
@@ -94,6 +98,8 @@ int fwd_gates_rows();
 void set_fwd_gates_rows(int r);
 void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
 void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
+int bwd_a_cells();                 // cells per column block of the phase-A kernel in use (BwdAJob::nblk_c = ceil(H / bwd_a_cells()))
+void set_bwd_a_form(int f);        // 2 (default): k_bwd_a2, 32-cell blocks; 1: k_bwd_a, 16-cell blocks
 void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
 void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
 // split-K phase B: fills ws/ldw/KG/... of every job (ws_base: >= bwd_b_ws_floats(jobs) floats) and launches both kernels
@@ -148,6 +154,20 @@ void launch_add_noise_rows(const float* src_tm, const float* noise, float* dst, 
                            int Ns, int row0, hipStream_t s);
 void launch_transpose(const float* src, int lds, float* dst, int ldd, int R, int C, hipStream_t s);        // dst[c][r] = src[r][c]
 void launch_fill(float* p, size_t n, float v, hipStream_t s);
+// Fragment-tiled ("swizzled") weight copies.  The step kernels feed v_mfma_f32_16x16x4_f32 with a B fragment per lane
+// l = (q = l >> 4, lr = l & 15): four consecutive k of output column lr.  Read from a row-major k-contiguous matrix that is 16 rows
+// x 64 B per wave-load, which the memory pipeline serves at ~15 B/clk/CU even from a hot L2 (tools/ubench/l2.hip section D:
+// 3.4x slower than a contiguous 1 KB wave-load).  A tiled copy stores the 16 columns x 16 k of one MFMA k-block as
+// [q][lr][4] = 256 floats, so lane l reads bytes [16 l, 16 l + 16) of a contiguous 1 KB tile; tiles of one column block are
+// contiguous along k.  Logical matrix M[c][k], c < 16*nct, k < 16*nkb, zero outside the source:
+//   gates == 0: M[c][k] = src[(c0 + c) * ld + k]                       (c < C, k < K1)               -- rows of a k-contiguous matrix
+//   gates >= 1: c = g * 16*ncb + cell (ncb = ceil(H/16) per gate); column of the source = g * H + cell;
+//               k < kx: row k (valid k < I) ; k >= kx: row I + (k - kx) (valid k - kx < P) ; M = src[row * ld + column]
+//               (the [x | m] concatenation of the gates product over a TF-layout kernel [(I+P)][4H]; kx = padded width of x, or 0)
+struct SwizzleJob { const float* src; float* dst; int ld, gates, H, C, c0, K1, I, P, kx, nct, nkb, blk_base; };
+struct SwizzleList { int n; SwizzleJob j[24]; };
+void launch_swizzle_many(SwizzleList& sl, hipStream_t s);
+inline size_t swizzle_floats(int nct, int nkb) { return (size_t)nct * nkb * 256; }
 struct TransposeJob { const float* src; float* dst; int lds, ldd, R, C, blk_base; };   // dst[c][r] = src[r][c]
 struct TransposeList { int n; TransposeJob j[16]; };
 void launch_transpose_many(TransposeList& tl, hipStream_t s);

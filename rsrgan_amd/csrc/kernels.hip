@@ -27,6 +27,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// tools/ubench/trace.hip compiles this file with RSR_TRACE: thread 0 of every workgroup stamps the shader clock at the phase
+// boundaries of the step kernels into g_trace[block][16] ([0] = 100 MHz real-time counter at entry, [1..9] = s_memtime stamps,
+// [14] = HW_ID, [15] = XCC_ID); the product build has no such code
+#ifdef RSR_TRACE
+__device__ unsigned long long g_trace[8192 * 16];
+#define TR_BEGIN() do { if (threadIdx.x == 0 && blockIdx.x < 8192) { unsigned long long* t_ = g_trace + (size_t)blockIdx.x * 16; \
+    t_[0] = __builtin_amdgcn_s_memrealtime(); t_[1] = __builtin_amdgcn_s_memtime(); \
+    t_[14] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); t_[15] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); \
+    for (int i_ = 2; i_ < 14; ++i_) t_[i_] = 0; } } while (0)
+#define TR(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_trace[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TR_END() do { if (threadIdx.x == 0 && blockIdx.x < 8192) { g_trace[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime(); \
+    g_trace[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define TR_BEGIN() do { } while (0)
+#define TR(i) do { } while (0)
+#define TR_END() do { } while (0)
+#endif
+
 template <typename JobT>
 __device__ __forceinline__ int find_job(const JobT* j, int n, int bid) {
   int ji = 0;
@@ -34,6 +52,40 @@ __device__ __forceinline__ int find_job(const JobT* j, int n, int bid) {
   for (int q = 1; q < MAXJ; ++q)
     if (q < n && bid >= j[q].blk_base) ji = q;
   return ji;
+}
+
+// The job record of a workgroup in ONE memory round trip: lane i of every wave loads dword i of the record (kernarg segment or a
+// device table, <= 256 B) and v_readlane moves it into scalar registers.  Reading the fields straight from the by-value
+// kernel argument costs 4-6 dependent scalar-cache round trips at the head of every workgroup (s_load as each group of fields
+// is first needed, ~0.3-0.5 us each on a cold scalar cache: tools/ubench/trace.hip, 1.5-2 us of "issue" time per workgroup).
+// (pointers rebuilt from raw dwords are generic to the compiler, which would make every access a flat_load/flat_store: the
+// integer -> address-space-1 pointer -> generic round trip lets InferAddressSpaces turn them back into global accesses)
+template <typename T>
+__device__ __forceinline__ T* as_global(T* p) { return (T*)(__attribute__((address_space(1))) T*)(unsigned long long)p; }
+#define RSR_G(f) J.f = as_global(J.f);
+__device__ __forceinline__ void globalize(FwdGateJob& J) {
+  RSR_G(x) RSR_G(KxT) RSR_G(m) RSR_G(KhT) RSR_G(Wsw) RSR_G(zx) RSR_G(bias) RSR_G(wf) RSR_G(wi) RSR_G(wo) RSR_G(c_prev) RSR_G(c_out) RSR_G(gates)
+  RSR_G(h) RSR_G(len) RSR_G(np_m_out) RSR_G(np_out) RSR_G(np_res_in) RSR_G(np_res_out)
+}
+__device__ __forceinline__ void globalize(FwdProjJob& J) {
+  RSR_G(h) RSR_G(WpT) RSR_G(WpT_sw) RSR_G(m_prev) RSR_G(m_out) RSR_G(out) RSR_G(res_in) RSR_G(res_out) RSR_G(len) RSR_G(bias) RSR_G(noise)
+}
+__device__ __forceinline__ void globalize(BwdAJob& J) {
+  RSR_G(dout) RSR_G(dmst) RSR_G(Wp) RSR_G(Wp_sw) RSR_G(dmt) RSR_G(gates) RSR_G(c_prev) RSR_G(c_cur) RSR_G(wf) RSR_G(wi) RSR_G(wo) RSR_G(dc) RSR_G(len)
+}
+__device__ __forceinline__ void globalize(BwdBJob& J) { RSR_G(dz) RSR_G(K) RSR_G(Ksw) RSR_G(dx) RSR_G(dmst) RSR_G(len) RSR_G(ws) }
+#undef RSR_G
+template <typename JobT>
+__device__ __forceinline__ JobT load_job(const JobT* p) {
+  constexpr int ND = (int)(sizeof(JobT) / 4);
+  static_assert(sizeof(JobT) % 4 == 0 && ND <= 64, "job record must fit one dword per lane");
+  const int lane = threadIdx.x & 63;
+  const unsigned v = reinterpret_cast<const unsigned*>(p)[lane < ND ? lane : 0];
+  union U { JobT j; unsigned d[ND]; __device__ U() {} } u;
+#pragma unroll
+  for (int i = 0; i < ND; ++i) u.d[i] = (unsigned)__builtin_amdgcn_readlane((int)v, i);
+  globalize(u.j);
+  return u.j;
 }
 
 // Column-block <-> XCD affinity: a job's blocks are laid out as nblk_r rows of nblk_c8 =
@@ -48,87 +100,36 @@ __device__ __forceinline__ bool tile_of_block(int lb, int nblk_c, int& cb, int& 
   return cb < nblk_c;
 }
 
-// One K segment of a tile product: per-lane row pointers (nullptr = out of range -> zeros).
+// One tile product's operands.  RULE for every load of the step kernels: the address is always valid (row / column / k
+// clamped by the caller) and the LOAD IS UNCONDITIONAL; what must not contribute is zeroed afterwards with a select.  A load
+// under a branch makes the compiler close the branch with s_waitcnt vmcnt(0), i.e. one full memory round trip per load
+// instead of one per batch (seen in the ISA of round 1's kernels: 6-18 serialised round trips per workgroup).
 template <int RT>
 struct Seg {
-  const float* a[RT];   // A rows of this lane (row = l&15 of each 16-row tile), k-contiguous
-  const float* w;       // W row of this lane (col = l&15), k-contiguous
-  int ld;               // zero-padded row length (multiple of 4)
+  const float* a[RT];   // A rows of this lane (row = l&15 of each 16-row tile, clamped to a real row), k-contiguous
+  const float* w;       // W row of this lane (col = l&15, clamped), k-contiguous -- used when wt == nullptr
+  const float* wt;      // or: this lane's float4 slot of k-block 0 of the fragment-tiled copy (kernels.h SwizzleJob), next k-block 256 floats on
+  int ld;               // row length (multiple of 4); k >= ld contributes nothing
   int nkb;              // ceil(ld/16) k-blocks
+  bool wok;             // this lane's output column exists (row-major W only; tiled copies hold zeros there)
 };
 
-// acc[i] (16x16, i < RT row tiles) += A_i[.,k] * W[.,k] over the k-blocks [jb,je) of the
-// concatenation of segments s0|s1.  All operand loads of a CH-k-block chunk are issued before the
-// first MFMA of the chunk, so a wave pays ~one L2 round trip per chunk instead of one per k-block.
-template <int RT, int CH>
-__device__ __forceinline__ void mma_2seg(f32x4 (&acc)[RT], const Seg<RT>& s0, const Seg<RT>& s1, int jb, int je, int q) {
-  for (int j0 = jb; j0 < je; j0 += CH) {
-    float4 av[CH][RT], bv[CH];
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int j = j0 + c;
-      const bool first = j < s0.nkb;
-      const int k = (first ? j : j - s0.nkb) * 16 + 4 * q;
-      const int ld = first ? s0.ld : s1.ld;
-      const bool ok = (j < je) && (k < ld);
-      const float* w = first ? s0.w : s1.w;
-      bv[c] = (ok && w) ? *reinterpret_cast<const float4*>(w + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        const float* a = first ? s0.a[i] : s1.a[i];
-        av[c][i] = (ok && a) ? *reinterpret_cast<const float4*>(a + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-#pragma unroll
-      for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].x, bv[c].x, acc[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].y, bv[c].y, acc[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].z, bv[c].z, acc[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].w, bv[c].w, acc[i], 0, 0, 0);
-    }
-  }
-}
-
-// Software-pipelined variant: two register sets; the loads of chunk c+1 are in flight while chunk c
-// feeds the matrix pipe (the compiler's counted vmcnt waits only for the set it is about to use).
-// VAR (ablation bits, micro-benchmarks only; production = 0): 1 = no A loads, 2 = no B loads, 4 = no MFMA
-template <int RT, int CH, int VAR = 0>
-__device__ __forceinline__ void load_chunk(float4 (&av)[CH][RT], float4 (&bv)[CH], const Seg<RT>& s0, const Seg<RT>& s1,
-                                           int j0, int je, int q) {
+// operands of the CH k-blocks [j0, j0 + CH) (blocks >= je: clamped loads, zero weights)
+template <int RT, int CH, bool TILED>
+__device__ __forceinline__ void load_chunk(float4 (&av)[CH][RT], float4 (&bv)[CH], const Seg<RT>& s, int j0, int je, int q) {
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
-    const int j = j0 + c;
-    const bool first = j < s0.nkb;
-    // VAR & 32: k-blocks are processed in pairs; lane q owns the 32 contiguous bytes [8q, 8q+8) of
-    // each 32-float super-block, so the 4 q-lanes of a row read one full 128-B line (single segment)
-    const int jj = first ? j : j - s0.nkb;
-    const int k = (VAR & 32) ? ((jj >> 1) * 32 + 8 * q + 4 * (jj & 1)) : (jj * 16 + 4 * q);
-    const int ld = first ? s0.ld : s1.ld;
-    const bool ok = (j < je) && (k < ld);
-    const float* w = first ? s0.w : s1.w;
-    if (VAR & 2) bv[c] = make_float4(1.f, 1.f, 1.f, 1.f);
-    else bv[c] = (ok && w) ? *reinterpret_cast<const float4*>(w + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int j = j0 + c, jc = min(j, s.nkb - 1);
+    const int k = jc * 16 + 4 * q, kc = min(k, s.ld - 4);
+    const float4 b = TILED ? *reinterpret_cast<const float4*>(s.wt + (size_t)jc * 256) : *reinterpret_cast<const float4*>(s.w + kc);
+    const bool ok = (j < je) && (k < s.ld) && (TILED || s.wok);
+    bv[c] = make_float4(ok ? b.x : 0.f, ok ? b.y : 0.f, ok ? b.z : 0.f, ok ? b.w : 0.f);
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-      const float* a = first ? s0.a[i] : s1.a[i];
-      if (VAR & 1) av[c][i] = make_float4(1.f, 1.f, 1.f, 1.f);
-      else av[c][i] = (ok && a) ? *reinterpret_cast<const float4*>(a + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int i = 0; i < RT; ++i) av[c][i] = *reinterpret_cast<const float4*>(s.a[i] + kc);
   }
 }
-template <int RT, int CH, int VAR = 0>
+template <int RT, int CH>
 __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[RT], const float4 (&av)[CH][RT], const float4 (&bv)[CH]) {
-  if (VAR & 4) {        // keep the loads alive without the matrix pipe
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-      for (int i = 0; i < RT; ++i) acc[i][0] += av[c][i].x + av[c][i].w + bv[c].x + bv[c].w;
-    return;
-  }
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
 #pragma unroll
@@ -141,20 +142,42 @@ __device__ __forceinline__ void mma_chunk(f32x4 (&acc)[RT], const float4 (&av)[C
     for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].w, bv[c].w, acc[i], 0, 0, 0);
   }
 }
-template <int RT, int CH, int VAR = 0>
-__device__ __forceinline__ void mma_2seg_pipe(f32x4 (&acc)[RT], const Seg<RT>& s0, const Seg<RT>& s1, int jb, int je, int q) {
+// acc[i] (16x16, i < RT row tiles) += A_i[.,k] * W[.,k] over the k-blocks [jb,je).  All operand loads of a CH-k-block chunk
+// are issued before the first MFMA of the chunk: one L2 round trip per chunk.
+template <int RT, int CH, bool TILED>
+__device__ __forceinline__ void mma_seg_t(f32x4 (&acc)[RT], const Seg<RT>& s, int jb, int je, int q) {
+  for (int j0 = jb; j0 < je; j0 += CH) {
+    float4 av[CH][RT], bv[CH];
+    load_chunk<RT, CH, TILED>(av, bv, s, j0, je, q);
+    __builtin_amdgcn_sched_barrier(0);        // all loads of the chunk are issued before its first MFMA (the scheduler would sink them)
+    mma_chunk<RT, CH>(acc, av, bv);
+  }
+}
+// Software-pipelined variant: two register sets; the loads of chunk c+1 are in flight while chunk c feeds the matrix pipe
+// (the compiler's counted vmcnt waits only for the set it is about to use).
+template <int RT, int CH, bool TILED>
+__device__ __forceinline__ void mma_seg_pipe_t(f32x4 (&acc)[RT], const Seg<RT>& s, int jb, int je, int q) {
   float4 a0[CH][RT], b0[CH], a1[CH][RT], b1[CH];
   if (jb >= je) return;                                   // (wave-uniform)
-  load_chunk<RT, CH, VAR>(a0, b0, s0, s1, jb, je, q);
+  load_chunk<RT, CH, TILED>(a0, b0, s, jb, je, q);
   for (int j0 = jb; j0 < je; j0 += 2 * CH) {
-    const bool more1 = j0 + CH < je, more2 = j0 + 2 * CH < je;
-    if (more1) load_chunk<RT, CH, VAR>(a1, b1, s0, s1, j0 + CH, je, q);
-    mma_chunk<RT, CH, VAR>(acc, a0, b0);
-    if (more1) {
-      if (more2) load_chunk<RT, CH, VAR>(a0, b0, s0, s1, j0 + 2 * CH, je, q);
-      mma_chunk<RT, CH, VAR>(acc, a1, b1);
-    }
+    load_chunk<RT, CH, TILED>(a1, b1, s, j0 + CH, je, q);           // past je: clamped addresses, zero weights
+    __builtin_amdgcn_sched_barrier(0);
+    mma_chunk<RT, CH>(acc, a0, b0);
+    load_chunk<RT, CH, TILED>(a0, b0, s, j0 + 2 * CH, je, q);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_chunk<RT, CH>(acc, a1, b1);
   }
+}
+template <int RT, int CH>
+__device__ __forceinline__ void mma_seg(f32x4 (&acc)[RT], const Seg<RT>& s, int jb, int je, int q) {
+  if (s.wt) mma_seg_t<RT, CH, true>(acc, s, jb, je, q);             // (uniform per workgroup)
+  else mma_seg_t<RT, CH, false>(acc, s, jb, je, q);
+}
+template <int RT, int CH>
+__device__ __forceinline__ void mma_seg_pipe(f32x4 (&acc)[RT], const Seg<RT>& s, int jb, int je, int q) {
+  if (s.wt) mma_seg_pipe_t<RT, CH, true>(acc, s, jb, je, q);
+  else mma_seg_pipe_t<RT, CH, false>(acc, s, jb, je, q);
 }
 
 constexpr int RT = 2;          // 16-row tiles per wave: one W fragment feeds 2 x 4 MFMAs
@@ -181,10 +204,12 @@ template <int CHB, int RTG, int RH = 1>
 __global__ __launch_bounds__(512 * RH, (RH == 1 && RTG == 2 && CHB <= 18) ? 4 : 2) void k_fwd_gates(const FwdGateJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = blockIdx.x;
+  TR_BEGIN();
   const int ji = find_job(jobs.j, jobs.n, bid);
-  const FwdGateJob& J = jobs.j[ji];
+  const FwdGateJob J = load_job(&jobs.j[ji]);
   int cb, rb;
   if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
+  TR(2);
   const int r0 = rb * 16 * RTG * RH, c0 = cb * 16;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform -> scalar branches
@@ -194,20 +219,15 @@ __global__ __launch_bounds__(512 * RH, (RH == 1 && RTG == 2 && CHB <= 18) ? 4 : 
   const int SA4 = gates_sa4(Ktot), SA = SA4 * 4;
 
   // (1) this wave's weight slice -> VGPRs (host guarantees <= CHB k-blocks per wave)
-  const int col = c0 + lr;
+  // (one contiguous 1 KB tile per wave-load from the fragment-tiled copy: zero beyond H cells / Ktot columns)
   const int nkb = (Ktot + 15) >> 4, per = (nkb + 1) >> 1;
   const int jb = ks * per, je = min(nkb, jb + per);
-  const size_t gcol = (size_t)gate * H + min(col, H - 1);
-  const float* wx = J.KxT + gcol * ldx;
-  const float* wm = J.KhT + gcol * ldm - ldx;          // so that wm[k] is valid for k >= ldx
+  const float* wt = J.Wsw + (size_t)(gate * J.nblk_c + cb) * nkb * 256 + lane * 4;
   float4 bv[CHB];
 #pragma unroll
-  for (int c = 0; c < CHB; ++c) {
-    const int k = (jb + c) * 16 + 4 * q;
-    const bool ok = (jb + c < je) && (k < Ktot) && (col < H);
-    const float* src = (k < ldx) ? wx : wm;
-    bv[c] = ok ? *reinterpret_cast<const float4*>(src + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  for (int c = 0; c < CHB; ++c)         // unconditional, clamped: the product below skips k-blocks >= je
+    bv[c] = *reinterpret_cast<const float4*>(wt + (size_t)min(jb + c, nkb - 1) * 256);
+  TR(10);
   // (2) A tile: lane p of the linear LDS image <- x / m element (rows >= N and pad columns get a
   // harmless finite dummy; they only ever meet zero weights or unstored rows)
   {
@@ -224,28 +244,32 @@ __global__ __launch_bounds__(512 * RH, (RH == 1 && RTG == 2 && CHB <= 18) ? 4 : 
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (size_t)p0 * 4), 16, 0, 0);
     }
   }
+  TR(11);
   // (3) epilogue operands of this thread's EPT (row, cell) elements, in flight together with (1) and (2)
   constexpr int EPT = RTG / 2;
   const int er = (tid >> 4) & 15, ec = tid & 15, ecell = c0 + ec;
   float zb[EPT][4], cp[EPT], pwi = 0.f, pwf = 0.f, pwo = 0.f;
   int elen[EPT];
   bool evalid[EPT];
-  if (ecell < H) { pwi = J.wi[ecell]; pwf = J.wf[ecell]; pwo = J.wo[ecell]; }
+  {
+    const int ecl = min(ecell, H - 1);                        // every load below is unconditional, from a clamped address
+    pwi = J.wi[ecl]; pwf = J.wf[ecl]; pwo = J.wo[ecl];
+    const float* zsrc = J.zx ? J.zx : J.bias;                 // (uniform select of the base pointer)
+    const size_t zrow = J.zx ? (size_t)H4 : 0;
 #pragma unroll
-  for (int u = 0; u < EPT; ++u) {
-    const int erow = r0 + ((tid >> 8) + 2 * RH * u) * 16 + er;
-    evalid[u] = erow < N && ecell < H;
-    cp[u] = 0.f; elen[u] = 0;
+    for (int u = 0; u < EPT; ++u) {
+      const int erow = r0 + ((tid >> 8) + 2 * RH * u) * 16 + er;
+      evalid[u] = erow < N && ecell < H;
+      const int erc = min(erow, N - 1);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) zb[u][g] = 0.f;
-    if (evalid[u]) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) zb[u][g] = J.zx ? J.zx[(size_t)erow * H4 + g * H + ecell] : J.bias[g * H + ecell];
-      cp[u] = J.c_prev[(size_t)erow * H + ecell];
-      elen[u] = J.len[erow];
+      for (int g = 0; g < 4; ++g) zb[u][g] = zsrc[(size_t)erc * zrow + g * H + ecl];
+      cp[u] = J.c_prev[(size_t)erc * H + ecl];
+      elen[u] = J.len[erc];
     }
   }
+  TR(3);
   __syncthreads();
+  TR(4);
   // (4) MFMAs: A fragments from LDS, B from registers; RTG independent accumulators interleave
   f32x4 acc[RTG];
 #pragma unroll
@@ -267,13 +291,16 @@ __global__ __launch_bounds__(512 * RH, (RH == 1 && RTG == 2 && CHB <= 18) ? 4 : 
       for (int i = 0; i < RTG; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bv[c].w, acc[i], 0, 0, 0);
     }
   }
+  TR(5);
   __syncthreads();                                     // everyone is done reading the A tile
+  TR(6);
   float (*zs)[RTG * RH][16][17] = reinterpret_cast<float (*)[RTG * RH][16][17]>(smem);      // zs[8][RTG*RH][16][17] aliases it
 #pragma unroll
   for (int i = 0; i < RTG; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) zs[w & 7][rh * RTG + i][q * 4 + r][lr] = acc[i][r];
   __syncthreads();
+  TR(7);
 
 #pragma unroll
   for (int u = 0; u < EPT; ++u) {
@@ -312,6 +339,7 @@ __global__ __launch_bounds__(512 * RH, (RH == 1 && RTG == 2 && CHB <= 18) ? 4 : 
       }
     }
   }
+  TR_END();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -321,8 +349,9 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW) void k_fwd_proj(const FwdProjJobs jobs) {
   __shared__ float zs[NW][RT][16][17];
   const int bid = blockIdx.x;
+  TR_BEGIN();
   const int ji = find_job(jobs.j, jobs.n, bid);
-  const FwdProjJob& J = jobs.j[ji];
+  const FwdProjJob J = load_job(&jobs.j[ji]);
   int cb, rb;
   if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
   const int r0 = rb * 16 * RT, c0 = cb * 16;
@@ -330,27 +359,45 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_proj(const FwdProjJobs jobs) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform -> scalar branches
   const int N = J.N, P = J.P;
   const int p = c0 + lr;
-  Seg<RT> s0, s1;
+  Seg<RT> s0;
   s0.ld = J.ldh; s0.nkb = (J.ldh + 15) >> 4;
-  s0.w = p < P ? J.WpT + (size_t)p * J.ldh : nullptr;
-  s1.ld = 0; s1.nkb = 0; s1.w = nullptr;
+  s0.w = J.WpT + (size_t)min(p, P - 1) * J.ldh; s0.wok = p < P;
+  s0.wt = J.WpT_sw ? J.WpT_sw + (size_t)cb * s0.nkb * 256 + lane * 4 : nullptr;
 #pragma unroll
-  for (int i = 0; i < RT; ++i) {
-    const int arow = r0 + i * 16 + lr;
-    s0.a[i] = arow < N ? J.h + (size_t)arow * J.ldh : nullptr;
-    s1.a[i] = nullptr;
+  for (int i = 0; i < RT; ++i) s0.a[i] = J.h + (size_t)min(r0 + i * 16 + lr, N - 1) * J.ldh;
+  // epilogue operands of this thread's elements, requested before the product (unconditional loads from clamped / stand-in
+  // addresses: m_out is always a valid [N][ldm] buffer)
+  constexpr int EPT = (RT * 256) / (64 * NW);
+  float e_mprev[EPT], e_bias[EPT], e_noise[EPT], e_res[EPT];
+  int e_len[EPT];
+#pragma unroll
+  for (int u = 0; u < EPT; ++u) {
+    const int e = tid + u * 64 * NW;
+    const int i = e >> 8, er = (e >> 4) & 15, ec = e & 15;
+    const int row = min(r0 + i * 16 + er, N - 1), pp = min(c0 + ec, P - 1);
+    const size_t mi = (size_t)row * J.ldm + pp;
+    e_mprev[u] = (J.m_prev ? J.m_prev : J.m_out)[mi];
+    e_bias[u] = (J.bias ? J.bias : J.WpT)[pp];
+    e_len[u] = (J.len ? J.len : reinterpret_cast<const int*>(J.WpT))[row];
+    e_noise[u] = (J.noise ? J.noise : J.m_out)[(size_t)row * P + pp];      // (P <= ldm: inside the stand-in too)
+    e_res[u] = (J.res_in ? J.res_in : J.m_out)[mi];
   }
   const int per = (s0.nkb + NW - 1) / NW;
   f32x4 acc[RT];
 #pragma unroll
   for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  mma_2seg<RT, 6>(acc, s0, s1, w * per, min(s0.nkb, (w + 1) * per), q);
+  TR(2);
+  mma_seg<RT, 6>(acc, s0, w * per, min(s0.nkb, (w + 1) * per), q);
+  TR(5);
 #pragma unroll
   for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) zs[w][i][q * 4 + r][lr] = acc[i][r];
   __syncthreads();
-  for (int e = tid; e < RT * 256; e += 64 * NW) {
+  TR(7);
+#pragma unroll
+  for (int u = 0; u < EPT; ++u) {
+    const int e = tid + u * 64 * NW;
     const int i = e >> 8, er = (e >> 4) & 15, ec = e & 15;
     const int row = r0 + i * 16 + er, pp = c0 + ec;
     if (row >= N || pp >= P) continue;
@@ -358,14 +405,15 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_proj(const FwdProjJobs jobs) {
 #pragma unroll
     for (int s = 0; s < NW; ++s) v += zs[s][i][er][ec];
     const size_t mi = (size_t)row * J.ldm + pp;
-    if (J.bias) v += J.bias[pp];
-    const bool live = J.len ? (J.t < J.len[row]) : true;
-    J.m_out[mi] = live ? v : J.m_prev[mi];
+    if (J.bias) v += e_bias[u];
+    const bool live = J.len ? (J.t < e_len[u]) : true;
+    J.m_out[mi] = live ? v : e_mprev[u];
     float o = live ? v : 0.f;
-    if (J.noise) o += J.noise[(size_t)row * P + pp];
+    if (J.noise) o += e_noise[u];
     J.out[(size_t)row * J.ldo + pp] = o;
-    if (J.res_out) J.res_out[mi] = (live ? v : 0.f) + J.res_in[mi];
+    if (J.res_out) J.res_out[mi] = (live ? v : 0.f) + e_res[u];
   }
+  TR_END();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -388,10 +436,12 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
   const int ka_ab = g_ka_ablate;
   if (!KA_ON(32)) return;
 #endif
+  TR_BEGIN();
   const int ji = find_job(jobs.j, jobs.n, bid);
-  const BwdAJob& J = jobs.j[ji];
+  const BwdAJob J = load_job(&jobs.j[ji]);
   int cb, rb;
   if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
+  TR(2);
   const int r0 = rb * 16 * RT, c0 = cb * 16;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform -> scalar branches
@@ -415,7 +465,8 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
   for (int c = 0; c < CH; ++c) {
     const int k = min((jb + c) * 16 + 4 * q, ldm - 4);
     bv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (KA_ON(2)) bv[c] = *reinterpret_cast<const float4*>(wrow + k);
+    if (KA_ON(2)) bv[c] = J.Wp_sw ? *reinterpret_cast<const float4*>(J.Wp_sw + ((size_t)cb * nkb + min(jb + c, nkb - 1)) * 256 + lane * 4)
+                                  : *reinterpret_cast<const float4*>(wrow + k);
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
       av[c][i] = make_float4(0.f, 0.f, 0.f, 0.f); dv[c][i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -425,6 +476,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
       }
     }
   }
+  TR(10);
   // epilogue operands (one (row, cell) per thread when NW == 8), in flight with the above
   float eg[4] = {0.f, 0.f, 0.f, 0.f}, ecp = 0.f, ecn = 0.f, edc = 0.f, ewo = 0.f, ewi = 0.f, ewf = 0.f;
   int elen = 0;
@@ -442,6 +494,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
   f32x4 acc[RT];
 #pragma unroll
   for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  TR(3);
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int k = (jb + c) * 16 + 4 * q;
@@ -473,11 +526,13 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
   }
   }
   static_assert(NW == 8, "k_bwd_a: 8 waves x 3 k-blocks cover K <= 384 floats; one epilogue element per thread");
+  TR(5);
 #pragma unroll
   for (int i = 0; i < RT; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) zs[w][i][q * 4 + r][lr] = acc[i][r];
   __syncthreads();
+  TR(7);
   if (evalid && KA_ON(8)) {
     float* g = J.gates + (size_t)erow * H4 + ecell;
     if (J.t < elen) {
@@ -503,6 +558,156 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
       g[0] = 0.f; g[H] = 0.f; g[2 * H] = 0.f; g[3 * H] = 0.f;     // dc passes through unchanged
     }
   }
+  TR_END();
+}
+
+// ---------------------------------------------------------------------------------------
+// backward phase A, second form (the default): WG = 4 waves on a 32-row x 32-cell tile.
+// What the phase trace of k_bwd_a shows (tools/ubench/trace.hip): its ~6 us blocks are instruction issue and latency, not
+// bytes -- 48 column blocks per row block each re-load the same dm rows as MFMA fragments (16 rows x 64 B per wave-load,
+// ~40 instructions of address arithmetic and predication per load), then reduce an 8-way K split through LDS.  Here
+//   - the operand dm = mask.(dout + dmst) [32 x P] is summed ONCE per workgroup from coalesced float4 loads into an LDS image
+//     (the column-block-0 workgroup also stores it as dm_t for the weight gradients),
+//   - every wave owns one 16x16 output tile with the full K = P in two interleaved accumulators (no cross-wave reduction),
+//     weights from the fragment-tiled copy (one contiguous 1 KB wave-load per k-block),
+//   - the cell gradients are finished in the accumulator layout (lane: rows 4q..4q+3, cell lr), their operands prefetched
+//     before the product.
+// ---------------------------------------------------------------------------------------
+template <int CHB>
+__global__ __launch_bounds__(256) void k_bwd_a2(const BwdAJobs jobs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int bid = blockIdx.x;
+  TR_BEGIN();
+  const int ji = find_job(jobs.j, jobs.n, bid);
+  const BwdAJob J = load_job(&jobs.j[ji]);
+  int cb, rb;
+  if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
+  TR(2);
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rt = w & 1, ct = w >> 1;
+  const int N = J.N, H = J.H, H4 = 4 * H, ldm = J.ldm;
+  const int r0 = rb * 32, c0 = cb * 32;
+  const bool noproj = J.Wp == nullptr;          // num_proj=None: dh = mask*(dout + dm_state), no product
+  // LDS image of dm: [32 rows][SA4 float4], SA4 odd (conflict-free ds_read_b128 fragment reads); without a projection only the
+  // tile's own 32 columns are staged
+  // (rows are padded with zeros up to whole k-blocks: the last fragment read of a row must not meet its neighbour or stale LDS)
+  const int nkb = (ldm + 15) >> 4;
+  const int k4_0 = noproj ? c0 >> 2 : 0, nk4 = noproj ? 8 : ldm >> 2, nk4p = noproj ? 8 : nkb * 4;
+  const int SA4 = nk4p | 1, SA = SA4 * 4;
+  // (1) stage dm: thread = (row tid/8, float4 slot tid%8 + 8 i)
+  {
+    const int srow = tid >> 3, s8 = tid & 7;
+    const int grow = min(r0 + srow, N - 1);
+    const int slen = J.len[grow];                                             // (unconditional: no branch around a load)
+    const bool live = (r0 + srow < N) & (J.t < slen);
+    const float* pm = J.dmst + (size_t)grow * ldm;
+    const float* pd = (J.dout ? J.dout : J.dmst) + (size_t)grow * ldm;        // (stand-in when there is no dout: zeroed below)
+    const float dscale = J.dout ? 1.f : 0.f;
+    float* pt = (cb == 0 && !noproj && r0 + srow < N) ? J.dmt + (size_t)grow * ldm : nullptr;
+    float4* dst = reinterpret_cast<float4*>(smem) + (size_t)srow * SA4;
+    constexpr int NI = (CHB * 4 + 7) / 8;
+    const int k4max = (ldm >> 2) - 1;
+    float4 va[NI], vd[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {          // unconditional loads from clamped slots (one round trip for all of them)
+      const int g4 = min(k4_0 + s8 + 8 * i, k4max);
+      va[i] = *reinterpret_cast<const float4*>(pm + g4 * 4);
+      vd[i] = *reinterpret_cast<const float4*>(pd + g4 * 4);
+    }
+    TR(10);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c4 = s8 + 8 * i;
+      const bool in = live && c4 < nk4 && k4_0 + c4 <= k4max;       // slots past the row's data: zeros
+      float4 v = make_float4(va[i].x + dscale * vd[i].x, va[i].y + dscale * vd[i].y, va[i].z + dscale * vd[i].z, va[i].w + dscale * vd[i].w);
+      v = make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
+      if (c4 < nk4p) dst[c4] = v;
+      if (pt && c4 < nk4) *reinterpret_cast<float4*>(pt + c4 * 4) = v;
+    }
+  }
+  // (2) this wave's weight tiles: column tile cb*2 + ct of the fragment-tiled copy, all k-blocks
+  float4 bv[CHB];
+  if (!noproj) {                 // (uniform) unconditional loads from clamped tiles: the product skips k-blocks >= nkb, and
+    const int tile_c = min(cb * 2 + ct, ((H + 15) >> 4) - 1);          // cells past H are never stored
+    const float* wt = J.Wp_sw + (size_t)tile_c * nkb * 256 + lane * 4;
+#pragma unroll
+    for (int c = 0; c < CHB; ++c) bv[c] = *reinterpret_cast<const float4*>(wt + (size_t)min(c, nkb - 1) * 256);
+  } else {
+#pragma unroll
+    for (int c = 0; c < CHB; ++c) bv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // (3) epilogue operands of this lane's four (row, cell) elements
+  const int ecell = c0 + ct * 16 + lr;
+  const bool cok = ecell < H;
+  const int ecl = min(ecell, H - 1);
+  const float ewo = J.wo[ecl], ewi = J.wi[ecl], ewf = J.wf[ecl];
+  float eg[4][4], ecp[4], ecn[4], edc[4];
+  bool elive[4], erok[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int row = r0 + rt * 16 + 4 * q + e;
+    erok[e] = row < N && cok;
+    const int rowc = min(row, N - 1);
+    elive[e] = J.t < J.len[rowc];
+    const float* g = J.gates + (size_t)rowc * H4 + ecl;
+    eg[e][0] = g[0]; eg[e][1] = g[H]; eg[e][2] = g[2 * H]; eg[e][3] = g[3 * H];
+    const size_t ci = (size_t)rowc * H + ecl;
+    ecp[e] = J.c_prev[ci]; ecn[e] = J.c_cur[ci]; edc[e] = J.dc[ci];
+  }
+  TR(3);
+  __syncthreads();
+  TR(4);
+  // (4) product: dh[16 x 16] = dm[rows rt*16.., :] . Wp[cells, :]^T
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  float dh[4];
+  if (!noproj) {
+    const float* ab = smem + (size_t)(rt * 16 + lr) * SA + 4 * q;
+#pragma unroll
+    for (int c = 0; c < CHB; c += 2) {
+      if (c < nkb) {
+        const float4 a = *reinterpret_cast<const float4*>(ab + c * 16);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv[c].x, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv[c].y, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv[c].z, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv[c].w, acc0, 0, 0, 0);
+      }
+      if (c + 1 < CHB && c + 1 < nkb) {
+        const float4 a = *reinterpret_cast<const float4*>(ab + (c + 1) * 16);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bv[c + 1].x, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bv[c + 1].y, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bv[c + 1].z, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bv[c + 1].w, acc1, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dh[e] = acc0[e] + acc1[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dh[e] = smem[(size_t)(rt * 16 + 4 * q + e) * SA + ct * 16 + lr];
+  }
+  TR(5);
+  // (5) gate / cell gradients (C layout of the MFMA: lane holds rows 4q + e of column lr)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (!erok[e]) continue;
+    const int row = r0 + rt * 16 + 4 * q + e;
+    float* g = J.gates + (size_t)row * H4 + ecell;
+    if (elive[e]) {
+      const float gi = eg[e][0], gj = eg[e][1], gf = eg[e][2], go = eg[e][3];
+      const float tc = tanhf(ecn[e]);
+      const float dao = dh[e] * tc * go * (1.f - go);
+      const float dcn = edc[e] + dh[e] * go * (1.f - tc * tc) + dao * ewo;
+      const float daf = dcn * ecp[e] * gf * (1.f - gf);
+      const float dai = dcn * gj * gi * (1.f - gi);
+      const float dj = dcn * gi * (1.f - gj * gj);
+      J.dc[(size_t)row * H + ecell] = dcn * gf + dai * ewi + daf * ewf;
+      g[0] = dai; g[H] = dj; g[2 * H] = daf; g[3 * H] = dao;
+    } else {
+      g[0] = 0.f; g[H] = 0.f; g[2 * H] = 0.f; g[3 * H] = 0.f;     // dc passes through unchanged
+    }
+  }
+  TR_END();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -513,7 +718,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_b(const BwdBJobs jobs) {
   __shared__ float zs[NW][RTB][16][17];
   const int bid = blockIdx.x;
   const int ji = find_job(jobs.j, jobs.n, bid);
-  const BwdBJob& J = jobs.j[ji];
+  const BwdBJob J = load_job(&jobs.j[ji]);
   int cb, rb;
   if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
   const int r0 = rb * 16 * RTB, n0 = J.n_begin + cb * 16;
@@ -521,37 +726,31 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_b(const BwdBJobs jobs) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform -> scalar branches
   const int N = J.N, H4 = J.H4;
   const int n = n0 + lr;
-  Seg<RTB> s0, s1;
+  Seg<RTB> s0;
   s0.ld = H4; s0.nkb = (H4 + 15) >> 4;
-  s0.w = n < J.n_end ? J.K + (size_t)n * H4 : nullptr;
-  s1.ld = 0; s1.nkb = 0; s1.w = nullptr;
+  s0.w = J.K + (size_t)min(n, J.n_end - 1) * H4; s0.wok = n < J.n_end;
+  s0.wt = J.Ksw ? J.Ksw + (size_t)cb * s0.nkb * 256 + lane * 4 : nullptr;
 #pragma unroll
-  for (int i = 0; i < RTB; ++i) {
-    const int arow = r0 + i * 16 + lr;
-    s0.a[i] = arow < N ? J.dz + (size_t)arow * H4 : nullptr;
-    s1.a[i] = nullptr;
-  }
-  // epilogue read-modify-write operands, prefetched (first RT*256 threads own one output each)
+  for (int i = 0; i < RTB; ++i) s0.a[i] = J.dz + (size_t)min(r0 + i * 16 + lr, N - 1) * H4;
+  // epilogue read-modify-write operand, prefetched (first RTB*256 threads own one output each): unconditional load from the
+  // clamped destination, kept only where the old value takes part (dx += ; masked rows pass the carried gradient through)
   const int e_i = tid >> 8, e_r = (tid >> 4) & 15, e_c = tid & 15;
   const int erow = r0 + e_i * 16 + e_r, enn = n0 + e_c;
   const bool evalid = tid < RTB * 256 && erow < N && enn < J.n_end;
-  float eold = 0.f;
-  float* edst = nullptr;
-  if (evalid) {
-    if (enn < J.I) {
-      edst = J.dx + (size_t)erow * J.lddx + enn;
-      if (J.dx_accumulate) eold = *edst;
-    } else {
-      edst = J.dmst + (size_t)erow * J.ldm + (enn - J.I);
-      if (!(J.t < J.len[erow])) eold = *edst;            // masked row: the carried gradient passes through
-    }
-  }
+  const int erc = min(erow, N - 1), enc = min(enn, J.n_end - 1);
+  const bool to_dx = enc < J.I;
+  float* edst = to_dx ? J.dx + (size_t)erc * J.lddx + enc : J.dmst + (size_t)erc * J.ldm + (enc - J.I);
+  float eold = *edst;
+  const int elen = (J.len ? J.len : reinterpret_cast<const int*>(J.dz))[erc];
+  // (bitwise, not && / ?: -- short-circuit control flow lets the optimizer sink the loads above back under a branch)
+  const bool keep = (to_dx & (J.dx_accumulate != 0)) | (!to_dx & (J.len != nullptr) & !(J.t < elen));
+  eold = keep ? eold : 0.f;
   const int per = (s0.nkb + NW - 1) / NW;
   f32x4 acc[RTB];
 #pragma unroll
   for (int i = 0; i < RTB; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (VAR & 8) mma_2seg<RTB, CH>(acc, s0, s1, w * per, min(s0.nkb, (w + 1) * per), q);      // un-pipelined
-  else mma_2seg_pipe<RTB, CH, VAR>(acc, s0, s1, w * per, min(s0.nkb, (w + 1) * per), q);
+  if (VAR & 8) mma_seg<RTB, CH>(acc, s0, w * per, min(s0.nkb, (w + 1) * per), q);      // un-pipelined
+  else mma_seg_pipe<RTB, CH>(acc, s0, w * per, min(s0.nkb, (w + 1) * per), q);
 #pragma unroll
   for (int i = 0; i < RTB; ++i)
 #pragma unroll
@@ -579,11 +778,12 @@ __host__ __device__ inline int bp_sa4(int kpg) { return kpg * 4 + 1; }      // L
 __global__ __launch_bounds__(512) void k_bwd_bp(const BwdBJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = blockIdx.x;
+  TR_BEGIN();
   int ji = 0;
 #pragma unroll
   for (int qq = 1; qq < MAXJ; ++qq)
     if (qq < jobs.n && bid >= jobs.j[qq].blk_base_p) ji = qq;
-  const BwdBJob& J = jobs.j[ji];
+  const BwdBJob J = load_job(&jobs.j[ji]);
   const int lb = bid - J.blk_base_p;
   const int per_kg = J.ncg * J.nrg;
   const int kg = lb / per_kg, rem = lb - kg * per_kg;
@@ -600,14 +800,23 @@ __global__ __launch_bounds__(512) void k_bwd_bp(const BwdBJobs jobs) {
   const int SA4 = bp_sa4(kpg), SA = SA4 * 4;
 
   // (1) weight slice of this wave's column tile -> VGPRs
-  const int n = J.n_begin + cg * 64 + ct * 16 + lr;
-  const bool nok = n < J.n_end;
-  const float* wrow = J.K + (size_t)(nok ? n : J.n_begin) * H4;
+  // (fragment-tiled copy of K's rows [n_begin, n_end): unconditional loads from clamped tiles -- the product skips k-blocks
+  //  >= je and columns past n_end are never stored)
   float4 bv[BP_CHB];
+  if (J.Ksw) {                                           // (uniform per workgroup: two straight-line load sequences)
+    const int tb = min(cg * 4 + ct, ((J.n_end - J.n_begin + 15) >> 4) - 1);      // 16-row block of K counted from n_begin
+    const float* wt = J.Ksw + (size_t)tb * nkb * 256 + lane * 4;
 #pragma unroll
-  for (int c = 0; c < BP_CHB; ++c) {
-    const int k = (jb + c) * 16 + 4 * q;
-    bv[c] = (nok && jb + c < je && k < H4) ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < BP_CHB; ++c) bv[c] = *reinterpret_cast<const float4*>(wt + (size_t)min(jb + c, nkb - 1) * 256);
+  } else {                                               // row-major K (per-step fully_connected stages): clamped row and k
+    const float* wrow = J.K + (size_t)min(J.n_begin + cg * 64 + ct * 16 + lr, J.n_end - 1) * H4;
+#pragma unroll
+    for (int c = 0; c < BP_CHB; ++c) {
+      const int k = (jb + c) * 16 + 4 * q;
+      const float4 b = *reinterpret_cast<const float4*>(wrow + min(k, H4 - 4));
+      const bool ok = k < H4;
+      bv[c] = make_float4(ok ? b.x : 0.f, ok ? b.y : 0.f, ok ? b.z : 0.f, ok ? b.w : 0.f);
+    }
   }
   // (2) dz slice [64 rows][kpg*16] -> LDS (rows >= N / columns past H4 get a finite dummy: they meet zero weights
   //     or unstored rows only)
@@ -622,7 +831,9 @@ __global__ __launch_bounds__(512) void k_bwd_bp(const BwdBJobs jobs) {
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (size_t)p0 * 4), 16, 0, 0);
     }
   }
+  TR(3);
   __syncthreads();
+  TR(4);
   // (3) MFMAs
   f32x4 acc[BP_RT];
 #pragma unroll
@@ -644,7 +855,9 @@ __global__ __launch_bounds__(512) void k_bwd_bp(const BwdBJobs jobs) {
       for (int i = 0; i < BP_RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, bv[c].w, acc[i], 0, 0, 0);
     }
   }
+  TR(5);
   __syncthreads();                                       // done reading the dz slice
+  TR(6);
   float (*zs)[BP_RT][16][17] = reinterpret_cast<float (*)[BP_RT][16][17]>(smem);     // zs[8][4][16][17] aliases it
 #pragma unroll
   for (int i = 0; i < BP_RT; ++i)
@@ -661,6 +874,7 @@ __global__ __launch_bounds__(512) void k_bwd_bp(const BwdBJobs jobs) {
       J.ws[((size_t)kg * N + grow) * J.ldw + gcol] = zs[t2][i][rr][cc] + zs[4 + t2][i][rr][cc];
     }
   }
+  TR_END();
 }
 
 __global__ __launch_bounds__(256) void k_bwd_b_red(const BwdBJobs jobs) {
@@ -669,22 +883,25 @@ __global__ __launch_bounds__(256) void k_bwd_b_red(const BwdBJobs jobs) {
 #pragma unroll
   for (int qq = 1; qq < MAXJ; ++qq)
     if (qq < jobs.n && bid >= jobs.j[qq].blk_base_r) ji = qq;
-  const BwdBJob& J = jobs.j[ji];
+  const BwdBJob J = load_job(&jobs.j[ji]);
   const int ncols = J.n_end - J.n_begin;
   const int e = (bid - J.blk_base_r) * 256 + threadIdx.x;
   if (e >= J.N * ncols) return;
   const int row = e / ncols, col = e - row * ncols;
   const int nn = J.n_begin + col;
-  float* dst;
-  float v = 0.f;
-  if (nn < J.I) {
-    dst = J.dx + (size_t)row * J.lddx + nn;
-    if (J.dx_accumulate) v = *dst;
-  } else {
-    dst = J.dmst + (size_t)row * J.ldm + (nn - J.I);
-    if (!(J.t < J.len[row])) v = *dst;                   // masked row: the carried gradient passes through
-  }
-  for (int g = 0; g < J.KG; ++g) v += J.ws[((size_t)g * J.N + row) * J.ldw + col];
+  // every load first (the KG partials, the old value, the row's length: independent, one round trip), then the fixed-order sum
+  const bool to_dx = nn < J.I;
+  float* dst = to_dx ? J.dx + (size_t)row * J.lddx + nn : J.dmst + (size_t)row * J.ldm + (nn - J.I);
+  const float old = *dst;
+  const int lenv = (J.len ? J.len : reinterpret_cast<const int*>(J.ws))[row];     // (fully_connected stages have no lengths)
+  constexpr int KGMAX = 16;
+  float part[KGMAX];
+#pragma unroll
+  for (int g = 0; g < KGMAX; ++g) part[g] = J.ws[((size_t)min(g, J.KG - 1) * J.N + row) * J.ldw + col];
+  const bool keep = (to_dx & (J.dx_accumulate != 0)) | (!to_dx & (J.len != nullptr) & !(J.t < lenv));   // masked row: the carried gradient passes through
+  float v = keep ? old : 0.f;
+#pragma unroll
+  for (int g = 0; g < KGMAX; ++g) v += g < J.KG ? part[g] : 0.f;
   *dst = v;
 }
 
@@ -697,7 +914,7 @@ size_t bwd_b_plan(BwdBJobs& jobs, float* ws_base) {
     static int kpg_target = -1;        // k-blocks per K slice: 24 -> 99 KB LDS (1 WG/CU), 12 -> 50 KB (3 WGs/CU overlap load and MFMA phases)
     if (kpg_target < 0) { const char* e = getenv("RSRGAN_BP_KPG"); kpg_target = e ? atoi(e) : 24; if (kpg_target < 2 || kpg_target > 2 * BP_CHB) kpg_target = 24; }
     int KG = std::max((nkb + kpg_target - 1) / kpg_target, std::min(8, nkb / 8));
-    KG = std::max(1, KG);
+    KG = std::min(16, std::max(1, KG));          // k_bwd_b_red holds <= 16 partials in registers
     b.kpg = (nkb + KG - 1) / KG;
     b.KG = (nkb + b.kpg - 1) / b.kpg;
     b.ncg = (ncols + 63) / 64; b.nrg = (b.N + 63) / 64;
@@ -753,7 +970,7 @@ void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, int kb_max, hip
   // resident WGs per CU some CUs get two heavy (K=560) WGs.  One slot per CU + heavy-first order makes
   // the dispatcher list-schedule: light WGs (layer 0, D) finish early and pick up the leftovers.
   static int one_per_cu = -1;
-  if (one_per_cu < 0) { const char* e = getenv("RSRGAN_GATES_ONE_PER_CU"); one_per_cu = e ? atoi(e) : 1; }
+  if (one_per_cu < 0) { const char* e = getenv("RSRGAN_GATES_ONE_PER_CU"); one_per_cu = e ? atoi(e) : 0; }
   if (one_per_cu && total_blocks > 256 && lds < 84 * 1024) lds = 84 * 1024;
   static bool attr_set = false;
   if (!attr_set) {
@@ -776,9 +993,22 @@ void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, int kb_max, hipS
   else
     hipLaunchKernelGGL(k_fwd_proj<8>, dim3(total_blocks), dim3(512), 0, s, jobs);
 }
+int g_bwd_a_form = 2;       // 2 = k_bwd_a2 (32 x 32 tiles, jobs' nblk_c counts 32-cell blocks), 1 = k_bwd_a (32 x 16); RSRGAN_BWD_A_FORM
+int bwd_a_cells() { return g_bwd_a_form == 2 ? 32 : 16; }
+void set_bwd_a_form(int f) { g_bwd_a_form = f == 1 ? 1 : 2; }
 void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
-  (void)kb_max;      // host asserts kb_max <= 24 (proj width <= 384)
-  hipLaunchKernelGGL(k_bwd_a<8>, dim3(total_blocks), dim3(512), 0, s, jobs);
+  if (g_bwd_a_form == 1) {      // host asserts kb_max <= 24 (proj width <= 384)
+    hipLaunchKernelGGL(k_bwd_a<8>, dim3(total_blocks), dim3(512), 0, s, jobs);
+    return;
+  }
+  // dynamic LDS: 32 rows x (widest dm row + pad) of the jobs in the launch (without a projection: 32 x 36 floats)
+  int sa4 = 9;
+  for (int i = 0; i < jobs.n; ++i)
+    if (jobs.j[i].Wp) sa4 = std::max(sa4, (((jobs.j[i].ldm + 15) >> 4) * 4) | 1);
+  const size_t lds = (size_t)32 * sa4 * 16;
+  if (kb_max <= 4) hipLaunchKernelGGL(k_bwd_a2<4>, dim3(total_blocks), dim3(256), lds, s, jobs);
+  else if (kb_max <= 18) hipLaunchKernelGGL(k_bwd_a2<18>, dim3(total_blocks), dim3(256), lds, s, jobs);
+  else hipLaunchKernelGGL(k_bwd_a2<24>, dim3(total_blocks), dim3(256), lds, s, jobs);
 }
 void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
   if (kb_max <= 64)  // small K (the discriminator alone): 8 waves x <= 8 k-blocks, one load round, no pipeline, 16-row tiles
@@ -895,6 +1125,48 @@ void launch_transpose_many(TransposeList& tl, hipStream_t s) {
   int base = 0;
   for (int i = 0; i < tl.n; ++i) { tl.j[i].blk_base = base; base += ((tl.j[i].C + 31) / 32) * ((tl.j[i].R + 31) / 32); }
   hipLaunchKernelGGL(k_transpose_many, dim3(base), dim3(256), 0, s, tl);
+}
+
+// every fragment-tiled weight copy of a network in ONE launch (after every optimizer step): one thread per float4 of the
+// tiled image (lane slot l of tile (ct, kb)), reads are 64-B runs per 16 lanes, writes are fully coalesced
+__global__ __launch_bounds__(256) void k_swizzle_many(SwizzleList sl) {
+  int j = 0;
+  while (j + 1 < sl.n && (int)blockIdx.x >= sl.j[j + 1].blk_base) ++j;
+  const SwizzleJob& J = sl.j[j];
+  const size_t i4 = (size_t)(blockIdx.x - J.blk_base) * 256 + threadIdx.x;
+  const size_t tile = i4 >> 6;
+  if (tile >= (size_t)J.nct * J.nkb) return;
+  const int l = (int)(i4 & 63), q = l >> 4, lr = l & 15;
+  const int ct = (int)(tile / J.nkb), kb = (int)(tile - (size_t)ct * J.nkb);
+  const int c = ct * 16 + lr, k0 = kb * 16 + 4 * q;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (J.gates == 0) {
+    if (c < J.C) {
+      const float* r = J.src + (size_t)(J.c0 + c) * J.ld;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k0 + u < J.K1) v[u] = r[k0 + u];
+    }
+  } else {
+    const int ncb16 = ((J.H + 15) >> 4) << 4;
+    const int g = c / ncb16, cell = c - g * ncb16;
+    if (g < J.gates && cell < J.H) {
+      const float* col = J.src + (size_t)g * J.H + cell;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u;
+        if (k < J.kx) { if (k < J.I) v[u] = col[(size_t)k * J.ld]; }
+        else if (k - J.kx < J.P) v[u] = col[(size_t)(J.I + k - J.kx) * J.ld];
+      }
+    }
+  }
+  *reinterpret_cast<float4*>(J.dst + i4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+void launch_swizzle_many(SwizzleList& sl, hipStream_t s) {
+  if (sl.n == 0) return;
+  int base = 0;
+  for (int i = 0; i < sl.n; ++i) { sl.j[i].blk_base = base; base += (int)(((size_t)sl.j[i].nct * sl.j[i].nkb * 64 + 255) / 256); }
+  hipLaunchKernelGGL(k_swizzle_many, dim3(base), dim3(256), 0, s, sl);
 }
 
 // ---------------------------------------------------------------------------------------

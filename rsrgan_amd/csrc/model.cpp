@@ -154,6 +154,7 @@ static void alloc_stash(Model& M, LstmStash& S, const LstmLayer& L, int N, int T
 int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   cfg = c;
   if (const char* e = getenv("RSRGAN_GATES_ROWS")) set_fwd_gates_rows(atoi(e));
+  if (const char* e = getenv("RSRGAN_BWD_A_FORM")) set_bwd_a_form(atoi(e));
   B = c.batch_size; Tmax = c.max_frames; Din = c.input_dim; Dout = c.output_dim;
   ldDin = pad4(Din); ldDout = pad4(Dout);
   if (B <= 0 || Tmax <= 0 || Din <= 0 || Dout <= 0 || c.g_layers <= 0 || c.d_layers <= 0 || c.g_cells <= 0 ||
@@ -255,6 +256,13 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
       L.KxT = alloc<float>((size_t)4 * L.H * L.ldI);
       L.KhT = alloc<float>((size_t)4 * L.H * L.ldP);
       L.WpT = L.has_proj ? alloc<float>((size_t)L.P * L.ldH) : nullptr;
+      const int ncb = (L.H + 15) / 16, kbI = (L.ldI + L.ldP + 15) / 16, kbP = (L.ldP + 15) / 16, kbH = (L.ldH + 15) / 16, kb4 = (4 * L.H + 15) / 16;
+      L.Wg_full = alloc<float>(swizzle_floats(4 * ncb, kbI));
+      L.Wg_h = alloc<float>(swizzle_floats(4 * ncb, kbP));
+      L.WpT_sw = L.has_proj ? alloc<float>(swizzle_floats((L.P + 15) / 16, kbH)) : nullptr;
+      L.Wp_sw = L.has_proj ? alloc<float>(swizzle_floats(ncb, kbP)) : nullptr;
+      L.Kb_full = alloc<float>(swizzle_floats((L.I + L.P + 15) / 16, kb4));
+      L.Kb_rec = alloc<float>(swizzle_floats((L.P + 15) / 16, kb4));
     }
   const size_t TB = (size_t)Tmax * B;
   x_tm = alloc<float>(TB * ldDin); lab_tm = alloc<float>(TB * ldDout); y_tm = alloc<float>(TB * ldDout);
@@ -500,6 +508,29 @@ void Model::refresh_transposes(int net, hipStream_t s) {
   if (net == RSRGAN_NET_G && g_fc_out_wT && g_fc_out_w >= 0)
     add(G.W(g_fc_out_w), ldDout, g_fc_out_wT, pad4(gR), gR, Dout);   // [P][ldDout] -> [Dout][ldP]
   launch_transpose_many(tl, s);
+  {
+    SwizzleList sl{};
+    auto addz = [&](const SwizzleJob& j) {
+      if (!j.dst) return;
+      if (sl.n == 24) { launch_swizzle_many(sl, s); sl.n = 0; }
+      sl.j[sl.n++] = j;
+    };
+    for (auto& L : layers) {
+      const float* K = ps.W(L.tK);
+      const int H4 = 4 * L.H, ncb = (L.H + 15) / 16, kbI = (L.ldI + L.ldP + 15) / 16, kbP = (L.ldP + 15) / 16, kbH = (L.ldH + 15) / 16, kb4 = (H4 + 15) / 16;
+      //            src  dst        ld     gates H    C          c0   K1  I    P    kx     nct                 nkb
+      addz(SwizzleJob{K, L.Wg_full, H4,    4,    L.H, 0,         0,   0,  L.I, L.P, L.ldI, 4 * ncb,            kbI, 0});
+      addz(SwizzleJob{K, L.Wg_h,    H4,    4,    L.H, 0,         0,   0,  L.I, L.P, 0,     4 * ncb,            kbP, 0});
+      addz(SwizzleJob{K, L.Kb_full, H4,    0,    0,   L.I + L.P, 0,   H4, 0,   0,   0,     (L.I + L.P + 15) / 16, kb4, 0});
+      addz(SwizzleJob{K, L.Kb_rec,  H4,    0,    0,   L.P,       L.I, H4, 0,   0,   0,     (L.P + 15) / 16,    kb4, 0});
+      if (L.has_proj) {
+        const float* Wp = ps.W(L.tWp);                   // [H][ldP]
+        addz(SwizzleJob{Wp, L.WpT_sw, L.ldP, 1,  L.P, 0,         0,   0,  L.H, 0,   16 * kbH, (L.P + 15) / 16, kbH, 0});     // M[p][k] = Wp[k][p]
+        addz(SwizzleJob{Wp, L.Wp_sw,  L.ldP, 0,  0,   L.H,       0,   L.P, 0,  0,   0,     ncb,                kbP, 0});     // M[cell][k] = Wp[cell][k]
+      }
+    }
+    launch_swizzle_many(sl, s);
+  }
   if (net == RSRGAN_NET_G)
     for (size_t l = 0; l < gconv.size(); ++l) {                       // R-CED: re-arranged filters of the implicit-GEMM conv
       const ConvLayer& L = gconv[l];
@@ -540,7 +571,7 @@ static void fill_gate(FwdGateJob& a, const LayerRun& R, int t, bool zx) {
   const int H = L.H, H4 = 4 * H;
   const size_t r = (size_t)t * R.Ns + R.row0, rn = (size_t)(t + 1) * R.Ns + R.row0;
   a.x = zx ? nullptr : R.in + r * L.ldI;
-  a.KxT = L.KxT; a.ldx = L.ldI;
+  a.KxT = L.KxT; a.ldx = L.ldI; a.Wsw = zx ? L.Wg_h : L.Wg_full;
   a.m = S.mst + r * L.ldP; a.KhT = L.KhT; a.ldm = L.ldP;
   a.zx = zx ? S.gates + r * H4 : nullptr; a.bias = ps.W(L.tb);
   a.wf = ps.W(L.twf); a.wi = ps.W(L.twi); a.wo = ps.W(L.two);
@@ -559,7 +590,7 @@ static void fill_gate(FwdGateJob& a, const LayerRun& R, int t, bool zx) {
 static void fill_proj(FwdProjJob& p, const LayerRun& R, int t) {
   const LstmLayer& L = *R.L; const LstmStash& S = *R.S;
   const size_t r = (size_t)t * R.Ns + R.row0, rn = (size_t)(t + 1) * R.Ns + R.row0;
-  p.h = S.h + r * L.ldH; p.WpT = L.WpT; p.ldh = L.ldH;
+  p.h = S.h + r * L.ldH; p.WpT = L.WpT; p.WpT_sw = L.WpT_sw; p.ldh = L.ldH;
   p.m_prev = S.mst + r * L.ldP; p.m_out = S.mst + rn * L.ldP; p.out = S.out + r * L.ldP;
   p.res_in = R.res_in ? R.res_in + r * L.ldP : nullptr;
   p.res_out = R.res_out ? R.res_out + r * L.ldP : nullptr;
@@ -568,7 +599,7 @@ static void fill_proj(FwdProjJob& p, const LayerRun& R, int t) {
   p.nblk_c = (L.P + 15) / 16;
 }
 static void fill_fc_fwd(FwdProjJob& p, const FcStage& F, int t) {
-  p.h = F.in + (size_t)t * F.N * F.ld_in; p.WpT = F.WT; p.ldh = F.ld_in;
+  p.h = F.in + (size_t)t * F.N * F.ld_in; p.WpT = F.WT; p.WpT_sw = nullptr; p.ldh = F.ld_in;
   p.m_prev = nullptr; p.m_out = F.y + (size_t)t * F.N * F.ldy; p.ldm = F.ldy;
   p.out = F.out2 + ((size_t)t * F.Ns2 + F.row02) * F.ld2; p.ldo = F.ld2;
   p.res_in = nullptr; p.res_out = nullptr; p.len = nullptr; p.bias = F.bias; p.noise = F.noise;
@@ -576,7 +607,7 @@ static void fill_fc_fwd(FwdProjJob& p, const FcStage& F, int t) {
   p.nblk_c = (F.D + 15) / 16;
 }
 static void fill_fc_bwd(BwdBJob& b, const FcStage& F, int t) {   // y[t] (=|+=) in[t] . W^T, W = [D rows][ld_in]
-  b.dz = F.in + (size_t)t * F.N * F.ld_in; b.K = F.WT; b.H4 = F.ld_in;
+  b.dz = F.in + (size_t)t * F.N * F.ld_in; b.K = F.WT; b.Ksw = nullptr; b.H4 = F.ld_in;
   b.dx = F.y + (size_t)t * F.N * F.ldy; b.lddx = F.ldy; b.dmst = nullptr; b.len = nullptr;
   b.I = F.D; b.n_begin = 0; b.n_end = F.D; b.ldm = 0; b.t = t; b.N = F.N;
   b.dx_accumulate = F.accumulate ? 1 : 0;
@@ -587,19 +618,19 @@ static void fill_bwd_a(BwdAJob& a, const LayerRun& R, int t) {
   const int H = L.H, H4 = 4 * H;
   const size_t r = (size_t)t * R.Ns + R.row0, rn = (size_t)(t + 1) * R.Ns + R.row0;
   a.dout = R.dout ? R.dout + r * L.ldP : nullptr;
-  a.dmst = S.dmst + (size_t)R.row0 * L.ldP; a.Wp = L.has_proj ? ps.W(L.tWp) : nullptr;
+  a.dmst = S.dmst + (size_t)R.row0 * L.ldP; a.Wp = L.has_proj ? ps.W(L.tWp) : nullptr; a.Wp_sw = L.has_proj ? L.Wp_sw : nullptr;
   a.dmt = S.dmt + r * L.ldP;
   a.gates = S.gates + r * H4;
   a.c_prev = S.c + r * H; a.c_cur = S.c + rn * H;
   a.wf = ps.W(L.twf); a.wi = ps.W(L.twi); a.wo = ps.W(L.two);
   a.dc = S.dc + (size_t)R.row0 * H; a.len = R.len; a.ldm = L.ldP; a.P = L.P; a.t = t; a.N = R.N; a.H = H;
-  a.nblk_c = (H + 15) / 16;
+  a.nblk_c = (H + bwd_a_cells() - 1) / bwd_a_cells();
 }
 static void fill_bwd_b(BwdBJob& b, const LayerRun& R, int t, bool with_dx) {
   const LstmLayer& L = *R.L; const LstmStash& S = *R.S; const ParamSet& ps = *R.ps;
   const int H4 = 4 * L.H;
   const size_t r = (size_t)t * R.Ns + R.row0;
-  b.dz = S.gates + r * H4; b.K = ps.W(L.tK);
+  b.dz = S.gates + r * H4; b.K = ps.W(L.tK); b.Ksw = with_dx ? L.Kb_full : L.Kb_rec;
   b.dx = with_dx ? R.din + r * L.ldI : nullptr;
   b.dmst = S.dmst + (size_t)R.row0 * L.ldP; b.len = R.len;
   b.I = L.I; b.n_begin = with_dx ? 0 : L.I; b.n_end = L.I + L.P; b.lddx = L.ldI; b.ldm = L.ldP; b.t = t; b.N = R.N; b.H4 = H4;
@@ -609,7 +640,7 @@ static void fill_bwd_b(BwdBJob& b, const LayerRun& R, int t, bool with_dx) {
 
 int Model::gates_blocks(int H, int N) const { return job_blocks((H + 15) / 16, N, fwd_gates_rows()); }
 int Model::proj_blocks(int P, int N) const { return job_blocks((P + 15) / 16, N); }
-int Model::bwd_a_blocks(int H, int N) const { return job_blocks((H + 15) / 16, N); }
+int Model::bwd_a_blocks(int H, int N) const { return job_blocks((H + bwd_a_cells() - 1) / bwd_a_cells(), N); }
 static void run_gates(const FwdGateJobs& gj, int blocks, int kb, hipStream_t s) { launch_fwd_gates(gj, blocks, kb, s); }
 static void run_proj(const FwdProjJobs& pj, int blocks, int kb, hipStream_t s) { launch_fwd_proj(pj, blocks, kb, s); }
 static void run_bwd_a(const BwdAJobs& aj, int blocks, int kb, hipStream_t s) { launch_bwd_a(aj, blocks, kb, s); }

@@ -41,7 +41,11 @@ struct LstmLayer {               // one tf.contrib.rnn.LSTMCell(H, use_peepholes
   bool has_proj = true;          // num_proj=None: m = h, P == H, no projection kernel (tWp = -1)
   int I, H, P, ldI, ldP, ldH;
   int tK, tb, twf, twi, two, tWp;        // indices into the ParamSet
-  float *KxT = nullptr, *KhT = nullptr, *WpT = nullptr;   // k-contiguous transposed copies (forward)
+  float *KxT = nullptr, *KhT = nullptr, *WpT = nullptr;   // k-contiguous transposed copies (forward; dlstm.hip, layer-0 GEMMs)
+  // fragment-tiled copies the step kernels stream with contiguous 1 KB wave-loads (kernels.h SwizzleJob), refreshed with the above
+  float *Wg_full = nullptr, *Wg_h = nullptr;              // gates: [x | m] . K and m . K[I:] alone (x-part batched)
+  float *WpT_sw = nullptr, *Wp_sw = nullptr;              // projection forward / backward phase A
+  float *Kb_full = nullptr, *Kb_rec = nullptr;            // backward phase B: rows [0, I+P) and rows [I, I+P) of K
 };
 
 struct ConvLayer {               // tf.contrib.layers.conv2d([S, fw], SAME) of models/rced.py: weights [S*fw*Cin][Cout] (= [S, fw, Cin, Cout])

@@ -118,7 +118,7 @@ int main(int argc, char** argv) {
     auto pull = [&](const float* w, int passes) { hipLaunchKernelGGL((k_pull<10, false>), dim3(256), dim3(512), 0, s, w, slice, nslices, passes, 0, sink); };
     const float p1 = time_graph(s, 100, 5, [&] { pull(W, 1); });
     const float p3 = time_graph(s, 100, 5, [&] { pull(W, 3); });
-    const float alt = time_graph(s, 100, 5, [&] { pull(W, 1); pull(W2, 1); }) * 2.f;      // per PAIR
+    const float alt = time_graph(s, 100, 5, [&] { pull(W, 1); pull(W2, 1); });      // per PAIR (time_graph divides by the number of calls of the lambda)
     printf("total %3d MB (%4.1f MB/XCD): b2b %.2f us -> pull %.2f us = %.1f TB/s | in-kernel hot pass %.2f us = %.1f TB/s | two sets alternating: %.2f us per pair\n",
            mb, mb / 8.0, p1, p1 - empty, total / ((p1 - empty) * 1e6), (p3 - p1) / 2, total / ((p3 - p1) / 2 * 1e6), alt);
   }
@@ -130,7 +130,7 @@ int main(int argc, char** argv) {
       for (int mode = 0; mode < 3; ++mode) {
         const size_t n = ((size_t)wmb << 20) / 4;
         const float w = time_graph(s, 100, 5, [&] { hipLaunchKernelGGL(k_write, dim3(256), dim3(256), 0, s, D, n, mode); });
-        const float both = time_graph(s, 100, 5, [&] { pull(); hipLaunchKernelGGL(k_write, dim3(256), dim3(256), 0, s, D, n, mode); }) * 2.f;
+        const float both = time_graph(s, 100, 5, [&] { pull(); hipLaunchKernelGGL(k_write, dim3(256), dim3(256), 0, s, D, n, mode); });
         printf("writer %2d MB %-5s: pair %.2f us (writer alone %.2f) -> pull %.2f us\n", wmb, mode == 0 ? "plain" : mode == 1 ? "nt" : "sc1", both, w, both - w - empty);
       }
     }
@@ -175,14 +175,14 @@ int main(int argc, char** argv) {
   {
     const size_t total = (size_t)20 << 20; const int nslices = 256; const size_t slice = total / 4 / nslices;
     auto pullw = [&](const float* w, float* snk) { hipLaunchKernelGGL((k_pull<10, false>), dim3(256), dim3(512), 0, s, w, slice, nslices, 1, 0, snk); };
-    const float e1 = time_graph(s, GN, GR, [&] { pullw(W, sink); pullw(W, sink); }) * 2.f;
-    const float e2 = time_graph(s, GN, GR, [&] { pullw(W, sink); pullw(W, sink + 1024); }) * 2.f;
-    const float e3 = time_graph(s, GN, GR, [&] { pullw(W, sink); hipLaunchKernelGGL(k_empty, dim3(256), dim3(512), 0, s); }) * 2.f;
-    const float e4 = time_graph(s, GN, GR, [&] { pullw(W, sink); hipLaunchKernelGGL((k_pull<10, false>), dim3(256), dim3(512), 0, s, W2, (size_t)64, nslices, 1, 0, sink); }) * 2.f;
-    const float e5 = time_graph(s, GN, GR, [&] { pullw(W, sink); pullw(W + ((size_t)32 << 18), sink); }) * 2.f;
-    const float e6 = time_graph(s, GN, GR, [&] { pullw(W, sink); hipLaunchKernelGGL((k_pull<5, false>), dim3(256), dim3(512), 0, s, W, slice, nslices, 1, 0, sink); }) * 2.f;
-    const float e7 = time_graph(s, GN, GR, [&] { pullw(W, sink); hipLaunchKernelGGL(k_write, dim3(256), dim3(256), 0, s, D, (size_t)1 << 14, 0); }) * 2.f;
-    const float e8 = time_graph(s, GN, GR, [&] { pullw(W, sink); pullw(W2, sink); pullw(W, sink); pullw(W2, sink); }) * 4.f / 2.f;
+    const float e1 = time_graph(s, GN, GR, [&] { pullw(W, sink); pullw(W, sink); });
+    const float e2 = time_graph(s, GN, GR, [&] { pullw(W, sink); pullw(W, sink + 1024); });
+    const float e3 = time_graph(s, GN, GR, [&] { pullw(W, sink); hipLaunchKernelGGL(k_empty, dim3(256), dim3(512), 0, s); });
+    const float e4 = time_graph(s, GN, GR, [&] { pullw(W, sink); hipLaunchKernelGGL((k_pull<10, false>), dim3(256), dim3(512), 0, s, W2, (size_t)64, nslices, 1, 0, sink); });
+    const float e5 = time_graph(s, GN, GR, [&] { pullw(W, sink); pullw(W + ((size_t)32 << 18), sink); });
+    const float e6 = time_graph(s, GN, GR, [&] { pullw(W, sink); hipLaunchKernelGGL((k_pull<5, false>), dim3(256), dim3(512), 0, s, W, slice, nslices, 1, 0, sink); });
+    const float e7 = time_graph(s, GN, GR, [&] { pullw(W, sink); hipLaunchKernelGGL(k_write, dim3(256), dim3(256), 0, s, D, (size_t)1 << 14, 0); });
+    const float e8 = time_graph(s, GN, GR, [&] { pullw(W, sink); pullw(W2, sink); pullw(W, sink); pullw(W2, sink); }) / 2.f;
     printf("e1 same W / same W                    : %.2f\n", e1);
     printf("e2 same W, other sink pointer         : %.2f\n", e2);
     printf("e3 W / empty kernel                   : %.2f\n", e3);
