@@ -75,6 +75,33 @@ __device__ __forceinline__ void globalize(BwdAJob& J) {
 }
 __device__ __forceinline__ void globalize(BwdBJob& J) { RSR_G(dz) RSR_G(K) RSR_G(Ksw) RSR_G(dx) RSR_G(dmst) RSR_G(len) RSR_G(ws) }
 #undef RSR_G
+// The job of block `bid` in ONE round trip: the records of ALL MAXJ jobs are requested at once (one dword per lane each) next to
+// the scalar load of the job count; the block's job is the last one whose first block id (dword OFF of the record) is <= bid.
+template <typename JobT, int OFF>
+__device__ __forceinline__ JobT pick_job(const JobT* j, const int& n_ref, int bid) {
+  constexpr int ND = (int)(sizeof(JobT) / 4);
+  static_assert(sizeof(JobT) % 4 == 0 && ND <= 64 && OFF < ND, "job record must fit one dword per lane");
+  const int lane = threadIdx.x & 63;
+  const int li = lane < ND ? lane : 0;
+  unsigned v[MAXJ];
+#pragma unroll
+  for (int q = 0; q < MAXJ; ++q) v[q] = reinterpret_cast<const unsigned*>(j + q)[li];
+  const int n = n_ref;
+  unsigned vs = v[0];
+#pragma unroll
+  for (int q = 1; q < MAXJ; ++q) {
+    const int bb = __builtin_amdgcn_readlane((int)v[q], OFF);
+    const bool take = q < n && bid >= bb;               // (uniform: blk_base ascends with q)
+    vs = take ? v[q] : vs;
+  }
+  union U { JobT j; unsigned d[ND]; __device__ U() {} } u;
+#pragma unroll
+  for (int i = 0; i < ND; ++i) u.d[i] = (unsigned)__builtin_amdgcn_readlane((int)vs, i);
+  globalize(u.j);
+  return u.j;
+}
+#define RSR_PICK(JobT, field) pick_job<JobT, (int)(__builtin_offsetof(JobT, field) / 4)>(jobs.j, jobs.n, bid)
+
 template <typename JobT>
 __device__ __forceinline__ JobT load_job(const JobT* p) {
   constexpr int ND = (int)(sizeof(JobT) / 4);
@@ -205,8 +232,7 @@ __global__ __launch_bounds__(512 * RH, (RH == 1 && RTG == 2 && CHB <= 18) ? 4 : 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = blockIdx.x;
   TR_BEGIN();
-  const int ji = find_job(jobs.j, jobs.n, bid);
-  const FwdGateJob J = load_job(&jobs.j[ji]);
+  const FwdGateJob J = RSR_PICK(FwdGateJob, blk_base);
   int cb, rb;
   if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
   TR(2);
@@ -232,16 +258,21 @@ __global__ __launch_bounds__(512 * RH, (RH == 1 && RTG == 2 && CHB <= 18) ? 4 : 
   // harmless finite dummy; they only ever meet zero weights or unstored rows)
   {
     const int P4 = 16 * RTG * RH * SA4;
-    for (int p0 = w * 64; p0 < P4; p0 += 512 * RH) {
-      const int p = p0 + lane;
-      const int row = p / SA4, k = (p - row * SA4) * 4;
-      const int arow = r0 + row;
-      const float* src = J.m;
-      if (p < P4 && arow < N) {
-        if (k < ldx) src = J.x + (size_t)arow * ldx + k;
-        else if (k < Ktot) src = J.m + (size_t)arow * ldm + (k - ldx);
-      }
+    // (row, float4 column) of slot p advance by a fixed (dq, dr) per round: one integer division per thread, none per load
+    constexpr int STEP = 512 * RH;
+    const int dq = STEP / SA4, dr = STEP - dq * SA4;
+    int row = (w * 64 + lane) / SA4, c4 = (w * 64 + lane) - row * SA4;
+    const int ldx4 = ldx >> 2, kt4 = Ktot >> 2;
+    for (int p0 = w * 64; p0 < P4; p0 += STEP) {
+      const int arow = min(r0 + row, N - 1);
+      const bool inx = c4 < ldx4, inm = c4 < kt4;
+      const float* sx = J.x + (size_t)arow * ldx + c4 * 4;
+      const float* sm = J.m + (size_t)arow * ldm + (c4 - ldx4) * 4;
+      const float* src = inx ? sx : (inm ? sm : J.m);           // (pad slots and rows >= N: any finite word)
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (size_t)p0 * 4), 16, 0, 0);
+      c4 += dr; row += dq;
+      const bool wrap = c4 >= SA4;
+      c4 -= wrap ? SA4 : 0; row += wrap ? 1 : 0;
     }
   }
   TR(11);
@@ -325,7 +356,8 @@ __global__ __launch_bounds__(512 * RH, (RH == 1 && RTG == 2 && CHB <= 18) ? 4 : 
       J.h[(size_t)erow * J.ldh + ecell] = hh;
       if (J.np_m_out) {
         const size_t mi = (size_t)erow * J.ldm + ecell;
-        J.np_m_out[mi] = hh; J.np_out[mi] = hh;
+        J.np_m_out[mi] = hh;
+        if (J.np_out) J.np_out[mi] = hh;
         if (J.np_res_out) J.np_res_out[mi] = hh + J.np_res_in[mi];
       }
     } else {                       // dynamic_rnn: t >= len -> state copied through, no gradient
@@ -334,7 +366,8 @@ __global__ __launch_bounds__(512 * RH, (RH == 1 && RTG == 2 && CHB <= 18) ? 4 : 
       J.h[(size_t)erow * J.ldh + ecell] = 0.f;
       if (J.np_m_out) {
         const size_t mi = (size_t)erow * J.ldm + ecell;
-        J.np_m_out[mi] = J.m[mi]; J.np_out[mi] = 0.f;
+        J.np_m_out[mi] = J.m[mi];
+        if (J.np_out) J.np_out[mi] = 0.f;
         if (J.np_res_out) J.np_res_out[mi] = J.np_res_in[mi];
       }
     }
@@ -350,8 +383,7 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_proj(const FwdProjJobs jobs) {
   __shared__ float zs[NW][RT][16][17];
   const int bid = blockIdx.x;
   TR_BEGIN();
-  const int ji = find_job(jobs.j, jobs.n, bid);
-  const FwdProjJob J = load_job(&jobs.j[ji]);
+  const FwdProjJob J = RSR_PICK(FwdProjJob, blk_base);
   int cb, rb;
   if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
   const int r0 = rb * 16 * RT, c0 = cb * 16;
@@ -437,8 +469,7 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
   if (!KA_ON(32)) return;
 #endif
   TR_BEGIN();
-  const int ji = find_job(jobs.j, jobs.n, bid);
-  const BwdAJob J = load_job(&jobs.j[ji]);
+  const BwdAJob J = RSR_PICK(BwdAJob, blk_base);
   int cb, rb;
   if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
   TR(2);
@@ -578,8 +609,7 @@ __global__ __launch_bounds__(256) void k_bwd_a2(const BwdAJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = blockIdx.x;
   TR_BEGIN();
-  const int ji = find_job(jobs.j, jobs.n, bid);
-  const BwdAJob J = load_job(&jobs.j[ji]);
+  const BwdAJob J = RSR_PICK(BwdAJob, blk_base);
   int cb, rb;
   if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
   TR(2);
@@ -717,8 +747,7 @@ template <int NW, int VAR = 0, int CH = 6, int RTB = RT>
 __global__ __launch_bounds__(NW * 64) void k_bwd_b(const BwdBJobs jobs) {
   __shared__ float zs[NW][RTB][16][17];
   const int bid = blockIdx.x;
-  const int ji = find_job(jobs.j, jobs.n, bid);
-  const BwdBJob J = load_job(&jobs.j[ji]);
+  const BwdBJob J = RSR_PICK(BwdBJob, blk_base);
   int cb, rb;
   if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
   const int r0 = rb * 16 * RTB, n0 = J.n_begin + cb * 16;
@@ -779,11 +808,7 @@ __global__ __launch_bounds__(512) void k_bwd_bp(const BwdBJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = blockIdx.x;
   TR_BEGIN();
-  int ji = 0;
-#pragma unroll
-  for (int qq = 1; qq < MAXJ; ++qq)
-    if (qq < jobs.n && bid >= jobs.j[qq].blk_base_p) ji = qq;
-  const BwdBJob J = load_job(&jobs.j[ji]);
+  const BwdBJob J = RSR_PICK(BwdBJob, blk_base_p);
   const int lb = bid - J.blk_base_p;
   const int per_kg = J.ncg * J.nrg;
   const int kg = lb / per_kg, rem = lb - kg * per_kg;
@@ -822,13 +847,15 @@ __global__ __launch_bounds__(512) void k_bwd_bp(const BwdBJobs jobs) {
   //     or unstored rows only)
   {
     const int P4 = 64 * SA4;
+    const int dq = 512 / SA4, dr = 512 - dq * SA4;       // slot p -> (row, float4 column) advances by (dq, dr) per round
+    int row = (w * 64 + lane) / SA4, c4 = (w * 64 + lane) - row * SA4;
+    const int k4max = (H4 >> 2) - 1 - j_begin * 4;       // last float4 column of dz inside this K slice
     for (int p0 = w * 64; p0 < P4; p0 += 512) {
-      const int p = p0 + lane;
-      const int row = p / SA4, c4 = p - row * SA4;
-      const int k = j_begin * 16 + c4 * 4;
-      const float* src = J.dz;
-      if (p < P4 && r0 + row < N && c4 < kpg * 4 && k < H4) src = J.dz + (size_t)(r0 + row) * H4 + k;
+      const float* src = J.dz + (size_t)min(r0 + row, N - 1) * H4 + (size_t)(j_begin * 16 + min(c4, k4max) * 4);
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (size_t)p0 * 4), 16, 0, 0);
+      c4 += dr; row += dq;
+      const bool wrap = c4 >= SA4;
+      c4 -= wrap ? SA4 : 0; row += wrap ? 1 : 0;
     }
   }
   TR(3);
@@ -879,11 +906,7 @@ __global__ __launch_bounds__(512) void k_bwd_bp(const BwdBJobs jobs) {
 
 __global__ __launch_bounds__(256) void k_bwd_b_red(const BwdBJobs jobs) {
   const int bid = blockIdx.x;
-  int ji = 0;
-#pragma unroll
-  for (int qq = 1; qq < MAXJ; ++qq)
-    if (qq < jobs.n && bid >= jobs.j[qq].blk_base_r) ji = qq;
-  const BwdBJob J = load_job(&jobs.j[ji]);
+  const BwdBJob J = RSR_PICK(BwdBJob, blk_base_r);
   const int ncols = J.n_end - J.n_begin;
   const int e = (bid - J.blk_base_r) * 256 + threadIdx.x;
   if (e >= J.N * ncols) return;

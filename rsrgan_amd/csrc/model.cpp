@@ -357,6 +357,30 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   adam_t_dev_d = alloc<int>(1);
   d_st.resize(dl.size());
   for (size_t l = 0; l < dl.size(); ++l) alloc_stash(*this, d_st[l], dl[l], 2 * B, Tmax);
+  if (const char* e = getenv("RSRGAN_DFOLD")) fold_env = atoi(e) != 0;
+  {   // folded views of the discriminator's cells (model.h): only for stacks of projected cells
+    bool ok = fold_env && !dl.empty();
+    for (auto& L : dl) ok = ok && L.has_proj && L.H <= 288 && (L.ldH & 3) == 0;
+    if (ok) {
+      dl_fold.resize(dl.size()); dl_fold_K.resize(dl.size()); d_fold_st.resize(dl.size());
+      for (size_t l = 0; l < dl.size(); ++l) {
+        LstmLayer F = dl[l];
+        F.has_proj = false; F.tWp = -1;
+        F.I = l == 0 ? dl[0].I : dl[l - 1].H; F.ldI = l == 0 ? dl[0].ldI : dl[l - 1].ldH;
+        F.P = dl[l].H; F.ldP = dl[l].ldH;
+        F.KxT = F.KhT = F.WpT = nullptr; F.WpT_sw = F.Wp_sw = F.Kb_full = F.Kb_rec = nullptr;
+        const int ncb = (F.H + 15) / 16;
+        F.Wg_full = alloc<float>(swizzle_floats(4 * ncb, (F.ldI + F.ldP + 15) / 16));
+        F.Wg_h = alloc<float>(swizzle_floats(4 * ncb, (F.ldP + 15) / 16));
+        dl_fold_K[l] = alloc<float>((size_t)(F.I + F.H) * 4 * F.H);
+        dl_fold[l] = F;
+        LstmStash S = d_st[l];
+        S.mst = alloc<float>((size_t)(Tmax + 1) * 2 * B * F.ldP);
+        S.out = nullptr; S.dmt = nullptr; S.dmst = nullptr;
+        d_fold_st[l] = S;
+      }
+    }
+  }
   const int dmaxld = std::max(ldPd, ldDout);
   d_dA = alloc<float>(TB2 * dmaxld); d_dB = alloc<float>(TB2 * dmaxld);
   len_dev = alloc<int>(2 * B);
@@ -531,6 +555,7 @@ void Model::refresh_transposes(int net, hipStream_t s) {
     }
     launch_swizzle_many(sl, s);
   }
+  if (net == RSRGAN_NET_D && !dl_fold.empty()) refresh_fold(s);
   if (net == RSRGAN_NET_G)
     for (size_t l = 0; l < gconv.size(); ++l) {                       // R-CED: re-arranged filters of the implicit-GEMM conv
       const ConvLayer& L = gconv[l];
@@ -582,7 +607,7 @@ static void fill_gate(FwdGateJob& a, const LayerRun& R, int t, bool zx) {
   a.nblk_c = (H + 15) / 16;
   if (L.has_proj) { a.np_m_out = nullptr; a.np_out = nullptr; a.np_res_in = nullptr; a.np_res_out = nullptr; }
   else {     // num_proj=None: m = h; the gates epilogue also does the dynamic_rnn masking and the residual add
-    a.np_m_out = S.mst + rn * L.ldP; a.np_out = S.out + r * L.ldP;
+    a.np_m_out = S.mst + rn * L.ldP; a.np_out = S.out ? S.out + r * L.ldP : nullptr;
     a.np_res_in = R.res_in ? R.res_in + r * L.ldP : nullptr;
     a.np_res_out = R.res_out ? R.res_out + r * L.ldP : nullptr;
   }
@@ -772,6 +797,47 @@ bool Model::dl_forward(Chain& ch, int T, hipStream_t s) {
   }
   if (!dl_fwd_supported(a)) return false;
   launch_dl_fwd(a, s);
+  return true;
+}
+
+// Kf_l = [ Kx' ; Wp_l . Kh_l ] with Kx' = K_0[0:I] (layer 0) or Wp_{l-1} . K_l[0:I_l] (I_l = P_{l-1}), then its fragment-tiled copies
+void Model::refresh_fold(hipStream_t s) {
+  SwizzleList sl{};
+  for (size_t l = 0; l < dl.size(); ++l) {
+    const LstmLayer& L = dl[l]; const LstmLayer& F = dl_fold[l];
+    const int H4 = 4 * L.H;
+    const float* K = D.W(L.tK);
+    float* Kf = dl_fold_K[l];
+    if (l == 0) (void)hipMemcpyAsync(Kf, K, (size_t)L.I * H4 * sizeof(float), hipMemcpyDeviceToDevice, s);
+    else gemm(D.W(dl[l - 1].tWp), dl[l - 1].ldP, true, K, H4, false, Kf, H4, dl[l - 1].H, H4, L.I, nullptr, 0, 0.f, false, s);
+    gemm(D.W(L.tWp), L.ldP, true, K + (size_t)L.I * H4, H4, false, Kf + (size_t)F.I * H4, H4, L.H, H4, L.P, nullptr, 0, 0.f, false, s);
+    const int ncb = (F.H + 15) / 16;
+    sl.j[sl.n++] = SwizzleJob{Kf, F.Wg_full, H4, 4, F.H, 0, 0, 0, F.I, F.P, F.ldI, 4 * ncb, (F.ldI + F.ldP + 15) / 16, 0};
+    sl.j[sl.n++] = SwizzleJob{Kf, F.Wg_h, H4, 4, F.H, 0, 0, 0, F.I, F.P, 0, 4 * ncb, (F.ldP + 15) / 16, 0};
+  }
+  launch_swizzle_many(sl, s);
+}
+
+// The forward recurrence of a discriminator chain running alone, one launch per time step (folded cells, model.h), then the
+// masked outputs of every layer as time-batched GEMMs.  The carried projection state mst is NOT produced (only the weight
+// gradients read it, and this path serves the runs that do not train the discriminator).
+bool Model::fold_forward(Chain& ch, int T, hipStream_t s) {
+  if (dl_fold.empty() || !wavefront() || ch.size() != dl_fold.size()) return false;
+  Chain fch;
+  for (size_t l = 0; l < ch.size(); ++l) {
+    const LayerRun& R = ch[l];
+    if (R.L != &dl[l] || R.S != &d_st[l] || R.res_in || R.res_out || R.zx_batched || R.want_wgrads || R.row0 != 0 || R.Ns != R.N) return false;
+    LayerRun Rf = R;
+    Rf.L = &dl_fold[l]; Rf.S = &d_fold_st[l];
+    if (l > 0) Rf.in = d_st[l - 1].h;                  // the masked h of the layer below (0 where t >= len)
+    fch.push_back(Rf);
+  }
+  std::vector<Chain> chains{fch};
+  rnn_forward(chains, T, s);
+  for (size_t l = 0; l < ch.size(); ++l) {           // out_t = h_t . Wp  (h_t = 0 on masked rows: dynamic_rnn's zero output)
+    const LstmLayer& L = dl[l];
+    gemm(d_st[l].h, L.ldH, true, D.W(L.tWp), L.ldP, false, d_st[l].out, L.ldP, T * ch[l].N, L.P, L.H, nullptr, 0, 0.f, false, s);
+  }
   return true;
 }
 
@@ -1205,7 +1271,7 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, B, 0, s);
     if (!d_dnn()) {
       std::vector<Chain> chains(1, d_chain(B, B, 0));
-      if (!dl_forward(chains[0], T, s)) rnn_forward(chains, T, s);
+      if (!fold_forward(chains[0], T, s) && !dl_forward(chains[0], T, s)) rnn_forward(chains, T, s);
     }
   }
   // g_adv = mean((D(G(x)) - d_real)^2)  (gan_rnn_placeholder.py:246): all rows "fake", target d_real

@@ -124,6 +124,16 @@ struct Model {
   unsigned *dl_flags = nullptr;  // persistent small-cell recurrence (dlstm.hip): [DL_MAXL][64] progress words + 1 error word
   bool dl_env = true;            // RSRGAN_DLSTM=0: launch-per-phase discriminator waves (round 1)
   bool dl_forward(Chain& ch, int T, hipStream_t s);      // false: not supported for this chain -> caller falls back to rnn_forward
+  // ---- folded small-cell recurrence (the discriminator running alone): m_{t-1}.Kh = h_{t-1}.(Wp.Kh) and, above layer 0,
+  // x_t.Kx = h^{below}_t.(Wp^{below}.Kx), so with the folded kernels Kf = [Kx' ; Wp.Kh] the cell's recurrent state is h itself
+  // (a num_proj=None cell): ONE launch per time step instead of gates + projection.  Same math re-associated (fp32, ~1e-7);
+  // the masked outputs out_t = h_t.Wp of the top layer follow as one time-batched GEMM (h_t is stored 0 on masked rows).
+  std::vector<LstmLayer> dl_fold;                         // folded views of dl (has_proj = false, I' = H below, P' = H)
+  std::vector<float*> dl_fold_K;                          // Kf [(I' + H)][4H], refreshed with the other weight copies
+  std::vector<LstmStash> d_fold_st;                       // gates / c / h alias d_st; mst = carried h [T+1][2B][ldH]
+  bool fold_env = true;                                   // RSRGAN_DFOLD=0: off
+  bool fold_forward(Chain& ch, int T, hipStream_t s);     // false: not applicable -> caller falls back
+  void refresh_fold(hipStream_t s);
   // fully-connected stacks: models/dnn.py generator and models/discriminator_dnn.py discriminator
   std::vector<FcLayer> gfc, dfc;
   std::vector<float*> g_act, d_act;        // act[l] = input of FC layer l, act[L] = output of the stack

@@ -154,6 +154,37 @@ int main(int argc, char** argv) {
     const int idx[] = {2, 10, 11, 3, 4, 5, 6, 7, 9};
     report("k_fwd_gates (3 G layers + 4 D jobs)", base, cls, names, idx, 9, us);
   }
+  // ------------------------------------------------------------------ forward gates: the folded discriminator alone (2 num_proj=None jobs, K = 296 / 512)
+  {
+    FwdGateJobs gj{}; gj.forget_bias = 1.f;
+    int base = 0;
+    std::vector<Cls> cls;
+    auto mk = [&](int n, int h, int ldx, const char* name) {
+      FwdGateJob& a = gj.j[gj.n++];
+      a = FwdGateJob{};
+      const int ldm = (h + 3) & ~3, ncb = (h + 15) / 16, nkb = (ldx + ldm + 15) / 16;
+      a.x = dal((size_t)n * ldx, 1.f); a.ldx = ldx; a.m = dal((size_t)n * ldm, 1.f); a.ldm = ldm;
+      a.Wsw = tiles(4 * ncb, nkb);
+      a.zx = nullptr; a.bias = dal(4 * h, 0.1f);
+      a.wf = dal(h, 0.1f); a.wi = dal(h, 0.1f); a.wo = dal(h, 0.1f);
+      a.c_prev = dal((size_t)n * h, 0.5f); a.c_out = dal((size_t)n * h, 0.f); a.gates = dal((size_t)n * 4 * h, 0.f);
+      a.ldh = ldm; a.h = dal((size_t)n * a.ldh, 0.f); a.len = len; a.t = 0; a.N = n; a.H = h; a.nblk_c = ncb;
+      a.np_m_out = dal((size_t)n * ldm, 0.f);
+      a.blk_base = base;
+      const int nb = job_blocks(ncb, n, 32);
+      cls.push_back(Cls{name, base, base + nb});
+      base += nb;
+    };
+    mk(N, HD, HD, "folded D layer 1 (K=512)"); mk(N, HD, PD, "folded D layer 0 (K=296)");
+    const int kb = (HD + HD + 15) / 16;
+    for (int i = 0; i < 20; ++i) launch_fwd_gates(gj, base, kb, s);
+    CK(hipStreamSynchronize(s));
+    const float us = time_graph(s, 50, 4, [&] { launch_fwd_gates(gj, base, kb, s); });
+    launch_fwd_gates(gj, base, kb, s); CK(hipStreamSynchronize(s));
+    const char* names[] = {"lookup", "issueW", "issueDMA", "issueEpi", "loads+bar", "mfma", "bar", "zs+bar", "epilogue"};
+    const int idx[] = {2, 10, 11, 3, 4, 5, 6, 7, 9};
+    report("k_fwd_gates (folded discriminator alone)", base, cls, names, idx, 9, us);
+  }
   // ------------------------------------------------------------------ forward projection: 3 G layers + 4 D jobs + output FC
   {
     FwdProjJobs pj{};
