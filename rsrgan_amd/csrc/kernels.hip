@@ -625,37 +625,24 @@ __global__ __launch_bounds__(256) void k_bwd_a2(const BwdAJobs jobs) {
   const int nkb = (ldm + 15) >> 4;
   const int k4_0 = noproj ? c0 >> 2 : 0, nk4 = noproj ? 8 : ldm >> 2, nk4p = noproj ? 8 : nkb * 4;
   const int SA4 = nk4p | 1, SA = SA4 * 4;
-  // (1) stage dm: thread = (row tid/8, float4 slot tid%8 + 8 i)
-  {
-    const int srow = tid >> 3, s8 = tid & 7;
-    const int grow = min(r0 + srow, N - 1);
-    const int slen = J.len[grow];                                             // (unconditional: no branch around a load)
-    const bool live = (r0 + srow < N) & (J.t < slen);
-    const float* pm = J.dmst + (size_t)grow * ldm;
-    const float* pd = (J.dout ? J.dout : J.dmst) + (size_t)grow * ldm;        // (stand-in when there is no dout: zeroed below)
-    const float dscale = J.dout ? 1.f : 0.f;
-    float* pt = (cb == 0 && !noproj && r0 + srow < N) ? J.dmt + (size_t)grow * ldm : nullptr;
-    float4* dst = reinterpret_cast<float4*>(smem) + (size_t)srow * SA4;
-    constexpr int NI = (CHB * 4 + 7) / 8;
-    const int k4max = (ldm >> 2) - 1;
-    float4 va[NI], vd[NI];
+  // Every load of the workgroup is issued first -- (1) the dm operand, (2) the weight tiles, (3) the epilogue operands -- and only
+  // then is (1) consumed: loads return in order, so staging dm into LDS overlaps the landing of (2) and (3).
+  // (1) dm: thread = (row tid/8, float4 slot tid%8 + 8 i)
+  const int srow = tid >> 3, s8 = tid & 7;
+  const int grow = min(r0 + srow, N - 1);
+  const float* pm = J.dmst + (size_t)grow * ldm;
+  const float* pd = (J.dout ? J.dout : J.dmst) + (size_t)grow * ldm;        // (stand-in when there is no dout: zeroed below)
+  constexpr int NI = (CHB * 4 + 7) / 8;
+  const int k4max = (ldm >> 2) - 1;
+  float4 va[NI], vd[NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {          // unconditional loads from clamped slots (one round trip for all of them)
-      const int g4 = min(k4_0 + s8 + 8 * i, k4max);
-      va[i] = *reinterpret_cast<const float4*>(pm + g4 * 4);
-      vd[i] = *reinterpret_cast<const float4*>(pd + g4 * 4);
-    }
-    TR(10);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int c4 = s8 + 8 * i;
-      const bool in = live && c4 < nk4 && k4_0 + c4 <= k4max;       // slots past the row's data: zeros
-      float4 v = make_float4(va[i].x + dscale * vd[i].x, va[i].y + dscale * vd[i].y, va[i].z + dscale * vd[i].z, va[i].w + dscale * vd[i].w);
-      v = make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
-      if (c4 < nk4p) dst[c4] = v;
-      if (pt && c4 < nk4) *reinterpret_cast<float4*>(pt + c4 * 4) = v;
-    }
+  for (int i = 0; i < NI; ++i) {          // unconditional loads from clamped slots (one round trip for all of them)
+    const int g4 = min(k4_0 + s8 + 8 * i, k4max);
+    va[i] = *reinterpret_cast<const float4*>(pm + g4 * 4);
+    vd[i] = *reinterpret_cast<const float4*>(pd + g4 * 4);
   }
+  const int slen = J.len[grow];                                             // (unconditional: no branch around a load)
+  TR(10);
   // (2) this wave's weight tiles: column tile cb*2 + ct of the fragment-tiled copy, all k-blocks
   float4 bv[CHB];
   if (!noproj) {                 // (uniform) unconditional loads from clamped tiles: the product skips k-blocks >= nkb, and
@@ -673,17 +660,35 @@ __global__ __launch_bounds__(256) void k_bwd_a2(const BwdAJobs jobs) {
   const int ecl = min(ecell, H - 1);
   const float ewo = J.wo[ecl], ewi = J.wi[ecl], ewf = J.wf[ecl];
   float eg[4][4], ecp[4], ecn[4], edc[4];
-  bool elive[4], erok[4];
+  int elen[4];
+  bool erok[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int row = r0 + rt * 16 + 4 * q + e;
     erok[e] = row < N && cok;
     const int rowc = min(row, N - 1);
-    elive[e] = J.t < J.len[rowc];
+    elen[e] = J.len[rowc];
     const float* g = J.gates + (size_t)rowc * H4 + ecl;
     eg[e][0] = g[0]; eg[e][1] = g[H]; eg[e][2] = g[2 * H]; eg[e][3] = g[3 * H];
     const size_t ci = (size_t)rowc * H + ecl;
     ecp[e] = J.c_prev[ci]; ecn[e] = J.c_cur[ci]; edc[e] = J.dc[ci];
+  }
+  __builtin_amdgcn_sched_barrier(0);       // keep the issue order above: nothing below may be hoisted between the loads
+  // (1') dm = mask.(dout + dmst) -> LDS image (and dm_t for the weight gradients from the column-block-0 workgroups)
+  {
+    const bool live = (r0 + srow < N) & (J.t < slen);
+    const float dscale = J.dout ? 1.f : 0.f;
+    float* pt = (cb == 0 && !noproj && r0 + srow < N) ? J.dmt + (size_t)grow * ldm : nullptr;
+    float4* dst = reinterpret_cast<float4*>(smem) + (size_t)srow * SA4;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c4 = s8 + 8 * i;
+      const bool in = live && c4 < nk4 && k4_0 + c4 <= k4max;       // slots past the row's data: zeros
+      float4 v = make_float4(va[i].x + dscale * vd[i].x, va[i].y + dscale * vd[i].y, va[i].z + dscale * vd[i].z, va[i].w + dscale * vd[i].w);
+      v = make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
+      if (c4 < nk4p) dst[c4] = v;
+      if (pt && c4 < nk4) *reinterpret_cast<float4*>(pt + c4 * 4) = v;
+    }
   }
   TR(3);
   __syncthreads();
@@ -723,7 +728,7 @@ __global__ __launch_bounds__(256) void k_bwd_a2(const BwdAJobs jobs) {
     if (!erok[e]) continue;
     const int row = r0 + rt * 16 + 4 * q + e;
     float* g = J.gates + (size_t)row * H4 + ecell;
-    if (elive[e]) {
+    if (J.t < elen[e]) {
       const float gi = eg[e][0], gj = eg[e][1], gf = eg[e][2], go = eg[e][3];
       const float tc = tanhf(ecn[e]);
       const float dao = dh[e] * tc * go * (1.f - go);
@@ -810,8 +815,9 @@ __global__ __launch_bounds__(512) void k_bwd_bp(const BwdBJobs jobs) {
   TR_BEGIN();
   const BwdBJob J = RSR_PICK(BwdBJob, blk_base_p);
   const int lb = bid - J.blk_base_p;
-  const int per_kg = J.ncg * J.nrg;
-  const int kg = lb / per_kg, rem = lb - kg * per_kg;
+  // K slice minor: with KG = 8 slices (the usual plan) block id % 8 = slice, so every workgroup of a slice runs on ONE XCD and
+  // that XCD's L2 only ever holds its own eighth of K (and of dz) across the whole recurrence
+  const int kg = lb % J.KG, rem = lb / J.KG;
   const int rg = rem / J.ncg, cg = rem - rg * J.ncg;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -961,6 +967,7 @@ void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s) {
   size_t lds = (size_t)64 * bp_sa4(kpg_max) * 16;
   lds = (lds + 8191) / 8192 * 8192;
   lds = std::max(lds, (size_t)8 * BP_RT * 16 * 17 * sizeof(float));
+  if (bp <= 256) lds = std::max(lds, (size_t)84 * 1024);        // one workgroup per CU: with <= 256 of them none should share a CU's matrix pipe
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_bp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

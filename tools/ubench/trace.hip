@@ -66,6 +66,23 @@ static void report(const char* kernel, int blocks, const std::vector<Cls>& cls, 
     const unsigned cu = (hw >> 8) & 15, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
     per_cu[(xcc << 16) | (se << 8) | (sh << 4) | cu]++;
   }
+  {   // which blocks share a CU?  (b, b + 256) pairs = the dispatcher fills CUs in block order, one workgroup per CU per round
+    std::map<unsigned, std::vector<int>> ids;
+    for (int b = 0; b < blocks; ++b) {
+      const unsigned long long* r = &t[(size_t)b * 16];
+      if (r[9] == 0) continue;
+      const unsigned hw = (unsigned)r[14], xcc = (unsigned)r[15] & 15;
+      ids[(xcc << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)].push_back(b);
+    }
+    int pairs = 0, p256 = 0;
+    for (auto& kv : ids) if (kv.second.size() == 2) { ++pairs; p256 += std::abs(kv.second[0] - kv.second[1]) == 256; }
+    if (pairs) {
+      printf("   CUs with two blocks: %d, of which ids differ by exactly 256: %d ; examples:", pairs, p256);
+      int shown = 0;
+      for (auto& kv : ids) if (kv.second.size() == 2 && shown++ < 6) printf(" (%d,%d)", kv.second[0], kv.second[1]);
+      printf("\n");
+    }
+  }
   int hist[8] = {0};
   for (auto& kv : per_cu) hist[std::min(kv.second, 7)]++;
   printf("   CUs used %zu ; CUs with 1/2/3/4+ working blocks: %d / %d / %d / %d\n", per_cu.size(), hist[1], hist[2], hist[3], hist[4] + hist[5] + hist[6] + hist[7]);
