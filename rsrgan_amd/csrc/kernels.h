@@ -10,6 +10,24 @@ namespace rsr {
 
 constexpr int MAXJ = 8;   // (layer, t) jobs fused into one launch of a step kernel
 
+// Placement of a job's workgroups in a launch (filled by the launchers, read by pick_job in kernels.hip).  Block id b has the XCD
+// slot x = b & 7 (observed on MI355X: block b runs on XCD (b + c) % 8 for a constant c, tools/ubench/l2.hip) and the round
+// s = b >> 3.  A job owns the slots [x0, x0 + nx) (mod 8) during the rounds [sb, se): its local block is
+// lb = (s - sb) * nx + ((x - x0) & 7), valid while lb < nb, and the tile kernels read lb as (column block lb % w, row block lb / w)
+// with w = the column-block count rounded up to a multiple of nx -- so a column block (= a slice of the layer's weights) always
+// runs on the same XCD, and a HEAVY job (a generator layer) owns a group of XCDs of its own: that group's L2 holds only this
+// layer's weights and operands (2.3 MB instead of an eighth of every layer's plus all the streaming traffic), the blocks that
+// produce a layer's h / m are the ones whose XCD consumes them in the next launch, and the heavy blocks sit one per CU.
+// nx = 8, x0 = 0 is the plain contiguous layout (lb = b - 8 sb).
+struct Place { int x0, nx, sb, se, nb, w; };
+// block id -> job index (0xFF = no job), filled from the places by the launchers: the kernels look their job up with one scalar
+// load instead of testing all MAXJ places (valid = 0: grid larger than the table, the kernels test the places)
+constexpr int JOBMAP_MAX = 768;
+struct JobMap { int valid; unsigned char job[JOBMAP_MAX]; };
+struct PlanItem { int ncol, nrow; double cost; int mult; };       // mult: nx must divide it (0 = any nx)
+// assigns every job a Place (`nb_of(job, nx)` = its block count when it owns nx slots per round); returns the grid size
+int plan_places(int n, const PlanItem* items, Place* out);
+
 // device-resident scalars (model.dyn): what the reference changes with tf.assign between steps
 enum { DYN_G_LR = 0, DYN_D_LR = 1, DYN_LAMBDA = 2, DYN_D_REAL = 3, DYN_D_FAKE = 4, DYN_L2 = 5, DYN_CLIP = 6,
        DYN_B1 = 7, DYN_B2 = 8, DYN_EPS = 9, DYN_EMA = 10, DYN_ADAM_LRT = 11, DYN_ADAM_LRT_D = 12, DYN_COUNT = 16 };
@@ -31,11 +49,12 @@ struct FwdGateJob {
   float* h;            // [N][ldh] out: sigma(o)*tanh(c)
   const int* len;      // [N]
   int ldx, ldm, ldh, t, N, H;
-  int nblk_c, blk_base;
+  int nblk_c;
+  Place pl;
   // num_proj=None layers (m = h): the epilogue also writes the carried state, the masked output and the residual sum
   float* np_m_out; float* np_out; const float* np_res_in; float* np_res_out;
 };
-struct FwdGateJobs { int n; float forget_bias; FwdGateJob j[MAXJ]; };
+struct FwdGateJobs { int n; float forget_bias; FwdGateJob j[MAXJ]; JobMap map; };
 
 // Forward phase 2: m_t = h_t . Wp ; dynamic_rnn masking ; optional residual add
 struct FwdProjJob {
@@ -51,9 +70,10 @@ struct FwdProjJob {
   const float* bias;    // [P] added to the product (fully_connected stage), or nullptr
   const float* noise;   // [N][P] added to `out` only (gaussian_noise_layer on D's input), or nullptr
   int ldh, ldm, ldo, P, t, N;     // ldm: stride of m_prev/m_out/res_*, ldo: stride of out
-  int nblk_c, blk_base;
+  int nblk_c;
+  Place pl;
 };
-struct FwdProjJobs { int n; FwdProjJob j[MAXJ]; };
+struct FwdProjJobs { int n; FwdProjJob j[MAXJ]; JobMap map; };
 
 // Backward phase A: dm = mask*(dout_t + dm_state); dh = dm . Wp^T ; gate grads -> dz ; dc
 struct BwdAJob {
@@ -69,9 +89,10 @@ struct BwdAJob {
   float* dc;            // [N][H]   carried grad of c (in/out)
   const int* len;
   int ldm, P, t, N, H;
-  int nblk_c, blk_base;
+  int nblk_c;
+  Place pl;
 };
-struct BwdAJobs { int n; BwdAJob j[MAXJ]; };
+struct BwdAJobs { int n; BwdAJob j[MAXJ]; JobMap map; };
 
 // Backward phase B: [dx_t | dm_rec] = dz_t . K^T restricted to kernel rows [n_begin, n_end)
 struct BwdBJob {
@@ -83,16 +104,17 @@ struct BwdBJob {
   const int* len;
   int I, n_begin, n_end, lddx, ldm, t, N, H4;
   int dx_accumulate;    // dx += instead of =
-  int nblk_c, blk_base;
+  int nblk_c;
+  Place pl;             // k_bwd_b (one launch of 32x16 / 16x16 tiles)
   // split-K form (k_bwd_bp + k_bwd_b_red): partial tiles ws[KG][N][ldw], KG groups of kpg k-blocks
   float* ws;
-  int ldw, KG, kpg, ncg, nrg, blk_base_p, blk_base_r;
+  int ldw, KG, kpg, ncg, nrg;
+  Place plp, plr;       // k_bwd_bp (lb -> K slice lb % KG, output tile lb / KG) and k_bwd_b_red (256 outputs per block)
 };
-struct BwdBJobs { int n; BwdBJob j[MAXJ]; };
+struct BwdBJobs { int n; BwdBJob j[MAXJ]; JobMap map, mapr; };      // map: k_bwd_b or k_bwd_bp (whichever runs), mapr: k_bwd_b_red
 
-// A job covers nblk_r = ceil(N/32) row blocks x roundup8(nblk_c) virtual column blocks; blk_base is
-// the job's first block id in the launch.  kb_max = largest 16-float k-block count of any job in
-// the launch (selects how many waves split K).
+// The launchers place the jobs (Place above) and size the grid themselves; `total_blocks` arguments are ignored hints.
+// kb_max = largest 16-float k-block count of any job in the launch (selects how many waves split K).
 inline int job_blocks(int nblk_c, int N, int rows = 32) { return ((nblk_c + 7) & ~7) * ((N + rows - 1) / rows); }
 int fwd_gates_rows();
 void set_fwd_gates_rows(int r);
@@ -105,7 +127,6 @@ void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, int kb_max, hipStream_
 // split-K phase B: fills ws/ldw/KG/... of every job (ws_base: >= bwd_b_ws_floats(jobs) floats) and launches both kernels
 size_t bwd_b_plan(BwdBJobs& jobs, float* ws_base);
 void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s);
-void launch_bwd_b_red(const BwdBJobs& jobs, hipStream_t s);       // fixed-order sum of the split-K partials + masked epilogue
 
 // ---------------------------------------------------------------- persistent small-cell recurrence (dlstm.hip)
 // One workgroup per (16-row tile, layer) walks all T steps of a stack of dynamic_rnn(LSTMCell) layers with the layer's weights in

@@ -36,23 +36,16 @@ __device__ unsigned long long g_trace[8192 * 16];
     t_[0] = __builtin_amdgcn_s_memrealtime(); t_[1] = __builtin_amdgcn_s_memtime(); \
     t_[14] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); t_[15] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); \
     for (int i_ = 2; i_ < 14; ++i_) t_[i_] = 0; } } while (0)
+#define TR_ID(ptr) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_trace[(size_t)blockIdx.x * 16 + 12] = (unsigned long long)(size_t)(ptr); } while (0)
 #define TR(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_trace[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define TR_END() do { if (threadIdx.x == 0 && blockIdx.x < 8192) { g_trace[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime(); \
     g_trace[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define TR_BEGIN() do { } while (0)
+#define TR_ID(ptr) do { } while (0)
 #define TR(i) do { } while (0)
 #define TR_END() do { } while (0)
 #endif
-
-template <typename JobT>
-__device__ __forceinline__ int find_job(const JobT* j, int n, int bid) {
-  int ji = 0;
-#pragma unroll
-  for (int q = 1; q < MAXJ; ++q)
-    if (q < n && bid >= j[q].blk_base) ji = q;
-  return ji;
-}
 
 // The job record of a workgroup in ONE memory round trip: lane i of every wave loads dword i of the record (kernarg segment or a
 // device table, <= 256 B) and v_readlane moves it into scalar registers.  Reading the fields straight from the by-value
@@ -76,23 +69,41 @@ __device__ __forceinline__ void globalize(BwdAJob& J) {
 __device__ __forceinline__ void globalize(BwdBJob& J) { RSR_G(dz) RSR_G(K) RSR_G(Ksw) RSR_G(dx) RSR_G(dmst) RSR_G(len) RSR_G(ws) }
 #undef RSR_G
 // The job of block `bid` in ONE round trip: the records of ALL MAXJ jobs are requested at once (one dword per lane each) next to
-// the scalar load of the job count; the block's job is the last one whose first block id (dword OFF of the record) is <= bid.
+// the scalar load of the block's entry of the job map; `lb` = the block's index inside its job from the job's Place (kernels.h;
+// 6 dwords at OFF), or -1 when no job wants this block (idle slot of an XCD group).  Without a map (grid > JOBMAP_MAX) the
+// places of all jobs are tested.
 template <typename JobT, int OFF>
-__device__ __forceinline__ JobT pick_job(const JobT* j, const int& n_ref, int bid) {
+__device__ __forceinline__ JobT pick_job(const JobT* j, const int& n_ref, const JobMap& map, int bid, int& lb) {
   constexpr int ND = (int)(sizeof(JobT) / 4);
-  static_assert(sizeof(JobT) % 4 == 0 && ND <= 64 && OFF < ND, "job record must fit one dword per lane");
+  static_assert(sizeof(JobT) % 4 == 0 && ND <= 64 && OFF + 5 < ND, "job record must fit one dword per lane");
   const int lane = threadIdx.x & 63;
   const int li = lane < ND ? lane : 0;
   unsigned v[MAXJ];
 #pragma unroll
   for (int q = 0; q < MAXJ; ++q) v[q] = reinterpret_cast<const unsigned*>(j + q)[li];
-  const int n = n_ref;
+  const int x = bid & 7, sr = bid >> 3;
   unsigned vs = v[0];
+  lb = -1;
+  if (map.valid) {                                       // (uniform)
+    const int ji = map.job[min(bid, JOBMAP_MAX - 1)];
 #pragma unroll
-  for (int q = 1; q < MAXJ; ++q) {
-    const int bb = __builtin_amdgcn_readlane((int)v[q], OFF);
-    const bool take = q < n && bid >= bb;               // (uniform: blk_base ascends with q)
-    vs = take ? v[q] : vs;
+    for (int q = 1; q < MAXJ; ++q) vs = ji == q ? v[q] : vs;
+    const int x0 = __builtin_amdgcn_readlane((int)vs, OFF), nx = __builtin_amdgcn_readlane((int)vs, OFF + 1);
+    const int sb = __builtin_amdgcn_readlane((int)vs, OFF + 2);
+    lb = ji == 0xFF ? -1 : (sr - sb) * nx + ((x - x0) & 7);
+  } else {
+    const int n = n_ref;
+#pragma unroll
+    for (int q = 0; q < MAXJ; ++q) {
+      const int x0 = __builtin_amdgcn_readlane((int)v[q], OFF), nx = __builtin_amdgcn_readlane((int)v[q], OFF + 1);
+      const int sb = __builtin_amdgcn_readlane((int)v[q], OFF + 2), se = __builtin_amdgcn_readlane((int)v[q], OFF + 3);
+      const int nb = __builtin_amdgcn_readlane((int)v[q], OFF + 4);
+      const int k = (x - x0) & 7;
+      const int l = (sr - sb) * nx + k;
+      const bool take = q < n && k < nx && sr >= sb && sr < se && l < nb;       // (uniform; the places of a launch are disjoint)
+      vs = take ? v[q] : vs;
+      lb = take ? l : lb;
+    }
   }
   union U { JobT j; unsigned d[ND]; __device__ U() {} } u;
 #pragma unroll
@@ -100,7 +111,8 @@ __device__ __forceinline__ JobT pick_job(const JobT* j, const int& n_ref, int bi
   globalize(u.j);
   return u.j;
 }
-#define RSR_PICK(JobT, field) pick_job<JobT, (int)(__builtin_offsetof(JobT, field) / 4)>(jobs.j, jobs.n, bid)
+#define RSR_PICK(JobT, field, lb) pick_job<JobT, (int)(__builtin_offsetof(JobT, field) / 4)>(jobs.j, jobs.n, jobs.map, bid, lb)
+#define RSR_PICK_M(JobT, field, mapf, lb) pick_job<JobT, (int)(__builtin_offsetof(JobT, field) / 4)>(jobs.j, jobs.n, jobs.mapf, bid, lb)
 
 template <typename JobT>
 __device__ __forceinline__ JobT load_job(const JobT* p) {
@@ -115,15 +127,13 @@ __device__ __forceinline__ JobT load_job(const JobT* p) {
   return u.j;
 }
 
-// Column-block <-> XCD affinity: a job's blocks are laid out as nblk_r rows of nblk_c8 =
-// roundup8(nblk_c) virtual column blocks, so (block id % 8) == (column block % 8) for every row
-// block and every time step: the slice of a weight matrix a column block streams stays in ONE
-// XCD's 4 MiB L2 across the whole recurrence (block id -> XCD id%8 is observed behaviour and only
-// affects speed).
-__device__ __forceinline__ bool tile_of_block(int lb, int nblk_c, int& cb, int& rb) {
-  const int nblk_c8 = (nblk_c + 7) & ~7;
-  cb = lb % nblk_c8;
-  rb = lb / nblk_c8;
+// Local block -> (column block, row block): pl.w = the job's column blocks rounded up to a multiple of its XCD slots, so
+// lb % nx (= the XCD slot) == cb % nx for every row block and every time step: the slice of a weight matrix a column block
+// streams stays in ONE XCD's 4 MiB L2 across the whole recurrence (block id -> XCD is observed behaviour, only speed depends on it).
+__device__ __forceinline__ bool tile_of_block(int lb, int nblk_c, const Place& pl, int& cb, int& rb) {
+  if (lb < 0) return false;
+  rb = lb / pl.w;
+  cb = lb - rb * pl.w;
   return cb < nblk_c;
 }
 
@@ -232,9 +242,11 @@ __global__ __launch_bounds__(512 * RH, (RH == 1 && RTG == 2 && CHB <= 18) ? 4 : 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = blockIdx.x;
   TR_BEGIN();
-  const FwdGateJob J = RSR_PICK(FwdGateJob, blk_base);
+  int lb;
+  const FwdGateJob J = RSR_PICK(FwdGateJob, pl, lb);
   int cb, rb;
-  if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
+  if (!tile_of_block(lb, J.nblk_c, J.pl, cb, rb)) return;
+  TR_ID(J.gates);
   TR(2);
   const int r0 = rb * 16 * RTG * RH, c0 = cb * 16;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
@@ -383,9 +395,11 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_proj(const FwdProjJobs jobs) {
   __shared__ float zs[NW][RT][16][17];
   const int bid = blockIdx.x;
   TR_BEGIN();
-  const FwdProjJob J = RSR_PICK(FwdProjJob, blk_base);
+  int lb;
+  const FwdProjJob J = RSR_PICK(FwdProjJob, pl, lb);
   int cb, rb;
-  if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
+  if (!tile_of_block(lb, J.nblk_c, J.pl, cb, rb)) return;
+  TR_ID(J.h);
   const int r0 = rb * 16 * RT, c0 = cb * 16;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform -> scalar branches
@@ -469,9 +483,11 @@ __global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
   if (!KA_ON(32)) return;
 #endif
   TR_BEGIN();
-  const BwdAJob J = RSR_PICK(BwdAJob, blk_base);
+  int lb;
+  const BwdAJob J = RSR_PICK(BwdAJob, pl, lb);
   int cb, rb;
-  if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
+  if (!tile_of_block(lb, J.nblk_c, J.pl, cb, rb)) return;
+  TR_ID(J.gates);
   TR(2);
   const int r0 = rb * 16 * RT, c0 = cb * 16;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
@@ -609,9 +625,11 @@ __global__ __launch_bounds__(256) void k_bwd_a2(const BwdAJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = blockIdx.x;
   TR_BEGIN();
-  const BwdAJob J = RSR_PICK(BwdAJob, blk_base);
+  int lb;
+  const BwdAJob J = RSR_PICK(BwdAJob, pl, lb);
   int cb, rb;
-  if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
+  if (!tile_of_block(lb, J.nblk_c, J.pl, cb, rb)) return;
+  TR_ID(J.gates);
   TR(2);
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -752,9 +770,10 @@ template <int NW, int VAR = 0, int CH = 6, int RTB = RT>
 __global__ __launch_bounds__(NW * 64) void k_bwd_b(const BwdBJobs jobs) {
   __shared__ float zs[NW][RTB][16][17];
   const int bid = blockIdx.x;
-  const BwdBJob J = RSR_PICK(BwdBJob, blk_base);
+  int lb;
+  const BwdBJob J = RSR_PICK(BwdBJob, pl, lb);
   int cb, rb;
-  if (!tile_of_block(bid - J.blk_base, J.nblk_c, cb, rb)) return;
+  if (!tile_of_block(lb, J.nblk_c, J.pl, cb, rb)) return;
   const int r0 = rb * 16 * RTB, n0 = J.n_begin + cb * 16;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform -> scalar branches
@@ -813,10 +832,12 @@ __global__ __launch_bounds__(512) void k_bwd_bp(const BwdBJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = blockIdx.x;
   TR_BEGIN();
-  const BwdBJob J = RSR_PICK(BwdBJob, blk_base_p);
-  const int lb = bid - J.blk_base_p;
-  // K slice minor: with KG = 8 slices (the usual plan) block id % 8 = slice, so every workgroup of a slice runs on ONE XCD and
-  // that XCD's L2 only ever holds its own eighth of K (and of dz) across the whole recurrence
+  int lb;
+  const BwdBJob J = RSR_PICK(BwdBJob, plp, lb);
+  if (lb < 0) return;
+  TR_ID(J.dz);
+  // K slice minor: KG is a multiple of the job's XCD slots, so lb % nx = slice % nx: every workgroup of a slice runs on ONE XCD
+  // and that XCD's L2 only ever holds its own share of K (and of dz) across the whole recurrence
   const int kg = lb % J.KG, rem = lb / J.KG;
   const int rg = rem / J.ncg, cg = rem - rg * J.ncg;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
@@ -912,9 +933,11 @@ __global__ __launch_bounds__(512) void k_bwd_bp(const BwdBJobs jobs) {
 
 __global__ __launch_bounds__(256) void k_bwd_b_red(const BwdBJobs jobs) {
   const int bid = blockIdx.x;
-  const BwdBJob J = RSR_PICK(BwdBJob, blk_base_r);
+  int lb;
+  const BwdBJob J = RSR_PICK_M(BwdBJob, plr, mapr, lb);
+  if (lb < 0) return;
   const int ncols = J.n_end - J.n_begin;
-  const int e = (bid - J.blk_base_r) * 256 + threadIdx.x;
+  const int e = lb * 256 + threadIdx.x;
   if (e >= J.N * ncols) return;
   const int row = e / ncols, col = e - row * ncols;
   const int nn = J.n_begin + col;
@@ -934,40 +957,148 @@ __global__ __launch_bounds__(256) void k_bwd_b_red(const BwdBJobs jobs) {
   *dst = v;
 }
 
+// ---------------------------------------------------------------------------------------
+// placement of the jobs of a launch (kernels.h Place)
+// ---------------------------------------------------------------------------------------
+static int g_xcd_groups = -1;          // RSRGAN_XCD_GROUPS=0: every job spans all 8 XCD slots (round 1's contiguous layout)
+// phase 1: XCD slots per job.  A job worth >= 12 % of the launch's work gets a group of slots of its own, sized by its share
+// (largest remainders, at least one, 8 in all); the others ("fillers") span all 8 slots after the groups' rounds.
+static void plan_groups(int n, const double* cost, int* nx, int* x0, bool* grouped) {
+  if (g_xcd_groups < 0) { const char* e = getenv("RSRGAN_XCD_GROUPS"); g_xcd_groups = e ? atoi(e) : 1; }
+  double total = 0.0;
+  for (int j = 0; j < n; ++j) total += cost[j];
+  int ng = 0;
+  double cg = 0.0;
+  for (int j = 0; j < n; ++j) { grouped[j] = g_xcd_groups && total > 0.0 && cost[j] >= 0.12 * total; ng += grouped[j]; cg += grouped[j] ? cost[j] : 0.0; }
+  if (ng < 2 || ng > 8) {
+    for (int j = 0; j < n; ++j) { grouped[j] = false; nx[j] = 8; x0[j] = 0; }
+    return;
+  }
+  double frac[MAXJ];
+  int sum = 0;
+  for (int j = 0; j < n; ++j) {
+    nx[j] = 8; x0[j] = 0; frac[j] = -1.0;
+    if (!grouped[j]) continue;
+    const double ideal = 8.0 * cost[j] / cg;
+    nx[j] = std::max(1, (int)ideal);
+    frac[j] = ideal - nx[j];
+    sum += nx[j];
+  }
+  while (sum < 8) {                      // hand the remaining slots to the largest remainders
+    int best = -1;
+    for (int j = 0; j < n; ++j) if (grouped[j] && (best < 0 || frac[j] > frac[best])) best = j;
+    nx[best]++; frac[best] -= 1.0; ++sum;
+  }
+  while (sum > 8) {                      // (only when many small groups were rounded up to one slot each)
+    int best = -1;
+    for (int j = 0; j < n; ++j) if (grouped[j] && nx[j] > 1 && (best < 0 || frac[j] < frac[best])) best = j;
+    if (best < 0) break;
+    nx[best]--; frac[best] += 1.0; --sum;
+  }
+  int x = 0;
+  for (int j = 0; j < n; ++j) if (grouped[j]) { x0[j] = x; x += nx[j]; }
+}
+// phase 2: rounds.  Groups start at round 0 side by side; fillers follow, each on all 8 slots.  Returns the grid size.
+static int plan_rounds(int n, const int* nb, const int* w, const int* nx, const int* x0, const bool* grouped, Place** out) {
+  int cur = 0;
+  for (int j = 0; j < n; ++j)
+    if (grouped[j]) { *out[j] = Place{x0[j], nx[j], 0, (nb[j] + nx[j] - 1) / nx[j], nb[j], w[j]}; cur = std::max(cur, out[j]->se); }
+  for (int j = 0; j < n; ++j)
+    if (!grouped[j]) { const int r = (nb[j] + 7) / 8; *out[j] = Place{0, 8, cur, cur + r, nb[j], w[j]}; cur += r; }
+  return 8 * std::max(cur, 1);
+}
+int plan_places(int n, const PlanItem* items, Place* out) {
+  double cost[MAXJ]; int nx[MAXJ], x0[MAXJ], nb[MAXJ], w[MAXJ]; bool grouped[MAXJ]; Place* po[MAXJ];
+  for (int j = 0; j < n; ++j) cost[j] = items[j].cost;
+  plan_groups(n, cost, nx, x0, grouped);
+  for (int j = 0; j < n; ++j) {
+    w[j] = (items[j].ncol + nx[j] - 1) / nx[j] * nx[j];
+    nb[j] = w[j] * items[j].nrow;
+    po[j] = out + j;
+  }
+  return plan_rounds(n, nb, w, nx, x0, grouped, po);
+}
+// block id -> job table of a launch from the jobs' places
+template <typename GetPlace>
+static void fill_map(JobMap& m, int n, int grid, GetPlace pl) {
+  m.valid = grid <= JOBMAP_MAX;
+  if (!m.valid) return;
+  for (int b = 0; b < grid; ++b) {
+    const int x = b & 7, sr = b >> 3;
+    unsigned char ji = 0xFF;
+    for (int q = 0; q < n; ++q) {
+      const Place& p = pl(q);
+      const int k = (x - p.x0) & 7, l = (sr - p.sb) * p.nx + k;
+      if (k < p.nx && sr >= p.sb && sr < p.se && l < p.nb) { ji = (unsigned char)q; break; }
+    }
+    m.job[b] = ji;
+  }
+}
+// tile kernels: column blocks x row blocks of `rows` rows, cost ~ blocks x K
+template <typename JobsT, typename CostF>
+static int place_tiles(JobsT& jobs, int rows, CostF kcost) {
+  PlanItem it[MAXJ]; Place pl[MAXJ];
+  for (int i = 0; i < jobs.n; ++i) {
+    it[i].ncol = jobs.j[i].nblk_c; it[i].nrow = (jobs.j[i].N + rows - 1) / rows; it[i].mult = 0;
+    it[i].cost = (double)it[i].ncol * it[i].nrow * kcost(jobs.j[i]);
+  }
+  const int grid = plan_places(jobs.n, it, pl);
+  for (int i = 0; i < jobs.n; ++i) jobs.j[i].pl = pl[i];
+  fill_map(jobs.map, jobs.n, grid, [&](int q) -> const Place& { return jobs.j[q].pl; });
+  return grid;
+}
+
 size_t bwd_b_plan(BwdBJobs& jobs, float* ws_base) {
   size_t off = 0;
-  int bp = 0, br = 0;
-  for (int i = 0; i < jobs.n; ++i) {
+  const int n = jobs.n;
+  double cost[MAXJ]; int nx[MAXJ], x0[MAXJ], nb[MAXJ], w1[MAXJ], nbr[MAXJ]; bool grouped[MAXJ], nogroup[MAXJ]; Place* pp[MAXJ]; Place* pr[MAXJ];
+  for (int i = 0; i < n; ++i) cost[i] = (double)(jobs.j[i].n_end - jobs.j[i].n_begin) * jobs.j[i].N * jobs.j[i].H4;
+  plan_groups(n, cost, nx, x0, grouped);
+  // measured in the step (not in isolation, tools/ubench/trace.hip): with XCD groups this kernel is 23 us instead of 14 -- the K
+  // slice <-> XCD affinity of the contiguous layout (slice = block id % 8) is what it needs; RSRGAN_BP_GROUPS=1 to try again
+  static int bp_groups = -1;
+  if (bp_groups < 0) { const char* e = getenv("RSRGAN_BP_GROUPS"); bp_groups = e ? atoi(e) : 0; }
+  if (!bp_groups) for (int i = 0; i < n; ++i) { grouped[i] = false; nx[i] = 8; x0[i] = 0; }
+  static int kpg_target = -1;        // k-blocks per K slice: 24 -> 99 KB LDS (1 WG/CU)
+  if (kpg_target < 0) { const char* e = getenv("RSRGAN_BP_KPG"); kpg_target = e ? atoi(e) : 24; if (kpg_target < 2 || kpg_target > 2 * BP_CHB) kpg_target = 24; }
+  for (int i = 0; i < n; ++i) {
     BwdBJob& b = jobs.j[i];
     const int nkb = (b.H4 + 15) >> 4, ncols = b.n_end - b.n_begin;
-    static int kpg_target = -1;        // k-blocks per K slice: 24 -> 99 KB LDS (1 WG/CU), 12 -> 50 KB (3 WGs/CU overlap load and MFMA phases)
-    if (kpg_target < 0) { const char* e = getenv("RSRGAN_BP_KPG"); kpg_target = e ? atoi(e) : 24; if (kpg_target < 2 || kpg_target > 2 * BP_CHB) kpg_target = 24; }
     int KG = std::max((nkb + kpg_target - 1) / kpg_target, std::min(8, nkb / 8));
-    KG = std::min(16, std::max(1, KG));          // k_bwd_b_red holds <= 16 partials in registers
+    KG = std::max(1, KG);
+    // a multiple of the job's XCD slots (slice lb % KG then stays on one XCD), while k_bwd_b_red holds <= 16 partials in registers
+    const int KGm = (KG + nx[i] - 1) / nx[i] * nx[i];
+    if (KGm <= 16 && KGm <= nkb) KG = KGm;
+    KG = std::min(16, KG);
     b.kpg = (nkb + KG - 1) / KG;
     b.KG = (nkb + b.kpg - 1) / b.kpg;
     b.ncg = (ncols + 63) / 64; b.nrg = (b.N + 63) / 64;
     b.ldw = (ncols + 3) & ~3;
     b.ws = ws_base ? ws_base + off : nullptr;
     off += (size_t)b.KG * b.N * b.ldw;
-    b.blk_base_p = bp; bp += b.KG * b.ncg * b.nrg;
-    b.blk_base_r = br; br += (b.N * ncols + 255) / 256;
+    nb[i] = b.KG * b.ncg * b.nrg; w1[i] = 1; pp[i] = &b.plp;
+    nbr[i] = (b.N * ncols + 255) / 256; nogroup[i] = false; pr[i] = &b.plr;
   }
+  const int gp = plan_rounds(n, nb, w1, nx, x0, grouped, pp);
+  int nx8[MAXJ], x00[MAXJ];
+  for (int i = 0; i < n; ++i) { nx8[i] = 8; x00[i] = 0; }
+  const int gr = plan_rounds(n, nbr, w1, nx8, x00, nogroup, pr);       // the reduce: elementwise, contiguous
+  fill_map(jobs.map, n, gp, [&](int q) -> const Place& { return jobs.j[q].plp; });
+  fill_map(jobs.mapr, n, gr, [&](int q) -> const Place& { return jobs.j[q].plr; });
   return off;
 }
 
 void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s) {
-  int bp = 0, br = 0, kpg_max = 1;
+  int bp = 8, br = 8, kpg_max = 1, nbp = 0;
   for (int i = 0; i < jobs.n; ++i) {
     const BwdBJob& b = jobs.j[i];
-    bp = std::max(bp, b.blk_base_p + b.KG * b.ncg * b.nrg);
-    br = std::max(br, b.blk_base_r + (b.N * (b.n_end - b.n_begin) + 255) / 256);
-    kpg_max = std::max(kpg_max, b.kpg);
+    bp = std::max(bp, 8 * b.plp.se); br = std::max(br, 8 * b.plr.se);
+    kpg_max = std::max(kpg_max, b.kpg); nbp += b.plp.nb;
   }
   size_t lds = (size_t)64 * bp_sa4(kpg_max) * 16;
   lds = (lds + 8191) / 8192 * 8192;
   lds = std::max(lds, (size_t)8 * BP_RT * 16 * 17 * sizeof(float));
-  if (bp <= 256) lds = std::max(lds, (size_t)84 * 1024);        // one workgroup per CU: with <= 256 of them none should share a CU's matrix pipe
+  if (nbp <= 256) lds = std::max(lds, (size_t)84 * 1024);       // one workgroup per CU: with <= 256 of them none should share a CU's matrix pipe
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bwd_bp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -976,18 +1107,14 @@ void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s) {
   hipLaunchKernelGGL(k_bwd_bp, dim3(bp), dim3(512), lds, s, jobs);
   hipLaunchKernelGGL(k_bwd_b_red, dim3(br), dim3(256), 0, s, jobs);
 }
-void launch_bwd_b_red(const BwdBJobs& jobs, hipStream_t s) {
-  int br = 0;
-  for (int i = 0; i < jobs.n; ++i) br = std::max(br, jobs.j[i].blk_base_r + (jobs.j[i].N * (jobs.j[i].n_end - jobs.j[i].n_begin) + 255) / 256);
-  hipLaunchKernelGGL(k_bwd_b_red, dim3(br), dim3(256), 0, s, jobs);
-}
 
-// total blocks of a job list and blk_base assignment happen on the host (model.cpp); `kb_max` is
-// the largest k-block count over the jobs, which picks the K split.
+// the launchers place the jobs (Place) and size the grid; `kb_max` is the largest k-block count over the jobs, which picks the K split.
 int g_gates_rows = 32;       // rows per k_fwd_gates workgroup (32 or 64); set once from RSRGAN_GATES_ROWS
 int fwd_gates_rows() { return g_gates_rows; }
 void set_fwd_gates_rows(int r) { g_gates_rows = (r == 64) ? 64 : 32; }
-void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
+void launch_fwd_gates(const FwdGateJobs& jobs_in, int total_blocks, int kb_max, hipStream_t s) {
+  FwdGateJobs jobs = jobs_in;
+  total_blocks = place_tiles(jobs, g_gates_rows, [](const FwdGateJob& j) { return (double)((j.x ? j.ldx : 0) + j.ldm); });
   // dynamic LDS: the widest job's A tile (rows x SA floats) rounded to the 8 KB DMA granule of the
   // 8 waves, and at least the reduction buffer
   const int ktot = kb_max * 16;
@@ -1017,7 +1144,9 @@ void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, int kb_max, hip
   } else if (rtg == 2) hipLaunchKernelGGL((k_fwd_gates<18, 2>), dim3(total_blocks), dim3(512), lds, s, jobs);
   else hipLaunchKernelGGL((k_fwd_gates<18, 2, 2>), dim3(total_blocks), dim3(1024), lds, s, jobs);
 }
-void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
+void launch_fwd_proj(const FwdProjJobs& jobs_in, int total_blocks, int kb_max, hipStream_t s) {
+  FwdProjJobs jobs = jobs_in;
+  total_blocks = place_tiles(jobs, 32, [](const FwdProjJob& j) { return (double)j.ldh; });
   if (kb_max <= 24)
     hipLaunchKernelGGL(k_fwd_proj<4>, dim3(total_blocks), dim3(256), 0, s, jobs);
   else
@@ -1026,7 +1155,9 @@ void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, int kb_max, hipS
 int g_bwd_a_form = 2;       // 2 = k_bwd_a2 (32 x 32 tiles, jobs' nblk_c counts 32-cell blocks), 1 = k_bwd_a (32 x 16); RSRGAN_BWD_A_FORM
 int bwd_a_cells() { return g_bwd_a_form == 2 ? 32 : 16; }
 void set_bwd_a_form(int f) { g_bwd_a_form = f == 1 ? 1 : 2; }
-void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
+void launch_bwd_a(const BwdAJobs& jobs_in, int total_blocks, int kb_max, hipStream_t s) {
+  BwdAJobs jobs = jobs_in;
+  total_blocks = place_tiles(jobs, 32, [](const BwdAJob& j) { return (double)(j.Wp ? j.ldm : 16); });
   if (g_bwd_a_form == 1) {      // host asserts kb_max <= 24 (proj width <= 384)
     hipLaunchKernelGGL(k_bwd_a<8>, dim3(total_blocks), dim3(512), 0, s, jobs);
     return;
@@ -1040,7 +1171,9 @@ void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, int kb_max, hipStream_
   else if (kb_max <= 18) hipLaunchKernelGGL(k_bwd_a2<18>, dim3(total_blocks), dim3(256), lds, s, jobs);
   else hipLaunchKernelGGL(k_bwd_a2<24>, dim3(total_blocks), dim3(256), lds, s, jobs);
 }
-void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, int kb_max, hipStream_t s) {
+void launch_bwd_b(const BwdBJobs& jobs_in, int total_blocks, int kb_max, hipStream_t s) {
+  BwdBJobs jobs = jobs_in;
+  total_blocks = place_tiles(jobs, kb_max <= 64 ? 16 : 32, [](const BwdBJob& j) { return (double)j.H4; });
   if (kb_max <= 64)  // small K (the discriminator alone): 8 waves x <= 8 k-blocks, one load round, no pipeline, 16-row tiles
     hipLaunchKernelGGL((k_bwd_b<8, 8, 8, 1>), dim3(total_blocks), dim3(512), 0, s, jobs);
   else               // 8 waves split K; each runs a double-buffered 6-k-block register pipeline

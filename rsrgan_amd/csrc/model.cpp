@@ -712,11 +712,11 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
         if (zx) zx_gemm(R);
         for (int t = 0; t < T; ++t) {
           FwdGateJobs gj{}; gj.n = 1; gj.forget_bias = cfg.forget_bias;
-          fill_gate(gj.j[0], R, t, zx); gj.j[0].blk_base = 0;
+          fill_gate(gj.j[0], R, t, zx);
           gates_launch(gj, gates_blocks(R.L->H, R.N), (zx ? 0 : kb16(R.L->ldI)) + kb16(R.L->ldP), s);
           if (R.L->has_proj) {
             FwdProjJobs pj{}; pj.n = 1;
-            fill_proj(pj.j[0], R, t); pj.j[0].blk_base = 0;
+            fill_proj(pj.j[0], R, t);
             run_proj(pj, proj_blocks(R.L->P, R.N), kb16(R.L->ldH), s);
           }
         }
@@ -747,7 +747,7 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
         if (t < 0 || t >= T) continue;
         const LayerRun& R = ch[l];
         if (gj.n == MAXJ) flush_g();
-        FwdGateJob& a = gj.j[gj.n++]; fill_gate(a, R, t, R.zx_batched); a.blk_base = gb; gb += gates_blocks(R.L->H, R.N);
+        FwdGateJob& a = gj.j[gj.n++]; fill_gate(a, R, t, R.zx_batched); gb += gates_blocks(R.L->H, R.N);
         gk = std::max(gk, (R.zx_batched ? 0 : kb16(R.L->ldI)) + kb16(R.L->ldP));
       }
     }
@@ -761,7 +761,7 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
         const LayerRun& R = ch[l];
         if (!R.L->has_proj) continue;
         if (pj.n == MAXJ) flush_p();
-        FwdProjJob& p = pj.j[pj.n++]; fill_proj(p, R, t); p.blk_base = pb; pb += proj_blocks(R.L->P, R.N);
+        FwdProjJob& p = pj.j[pj.n++]; fill_proj(p, R, t); pb += proj_blocks(R.L->P, R.N);
         pk = std::max(pk, kb16(R.L->ldH));
       }
     }
@@ -770,7 +770,7 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
         const int t = d - F.offset;
         if (t < 0 || t >= T) continue;
         if (pj.n == MAXJ) flush_p();
-        FwdProjJob& p = pj.j[pj.n++]; fill_fc_fwd(p, F, t); p.blk_base = pb; pb += proj_blocks(F.D, F.N);
+        FwdProjJob& p = pj.j[pj.n++]; fill_fc_fwd(p, F, t); pb += proj_blocks(F.D, F.N);
         pk = std::max(pk, kb16(F.ld_in));
       }
     flush_p();
@@ -886,9 +886,9 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
       for (int l = (int)ch.size() - 1; l >= 0; --l) {
         const LayerRun& R = ch[l];
         for (int t = T - 1; t >= 0; --t) {
-          BwdAJobs aj{}; aj.n = 1; fill_bwd_a(aj.j[0], R, t); aj.j[0].blk_base = 0;
+          BwdAJobs aj{}; aj.n = 1; fill_bwd_a(aj.j[0], R, t);
           run_bwd_a(aj, bwd_a_blocks(R.L->H, R.N), kb16(R.L->ldP), s);
-          BwdBJobs bj{}; bj.n = 1; fill_bwd_b(bj.j[0], R, t, false); bj.j[0].blk_base = 0;
+          BwdBJobs bj{}; bj.n = 1; fill_bwd_b(bj.j[0], R, t, false);
           if (bwd_b_splitk_ok(bj)) run_bwd_b_splitk(bj, s);
           else launch_bwd_b(bj, job_blocks(bj.j[0].nblk_c, R.N, kb16(4 * R.L->H) <= 64 ? 16 : 32), kb16(4 * R.L->H), s);
         }
@@ -924,10 +924,7 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
       if (bj.n) {
         if (bwd_b_splitk_ok(bj)) run_bwd_b_splitk(bj, s);
         else {
-          const int rows = bk <= 64 ? 16 : 32;        // small-K launches use 16-row tiles
-          int base = 0;
-          for (int i = 0; i < bj.n; ++i) { bj.j[i].blk_base = base; base += job_blocks(bj.j[i].nblk_c, bj.j[i].N, rows); }
-          launch_bwd_b(bj, base, bk, s);
+          launch_bwd_b(bj, bb, bk, s);                 // (small-K launches use 16-row tiles; the launcher places the jobs)
         }
       }
       bj.n = 0; bb = bk = 0;
@@ -939,7 +936,7 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
         const int t = T - 1 - (d - off - (Lc - 1 - l));
         if (t < 0 || t >= T) continue;
         if (aj.n == MAXJ) flush_a();
-        BwdAJob& a = aj.j[aj.n++]; fill_bwd_a(a, ch[l], t); a.blk_base = ab; ab += bwd_a_blocks(ch[l].L->H, ch[l].N);
+        BwdAJob& a = aj.j[aj.n++]; fill_bwd_a(a, ch[l], t); ab += bwd_a_blocks(ch[l].L->H, ch[l].N);
         ak = std::max(ak, kb16(ch[l].L->ldP));
       }
     }
@@ -952,7 +949,7 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
         if (t < 0 || t >= T) continue;
         const LayerRun& R = ch[l];
         if (bj.n == MAXJ) flush_b();
-        BwdBJob& b = bj.j[bj.n++]; fill_bwd_b(b, R, t, R.din != nullptr); b.blk_base = bb; bb += job_blocks(b.nblk_c, R.N);
+        BwdBJob& b = bj.j[bj.n++]; fill_bwd_b(b, R, t, R.din != nullptr); bb += job_blocks(b.nblk_c, R.N);
         bk = std::max(bk, kb16(4 * R.L->H));
       }
     }
@@ -961,7 +958,7 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
         const int t = T - 1 - (d - F.offset);
         if (t < 0 || t >= T) continue;
         if (bj.n == MAXJ) flush_b();
-        BwdBJob& b = bj.j[bj.n++]; fill_fc_bwd(b, F, t); b.blk_base = bb; bb += job_blocks(b.nblk_c, F.N);
+        BwdBJob& b = bj.j[bj.n++]; fill_fc_bwd(b, F, t); bb += job_blocks(b.nblk_c, F.N);
         bk = std::max(bk, kb16(F.ld_in));
       }
     flush_b();

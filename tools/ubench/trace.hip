@@ -32,7 +32,14 @@ static float* dal(size_t n, float v) {
   return p;
 }
 
-struct Cls { const char* name; int b0, b1; };
+static void clear_trace(hipStream_t s) {
+  void* p = nullptr;
+  CK(hipGetSymbolAddress(&p, HIP_SYMBOL(rsr::g_trace)));
+  CK(hipMemsetAsync(p, 0, sizeof(unsigned long long) * 8192 * 16, s));
+  CK(hipStreamSynchronize(s));
+}
+constexpr int TRACE_BLOCKS = 2048;      // the launchers size their own grids: read back this many trace records (unused ones are zero)
+struct Cls { const char* name; const void* id; };      // id = the job pointer the kernels stamp into trace slot 12
 
 static void report(const char* kernel, int blocks, const std::vector<Cls>& cls, const char* const* phase_names, const int* phase_idx, int nph, float us_graph) {
   std::vector<unsigned long long> t((size_t)blocks * 16);
@@ -90,9 +97,9 @@ static void report(const char* kernel, int blocks, const std::vector<Cls>& cls, 
     double start_min = 1e30, start_max = 0, end_max = 0, dur = 0;
     std::vector<double> ph(nph, 0.0);
     int n = 0;
-    for (int b = c.b0; b < c.b1; ++b) {
+    for (int b = 0; b < blocks; ++b) {
       const unsigned long long* r = &t[(size_t)b * 16];
-      if (r[9] == 0) continue;
+      if (r[9] == 0 || r[12] != (unsigned long long)(size_t)c.id) continue;
       ++n;
       const double st = (double)(r[0] - rt0) / 100.0, en = (double)(r[13] - rt0) / 100.0;
       start_min = std::min(start_min, st); start_max = std::max(start_max, st); end_max = std::max(end_max, en);
@@ -155,10 +162,8 @@ int main(int argc, char** argv) {
       a.wf = dal(h, 0.1f); a.wi = dal(h, 0.1f); a.wo = dal(h, 0.1f);
       a.c_prev = dal((size_t)n * h, 0.5f); a.c_out = dal((size_t)n * h, 0.f); a.gates = dal((size_t)n * 4 * h, 0.f);
       a.ldh = (h + 3) & ~3; a.h = dal((size_t)n * a.ldh, 0.f); a.len = len; a.t = 0; a.N = n; a.H = h; a.nblk_c = ncb;
-      a.blk_base = base;
-      const int nb = job_blocks(ncb, n, 32);
-      cls.push_back(Cls{name, base, base + nb});
-      base += nb;
+      cls.push_back(Cls{name, a.gates});
+      base += job_blocks(ncb, n, 32);
     };
     mk(N, H, P, P, false, "G layer 2 (K=560)"); mk(N, H, P, P, false, "G layer 1 (K=560)"); mk(N, H, P, P, true, "G layer 0 (K=280)");
     for (int i = 0; i < 4; ++i) mk(N, HD, PD, PD, false, "D job (K=80)");
@@ -166,10 +171,10 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 20; ++i) launch_fwd_gates(gj, base, kb, s);
     CK(hipStreamSynchronize(s));
     const float us = time_graph(s, 50, 4, [&] { launch_fwd_gates(gj, base, kb, s); });
-    launch_fwd_gates(gj, base, kb, s); CK(hipStreamSynchronize(s));
+    clear_trace(s); launch_fwd_gates(gj, base, kb, s); CK(hipStreamSynchronize(s));
     const char* names[] = {"lookup", "issueW", "issueDMA", "issueEpi", "loads+bar", "mfma", "bar", "zs+bar", "epilogue"};
     const int idx[] = {2, 10, 11, 3, 4, 5, 6, 7, 9};
-    report("k_fwd_gates (3 G layers + 4 D jobs)", base, cls, names, idx, 9, us);
+    report("k_fwd_gates (3 G layers + 4 D jobs)", TRACE_BLOCKS, cls, names, idx, 9, us);
   }
   // ------------------------------------------------------------------ forward gates: the folded discriminator alone (2 num_proj=None jobs, K = 296 / 512)
   {
@@ -187,20 +192,18 @@ int main(int argc, char** argv) {
       a.c_prev = dal((size_t)n * h, 0.5f); a.c_out = dal((size_t)n * h, 0.f); a.gates = dal((size_t)n * 4 * h, 0.f);
       a.ldh = ldm; a.h = dal((size_t)n * a.ldh, 0.f); a.len = len; a.t = 0; a.N = n; a.H = h; a.nblk_c = ncb;
       a.np_m_out = dal((size_t)n * ldm, 0.f);
-      a.blk_base = base;
-      const int nb = job_blocks(ncb, n, 32);
-      cls.push_back(Cls{name, base, base + nb});
-      base += nb;
+      cls.push_back(Cls{name, a.gates});
+      base += job_blocks(ncb, n, 32);
     };
     mk(N, HD, HD, "folded D layer 1 (K=512)"); mk(N, HD, PD, "folded D layer 0 (K=296)");
     const int kb = (HD + HD + 15) / 16;
     for (int i = 0; i < 20; ++i) launch_fwd_gates(gj, base, kb, s);
     CK(hipStreamSynchronize(s));
     const float us = time_graph(s, 50, 4, [&] { launch_fwd_gates(gj, base, kb, s); });
-    launch_fwd_gates(gj, base, kb, s); CK(hipStreamSynchronize(s));
+    clear_trace(s); launch_fwd_gates(gj, base, kb, s); CK(hipStreamSynchronize(s));
     const char* names[] = {"lookup", "issueW", "issueDMA", "issueEpi", "loads+bar", "mfma", "bar", "zs+bar", "epilogue"};
     const int idx[] = {2, 10, 11, 3, 4, 5, 6, 7, 9};
-    report("k_fwd_gates (folded discriminator alone)", base, cls, names, idx, 9, us);
+    report("k_fwd_gates (folded discriminator alone)", TRACE_BLOCKS, cls, names, idx, 9, us);
   }
   // ------------------------------------------------------------------ forward projection: 3 G layers + 4 D jobs + output FC
   {
@@ -213,10 +216,9 @@ int main(int argc, char** argv) {
       const int ldh = (h + 3) & ~3, ldp = (p + 3) & ~3;
       a.h = dal((size_t)n * ldh, 0.5f); a.WpT = dal((size_t)p * ldh, 0.05f); a.WpT_sw = tiles((p + 15) / 16, (ldh + 15) / 16);
       a.m_prev = dal((size_t)n * ldp, 0.1f); a.m_out = dal((size_t)n * ldp, 0.f); a.out = dal((size_t)n * ldp, 0.f);
-      a.len = len; a.ldh = ldh; a.ldm = ldp; a.ldo = ldp; a.P = p; a.t = 0; a.N = n; a.nblk_c = (p + 15) / 16; a.blk_base = base;
-      const int nb = job_blocks(a.nblk_c, n, 32);
-      cls.push_back(Cls{name, base, base + nb});
-      base += nb;
+      a.len = len; a.ldh = ldh; a.ldm = ldp; a.ldo = ldp; a.P = p; a.t = 0; a.N = n; a.nblk_c = (p + 15) / 16;
+      cls.push_back(Cls{name, a.h});
+      base += job_blocks(a.nblk_c, n, 32);
     };
     mk(N, H, P, "G layer (760->280)"); mk(N, H, P, "G layer (760->280)"); mk(N, H, P, "G layer (760->280)");
     for (int i = 0; i < 4; ++i) mk(N, HD, PD, "D job (256->40)");
@@ -224,10 +226,10 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 20; ++i) launch_fwd_proj(pj, base, kb, s);
     CK(hipStreamSynchronize(s));
     const float us = time_graph(s, 50, 4, [&] { launch_fwd_proj(pj, base, kb, s); });
-    launch_fwd_proj(pj, base, kb, s); CK(hipStreamSynchronize(s));
+    clear_trace(s); launch_fwd_proj(pj, base, kb, s); CK(hipStreamSynchronize(s));
     const char* names[] = {"lookup+setup", "loads+mfma", "zs+bar", "epilogue"};
     const int idx[] = {2, 5, 7, 9};
-    report("k_fwd_proj (3 G layers + 4 D jobs)", base, cls, names, idx, 4, us);
+    report("k_fwd_proj (3 G layers + 4 D jobs)", TRACE_BLOCKS, cls, names, idx, 4, us);
   }
   // ------------------------------------------------------------------ backward A: 3 G layers + 2 D jobs
   {
@@ -243,25 +245,24 @@ int main(int argc, char** argv) {
       a.dmt = dal((size_t)n * ldp, 0.f); a.gates = dal((size_t)n * 4 * h, 0.3f);
       a.c_prev = dal((size_t)n * h, 0.5f); a.c_cur = dal((size_t)n * h, 0.5f);
       a.wf = dal(h, 0.1f); a.wi = dal(h, 0.1f); a.wo = dal(h, 0.1f); a.dc = dal((size_t)n * h, 0.1f);
-      a.len = len; a.ldm = ldp; a.P = p; a.t = 0; a.N = n; a.H = h; a.nblk_c = (h + bwd_a_cells() - 1) / bwd_a_cells(); a.blk_base = base;
-      const int nb = job_blocks(a.nblk_c, n, 32);
-      cls.push_back(Cls{name, base, base + nb});
-      base += nb;
+      a.len = len; a.ldm = ldp; a.P = p; a.t = 0; a.N = n; a.H = h; a.nblk_c = (h + bwd_a_cells() - 1) / bwd_a_cells();
+      cls.push_back(Cls{name, a.gates});
+      base += job_blocks(a.nblk_c, n, 32);
     };
     mk(N, H, P, "G layer (280->760)"); mk(N, H, P, "G layer (280->760)"); mk(N, H, P, "G layer (280->760)");
     mk(N, HD, PD, "D job (40->256)"); mk(N, HD, PD, "D job (40->256)");
     for (int i = 0; i < 20; ++i) launch_bwd_a(aj, base, (P + 15) / 16, s);
     CK(hipStreamSynchronize(s));
     const float us = time_graph(s, 50, 4, [&] { launch_bwd_a(aj, base, (P + 15) / 16, s); });
-    launch_bwd_a(aj, base, (P + 15) / 16, s); CK(hipStreamSynchronize(s));
+    clear_trace(s); launch_bwd_a(aj, base, (P + 15) / 16, s); CK(hipStreamSynchronize(s));
     if (bwd_a_cells() == 32) {
       const char* names[] = {"lookup", "dm loads issued", "stage+issue W,epi", "bar", "mfma", "epilogue"};
       const int idx[] = {2, 10, 3, 4, 5, 9};
-      report("k_bwd_a2 (3 G layers + 2 D jobs)", base, cls, names, idx, 6, us);
+      report("k_bwd_a2 (3 G layers + 2 D jobs)", TRACE_BLOCKS, cls, names, idx, 6, us);
     } else {
       const char* names[] = {"lookup", "issueOps", "issueEpi", "loads land+mfma", "zs+bar", "epilogue"};
       const int idx[] = {2, 10, 3, 5, 7, 9};
-      report("k_bwd_a (3 G layers + 2 D jobs)", base, cls, names, idx, 6, us);
+      report("k_bwd_a (3 G layers + 2 D jobs)", TRACE_BLOCKS, cls, names, idx, 6, us);
     }
   }
   // ------------------------------------------------------------------ backward B split-K: 3 G layers (layer 0: recurrent rows only)
@@ -281,23 +282,24 @@ int main(int argc, char** argv) {
     mk(N, H, P, P, true); mk(N, H, P, P, true); mk(N, H, P, P, false);
     float* ws = dal((size_t)8 * 3 * N * 560 + 1024, 0.f);
     bwd_b_plan(bj, ws);
-    int bp = 0;
+    int bp = 8;
     for (int i = 0; i < bj.n; ++i) {
       const BwdBJob& b = bj.j[i];
-      cls.push_back(Cls{i < 2 ? "G layer (560 cols)" : "G layer 0 (280 cols)", b.blk_base_p, b.blk_base_p + b.KG * b.ncg * b.nrg});
-      bp = std::max(bp, b.blk_base_p + b.KG * b.ncg * b.nrg);
-      if (i == 0) printf("bwd_bp plan: KG %d kpg %d ncg %d nrg %d\n", b.KG, b.kpg, b.ncg, b.nrg);
+      cls.push_back(Cls{i < 2 ? "G layer (560 cols)" : "G layer 0 (280 cols)", b.dz});
+      bp = std::max(bp, 8 * b.plp.se);
+      printf("bwd_bp plan job %d: KG %d kpg %d ncg %d nrg %d  place x0 %d nx %d rounds %d..%d nb %d\n", i, b.KG, b.kpg, b.ncg, b.nrg, b.plp.x0, b.plp.nx, b.plp.sb, b.plp.se, b.plp.nb);
     }
     for (int i = 0; i < 20; ++i) launch_bwd_b_splitk(bj, s);
     CK(hipStreamSynchronize(s));
     const float us = time_graph(s, 50, 4, [&] { launch_bwd_b_splitk(bj, s); });
     launch_bwd_b_splitk(bj, s); CK(hipStreamSynchronize(s));
     // the trace buffer now holds the reduce launch's blocks on top: trace the split-K kernel alone
-    hipLaunchKernelGGL(k_bwd_bp, dim3(bp), dim3(512), (size_t)64 * bp_sa4(bj.j[0].kpg) * 16 + 8192, s, bj);
+    clear_trace(s);
+    hipLaunchKernelGGL(k_bwd_bp, dim3(bp), dim3(512), std::max((size_t)64 * bp_sa4(bj.j[0].kpg) * 16 + 8192, (size_t)84 * 1024), s, bj);
     CK(hipStreamSynchronize(s));
     const char* names[] = {"lookup+issue", "loads+bar", "mfma", "bar", "zs+partials"};
     const int idx[] = {3, 4, 5, 6, 9};
-    report("k_bwd_bp (+k_bwd_b_red in the timed pair)", bp, cls, names, idx, 5, us);
+    report("k_bwd_bp (+k_bwd_b_red in the timed pair)", TRACE_BLOCKS, cls, names, idx, 5, us);
   }
   for (void* p : g_bufs) (void)hipFree(p);
   return 0;
