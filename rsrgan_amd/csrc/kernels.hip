@@ -1082,7 +1082,7 @@ size_t bwd_b_plan(BwdBJobs& jobs, float* ws_base) {
   const int gp = plan_rounds(n, nb, w1, nx, x0, grouped, pp);
   int nx8[MAXJ], x00[MAXJ];
   for (int i = 0; i < n; ++i) { nx8[i] = 8; x00[i] = 0; }
-  const int gr = plan_rounds(n, nbr, w1, nx8, x00, nogroup, pr);       // the reduce: elementwise, contiguous
+  const int gr = plan_rounds(n, nbr, w1, nx8, x00, nogroup, pr);       // the reduce: elementwise, contiguous (grouping it by layer: 8.67 vs 8.59 ms/step)
   fill_map(jobs.map, n, gp, [&](int q) -> const Place& { return jobs.j[q].plp; });
   fill_map(jobs.mapr, n, gr, [&](int q) -> const Place& { return jobs.j[q].plr; });
   return off;
