@@ -963,7 +963,7 @@ __global__ __launch_bounds__(256) void k_bwd_b_red(const BwdBJobs jobs) {
 static int g_xcd_groups = -1;          // RSRGAN_XCD_GROUPS=0: every job spans all 8 XCD slots (round 1's contiguous layout)
 // phase 1: XCD slots per job.  A job worth >= 12 % of the launch's work gets a group of slots of its own, sized by its share
 // (largest remainders, at least one, 8 in all); the others ("fillers") span all 8 slots after the groups' rounds.
-static void plan_groups(int n, const double* cost, int* nx, int* x0, bool* grouped) {
+static void plan_groups(int n, const double* cost, int* nx, int* x0, bool* grouped, double balance_tol = 1.35) {
   if (g_xcd_groups < 0) { const char* e = getenv("RSRGAN_XCD_GROUPS"); g_xcd_groups = e ? atoi(e) : 1; }
   double total = 0.0;
   for (int j = 0; j < n; ++j) total += cost[j];
@@ -994,6 +994,13 @@ static void plan_groups(int n, const double* cost, int* nx, int* x0, bool* group
     for (int j = 0; j < n; ++j) if (grouped[j] && nx[j] > 1 && (best < 0 || frac[j] < frac[best])) best = j;
     if (best < 0) break;
     nx[best]--; frac[best] += 1.0; --sum;
+  }
+  // a group must not carry more than its share: the busiest XCD's work within balance_tol of an even spread, else no groups
+  double worst = 0.0;
+  for (int j = 0; j < n; ++j) if (grouped[j]) worst = std::max(worst, cost[j] / nx[j]);
+  if (worst > balance_tol * cg / 8.0) {
+    for (int j = 0; j < n; ++j) { grouped[j] = false; nx[j] = 8; x0[j] = 0; }
+    return;
   }
   int x = 0;
   for (int j = 0; j < n; ++j) if (grouped[j]) { x0[j] = x; x += nx[j]; }
@@ -1054,10 +1061,10 @@ size_t bwd_b_plan(BwdBJobs& jobs, float* ws_base) {
   double cost[MAXJ]; int nx[MAXJ], x0[MAXJ], nb[MAXJ], w1[MAXJ], nbr[MAXJ]; bool grouped[MAXJ], nogroup[MAXJ]; Place* pp[MAXJ]; Place* pr[MAXJ];
   for (int i = 0; i < n; ++i) cost[i] = (double)(jobs.j[i].n_end - jobs.j[i].n_begin) * jobs.j[i].N * jobs.j[i].H4;
   plan_groups(n, cost, nx, x0, grouped);
-  // measured in the step (not in isolation, tools/ubench/trace.hip): with XCD groups this kernel is 23 us instead of 14 -- the K
-  // slice <-> XCD affinity of the contiguous layout (slice = block id % 8) is what it needs; RSRGAN_BP_GROUPS=1 to try again
+  // a group's workgroups must fit ONE round at one per CU (32 CUs per XCD): three equal layers split 3 / 3 / 2 put 36 on the
+  // 2-XCD group's CUs and the launch took 23 us instead of 14 -- then no groups (slice = block id % 8 keeps its K-slice affinity)
   static int bp_groups = -1;
-  if (bp_groups < 0) { const char* e = getenv("RSRGAN_BP_GROUPS"); bp_groups = e ? atoi(e) : 0; }
+  if (bp_groups < 0) { const char* e = getenv("RSRGAN_BP_GROUPS"); bp_groups = e ? atoi(e) : 1; }
   if (!bp_groups) for (int i = 0; i < n; ++i) { grouped[i] = false; nx[i] = 8; x0[i] = 0; }
   static int kpg_target = -1;        // k-blocks per K slice: 24 -> 99 KB LDS (1 WG/CU)
   if (kpg_target < 0) { const char* e = getenv("RSRGAN_BP_KPG"); kpg_target = e ? atoi(e) : 24; if (kpg_target < 2 || kpg_target > 2 * BP_CHB) kpg_target = 24; }
@@ -1078,6 +1085,25 @@ size_t bwd_b_plan(BwdBJobs& jobs, float* ws_base) {
     off += (size_t)b.KG * b.N * b.ldw;
     nb[i] = b.KG * b.ncg * b.nrg; w1[i] = 1; pp[i] = &b.plp;
     nbr[i] = (b.N * ncols + 255) / 256; nogroup[i] = false; pr[i] = &b.plr;
+  }
+  {
+    bool over = false;
+    for (int i = 0; i < n; ++i) over = over || (grouped[i] && (nb[i] + nx[i] - 1) / nx[i] > 32);
+    if (over) {                    // re-plan without groups (KG depends on nx: recompute)
+      for (int i = 0; i < n; ++i) { grouped[i] = false; nx[i] = 8; x0[i] = 0; }
+      off = 0;
+      for (int i = 0; i < n; ++i) {
+        BwdBJob& b = jobs.j[i];
+        const int nkb = (b.H4 + 15) >> 4;
+        int KG = std::max((nkb + kpg_target - 1) / kpg_target, std::min(8, nkb / 8));
+        KG = std::min(16, std::max(1, KG));
+        b.kpg = (nkb + KG - 1) / KG;
+        b.KG = (nkb + b.kpg - 1) / b.kpg;
+        b.ws = ws_base ? ws_base + off : nullptr;
+        off += (size_t)b.KG * b.N * b.ldw;
+        nb[i] = b.KG * b.ncg * b.nrg;
+      }
+    }
   }
   const int gp = plan_rounds(n, nb, w1, nx, x0, grouped, pp);
   int nx8[MAXJ], x00[MAXJ];
