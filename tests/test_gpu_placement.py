@@ -1,0 +1,60 @@
+"""Placement of the jobs of a launch (rsrgan_amd/csrc/kernels.h Place: XCD groups, folded discriminator forward) changes which
+workgroup computes which tile and, for the fold, the association of one product -- never the arithmetic of a tile.  The step must
+be bit-identical with and without XCD groups, and agree to fp32 rounding with and without the fold."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import hashlib, json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import rsrgan_oracle as O
+from tests.helpers import NET_D, NET_G, build_hip_pair, rand_batch
+cfg = O.NetCfg()                      # the reference's sizes: G 3x760/p280, D 2x256/p40
+B, T = 8, 7
+model, _ = build_hip_pair(cfg, B, T, seed=5, flags=3)
+x, lab, ln = rand_batch(cfg, B, T, seed=6, ragged=True)
+out = {}
+for it in range(2):
+    d = np.ravel(model.d_step(x, lab, ln)); g = np.ravel(model.g_step(x, lab, ln, reuse_g_forward=True))
+    out["d%%d" %% it] = [float(v) for v in d]; out["g%%d" %% it] = [float(v) for v in g]
+gv, dv = model.get_vars()
+h = hashlib.sha256()
+for k in sorted(gv): h.update(np.ascontiguousarray(gv[k]).tobytes())
+for k in sorted(dv): h.update(np.ascontiguousarray(dv[k]).tobytes())
+out["vars_sha"] = h.hexdigest()
+out["g_norm"] = float(sum(float(np.square(v.astype(np.float64)).sum()) for v in gv.values()))
+print("RESULT " + json.dumps(out))
+""" % ROOT
+
+
+def _run(env):
+    e = dict(os.environ); e.update(env)
+    p = subprocess.run([sys.executable, "-c", WORKER], capture_output=True, text=True, env=e, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return json.loads(line[7:])
+
+
+def test_xcd_groups_do_not_change_a_bit():
+    a = _run({"RSRGAN_XCD_GROUPS": "1"})
+    b = _run({"RSRGAN_XCD_GROUPS": "0"})
+    assert a == b, (a, b)
+
+
+def test_folded_discriminator_forward_agrees():
+    a = _run({"RSRGAN_DFOLD": "1"})
+    b = _run({"RSRGAN_DFOLD": "0"})
+    for k in ("d0", "g0", "d1", "g1"):
+        assert np.allclose(a[k], b[k], rtol=2e-5, atol=1e-7), (k, a[k], b[k])
+    assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
