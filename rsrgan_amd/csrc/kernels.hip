@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512 * RH, (RH == 1 && RTG == 2 && CHB <= 18) ? 4 : 
   }
   TR(11);
   // (3) epilogue operands of this thread's EPT (row, cell) elements, in flight together with (1) and (2)
-  constexpr int EPT = RTG / 2;
+  constexpr int EPT = (RTG + 1) / 2;                           // (RTG = 1: 16-row blocks, the upper half of the threads has no element)
   const int er = (tid >> 4) & 15, ec = tid & 15, ecell = c0 + ec;
   float zb[EPT][4], cp[EPT], pwi = 0.f, pwf = 0.f, pwo = 0.f;
   int elen[EPT];
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512 * RH, (RH == 1 && RTG == 2 && CHB <= 18) ? 4 : 
 #pragma unroll
     for (int u = 0; u < EPT; ++u) {
       const int erow = r0 + ((tid >> 8) + 2 * RH * u) * 16 + er;
-      evalid[u] = erow < N && ecell < H;
+      evalid[u] = (tid >> 8) + 2 * RH * u < RTG * RH && erow < N && ecell < H;
       const int erc = min(erow, N - 1);
 #pragma unroll
       for (int g = 0; g < 4; ++g) zb[u][g] = zsrc[(size_t)erc * zrow + g * H + ecl];
@@ -1140,6 +1140,21 @@ int fwd_gates_rows() { return g_gates_rows; }
 void set_fwd_gates_rows(int r) { g_gates_rows = (r == 64) ? 64 : 32; }
 void launch_fwd_gates(const FwdGateJobs& jobs_in, int total_blocks, int kb_max, hipStream_t s) {
   FwdGateJobs jobs = jobs_in;
+  // a launch that would fill less than half of the chip with 32-row blocks (the discriminator alone) runs 16-row blocks: twice
+  // the workgroups, half the MFMA chain each (its time is the latency of one block, not bytes)
+  int blocks32 = 0;
+  for (int i = 0; i < jobs.n; ++i) blocks32 += jobs.j[i].nblk_c * ((jobs.j[i].N + 31) / 32);
+  const bool small = g_gates_rows == 32 && blocks32 <= 128 && kb_max <= 36;
+  if (small) {
+    total_blocks = place_tiles(jobs, 16, [](const FwdGateJob& j) { return (double)((j.x ? j.ldx : 0) + j.ldm); });
+    size_t lds = (size_t)16 * gates_sa4(kb_max * 16) * 16;
+    lds = (lds + 8191) / 8192 * 8192;
+    lds = std::max(lds, (size_t)8 * 16 * 17 * sizeof(float));
+    static bool attr1 = false;
+    if (!attr1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_gates<18, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+    hipLaunchKernelGGL((k_fwd_gates<18, 1>), dim3(total_blocks), dim3(512), lds, s, jobs);
+    return;
+  }
   total_blocks = place_tiles(jobs, g_gates_rows, [](const FwdGateJob& j) { return (double)((j.x ? j.ldx : 0) + j.ldm); });
   // dynamic LDS: the widest job's A tile (rows x SA floats) rounded to the 8 KB DMA granule of the
   // 8 waves, and at least the reduction buffer
