@@ -278,9 +278,9 @@ __global__ __launch_bounds__(512 * RH, (RH == 1 && RTG == 2 && CHB <= 18) ? 4 : 
     for (int p0 = w * 64; p0 < P4; p0 += STEP) {
       const int arow = min(r0 + row, N - 1);
       const bool inx = c4 < ldx4, inm = c4 < kt4;
-      const float* sx = J.x + (size_t)arow * ldx + c4 * 4;
-      const float* sm = J.m + (size_t)arow * ldm + (c4 - ldx4) * 4;
-      const float* src = inx ? sx : (inm ? sm : J.m);           // (pad slots and rows >= N: any finite word)
+      // (32-bit element offsets and selects: the pointer-valued ?: compiled to a divergent branch per DMA round)
+      const int ox = arow * ldx + c4 * 4, om = inm ? arow * ldm + (c4 - ldx4) * 4 : 0;
+      const float* src = (inx ? J.x : J.m) + (inx ? ox : om);   // (pad slots and rows >= N: any finite word)
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + (size_t)p0 * 4), 16, 0, 0);
       c4 += dr; row += dq;
       const bool wrap = c4 >= SA4;
