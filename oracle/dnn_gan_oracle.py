@@ -5,6 +5,10 @@ generator models/dnn.py:DNN and discriminator models/discriminator_dnn.py.
 *** PARITY UNPINNED w.r.t. the reference (TensorFlow 1.4 / Python 2 cannot run here; no fixtures
 *** exist for this path); pinned by torch-autograd and finite differences (tests/test_oracle_dnn.py).
 
+`DnnCfg.batch_norm=True` (run_gan_dnn.sh:134, run_dnn.sh:134): every hidden fully_connected becomes
+relu(batch_norm(x.W)) without a bias (contrib fully_connected drops `biases` when a normalizer_fn is given); the
+normaliser and the order of its state updates are restated in oracle/bn_renorm.py.
+
 Restated graph (batch_norm=False, keep_prob=1.0):
   G (dnn.py:79-110)              : 1+3 = 4 x [FC 1024, ReLU], FC -> output_dim (linear)
   d_inputs (gan.py:158-160)      : inputs[:, input_dim*left_context : +input_dim]   (centre frame)
@@ -22,6 +26,8 @@ from typing import Dict, List, Tuple
 
 import numpy as np
 
+from . import bn_renorm as bn
+
 
 @dataclass
 class DnnCfg:
@@ -35,6 +41,7 @@ class DnnCfg:
     d_hidden: int = 4             # discriminator_dnn.py:23-24
     clip_lo: float = -0.5         # discriminator_dnn.py:93
     clip_hi: float = 1.5
+    batch_norm: bool = False      # normalizer_fn=batch_norm(scale=True, renorm=True) on the hidden layers (dnn.py:56-61)
 
     @property
     def fed_dim(self):
@@ -49,29 +56,36 @@ def _fc_names(prefix, n):
     return [prefix + "/fully_connected" + ("" if i == 0 else "_%d" % i) for i in range(n)]
 
 
-def g_param_specs(cfg: DnnCfg) -> List[Tuple[str, Tuple[int, ...]]]:
-    dims = [cfg.fed_dim] + [cfg.g_units] * cfg.g_hidden + [cfg.output_dim]
+def _fc_specs(prefix, dims, batch_norm):
     s = []
-    for i, n in enumerate(_fc_names("g_model", cfg.g_hidden + 1)):
-        s += [(n + "/weights", (dims[i], dims[i + 1])), (n + "/biases", (dims[i + 1],))]
+    names = _fc_names(prefix, len(dims) - 1)
+    for i, n in enumerate(names):
+        s.append((n + "/weights", (dims[i], dims[i + 1])))
+        if batch_norm and i < len(names) - 1:
+            s += bn.var_specs(n, dims[i + 1])
+        else:
+            s.append((n + "/biases", (dims[i + 1],)))
     return s
+
+
+def g_param_specs(cfg: DnnCfg) -> List[Tuple[str, Tuple[int, ...]]]:
+    return _fc_specs("g_model", [cfg.fed_dim] + [cfg.g_units] * cfg.g_hidden + [cfg.output_dim], cfg.batch_norm)
 
 
 def d_param_specs(cfg: DnnCfg) -> List[Tuple[str, Tuple[int, ...]]]:
-    dims = [cfg.joint_dim] + [cfg.d_units] * cfg.d_hidden + [1]
-    s = []
-    for i, n in enumerate(_fc_names("d_model", cfg.d_hidden + 1)):
-        s += [(n + "/weights", (dims[i], dims[i + 1])), (n + "/biases", (dims[i + 1],))]
-    return s
+    return _fc_specs("d_model", [cfg.joint_dim] + [cfg.d_units] * cfg.d_hidden + [1], cfg.batch_norm)
 
 
 def init_params(specs, rng, dtype=np.float64, relu_init=False):
     """G: xavier_initializer() (dnn.py:85,95,106); D hidden: truncated normal std sqrt(2/units)
-    (discriminator_dnn.py:25-26), D output xavier; biases zero."""
+    (discriminator_dnn.py:25-26), D output xavier; biases zero; BatchNorm variables as normalization.py builds them."""
     out = {}
-    last = specs[-2][0]
+    last = [n for n, _ in specs if n.endswith("/weights")][-1]
     for name, shape in specs:
-        if name.endswith("biases"):
+        if "/BatchNorm/" in name:
+            one = name.endswith("gamma") or name.endswith("moving_variance")
+            out[name] = (np.ones if one else np.zeros)(shape, dtype)
+        elif name.endswith("biases"):
             out[name] = np.zeros(shape, dtype)
         elif relu_init and name != last:
             std = math.sqrt(2.0 / shape[1])
@@ -82,13 +96,32 @@ def init_params(specs, rng, dtype=np.float64, relu_init=False):
     return out
 
 
-def fc_stack_fwd(P, prefix, n_layers, x):
-    """n_layers FC layers, ReLU on all but the last.  Returns (y, acts) with acts[l] = input of layer l."""
-    acts = [x]
+def trainable(name):
+    return not bn.is_state(name)
+
+
+def fc_stack_fwd(P, prefix, n_layers, x, training=True):
+    """n_layers FC layers, ReLU on all but the last.  Returns (y, acts) with acts[l] = input of layer l; a hidden layer with
+    `<name>/BatchNorm/*` variables is relu(batch_norm(x.W)) and acts carries its cache in acts.bn[l]."""
+    acts = _Acts([x])
     for i, n in enumerate(_fc_names(prefix, n_layers)):
-        z = acts[-1] @ P[n + "/weights"] + P[n + "/biases"]
+        if n + "/BatchNorm/beta" in P:
+            z = acts[-1] @ P[n + "/weights"]
+            if training:
+                z, cache = bn.forward_train(P, n, z)
+                acts.bn[i] = cache
+            else:
+                z = bn.forward_infer(P, n, z)
+        else:
+            z = acts[-1] @ P[n + "/weights"] + P[n + "/biases"]
         acts.append(np.maximum(z, 0.0) if i < n_layers - 1 else z)
     return acts[-1], acts
+
+
+class _Acts(list):
+    def __init__(self, it):
+        super().__init__(it)
+        self.bn = {}
 
 
 def fc_stack_bwd(P, prefix, n_layers, acts, dy, want_dx=True):
@@ -98,15 +131,27 @@ def fc_stack_bwd(P, prefix, n_layers, acts, dy, want_dx=True):
     for i in range(n_layers - 1, -1, -1):
         if i < n_layers - 1:
             d = d * (acts[i + 1] > 0)
+        cache = getattr(acts, "bn", {}).get(i)
+        if cache is not None:
+            d, gb = bn.backward_train(P, cache, d)
+            grads.update(gb)
+        elif names[i] + "/biases" in P:
+            grads[names[i] + "/biases"] = d.sum(0)
         grads[names[i] + "/weights"] = acts[i].T @ d
-        grads[names[i] + "/biases"] = d.sum(0)
         if i > 0 or want_dx:
             d = d @ P[names[i] + "/weights"].T
     return (d if want_dx else None), grads
 
 
-def d_forward(cfg, Pd, joint):
-    raw, acts = fc_stack_fwd(Pd, "d_model", cfg.d_hidden + 1, joint)
+def bn_commit(P, acts, times=1):
+    """The batch-norm UPDATE_OPS of one forward call, `times` times (the graph holds that many identical calls)."""
+    for _ in range(times):
+        for i in sorted(getattr(acts, "bn", {})):
+            bn.commit(P, acts.bn[i])
+
+
+def d_forward(cfg, Pd, joint, training=True):
+    raw, acts = fc_stack_fwd(Pd, "d_model", cfg.d_hidden + 1, joint, training)
     return np.clip(raw, cfg.clip_lo, cfg.clip_hi), raw, acts
 
 
@@ -134,30 +179,52 @@ class GanDnnOracle:
         c = self.cfg
         return x[:, c.input_dim * c.left_context: c.input_dim * (c.left_context + 1)]     # gan.py:158-160
 
+    @property
+    def training(self):
+        """is_training of the batch-norm layers: False on the cross_validation twin (dnn.py:49-50, discriminator_dnn.py:29)."""
+        return not self.cross_validation
+
     # generator hooks (overridden by oracle/rced_oracle.py for the R-CED generator)
     def _g_fwd(self, x):
-        return fc_stack_fwd(self.g, "g_model", self.cfg.g_hidden + 1, x)
+        return fc_stack_fwd(self.g, "g_model", self.cfg.g_hidden + 1, x, self.training)
 
     def _g_bwd(self, cache, dy):
         return fc_stack_bwd(self.g, "g_model", self.cfg.g_hidden + 1, cache, dy, want_dx=False)[1]
 
+    def _g_commit(self, cache, times):
+        bn_commit(self.g, cache, times)
+
     def forward(self, x):
         return self._g_fwd(np.asarray(x, self.dtype))[0]
+
+    def _commit_run(self, gacts, d_real_acts, d_fake_acts):
+        """Every batch-norm update op of the graph runs in every training `sess.run` (gan.py:139-146); tower 0 holds two
+        generator calls, a dummy + a real discriminator call on the real joint and one on the fake joint (gan.py:162-181)."""
+        if not self.training:
+            return
+        self._g_commit(gacts, 2)
+        if d_real_acts is not None:
+            bn_commit(self.d, d_real_acts, 2)
+        if d_fake_acts is not None:
+            bn_commit(self.d, d_fake_acts, 1)
 
     def d_tower(self, x, lab, want_grads=True):
         cfg = self.cfg
         x, lab = np.asarray(x, self.dtype), np.asarray(lab, self.dtype)
-        y = self.forward(x)
+        y, gacts = self._g_fwd(x)
         di = self._d_inputs(x)
-        losses, grads = [], None
+        losses, grads, dacts = [], None, []
         for joint, target in ((np.concatenate([di, lab], 1), 1.0), (np.concatenate([di, y], 1), 0.0)):
-            out, raw, acts = d_forward(cfg, self.d, joint)
+            out, raw, acts = d_forward(cfg, self.d, joint, self.training)
+            dacts.append(acts)
             diff = out - target
             losses.append(float(np.mean(diff * diff)))
             if want_grads:
                 draw = 2.0 * diff / diff.size * clip_grad_mask(cfg, raw)
                 _, g = fc_stack_bwd(self.d, "d_model", cfg.d_hidden + 1, acts, draw, want_dx=False)
                 grads = g if grads is None else {k: grads[k] + g[k] for k in g}
+        if want_grads:
+            self._commit_run(gacts, dacts[0], dacts[1])
         return (losses[0], losses[1], losses[0] + losses[1]), grads
 
     def g_tower(self, x, lab, want_grads=True):
@@ -165,12 +232,15 @@ class GanDnnOracle:
         x, lab = np.asarray(x, self.dtype), np.asarray(lab, self.dtype)
         y, gacts = self._g_fwd(x)
         supervised = getattr(self, "supervised", False)          # models/dnn_trainer.py:139-148: g_loss = g_mse + g_l2
+        d_real_acts = dacts = None
         if supervised:
             g_adv = 0.0
         else:
-            out, raw, dacts = d_forward(cfg, self.d, np.concatenate([self._d_inputs(x), y], 1))
+            out, raw, dacts = d_forward(cfg, self.d, np.concatenate([self._d_inputs(x), y], 1), self.training)
             diff = out - 1.0
             g_adv = float(np.mean(diff * diff))
+            if want_grads and self.training and cfg.batch_norm:      # the real-joint call only contributes its update ops here
+                d_real_acts = d_forward(cfg, self.d, np.concatenate([self._d_inputs(x), lab], 1), True)[2]
         e = y - lab
         g_mse = float(0.5 * np.mean(e * e) * cfg.output_dim)
         if (not self.cross_validation) and self.l2_scale > 0:
@@ -190,6 +260,7 @@ class GanDnnOracle:
                 for k in grads:
                     if k.endswith("weights"):
                         grads[k] = grads[k] + self.l2_scale * self.g[k]
+            self._commit_run(gacts, d_real_acts, dacts)
         return (g_adv, g_mse, g_l2, g_loss), grads, y
 
     def _adam(self, which, params, grads, lr):
@@ -198,6 +269,8 @@ class GanDnnOracle:
         t = st["t"]
         lr_t = lr * math.sqrt(1 - self.beta2 ** t) / (1 - self.beta1 ** t)
         for k in params:
+            if not trainable(k):                 # batch-norm statistics: not in tf.trainable_variables()
+                continue
             st["m"][k] = self.beta1 * st["m"][k] + (1 - self.beta1) * grads[k]
             st["v"][k] = self.beta2 * st["v"][k] + (1 - self.beta2) * grads[k] * grads[k]
             params[k] = params[k] - lr_t * st["m"][k] / (np.sqrt(st["v"][k]) + self.eps)
