@@ -111,8 +111,13 @@ enum {
   RSRGAN_FLAG_NO_SPLITK_B = 8, /* backward phase B as one launch of 32x16 tiles (round-1 first form) instead of split-K + reduce */
   RSRGAN_FLAG_SUPERVISED = 16, /* generator-only trainer (models/rnn_trainer.py:66-156, models/dnn_trainer.py:64-148):
                                   g_loss = mse_lambda*g_mse + g_l2, no discriminator pass; rsrgan_d_step is an error */
-  RSRGAN_FLAG_OVERLAP = 4      /* weight-gradient GEMMs on a side stream, chunked over time, concurrent with the backward
+  RSRGAN_FLAG_OVERLAP = 4,     /* weight-gradient GEMMs on a side stream, chunked over time, concurrent with the backward
                                   wave (measured SLOWER on MI355X: 12.77 vs 12.20 ms/step; off by default) */
+  RSRGAN_FLAG_BATCH_NORM = 32  /* args.batch_norm (run_gan_dnn.sh:134, run_dnn.sh:134): the hidden fully_connected layers of the
+                                  frame-level generator (models/dnn.py:56-61) and of discriminator_dnn (:36-41) are
+                                  relu(batch_norm(x.W, is_training = !cross_validation, scale=True, renorm=True)) without biases;
+                                  the variable table gains <scope>/BatchNorm/{beta,gamma,moving_mean,moving_variance,renorm_mean,
+                                  renorm_mean_weight,renorm_stddev,renorm_stddev_weight}.  Frame-level nets only. */
 };
 
 typedef struct rsrgan_handle_s* rsrgan_handle;

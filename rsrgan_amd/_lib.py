@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librsrgan_hip.so")
 
 G_TYPES = {"lstm": 0, "res_lstm_l": 1, "res_lstm_base": 2, "dnn": 3, "rced": 4}
+FLAG_BATCH_NORM = 32          # include/rsrgan.h RSRGAN_FLAG_BATCH_NORM
 D_TYPES = {"lstm": 0, "dnn": 1}
 NET_G, NET_D = 0, 1
 SCALARS = {"g_learning_rate": 0, "d_learning_rate": 1, "mse_lambda": 2, "d_real": 3, "d_fake": 4,

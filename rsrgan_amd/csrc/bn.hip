@@ -1,0 +1,228 @@
+// bn.hip -- tf.contrib.layers.batch_norm(is_training, scale=True, renorm=True) as the frame-level generators and
+// discriminator_dnn use it (models/dnn.py:56-61, models/discriminator_dnn.py:36-41, models/rced.py:67-72): TF 1.4's
+// layers/normalization.py BatchNormalization with renorm, restated (see oracle/bn_renorm.py for the algorithm and the order of
+// the update ops).  All of it is HBM-bound column statistics + elementwise work over [rows][cols] fp32 activations:
+//   forward   k_bn_stats1 (row-slice partial sums, shifted by the first row) -> k_bn_stats2 (moments in double, the renorm
+//             corrections r, d from the state, the affine y = z*a + b) -> k_bn_apply (y = relu(z*a + b))
+//   backward  k_bn_bwd1 (partials of sum dy', sum dy'.xhat with dy' = dy.[y > 0]) -> k_bn_bwd2 (dbeta, dgamma, per-column
+//             constants) -> k_bn_bwd3 (dz in place)
+//   state     k_bn_commit (the UPDATE_OPS of one call, `times` times)
+// Every reduction has a fixed order (slices, then a serial sum), so results do not depend on the launch geometry.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace rsr {
+
+constexpr float BN_EPS = 1e-3f;            // contrib.layers.batch_norm epsilon
+constexpr double BN_DECAY = 0.999;         // decay
+constexpr double BN_RENORM_DECAY = 0.99;   // renorm_decay
+
+// partial sums of one row slice: scratch[slice][2][cols] = sum (z - z0), sum (z - z0)^2 with z0 = the call's first row
+__global__ __launch_bounds__(256) void k_bn_stats1(const float* __restrict__ z, int ld, int rows, int cols, int per,
+                                                   float* __restrict__ scratch) {
+  __shared__ float red[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int rbeg = blockIdx.y * per, rend = min(rows, rbeg + per);
+  float s1 = 0.f, s2 = 0.f;
+  if (c < cols) {
+    const float z0 = z[c];
+#pragma unroll 4
+    for (int r = rbeg + rl; r < rend; r += 4) {
+      const float v = z[(size_t)r * ld + c] - z0;
+      s1 += v; s2 += v * v;
+    }
+  }
+  red[0][rl][threadIdx.x & 63] = s1; red[1][rl][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (rl < 2 && c < cols) {
+    const int l = threadIdx.x & 63;
+    scratch[((size_t)blockIdx.y * 2 + rl) * cols + c] = ((red[rl][0][l] + red[rl][1][l]) + red[rl][2][l]) + red[rl][3][l];
+  }
+}
+
+// moments, corrections and the affine of one call.  stat rows: 0 mean, 1 stddev, 2 r, 3 d, 4 a, 5 b  (y = z*a + b)
+__global__ __launch_bounds__(256) void k_bn_stats2(const float* __restrict__ scratch, int slices, const float* __restrict__ z, int rows,
+                                                   int cols, BnVars v, float* __restrict__ stat, int ldc) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < slices; ++i) { s1 += scratch[((size_t)i * 2) * cols + c]; s2 += scratch[((size_t)i * 2 + 1) * cols + c]; }
+  const double m0 = s1 / rows;
+  const double var = fmax(s2 / rows - m0 * m0, 0.0);
+  const double mean = (double)z[c] + m0;
+  const double sd = sqrt(var + (double)BN_EPS);
+  const double mixed_mean = (double)v.rm[c] + (1.0 - (double)v.rmw[0]) * mean;
+  const double mixed_sd = (double)v.rs[c] + (1.0 - (double)v.rsw[0]) * sd;
+  const double r = sd / mixed_sd, d = (mean - mixed_mean) / mixed_sd;
+  const double g = v.gamma[c];
+  const double a = r * g / sd;
+  stat[c] = (float)mean; stat[ldc + c] = (float)sd; stat[2 * ldc + c] = (float)r; stat[3 * ldc + c] = (float)d;
+  stat[4 * ldc + c] = (float)a; stat[5 * ldc + c] = (float)(d * g + (double)v.beta[c] - mean * a);
+}
+
+// is_training=False: y = (z - moving_mean) / sqrt(moving_variance + eps) * gamma + beta
+__global__ __launch_bounds__(256) void k_bn_infer_coef(int cols, BnVars v, float* __restrict__ stat, int ldc) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const double a = (double)v.gamma[c] / sqrt((double)v.mv[c] + (double)BN_EPS);
+  stat[4 * ldc + c] = (float)a; stat[5 * ldc + c] = (float)((double)v.beta[c] - (double)v.mm[c] * a);
+}
+
+__global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ z, int ld, float* __restrict__ y, int ldy, size_t rows, int cols,
+                                                  const float* __restrict__ a, const float* __restrict__ b, int relu) {
+  const int c4 = cols >> 2;                       // cols is padded to a multiple of 4 by the caller's leading dimensions
+  const size_t n = rows * (size_t)c4;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / c4;
+    const int c = (int)(i - r * c4) * 4;
+    const float4 zv = *reinterpret_cast<const float4*>(z + r * ld + c);
+    const float4 av = *reinterpret_cast<const float4*>(a + c), bv = *reinterpret_cast<const float4*>(b + c);
+    float4 o = make_float4(zv.x * av.x + bv.x, zv.y * av.y + bv.y, zv.z * av.z + bv.z, zv.w * av.w + bv.w);
+    if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+    *reinterpret_cast<float4*>(y + r * ldy + c) = o;
+  }
+}
+
+// backward partials: scratch[slice][2][cols] = sum dy', sum dy'.xhat ; dy' = dy where y > 0 (the ReLU that follows), else 0
+__global__ __launch_bounds__(256) void k_bn_bwd1(const float* __restrict__ dy, int ldd, const float* __restrict__ y, int ldy,
+                                                 const float* __restrict__ z, int ldz, const float* __restrict__ stat, int ldc, int rows,
+                                                 int cols, int per, int relu, float* __restrict__ scratch) {
+  __shared__ float red[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int rbeg = blockIdx.y * per, rend = min(rows, rbeg + per);
+  float s1 = 0.f, s2 = 0.f;
+  if (c < cols) {
+    const float mean = stat[c], isd = 1.f / stat[ldc + c];
+#pragma unroll 4
+    for (int r = rbeg + rl; r < rend; r += 4) {
+      float g = dy[(size_t)r * ldd + c];
+      if (relu && !(y[(size_t)r * ldy + c] > 0.f)) g = 0.f;
+      s1 += g; s2 += g * ((z[(size_t)r * ldz + c] - mean) * isd);
+    }
+  }
+  red[0][rl][threadIdx.x & 63] = s1; red[1][rl][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (rl < 2 && c < cols) {
+    const int l = threadIdx.x & 63;
+    scratch[((size_t)blockIdx.y * 2 + rl) * cols + c] = ((red[rl][0][l] + red[rl][1][l]) + red[rl][2][l]) + red[rl][3][l];
+  }
+}
+
+// sums -> dbeta, dgamma (assigned or accumulated) and the per-column constants of dz: sums[0] = s1/n, sums[1] = s2/n
+__global__ __launch_bounds__(256) void k_bn_bwd2(const float* __restrict__ scratch, int slices, int rows, int cols,
+                                                 const float* __restrict__ stat, int ldc, float* __restrict__ dbeta,
+                                                 float* __restrict__ dgamma, int accumulate, float* __restrict__ sums) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < slices; ++i) { s1 += scratch[((size_t)i * 2) * cols + c]; s2 += scratch[((size_t)i * 2 + 1) * cols + c]; }
+  if (dbeta) {
+    const double gb = s1, gg = (double)stat[2 * ldc + c] * s2 + (double)stat[3 * ldc + c] * s1;
+    dbeta[c] = (float)(accumulate ? (double)dbeta[c] + gb : gb);
+    dgamma[c] = (float)(accumulate ? (double)dgamma[c] + gg : gg);
+  }
+  sums[c] = (float)(s1 / rows); sums[ldc + c] = (float)(s2 / rows);
+}
+
+// dz = gamma*r/stddev * (dy' - s1/n - xhat*s2/n), in place over dy.  stat[4] = a = gamma*r/stddev.
+__global__ __launch_bounds__(256) void k_bn_bwd3(float* __restrict__ dy, int ldd, const float* __restrict__ y, int ldy,
+                                                 const float* __restrict__ z, int ldz, const float* __restrict__ stat, int ldc,
+                                                 const float* __restrict__ sums, size_t rows, int cols, int relu) {
+  const int c4 = cols >> 2;
+  const size_t n = rows * (size_t)c4;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / c4;
+    const int c = (int)(i - r * c4) * 4;
+    float4 g = *reinterpret_cast<const float4*>(dy + r * ldd + c);
+    if (relu) {
+      const float4 yv = *reinterpret_cast<const float4*>(y + r * ldy + c);
+      g = make_float4(yv.x > 0.f ? g.x : 0.f, yv.y > 0.f ? g.y : 0.f, yv.z > 0.f ? g.z : 0.f, yv.w > 0.f ? g.w : 0.f);
+    }
+    const float4 zv = *reinterpret_cast<const float4*>(z + r * ldz + c);
+    const float4 mean = *reinterpret_cast<const float4*>(stat + c), sd = *reinterpret_cast<const float4*>(stat + ldc + c);
+    const float4 a = *reinterpret_cast<const float4*>(stat + 4 * ldc + c);
+    const float4 m1 = *reinterpret_cast<const float4*>(sums + c), m2 = *reinterpret_cast<const float4*>(sums + ldc + c);
+    // (padding columns carry stddev = 0 and a = 0: they must come out as 0, not NaN)
+    const float4 isd = make_float4(sd.x > 0.f ? 1.f / sd.x : 0.f, sd.y > 0.f ? 1.f / sd.y : 0.f, sd.z > 0.f ? 1.f / sd.z : 0.f,
+                                   sd.w > 0.f ? 1.f / sd.w : 0.f);
+    float4 o;
+    o.x = a.x * (g.x - m1.x - (zv.x - mean.x) * isd.x * m2.x);
+    o.y = a.y * (g.y - m1.y - (zv.y - mean.y) * isd.y * m2.y);
+    o.z = a.z * (g.z - m1.z - (zv.z - mean.z) * isd.z * m2.z);
+    o.w = a.w * (g.w - m1.w - (zv.w - mean.w) * isd.w * m2.w);
+    *reinterpret_cast<float4*>(dy + r * ldd + c) = o;
+  }
+}
+
+// UPDATE_OPS of one call, `times` times: assign_moving_average(v, value, decay, zero_debias=False) is v -= (v - value)*(1 - decay).
+// One workgroup per layer: every thread reads the two scalar weights before thread 0 rewrites them.
+__global__ __launch_bounds__(256) void k_bn_commit(int cols, BnVars v, const float* __restrict__ stat, int ldc, int times) {
+  const double w_mean0 = v.rmw[0], w_sd0 = v.rsw[0];
+  __syncthreads();
+  for (int c = threadIdx.x; c < cols; c += 256) {
+    const double mean = stat[c], sd = stat[ldc + c];
+    double rm = v.rm[c], rs = v.rs[c], mm = v.mm[c], mv = v.mv[c], wm = w_mean0, ws = w_sd0;
+    for (int t = 0; t < times; ++t) {
+      rm -= (rm - mean) * (1.0 - BN_RENORM_DECAY); wm -= (wm - 1.0) * (1.0 - BN_RENORM_DECAY);
+      rs -= (rs - sd) * (1.0 - BN_RENORM_DECAY); ws -= (ws - 1.0) * (1.0 - BN_RENORM_DECAY);
+      const double new_mean = rm / wm, new_sd = rs / ws;
+      mm -= (mm - new_mean) * (1.0 - BN_DECAY);
+      mv -= (mv - (new_sd * new_sd - (double)BN_EPS)) * (1.0 - BN_DECAY);
+    }
+    v.rm[c] = (float)rm; v.rs[c] = (float)rs; v.mm[c] = (float)mm; v.mv[c] = (float)mv;
+  }
+  if (threadIdx.x == 0) {
+    double wm = w_mean0, ws = w_sd0;
+    for (int t = 0; t < times; ++t) { wm -= (wm - 1.0) * (1.0 - BN_RENORM_DECAY); ws -= (ws - 1.0) * (1.0 - BN_RENORM_DECAY); }
+    v.rmw[0] = (float)wm; v.rsw[0] = (float)ws;
+  }
+}
+
+static int bn_slices(int rows, int cols, size_t scratch_floats, int* per) {
+  int slices = (int)std::min<size_t>(512, scratch_floats / ((size_t)2 * std::max(cols, 1)));
+  slices = std::max(1, std::min(slices, (rows + 63) / 64));
+  *per = (rows + slices - 1) / slices;
+  return (rows + *per - 1) / *per;
+}
+
+void launch_bn_forward(const float* z, int ldz, float* y, int ldy, int rows, int cols, const BnVars& v, float* stat, int ldc, bool training,
+                       bool relu, float* scratch, size_t scratch_floats, hipStream_t s) {
+  if (training) {
+    int per;
+    const int slices = bn_slices(rows, cols, scratch_floats, &per);
+    hipLaunchKernelGGL(k_bn_stats1, dim3((cols + 63) / 64, slices), dim3(256), 0, s, z, ldz, rows, cols, per, scratch);
+    hipLaunchKernelGGL(k_bn_stats2, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, slices, z, rows, cols, v, stat, ldc);
+  } else {
+    hipLaunchKernelGGL(k_bn_infer_coef, dim3((cols + 255) / 256), dim3(256), 0, s, cols, v, stat, ldc);
+  }
+  const int cp = (cols + 3) & ~3;
+  const size_t n = (size_t)rows * (cp >> 2);
+  const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_bn_apply, dim3(grid), dim3(256), 0, s, z, ldz, y, ldy, (size_t)rows, cp, stat + 4 * ldc, stat + 5 * ldc, relu ? 1 : 0);
+}
+
+// dy: gradient w.r.t. y (the layer's output AFTER its ReLU when relu) -> overwritten by the gradient w.r.t. z.
+// dbeta / dgamma may be null (data gradient only).  sums: 2*ldc floats of work space.
+void launch_bn_backward(float* dy, int ldd, const float* y, int ldy, const float* z, int ldz, int rows, int cols, const float* stat, int ldc,
+                        float* dbeta, float* dgamma, bool accumulate, bool relu, float* sums, float* scratch, size_t scratch_floats,
+                        hipStream_t s) {
+  int per;
+  const int slices = bn_slices(rows, cols, scratch_floats, &per);
+  hipLaunchKernelGGL(k_bn_bwd1, dim3((cols + 63) / 64, slices), dim3(256), 0, s, dy, ldd, y, ldy, z, ldz, stat, ldc, rows, cols, per,
+                     relu ? 1 : 0, scratch);
+  hipLaunchKernelGGL(k_bn_bwd2, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, slices, rows, cols, stat, ldc, dbeta, dgamma,
+                     accumulate ? 1 : 0, sums);
+  const int cp = (cols + 3) & ~3;
+  const size_t n = (size_t)rows * (cp >> 2);
+  const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_bn_bwd3, dim3(grid), dim3(256), 0, s, dy, ldd, y, ldy, z, ldz, stat, ldc, sums, (size_t)rows, cp, relu ? 1 : 0);
+}
+
+void launch_bn_commit(int cols, const BnVars& v, const float* stat, int ldc, int times, hipStream_t s) {
+  hipLaunchKernelGGL(k_bn_commit, dim3(1), dim3(256), 0, s, cols, v, stat, ldc, times);
+}
+
+}  // namespace rsr

@@ -18,25 +18,62 @@ namespace rsr {
 
 static const float kDClipLo = -0.5f, kDClipHi = 1.5f;     // discriminator_dnn.py:93 tf.clip_by_value(y, -0.5, 1.5)
 
-void Model::fc_forward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, hipStream_t s) {
-  for (size_t l = 0; l < L.size(); ++l)
-    gemm(act[l], L[l].ld_in, true, ps.W(L[l].tW), L[l].ld_out, false, act[l + 1], L[l].ld_out, rows, L[l].out, L[l].in,
-         ps.W(L[l].tb), l + 1 < L.size() ? 2 : 0, 0.f, false, s);
+BnVars Model::bn_vars(const ParamSet& ps, const FcLayer& F) const {
+  BnVars v;
+  v.beta = ps.W(F.tbn[0]); v.gamma = ps.W(F.tbn[1]); v.mm = ps.W(F.tbn[2]); v.mv = ps.W(F.tbn[3]);
+  v.rm = ps.W(F.tbn[4]); v.rmw = ps.W(F.tbn[5]); v.rs = ps.W(F.tbn[6]); v.rsw = ps.W(F.tbn[7]);
+  return v;
+}
+
+void Model::fc_forward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, hipStream_t s, int calls) {
+  for (size_t l = 0; l < L.size(); ++l) {
+    const FcLayer& F = L[l];
+    if (!F.bn) {
+      gemm(act[l], F.ld_in, true, ps.W(F.tW), F.ld_out, false, act[l + 1], F.ld_out, rows, F.out, F.in,
+           ps.W(F.tb), l + 1 < L.size() ? 2 : 0, 0.f, false, s);
+      continue;
+    }
+    // relu(batch_norm(x.W)): the product once over all rows, the normaliser once per call (each call has its own batch moments)
+    gemm(act[l], F.ld_in, true, ps.W(F.tW), F.ld_out, false, F.pre, F.ld_out, rows, F.out, F.in, nullptr, 0, 0.f, false, s);
+    const int per = rows / calls;
+    const BnVars v = bn_vars(ps, F);
+    for (int k = 0; k < calls; ++k)
+      launch_bn_forward(F.pre + (size_t)k * per * F.ld_out, F.ld_out, act[l + 1] + (size_t)k * per * F.ld_out, F.ld_out, per, F.out, v,
+                        F.stat + (size_t)k * BN_STAT_ROWS * F.ld_out, F.ld_out, bn_training(), true, scratch, scratch_floats, s);
+  }
+}
+
+// the UPDATE_OPS of call `call` of every batch-norm layer of the stack, `times` times (oracle/bn_renorm.py: order of the updates)
+void Model::bn_commit_stack(const ParamSet& ps, const std::vector<FcLayer>& L, int call, int times, hipStream_t s) {
+  for (const FcLayer& F : L)
+    if (F.bn) launch_bn_commit(F.out, bn_vars(ps, F), F.stat + (size_t)call * BN_STAT_ROWS * F.ld_out, F.ld_out, times, s);
 }
 
 // dtop: gradient w.r.t. the stack's (linear) output, [rows][ld_out of the last layer].  Returns the gradient w.r.t.
 // the stack's input (in fc_dA or fc_dB, leading dimension = ld_in of layer 0) when want_din, else nullptr.
+// With batch norm the rows are `calls` calls of rows/calls rows (statistics slots call0 ..), starting at row0 of act[] / pre.
 float* Model::fc_backward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, float* dtop,
-                          bool want_wgrads, bool want_din, hipStream_t s) {
+                          bool want_wgrads, bool want_din, hipStream_t s, int calls, int row0, int call0) {
   float* d = dtop;
   float* bufs[2] = {fc_dA, fc_dB};
   int nb = 0;
   for (int l = (int)L.size() - 1; l >= 0; --l) {
     const FcLayer& F = L[l];
-    if (l + 1 < (int)L.size()) launch_lrelu_bwd(act[l + 1], d, (size_t)rows, F.out, F.ld_out, 0.f, s);   // relu': d *= [h > 0]
+    const float* a_in = act[l] + (size_t)row0 * F.ld_in;
+    if (F.bn) {                            // d (w.r.t. the ReLU's output) -> gradient w.r.t. x.W, per call; dbeta / dgamma summed over the calls
+      const int per = rows / calls;
+      for (int k = 0; k < calls; ++k) {
+        const size_t ro = (size_t)k * per * F.ld_out, ra = ((size_t)row0 + (size_t)k * per) * F.ld_out;
+        launch_bn_backward(d + ro, F.ld_out, act[l + 1] + ra, F.ld_out, F.pre + ra, F.ld_out, per, F.out,
+                           F.stat + (size_t)(call0 + k) * BN_STAT_ROWS * F.ld_out, F.ld_out, want_wgrads ? ps.Gd(F.tbn[0]) : nullptr,
+                           want_wgrads ? ps.Gd(F.tbn[1]) : nullptr, k > 0, true, bn_sums, scratch, scratch_floats, s);
+      }
+    } else if (l + 1 < (int)L.size()) {
+      launch_lrelu_bwd(act[l + 1] + (size_t)row0 * F.ld_out, d, (size_t)rows, F.out, F.ld_out, 0.f, s);   // relu': d *= [h > 0]
+    }
     if (want_wgrads) {
-      gemm(act[l], F.ld_in, false, d, F.ld_out, false, ps.Gd(F.tW), F.ld_out, F.in, F.out, rows, nullptr, 0, 0.f, false, s);
-      launch_colsum(d, F.ld_out, nullptr, 0, ps.Gd(F.tb), rows, F.out, scratch, s);
+      gemm(a_in, F.ld_in, false, d, F.ld_out, false, ps.Gd(F.tW), F.ld_out, F.in, F.out, rows, nullptr, 0, 0.f, false, s);
+      if (!F.bn) launch_colsum(d, F.ld_out, nullptr, 0, ps.Gd(F.tb), rows, F.out, scratch, s);
     }
     if (l > 0 || want_din) {
       float* dn = bufs[nb]; nb ^= 1;
@@ -114,8 +151,15 @@ void Model::g_frame_backward(int rows, float* dy, hipStream_t s) {
 }
 
 // D(.) on d_act[0] ([T][Nd] rows), clipped LSGAN losses, dlogits
-void Model::d_dnn_forward_loss(int T, int Nd, int n_real, bool want_grads, float* loss3, hipStream_t s) {
-  fc_forward(D, dfc, d_act, T * Nd, s);
+// every training sess.run executes all batch-norm update ops of the graph (gan.py:139-146): the generator's call twice, the
+// discriminator's real-joint call twice (dummy + real, gan.py:162-181) and its fake-joint call once -- oracle/bn_renorm.py
+void Model::bn_commit_run(bool with_d, hipStream_t s) {
+  bn_commit_stack(G, gfc, 0, 2, s);
+  if (with_d) { bn_commit_stack(D, dfc, 0, 2, s); bn_commit_stack(D, dfc, 1, 1, s); }
+}
+
+void Model::d_dnn_forward_loss(int T, int Nd, int n_real, bool want_grads, float* loss3, hipStream_t s, int calls) {
+  fc_forward(D, dfc, d_act, T * Nd, s, calls);
   launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, Nd, n_real, dyn + DYN_D_REAL,
                n_real > 0 ? dyn + DYN_D_FAKE : dyn + DYN_D_REAL, loss3, s, true, kDClipLo, kDClipHi);
 }
@@ -133,9 +177,10 @@ int Model::dnn_d_backward(const float* x, const float* labels, int T, float* out
   // d_rl_joint = concat(d_inputs, labels) ; d_fk_joint = concat(d_inputs, g)   gan.py:173-174
   launch_build_joint(x_tm, ldDin, cfg.d_joint_off, cfg.d_joint_dim, lab_tm, ldDout, Dout, joint, ldJ, 0, R, s);
   launch_build_joint(x_tm, ldDin, cfg.d_joint_off, cfg.d_joint_dim, y_tm, ldDout, Dout, joint, ldJ, R, R, s);
-  d_dnn_forward_loss(1, 2 * R, R, want_grads, losses, s);
+  d_dnn_forward_loss(1, 2 * R, R, want_grads, losses, s, 2);
   if (want_grads) {
-    fc_backward(D, dfc, d_act, 2 * R, dlogits, true, false, s);
+    fc_backward(D, dfc, d_act, 2 * R, dlogits, true, false, s, 2);
+    if (bn_training()) bn_commit_run(true, s);
     { finish_buckets(RSRGAN_NET_D, s); d_grads_ready = true; }
   }
   if (out_losses) launch_copy_f(losses, out_losses, 3, s);
@@ -145,6 +190,7 @@ int Model::dnn_d_backward(const float* x, const float* labels, int T, float* out
 
 int Model::dnn_g_backward(const float* x, const float* labels, int T, float* out_losses, bool want_grads, bool reuse, hipStream_t s) {
   const int R = T * B;
+  if (bn_on() && !g_rced()) reuse = false;       // the D-run's update ops changed the generator's renorm state: its forward differs now
   if (reuse) {
     if (!g_fwd_valid || T != cur_T) { set_error("reuse_g_forward without a valid generator forward"); return RSRGAN_ERR_STATE; }
   } else {
@@ -159,6 +205,13 @@ int Model::dnn_g_backward(const float* x, const float* labels, int T, float* out
   const bool sup = supervised();           // DNNTrainer (models/dnn_trainer.py:139-148): g_loss = g_mse + g_l2, no discriminator
   if (sup) {
     HIPC(hipMemsetAsync(losses + 3, 0, sizeof(float), s));
+  } else if (bn_training() && want_grads) {
+    // with batch norm the real-joint call runs too (only its update ops matter here): rows [0, R) real, [R, 2R) fake as in the D-run
+    launch_build_joint(x_tm, ldDin, cfg.d_joint_off, cfg.d_joint_dim, lab_tm, ldDout, Dout, joint, ldJ, 0, R, s);
+    launch_build_joint(x_tm, ldDin, cfg.d_joint_off, cfg.d_joint_dim, y_tm, ldDout, Dout, joint, ldJ, R, R, s);
+    fc_forward(D, dfc, d_act, 2 * R, s, 2);
+    launch_lsgan(logits + (size_t)R * 4, 4, dlogits + (size_t)R * 4, 1, R, 0, dyn + DYN_D_REAL, dyn + DYN_D_REAL, tmp3, s, true, kDClipLo, kDClipHi);
+    launch_copy_f(tmp3 + 1, losses + 3, 1, s);
   } else {
     launch_build_joint(x_tm, ldDin, cfg.d_joint_off, cfg.d_joint_dim, y_tm, ldDout, Dout, joint, ldJ, 0, R, s);
     d_dnn_forward_loss(1, R, 0, want_grads, tmp3, s);      // g_adv = mean((D(fake) - 1)^2)  gan.py:202
@@ -167,7 +220,8 @@ int Model::dnn_g_backward(const float* x, const float* labels, int T, float* out
   const bool l2_on = !cfg.cross_validation && scal[RSRGAN_L2_SCALE] > 0.0;
   if (want_grads) {
     if (!sup) {
-      float* dj = fc_backward(D, dfc, d_act, R, dlogits, false, true, s);                 // d g_adv / d joint
+      float* dj = bn_training() ? fc_backward(D, dfc, d_act, R, dlogits + (size_t)R * 4, false, true, s, 1, R, 1)   // the fake half
+                                : fc_backward(D, dfc, d_act, R, dlogits, false, true, s);                           // d g_adv / d joint
       launch_slice_cols(dj, ldJ, cfg.d_joint_dim, dy_buf, ldDout, R, Dout, s);            // ... / d g
     }
     launch_mse(y_tm, lab_tm, ldDout, dy_buf, R, Dout, dyn + DYN_LAMBDA, !sup, losses + 4, scratch, s);
@@ -176,6 +230,7 @@ int Model::dnn_g_backward(const float* x, const float* labels, int T, float* out
       launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
       launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);
     }
+    if (bn_training()) bn_commit_run(!sup, s);
     { finish_buckets(RSRGAN_NET_G, s); g_grads_ready = true; }
   } else {
     launch_mse(y_tm, lab_tm, ldDout, nullptr, R, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s);

@@ -214,6 +214,19 @@ void launch_lstm_colsums(const float* dz, const float* cprev, const float* ccur,
 void launch_lrelu_bwd(const float* hval, float* d, size_t rows, int cols, int ld, float alpha, hipStream_t s); // d *= (h>0?1:alpha)
 // col sums over `rows` rows: out[c] = sum_r a[r*lda+c] * (b ? b[r*ldb+c] : 1)
 void launch_colsum_tall(const float* a, int lda, float* out, int rows, int cols, float* scratch, size_t scratch_floats, hipStream_t s);
+
+// ---- batch_norm(renorm=True, scale=True) of the frame-level nets (bn.hip) ----
+struct BnVars {           // one layer's <scope>/BatchNorm/* variables (device pointers into the ParamSet)
+  float *beta, *gamma;                                  // [C] trainable
+  float *mm, *mv, *rm, *rmw, *rs, *rsw;                  // moving_mean, moving_variance, renorm_mean, renorm_mean_weight [1], renorm_stddev, renorm_stddev_weight [1]
+};
+constexpr int BN_STAT_ROWS = 6;                          // per call: mean, stddev, r, d, a, b   (y = z*a + b), each [ldc]
+void launch_bn_forward(const float* z, int ldz, float* y, int ldy, int rows, int cols, const BnVars& v, float* stat, int ldc, bool training,
+                       bool relu, float* scratch, size_t scratch_floats, hipStream_t s);
+void launch_bn_backward(float* dy, int ldd, const float* y, int ldy, const float* z, int ldz, int rows, int cols, const float* stat, int ldc,
+                        float* dbeta, float* dgamma, bool accumulate, bool relu, float* sums, float* scratch, size_t scratch_floats,
+                        hipStream_t s);
+void launch_bn_commit(int cols, const BnVars& v, const float* stat, int ldc, int times, hipStream_t s);
 void launch_colsum(const float* a, int lda, const float* b, int ldb, float* out, int rows, int cols,
                    float* scratch /* >= 64*cols floats */, hipStream_t s);
 

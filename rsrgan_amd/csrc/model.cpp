@@ -174,11 +174,29 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   if (d_dnn() && (c.d_joint_dim < 0 || c.d_joint_off < 0 || c.d_joint_off + c.d_joint_dim > Din)) { set_error("bad d_joint slice"); return RSRGAN_ERR_INVALID; }
   const int P = gR, H = c.g_cells;
   auto fc_name = [](const char* net, int i) { return std::string(net) + "/fully_connected" + (i == 0 ? "" : "_" + std::to_string(i)); };
-  auto add_fc = [&](ParamSet& ps, std::vector<FcLayer>& out, const std::string& nm, int in, int o) {
+  auto add_fc = [&](ParamSet& ps, std::vector<FcLayer>& out, const std::string& nm, int in, int o, bool bn = false) {
     FcLayer F; F.in = in; F.out = o; F.ld_in = pad4(in); F.ld_out = pad4(o);
-    F.tW = ps.add(nm + "/weights", in, o, false); F.tb = ps.add(nm + "/biases", 1, o, true);
+    F.tW = ps.add(nm + "/weights", in, o, false);
+    if (bn) {              // contrib fully_connected creates no biases under a normalizer_fn; variables in normalization.py's build order
+      static const char* kBn[8] = {"beta", "gamma", "moving_mean", "moving_variance", "renorm_mean", "renorm_mean_weight", "renorm_stddev",
+                                   "renorm_stddev_weight"};
+      F.bn = true; F.tb = -1;
+      for (int k = 0; k < 8; ++k) {
+        const bool scalar = k == 5 || k == 7;
+        F.tbn[k] = ps.add(nm + "/BatchNorm/" + kBn[k], 1, scalar ? 1 : o, true);
+        ps.t[F.tbn[k]].l2 = false;                                     // constant-initialised, never regularised
+        ps.t[F.tbn[k]].bias_init = (k == 1 || k == 3) ? 1.f : 0.f;     // gamma = 1, moving_variance = 1
+        ps.t[F.tbn[k]].trainable = k < 2;
+      }
+    } else {
+      F.tb = ps.add(nm + "/biases", 1, o, true);
+    }
     out.push_back(F);
   };
+  if (bn_on() && (!g_dnn() || c.g_type == RSRGAN_G_RCED)) {
+    set_error("RSRGAN_FLAG_BATCH_NORM is built for the frame-level dnn generator + discriminator_dnn only");
+    return RSRGAN_ERR_INVALID;
+  }
   // ---- variable tables in graph-construction order (gan_rnn_placeholder.py:301-317) ----
   if (c.g_type == RSRGAN_G_RCED) {                                       // models/rced.py:90-116
     static const int kNum[9] = {12, 16, 20, 24, 32, 24, 20, 16, 12}, kWidth[9] = {13, 11, 9, 7, 7, 7, 9, 11, 13};
@@ -204,7 +222,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     G.t[rc_fc.tb].bias_init = 0.1f;
   } else if (c.g_type == RSRGAN_G_DNN) {                                 // models/dnn.py:79-110: (1+3) x [FC units, ReLU], FC -> Dout
     int in = Din;
-    for (int l = 0; l < c.g_layers; ++l) { add_fc(G, gfc, fc_name("g_model", l), in, c.g_cells); in = c.g_cells; }
+    for (int l = 0; l < c.g_layers; ++l) { add_fc(G, gfc, fc_name("g_model", l), in, c.g_cells, bn_on()); in = c.g_cells; }
     add_fc(G, gfc, fc_name("g_model", c.g_layers), in, Dout);
   } else if (c.g_type == RSRGAN_G_LSTM) {                                // models/lstm.py:82-124
     g_fc_in_w = G.add("g_model/fully_connected/weights", Din, P, false);
@@ -231,7 +249,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   }
   if (d_dnn()) {                                                         // models/discriminator_dnn.py:61-92
     int in = c.d_joint_dim + Dout;
-    for (int l = 0; l < c.d_layers; ++l) { add_fc(D, dfc, fc_name("d_model", l), in, c.d_cells); in = c.d_cells; }
+    for (int l = 0; l < c.d_layers; ++l) { add_fc(D, dfc, fc_name("d_model", l), in, c.d_cells, bn_on()); in = c.d_cells; }
     add_fc(D, dfc, fc_name("d_model", c.d_layers), in, 1);
   } else {                                                               // models/discriminator_lstm.py:70-104
     int in = Dout;
@@ -353,6 +371,11 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     for (auto& F : gfc) mx = std::max(mx, std::max(F.ld_in, F.ld_out));
     for (auto& F : dfc) mx = std::max(mx, std::max(F.ld_in, F.ld_out));
     fc_dA = alloc<float>(TB2 * mx); fc_dB = alloc<float>(TB2 * mx);
+    if (bn_on()) {
+      bn_sums = alloc<float>((size_t)2 * mx);
+      for (auto& F : gfc) if (F.bn) { F.pre = alloc<float>(TB * F.ld_out); F.stat = alloc<float>((size_t)2 * BN_STAT_ROWS * F.ld_out); }
+      for (auto& F : dfc) if (F.bn) { F.pre = alloc<float>(TB2 * F.ld_out); F.stat = alloc<float>((size_t)2 * BN_STAT_ROWS * F.ld_out); }
+    }
   }
   adam_t_dev_d = alloc<int>(1);
   d_st.resize(dl.size());

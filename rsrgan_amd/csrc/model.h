@@ -21,6 +21,7 @@ struct TensorDesc {
   int64_t off;              // float offset in the padded flat buffer (multiple of 64)
   int64_t dense_off;        // float offset in the dense (TF-shaped) flat vector
   bool l2;                  // takes the L2 term: "bias" not in name (gan_rnn_placeholder.py:254)
+  bool trainable = true;    // false: batch-norm statistics (not in tf.trainable_variables(): their gradient stays zero)
   bool is_vector;
   int xavier_fan_out = 0;   // > 0: fan_out of the xavier limit (conv: receptive field x Cout) instead of cols
   float bias_init = 0.f;    // constant initial value of a bias vector
@@ -52,7 +53,14 @@ struct ConvLayer {               // tf.contrib.layers.conv2d([S, fw], SAME) of m
   int fw, Cin, Cout, K, ldK, ldCin, ldCout, tW, tb;
 };
 
-struct FcLayer { int in, out, ld_in, ld_out, tW, tb; };   // contrib.layers.fully_connected: weights [in][out], biases [out]
+struct FcLayer {                 // contrib.layers.fully_connected: weights [in][out], biases [out]
+  int in, out, ld_in, ld_out, tW, tb;
+  // normalizer_fn=batch_norm(scale=True, renorm=True) (dnn.py:56-61): no biases (tb = -1), <scope>/BatchNorm/* instead
+  bool bn = false;
+  int tbn[8] = {-1, -1, -1, -1, -1, -1, -1, -1};   // beta gamma moving_mean moving_variance renorm_mean renorm_mean_weight renorm_stddev renorm_stddev_weight
+  float* pre = nullptr;          // [rows][ld_out] x.W before the normaliser (kept for the backward pass)
+  float* stat = nullptr;         // [2 calls][BN_STAT_ROWS][ld_out]: the real | fake discriminator calls keep their own moments
+};
 
 struct LstmStash {               // everything one dynamic_rnn keeps for BPTT, time-major
   float *gates = nullptr;        // [T][N][4H]   zx -> gate activations -> dz (in place)
@@ -162,10 +170,18 @@ struct Model {
   void rced_backward(int rows, float* dy, hipStream_t s);
   bool d_dnn() const { return cfg.d_type == RSRGAN_D_DNN; }
   bool d_adam() const { return g_dnn(); }     // models/gan.py:125 (Adam) vs gan_rnn_placeholder.py:144 (SGD)
-  void fc_forward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, hipStream_t s);
+  // `calls` = how many batch-norm calls the `rows` rows are (1, or 2 = the discriminator's real | fake halves, each with its own
+  // batch moments); row0 = first row of act[] / pre to work on (the fake half alone in the G-run's backward pass)
+  void fc_forward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, hipStream_t s, int calls = 1);
   float* fc_backward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, float* dtop,
-                     bool want_wgrads, bool want_din, hipStream_t s);
-  void d_dnn_forward_loss(int T, int Nd, int n_real, bool want_grads, float* loss3, hipStream_t s);
+                     bool want_wgrads, bool want_din, hipStream_t s, int calls = 1, int row0 = 0, int call0 = 0);
+  bool bn_on() const { return (cfg.flags & RSRGAN_FLAG_BATCH_NORM) != 0; }
+  bool bn_training() const { return bn_on() && !cfg.cross_validation; }      // is_training (dnn.py:49-50)
+  BnVars bn_vars(const ParamSet& ps, const FcLayer& F) const;
+  void bn_commit_stack(const ParamSet& ps, const std::vector<FcLayer>& L, int call, int times, hipStream_t s);
+  float* bn_sums = nullptr;      // [2][max ld_out] work space of launch_bn_backward
+  void d_dnn_forward_loss(int T, int Nd, int n_real, bool want_grads, float* loss3, hipStream_t s, int calls = 1);
+  void bn_commit_run(bool with_d, hipStream_t s);
   int dnn_d_backward(const float* x, const float* labels, int T, float* out_losses, bool want_grads, hipStream_t s);
   int dnn_g_backward(const float* x, const float* labels, int T, float* out_losses, bool want_grads, bool reuse, hipStream_t s);
 

@@ -36,7 +36,7 @@ class HipEngine:
                  g_proj: Optional[int] = None, d_layers: Optional[int] = None, d_cells: Optional[int] = None,
                  d_proj: Optional[int] = None, d_type: Optional[str] = None, d_joint_off: Optional[int] = None,
                  d_joint_dim: Optional[int] = None, clip_norm: Optional[float] = None, g_splice: Optional[int] = None,
-                 l2_scale: float = 0.0, cross_validation: bool = False,
+                 l2_scale: float = 0.0, cross_validation: bool = False, batch_norm: bool = False,
                  ema_decay: float = 0.9999, seed: int = 4321, device: Optional[torch.device] = None, flags: int = 3):
         if g_type not in _lib.G_TYPES:
             raise ValueError("Unrecognized G type {}".format(g_type))      # gan_rnn_placeholder.py:131-132
@@ -71,7 +71,7 @@ class HipEngine:
         cfg.l2_scale = l2_scale
         cfg.cross_validation = 1 if cross_validation else 0
         cfg.ema_decay = ema_decay
-        cfg.flags = flags
+        cfg.flags = flags | (_lib.FLAG_BATCH_NORM if batch_norm else 0)
         self.cfg = cfg
         self.batch_size, self.max_frames = batch_size, max_frames
         self.input_dim, self.output_dim = input_dim, output_dim

@@ -25,9 +25,11 @@ class GAN(Model):
         self.sess, self.cross_validation = sess, cross_validation
         self.MOVING_AVERAGE_DECAY = 0.9999
         self.keep_prob = 1.0 if cross_validation else getattr(args, "keep_prob", 1.0)
-        self.batch_norm = getattr(args, "batch_norm", False)
-        if self.batch_norm or self.keep_prob < 1.0:
-            raise NotImplementedError("batch_norm / dropout variants are not built (DESIGN.md section 7)")
+        self.batch_norm = bool(getattr(args, "batch_norm", False))
+        if self.keep_prob < 1.0:
+            raise NotImplementedError("dropout variants are not built (DESIGN.md section 7)")
+        if self.batch_norm and args.g_type != "dnn":
+            raise NotImplementedError("batch_norm is built for the dnn generator + discriminator_dnn (DESIGN.md section 6f)")
         self.batch_size, self.devices = args.batch_size, devices
         self.num_gpu = getattr(args, "num_gpu", 1)
         self.save_dir = getattr(args, "save_dir", None)
@@ -49,7 +51,7 @@ class GAN(Model):
                                     g_type=args.g_type, d_type="dnn", d_joint_off=self.input_dim * self.left_context,
                                     g_splice=self.left_context + 1 + self.right_context,
                                     d_joint_dim=self.input_dim, l2_scale=self.l2_scale, cross_validation=cross_validation,
-                                    seed=seed, **(net_overrides or {}))
+                                    batch_norm=self.batch_norm, seed=seed, **(net_overrides or {}))
         self.ema_enabled = getattr(self.engine, "ema_enabled", True)
         self._scalars = {}
         self.mse_lambda = getattr(args, "init_mse_weight", 10.0)
@@ -115,6 +117,8 @@ class GAN(Model):
             fw = self._RCED_WIDTHS[int(idx[1:]) if idx else 0]
             S = self.left_context + 1 + self.right_context
             return (S, fw, shape[0] // (S * fw), shape[1])
+        if name.endswith("_weight") and "/BatchNorm/renorm_" in name:      # renorm_mean_weight / renorm_stddev_weight: shape ()
+            return ()
         return tuple(shape)
 
     def get_vars(self):

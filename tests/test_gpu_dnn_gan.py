@@ -118,3 +118,113 @@ def test_sequence_model_with_discriminator_dnn(flags):
     _, dv = m.get_vars()
     for k in o.d:
         assert rel_err(dv[k], o.d[k]) < 1e-4, k
+
+
+def _bn_pair(cfg, N, seed, cross_validation=False, g=None, d=None, **kw):
+    from rsrgan_amd import GAN
+    rng = np.random.default_rng(seed)
+    if g is None:
+        g = DO.init_params(DO.g_param_specs(cfg), rng)
+        d = {k: (v * 2.0 if k.endswith("weights") else v) for k, v in DO.init_params(DO.d_param_specs(cfg), rng, relu_init=True).items()}
+        for p in (g, d):                     # a state some way into training: r != 1, d != 0
+            w = rng.uniform(0.2, 0.6)
+            for k in p:
+                if k.endswith("biases") or k.endswith("/beta"):
+                    p[k] = rng.normal(0, 0.1, p[k].shape)
+                elif k.endswith("/gamma"):
+                    p[k] = rng.uniform(0.7, 1.3, p[k].shape)
+                elif k.endswith("renorm_mean"):
+                    p[k] = w * rng.normal(0, 0.3, p[k].shape)
+                elif k.endswith("renorm_stddev"):
+                    p[k] = w * rng.uniform(0.5, 1.5, p[k].shape)
+                elif k.endswith("_weight"):
+                    p[k] = np.float64(w)
+                elif k.endswith("moving_mean"):
+                    p[k] = rng.normal(0, 0.3, p[k].shape)
+                elif k.endswith("moving_variance"):
+                    p[k] = rng.uniform(0.5, 1.5, p[k].shape)
+    g = {k: np.asarray(v, np.float32) for k, v in g.items()}
+    d = {k: np.asarray(v, np.float32) for k, v in d.items()}
+    args = SimpleNamespace(batch_size=N, input_dim=cfg.input_dim, output_dim=cfg.output_dim, left_context=cfg.left_context,
+                           right_context=cfg.right_context, g_type="dnn", keep_prob=1.0, batch_norm=True, num_gpu=1,
+                           save_dir=None, l2_scale=kw.get("l2_scale", 0.0), disc_updates=1, gen_updates=1, init_mse_weight=10.0,
+                           d_learning_rate=kw.get("d_lr", 1e-4), g_learning_rate=kw.get("g_lr", 1e-4))
+    m = GAN(None, args, ["gpu:0"], cross_validation=cross_validation,
+            net_overrides=dict(g_layers=cfg.g_hidden, g_cells=cfg.g_units, d_layers=cfg.d_hidden, d_cells=cfg.d_units))
+    shape1 = lambda s: (1,) if tuple(s) == () else tuple(s)       # the ABI reports a scalar variable as one element
+    assert [(n, tuple(s)) for n, s, _ in m.engine.tensor_table(NET_G)] == [(n, shape1(s)) for n, s in DO.g_param_specs(cfg)]
+    assert [(n, tuple(s)) for n, s, _ in m.engine.tensor_table(NET_D)] == [(n, shape1(s)) for n, s in DO.d_param_specs(cfg)]
+    m.set_vars(g, d)
+    o = DO.GanDnnOracle(cfg, g, d, l2_scale=kw.get("l2_scale", 0.0), g_learning_rate=float(np.float32(kw.get("g_lr", 1e-4))),
+                        d_learning_rate=float(np.float32(kw.get("d_lr", 1e-4))), cross_validation=cross_validation)
+    return m, o
+
+
+def _cmp_vars(m, o, tol=2e-4):
+    gv, dv = m.get_vars()
+    for got, want in ((gv, o.g), (dv, o.d)):
+        for k in want:
+            assert rel_err(got[k], want[k]) < tol or np.abs(got[k] - want[k]).max() < 1e-6, (k, got[k], want[k])
+
+
+@pytest.mark.parametrize("N", [8, 130])
+def test_frame_level_gan_batch_norm_renorm(N):
+    """run_gan_dnn.sh:134 --batch_norm=true: relu(batch_norm(x.W, scale=True, renorm=True)) in G and D (dnn.py:56-61,
+    discriminator_dnn.py:36-41) against oracle/bn_renorm.py: towers, gradients, update ops, Adam steps, the cross_validation twin."""
+    cfg = DO.DnnCfg(input_dim=6, output_dim=5, left_context=2, right_context=1, g_units=20, g_hidden=3, d_units=24, d_hidden=2, batch_norm=True)
+    m, o = _bn_pair(cfg, N, seed=N, l2_scale=1e-3, g_lr=1e-3, d_lr=2e-3)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((N, cfg.fed_dim)).astype(np.float32); lab = rng.standard_normal((N, cfg.output_dim)).astype(np.float32)
+    y = m.forward(x)                                        # is_training=True graph: batch statistics, no update ops fetched
+    assert np.abs(y - o.forward(x)).max() < 2e-4
+    _cmp_vars(m, o)
+    got = m.engine.d_backward(x[:, None], lab[:, None], None, train=True, apply=False).cpu().numpy()
+    want, wg = o.d_tower(x, lab)
+    assert np.allclose(got, want, rtol=2e-4), (got, want)
+    gr = split_flat(m.engine.get_grads(NET_D).cpu().numpy(), m.engine.tensor_table(NET_D))
+    for k in wg:
+        assert rel_err(gr[k], wg[k]) < 2e-3, k
+    _cmp_vars(m, o)                                         # the run's update ops: G x2, D real x2, D fake x1
+    got = m.engine.g_backward(x[:, None], lab[:, None], None, train=True, reuse=True, apply=False).cpu().numpy()
+    want, wg, _ = o.g_tower(x, lab)
+    assert np.allclose(got, want, rtol=2e-4), (got, want)
+    gr = split_flat(m.engine.get_grads(NET_G).cpu().numpy(), m.engine.tensor_table(NET_G))
+    for k in wg:
+        assert rel_err(gr[k], wg[k]) < 2e-3, k
+    _cmp_vars(m, o)
+    x2 = rng.standard_normal((N, cfg.fed_dim)).astype(np.float32) * 1.5 + 0.3
+    assert np.allclose(np.ravel(m.d_step(x2, lab)), o.d_step(x2, lab), rtol=2e-4)
+    assert np.allclose(np.ravel(m.g_step(x2, lab, reuse_g_forward=True)), o.g_step(x2, lab), rtol=2e-4)
+    assert np.allclose(np.ravel(m.g_step(x, lab)), o.g_step(x, lab), rtol=2e-4)
+    _cmp_vars(m, o)
+    for k, v in m.get_vars()[0].items():                    # the statistics are no trainable variables: Adam leaves them alone
+        if k.endswith("renorm_mean_weight"):
+            assert np.isclose(float(v), float(o.g[k]), rtol=1e-5)
+    # the cross_validation twin shares the variables and normalises with the moving statistics (is_training=False)
+    mcv, ocv = _bn_pair(cfg, N, seed=0, cross_validation=True, g=o.g, d=o.d)
+    assert np.allclose(np.ravel(mcv.d_step(x, lab, train=False)), ocv.d_step(x, lab, train=False), rtol=2e-4)
+    assert np.allclose(np.ravel(mcv.g_step(x, lab, train=False)), ocv.g_step(x, lab, train=False), rtol=2e-4)
+    assert np.abs(mcv.forward(x) - ocv.forward(x)).max() < 2e-4
+    _cmp_vars(mcv, ocv)
+
+
+def test_frame_level_gan_batch_norm_reference_sizes():
+    """2827 -> 4 x [1024, BN, ReLU] -> 40 ; 297 -> 4 x [1024, BN, ReLU] -> 1 at the shipped batch size (run_gan_dnn.sh:124: 256)."""
+    cfg = DO.DnnCfg(batch_norm=True)
+    N = 256
+    m, o = _bn_pair(cfg, N, seed=5)
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((N, cfg.fed_dim)).astype(np.float32); lab = rng.standard_normal((N, cfg.output_dim)).astype(np.float32)
+    got = m.engine.d_backward(x[:, None], lab[:, None], None, train=True, apply=False).cpu().numpy()
+    want, wg = o.d_tower(x, lab)
+    assert np.allclose(got, want, rtol=2e-4), (got, want)
+    gr = split_flat(m.engine.get_grads(NET_D).cpu().numpy(), m.engine.tensor_table(NET_D))
+    for k in wg:
+        assert rel_err(gr[k], wg[k]) < 3e-3, k
+    got = m.engine.g_backward(x[:, None], lab[:, None], None, train=True, reuse=False, apply=False).cpu().numpy()
+    want, wg, y = o.g_tower(x, lab)
+    assert np.allclose(got, want, rtol=2e-4), (got, want)
+    gr = split_flat(m.engine.get_grads(NET_G).cpu().numpy(), m.engine.tensor_table(NET_G))
+    for k in wg:
+        assert rel_err(gr[k], wg[k]) < 3e-3, k
+    _cmp_vars(m, o)
