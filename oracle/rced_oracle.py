@@ -5,6 +5,10 @@
 *** PARITY UNPINNED w.r.t. the reference (TensorFlow 1.4 cannot run here); pinned by finite differences and by an
 *** independent direct-loop convolution (tests/test_oracle_rced.py).
 
+`RcedCfg.batch_norm=True` (run_dnn.sh:134): every conv2d becomes relu(batch_norm(conv(x))) without a bias, statistics per output
+channel over [N, S, W] (oracle/bn_renorm.py); the linear output layer keeps its bias; is_training = not cross_validation
+(rced.py:37,60-61).
+
 Restated graph (batch_norm=False; rced.py:36-112):
   inputs [N, S*W] -> reshape [N, S, W, 1]   (S = left+1+right spliced frames = height, W = input_dim = width)
   9 x tf.contrib.layers.conv2d(num_outputs = 12,16,20,24,32,24,20,16,12; kernel [S, 13,11,9,7,7,7,9,11,13]; stride 1;
@@ -22,6 +26,7 @@ from typing import List, Tuple
 
 import numpy as np
 
+from . import bn_renorm as bn
 from .dnn_gan_oracle import DnnCfg, GanDnnOracle
 
 FILTERS_NUM = (12, 16, 20, 24, 32, 24, 20, 16, 12)        # rced.py:92
@@ -45,7 +50,9 @@ def _conv_names(n):
 def g_param_specs(cfg: RcedCfg) -> List[Tuple[str, Tuple[int, ...]]]:
     s, cin = [], 1
     for name, co, fw in zip(_conv_names(len(cfg.filters_num)), cfg.filters_num, cfg.filters_width):
-        s += [(name + "/weights", (cfg.splice, fw, cin, co)), (name + "/biases", (co,))]
+        s.append((name + "/weights", (cfg.splice, fw, cin, co)))
+        # contrib conv2d under normalizer_fn=batch_norm (rced.py:67-72,97-99): no biases, <scope>/BatchNorm/* over the channel axis
+        s += bn.var_specs(name, co) if cfg.batch_norm else [(name + "/biases", (co,))]
         cin = co
     s += [("g_model/fully_connected/weights", (cfg.splice * cfg.input_dim * cin, cfg.output_dim)),
           ("g_model/fully_connected/biases", (cfg.output_dim,))]
@@ -56,7 +63,10 @@ def init_params(specs, rng, dtype=np.float64):
     """xavier_initializer() uniform: conv fan_in = kh*kw*Cin, fan_out = kh*kw*Cout; FC biases 0.1 (rced.py:116)."""
     out = {}
     for name, shape in specs:
-        if name.endswith("biases"):
+        if "/BatchNorm/" in name:
+            one = name.endswith("gamma") or name.endswith("moving_variance")
+            out[name] = (np.ones if one else np.zeros)(shape, dtype)
+        elif name.endswith("biases"):
             out[name] = np.full(shape, 0.1 if "fully_connected" in name else 0.0, dtype)
         elif len(shape) == 4:
             rf = shape[0] * shape[1]
@@ -93,7 +103,7 @@ def col2im(dcol, shape, kh, kw):
     return dxp[:, pt:pt + S, pl:pl + W, :]
 
 
-def rced_fwd(cfg: RcedCfg, P, x):
+def rced_fwd(cfg: RcedCfg, P, x, training=True):
     N = x.shape[0]
     S, W = cfg.splice, cfg.input_dim
     h = x.reshape(N, S, W, 1)
@@ -101,9 +111,17 @@ def rced_fwd(cfg: RcedCfg, P, x):
     for name, fw in zip(_conv_names(len(cfg.filters_num)), cfg.filters_width):
         Wt = P[name + "/weights"]
         col = im2col(h, S, fw)
-        z = col @ Wt.reshape(-1, Wt.shape[3]) + P[name + "/biases"]
+        bcache = None
+        if name + "/BatchNorm/beta" in P:          # moments over [N, S, W] per channel = over the rows of the [N*S*W, C] matrix
+            z = col @ Wt.reshape(-1, Wt.shape[3])
+            if training:
+                z, bcache = bn.forward_train(P, name, z)
+            else:
+                z = bn.forward_infer(P, name, z)
+        else:
+            z = col @ Wt.reshape(-1, Wt.shape[3]) + P[name + "/biases"]
         a = np.maximum(z, 0.0)
-        cache.append((h.shape, col, a))
+        cache.append((h.shape, col, a, bcache))
         h = a.reshape(N, S, W, Wt.shape[3])
     flat = h.reshape(N, -1)
     y = flat @ P["g_model/fully_connected/weights"] + P["g_model/fully_connected/biases"]
@@ -117,11 +135,15 @@ def rced_bwd(cfg: RcedCfg, P, cache, dy):
     d = (dy @ P["g_model/fully_connected/weights"].T).reshape(-1, cfg.filters_num[-1])
     names = _conv_names(len(cfg.filters_num))
     for i in range(len(names) - 1, -1, -1):
-        in_shape, col, a = convs[i]
+        in_shape, col, a, bcache = convs[i]
         Wt = P[names[i] + "/weights"]
         d = d * (a > 0)
+        if bcache is not None:
+            d, gb = bn.backward_train(P, bcache, d)
+            grads.update(gb)
+        elif names[i] + "/biases" in P:
+            grads[names[i] + "/biases"] = d.sum(0)
         grads[names[i] + "/weights"] = (col.T @ d).reshape(Wt.shape)
-        grads[names[i] + "/biases"] = d.sum(0)
         if i > 0:
             dcol = d @ Wt.reshape(-1, Wt.shape[3]).T
             d = col2im(dcol, in_shape, S, cfg.filters_width[i]).reshape(-1, in_shape[3])
@@ -132,7 +154,13 @@ class GanRcedOracle(GanDnnOracle):
     """GanDnnOracle with the R-CED generator: `supervised = True` gives the DNNTrainer graph (dnn_trainer.py:98-99,139-148)."""
 
     def _g_fwd(self, x):
-        return rced_fwd(self.cfg, self.g, x)
+        return rced_fwd(self.cfg, self.g, x, self.training)
+
+    def _g_commit(self, cache, times):
+        for _ in range(times):
+            for conv in cache[0]:
+                if conv[3] is not None:
+                    bn.commit(self.g, conv[3])
 
     def _g_bwd(self, cache, dy):
         return rced_bwd(self.cfg, self.g, cache, dy)

@@ -18,12 +18,13 @@ namespace rsr {
 
 static const float kDClipLo = -0.5f, kDClipHi = 1.5f;     // discriminator_dnn.py:93 tf.clip_by_value(y, -0.5, 1.5)
 
-BnVars Model::bn_vars(const ParamSet& ps, const FcLayer& F) const {
+BnVars Model::bn_vars(const ParamSet& ps, const int (&tbn)[8]) const {
   BnVars v;
-  v.beta = ps.W(F.tbn[0]); v.gamma = ps.W(F.tbn[1]); v.mm = ps.W(F.tbn[2]); v.mv = ps.W(F.tbn[3]);
-  v.rm = ps.W(F.tbn[4]); v.rmw = ps.W(F.tbn[5]); v.rs = ps.W(F.tbn[6]); v.rsw = ps.W(F.tbn[7]);
+  v.beta = ps.W(tbn[0]); v.gamma = ps.W(tbn[1]); v.mm = ps.W(tbn[2]); v.mv = ps.W(tbn[3]);
+  v.rm = ps.W(tbn[4]); v.rmw = ps.W(tbn[5]); v.rs = ps.W(tbn[6]); v.rsw = ps.W(tbn[7]);
   return v;
 }
+BnVars Model::bn_vars(const ParamSet& ps, const FcLayer& F) const { return bn_vars(ps, F.tbn); }
 
 void Model::fc_forward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, hipStream_t s, int calls) {
   for (size_t l = 0; l < L.size(); ++l) {
@@ -97,12 +98,18 @@ void Model::rced_forward(int rows, hipStream_t s) {
       const float* src = rc_act[l];
       int ldc = L.ldCin;
       if (l == 0) { launch_expand_c4(x_tm, ldDin, rcS * rcW, rc_x4, (size_t)rows, s); src = rc_x4; ldc = 4; }
-      launch_conv_fwd(src, ldc, L.Cin, rc_ft_fwd[l], G.W(L.tb), true, rc_act[l + 1], L.ldCout, L.Cout, rows, rcS, rcW, L.fw, s);
-      continue;
+      launch_conv_fwd(src, ldc, L.Cin, rc_ft_fwd[l], L.bn ? nullptr : G.W(L.tb), !L.bn, L.bn ? L.pre : rc_act[l + 1], L.ldCout, L.Cout, rows,
+                      rcS, rcW, L.fw, s);
+    } else {
+      float* col = rc_keep_cols ? rc_cols[l] : rc_col;
+      launch_im2col(rc_act[l], l == 0 ? (size_t)ldDin : (size_t)rcS * rcW * L.ldCin, L.ldCin, L.Cin, rcS, rcW, rcS, L.fw, col, L.ldK, M, s);
+      gemm(col, L.ldK, true, G.W(L.tW), L.ldCout, false, L.bn ? L.pre : rc_act[l + 1], L.ldCout, (int)M, L.Cout, L.K, L.bn ? nullptr : G.W(L.tb),
+           L.bn ? 0 : 2, 0.f, false, s);
     }
-    float* col = rc_keep_cols ? rc_cols[l] : rc_col;
-    launch_im2col(rc_act[l], l == 0 ? (size_t)ldDin : (size_t)rcS * rcW * L.ldCin, L.ldCin, L.Cin, rcS, rcW, rcS, L.fw, col, L.ldK, M, s);
-    gemm(col, L.ldK, true, G.W(L.tW), L.ldCout, false, rc_act[l + 1], L.ldCout, (int)M, L.Cout, L.K, G.W(L.tb), 2, 0.f, false, s);
+    // relu(batch_norm(conv)): moments per channel over the M positions of the batch (rced.py:97-99)
+    if (L.bn)
+      launch_bn_forward(L.pre, L.ldCout, rc_act[l + 1], L.ldCout, (int)M, L.Cout, bn_vars(G, L.tbn), L.stat, L.ldCout, bn_training(), true,
+                        scratch, scratch_floats, s);
   }
   // reshape [rows, S*W*C] (rced.py:110: contiguous because C % 4 == 0) -> linear FC
   gemm(rc_act[gconv.size()], rc_fc.ld_in, true, G.W(rc_fc.tW), ldDout, false, y_tm, ldDout, rows, Dout, rc_fc.in, G.W(rc_fc.tb), 0, 0.f, false, s);
@@ -118,7 +125,11 @@ void Model::rced_backward(int rows, float* dy, hipStream_t s) {
   gemm(dy, ldDout, true, G.W(rc_fc.tW), ldDout, true, d, rc_fc.ld_in, rows, rc_fc.in, Dout, nullptr, 0, 0.f, false, s);   // = [M][Cout_last]
   for (int l = Lc - 1; l >= 0; --l) {
     const ConvLayer& L = gconv[l];
-    launch_lrelu_bwd(rc_act[l + 1], d, M, L.Cout, L.ldCout, 0.f, s);                      // relu': d *= [a > 0]
+    if (L.bn)
+      launch_bn_backward(d, L.ldCout, rc_act[l + 1], L.ldCout, L.pre, L.ldCout, (int)M, L.Cout, L.stat, L.ldCout, G.Gd(L.tbn[0]), G.Gd(L.tbn[1]),
+                         false, true, bn_sums, scratch, scratch_floats, s);
+    else
+      launch_lrelu_bwd(rc_act[l + 1], d, M, L.Cout, L.ldCout, 0.f, s);                    // relu': d *= [a > 0]
     if (rc_wgrad_implicit[l] && rc_wg_ws) {
       launch_conv_wgrad(l == 0 ? rc_x4 : rc_act[l], l == 0 ? 4 : L.ldCin, L.Cin, d, L.ldCout, L.Cout, G.Gd(L.tW), L.ldCout, rc_wg_ws, rows,
                         rcS, rcW, L.fw, s);
@@ -128,7 +139,7 @@ void Model::rced_backward(int rows, float* dy, hipStream_t s) {
         launch_im2col(rc_act[l], l == 0 ? (size_t)ldDin : (size_t)rcS * rcW * L.ldCin, L.ldCin, L.Cin, rcS, rcW, rcS, L.fw, col, L.ldK, M, s);
       gemm(col, L.ldK, false, d, L.ldCout, false, G.Gd(L.tW), L.ldCout, L.K, L.Cout, (int)M, nullptr, 0, 0.f, false, s);
     }
-    launch_colsum_tall(d, L.ldCout, G.Gd(L.tb), (int)M, L.Cout, scratch, scratch_floats, s);
+    if (!L.bn) launch_colsum_tall(d, L.ldCout, G.Gd(L.tb), (int)M, L.Cout, scratch, scratch_floats, s);
     if (l > 0) {
       if (rc_ft_bwd[l]) {                        // d(in) = conv_SAME(d, flipped filter): the same implicit-GEMM kernel
         launch_conv_fwd(d, L.ldCout, L.Cout, rc_ft_bwd[l], nullptr, false, other, L.ldCin, L.Cin, rows, rcS, rcW, L.fw, s);
@@ -155,6 +166,8 @@ void Model::g_frame_backward(int rows, float* dy, hipStream_t s) {
 // discriminator's real-joint call twice (dummy + real, gan.py:162-181) and its fake-joint call once -- oracle/bn_renorm.py
 void Model::bn_commit_run(bool with_d, hipStream_t s) {
   bn_commit_stack(G, gfc, 0, 2, s);
+  for (const ConvLayer& L : gconv)
+    if (L.bn) launch_bn_commit(L.Cout, bn_vars(G, L.tbn), L.stat, L.ldCout, 2, s);
   if (with_d) { bn_commit_stack(D, dfc, 0, 2, s); bn_commit_stack(D, dfc, 1, 1, s); }
 }
 
@@ -190,7 +203,7 @@ int Model::dnn_d_backward(const float* x, const float* labels, int T, float* out
 
 int Model::dnn_g_backward(const float* x, const float* labels, int T, float* out_losses, bool want_grads, bool reuse, hipStream_t s) {
   const int R = T * B;
-  if (bn_on() && !g_rced()) reuse = false;       // the D-run's update ops changed the generator's renorm state: its forward differs now
+  if (bn_on()) reuse = false;       // the D-run's update ops changed the generator's renorm state: its forward differs now
   if (reuse) {
     if (!g_fwd_valid || T != cur_T) { set_error("reuse_g_forward without a valid generator forward"); return RSRGAN_ERR_STATE; }
   } else {

@@ -174,27 +174,31 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   if (d_dnn() && (c.d_joint_dim < 0 || c.d_joint_off < 0 || c.d_joint_off + c.d_joint_dim > Din)) { set_error("bad d_joint slice"); return RSRGAN_ERR_INVALID; }
   const int P = gR, H = c.g_cells;
   auto fc_name = [](const char* net, int i) { return std::string(net) + "/fully_connected" + (i == 0 ? "" : "_" + std::to_string(i)); };
+  // <scope>/BatchNorm/* in normalization.py's build order (contrib layers create no biases under a normalizer_fn)
+  auto add_bn = [&](ParamSet& ps, const std::string& nm, int o, int (&tbn)[8]) {
+    static const char* kBn[8] = {"beta", "gamma", "moving_mean", "moving_variance", "renorm_mean", "renorm_mean_weight", "renorm_stddev",
+                                 "renorm_stddev_weight"};
+    for (int k = 0; k < 8; ++k) {
+      const bool scalar = k == 5 || k == 7;
+      tbn[k] = ps.add(nm + "/BatchNorm/" + kBn[k], 1, scalar ? 1 : o, true);
+      ps.t[tbn[k]].l2 = false;                                     // constant-initialised, never regularised
+      ps.t[tbn[k]].bias_init = (k == 1 || k == 3) ? 1.f : 0.f;     // gamma = 1, moving_variance = 1
+      ps.t[tbn[k]].trainable = k < 2;
+    }
+  };
   auto add_fc = [&](ParamSet& ps, std::vector<FcLayer>& out, const std::string& nm, int in, int o, bool bn = false) {
     FcLayer F; F.in = in; F.out = o; F.ld_in = pad4(in); F.ld_out = pad4(o);
     F.tW = ps.add(nm + "/weights", in, o, false);
-    if (bn) {              // contrib fully_connected creates no biases under a normalizer_fn; variables in normalization.py's build order
-      static const char* kBn[8] = {"beta", "gamma", "moving_mean", "moving_variance", "renorm_mean", "renorm_mean_weight", "renorm_stddev",
-                                   "renorm_stddev_weight"};
+    if (bn) {
       F.bn = true; F.tb = -1;
-      for (int k = 0; k < 8; ++k) {
-        const bool scalar = k == 5 || k == 7;
-        F.tbn[k] = ps.add(nm + "/BatchNorm/" + kBn[k], 1, scalar ? 1 : o, true);
-        ps.t[F.tbn[k]].l2 = false;                                     // constant-initialised, never regularised
-        ps.t[F.tbn[k]].bias_init = (k == 1 || k == 3) ? 1.f : 0.f;     // gamma = 1, moving_variance = 1
-        ps.t[F.tbn[k]].trainable = k < 2;
-      }
+      add_bn(ps, nm, o, F.tbn);
     } else {
       F.tb = ps.add(nm + "/biases", 1, o, true);
     }
     out.push_back(F);
   };
-  if (bn_on() && (!g_dnn() || c.g_type == RSRGAN_G_RCED)) {
-    set_error("RSRGAN_FLAG_BATCH_NORM is built for the frame-level dnn generator + discriminator_dnn only");
+  if (bn_on() && !g_dnn()) {
+    set_error("RSRGAN_FLAG_BATCH_NORM is built for the frame-level generators (dnn, rced) + discriminator_dnn only");
     return RSRGAN_ERR_INVALID;
   }
   // ---- variable tables in graph-construction order (gan_rnn_placeholder.py:301-317) ----
@@ -210,7 +214,9 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
       ConvLayer L; L.fw = kWidth[l]; L.Cin = cin; L.Cout = co; L.K = rcS * L.fw * cin; L.ldK = pad4(L.K);
       L.ldCin = l == 0 ? 1 : pad4(cin); L.ldCout = pad4(co);
       const std::string nm = std::string("g_model/Conv") + (l == 0 ? "" : "_" + std::to_string(l));
-      L.tW = G.add(nm + "/weights", L.K, co, false); L.tb = G.add(nm + "/biases", 1, co, true);
+      L.tW = G.add(nm + "/weights", L.K, co, false);
+      if (bn_on()) { L.bn = true; L.tb = -1; add_bn(G, nm, co, L.tbn); }
+      else L.tb = G.add(nm + "/biases", 1, co, true);
       G.t[L.tW].xavier_fan_out = rcS * L.fw * co;           // xavier for conv: receptive field x channels on both sides
       gconv.push_back(L);
       cin = co;
@@ -294,6 +300,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     rc_act.push_back(x_tm);
     for (auto& L : gconv) {
       rc_act.push_back(alloc<float>(M * L.ldCout));
+      if (L.bn) { L.pre = alloc<float>(M * L.ldCout); L.stat = alloc<float>((size_t)BN_STAT_ROWS * L.ldCout); }
       maxK = std::max(maxK, L.ldK); maxC = std::max(maxC, L.ldCout);
     }
     // implicit-GEMM convolution (conv.hip) for every layer it covers: forward and data gradient never build a patch matrix

@@ -51,6 +51,11 @@ struct LstmLayer {               // one tf.contrib.rnn.LSTMCell(H, use_peepholes
 
 struct ConvLayer {               // tf.contrib.layers.conv2d([S, fw], SAME) of models/rced.py: weights [S*fw*Cin][Cout] (= [S, fw, Cin, Cout])
   int fw, Cin, Cout, K, ldK, ldCin, ldCout, tW, tb;
+  // normalizer_fn=batch_norm (rced.py:67-72): no biases (tb = -1); moments per output channel over the M = N*S*W positions
+  bool bn = false;
+  int tbn[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+  float* pre = nullptr;          // [M][ldCout] conv output before the normaliser
+  float* stat = nullptr;         // [BN_STAT_ROWS][ldCout]
 };
 
 struct FcLayer {                 // contrib.layers.fully_connected: weights [in][out], biases [out]
@@ -178,6 +183,7 @@ struct Model {
   bool bn_on() const { return (cfg.flags & RSRGAN_FLAG_BATCH_NORM) != 0; }
   bool bn_training() const { return bn_on() && !cfg.cross_validation; }      // is_training (dnn.py:49-50)
   BnVars bn_vars(const ParamSet& ps, const FcLayer& F) const;
+  BnVars bn_vars(const ParamSet& ps, const int (&tbn)[8]) const;
   void bn_commit_stack(const ParamSet& ps, const std::vector<FcLayer>& L, int call, int times, hipStream_t s);
   float* bn_sums = nullptr;      // [2][max ld_out] work space of launch_bn_backward
   void d_dnn_forward_loss(int T, int Nd, int n_real, bool want_grads, float* loss3, hipStream_t s, int calls = 1);

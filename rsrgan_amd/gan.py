@@ -28,8 +28,6 @@ class GAN(Model):
         self.batch_norm = bool(getattr(args, "batch_norm", False))
         if self.keep_prob < 1.0:
             raise NotImplementedError("dropout variants are not built (DESIGN.md section 7)")
-        if self.batch_norm and args.g_type != "dnn":
-            raise NotImplementedError("batch_norm is built for the dnn generator + discriminator_dnn (DESIGN.md section 6f)")
         self.batch_size, self.devices = args.batch_size, devices
         self.num_gpu = getattr(args, "num_gpu", 1)
         self.save_dir = getattr(args, "save_dir", None)

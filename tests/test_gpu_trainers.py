@@ -7,7 +7,7 @@ import pytest
 
 from oracle import dnn_gan_oracle as DO
 from oracle import rsrgan_oracle as O
-from tests.helpers import NET_G, args_for, overrides, rand_batch, rand_params, rel_err, small_cfg, split_flat
+from tests.helpers import NET_D, NET_G, args_for, overrides, rand_batch, rand_params, rel_err, small_cfg, split_flat
 
 pytestmark = pytest.mark.gpu
 
@@ -172,7 +172,7 @@ def test_rced_generator_matches_oracle(N, gan, ctx, width):
     x = rng.standard_normal((N, cfg.fed_dim)).astype(np.float32); lab = rng.standard_normal((N, cfg.output_dim)).astype(np.float32)
     if full:
         _, (convs, _) = R.rced_fwd(cfg, {k: v.astype(np.float64) for k, v in g.items()}, x.astype(np.float64))
-        for (_, col, a), name in zip(convs, R._conv_names(9)):
+        for (_, col, a, _bn), name in zip(convs, R._conv_names(9)):
             z = col @ g[name + "/weights"].astype(np.float64).reshape(col.shape[1], -1) + g[name + "/biases"]
             assert np.abs(z).min() > 0.05, name           # the premise of the tie-free construction
     assert np.abs(m.forward(x) - o.forward(x)).max() < 1e-4
@@ -195,6 +195,104 @@ def test_rced_generator_matches_oracle(N, gan, ctx, width):
     gv, _ = m.get_vars()
     for k in o.g:
         assert gv[k].shape == o.g[k].shape and rel_err(gv[k], o.g[k]) < 1e-3, k
+
+
+@pytest.mark.parametrize("N,gan,ctx,width", [(6, False, (2, 1), 9), (5, True, (2, 2), 21), (4, False, (1, 1), -11), (3, True, (1, 1), 70)])
+def test_rced_batch_norm_matches_oracle(N, gan, ctx, width):
+    """run_dnn.sh:129-134 (--g_type=rced --batch_norm=true): relu(batch_norm(conv2d, scale=True, renorm=True)) per output channel over
+    [N, S, W] (models/rced.py:67-72,97-99), under DNNTrainer and paired with a batch-normalised discriminator_dnn, vs
+    oracle/rced_oracle.py + oracle/bn_renorm.py: tower losses, every gradient, the update ops, Adam steps, the cross_validation twin."""
+    from oracle import rced_oracle as R
+    from rsrgan_amd import GAN
+    from rsrgan_amd.trainer import DNNTrainer
+    full = width < 0
+    width = abs(width)
+    cfg = R.RcedCfg(input_dim=width, output_dim=5, left_context=ctx[0], right_context=ctx[1], d_units=20, d_hidden=2, batch_norm=True,
+                    filters_num=R.FILTERS_NUM if full else (4,) * 9)
+    rng = np.random.default_rng(100 + N)
+    g = R.init_params(R.g_param_specs(cfg), rng)
+    d = {k: (2.0 * v if k.endswith("weights") else v) for k, v in DO.init_params(DO.d_param_specs(cfg), rng, relu_init=True).items()}
+    for p in (g, d):                         # a state some way into training: r != 1, d != 0
+        w = rng.uniform(0.2, 0.6)
+        for k in p:
+            if k.endswith("biases") or k.endswith("/beta"):
+                p[k] = rng.normal(0.05, 0.1, p[k].shape)
+            elif k.endswith("/gamma"):
+                p[k] = rng.uniform(0.7, 1.3, p[k].shape)
+            elif k.endswith("renorm_mean"):
+                p[k] = w * rng.normal(0, 0.2, p[k].shape)
+            elif k.endswith("renorm_stddev"):
+                p[k] = w * rng.uniform(0.3, 1.0, p[k].shape)
+            elif k.endswith("_weight"):
+                p[k] = np.float64(w)
+            elif k.endswith("moving_mean"):
+                p[k] = rng.normal(0, 0.2, p[k].shape)
+            elif k.endswith("moving_variance"):
+                p[k] = rng.uniform(0.3, 1.0, p[k].shape)
+    g = {k: np.asarray(v, np.float32) for k, v in g.items()}
+    d = {k: np.asarray(v, np.float32) for k, v in d.items()}
+    ov = dict(g_layers=9, g_cells=32 if full else 4, d_layers=cfg.d_hidden, d_cells=cfg.d_units)
+
+    class RcedGan(GAN):
+        G_TYPES = ("dnn", "rced")
+
+    def build(cv, gp, dp):
+        args = SimpleNamespace(batch_size=N, input_dim=cfg.input_dim, output_dim=cfg.output_dim, left_context=cfg.left_context,
+                               right_context=cfg.right_context, g_type="rced", keep_prob=1.0, batch_norm=True, num_gpu=1, save_dir=None,
+                               l2_scale=1e-3, g_learning_rate=1e-3, d_learning_rate=2e-3, init_mse_weight=10.0, disc_updates=1, gen_updates=1)
+        if gan:
+            m = RcedGan(None, args, ["gpu:0"], cross_validation=cv, net_overrides=ov)
+            o = R.GanRcedOracle(cfg, gp, dp, l2_scale=1e-3, g_learning_rate=float(np.float32(1e-3)), d_learning_rate=float(np.float32(2e-3)),
+                                cross_validation=cv)
+        else:
+            m = DNNTrainer(None, args, ["gpu:0"], cross_validation=cv, net_overrides=ov)
+            o = R.GanRcedOracle(cfg, gp, dp, l2_scale=1e-3, g_learning_rate=float(np.float32(1e-3)), mse_lambda=1.0, cross_validation=cv)
+            o.supervised = True
+        m.set_vars({k: np.asarray(v, np.float32) for k, v in gp.items()}, {k: np.asarray(v, np.float32) for k, v in dp.items()})
+        return m, o
+
+    m, o = build(False, g, d)
+    table = [(n, m._tf_shape(n, s)) for n, s, _ in m.engine.tensor_table(NET_G)]
+    assert table == [(n, tuple(s)) for n, s in R.g_param_specs(cfg)], table
+
+    def cmp_vars(mm, oo, tol=1e-3):
+        gv, dv = mm.get_vars()
+        for got, want in ((gv, oo.g), (dv, oo.d if gan else {})):
+            for k in want:
+                assert got[k].shape == np.shape(want[k]) and (rel_err(got[k], want[k]) < tol or np.abs(got[k] - want[k]).max() < 1e-6), k
+
+    x = rng.standard_normal((N, cfg.fed_dim)).astype(np.float32); lab = rng.standard_normal((N, cfg.output_dim)).astype(np.float32)
+    assert np.abs(m.forward(x) - o.forward(x)).max() < 2e-4
+    if gan:
+        got = m.engine.d_backward(x[:, None], lab[:, None], None, train=True, apply=False).cpu().numpy()
+        want, wd = o.d_tower(x, lab)
+        assert np.allclose(got, want, rtol=2e-4), (got, want)
+        gr = split_flat(m.engine.get_grads(NET_D).cpu().numpy(), m.engine.tensor_table(NET_D))
+        for k in wd:
+            assert rel_err(gr[k], wd[k]) < 2e-3, k
+        cmp_vars(m, o)
+    got = m.engine.g_backward(x[:, None], lab[:, None], None, train=True, reuse=False, apply=False).cpu().numpy()
+    want, wg, _ = o.g_tower(x, lab)
+    assert np.allclose(got, want, rtol=2e-4, atol=1e-7), (got, want)
+    gr = split_flat(m.engine.get_grads(NET_G).cpu().numpy(), m.engine.tensor_table(NET_G))
+    for k in wg:
+        assert rel_err(gr[k].reshape(wg[k].shape), wg[k]) < 3e-3, k
+    cmp_vars(m, o)
+    x2 = (1.3 * rng.standard_normal((N, cfg.fed_dim)) + 0.2).astype(np.float32)
+    for xb in (x2, x):
+        if gan:
+            assert np.allclose(np.ravel(m.d_step(xb, lab)), o.d_step(xb, lab), rtol=1e-3)
+            assert np.allclose(np.ravel(m.g_step(xb, lab, reuse_g_forward=True)), o.g_step(xb, lab), rtol=1e-3)
+        else:
+            assert np.allclose(np.ravel(m.step(xb, lab)), np.ravel(o.g_step(xb, lab))[1:], rtol=1e-3)
+    cmp_vars(m, o)
+    mcv, ocv = build(True, o.g, o.d)                        # is_training=False: moving statistics, no update ops
+    if gan:
+        assert np.allclose(np.ravel(mcv.g_step(x, lab, train=False)), ocv.g_step(x, lab, train=False), rtol=1e-3)
+    else:
+        assert np.allclose(np.ravel(mcv.step(x, lab, train=False)), np.ravel(ocv.g_step(x, lab, train=False))[1:], rtol=1e-3)
+    assert np.abs(mcv.forward(x) - ocv.forward(x)).max() < 2e-4
+    cmp_vars(mcv, ocv)
 
 
 def test_rced_gan_full_size_properties():

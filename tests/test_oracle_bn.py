@@ -169,3 +169,44 @@ def test_cross_validation_twin_uses_moving_statistics_and_leaves_state():
     # inference statistics: a row's output does not depend on the rest of the batch
     assert np.allclose(cv.forward(x)[:5], cv.forward(x[:5]))
     assert np.isfinite(l1).all() and np.isfinite(l2).all()
+
+
+def test_rced_with_batch_norm_specs_gradients_and_schedule():
+    from oracle import rced_oracle as R
+    cfg = R.RcedCfg(input_dim=7, output_dim=3, left_context=1, right_context=1, filters_num=(3, 4, 2), filters_width=(5, 3, 3), batch_norm=True)
+    specs = R.g_param_specs(cfg)
+    names = [n for n, _ in specs]
+    assert names[:3] == ["g_model/Conv/weights", "g_model/Conv/BatchNorm/beta", "g_model/Conv/BatchNorm/gamma"]
+    assert names[-2:] == ["g_model/fully_connected/weights", "g_model/fully_connected/biases"] and len(names) == 3 * 9 + 2
+    assert dict(specs)["g_model/Conv_1/BatchNorm/renorm_stddev"] == (4,) and dict(specs)["g_model/Conv_1/BatchNorm/renorm_stddev_weight"] == ()
+    rng = np.random.default_rng(4)
+    g = R.init_params(specs, rng)
+    for k in g:
+        if k.endswith("/beta"):
+            g[k] = rng.normal(0, 0.2, g[k].shape)
+        elif k.endswith("/gamma"):
+            g[k] = rng.uniform(0.6, 1.4, g[k].shape)
+    x = rng.standard_normal((5, cfg.fed_dim)); lab = rng.standard_normal((5, cfg.output_dim))
+
+    def make(params):
+        o = R.GanRcedOracle(cfg, params, {}, mse_lambda=1.0, l2_scale=1e-2)
+        o.supervised = True
+        return o
+    losses, grads, y = make(g).g_tower(x, lab)
+    # zero renorm state: r = 1, d = 0 for any batch, so central differences of the loss see the same function
+    for name in [n for n in g if trainable(n)]:
+        idx = tuple(rng.integers(0, s) for s in g[name].shape)
+        vals = []
+        for sgn in (1, -1):
+            pp = {k: v.copy() for k, v in g.items()}
+            pp[name][idx] += sgn * 1e-6
+            vals.append(make(pp).g_tower(x, lab, want_grads=False)[0][3])
+        fd = (vals[0] - vals[1]) / 2e-6
+        assert abs(fd - grads[name][idx]) < 1e-6 * max(1.0, abs(fd)) + 1e-8, (name, fd, grads[name][idx])
+    o = make(g)
+    o.g_step(x, lab)
+    assert np.isclose(o.g["g_model/Conv_2/BatchNorm/renorm_mean_weight"], 1 - 0.99 ** 2)       # the generator's call twice
+    # per-channel moments over [N, S, W]
+    col = R.im2col(x.reshape(5, 3, 7, 1), 3, 5)
+    z = col @ g["g_model/Conv/weights"].reshape(-1, 3)
+    assert np.allclose(o.g["g_model/Conv/BatchNorm/renorm_mean"], (1 - 0.99 ** 2) * z.mean(0))
