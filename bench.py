@@ -187,8 +187,8 @@ def bench_dnn_gan(a, rank, local, world, dev):
     from rsrgan_amd import GAN, dist as rdist
     N = a.batch
     args = SimpleNamespace(batch_size=N, input_dim=257, output_dim=40, left_context=5, right_context=5, g_type="dnn",
-                           keep_prob=1.0, batch_norm=False, num_gpu=world, save_dir=None, l2_scale=0.0, disc_updates=1,
-                           gen_updates=1, init_mse_weight=10.0, d_learning_rate=1e-4 * world, g_learning_rate=1e-4 * world)
+                           keep_prob=1.0, batch_norm=bool(getattr(a, "batch_norm", False)), num_gpu=world, save_dir=None, l2_scale=0.0,
+                           disc_updates=1, gen_updates=1, init_mse_weight=10.0, d_learning_rate=1e-4 * world, g_learning_rate=1e-4 * world)
     trainer = a.net == "dnn_trainer"          # BASELINE.json configs[0]: the DNN generator alone under DNNTrainer (supervised)
     if trainer:
         from rsrgan_amd.trainer import DNNTrainer
@@ -236,6 +236,7 @@ def bench_dnn_gan(a, rank, local, world, dev):
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": ("models/dnn_trainer.py step, G=dnn(2827-4x1024-40), " if trainer else
                                        "models/gan.py 1D+1G step, G=dnn(2827-4x1024-40)+D=discriminator_dnn(297-4x1024-1), ") +
+                                      ("batch_norm(renorm=True), " if args.batch_norm else "") +
                                       "N=%d frames/GPU" % N, "global_batch": N * world, "parallelism": "dp%d" % world,
                           "losses_last_step": [round(float(v), 6) for v in last.mean(0).cpu().numpy()]},
                "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -255,7 +256,7 @@ def bench_rced(a, rank, local, world, dev):
     from rsrgan_amd.trainer import DNNTrainer
     N, W, S = a.batch, a.rced_width, 11
     args = SimpleNamespace(batch_size=N, input_dim=W, output_dim=40, left_context=5, right_context=5, g_type="rced", keep_prob=1.0,
-                           batch_norm=False, num_gpu=world, save_dir=None, l2_scale=0.0, g_learning_rate=1e-3 * world,
+                           batch_norm=bool(getattr(a, "batch_norm", False)), num_gpu=world, save_dir=None, l2_scale=0.0, g_learning_rate=1e-3 * world,
                            d_learning_rate=1e-4 * world, init_mse_weight=10.0, disc_updates=1, gen_updates=1)
     if a.rced_gan:          # BASELINE.json configs[3]: R-CED generator + discriminator_dnn (the reference's gan.py only accepts 'dnn')
         class RcedGan(GAN):
@@ -301,7 +302,7 @@ def bench_rced(a, rank, local, world, dev):
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt * 1e3 / a.steps, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": ("models/rced.py + discriminator_dnn, 1D+1G step" if a.rced_gan else "models/rced.py under DNNTrainer") +
-                                      " (batch_norm=False), frame width %d x splice 11, N=%d frames/GPU" % (W, N),
+                                      " (batch_norm=%s), frame width %d x splice 11, N=%d frames/GPU" % (args.batch_norm, W, N),
                           "global_batch": N * world, "parallelism": "dp%d" % world,
                           "losses_last_step": [round(float(v), 6) for v in last.mean(0).cpu().numpy()]},
                "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -331,6 +332,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the extra event-bracketed step (PMC passes count bytes per step)")
     ap.add_argument("--flags", type=int, default=int(os.environ.get("RSRGAN_FLAGS", "3")),
                     help="library schedule flags: 1 = wavefront, 2 = hipGraph replay, 4 = side-stream GEMM overlap (include/rsrgan.h)")
+    ap.add_argument("--batch-norm", action="store_true", help="--net dnn_gan / dnn_trainer / rced: batch_norm(renorm=True) on the hidden layers "
+                                                              "(run_gan_dnn.sh:134, run_dnn.sh:134)")
     ap.add_argument("--rced-gan", action="store_true", help="--net rced: 1 D + 1 G step with discriminator_dnn instead of the supervised trainer")
     ap.add_argument("--rced-width", type=int, default=40, help="--net rced: frame width (run_dnn.sh:137 uses 40-dim MFCC input)")
     ap.add_argument("--strong", action="store_true",
