@@ -179,10 +179,14 @@ class GanDnnOracle:
         c = self.cfg
         return x[:, c.input_dim * c.left_context: c.input_dim * (c.left_context + 1)]     # gan.py:158-160
 
+    _eval_call = False
+
     @property
     def training(self):
-        """is_training of the batch-norm layers: False on the cross_validation twin (dnn.py:49-50, discriminator_dnn.py:29)."""
-        return not self.cross_validation
+        """is_training of the batch-norm layers: False on the cross_validation twin (dnn.py:49-50, discriminator_dnn.py:29).
+        d_step / g_step with train=False ARE that twin's fetches on the shared variables (train_gan_dnn.py:182-215 runs them on
+        cv_model), so they normalise with the moving statistics too."""
+        return not self.cross_validation and not self._eval_call
 
     # generator hooks (overridden by oracle/rced_oracle.py for the R-CED generator)
     def _g_fwd(self, x):
@@ -283,13 +287,21 @@ class GanDnnOracle:
         self._adam("g", self.g, grads, self.g_learning_rate)
 
     def d_step(self, x, lab, train=True):
-        losses, grads = self.d_tower(x, lab, want_grads=train)
+        self._eval_call = not train
+        try:
+            losses, grads = self.d_tower(x, lab, want_grads=train)
+        finally:
+            self._eval_call = False
         if train:
             self.apply_d(grads)
         return losses
 
     def g_step(self, x, lab, train=True):
-        losses, grads, _ = self.g_tower(x, lab, want_grads=train)
+        self._eval_call = not train
+        try:
+            losses, grads, _ = self.g_tower(x, lab, want_grads=train)
+        finally:
+            self._eval_call = False
         if train:
             self.apply_g(grads)
         return losses

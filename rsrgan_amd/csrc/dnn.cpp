@@ -182,6 +182,7 @@ int Model::dnn_d_backward(const float* x, const float* labels, int T, float* out
   const int R = T * B;
   if (!x || !labels) { set_error("null input pointer"); return RSRGAN_ERR_INVALID; }
   if (T <= 0 || T > Tmax) { set_error("T=%d outside (0, max_frames=%d]", T, Tmax); return RSRGAN_ERR_INVALID; }
+  bn_eval_call = !want_grads;
   launch_pack_tm(x, x_tm, B, T, Din, ldDin, s);
   launch_pack_tm(labels, lab_tm, B, T, Dout, ldDout, s);
   cur_T = T;
@@ -203,6 +204,7 @@ int Model::dnn_d_backward(const float* x, const float* labels, int T, float* out
 
 int Model::dnn_g_backward(const float* x, const float* labels, int T, float* out_losses, bool want_grads, bool reuse, hipStream_t s) {
   const int R = T * B;
+  bn_eval_call = !want_grads;
   if (bn_on()) reuse = false;       // the D-run's update ops changed the generator's renorm state: its forward differs now
   if (reuse) {
     if (!g_fwd_valid || T != cur_T) { set_error("reuse_g_forward without a valid generator forward"); return RSRGAN_ERR_STATE; }

@@ -1079,7 +1079,7 @@ void Model::g_forward_tail(int T, hipStream_t s) {   // y = outputs.W + b (model
   g_fwd_valid = true;
 }
 void Model::g_forward(int T, hipStream_t s, Chain* extra) {
-  if (g_dnn()) { g_frame_forward(T * B, s); g_fwd_valid = true; return; }
+  if (g_dnn()) { bn_eval_call = false; g_frame_forward(T * B, s); g_fwd_valid = true; return; }
   g_forward_head(T, s);
   std::vector<Chain> chains;
   chains.push_back(g_chain(T));

@@ -181,7 +181,10 @@ struct Model {
   float* fc_backward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, float* dtop,
                      bool want_wgrads, bool want_din, hipStream_t s, int calls = 1, int row0 = 0, int call0 = 0);
   bool bn_on() const { return (cfg.flags & RSRGAN_FLAG_BATCH_NORM) != 0; }
-  bool bn_training() const { return bn_on() && !cfg.cross_validation; }      // is_training (dnn.py:49-50)
+  // is_training (dnn.py:49-50): false on the cross_validation twin -- a model built with cross_validation=1, or a d/g run without
+  // gradients on the training model (those ARE the twin's fetches on the shared variables: train_gan_dnn.py:182-215)
+  bool bn_eval_call = false;
+  bool bn_training() const { return bn_on() && !cfg.cross_validation && !bn_eval_call; }
   BnVars bn_vars(const ParamSet& ps, const FcLayer& F) const;
   BnVars bn_vars(const ParamSet& ps, const int (&tbn)[8]) const;
   void bn_commit_stack(const ParamSet& ps, const std::vector<FcLayer>& L, int call, int times, hipStream_t s);

@@ -24,6 +24,10 @@ from . import dist as rdist
 NET_G, NET_D = 0, 1
 
 
+def _bn_statistic(name):
+    return "/BatchNorm/" in name and name.rsplit("/", 1)[-1] not in ("beta", "gamma")
+
+
 class Model(object):
     """Base class (gan_rnn_placeholder.py:21-60): save / load with tf.train.Saver semantics
     (max_to_keep=10, `checkpoint` state file naming the latest), stored as .npz keyed by the
@@ -105,7 +109,8 @@ class Model(object):
             table = self.engine.tensor_table(net)
             flat = np.zeros(self.engine.param_count(net), np.float32)
             for name, shape, off in table:
-                key = name + "/ExponentialMovingAverage" if moving_average else name
+                # (batch-norm statistics are no trainable variables: variable_averages.apply(g_vars) has no shadow of them)
+                key = name + "/ExponentialMovingAverage" if moving_average and not _bn_statistic(name) else name
                 flat[off:off + int(np.prod(shape))] = data[key].reshape(-1)
             self.engine.set_params(net, flat, "variables")
             if not moving_average and self.ema_enabled and (table[0][0] + "/ExponentialMovingAverage") in data:

@@ -107,3 +107,65 @@ class PaddedBatchReader(object):
     def __iter__(self) -> Iterator[List]:
         for indices in self.plan():
             yield self.materialize(indices)
+
+
+class FrameBatchReader(object):
+    """get_batch of the frame-level recipes (io_funcs/tfrecords_io.py:206-255) without TFRecords: every utterance is normalised,
+    spliced and its frames `enqueue_many`-ed into a tf.RandomShuffleQueue(capacity = 1000 + (num_threads + 1) * batch_size,
+    min_after_dequeue = 1000); `dequeue_many(batch_size)` draws that many frames uniformly at random from the queue.  Yields
+    [inputs [N, D*(L+1+R)] f32, labels [N, Dout] f32].  Utterances are visited in shuffled order once per pass
+    (string_input_producer(shuffle=True, num_epochs)); the frames left over at the end of the data that do not fill a batch are
+    dropped, as dequeue_many does when the queue closes."""
+
+    def __init__(self, inputs_scp, labels_scp, batch_size, left_context=0, right_context=0, cmvn=None, num_threads=4,
+                 shuffle=True, seed=None):
+        self.inputs, self.labels = ArkReader(), ArkReader()
+        self.inputs(inputs_scp)
+        self.labels(labels_scp)
+        assert self.inputs.utt_ids == self.labels.utt_ids, "inputs_utt_id == labels_utt_id (make_tfrecords.py:35)"
+        self.batch_size, self.left, self.right, self.cmvn, self.shuffle = batch_size, left_context, right_context, cmvn, shuffle
+        self.capacity = 1000 + (num_threads + 1) * batch_size
+        self.min_after_dequeue = 1000 if shuffle else 0
+        self.rng = np.random.default_rng(seed)
+
+    def num_frames(self):
+        return sum(self.inputs.utt_shape_from_index(i)[0] for i in range(len(self.inputs.utt_ids)))
+
+    def num_batches(self):
+        """get_num_batch (train_gan_dnn.py:346-370) counts dequeued batches of one pass: floor(frames / batch_size)."""
+        return self.num_frames() // self.batch_size
+
+    def _utt(self, i):
+        x = self.inputs.read_utt_data_from_index(i).astype(np.float64)
+        y = self.labels.read_utt_data_from_index(i).astype(np.float64)
+        if self.cmvn is not None:
+            x, y = apply_cmvn(x, y, self.cmvn)
+        return splice_feats(x, self.left, self.right).astype(np.float32), y.astype(np.float32)
+
+    def __iter__(self):
+        order = np.arange(len(self.inputs.utt_ids))
+        if self.shuffle:
+            self.rng.shuffle(order)
+        qx, qy, held = [], [], 0                   # the queue as a list of per-utterance blocks + how many frames it holds
+        todo = list(order)
+        N = self.batch_size
+
+        def draw():
+            nonlocal qx, qy, held
+            X, Y = np.concatenate(qx), np.concatenate(qy)
+            pick = self.rng.choice(held, N, replace=False) if self.shuffle else np.arange(N)
+            keep = np.ones(held, bool); keep[pick] = False
+            bx, by = X[pick], Y[pick]
+            qx, qy, held = [X[keep]], [Y[keep]], held - N
+            return [bx, by]
+        while todo or held >= N:
+            # the enqueuing threads keep the queue as full as its capacity allows (an utterance is enqueued when it fits)
+            while todo and (held == 0 or held + self.inputs.utt_shape_from_index(int(todo[0]))[0] <= self.capacity):
+                x, y = self._utt(int(todo.pop(0)))
+                qx.append(x); qy.append(y); held += x.shape[0]
+            if held >= N and (held - N >= self.min_after_dequeue or not todo):
+                yield draw()
+            elif not todo:
+                break
+            elif held >= N:                        # an utterance longer than the room left: dequeue first, as a blocked enqueue would wait
+                yield draw()

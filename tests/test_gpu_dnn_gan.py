@@ -200,8 +200,14 @@ def test_frame_level_gan_batch_norm_renorm(N):
     for k, v in m.get_vars()[0].items():                    # the statistics are no trainable variables: Adam leaves them alone
         if k.endswith("renorm_mean_weight"):
             assert np.isclose(float(v), float(o.g[k]), rtol=1e-5)
+    # train=False on the training model IS the cross_validation twin's fetch on the shared variables: moving statistics, no L2, no update
+    assert np.allclose(np.ravel(m.d_step(x2, lab, train=False)), o.d_step(x2, lab, train=False), rtol=2e-4)
+    ev = np.ravel(m.g_step(x2, lab, train=False))
+    assert np.allclose(ev, o.g_step(x2, lab, train=False), rtol=2e-4) and ev[2] == 0.0
+    _cmp_vars(m, o)
     # the cross_validation twin shares the variables and normalises with the moving statistics (is_training=False)
     mcv, ocv = _bn_pair(cfg, N, seed=0, cross_validation=True, g=o.g, d=o.d)
+    assert np.allclose(np.ravel(mcv.g_step(x2, lab, train=False)), ev, rtol=1e-5)
     assert np.allclose(np.ravel(mcv.d_step(x, lab, train=False)), ocv.d_step(x, lab, train=False), rtol=2e-4)
     assert np.allclose(np.ravel(mcv.g_step(x, lab, train=False)), ocv.g_step(x, lab, train=False), rtol=2e-4)
     assert np.abs(mcv.forward(x) - ocv.forward(x)).max() < 2e-4

@@ -2,6 +2,8 @@
 in supervised mode: g_loss = 0.5*Dout*mse + l2, Adam, clip 15 (RNN) / none (DNN)."""
 from types import SimpleNamespace
 
+import os
+
 import numpy as np
 import pytest
 
@@ -341,3 +343,51 @@ def test_rced_gan_full_size_properties():
         acc_g += half.engine.get_grads(NET_G).cpu().numpy() / 2
     assert np.allclose(acc_dl, dl, rtol=1e-4) and np.allclose(acc_l, gl, rtol=1e-4), (acc_dl, dl, acc_l, gl)
     assert rel_err(acc_g, gg) < 1e-3
+
+
+def test_frame_level_outer_loop_on_gpu(tmp_path):
+    """scripts/train_gan_dnn.py end to end on the HIP path with --batch_norm=true: epochs of D-runs / G-runs on fresh random-shuffle
+    batches, the cross_validation fetches, accept / reject with checkpoints, the decay rule, then decode -> feats.ark with the
+    moving averages of the trainable variables and the batch-norm statistics."""
+    from rsrgan_amd import run_gan_dnn as RD
+    from rsrgan_amd.io import ArkReader, ArkWriter
+    rng = np.random.default_rng(0)
+    din, dout = 6, 4
+    A = rng.standard_normal((din, dout)) * 0.5
+
+    def data(tag, n):
+        wi, wl = ArkWriter(str(tmp_path / (tag + "_in.scp"))), ArkWriter(str(tmp_path / (tag + "_lab.scp")))
+        for i in range(n):
+            T = int(rng.integers(60, 100))
+            x = rng.standard_normal((T, din)) * 2 + 1
+            wi.write_next_utt(str(tmp_path / (tag + "_in.ark")), "%s%02d" % (tag, i), x)
+            wl.write_next_utt(str(tmp_path / (tag + "_lab.ark")), "%s%02d" % (tag, i), (x - 1) / 2 @ A - 1)
+        wi.close(); wl.close()
+        return str(tmp_path / (tag + "_in.scp")), str(tmp_path / (tag + "_lab.scp"))
+    tr, cv, te = data("tr", 40), data("cv", 8), data("te", 3)
+    np.savez(tmp_path / "train_cmvn.npz", mean_inputs=np.full(din, 1.0), stddev_inputs=np.full(din, 2.0),
+             mean_labels=np.full(dout, -1.0), stddev_labels=np.ones(dout))
+    FLAGS, _ = RD.build_parser().parse_known_args([
+        "--data_dir", str(tmp_path), "--tr_inputs_scp", tr[0], "--tr_labels_scp", tr[1], "--cv_inputs_scp", cv[0], "--cv_labels_scp", cv[1],
+        "--test_inputs_scp", te[0], "--input_dim", str(din), "--output_dim", str(dout), "--left_context", "1", "--right_context", "1",
+        "--batch_size", "64", "--min_epoches", "2", "--max_epoches", "4", "--keep_lr", "1", "--save_dir", str(tmp_path / "exp"),
+        "--g_learning_rate", "0.003", "--d_learning_rate", "0.001", "--batch_norm", "true", "--init_mse_weight", "10", "--num_threads", "2",
+        "--gen_updates", "2"])
+    ov = dict(g_layers=2, g_cells=32, d_layers=2, d_cells=16)
+    logs = []
+    hist = RD.train(FLAGS, log=logs.append, net_overrides=ov)
+    text = "\n".join(logs)
+    assert 1 <= len(hist) <= 4 and np.all(np.isfinite(hist))
+    assert "CROSSVAL.LOSS PRERUN" in text and "Nnet Accepted" in text and "Training Done." in text
+    assert os.path.exists(tmp_path / "exp" / "checkpoint") and os.path.exists(tmp_path / "batch_num.txt")
+    first = float(text.split("CROSSVAL.LOSS PRERUN")[1].split("g_mse_loss = ")[1].split(",")[0])
+    last = float(text.split("(CROSS AVG.LOSS)")[-1].split("g_mse_loss = ")[1].split(",")[0])
+    assert last < 0.7 * first, (first, last)                 # the supervised term learns the linear map
+    FLAGS.decode = True
+    scp = RD.decode(FLAGS, log=logs.append, net_overrides=ov)
+    r, src = ArkReader(), ArkReader()
+    r(scp); src(te[0])
+    assert r.utt_ids == src.utt_ids
+    for i in range(len(r.utt_ids)):
+        out = r.read_utt_data_from_index(i)
+        assert out.shape == (src.read_utt_data_from_index(i).shape[0], dout) and np.all(np.isfinite(out))
