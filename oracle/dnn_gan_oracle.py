@@ -185,7 +185,7 @@ class GanDnnOracle:
     def training(self):
         """is_training of the batch-norm layers: False on the cross_validation twin (dnn.py:49-50, discriminator_dnn.py:29).
         d_step / g_step with train=False ARE that twin's fetches on the shared variables (train_gan_dnn.py:182-215 runs them on
-        cv_model), so they normalise with the moving statistics too."""
+        cv_model), so they normalise with the moving statistics too and carry no L2 term (gan.py:207)."""
         return not self.cross_validation and not self._eval_call
 
     # generator hooks (overridden by oracle/rced_oracle.py for the R-CED generator)
@@ -247,7 +247,7 @@ class GanDnnOracle:
                 d_real_acts = d_forward(cfg, self.d, np.concatenate([self._d_inputs(x), lab], 1), True)[2]
         e = y - lab
         g_mse = float(0.5 * np.mean(e * e) * cfg.output_dim)
-        if (not self.cross_validation) and self.l2_scale > 0:
+        if self.training and self.l2_scale > 0:
             g_l2 = self.l2_scale * sum(0.5 * float(np.sum(v * v)) for k, v in self.g.items() if k.endswith("weights"))
         else:
             g_l2 = 0.0
@@ -260,7 +260,7 @@ class GanDnnOracle:
                 djoint, _ = fc_stack_bwd(self.d, "d_model", cfg.d_hidden + 1, dacts, draw, want_dx=True)
                 dy = dy + djoint[:, cfg.input_dim:]
             grads = self._g_bwd(gacts, dy)
-            if g_l2 != 0.0 or ((not self.cross_validation) and self.l2_scale > 0):
+            if g_l2 != 0.0 or (self.training and self.l2_scale > 0):
                 for k in grads:
                     if k.endswith("weights"):
                         grads[k] = grads[k] + self.l2_scale * self.g[k]
