@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -181,6 +182,148 @@ __global__ __launch_bounds__(256) void k_bn_commit(int cols, BnVars v, const flo
   }
 }
 
+// ---- few rows (the shipped frame-level batch: 256 frames): one launch per direction.  A workgroup owns 16 columns and all rows of
+// every call (the discriminator's real | fake halves are consecutive calls): 16 row lanes sum a column, LDS reduces them in a fixed
+// order, the column threads finish the moments / gradients, then the workgroup re-reads its (L2-resident) columns for the
+// elementwise pass. ----
+static int bn_small_rows() { static int v = -1; if (v < 0) { const char* e = getenv("RSRGAN_BN_SMALL_ROWS"); v = e ? atoi(e) : 384; } return v; }
+
+constexpr int BNS_CW = 16, BNS_RL = 16;          // small path: 16 columns x 16 row lanes per workgroup (cols / 16 workgroups)
+
+__device__ __forceinline__ float bns_reduce(float (*red)[BNS_CW], int l) {      // fixed-order sum over the row lanes
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < BNS_RL; ++i) t += red[i][l];
+  return t;
+}
+
+__global__ __launch_bounds__(256) void k_bn_fwd_small(const float* __restrict__ z, int ldz, float* __restrict__ y, int ldy, int rows, int cols,
+                                                      int calls, BnVars v, float* __restrict__ stat, int ldc, int training, int relu) {
+  __shared__ float red[2][BNS_RL][BNS_CW];
+  __shared__ float ab[2][BNS_CW];
+  const int l = threadIdx.x & (BNS_CW - 1), rl = threadIdx.x / BNS_CW, c = blockIdx.x * BNS_CW + l;
+  const bool cok = c < cols;
+  for (int k = 0; k < calls; ++k) {
+    const float* zk = z + (size_t)k * rows * ldz;
+    float* yk = y + (size_t)k * rows * ldy;
+    float* st = stat + (size_t)k * BN_STAT_ROWS * ldc;
+    if (training) {
+      float s1 = 0.f, s2 = 0.f;
+      const float z0 = cok ? zk[c] : 0.f;
+      if (cok) {
+#pragma unroll 8
+        for (int r = rl; r < rows; r += BNS_RL) { const float d = zk[(size_t)r * ldz + c] - z0; s1 += d; s2 += d * d; }
+      }
+      red[0][rl][l] = s1; red[1][rl][l] = s2;
+      __syncthreads();
+      if (rl == 0 && cok) {
+        const double t1 = (double)bns_reduce(red[0], l), t2 = (double)bns_reduce(red[1], l);
+        const double m0 = t1 / rows, var = fmax(t2 / rows - m0 * m0, 0.0), mean = (double)z0 + m0, sd = sqrt(var + (double)BN_EPS);
+        const double mixed_mean = (double)v.rm[c] + (1.0 - (double)v.rmw[0]) * mean;
+        const double mixed_sd = (double)v.rs[c] + (1.0 - (double)v.rsw[0]) * sd;
+        const double r = sd / mixed_sd, d = (mean - mixed_mean) / mixed_sd, g = v.gamma[c], a = r * g / sd;
+        const float af = (float)a, bf = (float)(d * g + (double)v.beta[c] - mean * a);
+        st[c] = (float)mean; st[ldc + c] = (float)sd; st[2 * ldc + c] = (float)r; st[3 * ldc + c] = (float)d;
+        st[4 * ldc + c] = af; st[5 * ldc + c] = bf;
+        ab[0][l] = af; ab[1][l] = bf;
+      }
+    } else if (rl == 0 && cok) {
+      const double a = (double)v.gamma[c] / sqrt((double)v.mv[c] + (double)BN_EPS);
+      const float af = (float)a, bf = (float)((double)v.beta[c] - (double)v.mm[c] * a);
+      st[4 * ldc + c] = af; st[5 * ldc + c] = bf;
+      ab[0][l] = af; ab[1][l] = bf;
+    }
+    __syncthreads();
+    if (cok) {
+      const float a = ab[0][l], b = ab[1][l];
+#pragma unroll 8
+      for (int r = rl; r < rows; r += BNS_RL) {
+        const float o = zk[(size_t)r * ldz + c] * a + b;
+        yk[(size_t)r * ldy + c] = relu ? fmaxf(o, 0.f) : o;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_bwd_small(float* __restrict__ dy, int ldd, const float* __restrict__ y, int ldy,
+                                                      const float* __restrict__ z, int ldz, int rows, int cols, int calls,
+                                                      const float* __restrict__ stat, int ldc, float* __restrict__ dbeta,
+                                                      float* __restrict__ dgamma, int relu) {
+  __shared__ float red[2][BNS_RL][BNS_CW];
+  __shared__ float ms[2][BNS_CW];
+  const int l = threadIdx.x & (BNS_CW - 1), rl = threadIdx.x / BNS_CW, c = blockIdx.x * BNS_CW + l;
+  const bool cok = c < cols;
+  double gb = 0.0, gg = 0.0;                       // (column thread rl == 0: dbeta / dgamma summed over the calls in call order)
+  for (int k = 0; k < calls; ++k) {
+    float* dk = dy + (size_t)k * rows * ldd;
+    const float* yk = y + (size_t)k * rows * ldy;
+    const float* zk = z + (size_t)k * rows * ldz;
+    const float* st = stat + (size_t)k * BN_STAT_ROWS * ldc;
+    const float mean = cok ? st[c] : 0.f, isd = cok ? 1.f / st[ldc + c] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (cok) {
+#pragma unroll 8
+      for (int r = rl; r < rows; r += BNS_RL) {
+        float g = dk[(size_t)r * ldd + c];
+        if (relu && !(yk[(size_t)r * ldy + c] > 0.f)) g = 0.f;
+        s1 += g; s2 += g * ((zk[(size_t)r * ldz + c] - mean) * isd);
+      }
+    }
+    red[0][rl][l] = s1; red[1][rl][l] = s2;
+    __syncthreads();
+    if (rl == 0 && cok) {
+      const double t1 = (double)bns_reduce(red[0], l), t2 = (double)bns_reduce(red[1], l);
+      gb += t1; gg += (double)st[2 * ldc + c] * t2 + (double)st[3 * ldc + c] * t1;
+      ms[0][l] = (float)(t1 / rows); ms[1][l] = (float)(t2 / rows);
+    }
+    __syncthreads();
+    if (cok) {
+      const float a = st[4 * ldc + c], m1 = ms[0][l], m2 = ms[1][l];
+#pragma unroll 8
+      for (int r = rl; r < rows; r += BNS_RL) {
+        float g = dk[(size_t)r * ldd + c];
+        if (relu && !(yk[(size_t)r * ldy + c] > 0.f)) g = 0.f;
+        dk[(size_t)r * ldd + c] = a * (g - m1 - (zk[(size_t)r * ldz + c] - mean) * isd * m2);
+      }
+    }
+    __syncthreads();
+  }
+  if (dbeta && rl == 0 && cok) { dbeta[c] = (float)gb; dgamma[c] = (float)gg; }
+}
+
+// several layers' update ops in one launch (blockIdx.x = entry)
+__global__ __launch_bounds__(256) void k_bn_commit_many(BnCommitList cl) {
+  const BnCommit e = cl.e[blockIdx.x];
+  const BnVars& v = e.v;
+  const double w_mean0 = v.rmw[0], w_sd0 = v.rsw[0];
+  __syncthreads();
+  for (int c = threadIdx.x; c < e.cols; c += 256) {
+    double rm = v.rm[c], rs = v.rs[c], mm = v.mm[c], mv = v.mv[c], wm = w_mean0, ws = w_sd0;
+    for (int u = 0; u < 2; ++u) {                 // update 0: call 0 `times0` times, update 1: call 1 `times1` times
+      if ((u == 0 ? e.times0 : e.times1) == 0) continue;          // (single-call layers have no second statistics slot)
+      const float* st = e.stat + (size_t)u * BN_STAT_ROWS * e.ldc;
+      const double mean = st[c], sd = st[e.ldc + c];
+      for (int t = 0; t < (u == 0 ? e.times0 : e.times1); ++t) {
+        rm -= (rm - mean) * (1.0 - BN_RENORM_DECAY); wm -= (wm - 1.0) * (1.0 - BN_RENORM_DECAY);
+        rs -= (rs - sd) * (1.0 - BN_RENORM_DECAY); ws -= (ws - 1.0) * (1.0 - BN_RENORM_DECAY);
+        const double new_mean = rm / wm, new_sd = rs / ws;
+        mm -= (mm - new_mean) * (1.0 - BN_DECAY);
+        mv -= (mv - (new_sd * new_sd - (double)BN_EPS)) * (1.0 - BN_DECAY);
+      }
+    }
+    v.rm[c] = (float)rm; v.rs[c] = (float)rs; v.mm[c] = (float)mm; v.mv[c] = (float)mv;
+  }
+  if (threadIdx.x == 0) {
+    double wm = w_mean0, ws = w_sd0;
+    for (int t = 0; t < e.times0 + e.times1; ++t) { wm -= (wm - 1.0) * (1.0 - BN_RENORM_DECAY); ws -= (ws - 1.0) * (1.0 - BN_RENORM_DECAY); }
+    v.rmw[0] = (float)wm; v.rsw[0] = (float)ws;
+  }
+}
+void launch_bn_commit_many(const BnCommitList& cl, hipStream_t s) {
+  if (cl.n > 0) hipLaunchKernelGGL(k_bn_commit_many, dim3(cl.n), dim3(256), 0, s, cl);
+}
+
 static int bn_slices(int rows, int cols, size_t scratch_floats, int* per) {
   int slices = (int)std::min<size_t>(512, scratch_floats / ((size_t)2 * std::max(cols, 1)));
   slices = std::max(1, std::min(slices, (rows + 63) / 64));
@@ -188,8 +331,17 @@ static int bn_slices(int rows, int cols, size_t scratch_floats, int* per) {
   return (rows + *per - 1) / *per;
 }
 
+// `calls` consecutive calls of `rows` rows each (statistics slots 0 .. calls-1 of `stat`)
 void launch_bn_forward(const float* z, int ldz, float* y, int ldy, int rows, int cols, const BnVars& v, float* stat, int ldc, bool training,
-                       bool relu, float* scratch, size_t scratch_floats, hipStream_t s) {
+                       bool relu, float* scratch, size_t scratch_floats, hipStream_t s, int calls) {
+  if (rows <= bn_small_rows() && cols >= 64) {
+    hipLaunchKernelGGL(k_bn_fwd_small, dim3((cols + BNS_CW - 1) / BNS_CW), dim3(256), 0, s, z, ldz, y, ldy, rows, cols, calls, v, stat, ldc,
+                       training ? 1 : 0, relu ? 1 : 0);
+    return;
+  }
+  for (int k = 1; k < calls; ++k)
+    launch_bn_forward(z + (size_t)k * rows * ldz, ldz, y + (size_t)k * rows * ldy, ldy, rows, cols, v, stat + (size_t)k * BN_STAT_ROWS * ldc, ldc,
+                      training, relu, scratch, scratch_floats, s, 1);
   if (training) {
     int per;
     const int slices = bn_slices(rows, cols, scratch_floats, &per);
@@ -208,7 +360,20 @@ void launch_bn_forward(const float* z, int ldz, float* y, int ldy, int rows, int
 // dbeta / dgamma may be null (data gradient only).  sums: 2*ldc floats of work space.
 void launch_bn_backward(float* dy, int ldd, const float* y, int ldy, const float* z, int ldz, int rows, int cols, const float* stat, int ldc,
                         float* dbeta, float* dgamma, bool accumulate, bool relu, float* sums, float* scratch, size_t scratch_floats,
-                        hipStream_t s) {
+                        hipStream_t s, int calls) {
+  if (rows <= bn_small_rows() && cols >= 64 && !accumulate) {
+    hipLaunchKernelGGL(k_bn_bwd_small, dim3((cols + BNS_CW - 1) / BNS_CW), dim3(256), 0, s, dy, ldd, y, ldy, z, ldz, rows, cols, calls, stat, ldc, dbeta,
+                       dgamma, relu ? 1 : 0);
+    return;
+  }
+  // (call 0 assigns dbeta / dgamma, the later calls accumulate: the order of the small path)
+  if (calls > 1) {
+    launch_bn_backward(dy, ldd, y, ldy, z, ldz, rows, cols, stat, ldc, dbeta, dgamma, accumulate, relu, sums, scratch, scratch_floats, s, 1);
+    for (int k = 1; k < calls; ++k)
+      launch_bn_backward(dy + (size_t)k * rows * ldd, ldd, y + (size_t)k * rows * ldy, ldy, z + (size_t)k * rows * ldz, ldz, rows, cols,
+                         stat + (size_t)k * BN_STAT_ROWS * ldc, ldc, dbeta, dgamma, true, relu, sums, scratch, scratch_floats, s, 1);
+    return;
+  }
   int per;
   const int slices = bn_slices(rows, cols, scratch_floats, &per);
   hipLaunchKernelGGL(k_bn_bwd1, dim3((cols + 63) / 64, slices), dim3(256), 0, s, dy, ldd, y, ldy, z, ldz, stat, ldc, rows, cols, per,

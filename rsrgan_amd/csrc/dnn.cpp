@@ -36,18 +36,15 @@ void Model::fc_forward(const ParamSet& ps, const std::vector<FcLayer>& L, const 
     }
     // relu(batch_norm(x.W)): the product once over all rows, the normaliser once per call (each call has its own batch moments)
     gemm(act[l], F.ld_in, true, ps.W(F.tW), F.ld_out, false, F.pre, F.ld_out, rows, F.out, F.in, nullptr, 0, 0.f, false, s);
-    const int per = rows / calls;
-    const BnVars v = bn_vars(ps, F);
-    for (int k = 0; k < calls; ++k)
-      launch_bn_forward(F.pre + (size_t)k * per * F.ld_out, F.ld_out, act[l + 1] + (size_t)k * per * F.ld_out, F.ld_out, per, F.out, v,
-                        F.stat + (size_t)k * BN_STAT_ROWS * F.ld_out, F.ld_out, bn_training(), true, scratch, scratch_floats, s);
+    launch_bn_forward(F.pre, F.ld_out, act[l + 1], F.ld_out, rows / calls, F.out, bn_vars(ps, F), F.stat, F.ld_out, bn_training(), true,
+                      scratch, scratch_floats, s, calls);
   }
 }
 
-// the UPDATE_OPS of call `call` of every batch-norm layer of the stack, `times` times (oracle/bn_renorm.py: order of the updates)
-void Model::bn_commit_stack(const ParamSet& ps, const std::vector<FcLayer>& L, int call, int times, hipStream_t s) {
+// the UPDATE_OPS of every batch-norm layer of the stack: call 0 `times0` times, then call 1 `times1` times (oracle/bn_renorm.py)
+void Model::bn_commit_stack(const ParamSet& ps, const std::vector<FcLayer>& L, int times0, int times1, BnCommitList& cl) {
   for (const FcLayer& F : L)
-    if (F.bn) launch_bn_commit(F.out, bn_vars(ps, F), F.stat + (size_t)call * BN_STAT_ROWS * F.ld_out, F.ld_out, times, s);
+    if (F.bn && cl.n < 24) cl.e[cl.n++] = BnCommit{bn_vars(ps, F), F.stat, F.out, F.ld_out, times0, times1};
 }
 
 // dtop: gradient w.r.t. the stack's (linear) output, [rows][ld_out of the last layer].  Returns the gradient w.r.t.
@@ -62,13 +59,10 @@ float* Model::fc_backward(const ParamSet& ps, const std::vector<FcLayer>& L, con
     const FcLayer& F = L[l];
     const float* a_in = act[l] + (size_t)row0 * F.ld_in;
     if (F.bn) {                            // d (w.r.t. the ReLU's output) -> gradient w.r.t. x.W, per call; dbeta / dgamma summed over the calls
-      const int per = rows / calls;
-      for (int k = 0; k < calls; ++k) {
-        const size_t ro = (size_t)k * per * F.ld_out, ra = ((size_t)row0 + (size_t)k * per) * F.ld_out;
-        launch_bn_backward(d + ro, F.ld_out, act[l + 1] + ra, F.ld_out, F.pre + ra, F.ld_out, per, F.out,
-                           F.stat + (size_t)(call0 + k) * BN_STAT_ROWS * F.ld_out, F.ld_out, want_wgrads ? ps.Gd(F.tbn[0]) : nullptr,
-                           want_wgrads ? ps.Gd(F.tbn[1]) : nullptr, k > 0, true, bn_sums, scratch, scratch_floats, s);
-      }
+      const size_t ra = (size_t)row0 * F.ld_out;
+      launch_bn_backward(d, F.ld_out, act[l + 1] + ra, F.ld_out, F.pre + ra, F.ld_out, rows / calls, F.out,
+                         F.stat + (size_t)call0 * BN_STAT_ROWS * F.ld_out, F.ld_out, want_wgrads ? ps.Gd(F.tbn[0]) : nullptr,
+                         want_wgrads ? ps.Gd(F.tbn[1]) : nullptr, false, true, bn_sums, scratch, scratch_floats, s, calls);
     } else if (l + 1 < (int)L.size()) {
       launch_lrelu_bwd(act[l + 1] + (size_t)row0 * F.ld_out, d, (size_t)rows, F.out, F.ld_out, 0.f, s);   // relu': d *= [h > 0]
     }
@@ -165,10 +159,12 @@ void Model::g_frame_backward(int rows, float* dy, hipStream_t s) {
 // every training sess.run executes all batch-norm update ops of the graph (gan.py:139-146): the generator's call twice, the
 // discriminator's real-joint call twice (dummy + real, gan.py:162-181) and its fake-joint call once -- oracle/bn_renorm.py
 void Model::bn_commit_run(bool with_d, hipStream_t s) {
-  bn_commit_stack(G, gfc, 0, 2, s);
+  BnCommitList cl; cl.n = 0;
+  bn_commit_stack(G, gfc, 2, 0, cl);
   for (const ConvLayer& L : gconv)
-    if (L.bn) launch_bn_commit(L.Cout, bn_vars(G, L.tbn), L.stat, L.ldCout, 2, s);
-  if (with_d) { bn_commit_stack(D, dfc, 0, 2, s); bn_commit_stack(D, dfc, 1, 1, s); }
+    if (L.bn && cl.n < 24) cl.e[cl.n++] = BnCommit{bn_vars(G, L.tbn), L.stat, L.Cout, L.ldCout, 2, 0};
+  if (with_d) bn_commit_stack(D, dfc, 2, 1, cl);
+  launch_bn_commit_many(cl, s);
 }
 
 void Model::d_dnn_forward_loss(int T, int Nd, int n_real, bool want_grads, float* loss3, hipStream_t s, int calls) {

@@ -221,12 +221,16 @@ struct BnVars {           // one layer's <scope>/BatchNorm/* variables (device p
   float *mm, *mv, *rm, *rmw, *rs, *rsw;                  // moving_mean, moving_variance, renorm_mean, renorm_mean_weight [1], renorm_stddev, renorm_stddev_weight [1]
 };
 constexpr int BN_STAT_ROWS = 6;                          // per call: mean, stddev, r, d, a, b   (y = z*a + b), each [ldc]
+// `calls` consecutive calls of `rows` rows each with their own batch moments (statistics slots 0 .. calls-1 of `stat`)
 void launch_bn_forward(const float* z, int ldz, float* y, int ldy, int rows, int cols, const BnVars& v, float* stat, int ldc, bool training,
-                       bool relu, float* scratch, size_t scratch_floats, hipStream_t s);
+                       bool relu, float* scratch, size_t scratch_floats, hipStream_t s, int calls = 1);
 void launch_bn_backward(float* dy, int ldd, const float* y, int ldy, const float* z, int ldz, int rows, int cols, const float* stat, int ldc,
                         float* dbeta, float* dgamma, bool accumulate, bool relu, float* sums, float* scratch, size_t scratch_floats,
-                        hipStream_t s);
+                        hipStream_t s, int calls = 1);
 void launch_bn_commit(int cols, const BnVars& v, const float* stat, int ldc, int times, hipStream_t s);
+struct BnCommit { BnVars v; const float* stat; int cols, ldc, times0, times1; };   // update ops: call 0 x times0, then call 1 x times1
+struct BnCommitList { int n; BnCommit e[24]; };
+void launch_bn_commit_many(const BnCommitList& cl, hipStream_t s);
 void launch_colsum(const float* a, int lda, const float* b, int ldb, float* out, int rows, int cols,
                    float* scratch /* >= 64*cols floats */, hipStream_t s);
 

@@ -187,7 +187,7 @@ struct Model {
   bool bn_training() const { return bn_on() && !cfg.cross_validation && !bn_eval_call; }
   BnVars bn_vars(const ParamSet& ps, const FcLayer& F) const;
   BnVars bn_vars(const ParamSet& ps, const int (&tbn)[8]) const;
-  void bn_commit_stack(const ParamSet& ps, const std::vector<FcLayer>& L, int call, int times, hipStream_t s);
+  void bn_commit_stack(const ParamSet& ps, const std::vector<FcLayer>& L, int times0, int times1, BnCommitList& cl);
   float* bn_sums = nullptr;      // [2][max ld_out] work space of launch_bn_backward
   void d_dnn_forward_loss(int T, int Nd, int n_real, bool want_grads, float* loss3, hipStream_t s, int calls = 1);
   void bn_commit_run(bool with_d, hipStream_t s);
