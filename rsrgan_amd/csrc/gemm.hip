@@ -17,22 +17,27 @@ namespace rsr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;
+#ifndef RSR_GBK
+#define RSR_GBK 16
+#endif
+constexpr int GBK = RSR_GBK;          // k-tile of k_gemm; 32 measured equal (115-127 TF at 4096^3, 79-87 at 6400x3040x280) at lower occupancy
 
 // Load a 128(x) x 16(k) operand tile into registers (2 float4 per thread).
 //  KC  (k contiguous): element(x,k) = P[x*ld + k]  -> thread: x = idx>>2, k4 = (idx&3)*4
 //  !KC (x contiguous): element(x,k) = P[k*ld + x]  -> thread: k = idx>>5, x4 = (idx&31)*4
 // `P2`/`ld2`/`X1` (x-contiguous operands only): rows x >= X1 of the operand come from a second matrix P2 (column
 // x - X1); X1 % 4 == 0 so a float4 never straddles.  This is how dK = [x_t | m_{t-1}]^T dZ reads its two stashes.
+constexpr int GNF = BM * GBK / 4 / 256;      // float4 per thread and operand tile
 template <bool KC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int x0, int X, int k0, int K,
-                                          int tid, float4 (&r)[2], const float* __restrict__ P2 = nullptr, int ld2 = 0,
+                                          int tid, float4 (&r)[GNF], const float* __restrict__ P2 = nullptr, int ld2 = 0,
                                           int X1 = 0) {
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < GNF; ++u) {
     const int idx = tid + 256 * u;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (KC) {
-      const int x = x0 + (idx >> 2), k = k0 + (idx & 3) * 4;
+      const int x = x0 + idx / (GBK / 4), k = k0 + (idx % (GBK / 4)) * 4;
       if (x < X && k < K) v = *reinterpret_cast<const float4*>(P + (size_t)x * ld + k);   // k..k+3 < ld (zero pad)
     } else {
       const int k = k0 + (idx >> 5), x = x0 + (idx & 31) * 4;
@@ -44,12 +49,12 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
   }
 }
 template <bool KC>
-__device__ __forceinline__ void store_tile(float (*S)[LDT], int tid, const float4 (&r)[2]) {
+__device__ __forceinline__ void store_tile(float (*S)[LDT], int tid, const float4 (&r)[GNF]) {
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < GNF; ++u) {
     const int idx = tid + 256 * u;
     if (KC) {
-      const int x = idx >> 2, k = (idx & 3) * 4;
+      const int x = idx / (GBK / 4), k = (idx % (GBK / 4)) * 4;
       S[k + 0][x] = r[u].x; S[k + 1][x] = r[u].y; S[k + 2][x] = r[u].z; S[k + 3][x] = r[u].w;
     } else {
       const int k = idx >> 5, x = (idx & 31) * 4;
@@ -64,8 +69,8 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
                                               const float* __restrict__ bias, int act, float alpha, int accumulate,
                                               float* __restrict__ ws, int ldw, int kt_per_split,
                                               const float* __restrict__ A2, int lda2, int M1) {
-  __shared__ __attribute__((aligned(16))) float As[BK][LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
+  __shared__ __attribute__((aligned(16))) float As[GBK][LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[GBK][LDT];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -87,22 +92,22 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
 
   // split-K: blockIdx.z owns k-tiles [kt0, kt1); partial tiles go to ws[z][M][ldw] and are summed in
   // a fixed order by k_splitk_reduce (deterministic, unlike float atomics)
-  const int nk_all = (K + BK - 1) / BK;
+  const int nk_all = (K + GBK - 1) / GBK;
   const int kt0 = blockIdx.z * kt_per_split;
   const int nk = min(nk_all, kt0 + kt_per_split);
-  float4 ra[2], rb[2];
-  load_tile<AKC>(A, lda, m0, MA, kt0 * BK, KA, tid, ra, A2, lda2, M1);
-  load_tile<BKC>(B, ldb, n0, NB, kt0 * BK, KB, tid, rb);
+  float4 ra[GNF], rb[GNF];
+  load_tile<AKC>(A, lda, m0, MA, kt0 * GBK, KA, tid, ra, A2, lda2, M1);
+  load_tile<BKC>(B, ldb, n0, NB, kt0 * GBK, KB, tid, rb);
   for (int kt = kt0; kt < nk; ++kt) {
     store_tile<AKC>(As, tid, ra);
     store_tile<BKC>(Bs, tid, rb);
     __syncthreads();
     if (kt + 1 < nk) {
-      load_tile<AKC>(A, lda, m0, MA, (kt + 1) * BK, KA, tid, ra, A2, lda2, M1);
-      load_tile<BKC>(B, ldb, n0, NB, (kt + 1) * BK, KB, tid, rb);
+      load_tile<AKC>(A, lda, m0, MA, (kt + 1) * GBK, KA, tid, ra, A2, lda2, M1);
+      load_tile<BKC>(B, ldb, n0, NB, (kt + 1) * GBK, KB, tid, rb);
     }
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
+    for (int kk = 0; kk < GBK / 2; ++kk) {
       const int k = 2 * kk + lh;
       const float a0 = As[k][wr * 64 + l31], a1 = As[k][wr * 64 + 32 + l31];
       const float b0 = Bs[k][wc * 64 + l31], b1 = Bs[k][wc * 64 + 32 + l31];
@@ -256,14 +261,14 @@ __global__ __launch_bounds__(256) void k_gemm_n32(const float* __restrict__ A, i
 // Split-K factor for an under-filled output grid (weight gradients: few tiles, K = T*B).  Model: the busiest CU runs
 // ceil(tiles*s/256) workgroups of ceil(nk/s) k-tiles (~1.2 us each; 25 % slower when fewer than two workgroups per CU
 // hide each other's latency), then the reduce streams s partial images at ~4 TB/s.
-static int pick_splits(int tiles, int nk, size_t out_bytes, int max_splits) {
+static int pick_splits(int tiles, int nk, size_t out_bytes, int max_splits, double tile_us = 1.2, int min_per = 4) {
   int best = 1;
   double best_cost = 1e30;
   for (int sp = 1; sp <= max_splits; ++sp) {
     const int per = (nk + sp - 1) / sp;
-    if (sp > 1 && per < 4) break;
+    if (sp > 1 && per < min_per) break;
     const int wgs = tiles * sp;
-    double cost = (double)((wgs + 255) / 256) * per * 1.2 * (wgs < 512 ? 1.25 : 1.0);
+    double cost = (double)((wgs + 255) / 256) * per * tile_us * (wgs < 512 ? 1.25 : 1.0);
     if (sp > 1) cost += 2.8 + (double)(sp + 1) * out_bytes / 4.0e6;
     if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
   }
@@ -297,13 +302,13 @@ void launch_gemm2(const float* A, int lda, const float* A2, int lda2, int M1, bo
     return;
   }
   const int gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
-  const int nk = (K + BK - 1) / BK;
+  const int nk = (K + GBK - 1) / GBK;
   int splits = 1;
   const int ldw = (N + 3) & ~3;
-  if (ws && gx * gy < 192 && nk >= 8) {
+  if (ws && gx * gy < 192 && nk * GBK >= 128) {
     int cap = 64;
     while (cap > 1 && (size_t)cap * M * ldw > ws_floats) --cap;
-    splits = pick_splits(gx * gy, nk, (size_t)M * ldw * sizeof(float), cap);
+    splits = pick_splits(gx * gy, nk, (size_t)M * ldw * sizeof(float), cap, 1.2 * GBK / 16, GBK == 16 ? 4 : 2);
   }
   const int per = std::max(1, (nk + splits - 1) / splits);
   splits = std::max(1, (nk + per - 1) / per);
