@@ -8,7 +8,13 @@
 // As[k][m], Bs[k][n] (row stride 132 floats: 16-B aligned rows, 4-bank shift per k) so that the
 // MFMA fragment reads (lane l: row/col = l&31, k = l>>5) are 32 consecutive floats per half-wave
 // = conflict-free ds_read_b32.
+#include <dlfcn.h>
+#include <hipblaslt/hipblaslt.h>
+
 #include <algorithm>
+#include <array>
+#include <cstdlib>
+#include <map>
 
 #include "kernels.h"
 
@@ -275,10 +281,100 @@ static int pick_splits(int tiles, int nk, size_t out_bytes, int max_splits, doub
   return best;
 }
 
+// ---- plain library GEMM for the big epilogue-free products (weight gradients dK = [x|m]^T.dZ: 560 x 3040 x 6400, data gradients):
+// hipBLASLt, resolved at run time (dlopen; the header only supplies types).  Without the library, or with RSRGAN_BLAS=0,
+// everything stays on k_gemm.  One algorithm per (shape, layout), taken once from the heuristic and cached. ----
+namespace {
+struct LtPlan { hipblasLtMatmulDesc_t desc; hipblasLtMatrixLayout_t a, b, c; hipblasLtMatmulAlgo_t algo; size_t ws; bool ok; };
+struct Blas {
+  bool tried = false, ok = false;
+  hipblasLtHandle_t handle = nullptr;
+  void* ws = nullptr;
+  size_t ws_bytes = 32u << 20;
+  decltype(&hipblasLtCreate) create = nullptr;
+  decltype(&hipblasLtMatmulDescCreate) desc_create = nullptr;
+  decltype(&hipblasLtMatmulDescSetAttribute) desc_set = nullptr;
+  decltype(&hipblasLtMatrixLayoutCreate) layout_create = nullptr;
+  decltype(&hipblasLtMatmulPreferenceCreate) pref_create = nullptr;
+  decltype(&hipblasLtMatmulPreferenceSetAttribute) pref_set = nullptr;
+  decltype(&hipblasLtMatmulPreferenceDestroy) pref_destroy = nullptr;
+  decltype(&hipblasLtMatmulAlgoGetHeuristic) heuristic = nullptr;
+  decltype(&hipblasLtMatmul) matmul = nullptr;
+  std::map<std::array<int64_t, 8>, LtPlan> plans;
+};
+Blas g_blas;
+template <class F>
+bool lt_sym(void* lib, const char* name, F& f) { f = reinterpret_cast<F>(dlsym(lib, name)); return f != nullptr; }
+bool blas_ready() {
+  if (g_blas.tried) return g_blas.ok;
+  g_blas.tried = true;
+  const char* e = getenv("RSRGAN_BLAS");
+  if (e && atoi(e) == 0) return false;
+  void* lib = dlopen("libhipblaslt.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("libhipblaslt.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return false;
+  Blas& g = g_blas;
+  if (!lt_sym(lib, "hipblasLtCreate", g.create) || !lt_sym(lib, "hipblasLtMatmulDescCreate", g.desc_create) ||
+      !lt_sym(lib, "hipblasLtMatmulDescSetAttribute", g.desc_set) || !lt_sym(lib, "hipblasLtMatrixLayoutCreate", g.layout_create) ||
+      !lt_sym(lib, "hipblasLtMatmulPreferenceCreate", g.pref_create) || !lt_sym(lib, "hipblasLtMatmulPreferenceSetAttribute", g.pref_set) ||
+      !lt_sym(lib, "hipblasLtMatmulPreferenceDestroy", g.pref_destroy) || !lt_sym(lib, "hipblasLtMatmulAlgoGetHeuristic", g.heuristic) ||
+      !lt_sym(lib, "hipblasLtMatmul", g.matmul))
+    return false;
+  if (g.create(&g.handle) != HIPBLAS_STATUS_SUCCESS || !g.handle) return false;
+  if (hipMalloc(&g.ws, g.ws_bytes) != hipSuccess) { g.ws = nullptr; return false; }
+  g.ok = true;
+  return true;
+}
+// row-major C[M][N] = op(A).op(B)  ==  column-major C^T[N][M] = op(B)^T.op(A)^T: the library's first operand is B, its second A.
+// B stored [N][K] (k contiguous) is the column-major K x N matrix (transpose it), stored [K][N] it is N x K already;
+// A stored [M][K] is the column-major K x M matrix (as is), stored [K][M] it is M x K (transpose it).
+bool blas_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool b_kc, float* C, int ldc, int M, int N, int K, hipStream_t s) {
+  Blas& g = g_blas;
+  const std::array<int64_t, 8> key = {M, N, K, lda, ldb, ldc, a_kc ? 1 : 0, b_kc ? 1 : 0};
+  auto it = g.plans.find(key);
+  if (it == g.plans.end()) {
+    LtPlan p{}; p.ok = false;
+    const int32_t opB = b_kc ? HIPBLAS_OP_T : HIPBLAS_OP_N, opA = a_kc ? HIPBLAS_OP_N : HIPBLAS_OP_T;
+    hipblasLtMatmulPreference_t pref = nullptr;
+    hipblasLtMatmulHeuristicResult_t res[1];
+    int found = 0;
+    if (g.desc_create(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS &&
+        g.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opB, sizeof(opB)) == HIPBLAS_STATUS_SUCCESS &&
+        g.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opA, sizeof(opA)) == HIPBLAS_STATUS_SUCCESS &&
+        g.layout_create(&p.a, HIP_R_32F, b_kc ? K : N, b_kc ? N : K, ldb) == HIPBLAS_STATUS_SUCCESS &&
+        g.layout_create(&p.b, HIP_R_32F, a_kc ? K : M, a_kc ? M : K, lda) == HIPBLAS_STATUS_SUCCESS &&
+        g.layout_create(&p.c, HIP_R_32F, N, M, ldc) == HIPBLAS_STATUS_SUCCESS &&
+        g.pref_create(&pref) == HIPBLAS_STATUS_SUCCESS &&
+        g.pref_set(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &g.ws_bytes, sizeof(g.ws_bytes)) == HIPBLAS_STATUS_SUCCESS &&
+        g.heuristic(g.handle, p.desc, p.a, p.b, p.c, p.c, pref, 1, res, &found) == HIPBLAS_STATUS_SUCCESS && found > 0 &&
+        res[0].workspaceSize <= g.ws_bytes) {
+      p.algo = res[0].algo; p.ws = res[0].workspaceSize; p.ok = true;
+    }
+    if (pref) g.pref_destroy(pref);
+    it = g.plans.emplace(key, p).first;
+  }
+  const LtPlan& p = it->second;
+  if (!p.ok) return false;
+  const float one = 1.f, zero = 0.f;
+  return g.matmul(g.handle, p.desc, &one, B, p.a, A, p.b, &zero, C, p.c, C, p.c, &p.algo, g.ws, p.ws, s) == HIPBLAS_STATUS_SUCCESS;
+}
+}  // namespace
+
 void launch_gemm2(const float* A, int lda, const float* A2, int lda2, int M1, bool a_kc, const float* B, int ldb, bool b_kc,
                   float* C, int ldc, int M, int N, int K, const float* bias, int act, float alpha, bool accumulate,
                   hipStream_t s, float* ws, size_t ws_floats) {
   if (M <= 0 || N <= 0) return;
+  // (measured, MI355X: the library wins where the output alone fills the chip -- 6400 x 1024 x 1024: 101 vs 90 TFLOP/s, 280 x 3040 x 6400:
+  //  105 vs 91 -- and loses on small outputs with a long K, where k_gemm's split-K is the better plan: 760 x 280 x 6400 40 vs 53)
+  const double out_elems = (double)(A2 ? std::min(M1, M - M1) : M) * N;
+  if (!bias && act == 0 && !accumulate && out_elems >= 0.8e6 && K >= 256 && N > NBN && (!A2 || !a_kc) && blas_ready()) {
+    bool ok;
+    if (A2) ok = blas_gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, M1, N, K, s) &&
+                 blas_gemm(A2, lda2, a_kc, B, ldb, b_kc, C + (size_t)M1 * ldc, ldc, M - M1, N, K, s);
+    else ok = blas_gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, s);
+    if (ok) return;
+    // (no algorithm for this shape, or a failed call: k_gemm for this product)
+  }
   if (N <= NBN && !b_kc && !A2 && M >= NBM) {         // narrow output: 256 x 32 tiles
     const int gy = (M + NBM - 1) / NBM, nk = (K + BK - 1) / BK, ldw = (N + 3) & ~3;
     int splits = 1;

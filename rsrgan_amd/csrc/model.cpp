@@ -59,7 +59,11 @@ void Model::run_seg(uint64_t key, hipStream_t s, F&& body) {
   if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); g.uses = -1; body(); return; }
   body();
   hipGraph_t gr = nullptr;
-  if (hipStreamEndCapture(s, &gr) != hipSuccess || !gr) { (void)hipGetLastError(); g.uses = -1; body(); return; }
+  if (hipStreamEndCapture(s, &gr) != hipSuccess || !gr) {
+    (void)hipGetLastError(); g.uses = -1;
+    if (getenv("RSRGAN_GRAPH_DEBUG")) fprintf(stderr, "rsrgan: capture of segment %llx failed, eager from here on\n", (unsigned long long)key);
+    body(); return;
+  }
   hipGraphExec_t ex = nullptr;
   if (hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0) != hipSuccess || !ex) { (void)hipGetLastError(); (void)hipGraphDestroy(gr); g.uses = -1; body(); return; }
   (void)hipGraphDestroy(gr);
