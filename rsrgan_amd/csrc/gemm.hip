@@ -281,6 +281,24 @@ static int pick_splits(int tiles, int nk, size_t out_bytes, int max_splits, doub
   return best;
 }
 
+// dst[r][0:w1] = a[r][0:w1], dst[r][w1:w1+w2] = b[r][0:w2]   (w1 % 4 == 0; float4 moves; pad columns zero)
+__global__ __launch_bounds__(256) void k_concat_cols(const float* __restrict__ a, int lda, int w1, const float* __restrict__ b, int ldb, int w2,
+                                                     float* __restrict__ dst, int ldd, int rows) {
+  const int c4n = ldd >> 2;
+  const size_t n = (size_t)rows * c4n;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / c4n;
+    const int c = (int)(i - r * c4n) * 4;
+    float4 v;
+    if (c < w1) v = *reinterpret_cast<const float4*>(a + r * lda + c);
+    else {
+      const int cb = c - w1;                      // (ldb is padded to 4: the last float4 of b may read its zero padding)
+      v = cb < w2 ? *reinterpret_cast<const float4*>(b + r * ldb + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    *reinterpret_cast<float4*>(dst + r * ldd + c) = v;
+  }
+}
+
 // ---- plain library GEMM for the big epilogue-free products (weight gradients dK = [x|m]^T.dZ: 560 x 3040 x 6400, data gradients):
 // hipBLASLt, resolved at run time (dlopen; the header only supplies types).  Without the library, or with RSRGAN_BLAS=0,
 // everything stays on k_gemm.  One algorithm per (shape, layout), taken once from the heuristic and cached. ----
@@ -366,12 +384,22 @@ void launch_gemm2(const float* A, int lda, const float* A2, int lda2, int M1, bo
   if (M <= 0 || N <= 0) return;
   // (measured, MI355X: the library wins where the output alone fills the chip -- 6400 x 1024 x 1024: 101 vs 90 TFLOP/s, 280 x 3040 x 6400:
   //  105 vs 91 -- and loses on small outputs with a long K, where k_gemm's split-K is the better plan: 760 x 280 x 6400 40 vs 53)
-  const double out_elems = (double)(A2 ? std::min(M1, M - M1) : M) * N;
+  const int ldcat = (M + 3) & ~3;
+  const bool cat = A2 && !a_kc && ws && (size_t)K * ldcat <= ws_floats;      // two-source operand: stack it once, one product
+  const double out_elems = (double)((A2 && !cat) ? std::min(M1, M - M1) : M) * N;
   if (!bias && act == 0 && !accumulate && out_elems >= 0.8e6 && K >= 256 && N > NBN && (!A2 || !a_kc) && blas_ready()) {
     bool ok;
-    if (A2) ok = blas_gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, M1, N, K, s) &&
-                 blas_gemm(A2, lda2, a_kc, B, ldb, b_kc, C + (size_t)M1 * ldc, ldc, M - M1, N, K, s);
-    else ok = blas_gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, s);
+    if (cat) {                  // [x_t | m_{t-1}] as one [K][M] operand in the (otherwise unused) split-K work space: one 560-row
+      const size_t total = (size_t)K * (ldcat >> 2);      // product runs at 131 TFLOP/s, two 280-row halves at 105
+      hipLaunchKernelGGL(k_concat_cols, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, A, lda, M1, A2, lda2,
+                         M - M1, ws, ldcat, K);
+      ok = blas_gemm(ws, ldcat, false, B, ldb, b_kc, C, ldc, M, N, K, s);
+    } else if (A2) {
+      ok = blas_gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, M1, N, K, s) &&
+           blas_gemm(A2, lda2, a_kc, B, ldb, b_kc, C + (size_t)M1 * ldc, ldc, M - M1, N, K, s);
+    } else {
+      ok = blas_gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, s);
+    }
     if (ok) return;
     // (no algorithm for this shape, or a failed call: k_gemm for this product)
   }
