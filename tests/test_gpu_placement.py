@@ -20,8 +20,9 @@ import numpy as np
 sys.path.insert(0, %r)
 from oracle import rsrgan_oracle as O
 from tests.helpers import NET_D, NET_G, build_hip_pair, rand_batch
+import os
 cfg = O.NetCfg()                      # the reference's sizes: G 3x760/p280, D 2x256/p40
-B, T = 8, 7
+B, T = int(os.environ.get("RSRGAN_TEST_B", "8")), int(os.environ.get("RSRGAN_TEST_T", "7"))
 model, _ = build_hip_pair(cfg, B, T, seed=5, flags=3)
 x, lab, ln = rand_batch(cfg, B, T, seed=6, ragged=True)
 out = {}
@@ -58,3 +59,17 @@ def test_folded_discriminator_forward_agrees():
     for k in ("d0", "g0", "d1", "g1"):
         assert np.allclose(a[k], b[k], rtol=2e-5, atol=1e-7), (k, a[k], b[k])
     assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
+
+
+def test_library_gemm_path_agrees_and_is_reproducible():
+    """The big epilogue-free products (dK = [x|m]^T.dZ with K = T*B >= 256) go to hipBLASLt (csrc/gemm.hip: blas_gemm); with
+    RSRGAN_BLAS=0 they stay on k_gemm.  Same step to fp32 rounding, and the library path repeats bit for bit."""
+    size = {"RSRGAN_TEST_B": "16", "RSRGAN_TEST_T": "16"}
+    a = _run(dict(size, RSRGAN_BLAS="1"))
+    a2 = _run(dict(size, RSRGAN_BLAS="1"))
+    b = _run(dict(size, RSRGAN_BLAS="0"))
+    assert a == a2, (a, a2)
+    for k in ("d0", "g0", "d1", "g1"):
+        assert np.allclose(a[k], b[k], rtol=2e-5, atol=1e-7), (k, a[k], b[k])
+    assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
+    assert a["vars_sha"] != b["vars_sha"] or a == b          # (different summation orders: the bits differ, the values agree)
