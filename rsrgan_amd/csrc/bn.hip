@@ -47,10 +47,22 @@ __global__ __launch_bounds__(256) void k_bn_stats1(const float* __restrict__ z, 
 // moments, corrections and the affine of one call.  stat rows: 0 mean, 1 stddev, 2 r, 3 d, 4 a, 5 b  (y = z*a + b)
 __global__ __launch_bounds__(256) void k_bn_stats2(const float* __restrict__ scratch, int slices, const float* __restrict__ z, int rows,
                                                    int cols, BnVars v, float* __restrict__ stat, int ldc) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int i = 0; i < slices; ++i) { s1 += scratch[((size_t)i * 2) * cols + c]; s2 += scratch[((size_t)i * 2 + 1) * cols + c]; }
+  // 64 columns x 4 slice lanes per workgroup: the (up to 512) slice partials of a column are summed by four threads with
+  // several loads in flight each, then combined in a fixed order (one thread walking them was ~100 us: 512 dependent round trips)
+  __shared__ double red2[2][4][64];
+  const int l = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + l;
+  {
+    double p1 = 0.0, p2 = 0.0;
+    if (c < cols) {
+#pragma unroll 8
+      for (int i = rl; i < slices; i += 4) { p1 += scratch[((size_t)i * 2) * cols + c]; p2 += scratch[((size_t)i * 2 + 1) * cols + c]; }
+    }
+    red2[0][rl][l] = p1; red2[1][rl][l] = p2;
+  }
+  __syncthreads();
+  if (rl != 0 || c >= cols) return;
+  const double s1 = ((red2[0][0][l] + red2[0][1][l]) + red2[0][2][l]) + red2[0][3][l];
+  const double s2 = ((red2[1][0][l] + red2[1][1][l]) + red2[1][2][l]) + red2[1][3][l];
   const double m0 = s1 / rows;
   const double var = fmax(s2 / rows - m0 * m0, 0.0);
   const double mean = (double)z[c] + m0;
@@ -116,10 +128,20 @@ __global__ __launch_bounds__(256) void k_bn_bwd1(const float* __restrict__ dy, i
 __global__ __launch_bounds__(256) void k_bn_bwd2(const float* __restrict__ scratch, int slices, int rows, int cols,
                                                  const float* __restrict__ stat, int ldc, float* __restrict__ dbeta,
                                                  float* __restrict__ dgamma, int accumulate, float* __restrict__ sums) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int i = 0; i < slices; ++i) { s1 += scratch[((size_t)i * 2) * cols + c]; s2 += scratch[((size_t)i * 2 + 1) * cols + c]; }
+  __shared__ double red2[2][4][64];
+  const int l = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + l;
+  {
+    double p1 = 0.0, p2 = 0.0;
+    if (c < cols) {
+#pragma unroll 8
+      for (int i = rl; i < slices; i += 4) { p1 += scratch[((size_t)i * 2) * cols + c]; p2 += scratch[((size_t)i * 2 + 1) * cols + c]; }
+    }
+    red2[0][rl][l] = p1; red2[1][rl][l] = p2;
+  }
+  __syncthreads();
+  if (rl != 0 || c >= cols) return;
+  const double s1 = ((red2[0][0][l] + red2[0][1][l]) + red2[0][2][l]) + red2[0][3][l];
+  const double s2 = ((red2[1][0][l] + red2[1][1][l]) + red2[1][2][l]) + red2[1][3][l];
   if (dbeta) {
     const double gb = s1, gg = (double)stat[2 * ldc + c] * s2 + (double)stat[3 * ldc + c] * s1;
     dbeta[c] = (float)(accumulate ? (double)dbeta[c] + gb : gb);
@@ -346,7 +368,7 @@ void launch_bn_forward(const float* z, int ldz, float* y, int ldy, int rows, int
     int per;
     const int slices = bn_slices(rows, cols, scratch_floats, &per);
     hipLaunchKernelGGL(k_bn_stats1, dim3((cols + 63) / 64, slices), dim3(256), 0, s, z, ldz, rows, cols, per, scratch);
-    hipLaunchKernelGGL(k_bn_stats2, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, slices, z, rows, cols, v, stat, ldc);
+    hipLaunchKernelGGL(k_bn_stats2, dim3((cols + 63) / 64), dim3(256), 0, s, scratch, slices, z, rows, cols, v, stat, ldc);
   } else {
     hipLaunchKernelGGL(k_bn_infer_coef, dim3((cols + 255) / 256), dim3(256), 0, s, cols, v, stat, ldc);
   }
@@ -378,7 +400,7 @@ void launch_bn_backward(float* dy, int ldd, const float* y, int ldy, const float
   const int slices = bn_slices(rows, cols, scratch_floats, &per);
   hipLaunchKernelGGL(k_bn_bwd1, dim3((cols + 63) / 64, slices), dim3(256), 0, s, dy, ldd, y, ldy, z, ldz, stat, ldc, rows, cols, per,
                      relu ? 1 : 0, scratch);
-  hipLaunchKernelGGL(k_bn_bwd2, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, slices, rows, cols, stat, ldc, dbeta, dgamma,
+  hipLaunchKernelGGL(k_bn_bwd2, dim3((cols + 63) / 64), dim3(256), 0, s, scratch, slices, rows, cols, stat, ldc, dbeta, dgamma,
                      accumulate ? 1 : 0, sums);
   const int cp = (cols + 3) & ~3;
   const size_t n = (size_t)rows * (cp >> 2);
