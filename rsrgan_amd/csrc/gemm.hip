@@ -346,9 +346,13 @@ bool blas_ready() {
 // row-major C[M][N] = op(A).op(B)  ==  column-major C^T[N][M] = op(B)^T.op(A)^T: the library's first operand is B, its second A.
 // B stored [N][K] (k contiguous) is the column-major K x N matrix (transpose it), stored [K][N] it is N x K already;
 // A stored [M][K] is the column-major K x M matrix (as is), stored [K][M] it is M x K (transpose it).
-bool blas_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool b_kc, float* C, int ldc, int M, int N, int K, hipStream_t s) {
+// bias (per output column = per row of the library's D) and relu ride the library's epilogue (BIAS / RELU_BIAS)
+bool blas_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool b_kc, float* C, int ldc, int M, int N, int K, hipStream_t s,
+               const float* bias = nullptr, bool relu = false) {
   Blas& g = g_blas;
-  const std::array<int64_t, 8> key = {M, N, K, lda, ldb, ldc, a_kc ? 1 : 0, b_kc ? 1 : 0};
+  const uint32_t epi = bias ? (relu ? HIPBLASLT_EPILOGUE_RELU_BIAS : HIPBLASLT_EPILOGUE_BIAS) : HIPBLASLT_EPILOGUE_DEFAULT;
+  if (relu && !bias) return false;
+  const std::array<int64_t, 8> key = {M, N, K, lda, ldb, ldc, (a_kc ? 1 : 0) | (b_kc ? 2 : 0), (int64_t)epi};
   auto it = g.plans.find(key);
   if (it == g.plans.end()) {
     LtPlan p{}; p.ok = false;
@@ -359,6 +363,8 @@ bool blas_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool
     if (g.desc_create(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS &&
         g.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opB, sizeof(opB)) == HIPBLAS_STATUS_SUCCESS &&
         g.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opA, sizeof(opA)) == HIPBLAS_STATUS_SUCCESS &&
+        g.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)) == HIPBLAS_STATUS_SUCCESS &&
+        (!bias || g.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) == HIPBLAS_STATUS_SUCCESS) &&
         g.layout_create(&p.a, HIP_R_32F, b_kc ? K : N, b_kc ? N : K, ldb) == HIPBLAS_STATUS_SUCCESS &&
         g.layout_create(&p.b, HIP_R_32F, a_kc ? K : M, a_kc ? M : K, lda) == HIPBLAS_STATUS_SUCCESS &&
         g.layout_create(&p.c, HIP_R_32F, N, M, ldc) == HIPBLAS_STATUS_SUCCESS &&
@@ -374,6 +380,7 @@ bool blas_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool
   const LtPlan& p = it->second;
   if (!p.ok) return false;
   const float one = 1.f, zero = 0.f;
+  if (bias && g.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) != HIPBLAS_STATUS_SUCCESS) return false;
   return g.matmul(g.handle, p.desc, &one, B, p.a, A, p.b, &zero, C, p.c, C, p.c, &p.algo, g.ws, p.ws, s) == HIPBLAS_STATUS_SUCCESS;
 }
 }  // namespace
@@ -387,7 +394,8 @@ void launch_gemm2(const float* A, int lda, const float* A2, int lda2, int M1, bo
   const int ldcat = (M + 3) & ~3;
   const bool cat = A2 && !a_kc && ws && (size_t)K * ldcat <= ws_floats;      // two-source operand: stack it once, one product
   const double out_elems = (double)((A2 && !cat) ? std::min(M1, M - M1) : M) * N;
-  if (!bias && act == 0 && !accumulate && out_elems >= 0.8e6 && K >= 256 && N > NBN && (!A2 || !a_kc) && blas_ready()) {
+  const bool epi_ok = act == 0 || (act == 2 && bias);               // none / bias / bias + relu (leaky-relu stays on k_gemm)
+  if (epi_ok && !(bias && A2) && !accumulate && out_elems >= 0.8e6 && K >= 256 && N > NBN && (!A2 || !a_kc) && blas_ready()) {
     bool ok;
     if (cat) {                  // [x_t | m_{t-1}] as one [K][M] operand in the (otherwise unused) split-K work space: one 560-row
       const size_t total = (size_t)K * (ldcat >> 2);      // product runs at 131 TFLOP/s, two 280-row halves at 105
@@ -398,7 +406,7 @@ void launch_gemm2(const float* A, int lda, const float* A2, int lda2, int M1, bo
       ok = blas_gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, M1, N, K, s) &&
            blas_gemm(A2, lda2, a_kc, B, ldb, b_kc, C + (size_t)M1 * ldc, ldc, M - M1, N, K, s);
     } else {
-      ok = blas_gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, s);
+      ok = blas_gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, s, bias, act == 2);
     }
     if (ok) return;
     // (no algorithm for this shape, or a failed call: k_gemm for this product)
