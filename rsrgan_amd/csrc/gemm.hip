@@ -307,7 +307,7 @@ struct LtPlan { hipblasLtMatmulDesc_t desc; hipblasLtMatrixLayout_t a, b, c; hip
 struct Blas {
   bool tried = false, ok = false;
   hipblasLtHandle_t handle = nullptr;
-  void* ws = nullptr;
+  std::map<hipStream_t, void*> ws;          // one work space per stream that issues products (concurrent streams must not share one)
   size_t ws_bytes = 32u << 20;
   decltype(&hipblasLtCreate) create = nullptr;
   decltype(&hipblasLtMatmulDescCreate) desc_create = nullptr;
@@ -339,7 +339,7 @@ bool blas_ready() {
       !lt_sym(lib, "hipblasLtMatmul", g.matmul))
     return false;
   if (g.create(&g.handle) != HIPBLAS_STATUS_SUCCESS || !g.handle) return false;
-  if (hipMalloc(&g.ws, g.ws_bytes) != hipSuccess) { g.ws = nullptr; return false; }
+  if (const char* w = getenv("RSRGAN_BLAS_WS")) g.ws_bytes = (size_t)atoll(w);      // 0: only algorithms without a work space
   g.ok = true;
   return true;
 }
@@ -380,8 +380,23 @@ bool blas_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool
   const LtPlan& p = it->second;
   if (!p.ok) return false;
   const float one = 1.f, zero = 0.f;
+  void* wsp = nullptr;
+  if (p.ws) {
+    auto w = g.ws.find(s);
+    if (w == g.ws.end()) {
+      void* mem = nullptr;
+      if (g.ws.size() >= 8) {                     // streams of models long gone: start over (never inside a capture: the first
+        (void)hipDeviceSynchronize();             // product of a stream runs in a segment's eager first pass)
+        for (auto& kv : g.ws) (void)hipFree(kv.second);
+        g.ws.clear();
+      }
+      if (hipMalloc(&mem, g.ws_bytes) != hipSuccess) return false;
+      w = g.ws.emplace(s, mem).first;
+    }
+    wsp = w->second;
+  }
   if (bias && g.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) != HIPBLAS_STATUS_SUCCESS) return false;
-  return g.matmul(g.handle, p.desc, &one, B, p.a, A, p.b, &zero, C, p.c, C, p.c, &p.algo, g.ws, p.ws, s) == HIPBLAS_STATUS_SUCCESS;
+  return g.matmul(g.handle, p.desc, &one, B, p.a, A, p.b, &zero, C, p.c, C, p.c, &p.algo, wsp, p.ws, s) == HIPBLAS_STATUS_SUCCESS;
 }
 }  // namespace
 
