@@ -232,7 +232,14 @@ constexpr int RT = 2;          // 16-row tiles per wave: one W fragment feeds 2 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__host__ __device__ inline int gates_sa4(int ktot) { int s = ktot / 4 + 1; return (s & 1) ? s : s + 1; }
+// LDS row stride (in float4) of an image whose rows are read as MFMA fragments with ds_read_b128 (lane (q, lr): row lr, float4 q of
+// a k-block).  gfx950 serves a ds_read_b128 in four fixed 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...), i.e. every
+// group holds all 16 rows, eight of them with float4 q and eight with q + 1, and a group is conflict-free iff its 16 slots
+// (address / 16 B) differ mod 16.  slot = lr * stride + 4c + q: stride == 2 (mod 16) puts the first eight on the even slots and the
+// others on the odd ones.  An odd stride -- the usual padding rule -- collides 4 to 28 of the 64 lanes (SQ_LDS_BANK_CONFLICT was
+// 50 % of SQ_LDS_IDX_ACTIVE in k_fwd_gates and k_bwd_bp, profiles/r2_final_pmc_lds_summary.txt).
+__host__ __device__ inline int frag_stride4(int n4) { return n4 + ((18 - (n4 & 15)) & 15); }
+__host__ __device__ inline int gates_sa4(int ktot) { return frag_stride4(ktot / 4 + 1); }
 
 // RTG 16-row tiles per wave, RH row halves per workgroup: <.,2,1> = 32 rows x 16 cells on 8 waves (gate x K-half);
 // <.,2,2> = 64 rows on 16 waves (gate x K-half x row-half): the two row halves request the same weight lines, so a column
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(256) void k_bwd_a2(const BwdAJobs jobs) {
   // (rows are padded with zeros up to whole k-blocks: the last fragment read of a row must not meet its neighbour or stale LDS)
   const int nkb = (ldm + 15) >> 4;
   const int k4_0 = noproj ? c0 >> 2 : 0, nk4 = noproj ? 8 : ldm >> 2, nk4p = noproj ? 8 : nkb * 4;
-  const int SA4 = nk4p | 1, SA = SA4 * 4;
+  const int SA4 = frag_stride4(nk4p), SA = SA4 * 4;
   // Every load of the workgroup is issued first -- (1) the dm operand, (2) the weight tiles, (3) the epilogue operands -- and only
   // then is (1) consumed: loads return in order, so staging dm into LDS overlaps the landing of (2) and (3).
   // (1) dm: thread = (row tid/8, float4 slot tid%8 + 8 i)
@@ -826,7 +833,7 @@ __global__ __launch_bounds__(NW * 64) void k_bwd_b(const BwdBJobs jobs) {
 // masked epilogue.  123 MB -> ~42 MB of operand traffic per generator-wave launch.
 // ---------------------------------------------------------------------------------------
 constexpr int BP_RT = 4, BP_CHB = 12;
-__host__ __device__ inline int bp_sa4(int kpg) { return kpg * 4 + 1; }      // LDS row stride in float4 (odd)
+__host__ __device__ inline int bp_sa4(int kpg) { return frag_stride4(kpg * 4); }      // LDS row stride in float4 (== 2 mod 16)
 
 __global__ __launch_bounds__(512) void k_bwd_bp(const BwdBJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1204,9 +1211,9 @@ void launch_bwd_a(const BwdAJobs& jobs_in, int total_blocks, int kb_max, hipStre
     return;
   }
   // dynamic LDS: 32 rows x (widest dm row + pad) of the jobs in the launch (without a projection: 32 x 36 floats)
-  int sa4 = 9;
+  int sa4 = frag_stride4(8);
   for (int i = 0; i < jobs.n; ++i)
-    if (jobs.j[i].Wp) sa4 = std::max(sa4, (((jobs.j[i].ldm + 15) >> 4) * 4) | 1);
+    if (jobs.j[i].Wp) sa4 = std::max(sa4, frag_stride4(((jobs.j[i].ldm + 15) >> 4) * 4));
   const size_t lds = (size_t)32 * sa4 * 16;
   if (kb_max <= 4) hipLaunchKernelGGL(k_bwd_a2<4>, dim3(total_blocks), dim3(256), lds, s, jobs);
   else if (kb_max <= 18) hipLaunchKernelGGL(k_bwd_a2<18>, dim3(total_blocks), dim3(256), lds, s, jobs);
