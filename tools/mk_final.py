@@ -37,7 +37,9 @@ def main():
     # steps are delimited by the optimizer kernel of the generator (one k_apply_adam per step)
     ends = [i for i, r in enumerate(rows) if "k_apply_adam" in r["Kernel_Name"]]
     lines = ["# per (1D+1G) step, from the kernel trace of `tools/prof.sh` (rocprofv3 --kernel-trace): kernels, sum of kernel durations,",
-             "# sum of positive gaps between consecutive kernels, wall (first start -> last end); ms"]
+             "# sum of positive gaps between consecutive kernels, wall (first start -> last end); ms",
+             "# (the first line may be a warm-up step that still captures graph segments; the last line is bench.py's extra step with",
+             "#  every launch bracketed by HIP events, issued eagerly: its gaps are the host, not the replayed graphs)"]
     for a, b in zip(ends[:-1], ends[1:]):
         seg = rows[a + 1:b + 1]
         dur = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg) / 1e6
