@@ -159,8 +159,10 @@ class FrameBatchReader(object):
             qx, qy, held = [X[keep]], [Y[keep]], held - N
             return [bx, by]
         while todo or held >= N:
-            # the enqueuing threads keep the queue as full as its capacity allows (an utterance is enqueued when it fits)
-            while todo and (held == 0 or held + self.inputs.utt_shape_from_index(int(todo[0]))[0] <= self.capacity):
+            # the enqueuing threads keep the queue as full as its capacity allows: an utterance is enqueued when it fits, and
+            # whenever no batch can be drawn (held < N) -- tf's enqueue_many admits an over-long utterance piecewise as room
+            # frees up, so it never blocks the dequeue side for good (an utterance longer than the capacity must not hang)
+            while todo and (held < N or held + self.inputs.utt_shape_from_index(int(todo[0]))[0] <= self.capacity):
                 x, y = self._utt(int(todo.pop(0)))
                 qx.append(x); qy.append(y); held += x.shape[0]
             if held >= N and (held - N >= self.min_after_dequeue or not todo):

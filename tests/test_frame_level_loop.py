@@ -1,6 +1,7 @@
 """Host logic of the frame-level recipe (scripts/train_gan_dnn.py, io_funcs/tfrecords_io.py:206-255): the random-shuffle frame
 reader and the epoch loop's run/batch accounting, on CPU with a recording stand-in for the model."""
 import numpy as np
+import pytest
 
 from rsrgan_amd import run_gan_dnn as R
 from rsrgan_amd.io import ArkWriter, FrameBatchReader
@@ -74,3 +75,28 @@ def test_epoch_loop_runs_and_batches():
     short = ([np.zeros((4, 2), np.float32), np.zeros((4, 1), np.float32)] for _ in range(4))
     R.train_one_epoch(m, short, 30, 1, FLAGS, log=lambda *_: None)         # the queue runs dry: OutOfRangeError ends the epoch
     assert len(m.calls) == 4
+
+
+@pytest.mark.timeout(60)
+def test_frame_reader_admits_an_utterance_longer_than_the_queue(tmp_path):
+    """An utterance that exceeds capacity - residual frames must not stall the reader (tf's enqueue_many admits it piecewise):
+    lengths [300, 1400, 200] at batch 32 hung the first version forever."""
+    wi, wl = ArkWriter(str(tmp_path / "in.scp")), ArkWriter(str(tmp_path / "lab.scp"))
+    lens = [300, 1400, 200]
+    for i, T in enumerate(lens):
+        x = np.zeros((T, 2), np.float32); x[:, 0] = i; x[:, 1] = np.arange(T)
+        wi.write_next_utt(str(tmp_path / "in.ark"), "u%d" % i, x)
+        wl.write_next_utt(str(tmp_path / "lab.ark"), "u%d" % i, x[:, :1])
+    wi.close(); wl.close()
+    for shuffle in (False, True):
+        r = FrameBatchReader(str(tmp_path / "in.scp"), str(tmp_path / "lab.scp"), 32, num_threads=1, shuffle=shuffle, seed=1)
+        assert r.capacity == 1000 + 2 * 32 < 1400
+        it, batches = iter(r), []
+        for _ in range(sum(lens) // 32 + 2):                   # bounded: a stalled iterator fails instead of hanging the suite
+            b = next(it, None)
+            if b is None:
+                break
+            batches.append(b)
+        assert len(batches) == sum(lens) // 32
+        seen = {(int(a), int(b)) for x, _ in batches for a, b in x}
+        assert len(seen) == 32 * len(batches)
