@@ -128,16 +128,28 @@ def rced_fwd(cfg: RcedCfg, P, x, training=True):
     return y, (cache, flat)
 
 
-def rced_bwd(cfg: RcedCfg, P, cache, dy):
+def rced_bwd(cfg: RcedCfg, P, cache, dy, trace=None, start=None):
+    """Gradients of every variable from dy = d loss / d y.  Test hooks: `trace` (a dict) receives, per conv layer, the gradient
+    w.r.t. the layer's ReLU OUTPUT (before the mask); `start = (layer, d)` skips everything above `layer` and back-propagates
+    the given gradient w.r.t. that layer's PRE-activation instead (the linear response to flipping ReLU masks there:
+    tests/test_gpu_trainers.py::test_rced_reference_frame_random_relu_masks)."""
     convs, flat = cache
     S = cfg.splice
-    grads = {"g_model/fully_connected/weights": flat.T @ dy, "g_model/fully_connected/biases": dy.sum(0)}
-    d = (dy @ P["g_model/fully_connected/weights"].T).reshape(-1, cfg.filters_num[-1])
     names = _conv_names(len(cfg.filters_num))
-    for i in range(len(names) - 1, -1, -1):
+    if start is None:
+        grads = {"g_model/fully_connected/weights": flat.T @ dy, "g_model/fully_connected/biases": dy.sum(0)}
+        d = (dy @ P["g_model/fully_connected/weights"].T).reshape(-1, cfg.filters_num[-1])
+        top = len(names) - 1
+    else:
+        grads = {}
+        top, d = start
+    for i in range(top, -1, -1):
         in_shape, col, a, bcache = convs[i]
         Wt = P[names[i] + "/weights"]
-        d = d * (a > 0)
+        if start is None or i < top:
+            if trace is not None:
+                trace[i] = d.copy()
+            d = d * (a > 0)
         if bcache is not None:
             d, gb = bn.backward_train(P, bcache, d)
             grads.update(gb)

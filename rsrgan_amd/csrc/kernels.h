@@ -117,40 +117,14 @@ struct BwdBJobs { int n; BwdBJob j[MAXJ]; JobMap map, mapr; };      // map: k_bw
 // kb_max = largest 16-float k-block count of any job in the launch (selects how many waves split K).
 inline int job_blocks(int nblk_c, int N, int rows = 32) { return ((nblk_c + 7) & ~7) * ((N + rows - 1) / rows); }
 int fwd_gates_rows();
-void set_fwd_gates_rows(int r);
 void launch_fwd_gates(const FwdGateJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
 void launch_fwd_proj(const FwdProjJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
 int bwd_a_cells();                 // cells per column block of the phase-A kernel in use (BwdAJob::nblk_c = ceil(H / bwd_a_cells()))
-void set_bwd_a_form(int f);        // 2 (default): k_bwd_a2, 32-cell blocks; 1: k_bwd_a, 16-cell blocks
 void launch_bwd_a(const BwdAJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
 void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, int kb_max, hipStream_t s);
 // split-K phase B: fills ws/ldw/KG/... of every job (ws_base: >= bwd_b_ws_floats(jobs) floats) and launches both kernels
 size_t bwd_b_plan(BwdBJobs& jobs, float* ws_base);
 void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s);
-
-// ---------------------------------------------------------------- persistent small-cell recurrence (dlstm.hip)
-// One workgroup per (16-row tile, layer) walks all T steps of a stack of dynamic_rnn(LSTMCell) layers with the layer's weights in
-// VGPRs; layer l+1 follows layer l through flags in `flags` ([L][ceil(N/16)] words, zeroed by the launcher).  Pointers are already
-// offset to the first row of the run; a time step is Ns rows apart in every buffer.
-constexpr int DL_MAXL = 4;
-struct DlLayer {
-  const float* in;      // [T][Ns][ldI] layer input (layer l > 0: the masked output of layer l-1)
-  const float* KxT; const float* KhT; const float* WpT;      // [4H][ldI], [4H][ldP], [P][ldH]
-  const float* K; const float* Wp;                           // TF layouts [(I+P)][4H], [H][ldP] (backward)
-  const float* bias; const float* wf; const float* wi; const float* wo;
-  float* gates; float* c; float* h; float* mst; float* out;  // stashes: [T][..][4H], [T+1][..][H], [T][..][ldH], [T+1][..][ldP], [T][..][ldP]
-  int I, H, P, ldI, ldP, ldH;
-};
-struct DlFwdArgs {
-  DlLayer layer[DL_MAXL];
-  const int* len;
-  unsigned* flags; unsigned* err;
-  float* dump;          // >= 384 floats: lanes without a real (row, cell) store here instead of branching
-  int L, N, Ns, T;
-  float forget_bias;
-};
-bool dl_fwd_supported(const DlFwdArgs& a);
-void launch_dl_fwd(const DlFwdArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- batched GEMM
 // C[M,N] (+)= A.B (+bias)(lrelu).  a_kc: A(m,k)=A[m*lda+k] else A[k*lda+m];

@@ -470,156 +470,9 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_proj(const FwdProjJobs jobs) {
 }
 
 // ---------------------------------------------------------------------------------------
-// backward phase A: dh = (mask*(dout+dm_state)).Wp^T over K = P split on NW waves, then the
-// cell's gate gradients
-// ---------------------------------------------------------------------------------------
-// tools/ubench compiles this file with KA_ABLATE to time k_bwd_a with parts switched off (bit 1: no MFMA, 2: no operand loads,
-// 4: no epilogue loads, 8: no epilogue stores, 16: no dmt store, 32: return at entry); the product build has no such code
-#ifdef KA_ABLATE
-__device__ int g_ka_ablate = 0;
-#define KA_ON(bit) (!(ka_ab & (bit)))
-#else
-#define KA_ON(bit) true
-#endif
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_bwd_a(const BwdAJobs jobs) {
-  __shared__ float zs[NW][RT][16][17];
-  const int bid = blockIdx.x;
-#ifdef KA_ABLATE
-  const int ka_ab = g_ka_ablate;
-  if (!KA_ON(32)) return;
-#endif
-  TR_BEGIN();
-  int lb;
-  const BwdAJob J = RSR_PICK(BwdAJob, pl, lb);
-  int cb, rb;
-  if (!tile_of_block(lb, J.nblk_c, J.pl, cb, rb)) return;
-  TR_ID(J.gates);
-  TR(2);
-  const int r0 = rb * 16 * RT, c0 = cb * 16;
-  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform -> scalar branches
-  const int N = J.N, H = J.H, H4 = 4 * H, ldm = J.ldm;
-  const int wcell = c0 + lr;
-  const bool noproj = J.Wp == nullptr;          // num_proj=None: dh = mask*(dout + dm_state), no product
-  const float* wrow = (noproj ? J.dmst : J.Wp) + (size_t)(noproj ? 0 : min(wcell, H - 1)) * ldm;
-  const bool wok = wcell < H && !noproj;
-  int arow[RT], alen[RT];
-#pragma unroll
-  for (int i = 0; i < RT; ++i) {
-    arow[i] = min(r0 + i * 16 + lr, N - 1);        // clamped: loads are unconditional, masks apply after
-    alen[i] = J.len[arow[i]];
-  }
-  const int nkb = (ldm + 15) >> 4, per = (nkb + NW - 1) / NW;
-  const int jb = w * per, je = min(nkb, (w + 1) * per);
-  constexpr int CH = 3;
-  // all operand loads of this wave's K slice are issued before anything is consumed
-  float4 av[CH][RT], dv[CH][RT], bv[CH];
-#pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int k = min((jb + c) * 16 + 4 * q, ldm - 4);
-    bv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (KA_ON(2)) bv[c] = J.Wp_sw ? *reinterpret_cast<const float4*>(J.Wp_sw + ((size_t)cb * nkb + min(jb + c, nkb - 1)) * 256 + lane * 4)
-                                  : *reinterpret_cast<const float4*>(wrow + k);
-#pragma unroll
-    for (int i = 0; i < RT; ++i) {
-      av[c][i] = make_float4(0.f, 0.f, 0.f, 0.f); dv[c][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (KA_ON(2)) {
-        av[c][i] = *reinterpret_cast<const float4*>(J.dmst + (size_t)arow[i] * ldm + k);
-        dv[c][i] = J.dout ? *reinterpret_cast<const float4*>(J.dout + (size_t)arow[i] * ldm + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-  }
-  TR(10);
-  // epilogue operands (one (row, cell) per thread when NW == 8), in flight with the above
-  float eg[4] = {0.f, 0.f, 0.f, 0.f}, ecp = 0.f, ecn = 0.f, edc = 0.f, ewo = 0.f, ewi = 0.f, ewf = 0.f;
-  int elen = 0;
-  const int e_i = tid >> 8, e_r = (tid >> 4) & 15, e_c = tid & 15;
-  const int erow = r0 + e_i * 16 + e_r, ecell = c0 + e_c;
-  const bool evalid = (NW == 8) && erow < N && ecell < H;
-  if (evalid && KA_ON(4)) {
-    const float* g = J.gates + (size_t)erow * H4 + ecell;
-    eg[0] = g[0]; eg[1] = g[H]; eg[2] = g[2 * H]; eg[3] = g[3 * H];
-    const size_t ci = (size_t)erow * H + ecell;
-    ecp = J.c_prev[ci]; ecn = J.c_cur[ci]; edc = J.dc[ci];
-    ewo = J.wo[ecell]; ewi = J.wi[ecell]; ewf = J.wf[ecell];
-    elen = J.len[erow];
-  }
-  f32x4 acc[RT];
-#pragma unroll
-  for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  TR(3);
-#pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int k = (jb + c) * 16 + 4 * q;
-    const bool kok = (jb + c < je) && (k < ldm);
-    float4 b = bv[c];
-    if (!(kok && wok)) b = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < RT; ++i) {
-      float4 a = av[c][i];
-      a.x += dv[c][i].x; a.y += dv[c][i].y; a.z += dv[c][i].z; a.w += dv[c][i].w;
-      const bool rowok = (r0 + i * 16 + lr) < N;
-      if (!(kok && rowok && J.t < alen[i])) a = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kok && rowok && cb == 0 && !noproj && KA_ON(16)) *reinterpret_cast<float4*>(J.dmt + (size_t)arow[i] * ldm + k) = a;
-      av[c][i] = a;
-    }
-    bv[c] = b;
-  }
-  if (KA_ON(1)) {
-#pragma unroll
-  for (int c = 0; c < CH; ++c) {
-#pragma unroll
-    for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].x, bv[c].x, acc[i], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].y, bv[c].y, acc[i], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].z, bv[c].z, acc[i], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i].w, bv[c].w, acc[i], 0, 0, 0);
-  }
-  }
-  static_assert(NW == 8, "k_bwd_a: 8 waves x 3 k-blocks cover K <= 384 floats; one epilogue element per thread");
-  TR(5);
-#pragma unroll
-  for (int i = 0; i < RT; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) zs[w][i][q * 4 + r][lr] = acc[i][r];
-  __syncthreads();
-  TR(7);
-  if (evalid && KA_ON(8)) {
-    float* g = J.gates + (size_t)erow * H4 + ecell;
-    if (J.t < elen) {
-      float dh = 0.f;
-      if (noproj) {
-        const size_t mi = (size_t)erow * ldm + ecell;
-        dh = J.dmst[mi] + (J.dout ? J.dout[mi] : 0.f);
-      } else {
-#pragma unroll
-        for (int s2 = 0; s2 < NW; ++s2) dh += zs[s2][e_i][e_r][e_c];
-      }
-      const size_t ci = (size_t)erow * H + ecell;
-      const float gi = eg[0], gj = eg[1], gf = eg[2], go = eg[3];
-      const float tc = tanhf(ecn);
-      const float dao = dh * tc * go * (1.f - go);
-      const float dcn = edc + dh * go * (1.f - tc * tc) + dao * ewo;
-      const float daf = dcn * ecp * gf * (1.f - gf);
-      const float dai = dcn * gj * gi * (1.f - gi);
-      const float dj = dcn * gi * (1.f - gj * gj);
-      J.dc[ci] = dcn * gf + dai * ewi + daf * ewf;
-      g[0] = dai; g[H] = dj; g[2 * H] = daf; g[3 * H] = dao;
-    } else {
-      g[0] = 0.f; g[H] = 0.f; g[2 * H] = 0.f; g[3 * H] = 0.f;     // dc passes through unchanged
-    }
-  }
-  TR_END();
-}
-
-// ---------------------------------------------------------------------------------------
-// backward phase A, second form (the default): WG = 4 waves on a 32-row x 32-cell tile.
-// What the phase trace of k_bwd_a shows (tools/ubench/trace.hip): its ~6 us blocks are instruction issue and latency, not
-// bytes -- 48 column blocks per row block each re-load the same dm rows as MFMA fragments (16 rows x 64 B per wave-load,
-// ~40 instructions of address arithmetic and predication per load), then reduce an 8-way K split through LDS.  Here
+// backward phase A: dh = (mask*(dout+dm_state)).Wp^T, then the cell's gate gradients.  WG = 4 waves on a 32-row x 32-cell tile.
+// (Round 1's form -- 16-cell column blocks, every wave re-loading the dm rows as MFMA fragments, an 8-way K split reduced through
+// LDS -- spent its ~6 us blocks on instruction issue and latency, tools/ubench/trace.hip; removed in round 3.)  Here
 //   - the operand dm = mask.(dout + dmst) [32 x P] is summed ONCE per workgroup from coalesced float4 loads into an LDS image
 //     (the column-block-0 workgroup also stores it as dm_t for the weight gradients),
 //   - every wave owns one 16x16 output tile with the full K = P in two interleaved accumulators (no cross-wave reduction),
@@ -1073,8 +926,7 @@ size_t bwd_b_plan(BwdBJobs& jobs, float* ws_base) {
   static int bp_groups = -1;
   if (bp_groups < 0) { const char* e = getenv("RSRGAN_BP_GROUPS"); bp_groups = e ? atoi(e) : 1; }
   if (!bp_groups) for (int i = 0; i < n; ++i) { grouped[i] = false; nx[i] = 8; x0[i] = 0; }
-  static int kpg_target = -1;        // k-blocks per K slice: 24 -> 99 KB LDS (1 WG/CU)
-  if (kpg_target < 0) { const char* e = getenv("RSRGAN_BP_KPG"); kpg_target = e ? atoi(e) : 24; if (kpg_target < 2 || kpg_target > 2 * BP_CHB) kpg_target = 24; }
+  constexpr int kpg_target = 24;     // k-blocks per K slice: 24 -> 99 KB LDS (1 WG/CU); 11 / 12 measured slower
   for (int i = 0; i < n; ++i) {
     BwdBJob& b = jobs.j[i];
     const int nkb = (b.H4 + 15) >> 4, ncols = b.n_end - b.n_begin;
@@ -1142,9 +994,8 @@ void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s) {
 }
 
 // the launchers place the jobs (Place) and size the grid; `kb_max` is the largest k-block count over the jobs, which picks the K split.
-int g_gates_rows = 32;       // rows per k_fwd_gates workgroup (32 or 64); set once from RSRGAN_GATES_ROWS
+constexpr int g_gates_rows = 32;       // rows per k_fwd_gates workgroup (64-row / 16-wave blocks measured slower twice; removed)
 int fwd_gates_rows() { return g_gates_rows; }
-void set_fwd_gates_rows(int r) { g_gates_rows = (r == 64) ? 64 : 32; }
 void launch_fwd_gates(const FwdGateJobs& jobs_in, int total_blocks, int kb_max, hipStream_t s) {
   FwdGateJobs jobs = jobs_in;
   // a launch that would fill less than half of the chip with 32-row blocks (the discriminator alone) runs 16-row blocks: twice
@@ -1171,16 +1022,9 @@ void launch_fwd_gates(const FwdGateJobs& jobs_in, int total_blocks, int kb_max, 
   const size_t granule = rtg == 2 ? 8192 : 16384;          // one DMA round of all waves of the workgroup
   lds = (lds + granule - 1) / granule * granule;
   if (lds < 8 * rtg * 16 * 17 * sizeof(float)) lds = 8 * rtg * 16 * 17 * sizeof(float);
-  // One WG per CU: a launch lasts as long as its most-loaded CU pulls operands (~12 B/clk/CU); with two
-  // resident WGs per CU some CUs get two heavy (K=560) WGs.  One slot per CU + heavy-first order makes
-  // the dispatcher list-schedule: light WGs (layer 0, D) finish early and pick up the leftovers.
-  static int one_per_cu = -1;
-  if (one_per_cu < 0) { const char* e = getenv("RSRGAN_GATES_ONE_PER_CU"); one_per_cu = e ? atoi(e) : 0; }
-  if (one_per_cu && total_blocks > 256 && lds < 84 * 1024) lds = 84 * 1024;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_gates<18, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwd_gates<18, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   if (kb_max > 36) {        // K = [x | m] wider than 576 floats (e.g. 512-cell layers without projection): 32 k-blocks per wave, 1 WG/CU
@@ -1189,8 +1033,7 @@ void launch_fwd_gates(const FwdGateJobs& jobs_in, int total_blocks, int kb_max, 
     size_t l2 = (size_t)32 * gates_sa4(ktot) * 16;
     l2 = (l2 + 8191) / 8192 * 8192;
     hipLaunchKernelGGL((k_fwd_gates<32, 2>), dim3(total_blocks), dim3(512), l2, s, jobs);
-  } else if (rtg == 2) hipLaunchKernelGGL((k_fwd_gates<18, 2>), dim3(total_blocks), dim3(512), lds, s, jobs);
-  else hipLaunchKernelGGL((k_fwd_gates<18, 2, 2>), dim3(total_blocks), dim3(1024), lds, s, jobs);
+  } else hipLaunchKernelGGL((k_fwd_gates<18, 2>), dim3(total_blocks), dim3(512), lds, s, jobs);
 }
 void launch_fwd_proj(const FwdProjJobs& jobs_in, int total_blocks, int kb_max, hipStream_t s) {
   FwdProjJobs jobs = jobs_in;
@@ -1200,16 +1043,10 @@ void launch_fwd_proj(const FwdProjJobs& jobs_in, int total_blocks, int kb_max, h
   else
     hipLaunchKernelGGL(k_fwd_proj<8>, dim3(total_blocks), dim3(512), 0, s, jobs);
 }
-int g_bwd_a_form = 2;       // 2 = k_bwd_a2 (32 x 32 tiles, jobs' nblk_c counts 32-cell blocks), 1 = k_bwd_a (32 x 16); RSRGAN_BWD_A_FORM
-int bwd_a_cells() { return g_bwd_a_form == 2 ? 32 : 16; }
-void set_bwd_a_form(int f) { g_bwd_a_form = f == 1 ? 1 : 2; }
+int bwd_a_cells() { return 32; }      // k_bwd_a2: 32 x 32 tiles, the jobs' nblk_c counts 32-cell blocks
 void launch_bwd_a(const BwdAJobs& jobs_in, int total_blocks, int kb_max, hipStream_t s) {
   BwdAJobs jobs = jobs_in;
   total_blocks = place_tiles(jobs, 32, [](const BwdAJob& j) { return (double)(j.Wp ? j.ldm : 16); });
-  if (g_bwd_a_form == 1) {      // host asserts kb_max <= 24 (proj width <= 384)
-    hipLaunchKernelGGL(k_bwd_a<8>, dim3(total_blocks), dim3(512), 0, s, jobs);
-    return;
-  }
   // dynamic LDS: 32 rows x (widest dm row + pad) of the jobs in the launch (without a projection: 32 x 36 floats)
   int sa4 = frag_stride4(8);
   for (int i = 0; i < jobs.n; ++i)

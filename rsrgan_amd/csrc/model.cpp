@@ -157,8 +157,6 @@ static void alloc_stash(Model& M, LstmStash& S, const LstmLayer& L, int N, int T
 
 int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   cfg = c;
-  if (const char* e = getenv("RSRGAN_GATES_ROWS")) set_fwd_gates_rows(atoi(e));
-  if (const char* e = getenv("RSRGAN_BWD_A_FORM")) set_bwd_a_form(atoi(e));
   B = c.batch_size; Tmax = c.max_frames; Din = c.input_dim; Dout = c.output_dim;
   ldDin = pad4(Din); ldDout = pad4(Dout);
   if (B <= 0 || Tmax <= 0 || Din <= 0 || Dout <= 0 || c.g_layers <= 0 || c.d_layers <= 0 || c.g_cells <= 0 ||
@@ -419,9 +417,6 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   d_dA = alloc<float>(TB2 * dmaxld); d_dB = alloc<float>(TB2 * dmaxld);
   len_dev = alloc<int>(2 * B);
   zeros = alloc<float>(64);
-  dl_flags = alloc<unsigned>(DL_MAXL * 64 + 64);
-  dl_dump = alloc<float>(512);
-  if (const char* e = getenv("RSRGAN_DLSTM")) dl_env = atoi(e) != 0;
   noise_r_buf = alloc<float>((size_t)B * Dout); noise_f_buf = alloc<float>((size_t)B * Dout);
   if (const char* e = getenv("RSRGAN_GRAPHS")) graphs_env = atoi(e) != 0;
   if (hipStreamCreateWithFlags(&main_s, hipStreamNonBlocking) != hipSuccess) main_s = nullptr;
@@ -809,29 +804,6 @@ void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const 
       }
     flush_p();
   }
-}
-
-// The whole forward recurrence of a small-cell chain (the discriminator running alone) as ONE persistent launch (dlstm.hip).
-bool Model::dl_forward(Chain& ch, int T, hipStream_t s) {
-  if (!dl_env || !wavefront() || ch.empty() || (int)ch.size() > DL_MAXL) return false;
-  DlFwdArgs a{};
-  a.L = (int)ch.size(); a.N = ch[0].N; a.Ns = ch[0].Ns; a.T = T; a.len = ch[0].len; a.forget_bias = cfg.forget_bias;
-  a.flags = dl_flags; a.err = dl_flags + DL_MAXL * 64; a.dump = dl_dump;
-  for (int l = 0; l < a.L; ++l) {
-    const LayerRun& R = ch[l];
-    const LstmLayer& L = *R.L; const LstmStash& S = *R.S; const ParamSet& ps = *R.ps;
-    if (!L.has_proj || R.res_in || R.res_out || R.zx_batched || R.N != a.N || R.Ns != a.Ns || R.row0 != ch[0].row0 || R.len != a.len) return false;
-    if (l > 0 && R.in != ch[l - 1].S->out) return false;
-    const size_t r0 = (size_t)R.row0;
-    DlLayer& y = a.layer[l];
-    y.in = R.in + r0 * L.ldI; y.KxT = L.KxT; y.KhT = L.KhT; y.WpT = L.WpT; y.K = ps.W(L.tK); y.Wp = ps.W(L.tWp);
-    y.bias = ps.W(L.tb); y.wf = ps.W(L.twf); y.wi = ps.W(L.twi); y.wo = ps.W(L.two);
-    y.gates = S.gates + r0 * 4 * L.H; y.c = S.c + r0 * L.H; y.h = S.h + r0 * L.ldH; y.mst = S.mst + r0 * L.ldP; y.out = S.out + r0 * L.ldP;
-    y.I = L.I; y.H = L.H; y.P = L.P; y.ldI = L.ldI; y.ldP = L.ldP; y.ldH = L.ldH;
-  }
-  if (!dl_fwd_supported(a)) return false;
-  launch_dl_fwd(a, s);
-  return true;
 }
 
 // Kf_l = [ Kx' ; Wp_l . Kh_l ] with Kx' = K_0[0:I] (layer 0) or Wp_{l-1} . K_l[0:I_l] (I_l = P_{l-1}), then its fragment-tiled copies
@@ -1305,7 +1277,7 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, B, 0, s);
     if (!d_dnn()) {
       std::vector<Chain> chains(1, d_chain(B, B, 0));
-      if (!fold_forward(chains[0], T, s) && !dl_forward(chains[0], T, s)) rnn_forward(chains, T, s);
+      if (!fold_forward(chains[0], T, s)) rnn_forward(chains, T, s);
     }
   }
   // g_adv = mean((D(G(x)) - d_real)^2)  (gan_rnn_placeholder.py:246): all rows "fake", target d_real

@@ -42,7 +42,7 @@ struct LstmLayer {               // one tf.contrib.rnn.LSTMCell(H, use_peepholes
   bool has_proj = true;          // num_proj=None: m = h, P == H, no projection kernel (tWp = -1)
   int I, H, P, ldI, ldP, ldH;
   int tK, tb, twf, twi, two, tWp;        // indices into the ParamSet
-  float *KxT = nullptr, *KhT = nullptr, *WpT = nullptr;   // k-contiguous transposed copies (forward; dlstm.hip, layer-0 GEMMs)
+  float *KxT = nullptr, *KhT = nullptr, *WpT = nullptr;   // k-contiguous transposed copies (forward: layer-0 GEMMs, folded kernels)
   // fragment-tiled copies the step kernels stream with contiguous 1 KB wave-loads (kernels.h SwizzleJob), refreshed with the above
   float *Wg_full = nullptr, *Wg_h = nullptr;              // gates: [x | m] . K and m . K[I:] alone (x-part batched)
   float *WpT_sw = nullptr, *Wp_sw = nullptr;              // projection forward / backward phase A
@@ -133,10 +133,6 @@ struct Model {
   float *d_dA = nullptr, *d_dB = nullptr, *last_dx0 = nullptr;
   int *len_dev = nullptr;        // [2B]: lengths duplicated for the real|fake stacked batch
   float *zeros = nullptr;        // 256 B of zeros
-  float *dl_dump = nullptr;
-  unsigned *dl_flags = nullptr;  // persistent small-cell recurrence (dlstm.hip): [DL_MAXL][64] progress words + 1 error word
-  bool dl_env = true;            // RSRGAN_DLSTM=0: launch-per-phase discriminator waves (round 1)
-  bool dl_forward(Chain& ch, int T, hipStream_t s);      // false: not supported for this chain -> caller falls back to rnn_forward
   // ---- folded small-cell recurrence (the discriminator running alone): m_{t-1}.Kh = h_{t-1}.(Wp.Kh) and, above layer 0,
   // x_t.Kx = h^{below}_t.(Wp^{below}.Kx), so with the folded kernels Kf = [Kx' ; Wp.Kh] the cell's recurrent state is h itself
   // (a num_proj=None cell): ONE launch per time step instead of gates + projection.  Same math re-associated (fp32, ~1e-7);

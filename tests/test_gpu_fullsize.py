@@ -16,12 +16,19 @@ def _grads(model, net):
     return split_flat(model.engine.get_grads(net).cpu().numpy(), model.engine.tensor_table(net))
 
 
+@pytest.mark.parametrize("flags", [1, 3])
 @pytest.mark.parametrize("B,T", [(32, 50), (64, 100)])
-def test_full_size_step_against_oracle(B, T):
+def test_full_size_step_against_oracle(B, T, flags):
+    """flags=3 is what bench.py times: the wavefront schedule replayed as hipGraphs.  A segment runs eagerly on its first use,
+    is captured on its second and replayed from the third on, so the graph case repeats each backward three times (the
+    gradients do not depend on the repetition: apply=False) and compares what the REPLAY produced."""
     cfg = O.NetCfg()
-    model, oracle = build_hip_pair(cfg, B, T, seed=100 + B, flags=1)
+    model, oracle = build_hip_pair(cfg, B, T, seed=100 + B, flags=flags)
     x, lab, ln = rand_batch(cfg, B, T, seed=200 + B, ragged=True)
     x64, lab64 = x.astype(np.float64), lab.astype(np.float64)
+    for _ in range(2 if flags & 2 else 0):
+        model.engine.d_backward(x, lab, ln, None, None, train=True, apply=False)
+        model.engine.g_backward(x, lab, ln, None, train=True, reuse=True, apply=False)
     got = model.engine.d_backward(x, lab, ln, None, None, train=True, apply=False).cpu().numpy()
     want, wg = oracle.d_tower(x64, lab64, ln)
     assert np.allclose(got, want, rtol=RTOL), (got, want)

@@ -47,9 +47,21 @@ def _run(env):
     return json.loads(line[7:])
 
 
-def test_xcd_groups_do_not_change_a_bit():
-    a = _run({"RSRGAN_XCD_GROUPS": "1"})
-    b = _run({"RSRGAN_XCD_GROUPS": "0"})
+@pytest.mark.parametrize("B,T", [(8, 7), (64, 100)])
+def test_xcd_groups_do_not_change_a_bit(B, T):
+    """(64, 100) is the benchmarked size: there the >= 12 %-share group rule and the split-K planner take the branches bench.py
+    runs (three generator layers in XCD groups, phase B as split-K partials)."""
+    size = {"RSRGAN_TEST_B": str(B), "RSRGAN_TEST_T": str(T)}
+    a = _run(dict(size, RSRGAN_XCD_GROUPS="1"))
+    b = _run(dict(size, RSRGAN_XCD_GROUPS="0"))
+    assert a == b, (a, b)
+
+
+def test_split_k_phase_b_groups_do_not_change_a_bit():
+    """RSRGAN_BP_GROUPS=0 keeps every split-K phase-B job on all 8 XCD slots: same tiles, same summation order."""
+    size = {"RSRGAN_TEST_B": "64", "RSRGAN_TEST_T": "12"}
+    a = _run(dict(size, RSRGAN_BP_GROUPS="1"))
+    b = _run(dict(size, RSRGAN_BP_GROUPS="0"))
     assert a == b, (a, b)
 
 

@@ -199,6 +199,71 @@ def test_rced_generator_matches_oracle(N, gan, ctx, width):
         assert gv[k].shape == o.g[k].shape and rel_err(gv[k], o.g[k]) < 1e-3, k
 
 
+def test_rced_reference_frame_random_relu_masks():
+    """The reference's frame (257-dim LPS x splice 11, filter table of models/rced.py:90-114: the 4 x 65-column strip path) with
+    RANDOM biases and weights, so every channel's ReLU mask varies over the positions.  A frame has ~1 M ReLU units; a handful of
+    pre-activations land within fp32 rounding of the kink, where fp32 and the fp64 oracle legitimately pick different
+    subgradients.  The test therefore allows exactly that and nothing else: the HIP gradient must equal the oracle's plus a
+    combination of the oracle's own linear responses to flipping the masks of the units with |z| < EPS -- a bounded number of
+    them, each taken fully or not at all."""
+    from oracle import rced_oracle as R
+    from rsrgan_amd.trainer import DNNTrainer
+    EPS, N = 2e-5, 1
+    cfg = R.RcedCfg(input_dim=257, output_dim=5, left_context=5, right_context=5, d_units=18, d_hidden=2, filters_num=R.FILTERS_NUM)
+    rng = np.random.default_rng(77)
+    g = {k: v.astype(np.float32) for k, v in R.init_params(R.g_param_specs(cfg), rng).items()}
+    for k in g:
+        if k.endswith("biases"):
+            g[k] = rng.normal(0.05, 0.1, g[k].shape).astype(np.float32)
+    d = {k: v.astype(np.float32) for k, v in DO.init_params(DO.d_param_specs(cfg), rng, relu_init=True).items()}
+    args = SimpleNamespace(batch_size=N, input_dim=cfg.input_dim, output_dim=cfg.output_dim, left_context=5, right_context=5,
+                           g_type="rced", keep_prob=1.0, batch_norm=False, num_gpu=1, save_dir=None, l2_scale=0.0,
+                           g_learning_rate=1e-3, d_learning_rate=2e-3, init_mse_weight=10.0, disc_updates=1, gen_updates=1)
+    m = DNNTrainer(None, args, ["gpu:0"], net_overrides=dict(g_layers=9, g_cells=32, d_layers=cfg.d_hidden, d_cells=cfg.d_units))
+    m.set_vars(g, d)
+    x = rng.standard_normal((N, cfg.fed_dim)).astype(np.float32); lab = rng.standard_normal((N, cfg.output_dim)).astype(np.float32)
+    P = {k: v.astype(np.float64) for k, v in g.items()}
+    y, cache = R.rced_fwd(cfg, P, x.astype(np.float64))
+    convs = cache[0]
+    names = R._conv_names(9)
+    assert np.abs(m.forward(x) - y).max() < 1e-4
+    # ReLU masks do vary within a channel (what the tie-free W=257 cases of test_rced_generator_matches_oracle cannot cover)
+    frac = [(c[2] > 0).mean(0) for c in convs]
+    assert sum(int(((f > 0.05) & (f < 0.95)).sum()) for f in frac) > 100
+    near = []
+    for i, (_, col, a, _bn) in enumerate(convs):
+        z = col @ P[names[i] + "/weights"].reshape(col.shape[1], -1) + P[names[i] + "/biases"]
+        near += [(i, int(p), int(c)) for p, c in zip(*np.nonzero(np.abs(z) < EPS))]
+    assert len(near) < 200, len(near)
+    dy = 0.5 * cfg.output_dim * 2.0 * (y - lab) / y.size          # d (0.5 * Dout * mse) / dy   (dnn_trainer.py:139-141)
+    trace = {}
+    base = R.rced_bwd(cfg, P, cache, dy, trace=trace)
+    got = m.engine.g_backward(x[:, None], lab[:, None], None, train=True, reuse=False, apply=False).cpu().numpy()
+    assert np.isclose(got[1], 0.5 * cfg.output_dim * np.mean((y - lab) ** 2), rtol=1e-4)
+    hip = {k: v.reshape(base[k].shape).astype(np.float64)
+           for k, v in split_flat(m.engine.get_grads(NET_G).cpu().numpy(), m.engine.tensor_table(NET_G)).items()}
+    keys = sorted(base)
+    scale = {k: 1.0 / max(np.linalg.norm(base[k]), 1e-30) for k in keys}
+    vec = lambda gr: np.concatenate([(gr[k] * scale[k]).ravel() if k in gr else np.zeros(base[k].size) for k in keys])
+    cols = []
+    for i, p, c in near:                   # flipping unit (i, p, c): the gradient w.r.t. its pre-activation changes by +-trace
+        dp = np.zeros_like(trace[i])
+        dp[p, c] = -trace[i][p, c] if convs[i][2][p, c] > 0 else trace[i][p, c]
+        cols.append(vec(R.rced_bwd(cfg, P, cache, None, start=(i, dp))))
+    resid = vec(hip) - vec(base)
+    if cols:
+        A = np.stack(cols, 1)
+        live = np.linalg.norm(A, axis=0) > 1e-6                     # a unit nobody's gradient reaches decides nothing
+        coef = np.linalg.lstsq(A[:, live], resid, rcond=None)[0]
+        assert np.all(np.abs(coef - np.round(coef)) < 0.1) and np.all((coef > -0.1) & (coef < 1.1)), coef
+        resid = resid - A[:, live] @ np.round(coef)
+    off = 0
+    for k in keys:                         # per tensor: what is left after the admissible flips is fp32 rounding
+        n = base[k].size
+        assert np.linalg.norm(resid[off:off + n]) < 2e-3, (k, np.linalg.norm(resid[off:off + n]), len(near))
+        off += n
+
+
 @pytest.mark.parametrize("N,gan,ctx,width", [(6, False, (2, 1), 9), (5, True, (2, 2), 21), (4, False, (1, 1), -11), (3, True, (1, 1), 70)])
 def test_rced_batch_norm_matches_oracle(N, gan, ctx, width):
     """run_dnn.sh:129-134 (--g_type=rced --batch_norm=true): relu(batch_norm(conv2d, scale=True, renorm=True)) per output channel over
