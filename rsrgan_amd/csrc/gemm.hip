@@ -1,32 +1,404 @@
-// gemm.hip -- time-batched fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF/s peak on
-// MI355X).  Used for everything that is NOT on the serial recurrence: the input/output
-// fully_connected layers (models/lstm.py:82-87,121-124), the x-part of every LSTM kernel
-// batched over all T*B frames, and all weight/data gradients batched over time.
+// gemm.hip -- time-batched fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF/s peak on MI355X), hand-written.
+// Used for everything that is NOT on the serial recurrence: the input/output fully_connected layers
+// (models/lstm.py:82-87,121-124), the x-part of every LSTM kernel batched over all T*B frames, all weight/data gradients
+// batched over time, the frame-level DNN stacks (models/dnn.py, discriminator_dnn.py) and -- through the row maps -- the
+// strided 1-D convolutions of the SEGAN-style networks (models/generator.py, discriminator.py: a downconv is the GEMM of an
+// overlapping-window VIEW of the channels-last activation with the [kwidth*Cin][Cout] filter).
 //
-// 128x128x16 block tile, 256 threads = 4 waves in 2x2, each wave 64x64 = 2x2 MFMA tiles.
-// Operands are staged global -> VGPR (prefetched one k-tile ahead) -> LDS in a k-major image
-// As[k][m], Bs[k][n] (row stride 132 floats: 16-B aligned rows, 4-bank shift per k) so that the
-// MFMA fragment reads (lane l: row/col = l&31, k = l>>5) are 32 consecutive floats per half-wave
-// = conflict-free ds_read_b32.
-#include <dlfcn.h>
-#include <hipblaslt/hipblaslt.h>
-
+// k_gemm (round 3; replaces the 128x128x16 single-buffer kernel and the hipBLASLt route of round 2):
+//   * block = 4 waves, tile BM x BN = 128x128 (2x2 waves of 64x64), 96x128 (1x4 waves of 96x32) or 128x96 (4x1 waves of 32x96):
+//     the host takes the shape that wastes the fewest MFMAs on padding (M = 560 = 5.83 x 96; N = 280 = 2.92 x 96).
+//   * k-tile 32 deep, LDS double-buffered, ONE barrier per k-tile.  The LDS image is k-major (S[k][x]); the MFMA fragment of
+//     lane l (row/col l&31, k = l>>5) is 32 consecutive floats per half-wave = conflict-free ds_read_b32, software-pipelined
+//     one k-pair ahead of the MFMAs.
+//       - x-contiguous operands ([K][X] in memory: weights [in][out], the stashes of the weight gradients) ARE that image:
+//         they go global -> LDS by DMA (global_load_lds, 1 KB per wave-instruction, no VGPRs).  Chunks outside the operand
+//         (K tail, column padding) are redirected to a 16-byte zero chunk: no predication anywhere.
+//       - k-contiguous operands ([X][K]: activations of a forward layer) are loaded as float4 with clamped addresses at the top
+//         of the k-tile, held across the MFMA phase and transposed into the image afterwards (row stride BX+1: conflict-free
+//         ds_write_b32); no load sits under a branch.
+//   * stream-K work split instead of a tile grid: W = 512 workers (two per CU).  Whole rounds of tiles are data-parallel; the
+//     last W..2W tiles are cut into W equal runs of (tile, k-tile) units, so every CU gets the same number of MFMAs whatever
+//     the tile count (120 tiles on 256 CUs is the weight-gradient case).  A worker writes a tile it owns completely straight
+//     through the epilogue; pieces go to a work space in the accumulator layout (coalesced 16-byte stores) and k_gemm_fixup
+//     sums the pieces of a tile in k order (fixed order: deterministic, no float atomics) and runs the same epilogue.
 #include <algorithm>
-#include <array>
+#include <cstdio>
 #include <cstdlib>
-#include <map>
 
 #include "kernels.h"
 
 namespace rsr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;
-#ifndef RSR_GBK
-#define RSR_GBK 16
+constexpr int GK = 32;                       // k-tile depth
+#ifndef RSR_GEMM_MINW
+#define RSR_GEMM_MINW 2                      // waves per SIMD the register budget leaves room for (one block of 6 waves per CU)
 #endif
-constexpr int GBK = RSR_GBK;          // k-tile of k_gemm; 32 measured equal (115-127 TF at 4096^3, 79-87 at 6400x3040x280) at lower occupancy
+#ifndef RSR_GEMM_ABL                         // tools/ubench/gemm_bench.hip builds timing-only variants with parts of the k-loop switched
+#define RSR_GEMM_ABL 0                       // off (1: no DMA, 2: no fragment reads after the first stage, 4: no barrier); product: 0
+#endif
+constexpr int BK = 16;                       // k-tile of the narrow kernel below
+__device__ __attribute__((aligned(16))) float g_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};
+#if RSR_GEMM_ABL & 8
+__device__ unsigned long long g_gemm_clk[4];      // shader clocks / 100 MHz ticks of worker 0 (micro-benchmark: the clock the chip held)
+#endif
+
+struct GemmArgs {
+  const float* A; const float* A2; const float* B; const float* bias; float* C; float* ws;
+  int lda, lda2, M1, ldb, ldc, M, N, K;
+  int act, accumulate; float alpha;
+  int tiles_m, tiles_n, NT, NK, W, n_dp;     // tile grid, tiles, k-tiles, workers, tiles of the data-parallel rounds
+  int Uq, Ur;                                // units of the stream-K region = Uq * W + Ur (all unit arithmetic is 32-bit)
+  GemmRowMap ma;                             // row map of A (kernels.h), used by the MAP instantiations only
+};
+// first unit of worker w: floor(w * U / W)
+__device__ __forceinline__ int worker_lo(const GemmArgs& g, int w) { return w * g.Uq + (w * g.Ur) / g.W; }
+// tile index -> (tile row, tile column): groups of 4 tile rows, column-major inside a group, so that the ~32 tiles an XCD works on
+// at a time (consecutive workers share an XCD) form a 4 x 8 block: 12 operand panels through that XCD's L2 instead of 33
+__device__ __forceinline__ void tile_rc(const GemmArgs& g, int t, int& tm, int& tn) {
+  const int per = 4 * g.tiles_n, grp = t / per, first = grp * 4, rows = min(4, g.tiles_m - first), r = t - grp * per;
+  tn = r / rows; tm = first + (r - tn * rows);
+}
+
+// address (float offset) of row `r` of a mapped operand: row r is sample r / rows_per, position r % rows_per
+__device__ __forceinline__ long long map_row(const GemmRowMap& m, int r) {
+  const int q = r / m.rows_per, p = r - q * m.rows_per;
+  return (long long)q * m.outer + (long long)p * m.inner;
+}
+
+// One operand tile (BX rows or columns x GK) of a k-tile, global -> LDS by DMA (global_load_lds, 16 bytes per lane, 1 KB per
+// wave-instruction), issued by the block's NL loader waves: loader `lw` owns the wave-instructions j = lw + NL u (image chunks
+// 64 j .. 64 j + 63).  No staging registers, no ds_write, no predication: a chunk outside the operand (K tail, column padding, no
+// successor tile) is fetched from a 16-byte zero chunk instead.
+//  !KC (x contiguous in memory, element(x,k) = P[k*ld + x]): the image is k-major S[k][x] = the memory layout, row by row.
+//  KC  (k contiguous, element(x,k) = P[x*ld + k]): the image is S[x][32 k] with the eight 16-byte chunks of a row stored at
+//       position kq ^ ((x >> 1) & 7) (the DMA writes lane-linear, so the permutation sits on the SOURCE side: the lane that fills
+//       position pos of row x fetches k-chunk pos ^ ((x >> 1) & 7)); the MFMA fragment is then one 8-byte read per k-quad (2-way
+//       bank conflict, irrelevant at the fp32 MFMA rate) instead of a 32-way conflicted column walk.
+#ifndef RSR_GEMM_NL
+#define RSR_GEMM_NL 2
+#endif
+constexpr int NL = RSR_GEMM_NL;                                    // loader waves per block
+// LDS ring: k-tiles resident (one being multiplied, the others landing): as many as fit beside ~16 KB of slack, at most 4
+// (measured at 4096^3, 128 x 128 tiles: 105 / 115 / 117 TFLOP/s with 2 / 3 / 4)
+constexpr int ring_depth(int bm, int bn) { return (144 * 1024) / ((bm + bn) * GK * 4) >= 4 ? 4 : (144 * 1024) / ((bm + bn) * GK * 4); }
+template <bool KC, int BX, bool MAP = false>
+struct Stage {
+  static constexpr int NI = BX * GK / 256 / NL;          // wave-instructions per loader wave and k-tile
+  static constexpr int FLOATS = GK * BX;
+  const float* p[NI];                                    // this lane's source of instruction u at the current k-tile
+  int mp[MAP && !KC ? NI : 1], mq[MAP && !KC ? NI : 1];  // mapped k-major operand: position / sample of the chunk's k row
+
+  static __device__ __forceinline__ int kc_kq(int lane, int lw) { return (lane & 7) ^ ((4 * lw + (lane >> 4)) & 7); }   // same for every u
+  __device__ __forceinline__ void init(const float* P, int ld, const float* P2, int ld2, int X1, int x0, int X, int k_first,
+                                       int lane, int lw, const GemmRowMap& map) {
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int c = 64 * (lw + NL * u) + lane;
+      if (KC) {
+        const int row = min(x0 + (c >> 3), X - 1);
+        p[u] = P + (MAP ? map_row(map, row) : (long long)row * ld) + k_first + 4 * kc_kq(lane, lw);
+      } else {
+        const int kr = c / (BX / 4), x = x0 + (c - kr * (BX / 4)) * 4;
+        const int xs = x < ((X + 3) & ~3) ? x : 0;
+        if (MAP) {                                       // row index = k: (sample, position) kept incrementally
+          const int kk = k_first + kr;
+          mq[u] = kk / map.rows_per; mp[u] = kk - mq[u] * map.rows_per;
+          p[u] = P + xs;
+        } else if (P2 && xs >= X1) p[u] = P2 + (long long)(k_first + kr) * ld2 + (xs - X1);
+        else p[u] = P + (long long)(k_first + kr) * ld + xs;
+      }
+    }
+  }
+  // all of this loader's instructions of the k-tile starting at k0 (K = reduction length; `on` false: a k-tile past the end of
+  // the run, zeros -- the instruction count per k-tile is fixed, the loaders wait with COUNTED vmcnt); `dst` = this operand's image
+  __device__ __forceinline__ void issue(int k0, int K, bool on, float* dst, int lane, int lw, int ld, int ld2, int X1, int x0, int X,
+                                        const float* P2, const GemmRowMap& map) {
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int j = lw + NL * u, c = 64 * j + lane;
+      bool v;
+      const float* src;
+      if (KC) {
+        v = on && k0 + 4 * kc_kq(lane, lw) < ((K + 3) & ~3);    // (k..k+3 < ld: zero padding of the row)
+        src = p[u];
+        p[u] += GK;
+      } else {
+        const int kr = c / (BX / 4), x = x0 + (c - kr * (BX / 4)) * 4;
+        v = on && x < ((X + 3) & ~3) && (k0 + kr < K);
+        if (MAP) {
+          src = p[u] + (long long)mq[u] * map.outer + (long long)mp[u] * map.inner;
+          mp[u] += GK;
+          const int cq = mp[u] / map.rows_per;
+          mp[u] -= cq * map.rows_per; mq[u] += cq;
+        } else {
+          src = p[u];
+          p[u] += GK * ((P2 && x >= X1) ? ld2 : ld);
+        }
+      }
+      src = v ? src : g_zero_chunk;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + 256 * j), 16, 0, 0);
+    }
+  }
+};
+
+// C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int RT, int CT>
+__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[RT][CT], int m_base, int n_base, int l31, int lh, const GemmArgs& g) {
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    const int col = n_base + j * 32 + l31;
+    const bool cok = col < g.N;
+    const int cc = cok ? col : g.N - 1;
+    const float bv = g.bias ? g.bias[cc] : 0.f;
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] + bv;
+      if (g.act == 1) {                                  // utils/ops.py:120-121 tf.maximum(x, alpha*x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], g.alpha * v[r]);
+      } else if (g.act == 2) {                           // tf.nn.relu (models/dnn.py:36)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      const int row0 = m_base + i * 32 + 4 * lh;
+      if (g.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(row0 + (r & 3) + 8 * (r >> 2), g.M - 1);
+          v[r] += g.C[(size_t)row * g.ldc + cc];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        if (cok && row < g.M) g.C[(size_t)row * g.ldc + col] = v[r];
+      }
+    }
+  }
+}
+
+// Block = 4 MFMA waves + NL loader waves.  An LDS-DMA costs the issuing wave ~60-180 cycles, a 32x32x2 MFMA occupies the matrix pipe
+// for 64: with the DMA in the MFMA waves' own instruction stream (round 3 first form, one chunk behind every fourth MFMA) the pipe
+// idled behind every DMA -- 112 TFLOP/s at 4096^3 with one wave per SIMD against 133 with the DMA ablated and 143 with DMA and
+// fragment reads ablated (tools/ubench/gemm_bench.hip `abl`).  A loader wave stalls on its own; the SIMD issues the MFMA wave next to it.
+template <bool AKC, bool BKC, int RT, int CT, int WM, bool MAPA>
+__global__ __launch_bounds__(64 * (4 + NL), RSR_GEMM_MINW) void k_gemm(const GemmArgs g) {
+  constexpr int WN = 4 / WM, BM = WM * RT * 32, BN = WN * CT * 32;
+  typedef Stage<AKC, BM, MAPA> SA;
+  typedef Stage<BKC, BN, false> SB;
+  constexpr int BUF = SA::FLOATS + SB::FLOATS, NBUF = ring_depth(BM, BN);
+  static_assert(NBUF >= 2, "tile too large for the LDS ring");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid / WN, wc = wid - wr * WN;
+  // logical worker: consecutive workers on one XCD (block b runs on XCD b % 8), so that the tiles sharing an operand panel
+  // share an L2
+  const int W = g.W;
+  const int bid = blockIdx.x;
+  const int w = (W & 7) ? bid : (bid & 7) * (W >> 3) + (bid >> 3);
+  const int u_lo = worker_lo(g, w), u_hi = worker_lo(g, w + 1);
+#if RSR_GEMM_ABL & 8
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  int u = u_lo;
+  int tdp = w;                                            // whole tiles of the data-parallel rounds: w, w + W, ... < n_dp
+  while (tdp < g.n_dp || u < u_hi) {
+    int t, i0, i1;
+    if (tdp < g.n_dp) { t = tdp; tdp += W; i0 = 0; i1 = g.NK; }
+    else {
+      const int ts = u / g.NK;
+      t = g.n_dp + ts; i0 = u - ts * g.NK;
+      i1 = min(g.NK, i0 + (u_hi - u));
+    }
+    int tm, tn;
+    tile_rc(g, t, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    if (wid >= 4) {
+      // ---- loader wave: runs NBUF-1 k-tiles ahead of the MFMA waves through a ring of NBUF LDS buffers.  One barrier per k-tile:
+      // behind it the MFMA waves are done with k-tile kt (its buffer is free) and -- by the loader's COUNTED vmcnt just before it
+      // -- k-tile kt+1 has landed, while the DMAs of kt+2.. stay in flight across the barrier (operands come through L2 from
+      // HBM / MALL: with one k-tile = 1.7 us of prefetch distance the MFMA waves waited on every tile)
+      const int lw = wid - 4;
+      SA sa; SB sb;
+      sa.init(g.A, g.lda, g.A2, g.lda2, g.M1, m0, g.M, i0 * GK, lane, lw, g.ma);
+      sb.init(g.B, g.ldb, nullptr, 0, 0, n0, g.N, i0 * GK, lane, lw, g.ma);
+      constexpr int NIT = SA::NI + SB::NI;                 // DMA instructions per k-tile of this wave
+      static_assert((NBUF - 2) * NIT < 64, "vmcnt is a 6-bit counter");
+#pragma unroll
+      for (int d = 0; d < NBUF - 1; ++d) {
+        sa.issue((i0 + d) * GK, g.K, i0 + d < i1, smem + d * BUF, lane, lw, g.lda, g.lda2, g.M1, m0, g.M, g.A2, g.ma);
+        sb.issue((i0 + d) * GK, g.K, i0 + d < i1, smem + d * BUF + SA::FLOATS, lane, lw, g.ldb, 0, 0, n0, g.N, nullptr, g.ma);
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * NIT) : "memory");
+      __builtin_amdgcn_s_barrier();
+      int slot = NBUF - 1;                                 // ring slot of k-tile kt + NBUF - 1
+      for (int kt = i0; kt < i1; ++kt) {
+        float* bn = smem + slot * BUF;
+        const int kn = kt + NBUF - 1;
+        if (!(RSR_GEMM_ABL & 1)) {
+          sa.issue(kn * GK, g.K, kn < i1, bn, lane, lw, g.lda, g.lda2, g.M1, m0, g.M, g.A2, g.ma);
+          sb.issue(kn * GK, g.K, kn < i1, bn + SA::FLOATS, lane, lw, g.ldb, 0, 0, n0, g.N, nullptr, g.ma);
+        }
+        slot = slot + 1 == NBUF ? 0 : slot + 1;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * NIT) : "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (zero fills of the slots past the run: done before the ring is reused)
+    } else {
+      // ---- MFMA wave
+      f32x16 acc[RT][CT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      __builtin_amdgcn_s_barrier();
+      // fragment addresses.  PAIRED (some operand k-contiguous): MFMA step 2s+e of the k-tile takes k = 4s + 2*(lane>>5) + e, so a
+      // k-contiguous operand reads its two values of a k-quad as one 8-byte word; otherwise step 2s+e takes k = 4s + 2e + (lane>>5).
+      constexpr bool PAIRED = AKC || BKC;
+      const int ra = wr * RT * 32 + l31, rb = wc * CT * 32 + l31;          // row / column of tile 0 inside the block tile
+      int slot = 0;
+      for (int kt = i0; kt < i1; ++kt) {
+        const float* bc = smem + slot * BUF;
+        slot = slot + 1 == NBUF ? 0 : slot + 1;
+        // The k-tile is ONE pinned instruction stream: NM MFMAs in k order; the fragments of stage s+1 (4 k = 2 MFMA steps) are
+        // read one per MFMA gap while stage s multiplies.  Left alone hipcc sinks every read to just before its MFMAs and reuses
+        // one register set (read -> wait -> MFMAs -> read ...: a bubble per k-pair on a wave that is alone on its SIMD); read as
+        // a cluster at the head of a stage they cost ~450 cycles per k-tile of 4096.
+        constexpr int NS = GK / 4;
+        constexpr int RA = AKC ? RT : 2 * RT, RB = BKC ? CT : 2 * CT, NR = RA + RB;      // fragment reads per stage
+        constexpr int NMS = 2 * RT * CT, RPG = (NR + NMS - 1) / NMS;                     // MFMAs per stage, reads per gap
+        float fa[2][2][RT], fb[2][2][CT];                                    // [stage parity][step in stage][tile]
+        auto read_one = [&](int st, int par, int r) {
+          if (r < RA) {
+            if (AKC) {
+              const int x = ra + r * 32;
+              const float* v = bc + x * 32 + ((st ^ ((x >> 1) & 7)) << 2) + 2 * lh;      // (two float reads: through a float2
+              fa[par][0][r] = v[0]; fa[par][1][r] = v[1];                               //  pointer hipcc drains the DMA queue first)
+            } else {
+              const int e = r / RT, i = r - e * RT;
+              fa[par][e][i] = bc[(4 * st + (PAIRED ? 2 * lh + e : 2 * e + lh)) * BM + ra + i * 32];
+            }
+          } else {
+            const float* bb = bc + SA::FLOATS;
+            const int q = r - RA;
+            if (BKC) {
+              const int x = rb + q * 32;
+              const float* v = bb + x * 32 + ((st ^ ((x >> 1) & 7)) << 2) + 2 * lh;
+              fb[par][0][q] = v[0]; fb[par][1][q] = v[1];
+            } else {
+              const int e = q / CT, j = q - e * CT;
+              fb[par][e][j] = bb[(4 * st + (PAIRED ? 2 * lh + e : 2 * e + lh)) * BN + rb + j * 32];
+            }
+          }
+        };
+#pragma unroll
+        for (int r = 0; r < NR; ++r) read_one(0, 0, r);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+              for (int j = 0; j < CT; ++j) {
+                const int m = (e * RT + i) * CT + j;                         // (compile-time after unrolling)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[(RSR_GEMM_ABL & 2) ? 0 : (st & 1)][e][i], fb[(RSR_GEMM_ABL & 2) ? 0 : (st & 1)][e][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 1 < NS && !(RSR_GEMM_ABL & 2)) {
+#pragma unroll
+                  for (int k = 0; k < RPG; ++k)
+                    if (m * RPG + k < NR) read_one(st + 1, (st + 1) & 1, m * RPG + k);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }
+        }
+        __builtin_amdgcn_s_barrier();        // (every fragment read above has been waited for by the MFMA that takes it)
+      }
+
+      if (i0 == 0 && i1 == g.NK) {
+        gemm_epilogue<RT, CT>(acc, m0 + wr * RT * 32, n0 + wc * CT * 32, l31, lh, g);
+      } else {
+        // a piece of a tile: raw accumulators, lane-native order ([tile][quad][thread] float4: coalesced)
+        const int slot = 2 * w + (u == u_lo ? 0 : 1);
+        float4* q = reinterpret_cast<float4*>(g.ws) + (size_t)slot * (RT * CT * 4 * 256) + tid;
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+              q[((i * CT + j) * 4 + r4) * 256] = make_float4(acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]);
+      }
+    }
+    if (t >= g.n_dp) u += i1 - i0;
+  }
+#if RSR_GEMM_ABL & 8
+  if (bid == 0 && tid == 0) { g_gemm_clk[0] = __builtin_amdgcn_s_memtime() - clk0; g_gemm_clk[1] = __builtin_amdgcn_s_memrealtime() - rt0; }
+#endif
+}
+
+// tile `ts` of the stream-K region: the workers whose runs cut it, in k order; first run of a worker -> slot 2w, last -> 2w+1
+template <int RT, int CT, int WM>
+__global__ __launch_bounds__(256) void k_gemm_fixup(const GemmArgs g) {
+  constexpr int WN = 4 / WM, BM = WM * RT * 32, BN = WN * CT * 32;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wid = tid >> 6, wr = wid / WN, wc = wid - wr * WN;
+  const int ts = blockIdx.x;
+  // the workers holding the tile's first and last unit: largest w with worker_lo(w) <= u
+  const int ua = ts * g.NK, ub = ua + g.NK - 1;
+  auto owner = [&](int u) {
+    int w = g.Uq > 0 ? min(g.W - 1, u / g.Uq) : g.W - 1;
+    while (w > 0 && worker_lo(g, w) > u) --w;
+    while (w + 1 < g.W && worker_lo(g, w + 1) <= u) ++w;
+    return w;
+  };
+  const int wa = owner(ua), wb = owner(ub);
+  if (wa == wb) return;                                   // one worker owned the whole tile and wrote it
+  f32x16 acc[RT][CT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < CT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int w = wa; w <= wb; ++w) {
+    const int slot = 2 * w + (worker_lo(g, w) / g.NK == ts ? 0 : 1);
+    const float4* q = reinterpret_cast<const float4*>(g.ws) + (size_t)slot * (RT * CT * 4 * 256) + tid;
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const float4 v = q[((i * CT + j) * 4 + r4) * 256];
+          acc[i][j][4 * r4] += v.x; acc[i][j][4 * r4 + 1] += v.y; acc[i][j][4 * r4 + 2] += v.z; acc[i][j][4 * r4 + 3] += v.w;
+        }
+  }
+  const int t = g.n_dp + ts;
+  int tm, tn;
+  tile_rc(g, t, tm, tn);
+  gemm_epilogue<RT, CT>(acc, tm * BM + wr * RT * 32, tn * BN + wc * CT * 32, l31, lh, g);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_gemm16: the 128 x 128 x 16 kernel of rounds 1-2 (register-staged operands, single LDS buffer, 3-4 blocks per CU, deterministic
+// split-K + k_splitk_reduce).  It stays the kernel of the products with little work per output tile -- short K (a tile of k_gemm
+// pays a ring fill and a 6-wave block's epilogue per tile, with ONE block per CU: 12800 x 1024 x 40 took 125 us against 18 here)
+// and small outputs with a long K (many pieces per tile) -- see launch_gemm_mapped for the rule.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, LDT = 132;
+constexpr int GBK = 16;               // k-tile of k_gemm16
 
 // Load a 128(x) x 16(k) operand tile into registers (2 float4 per thread).
 //  KC  (k contiguous): element(x,k) = P[x*ld + k]  -> thread: x = idx>>2, k4 = (idx&3)*4
@@ -70,7 +442,7 @@ __device__ __forceinline__ void store_tile(float (*S)[LDT], int tid, const float
 }
 
 template <bool AKC, bool BKC>
-__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+__global__ __launch_bounds__(256) void k_gemm16(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                               float* __restrict__ C, int ldc, int M, int N, int K,
                                               const float* __restrict__ bias, int act, float alpha, int accumulate,
                                               float* __restrict__ ws, int ldw, int kt_per_split,
@@ -169,6 +541,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
   }
 }
 
+
 // Narrow-N variant for outputs with N <= 32 columns (R-CED: a conv2d has 12..32 filters; 128-wide tiles would spend 75-90 %
 // of the MFMA work on padding): 256 x 32 x 16 block tile, 4 waves each 64 rows x 32 columns = 2 MFMA tiles.  B is [K][N]
 // (n contiguous) only.  Same k-major LDS image, register prefetch and deterministic split-K as k_gemm.
@@ -264,6 +637,7 @@ __global__ __launch_bounds__(256) void k_gemm_n32(const float* __restrict__ A, i
     }
 }
 
+
 // Split-K factor for an under-filled output grid (weight gradients: few tiles, K = T*B).  Model: the busiest CU runs
 // ceil(tiles*s/256) workgroups of ceil(nk/s) k-tiles (~1.2 us each; 25 % slower when fewer than two workgroups per CU
 // hide each other's latency), then the reduce streams s partial images at ~4 TB/s.
@@ -281,152 +655,118 @@ static int pick_splits(int tiles, int nk, size_t out_bytes, int max_splits, doub
   return best;
 }
 
-// dst[r][0:w1] = a[r][0:w1], dst[r][w1:w1+w2] = b[r][0:w2]   (w1 % 4 == 0; float4 moves; pad columns zero)
-__global__ __launch_bounds__(256) void k_concat_cols(const float* __restrict__ a, int lda, int w1, const float* __restrict__ b, int ldb, int w2,
-                                                     float* __restrict__ dst, int ldd, int rows) {
-  const int c4n = ldd >> 2;
-  const size_t n = (size_t)rows * c4n;
-  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const size_t r = i / c4n;
-    const int c = (int)(i - r * c4n) * 4;
-    float4 v;
-    if (c < w1) v = *reinterpret_cast<const float4*>(a + r * lda + c);
-    else {
-      const int cb = c - w1;                      // (ldb is padded to 4: the last float4 of b may read its zero padding)
-      v = cb < w2 ? *reinterpret_cast<const float4*>(b + r * ldb + cb) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    *reinterpret_cast<float4*>(dst + r * ldd + c) = v;
+
+int g_gemm_workers = 256;     // worker slots of a launch = one block (4 MFMA + 2 loader waves, ring of LDS buffers) per CU
+namespace {
+
+struct Plan { int W, n_dp, whole; double cost; };
+// Time model of one configuration (us).  The MFMA waves run at ~0.92 of the matrix rate when fed; a CU ingests operands at
+// ~14 GB/s (L2 -> LDS DMA, measured: 117 TFLOP/s at 128 x 128 tiles = 0.031 B/FLOP), so small tiles are ingest-bound; a cut
+// tile costs its pieces a write and a read plus the fix-up launch; whole-tile mode costs the idle CUs of the last round.
+Plan plan_cfg(int M, int N, int K, int bm, int bn, int workers, float* ws, size_t ws_floats) {
+  const int tm = (M + bm - 1) / bm, tn = (N + bn - 1) / bn, NT = tm * tn, NK = (K + GK - 1) / GK;
+  const double flops = 2.0 * tm * bm * (double)tn * bn * NK * GK;
+  const double t_mfma = flops / (157.3e6 * 0.92), t_in = flops * (2.0 / bm + 2.0 / bn) / 3.7e6;
+  const double t_full = std::max(t_mfma, t_in);            // us with all 256 CUs busy
+  const long long units = (long long)NT * NK;
+  int W = workers;
+  if (units < 8LL * W) W = (int)std::max<long long>(8, (units / 8) & ~7LL);
+  if (units < 64) W = 1;
+  Plan whole{std::min(W, NT), NT, 1, 0.0};
+  if (whole.W >= 8) whole.W &= ~7;
+  whole.cost = t_full * 256.0 / NT * ((NT + whole.W - 1) / whole.W);     // a worker = a CU: its tiles in sequence
+  Plan sk{W, 0, 0, 1e30};
+  while (ws && sk.W > 8 && 2 * (size_t)sk.W * bm * bn > ws_floats) sk.W -= 8;
+  if (ws && 2 * (size_t)sk.W * bm * bn <= ws_floats && NT < 8 * sk.W && sk.W > 1) {
+    sk.n_dp = NT >= 2 * sk.W ? (NT / sk.W - 1) * sk.W : 0;
+    const long long U = (long long)(NT - sk.n_dp) * NK;
+    const bool cut = !(U % sk.W == 0 && (U / sk.W) % NK == 0);
+    const double pieces = cut ? (double)(sk.W + (NT - sk.n_dp)) * bm * bn * 4.0 : 0.0;       // bytes, upper estimate
+    sk.cost = t_full * 256.0 / std::min(sk.W, 256) + (cut ? 4.0 + 2.0 * pieces / 3.0e6 : 0.0);
   }
+  return sk.cost < whole.cost ? sk : whole;
 }
 
-// ---- plain library GEMM for the big epilogue-free products (weight gradients dK = [x|m]^T.dZ: 560 x 3040 x 6400, data gradients):
-// hipBLASLt, resolved at run time (dlopen; the header only supplies types).  Without the library, or with RSRGAN_BLAS=0,
-// everything stays on k_gemm.  One algorithm per (shape, layout), taken once from the heuristic and cached. ----
-namespace {
-struct LtPlan { hipblasLtMatmulDesc_t desc; hipblasLtMatrixLayout_t a, b, c; hipblasLtMatmulAlgo_t algo; size_t ws; bool ok; };
-struct Blas {
-  bool tried = false, ok = false;
-  hipblasLtHandle_t handle = nullptr;
-  std::map<hipStream_t, void*> ws;          // one work space per stream that issues products (concurrent streams must not share one)
-  size_t ws_bytes = 32u << 20;
-  decltype(&hipblasLtCreate) create = nullptr;
-  decltype(&hipblasLtMatmulDescCreate) desc_create = nullptr;
-  decltype(&hipblasLtMatmulDescSetAttribute) desc_set = nullptr;
-  decltype(&hipblasLtMatrixLayoutCreate) layout_create = nullptr;
-  decltype(&hipblasLtMatmulPreferenceCreate) pref_create = nullptr;
-  decltype(&hipblasLtMatmulPreferenceSetAttribute) pref_set = nullptr;
-  decltype(&hipblasLtMatmulPreferenceDestroy) pref_destroy = nullptr;
-  decltype(&hipblasLtMatmulAlgoGetHeuristic) heuristic = nullptr;
-  decltype(&hipblasLtMatmul) matmul = nullptr;
-  std::map<std::array<int64_t, 8>, LtPlan> plans;
-};
-Blas g_blas;
-template <class F>
-bool lt_sym(void* lib, const char* name, F& f) { f = reinterpret_cast<F>(dlsym(lib, name)); return f != nullptr; }
-bool blas_ready() {
-  if (g_blas.tried) return g_blas.ok;
-  g_blas.tried = true;
-  const char* e = getenv("RSRGAN_BLAS");
-  if (e && atoi(e) == 0) return false;
-  void* lib = dlopen("libhipblaslt.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!lib) lib = dlopen("libhipblaslt.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!lib) return false;
-  Blas& g = g_blas;
-  if (!lt_sym(lib, "hipblasLtCreate", g.create) || !lt_sym(lib, "hipblasLtMatmulDescCreate", g.desc_create) ||
-      !lt_sym(lib, "hipblasLtMatmulDescSetAttribute", g.desc_set) || !lt_sym(lib, "hipblasLtMatrixLayoutCreate", g.layout_create) ||
-      !lt_sym(lib, "hipblasLtMatmulPreferenceCreate", g.pref_create) || !lt_sym(lib, "hipblasLtMatmulPreferenceSetAttribute", g.pref_set) ||
-      !lt_sym(lib, "hipblasLtMatmulPreferenceDestroy", g.pref_destroy) || !lt_sym(lib, "hipblasLtMatmulAlgoGetHeuristic", g.heuristic) ||
-      !lt_sym(lib, "hipblasLtMatmul", g.matmul))
-    return false;
-  if (g.create(&g.handle) != HIPBLAS_STATUS_SUCCESS || !g.handle) return false;
-  if (const char* w = getenv("RSRGAN_BLAS_WS")) g.ws_bytes = (size_t)atoll(w);      // 0: only algorithms without a work space
-  g.ok = true;
-  return true;
+template <bool AKC, bool BKC, int RT, int CT, int WM, bool MAPA>
+void launch_cfg(GemmArgs& g, const Plan& pl, hipStream_t s, float* ws) {
+  constexpr int WN = 4 / WM, BM = WM * RT * 32, BN = WN * CT * 32;
+  constexpr size_t lds = (size_t)ring_depth(BM, BN) * (BM + BN) * GK * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<AKC, BKC, RT, CT, WM, MAPA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  g.NT = g.tiles_m * g.tiles_n;
+  g.NK = (g.K + GK - 1) / GK;
+  if ((long long)g.NT * g.NK >= (1LL << 30)) { fprintf(stderr, "rsrgan: GEMM beyond the 32-bit (tile, k-tile) unit arithmetic\n"); abort(); }
+  g.ws = ws; g.W = pl.W; g.n_dp = pl.n_dp;
+  const int U = (g.NT - g.n_dp) * g.NK;
+  g.Uq = U / g.W; g.Ur = U % g.W;
+  hipLaunchKernelGGL((k_gemm<AKC, BKC, RT, CT, WM, MAPA>), dim3(g.W), dim3(64 * (4 + NL)), lds, s, g);
+  if (U > 0 && !(U % g.W == 0 && (U / g.W) % g.NK == 0))     // some tile is cut: sum its pieces
+    hipLaunchKernelGGL((k_gemm_fixup<RT, CT, WM>), dim3(g.NT - g.n_dp), dim3(256), 0, s, g);
 }
-// row-major C[M][N] = op(A).op(B)  ==  column-major C^T[N][M] = op(B)^T.op(A)^T: the library's first operand is B, its second A.
-// B stored [N][K] (k contiguous) is the column-major K x N matrix (transpose it), stored [K][N] it is N x K already;
-// A stored [M][K] is the column-major K x M matrix (as is), stored [K][M] it is M x K (transpose it).
-// bias (per output column = per row of the library's D) and relu ride the library's epilogue (BIAS / RELU_BIAS)
-bool blas_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool b_kc, float* C, int ldc, int M, int N, int K, hipStream_t s,
-               const float* bias = nullptr, bool relu = false) {
-  Blas& g = g_blas;
-  const uint32_t epi = bias ? (relu ? HIPBLASLT_EPILOGUE_RELU_BIAS : HIPBLASLT_EPILOGUE_BIAS) : HIPBLASLT_EPILOGUE_DEFAULT;
-  if (relu && !bias) return false;
-  const std::array<int64_t, 8> key = {M, N, K, lda, ldb, ldc, (a_kc ? 1 : 0) | (b_kc ? 2 : 0), (int64_t)epi};
-  auto it = g.plans.find(key);
-  if (it == g.plans.end()) {
-    LtPlan p{}; p.ok = false;
-    const int32_t opB = b_kc ? HIPBLAS_OP_T : HIPBLAS_OP_N, opA = a_kc ? HIPBLAS_OP_N : HIPBLAS_OP_T;
-    hipblasLtMatmulPreference_t pref = nullptr;
-    hipblasLtMatmulHeuristicResult_t res[1];
-    int found = 0;
-    if (g.desc_create(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS &&
-        g.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opB, sizeof(opB)) == HIPBLAS_STATUS_SUCCESS &&
-        g.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opA, sizeof(opA)) == HIPBLAS_STATUS_SUCCESS &&
-        g.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)) == HIPBLAS_STATUS_SUCCESS &&
-        (!bias || g.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) == HIPBLAS_STATUS_SUCCESS) &&
-        g.layout_create(&p.a, HIP_R_32F, b_kc ? K : N, b_kc ? N : K, ldb) == HIPBLAS_STATUS_SUCCESS &&
-        g.layout_create(&p.b, HIP_R_32F, a_kc ? K : M, a_kc ? M : K, lda) == HIPBLAS_STATUS_SUCCESS &&
-        g.layout_create(&p.c, HIP_R_32F, N, M, ldc) == HIPBLAS_STATUS_SUCCESS &&
-        g.pref_create(&pref) == HIPBLAS_STATUS_SUCCESS &&
-        g.pref_set(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &g.ws_bytes, sizeof(g.ws_bytes)) == HIPBLAS_STATUS_SUCCESS &&
-        g.heuristic(g.handle, p.desc, p.a, p.b, p.c, p.c, pref, 1, res, &found) == HIPBLAS_STATUS_SUCCESS && found > 0 &&
-        res[0].workspaceSize <= g.ws_bytes) {
-      p.algo = res[0].algo; p.ws = res[0].workspaceSize; p.ok = true;
-    }
-    if (pref) g.pref_destroy(pref);
-    it = g.plans.emplace(key, p).first;
+
+template <bool AKC, bool BKC, bool MAPA>
+void launch_layout(GemmArgs& g, hipStream_t s, float* ws, size_t ws_floats) {
+  // (192 x 128 and 256 x 128 tiles were measured too: +4 % at 4096^3, slower on every shape of the training steps -- fewer, larger
+  //  pieces to fix up -- and past the 256-register budget of a 6-wave block: they spill.  Not instantiated.)
+  static const int cfgs[][2] = {{128, 128}, {96, 128}, {128, 96}};
+  int best = 0;
+  Plan bp{};
+  for (int c = 0; c < 3; ++c) {
+    Plan pl = plan_cfg(g.M, g.N, g.K, cfgs[c][0], cfgs[c][1], g_gemm_workers, ws, ws_floats);
+    if (c == 0 || pl.cost < 0.97 * bp.cost) { best = c; bp = pl; }
   }
-  const LtPlan& p = it->second;
-  if (!p.ok) return false;
-  const float one = 1.f, zero = 0.f;
-  void* wsp = nullptr;
-  if (p.ws) {
-    auto w = g.ws.find(s);
-    if (w == g.ws.end()) {
-      void* mem = nullptr;
-      if (g.ws.size() >= 8) {                     // streams of models long gone: start over (never inside a capture: the first
-        (void)hipDeviceSynchronize();             // product of a stream runs in a segment's eager first pass)
-        for (auto& kv : g.ws) (void)hipFree(kv.second);
-        g.ws.clear();
-      }
-      if (hipMalloc(&mem, g.ws_bytes) != hipSuccess) return false;
-      w = g.ws.emplace(s, mem).first;
-    }
-    wsp = w->second;
+  switch (best) {
+    case 1: launch_cfg<AKC, BKC, 3, 1, 1, MAPA>(g, bp, s, ws); break;
+    case 2: launch_cfg<AKC, BKC, 1, 3, 4, MAPA>(g, bp, s, ws); break;
+    default: launch_cfg<AKC, BKC, 2, 2, 2, MAPA>(g, bp, s, ws); break;
   }
-  if (bias && g.desc_set(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) != HIPBLAS_STATUS_SUCCESS) return false;
-  return g.matmul(g.handle, p.desc, &one, B, p.a, A, p.b, &zero, C, p.c, C, p.c, &p.algo, wsp, p.ws, s) == HIPBLAS_STATUS_SUCCESS;
 }
 }  // namespace
 
-void launch_gemm2(const float* A, int lda, const float* A2, int lda2, int M1, bool a_kc, const float* B, int ldb, bool b_kc,
-                  float* C, int ldc, int M, int N, int K, const float* bias, int act, float alpha, bool accumulate,
-                  hipStream_t s, float* ws, size_t ws_floats) {
-  if (M <= 0 || N <= 0) return;
-  // (measured, MI355X: the library wins where the output alone fills the chip -- 6400 x 1024 x 1024: 101 vs 90 TFLOP/s, 280 x 3040 x 6400:
-  //  105 vs 91 -- and loses on small outputs with a long K, where k_gemm's split-K is the better plan: 760 x 280 x 6400 40 vs 53)
-  const int ldcat = (M + 3) & ~3;
-  const bool cat = A2 && !a_kc && ws && (size_t)K * ldcat <= ws_floats;      // two-source operand: stack it once, one product
-  const double out_elems = (double)((A2 && !cat) ? std::min(M1, M - M1) : M) * N;
-  const bool epi_ok = act == 0 || (act == 2 && bias);               // none / bias / bias + relu (leaky-relu stays on k_gemm)
-  if (epi_ok && !(bias && A2) && !accumulate && out_elems >= 0.8e6 && K >= 256 && N > NBN && (!A2 || !a_kc) && blas_ready()) {
-    bool ok;
-    if (cat) {                  // [x_t | m_{t-1}] as one [K][M] operand in the (otherwise unused) split-K work space: one 560-row
-      const size_t total = (size_t)K * (ldcat >> 2);      // product runs at 131 TFLOP/s, two 280-row halves at 105
-      hipLaunchKernelGGL(k_concat_cols, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, s, A, lda, M1, A2, lda2,
-                         M - M1, ws, ldcat, K);
-      ok = blas_gemm(ws, ldcat, false, B, ldb, b_kc, C, ldc, M, N, K, s);
-    } else if (A2) {
-      ok = blas_gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, M1, N, K, s) &&
-           blas_gemm(A2, lda2, a_kc, B, ldb, b_kc, C + (size_t)M1 * ldc, ldc, M - M1, N, K, s);
-    } else {
-      ok = blas_gemm(A, lda, a_kc, B, ldb, b_kc, C, ldc, M, N, K, s, bias, act == 2);
-    }
-    if (ok) return;
-    // (no algorithm for this shape, or a failed call: k_gemm for this product)
+static void launch_gemm16(const float* A, int lda, const float* A2, int lda2, int M1, bool a_kc, const float* B, int ldb, bool b_kc,
+                          float* C, int ldc, int M, int N, int K, const float* bias, int act, float alpha, bool accumulate,
+                          hipStream_t s, float* ws, size_t ws_floats) {
+  const int gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
+  const int nk = (K + GBK - 1) / GBK;
+  int splits = 1;
+  const int ldw = (N + 3) & ~3;
+  if (ws && gx * gy < 192 && nk * GBK >= 128) {
+    int cap = 64;
+    while (cap > 1 && (size_t)cap * M * ldw > ws_floats) --cap;
+    splits = pick_splits(gx * gy, nk, (size_t)M * ldw * sizeof(float), cap, 1.2 * GBK / 16, GBK == 16 ? 4 : 2);
   }
-  if (N <= NBN && !b_kc && !A2 && M >= NBM) {         // narrow output: 256 x 32 tiles
+  const int per = std::max(1, (nk + splits - 1) / splits);
+  splits = std::max(1, (nk + per - 1) / per);
+  float* w = splits > 1 ? ws : nullptr;
+  dim3 grid(gx, gy, splits), block(256);
+  const int acc = accumulate ? 1 : 0;
+  if (a_kc && !b_kc)
+    hipLaunchKernelGGL((k_gemm16<true, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per, nullptr, 0, 0);
+  else if (a_kc && b_kc)
+    hipLaunchKernelGGL((k_gemm16<true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per, nullptr, 0, 0);
+  else if (!a_kc && !b_kc)
+    hipLaunchKernelGGL((k_gemm16<false, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per, A2, lda2, M1);
+  else
+    hipLaunchKernelGGL((k_gemm16<false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per, A2, lda2, M1);
+  if (splits > 1) {
+    const size_t total = (size_t)M * N;
+    const int blocks = (int)std::min<size_t>(2048, (total + 255) / 256);
+    hipLaunchKernelGGL(k_splitk_reduce, dim3(blocks), dim3(256), 0, s, ws, ldw, splits, C, ldc, M, N, bias, act, alpha, acc);
+  }
+}
+
+
+void launch_gemm_mapped(const float* A, int lda, const GemmRowMap& ma, const float* A2, int lda2, int M1, bool a_kc, const float* B, int ldb,
+                        bool b_kc, float* C, int ldc, int M, int N, int K, const float* bias, int act, float alpha,
+                        bool accumulate, hipStream_t s, float* ws, size_t ws_floats) {
+  if (M <= 0 || N <= 0 || K <= 0) return;
+  const bool mapped = ma.rows_per > 0;
+  if (N <= NBN && !b_kc && !A2 && M >= NBM && !mapped) {         // narrow output: 256 x 32 tiles
     const int gy = (M + NBM - 1) / NBM, nk = (K + BK - 1) / BK, ldw = (N + 3) & ~3;
     int splits = 1;
     if (ws && gy < 192 && nk >= 8) {
@@ -448,33 +788,34 @@ void launch_gemm2(const float* A, int lda, const float* A2, int lda2, int M1, bo
     }
     return;
   }
-  const int gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
-  const int nk = (K + GBK - 1) / GBK;
-  int splits = 1;
-  const int ldw = (N + 3) & ~3;
-  if (ws && gx * gy < 192 && nk * GBK >= 128) {
-    int cap = 64;
-    while (cap > 1 && (size_t)cap * M * ldw > ws_floats) --cap;
-    splits = pick_splits(gx * gy, nk, (size_t)M * ldw * sizeof(float), cap, 1.2 * GBK / 16, GBK == 16 ? 4 : 2);
+  // k_gemm (stream-K, loader waves, LDS ring) for the window views and for the products with enough work per tile and enough
+  // tiles; k_gemm16 for the rest (measured, tools/ubench/gemm_bench.hip; the two are within noise of each other in between)
+  const double outs = (double)M * N;
+  if (!mapped && !(K >= 256 && outs >= 4.0e6) && !(K >= 2048 && outs >= 1.5e6)) {
+    launch_gemm16(A, lda, a_kc ? nullptr : A2, lda2, M1, a_kc, B, ldb, b_kc, C, ldc, M, N, K, bias, act, alpha, accumulate, s, ws, ws_floats);
+    return;
   }
-  const int per = std::max(1, (nk + splits - 1) / splits);
-  splits = std::max(1, (nk + per - 1) / per);
-  float* w = splits > 1 ? ws : nullptr;
-  dim3 grid(gx, gy, splits), block(256);
-  const int acc = accumulate ? 1 : 0;
-  if (a_kc && !b_kc)
-    hipLaunchKernelGGL((k_gemm<true, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per, nullptr, 0, 0);
-  else if (a_kc && b_kc)
-    hipLaunchKernelGGL((k_gemm<true, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per, nullptr, 0, 0);
-  else if (!a_kc && !b_kc)
-    hipLaunchKernelGGL((k_gemm<false, false>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per, A2, lda2, M1);
-  else
-    hipLaunchKernelGGL((k_gemm<false, true>), grid, block, 0, s, A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, acc, w, ldw, per, A2, lda2, M1);
-  if (splits > 1) {
-    const size_t total = (size_t)M * N;
-    const int blocks = (int)std::min<size_t>(2048, (total + 255) / 256);
-    hipLaunchKernelGGL(k_splitk_reduce, dim3(blocks), dim3(256), 0, s, ws, ldw, splits, C, ldc, M, N, bias, act, alpha, acc);
+  GemmArgs g{};
+  g.A = A; g.A2 = a_kc ? nullptr : A2; g.B = B; g.bias = bias; g.C = C;
+  g.lda = lda; g.lda2 = lda2; g.M1 = M1; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.act = act; g.accumulate = accumulate ? 1 : 0; g.alpha = alpha;
+  g.ma = ma;
+  if (mapped) {                 // the SEGAN-style convolutions: a window view times a [K][N] filter / gradient (b_kc never occurs)
+    g.A2 = nullptr;
+    if (a_kc) launch_layout<true, false, true>(g, s, ws, ws_floats);
+    else launch_layout<false, false, true>(g, s, ws, ws_floats);
   }
+  else if (a_kc && !b_kc) launch_layout<true, false, false>(g, s, ws, ws_floats);
+  else if (a_kc && b_kc) launch_layout<true, true, false>(g, s, ws, ws_floats);
+  else if (!a_kc && !b_kc) launch_layout<false, false, false>(g, s, ws, ws_floats);
+  else launch_layout<false, true, false>(g, s, ws, ws_floats);
+}
+
+void launch_gemm2(const float* A, int lda, const float* A2, int lda2, int M1, bool a_kc, const float* B, int ldb, bool b_kc,
+                  float* C, int ldc, int M, int N, int K, const float* bias, int act, float alpha, bool accumulate,
+                  hipStream_t s, float* ws, size_t ws_floats) {
+  const GemmRowMap none{0, 0, 0};
+  launch_gemm_mapped(A, lda, none, A2, lda2, M1, a_kc, B, ldb, b_kc, C, ldc, M, N, K, bias, act, alpha, accumulate, s, ws, ws_floats);
 }
 
 void launch_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool b_kc, float* C, int ldc,

@@ -129,6 +129,14 @@ void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s);
 // ---------------------------------------------------------------- batched GEMM
 // C[M,N] (+)= A.B (+bias)(lrelu).  a_kc: A(m,k)=A[m*lda+k] else A[k*lda+m];
 // b_kc: B(k,n)=B[n*ldb+k] else B[k*ldb+n].
+// Row map of a GEMM operand (rows_per > 0): row r lives at float offset (r / rows_per) * outer + (r % rows_per) * inner instead of
+// r * ld -- an overlapping-window view of a channels-last activation [sample][position][channel] (SEGAN-style strided conv1d as a
+// GEMM: inner = stride * channels, a row = kwidth * channels contiguous floats).  For a k-contiguous operand the mapped index is the
+// row (m or n); for an x-contiguous operand it is k.
+struct GemmRowMap { int rows_per; long long outer; long long inner; };
+void launch_gemm_mapped(const float* A, int lda, const GemmRowMap& ma, const float* A2, int lda2, int M1, bool a_kc, const float* B, int ldb,
+                        bool b_kc, float* C, int ldc, int M, int N, int K, const float* bias, int act, float alpha,
+                        bool accumulate, hipStream_t s, float* ws, size_t ws_floats);
 void launch_gemm2(const float* A, int lda, const float* A2, int lda2, int M1, bool a_kc, const float* B, int ldb, bool b_kc,
                   float* C, int ldc, int M, int N, int K, const float* bias, int act, float alpha, bool accumulate,
                   hipStream_t s, float* ws, size_t ws_floats);   // rows >= M1 of an m-contiguous A come from A2

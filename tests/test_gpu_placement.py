@@ -73,15 +73,10 @@ def test_folded_discriminator_forward_agrees():
     assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
 
 
-def test_library_gemm_path_agrees_and_is_reproducible():
-    """The big epilogue-free products (dK = [x|m]^T.dZ with K = T*B >= 256) go to hipBLASLt (csrc/gemm.hip: blas_gemm); with
-    RSRGAN_BLAS=0 they stay on k_gemm.  Same step to fp32 rounding, and the library path repeats bit for bit."""
+def test_stream_k_gemm_step_is_reproducible():
+    """Every time-batched product runs on the hand-written stream-K k_gemm (csrc/gemm.hip; no vendor library since round 3): the
+    pieces of a cut tile are summed in k order by k_gemm_fixup, no float atomics, so two processes produce the same bits."""
     size = {"RSRGAN_TEST_B": "16", "RSRGAN_TEST_T": "16"}
-    a = _run(dict(size, RSRGAN_BLAS="1"))
-    a2 = _run(dict(size, RSRGAN_BLAS="1"))
-    b = _run(dict(size, RSRGAN_BLAS="0"))
-    assert a == a2, (a, a2)
-    for k in ("d0", "g0", "d1", "g1"):
-        assert np.allclose(a[k], b[k], rtol=2e-5, atol=1e-7), (k, a[k], b[k])
-    assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
-    assert a["vars_sha"] != b["vars_sha"] or a == b          # (different summation orders: the bits differ, the values agree)
+    a = _run(dict(size))
+    b = _run(dict(size))
+    assert a == b, (a, b)
