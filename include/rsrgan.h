@@ -225,6 +225,53 @@ int rsrgan_op_gemm(const float* A, int32_t lda, int32_t a_kcontig,
                    float* C, int32_t ldc, int32_t M, int32_t N, int32_t K,
                    const float* bias, int32_t act, float alpha, int32_t accumulate, void* stream);
 
+/* ---- SEGAN-style conv G/D (models/segan.py:SEGAN with generator.py:AEGenerator, discriminator.py:discriminator, utils/bnorm.py:VBN;
+ * BASELINE.json configs[4]).  The reference's trainer cannot run as shipped (segan.py:136 calls an undefined variables_on_gpu0(),
+ * scripts/train_segan.py:20 imports a missing module); the graph it would build is fully specified and is what these entry
+ * points compute.  One run = sess.run([model.d_opt, model.d_losses[0]]) / sess.run([model.g_opt, model.g_losses[0]])
+ * (scripts/train_segan.py:32-52).  x [B, input_len], labels [B, output_dim]; the random draws of a run are INPUTS: z
+ * [B, len(code), depth_last] (generator.py:201-205) and one gaussian_noise_layer draw [B, input_len + output_dim] per
+ * discriminator call -- reference ("dummy") pass, real, fake (discriminator.py:74; NULL = std 0). */
+typedef struct rsrgan_segan_cfg {
+  int32_t batch_size;      /* args.batch_size (also the VBN mixing weight 1 / (B + 1), bnorm.py:37) */
+  int32_t input_len;       /* input_dim * (left_context + 1 + right_context) (segan.py:96-100) */
+  int32_t output_dim;      /* units of the generator's last dense layer (generator.py:283-287) */
+  int32_t n_layers;        /* len(g_enc_depths) = len(d_num_fmaps) = 11 (segan.py:89-91) */
+  int32_t g_depths[16];    /* 16,32,32,64,64,128,128,256,256,512,1024; multiples of 16 */
+  int32_t d_depths[16];
+  int32_t g_kwidth;        /* 20 (generator.py:151) */
+  int32_t d_kwidth;        /* 31 (discriminator.py:79,88) */
+  int32_t g_prelu;         /* args.g_nl == 'prelu' (run_segan.sh:120); 0 = leakyrelu */
+  float   lrelu_alpha;     /* utils/ops.py:120 (0.3) */
+  float   vbn_eps;         /* bnorm.py:17 (1e-5) */
+  float   rms_decay;       /* tf.train.RMSPropOptimizer defaults (segan.py:123-124): 0.9 */
+  float   rms_eps;         /* 1e-10 */
+} rsrgan_segan_cfg;
+typedef struct rsrgan_segan_handle_s* rsrgan_segan_handle;
+enum { RSRGAN_SEGAN_G_LR = 0, RSRGAN_SEGAN_D_LR = 1, RSRGAN_SEGAN_L1_LAMBDA = 2 };   /* segan.py:110-111,106 */
+int rsrgan_segan_default_cfg(rsrgan_segan_cfg* cfg);
+int rsrgan_segan_create(const rsrgan_segan_cfg* cfg, uint64_t seed, rsrgan_segan_handle* out);
+int rsrgan_segan_destroy(rsrgan_segan_handle h);
+int rsrgan_segan_set_scalar(rsrgan_segan_handle h, int32_t which, double v);
+/* variable table = tf.trainable_variables() split by the g_/d_ prefix (segan.py:269-283), graph-construction order */
+int rsrgan_segan_num_tensors(rsrgan_segan_handle h, int32_t net);
+int rsrgan_segan_tensor_info(rsrgan_segan_handle h, int32_t net, int32_t idx, char* name, int32_t name_cap, int32_t* rows, int32_t* cols,
+                             int64_t* dense_offset);
+int64_t rsrgan_segan_param_count(rsrgan_segan_handle h, int32_t net);
+/* what: 0 = variables, 1 = the RMSProp "rms" slots, 2 = last gradients (tower-local or all-reduced); dense flat DEVICE vectors */
+int rsrgan_segan_get_params(rsrgan_segan_handle h, int32_t net, int32_t what, float* dense, void* stream);
+int rsrgan_segan_set_params(rsrgan_segan_handle h, int32_t net, int32_t what, const float* dense, void* stream);
+/* G(x) [B, output_dim] (model.Gs, segan.py:194-197) */
+int rsrgan_segan_forward_g(rsrgan_segan_handle h, const float* x, const float* z, float* y, void* stream);
+/* per-tower compute_gradients (segan.py:139-146): losses DEVICE float[3] = {d_rl, d_fk, d_loss} / {g_adv, g_l1, g_loss}; train = 0: losses only */
+int rsrgan_segan_d_backward(rsrgan_segan_handle h, const float* x, const float* labels, const float* z, const float* noise_ref,
+                            const float* noise_real, const float* noise_fake, float* out_losses, int32_t train, void* stream);
+int rsrgan_segan_g_backward(rsrgan_segan_handle h, const float* x, const float* labels, const float* z, const float* noise_ref,
+                            const float* noise_fake, float* out_losses, int32_t train, void* stream);
+/* average_gradients (segan.py:148-149) = the caller's RCCL all-reduce(avg) of this buffer; then apply_gradients (:150-151) */
+int rsrgan_segan_grad_buffer(rsrgan_segan_handle h, int32_t net, float** ptr, int64_t* count);
+int rsrgan_segan_apply(rsrgan_segan_handle h, int32_t net, void* stream);
+
 int rsrgan_version(void);
 
 #ifdef __cplusplus

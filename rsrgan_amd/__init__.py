@@ -8,7 +8,8 @@ there is NO CPU fallback: constructing a model without the library or without a 
 from .gan_rnn import GAN_RNN, Model                      # noqa: F401
 from .gan import GAN                                     # noqa: F401
 from .trainer import RNNTrainer, DNNTrainer              # noqa: F401
+from .segan import SEGAN                                 # noqa: F401
 from .train import (train_one_iteration, eval_one_iteration,   # noqa: F401
                     exponential_decay)
 
-__all__ = ["GAN_RNN", "GAN", "RNNTrainer", "DNNTrainer", "Model", "train_one_iteration", "eval_one_iteration", "exponential_decay"]
+__all__ = ["GAN_RNN", "GAN", "SEGAN", "RNNTrainer", "DNNTrainer", "Model", "train_one_iteration", "eval_one_iteration", "exponential_decay"]

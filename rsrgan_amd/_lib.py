@@ -22,7 +22,11 @@ SYMBOLS = ["rsrgan_default_cfg", "rsrgan_create", "rsrgan_destroy", "rsrgan_last
            "rsrgan_g_step", "rsrgan_d_backward", "rsrgan_g_backward", "rsrgan_apply", "rsrgan_grad_buffer",
            "rsrgan_grad_bucket_count", "rsrgan_grad_bucket_info", "rsrgan_grad_bucket_wait",
            "rsrgan_profile_begin", "rsrgan_profile_read",
-           "rsrgan_op_gemm", "rsrgan_version"]
+           "rsrgan_op_gemm", "rsrgan_version",
+           "rsrgan_segan_default_cfg", "rsrgan_segan_create", "rsrgan_segan_destroy", "rsrgan_segan_set_scalar",
+           "rsrgan_segan_num_tensors", "rsrgan_segan_tensor_info", "rsrgan_segan_param_count", "rsrgan_segan_get_params",
+           "rsrgan_segan_set_params", "rsrgan_segan_forward_g", "rsrgan_segan_d_backward", "rsrgan_segan_g_backward",
+           "rsrgan_segan_grad_buffer", "rsrgan_segan_apply"]
 
 
 class RsrganCfg(C.Structure):
@@ -33,6 +37,14 @@ class RsrganCfg(C.Structure):
                 ("adam_beta2", C.c_float), ("adam_eps", C.c_float), ("ema_decay", C.c_float),
                 ("lrelu_alpha", C.c_float), ("forget_bias", C.c_float), ("cross_validation", C.c_int32),
                 ("flags", C.c_int32), ("d_joint_off", C.c_int32), ("d_joint_dim", C.c_int32), ("g_splice", C.c_int32)]
+
+
+class SeganCfg(C.Structure):
+    """include/rsrgan.h rsrgan_segan_cfg"""
+    _fields_ = [("batch_size", C.c_int32), ("input_len", C.c_int32), ("output_dim", C.c_int32), ("n_layers", C.c_int32),
+                ("g_depths", C.c_int32 * 16), ("d_depths", C.c_int32 * 16), ("g_kwidth", C.c_int32), ("d_kwidth", C.c_int32),
+                ("g_prelu", C.c_int32), ("lrelu_alpha", C.c_float), ("vbn_eps", C.c_float), ("rms_decay", C.c_float),
+                ("rms_eps", C.c_float)]
 
 
 class RsrganError(RuntimeError):
@@ -78,6 +90,21 @@ def load():
     lib.rsrgan_profile_begin.argtypes = [vp]
     lib.rsrgan_profile_read.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.rsrgan_op_gemm.argtypes = [p, i32, i32, p, i32, i32, p, i32, i32, i32, i32, p, i32, f32, i32, vp]
+    lib.rsrgan_segan_default_cfg.argtypes = [C.POINTER(SeganCfg)]
+    lib.rsrgan_segan_create.argtypes = [C.POINTER(SeganCfg), C.c_uint64, C.POINTER(vp)]
+    lib.rsrgan_segan_destroy.argtypes = [vp]
+    lib.rsrgan_segan_set_scalar.argtypes = [vp, i32, C.c_double]
+    lib.rsrgan_segan_num_tensors.argtypes = [vp, i32]
+    lib.rsrgan_segan_tensor_info.argtypes = [vp, i32, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64)]
+    lib.rsrgan_segan_param_count.argtypes = [vp, i32]
+    lib.rsrgan_segan_param_count.restype = i64
+    lib.rsrgan_segan_get_params.argtypes = [vp, i32, i32, p, vp]
+    lib.rsrgan_segan_set_params.argtypes = [vp, i32, i32, p, vp]
+    lib.rsrgan_segan_forward_g.argtypes = [vp, p, p, p, vp]
+    lib.rsrgan_segan_d_backward.argtypes = [vp, p, p, p, p, p, p, p, i32, vp]
+    lib.rsrgan_segan_g_backward.argtypes = [vp, p, p, p, p, p, p, i32, vp]
+    lib.rsrgan_segan_grad_buffer.argtypes = [vp, i32, C.POINTER(p), C.POINTER(i64)]
+    lib.rsrgan_segan_apply.argtypes = [vp, i32, vp]
     _lib = lib
     return lib
 
