@@ -314,6 +314,85 @@ def bench_rced(a, rank, local, world, dev):
     rdist.barrier()
 
 
+def segan_flops(L, U, depths, gk=20, dk=31):
+    """algorithmic conv / dense FLOP (2 x MAC) per sample: generator forward F_G, discriminator forward F_D of ONE call"""
+    le = [L]
+    for _ in depths:
+        le.append((le[-1] + 1) // 2)
+    fg, cin = 0, 1
+    for i, d in enumerate(depths):
+        fg += 2 * le[i + 1] * gk * cin * d
+        cin = d
+    cin = 2 * depths[-1]
+    dec = list(depths[:-1][::-1]) + [1]
+    for j, d in enumerate(dec):                             # conv2d_transpose: every input position meets every tap once
+        fg += 2 * le[len(depths) - j] * gk * cin * d
+        cin = 2 * d
+    fg += 2 * L * U
+    ld = [L + U]
+    for _ in depths:
+        ld.append((ld[-1] + 1) // 2)
+    fd, cin = 0, 1
+    for i, d in enumerate(depths):
+        fd += 2 * ld[i + 1] * dk * cin * d
+        cin = d
+    fd += 2 * ld[-1] * dk * cin + 2 * ld[-1]
+    return fg, fd
+
+
+def bench_segan(a, rank, local, world, dev):
+    """BASELINE.json configs[4]: SEGAN-style conv G/D (models/segan.py) on --segan-len-sample chunks, --batch chunks per GPU; one
+    step = one D-run + one G-run (scripts/train_segan.py:32-44), z and the three discriminator noise draws made on the device."""
+    from types import SimpleNamespace
+    from rsrgan_amd import SEGAN, dist as rdist
+    from rsrgan_amd.segan import DEPTHS
+    B, L, U = a.batch, a.segan_len, 40
+    args = SimpleNamespace(batch_size=B, input_dim=L, output_dim=U, left_context=0, right_context=0, g_type="ae", deconv_type="deconv",
+                           bias_downconv=True, bias_deconv=True, bias_D_conv=True, g_nl="prelu", init_noise_std=0.5, init_l1_weight=100.0,
+                           g_learning_rate=1e-3, d_learning_rate=1e-3, save_dir=None)      # run_segan.sh:96-124
+    model = SEGAN(None, args, ["gpu:%d" % local], seed=4321, process_group=(torch.distributed.group.WORLD if world > 1 else None))
+    rng = np.random.default_rng(1234 + rank)
+    x = torch.from_numpy(rng.standard_normal((B, L)).astype(np.float32)).to(dev)
+    lab = torch.from_numpy(rng.standard_normal((B, U)).astype(np.float32)).to(dev)
+
+    def step():
+        model.d_step(x, lab)
+        return model.g_step(x, lab)
+    for _ in range(a.warmup):
+        step()
+    rdist.barrier(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter(); e0.record()
+    for _ in range(a.steps):
+        last = step()
+    e1.record(); torch.cuda.synchronize(); rdist.barrier()
+    dt = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        t = torch.tensor([dt, dev_ms], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt, dev_ms = float(t[0]), float(t[1])
+    if rank == 0:
+        fg, fd = segan_flops(L, U, DEPTHS)
+        # D-run: G forward, three discriminator calls forward and backward (data + weight gradients); G-run: G forward, reference +
+        # fake calls forward, the fake call's data gradient, G backward (data + weight gradients)
+        fps = 4 * fg + 12 * fd
+        ach = fps * B / (dev_ms * 1e-3 / a.steps) / 1e12
+        out = {"metric": "GAN train chunks/sec (D-run + G-run), SEGAN-style conv G/D on %d-sample chunks (BASELINE configs[4])" % L,
+               "value": round(B * world * a.steps / dt, 2), "unit": "chunks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(dt * 1e3 / a.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "models/segan.py 1 D-run + 1 G-run, AEGenerator 11 x (k=20, 16..1024) + VBN discriminator 11 x (k=31), "
+                                      "%d-sample chunks -> %d, B=%d/GPU" % (L, U, B), "global_batch": B * world, "parallelism": "dp%d" % world,
+                          "losses_last_step": [round(float(v), 6) for v in last]},
+               "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                            "scope": "all launches of one step; algorithmic 4*F_G + 12*F_D = %d FLOP/chunk (F_G=%d, F_D=%d)" % (fps, fg, fd)}}
+        print(json.dumps(out), flush=True)
+    model.close()
+    rdist.barrier()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -321,7 +400,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--frames", type=int, default=100)
-    ap.add_argument("--net", default="lstm", choices=["lstm", "res_lstm_l", "dnn_gan", "dnn_trainer", "baseline_named", "rced"],
+    ap.add_argument("--net", default="lstm", choices=["lstm", "res_lstm_l", "dnn_gan", "dnn_trainer", "baseline_named", "rced", "segan"],
                     help="dnn_gan = the frame-level GAN of models/gan.py (SURVEY 8f-1): --batch frames per step, T ignored; "
                          "baseline_named = BASELINE.json's wording: 2-layer 512-unit LSTM (no projection, SURVEY 8d-iii) + DNN D")
     ap.add_argument("--d-type", default="lstm", choices=["lstm", "dnn"],
@@ -336,6 +415,7 @@ def main():
                                                               "(run_gan_dnn.sh:134, run_dnn.sh:134)")
     ap.add_argument("--rced-gan", action="store_true", help="--net rced: 1 D + 1 G step with discriminator_dnn instead of the supervised trainer")
     ap.add_argument("--rced-width", type=int, default=40, help="--net rced: frame width (run_dnn.sh:137 uses 40-dim MFCC input)")
+    ap.add_argument("--segan-len", type=int, default=16384, help="--net segan: samples per chunk (BASELINE.json configs[4]: 16384; --batch 32)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling (SURVEY 8d): --batch is the GLOBAL batch, split evenly over the ranks (default: weak, "
                          "--batch per GPU as the reference defines batch_size per tower)")
@@ -364,6 +444,8 @@ def main():
         return bench_dnn_gan(a, rank, local, world, dev)
     if a.net == "rced":
         return bench_rced(a, rank, local, world, dev)
+    if a.net == "segan":
+        return bench_segan(a, rank, local, world, dev)
     res = measure_sequence(a, a.net, a.d_type, a.batch, a.frames, a.steps, a.warmup, rank, local, world, dev)
     model, g_type, dt, dev_ms, losses, B, T = res["model"], res["g_type"], res["dt"], res["dev_ms"], res["losses"], a.batch, a.frames
     if a.net == "baseline_named":
@@ -474,6 +556,17 @@ def main():
                                     "ms_per_step": r3["ms_per_step"], "roofline_frac": r3["roofline"]["frac"]})
         except Exception as e:          # never lose the headline line to a variant
             out["variants"].append({"workload": "R-CED + discriminator_dnn (configs[3])", "error": str(e)[:200]})
+        try:           # BASELINE.json configs[4]: SEGAN-style conv G/D, 16384-sample chunks, B = 32 (bench.py --net segan --batch 32)
+            import contextlib, io
+            a4 = argparse.Namespace(**vars(a)); a4.net = "segan"; a4.batch = 32; a4.segan_len = 16384; a4.steps = 3; a4.warmup = 1
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                bench_segan(a4, rank, local, world, dev)
+            r4 = json.loads(buf.getvalue().strip().splitlines()[-1])
+            out["variants"].append({"workload": r4["config"]["workload"], "value": r4["value"], "unit": r4["unit"],
+                                    "ms_per_step": r4["ms_per_step"], "roofline_frac": r4["roofline"]["frac"]})
+        except Exception as e:
+            out["variants"].append({"workload": "SEGAN-style conv G/D (configs[4])", "error": str(e)[:200]})
     if rank == 0:
         print(json.dumps(out), flush=True)
     rdist.barrier()

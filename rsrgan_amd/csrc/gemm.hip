@@ -713,16 +713,19 @@ template <bool AKC, bool BKC, bool MAPA>
 void launch_layout(GemmArgs& g, hipStream_t s, float* ws, size_t ws_floats) {
   // (192 x 128 and 256 x 128 tiles were measured too: +4 % at 4096^3, slower on every shape of the training steps -- fewer, larger
   //  pieces to fix up -- and past the 256-register budget of a 6-wave block: they spill.  Not instantiated.)
-  static const int cfgs[][2] = {{128, 128}, {96, 128}, {128, 96}};
+  // 256 x 32 / 256 x 64: the window-view products of the first SEGAN layers have 16..64 output channels and ~1e5..1e6 rows
+  static const int cfgs[][2] = {{128, 128}, {96, 128}, {128, 96}, {256, 64}, {256, 32}};
   int best = 0;
   Plan bp{};
-  for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < 5; ++c) {
     Plan pl = plan_cfg(g.M, g.N, g.K, cfgs[c][0], cfgs[c][1], g_gemm_workers, ws, ws_floats);
     if (c == 0 || pl.cost < 0.97 * bp.cost) { best = c; bp = pl; }
   }
   switch (best) {
     case 1: launch_cfg<AKC, BKC, 3, 1, 1, MAPA>(g, bp, s, ws); break;
     case 2: launch_cfg<AKC, BKC, 1, 3, 4, MAPA>(g, bp, s, ws); break;
+    case 3: launch_cfg<AKC, BKC, 2, 2, 4, MAPA>(g, bp, s, ws); break;
+    case 4: launch_cfg<AKC, BKC, 2, 1, 4, MAPA>(g, bp, s, ws); break;
     default: launch_cfg<AKC, BKC, 2, 2, 2, MAPA>(g, bp, s, ws); break;
   }
 }

@@ -308,7 +308,7 @@ void SeganModel::g_backward_pass(hipStream_t s) {
   // last deconv (one output channel): dX = strided conv of dwave with the filter as [k][Cin]; dW[dk][ci] = view(dwave)^T . X
   {
     const SgLayer& L = dec[n - 1];
-    launch_sum_all(dwave, B, Lx, ldL, G.Gd(L.tb), s);
+    launch_sum_all(dwave, B, Lx, ldL, G.Gd(L.tb), red, s);
     launch_conv1_wgrad(dwave, ldL, B, Lx, L.k, xd[n - 1], L.Cin, L.Cin, G.Gd(L.tW), G.t[L.tW].ld, red, red_floats, s);
     launch_conv1_fwd(dwave, ldL, B, Lx, L.k, G.W(L.tW), G.t[L.tW].ld, nullptr, L.Cin, gB, L.Cin, s);
   }

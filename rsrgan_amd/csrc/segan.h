@@ -19,7 +19,7 @@ void launch_conv1_wgrad(const float* x, int ldx, int B, int L, int k, const floa
                         hipStream_t s);
 void launch_tconv1(const float* S, int lds, int B, int Ls, int C, int Lt, int k, const float* W, int ldw, const float* bias, float* t, int ldt,
                    hipStream_t s);
-void launch_sum_all(const float* src, int rows, int cols, int ld, float* out, hipStream_t s);
+void launch_sum_all(const float* src, int rows, int cols, int ld, float* out, float* scratch, hipStream_t s);
 void launch_prep_tconv(const float* W, int ldw, int nb, int na, int e, int ne, float* dst, int ldd, hipStream_t s);
 void launch_interleave(const float* T0, const float* T1, int Q0, int Q1, int i00, int i01, int pl, const float* bias, float* T, int B, int Lt, int C,
                        hipStream_t s);

@@ -271,8 +271,8 @@ __global__ __launch_bounds__(256) void k_colred_final(const float* __restrict__ 
 }
 void launch_colred(int mode, const float* a, int lda, int coff, const float* b, int ldb, int C, size_t rows_per, int P, const float* coef, int ldcoef,
                    float leak, float* out, int ldo, bool accumulate, float* scratch, size_t scratch_floats, hipStream_t s) {
-  int chunk = 256;
-  while (((rows_per + chunk - 1) / chunk) * (size_t)P * 2 * C > scratch_floats || (rows_per + chunk - 1) / chunk > 2048) chunk *= 2;
+  int chunk = 256;                                       // <= 128 partials per (pass, column): the final sum is one thread per column
+  while (((rows_per + chunk - 1) / chunk) * (size_t)P * 2 * C > scratch_floats || (rows_per + chunk - 1) / chunk > 128) chunk *= 2;
   const int chunks_per = (int)((rows_per + chunk - 1) / chunk);
   dim3 grid(P * chunks_per), block(256);
   if (mode == 0) hipLaunchKernelGGL(k_colred_part<0>, grid, block, 0, s, a, lda, coff, b, ldb, C, rows_per, chunk, chunks_per, coef, ldcoef, leak, scratch);
@@ -505,18 +505,20 @@ void launch_segan_l1(const float* G, const float* lab, int n, const float* lambd
   hipLaunchKernelGGL(k_segan_l1, dim3(1), dim3(256), 0, s, G, lab, n, lambda, dG, accumulate ? 1 : 0, loss3);
 }
 
-// out[0] = sum of src[rows][cols] (fixed order: one block)
-__global__ __launch_bounds__(256) void k_sum_all(const float* __restrict__ src, int rows, int cols, int ld, float* __restrict__ out) {
+// out[0] = sum of src[rows][cols]: 256 block partials, then one block (fixed order)
+__global__ __launch_bounds__(256) void k_sum_all(const float* __restrict__ src, size_t n, int cols, int ld, float* __restrict__ out, int final_pass) {
   __shared__ float red[256];
   float a = 0.f;
-  for (size_t i = threadIdx.x; i < (size_t)rows * cols; i += 256) a += src[(i / cols) * ld + (i % cols)];
+  if (final_pass) { for (size_t i = threadIdx.x; i < n; i += 256) a += src[i]; }
+  else for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a += src[(i / cols) * ld + (i % cols)];
   red[threadIdx.x] = a;
   __syncthreads();
   for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
-  if (threadIdx.x == 0) out[0] = red[0];
+  if (threadIdx.x == 0) out[final_pass ? 0 : blockIdx.x] = red[0];
 }
-void launch_sum_all(const float* src, int rows, int cols, int ld, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_sum_all, dim3(1), dim3(256), 0, s, src, rows, cols, ld, out);
+void launch_sum_all(const float* src, int rows, int cols, int ld, float* out, float* scratch, hipStream_t s) {
+  hipLaunchKernelGGL(k_sum_all, dim3(256), dim3(256), 0, s, src, (size_t)rows * cols, cols, ld, scratch, 0);
+  hipLaunchKernelGGL(k_sum_all, dim3(1), dim3(256), 0, s, scratch, (size_t)256, 1, 1, out, 1);
 }
 
 // ---- tf.train.RMSPropOptimizer(lr): ms = 0.9 ms + 0.1 g^2 ; w -= lr g / sqrt(ms + 1e-10)   (segan.py:123-124; TF 1.4 ApplyRMSProp, momentum 0)
