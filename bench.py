@@ -177,7 +177,15 @@ def measure_sequence(a, net, d_type, B, T, steps, warmup, rank, local, world, de
             model.engine.profile_begin()
             step()
             prof = model.engine.profile_read()
-    return dict(model=model, g_type=g_type, d_type=d_type, dt=dt, dev_ms=dev_ms, med_ms=med_ms, losses=losses, prof=prof)
+            chain = (model.engine.profile_launches(), model.engine.launch_floor(400, 0), model.engine.launch_floor(400, 1))
+        buckets = None
+        if world > 1:                       # one more untimed step with the bucketed gradient all-reduce timed on its communication stream
+            model.engine.bucket_timing = True
+            step()
+            buckets = model.engine.bucket_report()
+            model.engine.bucket_timing = False
+    return dict(model=model, g_type=g_type, d_type=d_type, dt=dt, dev_ms=dev_ms, med_ms=med_ms, losses=losses, prof=prof,
+                chain=(chain if not a.no_kernel_timing else None), buckets=buckets)
 
 
 def bench_dnn_gan(a, rank, local, world, dev):
@@ -492,6 +500,17 @@ def main():
                     "scope": "all launches of one (1D+1G) step on one GPU; algorithmic %d FLOP/frame x %d frames "
                              "(SURVEY 8d: 3*F_G+8*F_D, F_G=%d, F_D=%d) / HIP-event step time; traffic = HBM-side bytes "
                              "per step from profiles/r2_final_traffic.json (null when that file is stale)" % (fpf, B * T, fg, fd)}
+            if res.get("chain"):
+                # the third bound: the recurrence is a chain of dependent launches; each costs at least a kernel boundary
+                # plus one dependent operand round trip, whatever its FLOPs
+                n_c, us0, us1 = res["chain"]
+                roof["latency_bound_ms"] = round(n_c * us1 * 1e-3, 3)
+                roof["latency_bound"] = {"chain_launches_per_step": int(n_c), "floor_us_per_launch": round(us1, 3),
+                                         "kernel_boundary_us": round(us0, 3),
+                                         "how": "launches of the recurrence kernels (gates, projection, backward A / B / B-reduce) issued "
+                                                "in one (1D+1G) step x the measured cost of one launch in a replayed hipGraph of 400 dependent "
+                                                "256-workgroup launches that each read 1 KB per wave of their predecessor's output "
+                                                "(rsrgan_op_launch_floor mode 1; mode 0 = empty kernels = the boundary alone)"}
             n_l, us_l, fl_l = res["prof"]
             if n_l:
                 # the step is GPU-bound (sum of rocprof kernel durations = wall, profiles/r2_gap_summary.txt), so the kernel's
@@ -519,6 +538,10 @@ def main():
                           "schedule_flags": a.flags, "global_batch": B * world, "frames_per_step": B * T * world, "parallelism": "dp%d" % world,
                           "losses_last_step": [round(float(v), 6) for v in losses]},
                "roofline": roof}
+        if res.get("buckets"):
+            out["allreduce"] = dict(res["buckets"], how="rank 0, generator gradients of one extra step: all-reduce of bucket i on the "
+                                    "communication stream vs the moment the compute stream finished the last weight-gradient GEMM; "
+                                    "exposed_ms is what the step pays for communication (HipEngine.bucket_report)")
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.net if a.net in ("lstm", "res_lstm_l") else "lstm", B, T)
     if world == 1 and a.net == "lstm" and a.d_type == "lstm" and not a.no_variants:

@@ -215,6 +215,13 @@ int rsrgan_grad_bucket_wait(rsrgan_handle h, int32_t net, int32_t i, void* strea
 int rsrgan_profile_begin(rsrgan_handle h);
 int rsrgan_profile_read(rsrgan_handle h, int32_t* launches, double* total_us, double* alg_flops);
 
+/* launches of the recurrence kernels (gates / projection / backward A, B, B-reduce) the host issued since rsrgan_profile_begin: with the
+ * floor of a dependent launch (rsrgan_op_launch_floor) this is the serial-recurrence latency bound SURVEY 8d asks bench.py to report */
+int rsrgan_profile_launches(rsrgan_handle h, int64_t* n);
+/* microseconds per launch of a replayed hipGraph of n dependent 256-workgroup launches: mode 0 = empty kernels (the kernel boundary),
+ * mode 1 = each reads 1 KB per wave of what its predecessor wrote and stores it back (one dependent operand round trip) */
+int rsrgan_op_launch_floor(int32_t n, int32_t mode, double* us_per_launch, void* stream);
+
 /* ---- low-level operator entry points (unit parity tests + micro-benchmarks) ----
  * C[M,N] = op(A)*op(B) (+bias) with fp32 MFMA.  a_kcontig: A is [M,K] row-major
  * (else stored [K,M]); b_kcontig: B is stored [N,K] (else [K,N] row-major).

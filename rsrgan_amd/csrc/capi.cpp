@@ -294,6 +294,13 @@ int rsrgan_grad_bucket_wait(rsrgan_handle h, int32_t net, int32_t i, void* strea
 int rsrgan_profile_begin(rsrgan_handle h) {
   CHECK_H(h);
   h->m.prof_on = true; h->m.prof_n = 0; h->m.prof_flops = 0.0;
+  g_chain_launches = 0;
+  return RSRGAN_OK;
+}
+int rsrgan_profile_launches(rsrgan_handle h, int64_t* n) {
+  CHECK_H(h);
+  if (!n) { set_error("null output pointer"); return RSRGAN_ERR_INVALID; }
+  *n = g_chain_launches;
   return RSRGAN_OK;
 }
 int rsrgan_profile_read(rsrgan_handle h, int32_t* launches, double* total_us, double* alg_flops) {
@@ -310,6 +317,41 @@ int rsrgan_profile_read(rsrgan_handle h, int32_t* launches, double* total_us, do
   }
   *launches = m.prof_n; *total_us = us; *alg_flops = m.prof_flops;
   return RSRGAN_OK;
+}
+
+int rsrgan_op_launch_floor(int32_t n, int32_t mode, double* us_per_launch, void* stream) {
+  if (n <= 0 || !us_per_launch) { set_error("op_launch_floor: bad argument"); return RSRGAN_ERR_INVALID; }
+  // captured once and replayed, like the step's segments (an eager chain is host-bound at 3-5 us per launch)
+  static float* buf = nullptr;
+  if (!buf && hipMalloc((void**)&buf, 2 * 65536 * 4 * sizeof(float)) != hipSuccess) { set_error("hipMalloc failed"); return RSRGAN_ERR_HIP; }
+  hipStream_t s = nullptr;
+  hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = RSRGAN_ERR_HIP;
+  do {
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+    if (hipMemsetAsync(buf, 0, 2 * 65536 * 4 * sizeof(float), s) != hipSuccess) break;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) break;
+    launch_floor_chain(buf, buf + 65536 * 4, n, mode, s);
+    if (hipStreamEndCapture(s, &g) != hipSuccess) break;
+    if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) break;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) break;
+    if (hipGraphLaunch(ge, s) != hipSuccess) break;                 // warm-up replay
+    if (hipEventRecord(e0, s) != hipSuccess || hipGraphLaunch(ge, s) != hipSuccess || hipEventRecord(e1, s) != hipSuccess) break;
+    if (hipEventSynchronize(e1) != hipSuccess) break;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) break;
+    *us_per_launch = 1e3 * ms / n;
+    rc = RSRGAN_OK;
+  } while (0);
+  if (rc != RSRGAN_OK) set_error("op_launch_floor: HIP call failed");
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (ge) (void)hipGraphExecDestroy(ge);
+  if (g) (void)hipGraphDestroy(g);
+  if (s) (void)hipStreamDestroy(s);
+  (void)stream;
+  return rc;
 }
 
 int rsrgan_op_gemm(const float* A, int32_t lda, int32_t a_kc, const float* B, int32_t ldb, int32_t b_kc, float* C, int32_t ldc,

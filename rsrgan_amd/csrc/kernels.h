@@ -125,6 +125,8 @@ void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, int kb_max, hipStream_
 // split-K phase B: fills ws/ldw/KG/... of every job (ws_base: >= bwd_b_ws_floats(jobs) floats) and launches both kernels
 size_t bwd_b_plan(BwdBJobs& jobs, float* ws_base);
 void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s);
+extern long long g_chain_launches;
+void launch_floor_chain(float* a, float* b, int n, int mode, hipStream_t s);
 
 // ---------------------------------------------------------------- batched GEMM
 // C[M,N] (+)= A.B (+bias)(lrelu).  a_kc: A(m,k)=A[m*lda+k] else A[k*lda+m];

@@ -973,7 +973,21 @@ size_t bwd_b_plan(BwdBJobs& jobs, float* ws_base) {
   return off;
 }
 
+// ---- the floor of a dependent launch, measured live for bench.py's latency bound: n launches of 256 workgroups in one stream,
+// mode 0: empty kernels (the kernel boundary alone); mode 1: every workgroup reads what its predecessor launch wrote (one dependent
+// operand round trip: 1 KB per wave), adds, stores -- the shape of the lightest recurrence step
+__global__ __launch_bounds__(256) void k_floor(const float* __restrict__ in, float* __restrict__ out, int mode) {
+  if (mode == 0) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float4 v = reinterpret_cast<const float4*>(in)[i];
+  reinterpret_cast<float4*>(out)[i] = make_float4(v.x + 1.f, v.y, v.z, v.w);
+}
+void launch_floor_chain(float* a, float* b, int n, int mode, hipStream_t s) {
+  for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_floor, dim3(256), dim3(256), 0, s, (i & 1) ? b : a, (i & 1) ? a : b, mode);
+}
+long long g_chain_launches = 0;     // launches of the recurrence kernels issued by the host since the last reset (bench.py: latency bound)
 void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s) {
+  g_chain_launches += 2;
   int bp = 8, br = 8, kpg_max = 1, nbp = 0;
   for (int i = 0; i < jobs.n; ++i) {
     const BwdBJob& b = jobs.j[i];
@@ -997,6 +1011,7 @@ void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s) {
 constexpr int g_gates_rows = 32;       // rows per k_fwd_gates workgroup (64-row / 16-wave blocks measured slower twice; removed)
 int fwd_gates_rows() { return g_gates_rows; }
 void launch_fwd_gates(const FwdGateJobs& jobs_in, int total_blocks, int kb_max, hipStream_t s) {
+  ++g_chain_launches;
   FwdGateJobs jobs = jobs_in;
   // a launch that would fill less than half of the chip with 32-row blocks (the discriminator alone) runs 16-row blocks: twice
   // the workgroups, half the MFMA chain each (its time is the latency of one block, not bytes)
@@ -1036,6 +1051,7 @@ void launch_fwd_gates(const FwdGateJobs& jobs_in, int total_blocks, int kb_max, 
   } else hipLaunchKernelGGL((k_fwd_gates<18, 2>), dim3(total_blocks), dim3(512), lds, s, jobs);
 }
 void launch_fwd_proj(const FwdProjJobs& jobs_in, int total_blocks, int kb_max, hipStream_t s) {
+  ++g_chain_launches;
   FwdProjJobs jobs = jobs_in;
   total_blocks = place_tiles(jobs, 32, [](const FwdProjJob& j) { return (double)j.ldh; });
   if (kb_max <= 24)
@@ -1045,6 +1061,7 @@ void launch_fwd_proj(const FwdProjJobs& jobs_in, int total_blocks, int kb_max, h
 }
 int bwd_a_cells() { return 32; }      // k_bwd_a2: 32 x 32 tiles, the jobs' nblk_c counts 32-cell blocks
 void launch_bwd_a(const BwdAJobs& jobs_in, int total_blocks, int kb_max, hipStream_t s) {
+  ++g_chain_launches;
   BwdAJobs jobs = jobs_in;
   total_blocks = place_tiles(jobs, 32, [](const BwdAJob& j) { return (double)(j.Wp ? j.ldm : 16); });
   // dynamic LDS: 32 rows x (widest dm row + pad) of the jobs in the launch (without a projection: 32 x 36 floats)
@@ -1057,6 +1074,7 @@ void launch_bwd_a(const BwdAJobs& jobs_in, int total_blocks, int kb_max, hipStre
   else hipLaunchKernelGGL(k_bwd_a2<24>, dim3(total_blocks), dim3(256), lds, s, jobs);
 }
 void launch_bwd_b(const BwdBJobs& jobs_in, int total_blocks, int kb_max, hipStream_t s) {
+  ++g_chain_launches;
   BwdBJobs jobs = jobs_in;
   total_blocks = place_tiles(jobs, kb_max <= 64 ? 16 : 32, [](const BwdBJob& j) { return (double)j.H4; });
   if (kb_max <= 64)  // small K (the discriminator alone): 8 waves x <= 8 k-blocks, one load round, no pipeline, 16-row tiles

@@ -54,7 +54,7 @@ def all_reduce_mean_(flat: torch.Tensor, group=None) -> torch.Tensor:
     return flat
 
 
-def all_reduce_mean_buckets_(flat: torch.Tensor, buckets, group=None, wait_bucket=None, comm_stream=None) -> torch.Tensor:
+def all_reduce_mean_buckets_(flat: torch.Tensor, buckets, group=None, wait_bucket=None, comm_stream=None, timing=None) -> torch.Tensor:
     """average_gradients bucket by bucket: `buckets` = (offset, count) ranges of `flat` in the order the backward pass
     completes them.  `wait_bucket(i, stream)` makes `stream` wait until range i is final (HipEngine: rsrgan_grad_bucket_wait);
     with a `comm_stream` every all-reduce is issued there, so bucket i travels while the later buckets are still being
@@ -70,8 +70,17 @@ def all_reduce_mean_buckets_(flat: torch.Tensor, buckets, group=None, wait_bucke
         if wait_bucket is not None:
             wait_bucket(i, comm_stream)
         with torch.cuda.stream(comm_stream):
+            if timing is not None:          # diagnostic (bench.py --gpus N): when each bucket's all-reduce ran on the communication stream
+                e0 = torch.cuda.Event(enable_timing=True); e0.record(comm_stream)
             all_reduce_mean_(flat[off:off + cnt], group)
+            if timing is not None:
+                e1 = torch.cuda.Event(enable_timing=True); e1.record(comm_stream)
+                timing["buckets"].append((i, 4 * cnt, e0, e1))
+    if timing is not None:                  # the compute stream is done with every gradient here; what it waits for next is exposed
+        timing["ready"] = torch.cuda.Event(enable_timing=True); timing["ready"].record(cur)
     cur.wait_stream(comm_stream)
+    if timing is not None:
+        timing["joined"] = torch.cuda.Event(enable_timing=True); timing["joined"].record(cur)
     return flat
 
 

@@ -208,7 +208,26 @@ class HipEngine:
         def wait_bucket(i, stream):
             check(self.lib.rsrgan_grad_bucket_wait(self.h, net, i, C.c_void_p(stream.cuda_stream)))
 
-        rdist.all_reduce_mean_buckets_(view, buckets, group, wait_bucket, self._comm_stream)   # joins before rsrgan_apply
+        timing = {"buckets": []} if getattr(self, "bucket_timing", False) else None
+        rdist.all_reduce_mean_buckets_(view, buckets, group, wait_bucket, self._comm_stream, timing)   # joins before rsrgan_apply
+        if timing is not None:
+            self._last_timing = timing
+
+    def bucket_report(self):
+        """Diagnostic of the last bucketed all-reduce run with `engine.bucket_timing = True` (synchronises): per bucket its bytes,
+        the milliseconds its all-reduce took on the communication stream and when it started / ended relative to the moment the
+        compute stream had finished every gradient; `exposed_ms` = how long the compute stream then waited for the communication
+        stream (everything before that moment was hidden behind the weight-gradient GEMMs of the later buckets)."""
+        t = getattr(self, "_last_timing", None)
+        if not t:
+            return None
+        torch.cuda.synchronize(self.device)
+        rows = []
+        for i, nbytes, e0, e1 in t["buckets"]:
+            rows.append({"bucket": i, "bytes": int(nbytes), "allreduce_ms": round(e0.elapsed_time(e1), 4),
+                         "start_vs_compute_done_ms": round(t["ready"].elapsed_time(e0), 4),
+                         "end_vs_compute_done_ms": round(t["ready"].elapsed_time(e1), 4)})
+        return {"buckets": rows, "exposed_ms": round(t["ready"].elapsed_time(t["joined"]), 4)}
 
     # -- the path ----------------------------------------------------------------------
     def _check_batch(self, x, lab=None, ln=None):
@@ -275,6 +294,18 @@ class HipEngine:
         n, us, fl = C.c_int32(), C.c_double(), C.c_double()
         check(self.lib.rsrgan_profile_read(self.h, C.byref(n), C.byref(us), C.byref(fl)))
         return n.value, us.value, fl.value
+
+    def profile_launches(self):
+        """launches of the recurrence kernels the host issued since profile_begin (the profiled step runs eagerly)"""
+        n = C.c_int64()
+        check(self.lib.rsrgan_profile_launches(self.h, C.byref(n)))
+        return n.value
+
+    def launch_floor(self, n=400, mode=1):
+        """us per dependent launch of a replayed graph of n launches (mode 0: empty kernels, 1: one dependent operand round trip)"""
+        us = C.c_double()
+        check(self.lib.rsrgan_op_launch_floor(n, mode, C.byref(us), self._stream()))
+        return us.value
 
     # -- low-level op (unit tests, micro-bench) ------------------------------------------
     def op_gemm(self, A, a_kc, B, b_kc, C_, M, N, K, bias=None, act=0, alpha=0.3, accumulate=False):

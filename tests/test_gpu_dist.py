@@ -74,6 +74,15 @@ def test_nccl_world1_dp_path_equals_fused_step():
             for p_, q_ in zip(c.get_vars(), d.get_vars()):
                 for k in p_:
                     assert np.array_equal(p_[k], q_[k]), (g_type, k)
+            # the per-bucket diagnostic bench.py prints at --gpus N: one row per bucket, in completion order, nothing negative
+            d.engine.bucket_timing = True
+            d.engine.g_backward(xs, ls, lns, train=True, reuse=False, apply=False)
+            d.engine.all_reduce_grads(NET_G, force=True)
+            rep = d.engine.bucket_report()
+            d.engine.apply(NET_G)
+            assert [r["bucket"] for r in rep["buckets"]] == list(range(len(bk)))
+            assert sum(r["bytes"] for r in rep["buckets"]) == 4 * d.engine.grad_view(NET_G).numel()
+            assert rep["exposed_ms"] >= 0 and all(r["allreduce_ms"] >= 0 for r in rep["buckets"])
     finally:
         dist.destroy_process_group()
 
