@@ -120,6 +120,45 @@ def cpu_baseline(net, B, T, budget_s=9.0):
             "one_core": one, "all_cores": allc}
 
 
+def hbm_activity(step, ms_per_step, seconds=4.0):
+    """Device-level estimate of the REAL HBM traffic of the step: the memory controllers' activity (rocm-smi "GPU Memory Read/Write
+    Activity (%)" = amd-smi UMC_ACTIVITY) sampled while the step loop runs un-profiled for a few seconds.  The PMC figure
+    (roofline.traffic) counts the L2's fabric requests of serialised, cold-L2 dispatches, Infinity-Cache hits included: an upper
+    bound.  bytes per step ~ activity x 8 TB/s (spec peak, MI355X_MICROARCH.md) x step time; the counter has 1 % resolution."""
+    import re, shutil, subprocess, threading
+    smi = shutil.which("rocm-smi")
+    if not smi:
+        return None
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                out = subprocess.run([smi, "--showmemuse"], capture_output=True, text=True, timeout=5).stdout
+                m = re.search(r"Read/Write Activity \(%\):\s*([0-9.]+)", out)
+                if m:
+                    samples.append(float(m.group(1)))
+            except Exception:
+                pass
+            stop.wait(0.25)
+    th = threading.Thread(target=sampler, daemon=True)
+    t0 = time.time()
+    n = 0
+    th.start()
+    while time.time() - t0 < seconds:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize(); n += 20
+    stop.set(); th.join(timeout=6)
+    mid = samples[1:-1] if len(samples) > 4 else samples       # the first / last sample straddle the start / end of the loop
+    if not mid:
+        return None
+    pct = sum(mid) / len(mid)
+    return {"umc_activity_pct": round(pct, 2), "samples": len(mid), "steps": n,
+            "hbm_bytes_per_step_estimate": int(pct / 100.0 * 8.0e12 * ms_per_step * 1e-3),
+            "how": "mean rocm-smi memory read/write activity over %d samples while %d un-profiled steps ran, x 8 TB/s x ms/step" % (len(mid), n)}
+
+
 def measure_sequence(a, net, d_type, B, T, steps, warmup, rank, local, world, dev):
     """One timed run of the sequence-level GAN step: W untimed steps, then exactly `steps` steps between
     barrier + synchronize on both sides; MAX over ranks."""
@@ -177,7 +216,12 @@ def measure_sequence(a, net, d_type, B, T, steps, warmup, rank, local, world, de
             model.engine.profile_begin()
             step()
             prof = model.engine.profile_read()
-            chain = (model.engine.profile_launches(), model.engine.launch_floor(400, 0), model.engine.launch_floor(400, 1))
+            # (the floor chain is skipped under rocprofv3: 800 extra launches would distort the committed kernel statistics)
+            under_prof = any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ)
+            chain = (model.engine.profile_launches(), model.engine.launch_floor(400, 0), model.engine.launch_floor(400, 1)) if not under_prof else None
+        hbm = None
+        if not a.no_kernel_timing and world == 1 and net == "lstm" and not a.no_hbm_activity:
+            hbm = hbm_activity(step, dt * 1e3 / steps)
         buckets = None
         if world > 1:                       # one more untimed step with the bucketed gradient all-reduce timed on its communication stream
             model.engine.bucket_timing = True
@@ -185,7 +229,7 @@ def measure_sequence(a, net, d_type, B, T, steps, warmup, rank, local, world, de
             buckets = model.engine.bucket_report()
             model.engine.bucket_timing = False
     return dict(model=model, g_type=g_type, d_type=d_type, dt=dt, dev_ms=dev_ms, med_ms=med_ms, losses=losses, prof=prof,
-                chain=(chain if not a.no_kernel_timing else None), buckets=buckets)
+                chain=(chain if not a.no_kernel_timing else None), buckets=buckets, hbm=hbm)
 
 
 def bench_dnn_gan(a, rank, local, world, dev):
@@ -416,6 +460,7 @@ def main():
     ap.add_argument("--gen-updates", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the BASELINE.json-named network variant at N=1")
+    ap.add_argument("--no-hbm-activity", action="store_true", help="skip the ~4 s of extra steps under the rocm-smi memory-activity sampler")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the extra event-bracketed step (PMC passes count bytes per step)")
     ap.add_argument("--flags", type=int, default=int(os.environ.get("RSRGAN_FLAGS", "3")),
                     help="library schedule flags: 1 = wavefront, 2 = hipGraph replay, 4 = side-stream GEMM overlap (include/rsrgan.h)")
@@ -474,7 +519,7 @@ def main():
         k_traffic = None
         k_rocprof_us = None
         headline = a.net == "lstm" and a.d_type == "lstm" and (B, T, a.gen_updates) == (64, 100, 1)
-        tf_path = os.path.join(ROOT, "profiles", "r2_final_traffic.json")
+        tf_path = os.path.join(ROOT, "profiles", "r3_final_traffic.json")
         if headline and os.path.exists(tf_path):
             # HBM-side bytes from the committed PMC passes of this workload (tools/traffic.sh: separate FETCH_SIZE / WRITE_SIZE
             # passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); refused when the kernels have changed
@@ -487,7 +532,7 @@ def main():
                 w = [v for v in tj.get("top_write", []) if "k_fwd_gates" in v[0]]
                 if f and w and f[0][2] == w[0][2]:
                     k_traffic = int((2 * f[0][1] + w[0][1]) * 1024 / f[0][2])
-        cs_path = os.path.join(ROOT, "profiles", "r2_final_rocprofv3_kernel_stats.csv")
+        cs_path = os.path.join(ROOT, "profiles", "r3_final_rocprofv3_kernel_stats.csv")
         if headline and os.path.exists(cs_path):
             import csv
             for row in csv.DictReader(open(cs_path)):
@@ -499,7 +544,10 @@ def main():
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "scope": "all launches of one (1D+1G) step on one GPU; algorithmic %d FLOP/frame x %d frames "
                              "(SURVEY 8d: 3*F_G+8*F_D, F_G=%d, F_D=%d) / HIP-event step time; traffic = HBM-side bytes "
-                             "per step from profiles/r2_final_traffic.json (null when that file is stale)" % (fpf, B * T, fg, fd)}
+                             "per step from profiles/r3_final_traffic.json (null when that file is stale)" % (fpf, B * T, fg, fd)}
+            if res.get("hbm"):
+                roof["traffic_is"] = "L2 fabric requests of serialised cold-L2 dispatches incl. Infinity-Cache hits (PMC): an upper bound"
+                roof["hbm_activity"] = res["hbm"]
             if res.get("chain"):
                 # the third bound: the recurrence is a chain of dependent launches; each costs at least a kernel boundary
                 # plus one dependent operand round trip, whatever its FLOPs
@@ -526,7 +574,7 @@ def main():
                                                    if k_rocprof_us else None),
                     "how": "avg_us: every launch of one extra step bracketed by HIP events on its stream (rsrgan_profile_begin/"
                            "read; includes the event records, an upper bound); rocprofv3_avg_us: AverageNs of the same kernel in "
-                           "the committed profiles/r2_final_rocprofv3_kernel_stats.csv of this command"}
+                           "the committed profiles/r3_final_rocprofv3_kernel_stats.csv of this command"}
         out = {"metric": "GAN train frames/sec (G+D step), 257-dim LPS->40-dim MFCC", "value": round(value, 1),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt * 1e3 / a.steps, 4), "ms_per_step_median": round(res["med_ms"], 4),

@@ -4,7 +4,7 @@ tag=$1; shift; ctrs=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o r -- python $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu-baseline > $out/bench.log 2>&1
+timeout 300 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -o r -- python $GRAFT_REPO_ROOT/bench.py "$@" --no-cpu-baseline --no-hbm-activity > $out/bench.log 2>&1
 cd $GRAFT_REPO_ROOT
 python - <<PY
 import csv, collections, glob

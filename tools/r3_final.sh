@@ -1,5 +1,6 @@
 #!/bin/bash
-# final artefacts of a build: headline bench line, kernel stats, traffic passes, gap summary -> gpurun_out/, then tools/mk_final.py
+# final artefacts of a build: headline bench line, kernel stats, traffic passes (cold: every dispatch instrumented; warm: one kernel
+# class per pass), gap summary -> gpurun_out/, then tools/mk_final.py
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 tag=${1:-fin}
@@ -7,3 +8,4 @@ timeout 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-varian
 bash tools/prof.sh $tag --steps 5 --warmup 2 --no-variants > /dev/null 2>&1
 head -14 gpurun_out/prof_$tag/r_kernel_stats.csv | cut -c1-130
 bash tools/traffic.sh $tag --no-variants > gpurun_out/traffic_$tag.log 2>&1; tail -2 gpurun_out/traffic_$tag.log | cut -c1-300
+bash tools/traffic_warm.sh $tag > gpurun_out/traffic_warm_$tag.log 2>&1; tail -1 gpurun_out/traffic_warm_$tag.log | cut -c1-400

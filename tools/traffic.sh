@@ -5,7 +5,7 @@ tag=$1; shift
 for c in FETCH_SIZE WRITE_SIZE; do
   out=$GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$c
   mkdir -p $out
-  (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out -o r -- python $GRAFT_REPO_ROOT/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing > $out/bench.log 2>&1)
+  (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out -o r -- python $GRAFT_REPO_ROOT/bench.py "$@" --steps 1 --warmup 0 --no-cpu-baseline --no-hbm-activity --no-kernel-timing > $out/bench.log 2>&1)
 done
 python - <<PY
 import csv, glob, json, collections
