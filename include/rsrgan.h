@@ -215,6 +215,11 @@ int rsrgan_grad_bucket_wait(rsrgan_handle h, int32_t net, int32_t i, void* strea
 int rsrgan_profile_begin(rsrgan_handle h);
 int rsrgan_profile_read(rsrgan_handle h, int32_t* launches, double* total_us, double* alg_flops);
 
+/* Health of the persistent recurrence kernels (csrc/dpersist.hip): synchronises the handle's stream, returns in *code 0 or
+ * 1 + the first workgroup whose bounded wait for another workgroup's partials expired, and clears the (sticky) device word.
+ * A failed launch has already poisoned its step's losses with NaN; nothing in the reference corresponds to this. */
+int rsrgan_device_status(rsrgan_handle h, int32_t* code);
+
 /* launches of the recurrence kernels (gates / projection / backward A, B, B-reduce) the host issued since rsrgan_profile_begin: with the
  * floor of a dependent launch (rsrgan_op_launch_floor) this is the serial-recurrence latency bound SURVEY 8d asks bench.py to report */
 int rsrgan_profile_launches(rsrgan_handle h, int64_t* n);

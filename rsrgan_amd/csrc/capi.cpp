@@ -297,6 +297,23 @@ int rsrgan_profile_begin(rsrgan_handle h) {
   g_chain_launches = 0;
   return RSRGAN_OK;
 }
+int rsrgan_device_status(rsrgan_handle h, int32_t* code) {
+  CHECK_H(h);
+  if (!code) { set_error("null output pointer"); return RSRGAN_ERR_INVALID; }
+  Model& m = h->m;
+  *code = 0;
+  if (m.main_s && hipStreamSynchronize(m.main_s) != hipSuccess) { set_error("hipStreamSynchronize failed"); return RSRGAN_ERR_HIP; }
+  if (!m.dp_ctl) return RSRGAN_OK;
+  if (hipDeviceSynchronize() != hipSuccess) { set_error("hipDeviceSynchronize failed"); return RSRGAN_ERR_HIP; }
+  unsigned ctl[DP_CTL_WORDS];
+  if (hipMemcpy(ctl, m.dp_ctl, sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess) { set_error("hipMemcpy failed"); return RSRGAN_ERR_HIP; }
+  *code = (int32_t)ctl[DP_CTL_ERR];
+  if (ctl[DP_CTL_ERR] != 0 || ctl[DP_CTL_DONE] != 0) {          // (an aborted launch can leave the arrival count behind)
+    const unsigned z[2] = {0u, 0u};
+    if (hipMemcpy(m.dp_ctl + DP_CTL_DONE, z, sizeof(z), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed"); return RSRGAN_ERR_HIP; }
+  }
+  return RSRGAN_OK;
+}
 int rsrgan_profile_launches(rsrgan_handle h, int64_t* n) {
   CHECK_H(h);
   if (!n) { set_error("null output pointer"); return RSRGAN_ERR_INVALID; }

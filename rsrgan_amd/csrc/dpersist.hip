@@ -1,0 +1,477 @@
+// dpersist.hip -- the discriminator's forward recurrence as ONE persistent launch (gfx950).
+//
+// models/discriminator_lstm.py:70-91 runs tf.nn.dynamic_rnn over a stack of LSTMCell(256, use_peepholes, num_proj=40).  When the
+// discriminator runs alone (the G-run's D(G(x)) with the freshly updated D) a time step is far too small for a launch: 64 rows x
+// 1024 gate columns x K = 40 (+40).  Here the whole recurrence of every layer is one launch of nl x (N/16) x NQ workgroups:
+//   workgroup (layer l, 16-row tile r, cell quarter c) keeps its slices of K_h, K_x and W_p in VGPRs for all T steps; per step it
+//   computes z = zx + m_{t-1}.K_h (+ x_t.K_x), the cell, and its PARTIAL projection h[:, 64 cells].W_p[64 cells, :] (16 x P floats),
+//   which it publishes as 8-byte {tag = t+1, value} granules ("the data is the flag", cdna_hip_programming.md guideline 16 R2).
+//   The NQ workgroups of a row tile sum each other's partials in a fixed order (deterministic) to get m_t; the tile of the layer
+//   above sums the same granules to get its x_t.  Batch rows never interact, so a tile's cluster is NQ workgroups, placed on one XCD.
+// No grid barrier, no flag: a consumer wave re-reads the producer's granules until every tag matches.  The tag is the launch
+// GENERATION, a device word the last workgroup to finish increments (every step has its own slot, so the tag only has to tell this
+// launch from earlier ones): no memset per launch, nothing frozen into a captured graph.  Every spin is bounded (wall-clock) and
+// reports through the sticky `err` word of the control block (Model::check_persist reads and clears it); a failed launch also
+// poisons the top layer's output with NaN so the step's losses cannot look healthy.
+#include "kernels.h"
+
+namespace rsr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+constexpr int DP_NQ = 4;            // cell quarters per row tile (H = 64 * DP_NQ)
+constexpr int DP_KB = 3;            // k-blocks of 16 of the recurrent / input width (P <= 48)
+constexpr int DP_SLOT = DP_KB * 64 * 4;     // granules per (layer, tile, step, quarter): the consumer's A-fragment order [kb][lane][u]
+constexpr int DP_HS = 72;           // LDS row stride of the h tile (floats): 18 float4, == 2 mod 16 (conflict-free fragment reads)
+
+// tools/ubench/dpersist_trace.hip compiles this file with DP_TRACE: thread 0 of every workgroup stamps the 100 MHz counter at the
+// phase boundaries of every step; the product build has no such code
+#ifdef DP_TRACE
+__device__ unsigned g_dp_trace[64][128][12];
+// (stamps go to LDS and leave at the end: a global store behind the write-through granule stores would itself stall at issue)
+#define DPT(i) do { if (threadIdx.x == 0 && t < 128) dp_tr[t][i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#define DPG(i) do { if (threadIdx.x == 256 && t < 128) dp_tr[t][8 + (i)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#define DPT_DECL __shared__ unsigned dp_tr[128][12];
+#define DPT_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x < 64) for (int t_ = 0; t_ < 128; ++t_) for (int i_ = 0; i_ < 12; ++i_) g_dp_trace[blockIdx.x][t_][i_] = dp_tr[t_][i_]; } while (0)
+#else
+#define DPT(i) do { } while (0)
+#define DPG(i) do { } while (0)
+#define DPT_DECL
+#define DPT_FLUSH() do { } while (0)
+#endif
+
+__device__ __forceinline__ float4 dp_sel(bool c, const float4 a, const float4 b) {      // componentwise: a float4 ?: becomes a pointer select + scratch
+  return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
+}
+// Cell non-linearities on the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each): the cell phase of a workgroup is
+// 1024 elements x 5 transcendentals on ONE wave per SIMD, and libm's expf / tanhf / IEEE division made it 1.4 us of a step
+// (profiles/r3_dpersist_trace.txt).  |error| <= ~2e-7 absolute: tanh switches to its odd series below 0.1 where 1 - 2/(1+e^2x) cancels.
+__device__ __forceinline__ float dp_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
+__device__ __forceinline__ float dp_tanh(float x) {
+  const float x2 = x * x;
+  const float ser = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.05396825f * x2)));
+  const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008f * x));
+  return fabsf(x) < 0.1f ? ser : big;
+}
+
+// 16-byte write-through accesses carrying two granules each (8-byte scalar sc1 stores are one fabric write per lane: 2.7x the time
+// per byte, MI355X_MICROARCH.md "stores of each flavour"; the 8-byte halves of a 16-byte sc1 access are observed untorn).  Inline
+// asm: the compiler has no 16-byte agent-scope atomic.  (Its vmcnt bookkeeping does not see these: the loads wait inside the asm,
+// and an untracked store only makes a later compiler-placed wait stricter, vmcnt retiring in order.)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dp_store2(gu64* p, unsigned tag, float v0, float v1) {
+  const u32x4 x = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
+  // (s_nop: a store of more than 8 bytes followed by a write of its data registers needs a wait state; the compiler inserts it
+  // for its own stores, not behind an asm statement)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+}
+// the 12 granules of this lane in one slot: 6 loads in flight, one wait
+__device__ __forceinline__ void dp_load12(const gu64* g, int lane, u32x4 (&x)[6]) {
+  const gu64* p0 = g + (size_t)lane * 4;
+  asm volatile(
+      "global_load_dwordx4 %0, %6, off sc1\n\t"
+      "global_load_dwordx4 %1, %6, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %2, %6, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %3, %6, off offset:2064 sc1\n\t"
+      "global_load_dwordx4 %4, %7, off sc1\n\t"
+      "global_load_dwordx4 %5, %7, off offset:16 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5])
+      : "v"(p0), "v"(p0 + 512)
+      : "memory");
+}
+// two slots in one round trip
+__device__ __forceinline__ void dp_load24(const gu64* g0, const gu64* g1, int lane, u32x4 (&x)[6], u32x4 (&y)[6]) {
+  const gu64* p0 = g0 + (size_t)lane * 4;
+  const gu64* p1 = g1 + (size_t)lane * 4;
+  asm volatile(
+      "global_load_dwordx4 %0, %12, off sc1\n\t"
+      "global_load_dwordx4 %1, %12, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %2, %12, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %3, %12, off offset:2064 sc1\n\t"
+      "global_load_dwordx4 %4, %13, off sc1\n\t"
+      "global_load_dwordx4 %5, %13, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %6, %14, off sc1\n\t"
+      "global_load_dwordx4 %7, %14, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %8, %14, off offset:2048 sc1\n\t"
+      "global_load_dwordx4 %9, %14, off offset:2064 sc1\n\t"
+      "global_load_dwordx4 %10, %15, off sc1\n\t"
+      "global_load_dwordx4 %11, %15, off offset:16 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]),
+        "=&v"(y[4]), "=&v"(y[5])
+      : "v"(p0), "v"(p0 + 512), "v"(p1), "v"(p1 + 512)
+      : "memory");
+}
+__device__ __forceinline__ bool dp_take(const u32x4 (&x)[6], unsigned tag, float (&v)[DP_KB * 4]) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    v[2 * k] = __uint_as_float(x[k].x); v[2 * k + 1] = __uint_as_float(x[k].z);
+    ok &= x[k].y == tag && x[k].w == tag;
+  }
+  return __all(ok);
+}
+// One wave re-reads granules until all carry their tag: 12 of slot `gm_` (tag tm; skipped when null) and 12 of slot `gx_` (tag tx;
+// skipped when null).  false on time-out (or when another workgroup has failed).
+__device__ __forceinline__ bool dp_sweep2(const gu64* gm_, unsigned tm, float (&vm)[DP_KB * 4], const gu64* gx_, unsigned tx, float (&vx)[DP_KB * 4],
+                                          int lane, gu32* err) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  bool dm = gm_ == nullptr, dx = gx_ == nullptr;                   // (wave-uniform)
+  for (unsigned spins = 0;; ++spins) {
+    u32x4 x[6], y[6];
+    if (!dm && !dx) { dp_load24(gm_, gx_, lane, x, y); dm = dp_take(x, tm, vm); dx = dp_take(y, tx, vx); }
+    else if (!dm) { dp_load12(gm_, lane, x); dm = dp_take(x, tm, vm); }
+    else if (!dx) { dp_load12(gx_, lane, x); dx = dp_take(x, tx, vx); }
+    if (dm && dx) return true;
+    if ((spins & 63) == 63) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 3000000ull ||                       // 30 ms at 100 MHz
+          __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    }
+  }
+}
+
+// 8 waves: 0-3 compute (wave w: all four gates of cells [16w, 16w+16) of the quarter; waves 0-2 also one 16-column tile of the
+// partial projection), 4-7 gather (wave 4+j polls quarter j's granules and hands them over through LDS).  The gather waves issue
+// no global stores: vmcnt retires in order, so a wave that has just published would wait for the acknowledgements of its own
+// write-through stores before the first polled granule returns (measured: 1.2 us for a sweep of data that was long there).
+__device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigned gen) {
+  __shared__ __attribute__((aligned(16))) float part_m[DP_NQ][DP_KB][64][4];      // swept partials of m_{t-1}
+  __shared__ __attribute__((aligned(16))) float part_x[2][DP_NQ][DP_KB][64][4];   // ... of x_{t+1} (layers above 0), by parity of the step
+  // the step's stash staged for gather wave 3: [gates i, j, f, o | c | h][16 rows][DP_HS]; array 5 is the h tile the projection reads
+  __shared__ __attribute__((aligned(16))) float stage[6][16 * DP_HS];
+  __shared__ __attribute__((aligned(16))) float kx_lds[4][4][DP_KB][64][4];       // K_x fragments of the compute waves (off the recurrent path: not worth 48 VGPRs)
+  __shared__ __attribute__((aligned(16))) float wp_lds[4][4][64][4];               // W_p fragments of the projecting waves
+  __shared__ int dead;
+  DPT_DECL
+  const int RTn = a.N >> 4, ncl = a.nl * RTn;
+  const int cl = blockIdx.x % ncl, cq = blockIdx.x / ncl;           // cluster (layer, row tile) -> same XCD when ncl % 8 == 0
+  const int l = cl / RTn, r = cl - l * RTn;
+  const DPersistLayer L = a.L[l];                                   // by value: the fields stay in SGPRs (a reference re-reads the kernarg every step)
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, H4 = 4 * H, T = a.T, N = a.N, P = L.P, ldP = L.ldP, I = L.I;
+  const int r0 = r * 16;
+  gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
+  if (tid == 0) dead = 0;
+  const size_t slot_stride_t = (size_t)DP_NQ * DP_SLOT;
+  __syncthreads();
+
+  if (w >= 4) {
+    // ---------------- gather waves ----------------
+    __builtin_amdgcn_s_setprio(3);                                 // the hand-off is the critical path: ahead of the compute waves' run-ahead work
+    const int j = w - 4;
+    const gu64* gm = (const gu64*)a.gran + ((size_t)(l * RTn + r) * T) * slot_stride_t + (size_t)j * DP_SLOT;          // quarter j of my tile
+    const gu64* gx = (const gu64*)a.gran + ((size_t)(max(l - 1, 0) * RTn + r) * T) * slot_stride_t + (size_t)j * DP_SLOT;
+    gu64* gout = (gu64*)a.gran + ((size_t)(l * RTn + r) * T) * slot_stride_t + (size_t)cq * DP_SLOT;
+    float vm[DP_KB * 4], vx[DP_KB * 4];
+    auto put = [&](float (*part)[DP_KB][64][4], const float (&v)[DP_KB * 4]) {
+#pragma unroll
+      for (int kb = 0; kb < DP_KB; ++kb)
+        *reinterpret_cast<float4*>(&part[j][kb][lane][0]) = make_float4(v[kb * 4], v[kb * 4 + 1], v[kb * 4 + 2], v[kb * 4 + 3]);
+    };
+    auto fail = [&]() { if (lane == 0) { dead = 1; __hip_atomic_store(err, 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } };
+    if (l > 0) {                                                   // x_0 for the prologue
+      if (!dp_sweep2(nullptr, gen, vm, gx, gen, vx, lane, err)) fail();
+      put(part_x[0], vx);
+    }
+    __syncthreads();                                               // P
+    if (dead) return;
+    // iteration t delivers m_{t-1} (t > 0) and x_{t+1} (layers above 0) before barrier A(t); t = T: the last m for the tile leader
+    const int t_end = cq == 0 ? T + 1 : T;
+    for (int t = 0; t < t_end; ++t) {
+      const bool wm = t > 0, wx = l > 0 && t + 1 < T;
+      DPG(0);
+      if (wm || wx) {
+        if (!dp_sweep2(wm ? gm + (size_t)(t - 1) * slot_stride_t : nullptr, gen, vm,
+                       wx ? gx + (size_t)(t + 1) * slot_stride_t : nullptr, gen, vx, lane, err)) fail();
+        if (wm) put(part_m, vm);
+        if (wx) put(part_x[(t + 1) & 1], vx);
+      }
+      DPG(1);
+      __syncthreads();                                             // A(t)
+      if (dead) return;
+      if (t < T) {
+        __syncthreads();                                           // B(t): the h tile of step t is in LDS
+        DPG(2);
+        // Partial projection of this quarter's 64 cells, on the gather waves: the write-through granule stores must not sit in the
+        // compute waves' memory queue (whatever vector-memory instruction follows them waits ~0.9 us for their acknowledgement; here
+        // that is the next poll, which could not succeed earlier anyway).  TRANSPOSED (W_p^T as the A operand, h^T as B: for the
+        // 16x16x4 shapes A[row][k] and B[k][col] sit in the same lanes): lane (q, lr) ends up with m^T[p = 16j + 4q + i][row lr],
+        // i = 0..3 = the four consecutive granules of the consumer's lane (q, lr), k-block j: two 16-byte stores of 32 contiguous bytes
+        if (j < 3) {
+          f32x4 pm = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kb = 0; kb < 4; ++kb) {
+            const float4 af = *reinterpret_cast<const float4*>(&stage[5][lr * DP_HS + 16 * kb + 4 * q]);
+            const float4 bf = *reinterpret_cast<const float4*>(&wp_lds[j][kb][lane][0]);
+            pm = __builtin_amdgcn_mfma_f32_16x16x4f32(bf.x, af.x, pm, 0, 0, 0);
+            pm = __builtin_amdgcn_mfma_f32_16x16x4f32(bf.y, af.y, pm, 0, 0, 0);
+            pm = __builtin_amdgcn_mfma_f32_16x16x4f32(bf.z, af.z, pm, 0, 0, 0);
+            pm = __builtin_amdgcn_mfma_f32_16x16x4f32(bf.w, af.w, pm, 0, 0, 0);
+          }
+          gu64* go_ = gout + (size_t)t * slot_stride_t + ((size_t)j * 64 + lane) * 4;
+          dp_store2(go_, gen, pm[0], pm[1]);
+          dp_store2(go_ + 2, gen, pm[2], pm[3]);
+        }
+        else {
+          // Gather wave 3 (no projection tile) writes the step's stash from its LDS stage: whole 256-byte rows, 1 KB per instruction.
+          // From the compute waves the same bytes are 64-byte pieces of 16 rows per instruction and cost them 1000-2200 cycles of
+          // issue per step wherever they are placed (profiles/r3_dpersist_trace.txt).  (Plain stores: this wave's next poll waits
+          // for their acknowledgement, which comes well before its peer's granules.)
+          const int c4 = (lane & 15) * 4, rr = lane >> 4;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int row = 4 * rg + rr;
+            const size_t grow = (size_t)t * N + r0 + row;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4*>(L.gates + grow * H4 + g * H + cq * 64 + c4) = *reinterpret_cast<const float4*>(&stage[g][row * DP_HS + c4]);
+            *reinterpret_cast<float4*>(L.c + (grow + N) * H + cq * 64 + c4) = *reinterpret_cast<const float4*>(&stage[4][row * DP_HS + c4]);
+            *reinterpret_cast<float4*>(L.h + grow * L.ldH + cq * 64 + c4) = *reinterpret_cast<const float4*>(&stage[5][row * DP_HS + c4]);
+          }
+        }
+        DPG(3);
+      }
+    }
+    return;
+  }
+
+  // ---------------- compute waves ----------------
+  const int cell = cq * 64 + 16 * w + lr;
+  // gate kernels: B fragment of gate g, k-block kb: lane (q, lr) holds K[k0 + 16kb + 4q + u][g*H + cell], u = 0..3 (zero beyond the width)
+  float4 kh[4][DP_KB];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb) {
+      float vh[4], vx[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {                                 // all eight loads in flight, then the selects (the asm pins the loads
+        const int k = 16 * kb + 4 * q + u;                          // as unconditional: hipcc sinks a load into the branch of its select)
+        vh[u] = L.K[(size_t)(I + min(k, P - 1)) * H4 + g * H + cell];
+        vx[u] = L.K[(size_t)min(k, I - 1) * H4 + g * H + cell];
+      }
+      asm volatile("" : "+v"(vh[0]), "+v"(vh[1]), "+v"(vh[2]), "+v"(vh[3]), "+v"(vx[0]), "+v"(vx[1]), "+v"(vx[2]), "+v"(vx[3]));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = 16 * kb + 4 * q + u;
+        vh[u] = k < P ? vh[u] : 0.f;
+        vx[u] = (l > 0 && k < I) ? vx[u] : 0.f;
+      }
+      kh[g][kb] = make_float4(vh[0], vh[1], vh[2], vh[3]);
+      *reinterpret_cast<float4*>(&kx_lds[w][g][kb][lane][0]) = make_float4(vx[0], vx[1], vx[2], vx[3]);
+    }
+  // projection: wave w < 3 owns output columns [16w, 16w+16): B[k = cell 16kb + 4q + u of this quarter][col 16w + lr]
+  {
+    const int col = 16 * w + lr;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = L.Wp[(size_t)(cq * 64 + 16 * kb + 4 * q + u) * ldP + min(col, P - 1)];
+      asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = col < P ? v[u] : 0.f;
+      *reinterpret_cast<float4*>(&wp_lds[w][kb][lane][0]) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  // The gate products run TRANSPOSED (K^T as the A operand, m^T as B; the 16x16x4 fragments of A[row][k] and B[k][col] sit in the
+  // same lanes, so the resident registers serve either way): lane (q, lr) gets z[row lr][cells cb .. cb+3] -- four consecutive cells
+  // of ONE row, so zx, the gates, c and h move as 16-byte accesses (6 stores per step instead of 24: a scattered dword store costs
+  // ~125 cycles of issue, 3000 per step in profiles/r3_dpersist_trace.txt) and the masks are one comparison.
+  const int cb = cq * 64 + 16 * w + 4 * q;
+  const float4 pwi = *reinterpret_cast<const float4*>(L.wi + cb), pwf = *reinterpret_cast<const float4*>(L.wf + cb);
+  const float4 pwo = *reinterpret_cast<const float4*>(L.wo + cb);
+  f32x4 bs[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bs[g] = *reinterpret_cast<const f32x4*>(L.bias + g * H + cb);
+  const int lenF = a.len[r0 + lr];
+  float cp[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 mf[DP_KB];
+#pragma unroll
+  for (int kb = 0; kb < DP_KB; ++kb) mf[kb] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // slot 0 of the carried states is zero (cell.zero_state)
+  *reinterpret_cast<float4*>(L.c + (size_t)(r0 + lr) * H + cb) = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (cq == 0 && w == 0) {
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb)
+      if (16 * kb + 4 * q < P) *reinterpret_cast<float4*>(L.mst + (size_t)(r0 + lr) * ldP + 16 * kb + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  // acc init of the next step: zx (layer 0; the x-part of every step was batched into `gates`) or bias + x . K_x
+  f32x4 accn[4];
+  auto load_zx = [&](int t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) accn[g] = *reinterpret_cast<const f32x4*>(L.gates + ((size_t)t * N + r0 + lr) * H4 + g * H + cb);
+  };
+  // sum of the NQ handed-over partials, in quarter order (k-blocks beyond the width: zero)
+  auto sum_parts = [&](float (*part)[DP_KB][64][4], int width, float4 (&s)[DP_KB]) {
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb) {
+      const float4 p0 = *reinterpret_cast<const float4*>(&part[0][kb][lane][0]), p1 = *reinterpret_cast<const float4*>(&part[1][kb][lane][0]);
+      const float4 p2 = *reinterpret_cast<const float4*>(&part[2][kb][lane][0]), p3 = *reinterpret_cast<const float4*>(&part[3][kb][lane][0]);
+      s[kb] = dp_sel(16 * kb + 4 * q < width,
+                     make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
+                                 ((p0.w + p1.w) + p2.w) + p3.w), make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+  };
+  auto mma_part = [&](f32x4 (&acc)[4], const float4 (&af)[DP_KB], const float4 (&bf)[4][DP_KB]) {     // acc[g] += (af . bf[g])^T
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].x, af[kb].x, acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].y, af[kb].y, acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].z, af[kb].z, acc[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].w, af[kb].w, acc[g], 0, 0, 0);
+    }
+  };
+  // x-part of step t of a layer above 0 from the handed-over partials of the layer below: accn = bias + mask(x_t) . K_x
+  auto next_x = [&](int t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) accn[g] = bs[g];
+    float4 xs[DP_KB];
+    sum_parts(part_x[t & 1], I, xs);
+    const bool live = t < lenF;                                   // dynamic_rnn's output is zero past the row's length
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb) xs[kb] = dp_sel(live, xs[kb], make_float4(0.f, 0.f, 0.f, 0.f));
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb) {
+      float4 bf[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bf[g] = *reinterpret_cast<const float4*>(&kx_lds[w][g][kb][lane][0]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].x, xs[kb].x, accn[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].y, xs[kb].y, accn[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].z, xs[kb].z, accn[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].w, xs[kb].w, accn[g], 0, 0, 0);
+    }
+  };
+  // the full m of step t-1 (tile leader only): carried state -> mst[t], masked output -> out[t-1]
+  auto store_m = [&](int t, const float4 (&mnew)[DP_KB], bool live_prev) {
+    if (cq != 0 || w != 0) return;
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb)
+      if (16 * kb + 4 * q < P) {
+        *reinterpret_cast<float4*>(L.mst + ((size_t)t * N + r0 + lr) * ldP + 16 * kb + 4 * q) = mf[kb];
+        *reinterpret_cast<float4*>(L.out + ((size_t)(t - 1) * N + r0 + lr) * ldP + 16 * kb + 4 * q) =
+            dp_sel(live_prev, mnew[kb], make_float4(0.f, 0.f, 0.f, 0.f));
+      }
+  };
+
+  if (l == 0) load_zx(0);
+  __syncthreads();                                                 // P
+  if (dead) return;
+  if (l > 0) next_x(0);
+
+  float hv[4] = {0.f, 0.f, 0.f, 0.f}, sg[4][4] = {};
+  for (int t = 0; t < T; ++t) {
+    f32x4 acc[4];
+    DPT(0);
+    __syncthreads();                                               // A(t): m_{t-1} and x_{t+1} are in LDS
+    if (dead) return;
+    DPT(1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = accn[g];
+    // layer 0: the next step's zx is requested BEFORE this step's stores (vmcnt retires in order: a load behind the write-through
+    // granule stores would wait for their acknowledgements, 1.4 us per step in profiles/r3_dpersist_trace.txt)
+    if (l == 0) load_zx(min(t + 1, T - 1));
+    if (t > 0) {
+      float4 ms[DP_KB];
+      sum_parts(part_m, P, ms);
+      const bool live_prev = (t - 1) < lenF;
+#pragma unroll
+      for (int kb = 0; kb < DP_KB; ++kb) mf[kb] = dp_sel(live_prev, ms[kb], mf[kb]);
+      store_m(t, ms, live_prev);
+    }
+    mma_part(acc, mf, kh);
+    DPT(2);
+    // the cell, in the accumulator layout: lane = row lr, cells cb .. cb+3
+    const bool live = t < lenF;
+    const float pi_[4] = {pwi.x, pwi.y, pwi.z, pwi.w}, pf_[4] = {pwf.x, pwf.y, pwf.z, pwf.w}, po_[4] = {pwo.x, pwo.y, pwo.z, pwo.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float cpv = cp[i];
+      const float gi = dp_sigmoid(acc[0][i] + pi_[i] * cpv);
+      const float gf = dp_sigmoid(acc[2][i] + a.forget_bias + pf_[i] * cpv);
+      const float gj = dp_tanh(acc[1][i]);
+      const float cn = gf * cpv + gi * gj;
+      const float go = dp_sigmoid(acc[3][i] + po_[i] * cn);
+      const float hh = go * dp_tanh(cn);
+      hv[i] = live ? hh : 0.f;
+      sg[0][i] = live ? gi : 0.f; sg[1][i] = live ? gj : 0.f; sg[2][i] = live ? gf : 0.f; sg[3][i] = live ? go : 0.f;
+      cp[i] = live ? cn : cpv;
+    }
+    {
+      const int so = lr * DP_HS + 16 * w + 4 * q;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(&stage[g][so]) = make_float4(sg[g][0], sg[g][1], sg[g][2], sg[g][3]);
+      *reinterpret_cast<float4*>(&stage[4][so]) = make_float4(cp[0], cp[1], cp[2], cp[3]);
+      *reinterpret_cast<float4*>(&stage[5][so]) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+    }
+    DPT(3);
+    __syncthreads();                                               // B(t): the h tile is in LDS
+    DPT(4);
+    DPT(7);
+    // run ahead while the gather waves project, publish and poll: the x-part of step t+1
+    if (l > 0 && t + 1 < T) next_x(t + 1);
+    DPT(5);
+    DPT(6);
+  }
+  DPT_FLUSH();
+  if (cq == 0) {                                                   // the last step's m (block-uniform branch)
+    __syncthreads();                                               // A(T)
+    if (dead) return;
+    float4 ms[DP_KB];
+    sum_parts(part_m, P, ms);
+    const bool live_prev = (T - 1) < lenF;
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb) mf[kb] = dp_sel(live_prev, ms[kb], mf[kb]);
+    store_m(T, ms, live_prev);
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void k_dlstm_fwd(const DPersistArgs a) {
+  gu32* ctl = (gu32*)a.ctl;
+  // every wave reads the generation itself: it only changes when ALL workgroups have passed their epilogue
+  const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  dp_fwd_body(a, gen);
+  if (threadIdx.x == 0) {                                          // (thread 0 leaves the body on every path, failures included)
+    const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == gridDim.x - 1) {
+      if (__hip_atomic_load(ctl + DP_CTL_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        a.L[a.nl - 1].out[0] = __builtin_nanf("");                 // (the other workgroups have finished: nobody overwrites it)
+      __hip_atomic_store(ctl + DP_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ctl + DP_CTL_GEN, gen + 1u == 0u ? 1u : gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+size_t dpersist_granule_bytes(int nl, int N, int T) { return (size_t)nl * (N / 16) * T * DP_NQ * DP_SLOT * sizeof(unsigned long long); }
+
+bool dpersist_supported(const DPersistArgs& a) {
+  if (a.nl < 1 || a.nl > DP_MAXL || a.N % 16 != 0 || a.H != 64 * DP_NQ || a.T < 1) return false;
+  for (int l = 0; l < a.nl; ++l) {
+    const DPersistLayer& L = a.L[l];
+    if (L.P > 16 * DP_KB || L.P % 4 != 0 || L.ldP % 4 != 0 || L.P < 4) return false;
+    if (l > 0 && (L.I != a.L[l - 1].P)) return false;
+  }
+  return true;
+}
+
+// a.gran: zeroed ONCE at allocation (tag 0 is never a generation); a.ctl: {1, 0, 0, 0} at allocation
+void launch_dlstm_fwd(const DPersistArgs& a, hipStream_t s) {
+  const int blocks = a.nl * (a.N / 16) * DP_NQ;
+  hipLaunchKernelGGL(k_dlstm_fwd, dim3(blocks), dim3(512), 0, s, a);
+  ++g_chain_launches;
+}
+
+}  // namespace rsr

@@ -125,6 +125,25 @@ void launch_bwd_b(const BwdBJobs& jobs, int total_blocks, int kb_max, hipStream_
 // split-K phase B: fills ws/ldw/KG/... of every job (ws_base: >= bwd_b_ws_floats(jobs) floats) and launches both kernels
 size_t bwd_b_plan(BwdBJobs& jobs, float* ws_base);
 void launch_bwd_b_splitk(const BwdBJobs& jobs, hipStream_t s);
+// ---- persistent discriminator recurrence (dpersist.hip) ----
+constexpr int DP_MAXL = 3;
+constexpr int DP_CTL_GEN = 0, DP_CTL_DONE = 1, DP_CTL_ERR = 2, DP_CTL_WORDS = 4;   // err: 0, or 1 + the first workgroup whose bounded wait expired
+struct DPersistLayer {
+  const float *K, *bias, *wi, *wf, *wo, *Wp;      // TF-layout kernel [(I+P)][4H], bias [4H], peepholes [H], projection [H][ldP]
+  float *gates, *c, *h, *mst, *out;               // the layer's stash (model.h LstmStash); layer 0: gates holds zx = x.K_x + bias on entry
+  int I, P, ldP, ldH;
+};
+struct DPersistArgs {
+  DPersistLayer L[DP_MAXL];
+  int nl, N, T, H;
+  const int* len;
+  unsigned long long* gran;                       // dpersist_granule_bytes(nl, N, T), zeroed once at allocation
+  unsigned* ctl;                                  // control block [DP_CTL_*]: generation (starts at 1), finished workgroups, sticky error
+  float forget_bias;
+};
+size_t dpersist_granule_bytes(int nl, int N, int T);
+bool dpersist_supported(const DPersistArgs& a);
+void launch_dlstm_fwd(const DPersistArgs& a, hipStream_t s);
 extern long long g_chain_launches;
 void launch_floor_chain(float* a, float* b, int n, int mode, hipStream_t s);
 

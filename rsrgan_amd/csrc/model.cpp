@@ -413,6 +413,14 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
       }
     }
   }
+  if (const char* e = getenv("RSRGAN_DPERSIST")) dp_env = atoi(e) != 0;
+  if (dp_env && !dl.empty() && dl.size() <= (size_t)DP_MAXL && B % 16 == 0) {
+    dp_gran_bytes = dpersist_granule_bytes((int)dl.size(), B, Tmax);
+    dp_gran = (unsigned long long*)alloc<float>(dp_gran_bytes / sizeof(float));
+    dp_ctl = (unsigned*)alloc<float>(16);
+    const unsigned ctl0[DP_CTL_WORDS] = {1u, 0u, 0u, 0u};
+    HIPC(hipMemcpy(dp_ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice));
+  }
   const int dmaxld = std::max(ldPd, ldDout);
   d_dA = alloc<float>(TB2 * dmaxld); d_dB = alloc<float>(TB2 * dmaxld);
   len_dev = alloc<int>(2 * B);
@@ -850,6 +858,30 @@ bool Model::fold_forward(Chain& ch, int T, hipStream_t s) {
   return true;
 }
 
+// The same chain as ONE persistent launch (dpersist.hip): layer 0's x-part batched over time first, everything else in the kernel.
+// Produces the complete stash (gates, c, h, mst, out), unlike fold_forward.
+bool Model::persist_forward(Chain& ch, int T, hipStream_t s) {
+  if (!dp_gran || !wavefront() || ch.size() != dl.size()) return false;
+  DPersistArgs a{};
+  a.nl = (int)ch.size(); a.N = ch[0].N; a.T = T; a.H = dl[0].H; a.len = ch[0].len;
+  a.gran = dp_gran; a.ctl = dp_ctl; a.forget_bias = cfg.forget_bias;
+  for (size_t l = 0; l < ch.size(); ++l) {
+    const LayerRun& R = ch[l]; const LstmLayer& L = dl[l]; const LstmStash& S = d_st[l];
+    if (R.L != &L || R.S != &S || R.res_in || R.res_out || R.row0 != 0 || R.Ns != R.N || R.N != a.N || !L.has_proj || L.H != a.H) return false;
+    if (l > 0 && R.in != d_st[l - 1].out) return false;
+    DPersistLayer& D_ = a.L[l];
+    D_.K = D.W(L.tK); D_.bias = D.W(L.tb); D_.wi = D.W(L.twi); D_.wf = D.W(L.twf); D_.wo = D.W(L.two); D_.Wp = D.W(L.tWp);
+    D_.gates = S.gates; D_.c = S.c; D_.h = S.h; D_.mst = S.mst; D_.out = S.out;
+    D_.I = L.I; D_.P = L.P; D_.ldP = L.ldP; D_.ldH = L.ldH;
+  }
+  if (!dpersist_supported(a) || dpersist_granule_bytes(a.nl, a.N, a.T) > dp_gran_bytes) return false;
+  const LayerRun& R0 = ch[0];
+  const int H4 = 4 * a.H;
+  gemm(R0.in, R0.L->ldI, true, D.W(R0.L->tK), H4, false, d_st[0].gates, H4, T * R0.N, H4, R0.L->I, D.W(R0.L->tb), 0, 0.f, false, s);
+  launch_dlstm_fwd(a, s);
+  return true;
+}
+
 void Model::layer_wgrads_gemms(const LayerRun& R, int t0, int t1, bool accumulate, hipStream_t s) {
   const LstmLayer& L = *R.L; const LstmStash& S = *R.S; const ParamSet& ps = *R.ps;
   const int H = L.H, H4 = 4 * H, Rws = (t1 - t0) * R.N;      // needs Ns == N (rows contiguous over time)
@@ -1277,7 +1309,7 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, B, 0, s);
     if (!d_dnn()) {
       std::vector<Chain> chains(1, d_chain(B, B, 0));
-      if (!fold_forward(chains[0], T, s)) rnn_forward(chains, T, s);
+      if (!persist_forward(chains[0], T, s) && !fold_forward(chains[0], T, s)) rnn_forward(chains, T, s);
     }
   }
   // g_adv = mean((D(G(x)) - d_real)^2)  (gan_rnn_placeholder.py:246): all rows "fake", target d_real

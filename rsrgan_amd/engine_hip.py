@@ -295,6 +295,12 @@ class HipEngine:
         check(self.lib.rsrgan_profile_read(self.h, C.byref(n), C.byref(us), C.byref(fl)))
         return n.value, us.value, fl.value
 
+    def device_status(self):
+        """0, or 1 + the first workgroup of a persistent recurrence launch whose bounded wait expired (synchronises; clears the word)"""
+        code = C.c_int32()
+        check(self.lib.rsrgan_device_status(self.h, C.byref(code)))
+        return code.value
+
     def profile_launches(self):
         """launches of the recurrence kernels the host issued since profile_begin (the profiled step runs eagerly)"""
         n = C.c_int64()

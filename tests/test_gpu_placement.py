@@ -29,6 +29,11 @@ out = {}
 for it in range(2):
     d = np.ravel(model.d_step(x, lab, ln)); g = np.ravel(model.g_step(x, lab, ln, reuse_g_forward=True))
     out["d%%d" %% it] = [float(v) for v in d]; out["g%%d" %% it] = [float(v) for v in g]
+model.engine.profile_begin()
+model.d_step(x, lab, ln); model.g_step(x, lab, ln, reuse_g_forward=True)
+model.engine.profile_read()
+out["chain_launches"] = int(model.engine.profile_launches())
+out["device_status"] = int(model.engine.device_status())
 gv, dv = model.get_vars()
 h = hashlib.sha256()
 for k in sorted(gv): h.update(np.ascontiguousarray(gv[k]).tobytes())
@@ -71,6 +76,23 @@ def test_folded_discriminator_forward_agrees():
     for k in ("d0", "g0", "d1", "g1"):
         assert np.allclose(a[k], b[k], rtol=2e-5, atol=1e-7), (k, a[k], b[k])
     assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
+
+
+@pytest.mark.parametrize("B,T", [(16, 9), (64, 100)])
+def test_persistent_discriminator_forward_agrees(B, T):
+    """csrc/dpersist.hip: D(G(x)) of the G-run as ONE persistent launch (partial projections exchanged as tagged granules) against
+    the per-step launches.  Same products, the projection summed per cell quarter: fp32 rounding apart.  The launch count proves
+    which path ran: T + 1 per-step launches (folded cells) become one."""
+    size = {"RSRGAN_TEST_B": str(B), "RSRGAN_TEST_T": str(T)}
+    a = _run(dict(size, RSRGAN_DPERSIST="1"))
+    b = _run(dict(size, RSRGAN_DPERSIST="0"))
+    assert b["chain_launches"] - a["chain_launches"] >= T - 1, (a["chain_launches"], b["chain_launches"])
+    assert a["device_status"] == 0 and b["device_status"] == 0
+    for k in ("d0", "g0", "d1", "g1"):
+        assert np.allclose(a[k], b[k], rtol=2e-5, atol=1e-7), (k, a[k], b[k])
+    assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
+    c = _run(dict(size, RSRGAN_DPERSIST="1"))
+    assert a["vars_sha"] == c["vars_sha"]          # fixed summation order: reproducible bits
 
 
 def test_stream_k_gemm_step_is_reproducible():
