@@ -455,7 +455,295 @@ __global__ __launch_bounds__(512, 1) void k_dlstm_fwd(const DPersistArgs a) {
   }
 }
 
-size_t dpersist_granule_bytes(int nl, int N, int T) { return (size_t)nl * (N / 16) * T * DP_NQ * DP_SLOT * sizeof(unsigned long long); }
+// ------------------------------------------------------------------------------------------------------------------------
+// Backward recurrence of the same stack as ONE persistent launch (the D-run's BPTT through the discriminator, which runs alone).
+// Per step t (descending), workgroup (layer l, 16-row tile r, cell quarter c), everything in the transposed lane layout of the
+// forward kernel (lane (q, lr): row lr, cells cb .. cb+3):
+//   dm_t  = live(t) ? dout_t + dm_state : 0            dout_t: the top layer reads it from memory (dlogits . W_fc^T, batched),
+//                                                      a lower layer sums the dx partials the layer above published for step t
+//   dh^T  = W_p[cells, :] . dm_t^T                     12 MFMAs, W_p rows resident as the A operand
+//   the cell's gate gradients dz (kernels.hip k_bwd_a2, same formulas), dc carried in registers
+//   dm_state partial^T = K_h[:, this wave's gate columns] . dz^T    48 MFMAs: the lane's own dz registers ARE the B fragment
+//     (k = the wave's 16 cells of one gate = 4q + i), summed over the 4 compute waves through LDS by the gather waves, published as
+//     granules, summed over the 4 quarters by the consumers: dm_state(t-1) = live(t) ? sum : dm_state (masked rows pass it through)
+//   dx partial^T = K_x[...] . dz^T (layers above 0)   48 more MFMAs after barrier B, published one step later (the layer below lags)
+// dz replaces the gate activations in the stash (the weight-gradient GEMMs read it), dm_t goes to dmt.
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigned gen) {
+  __shared__ __attribute__((aligned(16))) float part_m[DP_NQ][DP_KB][64][4];      // swept partials of dm_state (from step t+1)
+  __shared__ __attribute__((aligned(16))) float part_x[2][DP_NQ][DP_KB][64][4];   // ... of dout (dx of the layer above), by parity of the step
+  __shared__ __attribute__((aligned(16))) float stage[4][16 * DP_HS];             // dz of the step, staged for gather wave 3
+  __shared__ __attribute__((aligned(16))) float psum[4][DP_KB][64][4];            // the compute waves' partial dm_state tiles
+  __shared__ __attribute__((aligned(16))) float psum_x[2][4][DP_KB][64][4];       // ... partial dx tiles, by parity of the step
+  __shared__ __attribute__((aligned(16))) float kx_lds[4][DP_KB][4][64][4];       // K_x fragments (A operand of the dx product)
+  __shared__ int dead;
+  const int RTn = a.N >> 4, ncl = a.nl * RTn;
+  const int cl = blockIdx.x % ncl, cq = blockIdx.x / ncl;
+  const int l = cl / RTn, r = cl - l * RTn;
+  const DPersistLayer L = a.L[l];
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, H4 = 4 * H, T = a.T, N = a.N, P = L.P, ldP = L.ldP, I = L.I;
+  const int r0 = r * 16;
+  const bool top = l == a.nl - 1;
+  gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
+  if (tid == 0) dead = 0;
+  const size_t slot_stride_t = (size_t)DP_NQ * DP_SLOT;
+  // edge 0: dm_state partials of this layer; edge 1: dx partials of this layer = dout of the layer below
+  auto edge = [&](int layer, int e) -> gu64* {
+    return (gu64*)a.gran + ((size_t)((layer * 2 + e) * RTn + r) * T) * slot_stride_t;
+  };
+  __syncthreads();
+
+  if (w >= 4) {
+    // ---------------- gather waves ----------------
+    __builtin_amdgcn_s_setprio(3);
+    const int j = w - 4;
+    const gu64* gm = edge(l, 0) + (size_t)j * DP_SLOT;
+    const gu64* gx = edge(min(l + 1, a.nl - 1), 1) + (size_t)j * DP_SLOT;
+    gu64* gout_m = edge(l, 0) + (size_t)cq * DP_SLOT;
+    gu64* gout_x = edge(l, 1) + (size_t)cq * DP_SLOT;
+    float vm[DP_KB * 4], vx[DP_KB * 4];
+    auto put = [&](float (*part)[DP_KB][64][4], const float (&v)[DP_KB * 4]) {
+#pragma unroll
+      for (int kb = 0; kb < DP_KB; ++kb)
+        *reinterpret_cast<float4*>(&part[j][kb][lane][0]) = make_float4(v[kb * 4], v[kb * 4 + 1], v[kb * 4 + 2], v[kb * 4 + 3]);
+    };
+    auto fail = [&]() { if (lane == 0) { dead = 1; __hip_atomic_store(err, 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } };
+    // the sum of the four compute waves' tile j, published as this quarter's partial
+    auto publish = [&](float (*ps)[DP_KB][64][4], gu64* dst) {
+      const float4 p0 = *reinterpret_cast<const float4*>(&ps[0][j][lane][0]), p1 = *reinterpret_cast<const float4*>(&ps[1][j][lane][0]);
+      const float4 p2 = *reinterpret_cast<const float4*>(&ps[2][j][lane][0]), p3 = *reinterpret_cast<const float4*>(&ps[3][j][lane][0]);
+      gu64* go_ = dst + ((size_t)j * 64 + lane) * 4;
+      dp_store2(go_, gen, ((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y);
+      dp_store2(go_ + 2, gen, ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+    };
+    if (!top) {                                                    // dout of step T-1 for the prologue
+      if (!dp_sweep2(nullptr, gen, vm, gx + (size_t)(T - 1) * slot_stride_t, gen, vx, lane, err)) fail();
+      put(part_x[(T - 1) & 1], vx);
+    }
+    __syncthreads();                                               // P
+    if (dead) return;
+    // iteration t delivers dm_state partials of step t+1 (t < T-1) and dout partials of step t-1 (lower layers) before barrier A(t)
+    for (int t = T - 1; t >= 0; --t) {
+      const bool wm = t < T - 1, wx = !top && t > 0;
+      if (wm || wx) {
+        if (!dp_sweep2(wm ? gm + (size_t)(t + 1) * slot_stride_t : nullptr, gen, vm,
+                       wx ? gx + (size_t)(t - 1) * slot_stride_t : nullptr, gen, vx, lane, err)) fail();
+        if (wm) put(part_m, vm);
+        if (wx) put(part_x[(t - 1) & 1], vx);
+      }
+      __syncthreads();                                             // A(t)
+      if (dead) return;
+      __syncthreads();                                             // B(t): psum(t), the dz stage and psum_x(t+1) are in LDS
+      if (j < 3) {
+        publish(psum, gout_m + (size_t)t * slot_stride_t);
+        if (l > 0 && t < T - 1) publish(psum_x[(t + 1) & 1], gout_x + (size_t)(t + 1) * slot_stride_t);
+      } else {
+        // gather wave 3 writes the step's dz over the gate activations: whole 256-byte rows from the LDS stage
+        const int c4 = (lane & 15) * 4, rr = lane >> 4;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int row = 4 * rg + rr;
+          const size_t grow = (size_t)t * N + r0 + row;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(L.gates + grow * H4 + g * H + cq * 64 + c4) = *reinterpret_cast<const float4*>(&stage[g][row * DP_HS + c4]);
+        }
+      }
+    }
+    if (l > 0) {                                                   // dx of step 0, computed after barrier B(0)
+      __syncthreads();                                             // C
+      if (j < 3) publish(psum_x[0], gout_x);
+    }
+    return;
+  }
+
+  // ---------------- compute waves ----------------
+  const int cb = cq * 64 + 16 * w + 4 * q;                          // this lane's four cells
+  // A operands, resident.  dh: W_p[cell 16w + lr][p = 16kb + 4q + u]; dm_state: K[I + p][g*H + cells cb .. cb+3], p = 16pt + lr
+  float4 wpA[DP_KB], khA[DP_KB][4];
+  {
+    const float* wrow = L.Wp + (size_t)(cq * 64 + 16 * w + lr) * ldP;
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb) {
+      const int k = 16 * kb + 4 * q;
+      const float4 v = *reinterpret_cast<const float4*>(wrow + min(k, P - 4));
+      wpA[kb] = dp_sel(k < P, v, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+#pragma unroll
+    for (int pt = 0; pt < DP_KB; ++pt) {
+      const int p = 16 * pt + lr;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 vh = *reinterpret_cast<const float4*>(L.K + (size_t)(I + min(p, P - 1)) * H4 + g * H + cb);
+        const float4 vx = *reinterpret_cast<const float4*>(L.K + (size_t)min(p, I - 1) * H4 + g * H + cb);
+        khA[pt][g] = dp_sel(p < P, vh, make_float4(0.f, 0.f, 0.f, 0.f));
+        *reinterpret_cast<float4*>(&kx_lds[w][pt][g][lane][0]) = dp_sel(l > 0 && p < I, vx, make_float4(0.f, 0.f, 0.f, 0.f));
+      }
+    }
+  }
+  const float4 pwi = *reinterpret_cast<const float4*>(L.wi + cb), pwf = *reinterpret_cast<const float4*>(L.wf + cb);
+  const float4 pwo = *reinterpret_cast<const float4*>(L.wo + cb);
+  const float pi_[4] = {pwi.x, pwi.y, pwi.z, pwi.w}, pf_[4] = {pwf.x, pwf.y, pwf.z, pwf.w}, po_[4] = {pwo.x, pwo.y, pwo.z, pwo.w};
+  const int lenF = a.len[r0 + lr];
+
+  float dc[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 mf[DP_KB];                                                 // dm_state of this lane's row: [k = 16kb + 4q + u]
+#pragma unroll
+  for (int kb = 0; kb < DP_KB; ++kb) mf[kb] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // operands of a step, requested one step ahead: the gate activations, c_{t-1} (c_t is last step's c_{t-1}) and the top layer's dout
+  f32x4 gn[4], cpn;
+  float4 don[DP_KB];
+  f32x4 ccur;
+  auto prefetch = [&](int t) {
+    const size_t row = (size_t)t * N + r0 + lr;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gn[g] = *reinterpret_cast<const f32x4*>(L.gates + row * H4 + g * H + cb);
+    cpn = *reinterpret_cast<const f32x4*>(L.c + row * H + cb);
+    if (top) {
+#pragma unroll
+      for (int kb = 0; kb < DP_KB; ++kb)
+        don[kb] = *reinterpret_cast<const float4*>(a.dout_top + row * a.ld_dout + min(16 * kb + 4 * q, P - 4));
+    }
+  };
+  auto sum_parts = [&](float (*part)[DP_KB][64][4], int width, float4 (&s)[DP_KB]) {
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb) {
+      const float4 p0 = *reinterpret_cast<const float4*>(&part[0][kb][lane][0]), p1 = *reinterpret_cast<const float4*>(&part[1][kb][lane][0]);
+      const float4 p2 = *reinterpret_cast<const float4*>(&part[2][kb][lane][0]), p3 = *reinterpret_cast<const float4*>(&part[3][kb][lane][0]);
+      s[kb] = dp_sel(16 * kb + 4 * q < width,
+                     make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
+                                 ((p0.w + p1.w) + p2.w) + p3.w), make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+  };
+  ccur = *reinterpret_cast<const f32x4*>(L.c + ((size_t)T * N + r0 + lr) * H + cb);      // c_T
+  prefetch(T - 1);
+  __syncthreads();                                                 // P
+  if (dead) return;
+
+  for (int t = T - 1; t >= 0; --t) {
+    __syncthreads();                                               // A(t)
+    if (dead) return;
+    const bool live = t < lenF;
+    // this step's operands out of the prefetch registers, the next step's requested
+    f32x4 gt[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gt[g] = gn[g];
+    const f32x4 cprev = cpn;
+    float4 dout[DP_KB];
+    if (top) {
+#pragma unroll
+      for (int kb = 0; kb < DP_KB; ++kb) dout[kb] = dp_sel(16 * kb + 4 * q < P, don[kb], make_float4(0.f, 0.f, 0.f, 0.f));
+    } else {
+      sum_parts(part_x[t & 1], P, dout);
+    }
+    prefetch(max(t - 1, 0));
+    if (t < T - 1) {
+      float4 ms[DP_KB];
+      sum_parts(part_m, P, ms);
+      const bool live_next = (t + 1) < lenF;                        // masked rows pass the carried gradient through
+#pragma unroll
+      for (int kb = 0; kb < DP_KB; ++kb) mf[kb] = dp_sel(live_next, ms[kb], mf[kb]);
+    }
+    float4 dm[DP_KB];
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb)
+      dm[kb] = dp_sel(live, make_float4(dout[kb].x + mf[kb].x, dout[kb].y + mf[kb].y, dout[kb].z + mf[kb].z, dout[kb].w + mf[kb].w),
+                      make_float4(0.f, 0.f, 0.f, 0.f));
+    if (cq == 0 && w == 0) {                                       // dm_t for the projection's weight gradient
+#pragma unroll
+      for (int kb = 0; kb < DP_KB; ++kb)
+        if (16 * kb + 4 * q < P) *reinterpret_cast<float4*>(L.dmt + ((size_t)t * N + r0 + lr) * ldP + 16 * kb + 4 * q) = dm[kb];
+    }
+    // dh^T[cell][row] = W_p[cell][:] . dm^T
+    f32x4 dh = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb) {
+      dh = __builtin_amdgcn_mfma_f32_16x16x4f32(wpA[kb].x, dm[kb].x, dh, 0, 0, 0);
+      dh = __builtin_amdgcn_mfma_f32_16x16x4f32(wpA[kb].y, dm[kb].y, dh, 0, 0, 0);
+      dh = __builtin_amdgcn_mfma_f32_16x16x4f32(wpA[kb].z, dm[kb].z, dh, 0, 0, 0);
+      dh = __builtin_amdgcn_mfma_f32_16x16x4f32(wpA[kb].w, dm[kb].w, dh, 0, 0, 0);
+    }
+    // gate / cell gradients (kernels.hip k_bwd_a2): lane = row lr, cells cb + i
+    float dz[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float gi = gt[0][i], gj = gt[1][i], gf = gt[2][i], go = gt[3][i];
+      const float tc = dp_tanh(ccur[i]);
+      const float dao = dh[i] * tc * go * (1.f - go);
+      const float dcn = dc[i] + dh[i] * go * (1.f - tc * tc) + dao * po_[i];
+      const float daf = dcn * cprev[i] * gf * (1.f - gf);
+      const float dai = dcn * gj * gi * (1.f - gi);
+      const float dj = dcn * gi * (1.f - gj * gj);
+      dz[0][i] = live ? dai : 0.f; dz[1][i] = live ? dj : 0.f; dz[2][i] = live ? daf : 0.f; dz[3][i] = live ? dao : 0.f;
+      dc[i] = live ? dcn * gf + dai * pi_[i] + daf * pf_[i] : dc[i];
+    }
+    ccur = cprev;
+    {
+      const int so = lr * DP_HS + 16 * w + 4 * q;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(&stage[g][so]) = make_float4(dz[g][0], dz[g][1], dz[g][2], dz[g][3]);
+    }
+    // partial dm_state^T over this wave's 64 gate columns: the lane's dz[g][0..3] is the B fragment of k-block (gate g)
+    f32x4 pa[DP_KB];
+#pragma unroll
+    for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(khA[pt][g].x, dz[g][0], pa[pt], 0, 0, 0);
+#pragma unroll
+      for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(khA[pt][g].y, dz[g][1], pa[pt], 0, 0, 0);
+#pragma unroll
+      for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(khA[pt][g].z, dz[g][2], pa[pt], 0, 0, 0);
+#pragma unroll
+      for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(khA[pt][g].w, dz[g][3], pa[pt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int pt = 0; pt < DP_KB; ++pt) *reinterpret_cast<f32x4*>(&psum[w][pt][lane][0]) = pa[pt];
+    __syncthreads();                                               // B(t)
+    if (l > 0) {                                                   // dx partial^T of this step: published by the gather waves after B(t-1)
+#pragma unroll
+      for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 af[DP_KB];
+#pragma unroll
+        for (int pt = 0; pt < DP_KB; ++pt) af[pt] = *reinterpret_cast<const float4*>(&kx_lds[w][pt][g][lane][0]);
+#pragma unroll
+        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt].x, dz[g][0], pa[pt], 0, 0, 0);
+#pragma unroll
+        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt].y, dz[g][1], pa[pt], 0, 0, 0);
+#pragma unroll
+        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt].z, dz[g][2], pa[pt], 0, 0, 0);
+#pragma unroll
+        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt].w, dz[g][3], pa[pt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int pt = 0; pt < DP_KB; ++pt) *reinterpret_cast<f32x4*>(&psum_x[t & 1][w][pt][lane][0]) = pa[pt];
+    }
+  }
+  if (l > 0) __syncthreads();                                      // C: dx of step 0 is in LDS
+}
+
+__global__ __launch_bounds__(512, 1) void k_dlstm_bwd(const DPersistArgs a) {
+  gu32* ctl = (gu32*)a.ctl;
+  const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  dp_bwd_body(a, gen);
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == gridDim.x - 1) {
+      if (__hip_atomic_load(ctl + DP_CTL_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        a.L[0].gates[0] = __builtin_nanf("");                      // poisons layer 0's kernel gradient, hence the clipped update
+      __hip_atomic_store(ctl + DP_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ctl + DP_CTL_GEN, gen + 1u == 0u ? 1u : gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// (the backward launch uses two edges per layer: dm_state partials and the dx partials for the layer below)
+size_t dpersist_granule_bytes(int nl, int N, int T) { return (size_t)2 * nl * (N / 16) * T * DP_NQ * DP_SLOT * sizeof(unsigned long long); }
 
 bool dpersist_supported(const DPersistArgs& a) {
   if (a.nl < 1 || a.nl > DP_MAXL || a.N % 16 != 0 || a.H != 64 * DP_NQ || a.T < 1) return false;
@@ -468,6 +756,12 @@ bool dpersist_supported(const DPersistArgs& a) {
 }
 
 // a.gran: zeroed ONCE at allocation (tag 0 is never a generation); a.ctl: {1, 0, 0, 0} at allocation
+void launch_dlstm_bwd(const DPersistArgs& a, hipStream_t s) {
+  const int blocks = a.nl * (a.N / 16) * DP_NQ;
+  hipLaunchKernelGGL(k_dlstm_bwd, dim3(blocks), dim3(512), 0, s, a);
+  ++g_chain_launches;
+}
+
 void launch_dlstm_fwd(const DPersistArgs& a, hipStream_t s) {
   const int blocks = a.nl * (a.N / 16) * DP_NQ;
   hipLaunchKernelGGL(k_dlstm_fwd, dim3(blocks), dim3(512), 0, s, a);

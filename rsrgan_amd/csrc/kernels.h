@@ -131,6 +131,7 @@ constexpr int DP_CTL_GEN = 0, DP_CTL_DONE = 1, DP_CTL_ERR = 2, DP_CTL_WORDS = 4;
 struct DPersistLayer {
   const float *K, *bias, *wi, *wf, *wo, *Wp;      // TF-layout kernel [(I+P)][4H], bias [4H], peepholes [H], projection [H][ldP]
   float *gates, *c, *h, *mst, *out;               // the layer's stash (model.h LstmStash); layer 0: gates holds zx = x.K_x + bias on entry
+  float* dmt;                                     // backward: [T][N][ldP] total dm per step (the projection's weight gradient reads it)
   int I, P, ldP, ldH;
 };
 struct DPersistArgs {
@@ -140,10 +141,13 @@ struct DPersistArgs {
   unsigned long long* gran;                       // dpersist_granule_bytes(nl, N, T), zeroed once at allocation
   unsigned* ctl;                                  // control block [DP_CTL_*]: generation (starts at 1), finished workgroups, sticky error
   float forget_bias;
+  const float* dout_top;                          // backward: [T][N][ld_dout] gradient of the top layer's masked outputs
+  int ld_dout;
 };
 size_t dpersist_granule_bytes(int nl, int N, int T);
 bool dpersist_supported(const DPersistArgs& a);
 void launch_dlstm_fwd(const DPersistArgs& a, hipStream_t s);
+void launch_dlstm_bwd(const DPersistArgs& a, hipStream_t s);      // gates: activations in, dz out; needs c, dmt, dout_top
 extern long long g_chain_launches;
 void launch_floor_chain(float* a, float* b, int n, int mode, hipStream_t s);
 

@@ -413,9 +413,9 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
       }
     }
   }
-  if (const char* e = getenv("RSRGAN_DPERSIST")) dp_env = atoi(e) != 0;
+  if (const char* e = getenv("RSRGAN_DPERSIST")) dp_env = atoi(e);        // bit 0: forward, bit 1: backward
   if (dp_env && !dl.empty() && dl.size() <= (size_t)DP_MAXL && B % 16 == 0) {
-    dp_gran_bytes = dpersist_granule_bytes((int)dl.size(), B, Tmax);
+    dp_gran_bytes = dpersist_granule_bytes((int)dl.size(), 2 * B, Tmax);
     dp_gran = (unsigned long long*)alloc<float>(dp_gran_bytes / sizeof(float));
     dp_ctl = (unsigned*)alloc<float>(16);
     const unsigned ctl0[DP_CTL_WORDS] = {1u, 0u, 0u, 0u};
@@ -861,7 +861,7 @@ bool Model::fold_forward(Chain& ch, int T, hipStream_t s) {
 // The same chain as ONE persistent launch (dpersist.hip): layer 0's x-part batched over time first, everything else in the kernel.
 // Produces the complete stash (gates, c, h, mst, out), unlike fold_forward.
 bool Model::persist_forward(Chain& ch, int T, hipStream_t s) {
-  if (!dp_gran || !wavefront() || ch.size() != dl.size()) return false;
+  if (!dp_gran || !(dp_env & 1) || !wavefront() || ch.size() != dl.size()) return false;
   DPersistArgs a{};
   a.nl = (int)ch.size(); a.N = ch[0].N; a.T = T; a.H = dl[0].H; a.len = ch[0].len;
   a.gran = dp_gran; a.ctl = dp_ctl; a.forget_bias = cfg.forget_bias;
@@ -879,6 +879,31 @@ bool Model::persist_forward(Chain& ch, int T, hipStream_t s) {
   const int H4 = 4 * a.H;
   gemm(R0.in, R0.L->ldI, true, D.W(R0.L->tK), H4, false, d_st[0].gates, H4, T * R0.N, H4, R0.L->I, D.W(R0.L->tb), 0, 0.f, false, s);
   launch_dlstm_fwd(a, s);
+  return true;
+}
+
+// BPTT through a discriminator chain running alone as ONE persistent launch (dpersist.hip k_dlstm_bwd), then the weight-gradient
+// GEMMs over the dz it leaves in the stash.  No input gradient for layer 0 (the D-run does not need one).
+bool Model::persist_backward(Chain& ch, int T, hipStream_t s) {
+  if (!dp_gran || !(dp_env & 2) || !wavefront() || ch.size() != dl.size() || ch[0].din) return false;
+  DPersistArgs a{};
+  a.nl = (int)ch.size(); a.N = ch[0].N; a.T = T; a.H = dl[0].H; a.len = ch[0].len;
+  a.gran = dp_gran; a.ctl = dp_ctl; a.forget_bias = cfg.forget_bias;
+  for (size_t l = 0; l < ch.size(); ++l) {
+    const LayerRun& R = ch[l]; const LstmLayer& L = dl[l]; const LstmStash& S = d_st[l];
+    if (R.L != &L || R.S != &S || R.res_in || R.res_out || R.row0 != 0 || R.Ns != R.N || R.N != a.N || !L.has_proj || L.H != a.H) return false;
+    if (l > 0 && R.in != d_st[l - 1].out) return false;
+    DPersistLayer& D_ = a.L[l];
+    D_.K = D.W(L.tK); D_.bias = D.W(L.tb); D_.wi = D.W(L.twi); D_.wf = D.W(L.twf); D_.wo = D.W(L.two); D_.Wp = D.W(L.tWp);
+    D_.gates = S.gates; D_.c = S.c; D_.h = S.h; D_.mst = S.mst; D_.out = S.out; D_.dmt = S.dmt;
+    D_.I = L.I; D_.P = L.P; D_.ldP = L.ldP; D_.ldH = L.ldH;
+  }
+  a.dout_top = ch.back().dout; a.ld_dout = dl.back().ldP;
+  if (!a.dout_top || !dpersist_supported(a) || dpersist_granule_bytes(a.nl, a.N, a.T) > dp_gran_bytes) return false;
+  launch_dlstm_bwd(a, s);
+  if (!defer_wgrads)
+    for (auto& R : ch)
+      if (R.want_wgrads) layer_wgrads(R, T, s);
   return true;
 }
 
@@ -1124,7 +1149,7 @@ void Model::d_backward_pass(int N, int T, bool want_wgrads, bool need_dx0, const
     ch[l].want_wgrads = want_wgrads;
     std::swap(cur, other);
   }
-  rnn_backward(chains, T, s);
+  if (!persist_backward(ch, T, s)) rnn_backward(chains, T, s);
   last_dx0 = cur;
 }
 

@@ -143,12 +143,13 @@ struct Model {
   bool fold_env = true;                                   // RSRGAN_DFOLD=0: off
   bool fold_forward(Chain& ch, int T, hipStream_t s);     // false: not applicable -> caller falls back
   void refresh_fold(hipStream_t s);
-  // ---- persistent recurrence (dpersist.hip): the same chain as ONE launch; RSRGAN_DPERSIST=0: off
+  // ---- persistent recurrence (dpersist.hip): the same chain as ONE launch; RSRGAN_DPERSIST=0: off (bits below)
   unsigned long long* dp_gran = nullptr;
   unsigned* dp_ctl = nullptr;                             // kernels.h DP_CTL_*
   size_t dp_gran_bytes = 0;
-  bool dp_env = true;
+  int dp_env = 3;                                         // RSRGAN_DPERSIST: bit 0 the forward launch, bit 1 the backward launch
   bool persist_forward(Chain& ch, int T, hipStream_t s);  // false: not applicable -> caller falls back to fold_forward
+  bool persist_backward(Chain& ch, int T, hipStream_t s); // BPTT of the chain + its weight gradients; false: not applicable
   // fully-connected stacks: models/dnn.py generator and models/discriminator_dnn.py discriminator
   std::vector<FcLayer> gfc, dfc;
   std::vector<float*> g_act, d_act;        // act[l] = input of FC layer l, act[L] = output of the stack
