@@ -381,9 +381,6 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
     DPT(1);
 #pragma unroll
     for (int g = 0; g < 4; ++g) acc[g] = accn[g];
-    // layer 0: the next step's zx is requested BEFORE this step's stores (vmcnt retires in order: a load behind the write-through
-    // granule stores would wait for their acknowledgements, 1.4 us per step in profiles/r3_dpersist_trace.txt)
-    if (l == 0) load_zx(min(t + 1, T - 1));
     if (t > 0) {
       float4 ms[DP_KB];
       sum_parts(part_m, P, ms);
@@ -421,8 +418,10 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
     __syncthreads();                                               // B(t): the h tile is in LDS
     DPT(4);
     DPT(7);
-    // run ahead while the gather waves project, publish and poll: the x-part of step t+1
+    // run ahead while the gather waves poll: the x-part of step t+1 (after their projection and publish, see the backward kernel)
+    __builtin_amdgcn_s_sleep(12);
     if (l > 0 && t + 1 < T) next_x(t + 1);
+    if (l == 0) load_zx(min(t + 1, T - 1));                        // (not right behind barrier B: see the backward kernel)
     DPT(5);
     DPT(6);
   }
@@ -477,6 +476,7 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
   __shared__ __attribute__((aligned(16))) float psum_x[2][4][DP_KB][64][4];       // ... partial dx tiles, by parity of the step
   __shared__ __attribute__((aligned(16))) float kx_lds[4][DP_KB][4][64][4];       // K_x fragments (A operand of the dx product)
   __shared__ int dead;
+  DPT_DECL
   const int RTn = a.N >> 4, ncl = a.nl * RTn;
   const int cl = blockIdx.x % ncl, cq = blockIdx.x / ncl;
   const int l = cl / RTn, r = cl - l * RTn;
@@ -527,18 +527,23 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
     // iteration t delivers dm_state partials of step t+1 (t < T-1) and dout partials of step t-1 (lower layers) before barrier A(t)
     for (int t = T - 1; t >= 0; --t) {
       const bool wm = t < T - 1, wx = !top && t > 0;
+      DPG(0);
       if (wm || wx) {
         if (!dp_sweep2(wm ? gm + (size_t)(t + 1) * slot_stride_t : nullptr, gen, vm,
                        wx ? gx + (size_t)(t - 1) * slot_stride_t : nullptr, gen, vx, lane, err)) fail();
         if (wm) put(part_m, vm);
         if (wx) put(part_x[(t - 1) & 1], vx);
       }
+      DPG(1);
       __syncthreads();                                             // A(t)
       if (dead) return;
-      __syncthreads();                                             // B(t): psum(t), the dz stage and psum_x(t+1) are in LDS
+      // dx of step t+1 (in LDS since before A(t)) leaves while the compute waves work: its write-through stores are acknowledged
+      // before the dm_state publish below (two publishes back to back cost the second one, and the poll behind it, ~0.75 us)
+      if (j < 3 && l > 0 && t < T - 1) publish(psum_x[(t + 1) & 1], gout_x + (size_t)(t + 1) * slot_stride_t);
+      __syncthreads();                                             // B(t): psum(t) and the dz stage are in LDS
+      DPG(2);
       if (j < 3) {
         publish(psum, gout_m + (size_t)t * slot_stride_t);
-        if (l > 0 && t < T - 1) publish(psum_x[(t + 1) & 1], gout_x + (size_t)(t + 1) * slot_stride_t);
       } else {
         // gather wave 3 writes the step's dz over the gate activations: whole 256-byte rows from the LDS stage
         const int c4 = (lane & 15) * 4, rr = lane >> 4;
@@ -551,6 +556,7 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
             *reinterpret_cast<float4*>(L.gates + grow * H4 + g * H + cq * 64 + c4) = *reinterpret_cast<const float4*>(&stage[g][row * DP_HS + c4]);
         }
       }
+      DPG(3);
     }
     if (l > 0) {                                                   // dx of step 0, computed after barrier B(0)
       __syncthreads();                                             // C
@@ -623,8 +629,10 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
   if (dead) return;
 
   for (int t = T - 1; t >= 0; --t) {
+    DPT(0);
     __syncthreads();                                               // A(t)
     if (dead) return;
+    DPT(1);
     const bool live = t < lenF;
     // this step's operands out of the prefetch registers, the next step's requested
     f32x4 gt[4];
@@ -638,6 +646,8 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
     } else {
       sum_parts(part_x[t & 1], P, dout);
     }
+    // (the next step's operands are requested HERE, on the compute path: behind barrier B the CU's memory pipe belongs to the gather
+    // waves' publish and polls -- these loads there, even delayed, cost the hand-off more than they save: 419-427 vs 406 us per launch)
     prefetch(max(t - 1, 0));
     if (t < T - 1) {
       float4 ms[DP_KB];
@@ -665,6 +675,7 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
       dh = __builtin_amdgcn_mfma_f32_16x16x4f32(wpA[kb].z, dm[kb].z, dh, 0, 0, 0);
       dh = __builtin_amdgcn_mfma_f32_16x16x4f32(wpA[kb].w, dm[kb].w, dh, 0, 0, 0);
     }
+    DPT(2);
     // gate / cell gradients (kernels.hip k_bwd_a2): lane = row lr, cells cb + i
     float dz[4][4];
 #pragma unroll
@@ -685,6 +696,7 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
 #pragma unroll
       for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(&stage[g][so]) = make_float4(dz[g][0], dz[g][1], dz[g][2], dz[g][3]);
     }
+    DPT(3);
     // partial dm_state^T over this wave's 64 gate columns: the lane's dz[g][0..3] is the B fragment of k-block (gate g)
     f32x4 pa[DP_KB];
 #pragma unroll
@@ -702,8 +714,13 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
     }
 #pragma unroll
     for (int pt = 0; pt < DP_KB; ++pt) *reinterpret_cast<f32x4*>(&psum[w][pt][lane][0]) = pa[pt];
+    DPT(4);
     __syncthreads();                                               // B(t)
+    DPT(5);
     if (l > 0) {                                                   // dx partial^T of this step: published by the gather waves after B(t-1)
+      // (first let the gather waves publish: this burst of LDS reads and MFMAs right behind the barrier held their ~350-cycle
+      // publish back by 1500 cycles on the shared SIMDs, s_setprio notwithstanding -- profiles/r3_dpersist_trace.txt)
+      __builtin_amdgcn_s_sleep(8);
 #pragma unroll
       for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -723,7 +740,9 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
 #pragma unroll
       for (int pt = 0; pt < DP_KB; ++pt) *reinterpret_cast<f32x4*>(&psum_x[t & 1][w][pt][lane][0]) = pa[pt];
     }
+    DPT(6);
   }
+  DPT_FLUSH();
   if (l > 0) __syncthreads();                                      // C: dx of step 0 is in LDS
 }
 
