@@ -166,7 +166,9 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict
   float* ds = smem + (size_t)(S + 1) * rowlen;            // [MP][36] gradient strip (4 positions = 144 floats apart: 16-bank steps)
   int* tab = reinterpret_cast<int*>(ds + (size_t)MP * 36); // [MP] h*rowlen + wl*C': LDS offset of position m's window in its own image row
   int* gtab = tab + MP;                                   // [MP] offset of position m in one frame of d (-1: outside the strip)
-  const int dh0 = blockIdx.x * DH, grp = blockIdx.y, strip = blockIdx.z;
+  // filter rows of this workgroup: dh0 + dd * dstep, INTERLEAVED over the row groups (rows near the middle meet the fewest padding
+  // positions: contiguous groups {0..5} / {6..10} of an 11-row filter carry 51 / 40 row-blocks, interleaved 48 / 43)
+  const int dh0 = blockIdx.x, dstep = gridDim.x, grp = blockIdx.y, strip = blockIdx.z;
   const int w0 = strip * TW, tw = min(TW, W - w0);
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -197,34 +199,131 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict
   __syncthreads();                                        // tab / gtab visible
   bool kt_ok[KT];
 #pragma unroll
-  for (int i = 0; i < KT; ++i) kt_ok[i] = (wv * KT + i) * 16 < KP;
+  for (int i = 0; i < KT; ++i) kt_ok[i] = (wv + NWV * i) * 16 < KP;      // k'-tile wv + NWV*i: a second tile only where the first round left some
   for (int f = 0; f < fpg; ++f) {
     const int r = grp * fpg + f;
     if (r >= R) break;
     __syncthreads();
     {
       // image strip: thread e0 owns float4 slot e0 of every row (row4 <= 512 is checked on the host); rows are independent loads
+      // All loads of a frame are in flight together: six image rows per batch and up to four gradient slots, UNCONDITIONAL from
+      // clamped / stand-in addresses, the zeros selected afterwards.  (Round 2's loops loaded under a branch inside a loop with a
+      // run-time bound: one global round trip per image row, 12 per frame -- 40 % of the kernel's time at W = 257.)
+      const float* dsrc = d + (size_t)r * S * W * ldc_d;
+      constexpr int DSLOTS = 4;                              // MP * 8 <= 4 * 1024 (checked on the host: conv_wgrad_supported)
+      float4 dv[DSLOTS];
+      int dgo[DSLOTS];
+#pragma unroll
+      for (int u = 0; u < DSLOTS; ++u) {                     // 8 float4 = 32 channels per position
+        const int i = tid + u * 64 * NWV;
+        const int m = min(i >> 3, MP - 1), c = (i & 7) * 4;
+        dgo[u] = (i < MP * 8 && c < N) ? gtab[m] : -1;
+        dv[u] = *reinterpret_cast<const float4*>(dsrc + (dgo[u] >= 0 ? dgo[u] + c : 0));
+      }
       if (e0 >= 0) {
-        const float* src = in + ((size_t)r * S * W + swcol) * ldc_in + sc;
-        for (int h = 0; h <= S; ++h) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (s_in && h < S) v = *reinterpret_cast<const float4*>(src + (size_t)h * W * ldc_in);
-          *reinterpret_cast<float4*>(img + (size_t)h * rowlen + (size_t)e0 * 4) = v;
+        const float* src = s_in ? in + ((size_t)r * S * W + swcol) * ldc_in + sc : in;
+        const size_t hs = s_in ? (size_t)W * ldc_in : 0;
+        for (int h0 = 0; h0 <= S; h0 += 6) {
+          float4 v[6];
+#pragma unroll
+          for (int u = 0; u < 6; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)min(h0 + u, S - 1) * hs);
+#pragma unroll
+          for (int u = 0; u < 6; ++u) {
+            const int h = h0 + u;
+            const bool ok = s_in && h < S;
+            const float4 z = make_float4(ok ? v[u].x : 0.f, ok ? v[u].y : 0.f, ok ? v[u].z : 0.f, ok ? v[u].w : 0.f);
+            if (h <= S) *reinterpret_cast<float4*>(img + (size_t)h * rowlen + (size_t)e0 * 4) = z;
+          }
         }
       }
-      const float* dsrc = d + (size_t)r * S * W * ldc_d;
-      for (int i = tid; i < MP * 8; i += 64 * NWV) {       // 8 float4 = 32 channels per position
+#pragma unroll
+      for (int u = 0; u < DSLOTS; ++u) {
+        const int i = tid + u * 64 * NWV;
         const int m = i >> 3, c = (i & 7) * 4;
-        const int go = gtab[m];
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (go >= 0 && c < N) v = *reinterpret_cast<const float4*>(dsrc + go + c);
-        *reinterpret_cast<float4*>(ds + (size_t)m * 36 + c) = v;
+        const bool ok = dgo[u] >= 0;
+        if (i < MP * 8) *reinterpret_cast<float4*>(ds + (size_t)m * 36 + c) = make_float4(ok ? dv[u].x : 0.f, ok ? dv[u].y : 0.f, ok ? dv[u].z : 0.f, ok ? dv[u].w : 0.f);
       }
     }
     __syncthreads();
+    if (!kt_ok[0]) continue;          // (wave-uniform) a wave without a k'-tile only stages: its MFMAs would take matrix-pipe time from the others
+    if constexpr (DH > 1) {
+      // Several filter rows per workgroup, the rows INSIDE the loop over the 16-position blocks: the gradient operand (and the
+      // window-offset table entries) of a block are read once for all DH rows -- 8 + 4 + 4*DH scalar LDS reads per 8*DH MFMAs
+      // (KT = 1, NT = 2) instead of 16 per 8 -- and a frame is staged once per DH rows.  No explicit software pipeline: the four
+      // waves of a SIMD cover each other's LDS latency, and the registers go to the DH accumulator sets.
+      int vlo[DH], vhi[DH], sh[DH];
+      int lo = MP, hi = 0;
+#pragma unroll
+      for (int dd = 0; dd < DH; ++dd) {
+        const int dh = dh0 + dd * dstep;
+        vlo[dd] = max(0, pt - dh) * TW; vhi[dd] = dh < S ? min(S, S + pt - dh) * TW : 0;      // (rows past S: empty range)
+        sh[dd] = (dh - pt) * rowlen;
+        if (vhi[dd] > vlo[dd]) { lo = min(lo, vlo[dd] / 16); hi = max(hi, min(MP / 16, (vhi[dd] + 15) / 16)); }
+      }
+      const int zoff = S * rowlen;
+      const int a_lane = wv * 16 + lr, b_lane = 4 * q * 36 + lr, t_lane = 4 * q;
+      const float* dsl = ds + b_lane;
+      const float* imgl = img + a_lane;
+      // software pipeline inside the wave: the gradient operand / table entries of block mb+1 and the image operand of row dd+1
+      // are requested before the MFMAs of (mb, dd) issue (loads are unconditional -- rows that only meet padding read the zero
+      // row -- so that nothing but the MFMAs sits under a branch)
+      float b_n[4][NT];
+      int tb_n[4];
+      auto load_b = [&](int mb, float (&b)[4][NT], int (&tb)[4]) {
+        const int mbc = min(mb, hi - 1);
+        const float* dp = dsl + mbc * (16 * 36);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          tb[j] = tab[mbc * 16 + t_lane + j];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) b[j][n] = dp[j * 36 + n * 16];
+        }
+      };
+      auto load_a = [&](int mb, int dd, const int (&tb)[4], float (&a)[4][KT]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int m = mb * 16 + t_lane + j;
+          const int off = (m >= vlo[dd] && m < vhi[dd]) ? tb[j] + sh[dd] : zoff;
+#pragma unroll
+          for (int i = 0; i < KT; ++i) a[j][i] = imgl[off + (kt_ok[i] ? i * NWV * 16 : 0)];
+        }
+      };
+      load_b(lo, b_n, tb_n);
+      for (int mb = lo; mb < hi; ++mb) {
+        float b[4][NT], a_n[4][KT];
+        int tb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          tb[j] = tb_n[j];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) b[j][n] = b_n[j][n];
+        }
+        load_a(mb, 0, tb, a_n);
+        load_b(mb + 1, b_n, tb_n);
+#pragma unroll
+        for (int dd = 0; dd < DH; ++dd) {
+          float a[4][KT];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < KT; ++i) a[j][i] = a_n[j][i];
+          if (dd + 1 < DH) load_a(mb, dd + 1, tb, a_n);
+          __builtin_amdgcn_sched_barrier(0);
+          if (mb * 16 >= vhi[dd] || mb * 16 + 16 <= vlo[dd]) continue;           // (uniform) the block only meets padding rows of this filter row
+#pragma unroll
+          for (int i = 0; i < KT; ++i) {
+            if (!kt_ok[i]) continue;                                                // (wave-uniform)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int n = 0; n < NT; ++n) acc[dd][i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][i], b[j][n], acc[dd][i][n], 0, 0, 0);
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int dd = 0; dd < DH; ++dd) {
-      const int dh = dh0 + dd;
+      const int dh = dh0 + dd * dstep;
       if (dh >= S) break;
       // positions whose patch row dh is not padding: [vlo, vhi) -> blocks [mb_lo, nmb); the rest would add zeros
       const int vlo = max(0, pt - dh) * TW, vhi = min(S, S + pt - dh) * TW;
@@ -236,7 +335,7 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict
       int off_n[4];
       float a_c[4][KT], b_c[4][NT], a_n[4][KT], b_n[4][NT];
       const int shift = (dh - pt) * rowlen, zoff = S * rowlen;
-      const int a_lane = wv * KT * 16 + lr, b_lane = 4 * q * 36 + lr, t_lane = 4 * q;
+      const int a_lane = wv * 16 + lr, b_lane = 4 * q * 36 + lr, t_lane = 4 * q;
       const float* dsl = ds + b_lane;
       const float* imgl = img + a_lane;
       auto load_off = [&](int mb, int (&off)[4]) {
@@ -255,7 +354,7 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict
 #pragma unroll
           for (int n = 0; n < NT; ++n) b[j][n] = dp[j * 36 + n * 16];
 #pragma unroll
-          for (int i = 0; i < KT; ++i) a[j][i] = kt_ok[i] ? imgl[off[j] + i * 16] : 0.f;
+          for (int i = 0; i < KT; ++i) a[j][i] = kt_ok[i] ? imgl[off[j] + i * NWV * 16] : 0.f;
         }
       };
       auto mma = [&](const float (&a)[4][KT], const float (&b)[4][NT]) {
@@ -284,16 +383,17 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict
         }
       }
     }
+    }   // (rows-outside form)
   }
   // partial tiles -> part[((grp*nstrips + strip)*S + dh)][k'][32]
 #pragma unroll
   for (int dd = 0; dd < DH; ++dd) {
-    const int dh = dh0 + dd;
+    const int dh = dh0 + dd * dstep;
     if (dh >= S) break;
     float* po = part + ((size_t)(grp * gridDim.z + strip) * S + dh) * (size_t)KP * 32;
 #pragma unroll
     for (int i = 0; i < KT; ++i) {
-      const int kt = wv * KT + i;
+      const int kt = wv + NWV * i;
       if (kt * 16 >= KP) continue;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -377,9 +477,29 @@ static int wgrad_tw(int S, int W) {          // narrower strips than the forward
   const int ns = (W + 31) / 32;
   return (W + ns - 1) / ns;
 }
-static void wgrad_plan(int R, int S, int nstrips, int& DH, int& fpg, int& groups) {
+static int g_wgrad_dhmax = -1;        // RSRGAN_WGRAD_DH: most filter rows per workgroup for multi-strip frames (3 = round 2's form)
+static void wgrad_plan(int R, int S, int nstrips, int KP, int& DH, int& fpg, int& groups) {
+  if (g_wgrad_dhmax < 0) { const char* e = getenv("RSRGAN_WGRAD_DH"); g_wgrad_dhmax = e ? atoi(e) : 6; }
   int best = 1 << 30;
   DH = 1; fpg = R; groups = 1;
+  // multi-strip frames with one k'-tile per wave (K' <= 256): 4 or 6 rows per workgroup in the rows-inside form (its accumulators
+  // fit the 128 registers of a 16-wave workgroup); the measure is the LDS operand reads + staged frames per MFMA
+  if (nstrips > 1 && KP > 16 * 16 && g_wgrad_dhmax >= 3) {        // two k'-tile rounds: 3 rows (accumulators: 3 x 2 x NT tiles)
+    const int ng = (S + 2) / 3, gmax = std::max(1, 256 / (ng * nstrips));
+    DH = 3; fpg = std::max(1, (R + gmax - 1) / gmax); groups = (R + fpg - 1) / fpg;
+    return;
+  }
+  if (nstrips > 1 && KP <= 16 * 16 && g_wgrad_dhmax > 3) {
+    for (int dhc : {6, 4}) {
+      if (dhc > g_wgrad_dhmax) continue;
+      const int ng = (S + dhc - 1) / dhc;
+      if (ng * dhc - S >= dhc / 2 + 1) continue;                  // (too many empty rows in the last group)
+      const int gmax = std::max(1, 256 / (ng * nstrips));
+      const int f = std::max(1, (R + gmax - 1) / gmax);
+      DH = dhc; fpg = f; groups = (R + f - 1) / f;
+      return;
+    }
+  }
   // measured: with one strip per frame (W = 40) one filter row per workgroup is faster (4.20 vs 4.39 ms/step) although it stages
   // three times as many frames; with 9 strips (W = 257) three rows per workgroup win (26.2 vs 28.0 ms/step)
   for (int dhc = 1; dhc <= (nstrips > 1 ? 3 : 1); ++dhc) {
@@ -392,7 +512,7 @@ static void wgrad_plan(int R, int S, int nstrips, int& DH, int& fpg, int& groups
 size_t conv_wgrad_ws_floats(int C, int R, int S, int W, int fw) {
   const int TW = wgrad_tw(S, W), nstrips = (W + TW - 1) / TW;
   int DH, fpg, groups;
-  wgrad_plan(R, S, nstrips, DH, fpg, groups);
+  wgrad_plan(R, S, nstrips, conv_kp(fw, C), DH, fpg, groups);
   return (size_t)groups * nstrips * S * conv_kp(fw, C) * 32;
 }
 bool conv_wgrad_supported(int C, int N, int S, int W, int fw) {
@@ -400,7 +520,7 @@ bool conv_wgrad_supported(int C, int N, int S, int W, int fw) {
   const int TW = wgrad_tw(S, W);
   const int MP = (S * TW + 15) / 16 * 16;
   const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 38) * sizeof(float);
-  return lds <= 160 * 1024 && conv_kp(fw, C) <= 16 * 2 * 16 && ((TW + fw - 1) * conv_cpad(C) + 16) / 4 <= 512 && (TW + fw) * conv_cpad(C) < (1 << 20);
+  return lds <= 160 * 1024 && MP * 8 <= 4 * 1024 && conv_kp(fw, C) <= 16 * 2 * 16 && ((TW + fw - 1) * conv_cpad(C) + 16) / 4 <= 512 && (TW + fw) * conv_cpad(C) < (1 << 20);
 }
 template <int KT, int NT>
 static void wgrad_launch_dh(int DH, dim3 grid, size_t lds, hipStream_t s, const float* in, int ldc_in, int C, const float* d, int ldc_d, int N,
@@ -410,18 +530,26 @@ static void wgrad_launch_dh(int DH, dim3 grid, size_t lds, hipStream_t s, const 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<KT, NT, 16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<KT, NT, 16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<KT, NT, 16, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (KT == 1) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<KT, NT, 16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<KT, NT, 16, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     attr = true;
   }
   if (DH == 1) hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 1>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
   else if (DH == 2) hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 2>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
-  else hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 3>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  else if (DH == 3) hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 3>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  else if constexpr (KT == 1) {
+    if (DH == 4) hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 4>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+    else hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 6>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  }
 }
 void launch_conv_wgrad(const float* in, int ldc_in, int C, const float* d, int ldc_d, int N, float* dW, int ldw, float* ws, int R, int S,
                        int W, int fw, hipStream_t s) {
   const int TW = wgrad_tw(S, W), nstrips = (W + TW - 1) / TW;
   int DH, fpg, groups;
-  wgrad_plan(R, S, nstrips, DH, fpg, groups);
   const int MP = (S * TW + 15) / 16 * 16, KP = conv_kp(fw, C);
+  wgrad_plan(R, S, nstrips, KP, DH, fpg, groups);
   const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 38) * sizeof(float);
   dim3 grid((S + DH - 1) / DH, groups, nstrips);
   const bool k2 = KP > 16 * 16, n1 = N <= 16;          // 16 waves: one k'-tile per wave up to K' = 256, two beyond
