@@ -45,7 +45,7 @@ __global__ void k_conv_prep(const float* __restrict__ F, int ldf_src, int S, int
 template <int RT, int NT>
 __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, int ldc_in, int C, const float* __restrict__ Ft,
                                                   const float* __restrict__ bias, int relu, float* __restrict__ out, int ldc_out, int N,
-                                                  int S, int W, int fw, int TW) {
+                                                  int S, int W, int fw, int TW, const float* __restrict__ mask) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Cp = conv_cpad(C), nkb = conv_kp(fw, C) / 16, ldf = conv_ldf(fw, C);
   const int pt = (S - 1) / 2, pl = (fw - 1) / 2;
@@ -88,14 +88,35 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // The filter slice of row dh+1 travels to registers while row dh is multiplied (<= 5 float4 per thread: 32 x ldf <= 32 x 280
+  // floats over 512 threads; checked on the host): staging it synchronously between two barriers cost ~2 us of each of the S rows,
+  // 17 % of the kernel at S = 11 (SQ_VALU_MFMA_BUSY_CYCLES 69 % of the CU-cycles, profiles/r3_rced_pmc.txt).
+  constexpr int FSL = 5;
+  const int n4 = NT * 16 * ldf / 4;
+  // (named scalars: hipcc leaves a float4 array that lives across the row loop in scratch memory)
+  static_assert(FSL == 5, "five named slots below");
+  const int fi0 = min(tid, n4 - 1), fi1 = min(tid + 512, n4 - 1), fi2 = min(tid + 1024, n4 - 1), fi3 = min(tid + 1536, n4 - 1),
+            fi4 = min(tid + 2048, n4 - 1);
+  float4 fr0, fr1, fr2, fr3, fr4;
+  {
+    const float4* src = reinterpret_cast<const float4*>(Ft);
+    fr0 = src[fi0]; fr1 = src[fi1]; fr2 = src[fi2]; fr3 = src[fi3]; fr4 = src[fi4];
+  }
   for (int dh = 0; dh < S; ++dh) {
     __syncthreads();                                      // image ready (first pass) / previous filter slice consumed
     {
-      const float4* src = reinterpret_cast<const float4*>(Ft + (size_t)dh * 32 * ldf);
       float4* dst = reinterpret_cast<float4*>(fts);
-      for (int i = tid; i < NT * 16 * ldf / 4; i += 512) dst[i] = src[i];
+      if (tid < n4) dst[tid] = fr0;
+      if (tid + 512 < n4) dst[tid + 512] = fr1;
+      if (tid + 1024 < n4) dst[tid + 1024] = fr2;
+      if (tid + 1536 < n4) dst[tid + 1536] = fr3;
+      if (tid + 2048 < n4) dst[tid + 2048] = fr4;
     }
     __syncthreads();
+    {
+      const float4* src = reinterpret_cast<const float4*>(Ft + (size_t)min(dh + 1, S - 1) * 32 * ldf);      // (the last row re-reads itself)
+      fr0 = src[fi0]; fr1 = src[fi1]; fr2 = src[fi2]; fr3 = src[fi3]; fr4 = src[fi4];
+    }
     // image rows h with 0 <= h + dh - pt < S take part in this filter row: positions [vlo, vhi) of the strip; a 16-position tile
     // outside that range only multiplies the zero row -- skipped (wave-uniform: 25 % of the MFMAs at S = 11)
     const int vlo = max(0, pt - dh) * TW, vhi = min(S, S + pt - dh) * TW;
@@ -110,6 +131,8 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
     }
     const float* b0 = fts + (size_t)lr * ldf + 4 * q;
     const float* b1 = b0 + (size_t)16 * ldf;
+    // (fragments stay single 16-byte reads although their odd row strides collide on half of the LDS cycles: two conflict-free
+    // 8-byte reads per fragment measured 629 vs 608 ms per step of the R-CED variant -- the loop is instruction-, not LDS-bound)
     for (int kb = 0; kb < nkb; ++kb) {
       float4 bv[NT];
       bv[0] = *reinterpret_cast<const float4*>(b0 + kb * 16);
@@ -144,7 +167,9 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
         if (m >= M || wl >= tw) continue;
         float v = acc[i][j][e] + bv;
         if (relu) v = fmaxf(v, 0.f);
-        out[((size_t)(r * S + h) * W + w0 + wl) * ldc_out + co] = v;
+        const size_t oi = ((size_t)(r * S + h) * W + w0 + wl) * ldc_out + co;
+        if (mask && !(mask[oi] > 0.f)) v = 0.f;       // data gradient: relu' of the layer below, its activations laid out like `out`
+        out[oi] = v;
       }
     }
 }
@@ -445,12 +470,13 @@ static bool conv_fwd_plan(int C, int S, int W, int fw, int& TW, int& RT, size_t&
 // true if the implicit kernel covers this shape (else the caller uses the patch-matrix path)
 bool conv_fwd_supported(int C, int N, int S, int W, int fw) {
   if ((C % 4 && C != 1) || N > 32 || !(S & 1) || !(fw & 1)) return false;      // C == 1: the caller pads the input to [positions][4]
+  if (32 * conv_ldf(fw, C) / 4 > 5 * 512) return false;                          // k_conv_fwd keeps a filter slice in 5 float4 per thread
   int TW, RT; size_t lds;
   return conv_fwd_plan(C, S, W, fw, TW, RT, lds);
 }
 
 void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const float* bias, bool relu, float* out, int ldc_out, int N,
-                     int R, int S, int W, int fw, hipStream_t s) {
+                     int R, int S, int W, int fw, hipStream_t s, const float* mask) {
   int TW = W, RT = 4; size_t lds = 0;
   if (!conv_fwd_plan(C, S, W, fw, TW, RT, lds)) return;
   const bool small = RT == 4;
@@ -464,10 +490,10 @@ void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const 
   }
   dim3 grid((W + TW - 1) / TW, R);
   const int rl = relu ? 1 : 0;
-  if (small && N <= 16) hipLaunchKernelGGL((k_conv_fwd<4, 1>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW);
-  else if (small) hipLaunchKernelGGL((k_conv_fwd<4, 2>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW);
-  else if (N <= 16) hipLaunchKernelGGL((k_conv_fwd<6, 1>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW);
-  else hipLaunchKernelGGL((k_conv_fwd<6, 2>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW);
+  if (small && N <= 16) hipLaunchKernelGGL((k_conv_fwd<4, 1>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask);
+  else if (small) hipLaunchKernelGGL((k_conv_fwd<4, 2>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask);
+  else if (N <= 16) hipLaunchKernelGGL((k_conv_fwd<6, 1>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask);
+  else hipLaunchKernelGGL((k_conv_fwd<6, 2>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask);
 }
 
 // Grid of the weight-gradient kernel: ceil(S / DH) filter-row groups x frame groups x strips, at most 256 workgroups (one round

@@ -117,13 +117,15 @@ void Model::rced_backward(int rows, float* dy, hipStream_t s) {
   float* d = rc_dA;
   float* other = rc_dB;
   gemm(dy, ldDout, true, G.W(rc_fc.tW), ldDout, true, d, rc_fc.ld_in, rows, rc_fc.in, Dout, nullptr, 0, 0.f, false, s);   // = [M][Cout_last]
+  bool d_masked = false;                     // relu' of this layer already applied by the data-gradient kernel of the layer above
   for (int l = Lc - 1; l >= 0; --l) {
     const ConvLayer& L = gconv[l];
     if (L.bn)
       launch_bn_backward(d, L.ldCout, rc_act[l + 1], L.ldCout, L.pre, L.ldCout, (int)M, L.Cout, L.stat, L.ldCout, G.Gd(L.tbn[0]), G.Gd(L.tbn[1]),
                          false, true, bn_sums, scratch, scratch_floats, s);
-    else
+    else if (!d_masked)
       launch_lrelu_bwd(rc_act[l + 1], d, M, L.Cout, L.ldCout, 0.f, s);                    // relu': d *= [a > 0]
+    d_masked = false;
     if (rc_wgrad_implicit[l] && rc_wg_ws) {
       launch_conv_wgrad(l == 0 ? rc_x4 : rc_act[l], l == 0 ? 4 : L.ldCin, L.Cin, d, L.ldCout, L.Cout, G.Gd(L.tW), L.ldCout, rc_wg_ws, rows,
                         rcS, rcW, L.fw, s);
@@ -136,7 +138,10 @@ void Model::rced_backward(int rows, float* dy, hipStream_t s) {
     if (!L.bn) launch_colsum_tall(d, L.ldCout, G.Gd(L.tb), (int)M, L.Cout, scratch, scratch_floats, s);
     if (l > 0) {
       if (rc_ft_bwd[l]) {                        // d(in) = conv_SAME(d, flipped filter): the same implicit-GEMM kernel
-        launch_conv_fwd(d, L.ldCout, L.Cout, rc_ft_bwd[l], nullptr, false, other, L.ldCin, L.Cin, rows, rcS, rcW, L.fw, s);
+        // (the layer below's relu' rides the epilogue: its activations rc_act[l] share the layout of d(in))
+        d_masked = !gconv[l - 1].bn;
+        launch_conv_fwd(d, L.ldCout, L.Cout, rc_ft_bwd[l], nullptr, false, other, L.ldCin, L.Cin, rows, rcS, rcW, L.fw, s,
+                        d_masked ? rc_act[l] : nullptr);
       } else {
         gemm(d, L.ldCout, true, G.W(L.tW), L.ldCout, true, rc_dcol, L.ldK, (int)M, L.K, L.Cout, nullptr, 0, 0.f, false, s);
         launch_col2im(rc_dcol, L.ldK, L.Cin, rcS, rcW, rcS, L.fw, other, L.ldCin, M, s);

@@ -204,7 +204,8 @@ size_t conv_prep_floats(int S, int fw, int C);
 void launch_conv_prep(const float* F, int ldf_src, int S, int fw, int Cin, int Cout, bool flip, float* Ft, hipStream_t s);
 bool conv_fwd_supported(int C, int N, int S, int W, int fw);
 void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const float* bias, bool relu, float* out, int ldc_out, int N,
-                     int R, int S, int W, int fw, hipStream_t s);
+                     int R, int S, int W, int fw, hipStream_t s,
+                     const float* mask = nullptr /* [positions][ldc_out]: out = 0 where mask <= 0 (relu' fused into the data gradient) */);
 bool conv_wgrad_supported(int C, int N, int S, int W, int fw);
 size_t conv_wgrad_ws_floats(int C, int R, int S, int W, int fw);
 void launch_conv_wgrad(const float* in, int ldc_in, int C, const float* d, int ldc_d, int N, float* dW, int ldw, float* ws, int R, int S,
