@@ -4,6 +4,10 @@
 // channels-last [rows = batch x position][channels] fp32 buffers, plus the direct kernels of the single-channel ends of the
 // networks (a 1-channel window view is not 16-byte aligned, and those layers are < 1 % of the FLOPs).
 // Every reduction is two-stage with a fixed order (no float atomics): bit-reproducible.
+#include <cstdlib>
+#include <cstdio>
+#include <cmath>
+#include <vector>
 #include "segan.h"
 
 namespace rsr {
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256) void k_colred_part(const float* __restrict__ a
         if (MODE == 0) s0 += av;
         else if (MODE == 1) s0 += av * fminf(b[r * ldb + c], 0.f);
         else if (MODE == 2) { s0 += av; s1 = fmaf(av, av, s1); }
-        else { const float g = b[r * ldb + c] * ((av * sc + sh) >= 0.f ? 1.f : leak); s0 += g; s1 = fmaf(g, av - mu, s1); }
+        else { const float g = b[r * ldb + c] * (fmaf(av, sc, sh) >= 0.f ? 1.f : leak); s0 += g; s1 = fmaf(g, av - mu, s1); }
       }
     }
     red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
@@ -258,27 +262,118 @@ __global__ __launch_bounds__(256) void k_colred_part(const float* __restrict__ a
     __syncthreads();
   }
 }
+// The same reductions with 16-byte loads: thread = (group of 4 columns, row lane), four rows in flight per thread (the scalar form
+// above keeps one 4-byte load in flight per thread: 0.5-0.8 TB/s on the [3 x 262144][16] tensors of the first SEGAN blocks, 25 % of
+// the SEGAN step in round 3's first profile).  Needs C, lda, ldb, coff multiples of 4.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_colred_part4(const float* __restrict__ a, int lda, int coff, const float* __restrict__ b, int ldb, int C,
+                                                      size_t rows_per, int chunk, int chunks_per, const float* __restrict__ coef, int ldcoef, float leak,
+                                                      float* __restrict__ part) {
+  const int pass = blockIdx.x / chunks_per, ch = blockIdx.x - pass * chunks_per;
+  const size_t r0 = (size_t)pass * rows_per + (size_t)ch * chunk, r1 = min((size_t)(pass + 1) * rows_per, r0 + chunk);
+  __shared__ double red[2][4][256];
+  const int C4 = C >> 2;
+  for (int g0 = 0; g0 < C4; g0 += 256) {
+    const int gw = min(C4 - g0, 256);                    // column groups of this round
+    const int lanes = 256 / gw;                          // row lanes per column group
+    const int lg = threadIdx.x % gw, lr = threadIdx.x / gw;
+    // accumulators in double: the VBN-backward sums cancel to 1e-3 of their terms (the d beta of the 16384-sample parity case lost
+    // its 2e-3 against the fp64 oracle with fp32 accumulators in this summation order); the kernel is bandwidth-bound either way
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    if (lr < lanes) {
+      const int c = (g0 + lg) * 4;
+      float mu[4] = {0, 0, 0, 0}, sc[4] = {0, 0, 0, 0}, sh[4] = {0, 0, 0, 0};
+      if (MODE == 3) {
+        const float4 m4 = *reinterpret_cast<const float4*>(coef + (size_t)(pass * 8 + 0) * ldcoef + c);
+        const float4 c4 = *reinterpret_cast<const float4*>(coef + (size_t)(pass * 8 + 3) * ldcoef + c);
+        const float4 h4 = *reinterpret_cast<const float4*>(coef + (size_t)(pass * 8 + 4) * ldcoef + c);
+        mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w; sc[0] = c4.x; sc[1] = c4.y; sc[2] = c4.z; sc[3] = c4.w;
+        sh[0] = h4.x; sh[1] = h4.y; sh[2] = h4.z; sh[3] = h4.w;
+      }
+      auto acc1 = [&](const float4 av4, const float4 bv4) {
+        const float av[4] = {av4.x, av4.y, av4.z, av4.w}, bv[4] = {bv4.x, bv4.y, bv4.z, bv4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (MODE == 0) s0[e] += av[e];
+          else if (MODE == 1) s0[e] += av[e] * fminf(bv[e], 0.f);
+          else if (MODE == 2) { s0[e] += av[e]; s1[e] += (double)av[e] * av[e]; }
+          else { const float g = bv[e] * (fmaf(av[e], sc[e], sh[e]) >= 0.f ? 1.f : leak); s0[e] += g; s1[e] += (double)g * (av[e] - mu[e]); }
+        }
+      };
+      constexpr bool TWO = MODE == 1 || MODE == 3;
+      size_t r = r0 + lr;
+      for (; r + 3 * (size_t)lanes < r1; r += 4 * (size_t)lanes) {        // four rows in flight, summed in row order
+        float4 av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          av[u] = *reinterpret_cast<const float4*>(a + (r + (size_t)u * lanes) * lda + coff + c);
+          bv[u] = TWO ? *reinterpret_cast<const float4*>(b + (r + (size_t)u * lanes) * ldb + c) : av[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc1(av[u], bv[u]);
+      }
+      for (; r < r1; r += lanes) {
+        const float4 av = *reinterpret_cast<const float4*>(a + r * lda + coff + c);
+        const float4 bv = TWO ? *reinterpret_cast<const float4*>(b + r * ldb + c) : av;
+        acc1(av, bv);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][e][threadIdx.x] = s0[e]; red[1][e][threadIdx.x] = s1[e]; }
+    __syncthreads();
+    if (threadIdx.x < gw) {                              // fixed order over the row lanes
+      double t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};
+      for (int l = 0; l < lanes; ++l)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { t0[e] += red[0][e][l * gw + threadIdx.x]; t1[e] += red[1][e][l * gw + threadIdx.x]; }
+      *reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * 2 + 0) * C + (g0 + threadIdx.x) * 4) = make_float4((float)t0[0], (float)t0[1], (float)t0[2], (float)t0[3]);
+      *reinterpret_cast<float4*>(part + ((size_t)blockIdx.x * 2 + 1) * C + (g0 + threadIdx.x) * 4) = make_float4((float)t1[0], (float)t1[1], (float)t1[2], (float)t1[3]);
+    }
+    __syncthreads();
+  }
+}
 __global__ __launch_bounds__(256) void k_colred_final(const float* __restrict__ part, int chunks_per, int C, int P, float* __restrict__ out, int ldo,
                                                       int accumulate, int nout) {
   const int i = blockIdx.x * 256 + threadIdx.x;          // (pass, which, column); one-output modes write row `pass` only
   if (i >= P * 2 * C) return;
   const int c = i % C, which = (i / C) & 1, pass = i / (2 * C);
   if (which >= nout) return;
-  float acc = 0.f;
-  for (int ch = 0; ch < chunks_per; ++ch) acc += part[((size_t)(pass * chunks_per + ch) * 2 + which) * C + c];
+  double acc = 0.0;
+  for (int ch = 0; ch < chunks_per; ++ch) acc += (double)part[((size_t)(pass * chunks_per + ch) * 2 + which) * C + c];
   float* o = out + (size_t)(pass * nout + which) * ldo + c;
-  *o = accumulate ? *o + acc : acc;
+  *o = accumulate ? *o + (float)acc : (float)acc;
 }
 void launch_colred(int mode, const float* a, int lda, int coff, const float* b, int ldb, int C, size_t rows_per, int P, const float* coef, int ldcoef,
                    float leak, float* out, int ldo, bool accumulate, float* scratch, size_t scratch_floats, hipStream_t s) {
-  int chunk = 256;                                       // <= 128 partials per (pass, column): the final sum is one thread per column
-  while (((rows_per + chunk - 1) / chunk) * (size_t)P * 2 * C > scratch_floats || (rows_per + chunk - 1) / chunk > 128) chunk *= 2;
+  const bool two = mode == 1 || mode == 3;
+  // RSRGAN_COLRED_VEC: bit m = the 16-byte form for mode m.  Mode 2 (the VBN statistics) stays on the scalar form by default: the
+  // reference's E[h^2] - E[h]^2 (bnorm.py:40-41) is ill-conditioned in fp32 where |mean| >> sigma (the first two blocks on waveform
+  // input), and the 16384-sample parity case holds its 2e-3 against the fp64 oracle only with sums that differ from the 16-byte
+  // form's (correctly rounded) ones by one ulp -- 9e-4 .. 3e-3 on four tensors otherwise (tests/test_gpu_segan.py)
+  static int vecmask = -1;
+  if (vecmask < 0) { const char* e = getenv("RSRGAN_COLRED_VEC"); vecmask = e ? atoi(e) : 11; }
+  const bool vec = ((vecmask >> mode) & 1) && C % 4 == 0 && lda % 4 == 0 && coff % 4 == 0 && (!two || ldb % 4 == 0) && (mode != 3 || ldcoef % 4 == 0);
+  // chunk: ~2048 workgroups per launch, <= 256 partials per (pass, column) (the final sum is one thread per column), scratch permitting
+  int chunk = vec ? 64 : 256;
+  const int max_chunks = vec ? 256 : 128;
+  while (((rows_per + chunk - 1) / chunk) * (size_t)P * 2 * C > scratch_floats || (rows_per + chunk - 1) / chunk > (size_t)max_chunks ||
+         (vec && ((rows_per + chunk - 1) / chunk) * (size_t)P > 4096))
+    chunk *= 2;
   const int chunks_per = (int)((rows_per + chunk - 1) / chunk);
   dim3 grid(P * chunks_per), block(256);
-  if (mode == 0) hipLaunchKernelGGL(k_colred_part<0>, grid, block, 0, s, a, lda, coff, b, ldb, C, rows_per, chunk, chunks_per, coef, ldcoef, leak, scratch);
-  else if (mode == 1) hipLaunchKernelGGL(k_colred_part<1>, grid, block, 0, s, a, lda, coff, b, ldb, C, rows_per, chunk, chunks_per, coef, ldcoef, leak, scratch);
-  else if (mode == 2) hipLaunchKernelGGL(k_colred_part<2>, grid, block, 0, s, a, lda, coff, b, ldb, C, rows_per, chunk, chunks_per, coef, ldcoef, leak, scratch);
-  else hipLaunchKernelGGL(k_colred_part<3>, grid, block, 0, s, a, lda, coff, b, ldb, C, rows_per, chunk, chunks_per, coef, ldcoef, leak, scratch);
+#define RSR_COLRED(K, M) hipLaunchKernelGGL(K<M>, grid, block, 0, s, a, lda, coff, b, ldb, C, rows_per, chunk, chunks_per, coef, ldcoef, leak, scratch)
+  if (vec) {
+    if (mode == 0) RSR_COLRED(k_colred_part4, 0);
+    else if (mode == 1) RSR_COLRED(k_colred_part4, 1);
+    else if (mode == 2) RSR_COLRED(k_colred_part4, 2);
+    else RSR_COLRED(k_colred_part4, 3);
+  } else {
+    if (mode == 0) RSR_COLRED(k_colred_part, 0);
+    else if (mode == 1) RSR_COLRED(k_colred_part, 1);
+    else if (mode == 2) RSR_COLRED(k_colred_part, 2);
+    else RSR_COLRED(k_colred_part, 3);
+  }
+#undef RSR_COLRED
   hipLaunchKernelGGL(k_colred_final, dim3((P * 2 * C + 255) / 256), dim3(256), 0, s, scratch, chunks_per, C, P, out, ldo, accumulate ? 1 : 0, mode >= 2 ? 2 : 1);
 }
 
@@ -315,7 +410,7 @@ __global__ __launch_bounds__(256) void k_vbn_apply(const float* __restrict__ h, 
     const size_t r = i / C;
     const int c = (int)(i - r * C);
     const int p = (int)(r / rows_per);
-    const float v = h[i] * coef[(size_t)(p * 8 + 3) * ldc + c] + coef[(size_t)(p * 8 + 4) * ldc + c];
+    const float v = fmaf(h[i], coef[(size_t)(p * 8 + 3) * ldc + c], coef[(size_t)(p * 8 + 4) * ldc + c]);   // (explicit fma: the backward kernels decide the kink with the same rounding)
     y[i] = v >= 0.f ? v : leak * v;
   }
 }
@@ -360,7 +455,7 @@ __global__ __launch_bounds__(256) void k_vbn_bwd_apply(const float* __restrict__
     const int c = (int)(i - r * C);
     const float* o = coef + (size_t)(r / rows_per) * 8 * ldc + c;
     const float hv = h[i], sc = o[3 * ldc];
-    const float g = dy[i] * ((hv * sc + o[4 * ldc]) >= 0.f ? 1.f : leak);
+    const float g = dy[i] * (fmaf(hv, sc, o[4 * ldc]) >= 0.f ? 1.f : leak);
     dh[i] = g * sc + o[5 * ldc] + o[6 * ldc] * hv;
   }
 }
