@@ -242,13 +242,23 @@ __global__ __launch_bounds__(256) void k_colred_part(const float* __restrict__ a
       const int c = c0 + lc;
       float mu = 0.f, sc = 0.f, sh = 0.f;
       if (MODE == 3) { mu = coef[(size_t)(pass * 8 + 0) * ldcoef + c]; sc = coef[(size_t)(pass * 8 + 3) * ldcoef + c]; sh = coef[(size_t)(pass * 8 + 4) * ldcoef + c]; }
-      for (size_t r = r0 + lr; r < r1; r += (cw == 256 ? 1 : lanes)) {
-        const float av = a[r * lda + coff + c];
+      const size_t step = cw == 256 ? 1 : lanes;
+      auto acc1 = [&](float av, float bv) {
         if (MODE == 0) s0 += av;
-        else if (MODE == 1) s0 += av * fminf(b[r * ldb + c], 0.f);
+        else if (MODE == 1) s0 += av * fminf(bv, 0.f);
         else if (MODE == 2) { s0 += av; s1 = fmaf(av, av, s1); }
-        else { const float g = b[r * ldb + c] * (fmaf(av, sc, sh) >= 0.f ? 1.f : leak); s0 += g; s1 = fmaf(g, av - mu, s1); }
+        else { const float g = bv * (fmaf(av, sc, sh) >= 0.f ? 1.f : leak); s0 += g; s1 = fmaf(g, av - mu, s1); }
+      };
+      constexpr bool TWO = MODE == 1 || MODE == 3;
+      size_t r = r0 + lr;
+      for (; r + 7 * step < r1; r += 8 * step) {           // eight rows in flight, accumulated in row order (same bits as one at a time)
+        float av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { av[u] = a[(r + u * step) * lda + coff + c]; bv[u] = TWO ? b[(r + u * step) * ldb + c] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc1(av[u], bv[u]);
       }
+      for (; r < r1; r += step) acc1(a[r * lda + coff + c], TWO ? b[r * ldb + c] : 0.f);
     }
     red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
     __syncthreads();
@@ -332,16 +342,27 @@ __global__ __launch_bounds__(256) void k_colred_part4(const float* __restrict__ 
     __syncthreads();
   }
 }
+// out[(pass, which)][c] (+)= sum over the chunks, in double and in a fixed order: 32 outputs per workgroup, 8 chunk lanes each
+// (one thread per output walked up to 256 dependent loads: 25 us per call, 2.5 ms of the SEGAN step)
 __global__ __launch_bounds__(256) void k_colred_final(const float* __restrict__ part, int chunks_per, int C, int P, float* __restrict__ out, int ldo,
                                                       int accumulate, int nout) {
-  const int i = blockIdx.x * 256 + threadIdx.x;          // (pass, which, column); one-output modes write row `pass` only
-  if (i >= P * 2 * C) return;
-  const int c = i % C, which = (i / C) & 1, pass = i / (2 * C);
-  if (which >= nout) return;
+  __shared__ double red[8][32];
+  const int o = threadIdx.x & 31, l = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + o;                     // (pass, which, column); one-output modes write row `pass` only
+  const bool in = i < P * 2 * C;
+  const int c = in ? i % C : 0, which = in ? (i / C) & 1 : 0, pass = in ? i / (2 * C) : 0;
   double acc = 0.0;
-  for (int ch = 0; ch < chunks_per; ++ch) acc += (double)part[((size_t)(pass * chunks_per + ch) * 2 + which) * C + c];
-  float* o = out + (size_t)(pass * nout + which) * ldo + c;
-  *o = accumulate ? *o + (float)acc : (float)acc;
+  if (in && which < nout)
+    for (int ch = l; ch < chunks_per; ch += 8) acc += (double)part[((size_t)(pass * chunks_per + ch) * 2 + which) * C + c];
+  red[l][o] = acc;
+  __syncthreads();
+  if (l == 0 && in && which < nout) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][o];
+    float* op = out + (size_t)(pass * nout + which) * ldo + c;
+    *op = accumulate ? *op + (float)t : (float)t;
+  }
 }
 void launch_colred(int mode, const float* a, int lda, int coff, const float* b, int ldb, int C, size_t rows_per, int P, const float* coef, int ldcoef,
                    float leak, float* out, int ldo, bool accumulate, float* scratch, size_t scratch_floats, hipStream_t s) {
@@ -374,7 +395,7 @@ void launch_colred(int mode, const float* a, int lda, int coff, const float* b, 
     else RSR_COLRED(k_colred_part, 3);
   }
 #undef RSR_COLRED
-  hipLaunchKernelGGL(k_colred_final, dim3((P * 2 * C + 255) / 256), dim3(256), 0, s, scratch, chunks_per, C, P, out, ldo, accumulate ? 1 : 0, mode >= 2 ? 2 : 1);
+  hipLaunchKernelGGL(k_colred_final, dim3((P * 2 * C + 31) / 32), dim3(256), 0, s, scratch, chunks_per, C, P, out, ldo, accumulate ? 1 : 0, mode >= 2 ? 2 : 1);
 }
 
 // ---- virtual batch norm (utils/bnorm.py).  Pass 0 of a call group is the reference ("dummy") pass; the live passes mix their
