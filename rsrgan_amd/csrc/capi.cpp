@@ -93,8 +93,9 @@ int rsrgan_set_scalar(rsrgan_handle h, int32_t which, double v) {
   CHECK_H(h);
   Model& m = h->m;
   // the copies below are synchronous on the null stream; the step kernels that read these device scalars may still be queued on
-  // the model's own stream, so drain it first (scalars change once per iteration: train_gan_rnn_placeholder.py:63-64,525-533)
-  if (m.main_s && hipStreamSynchronize(m.main_s) != hipSuccess) { set_error("hipStreamSynchronize failed"); return RSRGAN_ERR_HIP; }
+  // ANY stream the caller passed to the step entry points (the Python host runs them on a non-blocking pool stream the null stream
+  // does not order with), so drain the device first (scalars change once per iteration: train_gan_rnn_placeholder.py:63-64,525-533)
+  if (hipDeviceSynchronize() != hipSuccess) { set_error("hipDeviceSynchronize failed"); return RSRGAN_ERR_HIP; }
   int idx = -1;
   switch (which) {
     case RSRGAN_G_LEARNING_RATE: idx = DYN_G_LR; break;

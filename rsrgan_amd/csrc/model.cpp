@@ -203,6 +203,10 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     set_error("RSRGAN_FLAG_BATCH_NORM is built for the frame-level generators (dnn, rced) + discriminator_dnn only");
     return RSRGAN_ERR_INVALID;
   }
+  if (bn_on()) {      // the update ops of a run are ONE launch over a fixed table (kernels.h BnCommitList): refuse what it cannot hold
+    const int nbn = (c.g_type == RSRGAN_G_RCED ? 9 : c.g_layers) + (c.d_type == RSRGAN_D_DNN ? c.d_layers : 0);
+    if (nbn > 24) { set_error("batch norm: %d normalised layers, at most 24 are supported", nbn); return RSRGAN_ERR_INVALID; }
+  }
   // ---- variable tables in graph-construction order (gan_rnn_placeholder.py:301-317) ----
   if (c.g_type == RSRGAN_G_RCED) {                                       // models/rced.py:90-116
     static const int kNum[9] = {12, 16, 20, 24, 32, 24, 20, 16, 12}, kWidth[9] = {13, 11, 9, 7, 7, 7, 9, 11, 13};

@@ -97,3 +97,23 @@ def all_gather_rows(v: torch.Tensor, group=None) -> torch.Tensor:
 def barrier(group=None):
     if is_dist(group):
         dist.barrier(group=group)
+
+
+def run_on_rank0(fn, group=None):
+    """fn() on rank 0 only (one writer: checkpoints, decode output) while the other ranks wait.  The wait is a broadcast of rank 0's
+    status, reached on every path: if fn raises, rank 0 re-raises AFTER telling the others, and they raise too instead of sitting in
+    a barrier until the process-group timeout.  Returns fn's result on rank 0, None elsewhere."""
+    out, err = None, None
+    if rank(group) == 0:
+        try:
+            out = fn()
+        except BaseException as e:          # noqa: BLE001 -- re-raised below, after the other ranks have been released
+            err = e
+    if is_dist(group):
+        status = [None if err is None else "%s: %s" % (type(err).__name__, err)]
+        dist.broadcast_object_list(status, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if err is None and status[0] is not None:
+            raise RuntimeError("rank 0 failed: " + status[0])
+    if err is not None:
+        raise err
+    return out

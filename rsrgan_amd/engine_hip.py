@@ -107,9 +107,11 @@ class HipEngine:
             yield
             return
         self.stream.wait_stream(prev)
-        with torch.cuda.stream(self.stream):
-            yield
-        prev.wait_stream(self.stream)
+        try:
+            with torch.cuda.stream(self.stream):
+                yield
+        finally:                       # also when the block raises: later work on `prev` must still see what was queued here
+            prev.wait_stream(self.stream)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -45,10 +45,11 @@ class Model(object):
             rdist.all_reduce_mean_(self.engine.grad_view(net), self.process_group)
 
     def save(self, save_dir, step):
+        """rank 0 writes; every rank returns once the checkpoint exists (or raises if rank 0 could not write it)"""
         os.makedirs(save_dir, exist_ok=True)
-        if rdist.rank(self.process_group) != 0:
-            rdist.barrier(self.process_group)                      # rank 0 has written the checkpoint when this returns
-            return None
+        return rdist.run_on_rank0(lambda: self._save_rank0(save_dir, step), self.process_group)
+
+    def _save_rank0(self, save_dir, step):
         base = "%s-%d" % (self.name, int(step))
         payload = {}
         for net, tag in ((NET_G, ""), (NET_D, "")):
@@ -78,7 +79,6 @@ class Model(object):
             os.remove(old)
         with open(os.path.join(save_dir, "checkpoint"), "w") as f:
             f.write('model_checkpoint_path: "%s"\n' % base)
-        rdist.barrier(self.process_group)
         return path
 
     def load(self, save_dir, model_file=None, moving_average=False):

@@ -226,9 +226,7 @@ def main(argv=None):
     if world > 1:
         FLAGS.num_gpu = world
     if FLAGS.decode:
-        if rank == 0:
-            decode(FLAGS)
-        rdist.barrier()
+        rdist.run_on_rank0(lambda: decode(FLAGS))                     # one writer; a failure on rank 0 releases (and fails) the others
     else:
         train(FLAGS)
 

@@ -195,9 +195,7 @@ def main(argv=None):
     if world > 1:
         FLAGS.num_gpu = world
     if FLAGS.decode:
-        if rank == 0:                                                      # one writer for <save_dir>/test/feats.{ark,scp}
-            decode(FLAGS)
-        rdist.barrier()
+        rdist.run_on_rank0(lambda: decode(FLAGS))                          # one writer for <save_dir>/test/feats.{ark,scp}; a failure releases the others
     else:
         train(FLAGS)
 

@@ -38,6 +38,18 @@ def _on_stream(model):
     return f() if f is not None else contextlib.nullcontext()
 
 
+def _check_device(model, d, g):
+    """A persistent recurrence launch whose bounded wait expired poisons its losses with NaN (csrc/dpersist.hip): say so instead of
+    handing non-finite numbers to the accept / reject logic of the outer loop."""
+    if np.all(np.isfinite(d)) and np.all(np.isfinite(g)):
+        return
+    status = getattr(getattr(model, "engine", None), "device_status", None)
+    code = status() if status is not None else 0
+    if code:
+        raise RuntimeError("persistent recurrence launch failed on the device: workgroup %d timed out waiting for a peer "
+                           "(rsrgan_device_status; RSRGAN_DPERSIST=0 selects the per-step launches)" % (code - 1))
+
+
 def train_one_iteration(sess, model, tr_num_batch, iteration, train_queue, num_gpu=None, share_g_forward=True):
     with _on_stream(model):          # the whole iteration on the engine's stream: no per-call stream hand-over
         return _train_one_iteration(sess, model, tr_num_batch, iteration, train_queue, num_gpu, share_g_forward)
@@ -94,6 +106,7 @@ def _train_one_iteration(sess, model, tr_num_batch, iteration, train_queue, num_
         g_acc = rdist.all_reduce_mean_(g_acc.clone(), getattr(model, "process_group", None))
     d = (d_acc / max(d_counter, 1)).cpu().numpy() if d_acc is not None else np.zeros(3)
     g = (g_acc / max(g_counter, 1)).cpu().numpy() if g_acc is not None else np.zeros(4)
+    _check_device(model, d, g)
     return float(d[0]), float(d[1]), float(d[2]), float(g[0]), float(g[1]), float(g[2]), float(g[3])
 
 
@@ -123,4 +136,5 @@ def _eval_one_iteration(sess, model, cv_num_batch, iteration, valid_queue, num_g
         n += 1
     d = (d_acc / max(n, 1)).cpu().numpy() if d_acc is not None else np.zeros(3)
     g = (g_acc / max(n, 1)).cpu().numpy() if g_acc is not None else np.zeros(4)
+    _check_device(model, d, g)
     return float(d[0]), float(d[1]), float(d[2]), float(g[0]), float(g[1]), float(g[2]), float(g[3])

@@ -64,3 +64,37 @@ def test_two_rank_gloo_equals_two_tower_oracle(bucketed):
         assert np.allclose(res, want, rtol=1e-6), (r, res, want)
         assert np.allclose(flat, want_flat, rtol=1e-9, atol=1e-12), r
     assert np.array_equal(out[0][1], out[1][1])                     # replicas stay bit-identical
+
+
+def _rank0_worker(rank, world, port, out, fail):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rsrgan_amd import dist as rdist
+
+        def job():
+            if fail:
+                raise OSError("disk full")
+            return "written"
+        try:
+            out[rank] = ("ok", rdist.run_on_rank0(job))
+        except Exception as e:                                      # noqa: BLE001
+            out[rank] = ("raised", "%s: %s" % (type(e).__name__, e))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", [False, True])
+def test_rank0_section_releases_the_other_ranks(fail):
+    """Checkpoint writes and decode run on rank 0 only (Model.save, run_gan_*.main).  The waiting ranks used to sit in a barrier that a
+    failing rank 0 never reached: run_on_rank0 broadcasts rank 0's status on every path and every rank fails the same way."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rank0_worker, args=(world, _free_port(), out, fail), nprocs=world, join=True)
+    if fail:
+        assert out[0] == ("raised", "OSError: disk full")
+        assert out[1][0] == "raised" and "rank 0 failed: OSError: disk full" in out[1][1]
+    else:
+        assert out[0] == ("ok", "written") and out[1] == ("ok", None)
