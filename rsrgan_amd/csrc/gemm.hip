@@ -660,14 +660,13 @@ int g_gemm_workers = 256;     // worker slots of a launch = one block (4 MFMA + 
 namespace {
 
 struct Plan { int W, n_dp, whole; double cost; };
-// cost of a fix-up launch in the plan: fixed part (us) and bytes per us (RSRGAN_GEMM_FIX="us,bytes_per_us" for experiments)
-double g_fix_us = 4.0, g_fix_bw = 3.0e6;
-bool g_fix_init = false;
+// cost of a fix-up launch in the plan: fixed part (us) and bytes per us.  (The launches measure ~20 us in the SEGAN step, yet pricing
+// them at 10 - 40 us made that step slower, 25.1 -> 26.0 ms: cutting tiles is right even then.)
+constexpr double g_fix_us = 4.0, g_fix_bw = 3.0e6;
 // Time model of one configuration (us).  The MFMA waves run at ~0.92 of the matrix rate when fed; a CU ingests operands at
 // ~14 GB/s (L2 -> LDS DMA, measured: 117 TFLOP/s at 128 x 128 tiles = 0.031 B/FLOP), so small tiles are ingest-bound; a cut
 // tile costs its pieces a write and a read plus the fix-up launch; whole-tile mode costs the idle CUs of the last round.
 Plan plan_cfg(int M, int N, int K, int bm, int bn, int workers, float* ws, size_t ws_floats) {
-  if (!g_fix_init) { g_fix_init = true; if (const char* e = getenv("RSRGAN_GEMM_FIX")) sscanf(e, "%lf,%lf", &g_fix_us, &g_fix_bw); }
   const int tm = (M + bm - 1) / bm, tn = (N + bn - 1) / bn, NT = tm * tn, NK = (K + GK - 1) / GK;
   const double flops = 2.0 * tm * bm * (double)tn * bn * NK * GK;
   const double t_mfma = flops / (157.3e6 * 0.92), t_in = flops * (2.0 / bm + 2.0 / bn) / 3.7e6;

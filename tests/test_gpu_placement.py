@@ -103,3 +103,58 @@ def test_stream_k_gemm_step_is_reproducible():
     a = _run(dict(size))
     b = _run(dict(size))
     assert a == b, (a, b)
+
+
+SEGAN_WORKER = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from tests.test_gpu_segan import _pair, _batch, NET_D, NET_G
+cfg, m, o, rng = _pair(2, 300, 40, (16, 32, 32, 64, 64, 128), 20, 31, seed=11, l1=7.0)
+x, lab, z, nz = _batch(cfg, 2, rng)
+out = {"d": [float(v) for v in np.ravel(m.d_step(x, lab, z, nz, apply=False))]}
+gd = m.get_grads(NET_D)
+out["g"] = [float(v) for v in np.ravel(m.g_step(x, lab, z, (nz[0], nz[2]), apply=False))]
+gg = m.get_grads(NET_G)
+out["gd"] = {k: [float(np.linalg.norm(v)), float(np.sum(v.astype(np.float64)))] for k, v in gd.items()}
+out["gg"] = {k: [float(np.linalg.norm(v)), float(np.sum(v.astype(np.float64)))] for k, v in gg.items()}
+print("RESULT " + json.dumps(out))
+""" % ROOT
+
+
+def _run_worker(src, env):
+    e = dict(os.environ); e.update(env)
+    p = subprocess.run([sys.executable, "-c", src], capture_output=True, text=True, env=e, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+
+
+def test_segan_column_reduction_forms_agree():
+    """csrc/segan.hip launch_colred: the 16-byte / four-rows-in-flight form of each reduction mode (RSRGAN_COLRED_VEC bit m) against
+    the scalar form: same sums to fp32 rounding, so the towers and every gradient's norm agree closely."""
+    a = _run_worker(SEGAN_WORKER, {"RSRGAN_COLRED_VEC": "15"})
+    b = _run_worker(SEGAN_WORKER, {"RSRGAN_COLRED_VEC": "0"})
+    assert np.allclose(a["d"], b["d"], rtol=1e-5) and np.allclose(a["g"], b["g"], rtol=1e-5), (a["d"], b["d"], a["g"], b["g"])
+    for net in ("gd", "gg"):
+        for k in a[net]:
+            na, nb = a[net][k][0], b[net][k][0]
+            assert abs(na - nb) <= 1e-4 * nb + 1e-4, (net, k, na, nb)      # (biases in front of a VBN: zero gradient, fp32 noise)
+
+
+RCED_WORKER = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from tests.test_gpu_trainers import rced_gradient_norms
+print("RESULT " + json.dumps(rced_gradient_norms()))
+""" % ROOT
+
+
+def test_rced_weight_gradient_geometries_agree():
+    """csrc/conv.hip k_conv_wgrad: six filter rows per workgroup with the rows inside the position loop (RSRGAN_WGRAD_DH=6, the
+    default for multi-strip frames) against round 2's three rows: the same products in another summation order."""
+    a = _run_worker(RCED_WORKER, {"RSRGAN_WGRAD_DH": "6"})
+    b = _run_worker(RCED_WORKER, {"RSRGAN_WGRAD_DH": "3"})
+    assert a.keys() == b.keys() and len(a) > 0
+    for k in a:
+        assert abs(a[k] - b[k]) <= 2e-5 * max(abs(b[k]), 1e-6), (k, a[k], b[k])

@@ -199,6 +199,31 @@ def test_rced_generator_matches_oracle(N, gan, ctx, width):
         assert gv[k].shape == o.g[k].shape and rel_err(gv[k], o.g[k]) < 1e-3, k
 
 
+def rced_gradient_norms():
+    """(worker of tests/test_gpu_placement.py::test_rced_weight_gradient_geometries_agree) the reference's frame geometry (257 x 11,
+    multi-strip: the geometry RSRGAN_WGRAD_DH acts on), 3 frames, random weights and biases: one supervised backward, the norm of
+    every generator gradient"""
+    from oracle import rced_oracle as R
+    from rsrgan_amd.trainer import DNNTrainer
+    N = 3
+    cfg = R.RcedCfg(input_dim=257, output_dim=5, left_context=5, right_context=5, d_units=18, d_hidden=2, filters_num=R.FILTERS_NUM)
+    rng = np.random.default_rng(78)
+    g = {k: v.astype(np.float32) for k, v in R.init_params(R.g_param_specs(cfg), rng).items()}
+    for k in g:
+        if k.endswith("biases"):
+            g[k] = rng.normal(0.05, 0.1, g[k].shape).astype(np.float32)
+    d = {k: v.astype(np.float32) for k, v in DO.init_params(DO.d_param_specs(cfg), rng, relu_init=True).items()}
+    args = SimpleNamespace(batch_size=N, input_dim=cfg.input_dim, output_dim=cfg.output_dim, left_context=5, right_context=5,
+                           g_type="rced", keep_prob=1.0, batch_norm=False, num_gpu=1, save_dir=None, l2_scale=0.0,
+                           g_learning_rate=1e-3, d_learning_rate=2e-3, init_mse_weight=10.0, disc_updates=1, gen_updates=1)
+    m = DNNTrainer(None, args, ["gpu:0"], net_overrides=dict(g_layers=9, g_cells=32, d_layers=cfg.d_hidden, d_cells=cfg.d_units))
+    m.set_vars(g, d)
+    x = rng.standard_normal((N, cfg.fed_dim)).astype(np.float32); lab = rng.standard_normal((N, cfg.output_dim)).astype(np.float32)
+    m.engine.g_backward(x[:, None], lab[:, None], None, train=True, reuse=False, apply=False)
+    gg = split_flat(m.engine.get_grads(NET_G).cpu().numpy(), m.engine.tensor_table(NET_G))
+    return {k: float(np.linalg.norm(v.astype(np.float64))) for k, v in gg.items()}
+
+
 def test_rced_reference_frame_random_relu_masks():
     """The reference's frame (257-dim LPS x splice 11, filter table of models/rced.py:90-114: the 4 x 65-column strip path) with
     RANDOM biases and weights, so every channel's ReLU mask varies over the positions.  A frame has ~1 M ReLU units; a handful of
