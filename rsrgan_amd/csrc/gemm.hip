@@ -86,9 +86,9 @@ constexpr int NL = RSR_GEMM_NL;                                    // loader wav
 // LDS ring: k-tiles resident (one being multiplied, the others landing): as many as fit beside ~16 KB of slack, at most 4
 // (measured at 4096^3, 128 x 128 tiles: 105 / 115 / 117 TFLOP/s with 2 / 3 / 4)
 constexpr int ring_depth(int bm, int bn) { return (144 * 1024) / ((bm + bn) * GK * 4) >= 4 ? 4 : (144 * 1024) / ((bm + bn) * GK * 4); }
-template <bool KC, int BX, bool MAP = false>
+template <bool KC, int BX, bool MAP = false, int NLW = NL>
 struct Stage {
-  static constexpr int NI = BX * GK / 256 / NL;          // wave-instructions per loader wave and k-tile
+  static constexpr int NI = BX * GK / 256 / NLW;         // wave-instructions per loading wave and k-tile (NLW waves share the tile)
   static constexpr int FLOATS = GK * BX;
   const float* p[NI];                                    // this lane's source of instruction u at the current k-tile
   int mp[MAP && !KC ? NI : 1], mq[MAP && !KC ? NI : 1];  // mapped k-major operand: position / sample of the chunk's k row
@@ -98,7 +98,7 @@ struct Stage {
                                        int lane, int lw, const GemmRowMap& map) {
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
-      const int c = 64 * (lw + NL * u) + lane;
+      const int c = 64 * (lw + NLW * u) + lane;
       if (KC) {
         const int row = min(x0 + (c >> 3), X - 1);
         p[u] = P + (MAP ? map_row(map, row) : (long long)row * ld) + k_first + 4 * kc_kq(lane, lw);
@@ -119,8 +119,13 @@ struct Stage {
   __device__ __forceinline__ void issue(int k0, int K, bool on, float* dst, int lane, int lw, int ld, int ld2, int X1, int x0, int X,
                                         const float* P2, const GemmRowMap& map) {
 #pragma unroll
-    for (int u = 0; u < NI; ++u) {
-      const int j = lw + NL * u, c = 64 * j + lane;
+    for (int u = 0; u < NI; ++u) issue_one(u, k0, K, on, dst, lane, lw, ld, ld2, X1, x0, X, P2, map);
+  }
+  // instruction u alone (k_gemm_s spreads them over the MFMA stream of the k-tile before)
+  __device__ __forceinline__ void issue_one(int u, int k0, int K, bool on, float* dst, int lane, int lw, int ld, int ld2, int X1, int x0, int X,
+                                            const float* P2, const GemmRowMap& map) {
+    {
+      const int j = lw + NLW * u, c = 64 * j + lane;
       bool v;
       const float* src;
       if (KC) {
@@ -346,6 +351,145 @@ __global__ __launch_bounds__(64 * (4 + NL), RSR_GEMM_MINW) void k_gemm(const Gem
 #if RSR_GEMM_ABL & 8
   if (bid == 0 && tid == 0) { g_gemm_clk[0] = __builtin_amdgcn_s_memtime() - clk0; g_gemm_clk[1] = __builtin_amdgcn_s_memrealtime() - rt0; }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// k_gemm_s: the same product on 256-wide tiles with FOUR waves that load for themselves (no loader waves): one wave per SIMD owns the
+// whole 512-register file (accumulators of a 128 x 128 or 64 x 128 sub-tile in the AGPR half), every wave issues its quarter of the
+// next k-tile's DMA inside its own MFMA stream -- one 1 KB instruction per DPM MFMAs -- into the second of two LDS buffers; one
+// vmcnt(0) + barrier per k-tile.  k_gemm at 128 x 128 is ingest-bound (8 B/clk/CU against ~6.8); a 256 x 256 x 32 k-tile needs
+// 64 KB per 16384 MFMA cycles = 4 B/clk, 128 x 256 needs 6 (section 6-R3: the design point of the vendor library's kernels).
+// ------------------------------------------------------------------------------------------------------------------------
+template <bool AKC, bool BKC, int RT, int CT, int WM, bool MAPA>
+__global__ __launch_bounds__(256, 1) void k_gemm_s(const GemmArgs g) {
+  constexpr int WN = 4 / WM, BM = WM * RT * 32, BN = WN * CT * 32;
+  typedef Stage<AKC, BM, MAPA, 4> SA;
+  typedef Stage<BKC, BN, false, 4> SB;
+  constexpr int BUF = SA::FLOATS + SB::FLOATS;
+  static_assert(2 * BUF * 4 <= 160 * 1024, "two k-tiles must fit the LDS");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid / WN, wc = wid - wr * WN;
+  const int W = g.W;
+  const int bid = blockIdx.x;
+  const int w = (W & 7) ? bid : (bid & 7) * (W >> 3) + (bid >> 3);
+  const int u_lo = worker_lo(g, w), u_hi = worker_lo(g, w + 1);
+  int u = u_lo;
+  int tdp = w;
+  while (tdp < g.n_dp || u < u_hi) {
+    int t, i0, i1;
+    if (tdp < g.n_dp) { t = tdp; tdp += W; i0 = 0; i1 = g.NK; }
+    else {
+      const int ts = u / g.NK;
+      t = g.n_dp + ts; i0 = u - ts * g.NK;
+      i1 = min(g.NK, i0 + (u_hi - u));
+    }
+    int tm, tn;
+    tile_rc(g, t, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    SA sa; SB sb;
+    sa.init(g.A, g.lda, g.A2, g.lda2, g.M1, m0, g.M, i0 * GK, lane, wid, g.ma);
+    sb.init(g.B, g.ldb, nullptr, 0, 0, n0, g.N, i0 * GK, lane, wid, g.ma);
+    constexpr int NIT = SA::NI + SB::NI;                   // DMA instructions per wave and k-tile
+    __builtin_amdgcn_s_barrier();                          // the previous tile's last k-tile has been read by every wave
+    sa.issue(i0 * GK, g.K, true, smem, lane, wid, g.lda, g.lda2, g.M1, m0, g.M, g.A2, g.ma);
+    sb.issue(i0 * GK, g.K, true, smem + SA::FLOATS, lane, wid, g.ldb, 0, 0, n0, g.N, nullptr, g.ma);
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    constexpr bool PAIRED = AKC || BKC;
+    const int ra = wr * RT * 32 + l31, rb = wc * CT * 32 + l31;
+    // swizzle term of the k-contiguous images: ((x >> 1) & 7) with x = ra + 32 r is the same for every sub-tile r -- spelled out, a
+    // fragment address is ONE register per stage plus an immediate (r * 4 KB); left to the compiler every (stage, r) pair got its
+    // own hoisted register and the 256 x 256 tile spilled
+    const int swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;
+    int slot = 0;
+    for (int kt = i0; kt < i1; ++kt) {
+      const float* bc = smem + slot * BUF;
+      float* bnx = smem + (slot ^ 1) * BUF;
+      slot ^= 1;
+      const bool more = kt + 1 < i1;                       // (uniform) the next k-tile of this run: its DMA rides this k-tile's MFMAs
+      constexpr int NS = GK / 4;
+      constexpr int RA = AKC ? RT : 2 * RT, RB = BKC ? CT : 2 * CT, NR = RA + RB;
+      constexpr int NMS = 2 * RT * CT, RPG = (NR + NMS - 1) / NMS;
+      constexpr int NM = NS * NMS;                         // MFMAs per k-tile; DMA instruction d rides MFMA ((2d+1) NM) / (2 NIT)
+      static_assert(NM >= NIT, "at most one DMA instruction per MFMA");
+      float fa[2][2][RT], fb[2][2][CT];
+      auto read_one = [&](int st, int par, int r) {
+        if (r < RA) {
+          if (AKC) {
+            const float* v = bc + ra * 32 + ((st ^ swa) << 2) + 2 * lh + r * 1024;
+            fa[par][0][r] = v[0]; fa[par][1][r] = v[1];
+          } else {
+            const int e = r / RT, i = r - e * RT;
+            fa[par][e][i] = bc[(4 * st + (PAIRED ? 2 * lh + e : 2 * e + lh)) * BM + ra + i * 32];
+          }
+        } else {
+          const float* bb = bc + SA::FLOATS;
+          const int q = r - RA;
+          if (BKC) {
+            const float* v = bb + rb * 32 + ((st ^ swb) << 2) + 2 * lh + q * 1024;
+            fb[par][0][q] = v[0]; fb[par][1][q] = v[1];
+          } else {
+            const int e = q / CT, j = q - e * CT;
+            fb[par][e][j] = bb[(4 * st + (PAIRED ? 2 * lh + e : 2 * e + lh)) * BN + rb + j * 32];
+          }
+        }
+      };
+#pragma unroll
+      for (int r = 0; r < NR; ++r) read_one(0, 0, r);
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+              const int m = (e * RT + i) * CT + j;         // MFMA index inside the stage (compile-time after unrolling)
+              const int gm = st * NMS + m;                 // ... inside the k-tile
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st & 1][e][i], fb[st & 1][e][j], acc[i][j], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              const int d = (gm * NIT) / NM;
+              if (gm == ((2 * d + 1) * NM) / (2 * NIT) && more) {      // behind an MFMA: the matrix pipe has work while the DMA issues
+                if (d < SA::NI) sa.issue_one(d, (kt + 1) * GK, g.K, true, bnx, lane, wid, g.lda, g.lda2, g.M1, m0, g.M, g.A2, g.ma);
+                else sb.issue_one(d - SA::NI, (kt + 1) * GK, g.K, true, bnx + SA::FLOATS, lane, wid, g.ldb, 0, 0, n0, g.N, nullptr, g.ma);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+              if (st + 1 < NS) {
+#pragma unroll
+                for (int k = 0; k < RPG; ++k)
+                  if (m * RPG + k < NR) read_one(st + 1, (st + 1) & 1, m * RPG + k);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of k-tile kt+1 has landed
+      __builtin_amdgcn_s_barrier();                        // ... everybody's; and k-tile kt has been read by every wave
+    }
+    if (i0 == 0 && i1 == g.NK) {
+      gemm_epilogue<RT, CT>(acc, m0 + wr * RT * 32, n0 + wc * CT * 32, l31, lh, g);
+    } else {
+      const int pslot = 2 * w + (u == u_lo ? 0 : 1);
+      float4* q = reinterpret_cast<float4*>(g.ws) + (size_t)pslot * (RT * CT * 4 * 256) + tid;
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4)
+            q[((i * CT + j) * 4 + r4) * 256] = make_float4(acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]);
+    }
+    if (t >= g.n_dp) u += i1 - i0;
+  }
 }
 
 // tile `ts` of the stream-K region: the workers whose runs cut it, in k order; first run of a worker -> slot 2w, last -> 2w+1
@@ -712,15 +856,43 @@ void launch_cfg(GemmArgs& g, const Plan& pl, hipStream_t s, float* ws) {
     hipLaunchKernelGGL((k_gemm_fixup<RT, CT, WM>), dim3(g.NT - g.n_dp), dim3(256), 0, s, g);
 }
 
+template <bool AKC, bool BKC, int RT, int CT, int WM, bool MAPA>
+void launch_cfg_s(GemmArgs& g, const Plan& pl, hipStream_t s, float* ws) {
+  constexpr int WN = 4 / WM, BM = WM * RT * 32, BN = WN * CT * 32;
+  constexpr size_t lds = (size_t)2 * (BM + BN) * GK * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_s<AKC, BKC, RT, CT, WM, MAPA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  g.tiles_m = (g.M + BM - 1) / BM;
+  g.tiles_n = (g.N + BN - 1) / BN;
+  g.NT = g.tiles_m * g.tiles_n;
+  g.NK = (g.K + GK - 1) / GK;
+  if ((long long)g.NT * g.NK >= (1LL << 30)) { fprintf(stderr, "rsrgan: GEMM beyond the 32-bit (tile, k-tile) unit arithmetic\n"); abort(); }
+  g.ws = ws; g.W = pl.W; g.n_dp = pl.n_dp;
+  const int U = (g.NT - g.n_dp) * g.NK;
+  g.Uq = U / g.W; g.Ur = U % g.W;
+  hipLaunchKernelGGL((k_gemm_s<AKC, BKC, RT, CT, WM, MAPA>), dim3(g.W), dim3(256), lds, s, g);
+  if (U > 0 && !(U % g.W == 0 && (U / g.W) % g.NK == 0))
+    hipLaunchKernelGGL((k_gemm_fixup<RT, CT, WM>), dim3(g.NT - g.n_dp), dim3(256), 0, s, g);
+}
+
 template <bool AKC, bool BKC, bool MAPA>
 void launch_layout(GemmArgs& g, hipStream_t s, float* ws, size_t ws_floats) {
   // (192 x 128 and 256 x 128 tiles were measured too: +4 % at 4096^3, slower on every shape of the training steps -- fewer, larger
   //  pieces to fix up -- and past the 256-register budget of a 6-wave block: they spill.  Not instantiated.)
   // 256 x 32 / 256 x 64: the window-view products of the first SEGAN layers have 16..64 output channels and ~1e5..1e6 rows
-  static const int cfgs[][2] = {{128, 128}, {96, 128}, {128, 96}, {256, 64}, {256, 32}};
+  // 256 x 256 / 128 x 256 / 256 x 128: k_gemm_s (four self-loading waves); RSRGAN_GEMM_SELF=0 leaves them out
+  static const int cfgs[][2] = {{128, 128}, {96, 128}, {128, 96}, {256, 64}, {256, 32}, {256, 256}, {128, 256}, {256, 128}};
+  static int self = -1;
+  if (self < 0) { const char* e = getenv("RSRGAN_GEMM_SELF"); self = e ? atoi(e) : 1; }
   int best = 0;
   Plan bp{};
-  for (int c = 0; c < 5; ++c) {
+  for (int c = 0; c < (self ? 8 : 5); ++c) {
+    // the 256-wide tiles pay off with at least two full rounds of whole tiles (measured: 4096^3 118-121 -> 131-133 TFLOP/s,
+    // 32768 x 1024 x 1024 105-109 -> 116-118; 6400 x 1024 x 1024, 200 tiles of 128 x 256: 87 either way, the frame-level step 2 % slower)
+    if (c >= 5 && (long long)((g.M + cfgs[c][0] - 1) / cfgs[c][0]) * ((g.N + cfgs[c][1] - 1) / cfgs[c][1]) < 2LL * g_gemm_workers) continue;
     Plan pl = plan_cfg(g.M, g.N, g.K, cfgs[c][0], cfgs[c][1], g_gemm_workers, ws, ws_floats);
     if (c == 0 || pl.cost < 0.97 * bp.cost) { best = c; bp = pl; }
   }
@@ -729,6 +901,9 @@ void launch_layout(GemmArgs& g, hipStream_t s, float* ws, size_t ws_floats) {
     case 2: launch_cfg<AKC, BKC, 1, 3, 4, MAPA>(g, bp, s, ws); break;
     case 3: launch_cfg<AKC, BKC, 2, 2, 4, MAPA>(g, bp, s, ws); break;
     case 4: launch_cfg<AKC, BKC, 2, 1, 4, MAPA>(g, bp, s, ws); break;
+    case 5: launch_cfg_s<AKC, BKC, 4, 4, 2, MAPA>(g, bp, s, ws); break;
+    case 6: launch_cfg_s<AKC, BKC, 2, 4, 2, MAPA>(g, bp, s, ws); break;
+    case 7: launch_cfg_s<AKC, BKC, 4, 2, 2, MAPA>(g, bp, s, ws); break;
     default: launch_cfg<AKC, BKC, 2, 2, 2, MAPA>(g, bp, s, ws); break;
   }
 }

@@ -18,7 +18,8 @@ def pad4(n):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (300, 257, 40), (1600, 3040, 280), (37, 1, 40), (560, 3040, 640),
                                    (257, 280, 1003), (5, 7, 3),
-                                   (1000, 12, 143), (512, 32, 2464), (2500, 24, 20000), (256, 1, 77)])       # N <= 32: 256x32 tiles
+                                   (1000, 12, 143), (512, 32, 2464), (2500, 24, 20000), (256, 1, 77),       # N <= 32: 256x32 tiles
+                                   (8200, 2050, 72), (4100, 4100, 40)])      # >= 512 big tiles: k_gemm_s (128 x 256 / 256 x 256, four self-loading waves)
 @pytest.mark.parametrize("akc,bkc", [(True, False), (True, True), (False, False), (False, True)])
 def test_gemm_variants(M, N, K, akc, bkc):
     eng = _eng()
