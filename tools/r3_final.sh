@@ -8,7 +8,7 @@ timeout 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-varian
 bash tools/prof.sh $tag --steps 5 --warmup 2 --no-variants > /dev/null 2>&1
 head -14 gpurun_out/prof_$tag/r_kernel_stats.csv | cut -c1-130
 bash tools/traffic.sh $tag --no-variants > gpurun_out/traffic_$tag.log 2>&1; tail -2 gpurun_out/traffic_$tag.log | cut -c1-300
-bash tools/traffic_warm.sh $tag > gpurun_out/traffic_warm_$tag.log 2>&1; tail -1 gpurun_out/traffic_warm_$tag.log | cut -c1-400
+# (tools/traffic_warm.sh: the per-class variant, a negative result kept in profiles/r3_traffic_warm_by_class.json -- not part of the final set)
 # variants: R-CED GAN and SEGAN kernel statistics
 bash tools/prof.sh rced --net rced --rced-gan --batch 6400 --rced-width 257 --steps 1 --warmup 1 --no-variants > /dev/null 2>&1
 head -8 gpurun_out/prof_rced/r_kernel_stats.csv | cut -c1-130
