@@ -366,7 +366,8 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
       }
     }
   }
-  const int gmaxld = std::max(ldP, ldDin);
+  const int gmaxld = std::max(std::max(ldP, ldDin), ldDout);      // (g_dB / g_dC also carry dy [T*B][ldDout]: an output wider than the generator's
+                                                                  //  layers overflowed them -- found by __graft_entry__.smoke()'s second configuration)
   g_dA = alloc<float>(TB * gmaxld); g_dB = alloc<float>(TB * gmaxld); g_dC = alloc<float>(TB * gmaxld);
   const size_t TB2 = TB * 2;
   const int ldPd = d_dnn() ? 4 : pad4(dR);

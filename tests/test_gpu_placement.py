@@ -158,3 +158,26 @@ def test_rced_weight_gradient_geometries_agree():
     assert a.keys() == b.keys() and len(a) > 0
     for k in a:
         assert abs(a[k] - b[k]) <= 2e-5 * max(abs(b[k]), 1e-6), (k, a[k], b[k])
+
+
+def test_wide_output_small_generator_with_reference_discriminator():
+    """A generator narrower than its 40-dim output next to the reference's discriminator (2 x LSTMCell(256, num_proj=40)): dy
+    [T*B][40] used to overflow the generator's gradient ping-pong buffers (sized by its layer widths), found by
+    __graft_entry__.smoke().  Also the persistent discriminator recurrences against the ORACLE (not only against the per-step
+    launches): losses of two D + G updates."""
+    from oracle import rsrgan_oracle as O                 # noqa: F401
+    from tests.helpers import build_hip_pair, rand_batch, small_cfg
+    small = small_cfg("lstm")
+    m0, _ = build_hip_pair(small, 4, 6, seed=1)           # (another model first: the overflow only faulted with a shifted heap)
+    x0, l0, n0 = rand_batch(small, 4, 6, seed=2, ragged=True)
+    m0.d_step(x0, l0, n0)
+    cfg = small_cfg("lstm", output_dim=40, d_cells=256, d_proj=40)
+    B, T = 16, 5
+    model, oracle = build_hip_pair(cfg, B, T, seed=3, flags=3)
+    x, lab, ln = rand_batch(cfg, B, T, seed=4, ragged=True)
+    for _ in range(2):
+        d_hip = np.ravel(model.d_step(x, lab, ln)); d_ref = np.ravel(oracle.d_step(x, lab, ln))
+        g_hip = np.ravel(model.g_step(x, lab, ln, reuse_g_forward=True)); g_ref = np.ravel(oracle.g_step(x, lab, ln))
+        assert np.allclose(d_hip, d_ref, rtol=1e-3), (d_hip, d_ref)
+        assert np.allclose(g_hip, g_ref, rtol=1e-3), (g_hip, g_ref)
+    assert model.engine.device_status() == 0
