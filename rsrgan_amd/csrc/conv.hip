@@ -181,7 +181,8 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
 // [group][strip][dh][K'][32] are summed in a fixed order by k_conv_wgrad_red, which also undoes the k' padding.
 template <int KT, int NT, int NWV, int DH>
 __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict__ in, int ldc_in, int C, const float* __restrict__ d, int ldc_d,
-                                                         int N, float* __restrict__ part, int S, int W, int fw, int TW, int R, int fpg) {
+                                                         int N, float* __restrict__ part, int S, int W, int fw, int TW, int R, int fpg,
+                                                         float* __restrict__ bpart) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Cp = conv_cpad(C), KP = conv_kp(fw, C);
   const int pt = (S - 1) / 2, pl = (fw - 1) / 2;
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict
   bool kt_ok[KT];
 #pragma unroll
   for (int i = 0; i < KT; ++i) kt_ok[i] = (wv + NWV * i) * 16 < KP;      // k'-tile wv + NWV*i: a second tile only where the first round left some
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);             // this thread's channels 4 (tid & 7) .. + 3 over its positions of every frame
   for (int f = 0; f < fpg; ++f) {
     const int r = grp * fpg + f;
     if (r >= R) break;
@@ -238,6 +240,8 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict
       constexpr int DSLOTS = 4;                              // MP * 8 <= 4 * 1024 (checked on the host: conv_wgrad_supported)
       float4 dv[DSLOTS];
       int dgo[DSLOTS];
+      // (bias gradient = column sums of d: the row-group-0 workgroups see every gradient element of their frames exactly once on its
+      //  way to LDS -- a separate tall column sum re-read the 2.3 GB tensor per layer, 9 ms of the 608 ms step)
 #pragma unroll
       for (int u = 0; u < DSLOTS; ++u) {                     // 8 float4 = 32 channels per position
         const int i = tid + u * 64 * NWV;
@@ -266,7 +270,9 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict
         const int i = tid + u * 64 * NWV;
         const int m = i >> 3, c = (i & 7) * 4;
         const bool ok = dgo[u] >= 0;
-        if (i < MP * 8) *reinterpret_cast<float4*>(ds + (size_t)m * 36 + c) = make_float4(ok ? dv[u].x : 0.f, ok ? dv[u].y : 0.f, ok ? dv[u].z : 0.f, ok ? dv[u].w : 0.f);
+        const float4 z = make_float4(ok ? dv[u].x : 0.f, ok ? dv[u].y : 0.f, ok ? dv[u].z : 0.f, ok ? dv[u].w : 0.f);
+        if (i < MP * 8) *reinterpret_cast<float4*>(ds + (size_t)m * 36 + c) = z;
+        bsum.x += z.x; bsum.y += z.y; bsum.z += z.z; bsum.w += z.w;
       }
     }
     __syncthreads();
@@ -410,6 +416,17 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict
     }
     }   // (rows-outside form)
   }
+  if (bpart && blockIdx.x == 0) {                          // (uniform) fixed-order sum over the 64 * NWV / 8 threads of a channel group
+    __syncthreads();
+    float4* sb = reinterpret_cast<float4*>(smem);
+    sb[tid] = bsum;
+    __syncthreads();
+    if (tid < 8) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < 8 * NWV; ++j) { const float4 v = sb[tid + 8 * j]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+      *reinterpret_cast<float4*>(bpart + ((size_t)grp * gridDim.z + strip) * 32 + 4 * tid) = t;
+    }
+  }
   // partial tiles -> part[((grp*nstrips + strip)*S + dh)][k'][32]
 #pragma unroll
   for (int dd = 0; dd < DH; ++dd) {
@@ -428,10 +445,17 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict
   }
 }
 // dW[(dh*fw + dw)*C + c][co] = sum over partial tiles p of part[p][dh][dw*C' + c][co]   (fixed order)
-__global__ void k_conv_wgrad_red(const float* __restrict__ part, int nparts, int S, int fw, int C, int N, float* __restrict__ dW, int ldw) {
+__global__ void k_conv_wgrad_red(const float* __restrict__ part, int nparts, int S, int fw, int C, int N, float* __restrict__ dW, int ldw,
+                                 const float* __restrict__ bpart, float* __restrict__ db) {
   const int Cp = conv_cpad(C), KP = conv_kp(fw, C);
   const int total = S * fw * C * N;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (db && i >= total && i < total + N) {                 // the bias gradient from the row-group-0 workgroups' column sums
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += bpart[(size_t)p * 32 + (i - total)];
+    db[i - total] = s;
+    return;
+  }
   if (i >= total) return;
   const int co = i % N, k = i / N;
   const int c = k % C, dd = k / C, dw = dd % fw, dh = dd / fw;
@@ -539,7 +563,7 @@ size_t conv_wgrad_ws_floats(int C, int R, int S, int W, int fw) {
   const int TW = wgrad_tw(S, W), nstrips = (W + TW - 1) / TW;
   int DH, fpg, groups;
   wgrad_plan(R, S, nstrips, conv_kp(fw, C), DH, fpg, groups);
-  return (size_t)groups * nstrips * S * conv_kp(fw, C) * 32;
+  return (size_t)groups * nstrips * (S * conv_kp(fw, C) + 1) * 32;          // filter partials + one 32-float bias partial per (group, strip)
 }
 bool conv_wgrad_supported(int C, int N, int S, int W, int fw) {
   if (!conv_fwd_supported(C, N, S, W, fw)) return false;
@@ -550,7 +574,7 @@ bool conv_wgrad_supported(int C, int N, int S, int W, int fw) {
 }
 template <int KT, int NT>
 static void wgrad_launch_dh(int DH, dim3 grid, size_t lds, hipStream_t s, const float* in, int ldc_in, int C, const float* d, int ldc_d, int N,
-                            float* ws, int S, int W, int fw, int TW, int R, int fpg) {
+                            float* ws, int S, int W, int fw, int TW, int R, int fpg, float* bpart) {
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad<KT, NT, 16, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -562,29 +586,30 @@ static void wgrad_launch_dh(int DH, dim3 grid, size_t lds, hipStream_t s, const 
     }
     attr = true;
   }
-  if (DH == 1) hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 1>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
-  else if (DH == 2) hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 2>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
-  else if (DH == 3) hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 3>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  if (DH == 1) hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 1>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg, bpart);
+  else if (DH == 2) hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 2>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg, bpart);
+  else if (DH == 3) hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 3>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg, bpart);
   else if constexpr (KT == 1) {
-    if (DH == 4) hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 4>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
-    else hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 6>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+    if (DH == 4) hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 4>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg, bpart);
+    else hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 6>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg, bpart);
   }
 }
 void launch_conv_wgrad(const float* in, int ldc_in, int C, const float* d, int ldc_d, int N, float* dW, int ldw, float* ws, int R, int S,
-                       int W, int fw, hipStream_t s) {
+                       int W, int fw, hipStream_t s, float* db) {
   const int TW = wgrad_tw(S, W), nstrips = (W + TW - 1) / TW;
   int DH, fpg, groups;
   const int MP = (S * TW + 15) / 16 * 16, KP = conv_kp(fw, C);
   wgrad_plan(R, S, nstrips, KP, DH, fpg, groups);
   const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 38) * sizeof(float);
   dim3 grid((S + DH - 1) / DH, groups, nstrips);
+  float* bpart = db ? ws + (size_t)groups * nstrips * S * KP * 32 : nullptr;
   const bool k2 = KP > 16 * 16, n1 = N <= 16;          // 16 waves: one k'-tile per wave up to K' = 256, two beyond
-  if (k2 && n1) wgrad_launch_dh<2, 1>(DH, grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
-  else if (k2) wgrad_launch_dh<2, 2>(DH, grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
-  else if (n1) wgrad_launch_dh<1, 1>(DH, grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
-  else wgrad_launch_dh<1, 2>(DH, grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg);
+  if (k2 && n1) wgrad_launch_dh<2, 1>(DH, grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg, bpart);
+  else if (k2) wgrad_launch_dh<2, 2>(DH, grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg, bpart);
+  else if (n1) wgrad_launch_dh<1, 1>(DH, grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg, bpart);
+  else wgrad_launch_dh<1, 2>(DH, grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg, bpart);
   const int total = S * fw * C * N;
-  hipLaunchKernelGGL(k_conv_wgrad_red, dim3((total + 255) / 256), dim3(256), 0, s, ws, groups * nstrips, S, fw, C, N, dW, ldw);
+  hipLaunchKernelGGL(k_conv_wgrad_red, dim3((total + N + 255) / 256), dim3(256), 0, s, ws, groups * nstrips, S, fw, C, N, dW, ldw, bpart, db);
 }
 
 }  // namespace rsr

@@ -126,16 +126,18 @@ void Model::rced_backward(int rows, float* dy, hipStream_t s) {
     else if (!d_masked)
       launch_lrelu_bwd(rc_act[l + 1], d, M, L.Cout, L.ldCout, 0.f, s);                    // relu': d *= [a > 0]
     d_masked = false;
+    bool db_done = false;                    // bias gradient already summed by the weight-gradient kernel
     if (rc_wgrad_implicit[l] && rc_wg_ws) {
       launch_conv_wgrad(l == 0 ? rc_x4 : rc_act[l], l == 0 ? 4 : L.ldCin, L.Cin, d, L.ldCout, L.Cout, G.Gd(L.tW), L.ldCout, rc_wg_ws, rows,
-                        rcS, rcW, L.fw, s);
+                        rcS, rcW, L.fw, s, L.bn ? nullptr : G.Gd(L.tb));
+      db_done = !L.bn;
     } else {
       float* col = rc_keep_cols ? rc_cols[l] : rc_col;          // kept from the forward pass of the same batch, or rebuilt
       if (!rc_keep_cols)
         launch_im2col(rc_act[l], l == 0 ? (size_t)ldDin : (size_t)rcS * rcW * L.ldCin, L.ldCin, L.Cin, rcS, rcW, rcS, L.fw, col, L.ldK, M, s);
       gemm(col, L.ldK, false, d, L.ldCout, false, G.Gd(L.tW), L.ldCout, L.K, L.Cout, (int)M, nullptr, 0, 0.f, false, s);
     }
-    if (!L.bn) launch_colsum_tall(d, L.ldCout, G.Gd(L.tb), (int)M, L.Cout, scratch, scratch_floats, s);
+    if (!L.bn && !db_done) launch_colsum_tall(d, L.ldCout, G.Gd(L.tb), (int)M, L.Cout, scratch, scratch_floats, s);
     if (l > 0) {
       if (rc_ft_bwd[l]) {                        // d(in) = conv_SAME(d, flipped filter): the same implicit-GEMM kernel
         // (the layer below's relu' rides the epilogue: its activations rc_act[l] share the layout of d(in))

@@ -209,7 +209,8 @@ void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const 
 bool conv_wgrad_supported(int C, int N, int S, int W, int fw);
 size_t conv_wgrad_ws_floats(int C, int R, int S, int W, int fw);
 void launch_conv_wgrad(const float* in, int ldc_in, int C, const float* d, int ldc_d, int N, float* dW, int ldw, float* ws, int R, int S,
-                       int W, int fw, hipStream_t s);
+                       int W, int fw, hipStream_t s,
+                       float* db = nullptr /* also the bias gradient colsum(d)[0:N] */);
 // R-CED patch matrix (conv2d SAME as GEMM) and its adjoint; col2im needs C % 4 == 0
 void launch_im2col(const float* src, size_t row_stride, int ldc, int C, int S, int W, int kh, int kw, float* col, int ldk, size_t M,
                    hipStream_t s);
