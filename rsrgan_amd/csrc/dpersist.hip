@@ -127,7 +127,7 @@ __device__ __forceinline__ bool dp_sweep2(const gu64* gm_, unsigned tm, float (&
     else if (!dx) { dp_load12(gx_, lane, x); dx = dp_take(x, tx, vx); }
     if (dm && dx) return true;
     if ((spins & 63) == 63) {
-      if (__builtin_amdgcn_s_memrealtime() - t0 > 3000000ull ||                       // 30 ms at 100 MHz
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull ||                     // 1 s at 100 MHz (a peer that is merely not scheduled yet must not fail the launch)
           __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
     }
   }
@@ -766,6 +766,8 @@ size_t dpersist_granule_bytes(int nl, int N, int T) { return (size_t)2 * nl * (N
 
 bool dpersist_supported(const DPersistArgs& a) {
   if (a.nl < 1 || a.nl > DP_MAXL || a.N % 16 != 0 || a.H != 64 * DP_NQ || a.T < 1) return false;
+  // every workgroup must be resident at once (they wait for each other): at most half of the 256 CUs, one workgroup per CU
+  if (a.nl * (a.N / 16) * DP_NQ > 128) return false;
   for (int l = 0; l < a.nl; ++l) {
     const DPersistLayer& L = a.L[l];
     if (L.P > 16 * DP_KB || L.P % 4 != 0 || L.ldP % 4 != 0 || L.P < 4) return false;

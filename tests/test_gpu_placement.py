@@ -78,7 +78,8 @@ def test_folded_discriminator_forward_agrees():
     assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
 
 
-@pytest.mark.parametrize("B,T,mode", [(16, 9, 1), (16, 9, 2), (16, 9, 3), (64, 100, 3)])
+@pytest.mark.parametrize("B,T,mode", [(16, 9, 1), (16, 9, 2), (16, 9, 3), (64, 100, 3),
+                                      (16, 1, 3), (32, 2, 3), (48, 3, 3)])      # one / two steps; 3 row tiles (clusters across XCDs)
 def test_persistent_discriminator_recurrence_agrees(B, T, mode):
     """csrc/dpersist.hip: the discriminator's recurrences that run alone -- D(G(x)) of the G-run (mode bit 0) and the D-run's BPTT
     (bit 1) -- as ONE persistent launch each (partial products exchanged as generation-tagged granules) against the per-step
@@ -87,7 +88,8 @@ def test_persistent_discriminator_recurrence_agrees(B, T, mode):
     size = {"RSRGAN_TEST_B": str(B), "RSRGAN_TEST_T": str(T)}
     a = _run(dict(size, RSRGAN_DPERSIST=str(mode)))
     b = _run(dict(size, RSRGAN_DPERSIST="0"))
-    assert b["chain_launches"] - a["chain_launches"] >= (T - 1) * (1 if mode < 3 else 2), (a["chain_launches"], b["chain_launches"])
+    if T > 2:
+        assert b["chain_launches"] - a["chain_launches"] >= (T - 1) * (1 if mode < 3 else 2), (a["chain_launches"], b["chain_launches"])
     assert a["device_status"] == 0 and b["device_status"] == 0
     for k in ("d0", "g0", "d1", "g1"):
         assert np.allclose(a[k], b[k], rtol=2e-5, atol=1e-7), (k, a[k], b[k])
