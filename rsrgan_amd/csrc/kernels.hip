@@ -926,7 +926,8 @@ size_t bwd_b_plan(BwdBJobs& jobs, float* ws_base) {
   static int bp_groups = -1;
   if (bp_groups < 0) { const char* e = getenv("RSRGAN_BP_GROUPS"); bp_groups = e ? atoi(e) : 1; }
   if (!bp_groups) for (int i = 0; i < n; ++i) { grouped[i] = false; nx[i] = 8; x0[i] = 0; }
-  constexpr int kpg_target = 24;     // k-blocks per K slice: 24 -> 99 KB LDS (1 WG/CU); 11 / 12 measured slower
+  constexpr int kpg_target = 24;     // k-blocks per K slice: 24 -> 99 KB LDS (1 WG/CU); 11 / 12 measured slower; round 3:
+                                     // 22 / 20 / 19 (243-270 workgroups per generator diagonal) 8.02 / 8.24 / 8.24 ms per step, 27 / 32 7.48 / 7.50, 24 7.48
   for (int i = 0; i < n; ++i) {
     BwdBJob& b = jobs.j[i];
     const int nkb = (b.H4 + 15) >> 4, ncols = b.n_end - b.n_begin;
