@@ -188,16 +188,22 @@ int SeganModel::init(const rsrgan_segan_cfg& c, uint64_t seed) {
 }
 
 void SeganModel::refresh_weights(int net, hipStream_t s) {
+  PrepTconvList pl{};
+  auto add = [&](const float* W, int ldw, int nb, int na, int e, int ne, float* dst, int ldd) {
+    if (pl.n == 44) { launch_prep_tconv_many(pl, s); pl.n = 0; }
+    pl.j[pl.n++] = PrepTconvJob{W, dst, ldw, nb, na, e, ne, ldd};
+  };
   auto prep_down = [&](const ParamSet& ps, SgLayer& L) {   // data gradient of a downconv: Wt[(rr, co)][ci] = W[dk][ci][co]
-    for (int e = 0; e < 2; ++e) launch_prep_tconv(ps.W(L.tW), ps.t[L.tW].ld, L.Cin, L.Cout, e, L.ne[e], L.Wt[e], pad4(L.Cin), s);
+    for (int e = 0; e < 2; ++e) add(ps.W(L.tW), ps.t[L.tW].ld, L.Cin, L.Cout, e, L.ne[e], L.Wt[e], pad4(L.Cin));
   };
   if (net == RSRGAN_NET_G) {
     for (int i = 1; i < n; ++i) prep_down(G, enc[i]);
     for (int j = 0; j < n - 1; ++j)                        // deconv forward: Wt[(rr, ci)][co] = W[dk][co][ci]
-      for (int e = 0; e < 2; ++e) launch_prep_tconv(G.W(dec[j].tW), G.t[dec[j].tW].ld, dec[j].Cout, dec[j].Cin, e, dec[j].ne[e], dec[j].Wt[e], pad4(dec[j].Cout), s);
+      for (int e = 0; e < 2; ++e) add(G.W(dec[j].tW), G.t[dec[j].tW].ld, dec[j].Cout, dec[j].Cin, e, dec[j].ne[e], dec[j].Wt[e], pad4(dec[j].Cout));
   } else {
     for (int i = 1; i < n; ++i) prep_down(D, blk[i]);
   }
+  launch_prep_tconv_many(pl, s);
 }
 
 // ---- primitives

@@ -21,6 +21,9 @@ void launch_tconv1(const float* S, int lds, int B, int Ls, int C, int Lt, int k,
                    hipStream_t s);
 void launch_sum_all(const float* src, int rows, int cols, int ld, float* out, float* scratch, hipStream_t s);
 void launch_prep_tconv(const float* W, int ldw, int nb, int na, int e, int ne, float* dst, int ldd, hipStream_t s);
+struct PrepTconvJob { const float* W; float* dst; int ldw, nb, na, e, ne, ldd; };
+struct PrepTconvList { int n; int first[44]; PrepTconvJob j[44]; };      // <= 2 operands x 22 layers per launch (kernel argument: < 4 KB)
+void launch_prep_tconv_many(PrepTconvList& pl, hipStream_t s);
 void launch_interleave(const float* T0, const float* T1, int Q0, int Q1, int i00, int i01, int pl, const float* bias, float* T, int B, int Lt, int C,
                        hipStream_t s);
 void launch_act_fwd(const float* z, int C, const float* alpha, float leak, float* out, int ldo, int coff, size_t rows, hipStream_t s);

@@ -171,6 +171,30 @@ void launch_prep_tconv(const float* W, int ldw, int nb, int na, int e, int ne, f
   const size_t n = (size_t)ne * na * nb;
   hipLaunchKernelGGL(k_prep_tconv, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, W, ldw, nb, na, e, ne, dst, ldd);
 }
+// every parity-class operand of a net in ONE launch (a weight refresh used to be 40 + 20 launches of 2-60 us)
+__global__ __launch_bounds__(256) void k_prep_tconv_many(const PrepTconvList pl) {
+  int j = 0;
+  while (j + 1 < pl.n && (int)blockIdx.x >= pl.first[j + 1]) ++j;
+  const PrepTconvJob J = pl.j[j];
+  const size_t n = (size_t)J.ne * J.na * J.nb;
+  const int nblk = (j + 1 < pl.n ? pl.first[j + 1] : (int)gridDim.x) - pl.first[j];
+  for (size_t i = ((size_t)blockIdx.x - pl.first[j]) * 256 + threadIdx.x; i < n; i += (size_t)nblk * 256) {
+    const int b = (int)(i % J.nb);
+    const size_t ra = i / J.nb;
+    const int a = (int)(ra % J.na), rr = (int)(ra / J.na);
+    const int dk = 2 * (J.ne - 1 - rr) + J.e;
+    J.dst[ra * J.ldd + b] = J.W[((size_t)dk * J.nb + b) * J.ldw + a];
+  }
+}
+void launch_prep_tconv_many(PrepTconvList& pl, hipStream_t s) {
+  int blocks = 0;
+  for (int j = 0; j < pl.n; ++j) {
+    pl.first[j] = blocks;
+    const size_t n = (size_t)pl.j[j].ne * pl.j[j].na * pl.j[j].nb;
+    blocks += (int)std::min<size_t>((n + 255) / 256, 4096);
+  }
+  if (blocks) hipLaunchKernelGGL(k_prep_tconv_many, dim3(blocks), dim3(256), 0, s, pl);
+}
 
 // ---- T[b,i,:] = T_e[b, (i - i0_e) / 2, :] + bias, e = (i + pl) & 1: the two parity classes of a transposed convolution back in position order
 __global__ __launch_bounds__(256) void k_interleave(const float* __restrict__ T0, const float* __restrict__ T1, int Q0, int Q1, int i00, int i01, int pl,
