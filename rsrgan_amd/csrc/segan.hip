@@ -173,25 +173,35 @@ void launch_prep_tconv(const float* W, int ldw, int nb, int na, int e, int ne, f
 }
 // every parity-class operand of a net in ONE launch (a weight refresh used to be 40 + 20 launches of 2-60 us)
 __global__ __launch_bounds__(256) void k_prep_tconv_many(const PrepTconvList pl) {
+  // block = one 32 (a) x 32 (b) tile of one tap rr of one job, transposed through LDS: reads run along a (contiguous in W), writes
+  // along b (contiguous in dst).  (Thread-per-element with b fastest read W with a stride of ldw floats: 60 us for the 512 x 1024 layer.)
+  __shared__ float tile[32][33];
   int j = 0;
   while (j + 1 < pl.n && (int)blockIdx.x >= pl.first[j + 1]) ++j;
   const PrepTconvJob J = pl.j[j];
-  const size_t n = (size_t)J.ne * J.na * J.nb;
-  const int nblk = (j + 1 < pl.n ? pl.first[j + 1] : (int)gridDim.x) - pl.first[j];
-  for (size_t i = ((size_t)blockIdx.x - pl.first[j]) * 256 + threadIdx.x; i < n; i += (size_t)nblk * 256) {
-    const int b = (int)(i % J.nb);
-    const size_t ra = i / J.nb;
-    const int a = (int)(ra % J.na), rr = (int)(ra / J.na);
-    const int dk = 2 * (J.ne - 1 - rr) + J.e;
-    J.dst[ra * J.ldd + b] = J.W[((size_t)dk * J.nb + b) * J.ldw + a];
+  const int ta = (J.na + 31) / 32, tb = (J.nb + 31) / 32;
+  int t = (int)blockIdx.x - pl.first[j];
+  const int rr = t / (ta * tb); t -= rr * ta * tb;
+  const int a0 = (t / tb) * 32, b0 = (t % tb) * 32;
+  const int dk = 2 * (J.ne - 1 - rr) + J.e;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int b = b0 + ty + 8 * k, a = a0 + tx;
+    tile[ty + 8 * k][tx] = (b < J.nb && a < J.na) ? J.W[((size_t)dk * J.nb + b) * J.ldw + a] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int a = a0 + ty + 8 * k, b = b0 + tx;
+    if (a < J.na && b < J.nb) J.dst[((size_t)rr * J.na + a) * J.ldd + b] = tile[tx][ty + 8 * k];
   }
 }
 void launch_prep_tconv_many(PrepTconvList& pl, hipStream_t s) {
   int blocks = 0;
   for (int j = 0; j < pl.n; ++j) {
     pl.first[j] = blocks;
-    const size_t n = (size_t)pl.j[j].ne * pl.j[j].na * pl.j[j].nb;
-    blocks += (int)std::min<size_t>((n + 255) / 256, 4096);
+    blocks += pl.j[j].ne * ((pl.j[j].na + 31) / 32) * ((pl.j[j].nb + 31) / 32);
   }
   if (blocks) hipLaunchKernelGGL(k_prep_tconv_many, dim3(blocks), dim3(256), 0, s, pl);
 }
