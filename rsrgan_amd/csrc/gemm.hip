@@ -516,18 +516,42 @@ __global__ __launch_bounds__(256) void k_gemm_fixup(const GemmArgs g) {
     for (int j = 0; j < CT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  for (int w = wa; w <= wb; ++w) {
-    const int slot = 2 * w + (worker_lo(g, w) / g.NK == ts ? 0 : 1);
-    const float4* q = reinterpret_cast<const float4*>(g.ws) + (size_t)slot * (RT * CT * 4 * 256) + tid;
+  // pieces in k order, TWO in flight when the tile is small enough to hold them in registers (a tile of a long-K product is cut into
+  // 3-10 pieces: one dependent round trip per piece made this launch 20 us in the SEGAN step); the sums keep their order
+  constexpr int NQ4 = RT * CT * 4;
+  constexpr bool PAIR = NQ4 <= 16;
+  auto slot_of = [&](int w) { return 2 * w + (worker_lo(g, w) / g.NK == ts ? 0 : 1); };
+  for (int w = wa; w <= wb; w += PAIR ? 2 : 1) {
+    const float4* q0 = reinterpret_cast<const float4*>(g.ws) + (size_t)slot_of(w) * (NQ4 * 256) + tid;
+    const bool two = PAIR && w + 1 <= wb;
+    const float4* q1 = reinterpret_cast<const float4*>(g.ws) + (size_t)slot_of(two ? w + 1 : w) * (NQ4 * 256) + tid;
+    float4 v0[NQ4], v1[PAIR ? NQ4 : 1];
+#pragma unroll
+    for (int x = 0; x < NQ4; ++x) v0[x] = q0[x * 256];
+    if (PAIR) {
+#pragma unroll
+      for (int x = 0; x < NQ4; ++x) v1[x] = q1[x * 256];             // (unconditional: the last odd piece is read twice, added once)
+    }
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
       for (int j = 0; j < CT; ++j)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-          const float4 v = q[((i * CT + j) * 4 + r4) * 256];
+          const float4 v = v0[(i * CT + j) * 4 + r4];
           acc[i][j][4 * r4] += v.x; acc[i][j][4 * r4 + 1] += v.y; acc[i][j][4 * r4 + 2] += v.z; acc[i][j][4 * r4 + 3] += v.w;
         }
+    if (PAIR && two) {
+#pragma unroll
+      for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const float4 v = v1[(i * CT + j) * 4 + r4];
+            acc[i][j][4 * r4] += v.x; acc[i][j][4 * r4 + 1] += v.y; acc[i][j][4 * r4 + 2] += v.z; acc[i][j][4 * r4 + 3] += v.w;
+          }
+    }
   }
   const int t = g.n_dp + ts;
   int tm, tn;
