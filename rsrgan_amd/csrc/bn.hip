@@ -180,6 +180,137 @@ __global__ __launch_bounds__(256) void k_bn_bwd3(float* __restrict__ dy, int ldd
   }
 }
 
+// ---- tall narrow activations (the R-CED feature maps: 1.6 M positions x 12-32 channels, leading dimension = the padded channel
+// count) ----  The wide kernels above give a column to a lane: with 12-32 columns most lanes of a wave idle and every load is 4 bytes
+// (0.3 TB/s).  Here the matrix is one dense run of 16-byte quads: a thread keeps ONE quad column (its per-column constants live in
+// registers) and walks rows, 256/(ld/4) rows per workgroup pass, four rows in flight.  Partials keep the [slice][2][cols] layout, so
+// k_bn_stats2 / k_bn_bwd2 finish them unchanged; the order of every sum is fixed by (rows, ld, slices).
+__device__ __forceinline__ float4 bn_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_bn_part_narrow(const float* __restrict__ z, const float* __restrict__ dy, const float* __restrict__ y,
+                                                        const float* __restrict__ stat, int ldc, int ld, int rows, int cols, int per, int relu,
+                                                        float* __restrict__ scratch) {
+  __shared__ float red[2][256][4];
+  const int q = ld >> 2, R = 256 / q, t = threadIdx.x, rr = t / q, cq = t - rr * q;
+  const int rbeg = blockIdx.x * per, rend = min(rows, rbeg + per);
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (rr < R) {
+    float4 m, k;                               // forward: m = the call's first row (the shift); backward: m = mean, k = 1/stddev
+    if (BWD) {
+      m = bn_ld4(stat + cq * 4);
+      const float4 sd = bn_ld4(stat + ldc + cq * 4);
+      k = make_float4(1.f / sd.x, 1.f / sd.y, 1.f / sd.z, 1.f / sd.w);
+    } else {
+      m = bn_ld4(z + cq * 4); k = m;
+    }
+    const size_t step = (size_t)R * ld;
+    const float* pz = z + (size_t)(rbeg + rr) * ld + cq * 4;
+    const float* pd = BWD ? dy + (size_t)(rbeg + rr) * ld + cq * 4 : pz;
+    const float* py = BWD ? y + (size_t)(rbeg + rr) * ld + cq * 4 : pz;
+    auto acc = [&](float4 zv, float4 g, float4 yv) {
+      if (BWD) {
+        if (relu) { g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f; }
+        s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
+        s2.x += g.x * ((zv.x - m.x) * k.x); s2.y += g.y * ((zv.y - m.y) * k.y);
+        s2.z += g.z * ((zv.z - m.z) * k.z); s2.w += g.w * ((zv.w - m.w) * k.w);
+      } else {
+        const float vx = zv.x - m.x, vy = zv.y - m.y, vz = zv.z - m.z, vw = zv.w - m.w;
+        s1.x += vx; s1.y += vy; s1.z += vz; s1.w += vw;
+        s2.x += vx * vx; s2.y += vy * vy; s2.z += vz * vz; s2.w += vw * vw;
+      }
+    };
+    int r = rbeg + rr;
+    for (; r + 3 * R < rend; r += 4 * R) {
+      float4 zv[4], gv[4], yv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        zv[u] = bn_ld4(pz + u * step);
+        if (BWD) { gv[u] = bn_ld4(pd + u * step); yv[u] = relu ? bn_ld4(py + u * step) : zv[u]; } else { gv[u] = zv[u]; yv[u] = zv[u]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc(zv[u], gv[u], yv[u]);
+      pz += 4 * step; pd += 4 * step; py += 4 * step;
+    }
+    for (; r < rend; r += R) {
+      const float4 zv = bn_ld4(pz);
+      acc(zv, BWD ? bn_ld4(pd) : zv, BWD && relu ? bn_ld4(py) : zv);
+      pz += step; pd += step; py += step;
+    }
+  }
+  *reinterpret_cast<float4*>(red[0][t]) = s1; *reinterpret_cast<float4*>(red[1][t]) = s2;
+  __syncthreads();
+  if (t < 2 * ld) {
+    const int which = t / ld, c = t - which * ld;
+    if (c < cols) {
+      float sum = 0.f;
+      for (int i = 0; i < R; ++i) sum += red[which][i * q + (c >> 2)][c & 3];
+      scratch[((size_t)blockIdx.x * 2 + which) * cols + c] = sum;
+    }
+  }
+}
+
+// y = relu(z*a + b) (forward) / dz in place over dy (backward) on the same (row lane, quad column) decomposition
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_bn_elem_narrow(const float* __restrict__ z, float* __restrict__ out, const float* __restrict__ y,
+                                                        const float* __restrict__ stat, int ldc, const float* __restrict__ sums, int ld, int rows,
+                                                        int relu) {
+  const int q = ld >> 2, R = 256 / q, t = threadIdx.x, rr = t / q, cq = t - rr * q;
+  if (rr >= R) return;
+  const float4 a = bn_ld4(stat + 4 * ldc + cq * 4);
+  float4 b, mean, isd, m1, m2;
+  if (BWD) {
+    mean = bn_ld4(stat + cq * 4);
+    const float4 sd = bn_ld4(stat + ldc + cq * 4);
+    // (padding columns carry stddev = 0 and a = 0: they must come out as 0, not NaN)
+    isd = make_float4(sd.x > 0.f ? 1.f / sd.x : 0.f, sd.y > 0.f ? 1.f / sd.y : 0.f, sd.z > 0.f ? 1.f / sd.z : 0.f, sd.w > 0.f ? 1.f / sd.w : 0.f);
+    m1 = bn_ld4(sums + cq * 4); m2 = bn_ld4(sums + ldc + cq * 4);
+    b = a;
+  } else {
+    b = bn_ld4(stat + 5 * ldc + cq * 4);
+    mean = isd = m1 = m2 = a;
+  }
+  auto one = [&](float4 zv, float4 g, float4 yv) {
+    float4 o;
+    if (BWD) {
+      if (relu) { g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f; g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f; }
+      o.x = a.x * (g.x - m1.x - (zv.x - mean.x) * isd.x * m2.x);
+      o.y = a.y * (g.y - m1.y - (zv.y - mean.y) * isd.y * m2.y);
+      o.z = a.z * (g.z - m1.z - (zv.z - mean.z) * isd.z * m2.z);
+      o.w = a.w * (g.w - m1.w - (zv.w - mean.w) * isd.w * m2.w);
+    } else {
+      o = make_float4(zv.x * a.x + b.x, zv.y * a.y + b.y, zv.z * a.z + b.z, zv.w * a.w + b.w);
+      if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+    }
+    return o;
+  };
+  const size_t gstep = (size_t)gridDim.x * R;                 // rows between two passes of this thread
+  size_t r = (size_t)blockIdx.x * R + rr;
+  for (; r + 3 * gstep < (size_t)rows; r += 4 * gstep) {
+    float4 zv[4], gv[4], yv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t o = (r + u * gstep) * ld + cq * 4;
+      zv[u] = bn_ld4(z + o);
+      if (BWD) { gv[u] = bn_ld4(out + o); yv[u] = relu ? bn_ld4(y + o) : zv[u]; } else { gv[u] = zv[u]; yv[u] = zv[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(out + (r + u * gstep) * ld + cq * 4) = one(zv[u], gv[u], yv[u]);
+  }
+  for (; r < (size_t)rows; r += gstep) {
+    const size_t o = r * ld + cq * 4;
+    const float4 zv = bn_ld4(z + o);
+    *reinterpret_cast<float4*>(out + o) = one(zv, BWD ? bn_ld4(out + o) : zv, BWD && relu ? bn_ld4(y + o) : zv);
+  }
+}
+
+static bool bn_narrow(int rows, int cols, int l0, int l1, int l2) {
+  static int minrows = -1;                 // RSRGAN_BN_NARROW: least row count that takes this form (0 = never; tests set 1)
+  if (minrows < 0) { const char* e = getenv("RSRGAN_BN_NARROW"); minrows = e ? std::max(0, atoi(e)) : 4096; }
+  const int ld = (cols + 3) & ~3;
+  return minrows > 0 && ld <= 64 && rows >= minrows && l0 == ld && l1 == ld && l2 == ld;
+}
+
 // UPDATE_OPS of one call, `times` times: assign_moving_average(v, value, decay, zero_debias=False) is v -= (v - value)*(1 - decay).
 // One workgroup per layer: every thread reads the two scalar weights before thread 0 rewrites them.
 __global__ __launch_bounds__(256) void k_bn_commit(int cols, BnVars v, const float* __restrict__ stat, int ldc, int times) {
@@ -346,6 +477,11 @@ void launch_bn_commit_many(const BnCommitList& cl, hipStream_t s) {
   if (cl.n > 0) hipLaunchKernelGGL(k_bn_commit_many, dim3(cl.n), dim3(256), 0, s, cl);
 }
 
+static int bn_narrow_grid(int rows, int ld) {          // four rows per thread and pass, at most 8192 workgroups
+  const int R = 256 / (ld >> 2);
+  return std::max(1, std::min(8192, (rows + 4 * R - 1) / (4 * R)));
+}
+
 static int bn_slices(int rows, int cols, size_t scratch_floats, int* per) {
   int slices = (int)std::min<size_t>(512, scratch_floats / ((size_t)2 * std::max(cols, 1)));
   slices = std::max(1, std::min(slices, (rows + 63) / 64));
@@ -367,7 +503,10 @@ void launch_bn_forward(const float* z, int ldz, float* y, int ldy, int rows, int
   if (training) {
     int per;
     const int slices = bn_slices(rows, cols, scratch_floats, &per);
-    hipLaunchKernelGGL(k_bn_stats1, dim3((cols + 63) / 64, slices), dim3(256), 0, s, z, ldz, rows, cols, per, scratch);
+    if (bn_narrow(rows, cols, ldz, ldy, ldz))
+      hipLaunchKernelGGL(k_bn_part_narrow<false>, dim3(slices), dim3(256), 0, s, z, nullptr, nullptr, nullptr, 0, ldz, rows, cols, per, 0, scratch);
+    else
+      hipLaunchKernelGGL(k_bn_stats1, dim3((cols + 63) / 64, slices), dim3(256), 0, s, z, ldz, rows, cols, per, scratch);
     hipLaunchKernelGGL(k_bn_stats2, dim3((cols + 63) / 64), dim3(256), 0, s, scratch, slices, z, rows, cols, v, stat, ldc);
   } else {
     hipLaunchKernelGGL(k_bn_infer_coef, dim3((cols + 255) / 256), dim3(256), 0, s, cols, v, stat, ldc);
@@ -375,6 +514,11 @@ void launch_bn_forward(const float* z, int ldz, float* y, int ldy, int rows, int
   const int cp = (cols + 3) & ~3;
   const size_t n = (size_t)rows * (cp >> 2);
   const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  if (bn_narrow(rows, cols, ldz, ldy, ldz)) {
+    hipLaunchKernelGGL(k_bn_elem_narrow<false>, dim3(bn_narrow_grid(rows, ldz)), dim3(256), 0, s, z, y, nullptr, stat, ldc, nullptr, ldz, rows,
+                       relu ? 1 : 0);
+    return;
+  }
   hipLaunchKernelGGL(k_bn_apply, dim3(grid), dim3(256), 0, s, z, ldz, y, ldy, (size_t)rows, cp, stat + 4 * ldc, stat + 5 * ldc, relu ? 1 : 0);
 }
 
@@ -398,13 +542,21 @@ void launch_bn_backward(float* dy, int ldd, const float* y, int ldy, const float
   }
   int per;
   const int slices = bn_slices(rows, cols, scratch_floats, &per);
-  hipLaunchKernelGGL(k_bn_bwd1, dim3((cols + 63) / 64, slices), dim3(256), 0, s, dy, ldd, y, ldy, z, ldz, stat, ldc, rows, cols, per,
-                     relu ? 1 : 0, scratch);
+  const bool narrow = bn_narrow(rows, cols, ldd, ldy, ldz);
+  if (narrow)
+    hipLaunchKernelGGL(k_bn_part_narrow<true>, dim3(slices), dim3(256), 0, s, z, dy, y, stat, ldc, ldz, rows, cols, per, relu ? 1 : 0, scratch);
+  else
+    hipLaunchKernelGGL(k_bn_bwd1, dim3((cols + 63) / 64, slices), dim3(256), 0, s, dy, ldd, y, ldy, z, ldz, stat, ldc, rows, cols, per,
+                       relu ? 1 : 0, scratch);
   hipLaunchKernelGGL(k_bn_bwd2, dim3((cols + 63) / 64), dim3(256), 0, s, scratch, slices, rows, cols, stat, ldc, dbeta, dgamma,
                      accumulate ? 1 : 0, sums);
   const int cp = (cols + 3) & ~3;
   const size_t n = (size_t)rows * (cp >> 2);
   const int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  if (narrow) {
+    hipLaunchKernelGGL(k_bn_elem_narrow<true>, dim3(bn_narrow_grid(rows, ldz)), dim3(256), 0, s, z, dy, y, stat, ldc, sums, ldz, rows, relu ? 1 : 0);
+    return;
+  }
   hipLaunchKernelGGL(k_bn_bwd3, dim3(grid), dim3(256), 0, s, dy, ldd, y, ldy, z, ldz, stat, ldc, sums, (size_t)rows, cp, relu ? 1 : 0);
 }
 

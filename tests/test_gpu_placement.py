@@ -183,3 +183,14 @@ def test_wide_output_small_generator_with_reference_discriminator():
         assert np.allclose(d_hip, d_ref, rtol=1e-3), (d_hip, d_ref)
         assert np.allclose(g_hip, g_ref, rtol=1e-3), (g_hip, g_ref)
     assert model.engine.device_status() == 0
+
+
+def test_rced_batch_norm_narrow_kernels_match_oracle():
+    """csrc/bn.hip k_bn_part_narrow / k_bn_elem_narrow (the form the R-CED feature maps take from 4096 positions on): the oracle
+    parity cases of tests/test_gpu_trainers.py::test_rced_batch_norm_matches_oracle are a few hundred positions, so they run here
+    once more in a process where every eligible call takes the narrow form (RSRGAN_BN_NARROW = least row count)."""
+    e = dict(os.environ); e["RSRGAN_BN_NARROW"] = "1"
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_trainers.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "rced_batch_norm_matches_oracle", "-p", "no:cacheprovider"], capture_output=True, text=True, env=e, cwd=ROOT, timeout=900)
+    assert p.returncode == 0, (p.stdout[-3000:], p.stderr[-1000:])
+    assert "4 passed" in p.stdout, p.stdout[-500:]
