@@ -220,6 +220,13 @@ int rsrgan_profile_read(rsrgan_handle h, int32_t* launches, double* total_us, do
  * A failed launch has already poisoned its step's losses with NaN; nothing in the reference corresponds to this. */
 int rsrgan_device_status(rsrgan_handle h, int32_t* code);
 
+/* tf.nn.dropout(h, keep_prob) after every hidden ReLU of the frame-level nets (models/dnn.py:86,99,116-121 and
+ * models/discriminator_dnn.py:68,81,100-105; `--keep_prob` of scripts/train_gan_dnn.py).  0 < keep_prob <= 1.  As in the
+ * reference it only acts in training runs with l2_scale > 0 (dnn.py:67-71 resets keep_prob to 1.0 otherwise).  `seed` selects
+ * the mask stream (give every rank its own); masks change with every training run.  RSRGAN_ERR_INVALID on the sequence model
+ * (its DropoutWrapper, models/lstm.py:99-102, is not built) unless keep_prob == 1. */
+int rsrgan_set_dropout(rsrgan_handle h, float keep_prob, uint64_t seed);
+
 /* launches of the recurrence kernels (gates / projection / backward A, B, B-reduce) the host issued since rsrgan_profile_begin: with the
  * floor of a dependent launch (rsrgan_op_launch_floor) this is the serial-recurrence latency bound SURVEY 8d asks bench.py to report */
 int rsrgan_profile_launches(rsrgan_handle h, int64_t* n);

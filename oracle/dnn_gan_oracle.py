@@ -9,6 +9,12 @@ generator models/dnn.py:DNN and discriminator models/discriminator_dnn.py.
 relu(batch_norm(x.W)) without a bias (contrib fully_connected drops `biases` when a normalizer_fn is given); the
 normaliser and the order of its state updates are restated in oracle/bn_renorm.py.
 
+`keep_prob < 1` (dnn.py:86,99,116-121; discriminator_dnn.py:68,81,100-105): tf.nn.dropout after every hidden ReLU of both
+nets, y = x / keep_prob * mask (TF 1.4 nn_ops.dropout: `math_ops.div(x, keep_prob) * binary_tensor`), active only when
+l2_scale > 0 and is_training (dnn.py:67-71 / discriminator_dnn.py:47-51 reset keep_prob to 1.0 otherwise).  TF's random stream
+cannot be reproduced, so the MASKS ARE AN INPUT of this oracle: `mask_fn(run, net, layer, call, rows, cols)` -> {0,1} array, with
+run = index of the training sess.run (1, 2, ...), net 0 = G / 1 = D, call 0 = D on the real joint / 1 = D on the fake joint.
+
 Restated graph (batch_norm=False, keep_prob=1.0):
   G (dnn.py:79-110)              : 1+3 = 4 x [FC 1024, ReLU], FC -> output_dim (linear)
   d_inputs (gan.py:158-160)      : inputs[:, input_dim*left_context : +input_dim]   (centre frame)
@@ -100,9 +106,11 @@ def trainable(name):
     return not bn.is_state(name)
 
 
-def fc_stack_fwd(P, prefix, n_layers, x, training=True):
+def fc_stack_fwd(P, prefix, n_layers, x, training=True, drop=None):
     """n_layers FC layers, ReLU on all but the last.  Returns (y, acts) with acts[l] = input of layer l; a hidden layer with
-    `<name>/BatchNorm/*` variables is relu(batch_norm(x.W)) and acts carries its cache in acts.bn[l]."""
+    `<name>/BatchNorm/*` variables is relu(batch_norm(x.W)) and acts carries its cache in acts.bn[l].
+    drop = (keep_prob, mask_of_layer(layer, rows, cols)) or None: tf.nn.dropout on every hidden output; acts.drop[l] keeps
+    (relu output, mask) of layer l."""
     acts = _Acts([x])
     for i, n in enumerate(_fc_names(prefix, n_layers)):
         if n + "/BatchNorm/beta" in P:
@@ -114,7 +122,16 @@ def fc_stack_fwd(P, prefix, n_layers, x, training=True):
                 z = bn.forward_infer(P, n, z)
         else:
             z = acts[-1] @ P[n + "/weights"] + P[n + "/biases"]
-        acts.append(np.maximum(z, 0.0) if i < n_layers - 1 else z)
+        if i < n_layers - 1:
+            h = np.maximum(z, 0.0)
+            if drop is not None:
+                keep, mask_of = drop
+                m = np.asarray(mask_of(i, h.shape[0], h.shape[1]), h.dtype)
+                acts.drop[i] = (h, m, keep)
+                h = h / keep * m
+            acts.append(h)
+        else:
+            acts.append(z)
     return acts[-1], acts
 
 
@@ -122,6 +139,7 @@ class _Acts(list):
     def __init__(self, it):
         super().__init__(it)
         self.bn = {}
+        self.drop = {}
 
 
 def fc_stack_bwd(P, prefix, n_layers, acts, dy, want_dx=True):
@@ -130,7 +148,11 @@ def fc_stack_bwd(P, prefix, n_layers, acts, dy, want_dx=True):
     names = _fc_names(prefix, n_layers)
     for i in range(n_layers - 1, -1, -1):
         if i < n_layers - 1:
-            d = d * (acts[i + 1] > 0)
+            dr = getattr(acts, "drop", {}).get(i)
+            if dr is not None:                       # gradient of div(x, keep) * mask, then the ReLU on its own output
+                d = d * dr[1] / dr[2] * (dr[0] > 0)
+            else:
+                d = d * (acts[i + 1] > 0)
         cache = getattr(acts, "bn", {}).get(i)
         if cache is not None:
             d, gb = bn.backward_train(P, cache, d)
@@ -150,8 +172,8 @@ def bn_commit(P, acts, times=1):
             bn.commit(P, acts.bn[i])
 
 
-def d_forward(cfg, Pd, joint, training=True):
-    raw, acts = fc_stack_fwd(Pd, "d_model", cfg.d_hidden + 1, joint, training)
+def d_forward(cfg, Pd, joint, training=True, drop=None):
+    raw, acts = fc_stack_fwd(Pd, "d_model", cfg.d_hidden + 1, joint, training, drop)
     return np.clip(raw, cfg.clip_lo, cfg.clip_hi), raw, acts
 
 
@@ -164,8 +186,9 @@ class GanDnnOracle:
     """models/gan.py:GAN on one tower (every tower receives the same batch there, gan.py:136)."""
 
     def __init__(self, cfg: DnnCfg, g, d, *, g_learning_rate=1e-4, d_learning_rate=1e-4, mse_lambda=10.0, l2_scale=0.0,
-                 cross_validation=False, dtype=np.float64):
+                 cross_validation=False, dtype=np.float64, keep_prob=1.0, mask_fn=None):
         self.cfg, self.dtype = cfg, dtype
+        self.keep_prob, self.mask_fn, self._run = keep_prob, mask_fn, 0
         self.g = {k: np.array(v, dtype) for k, v in g.items()}
         self.d = {k: np.array(v, dtype) for k, v in d.items()}
         self.g_learning_rate, self.d_learning_rate = g_learning_rate, d_learning_rate
@@ -188,9 +211,17 @@ class GanDnnOracle:
         cv_model), so they normalise with the moving statistics too and carry no L2 term (gan.py:207)."""
         return not self.cross_validation and not self._eval_call
 
+    def _drop(self, net, call=0):
+        """(keep_prob, mask_of_layer) of one forward call of this run, or None: dropout only acts when l2_scale > 0 and
+        is_training (dnn.py:67-71, discriminator_dnn.py:47-51)."""
+        if not (self.keep_prob < 1.0 and self.l2_scale > 0 and not self.cross_validation and not self._eval_call):
+            return None
+        run = self._run
+        return self.keep_prob, (lambda layer, rows, cols: self.mask_fn(run, net, layer, call, rows, cols))
+
     # generator hooks (overridden by oracle/rced_oracle.py for the R-CED generator)
     def _g_fwd(self, x):
-        return fc_stack_fwd(self.g, "g_model", self.cfg.g_hidden + 1, x, self.training)
+        return fc_stack_fwd(self.g, "g_model", self.cfg.g_hidden + 1, x, self.training, self._drop(0))
 
     def _g_bwd(self, cache, dy):
         return fc_stack_bwd(self.g, "g_model", self.cfg.g_hidden + 1, cache, dy, want_dx=False)[1]
@@ -214,12 +245,13 @@ class GanDnnOracle:
 
     def d_tower(self, x, lab, want_grads=True):
         cfg = self.cfg
+        self._run += 1 if want_grads else 0                      # every training sess.run draws new dropout masks
         x, lab = np.asarray(x, self.dtype), np.asarray(lab, self.dtype)
         y, gacts = self._g_fwd(x)
         di = self._d_inputs(x)
         losses, grads, dacts = [], None, []
-        for joint, target in ((np.concatenate([di, lab], 1), 1.0), (np.concatenate([di, y], 1), 0.0)):
-            out, raw, acts = d_forward(cfg, self.d, joint, self.training)
+        for call, (joint, target) in enumerate(((np.concatenate([di, lab], 1), 1.0), (np.concatenate([di, y], 1), 0.0))):
+            out, raw, acts = d_forward(cfg, self.d, joint, self.training, self._drop(1, call))
             dacts.append(acts)
             diff = out - target
             losses.append(float(np.mean(diff * diff)))
@@ -233,6 +265,7 @@ class GanDnnOracle:
 
     def g_tower(self, x, lab, want_grads=True):
         cfg = self.cfg
+        self._run += 1 if want_grads else 0
         x, lab = np.asarray(x, self.dtype), np.asarray(lab, self.dtype)
         y, gacts = self._g_fwd(x)
         supervised = getattr(self, "supervised", False)          # models/dnn_trainer.py:139-148: g_loss = g_mse + g_l2
@@ -240,11 +273,11 @@ class GanDnnOracle:
         if supervised:
             g_adv = 0.0
         else:
-            out, raw, dacts = d_forward(cfg, self.d, np.concatenate([self._d_inputs(x), y], 1), self.training)
+            out, raw, dacts = d_forward(cfg, self.d, np.concatenate([self._d_inputs(x), y], 1), self.training, self._drop(1, 1))
             diff = out - 1.0
             g_adv = float(np.mean(diff * diff))
             if want_grads and self.training and cfg.batch_norm:      # the real-joint call only contributes its update ops here
-                d_real_acts = d_forward(cfg, self.d, np.concatenate([self._d_inputs(x), lab], 1), True)[2]
+                d_real_acts = d_forward(cfg, self.d, np.concatenate([self._d_inputs(x), lab], 1), True, self._drop(1, 0))[2]
         e = y - lab
         g_mse = float(0.5 * np.mean(e * e) * cfg.output_dim)
         if self.training and self.l2_scale > 0:

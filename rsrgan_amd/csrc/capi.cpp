@@ -298,6 +298,14 @@ int rsrgan_profile_begin(rsrgan_handle h) {
   g_chain_launches = 0;
   return RSRGAN_OK;
 }
+int rsrgan_set_dropout(rsrgan_handle h, float keep_prob, uint64_t seed) {
+  CHECK_H(h);
+  if (!(keep_prob > 0.f && keep_prob <= 1.f)) { set_error("keep_prob=%g outside (0, 1]", (double)keep_prob); return RSRGAN_ERR_INVALID; }
+  if (keep_prob < 1.f && !h->m.g_dnn()) { set_error("dropout is built for the frame-level nets only"); return RSRGAN_ERR_INVALID; }
+  h->m.keep_prob = keep_prob; h->m.drop_seed = seed; h->m.drop_run = 0;
+  return RSRGAN_OK;
+}
+
 int rsrgan_device_status(rsrgan_handle h, int32_t* code) {
   CHECK_H(h);
   if (!code) { set_error("null output pointer"); return RSRGAN_ERR_INVALID; }

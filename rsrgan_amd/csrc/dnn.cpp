@@ -26,18 +26,36 @@ BnVars Model::bn_vars(const ParamSet& ps, const int (&tbn)[8]) const {
 }
 BnVars Model::bn_vars(const ParamSet& ps, const FcLayer& F) const { return bn_vars(ps, F.tbn); }
 
-void Model::fc_forward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, hipStream_t s, int calls) {
+static inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+uint64_t Model::drop_key(int net, int layer, int call) const {
+  return splitmix64(splitmix64(drop_seed ^ (drop_run * 0xD1342543DE82EF95ull)) + (uint64_t)((net << 16) | (layer << 8) | call));
+}
+
+void Model::fc_forward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, hipStream_t s, int calls,
+                       int call0) {
+  const bool drop = drop_training();
   for (size_t l = 0; l < L.size(); ++l) {
     const FcLayer& F = L[l];
     if (!F.bn) {
       gemm(act[l], F.ld_in, true, ps.W(F.tW), F.ld_out, false, act[l + 1], F.ld_out, rows, F.out, F.in,
            ps.W(F.tb), l + 1 < L.size() ? 2 : 0, 0.f, false, s);
-      continue;
+    } else {
+      // relu(batch_norm(x.W)): the product once over all rows, the normaliser once per call (each call has its own batch moments)
+      gemm(act[l], F.ld_in, true, ps.W(F.tW), F.ld_out, false, F.pre, F.ld_out, rows, F.out, F.in, nullptr, 0, 0.f, false, s);
+      launch_bn_forward(F.pre, F.ld_out, act[l + 1], F.ld_out, rows / calls, F.out, bn_vars(ps, F), F.stat, F.ld_out, bn_training(), true,
+                        scratch, scratch_floats, s, calls);
     }
-    // relu(batch_norm(x.W)): the product once over all rows, the normaliser once per call (each call has its own batch moments)
-    gemm(act[l], F.ld_in, true, ps.W(F.tW), F.ld_out, false, F.pre, F.ld_out, rows, F.out, F.in, nullptr, 0, 0.f, false, s);
-    launch_bn_forward(F.pre, F.ld_out, act[l + 1], F.ld_out, rows / calls, F.out, bn_vars(ps, F), F.stat, F.ld_out, bn_training(), true,
-                      scratch, scratch_floats, s, calls);
+    if (drop && l + 1 < L.size()) {          // h = dropout(h, keep_prob): one draw per call (D(real) and D(fake) are two ops)
+      const int rpc = rows / calls;
+      for (int k = 0; k < calls; ++k)
+        launch_dropout_fwd(act[l + 1] + (size_t)k * rpc * F.ld_out, (size_t)rpc, F.out, F.ld_out, drop_key(&ps == &D ? 1 : 0, (int)l, call0 + k),
+                           drop_thr(), keep_prob, s);
+    }
   }
 }
 
@@ -58,6 +76,8 @@ float* Model::fc_backward(const ParamSet& ps, const std::vector<FcLayer>& L, con
   for (int l = (int)L.size() - 1; l >= 0; --l) {
     const FcLayer& F = L[l];
     const float* a_in = act[l] + (size_t)row0 * F.ld_in;
+    if (l + 1 < (int)L.size() && drop_training())          // through dropout and the ReLU under it: act[l + 1] is the dropped output
+      launch_dropout_bwd(act[l + 1] + (size_t)row0 * F.ld_out, d, (size_t)rows, F.out, F.ld_out, keep_prob, s);
     if (F.bn) {                            // d (w.r.t. the ReLU's output) -> gradient w.r.t. x.W, per call; dbeta / dgamma summed over the calls
       const size_t ra = (size_t)row0 * F.ld_out;
       launch_bn_backward(d, F.ld_out, act[l + 1] + ra, F.ld_out, F.pre + ra, F.ld_out, rows / calls, F.out,
@@ -174,8 +194,8 @@ void Model::bn_commit_run(bool with_d, hipStream_t s) {
   launch_bn_commit_many(cl, s);
 }
 
-void Model::d_dnn_forward_loss(int T, int Nd, int n_real, bool want_grads, float* loss3, hipStream_t s, int calls) {
-  fc_forward(D, dfc, d_act, T * Nd, s, calls);
+void Model::d_dnn_forward_loss(int T, int Nd, int n_real, bool want_grads, float* loss3, hipStream_t s, int calls, int call0) {
+  fc_forward(D, dfc, d_act, T * Nd, s, calls, call0);
   launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, Nd, n_real, dyn + DYN_D_REAL,
                n_real > 0 ? dyn + DYN_D_FAKE : dyn + DYN_D_REAL, loss3, s, true, kDClipLo, kDClipHi);
 }
@@ -186,6 +206,7 @@ int Model::dnn_d_backward(const float* x, const float* labels, int T, float* out
   if (!x || !labels) { set_error("null input pointer"); return RSRGAN_ERR_INVALID; }
   if (T <= 0 || T > Tmax) { set_error("T=%d outside (0, max_frames=%d]", T, Tmax); return RSRGAN_ERR_INVALID; }
   bn_eval_call = !want_grads;
+  if (want_grads) ++drop_run;
   launch_pack_tm(x, x_tm, B, T, Din, ldDin, s);
   launch_pack_tm(labels, lab_tm, B, T, Dout, ldDout, s);
   cur_T = T;
@@ -209,6 +230,8 @@ int Model::dnn_g_backward(const float* x, const float* labels, int T, float* out
   const int R = T * B;
   bn_eval_call = !want_grads;
   if (bn_on()) reuse = false;       // the D-run's update ops changed the generator's renorm state: its forward differs now
+  if (want_grads) ++drop_run;
+  if (drop_training()) reuse = false;   // a new sess.run draws new masks
   if (reuse) {
     if (!g_fwd_valid || T != cur_T) { set_error("reuse_g_forward without a valid generator forward"); return RSRGAN_ERR_STATE; }
   } else {
@@ -232,7 +255,7 @@ int Model::dnn_g_backward(const float* x, const float* labels, int T, float* out
     launch_copy_f(tmp3 + 1, losses + 3, 1, s);
   } else {
     launch_build_joint(x_tm, ldDin, cfg.d_joint_off, cfg.d_joint_dim, y_tm, ldDout, Dout, joint, ldJ, 0, R, s);
-    d_dnn_forward_loss(1, R, 0, want_grads, tmp3, s);      // g_adv = mean((D(fake) - 1)^2)  gan.py:202
+    d_dnn_forward_loss(1, R, 0, want_grads, tmp3, s, 1, 1);      // g_adv = mean((D(fake) - 1)^2)  gan.py:202 (call 1 = the fake joint)
     launch_copy_f(tmp3 + 1, losses + 3, 1, s);
   }
   const bool l2_on = !cfg.cross_validation && scal[RSRGAN_L2_SCALE] > 0.0;

@@ -221,6 +221,11 @@ void launch_zero_many(const ZeroList& zl, hipStream_t s);
 void launch_lstm_colsums(const float* dz, const float* cprev, const float* ccur, float* db, float* dwi, float* dwf, float* dwo,
                          int rows, int H, float* scratch /* >= 64*7*H floats */, hipStream_t s);
 void launch_lrelu_bwd(const float* hval, float* d, size_t rows, int cols, int ld, float alpha, hipStream_t s); // d *= (h>0?1:alpha)
+// tf.nn.dropout (models/dnn.py:116-121, discriminator_dnn.py:100-105): y = y / keep * mask in place; the mask of element (r, c) is
+// [ (splitmix64(key + r*cols + c) >> 40) < thr ] with thr = floor(keep * 2^24) -- oracle side: tests/helpers.py dropout_mask
+void launch_dropout_fwd(float* y, size_t rows, int cols, int ld, unsigned long long key, unsigned thr, float keep, hipStream_t s);
+// backward through dropout + the ReLU under it, given the dropped output y: d = y > 0 ? d / keep : 0
+void launch_dropout_bwd(const float* y, float* d, size_t rows, int cols, int ld, float keep, hipStream_t s);
 // col sums over `rows` rows: out[c] = sum_r a[r*lda+c] * (b ? b[r*ldb+c] : 1)
 void launch_colsum_tall(const float* a, int lda, float* out, int rows, int cols, float* scratch, size_t scratch_floats, hipStream_t s);
 

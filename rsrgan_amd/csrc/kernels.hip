@@ -1368,6 +1368,40 @@ void launch_lrelu_bwd(const float* hval, float* d, size_t rows, int cols, int ld
   hipLaunchKernelGGL(k_lrelu_bwd, dim3(blocks), dim3(256), 0, s, hval, d, rows, cols, ld, alpha);
 }
 
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void k_dropout_fwd(float* __restrict__ y, size_t rows, int cols, int ld, unsigned long long key, unsigned thr,
+                                                     float keep) {
+  const size_t n = rows * (size_t)cols;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / cols;
+    float* p = y + r * ld + (i - r * cols);
+    const bool on = (unsigned)(splitmix64(key + i) >> 40) < thr;
+    *p = on ? *p / keep : 0.f;
+  }
+}
+void launch_dropout_fwd(float* y, size_t rows, int cols, int ld, unsigned long long key, unsigned thr, float keep, hipStream_t s) {
+  const size_t n = rows * (size_t)cols;
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_dropout_fwd, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, s, y, rows, cols, ld, key, thr, keep);
+}
+__global__ __launch_bounds__(256) void k_dropout_bwd(const float* __restrict__ y, float* __restrict__ d, size_t rows, int cols, int ld, float keep) {
+  const size_t n = rows * (size_t)cols;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / cols, o = r * ld + (i - r * cols);
+    d[o] = y[o] > 0.f ? d[o] / keep : 0.f;
+  }
+}
+void launch_dropout_bwd(const float* y, float* d, size_t rows, int cols, int ld, float keep, hipStream_t s) {
+  const size_t n = rows * (size_t)cols;
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_dropout_bwd, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, s, y, d, rows, cols, ld, keep);
+}
+
 // column sums in two deterministic stages (bias and peephole gradients)
 constexpr int CS_SLICES = 64;
 __global__ __launch_bounds__(256) void k_colsum1(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,

@@ -180,7 +180,18 @@ struct Model {
   bool d_adam() const { return g_dnn(); }     // models/gan.py:125 (Adam) vs gan_rnn_placeholder.py:144 (SGD)
   // `calls` = how many batch-norm calls the `rows` rows are (1, or 2 = the discriminator's real | fake halves, each with its own
   // batch moments); row0 = first row of act[] / pre to work on (the fake half alone in the G-run's backward pass)
-  void fc_forward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, hipStream_t s, int calls = 1);
+  void fc_forward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, hipStream_t s, int calls = 1,
+                  int call0 = 0);
+  // tf.nn.dropout after every hidden ReLU of the frame-level nets (dnn.py:86,99, discriminator_dnn.py:68,81).  The reference resets
+  // keep_prob to 1.0 unless l2_scale > 0 and is_training (dnn.py:67-71, discriminator_dnn.py:47-51): so does drop_training().
+  // Masks are a counter-based hash of (seed, training run, net, layer, call, element): every sess.run draws fresh ones.
+  float keep_prob = 1.f;
+  uint64_t drop_seed = 0, drop_run = 0;
+  bool drop_training() const {
+    return g_dnn() && keep_prob < 1.f && !cfg.cross_validation && !bn_eval_call && scal[RSRGAN_L2_SCALE] > 0.0;
+  }
+  uint64_t drop_key(int net, int layer, int call) const;
+  unsigned drop_thr() const { return (unsigned)((double)keep_prob * 16777216.0); }
   float* fc_backward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, float* dtop,
                      bool want_wgrads, bool want_din, hipStream_t s, int calls = 1, int row0 = 0, int call0 = 0);
   bool bn_on() const { return (cfg.flags & RSRGAN_FLAG_BATCH_NORM) != 0; }
@@ -192,7 +203,7 @@ struct Model {
   BnVars bn_vars(const ParamSet& ps, const int (&tbn)[8]) const;
   void bn_commit_stack(const ParamSet& ps, const std::vector<FcLayer>& L, int times0, int times1, BnCommitList& cl);
   float* bn_sums = nullptr;      // [2][max ld_out] work space of launch_bn_backward
-  void d_dnn_forward_loss(int T, int Nd, int n_real, bool want_grads, float* loss3, hipStream_t s, int calls = 1);
+  void d_dnn_forward_loss(int T, int Nd, int n_real, bool want_grads, float* loss3, hipStream_t s, int calls = 1, int call0 = 0);
   void bn_commit_run(bool with_d, hipStream_t s);
   int dnn_d_backward(const float* x, const float* labels, int T, float* out_losses, bool want_grads, hipStream_t s);
   int dnn_g_backward(const float* x, const float* labels, int T, float* out_losses, bool want_grads, bool reuse, hipStream_t s);

@@ -303,6 +303,10 @@ class HipEngine:
         check(self.lib.rsrgan_device_status(self.h, C.byref(code)))
         return code.value
 
+    def set_dropout(self, keep_prob, seed=0):
+        """tf.nn.dropout(h, keep_prob) after every hidden ReLU of the frame-level nets (dnn.py:116-121); `seed` = mask stream"""
+        check(self.lib.rsrgan_set_dropout(self.h, float(keep_prob), int(seed) & 0xFFFFFFFFFFFFFFFF))
+
     def profile_launches(self):
         """launches of the recurrence kernels the host issued since profile_begin (the profiled step runs eagerly)"""
         n = C.c_int64()

@@ -24,10 +24,10 @@ class GAN(Model):
         super(GAN, self).__init__(name)
         self.sess, self.cross_validation = sess, cross_validation
         self.MOVING_AVERAGE_DECAY = 0.9999
-        self.keep_prob = 1.0 if cross_validation else getattr(args, "keep_prob", 1.0)
+        self.keep_prob = 1.0 if cross_validation else float(getattr(args, "keep_prob", 1.0))
+        if not getattr(args, "l2_scale", 0.0) > 0.0:
+            self.keep_prob = 1.0          # dnn.py:67-71, discriminator_dnn.py:47-51: reset unless l2_scale > 0 and is_training
         self.batch_norm = bool(getattr(args, "batch_norm", False))
-        if self.keep_prob < 1.0:
-            raise NotImplementedError("dropout variants are not built (DESIGN.md section 7)")
         self.batch_size, self.devices = args.batch_size, devices
         self.num_gpu = getattr(args, "num_gpu", 1)
         self.save_dir = getattr(args, "save_dir", None)
@@ -50,6 +50,8 @@ class GAN(Model):
                                     g_splice=self.left_context + 1 + self.right_context,
                                     d_joint_dim=self.input_dim, l2_scale=self.l2_scale, cross_validation=cross_validation,
                                     batch_norm=self.batch_norm, seed=seed, **(net_overrides or {}))
+        if self.keep_prob < 1.0:              # every rank draws its own masks
+            self.engine.set_dropout(self.keep_prob, seed + 0x9E3779B9 * rdist.rank(process_group))
         self.ema_enabled = getattr(self.engine, "ema_enabled", True)
         self._scalars = {}
         self.mse_lambda = getattr(args, "init_mse_weight", 10.0)

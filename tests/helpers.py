@@ -192,3 +192,27 @@ def build_hip_pair(cfg, B, Tmax, seed=0, flags=0, **argkw):
                             d_learning_rate=float(np.float32(args.d_learning_rate)),
                             mse_lambda=float(np.float32(args.init_mse_weight)))
     return model, oracle
+
+
+# ---- dropout masks of the HIP path (csrc/kernels.hip k_dropout_fwd, csrc/dnn.cpp Model::drop_key): a counter-based hash, restated
+# here so that the oracle (which takes masks as an input) and the device draw the same ones ----
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64_int(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def dropout_mask(seed, run, net, layer, call, rows, cols, keep_prob):
+    key = _splitmix64_int((_splitmix64_int((seed ^ ((run * 0xD1342543DE82EF95) & _M64)) & _M64) + ((net << 16) | (layer << 8) | call)) & _M64)
+    with np.errstate(over="ignore"):
+        x = np.uint64(key) + np.arange(rows * cols, dtype=np.uint64)
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    thr = int(float(np.float32(keep_prob)) * 16777216.0)
+    return ((x >> np.uint64(40)) < np.uint64(thr)).reshape(rows, cols).astype(np.float64)

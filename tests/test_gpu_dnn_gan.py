@@ -7,9 +7,18 @@ import pytest
 
 from oracle import dnn_gan_oracle as DO
 from oracle import rsrgan_oracle as O
-from tests.helpers import NET_D, NET_G, args_for, overrides, rand_batch, rand_params, rel_err, small_cfg, split_flat
+from tests.helpers import NET_D, NET_G, args_for, dropout_mask, overrides, rand_batch, rand_params, rel_err, small_cfg, split_flat
 
 pytestmark = pytest.mark.gpu
+
+
+def _drop_kw(kw):
+    """the oracle takes the dropout masks as an input: the ones the device draws (GAN's default seed 4321, rank 0)"""
+    keep = kw.get("keep_prob", 1.0)
+    if keep >= 1.0:
+        return {}
+    return dict(keep_prob=float(np.float32(keep)),
+                mask_fn=lambda run, net, layer, call, rows, cols: dropout_mask(4321, run, net, layer, call, rows, cols, keep))
 
 
 def _dnn_pair(cfg, N, seed, **kw):
@@ -22,7 +31,7 @@ def _dnn_pair(cfg, N, seed, **kw):
             if k.endswith("biases"):
                 p[k] = rng.normal(0, 0.1, p[k].shape).astype(np.float32)
     args = SimpleNamespace(batch_size=N, input_dim=cfg.input_dim, output_dim=cfg.output_dim, left_context=cfg.left_context,
-                           right_context=cfg.right_context, g_type="dnn", keep_prob=1.0, batch_norm=False, num_gpu=1,
+                           right_context=cfg.right_context, g_type="dnn", keep_prob=kw.get("keep_prob", 1.0), batch_norm=False, num_gpu=1,
                            save_dir=None, l2_scale=kw.get("l2_scale", 0.0), disc_updates=1, gen_updates=1, init_mse_weight=10.0,
                            d_learning_rate=kw.get("d_lr", 1e-4), g_learning_rate=kw.get("g_lr", 1e-4))
     m = GAN(None, args, ["gpu:0"], net_overrides=dict(g_layers=cfg.g_hidden, g_cells=cfg.g_units, d_layers=cfg.d_hidden, d_cells=cfg.d_units))
@@ -30,7 +39,7 @@ def _dnn_pair(cfg, N, seed, **kw):
     assert [(n, tuple(s)) for n, s, _ in m.engine.tensor_table(NET_D)] == [(n, tuple(s)) for n, s in DO.d_param_specs(cfg)]
     m.set_vars(g, d)
     o = DO.GanDnnOracle(cfg, g, d, l2_scale=kw.get("l2_scale", 0.0), g_learning_rate=float(np.float32(kw.get("g_lr", 1e-4))),
-                        d_learning_rate=float(np.float32(kw.get("d_lr", 1e-4))))
+                        d_learning_rate=float(np.float32(kw.get("d_lr", 1e-4))), **_drop_kw(kw))
     return m, o
 
 
@@ -146,7 +155,7 @@ def _bn_pair(cfg, N, seed, cross_validation=False, g=None, d=None, **kw):
     g = {k: np.asarray(v, np.float32) for k, v in g.items()}
     d = {k: np.asarray(v, np.float32) for k, v in d.items()}
     args = SimpleNamespace(batch_size=N, input_dim=cfg.input_dim, output_dim=cfg.output_dim, left_context=cfg.left_context,
-                           right_context=cfg.right_context, g_type="dnn", keep_prob=1.0, batch_norm=True, num_gpu=1,
+                           right_context=cfg.right_context, g_type="dnn", keep_prob=kw.get("keep_prob", 1.0), batch_norm=True, num_gpu=1,
                            save_dir=None, l2_scale=kw.get("l2_scale", 0.0), disc_updates=1, gen_updates=1, init_mse_weight=10.0,
                            d_learning_rate=kw.get("d_lr", 1e-4), g_learning_rate=kw.get("g_lr", 1e-4))
     m = GAN(None, args, ["gpu:0"], cross_validation=cross_validation,
@@ -156,7 +165,7 @@ def _bn_pair(cfg, N, seed, cross_validation=False, g=None, d=None, **kw):
     assert [(n, tuple(s)) for n, s, _ in m.engine.tensor_table(NET_D)] == [(n, shape1(s)) for n, s in DO.d_param_specs(cfg)]
     m.set_vars(g, d)
     o = DO.GanDnnOracle(cfg, g, d, l2_scale=kw.get("l2_scale", 0.0), g_learning_rate=float(np.float32(kw.get("g_lr", 1e-4))),
-                        d_learning_rate=float(np.float32(kw.get("d_lr", 1e-4))), cross_validation=cross_validation)
+                        d_learning_rate=float(np.float32(kw.get("d_lr", 1e-4))), cross_validation=cross_validation, **_drop_kw(kw))
     return m, o
 
 
@@ -234,3 +243,45 @@ def test_frame_level_gan_batch_norm_reference_sizes():
     for k in wg:
         assert rel_err(gr[k], wg[k]) < 3e-3, k
     _cmp_vars(m, o)
+
+
+@pytest.mark.parametrize("N,batch_norm", [(7, False), (130, False), (64, True)])
+def test_frame_level_gan_dropout(N, batch_norm):
+    """--keep_prob < 1 (scripts/train_gan_dnn.py): tf.nn.dropout after every hidden ReLU of G and D (dnn.py:86,99,
+    discriminator_dnn.py:68,81), new masks in every training run, the D's real and fake calls with their own; the oracle is fed
+    the masks the device draws (tests/helpers.py dropout_mask).  Towers, every gradient, Adam steps; evaluation runs and a model
+    with l2_scale = 0 do not drop (dnn.py:67-71)."""
+    cfg = DO.DnnCfg(input_dim=6, output_dim=5, left_context=2, right_context=1, g_units=20, g_hidden=3, d_units=24, d_hidden=2,
+                    batch_norm=batch_norm)
+    pair = _bn_pair if batch_norm else _dnn_pair
+    m, o = pair(cfg, N, seed=N, l2_scale=1e-3, g_lr=1e-3, d_lr=2e-3, keep_prob=0.8)
+    assert m.keep_prob == 0.8
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((N, cfg.fed_dim)).astype(np.float32); lab = rng.standard_normal((N, cfg.output_dim)).astype(np.float32)
+    got = m.engine.d_backward(x[:, None], lab[:, None], None, train=True, apply=False).cpu().numpy()
+    want, wg = o.d_tower(x, lab)
+    assert np.allclose(got, want, rtol=2e-4), (got, want)
+    plain = pair(cfg, N, seed=N, l2_scale=1e-3, g_lr=1e-3, d_lr=2e-3)[1].d_tower(x, lab)[0]
+    assert not np.allclose(want, plain, rtol=1e-3)                  # (the masks do change the losses)
+    gr = split_flat(m.engine.get_grads(NET_D).cpu().numpy(), m.engine.tensor_table(NET_D))
+    for k in wg:
+        assert rel_err(gr[k], wg[k]) < 2e-3, k
+    got = m.engine.g_backward(x[:, None], lab[:, None], None, train=True, reuse=True, apply=False).cpu().numpy()      # reuse is ignored: new masks
+    want, wg, _ = o.g_tower(x, lab)
+    assert np.allclose(got, want, rtol=2e-4), (got, want)
+    gr = split_flat(m.engine.get_grads(NET_G).cpu().numpy(), m.engine.tensor_table(NET_G))
+    for k in wg:
+        assert rel_err(gr[k], wg[k]) < 2e-3, k
+    for _ in range(2):
+        assert np.allclose(np.ravel(m.d_step(x, lab)), o.d_step(x, lab), rtol=2e-4)
+        assert np.allclose(np.ravel(m.g_step(x, lab, reuse_g_forward=True)), o.g_step(x, lab), rtol=2e-4)
+    _cmp_vars(m, o)
+    # evaluation fetches (the cross_validation twin's) and inference do not drop
+    assert np.allclose(np.ravel(m.d_step(x, lab, train=False)), o.d_step(x, lab, train=False), rtol=2e-4)
+    assert np.allclose(np.ravel(m.g_step(x, lab, train=False)), o.g_step(x, lab, train=False), rtol=2e-4)
+    if not batch_norm:
+        assert np.abs(m.forward(x) - o.forward(x)).max() < 2e-4
+    # l2_scale = 0: the reference resets keep_prob to 1.0
+    m0, o0 = pair(cfg, N, seed=N, l2_scale=0.0, keep_prob=0.8)
+    assert m0.keep_prob == 1.0
+    assert np.allclose(np.ravel(m0.d_step(x, lab)), o0.d_step(x, lab), rtol=2e-4)

@@ -92,3 +92,64 @@ def test_adam_both_nets_no_clipping_and_first_step_sign():
     assert o.adam["g"]["t"] == 2 and o.adam["d"]["t"] == 1
     e = o.ema["d"]
     assert all(np.allclose(e[k], 0.9999 * d0[k] + 1e-4 * o.d[k]) for k in d0)
+
+
+def test_dropout_towers_match_autograd_with_the_same_masks():
+    """keep_prob < 1 (dnn.py:86,99,116-121; discriminator_dnn.py:68,81): y = relu(.) / keep * mask after every hidden layer of both
+    nets, separate masks per run, per net, per layer and per D call; inert with l2_scale = 0 and in evaluation fetches
+    (dnn.py:67-71).  Masks are an input of the oracle; torch autograd on the same masks pins losses and gradients."""
+    cfg = small()
+    g, d = params(cfg, 4)
+    rng = np.random.default_rng(5)
+    N, keep, lam, l2 = 9, 0.75, 10.0, 1e-3
+    x = rng.normal(size=(N, cfg.fed_dim)); lab = rng.normal(size=(N, cfg.output_dim))
+    masks = {}
+
+    def mask_fn(run, net, layer, call, rows, cols):
+        k = (run, net, layer, call)
+        if k not in masks:
+            masks[k] = (np.random.default_rng(hash(k) & 0xFFFF).random((rows, cols)) < keep).astype(np.float64)
+        return masks[k]
+    o = DO.GanDnnOracle(cfg, g, d, mse_lambda=lam, l2_scale=l2, keep_prob=keep, mask_fn=mask_fn)
+
+    def tstack(P, prefix, n, h, run, net, call):
+        for i, name in enumerate(DO._fc_names(prefix, n)):
+            h = h @ P[name + "/weights"] + P[name + "/biases"]
+            if i < n - 1:
+                h = torch.relu(h) / keep * torch.tensor(masks[(run, net, i, call)])
+        return h
+    # D-run = training run 1: G forward, D(real) = call 0, D(fake) = call 1
+    (d_rl, d_fk, d_loss), dg = o.d_tower(x, lab)
+    assert sorted(masks) == [(1, 0, i, 0) for i in range(cfg.g_hidden)] + [(1, 1, i, c) for i in range(cfg.d_hidden) for c in (0, 1)]
+    G = {k: torch.tensor(v, requires_grad=True) for k, v in g.items()}
+    D = {k: torch.tensor(v, requires_grad=True) for k, v in d.items()}
+    X, L = torch.tensor(x), torch.tensor(lab)
+    di = X[:, cfg.input_dim * cfg.left_context: cfg.input_dim * (cfg.left_context + 1)]
+    y = tstack(G, "g_model", cfg.g_hidden + 1, X, 1, 0, 0)
+    dfun = lambda j, run, call: torch.clamp(tstack(D, "d_model", cfg.d_hidden + 1, j, run, 1, call), cfg.clip_lo, cfg.clip_hi)
+    t_rl = ((dfun(torch.cat([di, L], 1), 1, 0) - 1) ** 2).mean()
+    t_fk = (dfun(torch.cat([di, y.detach()], 1), 1, 1) ** 2).mean()
+    assert math.isclose(d_rl, t_rl.item(), rel_tol=1e-12) and math.isclose(d_fk, t_fk.item(), rel_tol=1e-12)
+    (t_rl + t_fk).backward()
+    for k in dg:
+        assert np.allclose(dg[k], D[k].grad.numpy(), rtol=1e-10, atol=1e-14), k
+    # G-run = training run 2: new masks for G and for D(fake)
+    (g_adv, g_mse, g_l2, g_loss), gg, _ = o.g_tower(x, lab)
+    assert (2, 0, 0, 0) in masks and (2, 1, 0, 1) in masks and (2, 1, 0, 0) not in masks
+    G = {k: torch.tensor(v, requires_grad=True) for k, v in g.items()}
+    y = tstack(G, "g_model", cfg.g_hidden + 1, X, 2, 0, 0)
+    t_adv = ((dfun(torch.cat([di, y], 1), 2, 1) - 1) ** 2).mean()
+    t_mse = 0.5 * ((y - L) ** 2).mean() * cfg.output_dim
+    t_l2 = l2 * sum(0.5 * (v ** 2).sum() for k, v in G.items() if k.endswith("weights"))
+    assert math.isclose(g_adv, t_adv.item(), rel_tol=1e-12) and math.isclose(g_mse, t_mse.item(), rel_tol=1e-12)
+    (t_adv + lam * t_mse + t_l2).backward()
+    for k in gg:
+        assert np.allclose(gg[k], G[k].grad.numpy(), rtol=1e-10, atol=1e-14), k
+    # evaluation fetches and l2_scale = 0 do not drop
+    n = len(masks)
+    plain = DO.GanDnnOracle(cfg, g, d, mse_lambda=lam, l2_scale=l2)
+    assert np.allclose(o.d_step(x, lab, train=False), plain.d_step(x, lab, train=False), rtol=1e-12)
+    o0 = DO.GanDnnOracle(cfg, g, d, mse_lambda=lam, l2_scale=0.0, keep_prob=keep, mask_fn=mask_fn)
+    p0 = DO.GanDnnOracle(cfg, g, d, mse_lambda=lam, l2_scale=0.0)
+    assert np.allclose(o0.d_tower(x, lab)[0], p0.d_tower(x, lab)[0], rtol=1e-12)
+    assert len(masks) == n
