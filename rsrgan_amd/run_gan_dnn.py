@@ -70,7 +70,7 @@ def _reader(FLAGS, inputs_scp, labels_scp, cmvn, shuffle, seed):
                             num_threads=FLAGS.num_threads, shuffle=shuffle, seed=seed)
 
 
-def _one_epoch(model, batches, num_batch, epoch, FLAGS, train, log):
+def _one_epoch(model, batches, num_batch, epoch, FLAGS, train, log, report=True):
     """train_one_epoch (:27-150) / eval_one_epoch (:153-215): int(num_batch / (disc_updates + gen_updates) / num_gpu) rounds of
     disc_updates D-runs then gen_updates G-runs, one fresh batch per run; tower means per run (np.mean), run means per epoch."""
     sums, d_counter, g_counter = np.zeros(7), 0, 0
@@ -93,7 +93,7 @@ def _one_epoch(model, batches, num_batch, epoch, FLAGS, train, log):
         except StopIteration:                      # tf.errors.OutOfRangeError: the queue ran dry
             break
         counter = (d_counter + g_counter) * FLAGS.num_gpu
-        if train and (counter / FLAGS.num_gpu) % 1000 == 0:                # :99-128
+        if train and report and (counter / FLAGS.num_gpu) % 1000 == 0:     # :99-128 (the iteration scripts have no such report)
             dur = (datetime.datetime.now() - start).total_seconds()
             log("Epoch {} (BATCH {}): ".format(epoch, counter) +
                 ", ".join("{} = {:.5f}".format(n, r / (d_rep if i < 3 else g_rep)) for i, (n, r) in enumerate(zip(LOSS_NAMES, rep))) +
@@ -184,7 +184,7 @@ def train(FLAGS, model_factory=None, log=print, net_overrides=None):
     return history
 
 
-def decode(FLAGS, model_factory=None, log=print, net_overrides=None):
+def decode(FLAGS, model_factory=None, log=print, net_overrides=None, moving_average=True):
     """decode (:218-302): the cross_validation graph on one utterance at a time, the exponential moving averages of the
     trainable variables (model.load(moving_average=True), :253), de-normalised with the label CMVN, feats.ark / feats.scp."""
     cmvn = _cmvn(FLAGS)
@@ -194,7 +194,7 @@ def decode(FLAGS, model_factory=None, log=print, net_overrides=None):
     mk = model_factory or (lambda n: GAN(None, argparse.Namespace(**dict(vars(FLAGS), batch_size=n)), ["gpu:%d" % rdist.rank()],
                                          cross_validation=True, net_overrides=net_overrides))
     model = mk(longest)                       # one utterance = one batch of frames (frames are independent in the inference graph)
-    if model.load(model.save_dir, moving_average=True):
+    if model.load(model.save_dir, moving_average=moving_average):
         log("[*] Load SUCCESS")
     else:
         raise SystemExit("[!] Load failed. Checkpoint not found. Exit now.")
