@@ -31,7 +31,6 @@ class GAN(Model):
         self.batch_size, self.devices = args.batch_size, devices
         self.num_gpu = getattr(args, "num_gpu", 1)
         self.save_dir = getattr(args, "save_dir", None)
-        self.writer = self.summaries = None
         self.l2_scale = getattr(args, "l2_scale", 0.0)
         self.input_dim, self.output_dim = args.input_dim, args.output_dim
         self.left_context, self.right_context = getattr(args, "left_context", 0), getattr(args, "right_context", 0)
@@ -50,6 +49,7 @@ class GAN(Model):
                                     g_splice=self.left_context + 1 + self.right_context,
                                     d_joint_dim=self.input_dim, l2_scale=self.l2_scale, cross_validation=cross_validation,
                                     batch_norm=self.batch_norm, seed=seed, **(net_overrides or {}))
+        self._open_writer(args)
         if self.keep_prob < 1.0:              # every rank draws its own masks
             self.engine.set_dropout(self.keep_prob, seed + 0x9E3779B9 * rdist.rank(process_group))
         self.ema_enabled = getattr(self.engine, "ema_enabled", True)
@@ -101,6 +101,11 @@ class GAN(Model):
             return tw
         tw = tw.cpu().numpy()
         return list(tw[:, 0]), list(tw[:, 1]), list(tw[:, 2]), list(tw[:, 3])
+
+    def _summary_fetch(self, inputs, labels, lengths=None):
+        d = self.d_step(inputs, labels, train=False)
+        g = self.g_step(inputs, labels, train=False)
+        return d, g, self.forward(inputs)
 
     def forward(self, inputs):
         """sess.run(model.generator outputs): enhanced MFCC frames [N, output_dim]."""

@@ -44,6 +44,36 @@ class Model(object):
         else:
             rdist.all_reduce_mean_(self.engine.grad_view(net), self.process_group)
 
+    # -- TensorBoard summaries (gan_rnn_placeholder.py:81-86,219-223,270-298; gan.py:77-82,184-250) -------------------
+    writer = None
+    _eval_writer = None
+
+    def _open_writer(self, args):
+        """tf.summary.FileWriter(save_dir/train) -- or /eval on a cross_validation model; rank 0 only; args.write_summaries=False
+        turns it off"""
+        if self.save_dir and getattr(args, "write_summaries", True) and rdist.rank(getattr(self, "process_group", None)) == 0:
+            from .summary import FileWriter
+            self.writer = FileWriter(os.path.join(self.save_dir, "eval" if self.cross_validation else "train"))
+
+    def writer_for(self, train):
+        """the outer loops here fetch the cross-validation twin's values from the training model (train=False): its events go to
+        save_dir/eval like the twin's"""
+        if train or self.writer is None or self.cross_validation:
+            return self.writer
+        if self._eval_writer is None:
+            from .summary import FileWriter
+            self._eval_writer = FileWriter(os.path.join(self.save_dir, "eval"))
+        return self._eval_writer
+
+    def run_summaries(self, inputs, labels, lengths=None):
+        """sess.run(model.summaries, feed) (train_gan_rnn_placeholder.py:118-121, train_gan_dnn.py:133): the seven loss scalars of
+        the fed batch (fetched without the *_opt ops) + histograms of the batch and of the generator's output, serialised as a
+        Summary for writer.add_summary."""
+        from .summary import model_summaries
+        d, g, y = self._summary_fetch(inputs, labels, lengths)
+        host = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+        return model_summaries([float(np.mean(v)) for v in list(d) + list(g)], host(inputs), host(labels), host(y))
+
     def save(self, save_dir, step):
         """rank 0 writes; every rank returns once the checkpoint exists (or raises if rank 0 could not write it)"""
         os.makedirs(save_dir, exist_ok=True)
@@ -161,8 +191,6 @@ class GAN_RNN(Model):
         self.devices = devices
         self.num_gpu = getattr(args, "num_gpu", 1)
         self.save_dir = getattr(args, "save_dir", None)
-        self.writer = None                                   # tf.summary.FileWriter: out of scope
-        self.summaries = None
         self.l2_scale = getattr(args, "l2_scale", 0.0)
         self.input_dim = args.input_dim
         self.output_dim = args.output_dim
@@ -198,6 +226,8 @@ class GAN_RNN(Model):
         else:
             self._scalars = share_engine_from._scalars
         self.disc_noise_std = getattr(args, "init_disc_noise_std", 0.0)
+        if share_engine_from is None or cross_validation:
+            self._open_writer(args)
         self._noise_gen = None
 
     # -- mutable scalars: sess.run(tf.assign(model.<x>, v)) --------------------------------
@@ -298,6 +328,11 @@ class GAN_RNN(Model):
             return tw
         tw = tw.cpu().numpy()
         return list(tw[:, 0]), list(tw[:, 1]), list(tw[:, 2]), list(tw[:, 3])
+
+    def _summary_fetch(self, inputs, labels, lengths):
+        d = self.d_step(inputs, labels, lengths, train=False)
+        g = self.g_step(inputs, labels, lengths, train=False)
+        return d, g, self.forward(inputs, lengths)
 
     def forward(self, inputs, lengths):
         """sess.run(model.g_outputs, {inputs, lengths}) (train_gan_rnn_placeholder.py:282-285)."""

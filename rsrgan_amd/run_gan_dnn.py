@@ -100,6 +100,9 @@ def _one_epoch(model, batches, num_batch, epoch, FLAGS, train, log, report=True)
                 ", time = {:.3} min".format(dur / 60.0))
             start = datetime.datetime.now()
             rep[:] = 0.0; d_rep = g_rep = 0
+    w = model.writer_for(train) if d_counter + g_counter and hasattr(model, "writer_for") else None
+    if w is not None:                              # Save summary (:132-134, :195-196): one more fetch on the last batch drawn
+        w.add_summary(model.run_summaries(x, lab), epoch * num_batch)
     d_counter, g_counter = max(d_counter, 1), max(g_counter, 1)
     return tuple(np.concatenate([sums[:3] / d_counter, sums[3:] / g_counter]))
 

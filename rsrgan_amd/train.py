@@ -99,6 +99,8 @@ def _train_one_iteration(sess, model, tr_num_batch, iteration, train_queue, num_
             m = tw.mean(0)
             g_acc = m if g_acc is None else g_acc + m
             g_counter += 1
+        if batch % 100 == 0 and getattr(model, "writer", None) is not None:        # Save summary (:116-122)
+            model.writer.add_summary(model.run_summaries(x, lab, ln), iteration * tr_num_batch)
     # np.mean over towers (:85-87,104-107) commutes with the mean over steps: one all-reduce of the 7 sums per iteration
     if d_acc is not None:
         d_acc = rdist.all_reduce_mean_(d_acc.clone(), getattr(model, "process_group", None))
@@ -134,6 +136,10 @@ def _eval_one_iteration(sess, model, cv_num_batch, iteration, valid_queue, num_g
         d_acc = td if d_acc is None else d_acc + td
         g_acc = tg if g_acc is None else g_acc + tg
         n += 1
+        last = (x, lab, ln)
+    w = model.writer_for(False) if n and hasattr(model, "writer_for") else None
+    if w is not None:                                                              # :186-190 (the last fed batch)
+        w.add_summary(model.run_summaries(*last), iteration * cv_num_batch)
     d = (d_acc / max(n, 1)).cpu().numpy() if d_acc is not None else np.zeros(3)
     g = (g_acc / max(n, 1)).cpu().numpy() if g_acc is not None else np.zeros(4)
     _check_device(model, d, g)

@@ -38,6 +38,9 @@ class RNNTrainer(GAN_RNN):
     def d_step(self, *a, **k):
         raise RuntimeError("RNNTrainer has no discriminator (models/rnn_trainer.py)")
 
+    def _summary_fetch(self, inputs, labels, lengths):          # no discriminator: the three d_* scalars are 0
+        return ([0.0], [0.0], [0.0]), self.g_step(inputs, labels, lengths, train=False), self.forward(inputs, lengths)
+
     def step(self, inputs, labels, lengths, train=True, sync=True):
         """sess.run([model.g_opt, model.g_mse_losses, model.g_l2_losses, model.g_losses])."""
         out = self.g_step(inputs, labels, lengths, train=train, sync=sync)
@@ -58,6 +61,9 @@ class DNNTrainer(GAN):
 
     def d_step(self, *a, **k):
         raise RuntimeError("DNNTrainer has no discriminator (models/dnn_trainer.py)")
+
+    def _summary_fetch(self, inputs, labels, lengths=None):
+        return ([0.0], [0.0], [0.0]), self.g_step(inputs, labels, train=False), self.forward(inputs)
 
     def step(self, inputs, labels, train=True, sync=True):
         out = self.g_step(inputs, labels, train=train, sync=sync)

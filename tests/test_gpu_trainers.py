@@ -473,6 +473,11 @@ def test_frame_level_outer_loop_on_gpu(tmp_path):
     first = float(text.split("CROSSVAL.LOSS PRERUN")[1].split("g_mse_loss = ")[1].split(",")[0])
     last = float(text.split("(CROSS AVG.LOSS)")[-1].split("g_mse_loss = ")[1].split(",")[0])
     assert last < 0.7 * first, (first, last)                 # the supervised term learns the linear map
+    import glob
+    from rsrgan_amd import summary as S                      # model.writer.add_summary once per epoch pass (train_gan_dnn.py:132-134,195-196)
+    for sub in ("train", "eval"):
+        ev = S.read_events(glob.glob(str(tmp_path / "exp" / sub / "events.out.tfevents.*"))[0])
+        assert len(ev) >= 2 and ev[0][3] == "brain.Event:2" and np.isfinite(ev[1][2]["g_loss"]) and ev[1][2]["g_clean"]["num"] == 64 * dout
     FLAGS.decode = True
     scp = RD.decode(FLAGS, log=logs.append, net_overrides=ov)
     r, src = ArkReader(), ArkReader()
