@@ -223,8 +223,11 @@ int rsrgan_device_status(rsrgan_handle h, int32_t* code);
 /* tf.nn.dropout(h, keep_prob) after every hidden ReLU of the frame-level nets (models/dnn.py:86,99,116-121 and
  * models/discriminator_dnn.py:68,81,100-105; `--keep_prob` of scripts/train_gan_dnn.py).  0 < keep_prob <= 1.  As in the
  * reference it only acts in training runs with l2_scale > 0 (dnn.py:67-71 resets keep_prob to 1.0 otherwise).  `seed` selects
- * the mask stream (give every rank its own); masks change with every training run.  RSRGAN_ERR_INVALID on the sequence model
- * (its DropoutWrapper, models/lstm.py:99-102, is not built) unless keep_prob == 1. */
+ * the mask stream (give every rank its own); masks change with every training run.
+ * On the sequence model it is tf.contrib.rnn.DropoutWrapper(cell, output_keep_prob=keep_prob) around every generator layer
+ * (models/lstm.py:99-102, models/res_lstm_l.py:96-99; the discriminator has none): the output of (layer, t) that feeds the layer
+ * above / the output FC / the residual sum is dropped, the carried state is not; is_training only, no l2_scale condition
+ * (lstm.py:71-72).  RSRGAN_ERR_INVALID for generator layers without a projection. */
 int rsrgan_set_dropout(rsrgan_handle h, float keep_prob, uint64_t seed);
 
 /* launches of the recurrence kernels (gates / projection / backward A, B, B-reduce) the host issued since rsrgan_profile_begin: with the

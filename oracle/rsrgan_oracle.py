@@ -270,11 +270,23 @@ def _put_layer_grads(grads, prefix, g):
             grads[prefix + n] = v
 
 
-def generator_fwd(cfg: NetCfg, params, x, lengths):
+def generator_fwd(cfg: NetCfg, params, x, lengths, drop=None):
     """LSTM.infer (models/lstm.py:41-129) / RES_LSTM_L.infer
-    (models/res_lstm_l.py:41-199).  x [B,T,Din] -> y [B,T,Dout]."""
+    (models/res_lstm_l.py:41-199).  x [B,T,Din] -> y [B,T,Dout].
+    drop = (keep_prob, mask_of_layer(l) -> {0,1} array [B,T,P]) or None: tf.contrib.rnn.DropoutWrapper(cell,
+    output_keep_prob) around every layer (lstm.py:99-102, res_lstm_l.py:96-99) -- the layer's OUTPUT sequence times mask / keep
+    (nn_ops.dropout: div(x, keep) * mask; a fresh mask per time step), the carried state untouched; finished rows output zeros
+    either way.  TF's random stream cannot be reproduced: the masks are an input."""
     hp = cfg.g_proj > 0
     cache = {}
+
+    def dropped(l, out):
+        if drop is None:
+            return out
+        keep, mask_of = drop
+        m = np.asarray(mask_of(l), out.dtype)
+        cache["drop%d" % l] = (m, keep)
+        return out / keep * m
     if cfg.g_type == "lstm":
         a = fc_fwd(x, params["g_model/fully_connected/weights"], params["g_model/fully_connected/biases"])
         h = leakyrelu(a, cfg.lrelu_alpha)
@@ -284,7 +296,7 @@ def generator_fwd(cfg: NetCfg, params, x, lengths):
             pre = "g_model/rnn/multi_rnn_cell/cell_%d/lstm_cell" % l
             out, c = lstmp_fwd(ins[-1], lengths, _layer_params(params, pre, hp), cfg.forget_bias)
             cache[pre] = c
-            ins.append(out)
+            ins.append(dropped(l, out))
         cache["ins"] = ins
         y = fc_fwd(ins[-1], params["g_model/fully_connected_1/weights"], params["g_model/fully_connected_1/biases"])
     else:
@@ -294,6 +306,7 @@ def generator_fwd(cfg: NetCfg, params, x, lengths):
             pre = "g_model/lstm_cell_%d/rnn/lstm_cell" % (l + 1)
             out, c = lstmp_fwd(ins[-1], lengths, _layer_params(params, pre, hp), cfg.forget_bias)
             cache[pre] = c
+            out = dropped(l, out)
             ins.append(out + ins[-1] if res else out)     # res_lstm_l.py:111,121,131,190
         cache["ins"] = ins
         y = fc_fwd(ins[-1], params["g_model/forward_out/fully_connected/weights"],
@@ -305,12 +318,16 @@ def generator_bwd(cfg: NetCfg, params, cache, dy):
     hp = cfg.g_proj > 0
     grads = {}
     ins = cache["ins"]
+
+    def through_drop(l, d):                      # gradient of div(x, keep) * mask
+        dr = cache.get("drop%d" % l)
+        return d if dr is None else d * dr[0] / dr[1]
     if cfg.g_type == "lstm":
         d, dw, db = fc_bwd(ins[-1], params["g_model/fully_connected_1/weights"], dy)
         grads["g_model/fully_connected_1/weights"], grads["g_model/fully_connected_1/biases"] = dw, db
         for l in range(cfg.g_layers - 1, -1, -1):
             pre = "g_model/rnn/multi_rnn_cell/cell_%d/lstm_cell" % l
-            d, g = lstmp_bwd(d, cache[pre], _layer_params(params, pre, hp))
+            d, g = lstmp_bwd(through_drop(l, d), cache[pre], _layer_params(params, pre, hp))
             _put_layer_grads(grads, pre, g)
         a = cache["a"]
         da = d * np.where(a > 0, 1.0, cfg.lrelu_alpha)
@@ -323,7 +340,7 @@ def generator_bwd(cfg: NetCfg, params, cache, dy):
         grads["g_model/forward_out/fully_connected/biases"] = db
         for l in range(cfg.g_layers - 1, -1, -1):
             pre = "g_model/lstm_cell_%d/rnn/lstm_cell" % (l + 1)
-            dx, g = lstmp_bwd(d, cache[pre], _layer_params(params, pre, hp))
+            dx, g = lstmp_bwd(through_drop(l, d), cache[pre], _layer_params(params, pre, hp))
             _put_layer_grads(grads, pre, g)
             d = dx + d if res else dx
     return grads
@@ -455,9 +472,12 @@ class GanRnnOracle:
     def __init__(self, cfg: NetCfg, g_params, d_params, *, batch_size, num_towers=1,
                  g_learning_rate=8e-5, d_learning_rate=1e-3, mse_lambda=10.0,
                  l2_scale=0.0, clip_norm=15.0, d_real=1.0, d_fake=0.0,
-                 cross_validation=False, dtype=np.float64):
+                 cross_validation=False, dtype=np.float64, keep_prob=1.0, mask_fn=None):
         self.cfg = cfg
         self.dtype = dtype
+        # DropoutWrapper on the generator's layers: mask_fn(run, tower, layer, B, T, P) -> {0,1} [B,T,P]; run = index of the
+        # training sess.run (1, 2, ...: every run draws new masks), is_training only (lstm.py:71-72)
+        self.keep_prob, self.mask_fn, self._run = keep_prob, mask_fn, 0
         self.g = {k: np.array(v, dtype) for k, v in g_params.items()}
         self.d = {k: np.array(v, dtype) for k, v in d_params.items()}
         self.batch_size = batch_size
@@ -481,15 +501,23 @@ class GanRnnOracle:
     def _slice(self, a, k):
         return None if a is None else a[self.batch_size * k:self.batch_size * (k + 1)]
 
+    def _drop(self, shape, training=True, tower=0):
+        if not (training and self.keep_prob < 1.0 and not self.cross_validation):
+            return None
+        run, (B, T) = self._run, shape[:2]
+        P = self.cfg.g_proj if self.cfg.g_proj > 0 else self.cfg.g_cells
+        return self.keep_prob, (lambda l: self.mask_fn(run, tower, l, B, T, P))
+
     def forward(self, inputs, lengths):
         """model.g_outputs (gan_rnn_placeholder.py:133-135)."""
-        y, _ = generator_fwd(self.cfg, self.g, np.asarray(inputs, self.dtype), np.asarray(lengths).astype(np.int32))
+        x = np.asarray(inputs, self.dtype)
+        y, _ = generator_fwd(self.cfg, self.g, x, np.asarray(lengths).astype(np.int32), self._drop(x.shape))
         return y
 
     # -- per-tower graphs (build_model_single_gpu :191-298) ---------------------
-    def d_tower(self, x, lab, ln, noise_real=None, noise_fake=None, want_grads=True):
+    def d_tower(self, x, lab, ln, noise_real=None, noise_fake=None, want_grads=True, tower=0):
         cfg = self.cfg
-        y, _ = generator_fwd(cfg, self.g, x, ln)
+        y, _ = generator_fwd(cfg, self.g, x, ln, self._drop(x.shape, want_grads, tower))
         lr_, cr = discriminator_fwd(cfg, self.d, lab, ln, noise_real)
         lf_, cf = discriminator_fwd(cfg, self.d, y, ln, noise_fake)
         d_rl, dlr = lsgan_mean_sq(lr_, self.d_real)
@@ -501,9 +529,9 @@ class GanRnnOracle:
             grads = {k: gr[k] + gf[k] for k in gr}
         return (d_rl, d_fk, d_rl + d_fk), grads
 
-    def g_tower(self, x, lab, ln, noise_fake=None, want_grads=True):
+    def g_tower(self, x, lab, ln, noise_fake=None, want_grads=True, tower=0):
         cfg = self.cfg
-        y, cg = generator_fwd(cfg, self.g, x, ln)
+        y, cg = generator_fwd(cfg, self.g, x, ln, self._drop(x.shape, want_grads, tower))
         mse, dy_mse = g_mse(y, lab, cfg.output_dim)
         if getattr(self, "supervised", False):
             # models/rnn_trainer.py:146-156 (RNNTrainer): g_loss = g_mse + g_l2, no discriminator in the graph
@@ -554,9 +582,10 @@ class GanRnnOracle:
         x = np.asarray(inputs, self.dtype); lab = np.asarray(labels, self.dtype)
         ln = np.asarray(lengths).astype(np.int32)
         losses, tower_grads = [], []
+        self._run += 1 if train else 0
         for k in range(self.num_towers):
             ls, g = self.d_tower(self._slice(x, k), self._slice(lab, k), self._slice(ln, k),
-                                 self._slice(noise_real, k), self._slice(noise_fake, k), want_grads=train)
+                                 self._slice(noise_real, k), self._slice(noise_fake, k), want_grads=train, tower=k)
             losses.append(ls); tower_grads.append(g)
         if train:
             self.apply_d(average_gradients(tower_grads))
@@ -568,9 +597,10 @@ class GanRnnOracle:
         x = np.asarray(inputs, self.dtype); lab = np.asarray(labels, self.dtype)
         ln = np.asarray(lengths).astype(np.int32)
         losses, tower_grads = [], []
+        self._run += 1 if train else 0
         for k in range(self.num_towers):
             ls, g, _ = self.g_tower(self._slice(x, k), self._slice(lab, k), self._slice(ln, k),
-                                    self._slice(noise_fake, k), want_grads=train)
+                                    self._slice(noise_fake, k), want_grads=train, tower=k)
             losses.append(ls); tower_grads.append(g)
         if train:
             self.apply_g(average_gradients(tower_grads))

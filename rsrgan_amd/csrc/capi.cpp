@@ -208,6 +208,7 @@ int rsrgan_forward_g(rsrgan_handle h, const float* x, const int32_t* lengths, in
     hipStream_t s = sc.work;
     int rc = m.prepare_batch(x, nullptr, lengths, T, s);
     if (rc) return rc;
+    m.bn_eval_call = false;     // the graph of THIS model: is_training unless it was built with cross_validation
     m.g_forward(T, s);
     m.g_fwd_valid = false;      // labels were not packed: the stash is not a valid training forward
     launch_unpack_bm(m.y_tm, m.ldDout, y, m.B, T, m.Dout, s);
@@ -301,8 +302,16 @@ int rsrgan_profile_begin(rsrgan_handle h) {
 int rsrgan_set_dropout(rsrgan_handle h, float keep_prob, uint64_t seed) {
   CHECK_H(h);
   if (!(keep_prob > 0.f && keep_prob <= 1.f)) { set_error("keep_prob=%g outside (0, 1]", (double)keep_prob); return RSRGAN_ERR_INVALID; }
-  if (keep_prob < 1.f && !h->m.g_dnn()) { set_error("dropout is built for the frame-level nets only"); return RSRGAN_ERR_INVALID; }
-  h->m.keep_prob = keep_prob; h->m.drop_seed = seed; h->m.drop_run = 0;
+  Model& m = h->m;
+  if (keep_prob < 1.f && !m.g_dnn()) {
+    for (const LstmLayer& L : m.gl)
+      if (!L.has_proj) { set_error("DropoutWrapper is built for generator layers with a projection (num_proj) only"); return RSRGAN_ERR_INVALID; }
+  }
+  if (hipDeviceSynchronize() != hipSuccess) { set_error("hipDeviceSynchronize failed"); return RSRGAN_ERR_HIP; }
+  m.keep_prob = keep_prob; m.drop_seed = seed; m.drop_run = 0;
+  if (m.drop_ctr && hipMemset(m.drop_ctr, 0, 16) != hipSuccess) { set_error("hipMemset failed"); return RSRGAN_ERR_HIP; }
+  m.drop_graphs();                                  // captured launch sequences carry the jobs' DropSpec
+  m.g_fwd_valid = false;
   return RSRGAN_OK;
 }
 

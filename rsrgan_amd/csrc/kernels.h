@@ -56,6 +56,18 @@ struct FwdGateJob {
 };
 struct FwdGateJobs { int n; float forget_bias; FwdGateJob j[MAXJ]; JobMap map; };
 
+// tf.contrib.rnn.DropoutWrapper(cell, output_keep_prob) (models/lstm.py:99-102, res_lstm_l.py:96-99): the output of (layer, t)
+// times mask / keep, a new mask in every training run.  mask[row][col] = [ (splitmix64(key + row*P + col) >> 40) < thr ] with
+// key = splitmix64(splitmix64(seed ^ run * 0xD1342543DE82EF95) + tag); `run` is read from device memory (*ctr, advanced by
+// k_drop_tick once per training run) so that a replayed hipGraph draws new masks.  tests/helpers.py dropout_mask restates it.
+struct DropSpec {
+  const unsigned long long* ctr;
+  unsigned long long seed, tag;
+  unsigned thr;
+  float keep;
+};
+void launch_drop_tick(unsigned long long* ctr, hipStream_t s);
+
 // Forward phase 2: m_t = h_t . Wp ; dynamic_rnn masking ; optional residual add
 struct FwdProjJob {
   const float* h;       // [N][ldh]
@@ -72,6 +84,7 @@ struct FwdProjJob {
   int ldh, ldm, ldo, P, t, N;     // ldm: stride of m_prev/m_out/res_*, ldo: stride of out
   int nblk_c;
   Place pl;
+  DropSpec drop;        // DropoutWrapper(output_keep_prob) on `out` (and on the residual sum's `out` term); ctr == nullptr: off
 };
 struct FwdProjJobs { int n; FwdProjJob j[MAXJ]; JobMap map; };
 
@@ -91,6 +104,7 @@ struct BwdAJob {
   int ldm, P, t, N, H;
   int nblk_c;
   Place pl;
+  DropSpec drop;        // the forward job's: dout is multiplied by mask / keep as it is loaded
 };
 struct BwdAJobs { int n; BwdAJob j[MAXJ]; JobMap map; };
 

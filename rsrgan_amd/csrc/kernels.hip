@@ -56,15 +56,28 @@ __device__ unsigned long long g_trace[8192 * 16];
 template <typename T>
 __device__ __forceinline__ T* as_global(T* p) { return (T*)(__attribute__((address_space(1))) T*)(unsigned long long)p; }
 #define RSR_G(f) J.f = as_global(J.f);
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+// DropSpec (kernels.h): the key of this (layer, t) in the current training run, and one element's mask
+__device__ __forceinline__ unsigned long long drop_key(const DropSpec& d) {
+  return splitmix64(splitmix64(d.seed ^ (*d.ctr * 0xD1342543DE82EF95ull)) + d.tag);
+}
+__device__ __forceinline__ bool drop_on(unsigned long long key, size_t idx, unsigned thr) { return (unsigned)(splitmix64(key + idx) >> 40) < thr; }
 __device__ __forceinline__ void globalize(FwdGateJob& J) {
   RSR_G(x) RSR_G(KxT) RSR_G(m) RSR_G(KhT) RSR_G(Wsw) RSR_G(zx) RSR_G(bias) RSR_G(wf) RSR_G(wi) RSR_G(wo) RSR_G(c_prev) RSR_G(c_out) RSR_G(gates)
   RSR_G(h) RSR_G(len) RSR_G(np_m_out) RSR_G(np_out) RSR_G(np_res_in) RSR_G(np_res_out)
 }
 __device__ __forceinline__ void globalize(FwdProjJob& J) {
   RSR_G(h) RSR_G(WpT) RSR_G(WpT_sw) RSR_G(m_prev) RSR_G(m_out) RSR_G(out) RSR_G(res_in) RSR_G(res_out) RSR_G(len) RSR_G(bias) RSR_G(noise)
+  J.drop.ctr = as_global(J.drop.ctr);
 }
 __device__ __forceinline__ void globalize(BwdAJob& J) {
   RSR_G(dout) RSR_G(dmst) RSR_G(Wp) RSR_G(Wp_sw) RSR_G(dmt) RSR_G(gates) RSR_G(c_prev) RSR_G(c_cur) RSR_G(wf) RSR_G(wi) RSR_G(wo) RSR_G(dc) RSR_G(len)
+  J.drop.ctr = as_global(J.drop.ctr);
 }
 __device__ __forceinline__ void globalize(BwdBJob& J) { RSR_G(dz) RSR_G(K) RSR_G(Ksw) RSR_G(dx) RSR_G(dmst) RSR_G(len) RSR_G(ws) }
 #undef RSR_G
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(512 * RH, (RH == 1 && RTG == 2 && CHB <= 18) ? 4 : 
 // ---------------------------------------------------------------------------------------
 // forward phase 2: 32x16 tile of m_t = h_t.Wp, K (=H) split over NW waves
 // ---------------------------------------------------------------------------------------
-template <int NW>
+template <int NW, bool DROP = false>          // DROP: some job of the launch has a DropSpec (a separate instantiation: the default one is untouched)
 __global__ __launch_bounds__(64 * NW) void k_fwd_proj(const FwdProjJobs jobs) {
   __shared__ float zs[NW][RT][16][17];
   const int bid = blockIdx.x;
@@ -448,6 +461,7 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_proj(const FwdProjJobs jobs) {
     for (int r = 0; r < 4; ++r) zs[w][i][q * 4 + r][lr] = acc[i][r];
   __syncthreads();
   TR(7);
+  const unsigned long long dkey = (DROP && J.drop.ctr) ? drop_key(J.drop) : 0ull;       // (uniform)
 #pragma unroll
   for (int u = 0; u < EPT; ++u) {
     const int e = tid + u * 64 * NW;
@@ -460,11 +474,11 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_proj(const FwdProjJobs jobs) {
     const size_t mi = (size_t)row * J.ldm + pp;
     if (J.bias) v += e_bias[u];
     const bool live = J.len ? (J.t < e_len[u]) : true;
-    J.m_out[mi] = live ? v : e_mprev[u];
+    J.m_out[mi] = live ? v : e_mprev[u];                 // the carried state is never dropped
     float o = live ? v : 0.f;
-    if (J.noise) o += e_noise[u];
-    J.out[(size_t)row * J.ldo + pp] = o;
-    if (J.res_out) J.res_out[mi] = (live ? v : 0.f) + e_res[u];
+    if (DROP && J.drop.ctr) o = drop_on(dkey, (size_t)row * P + pp, J.drop.thr) ? o / J.drop.keep : 0.f;
+    J.out[(size_t)row * J.ldo + pp] = J.noise ? o + e_noise[u] : o;
+    if (J.res_out) J.res_out[mi] = o + e_res[u];
   }
   TR_END();
 }
@@ -480,7 +494,7 @@ __global__ __launch_bounds__(64 * NW) void k_fwd_proj(const FwdProjJobs jobs) {
 //   - the cell gradients are finished in the accumulator layout (lane: rows 4q..4q+3, cell lr), their operands prefetched
 //     before the product.
 // ---------------------------------------------------------------------------------------
-template <int CHB>
+template <int CHB, bool DROP = false>
 __global__ __launch_bounds__(256) void k_bwd_a2(const BwdAJobs jobs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bid = blockIdx.x;
@@ -556,6 +570,19 @@ __global__ __launch_bounds__(256) void k_bwd_a2(const BwdAJobs jobs) {
   {
     const bool live = (r0 + srow < N) & (J.t < slen);
     const float dscale = J.dout ? 1.f : 0.f;
+    if (DROP && J.drop.ctr && J.dout) {                  // (uniform) dout through the forward's dropout: mask / keep per element
+      const unsigned long long dkey = drop_key(J.drop);
+      const float ik = 1.f / J.drop.keep;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int g4 = min(k4_0 + s8 + 8 * i, k4max);
+        const size_t e0 = (size_t)grow * J.P + g4 * 4;
+        vd[i].x = (g4 * 4 + 0 < J.P && drop_on(dkey, e0 + 0, J.drop.thr)) ? vd[i].x * ik : 0.f;
+        vd[i].y = (g4 * 4 + 1 < J.P && drop_on(dkey, e0 + 1, J.drop.thr)) ? vd[i].y * ik : 0.f;
+        vd[i].z = (g4 * 4 + 2 < J.P && drop_on(dkey, e0 + 2, J.drop.thr)) ? vd[i].z * ik : 0.f;
+        vd[i].w = (g4 * 4 + 3 < J.P && drop_on(dkey, e0 + 3, J.drop.thr)) ? vd[i].w * ik : 0.f;
+      }
+    }
     float* pt = (cb == 0 && !noproj && r0 + srow < N) ? J.dmt + (size_t)grow * ldm : nullptr;
     float4* dst = reinterpret_cast<float4*>(smem) + (size_t)srow * SA4;
 #pragma unroll
@@ -1055,7 +1082,12 @@ void launch_fwd_proj(const FwdProjJobs& jobs_in, int total_blocks, int kb_max, h
   ++g_chain_launches;
   FwdProjJobs jobs = jobs_in;
   total_blocks = place_tiles(jobs, 32, [](const FwdProjJob& j) { return (double)j.ldh; });
-  if (kb_max <= 24)
+  bool drop = false;
+  for (int i = 0; i < jobs.n; ++i) drop |= jobs.j[i].drop.ctr != nullptr;
+  if (drop) {
+    if (kb_max <= 24) hipLaunchKernelGGL((k_fwd_proj<4, true>), dim3(total_blocks), dim3(256), 0, s, jobs);
+    else hipLaunchKernelGGL((k_fwd_proj<8, true>), dim3(total_blocks), dim3(512), 0, s, jobs);
+  } else if (kb_max <= 24)
     hipLaunchKernelGGL(k_fwd_proj<4>, dim3(total_blocks), dim3(256), 0, s, jobs);
   else
     hipLaunchKernelGGL(k_fwd_proj<8>, dim3(total_blocks), dim3(512), 0, s, jobs);
@@ -1070,7 +1102,13 @@ void launch_bwd_a(const BwdAJobs& jobs_in, int total_blocks, int kb_max, hipStre
   for (int i = 0; i < jobs.n; ++i)
     if (jobs.j[i].Wp) sa4 = std::max(sa4, frag_stride4(((jobs.j[i].ldm + 15) >> 4) * 4));
   const size_t lds = (size_t)32 * sa4 * 16;
-  if (kb_max <= 4) hipLaunchKernelGGL(k_bwd_a2<4>, dim3(total_blocks), dim3(256), lds, s, jobs);
+  bool drop = false;
+  for (int i = 0; i < jobs.n; ++i) drop |= jobs.j[i].drop.ctr != nullptr;
+  if (drop) {
+    if (kb_max <= 4) hipLaunchKernelGGL((k_bwd_a2<4, true>), dim3(total_blocks), dim3(256), lds, s, jobs);
+    else if (kb_max <= 18) hipLaunchKernelGGL((k_bwd_a2<18, true>), dim3(total_blocks), dim3(256), lds, s, jobs);
+    else hipLaunchKernelGGL((k_bwd_a2<24, true>), dim3(total_blocks), dim3(256), lds, s, jobs);
+  } else if (kb_max <= 4) hipLaunchKernelGGL(k_bwd_a2<4>, dim3(total_blocks), dim3(256), lds, s, jobs);
   else if (kb_max <= 18) hipLaunchKernelGGL(k_bwd_a2<18>, dim3(total_blocks), dim3(256), lds, s, jobs);
   else hipLaunchKernelGGL(k_bwd_a2<24>, dim3(total_blocks), dim3(256), lds, s, jobs);
 }
@@ -1368,12 +1406,8 @@ void launch_lrelu_bwd(const float* hval, float* d, size_t rows, int cols, int ld
   hipLaunchKernelGGL(k_lrelu_bwd, dim3(blocks), dim3(256), 0, s, hval, d, rows, cols, ld, alpha);
 }
 
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
-}
+__global__ void k_drop_tick(unsigned long long* ctr) { if (threadIdx.x == 0) *ctr += 1ull; }
+void launch_drop_tick(unsigned long long* ctr, hipStream_t s) { hipLaunchKernelGGL(k_drop_tick, dim3(1), dim3(64), 0, s, ctr); }
 __global__ __launch_bounds__(256) void k_dropout_fwd(float* __restrict__ y, size_t rows, int cols, int ld, unsigned long long key, unsigned thr,
                                                      float keep) {
   const size_t n = rows * (size_t)cols;

@@ -426,6 +426,8 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     const unsigned ctl0[DP_CTL_WORDS] = {1u, 0u, 0u, 0u};
     HIPC(hipMemcpy(dp_ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice));
   }
+  drop_ctr = (unsigned long long*)alloc<float>(4);
+  HIPC(hipMemset(drop_ctr, 0, 16));
   const int dmaxld = std::max(ldPd, ldDout);
   d_dA = alloc<float>(TB2 * dmaxld); d_dB = alloc<float>(TB2 * dmaxld);
   len_dev = alloc<int>(2 * B);
@@ -664,6 +666,7 @@ static void fill_proj(FwdProjJob& p, const LayerRun& R, int t) {
   p.len = R.len; p.bias = nullptr; p.noise = nullptr;
   p.ldm = L.ldP; p.ldo = L.ldP; p.P = L.P; p.t = t; p.N = R.N;
   p.nblk_c = (L.P + 15) / 16;
+  p.drop = R.drop; p.drop.tag += (unsigned long long)t;
 }
 static void fill_fc_fwd(FwdProjJob& p, const FcStage& F, int t) {
   p.h = F.in + (size_t)t * F.N * F.ld_in; p.WpT = F.WT; p.WpT_sw = nullptr; p.ldh = F.ld_in;
@@ -672,6 +675,7 @@ static void fill_fc_fwd(FwdProjJob& p, const FcStage& F, int t) {
   p.res_in = nullptr; p.res_out = nullptr; p.len = nullptr; p.bias = F.bias; p.noise = F.noise;
   p.P = F.D; p.t = t; p.N = F.N;
   p.nblk_c = (F.D + 15) / 16;
+  p.drop = DropSpec{};
 }
 static void fill_fc_bwd(BwdBJob& b, const FcStage& F, int t) {   // y[t] (=|+=) in[t] . W^T, W = [D rows][ld_in]
   b.dz = F.in + (size_t)t * F.N * F.ld_in; b.K = F.WT; b.Ksw = nullptr; b.H4 = F.ld_in;
@@ -692,6 +696,7 @@ static void fill_bwd_a(BwdAJob& a, const LayerRun& R, int t) {
   a.wf = ps.W(L.twf); a.wi = ps.W(L.twi); a.wo = ps.W(L.two);
   a.dc = S.dc + (size_t)R.row0 * H; a.len = R.len; a.ldm = L.ldP; a.P = L.P; a.t = t; a.N = R.N; a.H = H;
   a.nblk_c = (H + bwd_a_cells() - 1) / bwd_a_cells();
+  a.drop = R.drop; a.drop.tag += (unsigned long long)t;
 }
 static void fill_bwd_b(BwdBJob& b, const LayerRun& R, int t, bool with_dx) {
   const LstmLayer& L = *R.L; const LstmStash& S = *R.S; const ParamSet& ps = *R.ps;
@@ -1088,6 +1093,7 @@ Chain Model::g_chain(int T) {
     R.N = B; R.Ns = B; R.row0 = 0; R.len = len_dev;
     R.zx_batched = (l == 0);                 // layer 0's input exists for all t before the wave starts
     if (res) { R.res_in = g_ins[l]; R.res_out = g_res[l]; }   // inputs_{l+1} = outputs_l + inputs_l (res_lstm_l.py:111,121,131,190)
+    if (seq_drop_on()) R.drop = DropSpec{drop_ctr, drop_seed, (1ull << 40) | ((unsigned long long)l << 20), drop_thr(), keep_prob};
     ch.push_back(R);
   }
   return ch;
@@ -1203,6 +1209,8 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
   if (g_dnn()) return dnn_d_backward(x, labels, T, out_losses, want_grads, s);
   int rc = prepare_batch(x, labels, lengths, T, s);
   if (rc) return rc;
+  bn_eval_call = !want_grads;                      // (is_training of this fetch: the DropoutWrapper masks)
+  if (seq_drop_on()) launch_drop_tick(drop_ctr, s);     // a new training run: new masks (read from device memory: graph-safe)
   if (d_dnn()) { nr = nullptr; nf = nullptr; }    // discriminator_dnn.py:58: the noise layer is commented out
   nr = stage_noise(nr, noise_r_buf, s); nf = stage_noise(nf, noise_f_buf, s);     // caller pointers never enter a graph
   const unsigned kbits = (want_grads ? 1u : 0u) | (nr ? 2u : 0u) | (nf ? 4u : 0u);
@@ -1254,6 +1262,8 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
                       float* out_losses, bool want_grads, bool reuse, hipStream_t s) {
   if (!labels) { set_error("labels required"); return RSRGAN_ERR_INVALID; }
   if (g_dnn()) return dnn_g_backward(x, labels, T, out_losses, want_grads, reuse, s);
+  bn_eval_call = !want_grads;                      // (is_training of this fetch)
+  if (seq_drop_on()) { reuse = false; launch_drop_tick(drop_ctr, s); }     // a new sess.run: new DropoutWrapper masks, a new forward
   if (supervised()) {
     // RNNTrainer (models/rnn_trainer.py:131-156): g_loss = 0.5*Dout*mse(G(x), labels) + l2; no discriminator in the graph
     int rc = prepare_batch(x, labels, lengths, T, s);

@@ -95,6 +95,7 @@ struct LayerRun {
   float* din = nullptr;           // [T][Ns][ldI] gradient w.r.t. the layer input (nullptr = not needed)
   bool din_accumulate = false;
   bool want_wgrads = false;
+  DropSpec drop{};                // DropoutWrapper on this layer's output (tag = the layer's; the jobs add t); ctr == nullptr: off
 };
 typedef std::vector<LayerRun> Chain;
 
@@ -191,6 +192,10 @@ struct Model {
     return g_dnn() && keep_prob < 1.f && !cfg.cross_validation && !bn_eval_call && scal[RSRGAN_L2_SCALE] > 0.0;
   }
   uint64_t drop_key(int net, int layer, int call) const;
+  // sequence generators: tf.contrib.rnn.DropoutWrapper(cell, output_keep_prob) on every layer (models/lstm.py:99-102,
+  // res_lstm_l.py:96-99; the discriminator has none), is_training only -- no l2_scale condition on this path (lstm.py:71-72)
+  unsigned long long* drop_ctr = nullptr;       // device: index of the training run (kernels.h DropSpec)
+  bool seq_drop_on() const { return !g_dnn() && keep_prob < 1.f && !cfg.cross_validation && !bn_eval_call; }
   unsigned drop_thr() const { return (unsigned)((double)keep_prob * 16777216.0); }
   float* fc_backward(const ParamSet& ps, const std::vector<FcLayer>& L, const std::vector<float*>& act, int rows, float* dtop,
                      bool want_wgrads, bool want_din, hipStream_t s, int calls = 1, int row0 = 0, int call0 = 0);

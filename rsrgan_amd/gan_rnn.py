@@ -184,8 +184,8 @@ class GAN_RNN(Model):
         self.max_grad_norm = 15
         self.keep_prob = 1.0 if cross_validation else getattr(args, "keep_prob", 1.0)
         self.batch_norm = getattr(args, "batch_norm", False)
-        if self.batch_norm or self.keep_prob < 1.0:
-            raise NotImplementedError("batch_norm / dropout are off on this path "
+        if self.batch_norm:
+            raise NotImplementedError("batch_norm is off on this path "
                                       "(run_gan_rnn_placeholder.sh:131; train_gan_rnn_placeholder.py:723-728)")
         self.batch_size = args.batch_size
         self.devices = devices
@@ -226,6 +226,9 @@ class GAN_RNN(Model):
         else:
             self._scalars = share_engine_from._scalars
         self.disc_noise_std = getattr(args, "init_disc_noise_std", 0.0)
+        if self.keep_prob < 1.0 and share_engine_from is None:
+            # DropoutWrapper(output_keep_prob) around the generator's cells (lstm.py:99-102, res_lstm_l.py:96-99, res_lstm_base.py:96-99); every rank its own masks
+            self.engine.set_dropout(self.keep_prob, seed + 0x9E3779B9 * rdist.rank(process_group))
         if share_engine_from is None or cross_validation:
             self._open_writer(args)
         self._noise_gen = None

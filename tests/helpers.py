@@ -187,10 +187,14 @@ def build_hip_pair(cfg, B, Tmax, seed=0, flags=0, **argkw):
     assert [(n, s) for n, s, _ in model.engine.tensor_table(NET_G)] == want_g
     assert [(n, s) for n, s, _ in model.engine.tensor_table(NET_D)] == want_d
     model.set_vars(g, d)
+    keep = float(getattr(args, "keep_prob", 1.0))
+    drop = {} if keep >= 1.0 else dict(        # the oracle is fed the masks the device draws (GAN_RNN's default seed, rank 0)
+        keep_prob=float(np.float32(keep)),
+        mask_fn=lambda run, tower, layer, b, t, p: seq_dropout_mask(4321, run, layer, b, t, p, keep))
     oracle = O.GanRnnOracle(cfg, g, d, batch_size=B, l2_scale=args.l2_scale,
                             g_learning_rate=float(np.float32(args.g_learning_rate)),
                             d_learning_rate=float(np.float32(args.d_learning_rate)),
-                            mse_lambda=float(np.float32(args.init_mse_weight)))
+                            mse_lambda=float(np.float32(args.init_mse_weight)), **drop)
     return model, oracle
 
 
@@ -207,7 +211,17 @@ def _splitmix64_int(x):
 
 
 def dropout_mask(seed, run, net, layer, call, rows, cols, keep_prob):
-    key = _splitmix64_int((_splitmix64_int((seed ^ ((run * 0xD1342543DE82EF95) & _M64)) & _M64) + ((net << 16) | (layer << 8) | call)) & _M64)
+    return _mask_of_tag(seed, run, (net << 16) | (layer << 8) | call, rows, cols, keep_prob)
+
+
+def seq_dropout_mask(seed, run, layer, B, T, P, keep_prob):
+    """DropoutWrapper masks of the sequence generators (csrc/kernels.h DropSpec; csrc/model.cpp g_chain: tag = 1<<40 | layer<<20 | t,
+    element = row * P + col) as a [B, T, P] array"""
+    return np.stack([_mask_of_tag(seed, run, (1 << 40) | (layer << 20) | t, B, P, keep_prob) for t in range(T)], axis=1)
+
+
+def _mask_of_tag(seed, run, tag, rows, cols, keep_prob):
+    key = _splitmix64_int((_splitmix64_int((seed ^ ((run * 0xD1342543DE82EF95) & _M64)) & _M64) + tag) & _M64)
     with np.errstate(over="ignore"):
         x = np.uint64(key) + np.arange(rows * cols, dtype=np.uint64)
         x = x + np.uint64(0x9E3779B97F4A7C15)

@@ -333,3 +333,35 @@ def test_graph_replay_is_bit_identical_to_eager(g_type):
         a = eager.engine.get_params(net).cpu().numpy(); b = graph.engine.get_params(net).cpu().numpy()
         assert np.array_equal(a, b)
     assert np.array_equal(eager.forward(x, ln), graph.forward(x, ln))
+
+
+@pytest.mark.parametrize("g_type,flags,B,T", [("lstm", 0, 6, 9), ("lstm", 1, 6, 9), ("lstm", 3, 6, 9), ("res_lstm_l", 3, 5, 7),
+                                              ("lstm", 3, 33, 4)])
+def test_dropout_wrapper_on_the_generator_layers(g_type, flags, B, T):
+    """--keep_prob < 1 (train_gan_rnn_placeholder.py:723-728): tf.contrib.rnn.DropoutWrapper(cell, output_keep_prob) around every
+    generator layer (models/lstm.py:99-102, res_lstm_l.py:96-99) -- masks per (training run, layer, t), drawn on the device inside
+    k_fwd_proj / k_bwd_a2 and replayed correctly by hipGraphs (the run index lives in device memory); the oracle is fed the same
+    masks (tests/helpers.py seq_dropout_mask).  Losses of D- and G-runs, every variable after 2 rounds, evaluation fetches
+    undropped, a G-run never reuses the D-run's (differently masked) forward."""
+    cfg = small_cfg(g_type)
+    model, oracle = build_hip_pair(cfg, B, T, seed=4, flags=flags, l2_scale=1e-3, g_learning_rate=1e-3, d_learning_rate=5e-2, keep_prob=0.8)
+    plain = build_hip_pair(cfg, B, T, seed=4, flags=flags, l2_scale=1e-3, g_learning_rate=1e-3, d_learning_rate=5e-2)[1]
+    x, lab, ln = rand_batch(cfg, B, T, seed=12, ragged=True)
+    for rnd in range(2):
+        a = model.d_step(x, lab, ln); b = oracle.d_step(x, lab, ln)
+        assert np.allclose(np.ravel(a), np.ravel(b), rtol=LOSS_RTOL), (rnd, a, b)
+        if rnd == 0:
+            assert not np.allclose(np.ravel(b)[1], np.ravel(plain.d_step(x, lab, ln))[1], rtol=1e-3)      # the masks do act
+        for i in range(2):
+            a = model.g_step(x, lab, ln, reuse_g_forward=(i == 0)); b = oracle.g_step(x, lab, ln)
+            assert np.allclose(np.ravel(a), np.ravel(b), rtol=LOSS_RTOL), (rnd, i, a, b)
+    gv, dv = model.get_vars()
+    for k in oracle.g:
+        assert rel_err(gv[k], oracle.g[k]) < 2e-4, k
+    for k in oracle.d:
+        assert rel_err(dv[k], oracle.d[k]) < 2e-4, k
+    a = model.g_step(x, lab, ln, train=False); b = oracle.g_step(x, lab, ln, train=False)
+    assert np.allclose(np.ravel(a)[:2], np.ravel(b)[:2], rtol=LOSS_RTOL)       # (g_adv, g_mse: the twin's fetch carries no L2 term)
+    a = model.d_step(x, lab, ln, train=False); b = oracle.d_step(x, lab, ln, train=False)
+    assert np.allclose(np.ravel(a), np.ravel(b), rtol=LOSS_RTOL)
+    assert model.engine.device_status() == 0

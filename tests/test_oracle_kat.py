@@ -281,3 +281,54 @@ def test_supervised_tower_is_the_mse_gradient():
         o.g[name][idx] = old
         fd = (lp - lm) / (2 * eps)
         assert abs(fd - grads[name][idx]) < 1e-6 * max(1.0, abs(fd)), (name, fd, grads[name][idx])
+
+
+@pytest.mark.parametrize("g_type", ["lstm", "res_lstm_l"])
+def test_dropout_wrapper_gradients_by_finite_differences(g_type):
+    """DropoutWrapper(cell, output_keep_prob) around every generator layer (models/lstm.py:99-102, res_lstm_l.py:96-99): the
+    layer's output sequence times mask / keep feeds the layer above / the residual sum / the output FC; the carried state is not
+    dropped.  Masks are an input of the oracle; its hand-written backward is pinned by central differences in fp64."""
+    cfg = small_cfg(g_type)
+    g, _ = rand_params(cfg, seed=11)
+    rng = np.random.default_rng(12)
+    B, T, keep = 3, 5, 0.7
+    x = rng.normal(size=(B, T, cfg.input_dim)); ln = np.array([5, 3, 1], np.int32)
+    masks = [(rng.random((B, T, cfg.g_proj)) < keep).astype(np.float64) for _ in range(cfg.g_layers)]
+    drop = (keep, lambda l: masks[l])
+    Rw = rng.normal(size=(B, T, cfg.output_dim))
+    y, cache = O.generator_fwd(cfg, g, x, ln, drop)
+    y0, _ = O.generator_fwd(cfg, g, x, ln)
+    assert not np.allclose(y, y0)
+    grads = O.generator_bwd(cfg, g, cache, Rw)
+    loss = lambda: float(np.sum(O.generator_fwd(cfg, g, x, ln, drop)[0] * Rw))
+    checked = 0
+    for name in sorted(g):
+        for _ in range(2):
+            idx = tuple(int(rng.integers(0, s)) for s in g[name].shape)
+            eps = 1e-6
+            g[name][idx] += eps; lp = loss()
+            g[name][idx] -= 2 * eps; lm = loss()
+            g[name][idx] += eps
+            assert math.isclose((lp - lm) / (2 * eps), grads[name][idx], rel_tol=2e-5, abs_tol=1e-8), (name, idx)
+            checked += 1
+    assert checked >= 2 * len(g)
+    # all-ones masks with keep = 1/2 double every layer output; an all-zero mask on the top layer leaves only the residual / bias path
+    ones = (0.5, lambda l: np.ones((B, T, cfg.g_proj)))
+    _, c1 = O.generator_fwd(cfg, g, x, ln, ones)
+    _, c0 = O.generator_fwd(cfg, g, x, ln)
+    first = c1["ins"][1] - (c1["ins"][0] if g_type == "res_lstm_l" else 0.0)
+    plain = c0["ins"][1] - (c0["ins"][0] if g_type == "res_lstm_l" else 0.0)
+    assert np.allclose(first, 2.0 * plain, rtol=1e-12, atol=1e-14)
+    # the model-level switch: training runs only, a new run index per training sess.run, evaluation fetches undropped
+    _, d = rand_params(cfg, seed=11)
+    seen = []
+
+    def mask_fn(run, tower, layer, b, t, p):
+        seen.append((run, tower, layer))
+        return np.ones((b, t, p))
+    om = O.GanRnnOracle(cfg, g, d, batch_size=B, keep_prob=0.5, mask_fn=mask_fn)
+    lab = rng.normal(size=(B, T, cfg.output_dim))
+    ev = om.g_step(x, lab, ln, train=False)
+    assert seen == [] and np.allclose(ev, O.GanRnnOracle(cfg, g, d, batch_size=B).g_step(x, lab, ln, train=False), rtol=1e-12)
+    om.d_step(x, lab, ln); om.g_step(x, lab, ln)
+    assert sorted(set(seen)) == [(r, 0, l) for r in (1, 2) for l in range(cfg.g_layers)]
