@@ -8,6 +8,7 @@
 // The same kernel computes the data gradient: d(in) = conv_SAME(d(out), flipped filter with in/out channels swapped).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -468,6 +469,187 @@ __global__ void k_conv_wgrad_red(const float* __restrict__ part, int nparts, int
 
 size_t conv_prep_floats(int S, int fw, int C) { return (size_t)S * 32 * conv_ldf(fw, C); }
 
+// ---- the same convolution on v_mfma_f32_4x4x1_16B_f32, for output widths that are no multiple of 16 (12, 20, 24 channels) ----
+// k_conv_fwd pads the output channels to 16 or 32 MFMA columns: 20 channels use 62 % of the columns, 12 and 24 use 75 %.  The
+// 4x4x1 instruction is sixteen 4x4 outer products at the same peak rate (512 flop per 8 cycles); measured lane map (tools/ubench/
+// mfma4.hip): D[lane][reg i] = A[4*srcblk + i] * B[lane], srcblk = the lane's own block, or with cbsz = 4 the block `abid` for
+// every lane.  So with the FILTER in the A slot (lane l holds Ft[channel l][k]: one register serves all channel groups, the
+// immediate abid picks channels 4c..4c+3) and the PATCH in the B slot (lane = one of 64 consecutive positions), a lane ends up
+// with four consecutive output channels of its own position: no padded columns for any N % 4 == 0, and a 16-byte store per lane.
+// Cost: four times the MFMA instructions per flop and ~2.4x the LDS reads per flop of the 16x16x4 form -- both under their limits.
+// Workgroup = 8 waves: waves w and w + 4 share the position groups {w & 3, (w & 3) + 4, ..} and split every filter row's k'
+// range in halves (balanced for any group count); the upper half hands its accumulators over through LDS at the end.
+template <int G, int NCG>
+__global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in, int ldc_in, int C, const float* __restrict__ Ft,
+                                                   const float* __restrict__ bias, int relu, float* __restrict__ out, int ldc_out, int N,
+                                                   int S, int W, int fw, int TW, const float* __restrict__ mask) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Cp = conv_cpad(C), ldf = conv_ldf(fw, C);
+  const int nk4 = fw * Cp / 4;                            // float4 steps of one filter row (no rounding to whole 16-float k-blocks here)
+  const int pt = (S - 1) / 2, pl = (fw - 1) / 2;
+  const int rowlen = (TW + fw - 1) * Cp + 16;
+  float* img = smem;                                      // [S + 1][rowlen], row S = zeros
+  float* fts = smem + (size_t)(S + 1) * rowlen;           // [32][ldf] filter slice of one dh
+  const int r = blockIdx.y, w0 = blockIdx.x * TW;
+  const int tw = min(TW, W - w0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wg = wv & 3, half = wv >> 2;
+  {
+    const int cp4 = Cp / 4, row4 = rowlen / 4;
+    const int total4 = (S + 1) * row4;
+    for (int i = tid; i < total4; i += 512) {
+      const int h = i / row4, e = i - h * row4;
+      const int x = e / cp4, c = (e - x * cp4) * 4;
+      const int wcol = w0 - pl + x;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (h < S && x < TW + fw - 1 && wcol >= 0 && wcol < W && c < C)
+        v = *reinterpret_cast<const float4*>(in + ((size_t)(r * S + h) * W + wcol) * ldc_in + c);
+      *reinterpret_cast<float4*>(img + (size_t)h * rowlen + (size_t)e * 4) = v;
+    }
+  }
+  const int M = S * TW;
+  int ph[G], pofs[G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) {
+    const int m = (i * 4 + wg) * 64 + lane;
+    const int h = m / TW, wl = m - h * TW;
+    const bool ok = m < M && wl < tw;
+    ph[i] = ok ? h : -1000;
+    pofs[i] = wl * Cp;
+  }
+  f32x4 acc[G][NCG];
+#pragma unroll
+  for (int i = 0; i < G; ++i)
+#pragma unroll
+    for (int c = 0; c < NCG; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int NROW = NCG > 4 ? 32 : 16;                 // filter rows staged per dh
+  const int n4 = NROW * ldf / 4;
+  const int fi0 = min(tid, n4 - 1), fi1 = min(tid + 512, n4 - 1), fi2 = min(tid + 1024, n4 - 1), fi3 = min(tid + 1536, n4 - 1),
+            fi4 = min(tid + 2048, n4 - 1);
+  float4 fr0, fr1, fr2, fr3, fr4;
+  {
+    const float4* src = reinterpret_cast<const float4*>(Ft);
+    fr0 = src[fi0]; fr1 = src[fi1]; fr2 = src[fi2]; fr3 = src[fi3]; fr4 = src[fi4];
+  }
+  const int s_lo = half ? nk4 / 2 : 0, s_hi = half ? nk4 : nk4 / 2;
+  const float* fb = fts + (size_t)(lane & (NROW - 1)) * ldf;
+  for (int dh = 0; dh < S; ++dh) {
+    __syncthreads();
+    {
+      float4* dst = reinterpret_cast<float4*>(fts);
+      if (tid < n4) dst[tid] = fr0;
+      if (tid + 512 < n4) dst[tid + 512] = fr1;
+      if (tid + 1024 < n4) dst[tid + 1024] = fr2;
+      if (tid + 1536 < n4) dst[tid + 1536] = fr3;
+      if (tid + 2048 < n4) dst[tid + 2048] = fr4;
+    }
+    __syncthreads();
+    {
+      const float4* src = reinterpret_cast<const float4*>(Ft + (size_t)min(dh + 1, S - 1) * 32 * ldf);
+      fr0 = src[fi0]; fr1 = src[fi1]; fr2 = src[fi2]; fr3 = src[fi3]; fr4 = src[fi4];
+    }
+    const int vlo = max(0, pt - dh) * TW, vhi = min(S, S + pt - dh) * TW;
+    const float* arow[G];
+    bool live[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const int hh = ph[i] + dh - pt;
+      arow[i] = img + (size_t)((hh >= 0 && hh < S) ? hh : S) * rowlen + pofs[i];
+      const int t0 = (i * 4 + wg) * 64;
+      live[i] = t0 + 63 >= vlo && t0 < vhi;             // (wave-uniform) a group outside the rows this filter row touches: only zeros
+    }
+    // The s loop is specialised on which of the wave's position groups are live (a uniform branch per group and component inside
+    // it cost a fifth of the issue slots: SQ_INSTS_SALU 1.2e9 next to 2.9e9 MFMAs) and unrolled by two with the operands of step
+    // s + 1 requested before the products of step s (two register sets, no copies).
+    int lm = 0;
+#pragma unroll
+    for (int i = 0; i < G; ++i) lm |= live[i] ? (1 << i) : 0;
+    auto run = [&](auto tag) {
+      constexpr int LM = decltype(tag)::value;
+      auto ldf4 = [&](int st) { return *reinterpret_cast<const float4*>(fb + 4 * st); };
+      auto prod = [&](const float4& fv, const float4 (&av)[G]) {
+#define RSR_C4(comp)                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < G; ++i) {                                                                       \
+          if (!((LM >> i) & 1)) continue;                                                                                     \
+          acc[i][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][0], 4, 0, 0);                            \
+          if (NCG > 1) acc[i][NCG > 1 ? 1 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 1 ? 1 : 0], 4, 1, 0); \
+          if (NCG > 2) acc[i][NCG > 2 ? 2 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 2 ? 2 : 0], 4, 2, 0); \
+          if (NCG > 3) acc[i][NCG > 3 ? 3 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 3 ? 3 : 0], 4, 3, 0); \
+          if (NCG > 4) acc[i][NCG > 4 ? 4 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 4 ? 4 : 0], 4, 4, 0); \
+          if (NCG > 5) acc[i][NCG > 5 ? 5 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 5 ? 5 : 0], 4, 5, 0); \
+          if (NCG > 6) acc[i][NCG > 6 ? 6 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 6 ? 6 : 0], 4, 6, 0); \
+          if (NCG > 7) acc[i][NCG > 7 ? 7 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 7 ? 7 : 0], 4, 7, 0); \
+        }
+        RSR_C4(x) RSR_C4(y) RSR_C4(z) RSR_C4(w)
+#undef RSR_C4
+      };
+      float4 f0 = ldf4(s_lo), f1;
+      float4 a0[G], a1[G];
+#pragma unroll
+      for (int i = 0; i < G; ++i) a0[i] = *reinterpret_cast<const float4*>(arow[i] + 4 * s_lo);
+      int st = s_lo;
+      for (; st + 1 < s_hi; st += 2) {
+        f1 = ldf4(st + 1);
+#pragma unroll
+        for (int i = 0; i < G; ++i) a1[i] = *reinterpret_cast<const float4*>(arow[i] + 4 * (st + 1));
+        prod(f0, a0);
+        const int s2 = min(st + 2, s_hi - 1);
+        f0 = ldf4(s2);
+#pragma unroll
+        for (int i = 0; i < G; ++i) a0[i] = *reinterpret_cast<const float4*>(arow[i] + 4 * s2);
+        prod(f1, a1);
+      }
+      if (st < s_hi) prod(f0, a0);
+    };
+    if (s_lo < s_hi) {
+      switch (lm) {                                       // (wave-uniform)
+        case 1: run(std::integral_constant<int, 1>{}); break;
+        case 2: run(std::integral_constant<int, 2>{}); break;
+        case 3: run(std::integral_constant<int, 3>{}); break;
+        case 4: run(std::integral_constant<int, G >= 3 ? 4 : 0>{}); break;
+        case 5: run(std::integral_constant<int, G >= 3 ? 5 : 0>{}); break;
+        case 6: run(std::integral_constant<int, G >= 3 ? 6 : 0>{}); break;
+        case 7: run(std::integral_constant<int, G >= 3 ? 7 : 0>{}); break;
+        default: break;
+      }
+    }
+  }
+  // the upper k' half hands its sums to the lower one: red[wg][i][c][lane] float4 over the (now idle) image
+  __syncthreads();
+  float4* red = reinterpret_cast<float4*>(smem);
+  if (half) {
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+      for (int c = 0; c < NCG; ++c)
+        red[((size_t)(wg * G + i) * NCG + c) * 64 + lane] = make_float4(acc[i][c][0], acc[i][c][1], acc[i][c][2], acc[i][c][3]);
+  }
+  __syncthreads();
+  if (half) return;
+#pragma unroll
+  for (int i = 0; i < G; ++i) {
+    const int m = (i * 4 + wg) * 64 + lane;
+    const int h = m / TW, wl = m - h * TW;
+    if (m >= M || wl >= tw) continue;
+    const size_t o0 = ((size_t)(r * S + h) * W + w0 + wl) * ldc_out;
+#pragma unroll
+    for (int c = 0; c < NCG; ++c) {
+      if (4 * c >= N) continue;
+      const float4 u = red[((size_t)(wg * G + i) * NCG + c) * 64 + lane];
+      float4 v = make_float4(acc[i][c][0] + u.x, acc[i][c][1] + u.y, acc[i][c][2] + u.z, acc[i][c][3] + u.w);
+      if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+      if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      if (mask) {
+        const float4 k = *reinterpret_cast<const float4*>(mask + o0 + 4 * c);
+        v = make_float4(k.x > 0.f ? v.x : 0.f, k.y > 0.f ? v.y : 0.f, k.z > 0.f ? v.z : 0.f, k.w > 0.f ? v.w : 0.f);
+      }
+      *reinterpret_cast<float4*>(out + o0 + 4 * c) = v;
+    }
+  }
+}
+
 void launch_conv_prep(const float* F, int ldf_src, int S, int fw, int Cin, int Cout, bool flip, float* Ft, hipStream_t s) {
   const size_t total = conv_prep_floats(S, fw, flip ? Cout : Cin);
   hipLaunchKernelGGL(k_conv_prep, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, F, ldf_src, S, fw, Cin, Cout, flip ? 1 : 0, Ft);
@@ -499,6 +681,22 @@ bool conv_fwd_supported(int C, int N, int S, int W, int fw) {
   return conv_fwd_plan(C, S, W, fw, TW, RT, lds);
 }
 
+template <int G, int NCG>
+static void launch_conv_fwd4_t(dim3 grid, size_t lds, hipStream_t s, const float* in, int ldc_in, int C, const float* Ft, const float* bias, int rl,
+                               float* out, int ldc_out, int N, int S, int W, int fw, int TW, const float* mask) {
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd4<G, NCG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL((k_conv_fwd4<G, NCG>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask);
+}
+static bool launch_conv_fwd4(int G, int ncg, dim3 grid, size_t lds, hipStream_t s, const float* in, int ldc_in, int C, const float* Ft,
+                             const float* bias, int rl, float* out, int ldc_out, int N, int S, int W, int fw, int TW, const float* mask) {
+#define RSR_L4(g, n) if (G == g && ncg == n) { launch_conv_fwd4_t<g, n>(grid, lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask); return true; }
+  RSR_L4(2, 1) RSR_L4(2, 2) RSR_L4(2, 3) RSR_L4(2, 4) RSR_L4(2, 5) RSR_L4(2, 6) RSR_L4(2, 7) RSR_L4(2, 8)
+  RSR_L4(3, 1) RSR_L4(3, 2) RSR_L4(3, 3) RSR_L4(3, 4) RSR_L4(3, 5) RSR_L4(3, 6) RSR_L4(3, 7) RSR_L4(3, 8)
+#undef RSR_L4
+  return false;
+}
+
 void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const float* bias, bool relu, float* out, int ldc_out, int N,
                      int R, int S, int W, int fw, hipStream_t s, const float* mask) {
   int TW = W, RT = 4; size_t lds = 0;
@@ -514,6 +712,14 @@ void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const 
   }
   dim3 grid((W + TW - 1) / TW, R);
   const int rl = relu ? 1 : 0;
+  // output widths that waste MFMA columns (N % 16 != 0) go to the 4x4x1 form; RSRGAN_CONV4: 0 = never, 1 = those (default), 2 = every N % 4 == 0
+  static int conv4 = -1;
+  if (conv4 < 0) { const char* e = getenv("RSRGAN_CONV4"); conv4 = e ? atoi(e) : 1; }
+  if (conv4 && N % 4 == 0 && ldc_out % 4 == 0 && (conv4 > 1 || N % 16 != 0) && (!bias || ((size_t)bias & 15) == 0)) {
+    const int G = small ? 2 : 3, ncg = N / 4;
+    const size_t lds4 = std::max(lds, (size_t)4 * G * ncg * 1024);
+    if (lds4 <= 160 * 1024 && launch_conv_fwd4(G, ncg, grid, lds4, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask)) return;
+  }
   if (small && N <= 16) hipLaunchKernelGGL((k_conv_fwd<4, 1>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask);
   else if (small) hipLaunchKernelGGL((k_conv_fwd<4, 2>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask);
   else if (N <= 16) hipLaunchKernelGGL((k_conv_fwd<6, 1>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask);

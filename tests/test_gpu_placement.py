@@ -162,6 +162,19 @@ def test_rced_weight_gradient_geometries_agree():
         assert abs(a[k] - b[k]) <= 2e-5 * max(abs(b[k]), 1e-6), (k, a[k], b[k])
 
 
+def test_rced_convolution_mfma_forms_agree():
+    """csrc/conv.hip: the 4x4x1 form (k_conv_fwd4) on every layer (RSRGAN_CONV4=2), on the widths that are no multiple of 16 (the
+    default) and nowhere (0): the same products in another summation order.  (Each form is also compared with the oracle:
+    tests/test_gpu_trainers.py runs under the default, and its R-CED cases pass under RSRGAN_CONV4=2 as well.)"""
+    a = _run_worker(RCED_WORKER, {"RSRGAN_CONV4": "2"})
+    b = _run_worker(RCED_WORKER, {"RSRGAN_CONV4": "0"})
+    c = _run_worker(RCED_WORKER, {})
+    assert a.keys() == b.keys() == c.keys() and len(a) > 0
+    for k in a:
+        assert abs(a[k] - b[k]) <= 2e-5 * max(abs(b[k]), 1e-6), (k, a[k], b[k])
+        assert abs(c[k] - b[k]) <= 2e-5 * max(abs(b[k]), 1e-6), (k, c[k], b[k])
+
+
 def test_wide_output_small_generator_with_reference_discriminator():
     """A generator narrower than its 40-dim output next to the reference's discriminator (2 x LSTMCell(256, num_proj=40)): dy
     [T*B][40] used to overflow the generator's gradient ping-pong buffers (sized by its layer widths), found by
