@@ -479,7 +479,7 @@ size_t conv_prep_floats(int S, int fw, int C) { return (size_t)S * 32 * conv_ldf
 // Cost: four times the MFMA instructions per flop and ~2.4x the LDS reads per flop of the 16x16x4 form -- both under their limits.
 // Workgroup = 8 waves: waves w and w + 4 share the position groups {w & 3, (w & 3) + 4, ..} and split every filter row's k'
 // range in halves (balanced for any group count); the upper half hands its accumulators over through LDS at the end.
-template <int G, int NCG>
+template <int G, int NCG, int KS = 2>          // KS: waves per position-group set (k' split); NSET = 8 / KS sets of G groups
 __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in, int ldc_in, int C, const float* __restrict__ Ft,
                                                    const float* __restrict__ bias, int relu, float* __restrict__ out, int ldc_out, int N,
                                                    int S, int W, int fw, int TW, const float* __restrict__ mask) {
@@ -494,7 +494,11 @@ __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in,
   const int tw = min(TW, W - w0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wg = wv & 3, half = wv >> 2;
+  // KS = 2: sets {w&3} of groups {w&3, (w&3)+4, ..}, k' halves.  KS = 4 (512-position workgroups): TWO interleaved sets (even / odd
+  // groups: the rows a filter row does not touch are a prefix or a suffix of the strip, so both sets lose the same number of
+  // groups +-1 and the skipped groups shorten the row for every wave) and k' quarters: 0.86 of the KS = 2 time at S = 11.
+  constexpr int NSET = 8 / KS;
+  const int wg = wv & (NSET - 1), half = wv / NSET;       // set, k' part
   {
     const int cp4 = Cp / 4, row4 = rowlen / 4;
     const int total4 = (S + 1) * row4;
@@ -512,7 +516,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in,
   int ph[G], pofs[G];
 #pragma unroll
   for (int i = 0; i < G; ++i) {
-    const int m = (i * 4 + wg) * 64 + lane;
+    const int m = (i * NSET + wg) * 64 + lane;
     const int h = m / TW, wl = m - h * TW;
     const bool ok = m < M && wl < tw;
     ph[i] = ok ? h : -1000;
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in,
     const float4* src = reinterpret_cast<const float4*>(Ft);
     fr0 = src[fi0]; fr1 = src[fi1]; fr2 = src[fi2]; fr3 = src[fi3]; fr4 = src[fi4];
   }
-  const int s_lo = half ? nk4 / 2 : 0, s_hi = half ? nk4 : nk4 / 2;
+  const int s_lo = nk4 * half / KS, s_hi = nk4 * (half + 1) / KS;
   const float* fb = fts + (size_t)(lane & (NROW - 1)) * ldf;
   for (int dh = 0; dh < S; ++dh) {
     __syncthreads();
@@ -557,34 +561,34 @@ __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in,
     for (int i = 0; i < G; ++i) {
       const int hh = ph[i] + dh - pt;
       arow[i] = img + (size_t)((hh >= 0 && hh < S) ? hh : S) * rowlen + pofs[i];
-      const int t0 = (i * 4 + wg) * 64;
-      live[i] = t0 + 63 >= vlo && t0 < vhi;             // (wave-uniform) a group outside the rows this filter row touches: only zeros
+      const int t0 = (i * NSET + wg) * 64;
+      live[i] = t0 + 63 >= vlo && t0 < vhi && t0 < M;             // (wave-uniform) a group outside the rows this filter row touches: only zeros
     }
-    // The s loop is specialised on which of the wave's position groups are live (a uniform branch per group and component inside
-    // it cost a fifth of the issue slots: SQ_INSTS_SALU 1.2e9 next to 2.9e9 MFMAs) and unrolled by two with the operands of step
-    // s + 1 requested before the products of step s (two register sets, no copies).
-    int lm = 0;
+    // One uniform branch per live group and step around its 4 * NCG products (a branch per group AND component cost a fifth of
+    // the issue slots: SQ_INSTS_SALU 1.2e9 next to 2.9e9 MFMAs; one specialised copy of the loop per live mask doubled the
+    // accumulator registers).  Unrolled by two: the operands of step s + 1 are requested before the products of step s.
+    auto ldf4 = [&](int st) { return *reinterpret_cast<const float4*>(fb + 4 * st); };
+    auto prod = [&](const float4& fv, const float4 (&av)[G]) {
 #pragma unroll
-    for (int i = 0; i < G; ++i) lm |= live[i] ? (1 << i) : 0;
-    auto run = [&](auto tag) {
-      constexpr int LM = decltype(tag)::value;
-      auto ldf4 = [&](int st) { return *reinterpret_cast<const float4*>(fb + 4 * st); };
-      auto prod = [&](const float4& fv, const float4 (&av)[G]) {
+      for (int i = 0; i < G; ++i) {
+        if (!live[i]) continue;
 #define RSR_C4(comp)                                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < G; ++i) {                                                                       \
-          if (!((LM >> i) & 1)) continue;                                                                                     \
-          acc[i][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][0], 4, 0, 0);                            \
-          if (NCG > 1) acc[i][NCG > 1 ? 1 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 1 ? 1 : 0], 4, 1, 0); \
-          if (NCG > 2) acc[i][NCG > 2 ? 2 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 2 ? 2 : 0], 4, 2, 0); \
-          if (NCG > 3) acc[i][NCG > 3 ? 3 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 3 ? 3 : 0], 4, 3, 0); \
-          if (NCG > 4) acc[i][NCG > 4 ? 4 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 4 ? 4 : 0], 4, 4, 0); \
-          if (NCG > 5) acc[i][NCG > 5 ? 5 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 5 ? 5 : 0], 4, 5, 0); \
-          if (NCG > 6) acc[i][NCG > 6 ? 6 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 6 ? 6 : 0], 4, 6, 0); \
-          if (NCG > 7) acc[i][NCG > 7 ? 7 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 7 ? 7 : 0], 4, 7, 0); \
-        }
+        acc[i][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][0], 4, 0, 0);                              \
+        if (NCG > 1) acc[i][NCG > 1 ? 1 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 1 ? 1 : 0], 4, 1, 0); \
+        if (NCG > 2) acc[i][NCG > 2 ? 2 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 2 ? 2 : 0], 4, 2, 0); \
+        if (NCG > 3) acc[i][NCG > 3 ? 3 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 3 ? 3 : 0], 4, 3, 0); \
+        if (NCG > 4) acc[i][NCG > 4 ? 4 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 4 ? 4 : 0], 4, 4, 0); \
+        if (NCG > 5) acc[i][NCG > 5 ? 5 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 5 ? 5 : 0], 4, 5, 0); \
+        if (NCG > 6) acc[i][NCG > 6 ? 6 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 6 ? 6 : 0], 4, 6, 0); \
+        if (NCG > 7) acc[i][NCG > 7 ? 7 : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(fv.comp, av[i].comp, acc[i][NCG > 7 ? 7 : 0], 4, 7, 0);
         RSR_C4(x) RSR_C4(y) RSR_C4(z) RSR_C4(w)
 #undef RSR_C4
-      };
+      }
+    };
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < G; ++i) any |= live[i];
+    if (any && s_lo < s_hi) {
       float4 f0 = ldf4(s_lo), f1;
       float4 a0[G], a1[G];
 #pragma unroll
@@ -602,43 +606,43 @@ __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in,
         prod(f1, a1);
       }
       if (st < s_hi) prod(f0, a0);
-    };
-    if (s_lo < s_hi) {
-      switch (lm) {                                       // (wave-uniform)
-        case 1: run(std::integral_constant<int, 1>{}); break;
-        case 2: run(std::integral_constant<int, 2>{}); break;
-        case 3: run(std::integral_constant<int, 3>{}); break;
-        case 4: run(std::integral_constant<int, G >= 3 ? 4 : 0>{}); break;
-        case 5: run(std::integral_constant<int, G >= 3 ? 5 : 0>{}); break;
-        case 6: run(std::integral_constant<int, G >= 3 ? 6 : 0>{}); break;
-        case 7: run(std::integral_constant<int, G >= 3 ? 7 : 0>{}); break;
-        default: break;
-      }
     }
   }
-  // the upper k' half hands its sums to the lower one: red[wg][i][c][lane] float4 over the (now idle) image
-  __syncthreads();
+  // the k' parts hand their sums down a tree (part p + h -> part p, h = KS/2, .., 1) through LDS, over the (now idle) image:
+  // red[(part - h) * NSET + set][i][c][lane] float4
   float4* red = reinterpret_cast<float4*>(smem);
-  if (half) {
 #pragma unroll
-    for (int i = 0; i < G; ++i)
+  for (int hh = KS / 2; hh >= 1; hh >>= 1) {
+    __syncthreads();
+    if (half >= hh && half < 2 * hh) {
 #pragma unroll
-      for (int c = 0; c < NCG; ++c)
-        red[((size_t)(wg * G + i) * NCG + c) * 64 + lane] = make_float4(acc[i][c][0], acc[i][c][1], acc[i][c][2], acc[i][c][3]);
+      for (int i = 0; i < G; ++i)
+#pragma unroll
+        for (int c = 0; c < NCG; ++c)
+          red[((size_t)(((half - hh) * NSET + wg) * G + i) * NCG + c) * 64 + lane] = make_float4(acc[i][c][0], acc[i][c][1], acc[i][c][2], acc[i][c][3]);
+    }
+    __syncthreads();
+    if (half < hh) {
+#pragma unroll
+      for (int i = 0; i < G; ++i)
+#pragma unroll
+        for (int c = 0; c < NCG; ++c) {
+          const float4 u = red[((size_t)((half * NSET + wg) * G + i) * NCG + c) * 64 + lane];
+          acc[i][c][0] += u.x; acc[i][c][1] += u.y; acc[i][c][2] += u.z; acc[i][c][3] += u.w;
+        }
+    }
   }
-  __syncthreads();
   if (half) return;
 #pragma unroll
   for (int i = 0; i < G; ++i) {
-    const int m = (i * 4 + wg) * 64 + lane;
+    const int m = (i * NSET + wg) * 64 + lane;
     const int h = m / TW, wl = m - h * TW;
     if (m >= M || wl >= tw) continue;
     const size_t o0 = ((size_t)(r * S + h) * W + w0 + wl) * ldc_out;
 #pragma unroll
     for (int c = 0; c < NCG; ++c) {
       if (4 * c >= N) continue;
-      const float4 u = red[((size_t)(wg * G + i) * NCG + c) * 64 + lane];
-      float4 v = make_float4(acc[i][c][0] + u.x, acc[i][c][1] + u.y, acc[i][c][2] + u.z, acc[i][c][3] + u.w);
+      float4 v = make_float4(acc[i][c][0], acc[i][c][1], acc[i][c][2], acc[i][c][3]);
       if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
       if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
       if (mask) {
@@ -681,18 +685,19 @@ bool conv_fwd_supported(int C, int N, int S, int W, int fw) {
   return conv_fwd_plan(C, S, W, fw, TW, RT, lds);
 }
 
-template <int G, int NCG>
+template <int G, int NCG, int KS>
 static void launch_conv_fwd4_t(dim3 grid, size_t lds, hipStream_t s, const float* in, int ldc_in, int C, const float* Ft, const float* bias, int rl,
                                float* out, int ldc_out, int N, int S, int W, int fw, int TW, const float* mask) {
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd4<G, NCG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  hipLaunchKernelGGL((k_conv_fwd4<G, NCG>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask);
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd4<G, NCG, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL((k_conv_fwd4<G, NCG, KS>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask);
 }
 static bool launch_conv_fwd4(int G, int ncg, dim3 grid, size_t lds, hipStream_t s, const float* in, int ldc_in, int C, const float* Ft,
                              const float* bias, int rl, float* out, int ldc_out, int N, int S, int W, int fw, int TW, const float* mask) {
-#define RSR_L4(g, n) if (G == g && ncg == n) { launch_conv_fwd4_t<g, n>(grid, lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask); return true; }
-  RSR_L4(2, 1) RSR_L4(2, 2) RSR_L4(2, 3) RSR_L4(2, 4) RSR_L4(2, 5) RSR_L4(2, 6) RSR_L4(2, 7) RSR_L4(2, 8)
-  RSR_L4(3, 1) RSR_L4(3, 2) RSR_L4(3, 3) RSR_L4(3, 4) RSR_L4(3, 5) RSR_L4(3, 6) RSR_L4(3, 7) RSR_L4(3, 8)
+#define RSR_L4(g, n, ks) if (G == g && ncg == n) { launch_conv_fwd4_t<g, n, ks>(grid, lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask); return true; }
+  RSR_L4(2, 1, 2) RSR_L4(2, 2, 2) RSR_L4(2, 3, 2) RSR_L4(2, 4, 2) RSR_L4(2, 5, 2) RSR_L4(2, 6, 2) RSR_L4(2, 7, 2) RSR_L4(2, 8, 2)
+  RSR_L4(3, 1, 2) RSR_L4(3, 2, 2) RSR_L4(3, 3, 2) RSR_L4(3, 4, 2) RSR_L4(3, 5, 2) RSR_L4(3, 6, 2) RSR_L4(3, 7, 2) RSR_L4(3, 8, 2)
+  RSR_L4(4, 1, 4) RSR_L4(4, 2, 4) RSR_L4(4, 3, 4) RSR_L4(4, 4, 4) RSR_L4(4, 5, 4) RSR_L4(4, 6, 4) RSR_L4(4, 7, 4) RSR_L4(4, 8, 4)
 #undef RSR_L4
   return false;
 }
@@ -716,8 +721,12 @@ void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const 
   static int conv4 = -1;
   if (conv4 < 0) { const char* e = getenv("RSRGAN_CONV4"); conv4 = e ? atoi(e) : 1; }
   if (conv4 && N % 4 == 0 && ldc_out % 4 == 0 && (conv4 > 1 || N % 16 != 0) && (!bias || ((size_t)bias & 15) == 0)) {
-    const int G = small ? 2 : 3, ncg = N / 4;
-    const size_t lds4 = std::max(lds, (size_t)4 * G * ncg * 1024);
+    // RSRGAN_CONV4_KS=4: two interleaved group sets x k' quarters for 512-position workgroups (0.86 of the MFMAs of the default
+    // four sets x k' halves at S = 11, measured slower: 566 vs 558 ms per step of the R-CED variant)
+    static int ks4 = -1;
+    if (ks4 < 0) { const char* e = getenv("RSRGAN_CONV4_KS"); ks4 = e ? atoi(e) : 2; }
+    const int G = small ? (ks4 == 4 ? 4 : 2) : 3, ncg = N / 4;
+    const size_t lds4 = std::max(lds, (size_t)8 * ncg * 1024 * (G == 3 ? 2 : G == 4 ? 2 : 1));      // the tree's widest round
     if (lds4 <= 160 * 1024 && launch_conv_fwd4(G, ncg, grid, lds4, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask)) return;
   }
   if (small && N <= 16) hipLaunchKernelGGL((k_conv_fwd<4, 1>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask);

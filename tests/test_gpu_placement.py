@@ -169,10 +169,11 @@ def test_rced_convolution_mfma_forms_agree():
     a = _run_worker(RCED_WORKER, {"RSRGAN_CONV4": "2"})
     b = _run_worker(RCED_WORKER, {"RSRGAN_CONV4": "0"})
     c = _run_worker(RCED_WORKER, {})
-    assert a.keys() == b.keys() == c.keys() and len(a) > 0
+    d = _run_worker(RCED_WORKER, {"RSRGAN_CONV4": "2", "RSRGAN_CONV4_KS": "4"})      # two group sets x k' quarters
+    assert a.keys() == b.keys() == c.keys() == d.keys() and len(a) > 0
     for k in a:
-        assert abs(a[k] - b[k]) <= 2e-5 * max(abs(b[k]), 1e-6), (k, a[k], b[k])
-        assert abs(c[k] - b[k]) <= 2e-5 * max(abs(b[k]), 1e-6), (k, c[k], b[k])
+        for other in (a, c, d):
+            assert abs(other[k] - b[k]) <= 2e-5 * max(abs(b[k]), 1e-6), (k, other[k], b[k])
 
 
 def test_wide_output_small_generator_with_reference_discriminator():
