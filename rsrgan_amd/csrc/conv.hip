@@ -445,15 +445,170 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad(const float* __restrict
     }
   }
 }
+// ---- weight gradient on v_mfma_f32_4x4x1_16B_f32 (output widths 12, 20, 24: no padded MFMA columns, see k_conv_fwd4) ----
+// D[lane][i] = A[4*abid + i] * B[lane]: the gradient vector of ONE position in the A slot (lane l holds d[m][channel l]: one LDS
+// read serves every channel group), 64 consecutive k' of that position's window in the B slot (a contiguous run of the image row:
+// conflict-free 4-byte reads) -> lane = filter element k', registers = four output channels.  The MFMA k axis is ONE position, so
+// there are no padded positions at all: a wave walks exactly the rows a filter row touches and the columns of the strip.
+// Wave roles (NWV = 8, 10 or 12 waves, chosen so that every wave has a role and the accumulators fit): k' group (64 k' each) x row set (RW of the workgroup's DH filter rows) x position part (columns wl = ps,
+// ps + PS, ..); waves beyond NKG * NRS * PS only stage.  Every (row set, position part) writes its own partial slot (the reducer
+// sums them in a fixed order).  Same staging, LDS layout and bias sums as k_conv_wgrad.
+template <int NCG, int RW, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_conv_wgrad4(const float* __restrict__ in, int ldc_in, int C, const float* __restrict__ d, int ldc_d,
+                                                      int N, float* __restrict__ part, int S, int W, int fw, int TW, int R, int fpg,
+                                                      float* __restrict__ bpart, int DH, int NKG, int PS) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Cp = conv_cpad(C), KP = conv_kp(fw, C);
+  const int pt = (S - 1) / 2, pl = (fw - 1) / 2;
+  const int rowlen = (TW + fw - 1) * Cp + 16;
+  const int MP = (S * TW + 15) / 16 * 16;
+  float* img = smem;                                      // [S + 1][rowlen], row S = zeros
+  float* ds = smem + (size_t)(S + 1) * rowlen;            // [MP][36] gradient strip
+  int* gtab = reinterpret_cast<int*>(ds + (size_t)MP * 36) + MP;      // [MP] offset of position m in one frame of d (-1: outside the strip)
+  const int dh0 = blockIdx.x, dstep = gridDim.x, grp = blockIdx.y, strip = blockIdx.z;
+  const int w0 = strip * TW, tw = min(TW, W - w0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NRS = (DH + RW - 1) / RW;
+  const int kg = wv % NKG, rs = (wv / NKG) % NRS, ps = wv / (NKG * NRS);
+  const bool active = ps < PS;
+  f32x4 acc[RW][NCG];
+#pragma unroll
+  for (int j = 0; j < RW; ++j)
+#pragma unroll
+    for (int c = 0; c < NCG; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int M = S * TW;
+  for (int m = tid; m < MP; m += 64 * NWV) {
+    const int h = m / TW, wl = m - h * TW;
+    gtab[m] = (m < M && wl < tw) ? (h * W + w0 + wl) * ldc_d : -1;
+  }
+  const int cp4 = Cp / 4, row4 = rowlen / 4;
+  const int e0 = tid < row4 ? tid : -1;
+  const int sx = e0 >= 0 ? e0 / cp4 : 0, sc = e0 >= 0 ? (e0 - sx * cp4) * 4 : 0;
+  const int swcol = w0 - pl + sx;
+  const bool s_in = e0 >= 0 && sx < TW + fw - 1 && swcol >= 0 && swcol < W && sc < C;
+  __syncthreads();
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nwl = active ? (tw - ps + PS - 1) / PS : 0;      // this wave's columns of a strip row
+  for (int f = 0; f < fpg; ++f) {
+    const int r = grp * fpg + f;
+    if (r >= R) break;
+    __syncthreads();
+    {
+      // image strip: thread e0 owns float4 slot e0 of every row (row4 <= 512 is checked on the host); rows are independent loads
+      // All loads of a frame are in flight together: six image rows per batch and up to four gradient slots, UNCONDITIONAL from
+      // clamped / stand-in addresses, the zeros selected afterwards.  (Round 2's loops loaded under a branch inside a loop with a
+      // run-time bound: one global round trip per image row, 12 per frame -- 40 % of the kernel's time at W = 257.)
+      const float* dsrc = d + (size_t)r * S * W * ldc_d;
+      constexpr int DSLOTS = (64 + NWV - 1) / NWV;            // MP * 8 <= 4096 <= DSLOTS * 64 * NWV
+      float4 dv[DSLOTS];
+      int dgo[DSLOTS];
+      // (bias gradient = column sums of d: the row-group-0 workgroups see every gradient element of their frames exactly once on its
+      //  way to LDS -- a separate tall column sum re-read the 2.3 GB tensor per layer, 9 ms of the 608 ms step)
+#pragma unroll
+      for (int u = 0; u < DSLOTS; ++u) {                     // 8 float4 = 32 channels per position
+        const int i = tid + u * 64 * NWV;
+        const int m = min(i >> 3, MP - 1), c = (i & 7) * 4;
+        dgo[u] = (i < MP * 8 && c < N) ? gtab[m] : -1;
+        dv[u] = *reinterpret_cast<const float4*>(dsrc + (dgo[u] >= 0 ? dgo[u] + c : 0));
+      }
+      if (e0 >= 0) {
+        const float* src = s_in ? in + ((size_t)r * S * W + swcol) * ldc_in + sc : in;
+        const size_t hs = s_in ? (size_t)W * ldc_in : 0;
+        for (int h0 = 0; h0 <= S; h0 += 6) {
+          float4 v[6];
+#pragma unroll
+          for (int u = 0; u < 6; ++u) v[u] = *reinterpret_cast<const float4*>(src + (size_t)min(h0 + u, S - 1) * hs);
+#pragma unroll
+          for (int u = 0; u < 6; ++u) {
+            const int h = h0 + u;
+            const bool ok = s_in && h < S;
+            const float4 z = make_float4(ok ? v[u].x : 0.f, ok ? v[u].y : 0.f, ok ? v[u].z : 0.f, ok ? v[u].w : 0.f);
+            if (h <= S) *reinterpret_cast<float4*>(img + (size_t)h * rowlen + (size_t)e0 * 4) = z;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < DSLOTS; ++u) {
+        const int i = tid + u * 64 * NWV;
+        const int m = i >> 3, c = (i & 7) * 4;
+        const bool ok = dgo[u] >= 0;
+        const float4 z = make_float4(ok ? dv[u].x : 0.f, ok ? dv[u].y : 0.f, ok ? dv[u].z : 0.f, ok ? dv[u].w : 0.f);
+        if (i < MP * 8) *reinterpret_cast<float4*>(ds + (size_t)m * 36 + c) = z;
+        bsum.x += z.x; bsum.y += z.y; bsum.z += z.z; bsum.w += z.w;
+      }
+    }
+    __syncthreads();
+    if (!active) continue;                                 // (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+      const int dd = rs * RW + j, dh = dh0 + dd * dstep;
+      if (dd >= DH || dh >= S) continue;                   // (uniform)
+      const int hlo = max(0, pt - dh), hhi = min(S, S + pt - dh);
+      // (a single position stream per filter row with scalar carries and the next step's operands requested ahead measured
+      //  SLOWER, 560 vs 535 ms per step: the other waves of the SIMD already cover the LDS latency, the carries cost issue slots)
+      for (int h = hlo; h < hhi; ++h) {
+        const float* pa = ds + (size_t)(h * TW + ps) * 36 + (lane & 31);
+        const float* pb = img + (size_t)(h + dh - pt) * rowlen + ps * Cp + 64 * kg + lane;
+        const int sa = PS * 36, sb = PS * Cp;
+        int t = 0;
+        for (; t + 4 <= nwl; t += 4) {
+          float av[4], bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { av[u] = pa[u * sa]; bv[u] = pb[u * sb]; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+#define RSR_W4(c) if (NCG > c) acc[j][NCG > c ? c : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[u], bv[u], acc[j][NCG > c ? c : 0], 4, c, 0);
+            RSR_W4(0) RSR_W4(1) RSR_W4(2) RSR_W4(3) RSR_W4(4) RSR_W4(5) RSR_W4(6) RSR_W4(7)
+          }
+          pa += 4 * sa; pb += 4 * sb;
+        }
+        for (; t < nwl; ++t) {                             // (the last 1-3 columns one by one: as ONE step with zero gradients past the end
+          const float a1 = pa[0], b1 = pb[0];              //  it measured slower, 550 vs 535 ms: the kernel is bound by its MFMA count)
+#define RSR_W4B(c) if (NCG > c) acc[j][NCG > c ? c : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b1, acc[j][NCG > c ? c : 0], 4, c, 0);
+          RSR_W4B(0) RSR_W4B(1) RSR_W4B(2) RSR_W4B(3) RSR_W4B(4) RSR_W4B(5) RSR_W4B(6) RSR_W4B(7)
+#undef RSR_W4B
+          pa += sa; pb += sb;
+        }
+#undef RSR_W4
+      }
+    }
+  }
+  if (bpart && blockIdx.x == 0) {                          // (uniform) fixed-order sum over the 64 * NWV / 8 threads of a channel group
+    __syncthreads();
+    float4* sb4 = reinterpret_cast<float4*>(smem);
+    sb4[tid] = bsum;
+    __syncthreads();
+    if (tid < 8) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < 8 * NWV; ++j) { const float4 v = sb4[tid + 8 * j]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+      *reinterpret_cast<float4*>(bpart + ((size_t)grp * gridDim.z + strip) * 32 + 4 * tid) = t;
+    }
+  }
+  // partial slot of (frame group, strip, position part): part[((grp*nstrips + strip)*PS + ps)][dh][k'][32]; rows of this slot that
+  // belong to other row sets are written by their waves (same ps)
+  if (!active) return;
+  const int kq = 64 * kg + lane;
+  if (kq >= KP) return;
+#pragma unroll
+  for (int j = 0; j < RW; ++j) {
+    const int dd = rs * RW + j, dh = dh0 + dd * dstep;
+    if (dd >= DH || dh >= S) continue;
+    float* po = part + (((size_t)(grp * gridDim.z + strip) * PS + ps) * S + dh) * (size_t)KP * 32 + (size_t)kq * 32;
+#pragma unroll
+    for (int c = 0; c < NCG; ++c) *reinterpret_cast<float4*>(po + 4 * c) = make_float4(acc[j][c][0], acc[j][c][1], acc[j][c][2], acc[j][c][3]);
+  }
+}
+
 // dW[(dh*fw + dw)*C + c][co] = sum over partial tiles p of part[p][dh][dw*C' + c][co]   (fixed order)
 __global__ void k_conv_wgrad_red(const float* __restrict__ part, int nparts, int S, int fw, int C, int N, float* __restrict__ dW, int ldw,
-                                 const float* __restrict__ bpart, float* __restrict__ db) {
+                                 const float* __restrict__ bpart, float* __restrict__ db, int nbparts) {
   const int Cp = conv_cpad(C), KP = conv_kp(fw, C);
   const int total = S * fw * C * N;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (db && i >= total && i < total + N) {                 // the bias gradient from the row-group-0 workgroups' column sums
     float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += bpart[(size_t)p * 32 + (i - total)];
+    for (int p = 0; p < nbparts; ++p) s += bpart[(size_t)p * 32 + (i - total)];
     db[i - total] = s;
     return;
   }
@@ -774,11 +929,22 @@ static void wgrad_plan(int R, int S, int nstrips, int KP, int& DH, int& fpg, int
     if (f < best) { best = f; DH = dhc; fpg = f; groups = (R + f - 1) / f; }
   }
 }
+// k_conv_wgrad4: position parts per (k' group, row set) of a 16-wave workgroup
+// (workgroup of 8, 10 or 12 waves: the largest of those that the roles k' group x row set x position part fill completely, else 8)
+static int wgrad4_waves(int KP, int DH, int& PS) {
+  const int roles = ((KP + 63) / 64) * ((DH + 2) / 3);
+  for (int w : {12, 10, 8})
+    if (roles <= w && w % roles == 0) { PS = w / roles; return w; }
+  PS = std::max(1, 8 / roles);
+  return roles <= 8 ? 8 : (roles <= 10 ? 10 : 12);
+}
+static int wgrad4_ps(int KP, int DH) { int ps; wgrad4_waves(KP, DH, ps); return ps; }
 size_t conv_wgrad_ws_floats(int C, int R, int S, int W, int fw) {
   const int TW = wgrad_tw(S, W), nstrips = (W + TW - 1) / TW;
   int DH, fpg, groups;
   wgrad_plan(R, S, nstrips, conv_kp(fw, C), DH, fpg, groups);
-  return (size_t)groups * nstrips * (S * conv_kp(fw, C) + 1) * 32;          // filter partials + one 32-float bias partial per (group, strip)
+  // filter partials (one slot per position part in the 4x4x1 form) + one 32-float bias partial per (group, strip)
+  return (size_t)groups * nstrips * ((size_t)wgrad4_ps(conv_kp(fw, C), DH) * S * conv_kp(fw, C) + 1) * 32;
 }
 bool conv_wgrad_supported(int C, int N, int S, int W, int fw) {
   if (!conv_fwd_supported(C, N, S, W, fw)) return false;
@@ -809,6 +975,21 @@ static void wgrad_launch_dh(int DH, dim3 grid, size_t lds, hipStream_t s, const 
     else hipLaunchKernelGGL((k_conv_wgrad<KT, NT, 16, 6>), grid, dim3(1024), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg, bpart);
   }
 }
+template <int NCG, int NWV>
+static void launch_conv_wgrad4_t(dim3 grid, size_t lds, hipStream_t s, const float* in, int ldc_in, int C, const float* d, int ldc_d, int N, float* ws,
+                                 int S, int W, int fw, int TW, int R, int fpg, float* bpart, int DH, int nkg, int PS) {
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_wgrad4<NCG, 3, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL((k_conv_wgrad4<NCG, 3, NWV>), grid, dim3(64 * NWV), lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg, bpart, DH, nkg, PS);
+}
+static void launch_conv_wgrad4(int ncg, int nwv, dim3 grid, size_t lds, hipStream_t s, const float* in, int ldc_in, int C, const float* d, int ldc_d, int N,
+                               float* ws, int S, int W, int fw, int TW, int R, int fpg, float* bpart, int DH, int nkg, int PS) {
+#define RSR_W(n, w) if (ncg == n && nwv == w) { launch_conv_wgrad4_t<n, w>(grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg, bpart, DH, nkg, PS); return; }
+#define RSR_WN(n) RSR_W(n, 8) RSR_W(n, 10) RSR_W(n, 12)
+  RSR_WN(1) RSR_WN(2) RSR_WN(3) RSR_WN(4) RSR_WN(5) RSR_WN(6) RSR_WN(7) RSR_WN(8)
+#undef RSR_WN
+#undef RSR_W
+}
 void launch_conv_wgrad(const float* in, int ldc_in, int C, const float* d, int ldc_d, int N, float* dW, int ldw, float* ws, int R, int S,
                        int W, int fw, hipStream_t s, float* db) {
   const int TW = wgrad_tw(S, W), nstrips = (W + TW - 1) / TW;
@@ -817,14 +998,31 @@ void launch_conv_wgrad(const float* in, int ldc_in, int C, const float* d, int l
   wgrad_plan(R, S, nstrips, KP, DH, fpg, groups);
   const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 38) * sizeof(float);
   dim3 grid((S + DH - 1) / DH, groups, nstrips);
-  float* bpart = db ? ws + (size_t)groups * nstrips * S * KP * 32 : nullptr;
+  // output widths that waste MFMA columns go to the 4x4x1 form (RSRGAN_CONV4 as for the forward kernel; RSRGAN_WGRAD4=0 keeps the
+  // weight gradient on 16x16x4)
+  static int w4 = -1;
+  if (w4 < 0) { const char* e = getenv("RSRGAN_CONV4"); const char* e2 = getenv("RSRGAN_WGRAD4"); w4 = e2 ? atoi(e2) : (e ? atoi(e) : 1); }
+  const int nkg = (KP + 63) / 64;
+  int PS = 1;
+  const int nwv4 = wgrad4_waves(KP, DH, PS);
+  const bool use4 = w4 && N % 4 == 0 && N <= 32 && (w4 > 1 || N % 16 != 0) && nkg * ((DH + 2) / 3) <= 12 &&
+                    ((TW + fw - 1) * conv_cpad(C) + 16) / 4 <= 64 * nwv4;
+  if (!use4) PS = 1;
+  const int nparts = groups * nstrips * PS;
+  float* bpart = db ? ws + (size_t)nparts * S * KP * 32 : nullptr;
+  if (use4) {
+    launch_conv_wgrad4(N / 4, nwv4, grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg, bpart, DH, nkg, PS);
+    const int total4 = S * fw * C * N;
+    hipLaunchKernelGGL(k_conv_wgrad_red, dim3((total4 + N + 255) / 256), dim3(256), 0, s, ws, nparts, S, fw, C, N, dW, ldw, bpart, db, groups * nstrips);
+    return;
+  }
   const bool k2 = KP > 16 * 16, n1 = N <= 16;          // 16 waves: one k'-tile per wave up to K' = 256, two beyond
   if (k2 && n1) wgrad_launch_dh<2, 1>(DH, grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg, bpart);
   else if (k2) wgrad_launch_dh<2, 2>(DH, grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg, bpart);
   else if (n1) wgrad_launch_dh<1, 1>(DH, grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg, bpart);
   else wgrad_launch_dh<1, 2>(DH, grid, lds, s, in, ldc_in, C, d, ldc_d, N, ws, S, W, fw, TW, R, fpg, bpart);
   const int total = S * fw * C * N;
-  hipLaunchKernelGGL(k_conv_wgrad_red, dim3((total + N + 255) / 256), dim3(256), 0, s, ws, groups * nstrips, S, fw, C, N, dW, ldw, bpart, db);
+  hipLaunchKernelGGL(k_conv_wgrad_red, dim3((total + N + 255) / 256), dim3(256), 0, s, ws, groups * nstrips, S, fw, C, N, dW, ldw, bpart, db, groups * nstrips);
 }
 
 }  // namespace rsr

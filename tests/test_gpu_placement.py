@@ -163,13 +163,16 @@ def test_rced_weight_gradient_geometries_agree():
 
 
 def test_rced_convolution_mfma_forms_agree():
-    """csrc/conv.hip: the 4x4x1 form (k_conv_fwd4) on every layer (RSRGAN_CONV4=2), on the widths that are no multiple of 16 (the
+    """csrc/conv.hip: the 4x4x1 forms (k_conv_fwd4, k_conv_wgrad4) on every layer (RSRGAN_CONV4=2), on the widths that are no multiple of 16 (the
     default) and nowhere (0): the same products in another summation order.  (Each form is also compared with the oracle:
     tests/test_gpu_trainers.py runs under the default, and its R-CED cases pass under RSRGAN_CONV4=2 as well.)"""
     a = _run_worker(RCED_WORKER, {"RSRGAN_CONV4": "2"})
     b = _run_worker(RCED_WORKER, {"RSRGAN_CONV4": "0"})
     c = _run_worker(RCED_WORKER, {})
     d = _run_worker(RCED_WORKER, {"RSRGAN_CONV4": "2", "RSRGAN_CONV4_KS": "4"})      # two group sets x k' quarters
+    e = _run_worker(RCED_WORKER, {"RSRGAN_CONV4": "1", "RSRGAN_WGRAD4": "0"})          # the weight gradient alone on 16x16x4
+    for k in b:
+        assert abs(e[k] - b[k]) <= 2e-5 * max(abs(b[k]), 1e-6), (k, e[k], b[k])
     assert a.keys() == b.keys() == c.keys() == d.keys() and len(a) > 0
     for k in a:
         for other in (a, c, d):
