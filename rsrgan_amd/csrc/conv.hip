@@ -46,30 +46,44 @@ __global__ void k_conv_prep(const float* __restrict__ F, int ldf_src, int S, int
 template <int RT, int NT>
 __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, int ldc_in, int C, const float* __restrict__ Ft,
                                                   const float* __restrict__ bias, int relu, float* __restrict__ out, int ldc_out, int N,
-                                                  int S, int W, int fw, int TW, const float* __restrict__ mask) {
+                                                  int S, int W, int fw, int TW, const float* __restrict__ mask, int wbase, int wend) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Cp = conv_cpad(C), nkb = conv_kp(fw, C) / 16, ldf = conv_ldf(fw, C);
   const int pt = (S - 1) / 2, pl = (fw - 1) / 2;
   const int rowlen = (TW + fw - 1) * Cp + 16;             // +16: the last k-block of the last position may run past its window
   float* img = smem;                                      // [S + 1][rowlen], row S = zeros
   float* fts = smem + (size_t)(S + 1) * rowlen;           // [32][ldf] filter slice of one dh
-  const int r = blockIdx.y, w0 = blockIdx.x * TW;
-  const int tw = min(TW, W - w0);
+  const int r = blockIdx.y, w0 = wbase + blockIdx.x * TW;      // this launch covers the columns [wbase, wend)
+  const int tw = min(TW, wend - w0);
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   // image strip -> LDS: position x of a row is image column w0 - pl + x; every slot (halo, channel pads, zero row) is written
   {
+    // six loads in flight per thread, UNCONDITIONAL from clamped / stand-in addresses, the zeros selected afterwards (a load under
+    // a branch in a loop with a run-time bound is one global round trip per iteration: up to 13 of them per workgroup)
     const int cp4 = Cp / 4, row4 = rowlen / 4;
     const int total4 = (S + 1) * row4;
-    for (int i = tid; i < total4; i += 512) {
-      const int h = i / row4, e = i - h * row4;
-      const int x = e / cp4, c = (e - x * cp4) * 4;
-      const int wcol = w0 - pl + x;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (h < S && x < TW + fw - 1 && wcol >= 0 && wcol < W && c < C)
-        v = *reinterpret_cast<const float4*>(in + ((size_t)(r * S + h) * W + wcol) * ldc_in + c);
-      *reinterpret_cast<float4*>(img + (size_t)h * rowlen + (size_t)e * 4) = v;
+    constexpr int SU = 6;
+    for (int i0 = tid; i0 < total4; i0 += 512 * SU) {
+      float4 v[SU];
+      bool ok[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int i = min(i0 + u * 512, total4 - 1);
+        const int h = i / row4, e = i - h * row4;
+        const int x = e / cp4, c = (e - x * cp4) * 4;
+        const int wcol = w0 - pl + x;
+        ok[u] = h < S && x < TW + fw - 1 && wcol >= 0 && wcol < W && c < C;
+        const float* src = ok[u] ? in + ((size_t)(r * S + h) * W + wcol) * ldc_in + c : in;
+        v[u] = *reinterpret_cast<const float4*>(src);
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int i = i0 + u * 512;
+        const float4 z = make_float4(ok[u] ? v[u].x : 0.f, ok[u] ? v[u].y : 0.f, ok[u] ? v[u].z : 0.f, ok[u] ? v[u].w : 0.f);
+        if (i < total4) *reinterpret_cast<float4*>(img + (size_t)i * 4) = z;
+      }
     }
   }
   // per-lane position of each row tile: m = (wv*RT + i)*16 + lr -> (h, wl); positions >= S*tw are parked on the zero row
@@ -637,7 +651,7 @@ size_t conv_prep_floats(int S, int fw, int C) { return (size_t)S * 32 * conv_ldf
 template <int G, int NCG, int KS = 2>          // KS: waves per position-group set (k' split); NSET = 8 / KS sets of G groups
 __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in, int ldc_in, int C, const float* __restrict__ Ft,
                                                    const float* __restrict__ bias, int relu, float* __restrict__ out, int ldc_out, int N,
-                                                   int S, int W, int fw, int TW, const float* __restrict__ mask) {
+                                                   int S, int W, int fw, int TW, const float* __restrict__ mask, int wbase, int wend) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Cp = conv_cpad(C), ldf = conv_ldf(fw, C);
   const int nk4 = fw * Cp / 4;                            // float4 steps of one filter row (no rounding to whole 16-float k-blocks here)
@@ -645,8 +659,8 @@ __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in,
   const int rowlen = (TW + fw - 1) * Cp + 16;
   float* img = smem;                                      // [S + 1][rowlen], row S = zeros
   float* fts = smem + (size_t)(S + 1) * rowlen;           // [32][ldf] filter slice of one dh
-  const int r = blockIdx.y, w0 = blockIdx.x * TW;
-  const int tw = min(TW, W - w0);
+  const int r = blockIdx.y, w0 = wbase + blockIdx.x * TW;      // this launch covers the columns [wbase, wend)
+  const int tw = min(TW, wend - w0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   // KS = 2: sets {w&3} of groups {w&3, (w&3)+4, ..}, k' halves.  KS = 4 (512-position workgroups): TWO interleaved sets (even / odd
@@ -655,16 +669,30 @@ __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in,
   constexpr int NSET = 8 / KS;
   const int wg = wv & (NSET - 1), half = wv / NSET;       // set, k' part
   {
+    // six loads in flight per thread, UNCONDITIONAL from clamped / stand-in addresses, the zeros selected afterwards (a load under
+    // a branch in a loop with a run-time bound is one global round trip per iteration: up to 13 of them per workgroup)
     const int cp4 = Cp / 4, row4 = rowlen / 4;
     const int total4 = (S + 1) * row4;
-    for (int i = tid; i < total4; i += 512) {
-      const int h = i / row4, e = i - h * row4;
-      const int x = e / cp4, c = (e - x * cp4) * 4;
-      const int wcol = w0 - pl + x;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (h < S && x < TW + fw - 1 && wcol >= 0 && wcol < W && c < C)
-        v = *reinterpret_cast<const float4*>(in + ((size_t)(r * S + h) * W + wcol) * ldc_in + c);
-      *reinterpret_cast<float4*>(img + (size_t)h * rowlen + (size_t)e * 4) = v;
+    constexpr int SU = 6;
+    for (int i0 = tid; i0 < total4; i0 += 512 * SU) {
+      float4 v[SU];
+      bool ok[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int i = min(i0 + u * 512, total4 - 1);
+        const int h = i / row4, e = i - h * row4;
+        const int x = e / cp4, c = (e - x * cp4) * 4;
+        const int wcol = w0 - pl + x;
+        ok[u] = h < S && x < TW + fw - 1 && wcol >= 0 && wcol < W && c < C;
+        const float* src = ok[u] ? in + ((size_t)(r * S + h) * W + wcol) * ldc_in + c : in;
+        v[u] = *reinterpret_cast<const float4*>(src);
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int i = i0 + u * 512;
+        const float4 z = make_float4(ok[u] ? v[u].x : 0.f, ok[u] ? v[u].y : 0.f, ok[u] ? v[u].z : 0.f, ok[u] ? v[u].w : 0.f);
+        if (i < total4) *reinterpret_cast<float4*>(img + (size_t)i * 4) = z;
+      }
     }
   }
   const int M = S * TW;
@@ -842,14 +870,14 @@ bool conv_fwd_supported(int C, int N, int S, int W, int fw) {
 
 template <int G, int NCG, int KS>
 static void launch_conv_fwd4_t(dim3 grid, size_t lds, hipStream_t s, const float* in, int ldc_in, int C, const float* Ft, const float* bias, int rl,
-                               float* out, int ldc_out, int N, int S, int W, int fw, int TW, const float* mask) {
+                               float* out, int ldc_out, int N, int S, int W, int fw, int TW, const float* mask, int wbase, int wend) {
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd4<G, NCG, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  hipLaunchKernelGGL((k_conv_fwd4<G, NCG, KS>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask);
+  hipLaunchKernelGGL((k_conv_fwd4<G, NCG, KS>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend);
 }
 static bool launch_conv_fwd4(int G, int ncg, dim3 grid, size_t lds, hipStream_t s, const float* in, int ldc_in, int C, const float* Ft,
-                             const float* bias, int rl, float* out, int ldc_out, int N, int S, int W, int fw, int TW, const float* mask) {
-#define RSR_L4(g, n, ks) if (G == g && ncg == n) { launch_conv_fwd4_t<g, n, ks>(grid, lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask); return true; }
+                             const float* bias, int rl, float* out, int ldc_out, int N, int S, int W, int fw, int TW, const float* mask, int wbase, int wend) {
+#define RSR_L4(g, n, ks) if (G == g && ncg == n) { launch_conv_fwd4_t<g, n, ks>(grid, lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend); return true; }
   RSR_L4(2, 1, 2) RSR_L4(2, 2, 2) RSR_L4(2, 3, 2) RSR_L4(2, 4, 2) RSR_L4(2, 5, 2) RSR_L4(2, 6, 2) RSR_L4(2, 7, 2) RSR_L4(2, 8, 2)
   RSR_L4(3, 1, 2) RSR_L4(3, 2, 2) RSR_L4(3, 3, 2) RSR_L4(3, 4, 2) RSR_L4(3, 5, 2) RSR_L4(3, 6, 2) RSR_L4(3, 7, 2) RSR_L4(3, 8, 2)
   RSR_L4(4, 1, 4) RSR_L4(4, 2, 4) RSR_L4(4, 3, 4) RSR_L4(4, 4, 4) RSR_L4(4, 5, 4) RSR_L4(4, 6, 4) RSR_L4(4, 7, 4) RSR_L4(4, 8, 4)
@@ -857,10 +885,9 @@ static bool launch_conv_fwd4(int G, int ncg, dim3 grid, size_t lds, hipStream_t 
   return false;
 }
 
-void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const float* bias, bool relu, float* out, int ldc_out, int N,
-                     int R, int S, int W, int fw, hipStream_t s, const float* mask) {
-  int TW = W, RT = 4; size_t lds = 0;
-  if (!conv_fwd_plan(C, S, W, fw, TW, RT, lds)) return;
+// one launch over the columns [wbase, wend) in strips of TW
+static void conv_fwd_range(int wbase, int wend, int TW, int RT, size_t lds, const float* in, int ldc_in, int C, const float* Ft, const float* bias,
+                           int rl, float* out, int ldc_out, int N, int R, int S, int W, int fw, hipStream_t s, const float* mask) {
   const bool small = RT == 4;
   static bool attr = false;
   if (!attr) {
@@ -870,8 +897,7 @@ void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd<6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  dim3 grid((W + TW - 1) / TW, R);
-  const int rl = relu ? 1 : 0;
+  dim3 grid((wend - wbase + TW - 1) / TW, R);
   // output widths that waste MFMA columns (N % 16 != 0) go to the 4x4x1 form; RSRGAN_CONV4: 0 = never, 1 = those (default), 2 = every N % 4 == 0
   static int conv4 = -1;
   if (conv4 < 0) { const char* e = getenv("RSRGAN_CONV4"); conv4 = e ? atoi(e) : 1; }
@@ -882,12 +908,37 @@ void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const 
     if (ks4 < 0) { const char* e = getenv("RSRGAN_CONV4_KS"); ks4 = e ? atoi(e) : 2; }
     const int G = small ? (ks4 == 4 ? 4 : 2) : 3, ncg = N / 4;
     const size_t lds4 = std::max(lds, (size_t)8 * ncg * 1024 * (G == 3 ? 2 : G == 4 ? 2 : 1));      // the tree's widest round
-    if (lds4 <= 160 * 1024 && launch_conv_fwd4(G, ncg, grid, lds4, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask)) return;
+    if (lds4 <= 160 * 1024 && launch_conv_fwd4(G, ncg, grid, lds4, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend)) return;
   }
-  if (small && N <= 16) hipLaunchKernelGGL((k_conv_fwd<4, 1>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask);
-  else if (small) hipLaunchKernelGGL((k_conv_fwd<4, 2>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask);
-  else if (N <= 16) hipLaunchKernelGGL((k_conv_fwd<6, 1>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask);
-  else hipLaunchKernelGGL((k_conv_fwd<6, 2>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask);
+  if (small && N <= 16) hipLaunchKernelGGL((k_conv_fwd<4, 1>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend);
+  else if (small) hipLaunchKernelGGL((k_conv_fwd<4, 2>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend);
+  else if (N <= 16) hipLaunchKernelGGL((k_conv_fwd<6, 1>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend);
+  else hipLaunchKernelGGL((k_conv_fwd<6, 2>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend);
+}
+
+void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const float* bias, bool relu, float* out, int ldc_out, int N,
+                     int R, int S, int W, int fw, hipStream_t s, const float* mask) {
+  int TW = W, RT = 4; size_t lds = 0;
+  if (!conv_fwd_plan(C, S, W, fw, TW, RT, lds)) return;
+  const int rl = relu ? 1 : 0;
+  // Row-aligned strips (RSRGAN_CONV_ROWS=0 turns them off): with 64-column strips a 16- or 64-position group never straddles two
+  // image rows, so the rows a filter row does not touch are skipped exactly and every lane of a full strip is a real position
+  // (a 257-wide frame cut into 6 x 43 columns used 69 % / 80 % of the position slots of the 4x4x1 / 16x16x4 kernel).  The W % 64
+  // columns that are left take a second launch with their own plan.
+  static int rows = -1;
+  if (rows < 0) { const char* e = getenv("RSRGAN_CONV_ROWS"); rows = e ? atoi(e) : 1; }
+  const size_t lds64 = ((size_t)(S + 1) * ((64 + fw - 1) * conv_cpad(C) + 16) + (size_t)32 * conv_ldf(fw, C)) * sizeof(float);
+  if (rows && W > 64 && S * 64 <= 8 * 6 * 16 && lds64 <= 160 * 1024) {
+    const int wmain = W / 64 * 64;
+    conv_fwd_range(0, wmain, 64, 6, lds64, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, R, S, W, fw, s, mask);
+    if (wmain < W) {
+      int TWr = W - wmain, RTr = 4; size_t ldsr = 0;
+      if (!conv_fwd_plan(C, S, W - wmain, fw, TWr, RTr, ldsr)) return;
+      conv_fwd_range(wmain, W, TWr, RTr, ldsr, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, R, S, W, fw, s, mask);
+    }
+    return;
+  }
+  conv_fwd_range(0, W, TW, RT, lds, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, R, S, W, fw, s, mask);
 }
 
 // Grid of the weight-gradient kernel: ceil(S / DH) filter-row groups x frame groups x strips, at most 256 workgroups (one round
