@@ -55,6 +55,40 @@ def test_rnn_trainer_matches_oracle(g_type, flags):
     assert np.allclose(ev, np.ravel(w)[1:], rtol=2e-4) and ev[1] == 0.0
 
 
+@pytest.mark.parametrize("g_type,flags", [("lstm", 1), ("res_lstm_base", 0)])
+def test_rnn_trainer_with_dropout_wrapper(g_type, flags):
+    """models/rnn_trainer.py:76-78 keep_prob + the generators' DropoutWrapper (lstm.py:99-102, res_lstm_base.py:96-99) on the
+    supervised path: three Adam steps with the device's masks fed to the oracle, then every variable; the evaluation fetch
+    is undropped."""
+    from rsrgan_amd.trainer import RNNTrainer
+    from tests.helpers import seq_dropout_mask
+    cfg = small_cfg(g_type)
+    B, T, keep = 5, 7, 0.75
+    g, d = rand_params(cfg, 11)
+    args = args_for(cfg, B, l2_scale=1e-3, g_learning_rate=1e-3, keep_prob=keep)
+    m = RNNTrainer(None, args, ["gpu:0"], max_frames=T, net_overrides=dict(overrides(cfg), flags=flags))
+    m.set_vars(g, d)
+    o = O.GanRnnOracle(cfg, g, d, batch_size=B, l2_scale=1e-3, g_learning_rate=float(np.float32(1e-3)), mse_lambda=1.0,
+                       keep_prob=float(np.float32(keep)),
+                       mask_fn=lambda run, tower, layer, b, t, p: seq_dropout_mask(4321, run, layer, b, t, p, keep))
+    o.supervised = True
+    plain = O.GanRnnOracle(cfg, g, d, batch_size=B, l2_scale=1e-3, g_learning_rate=float(np.float32(1e-3)), mse_lambda=1.0)
+    plain.supervised = True
+    for i in range(3):
+        xs, ls, lns = rand_batch(cfg, B, T, seed=20 + i, ragged=i % 2 == 0)
+        got = np.ravel(m.step(xs, ls, lns))
+        w = o.g_step(xs, ls, lns)
+        assert np.allclose(got, np.ravel(w)[1:], rtol=2e-4), (i, got, w)
+        if i == 0:
+            assert not np.allclose(np.ravel(w)[1], np.ravel(plain.g_step(xs, ls, lns))[1], rtol=1e-3)
+    gv, _ = m.get_vars()
+    for k in o.g:
+        assert rel_err(gv[k], o.g[k]) < 1e-3, k
+    x, lab, ln = rand_batch(cfg, B, T, seed=5, ragged=True)
+    ev = np.ravel(m.step(x, lab, ln, train=False)); w = np.ravel(o.g_step(x, lab, ln, train=False))
+    assert np.allclose(ev[0], w[1], rtol=2e-4)
+
+
 @pytest.mark.parametrize("N", [9, 200])
 def test_dnn_trainer_matches_oracle(N):
     from rsrgan_amd.trainer import DNNTrainer
