@@ -102,6 +102,32 @@ class GAN(Model):
         tw = tw.cpu().numpy()
         return list(tw[:, 0]), list(tw[:, 1]), list(tw[:, 2]), list(tw[:, 3])
 
+    BN_STATE = ("moving_mean", "moving_variance", "renorm_mean", "renorm_mean_weight", "renorm_stddev", "renorm_stddev_weight")
+
+    def sync_batch_norm_state(self):
+        """The reference's towers update ONE copy of the batch-norm statistics (models/gan.py:139-146: the update ops of every
+        tower act on shared variables); here every rank commits the statistics of its own batches, so they drift apart and a
+        checkpoint holds rank 0's.  This puts the mean over ranks into every rank's copy (the outer loops call it once per epoch /
+        iteration, before the cross-validation pass and the checkpoint).  Returns the number of floats exchanged."""
+        if not self.batch_norm or rdist.world_size(self.process_group) <= 1:
+            return 0
+        n = 0
+        for net in (NET_G, NET_D):
+            ranges = [(off, int(np.prod(shape))) for name, shape, off in self.engine.tensor_table(net)
+                      if "/BatchNorm/" in name and name.rsplit("/", 1)[1] in self.BN_STATE]
+            if not ranges:
+                continue
+            flat = self.engine.get_params(net, "variables")
+            packed = torch.cat([flat[o:o + c] for o, c in ranges])
+            rdist.all_reduce_mean_(packed, self.process_group)
+            at = 0
+            for o, c in ranges:
+                flat[o:o + c] = packed[at:at + c]
+                at += c
+            self.engine.set_params(net, flat, "variables")
+            n += at
+        return n
+
     def _summary_fetch(self, inputs, labels, lengths=None):
         d = self.d_step(inputs, labels, train=False)
         g = self.g_step(inputs, labels, train=False)

@@ -150,6 +150,8 @@ def train(FLAGS, model_factory=None, log=print, net_overrides=None):
     for epoch in range(FLAGS.max_epoches):
         start = datetime.datetime.now()
         tr = train_one_epoch(tr_model, tr_reader, tr_num_batch, epoch + 1, FLAGS, log)
+        if hasattr(tr_model, "sync_batch_norm_state"):
+            tr_model.sync_batch_norm_state()           # one copy of the batch-norm statistics over the ranks, like the towers' shared variables
         cv = eval_one_epoch(cv_model, cv_reader, cv_num_batch, epoch + 1, FLAGS, log)
         end = datetime.datetime.now()
         log("Epoch {} (TRAIN AVG.LOSS): {}, d_lr = {:.3e}, g_lr = {:.3e}\nEpoch {} (CROSS AVG.LOSS): {}, time = {:.2f} h".format(

@@ -115,6 +115,8 @@ def train(FLAGS, model_factory=None, log=print, net_overrides=None, batch_counts
     for iteration in range(max_iters):
         start = datetime.datetime.now()
         tr = train_one_iteration(tr_model, tr_batches, train_batch_per_iter, iteration + 1, FLAGS, log)
+        if hasattr(tr_model, "sync_batch_norm_state"):
+            tr_model.sync_batch_norm_state()
         cv = eval_one_iteration(cv_model, cv_batches, valid_batch_per_iter, iteration + 1, FLAGS, log)
         end = datetime.datetime.now()
         log("{0}/{1} (INFO): d_learning_rate = {2:.5e}, g_learning_rate = {3:.5e}, time = {4:.3f} min\n"

@@ -98,3 +98,57 @@ def test_rank0_section_releases_the_other_ranks(fail):
         assert out[1][0] == "raised" and "rank 0 failed: OSError: disk full" in out[1][1]
     else:
         assert out[0] == ("ok", "written") and out[1] == ("ok", None)
+
+
+class _StatEngine:
+    """a stand-in with the three engine calls GAN.sync_batch_norm_state uses"""
+
+    def __init__(self, rank):
+        import torch
+        names = ["g_model/fully_connected/weights", "g_model/fully_connected/BatchNorm/beta", "g_model/fully_connected/BatchNorm/moving_mean",
+                 "g_model/fully_connected/BatchNorm/renorm_stddev_weight", "g_model/fully_connected_1/weights"]
+        shapes = [(3, 4), (4,), (4,), (1,), (4, 2)]
+        self.table, off = [], 0
+        for n, sh in zip(names, shapes):
+            self.table.append((n, sh, off)); off += int(np.prod(sh))
+        self.flat = {0: torch.arange(off, dtype=torch.float32) + 100.0 * rank, 1: torch.zeros(0)}
+        self.sets = 0
+
+    def tensor_table(self, net):
+        return self.table if net == 0 else []
+
+    def get_params(self, net, what="variables"):
+        return self.flat[net].clone()
+
+    def set_params(self, net, flat, what="variables"):
+        self.flat[net] = flat.clone(); self.sets += 1
+
+
+def _bn_sync_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rsrgan_amd.gan import GAN
+        m = GAN.__new__(GAN)
+        m.batch_norm, m.process_group, m.engine = True, None, _StatEngine(rank)
+        n = m.sync_batch_norm_state()
+        out[rank] = (n, m.engine.flat[0].numpy().copy(), m.engine.sets)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_batch_norm_statistics_are_averaged_over_ranks():
+    """rsrgan_amd/gan.py sync_batch_norm_state: the moving / renorm statistics (not beta, gamma or the weights) become the mean over
+    the ranks on every rank -- the reference's towers update one shared copy (models/gan.py:139-146)."""
+    import torch.multiprocessing as mp
+    port, world = _free_port(), 2
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_bn_sync_worker, args=(world, port, out), nprocs=world, join=True)
+    base = np.arange(29, dtype=np.float32)
+    for rank in range(world):
+        n, flat, sets = out[rank]
+        assert n == 5 and sets == 1
+        want = base + 100.0 * rank
+        want[16:21] = base[16:21] + 50.0                    # moving_mean (4) + renorm_stddev_weight (1): the mean of +0 and +100
+        assert np.array_equal(flat, want), (rank, flat, want)
