@@ -46,14 +46,17 @@ __global__ void k_conv_prep(const float* __restrict__ F, int ldf_src, int S, int
 template <int RT, int NT>
 __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, int ldc_in, int C, const float* __restrict__ Ft,
                                                   const float* __restrict__ bias, int relu, float* __restrict__ out, int ldc_out, int N,
-                                                  int S, int W, int fw, int TW, const float* __restrict__ mask, int wbase, int wend) {
+                                                  int S, int W, int fw, int TW, const float* __restrict__ mask, int wbase, int wend, int FB, int R) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Cp = conv_cpad(C), nkb = conv_kp(fw, C) / 16, ldf = conv_ldf(fw, C);
   const int pt = (S - 1) / 2, pl = (fw - 1) / 2;
   const int rowlen = (TW + fw - 1) * Cp + 16;             // +16: the last k-block of the last position may run past its window
-  float* img = smem;                                      // [S + 1][rowlen], row S = zeros
-  float* fts = smem + (size_t)(S + 1) * rowlen;           // [32][ldf] filter slice of one dh
-  const int r = blockIdx.y, w0 = wbase + blockIdx.x * TW;      // this launch covers the columns [wbase, wend)
+  // FB frames per workgroup (1 but for narrow remainder strips: a one-column strip of ONE frame is 11 positions): image rows
+  // [fb][h], ONE zero row ZR = FB*S behind them; position m = (fb*S + h)*TW + wl
+  const int ZR = FB * S;
+  float* img = smem;                                      // [FB*S + 1][rowlen], row ZR = zeros
+  float* fts = smem + (size_t)(ZR + 1) * rowlen;          // [32][ldf] filter slice of one dh
+  const int r0 = blockIdx.y * FB, w0 = wbase + blockIdx.x * TW;      // this launch covers the columns [wbase, wend)
   const int tw = min(TW, wend - w0);
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
     // six loads in flight per thread, UNCONDITIONAL from clamped / stand-in addresses, the zeros selected afterwards (a load under
     // a branch in a loop with a run-time bound is one global round trip per iteration: up to 13 of them per workgroup)
     const int cp4 = Cp / 4, row4 = rowlen / 4;
-    const int total4 = (S + 1) * row4;
+    const int total4 = (ZR + 1) * row4;
     constexpr int SU = 6;
     for (int i0 = tid; i0 < total4; i0 += 512 * SU) {
       float4 v[SU];
@@ -71,11 +74,11 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
 #pragma unroll
       for (int u = 0; u < SU; ++u) {
         const int i = min(i0 + u * 512, total4 - 1);
-        const int h = i / row4, e = i - h * row4;
+        const int hr = i / row4, e = i - hr * row4;          // hr = fb*S + h: frames are consecutive in `in`, so is (r0*S + hr)
         const int x = e / cp4, c = (e - x * cp4) * 4;
         const int wcol = w0 - pl + x;
-        ok[u] = h < S && x < TW + fw - 1 && wcol >= 0 && wcol < W && c < C;
-        const float* src = ok[u] ? in + ((size_t)(r * S + h) * W + wcol) * ldc_in + c : in;
+        ok[u] = hr < ZR && r0 * S + hr < R * S && x < TW + fw - 1 && wcol >= 0 && wcol < W && c < C;
+        const float* src = ok[u] ? in + ((size_t)(r0 * S + hr) * W + wcol) * ldc_in + c : in;
         v[u] = *reinterpret_cast<const float4*>(src);
       }
 #pragma unroll
@@ -87,14 +90,16 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
     }
   }
   // per-lane position of each row tile: m = (wv*RT + i)*16 + lr -> (h, wl); positions >= S*tw are parked on the zero row
-  const int M = S * TW;
-  int ph[RT], pofs[RT];
+  const int M = ZR * TW;
+  int ph[RT], pofs[RT], pfr[RT];
 #pragma unroll
   for (int i = 0; i < RT; ++i) {
     const int m = (i * 8 + wv) * 16 + lr;
-    const int h = m / TW, wl = m - h * TW;
-    const bool ok = m < M && wl < tw;
+    const int hr = m / TW, wl = m - hr * TW;
+    const int fb = hr / S, h = hr - fb * S;
+    const bool ok = m < M && wl < tw && r0 + fb < R;
     ph[i] = ok ? h : -1000;
+    pfr[i] = fb * S;
     pofs[i] = wl * Cp + 4 * q;
   }
   f32x4 acc[RT][NT];
@@ -140,9 +145,9 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
       const int hh = ph[i] + dh - pt;
-      arow[i] = img + (size_t)((hh >= 0 && hh < S) ? hh : S) * rowlen + pofs[i];
+      arow[i] = img + (size_t)((hh >= 0 && hh < S) ? pfr[i] + hh : ZR) * rowlen + pofs[i];
       const int t0 = (i * 8 + wv) * 16;
-      live[i] = t0 + 15 >= vlo && t0 < vhi;
+      live[i] = FB > 1 ? t0 < M : (t0 + 15 >= vlo && t0 < vhi);       // (the row ranges below are one frame's)
     }
     const float* b0 = fts + (size_t)lr * ldf + 4 * q;
     const float* b1 = b0 + (size_t)16 * ldf;
@@ -178,11 +183,11 @@ __global__ __launch_bounds__(512) void k_conv_fwd(const float* __restrict__ in, 
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = (i * 8 + wv) * 16 + 4 * q + e;
-        const int h = m / TW, wl = m - h * TW;
-        if (m >= M || wl >= tw) continue;
+        const int h = m / TW, wl = m - h * TW;              // h = fb*S + row: frames are consecutive in `out`
+        if (m >= M || wl >= tw || r0 * S + h >= R * S) continue;
         float v = acc[i][j][e] + bv;
         if (relu) v = fmaxf(v, 0.f);
-        const size_t oi = ((size_t)(r * S + h) * W + w0 + wl) * ldc_out + co;
+        const size_t oi = ((size_t)(r0 * S + h) * W + w0 + wl) * ldc_out + co;
         if (mask && !(mask[oi] > 0.f)) v = 0.f;       // data gradient: relu' of the layer below, its activations laid out like `out`
         out[oi] = v;
       }
@@ -651,15 +656,18 @@ size_t conv_prep_floats(int S, int fw, int C) { return (size_t)S * 32 * conv_ldf
 template <int G, int NCG, int KS = 2>          // KS: waves per position-group set (k' split); NSET = 8 / KS sets of G groups
 __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in, int ldc_in, int C, const float* __restrict__ Ft,
                                                    const float* __restrict__ bias, int relu, float* __restrict__ out, int ldc_out, int N,
-                                                   int S, int W, int fw, int TW, const float* __restrict__ mask, int wbase, int wend) {
+                                                   int S, int W, int fw, int TW, const float* __restrict__ mask, int wbase, int wend, int FB, int R) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Cp = conv_cpad(C), ldf = conv_ldf(fw, C);
   const int nk4 = fw * Cp / 4;                            // float4 steps of one filter row (no rounding to whole 16-float k-blocks here)
   const int pt = (S - 1) / 2, pl = (fw - 1) / 2;
   const int rowlen = (TW + fw - 1) * Cp + 16;
-  float* img = smem;                                      // [S + 1][rowlen], row S = zeros
-  float* fts = smem + (size_t)(S + 1) * rowlen;           // [32][ldf] filter slice of one dh
-  const int r = blockIdx.y, w0 = wbase + blockIdx.x * TW;      // this launch covers the columns [wbase, wend)
+  // FB frames per workgroup (1 but for narrow remainder strips: a one-column strip of ONE frame is 11 positions): image rows
+  // [fb][h], ONE zero row ZR = FB*S behind them; position m = (fb*S + h)*TW + wl
+  const int ZR = FB * S;
+  float* img = smem;                                      // [FB*S + 1][rowlen], row ZR = zeros
+  float* fts = smem + (size_t)(ZR + 1) * rowlen;          // [32][ldf] filter slice of one dh
+  const int r0 = blockIdx.y * FB, w0 = wbase + blockIdx.x * TW;      // this launch covers the columns [wbase, wend)
   const int tw = min(TW, wend - w0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -672,7 +680,7 @@ __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in,
     // six loads in flight per thread, UNCONDITIONAL from clamped / stand-in addresses, the zeros selected afterwards (a load under
     // a branch in a loop with a run-time bound is one global round trip per iteration: up to 13 of them per workgroup)
     const int cp4 = Cp / 4, row4 = rowlen / 4;
-    const int total4 = (S + 1) * row4;
+    const int total4 = (ZR + 1) * row4;
     constexpr int SU = 6;
     for (int i0 = tid; i0 < total4; i0 += 512 * SU) {
       float4 v[SU];
@@ -680,11 +688,11 @@ __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in,
 #pragma unroll
       for (int u = 0; u < SU; ++u) {
         const int i = min(i0 + u * 512, total4 - 1);
-        const int h = i / row4, e = i - h * row4;
+        const int hr = i / row4, e = i - hr * row4;          // hr = fb*S + h: frames are consecutive in `in`, so is (r0*S + hr)
         const int x = e / cp4, c = (e - x * cp4) * 4;
         const int wcol = w0 - pl + x;
-        ok[u] = h < S && x < TW + fw - 1 && wcol >= 0 && wcol < W && c < C;
-        const float* src = ok[u] ? in + ((size_t)(r * S + h) * W + wcol) * ldc_in + c : in;
+        ok[u] = hr < ZR && r0 * S + hr < R * S && x < TW + fw - 1 && wcol >= 0 && wcol < W && c < C;
+        const float* src = ok[u] ? in + ((size_t)(r0 * S + hr) * W + wcol) * ldc_in + c : in;
         v[u] = *reinterpret_cast<const float4*>(src);
       }
 #pragma unroll
@@ -695,14 +703,16 @@ __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in,
       }
     }
   }
-  const int M = S * TW;
-  int ph[G], pofs[G];
+  const int M = ZR * TW;
+  int ph[G], pofs[G], pfr[G];
 #pragma unroll
   for (int i = 0; i < G; ++i) {
     const int m = (i * NSET + wg) * 64 + lane;
-    const int h = m / TW, wl = m - h * TW;
-    const bool ok = m < M && wl < tw;
+    const int hr = m / TW, wl = m - hr * TW;
+    const int fb = hr / S, h = hr - fb * S;
+    const bool ok = m < M && wl < tw && r0 + fb < R;
     ph[i] = ok ? h : -1000;
+    pfr[i] = fb * S;
     pofs[i] = wl * Cp;
   }
   f32x4 acc[G][NCG];
@@ -743,9 +753,9 @@ __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in,
 #pragma unroll
     for (int i = 0; i < G; ++i) {
       const int hh = ph[i] + dh - pt;
-      arow[i] = img + (size_t)((hh >= 0 && hh < S) ? hh : S) * rowlen + pofs[i];
+      arow[i] = img + (size_t)((hh >= 0 && hh < S) ? pfr[i] + hh : ZR) * rowlen + pofs[i];
       const int t0 = (i * NSET + wg) * 64;
-      live[i] = t0 + 63 >= vlo && t0 < vhi && t0 < M;             // (wave-uniform) a group outside the rows this filter row touches: only zeros
+      live[i] = FB > 1 ? t0 < M : (t0 + 63 >= vlo && t0 < vhi && t0 < M);             // (wave-uniform) a group outside the rows this filter row touches: only zeros
     }
     // One uniform branch per live group and step around its 4 * NCG products (a branch per group AND component cost a fifth of
     // the issue slots: SQ_INSTS_SALU 1.2e9 next to 2.9e9 MFMAs; one specialised copy of the loop per live mask doubled the
@@ -819,9 +829,9 @@ __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in,
 #pragma unroll
   for (int i = 0; i < G; ++i) {
     const int m = (i * NSET + wg) * 64 + lane;
-    const int h = m / TW, wl = m - h * TW;
-    if (m >= M || wl >= tw) continue;
-    const size_t o0 = ((size_t)(r * S + h) * W + w0 + wl) * ldc_out;
+    const int h = m / TW, wl = m - h * TW;                  // h = fb*S + row
+    if (m >= M || wl >= tw || r0 * S + h >= R * S) continue;
+    const size_t o0 = ((size_t)(r0 * S + h) * W + w0 + wl) * ldc_out;
 #pragma unroll
     for (int c = 0; c < NCG; ++c) {
       if (4 * c >= N) continue;
@@ -870,14 +880,14 @@ bool conv_fwd_supported(int C, int N, int S, int W, int fw) {
 
 template <int G, int NCG, int KS>
 static void launch_conv_fwd4_t(dim3 grid, size_t lds, hipStream_t s, const float* in, int ldc_in, int C, const float* Ft, const float* bias, int rl,
-                               float* out, int ldc_out, int N, int S, int W, int fw, int TW, const float* mask, int wbase, int wend) {
+                               float* out, int ldc_out, int N, int S, int W, int fw, int TW, const float* mask, int wbase, int wend, int FB, int R) {
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd4<G, NCG, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-  hipLaunchKernelGGL((k_conv_fwd4<G, NCG, KS>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend);
+  hipLaunchKernelGGL((k_conv_fwd4<G, NCG, KS>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend, FB, R);
 }
 static bool launch_conv_fwd4(int G, int ncg, dim3 grid, size_t lds, hipStream_t s, const float* in, int ldc_in, int C, const float* Ft,
-                             const float* bias, int rl, float* out, int ldc_out, int N, int S, int W, int fw, int TW, const float* mask, int wbase, int wend) {
-#define RSR_L4(g, n, ks) if (G == g && ncg == n) { launch_conv_fwd4_t<g, n, ks>(grid, lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend); return true; }
+                             const float* bias, int rl, float* out, int ldc_out, int N, int S, int W, int fw, int TW, const float* mask, int wbase, int wend, int FB, int R) {
+#define RSR_L4(g, n, ks) if (G == g && ncg == n) { launch_conv_fwd4_t<g, n, ks>(grid, lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend, FB, R); return true; }
   RSR_L4(2, 1, 2) RSR_L4(2, 2, 2) RSR_L4(2, 3, 2) RSR_L4(2, 4, 2) RSR_L4(2, 5, 2) RSR_L4(2, 6, 2) RSR_L4(2, 7, 2) RSR_L4(2, 8, 2)
   RSR_L4(3, 1, 2) RSR_L4(3, 2, 2) RSR_L4(3, 3, 2) RSR_L4(3, 4, 2) RSR_L4(3, 5, 2) RSR_L4(3, 6, 2) RSR_L4(3, 7, 2) RSR_L4(3, 8, 2)
   RSR_L4(4, 1, 4) RSR_L4(4, 2, 4) RSR_L4(4, 3, 4) RSR_L4(4, 4, 4) RSR_L4(4, 5, 4) RSR_L4(4, 6, 4) RSR_L4(4, 7, 4) RSR_L4(4, 8, 4)
@@ -887,7 +897,7 @@ static bool launch_conv_fwd4(int G, int ncg, dim3 grid, size_t lds, hipStream_t 
 
 // one launch over the columns [wbase, wend) in strips of TW
 static void conv_fwd_range(int wbase, int wend, int TW, int RT, size_t lds, const float* in, int ldc_in, int C, const float* Ft, const float* bias,
-                           int rl, float* out, int ldc_out, int N, int R, int S, int W, int fw, hipStream_t s, const float* mask) {
+                           int rl, float* out, int ldc_out, int N, int R, int S, int W, int fw, hipStream_t s, const float* mask, int FB = 1) {
   const bool small = RT == 4;
   static bool attr = false;
   if (!attr) {
@@ -897,7 +907,7 @@ static void conv_fwd_range(int wbase, int wend, int TW, int RT, size_t lds, cons
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_fwd<6, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  dim3 grid((wend - wbase + TW - 1) / TW, R);
+  dim3 grid((wend - wbase + TW - 1) / TW, (R + FB - 1) / FB);
   // output widths that waste MFMA columns (N % 16 != 0) go to the 4x4x1 form; RSRGAN_CONV4: 0 = never, 1 = those (default), 2 = every N % 4 == 0
   static int conv4 = -1;
   if (conv4 < 0) { const char* e = getenv("RSRGAN_CONV4"); conv4 = e ? atoi(e) : 1; }
@@ -908,12 +918,12 @@ static void conv_fwd_range(int wbase, int wend, int TW, int RT, size_t lds, cons
     if (ks4 < 0) { const char* e = getenv("RSRGAN_CONV4_KS"); ks4 = e ? atoi(e) : 2; }
     const int G = small ? (ks4 == 4 ? 4 : 2) : 3, ncg = N / 4;
     const size_t lds4 = std::max(lds, (size_t)8 * ncg * 1024 * (G == 3 ? 2 : G == 4 ? 2 : 1));      // the tree's widest round
-    if (lds4 <= 160 * 1024 && launch_conv_fwd4(G, ncg, grid, lds4, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend)) return;
+    if (lds4 <= 160 * 1024 && launch_conv_fwd4(G, ncg, grid, lds4, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend, FB, R)) return;
   }
-  if (small && N <= 16) hipLaunchKernelGGL((k_conv_fwd<4, 1>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend);
-  else if (small) hipLaunchKernelGGL((k_conv_fwd<4, 2>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend);
-  else if (N <= 16) hipLaunchKernelGGL((k_conv_fwd<6, 1>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend);
-  else hipLaunchKernelGGL((k_conv_fwd<6, 2>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend);
+  if (small && N <= 16) hipLaunchKernelGGL((k_conv_fwd<4, 1>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend, FB, R);
+  else if (small) hipLaunchKernelGGL((k_conv_fwd<4, 2>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend, FB, R);
+  else if (N <= 16) hipLaunchKernelGGL((k_conv_fwd<6, 1>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend, FB, R);
+  else hipLaunchKernelGGL((k_conv_fwd<6, 2>), grid, dim3(512), lds, s, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, S, W, fw, TW, mask, wbase, wend, FB, R);
 }
 
 void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const float* bias, bool relu, float* out, int ldc_out, int N,
@@ -934,7 +944,17 @@ void launch_conv_fwd(const float* in, int ldc_in, int C, const float* Ft, const 
     if (wmain < W) {
       int TWr = W - wmain, RTr = 4; size_t ldsr = 0;
       if (!conv_fwd_plan(C, S, W - wmain, fw, TWr, RTr, ldsr)) return;
-      conv_fwd_range(wmain, W, TWr, RTr, ldsr, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, R, S, W, fw, s, mask);
+      // a narrow remainder (one column of a 257-wide frame = 11 positions) takes several frames per workgroup: as many as fill the
+      // position slots and fit the LDS (one workgroup per frame cost 0.9 ms per layer, a quarter of a 64-column strip launch)
+      int FB = 1;
+      if ((W - wmain + TWr - 1) / TWr == 1) {
+        const size_t rowb = ((size_t)(TWr + fw - 1) * conv_cpad(C) + 16) * sizeof(float), filt = (size_t)32 * conv_ldf(fw, C) * sizeof(float);
+        const int cap = 8 * RTr * 16 / (S * TWr);
+        const int fit = (int)((128 * 1024 - filt - rowb) / (rowb * S));
+        FB = std::max(1, std::min(std::min(cap, fit), 16));
+        ldsr = ((size_t)FB * S + 1) * rowb + filt;
+      }
+      conv_fwd_range(wmain, W, TWr, RTr, ldsr, in, ldc_in, C, Ft, bias, rl, out, ldc_out, N, R, S, W, fw, s, mask, FB);
     }
     return;
   }
