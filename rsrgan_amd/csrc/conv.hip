@@ -509,6 +509,10 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad4(const float* __restric
   __syncthreads();
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
   const int nwl = active ? (tw - ps + PS - 1) / PS : 0;      // this wave's columns of a strip row
+  // lane -> filter element WITHOUT the channel pads of the LDS image (C' = 20 for 16 channels: 13 x 20 = 260 k' would need a fifth
+  // 64-lane group for 4 lanes): kq = dw*C + ci  ->  window offset dw*C' + ci, which is also its row in the partial slot
+  const int kq = 64 * kg + lane;
+  const int kdw = kq / C, loff = min(kdw, fw - 1) * Cp + (kq - kdw * C);
   for (int f = 0; f < fpg; ++f) {
     const int r = grp * fpg + f;
     if (r >= R) break;
@@ -568,7 +572,7 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad4(const float* __restric
       //  SLOWER, 560 vs 535 ms per step: the other waves of the SIMD already cover the LDS latency, the carries cost issue slots)
       for (int h = hlo; h < hhi; ++h) {
         const float* pa = ds + (size_t)(h * TW + ps) * 36 + (lane & 31);
-        const float* pb = img + (size_t)(h + dh - pt) * rowlen + ps * Cp + 64 * kg + lane;
+        const float* pb = img + (size_t)(h + dh - pt) * rowlen + ps * Cp + loff;
         const int sa = PS * 36, sb = PS * Cp;
         int t = 0;
         for (; t + 4 <= nwl; t += 4) {
@@ -607,13 +611,12 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad4(const float* __restric
   // partial slot of (frame group, strip, position part): part[((grp*nstrips + strip)*PS + ps)][dh][k'][32]; rows of this slot that
   // belong to other row sets are written by their waves (same ps)
   if (!active) return;
-  const int kq = 64 * kg + lane;
-  if (kq >= KP) return;
+  if (kq >= fw * C) return;
 #pragma unroll
   for (int j = 0; j < RW; ++j) {
     const int dd = rs * RW + j, dh = dh0 + dd * dstep;
     if (dd >= DH || dh >= S) continue;
-    float* po = part + (((size_t)(grp * gridDim.z + strip) * PS + ps) * S + dh) * (size_t)KP * 32 + (size_t)kq * 32;
+    float* po = part + (((size_t)(grp * gridDim.z + strip) * PS + ps) * S + dh) * (size_t)KP * 32 + (size_t)loff * 32;
 #pragma unroll
     for (int c = 0; c < NCG; ++c) *reinterpret_cast<float4*>(po + 4 * c) = make_float4(acc[j][c][0], acc[j][c][1], acc[j][c][2], acc[j][c][3]);
   }
@@ -1009,13 +1012,23 @@ static int wgrad4_waves(int KP, int DH, int& PS) {
   PS = std::max(1, 8 / roles);
   return roles <= 8 ? 8 : (roles <= 10 ? 10 : 12);
 }
-static int wgrad4_ps(int KP, int DH) { int ps; wgrad4_waves(KP, DH, ps); return ps; }
+// the plan of the 4x4x1 form: its 64-lane groups cover fw*C filter elements (no channel pads), and up to four of them take the
+// six-rows-per-workgroup plan whatever the padded K' is
+static void wgrad4_plan(int C, int R, int S, int nstrips, int fw, int& DH, int& fpg, int& groups, int& nkg, int& PS, int& nwv) {
+  nkg = (fw * C + 63) / 64;
+  const int KP = conv_kp(fw, C);
+  wgrad_plan(R, S, nstrips, nkg <= 4 ? std::min(KP, 256) : KP, DH, fpg, groups);
+  nwv = wgrad4_waves(64 * nkg, DH, PS);
+}
 size_t conv_wgrad_ws_floats(int C, int R, int S, int W, int fw) {
   const int TW = wgrad_tw(S, W), nstrips = (W + TW - 1) / TW;
-  int DH, fpg, groups;
+  int DH, fpg, groups, nkg, PS, nwv;
   wgrad_plan(R, S, nstrips, conv_kp(fw, C), DH, fpg, groups);
   // filter partials (one slot per position part in the 4x4x1 form) + one 32-float bias partial per (group, strip)
-  return (size_t)groups * nstrips * ((size_t)wgrad4_ps(conv_kp(fw, C), DH) * S * conv_kp(fw, C) + 1) * 32;
+  const size_t a = (size_t)groups * nstrips * ((size_t)S * conv_kp(fw, C) + 1) * 32;
+  wgrad4_plan(C, R, S, nstrips, fw, DH, fpg, groups, nkg, PS, nwv);
+  const size_t b = (size_t)groups * nstrips * ((size_t)PS * S * conv_kp(fw, C) + 1) * 32;
+  return std::max(a, b);
 }
 bool conv_wgrad_supported(int C, int N, int S, int W, int fw) {
   if (!conv_fwd_supported(C, N, S, W, fw)) return false;
@@ -1066,19 +1079,17 @@ void launch_conv_wgrad(const float* in, int ldc_in, int C, const float* d, int l
   const int TW = wgrad_tw(S, W), nstrips = (W + TW - 1) / TW;
   int DH, fpg, groups;
   const int MP = (S * TW + 15) / 16 * 16, KP = conv_kp(fw, C);
-  wgrad_plan(R, S, nstrips, KP, DH, fpg, groups);
   const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 38) * sizeof(float);
-  dim3 grid((S + DH - 1) / DH, groups, nstrips);
   // output widths that waste MFMA columns go to the 4x4x1 form (RSRGAN_CONV4 as for the forward kernel; RSRGAN_WGRAD4=0 keeps the
   // weight gradient on 16x16x4)
   static int w4 = -1;
   if (w4 < 0) { const char* e = getenv("RSRGAN_CONV4"); const char* e2 = getenv("RSRGAN_WGRAD4"); w4 = e2 ? atoi(e2) : (e ? atoi(e) : 1); }
-  const int nkg = (KP + 63) / 64;
-  int PS = 1;
-  const int nwv4 = wgrad4_waves(KP, DH, PS);
+  int nkg = 1, PS = 1, nwv4 = 8;
+  wgrad4_plan(C, R, S, nstrips, fw, DH, fpg, groups, nkg, PS, nwv4);
   const bool use4 = w4 && N % 4 == 0 && N <= 32 && (w4 > 1 || N % 16 != 0) && nkg * ((DH + 2) / 3) <= 12 &&
                     ((TW + fw - 1) * conv_cpad(C) + 16) / 4 <= 64 * nwv4;
-  if (!use4) PS = 1;
+  if (!use4) { PS = 1; wgrad_plan(R, S, nstrips, KP, DH, fpg, groups); }
+  dim3 grid((S + DH - 1) / DH, groups, nstrips);
   const int nparts = groups * nstrips * PS;
   float* bpart = db ? ws + (size_t)nparts * S * KP * 32 : nullptr;
   if (use4) {
