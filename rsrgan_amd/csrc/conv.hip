@@ -1080,10 +1080,11 @@ void launch_conv_wgrad(const float* in, int ldc_in, int C, const float* d, int l
   int DH, fpg, groups;
   const int MP = (S * TW + 15) / 16 * 16, KP = conv_kp(fw, C);
   const size_t lds = ((size_t)(S + 1) * ((TW + fw - 1) * conv_cpad(C) + 16) + (size_t)MP * 38) * sizeof(float);
-  // output widths that waste MFMA columns go to the 4x4x1 form (RSRGAN_CONV4 as for the forward kernel; RSRGAN_WGRAD4=0 keeps the
-  // weight gradient on 16x16x4)
+  // every output width that is a multiple of 4 goes to the 4x4x1 form (measured: 502 ms per R-CED step against 509 with only the
+  // widths that waste 16-wide MFMA columns; unlike the forward kernel it has no padded positions to pay for).  RSRGAN_WGRAD4: 0 =
+  // never, 1 = widths that are no multiple of 16, 2 = all (default); RSRGAN_CONV4=0 alone turns both directions off.
   static int w4 = -1;
-  if (w4 < 0) { const char* e = getenv("RSRGAN_CONV4"); const char* e2 = getenv("RSRGAN_WGRAD4"); w4 = e2 ? atoi(e2) : (e ? atoi(e) : 1); }
+  if (w4 < 0) { const char* e = getenv("RSRGAN_CONV4"); const char* e2 = getenv("RSRGAN_WGRAD4"); w4 = e2 ? atoi(e2) : ((e && !atoi(e)) ? 0 : 2); }
   int nkg = 1, PS = 1, nwv4 = 8;
   wgrad4_plan(C, R, S, nstrips, fw, DH, fpg, groups, nkg, PS, nwv4);
   const bool use4 = w4 && N % 4 == 0 && N <= 32 && (w4 > 1 || N % 16 != 0) && nkg * ((DH + 2) / 3) <= 12 &&

@@ -171,6 +171,9 @@ def test_rced_convolution_mfma_forms_agree():
     c = _run_worker(RCED_WORKER, {})
     d = _run_worker(RCED_WORKER, {"RSRGAN_CONV4": "2", "RSRGAN_CONV4_KS": "4"})      # two group sets x k' quarters
     e = _run_worker(RCED_WORKER, {"RSRGAN_CONV4": "1", "RSRGAN_WGRAD4": "0"})          # the weight gradient alone on 16x16x4
+    e1 = _run_worker(RCED_WORKER, {"RSRGAN_WGRAD4": "1"})                               # ... only its 12/20/24-channel layers on 4x4x1
+    for k in b:
+        assert abs(e1[k] - b[k]) <= 2e-5 * max(abs(b[k]), 1e-6), (k, e1[k], b[k])
     f = _run_worker(RCED_WORKER, {"RSRGAN_CONV_ROWS": "0"})                            # even strips (6 x 43) instead of 4 x 64 + 1 columns
     for k in b:
         assert abs(f[k] - b[k]) <= 2e-5 * max(abs(b[k]), 1e-6), (k, f[k], b[k])
