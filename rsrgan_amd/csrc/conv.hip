@@ -733,7 +733,12 @@ __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in,
     const float4* src = reinterpret_cast<const float4*>(Ft);
     fr0 = src[fi0]; fr1 = src[fi1]; fr2 = src[fi2]; fr3 = src[fi3]; fr4 = src[fi4];
   }
-  const int s_lo = nk4 * half / KS, s_hi = nk4 * (half + 1) / KS;
+  // the k loop walks the REAL channel quads of a filter row: quad qi = dw*C4 + j sits at k' = dw*C' + 4j; the pad quads of the LDS
+  // image (C' = 20 / 28 / 36 for 16 / 24 / 32 channels: every 5th / 7th / 9th quad) only multiply zeros of the filter
+  const int C4 = max(1, C / 4), nq = fw * C4;
+  const int s_lo = nq * half / KS, s_hi = nq * (half + 1) / KS;
+  const int j_lo = s_lo % C4, off_lo = (s_lo / C4) * Cp + 4 * j_lo;
+  (void)nk4;
   const float* fb = fts + (size_t)(lane & (NROW - 1)) * ldf;
   for (int dh = 0; dh < S; ++dh) {
     __syncthreads();
@@ -763,7 +768,6 @@ __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in,
     // One uniform branch per live group and step around its 4 * NCG products (a branch per group AND component cost a fifth of
     // the issue slots: SQ_INSTS_SALU 1.2e9 next to 2.9e9 MFMAs; one specialised copy of the loop per live mask doubled the
     // accumulator registers).  Unrolled by two: the operands of step s + 1 are requested before the products of step s.
-    auto ldf4 = [&](int st) { return *reinterpret_cast<const float4*>(fb + 4 * st); };
     auto prod = [&](const float4& fv, const float4 (&av)[G]) {
 #pragma unroll
       for (int i = 0; i < G; ++i) {
@@ -785,20 +789,24 @@ __global__ __launch_bounds__(512) void k_conv_fwd4(const float* __restrict__ in,
 #pragma unroll
     for (int i = 0; i < G; ++i) any |= live[i];
     if (any && s_lo < s_hi) {
-      float4 f0 = ldf4(s_lo), f1;
-      float4 a0[G], a1[G];
+      int off = off_lo, jq = j_lo, left = s_hi - s_lo;       // the next quad to request (uniform); past the end the last one is re-read
+      auto fetch = [&](float4& fv, float4 (&av)[G]) {
+        fv = *reinterpret_cast<const float4*>(fb + off);
 #pragma unroll
-      for (int i = 0; i < G; ++i) a0[i] = *reinterpret_cast<const float4*>(arow[i] + 4 * s_lo);
+        for (int i = 0; i < G; ++i) av[i] = *reinterpret_cast<const float4*>(arow[i] + off);
+        if (--left > 0) {
+          off += 4;
+          if (++jq == C4) { jq = 0; off += Cp - 4 * C4; }
+        }
+      };
+      float4 f0, f1;
+      float4 a0[G], a1[G];
+      fetch(f0, a0);
       int st = s_lo;
       for (; st + 1 < s_hi; st += 2) {
-        f1 = ldf4(st + 1);
-#pragma unroll
-        for (int i = 0; i < G; ++i) a1[i] = *reinterpret_cast<const float4*>(arow[i] + 4 * (st + 1));
+        fetch(f1, a1);
         prod(f0, a0);
-        const int s2 = min(st + 2, s_hi - 1);
-        f0 = ldf4(s2);
-#pragma unroll
-        for (int i = 0; i < G; ++i) a0[i] = *reinterpret_cast<const float4*>(arow[i] + 4 * s2);
+        fetch(f0, a0);
         prod(f1, a1);
       }
       if (st < s_hi) prod(f0, a0);
@@ -911,10 +919,12 @@ static void conv_fwd_range(int wbase, int wend, int TW, int RT, size_t lds, cons
     attr = true;
   }
   dim3 grid((wend - wbase + TW - 1) / TW, (R + FB - 1) / FB);
-  // output widths that waste MFMA columns (N % 16 != 0) go to the 4x4x1 form; RSRGAN_CONV4: 0 = never, 1 = those (default), 2 = every N % 4 == 0
+  // RSRGAN_CONV4: 0 = never the 4x4x1 form, 1 (default) = every output width that is a multiple of 4 except 16 (12 / 20 / 24 waste
+  // 16-wide MFMA columns; at 32 the 4x4x1 kernel is ahead since it walks only the real channel quads, 16.4 vs 18.0 ms per call;
+  // at 16 -- layers whose input has no channel pads -- the 16x16x4 kernel is, 8.7 vs 9.3), 2 = every multiple of 4
   static int conv4 = -1;
   if (conv4 < 0) { const char* e = getenv("RSRGAN_CONV4"); conv4 = e ? atoi(e) : 1; }
-  if (conv4 && N % 4 == 0 && ldc_out % 4 == 0 && (conv4 > 1 || N % 16 != 0) && (!bias || ((size_t)bias & 15) == 0)) {
+  if (conv4 && N % 4 == 0 && ldc_out % 4 == 0 && (conv4 > 1 || N != 16) && (!bias || ((size_t)bias & 15) == 0)) {
     // RSRGAN_CONV4_KS=4: two interleaved group sets x k' quarters for 512-position workgroups (0.86 of the MFMAs of the default
     // four sets x k' halves at S = 11, measured slower: 566 vs 558 ms per step of the R-CED variant)
     static int ks4 = -1;
