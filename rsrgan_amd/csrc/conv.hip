@@ -563,38 +563,66 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad4(const float* __restric
     }
     __syncthreads();
     if (!active) continue;                                 // (wave-uniform)
+    // The filter rows of this wave INSIDE the loop over positions: the gradient vector of a position is read once for all of them
+    // (1 + RW LDS reads per RW * NCG products instead of 2 per NCG -- with 12-24 output channels the kernel was bound by the LDS
+    // pipe, not by the matrix pipe: SQ_VALU_MFMA_BUSY 0.35-0.53 of the CU cycles, profiles/r3_rced_pmc_final.txt).  Which rows
+    // an image row h meets is uniform: one branch per row and four-position step.
+    // (measured and not kept: a single position stream per filter row with scalar carries and operands requested a step ahead, 560
+    //  vs 535 ms per step; the last 1-3 columns of a row as one zero-padded step, 550; their operands requested together, +-0)
+    int dhj[RW], sh[RW];
+    bool rowok[RW];
+    int hlo = S, hhi = 0;
 #pragma unroll
     for (int j = 0; j < RW; ++j) {
-      const int dd = rs * RW + j, dh = dh0 + dd * dstep;
-      if (dd >= DH || dh >= S) continue;                   // (uniform)
-      const int hlo = max(0, pt - dh), hhi = min(S, S + pt - dh);
-      // (a single position stream per filter row with scalar carries and the next step's operands requested ahead measured
-      //  SLOWER, 560 vs 535 ms per step: the other waves of the SIMD already cover the LDS latency, the carries cost issue slots)
-      for (int h = hlo; h < hhi; ++h) {
-        const float* pa = ds + (size_t)(h * TW + ps) * 36 + (lane & 31);
-        const float* pb = img + (size_t)(h + dh - pt) * rowlen + ps * Cp + loff;
-        const int sa = PS * 36, sb = PS * Cp;
-        int t = 0;
-        for (; t + 4 <= nwl; t += 4) {
-          float av[4], bv[4];
+      const int dd = rs * RW + j;
+      dhj[j] = dh0 + dd * dstep;
+      rowok[j] = dd < DH && dhj[j] < S;
+      sh[j] = (dhj[j] - pt) * rowlen;
+      if (rowok[j]) { hlo = min(hlo, max(0, pt - dhj[j])); hhi = max(hhi, min(S, S + pt - dhj[j])); }
+    }
+    const int sa = PS * 36, sb = PS * Cp;
+    for (int h = hlo; h < hhi; ++h) {
+      bool on[RW];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { av[u] = pa[u * sa]; bv[u] = pb[u * sb]; }
+      for (int j = 0; j < RW; ++j) { const int hh = h + dhj[j] - pt; on[j] = rowok[j] && hh >= 0 && hh < S; }
+      const float* pa = ds + (size_t)(h * TW + ps) * 36 + (lane & 31);
+      const float* pb = img + (size_t)h * rowlen + ps * Cp + loff;
+#define RSR_W4(c) if (NCG > c) acc[j][NCG > c ? c : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[u], bv[j][u], acc[j][NCG > c ? c : 0], 4, c, 0);
+      int t = 0;
+      for (; t + 4 <= nwl; t += 4) {
+        float av[4], bv[RW][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) av[u] = pa[u * sa];
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+          if (!on[j]) continue;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) bv[j][u] = pb[sh[j] + u * sb];
+        }
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+          if (!on[j]) continue;
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-#define RSR_W4(c) if (NCG > c) acc[j][NCG > c ? c : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[u], bv[u], acc[j][NCG > c ? c : 0], 4, c, 0);
             RSR_W4(0) RSR_W4(1) RSR_W4(2) RSR_W4(3) RSR_W4(4) RSR_W4(5) RSR_W4(6) RSR_W4(7)
           }
-          pa += 4 * sa; pb += 4 * sb;
         }
-        for (; t < nwl; ++t) {                             // (the last 1-3 columns one by one: as ONE step with zero gradients past the end
-          const float a1 = pa[0], b1 = pb[0];              //  it measured slower, 550 vs 535 ms: the kernel is bound by its MFMA count)
-#define RSR_W4B(c) if (NCG > c) acc[j][NCG > c ? c : 0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, b1, acc[j][NCG > c ? c : 0], 4, c, 0);
-          RSR_W4B(0) RSR_W4B(1) RSR_W4B(2) RSR_W4B(3) RSR_W4B(4) RSR_W4B(5) RSR_W4B(6) RSR_W4B(7)
-#undef RSR_W4B
-          pa += sa; pb += sb;
-        }
-#undef RSR_W4
+        pa += 4 * sa; pb += 4 * sb;
       }
+      for (; t < nwl; ++t) {
+        float av[1], bv[RW][1];
+        constexpr int u = 0;
+        av[0] = pa[0];
+#pragma unroll
+        for (int j = 0; j < RW; ++j) bv[j][0] = on[j] ? pb[sh[j]] : 0.f;
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+          if (!on[j]) continue;
+          RSR_W4(0) RSR_W4(1) RSR_W4(2) RSR_W4(3) RSR_W4(4) RSR_W4(5) RSR_W4(6) RSR_W4(7)
+        }
+        pa += sa; pb += sb;
+      }
+#undef RSR_W4
     }
   }
   if (bpart && blockIdx.x == 0) {                          // (uniform) fixed-order sum over the 64 * NWV / 8 threads of a channel group
