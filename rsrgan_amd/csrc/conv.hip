@@ -568,7 +568,8 @@ __global__ __launch_bounds__(64 * NWV) void k_conv_wgrad4(const float* __restric
     // pipe, not by the matrix pipe: SQ_VALU_MFMA_BUSY 0.35-0.53 of the CU cycles, profiles/r3_rced_pmc_final.txt).  Which rows
     // an image row h meets is uniform: one branch per row and four-position step.
     // (measured and not kept: a single position stream per filter row with scalar carries and operands requested a step ahead, 560
-    //  vs 535 ms per step; the last 1-3 columns of a row as one zero-padded step, 550; their operands requested together, +-0)
+    //  vs 535 ms per step; the last 1-3 columns of a row as one zero-padded step, 550; their operands requested together, +-0;
+    //  two operand sets inside a row -- step s + 1 requested before the products of step s -- in this rows-inside form: 476 vs 457)
     int dhj[RW], sh[RW];
     bool rowok[RW];
     int hlo = S, hhi = 0;
