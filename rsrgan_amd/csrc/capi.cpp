@@ -321,14 +321,20 @@ int rsrgan_device_status(rsrgan_handle h, int32_t* code) {
   Model& m = h->m;
   *code = 0;
   if (m.main_s && hipStreamSynchronize(m.main_s) != hipSuccess) { set_error("hipStreamSynchronize failed"); return RSRGAN_ERR_HIP; }
-  if (!m.dp_ctl) return RSRGAN_OK;
+  if (!m.dp_ctl && !m.gp_ctl) return RSRGAN_OK;
   if (hipDeviceSynchronize() != hipSuccess) { set_error("hipDeviceSynchronize failed"); return RSRGAN_ERR_HIP; }
-  unsigned ctl[DP_CTL_WORDS];
-  if (hipMemcpy(ctl, m.dp_ctl, sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess) { set_error("hipMemcpy failed"); return RSRGAN_ERR_HIP; }
-  *code = (int32_t)ctl[DP_CTL_ERR];
-  if (ctl[DP_CTL_ERR] != 0 || ctl[DP_CTL_DONE] != 0) {          // (an aborted launch can leave the arrival count behind)
-    const unsigned z[2] = {0u, 0u};
-    if (hipMemcpy(m.dp_ctl + DP_CTL_DONE, z, sizeof(z), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed"); return RSRGAN_ERR_HIP; }
+  // the control blocks of the persistent recurrences (dpersist.hip, gpersist.hip): the first failure wins; a generator failure is
+  // reported as 0x10000 + workgroup
+  unsigned* blocks[2] = {m.dp_ctl, m.gp_ctl};
+  for (int k = 0; k < 2; ++k) {
+    if (!blocks[k]) continue;
+    unsigned ctl[DP_CTL_WORDS];
+    if (hipMemcpy(ctl, blocks[k], sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess) { set_error("hipMemcpy failed"); return RSRGAN_ERR_HIP; }
+    if (*code == 0 && ctl[DP_CTL_ERR] != 0) *code = (int32_t)(ctl[DP_CTL_ERR] + (k ? 0x10000u : 0u));
+    if (ctl[DP_CTL_ERR] != 0 || ctl[DP_CTL_DONE] != 0) {          // (an aborted launch can leave the arrival count behind)
+      const unsigned z[2] = {0u, 0u};
+      if (hipMemcpy(blocks[k] + DP_CTL_DONE, z, sizeof(z), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed"); return RSRGAN_ERR_HIP; }
+    }
   }
   return RSRGAN_OK;
 }

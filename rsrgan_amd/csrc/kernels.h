@@ -162,6 +162,28 @@ size_t dpersist_granule_bytes(int nl, int N, int T);
 bool dpersist_supported(const DPersistArgs& a);
 void launch_dlstm_fwd(const DPersistArgs& a, hipStream_t s);
 void launch_dlstm_bwd(const DPersistArgs& a, hipStream_t s);      // gates: activations in, dz out; needs c, dmt, dout_top
+// ---- persistent generator recurrence (gpersist.hip): the forward pass of a stack of large projected LSTM cells ----
+constexpr int GP_MAXL = 4;
+constexpr int GP_ROWS = 32;                       // batch rows per row group (two 16-row MFMA tiles)
+struct GPersistLayer {
+  const float *KxT, *KhT;                         // k-contiguous transposed copies of the kernel: [4H][ldI], [4H][ldP] (zero padding)
+  const float *bias, *wi, *wf, *wo, *Wp;          // bias [4H], peepholes [H], projection [H][ldP]
+  float *gates, *c, *h, *mst, *out;               // the layer's stash (model.h LstmStash); layer 0: gates holds zx = x.K_x + bias on entry
+  int I, P, ldI, ldP, ldH;
+};
+struct GPersistArgs {
+  GPersistLayer L[GP_MAXL];
+  int nl, N, T, H;
+  int NT, NC;                                     // 4-cell gate tiles per workgroup, workgroups per (row group, layer)
+  const int* len;
+  unsigned long long *gran1, *gran2;              // hop 1 (partial projections, ring of two steps), hop 2 (m chunks, one slot per step); zeroed once
+  unsigned* ctl;                                  // control block [DP_CTL_*]
+  float forget_bias;
+};
+bool gpersist_plan(GPersistArgs& a);              // fills NT / NC; false: shape not supported
+size_t gpersist_gran1_bytes(const GPersistArgs& a);
+size_t gpersist_gran2_bytes(const GPersistArgs& a);
+void launch_glstm_fwd(const GPersistArgs& a, hipStream_t s);
 extern long long g_chain_launches;
 void launch_floor_chain(float* a, float* b, int n, int mode, hipStream_t s);
 

@@ -426,6 +426,20 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     const unsigned ctl0[DP_CTL_WORDS] = {1u, 0u, 0u, 0u};
     HIPC(hipMemcpy(dp_ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice));
   }
+  if (const char* e = getenv("RSRGAN_GPERSIST")) gp_env = atoi(e);        // bit 0: the generator's forward recurrence
+  if (gp_env && !g_dnn()) {
+    GPersistArgs ga{};
+    if (gpersist_args(ga, Tmax)) {
+      gp_gran1 = (unsigned long long*)alloc<float>(gpersist_gran1_bytes(ga) / sizeof(float));
+      gp_gran2_bytes = gpersist_gran2_bytes(ga);
+      gp_gran2 = (unsigned long long*)alloc<float>(gp_gran2_bytes / sizeof(float));
+      gp_ctl = (unsigned*)alloc<float>(16);
+      if (gp_gran1 && gp_gran2 && gp_ctl) {
+        const unsigned ctl0[DP_CTL_WORDS] = {1u, 0u, 0u, 0u};
+        HIPC(hipMemcpy(gp_ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice));
+      } else { gp_gran1 = gp_gran2 = nullptr; gp_ctl = nullptr; }
+    }
+  }
   drop_ctr = (unsigned long long*)alloc<float>(4);
   HIPC(hipMemset(drop_ctr, 0, 16));
   const int dmaxld = std::max(ldPd, ldDout);
@@ -892,6 +906,35 @@ bool Model::persist_forward(Chain& ch, int T, hipStream_t s) {
   return true;
 }
 
+// The generator's stack as ONE persistent launch (gpersist.hip).  Same stash as the wavefront launches leave (gates, c, h, mst, out of
+// every layer), so the backward pass does not know which forward ran.
+bool Model::gpersist_args(GPersistArgs& a, int T) const {
+  if (!(gp_env & 1) || gl.empty() || gl.size() > (size_t)GP_MAXL || cfg.g_type != RSRGAN_G_LSTM) return false;
+  a = GPersistArgs{};
+  a.nl = (int)gl.size(); a.N = B; a.T = T; a.H = gl[0].H; a.len = len_dev;
+  a.gran1 = gp_gran1; a.gran2 = gp_gran2; a.ctl = gp_ctl; a.forget_bias = cfg.forget_bias;
+  for (size_t l = 0; l < gl.size(); ++l) {
+    const LstmLayer& L = gl[l]; const LstmStash& S = g_st[l];
+    if (!L.has_proj || L.H != a.H) return false;
+    GPersistLayer& G_ = a.L[l];
+    G_.KxT = L.KxT; G_.KhT = L.KhT; G_.bias = G.W(L.tb); G_.wi = G.W(L.twi); G_.wf = G.W(L.twf); G_.wo = G.W(L.two); G_.Wp = G.W(L.tWp);
+    G_.gates = S.gates; G_.c = S.c; G_.h = S.h; G_.mst = S.mst; G_.out = S.out;
+    G_.I = L.I; G_.P = L.P; G_.ldI = L.ldI; G_.ldP = L.ldP; G_.ldH = L.ldH;
+  }
+  return gpersist_plan(a);
+}
+
+bool Model::persist_forward_g(int T, hipStream_t s) {
+  if (!gp_gran1 || !wavefront() || seq_drop_on()) return false;
+  GPersistArgs a{};
+  if (!gpersist_args(a, T) || gpersist_gran2_bytes(a) > gp_gran2_bytes) return false;
+  const LstmLayer& L0 = gl[0];
+  const int H4 = 4 * L0.H;
+  gemm(g_ins[0], L0.ldI, true, G.W(L0.tK), H4, false, g_st[0].gates, H4, T * B, H4, L0.I, G.W(L0.tb), 0, 0.f, false, s);
+  launch_glstm_fwd(a, s);
+  return true;
+}
+
 // BPTT through a discriminator chain running alone as ONE persistent launch (dpersist.hip k_dlstm_bwd), then the weight-gradient
 // GEMMs over the dz it leaves in the stash.  No input gradient for layer 0 (the D-run does not need one).
 bool Model::persist_backward(Chain& ch, int T, hipStream_t s) {
@@ -1125,6 +1168,7 @@ void Model::g_forward_tail(int T, hipStream_t s) {   // y = outputs.W + b (model
 void Model::g_forward(int T, hipStream_t s, Chain* extra) {
   if (g_dnn()) { bn_eval_call = false; g_frame_forward(T * B, s); g_fwd_valid = true; return; }
   g_forward_head(T, s);
+  if (!extra && persist_forward_g(T, s)) { g_forward_tail(T, s); return; }
   std::vector<Chain> chains;
   chains.push_back(g_chain(T));
   if (extra) chains.push_back(*extra);
@@ -1217,10 +1261,25 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
   run_seg(seg_key(SEG_D, T, kbits), s, [&]() {
   // discriminator input rows [0,B) = labels + noise_real (gan_rnn_placeholder.py:207,212; utils/ops.py:19-30)
   launch_add_noise_rows(lab_tm, nr, xd, B, T, Dout, ldDout, 2 * B, 0, s);
-  if (wavefront()) {
+  bool g_done = false;
+  if (wavefront() && gp_gran1) {
+    // the generator as ONE persistent launch, then both discriminator calls stacked (N = 2B) as another
+    g_forward_head(T, s);
+    g_done = persist_forward_g(T, s);
+    if (g_done) {
+      g_forward_tail(T, s);
+      launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, 2 * B, B, s);
+      if (!d_dnn()) {
+        std::vector<Chain> chains(1, d_chain(2 * B, 2 * B, 0));
+        if (!persist_forward(chains[0], T, s)) rnn_forward(chains, T, s);
+      }
+    }
+  }
+  if (g_done) {
+  } else if (wavefront()) {
     // ONE wave: G's layers | D(real) (independent of G) | per-step output FC -> y_t, xd fake rows |
     // D(fake) two diagonals behind G's top layer
-    g_forward_head(T, s);
+    if (!gp_gran1) g_forward_head(T, s);
     const int Lg = (int)gl.size(), ldP = pad4(gR);
     std::vector<Chain> chains{g_chain(T)};
     std::vector<int> offs{0};
@@ -1332,10 +1391,16 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   if (wave_bwd) build_bw_chains();                // host-only bookkeeping (bufA after the loop = d(h0))
 
   run_seg(seg_key(SEG_G_MAIN, T, kbits), s, [&]() {
+  bool g_done = false;
   if (!reuse && !wavefront()) g_forward(T, s);
-  if (!reuse && wavefront()) {
-    // ONE forward wave: G's layers | per-step output FC (-> y_t and D's input rows, noise added) | D's layers
+  if (!reuse && wavefront() && gp_gran1) {
     g_forward_head(T, s);
+    g_done = persist_forward_g(T, s);
+    if (g_done) g_forward_tail(T, s);
+  }
+  if (!reuse && wavefront() && !g_done) {
+    // ONE forward wave: G's layers | per-step output FC (-> y_t and D's input rows, noise added) | D's layers
+    if (!gp_gran1) g_forward_head(T, s);
     std::vector<Chain> chains{g_chain(T)};
     std::vector<int> offs{0};
     if (!d_dnn()) { chains.push_back(d_chain(B, B, 0)); offs.push_back(Lg + 1); }

@@ -151,6 +151,14 @@ struct Model {
   int dp_env = 3;                                         // RSRGAN_DPERSIST: bit 0 the forward launch, bit 1 the backward launch
   bool persist_forward(Chain& ch, int T, hipStream_t s);  // false: not applicable -> caller falls back to fold_forward
   bool persist_backward(Chain& ch, int T, hipStream_t s); // BPTT of the chain + its weight gradients; false: not applicable
+  // ---- persistent GENERATOR recurrence (gpersist.hip): the forward pass of the generator's stack as ONE launch (weights resident
+  // in VGPRs / LDS for all T steps); RSRGAN_GPERSIST bit 0.  Needs B % 32 == 0, projected cells, no residual sums, no dropout.
+  unsigned long long *gp_gran1 = nullptr, *gp_gran2 = nullptr;
+  unsigned* gp_ctl = nullptr;
+  size_t gp_gran2_bytes = 0;
+  int gp_env = 0;
+  bool gpersist_args(GPersistArgs& a, int T) const;       // false: not applicable
+  bool persist_forward_g(int T, hipStream_t s);           // layer 0's x-part batched first; fills the complete stash of every layer
   // fully-connected stacks: models/dnn.py generator and models/discriminator_dnn.py discriminator
   std::vector<FcLayer> gfc, dfc;
   std::vector<float*> g_act, d_act;        // act[l] = input of FC layer l, act[L] = output of the stack

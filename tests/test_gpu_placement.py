@@ -98,6 +98,24 @@ def test_persistent_discriminator_recurrence_agrees(B, T, mode):
     assert a["vars_sha"] == c["vars_sha"]          # fixed summation order: reproducible bits
 
 
+@pytest.mark.parametrize("B,T", [(32, 9), (64, 100)])
+def test_persistent_generator_recurrence_agrees(B, T):
+    """csrc/gpersist.hip: the generator's forward recurrence (models/lstm.py:89-112) as ONE persistent launch -- weights resident,
+    partial projections reduce-scattered and the state all-gathered as tagged granules -- against the launch-per-phase wavefront.
+    Same products; the projection is summed per slice of 20 cells and the gates per k-block group: fp32 rounding apart.  Ragged
+    lengths exercise dynamic_rnn's masking in the consumers.  The launch count proves which path ran."""
+    size = {"RSRGAN_TEST_B": str(B), "RSRGAN_TEST_T": str(T)}
+    a = _run(dict(size, RSRGAN_GPERSIST="1"))
+    b = _run(dict(size, RSRGAN_GPERSIST="0"))
+    assert b["chain_launches"] - a["chain_launches"] >= T - 1, (a["chain_launches"], b["chain_launches"])
+    assert a["device_status"] == 0 and b["device_status"] == 0
+    for k in ("d0", "g0", "d1", "g1"):
+        assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-7), (k, a[k], b[k])
+    assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
+    c = _run(dict(size, RSRGAN_GPERSIST="1"))
+    assert a["vars_sha"] == c["vars_sha"]          # fixed summation order: reproducible bits
+
+
 def test_stream_k_gemm_step_is_reproducible():
     """Every time-batched product runs on the hand-written stream-K k_gemm (csrc/gemm.hip; no vendor library since round 3): the
     pieces of a cut tile are summed in k order by k_gemm_fixup, no float atomics, so two processes produce the same bits."""

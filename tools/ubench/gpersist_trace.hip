@@ -1,0 +1,97 @@
+// gpersist_trace.hip -- stand-alone phase timeline of the persistent generator recurrence (csrc/gpersist.hip, compiled here with
+// GP_TRACE); not part of the product library.  Synthetic weights at the reference's sizes (3 x LSTMCell(760, num_proj=280), N rows,
+// T steps); prints the launch time per step and the mean duration of every phase of a step per layer and wave role.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 gpersist_trace.hip -o gpersist_trace      Run: ./gpersist_trace [N] [T] [layers]
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+namespace rsr { long long g_chain_launches = 0; }
+#define GP_TRACE 1
+#include "../../rsrgan_amd/csrc/gpersist.hip"
+using namespace rsr;
+
+static float* dal(size_t n, float v) {
+  float* p; CK(hipMalloc(&p, n * 4));
+  std::vector<float> h(n);
+  for (size_t i = 0; i < n; ++i) h[i] = v * ((float)((i * 2654435761u >> 20) & 255) / 128.f - 1.f);
+  CK(hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice));
+  return p;
+}
+
+int main(int argc, char** argv) {
+  const int N = argc > 1 ? atoi(argv[1]) : 64, T = argc > 2 ? atoi(argv[2]) : 100, nl = argc > 3 ? atoi(argv[3]) : 3, H = 760, P = 280;
+  GPersistArgs a{};
+  a.nl = nl; a.N = N; a.T = T; a.H = H; a.forget_bias = 1.f;
+  std::vector<int> len(N, T);
+  int* dlen; CK(hipMalloc(&dlen, N * 4)); CK(hipMemcpy(dlen, len.data(), N * 4, hipMemcpyHostToDevice));
+  a.len = dlen;
+  for (int l = 0; l < nl; ++l) {
+    GPersistLayer& L = a.L[l];
+    L.I = P; L.P = P; L.ldI = P; L.ldP = P; L.ldH = H;
+    L.KxT = dal((size_t)4 * H * P, 0.03f); L.KhT = dal((size_t)4 * H * P, 0.03f); L.bias = dal(4 * H, 0.1f); L.wi = dal(H, 0.1f); L.wf = dal(H, 0.1f); L.wo = dal(H, 0.1f);
+    L.Wp = dal((size_t)H * P, 0.03f);
+    L.gates = dal((size_t)T * N * 4 * H, 0.5f); L.c = dal((size_t)(T + 1) * N * H, 0.f); L.h = dal((size_t)T * N * H, 0.f);
+    L.mst = dal((size_t)(T + 1) * N * P, 0.f); L.out = dal((size_t)T * N * P, 0.f);
+  }
+  if (!gpersist_plan(a)) { printf("unsupported shape\n"); return 1; }
+  const size_t g1 = gpersist_gran1_bytes(a), g2 = gpersist_gran2_bytes(a);
+  CK(hipMalloc(&a.gran1, g1)); CK(hipMalloc(&a.gran2, g2)); CK(hipMalloc(&a.ctl, 64));
+  CK(hipMemset(a.gran1, 0, g1)); CK(hipMemset(a.gran2, 0, g2));
+  { const unsigned c0[4] = {1u, 0u, 0u, 0u}; CK(hipMemcpy(a.ctl, c0, 16, hipMemcpyHostToDevice)); }
+  hipStream_t s; CK(hipStreamCreate(&s));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e9f;
+  for (int it = 0; it < 5; ++it) {
+    CK(hipEventRecord(e0, s));
+    launch_glstm_fwd(a, s);
+    CK(hipEventRecord(e1, s));
+    CK(hipStreamSynchronize(s));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    best = ms < best ? ms : best;
+  }
+  unsigned ctl[4]; CK(hipMemcpy(ctl, a.ctl, 16, hipMemcpyDeviceToHost));
+  printf("k_glstm_fwd N=%d T=%d layers=%d (NT=%d NC=%d, %zu + %zu MB of granule slots): %.1f us per launch = %.2f us per step (err word %u, generation %u)\n",
+         N, T, nl, a.NT, a.NC, g1 >> 20, g2 >> 20, best * 1e3f, best * 1e3f / T, ctl[2], ctl[0]);
+  static unsigned tr[256][24][24];
+  CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(rsr::g_gp_trace), sizeof(tr)));
+  // R wave 0 stamps: 0 top, 1 x-part there, 2 m(t-1) there, 3 recurrent MFMAs + tiles written, 4 all partials there, 5 cell done
+  // G wave 0: 6 top, 7 all cells done, 12 projection + publish issued, 13 hop 1 swept, 14 chunk published, 15 hop 2 swept; X wave 0: 8 / 10 sweep
+  // start (row tile 0 / 1), 9 / 11 sweep done
+  const char* rn[5] = {"wait: x-part of the step (X waves)", "wait: m(t-1) gathered (hop 2)", "recurrent MFMAs (2 row tiles) + tiles -> LDS",
+                       "wait: the other R waves' partials", "cell"};
+  const int ngr = N / 32, xpg = 8 / ngr, nblk = 8 * ((nl * a.NC + xpg - 1) / xpg);
+  for (int l = 0; l < nl; ++l) {
+    double ph[5] = {0}, per = 0, gx[6] = {0}, xs[8] = {0}, pro = 0; long cnt = 0, nb_ = 0;
+    for (int b = 0; b < nblk && b < 256; ++b) {
+      const int xcd = b & 7, slot = b >> 3, idx = slot * xpg + (xcd % xpg);
+      if (idx >= nl * a.NC || idx / a.NC != l || idx % a.NC >= 2 * ((P + 15) / 16)) continue;     // (reducers only: the others skip stamps 13, 14)
+      pro += (double)(unsigned)(tr[b][0][20] - tr[b][0][21]); ++nb_;
+      for (int t = 10; t < T - 1 && t < 23; ++t) {
+        for (int i = 0; i < 5; ++i) ph[i] += (double)(unsigned)(tr[b][t][i + 1] - tr[b][t][i]);
+        per += (double)(unsigned)(tr[b][t + 1][0] - tr[b][t][0]);
+        gx[0] += (double)(unsigned)(tr[b][t][7] - tr[b][t][6]); gx[1] += (double)(unsigned)(tr[b][t][12] - tr[b][t][7]);
+        gx[2] += (double)(unsigned)(tr[b][t][13] - tr[b][t][12]); gx[3] += (double)(unsigned)(tr[b][t][14] - tr[b][t][13]);
+        gx[4] += (double)(unsigned)(tr[b][t][15] - tr[b][t][14]); gx[5] += (double)(unsigned)(tr[b][t + 1][2] - tr[b][t][5]);
+        xs[0] += (double)(unsigned)(tr[b][t][9] - tr[b][t][8]); xs[1] += (double)(unsigned)(tr[b][t][16] - tr[b][t][9]);
+        xs[2] += 0; xs[3] += (double)(unsigned)(tr[b][t][11] - tr[b][t][10]);
+        xs[4] += (double)(unsigned)(tr[b][t][17] - tr[b][t][11]); xs[5] += (double)(unsigned)(tr[b][t][18] - tr[b][t][17]);
+        xs[6] += (double)(unsigned)(tr[b][t][19] - tr[b][t][18]); xs[7] += (double)(unsigned)(tr[b][t + 1][8] - tr[b][t][8]);
+        ++cnt;
+      }
+    }
+    if (!cnt) continue;
+    printf("layer %d, shader-clock cycles (s_memtime), mean over workgroups and steps 10..%d: period %.0f\n", l, T - 2 < 22 ? T - 2 : 22, per / cnt);
+    for (int i = 0; i < 5; ++i) printf("   R0 %-48s %6.0f\n", rn[i], ph[i] / cnt);
+    printf("   G0 wait for the cells %.0f | projection + publish (issue) %.0f | hop-1 sweep %.0f | reduce + publish chunk %.0f | hop-2 sweep %.0f\n",
+           gx[0] / cnt, gx[1] / cnt, gx[2] / cnt, gx[3] / cnt, gx[4] / cnt);
+    printf("   cell(t) done on R0 -> m(t) in LDS (the whole hand-off): %.0f\n", gx[5] / cnt);
+    if (l > 0) printf("   X0 period %.0f: sweep r0 %.0f | MFMAs r0 %.0f | (%.0f) | sweep r1 %.0f | MFMAs r1 %.0f | wait cells(t-1) + tiles + signal %.0f | stash(t-1) %.0f\n",
+                      xs[7] / cnt, xs[0] / cnt, xs[1] / cnt, xs[2] / cnt, xs[3] / cnt, xs[4] / cnt, xs[5] / cnt, xs[6] / cnt);
+    printf("   prologue (kernel entry -> R0 enters step 0): %.0f cycles\n", pro / nb_);
+  }
+  return 0;
+}
