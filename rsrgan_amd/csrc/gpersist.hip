@@ -8,20 +8,27 @@
 //   * workgroup (row group g, layer l, slice c) owns NT gate tiles of 4 cells (16 gate columns: i, j, f, o of 4 cells, so that one
 //     lane of the 16x16x4 accumulator holds all four gates of ONE cell of ONE row) = 4*NT cells; NC = ceil(H / (4 NT)) slices;
 //   * 12 waves: R0..R3 keep K_h (the recurrent rows of the kernel, split by k-block over the four waves) in VGPRs and run the
-//     critical path (m(t-1).K_h, the cell, the partial projection); X0..X3 keep K_x and run one step AHEAD of the R waves (the
-//     x-part of step t+1 only needs the layer below); G0..G3 poll, reduce and publish;
-//   * all products run TRANSPOSED (weights = MFMA A operand, activations = B operand), as in dpersist.hip.
+//     critical compute (m(t-1).K_h, the cell, the stash); X0..X3 keep K_x and run AHEAD of the R waves (the x-part of step t only
+//     needs the layer below); G0..G3 project, publish, poll and reduce -- the R waves never wait for global memory;
+//   * all products run TRANSPOSED (weights = MFMA A operand, activations = B operand), as in dpersist.hip;
+//   * the two 16-row tiles of a group are two independent LANES of the same workgroup, half a chain apart: while tile 0's
+//     hand-off is in flight (G waves 0, 2) the R waves compute tile 1 (whose hand-off G waves 1, 3 run), so a step costs one tile's
+//     chain, not compute + hand-off of both (first version: 32 k cycles per step, 21 k of them hand-off with the R waves idle).
 //
-// Two hand-offs per step and layer, both "the data is the flag" (8-byte {value, tag} granules in 16-byte write-through accesses,
-// cdna_hip_programming.md guideline 16 R2):
-//   hop 1  every workgroup publishes its PARTIAL projection h[:, its cells] . W_p[its cells, :] (32 x P) cut into (k-block, row tile)
-//          chunks of 16 x 16; workgroup c of the layer is the REDUCER of chunk c: it sums the NC partials in slice order
-//          (deterministic) -- a reduce-scatter;
-//   hop 2  the reducer publishes its chunk of m(t); every workgroup of the layer (for the recurrent product of step t+1) and of the
-//          layer above (x of step t) gathers all chunks -- an all-gather.  The chunk's lane layout IS the consumer's B fragment.
-// Inside a workgroup the three roles synchronise through monotonic LDS counters (no s_barrier: the X waves are not in lock step).
+// Two hand-offs per step, layer and tile, both "the data is the flag" (8-byte {value, tag} granules in 16-byte write-through
+// accesses, cdna_hip_programming.md guideline 16 R2):
+//   hop 1  every workgroup publishes its PARTIAL projection h[:, its cells] . W_p[its cells, :] (16 x P per tile) as 16 x 16 chunks,
+//          one per k-block of P; workgroup c of the layer is the REDUCER of the 8-column half (k-block c >> 1, half c & 1) of BOTH
+//          tiles: it sums the NC partials in slice order (deterministic) -- a reduce-scatter;
+//   hop 2  the reducer publishes its half chunk of m(t); every workgroup of the layer (for the recurrent product of step t+1) and
+//          of the layer above (x of step t) gathers all chunks -- an all-gather.  A chunk slot is [half][2][32 lanes][16 bytes]:
+//          lane pl of the producer / consumer fragment owns bytes (pl >> 5) * 1024 + j * 512 + (pl & 31) * 16, j = 0, 1, so that
+//          every store / load instruction moves whole 128-byte lines and a reducer's half is one contiguous KB.
+// Inside a workgroup the three roles synchronise through monotonic LDS counters (no s_barrier: the roles are not in lock step).
 // Tags: hop 2 has one slot per step, tag = launch generation (dpersist.hip); hop 1 is a ring of two steps, tag = generation and step.
 // Every spin is bounded; failures go to the sticky err word of the control block and poison the top layer's output with NaN.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace rsr {
@@ -41,6 +48,7 @@ constexpr unsigned GP_SC1 = 16u;         // aux of the raw-buffer builtins: sc1 
 constexpr unsigned GP_VOL = 1u << 31;    // ... compiler-only: volatile (a polled load must not be hoisted out of its loop)
 
 #ifdef GP_TRACE
+__device__ unsigned g_gp_cnt[8];          // [0] cached first reads, [1] of them with a stale / missing tag; [2], [3] the same for write-through first reads
 __device__ unsigned g_gp_trace[256][24][24];
 #define GPT_DECL __shared__ unsigned gp_tr[24][24];
 #define GPT(i) do { if ((w & 3) == 0 && lane == 0 && t < 24) gp_tr[t][i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
@@ -82,71 +90,78 @@ struct GpBuf { __amdgpu_buffer_rsrc_t rs; };
 __device__ __forceinline__ GpBuf gp_buf(const void* p, size_t bytes) {
   GpBuf b; b.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); return b;
 }
-// one chunk slot = two contiguous 1 KB halves, [64 lanes] x {v0, tag, v1, tag} and [64 lanes] x {v2, tag, v3, tag}: every store / load
-// instruction moves whole 128-byte lines (with the two 16-byte pieces of a lane side by side each instruction touched 16 lines half
-// full: ~700 cycles of issue per store, profiles/r4_gpersist_trace.txt)
-__device__ __forceinline__ void gp_publish(const GpBuf& b, unsigned off, int lane, unsigned tag, const f32x4 v) {
-  const u32x4 x0 = {__float_as_uint(v[0]), tag, __float_as_uint(v[1]), tag};
-  const u32x4 x1 = {__float_as_uint(v[2]), tag, __float_as_uint(v[3]), tag};
-  __builtin_amdgcn_raw_buffer_store_b128(x0, b.rs, off + (unsigned)lane * 16u, 0, GP_SC1);
-  __builtin_amdgcn_raw_buffer_store_b128(x1, b.rs, off + 1024u + (unsigned)lane * 16u, 0, GP_SC1);
+__device__ __forceinline__ void gp_store(const GpBuf& b, unsigned off, unsigned tag, float v0, float v1) {
+  const u32x4 x = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
+  __builtin_amdgcn_raw_buffer_store_b128(x, b.rs, off, 0, GP_SC1);
 }
-// One wave waits for NS chunk slots (byte offsets off[]) and reads them.  Polling must be CHEAP: a spinning full sweep (20 KB per pass
-// and wave, 1800 waves) saturates the fabric and starves every other access of the chip (first version: 700 us per step).  The slots
-// are read in full once; if a tag is missing, lane k polls one SENTINEL -- the last 16 bytes of slot k -- with a sleep between polls,
-// and the slots are read again when every sentinel carries `tag`.  false on time-out / peer failure.
-// POLL_FIRST: the caller arrives before the data as a rule (the hand-offs of the critical path): start with the sentinels.
-// BATCH: slots read per round trip (a wave that keeps 100 weight registers cannot hold 10 loads' worth of granules as well).
-template <int NS, bool POLL_FIRST, int BATCH = NS>
-__device__ __forceinline__ bool gp_sweep(const GpBuf& b, const unsigned (&off)[NS], int ns, int lane, unsigned tag, f32x4 (&v)[NS], gu32* err) {
+// One wave waits for NL 16-byte-per-lane pieces (wave-uniform byte offsets lo[], + this lane's lane_off) and hands them to
+// consume(k, a, b) in order.  Polling must be CHEAP: a spinning full read (20 KB per pass and wave, 1800 waves) saturates the fabric
+// and starves every other access of the chip (first version: 700 us per step).  So a lane polls one SENTINEL (byte offset so, the
+// last 16 bytes of something it waits for; son = this lane has one) with a sleep between polls; only when every sentinel carries
+// `tag` the pieces are read in full, and re-read in the rare case that a store of theirs has not landed yet.  POLL_FIRST: the caller
+// arrives before the data as a rule (the hand-offs of the critical path).  BATCH: pieces per round trip (a wave that keeps 100
+// weight registers cannot hold 20 loads' worth of granules as well).  consume() must be idempotent (a failed pass is repeated).
+// CACHED: the first full read uses ordinary (L2-cacheable) loads.  The all-gathered chunks are read by ~19 workgroups per XCD, and
+// as write-through (sc1) reads every one of them crossed the fabric: the step was bound by ~5 TB/s of such traffic.  Every 16 bytes
+// carry their tag, so a stale line -- from a cache, whatever the reason -- is detected like a store that has not landed, and the
+// retry reads past the caches (sc1); slots that are written once per launch (hop 2) never go stale within one.
+// false on time-out / peer failure.
+template <int NL, bool POLL_FIRST, int BATCH, bool CACHED, class F>
+__device__ __forceinline__ bool gp_sweep(const GpBuf& b, const unsigned (&lo)[NL], int nl, unsigned lane_off, unsigned so, bool son,
+                                         unsigned tag, gu32* err, F&& consume) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  // (the offsets as scalar VALUES first: hipcc turns `c ? off[k] : off[0]` into a load through a selected pointer, which keeps the
+  // (the offsets as scalar VALUES first: hipcc turns `c ? lo[k] : lo[0]` into a load through a selected pointer, which keeps the
   // array in scratch / LDS)
-  unsigned of[NS];
+  unsigned of[NL];
 #pragma unroll
-  for (int k = 0; k < NS; ++k) of[k] = (unsigned)__builtin_amdgcn_readfirstlane((int)off[k]);
-  unsigned so = of[0];
+  for (int k = 0; k < NL; ++k) of[k] = (unsigned)__builtin_amdgcn_readfirstlane((int)lo[k]);
+  auto read_all = [&](auto through_caches) -> bool {
+    constexpr unsigned AUX = decltype(through_caches)::value ? GP_VOL : (GP_SC1 | GP_VOL);
+    bool ok = true;
 #pragma unroll
-  for (int k = 1; k < NS; ++k) so = (lane == k && k < ns) ? of[k] : so;
-  so += 1024u + 63u * 16u;
-  bool read_now = !POLL_FIRST;
-  for (unsigned spins = 0;; ++spins) {
-    if (read_now) {
-      bool ok = true;
+    for (int k0 = 0; k0 < NL; k0 += BATCH) {
+      u32x4 x[BATCH];
 #pragma unroll
-      for (int k0 = 0; k0 < NS; k0 += BATCH) {
-        u32x4 x[BATCH][2];
+      for (int j = 0; j < BATCH; ++j) {
+        const int k = k0 + j < NL ? k0 + j : NL - 1;
+        x[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, (k < nl ? of[k] : of[0]) + lane_off, 0, AUX);   // (unconditional)
+      }
 #pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-          const int k = k0 + j < NS ? k0 + j : NS - 1;
-          const unsigned o = (k < ns ? of[k] : of[0]) + (unsigned)lane * 16u; // (unconditional loads: a slot beyond ns re-reads slot 0)
-          x[j][0] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, o, 0, GP_SC1 | GP_VOL);
-          x[j][1] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, o + 1024u, 0, GP_SC1 | GP_VOL);
-        }
-#pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-          const int k = k0 + j;
-          if (k < NS) {
-            // (real moves: hipcc otherwise keeps the {value, tag, value, tag} load tuples alive and picks the values out of them
-            // where they are used -- twice the registers, in 4-aligned tuples)
-            float v0, v1, v2, v3;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(v0) : "v"(x[j][0][0]));
-            asm volatile("v_mov_b32 %0, %1" : "=v"(v1) : "v"(x[j][0][2]));
-            asm volatile("v_mov_b32 %0, %1" : "=v"(v2) : "v"(x[j][1][0]));
-            asm volatile("v_mov_b32 %0, %1" : "=v"(v3) : "v"(x[j][1][2]));
-            v[k] = f32x4{v0, v1, v2, v3};
-            ok &= (k >= ns) || (x[j][0][1] == tag && x[j][0][3] == tag && x[j][1][1] == tag && x[j][1][3] == tag);
-          }
+      for (int j = 0; j < BATCH; ++j) {
+        const int k = k0 + j;
+        if (k < NL) {
+          // (real moves: hipcc otherwise keeps the {value, tag, value, tag} load tuples alive and picks the values out of them
+          // where they are used -- twice the registers, in 4-aligned tuples)
+          float v0, v1;
+          asm volatile("v_mov_b32 %0, %1" : "=v"(v0) : "v"(x[j][0]));
+          asm volatile("v_mov_b32 %0, %1" : "=v"(v1) : "v"(x[j][2]));
+          ok &= (k >= nl) || (x[j][1] == tag && x[j][3] == tag);
+          consume(k, v0, v1);
         }
       }
-      if (__all(ok)) return true;
+    }
+    return __all(ok);
+  };
+  bool read_now = !POLL_FIRST, first = true;
+  for (unsigned spins = 0;; ++spins) {
+#ifdef GP_ABL
+    if (read_now && POLL_FIRST && ((GP_ABL >> (CACHED ? 2 : 1)) & 1)) return true;      // timing ablation: the sentinels only
+    if (!POLL_FIRST && (GP_ABL & 1)) return true;                                        // timing ablation: no x sweeps
+#endif
+    if (read_now) {
+      const bool ok = (CACHED && first) ? read_all(std::true_type{}) : read_all(std::false_type{});
+#ifdef GP_TRACE
+      if (first && (threadIdx.x & 63) == 0) { atomicAdd(&g_gp_cnt[CACHED ? 0 : 2], 1u); if (!ok) atomicAdd(&g_gp_cnt[CACHED ? 1 : 3], 1u); }
+#endif
+      first = false;
+      if (ok) return true;
       asm volatile("" ::: "memory");
       if (spins > 1000000u) return false;
     }
     read_now = true;
     for (unsigned polls = 0;; ++polls) {
       const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(b.rs, so, 0, GP_SC1 | GP_VOL);
-      if (__all(y[1] == tag && y[3] == tag)) break;
+      if (__all(!son || (y[1] == tag && y[3] == tag))) break;
       asm volatile("" ::: "memory");
       if ((polls & 63) == 63) {
         if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull ||          // 1 s at 100 MHz
@@ -157,19 +172,18 @@ __device__ __forceinline__ bool gp_sweep(const GpBuf& b, const unsigned (&off)[N
   }
 }
 
-// LDS of a workgroup (NT = 5: 152 KB)
+// LDS of a workgroup (NT = 5: 129 KB)
 template <int NT>
 struct GpLds {
   float wp[GP_NKB][NT][64];                 // W_p^T fragments: A operand of the partial projection [k-block of P][k-step of 4 cells][lane]
   float mB[GP_NR][GP_NKB][64][4];           // carried m(t-1) as B fragments [row tile][k-block][lane][4]
   float pb[4][NT][GP_NR][64][4];            // accumulator tiles: x-part (X wave w -> R wave w), then the R waves' partial sums
   float st[6][GP_ROWS][4 * NT];             // the step's stash: gates i, j, f, o | c | h   (h also feeds the projection)
-  float gs[2][4][64][4];                    // the G waves' partial chunk sums by parity
-  float xs[4][NT][64][4];                   // X wave w parks its row-tile-0 accumulators here while it works on row tile 1
+  float gs[GP_NR][2][64][2];                // the two reducing G waves' partial sums of this workgroup's half chunk, per tile
   float kx4[2][NT][64][4];                  // the fifth K_x k-block of X waves 0, 1 (k-blocks 16, 17): 100 weight registers do not fit beside the sweeps
   float peep[4 * NT][4];                    // {w_i, w_f, w_o, -} per cell of this slice (one 16-byte read per cell)
   float bias[4 * NT][4];                    // {b_i, b_j, b_f, b_o} per cell: the accumulator registers of a lane
-  unsigned cnt_x[4], cnt_p, cnt_h, cnt_m, cnt_g, dead, cnt_s, pad_[6];
+  unsigned cnt_x[GP_NR][4], cnt_p[GP_NR], cnt_h[GP_NR], cnt_m[GP_NR], cnt_g[GP_NR], cnt_s[GP_NR], dead, pad_[13];
 };
 
 template <int NT>
@@ -179,7 +193,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigne
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef GP_TRACE
-  if (tid == 0) gp_tr[0][21] = (unsigned)__builtin_amdgcn_s_memtime();          // kernel entry -> [0][20]: the prologue (weights into VGPRs / LDS)
+  if (tid == 0) gp_tr[0][23] = (unsigned)__builtin_amdgcn_s_memtime();          // kernel entry -> [0][22]: the prologue (weights into VGPRs / LDS)
 #endif
   // block -> (row group, layer, slice): block b runs on XCD b & 7 (observed; speed only) -- a row group owns 8 / groups XCDs
   const int ngr = a.N / GP_ROWS, xpg = 8 / ngr;
@@ -189,15 +203,18 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigne
   const int l = idx / a.NC, c = idx - l * a.NC;
   const GPersistLayer L = a.L[l];
   const int H = a.H, H4 = 4 * H, T = a.T, N = a.N, P = L.P, ldP = L.ldP, I = L.I, NC = a.NC;
-  const int nkb = (P + 15) >> 4, nch = nkb * NR, nkbx = (I + 15) >> 4;
+  const int nkb = (P + 15) >> 4, nkbx = (I + 15) >> 4;
   const int row0 = grp * GP_ROWS, cell0 = c * CW;
   gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
-  // hop 1: [group][layer][parity][chunk][producer] slots; hop 2: [group][layer][t][chunk] slots
+  // hop 1: [group][layer][parity][tile][k-block][producer] slots; hop 2: [group][layer][t][tile][k-block] slots
   const size_t g1_per = (size_t)GP_NCH * NC * GP_SLOT, g2_per = (size_t)GP_NCH * GP_SLOT;
   const GpBuf b1 = gp_buf((const char*)a.gran1 + (size_t)(grp * a.nl + l) * 2 * g1_per, 2 * g1_per);
   const GpBuf b2 = gp_buf((const char*)a.gran2 + (size_t)(grp * a.nl + l) * T * g2_per, (size_t)T * g2_per);
   const GpBuf b2x = gp_buf((const char*)a.gran2 + (size_t)(grp * a.nl + (l > 0 ? l - 1 : 0)) * T * g2_per, (size_t)T * g2_per);
   const unsigned tagbase = gen << 11;                                  // hop 1: tag = generation (21 bits) and step + 1
+  const unsigned frag_off = (unsigned)((lane >> 5) * 1024 + (lane & 31) * 16);   // a fragment lane's bytes in a chunk slot (+ j * 512)
+  auto slot1 = [&](int par, int r, int jb, int p) { return (unsigned)((((size_t)(par * NR + r) * GP_NKB + jb) * NC + p) * GP_SLOT); };
+  auto slot2 = [&](int t, int r, int jb) { return (unsigned)((((size_t)t * NR + r) * GP_NKB + jb) * GP_SLOT); };
 
   // ---- cooperative prologue: W_p fragments, peepholes, bias, counters ----
   for (int e = tid; e < GP_NKB * NT * 64; e += GP_WAVES * 64) {
@@ -211,7 +228,9 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigne
     if (k < 3) S.peep[cl][k] = (k == 0 ? L.wi : k == 1 ? L.wf : L.wo)[cell];
     else S.bias[cl][k - 3] = L.bias[(k - 3) * H + cell];
   }
-  if (tid < 16) (&S.cnt_x[0])[tid] = 0u;
+  for (int e = tid; e < GP_NR * GP_NKB * 64; e += GP_WAVES * 64)       // the carried state m(-1) is zero (cell.zero_state)
+    *reinterpret_cast<f32x4*>(&S.mB[0][0][0][0] + 4 * e) = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tid < 32) (&S.cnt_x[0][0])[tid] = 0u;
   __syncthreads();
   const unsigned* dead = &S.dead;
   auto fail = [&]() {
@@ -221,23 +240,9 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigne
     }
   };
   const int len0 = a.len[row0 + lr], len1 = a.len[row0 + 16 + lr];
-  // the stash of step t (gate activations, c, h: 15 KB) from its LDS stage, a quarter per R wave: NT consecutive lanes write one
-  // 16 NT-byte row piece.  The R waves do it: they idle during the hand-off and touch no other global memory (the X waves' sweeps
-  // queued behind these stores, and a wave that publishes or polls must not have them in front of its hand-off traffic).
-  auto stash = [&](int t, int rw) {
-#pragma unroll
-    for (int it = 0; it < (6 * GP_ROWS * NT + 255) / 256; ++it) {
-      const int e = it * 256 + rw * 64 + lane;
-      const int cq = e % NT, pr = e / NT, row = pr % GP_ROWS, k = min(pr / GP_ROWS, 5);
-      const float4 v = *reinterpret_cast<const float4*>(&S.st[k][row][4 * cq]);
-      const size_t rowg = (size_t)t * N + row0 + row;
-      float* dst = (k < 4 ? L.gates + rowg * H4 + k * H : k == 4 ? L.c + (rowg + N) * H : L.h + rowg * L.ldH) + cell0 + 4 * cq;
-      if (e < 6 * GP_ROWS * NT && cell0 + 4 * cq < H) *reinterpret_cast<float4*>(dst) = v;
-    }
-  };
 
   if (w < 4) {
-    // =============================== R waves: the critical path ===============================
+    // =============================== R waves: the critical compute ===============================
     // resident K_h fragments: A[row lr = 4 * cell + gate][k = 16 jb + 4 q + u], jb = w + 4 jj
     float4 kh[NT][GP_KBW];
 #pragma unroll
@@ -253,119 +258,133 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigne
         kh[i][jj] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
       }
     }
-    float cprev[3] = {0.f, 0.f, 0.f};
+    // cell units of a row tile: gate tile w on every wave, gate tile 4 + w' (w' = 0 .. NT - 5) on wave w' as well
+    float cprev[NR][2] = {{0.f, 0.f}, {0.f, 0.f}};
     // every LDS access below is one base register + a compile-time offset (hipcc otherwise hoists dozens of loop-invariant addresses
-    // out of the step loop and spills them).  Cell units of this wave: u = w + 4 s = (tile (w >> 1) + 2 s, row tile w & 1); projection
-    // chunks: ch = w + 4 n = (k-block (w >> 1) + 2 n, row tile w & 1)
+    // out of the step loop and spills them)
     float* const pbw = &S.pb[w][0][0][lane][0];                        // + (i * NR + r) * 256
     const float* const mbw = &S.mB[0][w][lane][0];                     // + (r * GP_NKB + 4 jj) * 256
-    const float* const pbc = &S.pb[0][w >> 1][w & 1][lane][0];         // + (k * NU + 2 s * NR) * 256
-    const float* const pwc = &S.peep[4 * (w >> 1) + q][0];             // + 32 s
-    const int rowc = 16 * (w & 1) + lr, clc = 4 * (w >> 1) + q, lenc = (w & 1) ? len1 : len0;
+    const float* const pbc = &S.pb[0][w][0][lane][0];                  // + (k * NU + s * 4 * NR + r) * 256   (gate tile w + 4 s)
+    const float* const pwc = &S.peep[4 * w + q][0];                    // + s * 64
+    float* const stc = &S.st[0][lr][4 * w + q];                        // + k * GP_ROWS * CW + r * 16 * CW + s * 16
+    const bool two = w + 4 < NT;                                       // this wave owns a second gate tile
     for (int t = 0; t < T; ++t) {
 #ifdef GP_TRACE
-      if (t == 0 && w == 0 && lane == 0) gp_tr[0][20] = (unsigned)__builtin_amdgcn_s_memtime();
+      if (t == 0 && w == 0 && lane == 0) gp_tr[0][22] = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
-      GPT(0);
-      if (!gp_wait(&S.cnt_x[w], (unsigned)t + 1u, dead)) return;       // x-part (+ bias) of step t
-      GPT(1);
-      if (t > 0 && !gp_wait(&S.cnt_m, 4u * (unsigned)t, dead)) return; // carried m(t-1) is in LDS
-      GPT(2);
-      __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-      for (int r = 0; r < NR; ++r) {                                   // (one row tile at a time: 20 accumulator registers instead of 40)
-        f32x4 acc[NT];
+      for (int r = 0; r < NR; ++r) {
+        GPT(6 * r + 0);
+        if (!gp_wait(&S.cnt_x[r][w], (unsigned)t + 1u, dead)) return;     // x-part (+ bias) of step t, tile r
+        GPT(6 * r + 1);
+        if (t > 0 && !gp_wait(&S.cnt_m[r], 2u * (unsigned)t, dead)) return;   // carried m(t-1) of the tile is in LDS
+        GPT(6 * r + 2);
+        {
+          f32x4 acc[NT];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) acc[i] = *reinterpret_cast<const f32x4*>(pbw + (i * NR + r) * 256);
-        if (t > 0) {
+          for (int i = 0; i < NT; ++i) acc[i] = *reinterpret_cast<const f32x4*>(pbw + (i * NR + r) * 256);
+          if (t > 0) {
+            __builtin_amdgcn_s_setprio(2);
 #pragma unroll
-          for (int jj = 0; jj < GP_KBW; ++jj) {
-            if (w + 4 * jj < nkb) {
-              const float4 b = *reinterpret_cast<const float4*>(mbw + (r * GP_NKB + 4 * jj) * 256);
+            for (int jj = 0; jj < GP_KBW; ++jj) {
+              if (w + 4 * jj < nkb) {
+                const float4 b = *reinterpret_cast<const float4*>(mbw + (r * GP_NKB + 4 * jj) * 256);
 #pragma unroll
-              for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kh[i][jj].x, b.x, acc[i], 0, 0, 0);
+                for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kh[i][jj].x, b.x, acc[i], 0, 0, 0);
 #pragma unroll
-              for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kh[i][jj].y, b.y, acc[i], 0, 0, 0);
+                for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kh[i][jj].y, b.y, acc[i], 0, 0, 0);
 #pragma unroll
-              for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kh[i][jj].z, b.z, acc[i], 0, 0, 0);
+                for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kh[i][jj].z, b.z, acc[i], 0, 0, 0);
 #pragma unroll
-              for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kh[i][jj].w, b.w, acc[i], 0, 0, 0);
+                for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(kh[i][jj].w, b.w, acc[i], 0, 0, 0);
+              }
             }
+            __builtin_amdgcn_s_setprio(0);
+          }
+#pragma unroll
+          for (int i = 0; i < NT; ++i) *reinterpret_cast<f32x4*>(pbw + (i * NR + r) * 256) = acc[i];
+        }
+        GPT(6 * r + 3);
+        gp_signal(&S.cnt_p[r], lane);
+        if (!gp_wait(&S.cnt_p[r], 4u * ((unsigned)t + 1u), dead)) return;
+        if (t > 0 && !gp_wait(&S.cnt_s[r], 4u * (unsigned)t, dead)) return;  // the stash of step t-1 has left the stage (long ago)
+        GPT(6 * r + 4);
+        // the cell, on the accumulator layout: lane (q, lr) of (gate tile i, row tile r) = row 16 r + lr, cell 4 i + q, gates i j f o
+        const bool live = t < (r ? len1 : len0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s == 0 || two) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(pbc + (0 * NU + s * 4 * NR + r) * 256), p1 = *reinterpret_cast<const f32x4*>(pbc + (1 * NU + s * 4 * NR + r) * 256);
+            const f32x4 p2 = *reinterpret_cast<const f32x4*>(pbc + (2 * NU + s * 4 * NR + r) * 256), p3 = *reinterpret_cast<const f32x4*>(pbc + (3 * NU + s * 4 * NR + r) * 256);
+            const f32x4 z = ((p0 + p1) + p2) + p3;
+            const float cpv = cprev[r][s];
+            const f32x4 pw = *reinterpret_cast<const f32x4*>(pwc + s * 64);
+            const float gi = gp_sigmoid(z[0] + pw[0] * cpv);
+            const float gf = gp_sigmoid(z[2] + a.forget_bias + pw[1] * cpv);
+            const float gj = gp_tanh(z[1]);
+            const float cn = gf * cpv + gi * gj;
+            const float go = gp_sigmoid(z[3] + pw[2] * cn);
+            const float hh = go * gp_tanh(cn);
+            cprev[r][s] = live ? cn : cpv;
+            float* const d = stc + r * 16 * CW + s * 16;
+            d[0 * GP_ROWS * CW] = live ? gi : 0.f; d[1 * GP_ROWS * CW] = live ? gj : 0.f;
+            d[2 * GP_ROWS * CW] = live ? gf : 0.f; d[3 * GP_ROWS * CW] = live ? go : 0.f;
+            d[4 * GP_ROWS * CW] = cprev[r][s];
+            d[5 * GP_ROWS * CW] = live ? hh : 0.f;
           }
         }
+        gp_signal(&S.cnt_h[r], lane);
+        GPT(6 * r + 5);
+        if (!gp_wait(&S.cnt_h[r], 4u * ((unsigned)t + 1u), dead)) return;     // every cell of the tile is in the stage
+        // the tile's stash (gate activations, c, h: 7.5 KB) from the LDS stage, a quarter per R wave: NT consecutive lanes write one
+        // 16 NT-byte row piece.  The R waves do it: they have nothing in the vector-memory queue that it could delay (the X waves'
+        // sweeps queued behind these stores, and a wave that publishes or polls must not have them in front of its hand-off traffic)
 #pragma unroll
-        for (int i = 0; i < NT; ++i) *reinterpret_cast<f32x4*>(pbw + (i * NR + r) * 256) = acc[i];
-      }
-      __builtin_amdgcn_s_setprio(0);
-      GPT(3);
-      gp_signal(&S.cnt_p, lane);
-      if (!gp_wait(&S.cnt_p, 4u * ((unsigned)t + 1u), dead)) return;
-      GPT(4);
-      // the cell, on the accumulator layout: lane (q, lr) of unit (tile i, row tile r) = row 16 r + lr, cell 4 i + q, gates i j f o
-      if (t > 0 && !gp_wait(&S.cnt_s, 4u * (unsigned)t, dead)) return; // the stash of step t-1 has left the stage (long ago: right after its cells)
-      float* const stc = &S.st[0][rowc][clc];                          // + k * GP_ROWS * CW + 8 s
-      const bool live = t < lenc;
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        if (w + 4 * s < NU) {
-          const f32x4 p0 = *reinterpret_cast<const f32x4*>(pbc + (0 * NU + 2 * s * NR) * 256), p1 = *reinterpret_cast<const f32x4*>(pbc + (1 * NU + 2 * s * NR) * 256);
-          const f32x4 p2 = *reinterpret_cast<const f32x4*>(pbc + (2 * NU + 2 * s * NR) * 256), p3 = *reinterpret_cast<const f32x4*>(pbc + (3 * NU + 2 * s * NR) * 256);
-          const f32x4 z = ((p0 + p1) + p2) + p3;
-          const float cpv = cprev[s];
-          const f32x4 pw = *reinterpret_cast<const f32x4*>(pwc + 32 * s);
-          const float gi = gp_sigmoid(z[0] + pw[0] * cpv);
-          const float gf = gp_sigmoid(z[2] + a.forget_bias + pw[1] * cpv);
-          const float gj = gp_tanh(z[1]);
-          const float cn = gf * cpv + gi * gj;
-          const float go = gp_sigmoid(z[3] + pw[2] * cn);
-          const float hh = go * gp_tanh(cn);
-          cprev[s] = live ? cn : cpv;
-          stc[0 * GP_ROWS * CW + 8 * s] = live ? gi : 0.f; stc[1 * GP_ROWS * CW + 8 * s] = live ? gj : 0.f;
-          stc[2 * GP_ROWS * CW + 8 * s] = live ? gf : 0.f; stc[3 * GP_ROWS * CW + 8 * s] = live ? go : 0.f;
-          stc[4 * GP_ROWS * CW + 8 * s] = cprev[s];
-          stc[5 * GP_ROWS * CW + 8 * s] = live ? hh : 0.f;
+        for (int it = 0; it < (6 * 16 * NT + 255) / 256; ++it) {
+          const int e = it * 256 + w * 64 + lane;
+          const int cq = e % NT, pr = e / NT, row = 16 * r + (pr & 15), k = min(pr >> 4, 5);
+          const float4 v = *reinterpret_cast<const float4*>(&S.st[k][row][4 * cq]);
+          const size_t rowg = (size_t)t * N + row0 + row;
+          float* dst = (k < 4 ? L.gates + rowg * H4 + k * H : k == 4 ? L.c + (rowg + N) * H : L.h + rowg * L.ldH) + cell0 + 4 * cq;
+          if (e < 6 * 16 * NT && cell0 + 4 * cq < H) *reinterpret_cast<float4*>(dst) = v;
         }
+        gp_signal(&S.cnt_s[r], lane);
       }
-      gp_signal(&S.cnt_h, lane);
-      GPT(5);
-      if (!gp_wait(&S.cnt_h, 4u * ((unsigned)t + 1u), dead)) return;   // every cell of the step is in the stage
-      stash(t, w);
-      gp_signal(&S.cnt_s, lane);
     }
 #ifdef GP_TRACE
-    if (w == 0) { { const int i0_ = 0, i1_ = 6; GPT_FLUSH(); } { const int i0_ = 20, i1_ = 22; GPT_FLUSH(); } }
+    if (w == 0) { { const int i0_ = 0, i1_ = 12; GPT_FLUSH(); } { const int i0_ = 22, i1_ = 24; GPT_FLUSH(); } }
 #endif
     return;
   }
 
   if (w < 8) {
-    // =============================== X waves: one step ahead ===============================
+    // =============================== X waves: ahead of the R waves ===============================
     const int xw = w - 4;
+    float* const pbx = &S.pb[xw][0][0][lane][0];                       // + (i * NR + r) * 256
     if (l == 0) {
-      // layer 0: the x-part of every step was batched into `gates` (zx = x . K_x + bias); X wave xw fetches the units u = xw (mod 4)
+      // layer 0: the x-part of every step was batched into `gates` (zx = x . K_x + bias); X wave xw fetches gate tile xw (and 4 + xw)
+      const bool two = xw + 4 < NT;
       for (int t = 0; t < T; ++t) {
-        float zv[3][4];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          const int u = min(xw + 4 * s, NU - 1), i = u / NR, r = u - i * NR;
-          const int cell = min(cell0 + 4 * i + q, H - 1);
-          const float* zr = L.gates + ((size_t)t * N + row0 + 16 * r + lr) * H4 + cell;
+        for (int r = 0; r < NR; ++r) {
+          float zv[2][4];
 #pragma unroll
-          for (int g = 0; g < 4; ++g) zv[s][g] = zr[g * H];
-        }
-        if (t > 0 && !gp_wait(&S.cnt_h, 4u * (unsigned)t, dead)) return;     // the cell of step t-1 has read the tiles
+          for (int s = 0; s < 2; ++s) {
+            const int i = min(xw + 4 * s, NT - 1), cell = min(cell0 + 4 * i + q, H - 1);
+            const float* zr = L.gates + ((size_t)t * N + row0 + 16 * r + lr) * H4 + cell;
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-          for (int r = 0; r < NR; ++r) {
-            const int u = i * NR + r;
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 3; ++s)
-              if (u == xw + 4 * s) v = f32x4{zv[s][0], zv[s][1], zv[s][2], zv[s][3]};
-            *reinterpret_cast<f32x4*>(&S.pb[xw][0][0][lane][0] + (i * NR + r) * 256) = v;
+            for (int g = 0; g < 4; ++g) zv[s][g] = zr[g * H];
           }
-        gp_signal(&S.cnt_x[xw], lane);
+          if (t > 0 && !gp_wait(&S.cnt_h[r], 4u * (unsigned)t, dead)) return;     // the cells of step t-1 have read the tiles
+#pragma unroll
+          for (int i = 0; i < NT; ++i) {
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i == xw) v = f32x4{zv[0][0], zv[0][1], zv[0][2], zv[0][3]};
+            if (two && i == xw + 4) v = f32x4{zv[1][0], zv[1][1], zv[1][2], zv[1][3]};
+            *reinterpret_cast<f32x4*>(pbx + (i * NR + r) * 256) = v;
+          }
+          gp_signal(&S.cnt_x[r][xw], lane);
+        }
       }
       return;
     }
@@ -386,112 +405,95 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigne
       }
     }
     const float* const kx4w = &S.kx4[xw & 1][0][lane][0];              // + i * 256
+    const int nsx = (nkbx - xw + 3) >> 2;                              // this wave's k-blocks: xw, xw + 4, ...
     for (int t = 0; t < T; ++t) {
-      // both row tiles BEFORE the wait for the cells of step t-1: behind it only the tile stores are left, so the R waves get the
-      // x-part of step t right after their cell of step t-1.  (Row tile 0's accumulators wait in this wave's own LDS stage: 20
-      // registers less while row tile 1 is swept.)
-      f32x4 acc[NT];
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        // x(t) = the masked output of the layer below: chunks (k-block xw + 4 jj, row tile r) of its m(t)
-        unsigned off[GP_KBW];
-        int ns = 0;
+        // x(t) = the masked output of the layer below: fragments (k-block xw + 4 jj, tile r) of its m(t), two 16-byte pieces each
+        unsigned lo[2 * GP_KBW];
 #pragma unroll
         for (int jj = 0; jj < GP_KBW; ++jj) {
-          const int jb = xw + 4 * jj;
-          off[jj] = (unsigned)(((size_t)t * GP_NCH + min(jb, nkbx - 1) * NR + r) * GP_SLOT);
-          ns += jb < nkbx ? 1 : 0;
+          const unsigned o = slot2(t, r, min(xw + 4 * jj, nkbx - 1));
+          lo[2 * jj] = o; lo[2 * jj + 1] = o + 512u;
         }
-        f32x4 xv[GP_KBW];
-        GPT(8 + 2 * r);
-        if (!gp_sweep<GP_KBW, false, 3>(b2x, off, ns, lane, gen, xv, err)) { fail(); return; }
-        GPT(9 + 2 * r);
+        float xv[2 * GP_KBW][2];
+        GPT(18 + 2 * r);
+        if (!gp_sweep<2 * GP_KBW, false, 6, true>(b2x, lo, 2 * nsx, frag_off, slot2(t, r, min(xw + 4 * (lane >> 1), nkbx - 1)) + (unsigned)(lane & 1) * 1024u + 1008u,
+                                            lane < 2 * nsx, gen, err, [&](int k, float va, float vb) { xv[k][0] = va; xv[k][1] = vb; })) { fail(); return; }
+        GPT(19 + 2 * r);
         const bool live = t < (r ? len1 : len0);
+        f32x4 acc[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i)
           acc[i] = xw == 0 ? *reinterpret_cast<const f32x4*>(&S.bias[q][0] + 16 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
-        __builtin_amdgcn_s_setprio(2);                                 // (below the R waves' and the projection's bursts, above every spin loop)
+        __builtin_amdgcn_s_setprio(1);                                 // (below the R waves' and the projection's bursts, above every spin loop)
 #pragma unroll
         for (int jj = 0; jj < GP_KBW; ++jj) {
           if (xw + 4 * jj < nkbx) {
-            const f32x4 b = live ? xv[jj] : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float b0 = live ? xv[2 * jj][0] : 0.f, b1 = live ? xv[2 * jj][1] : 0.f, b2_ = live ? xv[2 * jj + 1][0] : 0.f, b3 = live ? xv[2 * jj + 1][1] : 0.f;
             float4 ka[NT];
 #pragma unroll
             for (int i = 0; i < NT; ++i) ka[i] = jj < GP_KBW - 1 ? kx[i][jj < GP_KBW - 1 ? jj : 0] : *reinterpret_cast<const float4*>(kx4w + i * 256);
 #pragma unroll
-            for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].x, b[0], acc[i], 0, 0, 0);
+            for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].x, b0, acc[i], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].y, b[1], acc[i], 0, 0, 0);
+            for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].y, b1, acc[i], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].z, b[2], acc[i], 0, 0, 0);
+            for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].z, b2_, acc[i], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].w, b[3], acc[i], 0, 0, 0);
+            for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].w, b3, acc[i], 0, 0, 0);
           }
         }
         __builtin_amdgcn_s_setprio(0);
-        GPT(16 + r);
-        if (r == 0) {
+        if (t > 0 && !gp_wait(&S.cnt_h[r], 4u * (unsigned)t, dead)) return;       // the cells of step t-1 have read the tiles
 #pragma unroll
-          for (int i = 0; i < NT; ++i) *reinterpret_cast<f32x4*>(&S.xs[xw][i][lane][0]) = acc[i];
-        }
+        for (int i = 0; i < NT; ++i) *reinterpret_cast<f32x4*>(pbx + (i * NR + r) * 256) = acc[i];
+        gp_signal(&S.cnt_x[r][xw], lane);
       }
-      if (t > 0 && !gp_wait(&S.cnt_h, 4u * (unsigned)t, dead)) return;                   // the cell of step t-1 has read the tiles
-#pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        *reinterpret_cast<f32x4*>(&S.pb[xw][0][0][lane][0] + (i * NR + 0) * 256) = *reinterpret_cast<const f32x4*>(&S.xs[xw][i][lane][0]);
-        *reinterpret_cast<f32x4*>(&S.pb[xw][0][0][lane][0] + (i * NR + 1) * 256) = acc[i];
-      }
-      gp_signal(&S.cnt_x[xw], lane);
-      GPT(18);
-      GPT(19);
     }
 #ifdef GP_TRACE
-    if (xw == 0) { { const int i0_ = 8, i1_ = 12; GPT_FLUSH(); } { const int i0_ = 16, i1_ = 20; GPT_FLUSH(); } }
+    if (xw == 0) { const int i0_ = 18, i1_ = 22; GPT_FLUSH(); }
 #endif
     return;
   }
 
-  // =============================== G waves: reduce, publish, gather, stash ===============================
-  __builtin_amdgcn_s_setprio(1);                                       // (polls sleep between tries; the R waves' MFMA bursts run at 3)
-  const int gw = w - 8;
-  const bool reducer = c < nch;                                        // this workgroup sums chunk c = (k-block jbr, row tile rr)
-  const int jbr = c / NR, rr = c - jbr * NR;
-  const int lenr = rr ? len1 : len0;
-  const int ppw = (NC + 3) >> 2, pp0 = gw * ppw, pn = max(0, min(ppw, NC - pp0));   // this wave's producers [pp0, pp0 + pn), pn <= 10
-  f32x4 mcar = f32x4{0.f, 0.f, 0.f, 0.f};                              // carried state of chunk c (the stash's mst)
-  // the carried state of the chunks this wave gathers (ch = gw + 4 n) lives in mB itself: zero before step 0
-#pragma unroll
-  for (int n = 0; n < 9; ++n)
-    if (gw + 4 * n < nch) *reinterpret_cast<f32x4*>(&S.mB[gw & 1][gw >> 1][lane][0] + 2 * n * 256) = f32x4{0.f, 0.f, 0.f, 0.f};
-  // slot 0 of the carried states is zero (cell.zero_state)
-  if (gw >= 2) {
-    for (int e = (gw - 2) * 64 + lane; e < GP_ROWS * NT; e += 128) {
-      const int row = e / NT, cq = e - row * NT;
-      if (cell0 + 4 * cq < H) *reinterpret_cast<float4*>(L.c + (size_t)(row0 + row) * H + cell0 + 4 * cq) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  } else if (gw == 1 && reducer) {
-    if (16 * jbr + 4 * q < ldP) *reinterpret_cast<float4*>(L.mst + (size_t)(row0 + 16 * rr + lr) * ldP + 16 * jbr + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  // =============================== G waves: project, publish, reduce, gather (tile gw & 1) ===============================
+  __builtin_amdgcn_s_setprio(3);                                       // the hand-off is the critical path and these waves issue little (their polls sleep); R bursts run at 2, X bursts at 1
+  const int gw = w - 8, r = gw & 1, gp = gw >> 1;                      // this wave's tile, and which of the tile's two G waves it is
+  const int lenr = r ? len1 : len0;
   // The partial projection of this slice's cells and its publication run HERE, not on the R waves: whatever vector-memory access
-  // follows the write-through granule stores in a wave's queue waits for their acknowledgement (vmcnt retires in order) -- the R waves
-  // touch no global memory at all.  Chunk ch = gw + 4 n = (k-block (gw >> 1) + 2 n of P, row tile gw & 1):
+  // follows the write-through granule stores in a wave's queue waits for their acknowledgement (vmcnt retires in order).
+  // Chunk n of this wave = k-block gp + 2 n of P, tile r:
   // m^T[col 16 jb + 4 q + i][row 16 r + lr] = sum_k W_p[cell k][col] h[row][cell k]   (k-blocks beyond P hold zero weights)
-  const float* const wpw = &S.wp[gw >> 1][0][lane];                    // + (2 n * NT + ks) * 64
-  const int rowp = 16 * (gw & 1) + lr;
+  const float* const wpw = &S.wp[gp][0][lane];                         // + (2 n * NT + ks) * 64
+  const float* const sth = &S.st[5][16 * r + lr][q];                   // + 4 ks
+  float* const mbg = &S.mB[r][gp][lane][0];                            // + 2 n * 256
+  const int nvg = (nkb - gp + 1) >> 1;                                 // this wave's k-blocks: gp, gp + 2, ...
+  // this workgroup REDUCES the 8-column half (k-block jbr, half hh) of both tiles; this wave: tile r, producers [pp0, pp0 + pn)
+  const bool reducer = c < 2 * nkb;
+  const int jbr = c >> 1, hh = c & 1;
+  const int ppw = (NC + 1) >> 1, pp0 = gp * ppw, pn = max(0, min(ppw, NC - pp0));
+  // reducer lane L holds the two values {2 j, 2 j + 1} (j = L >> 5) of fragment lane pl = 32 hh + (L & 31): row pl & 15, cols 4 (pl >> 4) + 2 j
+  const int rrow = row0 + 16 * r + ((32 * hh + (lane & 31)) & 15), rcol = 16 * jbr + 4 * ((32 * hh + (lane & 31)) >> 4) + 2 * (lane >> 5);
+  const int rlen = a.len[rrow];
+  float mcar0 = 0.f, mcar1 = 0.f;                                      // carried state of the reducer's two columns (the stash's mst)
+  // slot 0 of the carried states is zero (cell.zero_state)
+  for (int e = gw * 64 + lane; e < GP_ROWS * NT; e += 256) {
+    const int row = e / NT, cq = e - row * NT;
+    if (cell0 + 4 * cq < H) *reinterpret_cast<float4*>(L.c + (size_t)(row0 + row) * H + cell0 + 4 * cq) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (reducer && gp == 1 && rcol < ldP) *reinterpret_cast<float2*>(L.mst + (size_t)rrow * ldP + rcol) = make_float2(0.f, 0.f);
   for (int t = 0; t < T; ++t) {
     const int par = t & 1;
-    f32x4 total = f32x4{0.f, 0.f, 0.f, 0.f};
-    GPT(6);
-    if (!gp_wait(&S.cnt_h, 4u * ((unsigned)t + 1u), dead)) return;     // the cells of step t: h is in LDS
-    GPT(7);
+    GPT(12);
+    if (!gp_wait(&S.cnt_h[r], 4u * ((unsigned)t + 1u), dead)) return;  // the cells of step t, tile r: h is in LDS
+    GPT(13);
     {
-      const float* const sth = &S.st[5][rowp][q];                      // + 4 ks
       float hv[NT];
 #pragma unroll
       for (int ks = 0; ks < NT; ++ks) hv[ks] = sth[4 * ks];
       const unsigned tagp = tagbase | ((unsigned)t + 1u);
-      const unsigned pub0 = (unsigned)(((size_t)par * GP_NCH + gw) * NC + c) * GP_SLOT;
-      __builtin_amdgcn_s_setprio(3);
+      const unsigned pub0 = slot1(par, r, gp, c) + frag_off;
       // three chunks in flight (the dependent-accumulator latency of the 16x16x4 form is 40 cycles for a 32-cycle issue); a chunk
       // leaves as soon as its NT products are done, so the write-through stores overlap the remaining MFMAs
 #pragma unroll
@@ -505,73 +507,65 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigne
           for (int j = 0; j < 3; ++j) pm[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpw[(2 * (n0 + j) * NT + ks) * 64], hv[ks], pm[j], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-          if (gw + 4 * (n0 + j) < nch) gp_publish(b1, pub0 + (unsigned)(4 * (n0 + j)) * (unsigned)NC * GP_SLOT, lane, tagp, pm[j]);
+          if (n0 + j < nvg) {
+            const unsigned o = pub0 + (unsigned)(2 * (n0 + j)) * (unsigned)NC * GP_SLOT;
+            gp_store(b1, o, tagp, pm[j][0], pm[j][1]);
+            gp_store(b1, o + 512u, tagp, pm[j][2], pm[j][3]);
+          }
       }
-      __builtin_amdgcn_s_setprio(1);
     }
-    GPT(12);
+    GPT(14);
+    float tot0 = 0.f, tot1 = 0.f;
     if (reducer) {
-      // hop 1: the NC partial projections of chunk c, summed in slice order
+      // hop 1: the NC partial projections of this half chunk, tile r, summed in slice order (this wave: its half of the slices)
       const unsigned tag1 = tagbase | ((unsigned)t + 1u);
-      unsigned off[10];
+      unsigned lo[20];
 #pragma unroll
-      for (int k = 0; k < 10; ++k) off[k] = (unsigned)(((size_t)par * GP_NCH + c) * NC + min(pp0 + k, NC - 1)) * GP_SLOT;
-      f32x4 pv[10];
-      if (!gp_sweep<10, true>(b1, off, pn, lane, tag1, pv, err)) { fail(); return; }
-      GPT(13);
-      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int k = 0; k < 10; ++k)
-        if (k < pn) s = k == 0 ? pv[0] : s + pv[k];
-      *reinterpret_cast<f32x4*>(&S.gs[par][gw][lane][0]) = s;
-      gp_signal(&S.cnt_g, lane);
-      if (!gp_wait(&S.cnt_g, 4u * ((unsigned)t + 1u), dead)) return;
-      const f32x4 s0 = *reinterpret_cast<const f32x4*>(&S.gs[par][0][lane][0]), s1 = *reinterpret_cast<const f32x4*>(&S.gs[par][1][lane][0]);
-      const f32x4 s2 = *reinterpret_cast<const f32x4*>(&S.gs[par][2][lane][0]), s3 = *reinterpret_cast<const f32x4*>(&S.gs[par][3][lane][0]);
-      total = ((s0 + s1) + s2) + s3;
-      // hop 2: chunk c of m(t)
-      if (gw == 0) gp_publish(b2, (unsigned)(((size_t)t * GP_NCH + c) * GP_SLOT), lane, gen, total);
-      GPT(14);
+      for (int k = 0; k < 20; ++k) lo[k] = slot1(par, r, jbr, min(pp0 + k, NC - 1)) + (unsigned)hh * 1024u;
+      float s0 = 0.f, s1 = 0.f;
+      if (!gp_sweep<20, true, 20, false>(b1, lo, pn, (unsigned)lane * 16u, slot1(par, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 1024u + 1008u, lane < pn, tag1, err,
+                                  [&](int k, float va, float vb) { if (k == 0) { s0 = va; s1 = vb; } else if (k < pn) { s0 += va; s1 += vb; } })) { fail(); return; }
+      GPT(15);
+      *reinterpret_cast<float2*>(&S.gs[r][gp][lane][0]) = make_float2(s0, s1);
+      gp_signal(&S.cnt_g[r], lane);
+      if (!gp_wait(&S.cnt_g[r], 2u * ((unsigned)t + 1u), dead)) return;
+      const float2 g0 = *reinterpret_cast<const float2*>(&S.gs[r][0][lane][0]), g1 = *reinterpret_cast<const float2*>(&S.gs[r][1][lane][0]);
+      tot0 = g0.x + g1.x; tot1 = g0.y + g1.y;
+      // hop 2: this half chunk of m(t), tile r
+      if (gp == 0) gp_store(b2, slot2(t, r, jbr) + (unsigned)hh * 1024u + (unsigned)lane * 16u, gen, tot0, tot1);
+      GPT(16);
     }
     if (t + 1 < T) {
-      // gather m(t) of this layer for the recurrent product of step t+1: chunks gw, gw + 4, ...; dynamic_rnn carries the state of a
-      // finished row through unchanged
-      unsigned off[9];
-      int ns = 0;
+      // gather m(t) of the tile for the recurrent product of step t+1: k-blocks gp, gp + 2, ... as B fragments; dynamic_rnn carries the
+      // state of a finished row through unchanged (the carried state lives in mB itself)
+      unsigned lo[18];
 #pragma unroll
       for (int n = 0; n < 9; ++n) {
-        const int ch = gw + 4 * n;
-        off[n] = (unsigned)(((size_t)t * GP_NCH + min(ch, nch - 1)) * GP_SLOT);
-        ns += ch < nch ? 1 : 0;
+        const unsigned o = slot2(t, r, min(gp + 2 * n, nkb - 1));
+        lo[2 * n] = o; lo[2 * n + 1] = o + 512u;
       }
-      f32x4 mv[9];
-      if (!gp_sweep<9, true>(b2, off, ns, lane, gen, mv, err)) { fail(); return; }
-      GPT(15);
-#pragma unroll
-      for (int n = 0; n < 9; ++n) {
-        const int ch = gw + 4 * n;
-        if (ch < nch) {
-          const bool live = t < ((ch & 1) ? len1 : len0);
-          if (live) *reinterpret_cast<f32x4*>(&S.mB[gw & 1][gw >> 1][lane][0] + 2 * n * 256) = mv[n];
-        }
-      }
-      gp_signal(&S.cnt_m, lane);
-    }
-    // the step's stash, behind the hand-offs (plain stores: this wave's next poll waits for their acknowledgement, which comes
-    // long before its peers' granules)
-    if (gw == 1 && reducer) {
+      float mv[18][2];
+      if (!gp_sweep<18, true, 18, true>(b2, lo, 2 * nvg, frag_off, slot2(t, r, min(gp + 2 * (lane >> 1), nkb - 1)) + (unsigned)(lane & 1) * 1024u + 1008u,
+                                  lane < 2 * nvg, gen, err, [&](int k, float va, float vb) { mv[k][0] = va; mv[k][1] = vb; })) { fail(); return; }
+      GPT(17);
       const bool live = t < lenr;
-      mcar = live ? total : mcar;
-      const f32x4 o = live ? total : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (16 * jbr + 4 * q < ldP) {
-        const size_t rowg = (size_t)row0 + 16 * rr + lr;
-        *reinterpret_cast<f32x4*>(L.mst + ((size_t)(t + 1) * N + rowg) * ldP + 16 * jbr + 4 * q) = mcar;
-        *reinterpret_cast<f32x4*>(L.out + ((size_t)t * N + rowg) * ldP + 16 * jbr + 4 * q) = o;
+#pragma unroll
+      for (int n = 0; n < 9; ++n)
+        if (n < nvg && live) *reinterpret_cast<f32x4*>(mbg + 2 * n * 256) = f32x4{mv[2 * n][0], mv[2 * n][1], mv[2 * n + 1][0], mv[2 * n + 1][1]};
+      gp_signal(&S.cnt_m[r], lane);
+    }
+    // the reducer's two columns of the stash (carried state, masked output), behind the hand-offs
+    if (reducer && gp == 1) {
+      const bool live = t < rlen;
+      mcar0 = live ? tot0 : mcar0; mcar1 = live ? tot1 : mcar1;
+      if (rcol < ldP) {
+        *reinterpret_cast<float2*>(L.mst + ((size_t)(t + 1) * N + rrow) * ldP + rcol) = make_float2(mcar0, mcar1);
+        *reinterpret_cast<float2*>(L.out + ((size_t)t * N + rrow) * ldP + rcol) = make_float2(live ? tot0 : 0.f, live ? tot1 : 0.f);
       }
     }
   }
 #ifdef GP_TRACE
-  if (gw == 0) { { const int i0_ = 6, i1_ = 8; GPT_FLUSH(); } { const int i0_ = 12, i1_ = 16; GPT_FLUSH(); } }
+  if (gw == 0) { const int i0_ = 12, i1_ = 18; GPT_FLUSH(); }
 #endif
 }
 
@@ -609,7 +603,7 @@ bool gpersist_plan(GPersistArgs& a) {
     const GPersistLayer& L = a.L[l];
     if (L.P < 4 || L.P > 16 * GP_NKB || L.P % 4 != 0 || L.ldP % 4 != 0 || L.I > 16 * GP_NKB || L.ldH % 4 != 0) return false;
     if (l > 0 && L.I != a.L[l - 1].P) return false;
-    if (((L.P + 15) / 16) * GP_NR > a.NC) return false;            // every chunk needs its reducer
+    if (((L.P + 15) / 16) * 2 > a.NC) return false;                // every 8-column half of a chunk needs its reducer
     if (a.NC > 40) return false;                                    // a G wave sums at most 10 producers
   }
   // every workgroup must be resident at once (they wait for each other): one 12-wave workgroup per CU

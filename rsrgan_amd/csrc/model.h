@@ -156,7 +156,7 @@ struct Model {
   unsigned long long *gp_gran1 = nullptr, *gp_gran2 = nullptr;
   unsigned* gp_ctl = nullptr;
   size_t gp_gran2_bytes = 0;
-  int gp_env = 0;
+  int gp_env = 1;                                         // RSRGAN_GPERSIST: bit 0 the forward launch (0: the launch-per-phase wavefront)
   bool gpersist_args(GPersistArgs& a, int T) const;       // false: not applicable
   bool persist_forward_g(int T, hipStream_t s);           // layer 0's x-part batched first; fills the complete stash of every layer
   // fully-connected stacks: models/dnn.py generator and models/discriminator_dnn.py discriminator

@@ -56,41 +56,41 @@ int main(int argc, char** argv) {
   unsigned ctl[4]; CK(hipMemcpy(ctl, a.ctl, 16, hipMemcpyDeviceToHost));
   printf("k_glstm_fwd N=%d T=%d layers=%d (NT=%d NC=%d, %zu + %zu MB of granule slots): %.1f us per launch = %.2f us per step (err word %u, generation %u)\n",
          N, T, nl, a.NT, a.NC, g1 >> 20, g2 >> 20, best * 1e3f, best * 1e3f / T, ctl[2], ctl[0]);
+  { unsigned cn[8]; CK(hipMemcpyFromSymbol(cn, HIP_SYMBOL(rsr::g_gp_cnt), sizeof(cn)));
+    printf("first full reads (5 launches): through the caches %u, of them failed %u; write-through %u, failed %u\n", cn[0], cn[1], cn[2], cn[3]); }
   static unsigned tr[256][24][24];
   CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(rsr::g_gp_trace), sizeof(tr)));
-  // R wave 0 stamps: 0 top, 1 x-part there, 2 m(t-1) there, 3 recurrent MFMAs + tiles written, 4 all partials there, 5 cell done
-  // G wave 0: 6 top, 7 all cells done, 12 projection + publish issued, 13 hop 1 swept, 14 chunk published, 15 hop 2 swept; X wave 0: 8 / 10 sweep
-  // start (row tile 0 / 1), 9 / 11 sweep done
-  const char* rn[5] = {"wait: x-part of the step (X waves)", "wait: m(t-1) gathered (hop 2)", "recurrent MFMAs (2 row tiles) + tiles -> LDS",
-                       "wait: the other R waves' partials", "cell"};
+  // R wave 0, tile r (stamps 6 r + ..): 0 top, 1 x-part there, 2 m(t-1) there, 3 recurrent MFMAs + tiles written, 4 all partials there, 5 cell done
+  // G wave 0 (tile 0): 12 top, 13 all cells done, 14 projection + publish issued, 15 hop 1 swept, 16 half chunk published, 17 hop 2 swept
+  // X wave 0: 18 / 20 sweep start (tile 0 / 1), 19 / 21 sweep done; 22, 23: prologue
+  const char* rn[5] = {"wait: x-part of the step (X waves)", "wait: m(t-1) gathered (hop 2)", "recurrent MFMAs + tiles -> LDS",
+                       "wait: the other R waves' partials (+ stash gone)", "cell"};
   const int ngr = N / 32, xpg = 8 / ngr, nblk = 8 * ((nl * a.NC + xpg - 1) / xpg);
   for (int l = 0; l < nl; ++l) {
-    double ph[5] = {0}, per = 0, gx[6] = {0}, xs[8] = {0}, pro = 0; long cnt = 0, nb_ = 0;
+    double ph[2][5] = {{0}}, per = 0, gx[6] = {0}, xs[2] = {0}, pro = 0, lag = 0; long cnt = 0, nb_ = 0;
     for (int b = 0; b < nblk && b < 256; ++b) {
       const int xcd = b & 7, slot = b >> 3, idx = slot * xpg + (xcd % xpg);
-      if (idx >= nl * a.NC || idx / a.NC != l || idx % a.NC >= 2 * ((P + 15) / 16)) continue;     // (reducers only: the others skip stamps 13, 14)
-      pro += (double)(unsigned)(tr[b][0][20] - tr[b][0][21]); ++nb_;
+      if (idx >= nl * a.NC || idx / a.NC != l || idx % a.NC >= 2 * ((P + 15) / 16)) continue;     // (reducers only: the others skip stamps 15, 16)
+      pro += (double)(unsigned)(tr[b][0][22] - tr[b][0][23]); ++nb_;
       for (int t = 10; t < T - 1 && t < 23; ++t) {
-        for (int i = 0; i < 5; ++i) ph[i] += (double)(unsigned)(tr[b][t][i + 1] - tr[b][t][i]);
+        for (int r = 0; r < 2; ++r)
+          for (int i = 0; i < 5; ++i) ph[r][i] += (double)(unsigned)(tr[b][t][6 * r + i + 1] - tr[b][t][6 * r + i]);
         per += (double)(unsigned)(tr[b][t + 1][0] - tr[b][t][0]);
-        gx[0] += (double)(unsigned)(tr[b][t][7] - tr[b][t][6]); gx[1] += (double)(unsigned)(tr[b][t][12] - tr[b][t][7]);
-        gx[2] += (double)(unsigned)(tr[b][t][13] - tr[b][t][12]); gx[3] += (double)(unsigned)(tr[b][t][14] - tr[b][t][13]);
-        gx[4] += (double)(unsigned)(tr[b][t][15] - tr[b][t][14]); gx[5] += (double)(unsigned)(tr[b][t + 1][2] - tr[b][t][5]);
-        xs[0] += (double)(unsigned)(tr[b][t][9] - tr[b][t][8]); xs[1] += (double)(unsigned)(tr[b][t][16] - tr[b][t][9]);
-        xs[2] += 0; xs[3] += (double)(unsigned)(tr[b][t][11] - tr[b][t][10]);
-        xs[4] += (double)(unsigned)(tr[b][t][17] - tr[b][t][11]); xs[5] += (double)(unsigned)(tr[b][t][18] - tr[b][t][17]);
-        xs[6] += (double)(unsigned)(tr[b][t][19] - tr[b][t][18]); xs[7] += (double)(unsigned)(tr[b][t + 1][8] - tr[b][t][8]);
+        lag += (double)(unsigned)(tr[b][t][6] - tr[b][t][0]);
+        gx[0] += (double)(unsigned)(tr[b][t][13] - tr[b][t][12]); gx[1] += (double)(unsigned)(tr[b][t][14] - tr[b][t][13]);
+        gx[2] += (double)(unsigned)(tr[b][t][15] - tr[b][t][14]); gx[3] += (double)(unsigned)(tr[b][t][16] - tr[b][t][15]);
+        gx[4] += (double)(unsigned)(tr[b][t][17] - tr[b][t][16]); gx[5] += (double)(unsigned)(tr[b][t + 1][2] - tr[b][t][5]);
+        xs[0] += (double)(unsigned)(tr[b][t][19] - tr[b][t][18]); xs[1] += (double)(unsigned)(tr[b][t][21] - tr[b][t][20]);
         ++cnt;
       }
     }
     if (!cnt) continue;
-    printf("layer %d, shader-clock cycles (s_memtime), mean over workgroups and steps 10..%d: period %.0f\n", l, T - 2 < 22 ? T - 2 : 22, per / cnt);
-    for (int i = 0; i < 5; ++i) printf("   R0 %-48s %6.0f\n", rn[i], ph[i] / cnt);
-    printf("   G0 wait for the cells %.0f | projection + publish (issue) %.0f | hop-1 sweep %.0f | reduce + publish chunk %.0f | hop-2 sweep %.0f\n",
+    printf("layer %d, shader-clock cycles (s_memtime), mean over reducer workgroups and steps 10..%d: period %.0f (tile 1 enters %.0f behind tile 0)\n", l, T - 2 < 22 ? T - 2 : 22, per / cnt, lag / cnt);
+    for (int i = 0; i < 5; ++i) printf("   R0 %-52s tile 0 %6.0f   tile 1 %6.0f\n", rn[i], ph[0][i] / cnt, ph[1][i] / cnt);
+    printf("   G0 (tile 0) wait for the cells %.0f | projection + publish (issue) %.0f | hop-1 sweep %.0f | reduce + publish half chunk %.0f | hop-2 sweep %.0f\n",
            gx[0] / cnt, gx[1] / cnt, gx[2] / cnt, gx[3] / cnt, gx[4] / cnt);
-    printf("   cell(t) done on R0 -> m(t) in LDS (the whole hand-off): %.0f\n", gx[5] / cnt);
-    if (l > 0) printf("   X0 period %.0f: sweep r0 %.0f | MFMAs r0 %.0f | (%.0f) | sweep r1 %.0f | MFMAs r1 %.0f | wait cells(t-1) + tiles + signal %.0f | stash(t-1) %.0f\n",
-                      xs[7] / cnt, xs[0] / cnt, xs[1] / cnt, xs[2] / cnt, xs[3] / cnt, xs[4] / cnt, xs[5] / cnt, xs[6] / cnt);
+    printf("   tile 0: cell(t) done on R0 -> m(t) in LDS (the whole hand-off): %.0f\n", gx[5] / cnt);
+    if (l > 0) printf("   X0 sweep of x(t), tile 0 / 1: %.0f / %.0f\n", xs[0] / cnt, xs[1] / cnt);
     printf("   prologue (kernel entry -> R0 enters step 0): %.0f cycles\n", pro / nb_);
   }
   return 0;
