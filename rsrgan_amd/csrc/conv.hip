@@ -1059,7 +1059,7 @@ static void wgrad4_plan(int C, int R, int S, int nstrips, int fw, int& DH, int& 
   wgrad_plan(R, S, nstrips, nkg <= 4 ? std::min(KP, 256) : KP, DH, fpg, groups);
   nwv = wgrad4_waves(64 * nkg, DH, PS);
 }
-size_t conv_wgrad_ws_floats(int C, int R, int S, int W, int fw) {
+static size_t conv_wgrad_ws_floats_at(int C, int R, int S, int W, int fw) {
   const int TW = wgrad_tw(S, W), nstrips = (W + TW - 1) / TW;
   int DH, fpg, groups, nkg, PS, nwv;
   wgrad_plan(R, S, nstrips, conv_kp(fw, C), DH, fpg, groups);
@@ -1068,6 +1068,13 @@ size_t conv_wgrad_ws_floats(int C, int R, int S, int W, int fw) {
   wgrad4_plan(C, R, S, nstrips, fw, DH, fpg, groups, nkg, PS, nwv);
   const size_t b = (size_t)groups * nstrips * ((size_t)PS * S * conv_kp(fw, C) + 1) * 32;
   return std::max(a, b);
+}
+// The work space for up to R frames.  The planners' group count is NOT monotonic in the frame count (groups = ceil(R / ceil(R / gmax)):
+// 57 frames at gmax = 28 make 19 groups, 28 frames make 28), and the C ABI accepts any T <= max_frames: size it for the worst R' <= R.
+size_t conv_wgrad_ws_floats(int C, int R, int S, int W, int fw) {
+  size_t need = 0;
+  for (int r = 1; r <= R; ++r) need = std::max(need, conv_wgrad_ws_floats_at(C, r, S, W, fw));
+  return need;
 }
 bool conv_wgrad_supported(int C, int N, int S, int W, int fw) {
   if (!conv_fwd_supported(C, N, S, W, fw)) return false;

@@ -129,9 +129,11 @@ class GAN(Model):
         return n
 
     def _summary_fetch(self, inputs, labels, lengths=None):
-        d = self.d_step(inputs, labels, train=False)
-        g = self.g_step(inputs, labels, train=False)
-        return d, g, self.forward(inputs)
+        """collective-free (only the writer's rank calls it): the engine directly, on the batch this rank drew"""
+        x, lab = self._frames(inputs), self._frames(labels)
+        d = self.engine.d_backward(x, lab, None, train=False, apply=False)
+        g = self.engine.g_backward(x, lab, None, train=False, reuse=False, apply=False)
+        return d, g, inputs, labels, self.forward(inputs)
 
     def forward(self, inputs):
         """sess.run(model.generator outputs): enhanced MFCC frames [N, output_dim]."""

@@ -70,9 +70,13 @@ class Model(object):
         the fed batch (fetched without the *_opt ops) + histograms of the batch and of the generator's output, serialised as a
         Summary for writer.add_summary."""
         from .summary import model_summaries
-        d, g, y = self._summary_fetch(inputs, labels, lengths)
+        # Only the rank that owns the writer (rank 0) gets here, so the fetch must not contain a collective: _summary_fetch works
+        # on this rank's shard of the fed batch and calls the engine directly (d_step / g_step gather the towers' losses, and the
+        # other ranks are already in their next gradient all-reduce).  The summary describes tower 0, as the reference's
+        # tf.summary ops do (gan_rnn_placeholder.py:219-223 are built in tower 0's name scope).
+        d, g, x, lab, y = self._summary_fetch(inputs, labels, lengths)
         host = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-        return model_summaries([float(np.mean(v)) for v in list(d) + list(g)], host(inputs), host(labels), host(y))
+        return model_summaries([float(v) for v in list(host(d).reshape(-1)) + list(host(g).reshape(-1))], host(x), host(lab), host(y))
 
     def save(self, save_dir, step):
         """rank 0 writes; every rank returns once the checkpoint exists (or raises if rank 0 could not write it)"""
@@ -333,9 +337,13 @@ class GAN_RNN(Model):
         return list(tw[:, 0]), list(tw[:, 1]), list(tw[:, 2]), list(tw[:, 3])
 
     def _summary_fetch(self, inputs, labels, lengths):
-        d = self.d_step(inputs, labels, lengths, train=False)
-        g = self.g_step(inputs, labels, lengths, train=False)
-        return d, g, self.forward(inputs, lengths)
+        """the 3 + 4 losses and G(x) of THIS rank's rows, without the *_opt ops and without any collective"""
+        x, lab, ln = self._shard(inputs), self._shard(labels), self._shard(lengths)
+        with self.on_stream():
+            d = self.engine.d_backward(x, lab, ln, self._draw_noise(), self._draw_noise(), train=False, apply=False)
+            g = self.engine.g_backward(x, lab, ln, self._draw_noise(), train=False, reuse=False, apply=False)
+            y = self.engine.forward_g(x, ln)
+        return d, g, x, lab, y
 
     def forward(self, inputs, lengths):
         """sess.run(model.g_outputs, {inputs, lengths}) (train_gan_rnn_placeholder.py:282-285)."""

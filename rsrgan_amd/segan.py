@@ -68,7 +68,8 @@ class SEGAN(object):
         self.code_len = self.input_len
         for _ in depths:
             self.code_len = (self.code_len + 1) // 2
-        self.group, self.world = process_group, (rdist.world_size(process_group) if process_group is not None else 1)
+        # (process_group=None under torchrun = the default group, as in GAN / GAN_RNN: the towers' gradients are averaged)
+        self.group, self.world = process_group, rdist.world_size(process_group)
         self.set_scalar("g_learning_rate", float(getattr(args, "g_learning_rate", 1e-3)))
         self.set_scalar("d_learning_rate", float(getattr(args, "d_learning_rate", 1e-3)))
         self.set_scalar("l1_lambda", float(getattr(args, "init_l1_weight", 100.0)))
@@ -212,15 +213,19 @@ class SEGAN(object):
 
     # ---- tf.train.Saver (segan.py:26-54): variables + RMSProp slots
     def save(self, save_dir, step):
+        """rank 0 writes; every rank returns once the checkpoint exists (or raises if rank 0 could not write it)"""
         os.makedirs(save_dir, exist_ok=True)
-        if rdist.rank(self.group) != 0:
-            return
+        return rdist.run_on_rank0(lambda: self._save_rank0(save_dir, step), self.group)
+
+    def _save_rank0(self, save_dir, step):
         g, d = self.get_vars(0)
         gm, dm = self.get_vars(1)
-        path = os.path.join(save_dir, "%s-%d.npz" % (self.name, step))
+        base = "%s-%d" % (self.name, int(step))
+        path = os.path.join(save_dir, base + ".npz")
         np.savez(path, **{"v/" + k: v for k, v in {**g, **d}.items()}, **{"rms/" + k: v for k, v in {**gm, **dm}.items()})
-        with open(os.path.join(save_dir, "checkpoint"), "w") as f:
-            f.write(os.path.basename(path) + "\n")
+        with open(os.path.join(save_dir, "checkpoint"), "w") as f:          # the state file of Model.save (gan_rnn.py)
+            f.write('model_checkpoint_path: "%s"\n' % base)
+        return path
 
     def load(self, save_dir, model_file=None):
         if not save_dir or not os.path.exists(save_dir):
@@ -230,7 +235,11 @@ class SEGAN(object):
             ck = os.path.join(save_dir, "checkpoint")
             if not os.path.exists(ck):
                 return False
-            model_file = open(ck).read().strip()
+            with open(ck) as f:
+                line = f.readline().strip()
+            model_file = line.split('"')[1] if '"' in line else line        # (a bare file name: checkpoints written before round 4)
+        if not model_file.endswith(".npz"):
+            model_file += ".npz"
         data = np.load(os.path.join(save_dir, model_file))
         for what, pre in ((0, "v/"), (1, "rms/")):
             g = {nm: data[pre + nm] for nm, _, _ in self.tensor_table(NET_G)}

@@ -66,6 +66,87 @@ def test_two_rank_gloo_equals_two_tower_oracle(bucketed):
     assert np.array_equal(out[0][1], out[1][1])                     # replicas stay bit-identical
 
 
+def _summary_worker(rank, world, port, out, save_dir):
+    """train_one_iteration + eval_one_iteration with a TensorBoard writer on rank 0 (save_dir set): the summary fetch runs on rank 0
+    alone, so it must not contain a collective -- the other rank is already in the next step's gradient all-reduce."""
+    import datetime
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        from rsrgan_amd import GAN_RNN, eval_one_iteration, train_one_iteration
+        cfg = small_cfg()
+        B, T = 2, 5
+        g, d = rand_params(cfg, 5)
+        m = GAN_RNN(None, args_for(cfg, B, num_gpu=world, save_dir=save_dir), ["cpu:%d" % rank], engine=OracleEngine(cfg, g, d, B))
+        assert (m.writer is not None) == (rank == 0)
+        batches = [rand_batch(cfg, B * world, T, 60 + i, ragged=True) for i in range(3)]
+        q = [[None] + list(b) for b in batches]
+        res = train_one_iteration(None, m, len(batches) * world, 0, q)          # batch 0 is summarised (batch % 100 == 0)
+        ev = eval_one_iteration(None, m, len(batches) * world, 0, q)            # the last fed (global) batch is summarised
+        m.save(save_dir, 1)
+        flat = np.concatenate([m.engine.o.g[n].reshape(-1) for n, _ in O.g_param_specs(cfg)])
+        out[rank] = (res, ev, flat)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_summaries_do_not_break_multi_rank_training(tmp_path):
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_summary_worker, args=(world, _free_port(), out, str(tmp_path)), nprocs=world, join=True)
+    assert np.allclose(out[0][0], out[1][0]) and np.allclose(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2])                     # the replicas stayed in step
+    ev = [f for sub in ("train", "eval") for f in os.listdir(os.path.join(str(tmp_path), sub))]
+    assert len(ev) == 2 and all(f.startswith("events.out.tfevents") for f in ev), ev
+
+
+def _world8_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        from rsrgan_amd import GAN_RNN, train_one_iteration
+        cfg = small_cfg()
+        B, T = 1, 4
+        g, d = rand_params(cfg, 5)
+        m = GAN_RNN(None, args_for(cfg, B, num_gpu=world, g_learning_rate=8e-5 * world, d_learning_rate=1e-3 * world),
+                    ["cpu:%d" % rank], engine=OracleEngine(cfg, g, d, B))
+        m.engine.bucketed = True
+        batches = [rand_batch(cfg, B * world, T, 80 + i, ragged=True) for i in range(2)]
+        res = train_one_iteration(None, m, len(batches) * world, 0, [[None] + list(b) for b in batches])
+        flat = np.concatenate([m.engine.o.g[n].reshape(-1) for n, _ in O.g_param_specs(cfg)] +
+                              [m.engine.o.d[n].reshape(-1) for n, _ in O.d_param_specs(cfg)])
+        out[rank] = (res, flat)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_equals_eight_tower_oracle():
+    """The 8-GPU half of BASELINE.json configs[2] on CPU: 8 ranks, the bucketed all-reduce path, ragged shards (one utterance per rank),
+    lr x 8 (train...py:458-459) == the oracle run as 8 in-graph towers (utils/ops.py:343-376, gan_rnn_placeholder.py:157-184)."""
+    world = 8
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_world8_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    cfg = small_cfg()
+    B, T = 1, 4
+    g, d = rand_params(cfg, 5)
+    ref = O.GanRnnOracle(cfg, g, d, batch_size=B, num_towers=world,
+                         g_learning_rate=float(np.float32(8e-5 * world)), d_learning_rate=float(np.float32(1e-3 * world)))
+    batches = [rand_batch(cfg, B * world, T, 80 + i, ragged=True) for i in range(2)]
+    want = O.train_one_iteration(ref, batches, 1, 1)
+    want_flat = np.concatenate([ref.g[n].reshape(-1) for n, _ in O.g_param_specs(cfg)] +
+                               [ref.d[n].reshape(-1) for n, _ in O.d_param_specs(cfg)])
+    for r in range(world):
+        res, flat = out[r]
+        assert np.allclose(res, want, rtol=1e-6), (r, res, want)
+        assert np.allclose(flat, want_flat, rtol=1e-9, atol=1e-12), r
+        assert np.array_equal(flat, out[0][1])                      # replicas stay bit-identical
+
+
 def _rank0_worker(rank, world, port, out, fail):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
