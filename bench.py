@@ -211,11 +211,13 @@ def measure_sequence(a, net, d_type, B, T, steps, warmup, rank, local, world, de
         if not np.all(np.isfinite(losses)):
             raise SystemExit("non-finite losses: %s" % losses)
         # one more (untimed) step with every launch of the dominant kernel bracketed by HIP events on its stream
-        prof = (0, 0.0, 0.0)
+        prof = ("k_fwd_gates", 0, 0.0, 0.0)
         if not a.no_kernel_timing:
             model.engine.profile_begin()
             step()
-            prof = model.engine.profile_read()
+            prof_gp = model.engine.profile_read_kind(1)            # k_glstm_fwd: the persistent generator recurrence (csrc/gpersist.hip)
+            prof = model.engine.profile_read()                    # k_fwd_gates launches of the same step
+            prof = ("k_glstm_fwd",) + tuple(prof_gp) if prof_gp[1] > prof[1] else ("k_fwd_gates",) + tuple(prof)
             # (the floor chain is skipped under rocprofv3: 800 extra launches would distort the committed kernel statistics)
             under_prof = any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ)
             chain = (model.engine.profile_launches(), model.engine.launch_floor(400, 0), model.engine.launch_floor(400, 1)) if not under_prof else None
@@ -340,15 +342,25 @@ def bench_rced(a, rank, local, world, dev):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt, dev_ms = float(t[0]), float(t[1])
     if rank == 0:
-        num, wid, cin, fl = (12, 16, 20, 24, 32, 24, 20, 16, 12), (13, 11, 9, 7, 7, 7, 9, 11, 13), 1, 0
+        # Algorithmic FLOP per frame, two conventions.  VALID TAPS (the roofline fraction): a SAME convolution only multiplies the
+        # taps that meet data -- output row h meets S - |h - (S-1)/2| of the S filter rows (91 of 121 at S = 11), output column w
+        # meets the fw taps minus those beyond the frame edge (fw W - pl (pl + 1) summed over w, pl = (fw - 1) / 2) -- and the
+        # kernels skip the rest (conv.hip:143-151).  INCLUDING PADDING: 2 S W (S fw Cin) Cout per layer, every tap of every position
+        # (what round 3 printed as the only figure).
+        num, wid, cin, fl, flp = (12, 16, 20, 24, 32, 24, 20, 16, 12), (13, 11, 9, 7, 7, 7, 9, 11, 13), 1, 0, 0
+        rows_valid = sum(S - abs(h - (S - 1) // 2) for h in range(S))
         for co, fw in zip(num, wid):
-            fl += 2 * S * W * (S * fw * cin) * co          # per frame: positions x patch size x filters
+            pl = (fw - 1) // 2
+            fl += 2 * rows_valid * (fw * W - pl * (pl + 1)) * cin * co
+            flp += 2 * S * W * (S * fw * cin) * co
             cin = co
-        fl += 2 * S * W * cin * 40
-        fpf = 3 * fl                                      # forward + data gradient + weight gradient
-        if a.rced_gan:                                    # + the D-run's own generator forward, discriminator_dnn terms as SURVEY 8d
-            fpf += fl + 8 * 2 * ((W + 40) * 1024 + 3 * 1024 * 1024 + 1024)
+        fl += 2 * S * W * cin * 40; flp += 2 * S * W * cin * 40
+        extra = fl + 8 * 2 * ((W + 40) * 1024 + 3 * 1024 * 1024 + 1024) if a.rced_gan else 0     # the D-run's own generator forward + 8 F_D
+        extra_p = extra - fl + flp if a.rced_gan else 0
+        fpf = 3 * fl + extra                              # forward + data gradient + weight gradient
+        fpf_p = 3 * flp + extra_p
         ach = fpf * N / (dev_ms * 1e-3 / a.steps) / 1e12
+        ach_p = fpf_p * N / (dev_ms * 1e-3 / a.steps) / 1e12
         out = {"metric": ("GAN train frames/sec (G+D step), R-CED generator + discriminator_dnn (BASELINE configs[3])" if a.rced_gan
                           else "supervised train frames/sec, R-CED generator (SURVEY 8f-2)"), "value": round(N * world * a.steps / dt, 1),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt * 1e3 / a.steps, 4),
@@ -358,9 +370,10 @@ def bench_rced(a, rank, local, world, dev):
                           "global_batch": N * world, "parallelism": "dp%d" % world,
                           "losses_last_step": [round(float(v), 6) for v in last.mean(0).cpu().numpy()]},
                "roofline": {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                            "scope": "all launches of one step; algorithmic %d FLOP/frame (%s x %d conv + FC GEMM terms%s)" % (
-                                fpf, "4" if a.rced_gan else "3", fl, " + 8 F_D" if a.rced_gan else "")}}
+                            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "frac_incl_padding": round(ach_p / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                            "scope": "all launches of one step; algorithmic %d FLOP/frame on VALID taps (%s x %d conv + FC GEMM terms%s); "
+                                     "frac_incl_padding counts the zero-padding taps of the SAME convolutions too (%d FLOP/frame), which "
+                                     "the kernels skip" % (fpf, "4" if a.rced_gan else "3", fl, " + 8 F_D" if a.rced_gan else "", fpf_p)}}
         print(json.dumps(out), flush=True)
     stack.close()
     rdist.barrier()
@@ -519,7 +532,7 @@ def main():
         k_traffic = None
         k_rocprof_us = None
         headline = a.net == "lstm" and a.d_type == "lstm" and (B, T, a.gen_updates) == (64, 100, 1)
-        tf_path = os.path.join(ROOT, "profiles", "r3_final_traffic.json")
+        tf_path = os.path.join(ROOT, "profiles", "r4_final_traffic.json")
         if headline and os.path.exists(tf_path):
             # HBM-side bytes from the committed PMC passes of this workload (tools/traffic.sh: separate FETCH_SIZE / WRITE_SIZE
             # passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); refused when the kernels have changed
@@ -528,15 +541,15 @@ def main():
             rec = tj.get("ms_per_step")
             if rec and abs(rec - step_dev_s * 1e3) <= 0.10 * step_dev_s * 1e3:
                 traffic = tj.get("hbm_bytes_per_step")
-                f = [v for v in tj.get("top_fetch", []) if "k_fwd_gates" in v[0]]
-                w = [v for v in tj.get("top_write", []) if "k_fwd_gates" in v[0]]
+                f = [v for v in tj.get("top_fetch", []) if res["prof"][0] in v[0]]
+                w = [v for v in tj.get("top_write", []) if res["prof"][0] in v[0]]
                 if f and w and f[0][2] == w[0][2]:
                     k_traffic = int((2 * f[0][1] + w[0][1]) * 1024 / f[0][2])
-        cs_path = os.path.join(ROOT, "profiles", "r3_final_rocprofv3_kernel_stats.csv")
+        cs_path = os.path.join(ROOT, "profiles", "r4_final_rocprofv3_kernel_stats.csv")
         if headline and os.path.exists(cs_path):
             import csv
             for row in csv.DictReader(open(cs_path)):
-                if "k_fwd_gates" in row["Name"]:
+                if res["prof"][0] in row["Name"]:
                     k_rocprof_us = round(float(row["AverageNs"]) / 1e3, 3); break
         if fpf:
             ach = fpf * B * T / step_dev_s / 1e12          # per GPU, HIP-event time of the whole step's launches
@@ -544,7 +557,7 @@ def main():
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "scope": "all launches of one (1D+1G) step on one GPU; algorithmic %d FLOP/frame x %d frames "
                              "(SURVEY 8d: 3*F_G+8*F_D, F_G=%d, F_D=%d) / HIP-event step time; traffic = HBM-side bytes "
-                             "per step from profiles/r3_final_traffic.json (null when that file is stale)" % (fpf, B * T, fg, fd)}
+                             "per step from profiles/r4_final_traffic.json (null when that file is absent or stale)" % (fpf, B * T, fg, fd)}
             if res.get("hbm"):
                 roof["traffic_is"] = "L2 fabric requests of serialised cold-L2 dispatches incl. Infinity-Cache hits (PMC): an upper bound"
                 roof["hbm_activity"] = res["hbm"]
@@ -559,22 +572,25 @@ def main():
                                                 "in one (1D+1G) step x the measured cost of one launch in a replayed hipGraph of 400 dependent "
                                                 "256-workgroup launches that each read 1 KB per wave of their predecessor's output "
                                                 "(rsrgan_op_launch_floor mode 1; mode 0 = empty kernels = the boundary alone)"}
-            n_l, us_l, fl_l = res["prof"]
+            k_name, n_l, us_l, fl_l = res["prof"]
             if n_l:
                 # the step is GPU-bound (sum of rocprof kernel durations = wall, profiles/r2_gap_summary.txt), so the kernel's
                 # duration is what rocprofv3 reports; the live HIP-event bracket also contains the two event records and is
                 # an upper bound -- both are given, the roofline fraction uses the live one measured in THIS run
                 k_ach = fl_l / (us_l * 1e-6) / 1e12
                 roof["dominant_kernel"] = {
-                    "name": "k_fwd_gates", "launches_per_step": n_l, "avg_us": round(us_l / n_l, 3),
+                    "name": k_name, "launches_per_step": n_l, "avg_us": round(us_l / n_l, 3),
                     "rocprofv3_avg_us": k_rocprof_us,
                     "algorithmic_flop_per_launch": round(fl_l / n_l), "achieved": round(k_ach, 3), "unit": "TFLOP/s",
                     "frac": round(k_ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": k_traffic,
                     "frac_at_rocprofv3_duration": (round(fl_l / n_l / (k_rocprof_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
                                                    if k_rocprof_us else None),
-                    "how": "avg_us: every launch of one extra step bracketed by HIP events on its stream (rsrgan_profile_begin/"
-                           "read; includes the event records, an upper bound); rocprofv3_avg_us: AverageNs of the same kernel in "
-                           "the committed profiles/r3_final_rocprofv3_kernel_stats.csv of this command"}
+                    "how": "the kernel class with the largest total duration in the step: k_glstm_fwd (csrc/gpersist.hip: the generator's "
+                           "whole forward recurrence as ONE persistent launch; algorithmic FLOP = every layer's recurrent product and "
+                           "projection + the input product above layer 0) or, with RSRGAN_GPERSIST=0, the k_fwd_gates launches of the "
+                           "wavefront.  avg_us: every launch of one extra step bracketed by HIP events on its stream (rsrgan_profile_begin "
+                           "/ read_kind / read; includes the event records, an upper bound); rocprofv3_avg_us: AverageNs of the same "
+                           "kernel in the committed profiles/r4_final_rocprofv3_kernel_stats.csv of this command"}
         out = {"metric": "GAN train frames/sec (G+D step), 257-dim LPS->40-dim MFCC", "value": round(value, 1),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt * 1e3 / a.steps, 4), "ms_per_step_median": round(res["med_ms"], 4),
@@ -607,9 +623,20 @@ def main():
                             "value": round(B * T * n2 / v["dt"], 1), "unit": "frames/s", "ms_per_step": round(v["dt"] * 1e3 / n2, 4),
                             "roofline_frac": round(f2 * B * T / (v["dev_ms"] * 1e-3 / n2) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
                             "flop_per_frame": f2}]
-        # the shipped schedule: 1 D-run + 2 G-runs per batch (run_gan_rnn_placeholder.sh:129-130), reference-true networks
+        # the network the shipped recipe selects (run_gan_rnn_placeholder.sh:124,149: --g_type res_lstm_l = 4 x LSTMP(760, p257) with the
+        # running residual sum, models/res_lstm_l.py:101-194): 3*F_G + 8*F_D with F_G = 14 083 600
         del v
         torch.cuda.empty_cache()
+        vr = measure_sequence(a, "res_lstm_l", "lstm", B, T, n2, 2, rank, local, world, dev)
+        cr = vr["model"].engine.cfg
+        fr, fgr, fdr = flop_per_frame(257, 40, vr["g_type"], cr.g_layers, cr.g_cells, cr.g_proj, cr.d_layers, cr.d_cells, cr.d_proj)
+        out["variants"].append({"workload": "shipped network: G=res_lstm_l(4x760/p257) + D=lstm(2x256/p40), 1D+1G, B=%d T=%d" % (B, T),
+                                "value": round(B * T * n2 / vr["dt"], 1), "unit": "frames/s", "ms_per_step": round(vr["dt"] * 1e3 / n2, 4),
+                                "roofline_frac": round(fr * B * T / (vr["dev_ms"] * 1e-3 / n2) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                "flop_per_frame": fr, "F_G": fgr, "F_D": fdr})
+        del vr
+        torch.cuda.empty_cache()
+        # the shipped schedule: 1 D-run + 2 G-runs per batch (run_gan_rnn_placeholder.sh:129-130), reference-true networks
         a2 = argparse.Namespace(**vars(a)); a2.gen_updates = 2
         v2 = measure_sequence(a2, "lstm", "lstm", B, T, n2, 2, rank, local, world, dev)
         out["variants"].append({"workload": "shipped schedule 1D+2G per batch, reference-true networks, B=%d T=%d" % (B, T),
@@ -624,7 +651,8 @@ def main():
                 bench_rced(a3, rank, local, world, dev)
             r3 = json.loads(buf.getvalue().strip().splitlines()[-1])
             out["variants"].append({"workload": r3["config"]["workload"], "value": r3["value"], "unit": "frames/s",
-                                    "ms_per_step": r3["ms_per_step"], "roofline_frac": r3["roofline"]["frac"]})
+                                    "ms_per_step": r3["ms_per_step"], "roofline_frac": r3["roofline"]["frac"],
+                                    "roofline_frac_incl_padding": r3["roofline"]["frac_incl_padding"]})
         except Exception as e:          # never lose the headline line to a variant
             out["variants"].append({"workload": "R-CED + discriminator_dnn (configs[3])", "error": str(e)[:200]})
         try:           # BASELINE.json configs[4]: SEGAN-style conv G/D, 16384-sample chunks, B = 32 (bench.py --net segan --batch 32)

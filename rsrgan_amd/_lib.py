@@ -21,7 +21,7 @@ SYMBOLS = ["rsrgan_default_cfg", "rsrgan_create", "rsrgan_destroy", "rsrgan_last
            "rsrgan_get_params", "rsrgan_set_params", "rsrgan_get_grads", "rsrgan_forward_g", "rsrgan_d_step",
            "rsrgan_g_step", "rsrgan_d_backward", "rsrgan_g_backward", "rsrgan_apply", "rsrgan_grad_buffer",
            "rsrgan_grad_bucket_count", "rsrgan_grad_bucket_info", "rsrgan_grad_bucket_wait",
-           "rsrgan_profile_begin", "rsrgan_profile_read", "rsrgan_profile_launches", "rsrgan_op_launch_floor", "rsrgan_device_status", "rsrgan_set_dropout",
+           "rsrgan_profile_begin", "rsrgan_profile_read", "rsrgan_profile_read_kind", "rsrgan_profile_launches", "rsrgan_op_launch_floor", "rsrgan_device_status", "rsrgan_set_dropout",
            "rsrgan_op_gemm", "rsrgan_version",
            "rsrgan_segan_default_cfg", "rsrgan_segan_create", "rsrgan_segan_destroy", "rsrgan_segan_set_scalar",
            "rsrgan_segan_num_tensors", "rsrgan_segan_tensor_info", "rsrgan_segan_param_count", "rsrgan_segan_get_params",
@@ -89,6 +89,7 @@ def load():
     lib.rsrgan_grad_bucket_wait.argtypes = [vp, i32, i32, vp]
     lib.rsrgan_profile_begin.argtypes = [vp]
     lib.rsrgan_profile_read.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.rsrgan_profile_read_kind.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.rsrgan_device_status.argtypes = [vp, C.POINTER(i32)]
     lib.rsrgan_set_dropout.argtypes = [vp, f32, C.c_uint64]
     lib.rsrgan_profile_launches.argtypes = [vp, C.POINTER(i64)]

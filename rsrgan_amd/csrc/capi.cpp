@@ -295,7 +295,7 @@ int rsrgan_grad_bucket_wait(rsrgan_handle h, int32_t net, int32_t i, void* strea
 
 int rsrgan_profile_begin(rsrgan_handle h) {
   CHECK_H(h);
-  h->m.prof_on = true; h->m.prof_n = 0; h->m.prof_flops = 0.0;
+  h->m.prof_on = true; h->m.prof_n = 0; h->m.prof_flops = 0.0; h->m.prof_gp_n = 0; h->m.prof_gp_flops = 0.0;
   g_chain_launches = 0;
   return RSRGAN_OK;
 }
@@ -357,6 +357,21 @@ int rsrgan_profile_read(rsrgan_handle h, int32_t* launches, double* total_us, do
     us += 1e3 * ms;
   }
   *launches = m.prof_n; *total_us = us; *alg_flops = m.prof_flops;
+  return RSRGAN_OK;
+}
+int rsrgan_profile_read_kind(rsrgan_handle h, int32_t kind, int32_t* launches, double* total_us, double* alg_flops) {
+  CHECK_H(h);
+  if (kind == 0) return rsrgan_profile_read(h, launches, total_us, alg_flops);
+  Model& m = h->m;
+  if (kind != 1 || !launches || !total_us || !alg_flops) { set_error("profile_read_kind: bad argument"); return RSRGAN_ERR_INVALID; }
+  double us = 0.0;
+  for (int i = 0; i < m.prof_gp_n; ++i) {
+    if (hipEventSynchronize(m.prof_gp_ev[2 * i + 1]) != hipSuccess) { set_error("hipEventSynchronize failed"); return RSRGAN_ERR_HIP; }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, m.prof_gp_ev[2 * i], m.prof_gp_ev[2 * i + 1]) != hipSuccess) { set_error("hipEventElapsedTime failed"); return RSRGAN_ERR_HIP; }
+    us += 1e3 * ms;
+  }
+  *launches = m.prof_gp_n; *total_us = us; *alg_flops = m.prof_gp_flops;
   return RSRGAN_OK;
 }
 

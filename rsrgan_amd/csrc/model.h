@@ -275,6 +275,10 @@ struct Model {
   std::vector<hipEvent_t> prof_ev;
   int prof_n = 0;
   double prof_flops = 0.0;
+  // ... and the same for the persistent generator launch (k_glstm_fwd: one launch per forward pass): rsrgan_profile_read_kind(h, 1, ...)
+  std::vector<hipEvent_t> prof_gp_ev;
+  int prof_gp_n = 0;
+  double prof_gp_flops = 0.0;
   void gates_launch(const FwdGateJobs& gj, int blocks, int kb, hipStream_t s);
   int gates_blocks(int H, int N) const;
   int proj_blocks(int P, int N) const;

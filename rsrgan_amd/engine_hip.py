@@ -291,6 +291,12 @@ class HipEngine:
     def profile_begin(self):
         check(self.lib.rsrgan_profile_begin(self.h))
 
+    def profile_read_kind(self, kind):
+        """(launches, total_us, algorithmic_flops) of kernel class `kind` (1 = k_glstm_fwd) since profile_begin; call before profile_read"""
+        n, us, fl = C.c_int32(), C.c_double(), C.c_double()
+        check(self.lib.rsrgan_profile_read_kind(self.h, kind, C.byref(n), C.byref(us), C.byref(fl)))
+        return n.value, us.value, fl.value
+
     def profile_read(self):
         """(launches, total_us, algorithmic_flops) of k_fwd_gates since profile_begin (synchronises)."""
         n, us, fl = C.c_int32(), C.c_double(), C.c_double()

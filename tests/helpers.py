@@ -57,8 +57,11 @@ def args_for(cfg, B, **kw):
 
 
 def overrides(cfg):
-    return dict(g_layers=cfg.g_layers, g_cells=cfg.g_cells, g_proj=cfg.g_proj, d_layers=cfg.d_layers,
-                d_cells=cfg.d_cells, d_proj=cfg.d_proj)
+    o = dict(g_layers=cfg.g_layers, g_cells=cfg.g_cells, g_proj=cfg.g_proj, d_layers=cfg.d_layers,
+             d_cells=cfg.d_cells, d_proj=cfg.d_proj)
+    if getattr(cfg, "d_type", "lstm") != "lstm":
+        o["d_type"] = cfg.d_type
+    return o
 
 
 def split_flat(flat, table):

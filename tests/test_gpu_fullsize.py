@@ -16,15 +16,9 @@ def _grads(model, net):
     return split_flat(model.engine.get_grads(net).cpu().numpy(), model.engine.tensor_table(net))
 
 
-@pytest.mark.parametrize("flags", [1, 3])
-@pytest.mark.parametrize("B,T", [(32, 50), (64, 100)])
-def test_full_size_step_against_oracle(B, T, flags):
-    """flags=3 is what bench.py times: the wavefront schedule replayed as hipGraphs.  A segment runs eagerly on its first use,
-    is captured on its second and replayed from the third on, so the graph case repeats each backward three times (the
-    gradients do not depend on the repetition: apply=False) and compares what the REPLAY produced."""
-    cfg = O.NetCfg()
-    model, oracle = build_hip_pair(cfg, B, T, seed=100 + B, flags=flags)
-    x, lab, ln = rand_batch(cfg, B, T, seed=200 + B, ragged=True)
+def _step_against_oracle(cfg, B, T, flags, seed):
+    model, oracle = build_hip_pair(cfg, B, T, seed=seed, flags=flags)
+    x, lab, ln = rand_batch(cfg, B, T, seed=seed + 100, ragged=True)
     x64, lab64 = x.astype(np.float64), lab.astype(np.float64)
     for _ in range(2 if flags & 2 else 0):
         model.engine.d_backward(x, lab, ln, None, None, train=True, apply=False)
@@ -50,6 +44,33 @@ def test_full_size_step_against_oracle(B, T, flags):
     assert np.allclose(np.ravel(a), np.ravel(b), rtol=RTOL)
     a = model.g_step(x, lab, ln, train=False); b = oracle.g_step(x64, lab64, ln, train=False)
     assert np.allclose(np.ravel(a), np.ravel(b), rtol=RTOL), (a, b)
+    assert model.engine.device_status() == 0
+
+
+@pytest.mark.parametrize("flags", [1, 3])
+@pytest.mark.parametrize("B,T", [(32, 50), (64, 100)])
+def test_full_size_step_against_oracle(B, T, flags):
+    """flags=3 is what bench.py times: the wavefront schedule replayed as hipGraphs.  A segment runs eagerly on its first use,
+    is captured on its second and replayed from the third on, so the graph case repeats each backward three times (the
+    gradients do not depend on the repetition: apply=False) and compares what the REPLAY produced.  At these sizes the generator's
+    forward recurrence is the persistent launch of csrc/gpersist.hip (B % 32 == 0) and both discriminator-only recurrences are
+    the persistent launches of csrc/dpersist.hip."""
+    _step_against_oracle(O.NetCfg(), B, T, flags, seed=100 + B)
+
+
+OTHER_NETS = {
+    # the network the shipped run_gan_rnn_placeholder.sh:124,149 selects: 4 x LSTMP(760, p257) with the running residual sum
+    # (models/res_lstm_l.py:101-194); at B = 64 its four layers and P = 257 take other XCD-group / split-K plans than at B = 4
+    "res_lstm_l": lambda: O.NetCfg.res_lstm_l(),
+    # BASELINE.json configs[1] as worded: 2-layer 512-unit LSTM generator (num_proj=None) + DNN discriminator (4 x 1024)
+    "baseline_named": lambda: O.NetCfg(g_type="lstm", g_layers=2, g_cells=512, g_proj=0, d_type="dnn", d_layers=4, d_cells=1024),
+}
+
+
+@pytest.mark.parametrize("flags", [1, 3])
+@pytest.mark.parametrize("net,B,T", [("res_lstm_l", 64, 100), ("res_lstm_l", 32, 50), ("baseline_named", 32, 50)])
+def test_full_size_other_networks_against_oracle(net, B, T, flags):
+    _step_against_oracle(OTHER_NETS[net](), B, T, flags, seed=300 + B)
 
 
 def test_full_size_tower_mean_property():

@@ -121,6 +121,53 @@ def test_segan_waveform_chunk_against_oracle():
         assert np.allclose(a, b, rtol=1e-3), (a, b)
 
 
+def test_segan_at_the_benchmarked_batch_against_golden():
+    """BASELINE.json configs[4] at B = 32 (what bench.py --net segan --batch 32 times): the virtual batch norm's 1 / (B + 1) mix
+    (utils/bnorm.py:36-48) and every planner branch (stream-K cuts at M = 32 L, the fix-up pieces) differ from the B = 2 case above.
+    The fp64 oracle ran in the build container (tests/golden/make_segan_golden.py: same seeds, same draws as _pair / _batch here) and
+    left the towers' losses, a sample of G(x), the norm of every gradient tensor and -- after one RMSProp step of each net -- the
+    next losses and the norm of every variable's change."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "segan_b32_l16384.npz"))
+    B, L, U = int(gold["B"]), int(gold["L"]), int(gold["U"])
+    assert (B, L, U) == (32, 16384, 40)
+    cfg, m, o, rng = _pair(B, L, U, S.DEPTHS, 20, 31, seed=int(gold["seed"]), l1=100.0)
+    x, lab, z, nz = _batch(cfg, B, rng, noise=0.1)
+    g0, d0 = m.get_vars()
+    y = m.forward(x, z)
+    assert abs(np.abs(y).mean() - float(gold["y_abs_mean"])) < 1e-3 * float(gold["y_abs_mean"])
+    assert np.abs(y[:, ::4] - gold["y_sample"]).mean() / np.abs(gold["y_sample"]).mean() < 1e-3
+    got = m.d_step(x, lab, z, nz, apply=False)
+    assert np.allclose(got, gold["d_losses"], rtol=1e-4), (got, gold["d_losses"])
+    gd = m.get_grads(NET_D)
+    for k in gd:
+        want = float(gold["dgrad_norm/" + k])
+        scale = float(gold["dgrad_norm/" + k[:-1] + "W"]) if k.endswith("downconv/b") else None
+        if scale is not None and want <= 1e-9 * scale:                 # a bias in front of a VBN: exactly zero gradient (see _close)
+            assert np.linalg.norm(gd[k]) <= 1e-4 * scale, ("D", k)
+        else:
+            assert abs(np.linalg.norm(gd[k].astype(np.float64)) - want) <= 2e-3 * want + 1e-9, ("D", k, np.linalg.norm(gd[k]), want)
+    got = m.g_step(x, lab, z, (nz[0], nz[2]), apply=False)
+    assert np.allclose(got, gold["g_losses"], rtol=1e-4), (got, gold["g_losses"])
+    gg = m.get_grads(NET_G)
+    for k in gg:
+        want = float(gold["ggrad_norm/" + k])
+        assert abs(np.linalg.norm(gg[k].astype(np.float64)) - want) <= 2e-3 * want + 1e-9, ("G", k, np.linalg.norm(gg[k]), want)
+    a = m.d_step(x, lab, z, nz)
+    assert np.allclose(a, gold["d_step"], rtol=1e-3), (a, gold["d_step"])
+    a = m.g_step(x, lab, z, (nz[0], nz[2]))
+    assert np.allclose(a, gold["g_step"], rtol=1e-3), (a, gold["g_step"])
+    g1, d1 = m.get_vars()
+    for k in d1:
+        want = float(gold["d1_delta_norm/" + k])
+        assert abs(np.linalg.norm(d1[k].astype(np.float64) - d0[k]) - want) <= 5e-3 * want + 1e-7, ("dD", k)
+    for k in g1:
+        want = float(gold["g1_delta_norm/" + k])
+        assert abs(np.linalg.norm(g1[k].astype(np.float64) - g0[k]) - want) <= 5e-3 * want + 1e-7, ("dG", k)
+    a = m.d_step(x, lab, z, nz, apply=False)
+    assert np.allclose(a, gold["d_next"], rtol=1e-3), (a, gold["d_next"])
+
+
 def test_segan_checkpoint_and_device_draws(tmp_path):
     cfg, m, o, rng = _pair(2, 40, 4, (16, 16), 6, 5, seed=9)
     x, lab, z, nz = _batch(cfg, 2, rng)

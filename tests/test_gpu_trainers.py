@@ -89,10 +89,20 @@ def test_rnn_trainer_with_dropout_wrapper(g_type, flags):
     assert np.allclose(ev[0], w[1], rtol=2e-4)
 
 
-@pytest.mark.parametrize("N", [9, 200])
-def test_dnn_trainer_matches_oracle(N):
+DNN_TRAINER_CASES = {
+    "toy-9": (9, dict(input_dim=6, output_dim=5, left_context=2, right_context=1, g_units=20, g_hidden=3, d_units=18, d_hidden=2)),
+    "toy-200": (200, dict(input_dim=6, output_dim=5, left_context=2, right_context=1, g_units=20, g_hidden=3, d_units=18, d_hidden=2)),
+    # BASELINE.json configs[0] at its own size: models/dnn.py:32-114 (1 + 3 hidden ReLU-1024 layers + linear 40) on 1000 frames of
+    # 257-dim LPS, context 0 (the shape bench.py --net dnn_trainer --batch 1000 times)
+    "configs0-1000x257": (1000, dict(input_dim=257, output_dim=40, left_context=0, right_context=0, g_units=1024, g_hidden=4, d_units=18, d_hidden=2)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(DNN_TRAINER_CASES))
+def test_dnn_trainer_matches_oracle(case):
     from rsrgan_amd.trainer import DNNTrainer
-    cfg = DO.DnnCfg(input_dim=6, output_dim=5, left_context=2, right_context=1, g_units=20, g_hidden=3, d_units=18, d_hidden=2)
+    N, kw = DNN_TRAINER_CASES[case]
+    cfg = DO.DnnCfg(**kw)
     rng = np.random.default_rng(N)
     g = {k: v.astype(np.float32) for k, v in DO.init_params(DO.g_param_specs(cfg), rng).items()}
     d = {k: v.astype(np.float32) for k, v in DO.init_params(DO.d_param_specs(cfg), rng, relu_init=True).items()}
