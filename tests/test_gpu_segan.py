@@ -157,13 +157,15 @@ def test_segan_at_the_benchmarked_batch_against_golden():
     assert np.allclose(a, gold["d_step"], rtol=1e-3), (a, gold["d_step"])
     a = m.g_step(x, lab, z, (nz[0], nz[2]))
     assert np.allclose(a, gold["g_step"], rtol=1e-3), (a, gold["g_step"])
+    # (an fp32 variable moves in steps of its own ulp: where the RMSProp step is of that size -- the big decoder filters: |delta| ~ 1e-9
+    # per element -- the norm of the change carries rounding noise of ~1e-7 of the VARIABLE's norm)
     g1, d1 = m.get_vars()
     for k in d1:
         want = float(gold["d1_delta_norm/" + k])
-        assert abs(np.linalg.norm(d1[k].astype(np.float64) - d0[k]) - want) <= 5e-3 * want + 1e-7, ("dD", k)
+        assert abs(np.linalg.norm(d1[k].astype(np.float64) - d0[k]) - want) <= 5e-3 * want + 1e-7 * np.linalg.norm(d0[k]) + 1e-7, ("dD", k)
     for k in g1:
         want = float(gold["g1_delta_norm/" + k])
-        assert abs(np.linalg.norm(g1[k].astype(np.float64) - g0[k]) - want) <= 5e-3 * want + 1e-7, ("dG", k)
+        assert abs(np.linalg.norm(g1[k].astype(np.float64) - g0[k]) - want) <= 5e-3 * want + 1e-7 * np.linalg.norm(g0[k]) + 1e-7, ("dG", k)
     a = m.d_step(x, lab, z, nz, apply=False)
     assert np.allclose(a, gold["d_next"], rtol=1e-3), (a, gold["d_next"])
 
