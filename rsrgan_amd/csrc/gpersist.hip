@@ -48,7 +48,7 @@ constexpr unsigned GP_SC1 = 16u;         // aux of the raw-buffer builtins: sc1 
 constexpr unsigned GP_VOL = 1u << 31;    // ... compiler-only: volatile (a polled load must not be hoisted out of its loop)
 
 #ifdef GP_TRACE
-__device__ unsigned g_gp_cnt[8];          // [0] cached first reads, [1] of them with a stale / missing tag; [2], [3] the same for write-through first reads
+__device__ unsigned g_gp_cnt[8];          // (GP_COUNT builds only: the atomics distort the timeline)          // [0] cached first reads, [1] of them with a stale / missing tag; [2], [3] the same for write-through first reads
 __device__ unsigned g_gp_trace[256][24][24];
 #define GPT_DECL __shared__ unsigned gp_tr[24][24];
 #define GPT(i) do { if ((w & 3) == 0 && lane == 0 && t < 24) gp_tr[t][i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
@@ -150,7 +150,7 @@ __device__ __forceinline__ bool gp_sweep(const GpBuf& b, const unsigned (&lo)[NL
 #endif
     if (read_now) {
       const bool ok = (CACHED && first) ? read_all(std::true_type{}) : read_all(std::false_type{});
-#ifdef GP_TRACE
+#ifdef GP_COUNT
       if (first && (threadIdx.x & 63) == 0) { atomicAdd(&g_gp_cnt[CACHED ? 0 : 2], 1u); if (!ok) atomicAdd(&g_gp_cnt[CACHED ? 1 : 3], 1u); }
 #endif
       first = false;

@@ -26,6 +26,24 @@ B, T = int(os.environ.get("RSRGAN_TEST_B", "8")), int(os.environ.get("RSRGAN_TES
 model, _ = build_hip_pair(cfg, B, T, seed=5, flags=3)
 x, lab, ln = rand_batch(cfg, B, T, seed=6, ragged=True)
 out = {}
+side = None
+if os.environ.get("RSRGAN_TEST_SIDELOAD") == "1":
+    # a second stream keeps the chip busy with foreign kernels for the whole test: a single-workgroup spin kernel that holds one CU
+    # for ~40 ms at a time, and streaming adds over 1 GB that take every CU in turn (what an RCCL kernel on the communication stream or
+    # another tenant of the GPU does to the persistent launches' "every workgroup resident" assumption)
+    import threading, torch
+    stop = threading.Event()
+    def load():
+        st = torch.cuda.Stream()
+        a = torch.ones(1 << 28, device="cuda"); b = torch.ones(1 << 28, device="cuda")
+        with torch.cuda.stream(st):
+            while not stop.is_set():
+                torch.cuda._sleep(100_000_000)
+                for _ in range(8):
+                    a.add_(b)
+                st.synchronize()
+    side = threading.Thread(target=load, daemon=True); side.start()
+    import time; time.sleep(0.3)
 for it in range(2):
     d = np.ravel(model.d_step(x, lab, ln)); g = np.ravel(model.g_step(x, lab, ln, reuse_g_forward=True))
     out["d%%d" %% it] = [float(v) for v in d]; out["g%%d" %% it] = [float(v) for v in g]
@@ -40,6 +58,8 @@ for k in sorted(gv): h.update(np.ascontiguousarray(gv[k]).tobytes())
 for k in sorted(dv): h.update(np.ascontiguousarray(dv[k]).tobytes())
 out["vars_sha"] = h.hexdigest()
 out["g_norm"] = float(sum(float(np.square(v.astype(np.float64)).sum()) for v in gv.values()))
+if side is not None:
+    stop.set(); side.join(timeout=10)
 print("RESULT " + json.dumps(out))
 """ % ROOT
 
@@ -114,6 +134,20 @@ def test_persistent_generator_recurrence_agrees(B, T):
     assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
     c = _run(dict(size, RSRGAN_GPERSIST="1"))
     assert a["vars_sha"] == c["vars_sha"]          # fixed summation order: reproducible bits
+
+
+def test_persistent_launches_survive_a_busy_side_stream():
+    """The persistent recurrences (csrc/gpersist.hip, dpersist.hip) wait for each other inside a launch, so every workgroup must become
+    resident -- without a cooperative launch.  With foreign kernels on another stream holding CUs (a spin kernel, streaming adds:
+    the N > 1 schedule's RCCL kernels on the communication stream, or another tenant) the workgroups arrive late but arrive: no
+    bounded wait may expire (rsrgan_device_status == 0) and the step must produce the same bits as on an idle chip."""
+    size = {"RSRGAN_TEST_B": "64", "RSRGAN_TEST_T": "40"}
+    a = _run(dict(size, RSRGAN_TEST_SIDELOAD="1"))
+    b = _run(dict(size, RSRGAN_TEST_SIDELOAD="0"))
+    assert a["device_status"] == 0 and b["device_status"] == 0
+    for k in ("d0", "g0", "d1", "g1"):
+        assert a[k] == b[k], (k, a[k], b[k])
+    assert a["vars_sha"] == b["vars_sha"]
 
 
 def test_stream_k_gemm_step_is_reproducible():

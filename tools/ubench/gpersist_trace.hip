@@ -2,6 +2,8 @@
 // GP_TRACE); not part of the product library.  Synthetic weights at the reference's sizes (3 x LSTMCell(760, num_proj=280), N rows,
 // T steps); prints the launch time per step and the mean duration of every phase of a step per layer and wave role.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 gpersist_trace.hip -o gpersist_trace      Run: ./gpersist_trace [N] [T] [layers]
+// -DGP_COUNT: also count the first full reads of the sweeps that fail (atomics: the timeline of such a build is not representative);
+// -DGP_ABL=mask: timing ablations (1: no x sweeps, 2: hop-1 sentinels only, 4: hop-2 sentinels only)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -56,8 +58,10 @@ int main(int argc, char** argv) {
   unsigned ctl[4]; CK(hipMemcpy(ctl, a.ctl, 16, hipMemcpyDeviceToHost));
   printf("k_glstm_fwd N=%d T=%d layers=%d (NT=%d NC=%d, %zu + %zu MB of granule slots): %.1f us per launch = %.2f us per step (err word %u, generation %u)\n",
          N, T, nl, a.NT, a.NC, g1 >> 20, g2 >> 20, best * 1e3f, best * 1e3f / T, ctl[2], ctl[0]);
+#ifdef GP_COUNT
   { unsigned cn[8]; CK(hipMemcpyFromSymbol(cn, HIP_SYMBOL(rsr::g_gp_cnt), sizeof(cn)));
     printf("first full reads (5 launches): through the caches %u, of them failed %u; write-through %u, failed %u\n", cn[0], cn[1], cn[2], cn[3]); }
+#endif
   static unsigned tr[256][24][24];
   CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(rsr::g_gp_trace), sizeof(tr)));
   // R wave 0, tile r (stamps 6 r + ..): 0 top, 1 x-part there, 2 m(t-1) there, 3 recurrent MFMAs + tiles written, 4 all partials there, 5 cell done
