@@ -52,10 +52,12 @@ __device__ unsigned g_gp_cnt[8];          // (GP_COUNT builds only: the atomics 
 __device__ unsigned g_gp_trace[256][24][24];
 #define GPT_DECL __shared__ unsigned gp_tr[24][24];
 #define GPT(i) do { if ((w & 3) == 0 && lane == 0 && t < 24) gp_tr[t][i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#define GPTS(i) do { if ((w & 3) == 0 && lane == 0 && s < 24) gp_tr[s][i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
 #define GPT_FLUSH() do { if (lane == 0) for (int t_ = 0; t_ < 24; ++t_) for (int i_ = i0_; i_ < i1_; ++i_) g_gp_trace[blockIdx.x][t_][i_] = gp_tr[t_][i_]; } while (0)
 #else
 #define GPT_DECL
 #define GPT(i) do { } while (0)
+#define GPTS(i) do { } while (0)
 #define GPT_FLUSH() do { } while (0)
 #endif
 
@@ -179,7 +181,7 @@ struct GpLds {
   float mB[GP_NR][GP_NKB][64][4];           // carried m(t-1) as B fragments [row tile][k-block][lane][4]
   float pb[4][NT][GP_NR][64][4];            // accumulator tiles: x-part (X wave w -> R wave w), then the R waves' partial sums
   float st[6][GP_ROWS][4 * NT];             // the step's stash: gates i, j, f, o | c | h   (h also feeds the projection)
-  float gs[GP_NR][2][64][2];                // the two reducing G waves' partial sums of this workgroup's half chunk, per tile
+  float gs[2][GP_NR][2][64][2];             // the two reducing G waves' partial sums of this workgroup's half chunk [step parity][tile][wave]
   float kx4[2][NT][64][4];                  // the fifth K_x k-block of X waves 0, 1 (k-blocks 16, 17): 100 weight registers do not fit beside the sweeps
   float peep[4 * NT][4];                    // {w_i, w_f, w_o, -} per cell of this slice (one 16-byte read per cell)
   float bias[4 * NT][4];                    // {b_i, b_j, b_f, b_o} per cell: the accumulator registers of a lane
@@ -187,7 +189,8 @@ struct GpLds {
 };
 
 template <int NT>
-__device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigned gen, GpLds<NT>& S) {
+__device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigned gen_, GpLds<NT>& S) {
+  const unsigned gen = (unsigned)__builtin_amdgcn_readfirstlane((int)gen_);
   constexpr int NR = GP_NR, NU = NT * NR, CW = 4 * NT;
   GPT_DECL
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
@@ -526,10 +529,10 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigne
       if (!gp_sweep<20, true, 20, false>(b1, lo, pn, (unsigned)lane * 16u, slot1(par, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 1024u + 1008u, lane < pn, tag1, err,
                                   [&](int k, float va, float vb) { if (k == 0) { s0 = va; s1 = vb; } else if (k < pn) { s0 += va; s1 += vb; } })) { fail(); return; }
       GPT(15);
-      *reinterpret_cast<float2*>(&S.gs[r][gp][lane][0]) = make_float2(s0, s1);
+      *reinterpret_cast<float2*>(&S.gs[par][r][gp][lane][0]) = make_float2(s0, s1);
       gp_signal(&S.cnt_g[r], lane);
       if (!gp_wait(&S.cnt_g[r], 2u * ((unsigned)t + 1u), dead)) return;
-      const float2 g0 = *reinterpret_cast<const float2*>(&S.gs[r][0][lane][0]), g1 = *reinterpret_cast<const float2*>(&S.gs[r][1][lane][0]);
+      const float2 g0 = *reinterpret_cast<const float2*>(&S.gs[par][r][0][lane][0]), g1 = *reinterpret_cast<const float2*>(&S.gs[par][r][1][lane][0]);
       tot0 = g0.x + g1.x; tot1 = g0.y + g1.y;
       // hop 2: this half chunk of m(t), tile r
       if (gp == 0) gp_store(b2, slot2(t, r, jbr) + (unsigned)hh * 1024u + (unsigned)lane * 16u, gen, tot0, tot1);
@@ -588,6 +591,455 @@ __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_fwd(const GPersistAr
   }
 }
 
+// =====================================================================================================================================
+// BPTT through the same stack as ONE persistent launch (the mirror of k_glstm_fwd; the launch-per-phase form is kernels.hip
+// k_bwd_a2 + k_bwd_bp + k_bwd_b_red: 26 us per wavefront diagonal).  Same decomposition -- workgroup = (row group, layer, slice of
+// 4 NT cells), two tile lanes, 12 waves -- and the same two hand-offs per step, now carrying gradients:
+//   hop 1  every workgroup publishes its PARTIAL state gradient dz(t)[:, its gate columns] . K_h[:, its gate columns]^T (R waves) and
+//          its partial input gradient dz(t) . K_x^T (X waves, to the LAYER BELOW); reducer c sums, for its 8-column half chunk of
+//          both tiles, the NC input-gradient partials of the layer above at time t (the top layer reads d(outputs) from memory
+//          instead), then the NC state-gradient partials of its own layer from time t + 1, masks finished rows: dm(t);
+//   hop 2  it publishes the half chunk and writes it to the stash (dmt: the projection's weight gradient); every workgroup of the
+//          layer gathers dm(t), multiplies by its W_p slice (dh), runs the cell's gradient (dz: in place over the gate activations
+//          in the stash, and as the B operand of the two products above).
+// The state-gradient ring has two steps like the forward's (a producer cannot be two steps ahead of a consumer it needs the sum
+// from); the input-gradient ring between two layers has GP_XR steps and an explicit back-pressure check: the upper layer does not
+// depend on the lower one, so before re-using a ring slot it polls the lower layer's dm chunk of GP_XR steps ago (published by the
+// reducer AFTER it has summed that slot).  Layer 0's input gradient is a time-batched GEMM over the dz stash afterwards.
+// Cell gradient: kernels.hip k_bwd_a2 (peepholes, o's peephole on the new c, dynamic_rnn masking: a finished row has dz = 0 and
+// carries dc through).
+constexpr int GP_XR = 4;
+
+template <int NT>
+struct GpLdsB {
+  float wpa[GP_NKB][64][4];                 // W_p fragments, A operand of dh^T = W_p . dm^T: [k-block of P][lane][4 k-steps]; row 4 q + i = cell 4 i + q (so that accumulator register i of lane (q, lr) is gate tile i's cell q)
+  float wpb[GP_NKB][16][4];                 // ... of the fifth gate tile: [k-block][4 (k quarter) + cell - 16][4 k-steps]; A row 4 q = cell 16 + q, the other rows of that product are never read (every lane of a row group reads the same entry)
+  float mB[GP_NR][GP_NKB][64][4];           // dm(t) as B fragments [row tile][k-block][lane][4]
+  float kl[8][NT][64][4];                   // weights that do not fit the register file [slot][gate tile][lane][gate]: slots 0..3 R wave w's output tile 12 + w, 4, 5 R waves' tiles 16, 17, 6, 7 X waves' tiles 16, 17
+  float pd[4][GP_NR][NT][64];               // dh partial sums [R wave = k-blocks w, w + 4, ..][row tile][gate tile][lane]
+  float dzB[GP_NR][NT][64][4];              // dz(t) as B fragments of both gradient products [row tile][gate tile][lane (cell q, row lr)][gate]
+  float st[4][GP_ROWS][4 * NT];             // dz(t) in stash order [gate][row][cell]
+  float gs[2][GP_NR][2][64][2];             // the two reducing G waves' sums [step parity][tile][wave]
+  float pfs[GP_NR][5][16][4 * NT];          // the stash of the NEXT step of a tile: gate activations i, j, f, o and c(t-1) (the X waves fetch it a step ahead)
+  float peep[4 * NT][4];                    // {w_i, w_f, w_o, -} per cell
+  float car[4][2][GP_NR][64][2];            // c(t) and the carried dc of an R wave's cells [wave][gate tile w | 4 + w][row tile][lane] (in registers they get spilled, and a scratch reload waits for the wave's write-through stores)
+  unsigned cnt_p[GP_NR], cnt_h[GP_NR], cnt_m[GP_NR], cnt_g[GP_NR], cnt_z[GP_NR], cnt_f[GP_NR], dead, pad_[3];
+};
+
+// one lane = one sentinel (16 bytes at `so` when son): wait until every one carries `tag`
+__device__ __forceinline__ bool gp_poll(const GpBuf& b, unsigned so, bool son, unsigned tag, gu32* err) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (unsigned polls = 0;; ++polls) {
+    const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(b.rs, so, 0, GP_SC1 | GP_VOL);
+    if (__all(!son || (y[1] == tag && y[3] == tag))) return true;
+    asm volatile("" ::: "memory");
+    if ((polls & 63) == 63) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, const unsigned gen_, GpLdsB<NT>& S) {
+  const unsigned gen = (unsigned)__builtin_amdgcn_readfirstlane((int)gen_);      // (a scalar: as a vector register it is spilled, and its reload sits behind the write-through stores)
+  constexpr int NR = GP_NR, CW = 4 * NT;
+  GPT_DECL
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef GP_TRACE
+  if (tid == 0) gp_tr[0][23] = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+  const int ngr = a.N / GP_ROWS, xpg = 8 / ngr;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int grp = xcd / xpg, idx = slot * xpg + (xcd % xpg);
+  if (idx >= a.nl * a.NC) return;
+  const int l = idx / a.NC, c = idx - l * a.NC;
+  const GPersistLayer L = a.L[l];
+  const int H = a.H, H4 = 4 * H, T = a.T, N = a.N, P = L.P, ldP = L.ldP, I = L.I, NC = a.NC;
+  const int nkb = (P + 15) >> 4, nkbx = (I + 15) >> 4;
+  const int row0 = grp * GP_ROWS, cell0 = c * CW;
+  const bool top = l == a.nl - 1;
+  gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
+  const size_t g1_per = (size_t)GP_NCH * NC * GP_SLOT, g2_per = (size_t)GP_NCH * GP_SLOT;
+  const GpBuf b1 = gp_buf((const char*)a.gran1 + (size_t)(grp * a.nl + l) * 2 * g1_per, 2 * g1_per);
+  const GpBuf b2 = gp_buf((const char*)a.gran2 + (size_t)(grp * a.nl + l) * T * g2_per, (size_t)T * g2_per);
+  const GpBuf b2x = gp_buf((const char*)a.gran2 + (size_t)(grp * a.nl + (l > 0 ? l - 1 : 0)) * T * g2_per, (size_t)T * g2_per);
+  const GpBuf b3 = gp_buf((const char*)a.gran3 + (size_t)(grp * a.nl + l) * GP_XR * g1_per, GP_XR * g1_per);              // what the layer above hands to this one
+  const GpBuf b3x = gp_buf((const char*)a.gran3 + (size_t)(grp * a.nl + (l > 0 ? l - 1 : 0)) * GP_XR * g1_per, GP_XR * g1_per);   // what this layer hands down
+  const unsigned tagbase = gen << 11;
+  const unsigned frag_off = (unsigned)((lane >> 5) * 1024 + (lane & 31) * 16);
+  auto slot1 = [&](int par, int r, int jb, int p) { return (unsigned)((((size_t)(par * NR + r) * GP_NKB + jb) * NC + p) * GP_SLOT); };   // (both rings)
+  auto slot2 = [&](int t, int r, int jb) { return (unsigned)((((size_t)t * NR + r) * GP_NKB + jb) * GP_SLOT); };
+
+  // ---- cooperative prologue ----
+  for (int e = tid; e < GP_NKB * 80; e += GP_WAVES * 64) {
+    const int jb = e / 80, ln = e - jb * 80, at = ln >= 64;
+    const int m = ln & 15, kq = at ? (ln - 64) >> 2 : ln >> 4;
+    const int cell = cell0 + (at ? 16 + (ln & 3) : 4 * (m & 3) + (m >> 2));
+    const bool cok = cell < H && cell < cell0 + CW;
+    const float* wr = L.Wp + (size_t)min(cell, H - 1) * ldP;
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int col = 16 * jb + 4 * kq + u;
+      v[u] = (cok && col < P) ? wr[min(col, P - 1)] : 0.f;
+    }
+    if (at) *reinterpret_cast<float4*>(&S.wpb[jb][ln - 64][0]) = make_float4(v[0], v[1], v[2], v[3]);
+    else *reinterpret_cast<float4*>(&S.wpa[jb][ln][0]) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  for (int e = tid; e < 3 * CW; e += GP_WAVES * 64) {
+    const int k = e / CW, cl = e - k * CW, cell = min(cell0 + cl, H - 1);
+    S.peep[cl][k] = (k == 0 ? L.wi : k == 1 ? L.wf : L.wo)[cell];
+  }
+  if (tid < 16) (&S.cnt_p[0])[tid] = 0u;                                // (all counters, dead)
+  __syncthreads();
+  // every counter through ONE base register + a compile-time offset (hipcc otherwise keeps a dozen LDS addresses in registers
+  // across the step loop; the zero is opaque to it)
+  unsigned zed;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(zed));
+  unsigned* const cnt = &S.cnt_p[0] + zed;
+  constexpr int C_P = 0, C_H = GP_NR, C_M = 2 * GP_NR, C_G = 3 * GP_NR, C_Z = 4 * GP_NR, C_F = 5 * GP_NR, C_DEAD = 6 * GP_NR;
+  const unsigned* dead = cnt + C_DEAD;
+  auto fail = [&]() {
+    if (lane == 0) {
+      __hip_atomic_store(cnt + C_DEAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(err, 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  const int len0 = a.len[row0 + lr], len1 = a.len[row0 + 16 + lr];
+
+  if (w < 8) {
+    // R waves (w < 4): K_h, the state-gradient product, dh and the cell.  X waves: K_x, the input-gradient product for the layer below.
+    // Resident weights: output tile pt = ww + 4 jj of the product's P (or I) columns, gate tile i:
+    //   A[row lr = column 16 pt + lr][k = cell 4 i + q] for the four k-steps gate 0..3
+    const bool isx = w >= 4;
+    const int ww = w & 3;
+    const bool noprod = isx && l == 0;                                   // layer 0 hands no input gradient down (a GEMM afterwards)
+    const float* KT = isx ? L.KxT : L.KhT;
+    const int ldK = isx ? L.ldI : ldP, PW = isx ? I : P, nkw = isx ? nkbx : nkb;
+    float4 kw[GP_KBW - 1][NT];
+#pragma unroll
+    for (int jj = 0; jj < GP_KBW; ++jj) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int col = 16 * (ww + 4 * jj) + lr, cell = cell0 + 4 * i + q;
+        const float* kr = KT + (size_t)min(cell, H - 1) * ldK + min(col, ldK - 1);
+        const size_t gs_ = (size_t)H * ldK;
+        float4 v = make_float4(kr[0], kr[gs_], kr[2 * gs_], kr[3 * gs_]);
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+        const bool ok = col < PW && cell < H && !noprod;
+        const float4 f = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        if (jj < (isx ? GP_KBW - 1 : GP_KBW - 2)) kw[jj][i] = f;
+        else if (jj == GP_KBW - 2) *reinterpret_cast<float4*>(&S.kl[ww][i][lane][0]) = f;
+        else if (ww < 2) *reinterpret_cast<float4*>(&S.kl[(isx ? 6 : 4) + ww][i][lane][0]) = f;
+      }
+    }
+    const float* const k4w = &S.kl[(isx ? 6 : 4) + (ww & 1)][0][lane][0];   // + i * 256
+    const float* const k3w = &S.kl[ww][0][lane][0];                     // + i * 256   (R waves)
+    const bool five = ww + 16 < nkw;                                    // this wave owns a fifth output tile
+    const float* const dzr = &S.dzB[0][0][lane][0];                     // + (r * NT + i) * 256
+    const GpBuf& bpub = isx ? b3x : b1;
+    // the product of one row tile and its publication: three output tiles in flight, a tile leaves as soon as its 4 NT products are done
+    auto product = [&](int r, int ring, unsigned tag) {
+      // (opaque copies: hipcc otherwise computes every slot offset and row address of the step loop once, in front of it, and
+      // spills them -- a scratch reload behind the write-through stores below waits for their acknowledgement)
+      const unsigned ln_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // (the lane id again: two VALU instructions, no register kept, no spill)
+      const unsigned fo = ((ln_ >> 5) << 10) | ((ln_ & 31u) << 4);
+      if (isx) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+      for (int j0 = 0; j0 < GP_KBW; j0 += 3) {
+        if (j0 + 3 >= GP_KBW && ww + 4 * j0 >= nkw) break;              // (uniform)
+        f32x4 acc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          const float4 b = *reinterpret_cast<const float4*>(dzr + (r * NT + i) * 256);
+          float4 ka[3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const int jj = j0 + j;
+            if (jj < GP_KBW - 2 || (jj == GP_KBW - 2 && isx)) ka[j] = kw[jj < GP_KBW - 1 ? jj : 0][i];
+            else if (jj == GP_KBW - 2) ka[j] = *reinterpret_cast<const float4*>(k3w + i * 256);
+            else if (jj == GP_KBW - 1) ka[j] = *reinterpret_cast<const float4*>(k4w + i * 256);
+            else ka[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int j = 0; j < 3; ++j) if (j0 + j < GP_KBW) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[j].x, b.x, acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) if (j0 + j < GP_KBW) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[j].y, b.y, acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) if (j0 + j < GP_KBW) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[j].z, b.z, acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) if (j0 + j < GP_KBW) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[j].w, b.w, acc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int jj = j0 + j;
+          if (jj < GP_KBW && ww + 4 * jj < nkw && (jj < GP_KBW - 1 || five)) {
+            const unsigned o = slot1(ring, r, ww + 4 * jj, c) + fo;
+#if defined(GP_ABL) && (GP_ABL & 8)
+            if (false)                                                 // timing ablation: half the published bytes
+#endif
+            gp_store(bpub, o, tag, acc[j][0], acc[j][1]);
+            gp_store(bpub, o + 512u, tag, acc[j][2], acc[j][3]);
+          }
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+    };
+
+    if (isx) {
+      // =============================== X waves ===============================
+      const int nsx = (nkbx - ww + 3) >> 2;                             // this wave's output tiles: ww, ww + 4, ...
+      // The stash of step t-1 (gate activations, c(t-2): 16 rows x 4 NT cells x 5 values per tile) travels through these waves into
+      // LDS a step ahead, as 16-byte row pieces (the mirror of the R waves' stash store): the R waves keep 80 weight registers and
+      // cannot hold it, and a load issued in front of the publication below does not wait for a write-through acknowledgement.
+      float4 pv[2];
+      auto fetch = [&](int t, int r) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int e = it * 256 + ww * 64 + ln;
+          const int cq = e % NT, pr = min(e / NT, 79), row = pr & 15, k = pr >> 4;
+          const size_t rowg = (size_t)t * N + row0 + 16 * r + row;
+          const int cell = min(cell0 + 4 * cq, H - 4);
+          pv[it] = *reinterpret_cast<const float4*>((k < 4 ? L.gates + rowg * H4 + k * H : L.c + rowg * H) + cell);
+        }
+      };
+      auto stage = [&](int r) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int e = it * 256 + ww * 64 + ln;
+          const int cq = e % NT, pr = e / NT, row = pr & 15, k = min(pr >> 4, 4);
+          if (e < 5 * 16 * NT) *reinterpret_cast<float4*>(&S.pfs[r][k][row][4 * cq]) = pv[it];
+        }
+        gp_signal(cnt + C_F + r, lane);
+      };
+#pragma unroll
+      for (int r = 0; r < NR; ++r) { fetch(T - 1, r); stage(r); }
+      for (int s = 0; s < T; ++s) {
+        const int t = T - 1 - s;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          GPTS(18 + 2 * r);
+          // back-pressure: ring slot s % GP_XR was summed by the layer below when it has published its dm(t + GP_XR)
+          if (!noprod && s >= GP_XR && !gp_poll(b2x, slot2(t + GP_XR, r, min(ww + 4 * (lane >> 1), nkbx - 1)) + (unsigned)(lane & 1) * 1024u + 1008u, lane < 2 * nsx, gen, err)) { fail(); return; }
+          if (!gp_wait(cnt + C_H + r, 4u * ((unsigned)s + 1u), dead)) return;       // dz(t) of the tile is in LDS (and the cells have read the stage)
+          GPTS(19 + 2 * r);
+          if (!noprod) {
+            product(r, s % GP_XR, tagbase | ((unsigned)s + 1u));
+            gp_signal(cnt + C_Z + r, lane);                                 // (the product has read dzB)
+          }
+          if (t > 0) { fetch(t - 1, r); stage(r); }                       // (needed by the cells a whole hand-off from now)
+        }
+      }
+#ifdef GP_TRACE
+      if (ww == 0) { const int i0_ = 18, i1_ = 22; GPT_FLUSH(); }
+#endif
+      return;
+    }
+
+    // =============================== R waves ===============================
+    const bool two = w + 4 < NT;                                         // this wave owns a second gate tile
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl)
+        *reinterpret_cast<float2*>(&S.car[w][sl][r][lane][0]) = make_float2(L.c[((size_t)T * N + row0 + 16 * r + lr) * H + min(cell0 + 4 * (w + 4 * sl) + q, H - 1)], 0.f);
+    float* const carw = &S.car[w][0][0][lane][0];                        // + (sl * NR + r) * 128
+    const float* const pfc = &S.pfs[0][0][lr][4 * w + q];                // + ((r * 5 + k) * 16) * CW + sl * 16
+    const float* const mbw = &S.mB[0][w][lane][0];                       // + (r * GP_NKB + 4 jj) * 256
+    const float* const wpw = &S.wpa[w][lane][0];                         // + 4 jj * 256
+    const float* const wpv = &S.wpb[w][4 * q + (lr >> 2)][0];            // + 4 jj * 64
+    float* const pdw = &S.pd[w][0][0][lane];                             // + (r * NT + i) * 64
+    const float* const pdc = &S.pd[0][0][w][lane];                       // + (k * NR * NT + r * NT + 4 sl) * 64
+    const float* const pwc = &S.peep[4 * w + q][0];                      // + sl * 64
+    float* const dzw = &S.dzB[0][w][lane][0];                            // + (r * NT + 4 sl) * 256
+    float* const stc = &S.st[0][lr][4 * w + q];                          // + g * GP_ROWS * CW + r * 16 * CW + sl * 16
+    for (int s = 0; s < T; ++s) {
+      const int t = T - 1 - s;
+#ifdef GP_TRACE
+      if (s == 0 && w == 0 && lane == 0) gp_tr[0][22] = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        GPTS(6 * r + 0);
+        if (!gp_wait(cnt + C_M + r, 2u * ((unsigned)s + 1u), dead)) return;      // dm(t) of the tile is in LDS
+        GPTS(6 * r + 1);
+        {
+          // dh^T[cells][rows] = W_p . dm^T, this wave's k-blocks w, w + 4, ...
+          f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+          __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+          for (int jj = 0; jj < GP_KBW; ++jj) {
+            if (w + 4 * jj < nkb) {
+              const float4 b = *reinterpret_cast<const float4*>(mbw + (r * GP_NKB + 4 * jj) * 256);
+              const float4 a0 = *reinterpret_cast<const float4*>(wpw + 4 * jj * 256), a1 = *reinterpret_cast<const float4*>(wpv + 4 * jj * 64);
+              d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, d0, 0, 0, 0);
+              d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, d1, 0, 0, 0);
+              d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, d0, 0, 0, 0);
+              d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, d1, 0, 0, 0);
+              d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b.z, d0, 0, 0, 0);
+              d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b.z, d1, 0, 0, 0);
+              d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b.w, d0, 0, 0, 0);
+              d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b.w, d1, 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pdw[(r * NT + i) * 64] = d0[i];
+          if (NT > 4) pdw[(r * NT + 4) * 64] = d1[0];
+        }
+        GPTS(6 * r + 2);
+        gp_signal(cnt + C_P + r, lane);
+        if (!gp_wait(cnt + C_P + r, 4u * ((unsigned)s + 1u), dead)) return;
+        if (l > 0 && s > 0 && !gp_wait(cnt + C_Z + r, 4u * (unsigned)s, dead)) return;     // the X waves have taken dz(t+1)
+        if (!gp_wait(cnt + C_F + r, 4u * ((unsigned)s + 1u), dead)) return;                // the stash of step t is in LDS
+        GPTS(6 * r + 3);
+        const bool live = t < (r ? len1 : len0);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+          if (sl == 0 || two) {
+            const float dh = ((pdc[(0 * NR * NT + r * NT + 4 * sl) * 64] + pdc[(1 * NR * NT + r * NT + 4 * sl) * 64]) + pdc[(2 * NR * NT + r * NT + 4 * sl) * 64]) + pdc[(3 * NR * NT + r * NT + 4 * sl) * 64];
+            const f32x4 pw = *reinterpret_cast<const f32x4*>(pwc + sl * 64);
+            const float* const pq = pfc + r * 5 * 16 * CW + sl * 16;
+            const float gi = pq[0], gj = pq[16 * CW], gf = pq[2 * 16 * CW], go = pq[3 * 16 * CW], cp = pq[4 * 16 * CW];
+            const float2 cv = *reinterpret_cast<const float2*>(carw + (sl * NR + r) * 128);
+            const float cc = cv.x, dcv = cv.y;
+            const float tc = gp_tanh(cc);
+            const float dao = dh * tc * go * (1.f - go);
+            const float dcn = dcv + dh * go * (1.f - tc * tc) + dao * pw[2];
+            const float daf = dcn * cp * gf * (1.f - gf);
+            const float dai = dcn * gj * gi * (1.f - gi);
+            const float dj = dcn * gi * (1.f - gj * gj);
+            const float dcx = live ? dcn * gf + dai * pw[0] + daf * pw[1] : dcv;
+            *reinterpret_cast<float2*>(carw + (sl * NR + r) * 128) = make_float2(cp, dcx);
+            const f32x4 dz = {live ? dai : 0.f, live ? dj : 0.f, live ? daf : 0.f, live ? dao : 0.f};
+            *reinterpret_cast<f32x4*>(dzw + (r * NT + 4 * sl) * 256) = dz;
+            float* const d = stc + r * 16 * CW + sl * 16;
+            d[0 * GP_ROWS * CW] = dz[0]; d[1 * GP_ROWS * CW] = dz[1]; d[2 * GP_ROWS * CW] = dz[2]; d[3 * GP_ROWS * CW] = dz[3];
+          }
+        }
+        gp_signal(cnt + C_H + r, lane);
+        GPTS(6 * r + 4);
+        if (!gp_wait(cnt + C_H + r, 4u * ((unsigned)s + 1u), dead)) return;       // every cell's dz of the tile is in LDS
+        if (t > 0) product(r, s & 1, tagbase | ((unsigned)s + 1u));              // (dm(-1) has no consumer)
+        GPTS(6 * r + 5);
+        // dz(t) over the gate activations of the stash, a quarter of the tile per R wave: NT consecutive lanes write one 16 NT-byte row piece
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int it = 0; it < (4 * 16 * NT + 255) / 256; ++it) {
+          const int e = it * 256 + w * 64 + ln;
+          const int cq = e % NT, pr = e / NT, row = 16 * r + (pr & 15), k = min(pr >> 4, 3);
+          const float4 v = *reinterpret_cast<const float4*>(&S.st[k][row][4 * cq]);
+          float* dst = L.gates + ((size_t)t * N + row0 + row) * H4 + k * H + cell0 + 4 * cq;
+          if (e < 4 * 16 * NT && cell0 + 4 * cq < H) *reinterpret_cast<float4*>(dst) = v;
+        }
+      }
+    }
+#ifdef GP_TRACE
+    if (w == 0) { { const int i0_ = 0, i1_ = 12; GPT_FLUSH(); } { const int i0_ = 22, i1_ = 24; GPT_FLUSH(); } }
+#endif
+    return;
+  }
+
+  // =============================== G waves: reduce, publish, gather (tile gw & 1) ===============================
+  __builtin_amdgcn_s_setprio(3);
+  const int gw = w - 8, r = gw & 1, gp = gw >> 1;
+  float* const mbg = &S.mB[r][gp][lane][0];                            // + 2 n * 256
+  const int nvg = (nkb - gp + 1) >> 1;                                 // this wave's k-blocks: gp, gp + 2, ...
+  const bool reducer = c < 2 * nkb;
+  const int jbr = c >> 1, hh = c & 1;
+  const int ppw = (NC + 1) >> 1, pp0 = gp * ppw, pn = max(0, min(ppw, NC - pp0));
+  const int rrow = row0 + 16 * r + ((32 * hh + (lane & 31)) & 15), rcol = 16 * jbr + 4 * ((32 * hh + (lane & 31)) >> 4) + 2 * (lane >> 5);
+  const int rlen = a.len[rrow];
+  for (int s = 0; s < T; ++s) {
+    const int t = T - 1 - s;
+    GPTS(12);
+    float tot0 = 0.f, tot1 = 0.f;
+    if (reducer) {
+      float2 dtop = make_float2(0.f, 0.f);
+      if (top && rcol < a.ld_dout) dtop = *reinterpret_cast<const float2*>(a.dout_top + ((size_t)t * N + rrow) * a.ld_dout + rcol);
+      float s0 = 0.f, s1 = 0.f;
+      if (!top) {
+        // the input-gradient partials of the layer above at time t (published a diagonal ago as a rule: read first, poll if not there)
+        unsigned lo[20];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) lo[k] = slot1(s % GP_XR, r, jbr, min(pp0 + k, NC - 1)) + (unsigned)hh * 1024u;
+        if (!gp_sweep<20, false, 20, false>(b3, lo, pn, (unsigned)lane * 16u, slot1(s % GP_XR, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 1024u + 1008u, lane < pn,
+                                     tagbase | ((unsigned)s + 1u), err, [&](int k, float va, float vb) { if (k == 0) { s0 = va; s1 = vb; } else if (k < pn) { s0 += va; s1 += vb; } })) { fail(); return; }
+      }
+      GPTS(13);
+      if (s > 0) {
+        // the state-gradient partials of this layer from time t + 1
+        unsigned lo[20];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) lo[k] = slot1((s - 1) & 1, r, jbr, min(pp0 + k, NC - 1)) + (unsigned)hh * 1024u;
+        float u0 = 0.f, u1 = 0.f;
+        if (!gp_sweep<20, true, 20, false>(b1, lo, pn, (unsigned)lane * 16u, slot1((s - 1) & 1, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 1024u + 1008u, lane < pn,
+                                    tagbase | (unsigned)s, err, [&](int k, float va, float vb) { if (k == 0) { u0 = va; u1 = vb; } else if (k < pn) { u0 += va; u1 += vb; } })) { fail(); return; }
+        s0 += u0; s1 += u1;
+      }
+      GPTS(14);
+      *reinterpret_cast<float2*>(&S.gs[s & 1][r][gp][lane][0]) = make_float2(s0, s1);
+      gp_signal(cnt + C_G + r, lane);
+      if (!gp_wait(cnt + C_G + r, 2u * ((unsigned)s + 1u), dead)) return;
+      const float2 g0 = *reinterpret_cast<const float2*>(&S.gs[s & 1][r][0][lane][0]), g1 = *reinterpret_cast<const float2*>(&S.gs[s & 1][r][1][lane][0]);
+      const bool live = t < rlen;
+      tot0 = live ? (g0.x + g1.x) + dtop.x : 0.f; tot1 = live ? (g0.y + g1.y) + dtop.y : 0.f;
+      if (gp == 0) gp_store(b2, slot2(t, r, jbr) + (unsigned)hh * 1024u + (unsigned)lane * 16u, gen, tot0, tot1);
+      GPTS(15);
+    }
+    {
+      // gather dm(t) of the tile: k-blocks gp, gp + 2, ... as B fragments of dh = dm . W_p^T
+      unsigned lo[18];
+#pragma unroll
+      for (int n = 0; n < 9; ++n) {
+        const unsigned o = slot2(t, r, min(gp + 2 * n, nkb - 1));
+        lo[2 * n] = o; lo[2 * n + 1] = o + 512u;
+      }
+      float mv[18][2];
+      if (!gp_sweep<18, true, 18, true>(b2, lo, 2 * nvg, frag_off, slot2(t, r, min(gp + 2 * (lane >> 1), nkb - 1)) + (unsigned)(lane & 1) * 1024u + 1008u,
+                                  lane < 2 * nvg, gen, err, [&](int k, float va, float vb) { mv[k][0] = va; mv[k][1] = vb; })) { fail(); return; }
+      GPTS(16);
+#pragma unroll
+      for (int n = 0; n < 9; ++n)
+        if (n < nvg) *reinterpret_cast<f32x4*>(mbg + 2 * n * 256) = f32x4{mv[2 * n][0], mv[2 * n][1], mv[2 * n + 1][0], mv[2 * n + 1][1]};
+      gp_signal(cnt + C_M + r, lane);
+      GPTS(17);
+    }
+    if (reducer && gp == 1 && rcol < ldP) *reinterpret_cast<float2*>(L.dmt + ((size_t)t * N + rrow) * ldP + rcol) = make_float2(tot0, tot1);
+  }
+#ifdef GP_TRACE
+  if (gw == 0) { const int i0_ = 12, i1_ = 18; GPT_FLUSH(); }
+#endif
+}
+
+template <int NT>
+__global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_bwd(const GPersistArgs a) {
+  __shared__ __attribute__((aligned(16))) GpLdsB<NT> S;
+  gu32* ctl = (gu32*)a.ctl;
+  const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  gp_bwd_body<NT>(a, gen, S);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == gridDim.x - 1) {
+      if (__hip_atomic_load(ctl + DP_CTL_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        a.L[0].gates[0] = __builtin_nanf("");
+      __hip_atomic_store(ctl + DP_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned g1 = gen + 1u;
+      __hip_atomic_store(ctl + DP_CTL_GEN, g1 >= (1u << 21) ? 1u : g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 static int gp_grid(const GPersistArgs& a) {
   const int ngr = a.N / GP_ROWS, xpg = 8 / ngr, nwg = a.nl * a.NC;
   return 8 * ((nwg + xpg - 1) / xpg);
@@ -611,9 +1063,14 @@ bool gpersist_plan(GPersistArgs& a) {
 }
 size_t gpersist_gran1_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * 2 * GP_NCH * a.NC * GP_SLOT; }
 size_t gpersist_gran2_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * a.T * GP_NCH * GP_SLOT; }
+size_t gpersist_gran3_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * GP_XR * GP_NCH * a.NC * GP_SLOT; }
 
 void launch_glstm_fwd(const GPersistArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_glstm_fwd<5>, dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
+  ++g_chain_launches;
+}
+void launch_glstm_bwd(const GPersistArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_glstm_bwd<5>, dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
   ++g_chain_launches;
 }
 

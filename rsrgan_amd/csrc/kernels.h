@@ -169,6 +169,7 @@ struct GPersistLayer {
   const float *KxT, *KhT;                         // k-contiguous transposed copies of the kernel: [4H][ldI], [4H][ldP] (zero padding)
   const float *bias, *wi, *wf, *wo, *Wp;          // bias [4H], peepholes [H], projection [H][ldP]
   float *gates, *c, *h, *mst, *out;               // the layer's stash (model.h LstmStash); layer 0: gates holds zx = x.K_x + bias on entry
+  float* dmt;                                     // backward: [T][N][ldP] total dm per step (the projection's weight gradient reads it)
   int I, P, ldI, ldP, ldH;
 };
 struct GPersistArgs {
@@ -179,11 +180,16 @@ struct GPersistArgs {
   unsigned long long *gran1, *gran2;              // hop 1 (partial projections, ring of two steps), hop 2 (m chunks, one slot per step); zeroed once
   unsigned* ctl;                                  // control block [DP_CTL_*]
   float forget_bias;
+  unsigned long long* gran3;                      // backward: the partial input gradients a layer hands to the layer below (ring of GP_XR steps); zeroed once
+  const float* dout_top;                          // backward: [T][N][ld_dout] gradient of the top layer's masked outputs
+  int ld_dout;
 };
 bool gpersist_plan(GPersistArgs& a);              // fills NT / NC; false: shape not supported
 size_t gpersist_gran1_bytes(const GPersistArgs& a);
 size_t gpersist_gran2_bytes(const GPersistArgs& a);
+size_t gpersist_gran3_bytes(const GPersistArgs& a);
 void launch_glstm_fwd(const GPersistArgs& a, hipStream_t s);
+void launch_glstm_bwd(const GPersistArgs& a, hipStream_t s);      // gates: activations in, dz out; needs c, dmt, dout_top; no input gradient for layer 0
 extern long long g_chain_launches;
 void launch_floor_chain(float* a, float* b, int n, int mode, hipStream_t s);
 

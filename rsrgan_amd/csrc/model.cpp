@@ -426,7 +426,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     const unsigned ctl0[DP_CTL_WORDS] = {1u, 0u, 0u, 0u};
     HIPC(hipMemcpy(dp_ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice));
   }
-  if (const char* e = getenv("RSRGAN_GPERSIST")) gp_env = atoi(e);        // bit 0: the generator's forward recurrence
+  if (const char* e = getenv("RSRGAN_GPERSIST")) gp_env = atoi(e);        // bit 0: the generator's forward recurrence, bit 1: its BPTT
   if (gp_env && !g_dnn()) {
     GPersistArgs ga{};
     if (gpersist_args(ga, Tmax)) {
@@ -434,6 +434,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
       gp_gran2_bytes = gpersist_gran2_bytes(ga);
       gp_gran2 = (unsigned long long*)alloc<float>(gp_gran2_bytes / sizeof(float));
       gp_ctl = (unsigned*)alloc<float>(16);
+      if (gp_env & 2) gp_gran3 = (unsigned long long*)alloc<float>(gpersist_gran3_bytes(ga) / sizeof(float));
       if (gp_gran1 && gp_gran2 && gp_ctl) {
         const unsigned ctl0[DP_CTL_WORDS] = {1u, 0u, 0u, 0u};
         HIPC(hipMemcpy(gp_ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice));
@@ -911,23 +912,23 @@ bool Model::persist_forward(Chain& ch, int T, hipStream_t s) {
 // The generator's stack as ONE persistent launch (gpersist.hip).  Same stash as the wavefront launches leave (gates, c, h, mst, out of
 // every layer), so the backward pass does not know which forward ran.
 bool Model::gpersist_args(GPersistArgs& a, int T) const {
-  if (!(gp_env & 1) || gl.empty() || gl.size() > (size_t)GP_MAXL || cfg.g_type != RSRGAN_G_LSTM) return false;
+  if (!gp_env || gl.empty() || gl.size() > (size_t)GP_MAXL || cfg.g_type != RSRGAN_G_LSTM) return false;
   a = GPersistArgs{};
   a.nl = (int)gl.size(); a.N = B; a.T = T; a.H = gl[0].H; a.len = len_dev;
-  a.gran1 = gp_gran1; a.gran2 = gp_gran2; a.ctl = gp_ctl; a.forget_bias = cfg.forget_bias;
+  a.gran1 = gp_gran1; a.gran2 = gp_gran2; a.gran3 = gp_gran3; a.ctl = gp_ctl; a.forget_bias = cfg.forget_bias;
   for (size_t l = 0; l < gl.size(); ++l) {
     const LstmLayer& L = gl[l]; const LstmStash& S = g_st[l];
     if (!L.has_proj || L.H != a.H) return false;
     GPersistLayer& G_ = a.L[l];
     G_.KxT = L.KxT; G_.KhT = L.KhT; G_.bias = G.W(L.tb); G_.wi = G.W(L.twi); G_.wf = G.W(L.twf); G_.wo = G.W(L.two); G_.Wp = G.W(L.tWp);
-    G_.gates = S.gates; G_.c = S.c; G_.h = S.h; G_.mst = S.mst; G_.out = S.out;
+    G_.gates = S.gates; G_.c = S.c; G_.h = S.h; G_.mst = S.mst; G_.out = S.out; G_.dmt = S.dmt;
     G_.I = L.I; G_.P = L.P; G_.ldI = L.ldI; G_.ldP = L.ldP; G_.ldH = L.ldH;
   }
   return gpersist_plan(a);
 }
 
 bool Model::persist_forward_g(int T, hipStream_t s) {
-  if (!gp_gran1 || !wavefront() || seq_drop_on()) return false;
+  if (!gp_fwd_on() || !wavefront() || seq_drop_on()) return false;
   GPersistArgs a{};
   if (!gpersist_args(a, T) || gpersist_gran2_bytes(a) > gp_gran2_bytes) return false;
   const LstmLayer& L0 = gl[0];
@@ -949,6 +950,33 @@ bool Model::persist_forward_g(int T, hipStream_t s) {
     return true;
   }
   launch_glstm_fwd(a, s);
+  return true;
+}
+
+// BPTT through the generator's stack as ONE persistent launch (gpersist.hip k_glstm_bwd): dz over the gate activations of every
+// layer's stash, dm per step in dmt.  Layer 0's input gradient (the input FC's d(h0)) is one GEMM over the dz stash afterwards.
+bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only) {
+  if (!gp_gran1 || !gp_gran3 || !(gp_env & 2) || !wavefront() || seq_drop_on() || ch.size() != gl.size()) return false;
+  GPersistArgs a{};
+  if (!gpersist_args(a, T) || gpersist_gran2_bytes(a) > gp_gran2_bytes) return false;
+  for (size_t l = 0; l < ch.size(); ++l) {
+    const LayerRun& R = ch[l];
+    if (R.L != &gl[l] || R.S != &g_st[l] || R.res_in || R.res_out || R.row0 != 0 || R.Ns != R.N || R.N != a.N || R.len != a.len) return false;
+    if (l > 0 && (R.din_accumulate || ch[l].din != ch[l - 1].dout)) return false;
+  }
+  if (ch[0].din && ch[0].din_accumulate) return false;
+  a.dout_top = ch.back().dout; a.ld_dout = gl.back().ldP;
+  if (!a.dout_top) return false;
+  if (check_only) return true;
+  launch_glstm_bwd(a, s);
+  if (ch[0].din) {               // d(inputs of layer 0) = dZ_0 . K_x^T, batched over time
+    const LayerRun& R = ch[0];
+    const int H4 = 4 * R.L->H;
+    gemm(R.S->gates, H4, true, R.ps->W(R.L->tK), H4, true, R.din, R.L->ldI, T * R.N, R.L->I, H4, nullptr, 0, 0.f, false, s);
+  }
+  if (!defer_wgrads)
+    for (auto& R : ch)
+      if (R.want_wgrads) layer_wgrads(R, T, s);
   return true;
 }
 
@@ -1243,7 +1271,7 @@ void Model::g_backward_pass(int T, float* dy, hipStream_t s) {
       ch[l].dout = cur; ch[l].din = other; ch[l].din_accumulate = false;
       std::swap(cur, other);
     }
-    rnn_backward(chains, T, s);
+    if (!persist_backward_g(ch, T, s)) rnn_backward(chains, T, s);
     // through leakyrelu and the input FC (models/lstm.py:82-87)
     launch_lrelu_bwd(g_h0, cur, (size_t)R, P, ldP, cfg.lrelu_alpha, s);
     gemm(x_tm, ldDin, false, cur, ldP, false, G.Gd(g_fc_in_w), ldP, Din, P, R, nullptr, 0, 0.f, false, s);
@@ -1279,7 +1307,7 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
   // discriminator input rows [0,B) = labels + noise_real (gan_rnn_placeholder.py:207,212; utils/ops.py:19-30)
   launch_add_noise_rows(lab_tm, nr, xd, B, T, Dout, ldDout, 2 * B, 0, s);
   bool g_done = false;
-  if (wavefront() && gp_gran1) {
+  if (wavefront() && gp_fwd_on()) {
     // the generator as ONE persistent launch, then both discriminator calls stacked (N = 2B) as another
     g_forward_head(T, s);
     g_done = persist_forward_g(T, s);
@@ -1296,7 +1324,7 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
   } else if (wavefront()) {
     // ONE wave: G's layers | D(real) (independent of G) | per-step output FC -> y_t, xd fake rows |
     // D(fake) two diagonals behind G's top layer
-    if (!gp_gran1) g_forward_head(T, s);
+    if (!gp_fwd_on()) g_forward_head(T, s);
     const int Lg = (int)gl.size(), ldP = pad4(gR);
     std::vector<Chain> chains{g_chain(T)};
     std::vector<int> offs{0};
@@ -1410,14 +1438,14 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   run_seg(seg_key(SEG_G_MAIN, T, kbits), s, [&]() {
   bool g_done = false;
   if (!reuse && !wavefront()) g_forward(T, s);
-  if (!reuse && wavefront() && gp_gran1) {
+  if (!reuse && wavefront() && gp_fwd_on()) {
     g_forward_head(T, s);
     g_done = persist_forward_g(T, s);
     if (g_done) g_forward_tail(T, s);
   }
   if (!reuse && wavefront() && !g_done) {
     // ONE forward wave: G's layers | per-step output FC (-> y_t and D's input rows, noise added) | D's layers
-    if (!gp_gran1) g_forward_head(T, s);
+    if (!gp_fwd_on()) g_forward_head(T, s);
     std::vector<Chain> chains{g_chain(T)};
     std::vector<int> offs{0};
     if (!d_dnn()) { chains.push_back(d_chain(B, B, 0)); offs.push_back(Lg + 1); }
@@ -1458,7 +1486,19 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     std::vector<int> offs{0, Ld + 1};
     std::vector<FcStage> fcs{F};
     defer_wgrads = bucketed;
-    rnn_backward(bw_chains, T, s, &offs, &fcs);
+    if (dl[0].ldI == ldDout && persist_backward_g(bw_chains[1], T, s, true)) {
+      // the generator's BPTT as ONE persistent launch: the discriminator's data gradient first and alone (its own persistent launch,
+      // layer 0's input gradient as a GEMM on top of the mse term in dy), then the output FC's data gradient as one GEMM
+      std::vector<Chain> dc1(1, bw_chains[0]);
+      dc1[0][0].din = nullptr;
+      if (!persist_backward(dc1[0], T, s)) rnn_backward(dc1, T, s);
+      const int H4d = 4 * dl[0].H;
+      gemm(d_st[0].gates, H4d, true, D.W(dl[0].tK), H4d, true, dy, ldDout, R, dl[0].I, H4d, nullptr, 0, 0.f, true, s);
+      gemm(dy, ldDout, true, G.W(g_fc_out_w), ldDout, true, g_dA, ldP, R, P, Dout, nullptr, 0, 0.f, false, s);
+      persist_backward_g(bw_chains[1], T, s);
+    } else {
+      rnn_backward(bw_chains, T, s, &offs, &fcs);
+    }
     defer_wgrads = false;
     // output FC parameter gradients (batched over time, dy is complete now)
     gemm(g_ins[Lg], ldP, false, dy, ldDout, false, G.Gd(g_fc_out_w), ldDout, P, Dout, R, nullptr, 0, 0.f, false, s);

@@ -153,12 +153,14 @@ struct Model {
   bool persist_backward(Chain& ch, int T, hipStream_t s); // BPTT of the chain + its weight gradients; false: not applicable
   // ---- persistent GENERATOR recurrence (gpersist.hip): the forward pass of the generator's stack as ONE launch (weights resident
   // in VGPRs / LDS for all T steps); RSRGAN_GPERSIST bit 0.  Needs B % 32 == 0, projected cells, no residual sums, no dropout.
-  unsigned long long *gp_gran1 = nullptr, *gp_gran2 = nullptr;
+  unsigned long long *gp_gran1 = nullptr, *gp_gran2 = nullptr, *gp_gran3 = nullptr;
   unsigned* gp_ctl = nullptr;
   size_t gp_gran2_bytes = 0;
-  int gp_env = 1;                                         // RSRGAN_GPERSIST: bit 0 the forward launch (0: the launch-per-phase wavefront)
+  int gp_env = 3;                                         // RSRGAN_GPERSIST: bit 0 the forward launch, bit 1 the backward launch (0: the launch-per-phase wavefront)
+  bool gp_fwd_on() const { return gp_gran1 && (gp_env & 1); }
   bool gpersist_args(GPersistArgs& a, int T) const;       // false: not applicable
   bool persist_forward_g(int T, hipStream_t s);           // layer 0's x-part batched first; fills the complete stash of every layer
+  bool persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only = false);   // BPTT of the generator chain (k_glstm_bwd), layer 0's input gradient as a GEMM, the weight gradients unless deferred
   // fully-connected stacks: models/dnn.py generator and models/discriminator_dnn.py discriminator
   std::vector<FcLayer> gfc, dfc;
   std::vector<float*> g_act, d_act;        // act[l] = input of FC layer l, act[L] = output of the stack

@@ -26,6 +26,7 @@ static float* dal(size_t n, float v) {
 
 int main(int argc, char** argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 64, T = argc > 2 ? atoi(argv[2]) : 100, nl = argc > 3 ? atoi(argv[3]) : 3, H = 760, P = 280;
+  const bool bwd = argc > 4 && argv[4][0] == 'b';                   // k_glstm_bwd instead (same shapes, synthetic stash)
   GPersistArgs a{};
   a.nl = nl; a.N = N; a.T = T; a.H = H; a.forget_bias = 1.f;
   std::vector<int> len(N, T);
@@ -38,25 +39,28 @@ int main(int argc, char** argv) {
     L.Wp = dal((size_t)H * P, 0.03f);
     L.gates = dal((size_t)T * N * 4 * H, 0.5f); L.c = dal((size_t)(T + 1) * N * H, 0.f); L.h = dal((size_t)T * N * H, 0.f);
     L.mst = dal((size_t)(T + 1) * N * P, 0.f); L.out = dal((size_t)T * N * P, 0.f);
+    if (bwd) L.dmt = dal((size_t)T * N * P, 0.f);
   }
+  if (bwd) { a.dout_top = dal((size_t)T * N * P, 0.01f); a.ld_dout = P; }
   if (!gpersist_plan(a)) { printf("unsupported shape\n"); return 1; }
   const size_t g1 = gpersist_gran1_bytes(a), g2 = gpersist_gran2_bytes(a);
   CK(hipMalloc(&a.gran1, g1)); CK(hipMalloc(&a.gran2, g2)); CK(hipMalloc(&a.ctl, 64));
   CK(hipMemset(a.gran1, 0, g1)); CK(hipMemset(a.gran2, 0, g2));
+  if (bwd) { const size_t g3 = gpersist_gran3_bytes(a); CK(hipMalloc(&a.gran3, g3)); CK(hipMemset(a.gran3, 0, g3)); }
   { const unsigned c0[4] = {1u, 0u, 0u, 0u}; CK(hipMemcpy(a.ctl, c0, 16, hipMemcpyHostToDevice)); }
   hipStream_t s; CK(hipStreamCreate(&s));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e9f;
   for (int it = 0; it < 5; ++it) {
     CK(hipEventRecord(e0, s));
-    launch_glstm_fwd(a, s);
+    if (bwd) launch_glstm_bwd(a, s); else launch_glstm_fwd(a, s);
     CK(hipEventRecord(e1, s));
     CK(hipStreamSynchronize(s));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     best = ms < best ? ms : best;
   }
   unsigned ctl[4]; CK(hipMemcpy(ctl, a.ctl, 16, hipMemcpyDeviceToHost));
-  printf("k_glstm_fwd N=%d T=%d layers=%d (NT=%d NC=%d, %zu + %zu MB of granule slots): %.1f us per launch = %.2f us per step (err word %u, generation %u)\n",
+  printf(bwd ? "k_glstm_bwd N=%d T=%d layers=%d (NT=%d NC=%d, %zu + %zu MB of granule slots): %.1f us per launch = %.2f us per step (err word %u, generation %u)\n" : "k_glstm_fwd N=%d T=%d layers=%d (NT=%d NC=%d, %zu + %zu MB of granule slots): %.1f us per launch = %.2f us per step (err word %u, generation %u)\n",
          N, T, nl, a.NT, a.NC, g1 >> 20, g2 >> 20, best * 1e3f, best * 1e3f / T, ctl[2], ctl[0]);
 #ifdef GP_COUNT
   { unsigned cn[8]; CK(hipMemcpyFromSymbol(cn, HIP_SYMBOL(rsr::g_gp_cnt), sizeof(cn)));
@@ -67,8 +71,14 @@ int main(int argc, char** argv) {
   // R wave 0, tile r (stamps 6 r + ..): 0 top, 1 x-part there, 2 m(t-1) there, 3 recurrent MFMAs + tiles written, 4 all partials there, 5 cell done
   // G wave 0 (tile 0): 12 top, 13 all cells done, 14 projection + publish issued, 15 hop 1 swept, 16 half chunk published, 17 hop 2 swept
   // X wave 0: 18 / 20 sweep start (tile 0 / 1), 19 / 21 sweep done; 22, 23: prologue
-  const char* rn[5] = {"wait: x-part of the step (X waves)", "wait: m(t-1) gathered (hop 2)", "recurrent MFMAs + tiles -> LDS",
+  const char* rnf[5] = {"wait: x-part of the step (X waves)", "wait: m(t-1) gathered (hop 2)", "recurrent MFMAs + tiles -> LDS",
                        "wait: the other R waves' partials (+ stash gone)", "cell"};
+  // backward: R wave 0: 0 top, 1 dm(t) there, 2 dh MFMAs + partials written, 3 all partials there (and the X waves have taken dz(t+1)), 4 cell done,
+  // 5 state-gradient product + publish issued (then: dz to the stash, prefetch of step t-1); G wave 0: 12 top, 13 input-gradient partials
+  // summed, 14 state-gradient partials summed, 15 half chunk published, 16 hop 2 swept, 17 dm in LDS; X wave 0: 18 / 20 top, 19 / 21 dz there
+  const char* rnb[5] = {"wait: dm(t) gathered (hop 2)", "dh = dm . W_p^T MFMAs + partials -> LDS", "wait: the other R waves' partials (+ X waves took dz)",
+                        "cell gradient", "state-gradient product + publish (after all cells)"};
+  const char** rn = bwd ? rnb : rnf;
   const int ngr = N / 32, xpg = 8 / ngr, nblk = 8 * ((nl * a.NC + xpg - 1) / xpg);
   for (int l = 0; l < nl; ++l) {
     double ph[2][5] = {{0}}, per = 0, gx[6] = {0}, xs[2] = {0}, pro = 0, lag = 0; long cnt = 0, nb_ = 0;
@@ -91,10 +101,16 @@ int main(int argc, char** argv) {
     if (!cnt) continue;
     printf("layer %d, shader-clock cycles (s_memtime), mean over reducer workgroups and steps 10..%d: period %.0f (tile 1 enters %.0f behind tile 0)\n", l, T - 2 < 22 ? T - 2 : 22, per / cnt, lag / cnt);
     for (int i = 0; i < 5; ++i) printf("   R0 %-52s tile 0 %6.0f   tile 1 %6.0f\n", rn[i], ph[0][i] / cnt, ph[1][i] / cnt);
+    if (bwd) {
+      printf("   G0 (tile 0) input-gradient partials (layer above) %.0f | state-gradient partials (hop 1) %.0f | reduce + publish half chunk %.0f | hop-2 sweep %.0f | dm -> LDS %.0f\n",
+             gx[0] / cnt, gx[1] / cnt, gx[2] / cnt, gx[3] / cnt, gx[4] / cnt);
+      if (l > 0) printf("   X0 back-pressure poll + wait for dz, tile 0 / 1: %.0f / %.0f\n", xs[0] / cnt, xs[1] / cnt);
+    } else {
     printf("   G0 (tile 0) wait for the cells %.0f | projection + publish (issue) %.0f | hop-1 sweep %.0f | reduce + publish half chunk %.0f | hop-2 sweep %.0f\n",
            gx[0] / cnt, gx[1] / cnt, gx[2] / cnt, gx[3] / cnt, gx[4] / cnt);
     printf("   tile 0: cell(t) done on R0 -> m(t) in LDS (the whole hand-off): %.0f\n", gx[5] / cnt);
     if (l > 0) printf("   X0 sweep of x(t), tile 0 / 1: %.0f / %.0f\n", xs[0] / cnt, xs[1] / cnt);
+    }
     printf("   prologue (kernel entry -> R0 enters step 0): %.0f cycles\n", pro / nb_);
   }
   return 0;
