@@ -94,6 +94,9 @@ __device__ __forceinline__ GpBuf gp_buf(const void* p, size_t bytes) {
 }
 __device__ __forceinline__ void gp_store(const GpBuf& b, unsigned off, unsigned tag, float v0, float v1) {
   const u32x4 x = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
+#if defined(GP_ABL) && (GP_ABL & 16)
+  if (off & 512u) return;                                                // timing ablation: half the bytes of every hand-off (a tag-free payload)
+#endif
   __builtin_amdgcn_raw_buffer_store_b128(x, b.rs, off, 0, GP_SC1);
 }
 // One wave waits for NL 16-byte-per-lane pieces (wave-uniform byte offsets lo[], + this lane's lane_off) and hands them to
@@ -126,7 +129,11 @@ __device__ __forceinline__ bool gp_sweep(const GpBuf& b, const unsigned (&lo)[NL
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
         const int k = k0 + j < NL ? k0 + j : NL - 1;
+#if defined(GP_ABL) && (GP_ABL & 16)
+        x[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, ((k < nl ? of[k] : of[0]) + lane_off) & ~512u, 0, AUX);
+#else
         x[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, (k < nl ? of[k] : of[0]) + lane_off, 0, AUX);   // (unconditional)
+#endif
       }
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
@@ -162,7 +169,11 @@ __device__ __forceinline__ bool gp_sweep(const GpBuf& b, const unsigned (&lo)[NL
     }
     read_now = true;
     for (unsigned polls = 0;; ++polls) {
+#if defined(GP_ABL) && (GP_ABL & 16)
+      const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(b.rs, so & ~512u, 0, GP_SC1 | GP_VOL);
+#else
       const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(b.rs, so, 0, GP_SC1 | GP_VOL);
+#endif
       if (__all(!son || (y[1] == tag && y[3] == tag))) break;
       asm volatile("" ::: "memory");
       if ((polls & 63) == 63) {
@@ -630,7 +641,11 @@ struct GpLdsB {
 __device__ __forceinline__ bool gp_poll(const GpBuf& b, unsigned so, bool son, unsigned tag, gu32* err) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (unsigned polls = 0;; ++polls) {
+#if defined(GP_ABL) && (GP_ABL & 16)
+    const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(b.rs, so & ~512u, 0, GP_SC1 | GP_VOL);
+#else
     const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(b.rs, so, 0, GP_SC1 | GP_VOL);
+#endif
     if (__all(!son || (y[1] == tag && y[3] == tag))) return true;
     asm volatile("" ::: "memory");
     if ((polls & 63) == 63) {
