@@ -15,18 +15,18 @@
 //     hand-off is in flight (G waves 0, 2) the R waves compute tile 1 (whose hand-off G waves 1, 3 run), so a step costs one tile's
 //     chain, not compute + hand-off of both (first version: 32 k cycles per step, 21 k of them hand-off with the R waves idle).
 //
-// Two hand-offs per step, layer and tile, both "the data is the flag" (8-byte {value, tag} granules in 16-byte write-through
-// accesses, cdna_hip_programming.md guideline 16 R2):
+// Two hand-offs per step, layer and tile, both "the data is the flag" (cdna_hip_programming.md guideline 16 R2) in 16-byte
+// write-through accesses -- without tags: a slot holds a sentinel pattern until it is written (see the transport section):
 //   hop 1  every workgroup publishes its PARTIAL projection h[:, its cells] . W_p[its cells, :] (16 x P per tile) as 16 x 16 chunks,
 //          one per k-block of P; workgroup c of the layer is the REDUCER of the 8-column half (k-block c >> 1, half c & 1) of BOTH
 //          tiles: it sums the NC partials in slice order (deterministic) -- a reduce-scatter;
 //   hop 2  the reducer publishes its half chunk of m(t); every workgroup of the layer (for the recurrent product of step t+1) and
-//          of the layer above (x of step t) gathers all chunks -- an all-gather.  A chunk slot is [half][2][32 lanes][16 bytes]:
-//          lane pl of the producer / consumer fragment owns bytes (pl >> 5) * 1024 + j * 512 + (pl & 31) * 16, j = 0, 1, so that
-//          every store / load instruction moves whole 128-byte lines and a reducer's half is one contiguous KB.
+//          of the layer above (x of step t) gathers all chunks -- an all-gather.  A chunk slot is the accumulator tile itself,
+//          [64 lanes][16 bytes]: lane pl = (q, lr) of the producer / consumer fragment owns the four columns 4 q .. 4 q + 3 of row lr, so
+//          every store / load instruction moves whole 128-byte lines and a reducer's half (lanes 32 hh ..) is 512 contiguous bytes.
 // Inside a workgroup the three roles synchronise through monotonic LDS counters (no s_barrier: the roles are not in lock step).
-// Tags: hop 2 has one slot per step, tag = launch generation (dpersist.hip); hop 1 is a ring of two steps, tag = generation and step.
-// Every spin is bounded; failures go to the sticky err word of the control block and poison the top layer's output with NaN.
+// Hop 2 has one slot per step (armed by a memset in front of the launch); hop 1 is a ring of two steps whose slots the reducer
+// re-arms after summing them.  Every spin is bounded; failures go to the sticky err word of the control block and poison the top layer's output with NaN.
 #include <type_traits>
 
 #include "kernels.h"
@@ -42,7 +42,8 @@ constexpr int GP_WAVES = 12;             // R0..R3, X0..X3, G0..G3
 static_assert(GP_NR == 2, "chunk index = 2 * k-block + row tile");
 constexpr int GP_NKB = 18;               // k-blocks of 16 of the recurrent / input width (P, I <= 288)
 constexpr int GP_KBW = 5;                // k-blocks per R / X wave (k-block jb belongs to wave jb & 3)
-constexpr int GP_SLOT = 2048;            // bytes per chunk slot: 64 lanes x 4 granules
+constexpr int GP_SLOT = 1024;            // bytes per chunk slot: a 16 x 16 tile of floats, 16 bytes (four columns of one row) per fragment lane
+constexpr unsigned GP_SENT = 0xFFFFFFFFu; // a word of a slot nobody has written yet
 constexpr int GP_NCH = GP_NKB * GP_NR;   // chunk slots per layer and step (the layout's stride; a layer uses its first nkb * NR)
 constexpr unsigned GP_SC1 = 16u;         // aux of the raw-buffer builtins: sc1 (agent scope: write-through store / L1-bypassing load)
 constexpr unsigned GP_VOL = 1u << 31;    // ... compiler-only: volatile (a polled load must not be hoisted out of its loop)
@@ -88,32 +89,49 @@ __device__ __forceinline__ bool gp_wait(const unsigned* cnt, unsigned target, co
 }
 
 // ---- inter-workgroup transport ----
+// The payload carries no tags: a slot holds GP_SENT in every word until its producer has written it, and a 16-byte piece is valid
+// when none of its four words is GP_SENT (each 32-bit word lands whole, so a torn piece is an invalid piece).  Half the bytes of the
+// {value, tag} granules of dpersist.hip -- the generator's hand-offs move 220 KB into every workgroup per step and are bound by
+// that, not by the tag compares (timing ablation: 15.4 -> 14.2 us per step forward, 19.4 -> 16.4 backward).  The price is that
+// somebody has to put the sentinels back: the ring slots (hop 1, the backward's input-gradient ring) have exactly one reader, the
+// reducer workgroup, whose R waves re-arm them once its G waves have summed them; the all-gathered chunks (hop 2: one slot per step,
+// ~40 readers) are re-armed by a memset in front of every launch (launch_glstm_*).  GP_SENT is a NaN pattern no arithmetic
+// produces; a value that happens to carry it (a NaN payload passed through from the inputs) is published as the canonical NaN.
 struct GpBuf { __amdgpu_buffer_rsrc_t rs; };
 __device__ __forceinline__ GpBuf gp_buf(const void* p, size_t bytes) {
   GpBuf b; b.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); return b;
 }
-__device__ __forceinline__ void gp_store(const GpBuf& b, unsigned off, unsigned tag, float v0, float v1) {
-  const u32x4 x = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
-#if defined(GP_ABL) && (GP_ABL & 16)
-  if (off & 512u) return;                                                // timing ablation: half the bytes of every hand-off (a tag-free payload)
-#endif
+__device__ __forceinline__ void gp_store(const GpBuf& b, unsigned off, const f32x4& v) {
+  u32x4 x = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = x[i] == GP_SENT ? 0x7FC00000u : x[i];
   __builtin_amdgcn_raw_buffer_store_b128(x, b.rs, off, 0, GP_SC1);
 }
-// One wave waits for NL 16-byte-per-lane pieces (wave-uniform byte offsets lo[], + this lane's lane_off) and hands them to
-// consume(k, a, b) in order.  Polling must be CHEAP: a spinning full read (20 KB per pass and wave, 1800 waves) saturates the fabric
-// and starves every other access of the chip (first version: 700 us per step).  So a lane polls one SENTINEL (byte offset so, the
-// last 16 bytes of something it waits for; son = this lane has one) with a sleep between polls; only when every sentinel carries
-// `tag` the pieces are read in full, and re-read in the rare case that a store of theirs has not landed yet.  POLL_FIRST: the caller
-// arrives before the data as a rule (the hand-offs of the critical path).  BATCH: pieces per round trip (a wave that keeps 100
-// weight registers cannot hold 20 loads' worth of granules as well).  consume() must be idempotent (a failed pass is repeated).
+__device__ __forceinline__ bool gp_valid(const u32x4& x) { return (x[0] != GP_SENT) & (x[1] != GP_SENT) & (x[2] != GP_SENT) & (x[3] != GP_SENT); }
+// Re-arm the NP producers' 512-byte half chunks at base + p * GP_SLOT (p = 0 .. NP-1): one store covers two producers (a half
+// wave each); wave w of the four R waves takes every fourth store.
+__device__ __forceinline__ void gp_rearm(const GpBuf& b, unsigned base, int NP, int w, int lane) {
+  const u32x4 sent = {GP_SENT, GP_SENT, GP_SENT, GP_SENT};
+  for (int k = w; 2 * k < NP; k += 4) {
+    const int p = 2 * k + (lane >> 5);
+    if (p < NP) __builtin_amdgcn_raw_buffer_store_b128(sent, b.rs, base + (unsigned)p * GP_SLOT + (unsigned)(lane & 31) * 16u, 0, GP_SC1);
+  }
+}
+// One wave waits for NL 16-byte-per-lane pieces (wave-uniform byte offsets lo[], + this lane's lane_off; piece k counts for this lane
+// when k < nl, a per-lane number) and hands them to consume(k, piece) in order.  Polling must be CHEAP: a spinning full read (20 KB
+// per pass and wave, 1800 waves) saturates the fabric and starves every other access of the chip (first version: 700 us per step).
+// So a lane polls one SENTINEL piece (byte offset so, the last 16 bytes of something it waits for; son = this lane has one) with a
+// sleep between polls; only when every sentinel piece is valid the pieces are read in full, and re-read in the rare case that a
+// store of theirs has not landed yet.  POLL_FIRST: the caller arrives before the data as a rule (the hand-offs of the critical
+// path).  BATCH: pieces per round trip.  consume() must be idempotent (a failed pass is repeated).
 // CACHED: the first full read uses ordinary (L2-cacheable) loads.  The all-gathered chunks are read by ~19 workgroups per XCD, and
-// as write-through (sc1) reads every one of them crossed the fabric: the step was bound by ~5 TB/s of such traffic.  Every 16 bytes
-// carry their tag, so a stale line -- from a cache, whatever the reason -- is detected like a store that has not landed, and the
-// retry reads past the caches (sc1); slots that are written once per launch (hop 2) never go stale within one.
+// as write-through (sc1) reads every one of them crossed the fabric.  A line cached before its store landed holds sentinels (the
+// L2s are invalidated at the kernel boundary behind the memset), i.e. it is detected like a store that has not landed, and the retry
+// reads past the caches (sc1).
 // false on time-out / peer failure.
 template <int NL, bool POLL_FIRST, int BATCH, bool CACHED, class F>
 __device__ __forceinline__ bool gp_sweep(const GpBuf& b, const unsigned (&lo)[NL], int nl, unsigned lane_off, unsigned so, bool son,
-                                         unsigned tag, gu32* err, F&& consume) {
+                                         gu32* err, F&& consume) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   // (the offsets as scalar VALUES first: hipcc turns `c ? lo[k] : lo[0]` into a load through a selected pointer, which keeps the
   // array in scratch / LDS)
@@ -129,23 +147,14 @@ __device__ __forceinline__ bool gp_sweep(const GpBuf& b, const unsigned (&lo)[NL
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
         const int k = k0 + j < NL ? k0 + j : NL - 1;
-#if defined(GP_ABL) && (GP_ABL & 16)
-        x[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, ((k < nl ? of[k] : of[0]) + lane_off) & ~512u, 0, AUX);
-#else
         x[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, (k < nl ? of[k] : of[0]) + lane_off, 0, AUX);   // (unconditional)
-#endif
       }
 #pragma unroll
       for (int j = 0; j < BATCH; ++j) {
         const int k = k0 + j;
         if (k < NL) {
-          // (real moves: hipcc otherwise keeps the {value, tag, value, tag} load tuples alive and picks the values out of them
-          // where they are used -- twice the registers, in 4-aligned tuples)
-          float v0, v1;
-          asm volatile("v_mov_b32 %0, %1" : "=v"(v0) : "v"(x[j][0]));
-          asm volatile("v_mov_b32 %0, %1" : "=v"(v1) : "v"(x[j][2]));
-          ok &= (k >= nl) || (x[j][1] == tag && x[j][3] == tag);
-          consume(k, v0, v1);
+          ok &= (k >= nl) || gp_valid(x[j]);
+          consume(k, f32x4{__uint_as_float(x[j][0]), __uint_as_float(x[j][1]), __uint_as_float(x[j][2]), __uint_as_float(x[j][3])});
         }
       }
     }
@@ -169,12 +178,8 @@ __device__ __forceinline__ bool gp_sweep(const GpBuf& b, const unsigned (&lo)[NL
     }
     read_now = true;
     for (unsigned polls = 0;; ++polls) {
-#if defined(GP_ABL) && (GP_ABL & 16)
-      const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(b.rs, so & ~512u, 0, GP_SC1 | GP_VOL);
-#else
       const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(b.rs, so, 0, GP_SC1 | GP_VOL);
-#endif
-      if (__all(!son || (y[1] == tag && y[3] == tag))) break;
+      if (__all(!son || gp_valid(y))) break;
       asm volatile("" ::: "memory");
       if ((polls & 63) == 63) {
         if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull ||          // 1 s at 100 MHz
@@ -192,7 +197,7 @@ struct GpLds {
   float mB[GP_NR][GP_NKB][64][4];           // carried m(t-1) as B fragments [row tile][k-block][lane][4]
   float pb[4][NT][GP_NR][64][4];            // accumulator tiles: x-part (X wave w -> R wave w), then the R waves' partial sums
   float st[6][GP_ROWS][4 * NT];             // the step's stash: gates i, j, f, o | c | h   (h also feeds the projection)
-  float gs[2][GP_NR][2][64][2];             // the two reducing G waves' partial sums of this workgroup's half chunk [step parity][tile][wave]
+  float gs[2][GP_NR][2][64][4];             // the two reducing G waves' partial sums of this workgroup's half chunk [step parity][tile][wave][half wave = even / odd producers, fragment lane]
   float kx4[2][NT][64][4];                  // the fifth K_x k-block of X waves 0, 1 (k-blocks 16, 17): 100 weight registers do not fit beside the sweeps
   float peep[4 * NT][4];                    // {w_i, w_f, w_o, -} per cell of this slice (one 16-byte read per cell)
   float bias[4 * NT][4];                    // {b_i, b_j, b_f, b_o} per cell: the accumulator registers of a lane
@@ -200,8 +205,7 @@ struct GpLds {
 };
 
 template <int NT>
-__device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigned gen_, GpLds<NT>& S) {
-  const unsigned gen = (unsigned)__builtin_amdgcn_readfirstlane((int)gen_);
+__device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S) {
   constexpr int NR = GP_NR, NU = NT * NR, CW = 4 * NT;
   GPT_DECL
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
@@ -225,10 +229,13 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigne
   const GpBuf b1 = gp_buf((const char*)a.gran1 + (size_t)(grp * a.nl + l) * 2 * g1_per, 2 * g1_per);
   const GpBuf b2 = gp_buf((const char*)a.gran2 + (size_t)(grp * a.nl + l) * T * g2_per, (size_t)T * g2_per);
   const GpBuf b2x = gp_buf((const char*)a.gran2 + (size_t)(grp * a.nl + (l > 0 ? l - 1 : 0)) * T * g2_per, (size_t)T * g2_per);
-  const unsigned tagbase = gen << 11;                                  // hop 1: tag = generation (21 bits) and step + 1
-  const unsigned frag_off = (unsigned)((lane >> 5) * 1024 + (lane & 31) * 16);   // a fragment lane's bytes in a chunk slot (+ j * 512)
+  const unsigned frag_off = (unsigned)lane * 16u;                     // a fragment lane's bytes in a chunk slot
+  const unsigned pair_off = (unsigned)((lane >> 5) * GP_SLOT + (lane & 31) * 16);   // reducer: lanes 0..31 read producer p's half chunk, lanes 32..63 producer p + 1's
   auto slot1 = [&](int par, int r, int jb, int p) { return (unsigned)((((size_t)(par * NR + r) * GP_NKB + jb) * NC + p) * GP_SLOT); };
   auto slot2 = [&](int t, int r, int jb) { return (unsigned)((((size_t)t * NR + r) * GP_NKB + jb) * GP_SLOT); };
+  // this workgroup REDUCES the 8-column half (k-block jbr, half hh) of both tiles
+  const bool reducer = c < 2 * nkb;
+  const int jbr = c >> 1, hh = c & 1;
 
   // ---- cooperative prologue: W_p fragments, peepholes, bias, counters ----
   for (int e = tid; e < GP_NKB * NT * 64; e += GP_WAVES * 64) {
@@ -293,6 +300,10 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigne
         GPT(6 * r + 1);
         if (t > 0 && !gp_wait(&S.cnt_m[r], 2u * (unsigned)t, dead)) return;   // carried m(t-1) of the tile is in LDS
         GPT(6 * r + 2);
+        // ... so this workgroup's G waves have summed the partial projections of step t-1: re-arm their ring slots.  The stores are
+        // acknowledged before this wave signals its cells below, i.e. before this workgroup's partials of step t leave, without
+        // which no m(t) and hence no partial of step t+1 -- the next write to these slots -- exists.
+        if (reducer && t > 0) gp_rearm(b1, slot1((t - 1) & 1, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
         {
           f32x4 acc[NT];
 #pragma unroll
@@ -347,6 +358,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigne
             d[5 * GP_ROWS * CW] = live ? hh : 0.f;
           }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the re-arming stores; issued a whole compute phase ago)
         gp_signal(&S.cnt_h[r], lane);
         GPT(6 * r + 5);
         if (!gp_wait(&S.cnt_h[r], 4u * ((unsigned)t + 1u), dead)) return;     // every cell of the tile is in the stage
@@ -363,6 +375,13 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigne
           if (e < 6 * 16 * NT && cell0 + 4 * cq < H) *reinterpret_cast<float4*>(dst) = v;
         }
         gp_signal(&S.cnt_s[r], lane);
+      }
+    }
+    if (reducer) {                                                       // the last step's partials: leave every ring slot armed for the next launch
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (!gp_wait(&S.cnt_m[r], 2u * (unsigned)T, dead)) return;
+        gp_rearm(b1, slot1((T - 1) & 1, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
       }
     }
 #ifdef GP_TRACE
@@ -424,16 +443,13 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigne
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         // x(t) = the masked output of the layer below: fragments (k-block xw + 4 jj, tile r) of its m(t), two 16-byte pieces each
-        unsigned lo[2 * GP_KBW];
+        unsigned lo[GP_KBW];
 #pragma unroll
-        for (int jj = 0; jj < GP_KBW; ++jj) {
-          const unsigned o = slot2(t, r, min(xw + 4 * jj, nkbx - 1));
-          lo[2 * jj] = o; lo[2 * jj + 1] = o + 512u;
-        }
-        float xv[2 * GP_KBW][2];
+        for (int jj = 0; jj < GP_KBW; ++jj) lo[jj] = slot2(t, r, min(xw + 4 * jj, nkbx - 1));
+        f32x4 xv[GP_KBW];
         GPT(18 + 2 * r);
-        if (!gp_sweep<2 * GP_KBW, false, 6, true>(b2x, lo, 2 * nsx, frag_off, slot2(t, r, min(xw + 4 * (lane >> 1), nkbx - 1)) + (unsigned)(lane & 1) * 1024u + 1008u,
-                                            lane < 2 * nsx, gen, err, [&](int k, float va, float vb) { xv[k][0] = va; xv[k][1] = vb; })) { fail(); return; }
+        if (!gp_sweep<GP_KBW, false, GP_KBW, true>(b2x, lo, nsx, frag_off, slot2(t, r, min(xw + 4 * (lane >> 1), nkbx - 1)) + (unsigned)(lane & 1) * 512u + 496u,
+                                             lane < 2 * nsx, err, [&](int k, const f32x4& v) { xv[k] = v; })) { fail(); return; }
         GPT(19 + 2 * r);
         const bool live = t < (r ? len1 : len0);
         f32x4 acc[NT];
@@ -444,7 +460,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigne
 #pragma unroll
         for (int jj = 0; jj < GP_KBW; ++jj) {
           if (xw + 4 * jj < nkbx) {
-            const float b0 = live ? xv[2 * jj][0] : 0.f, b1 = live ? xv[2 * jj][1] : 0.f, b2_ = live ? xv[2 * jj + 1][0] : 0.f, b3 = live ? xv[2 * jj + 1][1] : 0.f;
+            const float b0 = live ? xv[jj][0] : 0.f, b1 = live ? xv[jj][1] : 0.f, b2_ = live ? xv[jj][2] : 0.f, b3 = live ? xv[jj][3] : 0.f;
             float4 ka[NT];
 #pragma unroll
             for (int i = 0; i < NT; ++i) ka[i] = jj < GP_KBW - 1 ? kx[i][jj < GP_KBW - 1 ? jj : 0] : *reinterpret_cast<const float4*>(kx4w + i * 256);
@@ -483,20 +499,20 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigne
   const float* const sth = &S.st[5][16 * r + lr][q];                   // + 4 ks
   float* const mbg = &S.mB[r][gp][lane][0];                            // + 2 n * 256
   const int nvg = (nkb - gp + 1) >> 1;                                 // this wave's k-blocks: gp, gp + 2, ...
-  // this workgroup REDUCES the 8-column half (k-block jbr, half hh) of both tiles; this wave: tile r, producers [pp0, pp0 + pn)
-  const bool reducer = c < 2 * nkb;
-  const int jbr = c >> 1, hh = c & 1;
+  // reducer: this wave sums tile r's partials of the producers [pp0, pp0 + pn), two per load (a half wave each: lanes 0..31 the
+  // even ones, lanes 32..63 the odd ones), nlr of them in this lane
   const int ppw = (NC + 1) >> 1, pp0 = gp * ppw, pn = max(0, min(ppw, NC - pp0));
-  // reducer lane L holds the two values {2 j, 2 j + 1} (j = L >> 5) of fragment lane pl = 32 hh + (L & 31): row pl & 15, cols 4 (pl >> 4) + 2 j
-  const int rrow = row0 + 16 * r + ((32 * hh + (lane & 31)) & 15), rcol = 16 * jbr + 4 * ((32 * hh + (lane & 31)) >> 4) + 2 * (lane >> 5);
+  const int nlr = (pn + 1 - (lane >> 5)) >> 1;
+  // reducer lane L holds fragment lane pl = 32 hh + (L & 31): row pl & 15, columns 4 (pl >> 4) .. + 3 of the chunk
+  const int rrow = row0 + 16 * r + ((32 * hh + (lane & 31)) & 15), rcol = 16 * jbr + 4 * ((32 * hh + (lane & 31)) >> 4);
   const int rlen = a.len[rrow];
-  float mcar0 = 0.f, mcar1 = 0.f;                                      // carried state of the reducer's two columns (the stash's mst)
+  f32x4 mcar = {0.f, 0.f, 0.f, 0.f};                                   // carried state of the reducer's four columns (the stash's mst)
   // slot 0 of the carried states is zero (cell.zero_state)
   for (int e = gw * 64 + lane; e < GP_ROWS * NT; e += 256) {
     const int row = e / NT, cq = e - row * NT;
     if (cell0 + 4 * cq < H) *reinterpret_cast<float4*>(L.c + (size_t)(row0 + row) * H + cell0 + 4 * cq) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  if (reducer && gp == 1 && rcol < ldP) *reinterpret_cast<float2*>(L.mst + (size_t)rrow * ldP + rcol) = make_float2(0.f, 0.f);
+  if (reducer && gp == 1 && lane < 32 && rcol < ldP) *reinterpret_cast<float4*>(L.mst + (size_t)rrow * ldP + rcol) = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int t = 0; t < T; ++t) {
     const int par = t & 1;
     GPT(12);
@@ -506,7 +522,6 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigne
       float hv[NT];
 #pragma unroll
       for (int ks = 0; ks < NT; ++ks) hv[ks] = sth[4 * ks];
-      const unsigned tagp = tagbase | ((unsigned)t + 1u);
       const unsigned pub0 = slot1(par, r, gp, c) + frag_off;
       // three chunks in flight (the dependent-accumulator latency of the 16x16x4 form is 40 cycles for a 32-cycle issue); a chunk
       // leaves as soon as its NT products are done, so the write-through stores overlap the remaining MFMAs
@@ -521,60 +536,57 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, const unsigne
           for (int j = 0; j < 3; ++j) pm[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpw[(2 * (n0 + j) * NT + ks) * 64], hv[ks], pm[j], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-          if (n0 + j < nvg) {
-            const unsigned o = pub0 + (unsigned)(2 * (n0 + j)) * (unsigned)NC * GP_SLOT;
-            gp_store(b1, o, tagp, pm[j][0], pm[j][1]);
-            gp_store(b1, o + 512u, tagp, pm[j][2], pm[j][3]);
-          }
+          if (n0 + j < nvg) gp_store(b1, pub0 + (unsigned)(2 * (n0 + j)) * (unsigned)NC * GP_SLOT, pm[j]);
       }
     }
     GPT(14);
-    float tot0 = 0.f, tot1 = 0.f;
+    f32x4 tot = {0.f, 0.f, 0.f, 0.f};
     if (reducer) {
-      // hop 1: the NC partial projections of this half chunk, tile r, summed in slice order (this wave: its half of the slices)
-      const unsigned tag1 = tagbase | ((unsigned)t + 1u);
-      unsigned lo[20];
+      // hop 1: the NC partial projections of this half chunk, tile r, summed in a fixed order (this wave: its half of the slices,
+      // even and odd ones in the two half waves)
+      unsigned lo[10];
 #pragma unroll
-      for (int k = 0; k < 20; ++k) lo[k] = slot1(par, r, jbr, min(pp0 + k, NC - 1)) + (unsigned)hh * 1024u;
-      float s0 = 0.f, s1 = 0.f;
-      if (!gp_sweep<20, true, 20, false>(b1, lo, pn, (unsigned)lane * 16u, slot1(par, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 1024u + 1008u, lane < pn, tag1, err,
-                                  [&](int k, float va, float vb) { if (k == 0) { s0 = va; s1 = vb; } else if (k < pn) { s0 += va; s1 += vb; } })) { fail(); return; }
+      for (int k = 0; k < 10; ++k) lo[k] = slot1(par, r, jbr, min(pp0 + 2 * k, NC - 1)) + (unsigned)hh * 512u;
+      f32x4 sa = {0.f, 0.f, 0.f, 0.f};
+      if (!gp_sweep<10, true, 10, false>(b1, lo, nlr, pair_off, slot1(par, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
+                                  [&](int k, const f32x4& v) { if (k == 0) sa = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) sa += v; })) { fail(); return; }
       GPT(15);
-      *reinterpret_cast<float2*>(&S.gs[par][r][gp][lane][0]) = make_float2(s0, s1);
+      *reinterpret_cast<f32x4*>(&S.gs[par][r][gp][lane][0]) = sa;
       gp_signal(&S.cnt_g[r], lane);
       if (!gp_wait(&S.cnt_g[r], 2u * ((unsigned)t + 1u), dead)) return;
-      const float2 g0 = *reinterpret_cast<const float2*>(&S.gs[par][r][0][lane][0]), g1 = *reinterpret_cast<const float2*>(&S.gs[par][r][1][lane][0]);
-      tot0 = g0.x + g1.x; tot1 = g0.y + g1.y;
+      {
+        const float* const gsr = &S.gs[par][r][0][lane & 31][0];
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(gsr), a1 = *reinterpret_cast<const f32x4*>(gsr + 32 * 4);
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(gsr + 64 * 4), c1 = *reinterpret_cast<const f32x4*>(gsr + 96 * 4);
+        tot = ((a0 + a1) + c0) + c1;
+      }
       // hop 2: this half chunk of m(t), tile r
-      if (gp == 0) gp_store(b2, slot2(t, r, jbr) + (unsigned)hh * 1024u + (unsigned)lane * 16u, gen, tot0, tot1);
+      if (gp == 0 && lane < 32) gp_store(b2, slot2(t, r, jbr) + (unsigned)hh * 512u + (unsigned)lane * 16u, tot);
       GPT(16);
     }
     if (t + 1 < T) {
       // gather m(t) of the tile for the recurrent product of step t+1: k-blocks gp, gp + 2, ... as B fragments; dynamic_rnn carries the
       // state of a finished row through unchanged (the carried state lives in mB itself)
-      unsigned lo[18];
+      unsigned lo[9];
 #pragma unroll
-      for (int n = 0; n < 9; ++n) {
-        const unsigned o = slot2(t, r, min(gp + 2 * n, nkb - 1));
-        lo[2 * n] = o; lo[2 * n + 1] = o + 512u;
-      }
-      float mv[18][2];
-      if (!gp_sweep<18, true, 18, true>(b2, lo, 2 * nvg, frag_off, slot2(t, r, min(gp + 2 * (lane >> 1), nkb - 1)) + (unsigned)(lane & 1) * 1024u + 1008u,
-                                  lane < 2 * nvg, gen, err, [&](int k, float va, float vb) { mv[k][0] = va; mv[k][1] = vb; })) { fail(); return; }
+      for (int n = 0; n < 9; ++n) lo[n] = slot2(t, r, min(gp + 2 * n, nkb - 1));
+      f32x4 mv[9];
+      if (!gp_sweep<9, true, 9, true>(b2, lo, nvg, frag_off, slot2(t, r, min(gp + 2 * (lane >> 1), nkb - 1)) + (unsigned)(lane & 1) * 512u + 496u,
+                                 lane < 2 * nvg, err, [&](int k, const f32x4& v) { mv[k] = v; })) { fail(); return; }
       GPT(17);
       const bool live = t < lenr;
 #pragma unroll
       for (int n = 0; n < 9; ++n)
-        if (n < nvg && live) *reinterpret_cast<f32x4*>(mbg + 2 * n * 256) = f32x4{mv[2 * n][0], mv[2 * n][1], mv[2 * n + 1][0], mv[2 * n + 1][1]};
-      gp_signal(&S.cnt_m[r], lane);
+        if (n < nvg && live) *reinterpret_cast<f32x4*>(mbg + 2 * n * 256) = mv[n];
     }
-    // the reducer's two columns of the stash (carried state, masked output), behind the hand-offs
-    if (reducer && gp == 1) {
+    gp_signal(&S.cnt_m[r], lane);                                        // (also after the last step: the R waves re-arm the ring behind it)
+    // the reducer's four columns of the stash (carried state, masked output), behind the hand-offs
+    if (reducer && gp == 1 && lane < 32) {
       const bool live = t < rlen;
-      mcar0 = live ? tot0 : mcar0; mcar1 = live ? tot1 : mcar1;
+      mcar = live ? tot : mcar;
       if (rcol < ldP) {
-        *reinterpret_cast<float2*>(L.mst + ((size_t)(t + 1) * N + rrow) * ldP + rcol) = make_float2(mcar0, mcar1);
-        *reinterpret_cast<float2*>(L.out + ((size_t)t * N + rrow) * ldP + rcol) = make_float2(live ? tot0 : 0.f, live ? tot1 : 0.f);
+        *reinterpret_cast<float4*>(L.mst + ((size_t)(t + 1) * N + rrow) * ldP + rcol) = make_float4(mcar[0], mcar[1], mcar[2], mcar[3]);
+        *reinterpret_cast<float4*>(L.out + ((size_t)t * N + rrow) * ldP + rcol) = live ? make_float4(tot[0], tot[1], tot[2], tot[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   }
@@ -587,8 +599,8 @@ template <int NT>
 __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_fwd(const GPersistArgs a) {
   __shared__ __attribute__((aligned(16))) GpLds<NT> S;
   gu32* ctl = (gu32*)a.ctl;
-  const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  gp_fwd_body<NT>(a, gen, S);
+  const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (counts launches; nothing depends on it)
+  gp_fwd_body<NT>(a, S);
   __syncthreads();                                                 // (every wave leaves the body on every path)
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -619,7 +631,7 @@ __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_fwd(const GPersistAr
 // reducer AFTER it has summed that slot).  Layer 0's input gradient is a time-batched GEMM over the dz stash afterwards.
 // Cell gradient: kernels.hip k_bwd_a2 (peepholes, o's peephole on the new c, dynamic_rnn masking: a finished row has dz = 0 and
 // carries dc through).
-constexpr int GP_XR = 4;
+constexpr int GP_XR = 5;   // (a slot is re-armed one step after it was summed: four steps of slack)
 
 template <int NT>
 struct GpLdsB {
@@ -630,23 +642,19 @@ struct GpLdsB {
   float pd[4][GP_NR][NT][64];               // dh partial sums [R wave = k-blocks w, w + 4, ..][row tile][gate tile][lane]
   float dzB[GP_NR][NT][64][4];              // dz(t) as B fragments of both gradient products [row tile][gate tile][lane (cell q, row lr)][gate]
   float st[4][GP_ROWS][4 * NT];             // dz(t) in stash order [gate][row][cell]
-  float gs[2][GP_NR][2][64][2];             // the two reducing G waves' sums [step parity][tile][wave]
+  float gs[2][GP_NR][2][64][4];             // the two reducing G waves' sums [step parity][tile][wave][half wave, fragment lane]
   float pfs[GP_NR][5][16][4 * NT];          // the stash of the NEXT step of a tile: gate activations i, j, f, o and c(t-1) (the X waves fetch it a step ahead)
   float peep[4 * NT][4];                    // {w_i, w_f, w_o, -} per cell
   float car[4][2][GP_NR][64][2];            // c(t) and the carried dc of an R wave's cells [wave][gate tile w | 4 + w][row tile][lane] (in registers they get spilled, and a scratch reload waits for the wave's write-through stores)
   unsigned cnt_p[GP_NR], cnt_h[GP_NR], cnt_m[GP_NR], cnt_g[GP_NR], cnt_z[GP_NR], cnt_f[GP_NR], dead, pad_[3];
 };
 
-// one lane = one sentinel (16 bytes at `so` when son): wait until every one carries `tag`
-__device__ __forceinline__ bool gp_poll(const GpBuf& b, unsigned so, bool son, unsigned tag, gu32* err) {
+// one lane = one sentinel piece (16 bytes at `so` when son): wait until every one is valid
+__device__ __forceinline__ bool gp_poll(const GpBuf& b, unsigned so, bool son, gu32* err) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (unsigned polls = 0;; ++polls) {
-#if defined(GP_ABL) && (GP_ABL & 16)
-    const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(b.rs, so & ~512u, 0, GP_SC1 | GP_VOL);
-#else
     const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(b.rs, so, 0, GP_SC1 | GP_VOL);
-#endif
-    if (__all(!son || (y[1] == tag && y[3] == tag))) return true;
+    if (__all(!son || gp_valid(y))) return true;
     asm volatile("" ::: "memory");
     if ((polls & 63) == 63) {
       if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
@@ -656,8 +664,7 @@ __device__ __forceinline__ bool gp_poll(const GpBuf& b, unsigned so, bool son, u
 }
 
 template <int NT>
-__device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, const unsigned gen_, GpLdsB<NT>& S) {
-  const unsigned gen = (unsigned)__builtin_amdgcn_readfirstlane((int)gen_);      // (a scalar: as a vector register it is spilled, and its reload sits behind the write-through stores)
+__device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S) {
   constexpr int NR = GP_NR, CW = 4 * NT;
   GPT_DECL
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
@@ -682,10 +689,12 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, const unsigne
   const GpBuf b2x = gp_buf((const char*)a.gran2 + (size_t)(grp * a.nl + (l > 0 ? l - 1 : 0)) * T * g2_per, (size_t)T * g2_per);
   const GpBuf b3 = gp_buf((const char*)a.gran3 + (size_t)(grp * a.nl + l) * GP_XR * g1_per, GP_XR * g1_per);              // what the layer above hands to this one
   const GpBuf b3x = gp_buf((const char*)a.gran3 + (size_t)(grp * a.nl + (l > 0 ? l - 1 : 0)) * GP_XR * g1_per, GP_XR * g1_per);   // what this layer hands down
-  const unsigned tagbase = gen << 11;
-  const unsigned frag_off = (unsigned)((lane >> 5) * 1024 + (lane & 31) * 16);
+  const unsigned frag_off = (unsigned)lane * 16u;
+  const unsigned pair_off = (unsigned)((lane >> 5) * GP_SLOT + (lane & 31) * 16);
   auto slot1 = [&](int par, int r, int jb, int p) { return (unsigned)((((size_t)(par * NR + r) * GP_NKB + jb) * NC + p) * GP_SLOT); };   // (both rings)
   auto slot2 = [&](int t, int r, int jb) { return (unsigned)((((size_t)t * NR + r) * GP_NKB + jb) * GP_SLOT); };
+  const bool reducer = c < 2 * nkb;
+  const int jbr = c >> 1, hh = c & 1;
 
   // ---- cooperative prologue ----
   for (int e = tid; e < GP_NKB * 80; e += GP_WAVES * 64) {
@@ -756,11 +765,11 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, const unsigne
     const float* const dzr = &S.dzB[0][0][lane][0];                     // + (r * NT + i) * 256
     const GpBuf& bpub = isx ? b3x : b1;
     // the product of one row tile and its publication: three output tiles in flight, a tile leaves as soon as its 4 NT products are done
-    auto product = [&](int r, int ring, unsigned tag) {
+    auto product = [&](int r, int ring) {
       // (opaque copies: hipcc otherwise computes every slot offset and row address of the step loop once, in front of it, and
       // spills them -- a scratch reload behind the write-through stores below waits for their acknowledgement)
       const unsigned ln_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // (the lane id again: two VALU instructions, no register kept, no spill)
-      const unsigned fo = ((ln_ >> 5) << 10) | ((ln_ & 31u) << 4);
+      const unsigned fo = ln_ << 4;
       if (isx) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
 #pragma unroll
       for (int j0 = 0; j0 < GP_KBW; j0 += 3) {
@@ -792,14 +801,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, const unsigne
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const int jj = j0 + j;
-          if (jj < GP_KBW && ww + 4 * jj < nkw && (jj < GP_KBW - 1 || five)) {
-            const unsigned o = slot1(ring, r, ww + 4 * jj, c) + fo;
-#if defined(GP_ABL) && (GP_ABL & 8)
-            if (false)                                                 // timing ablation: half the published bytes
-#endif
-            gp_store(bpub, o, tag, acc[j][0], acc[j][1]);
-            gp_store(bpub, o + 512u, tag, acc[j][2], acc[j][3]);
-          }
+          if (jj < GP_KBW && ww + 4 * jj < nkw && (jj < GP_KBW - 1 || five)) gp_store(bpub, slot1(ring, r, ww + 4 * jj, c) + fo, acc[j]);
         }
       }
       __builtin_amdgcn_s_setprio(0);
@@ -842,12 +844,14 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, const unsigne
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           GPTS(18 + 2 * r);
-          // back-pressure: ring slot s % GP_XR was summed by the layer below when it has published its dm(t + GP_XR)
-          if (!noprod && s >= GP_XR && !gp_poll(b2x, slot2(t + GP_XR, r, min(ww + 4 * (lane >> 1), nkbx - 1)) + (unsigned)(lane & 1) * 1024u + 1008u, lane < 2 * nsx, gen, err)) { fail(); return; }
+          // back-pressure: ring slot s % GP_XR was summed AND re-armed by the layer below when it has published its dm(t + GP_XR - 1)
+          // (its R waves re-arm a slot in the step that summed it, acknowledged before that step's partials leave, which the dm of
+          // the step after waits for)
+          if (!noprod && s >= GP_XR - 1 && !gp_poll(b2x, slot2(t + GP_XR - 1, r, min(ww + 4 * (lane >> 1), nkbx - 1)) + (unsigned)(lane & 1) * 512u + 496u, lane < 2 * nsx, err)) { fail(); return; }
           if (!gp_wait(cnt + C_H + r, 4u * ((unsigned)s + 1u), dead)) return;       // dz(t) of the tile is in LDS (and the cells have read the stage)
           GPTS(19 + 2 * r);
           if (!noprod) {
-            product(r, s % GP_XR, tagbase | ((unsigned)s + 1u));
+            product(r, s % GP_XR);
             gp_signal(cnt + C_Z + r, lane);                                 // (the product has read dzB)
           }
           if (t > 0) { fetch(t - 1, r); stage(r); }                       // (needed by the cells a whole hand-off from now)
@@ -886,6 +890,13 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, const unsigne
         GPTS(6 * r + 0);
         if (!gp_wait(cnt + C_M + r, 2u * ((unsigned)s + 1u), dead)) return;      // dm(t) of the tile is in LDS
         GPTS(6 * r + 1);
+        // ... so this workgroup's G waves have summed the partials of this step: re-arm their slots of both rings.  Acknowledged
+        // before this wave signals its cells below, i.e. before this workgroup's partials of the step leave, without which no
+        // dm of the next step -- and no later write to these slots -- exists.
+        if (reducer) {
+          if (s > 0) gp_rearm(b1, slot1((s - 1) & 1, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
+          if (!top) gp_rearm(b3, slot1(s % GP_XR, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
+        }
         {
           // dh^T[cells][rows] = W_p . dm^T, this wave's k-blocks w, w + 4, ...
           f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
@@ -940,10 +951,11 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, const unsigne
             d[0 * GP_ROWS * CW] = dz[0]; d[1 * GP_ROWS * CW] = dz[1]; d[2 * GP_ROWS * CW] = dz[2]; d[3 * GP_ROWS * CW] = dz[3];
           }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the re-arming stores)
         gp_signal(cnt + C_H + r, lane);
         GPTS(6 * r + 4);
         if (!gp_wait(cnt + C_H + r, 4u * ((unsigned)s + 1u), dead)) return;       // every cell's dz of the tile is in LDS
-        if (t > 0) product(r, s & 1, tagbase | ((unsigned)s + 1u));              // (dm(-1) has no consumer)
+        if (t > 0) product(r, s & 1);                                             // (dm(-1) has no consumer)
         GPTS(6 * r + 5);
         // dz(t) over the gate activations of the stash, a quarter of the tile per R wave: NT consecutive lanes write one 16 NT-byte row piece
         int ln = lane;
@@ -969,67 +981,66 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, const unsigne
   const int gw = w - 8, r = gw & 1, gp = gw >> 1;
   float* const mbg = &S.mB[r][gp][lane][0];                            // + 2 n * 256
   const int nvg = (nkb - gp + 1) >> 1;                                 // this wave's k-blocks: gp, gp + 2, ...
-  const bool reducer = c < 2 * nkb;
-  const int jbr = c >> 1, hh = c & 1;
   const int ppw = (NC + 1) >> 1, pp0 = gp * ppw, pn = max(0, min(ppw, NC - pp0));
-  const int rrow = row0 + 16 * r + ((32 * hh + (lane & 31)) & 15), rcol = 16 * jbr + 4 * ((32 * hh + (lane & 31)) >> 4) + 2 * (lane >> 5);
+  const int nlr = (pn + 1 - (lane >> 5)) >> 1;                           // (two producers per load: lanes 0..31 the even ones, 32..63 the odd ones)
+  const int rrow = row0 + 16 * r + ((32 * hh + (lane & 31)) & 15), rcol = 16 * jbr + 4 * ((32 * hh + (lane & 31)) >> 4);
   const int rlen = a.len[rrow];
   for (int s = 0; s < T; ++s) {
     const int t = T - 1 - s;
     GPTS(12);
-    float tot0 = 0.f, tot1 = 0.f;
+    f32x4 tot = {0.f, 0.f, 0.f, 0.f};
     if (reducer) {
-      float2 dtop = make_float2(0.f, 0.f);
-      if (top && rcol < a.ld_dout) dtop = *reinterpret_cast<const float2*>(a.dout_top + ((size_t)t * N + rrow) * a.ld_dout + rcol);
-      float s0 = 0.f, s1 = 0.f;
+      float4 dtop = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (top && rcol < a.ld_dout) dtop = *reinterpret_cast<const float4*>(a.dout_top + ((size_t)t * N + rrow) * a.ld_dout + rcol);
+      f32x4 sa = {0.f, 0.f, 0.f, 0.f};
       if (!top) {
         // the input-gradient partials of the layer above at time t (published a diagonal ago as a rule: read first, poll if not there)
-        unsigned lo[20];
+        unsigned lo[10];
 #pragma unroll
-        for (int k = 0; k < 20; ++k) lo[k] = slot1(s % GP_XR, r, jbr, min(pp0 + k, NC - 1)) + (unsigned)hh * 1024u;
-        if (!gp_sweep<20, false, 20, false>(b3, lo, pn, (unsigned)lane * 16u, slot1(s % GP_XR, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 1024u + 1008u, lane < pn,
-                                     tagbase | ((unsigned)s + 1u), err, [&](int k, float va, float vb) { if (k == 0) { s0 = va; s1 = vb; } else if (k < pn) { s0 += va; s1 += vb; } })) { fail(); return; }
+        for (int k = 0; k < 10; ++k) lo[k] = slot1(s % GP_XR, r, jbr, min(pp0 + 2 * k, NC - 1)) + (unsigned)hh * 512u;
+        if (!gp_sweep<10, false, 10, false>(b3, lo, nlr, pair_off, slot1(s % GP_XR, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
+                                     [&](int k, const f32x4& v) { if (k == 0) sa = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) sa += v; })) { fail(); return; }
       }
       GPTS(13);
       if (s > 0) {
         // the state-gradient partials of this layer from time t + 1
-        unsigned lo[20];
+        unsigned lo[10];
 #pragma unroll
-        for (int k = 0; k < 20; ++k) lo[k] = slot1((s - 1) & 1, r, jbr, min(pp0 + k, NC - 1)) + (unsigned)hh * 1024u;
-        float u0 = 0.f, u1 = 0.f;
-        if (!gp_sweep<20, true, 20, false>(b1, lo, pn, (unsigned)lane * 16u, slot1((s - 1) & 1, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 1024u + 1008u, lane < pn,
-                                    tagbase | (unsigned)s, err, [&](int k, float va, float vb) { if (k == 0) { u0 = va; u1 = vb; } else if (k < pn) { u0 += va; u1 += vb; } })) { fail(); return; }
-        s0 += u0; s1 += u1;
+        for (int k = 0; k < 10; ++k) lo[k] = slot1((s - 1) & 1, r, jbr, min(pp0 + 2 * k, NC - 1)) + (unsigned)hh * 512u;
+        f32x4 ua = {0.f, 0.f, 0.f, 0.f};
+        if (!gp_sweep<10, true, 10, false>(b1, lo, nlr, pair_off, slot1((s - 1) & 1, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
+                                    [&](int k, const f32x4& v) { if (k == 0) ua = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) ua += v; })) { fail(); return; }
+        sa += ua;
       }
       GPTS(14);
-      *reinterpret_cast<float2*>(&S.gs[s & 1][r][gp][lane][0]) = make_float2(s0, s1);
+      *reinterpret_cast<f32x4*>(&S.gs[s & 1][r][gp][lane][0]) = sa;
       gp_signal(cnt + C_G + r, lane);
       if (!gp_wait(cnt + C_G + r, 2u * ((unsigned)s + 1u), dead)) return;
-      const float2 g0 = *reinterpret_cast<const float2*>(&S.gs[s & 1][r][0][lane][0]), g1 = *reinterpret_cast<const float2*>(&S.gs[s & 1][r][1][lane][0]);
+      const float* const gsr = &S.gs[s & 1][r][0][lane & 31][0];
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(gsr), a1 = *reinterpret_cast<const f32x4*>(gsr + 32 * 4);
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(gsr + 64 * 4), c1 = *reinterpret_cast<const f32x4*>(gsr + 96 * 4);
       const bool live = t < rlen;
-      tot0 = live ? (g0.x + g1.x) + dtop.x : 0.f; tot1 = live ? (g0.y + g1.y) + dtop.y : 0.f;
-      if (gp == 0) gp_store(b2, slot2(t, r, jbr) + (unsigned)hh * 1024u + (unsigned)lane * 16u, gen, tot0, tot1);
+      tot = (((a0 + a1) + c0) + c1) + f32x4{dtop.x, dtop.y, dtop.z, dtop.w};
+      if (!live) tot = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (gp == 0 && lane < 32) gp_store(b2, slot2(t, r, jbr) + (unsigned)hh * 512u + (unsigned)lane * 16u, tot);
       GPTS(15);
     }
     {
       // gather dm(t) of the tile: k-blocks gp, gp + 2, ... as B fragments of dh = dm . W_p^T
-      unsigned lo[18];
+      unsigned lo[9];
 #pragma unroll
-      for (int n = 0; n < 9; ++n) {
-        const unsigned o = slot2(t, r, min(gp + 2 * n, nkb - 1));
-        lo[2 * n] = o; lo[2 * n + 1] = o + 512u;
-      }
-      float mv[18][2];
-      if (!gp_sweep<18, true, 18, true>(b2, lo, 2 * nvg, frag_off, slot2(t, r, min(gp + 2 * (lane >> 1), nkb - 1)) + (unsigned)(lane & 1) * 1024u + 1008u,
-                                  lane < 2 * nvg, gen, err, [&](int k, float va, float vb) { mv[k][0] = va; mv[k][1] = vb; })) { fail(); return; }
+      for (int n = 0; n < 9; ++n) lo[n] = slot2(t, r, min(gp + 2 * n, nkb - 1));
+      f32x4 mv[9];
+      if (!gp_sweep<9, true, 9, true>(b2, lo, nvg, frag_off, slot2(t, r, min(gp + 2 * (lane >> 1), nkb - 1)) + (unsigned)(lane & 1) * 512u + 496u,
+                                 lane < 2 * nvg, err, [&](int k, const f32x4& v) { mv[k] = v; })) { fail(); return; }
       GPTS(16);
 #pragma unroll
       for (int n = 0; n < 9; ++n)
-        if (n < nvg) *reinterpret_cast<f32x4*>(mbg + 2 * n * 256) = f32x4{mv[2 * n][0], mv[2 * n][1], mv[2 * n + 1][0], mv[2 * n + 1][1]};
+        if (n < nvg) *reinterpret_cast<f32x4*>(mbg + 2 * n * 256) = mv[n];
       gp_signal(cnt + C_M + r, lane);
       GPTS(17);
     }
-    if (reducer && gp == 1 && rcol < ldP) *reinterpret_cast<float2*>(L.dmt + ((size_t)t * N + rrow) * ldP + rcol) = make_float2(tot0, tot1);
+    if (reducer && gp == 1 && lane < 32 && rcol < ldP) *reinterpret_cast<float4*>(L.dmt + ((size_t)t * N + rrow) * ldP + rcol) = make_float4(tot[0], tot[1], tot[2], tot[3]);
   }
 #ifdef GP_TRACE
   if (gw == 0) { const int i0_ = 12, i1_ = 18; GPT_FLUSH(); }
@@ -1040,8 +1051,8 @@ template <int NT>
 __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_bwd(const GPersistArgs a) {
   __shared__ __attribute__((aligned(16))) GpLdsB<NT> S;
   gu32* ctl = (gu32*)a.ctl;
-  const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  gp_bwd_body<NT>(a, gen, S);
+  const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (counts launches)
+  gp_bwd_body<NT>(a, S);
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1080,11 +1091,18 @@ size_t gpersist_gran1_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_RO
 size_t gpersist_gran2_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * a.T * GP_NCH * GP_SLOT; }
 size_t gpersist_gran3_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * GP_XR * GP_NCH * a.NC * GP_SLOT; }
 
+// (the memset arms the launch's hop-2 slots; gran1 / gran3 are armed once, gpersist_arm, and re-armed by the kernels themselves)
+void gpersist_arm(const GPersistArgs& a, hipStream_t s) {
+  (void)hipMemsetAsync(a.gran1, 0xFF, gpersist_gran1_bytes(a), s);
+  if (a.gran3) (void)hipMemsetAsync(a.gran3, 0xFF, gpersist_gran3_bytes(a), s);
+}
 void launch_glstm_fwd(const GPersistArgs& a, hipStream_t s) {
+  (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_gran2_bytes(a), s);
   hipLaunchKernelGGL(k_glstm_fwd<5>, dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
   ++g_chain_launches;
 }
 void launch_glstm_bwd(const GPersistArgs& a, hipStream_t s) {
+  (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_gran2_bytes(a), s);
   hipLaunchKernelGGL(k_glstm_bwd<5>, dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
   ++g_chain_launches;
 }

@@ -177,10 +177,10 @@ struct GPersistArgs {
   int nl, N, T, H;
   int NT, NC;                                     // 4-cell gate tiles per workgroup, workgroups per (row group, layer)
   const int* len;
-  unsigned long long *gran1, *gran2;              // hop 1 (partial projections, ring of two steps), hop 2 (m chunks, one slot per step); zeroed once
+  unsigned long long *gran1, *gran2;              // hop 1 (partial projections, ring of two steps: armed once, gpersist_arm), hop 2 (m chunks, one slot per step: armed by every launch)
   unsigned* ctl;                                  // control block [DP_CTL_*]
   float forget_bias;
-  unsigned long long* gran3;                      // backward: the partial input gradients a layer hands to the layer below (ring of GP_XR steps); zeroed once
+  unsigned long long* gran3;                      // backward: the partial input gradients a layer hands to the layer below (ring of GP_XR steps); armed once
   const float* dout_top;                          // backward: [T][N][ld_dout] gradient of the top layer's masked outputs
   int ld_dout;
 };
@@ -188,6 +188,7 @@ bool gpersist_plan(GPersistArgs& a);              // fills NT / NC; false: shape
 size_t gpersist_gran1_bytes(const GPersistArgs& a);
 size_t gpersist_gran2_bytes(const GPersistArgs& a);
 size_t gpersist_gran3_bytes(const GPersistArgs& a);
+void gpersist_arm(const GPersistArgs& a, hipStream_t s);          // once after allocation: the "not written" pattern in every slot of gran1 / gran3
 void launch_glstm_fwd(const GPersistArgs& a, hipStream_t s);
 void launch_glstm_bwd(const GPersistArgs& a, hipStream_t s);      // gates: activations in, dz out; needs c, dmt, dout_top; no input gradient for layer 0
 extern long long g_chain_launches;

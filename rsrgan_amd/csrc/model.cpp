@@ -438,6 +438,8 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
       if (gp_gran1 && gp_gran2 && gp_ctl) {
         const unsigned ctl0[DP_CTL_WORDS] = {1u, 0u, 0u, 0u};
         HIPC(hipMemcpy(gp_ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice));
+        GPersistArgs gb{};
+        if (gpersist_args(gb, Tmax)) { gpersist_arm(gb, 0); HIPC(hipDeviceSynchronize()); }     // every ring slot holds the "not written" pattern
       } else { gp_gran1 = gp_gran2 = nullptr; gp_ctl = nullptr; }
     }
   }

@@ -45,8 +45,8 @@ int main(int argc, char** argv) {
   if (!gpersist_plan(a)) { printf("unsupported shape\n"); return 1; }
   const size_t g1 = gpersist_gran1_bytes(a), g2 = gpersist_gran2_bytes(a);
   CK(hipMalloc(&a.gran1, g1)); CK(hipMalloc(&a.gran2, g2)); CK(hipMalloc(&a.ctl, 64));
-  CK(hipMemset(a.gran1, 0, g1)); CK(hipMemset(a.gran2, 0, g2));
-  if (bwd) { const size_t g3 = gpersist_gran3_bytes(a); CK(hipMalloc(&a.gran3, g3)); CK(hipMemset(a.gran3, 0, g3)); }
+  if (bwd) { const size_t g3 = gpersist_gran3_bytes(a); CK(hipMalloc(&a.gran3, g3)); }
+  gpersist_arm(a, 0); CK(hipDeviceSynchronize());
   { const unsigned c0[4] = {1u, 0u, 0u, 0u}; CK(hipMemcpy(a.ctl, c0, 16, hipMemcpyHostToDevice)); }
   hipStream_t s; CK(hipStreamCreate(&s));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
