@@ -25,7 +25,7 @@
 //          [64 lanes][16 bytes]: lane pl = (q, lr) of the producer / consumer fragment owns the four columns 4 q .. 4 q + 3 of row lr, so
 //          every store / load instruction moves whole 128-byte lines and a reducer's half (lanes 32 hh ..) is 512 contiguous bytes.
 // Inside a workgroup the three roles synchronise through monotonic LDS counters (no s_barrier: the roles are not in lock step).
-// Hop 2 has one slot per step (armed by a memset in front of the launch); hop 1 is a ring of two steps whose slots the reducer
+// Hop 2 has one slot per step (armed by a memset in front of the launch); hop 1 is a ring of GP_R1 steps whose slots the reducer
 // re-arms after summing them.  Every spin is bounded; failures go to the sticky err word of the control block and poison the top layer's output with NaN.
 #include <type_traits>
 
@@ -44,6 +44,7 @@ constexpr int GP_NKB = 18;               // k-blocks of 16 of the recurrent / in
 constexpr int GP_KBW = 5;                // k-blocks per R / X wave (k-block jb belongs to wave jb & 3)
 constexpr int GP_SLOT = 1024;            // bytes per chunk slot: a 16 x 16 tile of floats, 16 bytes (four columns of one row) per fragment lane
 constexpr unsigned GP_SENT = 0xFFFFFFFFu; // a word of a slot nobody has written yet
+constexpr int GP_R1 = 3;                 // steps in the hop-1 ring: a slot is summed in step t, re-armed at the end of step t + 1, written again in step t + 3
 constexpr int GP_NCH = GP_NKB * GP_NR;   // chunk slots per layer and step (the layout's stride; a layer uses its first nkb * NR)
 constexpr unsigned GP_SC1 = 16u;         // aux of the raw-buffer builtins: sc1 (agent scope: write-through store / L1-bypassing load)
 constexpr unsigned GP_VOL = 1u << 31;    // ... compiler-only: volatile (a polled load must not be hoisted out of its loop)
@@ -226,7 +227,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
   gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
   // hop 1: [group][layer][parity][tile][k-block][producer] slots; hop 2: [group][layer][t][tile][k-block] slots
   const size_t g1_per = (size_t)GP_NCH * NC * GP_SLOT, g2_per = (size_t)GP_NCH * GP_SLOT;
-  const GpBuf b1 = gp_buf((const char*)a.gran1 + (size_t)(grp * a.nl + l) * 2 * g1_per, 2 * g1_per);
+  const GpBuf b1 = gp_buf((const char*)a.gran1 + (size_t)(grp * a.nl + l) * GP_R1 * g1_per, GP_R1 * g1_per);
   const GpBuf b2 = gp_buf((const char*)a.gran2 + (size_t)(grp * a.nl + l) * T * g2_per, (size_t)T * g2_per);
   const GpBuf b2x = gp_buf((const char*)a.gran2 + (size_t)(grp * a.nl + (l > 0 ? l - 1 : 0)) * T * g2_per, (size_t)T * g2_per);
   const unsigned frag_off = (unsigned)lane * 16u;                     // a fragment lane's bytes in a chunk slot
@@ -300,10 +301,6 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
         GPT(6 * r + 1);
         if (t > 0 && !gp_wait(&S.cnt_m[r], 2u * (unsigned)t, dead)) return;   // carried m(t-1) of the tile is in LDS
         GPT(6 * r + 2);
-        // ... so this workgroup's G waves have summed the partial projections of step t-1: re-arm their ring slots.  The stores are
-        // acknowledged before this wave signals its cells below, i.e. before this workgroup's partials of step t leave, without
-        // which no m(t) and hence no partial of step t+1 -- the next write to these slots -- exists.
-        if (reducer && t > 0) gp_rearm(b1, slot1((t - 1) & 1, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
         {
           f32x4 acc[NT];
 #pragma unroll
@@ -358,7 +355,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
             d[5 * GP_ROWS * CW] = live ? hh : 0.f;
           }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the re-arming stores; issued a whole compute phase ago)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the re-arming stores of the step before: acknowledged long ago)
         gp_signal(&S.cnt_h[r], lane);
         GPT(6 * r + 5);
         if (!gp_wait(&S.cnt_h[r], 4u * ((unsigned)t + 1u), dead)) return;     // every cell of the tile is in the stage
@@ -375,13 +372,18 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
           if (e < 6 * 16 * NT && cell0 + 4 * cq < H) *reinterpret_cast<float4*>(dst) = v;
         }
         gp_signal(&S.cnt_s[r], lane);
+        // This workgroup's G waves summed the partial projections of step t-1 before they gathered m(t-1) (the wait at the top):
+        // re-arm those ring slots, here, where the wave has nothing urgent to do.  The stores are acknowledged before the wave
+        // signals its cells of step t+1, i.e. before this workgroup's partials of step t+1 leave, without which no m(t+1) and
+        // hence no partial of step t+2 -- the next write to these slots -- exists.
+        if (reducer && t > 0) gp_rearm(b1, slot1((t - 1) % GP_R1, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
       }
     }
     if (reducer) {                                                       // the last step's partials: leave every ring slot armed for the next launch
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         if (!gp_wait(&S.cnt_m[r], 2u * (unsigned)T, dead)) return;
-        gp_rearm(b1, slot1((T - 1) & 1, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
+        gp_rearm(b1, slot1((T - 1) % GP_R1, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
       }
     }
 #ifdef GP_TRACE
@@ -514,7 +516,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
   }
   if (reducer && gp == 1 && lane < 32 && rcol < ldP) *reinterpret_cast<float4*>(L.mst + (size_t)rrow * ldP + rcol) = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int t = 0; t < T; ++t) {
-    const int par = t & 1;
+    const int par = t & 1, par1 = t % GP_R1;
     GPT(12);
     if (!gp_wait(&S.cnt_h[r], 4u * ((unsigned)t + 1u), dead)) return;  // the cells of step t, tile r: h is in LDS
     GPT(13);
@@ -522,7 +524,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
       float hv[NT];
 #pragma unroll
       for (int ks = 0; ks < NT; ++ks) hv[ks] = sth[4 * ks];
-      const unsigned pub0 = slot1(par, r, gp, c) + frag_off;
+      const unsigned pub0 = slot1(par1, r, gp, c) + frag_off;
       // three chunks in flight (the dependent-accumulator latency of the 16x16x4 form is 40 cycles for a 32-cycle issue); a chunk
       // leaves as soon as its NT products are done, so the write-through stores overlap the remaining MFMAs
 #pragma unroll
@@ -546,9 +548,9 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
       // even and odd ones in the two half waves)
       unsigned lo[10];
 #pragma unroll
-      for (int k = 0; k < 10; ++k) lo[k] = slot1(par, r, jbr, min(pp0 + 2 * k, NC - 1)) + (unsigned)hh * 512u;
+      for (int k = 0; k < 10; ++k) lo[k] = slot1(par1, r, jbr, min(pp0 + 2 * k, NC - 1)) + (unsigned)hh * 512u;
       f32x4 sa = {0.f, 0.f, 0.f, 0.f};
-      if (!gp_sweep<10, true, 10, false>(b1, lo, nlr, pair_off, slot1(par, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
+      if (!gp_sweep<10, true, 10, false>(b1, lo, nlr, pair_off, slot1(par1, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
                                   [&](int k, const f32x4& v) { if (k == 0) sa = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) sa += v; })) { fail(); return; }
       GPT(15);
       *reinterpret_cast<f32x4*>(&S.gs[par][r][gp][lane][0]) = sa;
@@ -625,13 +627,14 @@ __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_fwd(const GPersistAr
 //   hop 2  it publishes the half chunk and writes it to the stash (dmt: the projection's weight gradient); every workgroup of the
 //          layer gathers dm(t), multiplies by its W_p slice (dh), runs the cell's gradient (dz: in place over the gate activations
 //          in the stash, and as the B operand of the two products above).
-// The state-gradient ring has two steps like the forward's (a producer cannot be two steps ahead of a consumer it needs the sum
-// from); the input-gradient ring between two layers has GP_XR steps and an explicit back-pressure check: the upper layer does not
-// depend on the lower one, so before re-using a ring slot it polls the lower layer's dm chunk of GP_XR steps ago (published by the
-// reducer AFTER it has summed that slot).  Layer 0's input gradient is a time-batched GEMM over the dz stash afterwards.
+// The state-gradient ring has GP_R1 steps like the forward's (a producer cannot be two steps ahead of a consumer it needs the sum
+// from; the third step is the re-arming's slack); the input-gradient ring between two layers has GP_XR steps and an explicit
+// back-pressure check: the upper layer does not depend on the lower one, so before re-using a ring slot it polls the lower layer's
+// dm chunk of GP_XR - 2 steps ago (published by the reducer AFTER it has summed and re-armed that slot).  Layer 0's input gradient
+// is a time-batched GEMM over the dz stash afterwards.
 // Cell gradient: kernels.hip k_bwd_a2 (peepholes, o's peephole on the new c, dynamic_rnn masking: a finished row has dz = 0 and
 // carries dc through).
-constexpr int GP_XR = 5;   // (a slot is re-armed one step after it was summed: four steps of slack)
+constexpr int GP_XR = 6;   // (a slot is re-armed, acknowledged, two steps after it was summed: four steps of slack)
 
 template <int NT>
 struct GpLdsB {
@@ -646,7 +649,7 @@ struct GpLdsB {
   float pfs[GP_NR][5][16][4 * NT];          // the stash of the NEXT step of a tile: gate activations i, j, f, o and c(t-1) (the X waves fetch it a step ahead)
   float peep[4 * NT][4];                    // {w_i, w_f, w_o, -} per cell
   float car[4][2][GP_NR][64][2];            // c(t) and the carried dc of an R wave's cells [wave][gate tile w | 4 + w][row tile][lane] (in registers they get spilled, and a scratch reload waits for the wave's write-through stores)
-  unsigned cnt_p[GP_NR], cnt_h[GP_NR], cnt_m[GP_NR], cnt_g[GP_NR], cnt_z[GP_NR], cnt_f[GP_NR], dead, pad_[3];
+  unsigned cnt_p[GP_NR], cnt_h[GP_NR], cnt_m[GP_NR], cnt_g[GP_NR], cnt_z[GP_NR], cnt_f[GP_NR], cnt_q[GP_NR], dead, pad_[1];
 };
 
 // one lane = one sentinel piece (16 bytes at `so` when son): wait until every one is valid
@@ -684,7 +687,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
   const bool top = l == a.nl - 1;
   gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
   const size_t g1_per = (size_t)GP_NCH * NC * GP_SLOT, g2_per = (size_t)GP_NCH * GP_SLOT;
-  const GpBuf b1 = gp_buf((const char*)a.gran1 + (size_t)(grp * a.nl + l) * 2 * g1_per, 2 * g1_per);
+  const GpBuf b1 = gp_buf((const char*)a.gran1 + (size_t)(grp * a.nl + l) * GP_R1 * g1_per, GP_R1 * g1_per);
   const GpBuf b2 = gp_buf((const char*)a.gran2 + (size_t)(grp * a.nl + l) * T * g2_per, (size_t)T * g2_per);
   const GpBuf b2x = gp_buf((const char*)a.gran2 + (size_t)(grp * a.nl + (l > 0 ? l - 1 : 0)) * T * g2_per, (size_t)T * g2_per);
   const GpBuf b3 = gp_buf((const char*)a.gran3 + (size_t)(grp * a.nl + l) * GP_XR * g1_per, GP_XR * g1_per);              // what the layer above hands to this one
@@ -723,7 +726,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
   unsigned zed;
   asm volatile("v_mov_b32 %0, 0" : "=v"(zed));
   unsigned* const cnt = &S.cnt_p[0] + zed;
-  constexpr int C_P = 0, C_H = GP_NR, C_M = 2 * GP_NR, C_G = 3 * GP_NR, C_Z = 4 * GP_NR, C_F = 5 * GP_NR, C_DEAD = 6 * GP_NR;
+  constexpr int C_P = 0, C_H = GP_NR, C_M = 2 * GP_NR, C_G = 3 * GP_NR, C_Z = 4 * GP_NR, C_F = 5 * GP_NR, C_Q = 6 * GP_NR, C_DEAD = 7 * GP_NR;
   const unsigned* dead = cnt + C_DEAD;
   auto fail = [&]() {
     if (lane == 0) {
@@ -844,17 +847,21 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           GPTS(18 + 2 * r);
-          // back-pressure: ring slot s % GP_XR was summed AND re-armed by the layer below when it has published its dm(t + GP_XR - 1)
-          // (its R waves re-arm a slot in the step that summed it, acknowledged before that step's partials leave, which the dm of
-          // the step after waits for)
-          if (!noprod && s >= GP_XR - 1 && !gp_poll(b2x, slot2(t + GP_XR - 1, r, min(ww + 4 * (lane >> 1), nkbx - 1)) + (unsigned)(lane & 1) * 512u + 496u, lane < 2 * nsx, err)) { fail(); return; }
+          // back-pressure: ring slot s % GP_XR was summed AND re-armed by the layer below when it has published its dm(t + GP_XR - 2)
+          // (its R waves re-arm a slot at the end of the step that summed it, acknowledged before the next step's partials leave,
+          // which the dm of the step after that waits for)
+          if (!noprod && s >= GP_XR - 2 && !gp_poll(b2x, slot2(t + GP_XR - 2, r, min(ww + 4 * (lane >> 1), nkbx - 1)) + (unsigned)(lane & 1) * 512u + 496u, lane < 2 * nsx, err)) { fail(); return; }
           if (!gp_wait(cnt + C_H + r, 4u * ((unsigned)s + 1u), dead)) return;       // dz(t) of the tile is in LDS (and the cells have read the stage)
           GPTS(19 + 2 * r);
+          if (t > 0) { fetch(t - 1, r); stage(r); }                       // (needed by the cells a whole hand-off from now)
           if (!noprod) {
+            // The R waves' state-gradient product starts at the same moment on the same SIMDs and is on the recurrence's critical
+            // path; this one only feeds the layer below, which runs a ring's worth of steps behind: let theirs go first (side by
+            // side both took 6-7.6 k cycles for 3.2 k of MFMA issue each, s_setprio notwithstanding).
+            if (t > 0 && !gp_wait(cnt + C_Q + r, 4u * ((unsigned)s + 1u), dead)) return;
             product(r, s % GP_XR);
             gp_signal(cnt + C_Z + r, lane);                                 // (the product has read dzB)
           }
-          if (t > 0) { fetch(t - 1, r); stage(r); }                       // (needed by the cells a whole hand-off from now)
         }
       }
 #ifdef GP_TRACE
@@ -890,13 +897,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
         GPTS(6 * r + 0);
         if (!gp_wait(cnt + C_M + r, 2u * ((unsigned)s + 1u), dead)) return;      // dm(t) of the tile is in LDS
         GPTS(6 * r + 1);
-        // ... so this workgroup's G waves have summed the partials of this step: re-arm their slots of both rings.  Acknowledged
-        // before this wave signals its cells below, i.e. before this workgroup's partials of the step leave, without which no
-        // dm of the next step -- and no later write to these slots -- exists.
-        if (reducer) {
-          if (s > 0) gp_rearm(b1, slot1((s - 1) & 1, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
-          if (!top) gp_rearm(b3, slot1(s % GP_XR, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
-        }
+
         {
           // dh^T[cells][rows] = W_p . dm^T, this wave's k-blocks w, w + 4, ...
           f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
@@ -951,11 +952,11 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
             d[0 * GP_ROWS * CW] = dz[0]; d[1 * GP_ROWS * CW] = dz[1]; d[2 * GP_ROWS * CW] = dz[2]; d[3 * GP_ROWS * CW] = dz[3];
           }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the re-arming stores)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the re-arming stores of the step before)
         gp_signal(cnt + C_H + r, lane);
         GPTS(6 * r + 4);
         if (!gp_wait(cnt + C_H + r, 4u * ((unsigned)s + 1u), dead)) return;       // every cell's dz of the tile is in LDS
-        if (t > 0) product(r, s & 1);                                             // (dm(-1) has no consumer)
+        if (t > 0) { product(r, s % GP_R1); gp_signal(cnt + C_Q + r, lane); }     // (dm(-1) has no consumer)
         GPTS(6 * r + 5);
         // dz(t) over the gate activations of the stash, a quarter of the tile per R wave: NT consecutive lanes write one 16 NT-byte row piece
         int ln = lane;
@@ -967,6 +968,13 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
           const float4 v = *reinterpret_cast<const float4*>(&S.st[k][row][4 * cq]);
           float* dst = L.gates + ((size_t)t * N + row0 + row) * H4 + k * H + cell0 + 4 * cq;
           if (e < 4 * 16 * NT && cell0 + 4 * cq < H) *reinterpret_cast<float4*>(dst) = v;
+        }
+        // This workgroup's G waves summed this step's partials before they gathered dm(t) (the wait at the top): re-arm their slots of
+        // both rings.  Acknowledged before the wave signals its cells of the next step, i.e. before this workgroup's partials of that
+        // step leave, without which no dm of the step after -- and no later write to these slots -- exists.
+        if (reducer) {
+          if (s > 0) gp_rearm(b1, slot1((s - 1) % GP_R1, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
+          if (!top) gp_rearm(b3, slot1(s % GP_XR, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
         }
       }
     }
@@ -1006,9 +1014,9 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
         // the state-gradient partials of this layer from time t + 1
         unsigned lo[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) lo[k] = slot1((s - 1) & 1, r, jbr, min(pp0 + 2 * k, NC - 1)) + (unsigned)hh * 512u;
+        for (int k = 0; k < 10; ++k) lo[k] = slot1((s + GP_R1 - 1) % GP_R1, r, jbr, min(pp0 + 2 * k, NC - 1)) + (unsigned)hh * 512u;
         f32x4 ua = {0.f, 0.f, 0.f, 0.f};
-        if (!gp_sweep<10, true, 10, false>(b1, lo, nlr, pair_off, slot1((s - 1) & 1, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
+        if (!gp_sweep<10, true, 10, false>(b1, lo, nlr, pair_off, slot1((s + GP_R1 - 1) % GP_R1, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
                                     [&](int k, const f32x4& v) { if (k == 0) ua = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) ua += v; })) { fail(); return; }
         sa += ua;
       }
@@ -1087,7 +1095,7 @@ bool gpersist_plan(GPersistArgs& a) {
   // every workgroup must be resident at once (they wait for each other): one 12-wave workgroup per CU
   return gp_grid(a) <= 256;
 }
-size_t gpersist_gran1_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * 2 * GP_NCH * a.NC * GP_SLOT; }
+size_t gpersist_gran1_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * GP_R1 * GP_NCH * a.NC * GP_SLOT; }
 size_t gpersist_gran2_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * a.T * GP_NCH * GP_SLOT; }
 size_t gpersist_gran3_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * GP_XR * GP_NCH * a.NC * GP_SLOT; }
 

@@ -177,7 +177,7 @@ struct GPersistArgs {
   int nl, N, T, H;
   int NT, NC;                                     // 4-cell gate tiles per workgroup, workgroups per (row group, layer)
   const int* len;
-  unsigned long long *gran1, *gran2;              // hop 1 (partial projections, ring of two steps: armed once, gpersist_arm), hop 2 (m chunks, one slot per step: armed by every launch)
+  unsigned long long *gran1, *gran2;              // hop 1 (partial projections, ring of three steps: armed once, gpersist_arm), hop 2 (m chunks, one slot per step: armed by every launch)
   unsigned* ctl;                                  // control block [DP_CTL_*]
   float forget_bias;
   unsigned long long* gran3;                      // backward: the partial input gradients a layer hands to the layer below (ring of GP_XR steps); armed once

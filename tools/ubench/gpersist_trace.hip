@@ -12,7 +12,9 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 namespace rsr { long long g_chain_launches = 0; }
+#ifndef GP_NOTRACE                 // -DGP_NOTRACE: the product's code (no stamps: the launch time only; the stamps cost the backward kernel 18 spilled registers)
 #define GP_TRACE 1
+#endif
 #include "../../rsrgan_amd/csrc/gpersist.hip"
 using namespace rsr;
 
@@ -66,6 +68,9 @@ int main(int argc, char** argv) {
   { unsigned cn[8]; CK(hipMemcpyFromSymbol(cn, HIP_SYMBOL(rsr::g_gp_cnt), sizeof(cn)));
     printf("first full reads (5 launches): through the caches %u, of them failed %u; write-through %u, failed %u\n", cn[0], cn[1], cn[2], cn[3]); }
 #endif
+#ifdef GP_NOTRACE
+  return 0;
+#else
   static unsigned tr[256][24][24];
   CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(rsr::g_gp_trace), sizeof(tr)));
   // R wave 0, tile r (stamps 6 r + ..): 0 top, 1 x-part there, 2 m(t-1) there, 3 recurrent MFMAs + tiles written, 4 all partials there, 5 cell done
@@ -114,4 +119,5 @@ int main(int argc, char** argv) {
     printf("   prologue (kernel entry -> R0 enters step 0): %.0f cycles\n", pro / nb_);
   }
   return 0;
+#endif
 }
