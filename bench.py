@@ -216,8 +216,9 @@ def measure_sequence(a, net, d_type, B, T, steps, warmup, rank, local, world, de
             model.engine.profile_begin()
             step()
             prof_gp = model.engine.profile_read_kind(1)            # k_glstm_fwd: the persistent generator recurrence (csrc/gpersist.hip)
+            prof_gb = model.engine.profile_read_kind(2)            # k_glstm_bwd: its BPTT
             prof = model.engine.profile_read()                    # k_fwd_gates launches of the same step
-            prof = ("k_glstm_fwd",) + tuple(prof_gp) if prof_gp[1] > prof[1] else ("k_fwd_gates",) + tuple(prof)
+            prof = max([("k_glstm_bwd",) + tuple(prof_gb), ("k_glstm_fwd",) + tuple(prof_gp), ("k_fwd_gates",) + tuple(prof)], key=lambda p_: p_[2])
             # (the floor chain is skipped under rocprofv3: 800 extra launches would distort the committed kernel statistics)
             under_prof = any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ)
             chain = (model.engine.profile_launches(), model.engine.launch_floor(400, 0), model.engine.launch_floor(400, 1)) if not under_prof else None
@@ -585,12 +586,14 @@ def main():
                     "frac": round(k_ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": k_traffic,
                     "frac_at_rocprofv3_duration": (round(fl_l / n_l / (k_rocprof_us * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)
                                                    if k_rocprof_us else None),
-                    "how": "the kernel class with the largest total duration in the step: k_glstm_fwd (csrc/gpersist.hip: the generator's "
-                           "whole forward recurrence as ONE persistent launch; algorithmic FLOP = every layer's recurrent product and "
-                           "projection + the input product above layer 0) or, with RSRGAN_GPERSIST=0, the k_fwd_gates launches of the "
-                           "wavefront.  avg_us: every launch of one extra step bracketed by HIP events on its stream (rsrgan_profile_begin "
-                           "/ read_kind / read; includes the event records, an upper bound); rocprofv3_avg_us: AverageNs of the same "
-                           "kernel in the committed profiles/r4_final_rocprofv3_kernel_stats.csv of this command"}
+                    "how": "the kernel class with the largest total duration in the step: k_glstm_bwd (csrc/gpersist.hip: the generator's "
+                           "whole BPTT as ONE persistent launch; algorithmic FLOP = every layer's state-gradient product and dh = dm.Wp^T "
+                           "+ the input-gradient product above layer 0), k_glstm_fwd (its forward recurrence: recurrent product, projection, "
+                           "input product above layer 0) or, with RSRGAN_GPERSIST=0, the k_fwd_gates launches of the wavefront.  avg_us: "
+                           "every launch of one extra step bracketed by HIP events on its stream (rsrgan_profile_begin / read_kind / read; "
+                           "includes the event records and the memset that arms the launch's hop-2 slots, an upper bound); "
+                           "rocprofv3_avg_us: AverageNs of the same kernel in the committed profiles/r4_final_rocprofv3_kernel_stats.csv "
+                           "of this command"}
         out = {"metric": "GAN train frames/sec (G+D step), 257-dim LPS->40-dim MFCC", "value": round(value, 1),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt * 1e3 / a.steps, 4), "ms_per_step_median": round(res["med_ms"], 4),

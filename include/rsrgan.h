@@ -216,7 +216,8 @@ int rsrgan_profile_begin(rsrgan_handle h);
 int rsrgan_profile_read(rsrgan_handle h, int32_t* launches, double* total_us, double* alg_flops);
 /* the same window for another kernel class: kind 0 = k_fwd_gates (as above), kind 1 = k_glstm_fwd, the persistent launch that runs the
  * generator's whole forward recurrence (csrc/gpersist.hip; algorithmic FLOP = every layer's recurrent product and projection + the
- * input product above layer 0).  Call before rsrgan_profile_read (which closes the window). */
+ * input product above layer 0), kind 2 = k_glstm_bwd, its BPTT (state-gradient product, dh = dm . W_p^T, the input-gradient product
+ * above layer 0).  Call before rsrgan_profile_read (which closes the window). */
 int rsrgan_profile_read_kind(rsrgan_handle h, int32_t kind, int32_t* launches, double* total_us, double* alg_flops);
 
 /* Health of the persistent recurrence kernels (csrc/dpersist.hip): synchronises the handle's stream, returns in *code 0 or

@@ -295,7 +295,7 @@ int rsrgan_grad_bucket_wait(rsrgan_handle h, int32_t net, int32_t i, void* strea
 
 int rsrgan_profile_begin(rsrgan_handle h) {
   CHECK_H(h);
-  h->m.prof_on = true; h->m.prof_n = 0; h->m.prof_flops = 0.0; h->m.prof_gp_n = 0; h->m.prof_gp_flops = 0.0;
+  h->m.prof_on = true; h->m.prof_n = 0; h->m.prof_flops = 0.0; h->m.prof_gp_n = 0; h->m.prof_gp_flops = 0.0; h->m.prof_gb_n = 0; h->m.prof_gb_flops = 0.0;
   g_chain_launches = 0;
   return RSRGAN_OK;
 }
@@ -334,6 +334,7 @@ int rsrgan_device_status(rsrgan_handle h, int32_t* code) {
     if (ctl[DP_CTL_ERR] != 0 || ctl[DP_CTL_DONE] != 0) {          // (an aborted launch can leave the arrival count behind)
       const unsigned z[2] = {0u, 0u};
       if (hipMemcpy(blocks[k] + DP_CTL_DONE, z, sizeof(z), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed"); return RSRGAN_ERR_HIP; }
+      if (k == 1) m.gpersist_rearm();                               // (an aborted generator launch leaves ring slots written: arm them again)
     }
   }
   return RSRGAN_OK;
@@ -363,15 +364,17 @@ int rsrgan_profile_read_kind(rsrgan_handle h, int32_t kind, int32_t* launches, d
   CHECK_H(h);
   if (kind == 0) return rsrgan_profile_read(h, launches, total_us, alg_flops);
   Model& m = h->m;
-  if (kind != 1 || !launches || !total_us || !alg_flops) { set_error("profile_read_kind: bad argument"); return RSRGAN_ERR_INVALID; }
+  if ((kind != 1 && kind != 2) || !launches || !total_us || !alg_flops) { set_error("profile_read_kind: bad argument"); return RSRGAN_ERR_INVALID; }
+  std::vector<hipEvent_t>& ev = kind == 1 ? m.prof_gp_ev : m.prof_gb_ev;
+  const int n = kind == 1 ? m.prof_gp_n : m.prof_gb_n;
   double us = 0.0;
-  for (int i = 0; i < m.prof_gp_n; ++i) {
-    if (hipEventSynchronize(m.prof_gp_ev[2 * i + 1]) != hipSuccess) { set_error("hipEventSynchronize failed"); return RSRGAN_ERR_HIP; }
+  for (int i = 0; i < n; ++i) {
+    if (hipEventSynchronize(ev[2 * i + 1]) != hipSuccess) { set_error("hipEventSynchronize failed"); return RSRGAN_ERR_HIP; }
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, m.prof_gp_ev[2 * i], m.prof_gp_ev[2 * i + 1]) != hipSuccess) { set_error("hipEventElapsedTime failed"); return RSRGAN_ERR_HIP; }
+    if (hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]) != hipSuccess) { set_error("hipEventElapsedTime failed"); return RSRGAN_ERR_HIP; }
     us += 1e3 * ms;
   }
-  *launches = m.prof_gp_n; *total_us = us; *alg_flops = m.prof_gp_flops;
+  *launches = n; *total_us = us; *alg_flops = kind == 1 ? m.prof_gp_flops : m.prof_gb_flops;
   return RSRGAN_OK;
 }
 

@@ -438,8 +438,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
       if (gp_gran1 && gp_gran2 && gp_ctl) {
         const unsigned ctl0[DP_CTL_WORDS] = {1u, 0u, 0u, 0u};
         HIPC(hipMemcpy(gp_ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice));
-        GPersistArgs gb{};
-        if (gpersist_args(gb, Tmax)) { gpersist_arm(gb, 0); HIPC(hipDeviceSynchronize()); }     // every ring slot holds the "not written" pattern
+        gpersist_rearm();
       } else { gp_gran1 = gp_gran2 = nullptr; gp_ctl = nullptr; }
     }
   }
@@ -532,6 +531,8 @@ void Model::destroy() {
   prof_ev.clear();
   for (auto& e : prof_gp_ev) if (e) (void)hipEventDestroy(e);
   prof_gp_ev.clear();
+  for (auto& e : prof_gb_ev) if (e) (void)hipEventDestroy(e);
+  prof_gb_ev.clear();
   for (void* p : allocs) (void)hipFree(p);
   allocs.clear();
 }
@@ -929,6 +930,13 @@ bool Model::gpersist_args(GPersistArgs& a, int T) const {
   return gpersist_plan(a);
 }
 
+void Model::gpersist_rearm() {
+  GPersistArgs a{};
+  if (!gp_gran1 || !gpersist_args(a, Tmax)) return;
+  gpersist_arm(a, 0);
+  (void)hipDeviceSynchronize();
+}
+
 bool Model::persist_forward_g(int T, hipStream_t s) {
   if (!gp_fwd_on() || !wavefront() || seq_drop_on()) return false;
   GPersistArgs a{};
@@ -970,7 +978,21 @@ bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only)
   a.dout_top = ch.back().dout; a.ld_dout = gl.back().ldP;
   if (!a.dout_top) return false;
   if (check_only) return true;
-  launch_glstm_bwd(a, s);
+  if (prof_on) {
+    if ((size_t)(2 * prof_gb_n + 2) > prof_gb_ev.size()) {
+      const size_t old = prof_gb_ev.size();
+      prof_gb_ev.resize(old + 8, nullptr);
+      for (size_t i = old; i < prof_gb_ev.size(); ++i) (void)hipEventCreate(&prof_gb_ev[i]);
+    }
+    // algorithmic FLOP of the launch: every layer's state-gradient product and dh = dm . W_p^T, the input-gradient product above layer 0
+    for (size_t l = 0; l < gl.size(); ++l)
+      prof_gb_flops += 2.0 * B * T * ((double)((l ? gl[l].I : 0) + gl[l].P) * 4.0 * gl[l].H + (double)gl[l].H * gl[l].P);
+    (void)hipEventRecord(prof_gb_ev[2 * prof_gb_n], s);
+    launch_glstm_bwd(a, s);
+    (void)hipEventRecord(prof_gb_ev[2 * prof_gb_n + 1], s);
+    ++prof_gb_n;
+  } else
+    launch_glstm_bwd(a, s);
   if (ch[0].din) {               // d(inputs of layer 0) = dZ_0 . K_x^T, batched over time
     const LayerRun& R = ch[0];
     const int H4 = 4 * R.L->H;

@@ -159,6 +159,7 @@ struct Model {
   int gp_env = 3;                                         // RSRGAN_GPERSIST: bit 0 the forward launch, bit 1 the backward launch (0: the launch-per-phase wavefront)
   bool gp_fwd_on() const { return gp_gran1 && (gp_env & 1); }
   bool gpersist_args(GPersistArgs& a, int T) const;       // false: not applicable
+  void gpersist_rearm();                                  // the "not written" pattern in every ring slot (after allocation, after a failed launch)
   bool persist_forward_g(int T, hipStream_t s);           // layer 0's x-part batched first; fills the complete stash of every layer
   bool persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only = false);   // BPTT of the generator chain (k_glstm_bwd), layer 0's input gradient as a GEMM, the weight gradients unless deferred
   // fully-connected stacks: models/dnn.py generator and models/discriminator_dnn.py discriminator
@@ -281,6 +282,10 @@ struct Model {
   std::vector<hipEvent_t> prof_gp_ev;
   int prof_gp_n = 0;
   double prof_gp_flops = 0.0;
+  // ... and for the persistent generator BPTT (k_glstm_bwd: one launch per G-run): rsrgan_profile_read_kind(h, 2, ...)
+  std::vector<hipEvent_t> prof_gb_ev;
+  int prof_gb_n = 0;
+  double prof_gb_flops = 0.0;
   void gates_launch(const FwdGateJobs& gj, int blocks, int kb, hipStream_t s);
   int gates_blocks(int H, int N) const;
   int proj_blocks(int P, int N) const;

@@ -118,21 +118,24 @@ def test_persistent_discriminator_recurrence_agrees(B, T, mode):
     assert a["vars_sha"] == c["vars_sha"]          # fixed summation order: reproducible bits
 
 
-@pytest.mark.parametrize("B,T", [(32, 9), (64, 100)])
-def test_persistent_generator_recurrence_agrees(B, T):
-    """csrc/gpersist.hip: the generator's forward recurrence (models/lstm.py:89-112) as ONE persistent launch -- weights resident,
-    partial projections reduce-scattered and the state all-gathered as tagged granules -- against the launch-per-phase wavefront.
-    Same products; the projection is summed per slice of 20 cells and the gates per k-block group: fp32 rounding apart.  Ragged
-    lengths exercise dynamic_rnn's masking in the consumers.  The launch count proves which path ran."""
+@pytest.mark.parametrize("B,T,mode", [(32, 9, 1), (64, 100, 1), (32, 9, 3), (64, 100, 3), (32, 1, 3), (32, 2, 3), (64, 7, 2)])
+def test_persistent_generator_recurrence_agrees(B, T, mode):
+    """csrc/gpersist.hip: the generator's forward recurrence (models/lstm.py:89-112; mode bit 0) and its BPTT (bit 1) as ONE persistent
+    launch each -- weights resident, partial projections / partial state and input gradients reduce-scattered and the state (its
+    gradient) all-gathered as sentinel-armed 16-byte pieces -- against the launch-per-phase wavefront.  Same products; the projection
+    is summed per slice of 20 cells and the gates per k-block group: fp32 rounding apart.  Ragged lengths exercise dynamic_rnn's
+    masking in the consumers; T = 1, 2, 7 the ring start-up, wrap-around (rings of 3 and 6 steps) and the re-arming epilogue (the
+    second update of each net runs on re-armed slots).  The launch count proves which path ran."""
     size = {"RSRGAN_TEST_B": str(B), "RSRGAN_TEST_T": str(T)}
-    a = _run(dict(size, RSRGAN_GPERSIST="1"))
+    a = _run(dict(size, RSRGAN_GPERSIST=str(mode)))
     b = _run(dict(size, RSRGAN_GPERSIST="0"))
-    assert b["chain_launches"] - a["chain_launches"] >= T - 1, (a["chain_launches"], b["chain_launches"])
+    if T > 2:
+        assert b["chain_launches"] - a["chain_launches"] >= (T - 1) * (1 if mode < 3 else 2), (a["chain_launches"], b["chain_launches"])
     assert a["device_status"] == 0 and b["device_status"] == 0
     for k in ("d0", "g0", "d1", "g1"):
         assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-7), (k, a[k], b[k])
     assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
-    c = _run(dict(size, RSRGAN_GPERSIST="1"))
+    c = _run(dict(size, RSRGAN_GPERSIST=str(mode)))
     assert a["vars_sha"] == c["vars_sha"]          # fixed summation order: reproducible bits
 
 

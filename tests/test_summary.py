@@ -78,7 +78,9 @@ class _Model:
         return np.asarray(x)[:, :1] * 2
 
     def _summary_fetch(self, inputs, labels, lengths=None):
-        return self.d_step(inputs, labels, train=False), self.g_step(inputs, labels, train=False), self.forward(inputs)
+        # (the contract of Model._summary_fetch: losses of the D and G fetches, then this rank's shard of the batch and G's output on it)
+        return (self.d_step(inputs, labels, train=False), self.g_step(inputs, labels, train=False), np.asarray(inputs), np.asarray(labels),
+                self.forward(inputs))
 
 
 def test_frame_level_loops_write_train_and_eval_events(tmp_path):
