@@ -993,14 +993,15 @@ bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only)
     ++prof_gb_n;
   } else
     launch_glstm_bwd(a, s);
-  if (ch[0].din) {               // d(inputs of layer 0) = dZ_0 . K_x^T, batched over time
-    const LayerRun& R = ch[0];
-    const int H4 = 4 * R.L->H;
-    gemm(R.S->gates, H4, true, R.ps->W(R.L->tK), H4, true, R.din, R.L->ldI, T * R.N, R.L->I, H4, nullptr, 0, 0.f, false, s);
-  }
-  if (!defer_wgrads)
-    for (auto& R : ch)
-      if (R.want_wgrads) layer_wgrads(R, T, s);
+  auto din0 = [&]() {
+    if (ch[0].din) {             // d(inputs of layer 0) = dZ_0 . K_x^T, batched over time
+      const LayerRun& R = ch[0];
+      const int H4 = 4 * R.L->H;
+      gemm(R.S->gates, H4, true, R.ps->W(R.L->tK), H4, true, R.din, R.L->ldI, T * R.N, R.L->I, H4, nullptr, 0, 0.f, false, s);
+    }
+  };
+  if (!defer_wgrads) chain_wgrads(ch, T, s, din0);
+  else din0();
   return true;
 }
 
@@ -1023,7 +1024,7 @@ bool Model::persist_backward(Chain& ch, int T, hipStream_t s) {
   a.dout_top = ch.back().dout; a.ld_dout = dl.back().ldP;
   if (!a.dout_top || !dpersist_supported(a) || dpersist_granule_bytes(a.nl, a.N, a.T) > dp_gran_bytes) return false;
   launch_dlstm_bwd(a, s);
-  if (!defer_wgrads)
+  if (!defer_wgrads)             // (on one stream: the discriminator's sequences are ten short launches, two streams cost them 0.04 ms)
     for (auto& R : ch)
       if (R.want_wgrads) layer_wgrads(R, T, s);
   return true;
@@ -1055,6 +1056,36 @@ void Model::layer_wgrads_colsums(const LayerRun& R, int T, hipStream_t s, float*
 void Model::layer_wgrads(const LayerRun& R, int T, hipStream_t s) {
   layer_wgrads_gemms(R, 0, T, false, s);
   layer_wgrads_colsums(R, T, s, (side && s == side) ? scratch2 : scratch);
+}
+// The weight gradients of a chain whose BPTT is complete (the persistent launches leave every layer's dz at once): the layers'
+// launch sequences (dK GEMM + fix-up, dWp GEMM + reduce, the two column-sum kernels) do not depend on each other, and only the dK
+// GEMM fills the chip -- the upper layers' sequences ride the side stream beside the lowest layer's (and `between`, the caller's
+// launches that only need the BPTT), joined before returning.  RSRGAN_WGRAD_STREAMS=1: everything on s.
+void Model::chain_wgrads(Chain& ch, int T, hipStream_t s, const std::function<void()>& between) {
+  static const int streams = [] { const char* e = getenv("RSRGAN_WGRAD_STREAMS"); return e ? atoi(e) : 2; }();
+  int nw = 0;
+  for (auto& R : ch) nw += R.want_wgrads ? 1 : 0;
+  if (!side || streams < 2 || nw < 2) {
+    if (between) between();
+    for (auto& R : ch)
+      if (R.want_wgrads) layer_wgrads(R, T, s);
+    return;
+  }
+  hipEvent_t ev = ev_pool[ev_next++ & 15];
+  (void)hipEventRecord(ev, s);
+  (void)hipStreamWaitEvent(side, ev, 0);
+  bool first = true;
+  for (auto& R : ch) {
+    if (!R.want_wgrads) continue;
+    if (first) { first = false; continue; }                  // (the lowest layer with weight gradients stays on s)
+    layer_wgrads(R, T, side);
+  }
+  if (between) between();
+  for (auto& R : ch)
+    if (R.want_wgrads) { layer_wgrads(R, T, s); break; }
+  ev = ev_pool[ev_next++ & 15];
+  (void)hipEventRecord(ev, side);
+  (void)hipStreamWaitEvent(s, ev, 0);                       // join: the optimizer needs every gradient
 }
 
 void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const std::vector<int>* offsets,
@@ -1427,7 +1458,10 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   nf = stage_noise(nf, noise_f_buf, s);
   const bool l2_on = !cfg.cross_validation && scal[RSRGAN_L2_SCALE] > 0.0;
   const bool wave_bwd = want_grads && !d_dnn() && wavefront();
-  const bool bucketed = wave_bwd && gbk[RSRGAN_NET_G].size() > 1 && !overlap();
+  // (per-layer weight-gradient segments exist for the caller's bucketed all-reduce; rsrgan_g_step applies the update itself, so
+  // nothing can run between the backward pass and the optimizer: one segment, no graph boundaries between the layers)
+  static const bool fused_seg = [] { const char* e = getenv("RSRGAN_FUSED_SEG"); return !e || atoi(e) != 0; }();
+  const bool bucketed = wave_bwd && gbk[RSRGAN_NET_G].size() > 1 && !overlap() && !(fused_apply && fused_seg);
   const unsigned kbits = (want_grads ? 1u : 0u) | (nf ? 2u : 0u) | (reuse ? 4u : 0u) | (l2_on ? 8u : 0u) | (bucketed ? 16u : 0u);
   const int R = T * B, Ld = (int)dl.size(), Lg = (int)gl.size();
   const int ldPd = pad4(dR), P = gR, ldP = pad4(P);

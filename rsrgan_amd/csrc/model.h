@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <string>
 #include <unordered_map>
+#include <functional>
 #include <vector>
 
 #include "../../include/rsrgan.h"
@@ -259,6 +260,7 @@ struct Model {
   void rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const std::vector<int>* offsets = nullptr,
                     const std::vector<FcStage>* fcs = nullptr);
   void layer_wgrads(const LayerRun& R, int T, hipStream_t s);
+  void chain_wgrads(Chain& ch, int T, hipStream_t s, const std::function<void()>& between);   // all layers of a finished BPTT, on two streams
   void layer_wgrads_gemms(const LayerRun& R, int t0, int t1, bool accumulate, hipStream_t s);
   void layer_wgrads_colsums(const LayerRun& R, int T, hipStream_t s, float* scr);
   // side stream: weight-gradient GEMMs (MFMA-bound) overlap the byte-bound backward wave
@@ -268,6 +270,7 @@ struct Model {
   // weight-gradient GEMMs of bucket i+1.. are still running.
   struct GradBucket { int64_t off = 0, count = 0; hipEvent_t ev = nullptr; bool marked = false; };
   std::vector<GradBucket> gbk[2];
+  bool fused_apply = false;        // set by rsrgan_g_step around g_backward: the update follows in the same call (no all-reduce in between)
   bool defer_wgrads = false;       // rnn_backward leaves the weight-gradient launches of want_wgrads runs to its caller
   int build_buckets();
   void mark_bucket(int net, int i, hipStream_t s);
