@@ -442,6 +442,10 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
       } else { gp_gran1 = gp_gran2 = nullptr; gp_ctl = nullptr; }
     }
   }
+  {
+    static const bool lazy_env = [] { const char* e = getenv("RSRGAN_LAZY_SWIZZLE"); return !e || atoi(e) != 0; }();
+    lazy_sw = lazy_env && wavefront() && gp_gran1 && gp_gran3 && (gp_env & 3) == 3 && dp_gran && (dp_env & 3) == 3;
+  }
   drop_ctr = (unsigned long long*)alloc<float>(4);
   HIPC(hipMemset(drop_ctr, 0, 16));
   const int dmaxld = std::max(ldPd, ldDout);
@@ -596,6 +600,24 @@ void Model::refresh_transposes(int net, hipStream_t s) {
   if (net == RSRGAN_NET_G && g_fc_out_wT && g_fc_out_w >= 0)
     add(G.W(g_fc_out_w), ldDout, g_fc_out_wT, pad4(gR), gR, Dout);   // [P][ldDout] -> [Dout][ldP]
   launch_transpose_many(tl, s);
+  if (!lazy_sw) refresh_swizzles(net, s);
+  // (the folded discriminator kernels are derived where they are used, fold_forward: with the persistent discriminator launch on,
+  //  that is never -- three GEMMs, a copy and a swizzle launch, 60 us per step, used to follow every discriminator update)
+  if (net == RSRGAN_NET_G)
+    for (size_t l = 0; l < gconv.size(); ++l) {                       // R-CED: re-arranged filters of the implicit-GEMM conv
+      const ConvLayer& L = gconv[l];
+      if (rc_ft_fwd[l]) launch_conv_prep(G.W(L.tW), L.ldCout, rcS, L.fw, L.Cin, L.Cout, false, rc_ft_fwd[l], s);
+      if (rc_ft_bwd[l]) launch_conv_prep(G.W(L.tW), L.ldCout, rcS, L.fw, L.Cin, L.Cout, true, rc_ft_bwd[l], s);
+    }
+}
+
+// The fragment-tiled weight copies of the launch-per-phase recurrence kernels (k_fwd_gates, k_fwd_proj, k_bwd_a2, k_bwd_bp).  With
+// both generator and discriminator recurrences on their persistent launches (lazy_sw) nothing reads them in a training step: they are
+// then rebuilt at the top of rnn_forward / rnn_backward -- the only readers -- instead of after every optimizer step (46 us for the
+// generator's 23 MB, 11 us for the discriminator).
+void Model::refresh_swizzles(int net, hipStream_t s) {
+  const ParamSet& ps = net == RSRGAN_NET_G ? G : D;
+  auto& layers = net == RSRGAN_NET_G ? gl : dl;
   {
     SwizzleList sl{};
     auto addz = [&](const SwizzleJob& j) {
@@ -619,13 +641,6 @@ void Model::refresh_transposes(int net, hipStream_t s) {
     }
     launch_swizzle_many(sl, s);
   }
-  if (net == RSRGAN_NET_D && !dl_fold.empty()) refresh_fold(s);
-  if (net == RSRGAN_NET_G)
-    for (size_t l = 0; l < gconv.size(); ++l) {                       // R-CED: re-arranged filters of the implicit-GEMM conv
-      const ConvLayer& L = gconv[l];
-      if (rc_ft_fwd[l]) launch_conv_prep(G.W(L.tW), L.ldCout, rcS, L.fw, L.Cin, L.Cout, false, rc_ft_fwd[l], s);
-      if (rc_ft_bwd[l]) launch_conv_prep(G.W(L.tW), L.ldCout, rcS, L.fw, L.Cin, L.Cout, true, rc_ft_bwd[l], s);
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -757,6 +772,7 @@ void Model::gates_launch(const FwdGateJobs& gj, int blocks, int kb, hipStream_t 
 
 void Model::rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const std::vector<int>* offsets,
                         const std::vector<FcStage>* fcs) {
+  if (lazy_sw) { refresh_swizzles(RSRGAN_NET_G, s); refresh_swizzles(RSRGAN_NET_D, s); }      // (from the current variables, every time)
   // zero initial state (cell.zero_state, models/lstm.py:107): slot 0 of c / m for the rows of each run
   {
     ZeroList zl{};
@@ -876,6 +892,7 @@ bool Model::fold_forward(Chain& ch, int T, hipStream_t s) {
     if (l > 0) Rf.in = d_st[l - 1].h;                  // the masked h of the layer below (0 where t >= len)
     fch.push_back(Rf);
   }
+  refresh_fold(s);                                   // from the current variables, every time: nothing can go stale, capture or not
   std::vector<Chain> chains{fch};
   const bool prof_was = prof_on;
   prof_on = false;                                   // bench.py's dominant-kernel timing covers the merged forward wave's launches only
@@ -1090,6 +1107,7 @@ void Model::chain_wgrads(Chain& ch, int T, hipStream_t s, const std::function<vo
 
 void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const std::vector<int>* offsets,
                          const std::vector<FcStage>* fcs) {
+  if (lazy_sw) { refresh_swizzles(RSRGAN_NET_G, s); refresh_swizzles(RSRGAN_NET_D, s); }
   {
     ZeroList zl{};
     for (auto& ch : chains)

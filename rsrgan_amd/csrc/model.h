@@ -253,6 +253,8 @@ struct Model {
                  float* out_losses, bool want_grads, bool reuse, hipStream_t s);
   int apply(int net, hipStream_t s);
   void refresh_transposes(int net, hipStream_t s);
+  void refresh_swizzles(int net, hipStream_t s);
+  bool lazy_sw = false;            // the fragment-tiled copies are rebuilt where they are read (rnn_forward / rnn_backward), not after every update
 
   // building blocks: run chains layer-by-layer (v1) or as one fused (layer,t) wavefront
   void rnn_forward(std::vector<Chain>& chains, int T, hipStream_t s, const std::vector<int>* offsets = nullptr,
