@@ -396,33 +396,6 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
     // =============================== X waves: ahead of the R waves ===============================
     const int xw = w - 4;
     float* const pbx = &S.pb[xw][0][0][lane][0];                       // + (i * NR + r) * 256
-    if (l == 0) {
-      // layer 0: the x-part of every step was batched into `gates` (zx = x . K_x + bias); X wave xw fetches gate tile xw (and 4 + xw)
-      const bool two = xw + 4 < NT;
-      for (int t = 0; t < T; ++t) {
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          float zv[2][4];
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const int i = min(xw + 4 * s, NT - 1), cell = min(cell0 + 4 * i + q, H - 1);
-            const float* zr = L.gates + ((size_t)t * N + row0 + 16 * r + lr) * H4 + cell;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) zv[s][g] = zr[g * H];
-          }
-          if (t > 0 && !gp_wait(&S.cnt_h[r], 4u * (unsigned)t, dead)) return;     // the cells of step t-1 have read the tiles
-#pragma unroll
-          for (int i = 0; i < NT; ++i) {
-            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (i == xw) v = f32x4{zv[0][0], zv[0][1], zv[0][2], zv[0][3]};
-            if (two && i == xw + 4) v = f32x4{zv[1][0], zv[1][1], zv[1][2], zv[1][3]};
-            *reinterpret_cast<f32x4*>(pbx + (i * NR + r) * 256) = v;
-          }
-          gp_signal(&S.cnt_x[r][xw], lane);
-        }
-      }
-      return;
-    }
     float4 kx[NT][GP_KBW - 1];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -450,8 +423,21 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
         for (int jj = 0; jj < GP_KBW; ++jj) lo[jj] = slot2(t, r, min(xw + 4 * jj, nkbx - 1));
         f32x4 xv[GP_KBW];
         GPT(18 + 2 * r);
-        if (!gp_sweep<GP_KBW, false, GP_KBW, true>(b2x, lo, nsx, frag_off, slot2(t, r, min(xw + 4 * (lane >> 1), nkbx - 1)) + (unsigned)(lane & 1) * 512u + 496u,
-                                             lane < 2 * nsx, err, [&](int k, const f32x4& v) { xv[k] = v; })) { fail(); return; }
+        if (l == 0) {
+          // layer 0: x(t) is the stack's input (models/lstm.py:82-87: the leaky-ReLU FC over the LPS frame), in memory before the launch:
+          // the same fragments as plain loads (16 bytes of one row per lane), no hand-off.  (Until round 4 this product was a
+          // time-batched GEMM in front of the launch, 136 us; these waves and 60 % of the MFMA pipe were idle.)
+          const float* xr = L.in + ((size_t)t * N + row0 + 16 * r + lr) * L.ldI;
+#pragma unroll
+          for (int jj = 0; jj < GP_KBW; ++jj)                            // (all five in flight, unconditional)
+            xv[jj] = *reinterpret_cast<const f32x4*>(xr + min(16 * min(xw + 4 * jj, nkbx - 1) + 4 * q, I - 4));
+          asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]));
+          static_assert(GP_KBW == 5, "the five pieces above");
+#pragma unroll
+          for (int jj = 0; jj < GP_KBW; ++jj)
+            if (16 * min(xw + 4 * jj, nkbx - 1) + 4 * q >= I) xv[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else if (!gp_sweep<GP_KBW, false, GP_KBW, true>(b2x, lo, nsx, frag_off, slot2(t, r, min(xw + 4 * (lane >> 1), nkbx - 1)) + (unsigned)(lane & 1) * 512u + 496u,
+                                                    lane < 2 * nsx, err, [&](int k, const f32x4& v) { xv[k] = v; })) { fail(); return; }
         GPT(19 + 2 * r);
         const bool live = t < (r ? len1 : len0);
         f32x4 acc[NT];
@@ -1088,6 +1074,7 @@ bool gpersist_plan(GPersistArgs& a) {
   for (int l = 0; l < a.nl; ++l) {
     const GPersistLayer& L = a.L[l];
     if (L.P < 4 || L.P > 16 * GP_NKB || L.P % 4 != 0 || L.ldP % 4 != 0 || L.I > 16 * GP_NKB || L.ldH % 4 != 0) return false;
+    if (l == 0 && (L.I < 4 || L.I % 4 != 0 || L.ldI % 4 != 0)) return false;       // (16-byte pieces of the input rows)
     if (l > 0 && L.I != a.L[l - 1].P) return false;
     if (((L.P + 15) / 16) * 2 > a.NC) return false;                // every 8-column half of a chunk needs its reducer
     if (a.NC > 40) return false;                                    // a G wave sums at most 10 producers

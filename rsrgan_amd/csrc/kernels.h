@@ -144,7 +144,8 @@ constexpr int DP_MAXL = 3;
 constexpr int DP_CTL_GEN = 0, DP_CTL_DONE = 1, DP_CTL_ERR = 2, DP_CTL_WORDS = 4;   // err: 0, or 1 + the first workgroup whose bounded wait expired
 struct DPersistLayer {
   const float *K, *bias, *wi, *wf, *wo, *Wp;      // TF-layout kernel [(I+P)][4H], bias [4H], peepholes [H], projection [H][ldP]
-  float *gates, *c, *h, *mst, *out;               // the layer's stash (model.h LstmStash); layer 0: gates holds zx = x.K_x + bias on entry
+  float *gates, *c, *h, *mst, *out;               // the layer's stash (model.h LstmStash)
+  const float* in;                                // layer 0: the stack's input [T][N][ldI] (forward)
   float* dmt;                                     // backward: [T][N][ldP] total dm per step (the projection's weight gradient reads it)
   int I, P, ldP, ldH;
 };
@@ -168,7 +169,8 @@ constexpr int GP_ROWS = 32;                       // batch rows per row group (t
 struct GPersistLayer {
   const float *KxT, *KhT;                         // k-contiguous transposed copies of the kernel: [4H][ldI], [4H][ldP] (zero padding)
   const float *bias, *wi, *wf, *wo, *Wp;          // bias [4H], peepholes [H], projection [H][ldP]
-  float *gates, *c, *h, *mst, *out;               // the layer's stash (model.h LstmStash); layer 0: gates holds zx = x.K_x + bias on entry
+  float *gates, *c, *h, *mst, *out;               // the layer's stash (model.h LstmStash)
+  const float* in;                                // layer 0: the stack's input [T][N][ldI] (forward)
   float* dmt;                                     // backward: [T][N][ldP] total dm per step (the projection's weight gradient reads it)
   int I, P, ldI, ldP, ldH;
 };

@@ -958,18 +958,16 @@ bool Model::persist_forward_g(int T, hipStream_t s) {
   if (!gp_fwd_on() || !wavefront() || seq_drop_on()) return false;
   GPersistArgs a{};
   if (!gpersist_args(a, T) || gpersist_gran2_bytes(a) > gp_gran2_bytes) return false;
-  const LstmLayer& L0 = gl[0];
-  const int H4 = 4 * L0.H;
-  gemm(g_ins[0], L0.ldI, true, G.W(L0.tK), H4, false, g_st[0].gates, H4, T * B, H4, L0.I, G.W(L0.tb), 0, 0.f, false, s);
+  a.L[0].in = g_ins[0];                                // (layer 0's input product runs inside the launch as well)
   if (prof_on) {
     if ((size_t)(2 * prof_gp_n + 2) > prof_gp_ev.size()) {
       const size_t old = prof_gp_ev.size();
       prof_gp_ev.resize(old + 8, nullptr);
       for (size_t i = old; i < prof_gp_ev.size(); ++i) (void)hipEventCreate(&prof_gp_ev[i]);
     }
-    // algorithmic FLOP of the launch: every layer's recurrent product and projection, the x-part above layer 0 (layer 0's is the GEMM above)
+    // algorithmic FLOP of the launch: every layer's input and recurrent product and its projection
     for (size_t l = 0; l < gl.size(); ++l)
-      prof_gp_flops += 2.0 * B * T * ((double)((l ? gl[l].I : 0) + gl[l].P) * 4.0 * gl[l].H + (double)gl[l].H * gl[l].P);
+      prof_gp_flops += 2.0 * B * T * ((double)(gl[l].I + gl[l].P) * 4.0 * gl[l].H + (double)gl[l].H * gl[l].P);
     (void)hipEventRecord(prof_gp_ev[2 * prof_gp_n], s);
     launch_glstm_fwd(a, s);
     (void)hipEventRecord(prof_gp_ev[2 * prof_gp_n + 1], s);

@@ -41,6 +41,7 @@ int main(int argc, char** argv) {
     L.Wp = dal((size_t)H * P, 0.03f);
     L.gates = dal((size_t)T * N * 4 * H, 0.5f); L.c = dal((size_t)(T + 1) * N * H, 0.f); L.h = dal((size_t)T * N * H, 0.f);
     L.mst = dal((size_t)(T + 1) * N * P, 0.f); L.out = dal((size_t)T * N * P, 0.f);
+    if (l == 0) L.in = dal((size_t)T * N * P, 0.3f);
     if (bwd) L.dmt = dal((size_t)T * N * P, 0.f);
   }
   if (bwd) { a.dout_top = dal((size_t)T * N * P, 0.01f); a.ld_dout = P; }
