@@ -259,7 +259,7 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
       for (int u = 0; u < 4; ++u) {
         const int k = 16 * kb + 4 * q + u;
         vh[u] = k < P ? vh[u] : 0.f;
-        vx[u] = (l > 0 && k < I) ? vx[u] : 0.f;
+        vx[u] = k < I ? vx[u] : 0.f;
       }
       kh[g][kb] = make_float4(vh[0], vh[1], vh[2], vh[3]);
       *reinterpret_cast<float4*>(&kx_lds[w][g][kb][lane][0]) = make_float4(vx[0], vx[1], vx[2], vx[3]);
@@ -301,11 +301,15 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
       if (16 * kb + 4 * q < P) *reinterpret_cast<float4*>(L.mst + (size_t)(r0 + lr) * ldP + 16 * kb + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
-  // acc init of the next step: zx (layer 0; the x-part of every step was batched into `gates`) or bias + x . K_x
+  // acc init of the next step: bias + x . K_x.  Layer 0's x is the stack's input, in memory before the launch: its rows travel as
+  // plain 16-byte loads issued a whole step before their product (until round 4 that product was a time-batched GEMM in front of
+  // the launch, 43 us for 12800 rows, whose 52 MB of output these waves then read back).
   f32x4 accn[4];
-  auto load_zx = [&](int t) {
+  float4 xn[DP_KB];
+  auto load_x = [&](int t) {
+    const float* xr = L.in + ((size_t)t * N + r0 + lr) * L.ldI;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) accn[g] = *reinterpret_cast<const f32x4*>(L.gates + ((size_t)t * N + r0 + lr) * H4 + g * H + cb);
+    for (int kb = 0; kb < DP_KB; ++kb) xn[kb] = *reinterpret_cast<const float4*>(xr + min(16 * kb + 4 * q, I - 4));
   };
   // sum of the NQ handed-over partials, in quarter order (k-blocks beyond the width: zero)
   auto sum_parts = [&](float (*part)[DP_KB][64][4], int width, float4 (&s)[DP_KB]) {
@@ -331,15 +335,21 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
       for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].w, af[kb].w, acc[g], 0, 0, 0);
     }
   };
-  // x-part of step t of a layer above 0 from the handed-over partials of the layer below: accn = bias + mask(x_t) . K_x
+  // x-part of step t of a layer above 0 from the handed-over partials of the layer below: accn = bias + mask(x_t) . K_x;
+  // layer 0: from the rows load_x fetched (dynamic_rnn does not mask its inputs; the cell discards what lies past a row's length)
   auto next_x = [&](int t) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) accn[g] = bs[g];
     float4 xs[DP_KB];
-    sum_parts(part_x[t & 1], I, xs);
-    const bool live = t < lenF;                                   // dynamic_rnn's output is zero past the row's length
+    if (l > 0) {
+      sum_parts(part_x[t & 1], I, xs);
+      const bool live = t < lenF;                                 // dynamic_rnn's output is zero past the row's length
 #pragma unroll
-    for (int kb = 0; kb < DP_KB; ++kb) xs[kb] = dp_sel(live, xs[kb], make_float4(0.f, 0.f, 0.f, 0.f));
+      for (int kb = 0; kb < DP_KB; ++kb) xs[kb] = dp_sel(live, xs[kb], make_float4(0.f, 0.f, 0.f, 0.f));
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < DP_KB; ++kb) xs[kb] = dp_sel(16 * kb + 4 * q < I, xn[kb], make_float4(0.f, 0.f, 0.f, 0.f));
+    }
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb) {
       float4 bf[4];
@@ -367,10 +377,11 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
       }
   };
 
-  if (l == 0) load_zx(0);
+  if (l == 0) load_x(0);
   __syncthreads();                                                 // P
   if (dead) return;
-  if (l > 0) next_x(0);
+  next_x(0);
+  if (l == 0) load_x(min(1, T - 1));
 
   float hv[4] = {0.f, 0.f, 0.f, 0.f}, sg[4][4] = {};
   for (int t = 0; t < T; ++t) {
@@ -420,8 +431,8 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
     DPT(7);
     // run ahead while the gather waves poll: the x-part of step t+1 (after their projection and publish, see the backward kernel)
     __builtin_amdgcn_s_sleep(12);
-    if (l > 0 && t + 1 < T) next_x(t + 1);
-    if (l == 0) load_zx(min(t + 1, T - 1));                        // (not right behind barrier B: see the backward kernel)
+    if (t + 1 < T) next_x(t + 1);
+    if (l == 0) load_x(min(t + 2, T - 1));                         // (consumed a step from now; not right behind barrier B: see the backward kernel)
     DPT(5);
     DPT(6);
   }
@@ -772,6 +783,7 @@ bool dpersist_supported(const DPersistArgs& a) {
     const DPersistLayer& L = a.L[l];
     if (L.P > 16 * DP_KB || L.P % 4 != 0 || L.ldP % 4 != 0 || L.P < 4) return false;
     if (l > 0 && (L.I != a.L[l - 1].P)) return false;
+    if (L.I > 16 * DP_KB || (l == 0 && (L.I < 4 || L.I % 4 != 0 || L.ldI % 4 != 0))) return false;      // (layer 0 reads 16-byte pieces of its input rows)
   }
   return true;
 }

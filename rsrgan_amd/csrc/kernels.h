@@ -147,7 +147,7 @@ struct DPersistLayer {
   float *gates, *c, *h, *mst, *out;               // the layer's stash (model.h LstmStash)
   const float* in;                                // layer 0: the stack's input [T][N][ldI] (forward)
   float* dmt;                                     // backward: [T][N][ldP] total dm per step (the projection's weight gradient reads it)
-  int I, P, ldP, ldH;
+  int I, P, ldP, ldH, ldI;
 };
 struct DPersistArgs {
   DPersistLayer L[DP_MAXL];

@@ -919,12 +919,10 @@ bool Model::persist_forward(Chain& ch, int T, hipStream_t s) {
     DPersistLayer& D_ = a.L[l];
     D_.K = D.W(L.tK); D_.bias = D.W(L.tb); D_.wi = D.W(L.twi); D_.wf = D.W(L.twf); D_.wo = D.W(L.two); D_.Wp = D.W(L.tWp);
     D_.gates = S.gates; D_.c = S.c; D_.h = S.h; D_.mst = S.mst; D_.out = S.out;
-    D_.I = L.I; D_.P = L.P; D_.ldP = L.ldP; D_.ldH = L.ldH;
+    D_.I = L.I; D_.P = L.P; D_.ldP = L.ldP; D_.ldH = L.ldH; D_.ldI = L.ldI;
+    D_.in = l == 0 ? R.in : nullptr;                   // (layer 0's input product runs inside the launch as well)
   }
   if (!dpersist_supported(a) || dpersist_granule_bytes(a.nl, a.N, a.T) > dp_gran_bytes) return false;
-  const LayerRun& R0 = ch[0];
-  const int H4 = 4 * a.H;
-  gemm(R0.in, R0.L->ldI, true, D.W(R0.L->tK), H4, false, d_st[0].gates, H4, T * R0.N, H4, R0.L->I, D.W(R0.L->tb), 0, 0.f, false, s);
   launch_dlstm_fwd(a, s);
   return true;
 }

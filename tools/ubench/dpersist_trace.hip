@@ -32,7 +32,8 @@ int main(int argc, char** argv) {
   a.len = dlen;
   for (int l = 0; l < 2; ++l) {
     DPersistLayer& L = a.L[l];
-    L.I = l == 0 ? I0 : P; L.P = P; L.ldP = P; L.ldH = H;
+    L.I = l == 0 ? I0 : P; L.P = P; L.ldP = P; L.ldH = H; L.ldI = L.I;
+    if (l == 0) L.in = dal((size_t)T * N * I0, 0.3f);
     L.K = dal((size_t)(L.I + P) * 4 * H, 0.05f); L.bias = dal(4 * H, 0.1f); L.wi = dal(H, 0.1f); L.wf = dal(H, 0.1f); L.wo = dal(H, 0.1f);
     L.Wp = dal((size_t)H * P, 0.05f);
     L.gates = dal((size_t)T * N * 4 * H, 0.5f); L.c = dal((size_t)(T + 1) * N * H, 0.f); L.h = dal((size_t)T * N * H, 0.f);
