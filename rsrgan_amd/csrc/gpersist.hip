@@ -635,7 +635,7 @@ struct GpLdsB {
   float pfs[GP_NR][5][16][4 * NT];          // the stash of the NEXT step of a tile: gate activations i, j, f, o and c(t-1) (the X waves fetch it a step ahead)
   float peep[4 * NT][4];                    // {w_i, w_f, w_o, -} per cell
   float car[4][2][GP_NR][64][2];            // c(t) and the carried dc of an R wave's cells [wave][gate tile w | 4 + w][row tile][lane] (in registers they get spilled, and a scratch reload waits for the wave's write-through stores)
-  unsigned cnt_p[GP_NR], cnt_h[GP_NR], cnt_m[GP_NR], cnt_g[GP_NR], cnt_z[GP_NR], cnt_f[GP_NR], cnt_q[GP_NR], dead, pad_[1];
+  unsigned cnt_p[GP_NR], cnt_h[GP_NR], cnt_m[GP_NR], cnt_g[GP_NR], cnt_z[GP_NR], cnt_f[GP_NR], cnt_q[GP_NR], cnt_d[GP_NR], dead, pad_[3];
 };
 
 // one lane = one sentinel piece (16 bytes at `so` when son): wait until every one is valid
@@ -676,8 +676,14 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
   const GpBuf b1 = gp_buf((const char*)a.gran1 + (size_t)(grp * a.nl + l) * GP_R1 * g1_per, GP_R1 * g1_per);
   const GpBuf b2 = gp_buf((const char*)a.gran2 + (size_t)(grp * a.nl + l) * T * g2_per, (size_t)T * g2_per);
   const GpBuf b2x = gp_buf((const char*)a.gran2 + (size_t)(grp * a.nl + (l > 0 ? l - 1 : 0)) * T * g2_per, (size_t)T * g2_per);
-  const GpBuf b3 = gp_buf((const char*)a.gran3 + (size_t)(grp * a.nl + l) * GP_XR * g1_per, GP_XR * g1_per);              // what the layer above hands to this one
-  const GpBuf b3x = gp_buf((const char*)a.gran3 + (size_t)(grp * a.nl + (l > 0 ? l - 1 : 0)) * GP_XR * g1_per, GP_XR * g1_per);   // what this layer hands down
+  // gran3 holds nl + 1 rings per row group: ring l + 1 = what layer l + 1 hands to layer l, ring 0 = what layer 0 hands to its OWN reducers
+  const GpBuf b3 = gp_buf((const char*)a.gran3 + (size_t)(grp * (a.nl + 1) + l + 1) * GP_XR * g1_per, GP_XR * g1_per);      // what the layer above hands to this one
+  const GpBuf b3x = gp_buf((const char*)a.gran3 + (size_t)(grp * (a.nl + 1) + l) * GP_XR * g1_per, GP_XR * g1_per);         // what this layer hands down
+  // Layer 0's input gradient dz_0 . K_x^T (the input FC's d(h0): until round 4 a time-batched GEMM behind the launch, 126 us): its X
+  // waves -- idle otherwise -- run the same product as every other layer's and publish it to a ring of their own (ring 0); the
+  // layer's reducers, which spend most of a step waiting for the layers above, sum it one step late and write it to din0.
+  const bool dx0 = l == 0 && a.din0 != nullptr;
+  const bool dxr = dx0 && c < 2 * nkbx;                                  // this workgroup reduces a half chunk of it
   const unsigned frag_off = (unsigned)lane * 16u;
   const unsigned pair_off = (unsigned)((lane >> 5) * GP_SLOT + (lane & 31) * 16);
   auto slot1 = [&](int par, int r, int jb, int p) { return (unsigned)((((size_t)(par * NR + r) * GP_NKB + jb) * NC + p) * GP_SLOT); };   // (both rings)
@@ -705,14 +711,14 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
     const int k = e / CW, cl = e - k * CW, cell = min(cell0 + cl, H - 1);
     S.peep[cl][k] = (k == 0 ? L.wi : k == 1 ? L.wf : L.wo)[cell];
   }
-  if (tid < 16) (&S.cnt_p[0])[tid] = 0u;                                // (all counters, dead)
+  if (tid < 20) (&S.cnt_p[0])[tid] = 0u;                                // (all counters, dead)
   __syncthreads();
   // every counter through ONE base register + a compile-time offset (hipcc otherwise keeps a dozen LDS addresses in registers
   // across the step loop; the zero is opaque to it)
   unsigned zed;
   asm volatile("v_mov_b32 %0, 0" : "=v"(zed));
   unsigned* const cnt = &S.cnt_p[0] + zed;
-  constexpr int C_P = 0, C_H = GP_NR, C_M = 2 * GP_NR, C_G = 3 * GP_NR, C_Z = 4 * GP_NR, C_F = 5 * GP_NR, C_Q = 6 * GP_NR, C_DEAD = 7 * GP_NR;
+  constexpr int C_P = 0, C_H = GP_NR, C_M = 2 * GP_NR, C_G = 3 * GP_NR, C_Z = 4 * GP_NR, C_F = 5 * GP_NR, C_Q = 6 * GP_NR, C_D = 7 * GP_NR, C_DEAD = 8 * GP_NR;
   const unsigned* dead = cnt + C_DEAD;
   auto fail = [&]() {
     if (lane == 0) {
@@ -728,7 +734,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
     //   A[row lr = column 16 pt + lr][k = cell 4 i + q] for the four k-steps gate 0..3
     const bool isx = w >= 4;
     const int ww = w & 3;
-    const bool noprod = isx && l == 0;                                   // layer 0 hands no input gradient down (a GEMM afterwards)
+    const bool noprod = isx && l == 0 && !dx0;                           // (layer 0 without a consumer of its input gradient)
     const float* KT = isx ? L.KxT : L.KhT;
     const int ldK = isx ? L.ldI : ldP, PW = isx ? I : P, nkw = isx ? nkbx : nkb;
     float4 kw[GP_KBW - 1][NT];
@@ -836,7 +842,8 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
           // back-pressure: ring slot s % GP_XR was summed AND re-armed by the layer below when it has published its dm(t + GP_XR - 2)
           // (its R waves re-arm a slot at the end of the step that summed it, acknowledged before the next step's partials leave,
           // which the dm of the step after that waits for)
-          if (!noprod && s >= GP_XR - 2 && !gp_poll(b2x, slot2(t + GP_XR - 2, r, min(ww + 4 * (lane >> 1), nkbx - 1)) + (unsigned)(lane & 1) * 512u + 496u, lane < 2 * nsx, err)) { fail(); return; }
+          // (layer 0's own ring: summed a step late, re-armed a step after that: the dm of three steps ago; b2x is this layer's then)
+          if (!noprod && s >= GP_XR - (l == 0 ? 3 : 2) && !gp_poll(b2x, slot2(t + GP_XR - (l == 0 ? 3 : 2), r, min(ww + 4 * (lane >> 1), nkbx - 1)) + (unsigned)(lane & 1) * 512u + 496u, lane < 2 * nsx, err)) { fail(); return; }
           if (!gp_wait(cnt + C_H + r, 4u * ((unsigned)s + 1u), dead)) return;       // dz(t) of the tile is in LDS (and the cells have read the stage)
           GPTS(19 + 2 * r);
           if (t > 0) { fetch(t - 1, r); stage(r); }                       // (needed by the cells a whole hand-off from now)
@@ -961,7 +968,18 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
         if (reducer) {
           if (s > 0) gp_rearm(b1, slot1((s - 1) % GP_R1, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
           if (!top) gp_rearm(b3, slot1(s % GP_XR, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
+          if (dxr && s > 0) {                                              // (the G wave summed layer 0's input gradient of step s-1 long ago)
+            if (!gp_wait(cnt + C_D + r, (unsigned)s, dead)) return;
+            gp_rearm(b3x, slot1((s - 1) % GP_XR, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
+          }
         }
+      }
+    }
+    if (dxr) {                                                             // the last step's slots: leave the ring armed for the next launch
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (!gp_wait(cnt + C_D + r, (unsigned)T, dead)) return;
+        gp_rearm(b3x, slot1((T - 1) % GP_XR, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
       }
     }
 #ifdef GP_TRACE
@@ -979,6 +997,44 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
   const int nlr = (pn + 1 - (lane >> 5)) >> 1;                           // (two producers per load: lanes 0..31 the even ones, 32..63 the odd ones)
   const int rrow = row0 + 16 * r + ((32 * hh + (lane & 31)) & 15), rcol = 16 * jbr + 4 * ((32 * hh + (lane & 31)) >> 4);
   const int rlen = a.len[rrow];
+  // layer 0's input gradient of step sx (time T-1-sx): all NC partials of this half chunk, tile r, by ONE wave (gp == 0; off the
+  // critical path, no exchange with the other G wave), even producers in lanes 0..31, odd ones in 32..63, then the two halves
+  auto sum_dx0 = [&](int sx) -> bool {
+    // (a plain loop, four loads in flight: the unrolled gp_sweep over 20 pieces cost the kernel 8 spilled registers, and this sum has
+    // a whole step of slack)
+    const unsigned base = slot1(sx % GP_XR, r, jbr, 0) + (unsigned)hh * 512u;
+    if (!gp_poll(b3x, base + (unsigned)min(lane, NC - 1) * GP_SLOT + 496u, lane < NC, err)) return false;
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f};
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int k0 = 0; 2 * k0 < NC; k0 += 4) {
+      for (;;) {
+        u32x4 x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          x[j] = __builtin_amdgcn_raw_buffer_load_b128(b3x.rs, base + (unsigned)min(2 * (k0 + j) + (lane >> 5), NC - 1) * GP_SLOT + (unsigned)(lane & 31) * 16u, 0, GP_SC1 | GP_VOL);
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ok &= (2 * (k0 + j) + (lane >> 5) >= NC) || gp_valid(x[j]);
+        if (__all(ok)) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (2 * (k0 + j) + (lane >> 5) < NC) sa += f32x4{__uint_as_float(x[j][0]), __uint_as_float(x[j][1]), __uint_as_float(x[j][2]), __uint_as_float(x[j][3])};
+          break;
+        }
+        asm volatile("" ::: "memory");
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    f32x4 sb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sb[i] = __shfl_xor(sa[i], 32);
+    const f32x4 tt = lane < 32 ? sa + sb : sb + sa;                      // (even-producer half first, in both halves of the wave)
+    if (lane < 32 && rcol < a.ld_din0)
+      *reinterpret_cast<float4*>(a.din0 + ((size_t)(T - 1 - sx) * N + rrow) * a.ld_din0 + rcol) = make_float4(tt[0], tt[1], tt[2], tt[3]);
+    gp_signal(cnt + C_D + r, lane);
+    return true;
+  };
   for (int s = 0; s < T; ++s) {
     const int t = T - 1 - s;
     GPTS(12);
@@ -1035,7 +1091,9 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
       GPTS(17);
     }
     if (reducer && gp == 1 && lane < 32 && rcol < ldP) *reinterpret_cast<float4*>(L.dmt + ((size_t)t * N + rrow) * ldP + rcol) = make_float4(tot[0], tot[1], tot[2], tot[3]);
+    if (dxr && gp == 0 && s > 0) { if (!sum_dx0(s - 1)) { fail(); return; } }
   }
+  if (dxr && gp == 0 && !sum_dx0(T - 1)) { fail(); return; }
 #ifdef GP_TRACE
   if (gw == 0) { const int i0_ = 12, i1_ = 18; GPT_FLUSH(); }
 #endif
@@ -1084,7 +1142,7 @@ bool gpersist_plan(GPersistArgs& a) {
 }
 size_t gpersist_gran1_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * GP_R1 * GP_NCH * a.NC * GP_SLOT; }
 size_t gpersist_gran2_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * a.T * GP_NCH * GP_SLOT; }
-size_t gpersist_gran3_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * GP_XR * GP_NCH * a.NC * GP_SLOT; }
+size_t gpersist_gran3_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * (a.nl + 1) * GP_XR * GP_NCH * a.NC * GP_SLOT; }
 
 // (the memset arms the launch's hop-2 slots; gran1 / gran3 are armed once, gpersist_arm, and re-armed by the kernels themselves)
 void gpersist_arm(const GPersistArgs& a, hipStream_t s) {

@@ -182,9 +182,11 @@ struct GPersistArgs {
   unsigned long long *gran1, *gran2;              // hop 1 (partial projections, ring of three steps: armed once, gpersist_arm), hop 2 (m chunks, one slot per step: armed by every launch)
   unsigned* ctl;                                  // control block [DP_CTL_*]
   float forget_bias;
-  unsigned long long* gran3;                      // backward: the partial input gradients a layer hands to the layer below (ring of GP_XR steps); armed once
+  unsigned long long* gran3;                      // backward: the partial input gradients a layer hands to the layer below -- layer 0 to its own reducers (nl + 1 rings of GP_XR steps); armed once
   const float* dout_top;                          // backward: [T][N][ld_dout] gradient of the top layer's masked outputs
   int ld_dout;
+  float* din0;                                    // backward: [T][N][ld_din0] gradient of the stack's input (null: not wanted)
+  int ld_din0;
 };
 bool gpersist_plan(GPersistArgs& a);              // fills NT / NC; false: shape not supported
 size_t gpersist_gran1_bytes(const GPersistArgs& a);

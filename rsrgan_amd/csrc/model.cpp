@@ -991,15 +991,23 @@ bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only)
   a.dout_top = ch.back().dout; a.ld_dout = gl.back().ldP;
   if (!a.dout_top) return false;
   if (check_only) return true;
+  // d(inputs of layer 0) = dZ_0 . K_x^T: a time-batched GEMM behind the launch (126 us).  RSRGAN_GP_DIN0=1 runs it inside the launch
+  // (layer 0's X waves publish partials to ring 0 of gran3, its reducers sum them a step late): built, bit-stable, parity-green --
+  // and 0.2 ms per step SLOWER (k_glstm_bwd 16.7 -> 19.4 us per step: a third more hand-off traffic and MFMA bursts on the layer
+  // every other layer waits for), so it stays off.
+  static const bool din0_env = [] { const char* e = getenv("RSRGAN_GP_DIN0"); return e && atoi(e) != 0; }();
+  const bool din_inside = ch[0].din && din0_env && (gl[0].I + 15) / 16 <= (gl[0].P + 15) / 16 && gl[0].ldI % 4 == 0;
+  if (din_inside) { a.din0 = ch[0].din; a.ld_din0 = gl[0].ldI; }
   if (prof_on) {
     if ((size_t)(2 * prof_gb_n + 2) > prof_gb_ev.size()) {
       const size_t old = prof_gb_ev.size();
       prof_gb_ev.resize(old + 8, nullptr);
       for (size_t i = old; i < prof_gb_ev.size(); ++i) (void)hipEventCreate(&prof_gb_ev[i]);
     }
-    // algorithmic FLOP of the launch: every layer's state-gradient product and dh = dm . W_p^T, the input-gradient product above layer 0
+    // algorithmic FLOP of the launch: every layer's state-gradient product and dh = dm . W_p^T, the input-gradient product (layer 0's
+    // only when it runs inside the launch)
     for (size_t l = 0; l < gl.size(); ++l)
-      prof_gb_flops += 2.0 * B * T * ((double)((l ? gl[l].I : 0) + gl[l].P) * 4.0 * gl[l].H + (double)gl[l].H * gl[l].P);
+      prof_gb_flops += 2.0 * B * T * ((double)((l || din_inside ? gl[l].I : 0) + gl[l].P) * 4.0 * gl[l].H + (double)gl[l].H * gl[l].P);
     (void)hipEventRecord(prof_gb_ev[2 * prof_gb_n], s);
     launch_glstm_bwd(a, s);
     (void)hipEventRecord(prof_gb_ev[2 * prof_gb_n + 1], s);
@@ -1007,7 +1015,7 @@ bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only)
   } else
     launch_glstm_bwd(a, s);
   auto din0 = [&]() {
-    if (ch[0].din) {             // d(inputs of layer 0) = dZ_0 . K_x^T, batched over time
+    if (ch[0].din && !din_inside) {
       const LayerRun& R = ch[0];
       const int H4 = 4 * R.L->H;
       gemm(R.S->gates, H4, true, R.ps->W(R.L->tK), H4, true, R.din, R.L->ldI, T * R.N, R.L->I, H4, nullptr, 0, 0.f, false, s);

@@ -23,7 +23,7 @@ static float* dal(size_t n, float v) {
 }
 
 int main(int argc, char** argv) {
-  const int N = argc > 1 ? atoi(argv[1]) : 64, T = argc > 2 ? atoi(argv[2]) : 100, H = 256, P = 40, I0 = 300;
+  const int N = argc > 1 ? atoi(argv[1]) : 64, T = argc > 2 ? atoi(argv[2]) : 100, H = 256, P = 40, I0 = 40;          // (layer 0 reads the discriminator input: 40-dim MFCC rows)
   const bool bwd = argc > 3;
   DPersistArgs a{};
   a.nl = 2; a.N = N; a.T = T; a.H = H; a.forget_bias = 1.f;

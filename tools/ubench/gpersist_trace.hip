@@ -48,7 +48,11 @@ int main(int argc, char** argv) {
   if (!gpersist_plan(a)) { printf("unsupported shape\n"); return 1; }
   const size_t g1 = gpersist_gran1_bytes(a), g2 = gpersist_gran2_bytes(a);
   CK(hipMalloc(&a.gran1, g1)); CK(hipMalloc(&a.gran2, g2)); CK(hipMalloc(&a.ctl, 64));
-  if (bwd) { const size_t g3 = gpersist_gran3_bytes(a); CK(hipMalloc(&a.gran3, g3)); }
+  if (bwd) {
+    const size_t g3 = gpersist_gran3_bytes(a);
+    CK(hipMalloc(&a.gran3, g3));
+    a.din0 = dal((size_t)T * N * P, 0.f); a.ld_din0 = P;
+  }
   gpersist_arm(a, 0); CK(hipDeviceSynchronize());
   { const unsigned c0[4] = {1u, 0u, 0u, 0u}; CK(hipMemcpy(a.ctl, c0, 16, hipMemcpyHostToDevice)); }
   hipStream_t s; CK(hipStreamCreate(&s));
