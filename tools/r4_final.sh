@@ -12,6 +12,6 @@ bash tools/pmc.sh ${tag}_sq "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_
 bash tools/pmc.sh ${tag}_lds "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" --steps 2 --warmup 1 --no-variants --no-kernel-timing > gpurun_out/pmc_${tag}_lds.log 2>&1; tail -14 gpurun_out/pmc_${tag}_lds.log | cut -c1-260
 bash tools/prof.sh ${tag}_res --net res_lstm_l --steps 5 --warmup 2 --no-variants > /dev/null 2>&1
 head -10 gpurun_out/prof_${tag}_res/r_kernel_stats.csv | cut -c1-130
-timeout 60 tools/ubench/gpersist_trace 64 100 3 > gpurun_out/gptrace_64.txt 2>&1; timeout 60 tools/ubench/gpersist_trace 32 50 3 > gpurun_out/gptrace_32.txt 2>&1
+timeout 60 tools/ubench/gpersist_trace 64 100 3 > gpurun_out/gptrace_64.txt 2>&1; timeout 60 tools/ubench/gpersist_trace 32 50 3 > gpurun_out/gptrace_32.txt 2>&1; timeout 60 tools/ubench/gpersist_trace 64 100 3 b > gpurun_out/gptrace_64b.txt 2>&1; for m in "" b; do timeout 60 tools/ubench/gpersist_trace_nt 64 100 3 $m; timeout 60 tools/ubench/gpersist_trace_nt 32 50 3 $m; done > gpurun_out/gptrace_nt.txt 2>&1
 timeout 60 tools/ubench/dpersist_trace 128 100 > gpurun_out/dptrace_fwd128.txt 2>&1; timeout 60 tools/ubench/dpersist_trace 64 100 > gpurun_out/dptrace_fwd.txt 2>&1; timeout 60 tools/ubench/dpersist_trace 128 100 bwd > gpurun_out/dptrace_bwd.txt 2>&1
 head -3 gpurun_out/gptrace_64.txt
