@@ -1,7 +1,7 @@
 // gpersist_trace.hip -- stand-alone phase timeline of the persistent generator recurrence (csrc/gpersist.hip, compiled here with
 // GP_TRACE); not part of the product library.  Synthetic weights at the reference's sizes (3 x LSTMCell(760, num_proj=280), N rows,
 // T steps); prints the launch time per step and the mean duration of every phase of a step per layer and wave role.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 gpersist_trace.hip -o gpersist_trace      Run: ./gpersist_trace [N] [T] [layers]
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 gpersist_trace.hip -o gpersist_trace      Run: ./gpersist_trace [N] [T] [layers] [b = the backward kernel] [x = with layer 0's input gradient inside it]
 // -DGP_COUNT: also count the first full reads of the sweeps that fail (atomics: the timeline of such a build is not representative);
 // -DGP_ABL=mask: timing ablations (1: no x sweeps, 2: hop-1 sentinels only, 4: hop-2 sentinels only)
 #include <hip/hip_runtime.h>
@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
   if (bwd) {
     const size_t g3 = gpersist_gran3_bytes(a);
     CK(hipMalloc(&a.gran3, g3));
-    a.din0 = dal((size_t)T * N * P, 0.f); a.ld_din0 = P;
+    if (argc > 5 && argv[5][0] == 'x') { a.din0 = dal((size_t)T * N * P, 0.f); a.ld_din0 = P; }      // layer 0's input gradient inside the launch (the product: RSRGAN_GP_DIN0=1)
   }
   gpersist_arm(a, 0); CK(hipDeviceSynchronize());
   { const unsigned c0[4] = {1u, 0u, 0u, 0u}; CK(hipMemcpy(a.ctl, c0, 16, hipMemcpyHostToDevice)); }
