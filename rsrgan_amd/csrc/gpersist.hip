@@ -55,11 +55,25 @@ __device__ unsigned g_gp_trace[256][24][24];
 #define GPT_DECL __shared__ unsigned gp_tr[24][24];
 #define GPT(i) do { if ((w & 3) == 0 && lane == 0 && t < 24) gp_tr[t][i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
 #define GPTS(i) do { if ((w & 3) == 0 && lane == 0 && s < 24) gp_tr[s][i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
-#define GPT_FLUSH() do { if (lane == 0) for (int t_ = 0; t_ < 24; ++t_) for (int i_ = i0_; i_ < i1_; ++i_) g_gp_trace[blockIdx.x][t_][i_] = gp_tr[t_][i_]; } while (0)
+// (the backward kernel has no register to spare: -DGP_TRACE_NOR / -DGP_TRACE_NOG drop the stamps of its R / X waves or of its G waves,
+//  so that the other half is traced on the product's register allocation)
+#ifdef GP_TRACE_NOR
+#define GPTSR(i) do { } while (0)
+#else
+#define GPTSR(i) GPTS(i)
+#endif
+#ifdef GP_TRACE_NOG
+#define GPTSG(i) do { } while (0)
+#else
+#define GPTSG(i) GPTS(i)
+#endif
+#define GPT_FLUSH() do { if (lane == 0) { _Pragma("unroll 1") for (int t_ = 0; t_ < 24; ++t_) { _Pragma("unroll 1") for (int i_ = i0_; i_ < i1_; ++i_) g_gp_trace[blockIdx.x][t_][i_] = gp_tr[t_][i_]; } } } while (0)
 #else
 #define GPT_DECL
 #define GPT(i) do { } while (0)
 #define GPTS(i) do { } while (0)
+#define GPTSR(i) do { } while (0)
+#define GPTSG(i) do { } while (0)
 #define GPT_FLUSH() do { } while (0)
 #endif
 
@@ -838,14 +852,14 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
         const int t = T - 1 - s;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-          GPTS(18 + 2 * r);
+          GPTSR(18 + 2 * r);
           // back-pressure: ring slot s % GP_XR was summed AND re-armed by the layer below when it has published its dm(t + GP_XR - 2)
           // (its R waves re-arm a slot at the end of the step that summed it, acknowledged before the next step's partials leave,
           // which the dm of the step after that waits for)
           // (layer 0's own ring: summed a step late, re-armed a step after that: the dm of three steps ago; b2x is this layer's then)
           if (!noprod && s >= GP_XR - (l == 0 ? 3 : 2) && !gp_poll(b2x, slot2(t + GP_XR - (l == 0 ? 3 : 2), r, min(ww + 4 * (lane >> 1), nkbx - 1)) + (unsigned)(lane & 1) * 512u + 496u, lane < 2 * nsx, err)) { fail(); return; }
           if (!gp_wait(cnt + C_H + r, 4u * ((unsigned)s + 1u), dead)) return;       // dz(t) of the tile is in LDS (and the cells have read the stage)
-          GPTS(19 + 2 * r);
+          GPTSR(19 + 2 * r);
           if (t > 0) { fetch(t - 1, r); stage(r); }                       // (needed by the cells a whole hand-off from now)
           if (!noprod) {
             // The R waves' state-gradient product starts at the same moment on the same SIMDs and is on the recurrence's critical
@@ -887,9 +901,9 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
 #endif
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
-        GPTS(6 * r + 0);
+        GPTSR(6 * r + 0);
         if (!gp_wait(cnt + C_M + r, 2u * ((unsigned)s + 1u), dead)) return;      // dm(t) of the tile is in LDS
-        GPTS(6 * r + 1);
+        GPTSR(6 * r + 1);
 
         {
           // dh^T[cells][rows] = W_p . dm^T, this wave's k-blocks w, w + 4, ...
@@ -915,12 +929,12 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
           for (int i = 0; i < 4; ++i) pdw[(r * NT + i) * 64] = d0[i];
           if (NT > 4) pdw[(r * NT + 4) * 64] = d1[0];
         }
-        GPTS(6 * r + 2);
+        GPTSR(6 * r + 2);
         gp_signal(cnt + C_P + r, lane);
         if (!gp_wait(cnt + C_P + r, 4u * ((unsigned)s + 1u), dead)) return;
         if (l > 0 && s > 0 && !gp_wait(cnt + C_Z + r, 4u * (unsigned)s, dead)) return;     // the X waves have taken dz(t+1)
         if (!gp_wait(cnt + C_F + r, 4u * ((unsigned)s + 1u), dead)) return;                // the stash of step t is in LDS
-        GPTS(6 * r + 3);
+        GPTSR(6 * r + 3);
         const bool live = t < (r ? len1 : len0);
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
@@ -947,10 +961,10 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the re-arming stores of the step before)
         gp_signal(cnt + C_H + r, lane);
-        GPTS(6 * r + 4);
+        GPTSR(6 * r + 4);
         if (!gp_wait(cnt + C_H + r, 4u * ((unsigned)s + 1u), dead)) return;       // every cell's dz of the tile is in LDS
         if (t > 0) { product(r, s % GP_R1); gp_signal(cnt + C_Q + r, lane); }     // (dm(-1) has no consumer)
-        GPTS(6 * r + 5);
+        GPTSR(6 * r + 5);
         // dz(t) over the gate activations of the stash, a quarter of the tile per R wave: NT consecutive lanes write one 16 NT-byte row piece
         int ln = lane;
         asm volatile("" : "+v"(ln));
@@ -1037,7 +1051,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
   };
   for (int s = 0; s < T; ++s) {
     const int t = T - 1 - s;
-    GPTS(12);
+    GPTSG(12);
     f32x4 tot = {0.f, 0.f, 0.f, 0.f};
     if (reducer) {
       float4 dtop = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1051,7 +1065,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
         if (!gp_sweep<10, false, 10, false>(b3, lo, nlr, pair_off, slot1(s % GP_XR, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
                                      [&](int k, const f32x4& v) { if (k == 0) sa = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) sa += v; })) { fail(); return; }
       }
-      GPTS(13);
+      GPTSG(13);
       if (s > 0) {
         // the state-gradient partials of this layer from time t + 1
         unsigned lo[10];
@@ -1062,7 +1076,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
                                     [&](int k, const f32x4& v) { if (k == 0) ua = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) ua += v; })) { fail(); return; }
         sa += ua;
       }
-      GPTS(14);
+      GPTSG(14);
       *reinterpret_cast<f32x4*>(&S.gs[s & 1][r][gp][lane][0]) = sa;
       gp_signal(cnt + C_G + r, lane);
       if (!gp_wait(cnt + C_G + r, 2u * ((unsigned)s + 1u), dead)) return;
@@ -1073,7 +1087,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
       tot = (((a0 + a1) + c0) + c1) + f32x4{dtop.x, dtop.y, dtop.z, dtop.w};
       if (!live) tot = f32x4{0.f, 0.f, 0.f, 0.f};
       if (gp == 0 && lane < 32) gp_store(b2, slot2(t, r, jbr) + (unsigned)hh * 512u + (unsigned)lane * 16u, tot);
-      GPTS(15);
+      GPTSG(15);
     }
     {
       // gather dm(t) of the tile: k-blocks gp, gp + 2, ... as B fragments of dh = dm . W_p^T
@@ -1083,12 +1097,12 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
       f32x4 mv[9];
       if (!gp_sweep<9, true, 9, true>(b2, lo, nvg, frag_off, slot2(t, r, min(gp + 2 * (lane >> 1), nkb - 1)) + (unsigned)(lane & 1) * 512u + 496u,
                                  lane < 2 * nvg, err, [&](int k, const f32x4& v) { mv[k] = v; })) { fail(); return; }
-      GPTS(16);
+      GPTSG(16);
 #pragma unroll
       for (int n = 0; n < 9; ++n)
         if (n < nvg) *reinterpret_cast<f32x4*>(mbg + 2 * n * 256) = mv[n];
       gp_signal(cnt + C_M + r, lane);
-      GPTS(17);
+      GPTSG(17);
     }
     if (reducer && gp == 1 && lane < 32 && rcol < ldP) *reinterpret_cast<float4*>(L.dmt + ((size_t)t * N + rrow) * ldP + rcol) = make_float4(tot[0], tot[1], tot[2], tot[3]);
     if (dxr && gp == 0 && s > 0) { if (!sum_dx0(s - 1)) { fail(); return; } }

@@ -78,6 +78,10 @@ int main(int argc, char** argv) {
 #else
   static unsigned tr[256][24][24];
   CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(rsr::g_gp_trace), sizeof(tr)));
+  if (const char* dump = getenv("GP_DUMP")) {                      // raw stamps [block][step][stamp] for an offline look at the skew between workgroups
+    FILE* f = fopen(dump, "wb");
+    if (f) { fwrite(tr, 1, sizeof(tr), f); fclose(f); }
+  }
   // R wave 0, tile r (stamps 6 r + ..): 0 top, 1 x-part there, 2 m(t-1) there, 3 recurrent MFMAs + tiles written, 4 all partials there, 5 cell done
   // G wave 0 (tile 0): 12 top, 13 all cells done, 14 projection + publish issued, 15 hop 1 swept, 16 half chunk published, 17 hop 2 swept
   // X wave 0: 18 / 20 sweep start (tile 0 / 1), 19 / 21 sweep done; 22, 23: prologue
