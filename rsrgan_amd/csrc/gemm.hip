@@ -610,11 +610,11 @@ __device__ __forceinline__ void store_tile(float (*S)[LDT], int tid, const float
 }
 
 template <bool AKC, bool BKC>
-__global__ __launch_bounds__(256) void k_gemm16(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                              float* __restrict__ C, int ldc, int M, int N, int K,
-                                              const float* __restrict__ bias, int act, float alpha, int accumulate,
-                                              float* __restrict__ ws, int ldw, int kt_per_split,
-                                              const float* __restrict__ A2, int lda2, int M1) {
+__device__ __forceinline__ void gemm16_body(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                            float* __restrict__ C, int ldc, int M, int N, int K,
+                                            const float* __restrict__ bias, int act, float alpha, int accumulate,
+                                            float* __restrict__ ws, int ldw, int kt_per_split,
+                                            const float* __restrict__ A2, int lda2, int M1, const int zs) {      // zs: this block's k split
   __shared__ __attribute__((aligned(16))) float As[GBK][LDT];
   __shared__ __attribute__((aligned(16))) float Bs[GBK][LDT];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void k_gemm16(const float* __restrict__ A, int
   // split-K: blockIdx.z owns k-tiles [kt0, kt1); partial tiles go to ws[z][M][ldw] and are summed in
   // a fixed order by k_splitk_reduce (deterministic, unlike float atomics)
   const int nk_all = (K + GBK - 1) / GBK;
-  const int kt0 = blockIdx.z * kt_per_split;
+  const int kt0 = zs * kt_per_split;
   const int nk = min(nk_all, kt0 + kt_per_split);
   float4 ra[GNF], rb[GNF];
   load_tile<AKC>(A, lda, m0, MA, kt0 * GBK, KA, tid, ra, A2, lda2, M1);
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256) void k_gemm16(const float* __restrict__ A, int
         const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row >= M) continue;
         if (ws) {
-          ws[((size_t)blockIdx.z * M + row) * ldw + col] = acc[i][j][r];
+          ws[((size_t)zs * M + row) * ldw + col] = acc[i][j][r];
           continue;
         }
         float v = acc[i][j][r] + bv;
@@ -689,6 +689,38 @@ __global__ __launch_bounds__(256) void k_gemm16(const float* __restrict__ A, int
         *c = v;
       }
     }
+}
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void k_gemm16(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                              float* __restrict__ C, int ldc, int M, int N, int K,
+                                              const float* __restrict__ bias, int act, float alpha, int accumulate,
+                                              float* __restrict__ ws, int ldw, int kt_per_split,
+                                              const float* __restrict__ A2, int lda2, int M1) {
+  gemm16_body<AKC, BKC>(A, lda, B, ldb, C, ldc, M, N, K, bias, act, alpha, accumulate, ws, ldw, kt_per_split, A2, lda2, M1, blockIdx.z);
+}
+// Up to GEMM16_MAXB products of ONE shape in one launch (the weight gradients of a stack's layers: [x | m]^T dZ, h^T dm -- short
+// launches that each left most of the chip idle and paid a launch + a reduce launch of their own): blockIdx.z = problem * nsplit + split.
+__global__ __launch_bounds__(256) void k_gemm16_b(const Gemm16Batch bt, int lda, int ldb, int ldc, int M, int N, int K, int accumulate,
+                                                  float* __restrict__ ws, int ldw, int kt_per_split, int nsplit, int lda2, int M1) {
+  const int p = blockIdx.z / nsplit, zs = blockIdx.z - p * nsplit;
+  gemm16_body<false, false>(bt.A[p], lda, bt.B[p], ldb, bt.C[p], ldc, M, N, K, nullptr, 0, 0.f, accumulate,
+                            ws ? ws + (size_t)p * nsplit * M * ldw : nullptr, ldw, kt_per_split, bt.A2[p], lda2, M1, zs);
+}
+__global__ __launch_bounds__(256) void k_splitk_reduce_b(const float* __restrict__ ws, int ldw, int splits, const Gemm16Batch bt, int ldc,
+                                                         int M, int N, int accumulate) {
+  const int p = blockIdx.y;
+  const float* w = ws + (size_t)p * splits * M * ldw;
+  float* C = bt.C[p];
+  const size_t total = (size_t)M * N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / N), col = (int)(i % N);
+    float v = 0.f;
+#pragma unroll 8
+    for (int z = 0; z < splits; ++z) v += w[((size_t)z * M + row) * ldw + col];
+    float* c = C + (size_t)row * ldc + col;
+    if (accumulate) v += *c;
+    *c = v;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ ws, int ldw, int splits, float* __restrict__ C,
@@ -965,6 +997,31 @@ static void launch_gemm16(const float* A, int lda, const float* A2, int lda2, in
   }
 }
 
+
+// The batch of launch_gemm16: operands x-contiguous ([K][M], [K][N]), no bias / activation.  Same split rule, over all problems' tiles.
+void launch_gemm16_batch(const Gemm16Batch& bt, int lda, int lda2, int M1, int ldb, int ldc, int M, int N, int K, bool accumulate,
+                         hipStream_t s, float* ws, size_t ws_floats) {
+  if (bt.n <= 0 || M <= 0 || N <= 0 || K <= 0) return;
+  const int gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
+  const int nk = (K + GBK - 1) / GBK;
+  int splits = 1;
+  const int ldw = (N + 3) & ~3;
+  if (ws && gx * gy * bt.n < 192 && nk * GBK >= 128) {
+    int cap = 64;
+    while (cap > 1 && (size_t)cap * bt.n * M * ldw > ws_floats) --cap;
+    splits = pick_splits(gx * gy * bt.n, nk, (size_t)M * ldw * sizeof(float), cap, 1.2 * GBK / 16, GBK == 16 ? 4 : 2);
+  }
+  const int per = std::max(1, (nk + splits - 1) / splits);
+  splits = std::max(1, (nk + per - 1) / per);
+  float* w = splits > 1 ? ws : nullptr;
+  hipLaunchKernelGGL(k_gemm16_b, dim3(gx, gy, splits * bt.n), dim3(256), 0, s, bt, lda, ldb, ldc, M, N, K, accumulate ? 1 : 0, w, ldw, per,
+                     splits, lda2, M1);
+  if (splits > 1) {
+    const size_t total = (size_t)M * N;
+    const int blocks = (int)std::min<size_t>(2048, (total + 255) / 256);
+    hipLaunchKernelGGL(k_splitk_reduce_b, dim3(blocks, bt.n), dim3(256), 0, s, ws, ldw, splits, bt, ldc, M, N, accumulate ? 1 : 0);
+  }
+}
 
 void launch_gemm_mapped(const float* A, int lda, const GemmRowMap& ma, const float* A2, int lda2, int M1, bool a_kc, const float* B, int ldb,
                         bool b_kc, float* C, int ldc, int M, int N, int K, const float* bias, int act, float alpha,

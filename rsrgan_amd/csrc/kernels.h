@@ -209,6 +209,11 @@ struct GemmRowMap { int rows_per; long long outer; long long inner; };
 void launch_gemm_mapped(const float* A, int lda, const GemmRowMap& ma, const float* A2, int lda2, int M1, bool a_kc, const float* B, int ldb,
                         bool b_kc, float* C, int ldc, int M, int N, int K, const float* bias, int act, float alpha,
                         bool accumulate, hipStream_t s, float* ws, size_t ws_floats);
+// up to 4 products of one shape in one k_gemm16 launch (+ one reduce launch): C[p] (+)= [A[p] | A2[p]]^T . B[p], operands [K][M1 | M - M1], [K][N]
+constexpr int GEMM16_MAXB = 4;
+struct Gemm16Batch { const float* A[GEMM16_MAXB]; const float* A2[GEMM16_MAXB]; const float* B[GEMM16_MAXB]; float* C[GEMM16_MAXB]; int n; };
+void launch_gemm16_batch(const Gemm16Batch& bt, int lda, int lda2, int M1, int ldb, int ldc, int M, int N, int K, bool accumulate,
+                         hipStream_t s, float* ws, size_t ws_floats);
 void launch_gemm2(const float* A, int lda, const float* A2, int lda2, int M1, bool a_kc, const float* B, int ldb, bool b_kc,
                   float* C, int ldc, int M, int N, int K, const float* bias, int act, float alpha, bool accumulate,
                   hipStream_t s, float* ws, size_t ws_floats);   // rows >= M1 of an m-contiguous A come from A2
@@ -265,6 +270,8 @@ void launch_expand_c4(const float* src, int ld_src, int n, float* dst, size_t ro
 void launch_col2im(const float* dcol, int ldk, int C, int S, int W, int kh, int kw, float* dst, int ldc, size_t M, hipStream_t s);
 struct ZeroList { int n; float* p[32]; unsigned len[32]; };        // many small buffers zeroed by ONE launch
 void launch_zero_many(const ZeroList& zl, hipStream_t s);
+struct ColsumsBatch { const float* dz[4]; const float* cprev[4]; const float* ccur[4]; float* db[4]; float* dwi[4]; float* dwf[4]; float* dwo[4]; int n; };
+void launch_lstm_colsums_batch(const ColsumsBatch& bt, int rows, int H, float* scratch, hipStream_t s);      // scratch: n x 64 x 7H floats
 void launch_lstm_colsums(const float* dz, const float* cprev, const float* ccur, float* db, float* dwi, float* dwf, float* dwo,
                          int rows, int H, float* scratch /* >= 64*7*H floats */, hipStream_t s);
 void launch_lrelu_bwd(const float* hval, float* d, size_t rows, int cols, int ld, float alpha, hipStream_t s); // d *= (h>0?1:alpha)

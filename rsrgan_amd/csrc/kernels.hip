@@ -1541,6 +1541,53 @@ __global__ void k_lstm_colsums2(const float* __restrict__ scratch, float* __rest
   db[c] = s[0]; db[H + c] = s[1]; db[2 * H + c] = s[2]; db[3 * H + c] = s[3];
   dwi[c] = s[4]; dwf[c] = s[5]; dwo[c] = s[6];
 }
+// the same for up to 4 layers of one shape in one launch each (blockIdx.z = layer; scratch: n x CS_SLICES x 7H floats)
+__global__ __launch_bounds__(256) void k_lstm_colsums1_b(const ColsumsBatch bt, float* __restrict__ scratch, int rows, int H) {
+  __shared__ float red[7][4][64];
+  const int p = blockIdx.z;
+  const float* __restrict__ dz = bt.dz[p]; const float* __restrict__ cprev = bt.cprev[p]; const float* __restrict__ ccur = bt.ccur[p];
+  scratch += (size_t)p * CS_SLICES * 7 * H;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int per = (rows + CS_SLICES - 1) / CS_SLICES;
+  const int rbeg = blockIdx.y * per, rend = min(rows, rbeg + per);
+  float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < H) {
+#pragma unroll 4
+    for (int r = rbeg + rl; r < rend; r += 4) {
+      const float* z = dz + (size_t)r * 4 * H + c;
+      const float di = z[0], dj = z[H], df = z[2 * H], d_o = z[3 * H];
+      const float cp = cprev[(size_t)r * H + c], cc = ccur[(size_t)r * H + c];
+      s[0] += di; s[1] += dj; s[2] += df; s[3] += d_o; s[4] += di * cp; s[5] += df * cp; s[6] += d_o * cc;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) red[k][rl][threadIdx.x & 63] = s[k];
+  __syncthreads();
+  if (rl == 0 && c < H) {
+    const int x = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+      scratch[((size_t)blockIdx.y * 7 + k) * H + c] = ((red[k][0][x] + red[k][1][x]) + red[k][2][x]) + red[k][3][x];
+  }
+}
+__global__ void k_lstm_colsums2_b(const float* __restrict__ scratch, const ColsumsBatch bt, int H) {
+  const int p = blockIdx.y;
+  scratch += (size_t)p * CS_SLICES * 7 * H;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int i = 0; i < CS_SLICES; ++i)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s[k] += scratch[((size_t)i * 7 + k) * H + c];
+  float* db = bt.db[p];
+  db[c] = s[0]; db[H + c] = s[1]; db[2 * H + c] = s[2]; db[3 * H + c] = s[3];
+  bt.dwi[p][c] = s[4]; bt.dwf[p][c] = s[5]; bt.dwo[p][c] = s[6];
+}
+void launch_lstm_colsums_batch(const ColsumsBatch& bt, int rows, int H, float* scratch, hipStream_t s) {
+  hipLaunchKernelGGL(k_lstm_colsums1_b, dim3((H + 63) / 64, CS_SLICES, bt.n), dim3(256), 0, s, bt, scratch, rows, H);
+  hipLaunchKernelGGL(k_lstm_colsums2_b, dim3((H + 255) / 256, bt.n), dim3(256), 0, s, scratch, bt, H);
+}
 void launch_lstm_colsums(const float* dz, const float* cprev, const float* ccur, float* db, float* dwi, float* dwf, float* dwo,
                          int rows, int H, float* scratch, hipStream_t s) {
   hipLaunchKernelGGL(k_lstm_colsums1, dim3((H + 63) / 64, CS_SLICES), dim3(256), 0, s, dz, cprev, ccur, scratch, rows, H);

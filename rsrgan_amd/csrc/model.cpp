@@ -462,9 +462,9 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   size_t maxcols = 7 * (size_t)std::max(c.g_cells, c.d_cells);
   maxcols = std::max(maxcols, (size_t)Din + 4);
   maxcols = std::max(maxcols, (size_t)std::max(ldP, ldDin));
-  scratch_floats = std::max<size_t>(64 * maxcols, 16384);
+  scratch_floats = std::max<size_t>(4 * 64 * maxcols, 16384);            // (x 4: the column sums of up to four layers in one launch)
   scratch = alloc<float>(scratch_floats);
-  scratch2 = alloc<float>(std::max<size_t>(64 * maxcols, 1024));
+  scratch2 = alloc<float>(std::max<size_t>(4 * 64 * maxcols, 1024));
   g_fc_out_wT = g_dnn() ? nullptr : alloc<float>((size_t)Dout * ldP);
   if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) side = nullptr;
   if (side) {
@@ -1045,27 +1045,82 @@ bool Model::persist_backward(Chain& ch, int T, hipStream_t s) {
   a.dout_top = ch.back().dout; a.ld_dout = dl.back().ldP;
   if (!a.dout_top || !dpersist_supported(a) || dpersist_granule_bytes(a.nl, a.N, a.T) > dp_gran_bytes) return false;
   launch_dlstm_bwd(a, s);
-  if (!defer_wgrads)             // (on one stream: the discriminator's sequences are ten short launches, two streams cost them 0.04 ms)
+  if (!defer_wgrads) {           // (on one stream: the discriminator's sequences are short launches, two streams cost them 0.04 ms)
+    bool dK_done = false;
+    const bool rest = batch_wgrads(ch, T, s, true, &dK_done);
     for (auto& R : ch)
-      if (R.want_wgrads) layer_wgrads(R, T, s);
+      if (R.want_wgrads) {
+        if (!dK_done || !rest) layer_wgrads_gemms(R, 0, T, false, s, !dK_done, !rest);
+        if (!rest) layer_wgrads_colsums(R, T, s, (side && s == side) ? scratch2 : scratch);
+      }
+  }
   return true;
 }
 
-void Model::layer_wgrads_gemms(const LayerRun& R, int t0, int t1, bool accumulate, hipStream_t s) {
+void Model::layer_wgrads_gemms(const LayerRun& R, int t0, int t1, bool accumulate, hipStream_t s, bool do_dK, bool do_dWp) {
   const LstmLayer& L = *R.L; const LstmStash& S = *R.S; const ParamSet& ps = *R.ps;
   const int H = L.H, H4 = 4 * H, Rws = (t1 - t0) * R.N;      // needs Ns == N (rows contiguous over time)
   const size_t r0 = (size_t)t0 * R.N;
   float* dK = ps.Gd(L.tK);
   // dK[0:I] (+)= in^T . dZ ; dK[I:I+P] (+)= m_{t-1}^T . dZ ; dWp (+)= h^T . dm   over frames [t0, t1)
-  if (L.I % 4 == 0) {        // one GEMM over the stacked operand [x_t | m_{t-1}] (two source stashes, one output tensor)
+  if (!do_dK) {
+  } else if (L.I % 4 == 0) {        // one GEMM over the stacked operand [x_t | m_{t-1}] (two source stashes, one output tensor)
     launch_gemm2(R.in + r0 * L.ldI, L.ldI, S.mst + r0 * L.ldP, L.ldP, L.I, false, S.gates + r0 * H4, H4, false, dK, H4,
                  L.I + L.P, H4, Rws, nullptr, 0, 0.f, accumulate, s, (side && s == side) ? gemm_ws2 : gemm_ws, gemm_ws_floats);
   } else {
     gemm(R.in + r0 * L.ldI, L.ldI, false, S.gates + r0 * H4, H4, false, dK, H4, L.I, H4, Rws, nullptr, 0, 0.f, accumulate, s);
     gemm(S.mst + r0 * L.ldP, L.ldP, false, S.gates + r0 * H4, H4, false, dK + (size_t)L.I * H4, H4, L.P, H4, Rws, nullptr, 0, 0.f, accumulate, s);
   }
-  if (L.has_proj)
+  if (L.has_proj && do_dWp)
     gemm(S.h + r0 * L.ldH, L.ldH, false, S.dmt + r0 * L.ldP, L.ldP, false, ps.Gd(L.tWp), L.ldP, H, L.P, Rws, nullptr, 0, 0.f, accumulate, s);
+}
+
+// The layers of a stack have ONE shape more often than not (generator: 3 x (280 + 280 -> 760 / p280), discriminator: 2 x (40 + 40 -> 256 /
+// p40)): their projection gradients h^T dm, their bias / peephole column sums and -- where the product is small enough for k_gemm16 --
+// their kernel gradients [x | m]^T dZ run as one launch per kind for all layers (blockIdx.z = layer) instead of one per layer: these
+// launches are latency-bound (the discriminator's six per layer left the chip idle for 0.26 ms per D-run).  Returns whether dWp and
+// the column sums are done (*dK_done: the kernel gradients as well); the caller runs per layer what is not.
+bool Model::batch_wgrads(Chain& ch, int T, hipStream_t s, bool dK_too, bool* dK_done) {
+  static const bool on = [] { const char* e = getenv("RSRGAN_WGRAD_BATCH"); return !e || atoi(e) != 0; }();
+  *dK_done = false;
+  std::vector<const LayerRun*> rs;
+  for (auto& R : ch) if (R.want_wgrads) rs.push_back(&R);
+  if (!on || rs.size() < 2 || rs.size() > (size_t)GEMM16_MAXB) return false;
+  const LstmLayer& L0 = *rs[0]->L;
+  for (auto* R : rs) {
+    const LstmLayer& L = *R->L;
+    if (L.I != L0.I || L.P != L0.P || L.H != L0.H || L.ldI != L0.ldI || L.ldP != L0.ldP || L.ldH != L0.ldH || !L.has_proj || L.I % 4 != 0 ||
+        R->N != rs[0]->N || R->Ns != R->N || R->row0 != 0)
+      return false;
+  }
+  const int H = L0.H, H4 = 4 * H, Rws = T * rs[0]->N;
+  if ((size_t)rs.size() * 64 * 7 * H > scratch_floats) return false;
+  float* ws = (side && s == side) ? gemm_ws2 : gemm_ws;
+  float* scr = (side && s == side) ? scratch2 : scratch;
+  // (the rule of launch_gemm_mapped: only products with little work per tile run on k_gemm16)
+  auto small = [&](int M, int N, int K) { const double outs = (double)M * N; return !(K >= 256 && outs >= 4.0e6) && !(K >= 2048 && outs >= 1.5e6); };
+  if (dK_too && small(L0.I + L0.P, H4, Rws)) {
+    Gemm16Batch bt{}; bt.n = (int)rs.size();
+    for (int p = 0; p < bt.n; ++p) { bt.A[p] = rs[p]->in; bt.A2[p] = rs[p]->S->mst; bt.B[p] = rs[p]->S->gates; bt.C[p] = rs[p]->ps->Gd(rs[p]->L->tK); }
+    launch_gemm16_batch(bt, L0.ldI, L0.ldP, L0.I, H4, H4, L0.I + L0.P, H4, Rws, false, s, ws, gemm_ws_floats);
+    *dK_done = true;
+  }
+  if (!small(H, L0.P, Rws)) return false;                     // (never for the nets of this repository: the caller runs the rest per layer)
+  {
+    Gemm16Batch bt{}; bt.n = (int)rs.size();
+    for (int p = 0; p < bt.n; ++p) { bt.A[p] = rs[p]->S->h; bt.A2[p] = nullptr; bt.B[p] = rs[p]->S->dmt; bt.C[p] = rs[p]->ps->Gd(rs[p]->L->tWp); }
+    launch_gemm16_batch(bt, L0.ldH, 0, 0, L0.ldP, L0.ldP, H, L0.P, Rws, false, s, ws, gemm_ws_floats);
+  }
+  {
+    ColsumsBatch cb{}; cb.n = (int)rs.size();
+    for (int p = 0; p < cb.n; ++p) {
+      const LayerRun& R = *rs[p]; const LstmLayer& L = *R.L; const ParamSet& ps = *R.ps;
+      cb.dz[p] = R.S->gates; cb.cprev[p] = R.S->c; cb.ccur[p] = R.S->c + (size_t)R.N * H;
+      cb.db[p] = ps.Gd(L.tb); cb.dwi[p] = ps.Gd(L.twi); cb.dwf[p] = ps.Gd(L.twf); cb.dwo[p] = ps.Gd(L.two);
+    }
+    launch_lstm_colsums_batch(cb, Rws, H, scr, s);
+  }
+  return true;
 }
 void Model::layer_wgrads_colsums(const LayerRun& R, int T, hipStream_t s, float* scr) {
   const LstmLayer& L = *R.L; const LstmStash& S = *R.S; const ParamSet& ps = *R.ps;
@@ -1095,15 +1150,23 @@ void Model::chain_wgrads(Chain& ch, int T, hipStream_t s, const std::function<vo
   hipEvent_t ev = ev_pool[ev_next++ & 15];
   (void)hipEventRecord(ev, s);
   (void)hipStreamWaitEvent(side, ev, 0);
-  bool first = true;
-  for (auto& R : ch) {
-    if (!R.want_wgrads) continue;
-    if (first) { first = false; continue; }                  // (the lowest layer with weight gradients stays on s)
-    layer_wgrads(R, T, side);
+  bool dK_done = false;
+  if (batch_wgrads(ch, T, side, false, &dK_done)) {
+    // every layer's dWp + column sums as three launches beside the chip-filling dK GEMMs, which stay on s one after the other
+    if (between) between();
+    for (auto& R : ch)
+      if (R.want_wgrads) layer_wgrads_gemms(R, 0, T, false, s, true, false);
+  } else {
+    bool first = true;
+    for (auto& R : ch) {
+      if (!R.want_wgrads) continue;
+      if (first) { first = false; continue; }                  // (the lowest layer with weight gradients stays on s)
+      layer_wgrads(R, T, side);
+    }
+    if (between) between();
+    for (auto& R : ch)
+      if (R.want_wgrads) { layer_wgrads(R, T, s); break; }
   }
-  if (between) between();
-  for (auto& R : ch)
-    if (R.want_wgrads) { layer_wgrads(R, T, s); break; }
   ev = ev_pool[ev_next++ & 15];
   (void)hipEventRecord(ev, side);
   (void)hipStreamWaitEvent(s, ev, 0);                       // join: the optimizer needs every gradient

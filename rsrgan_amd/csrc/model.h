@@ -263,7 +263,8 @@ struct Model {
                     const std::vector<FcStage>* fcs = nullptr);
   void layer_wgrads(const LayerRun& R, int T, hipStream_t s);
   void chain_wgrads(Chain& ch, int T, hipStream_t s, const std::function<void()>& between);   // all layers of a finished BPTT, on two streams
-  void layer_wgrads_gemms(const LayerRun& R, int t0, int t1, bool accumulate, hipStream_t s);
+  void layer_wgrads_gemms(const LayerRun& R, int t0, int t1, bool accumulate, hipStream_t s, bool do_dK = true, bool do_dWp = true);
+  bool batch_wgrads(Chain& ch, int T, hipStream_t s, bool dK_too, bool* dK_done);      // all layers of one shape: one launch per kind
   void layer_wgrads_colsums(const LayerRun& R, int T, hipStream_t s, float* scr);
   // side stream: weight-gradient GEMMs (MFMA-bound) overlap the byte-bound backward wave
   hipStream_t side = nullptr;
