@@ -305,6 +305,15 @@ void launch_colsum(const float* a, int lda, const float* b, int ldb, float* out,
 // LSGAN: logits [T*Nd][ldl] col 0.  rows with (r % Nd) < n_real use target_real and go to
 // loss[0], the others target_fake and loss[1]; loss[2] = loss[0]+loss[1].  Means over T*n_real /
 // T*(Nd-n_real) entries.  dlogits[r][0] = 2*(l-target)/count  (nullptr = skip).
+// discriminator_lstm's head, forward and backward in one pass (kernels.hip k_dhead1): top [T*Nd][ldt] -> logits, losses, dlogits, dout,
+// the FC's gradients gw [dR][ldw] / gb.  part: ceil(T*Nd / 256) x (DH_MAXR + 3) floats.  dR % 4 == 0, dR <= DH_MAXR.
+constexpr int DH_MAXR = 64;
+struct DHeadArgs {
+  const float* top; int ldt; const float* w; int ldw; const float* b;
+  float* logits; int ldl; float* dlogits; float* dout; int ldo; float* gw; float* gb;
+  int T, Nd, n_real, dR; const float* t_real; const float* t_fake; float* loss3; float* part; int want_grads, want_wgrads;
+};
+void launch_dhead(const DHeadArgs& a, hipStream_t s);
 void launch_lsgan(const float* logits, int ldl, float* dlogits, int T, int Nd, int n_real,
                   const float* target_real, const float* target_fake, float* loss3, hipStream_t s,
                   bool clip_on = false, float clip_lo = 0.f, float clip_hi = 0.f);

@@ -1647,6 +1647,91 @@ void launch_lsgan(const float* logits, int ldl, float* dlogits, int T, int Nd, i
                      clip_on ? 1 : 0, clip_lo, clip_hi);
 }
 
+// The head of discriminator_lstm in ONE pass over its top layer's outputs (models/discriminator_lstm.py:93-104: fully_connected to one
+// logit; gan_rnn_placeholder.py:244-250: the LSGAN terms over ALL frames, padded ones included) and, when gradients are wanted, its
+// backward half as well: logits, the three losses, dlogits, d(outputs) = dlogits . W^T and the FC's own gradients (dW = out^T dlogits,
+// db = sum dlogits).  Was gemm_n32 + k_lsgan (one block) + gemm16 + split-K reduce + two column-sum kernels + gemm16: seven launches,
+// 85 us between the discriminator's forward and backward recurrences with the chip idle.  One row per thread; block partials summed in
+// block order by k_dhead2 (deterministic).
+__global__ __launch_bounds__(256) void k_dhead1(const DHeadArgs a) {
+  __shared__ float wsh[DH_MAXR + 1];
+  __shared__ float red[4][DH_MAXR + 3];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int rows = a.T * a.Nd, dR = a.dR;
+  if (tid < dR) wsh[tid] = a.w[(size_t)tid * a.ldw];
+  if (tid == dR) wsh[dR] = a.b[0];
+  __syncthreads();
+  const int r = blockIdx.x * 256 + tid;
+  const bool on = r < rows;
+  const float tr = *a.t_real, tf = *a.t_fake;
+  const float cr = (float)a.T * (float)a.n_real, cf = (float)a.T * (float)(a.Nd - a.n_real);
+  float x[DH_MAXR];
+  float logit = wsh[dR];
+  const float* xr = a.top + (size_t)(on ? r : 0) * a.ldt;
+#pragma unroll
+  for (int c = 0; c < DH_MAXR; c += 4) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < dR) v = *reinterpret_cast<const float4*>(xr + c);          // (dR % 4 == 0: uniform)
+    x[c] = v.x; x[c + 1] = v.y; x[c + 2] = v.z; x[c + 3] = v.w;
+  }
+#pragma unroll
+  for (int c = 0; c < DH_MAXR; ++c) if (c < dR) logit += x[c] * wsh[c];
+  const bool real = on && (r % a.Nd) < a.n_real;
+  const float d = logit - (real ? tr : tf);
+  float sr = (on && real) ? d * d : 0.f, sf = (on && !real) ? d * d : 0.f;
+  const float dl = on ? 2.f * d / (real ? cr : cf) : 0.f;
+  if (on) {
+    a.logits[(size_t)r * a.ldl] = logit;
+    if (a.want_grads) {
+      a.dlogits[(size_t)r * a.ldl] = dl;
+      float* o = a.dout + (size_t)r * a.ldo;
+#pragma unroll
+      for (int c = 0; c < DH_MAXR; c += 4)
+        if (c < dR) *reinterpret_cast<float4*>(o + c) = make_float4(dl * wsh[c], dl * wsh[c + 1], dl * wsh[c + 2], dl * wsh[c + 3]);
+    }
+  }
+  // block partials: [0] sum over real rows, [1] over fake rows, [2] sum dlogits, [3 + c] sum out[:, c] * dlogits
+  auto wsum = [&](float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64); return v; };
+  sr = wsum(sr); sf = wsum(sf);
+  if (lane == 0) { red[wv][0] = sr; red[wv][1] = sf; }
+  if (a.want_wgrads) {
+    const float sd = wsum(dl);
+    if (lane == 0) red[wv][2] = sd;
+#pragma unroll
+    for (int c = 0; c < DH_MAXR; ++c)
+      if (c < dR) { const float v = wsum(x[c] * dl); if (lane == 0) red[wv][3 + c] = v; }
+  }
+  __syncthreads();
+  const int nq = a.want_wgrads ? 3 + dR : 2;
+  if (tid < nq) a.part[(size_t)blockIdx.x * (DH_MAXR + 3) + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+__global__ __launch_bounds__(128) void k_dhead2(const DHeadArgs a, int nblocks) {
+  __shared__ float tot[DH_MAXR + 3];
+  const int q = threadIdx.x;
+  const int nq = a.want_wgrads ? 3 + a.dR : 2;
+  if (q < nq) {
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += a.part[(size_t)b * (DH_MAXR + 3) + q];
+    tot[q] = s;
+    if (a.want_wgrads) {
+      if (q == 2) a.gb[0] = s;
+      if (q >= 3) a.gw[(size_t)(q - 3) * a.ldw] = s;
+    }
+  }
+  __syncthreads();
+  if (q == 0) {
+    const float cr = (float)a.T * (float)a.n_real, cf = (float)a.T * (float)(a.Nd - a.n_real);
+    const float lr_ = a.n_real > 0 ? tot[0] / cr : 0.f;
+    const float lf_ = (a.Nd - a.n_real) > 0 ? tot[1] / cf : 0.f;
+    a.loss3[0] = lr_; a.loss3[1] = lf_; a.loss3[2] = lr_ + lf_;
+  }
+}
+void launch_dhead(const DHeadArgs& a, hipStream_t s) {
+  const int rows = a.T * a.Nd, nb = (rows + 255) / 256;
+  hipLaunchKernelGGL(k_dhead1, dim3(nb), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_dhead2, dim3(1), dim3(128), 0, s, a, nb);
+}
+
 // models/gan.py:158-175: joint[r] = concat(x[r][off : off+dim], tail[r][0 : Dt]); rows [row0, row0+R) of `joint`
 __global__ void k_build_joint(const float* __restrict__ x, int ldx, int off, int dim, const float* __restrict__ tail, int ldt, int Dt,
                               float* __restrict__ joint, int ldj, int row0, int R) {

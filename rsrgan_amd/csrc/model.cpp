@@ -1366,20 +1366,37 @@ void Model::d_logits(int N, int T, hipStream_t s) {
   gemm(d_st[dl.size() - 1].out, ldPd, true, D.W(d_fc_w), 4, false, logits, 4, T * N, 1, dR, D.W(d_fc_b), 0, 0.f, false, s);
 }
 
+// discriminator_lstm's head in one pass (kernels.hip k_dhead1 / 2): logits and the LSGAN terms of N rows per frame (the first n_real
+// of them against *t_real), and with want_grads dlogits and d(outputs) in d_dB, with want_wgrads the output FC's gradients too.
+// False: not applicable (the caller runs d_logits + launch_lsgan + the GEMMs of d_backward_pass).
+bool Model::d_head(int N, int T, int n_real, const float* t_real, const float* t_fake, float* loss3, bool want_grads, bool want_wgrads,
+                   hipStream_t s) {
+  static const bool on = [] { const char* e = getenv("RSRGAN_DHEAD"); return !e || atoi(e) != 0; }();
+  const int ldPd = pad4(dR), nb = (T * N + 255) / 256;
+  if (!on || d_dnn() || dl.empty() || dR % 4 != 0 || dR > DH_MAXR || (size_t)nb * (DH_MAXR + 3) > scratch_floats) return false;
+  DHeadArgs a{};
+  a.top = d_st[dl.size() - 1].out; a.ldt = ldPd; a.w = D.W(d_fc_w); a.ldw = 4; a.b = D.W(d_fc_b);
+  a.logits = logits; a.ldl = 4; a.dlogits = dlogits; a.dout = d_dB; a.ldo = ldPd; a.gw = D.Gd(d_fc_w); a.gb = D.Gd(d_fc_b);
+  a.T = T; a.Nd = N; a.n_real = n_real; a.dR = dR; a.t_real = t_real; a.t_fake = t_fake; a.loss3 = loss3; a.part = scratch;
+  a.want_grads = want_grads ? 1 : 0; a.want_wgrads = want_wgrads ? 1 : 0;
+  launch_dhead(a, s);
+  return true;
+}
+
 // leaves in last_dx0 (d_dA or d_dB) the gradient w.r.t. the discriminator input when need_dx0
-void Model::d_backward_pass(int N, int T, bool want_wgrads, bool need_dx0, const float* dlog, hipStream_t s) {
+void Model::d_backward_pass(int N, int T, bool want_wgrads, bool need_dx0, const float* dlog, hipStream_t s, bool head_done) {
   const int R = T * N;
   const int ldPd = pad4(dR);
   const size_t Ld = dl.size();
   const float* top = d_st[Ld - 1].out;
-  if (want_wgrads) {
+  if (want_wgrads && !head_done) {
     gemm(top, ldPd, false, dlog, 4, false, D.Gd(d_fc_w), 4, dR, 1, R, nullptr, 0, 0.f, false, s);
     launch_colsum(dlog, 4, nullptr, 0, D.Gd(d_fc_b), R, 1, scratch, s);
   }
   float* cur = d_dB;
   float* other = d_dA;
-  // d(outputs) = dlogits . W^T
-  gemm(dlog, 4, true, D.W(d_fc_w), 4, true, cur, ldPd, R, dR, 1, nullptr, 0, 0.f, false, s);
+  // d(outputs) = dlogits . W^T  (d_head has left it in d_dB)
+  if (!head_done) gemm(dlog, 4, true, D.W(d_fc_w), 4, true, cur, ldPd, R, dR, 1, nullptr, 0, 0.f, false, s);
   std::vector<Chain> chains(1, d_chain(N, N, 0));
   Chain& ch = chains[0];
   for (int l = (int)Ld - 1; l >= 0; --l) {
@@ -1490,9 +1507,12 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
     d_dnn_forward_loss(T, 2 * B, B, want_grads, losses, s);
     if (want_grads) fc_backward(D, dfc, d_act, T * 2 * B, dlogits, true, false, s);
   } else {
-    d_logits(2 * B, T, s);
-    launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, 2 * B, B, dyn + DYN_D_REAL, dyn + DYN_D_FAKE, losses, s);
-    if (want_grads) d_backward_pass(2 * B, T, true, false, dlogits, s);
+    const bool head = d_head(2 * B, T, B, dyn + DYN_D_REAL, dyn + DYN_D_FAKE, losses, want_grads, want_grads, s);
+    if (!head) {
+      d_logits(2 * B, T, s);
+      launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, 2 * B, B, dyn + DYN_D_REAL, dyn + DYN_D_FAKE, losses, s);
+    }
+    if (want_grads) d_backward_pass(2 * B, T, true, false, dlogits, s, head);
   }
   });
   g_fwd_valid = true;
@@ -1606,11 +1626,15 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     }
   }
   // g_adv = mean((D(G(x)) - d_real)^2)  (gan_rnn_placeholder.py:246): all rows "fake", target d_real
+  bool g_head = false;
   if (d_dnn()) {
     d_dnn_forward_loss(T, B, 0, want_grads, tmp3, s);
   } else {
-    d_logits(B, T, s);
-    launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, B, 0, dyn + DYN_D_REAL, dyn + DYN_D_REAL, tmp3, s);
+    g_head = d_head(B, T, 0, dyn + DYN_D_REAL, dyn + DYN_D_REAL, tmp3, want_grads, false, s);
+    if (!g_head) {
+      d_logits(B, T, s);
+      launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, B, 0, dyn + DYN_D_REAL, dyn + DYN_D_REAL, tmp3, s);
+    }
   }
   launch_copy_f(tmp3 + 1, losses + 3, 1, s);
   if (want_grads && d_dnn()) {
@@ -1621,7 +1645,7 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   } else if (wave_bwd) {
     // ONE backward wave: D's layers (data gradient only) | per-step output-FC backward | G's layers.
     // dy[t] = lambda*(y-lab)/(B*T) (written first) + d g_adv/d y[t] (accumulated by D layer 0's phase B)
-    gemm(dlogits, 4, true, D.W(d_fc_w), 4, true, d_dB, ldPd, R, dR, 1, nullptr, 0, 0.f, false, s);      // d(D outputs) = dlogits . W^T
+    if (!g_head) gemm(dlogits, 4, true, D.W(d_fc_w), 4, true, d_dB, ldPd, R, dR, 1, nullptr, 0, 0.f, false, s);      // d(D outputs) = dlogits . W^T
     launch_mse(y_tm, lab_tm, ldDout, dy, R, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s);
     FcStage F;                                     // d(ins[L])[t] = dy[t] . W_out^T
     F.offset = Ld; F.N = B; F.K = Dout; F.D = P;
@@ -1647,7 +1671,7 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     gemm(g_ins[Lg], ldP, false, dy, ldDout, false, G.Gd(g_fc_out_w), ldDout, P, Dout, R, nullptr, 0, 0.f, false, s);
     launch_colsum(dy, ldDout, nullptr, 0, G.Gd(g_fc_out_b), R, Dout, scratch, s);
   } else if (want_grads) {
-    d_backward_pass(B, T, false, true, dlogits, s);
+    d_backward_pass(B, T, false, true, dlogits, s, g_head);
     float* dyd = last_dx0;                        // d g_adv / d y
     launch_mse(y_tm, lab_tm, ldDout, dyd, T * B, Dout, dyn + DYN_LAMBDA, true, losses + 4, scratch, s);
     g_backward_pass(T, dyd, s);

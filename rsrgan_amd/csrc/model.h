@@ -245,7 +245,8 @@ struct Model {
   void g_forward_head(int T, hipStream_t s);
   void g_forward_tail(int T, hipStream_t s);
   void d_logits(int N, int T, hipStream_t s);
-  void d_backward_pass(int N, int T, bool want_wgrads, bool need_dx0, const float* dlog, hipStream_t s);
+  void d_backward_pass(int N, int T, bool want_wgrads, bool need_dx0, const float* dlog, hipStream_t s, bool head_done = false);
+  bool d_head(int N, int T, int n_real, const float* t_real, const float* t_fake, float* loss3, bool want_grads, bool want_wgrads, hipStream_t s);
   void g_backward_pass(int T, float* dy, hipStream_t s);
   int d_backward(const float* x, const float* labels, const int32_t* lengths, int T, const float* nr, const float* nf,
                  float* out_losses, bool want_grads, hipStream_t s);
