@@ -306,7 +306,7 @@ void launch_colsum(const float* a, int lda, const float* b, int ldb, float* out,
 // loss[0], the others target_fake and loss[1]; loss[2] = loss[0]+loss[1].  Means over T*n_real /
 // T*(Nd-n_real) entries.  dlogits[r][0] = 2*(l-target)/count  (nullptr = skip).
 // discriminator_lstm's head, forward and backward in one pass (kernels.hip k_dhead1): top [T*Nd][ldt] -> logits, losses, dlogits, dout,
-// the FC's gradients gw [dR][ldw] / gb.  part: ceil(T*Nd / 256) x (DH_MAXR + 3) floats.  dR % 4 == 0, dR <= DH_MAXR.
+// the FC's gradients gw [dR][ldw] / gb.  part: ceil(T*Nd / 64) x (DH_MAXR + 3) floats.  dR % 4 == 0, dR <= DH_MAXR.
 constexpr int DH_MAXR = 64;
 struct DHeadArgs {
   const float* top; int ldt; const float* w; int ldw; const float* b;

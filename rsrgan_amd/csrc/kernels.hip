@@ -1651,22 +1651,21 @@ void launch_lsgan(const float* logits, int ldl, float* dlogits, int T, int Nd, i
 // logit; gan_rnn_placeholder.py:244-250: the LSGAN terms over ALL frames, padded ones included) and, when gradients are wanted, its
 // backward half as well: logits, the three losses, dlogits, d(outputs) = dlogits . W^T and the FC's own gradients (dW = out^T dlogits,
 // db = sum dlogits).  Was gemm_n32 + k_lsgan (one block) + gemm16 + split-K reduce + two column-sum kernels + gemm16: seven launches,
-// 85 us between the discriminator's forward and backward recurrences with the chip idle.  One row per thread; block partials summed in
-// block order by k_dhead2 (deterministic).
-__global__ __launch_bounds__(256) void k_dhead1(const DHeadArgs a) {
+// 85 us between the discriminator's forward and backward recurrences with the chip idle.  One row per thread, one wave per block; the
+// waves' partials are summed in a fixed order by k_dhead2 (deterministic).
+__global__ __launch_bounds__(64) void k_dhead1(const DHeadArgs a) {
   __shared__ float wsh[DH_MAXR + 1];
-  __shared__ float red[4][DH_MAXR + 3];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lane = threadIdx.x;
   const int rows = a.T * a.Nd, dR = a.dR;
-  if (tid < dR) wsh[tid] = a.w[(size_t)tid * a.ldw];
-  if (tid == dR) wsh[dR] = a.b[0];
+  if (lane < dR) wsh[lane] = a.w[(size_t)lane * a.ldw];
+  if (lane == 0) wsh[DH_MAXR] = a.b[0];
   __syncthreads();
-  const int r = blockIdx.x * 256 + tid;
+  const int r = blockIdx.x * 64 + lane;
   const bool on = r < rows;
   const float tr = *a.t_real, tf = *a.t_fake;
   const float cr = (float)a.T * (float)a.n_real, cf = (float)a.T * (float)(a.Nd - a.n_real);
   float x[DH_MAXR];
-  float logit = wsh[dR];
+  float logit = wsh[DH_MAXR];
   const float* xr = a.top + (size_t)(on ? r : 0) * a.ldt;
 #pragma unroll
   for (int c = 0; c < DH_MAXR; c += 4) {
@@ -1690,28 +1689,29 @@ __global__ __launch_bounds__(256) void k_dhead1(const DHeadArgs a) {
         if (c < dR) *reinterpret_cast<float4*>(o + c) = make_float4(dl * wsh[c], dl * wsh[c + 1], dl * wsh[c + 2], dl * wsh[c + 3]);
     }
   }
-  // block partials: [0] sum over real rows, [1] over fake rows, [2] sum dlogits, [3 + c] sum out[:, c] * dlogits
+  // the wave's partials: [0] sum over real rows, [1] over fake rows, [2] sum dlogits, [3 + c] sum out[:, c] * dlogits
   auto wsum = [&](float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64); return v; };
+  float* part = a.part + (size_t)blockIdx.x * (DH_MAXR + 3);
   sr = wsum(sr); sf = wsum(sf);
-  if (lane == 0) { red[wv][0] = sr; red[wv][1] = sf; }
+  if (lane == 0) { part[0] = sr; part[1] = sf; }
   if (a.want_wgrads) {
     const float sd = wsum(dl);
-    if (lane == 0) red[wv][2] = sd;
+    if (lane == 0) part[2] = sd;
 #pragma unroll
     for (int c = 0; c < DH_MAXR; ++c)
-      if (c < dR) { const float v = wsum(x[c] * dl); if (lane == 0) red[wv][3 + c] = v; }
+      if (c < dR) { const float v = wsum(x[c] * dl); if (lane == 0) part[3 + c] = v; }
   }
-  __syncthreads();
-  const int nq = a.want_wgrads ? 3 + dR : 2;
-  if (tid < nq) a.part[(size_t)blockIdx.x * (DH_MAXR + 3) + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
-__global__ __launch_bounds__(128) void k_dhead2(const DHeadArgs a, int nblocks) {
+// 16 lanes per quantity: lane j sums the partials of blocks j, j + 16, ... in order, then a fixed shuffle tree over the 16
+__global__ __launch_bounds__(1024) void k_dhead2(const DHeadArgs a, int nblocks) {
   __shared__ float tot[DH_MAXR + 3];
-  const int q = threadIdx.x;
+  const int q = threadIdx.x >> 4, j = threadIdx.x & 15;
   const int nq = a.want_wgrads ? 3 + a.dR : 2;
-  if (q < nq) {
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += a.part[(size_t)b * (DH_MAXR + 3) + q];
+  float s = 0.f;
+  if (q < nq)
+    for (int b = j; b < nblocks; b += 16) s += a.part[(size_t)b * (DH_MAXR + 3) + q];
+  s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+  if (q < nq && j == 0) {
     tot[q] = s;
     if (a.want_wgrads) {
       if (q == 2) a.gb[0] = s;
@@ -1719,7 +1719,7 @@ __global__ __launch_bounds__(128) void k_dhead2(const DHeadArgs a, int nblocks) 
     }
   }
   __syncthreads();
-  if (q == 0) {
+  if (threadIdx.x == 0) {
     const float cr = (float)a.T * (float)a.n_real, cf = (float)a.T * (float)(a.Nd - a.n_real);
     const float lr_ = a.n_real > 0 ? tot[0] / cr : 0.f;
     const float lf_ = (a.Nd - a.n_real) > 0 ? tot[1] / cf : 0.f;
@@ -1727,9 +1727,9 @@ __global__ __launch_bounds__(128) void k_dhead2(const DHeadArgs a, int nblocks) 
   }
 }
 void launch_dhead(const DHeadArgs& a, hipStream_t s) {
-  const int rows = a.T * a.Nd, nb = (rows + 255) / 256;
-  hipLaunchKernelGGL(k_dhead1, dim3(nb), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_dhead2, dim3(1), dim3(128), 0, s, a, nb);
+  const int rows = a.T * a.Nd, nb = (rows + 63) / 64;
+  hipLaunchKernelGGL(k_dhead1, dim3(nb), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_dhead2, dim3(1), dim3(1024), 0, s, a, nb);
 }
 
 // models/gan.py:158-175: joint[r] = concat(x[r][off : off+dim], tail[r][0 : Dt]); rows [row0, row0+R) of `joint`

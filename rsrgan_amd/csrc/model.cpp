@@ -1372,7 +1372,7 @@ void Model::d_logits(int N, int T, hipStream_t s) {
 bool Model::d_head(int N, int T, int n_real, const float* t_real, const float* t_fake, float* loss3, bool want_grads, bool want_wgrads,
                    hipStream_t s) {
   static const bool on = [] { const char* e = getenv("RSRGAN_DHEAD"); return !e || atoi(e) != 0; }();
-  const int ldPd = pad4(dR), nb = (T * N + 255) / 256;
+  const int ldPd = pad4(dR), nb = (T * N + 63) / 64;
   if (!on || d_dnn() || dl.empty() || dR % 4 != 0 || dR > DH_MAXR || (size_t)nb * (DH_MAXR + 3) > scratch_floats) return false;
   DHeadArgs a{};
   a.top = d_st[dl.size() - 1].out; a.ldt = ldPd; a.w = D.W(d_fc_w); a.ldw = 4; a.b = D.W(d_fc_b);
