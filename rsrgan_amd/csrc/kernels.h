@@ -223,6 +223,10 @@ void launch_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bo
                  float* splitk_ws = nullptr, size_t splitk_ws_floats = 0);
 
 // ---------------------------------------------------------------- layout / pointwise
+struct StagePack { const float* src; float* dst; int D, ld; };              // [B][T][D] -> [T][B][ld]
+struct StageCopy { const void* src; void* dst; int n; };                     // n 32-bit words
+struct StageJobs { StagePack pack[2]; StageCopy copy[4]; int B, T; };
+void launch_stage_inputs(const StageJobs& j, hipStream_t s);
 void launch_pack_tm(const float* src_bm, float* dst_tm, int B, int T, int D, int ld, hipStream_t s);      // [B,T,D] -> [T][B][ld]
 void launch_unpack_bm(const float* src_tm, int ld, float* dst_bm, int B, int T, int D, hipStream_t s);    // [T][B][ld] -> [B,T,D]
 // xd[t][b] = labels[t][b] + noise_r[b]   (b <  B)   (only when with_real)

@@ -1137,6 +1137,31 @@ __global__ void k_unpack_bm(const float* __restrict__ src, int ld, float* __rest
   float* d = dst + ((size_t)b * T + t) * D;
   for (int i = threadIdx.x; i < D; i += blockDim.x) d[i] = s[i];
 }
+// Everything a call stages from the caller's buffers in ONE launch (was two k_pack_tm + up to four 5 us device-to-device copies, all
+// eager: caller pointers never enter a captured graph): z = 0, 1 the batch-major -> time-major packs, z = 2 the small copies.
+__global__ void k_stage_inputs(const StageJobs j) {
+  const int z = blockIdx.z;
+  if (z < 2) {
+    const StagePack& p = j.pack[z];
+    if (!p.src) return;
+    const int t = blockIdx.x, b = blockIdx.y;
+    const float* s = p.src + ((size_t)b * j.T + t) * p.D;
+    float* d = p.dst + ((size_t)t * j.B + b) * p.ld;
+    for (int i = threadIdx.x; i < p.D; i += blockDim.x) d[i] = s[i];
+    return;
+  }
+  if (blockIdx.x || blockIdx.y) return;                               // the copies (a few KB in all): one block
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (!j.copy[c].src) continue;
+    const unsigned* s = (const unsigned*)j.copy[c].src;
+    unsigned* d = (unsigned*)j.copy[c].dst;
+    for (int i = threadIdx.x; i < j.copy[c].n; i += blockDim.x) d[i] = s[i];
+  }
+}
+void launch_stage_inputs(const StageJobs& j, hipStream_t s) {
+  hipLaunchKernelGGL(k_stage_inputs, dim3(j.T, j.B, 3), dim3(128), 0, s, j);
+}
 void launch_pack_tm(const float* src, float* dst, int B, int T, int D, int ld, hipStream_t s) {
   hipLaunchKernelGGL(k_pack_tm, dim3(T, B), dim3(D >= 128 ? 128 : 64), 0, s, src, dst, B, T, D, ld);
 }

@@ -1297,15 +1297,18 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
 }
 
 // ------------------------------------------------------------------------------------------
-int Model::prepare_batch(const float* x, const float* labels, const int32_t* lengths, int T, hipStream_t s) {
+int Model::prepare_batch(const float* x, const float* labels, const int32_t* lengths, int T, hipStream_t s, const float** nr,
+                         const float** nf) {
   if (T <= 0 || T > Tmax) { set_error("T=%d outside (0, max_frames=%d]", T, Tmax); return RSRGAN_ERR_INVALID; }
   if (!x || (!lengths && !g_dnn())) { set_error("null input pointer"); return RSRGAN_ERR_INVALID; }
-  launch_pack_tm(x, x_tm, B, T, Din, ldDin, s);
-  if (labels) launch_pack_tm(labels, lab_tm, B, T, Dout, ldDout, s);
-  if (lengths) {
-    HIPC(hipMemcpyAsync(len_dev, lengths, B * sizeof(int), hipMemcpyDeviceToDevice, s));
-    HIPC(hipMemcpyAsync(len_dev + B, lengths, B * sizeof(int), hipMemcpyDeviceToDevice, s));
-  }
+  // one launch: both packs, the lengths (twice: the stacked discriminator batch reads rows [B, 2B) as well) and the callers' noise
+  StageJobs j{}; j.B = B; j.T = T;
+  j.pack[0] = StagePack{x, x_tm, Din, ldDin};
+  if (labels) j.pack[1] = StagePack{labels, lab_tm, Dout, ldDout};
+  if (lengths) { j.copy[0] = StageCopy{lengths, len_dev, B}; j.copy[1] = StageCopy{lengths, len_dev + B, B}; }
+  if (nr && *nr) { j.copy[2] = StageCopy{*nr, noise_r_buf, B * Dout}; *nr = noise_r_buf; }
+  if (nf && *nf) { j.copy[3] = StageCopy{*nf, noise_f_buf, B * Dout}; *nf = noise_f_buf; }
+  launch_stage_inputs(j, s);
   cur_T = T;
   g_fwd_valid = false;
   return RSRGAN_OK;
@@ -1453,12 +1456,11 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
   if (!labels) { set_error("labels required"); return RSRGAN_ERR_INVALID; }
   if (supervised()) { set_error("RSRGAN_FLAG_SUPERVISED: the trainer graph has no discriminator step"); return RSRGAN_ERR_STATE; }
   if (g_dnn()) return dnn_d_backward(x, labels, T, out_losses, want_grads, s);
-  int rc = prepare_batch(x, labels, lengths, T, s);
+  if (d_dnn()) { nr = nullptr; nf = nullptr; }    // discriminator_dnn.py:58: the noise layer is commented out
+  int rc = prepare_batch(x, labels, lengths, T, s, &nr, &nf);      // (stages the noise too: caller pointers never enter a graph)
   if (rc) return rc;
   bn_eval_call = !want_grads;                      // (is_training of this fetch: the DropoutWrapper masks)
   if (seq_drop_on()) launch_drop_tick(drop_ctr, s);     // a new training run: new masks (read from device memory: graph-safe)
-  if (d_dnn()) { nr = nullptr; nf = nullptr; }    // discriminator_dnn.py:58: the noise layer is commented out
-  nr = stage_noise(nr, noise_r_buf, s); nf = stage_noise(nf, noise_f_buf, s);     // caller pointers never enter a graph
   const unsigned kbits = (want_grads ? 1u : 0u) | (nr ? 2u : 0u) | (nf ? 4u : 0u);
   run_seg(seg_key(SEG_D, T, kbits), s, [&]() {
   // discriminator input rows [0,B) = labels + noise_real (gan_rnn_placeholder.py:207,212; utils/ops.py:19-30)

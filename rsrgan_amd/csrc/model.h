@@ -240,7 +240,8 @@ struct Model {
   void destroy();
 
   // steps
-  int prepare_batch(const float* x, const float* labels, const int32_t* lengths, int T, hipStream_t s);
+  int prepare_batch(const float* x, const float* labels, const int32_t* lengths, int T, hipStream_t s, const float** nr = nullptr,
+                    const float** nf = nullptr);      // nr / nf: callers' noise, staged in the same launch (in/out: the staged copy)
   void g_forward(int T, hipStream_t s, Chain* extra = nullptr);
   void g_forward_head(int T, hipStream_t s);
   void g_forward_tail(int T, hipStream_t s);
