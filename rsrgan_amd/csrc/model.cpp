@@ -978,7 +978,7 @@ bool Model::persist_forward_g(int T, hipStream_t s) {
 
 // BPTT through the generator's stack as ONE persistent launch (gpersist.hip k_glstm_bwd): dz over the gate activations of every
 // layer's stash, dm per step in dmt.  Layer 0's input gradient (the input FC's d(h0)) is one GEMM over the dz stash afterwards.
-bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only) {
+bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only, const StreamFn& pre, const StreamFn& post) {
   if (!gp_gran1 || !gp_gran3 || !(gp_env & 2) || !wavefront() || seq_drop_on() || ch.size() != gl.size()) return false;
   GPersistArgs a{};
   if (!gpersist_args(a, T) || gpersist_gran2_bytes(a) > gp_gran2_bytes) return false;
@@ -1021,8 +1021,8 @@ bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only)
       gemm(R.S->gates, H4, true, R.ps->W(R.L->tK), H4, true, R.din, R.L->ldI, T * R.N, R.L->I, H4, nullptr, 0, 0.f, false, s);
     }
   };
-  if (!defer_wgrads) chain_wgrads(ch, T, s, din0);
-  else din0();
+  if (!defer_wgrads) chain_wgrads(ch, T, s, din0, pre, post);
+  else { if (pre) pre(s); din0(); if (post) post(s); }
   return true;
 }
 
@@ -1137,12 +1137,17 @@ void Model::layer_wgrads(const LayerRun& R, int T, hipStream_t s) {
 // launch sequences (dK GEMM + fix-up, dWp GEMM + reduce, the two column-sum kernels) do not depend on each other, and only the dK
 // GEMM fills the chip -- the upper layers' sequences ride the side stream beside the lowest layer's (and `between`, the caller's
 // launches that only need the BPTT), joined before returning.  RSRGAN_WGRAD_STREAMS=1: everything on s.
-void Model::chain_wgrads(Chain& ch, int T, hipStream_t s, const std::function<void()>& between) {
+// `pre` / `post` (optional): launches of the caller that only need the BPTT's inputs / only `between`'s result (the output and input
+// FCs' parameter gradients: short launches that used to follow the dK GEMMs): they ride the side stream too, `post` behind an event
+// recorded on s right after `between`.
+void Model::chain_wgrads(Chain& ch, int T, hipStream_t s, const std::function<void()>& between, const StreamFn& pre, const StreamFn& post) {
   static const int streams = [] { const char* e = getenv("RSRGAN_WGRAD_STREAMS"); return e ? atoi(e) : 2; }();
   int nw = 0;
   for (auto& R : ch) nw += R.want_wgrads ? 1 : 0;
   if (!side || streams < 2 || nw < 2) {
+    if (pre) pre(s);
     if (between) between();
+    if (post) post(s);
     for (auto& R : ch)
       if (R.want_wgrads) layer_wgrads(R, T, s);
     return;
@@ -1150,10 +1155,19 @@ void Model::chain_wgrads(Chain& ch, int T, hipStream_t s, const std::function<vo
   hipEvent_t ev = ev_pool[ev_next++ & 15];
   (void)hipEventRecord(ev, s);
   (void)hipStreamWaitEvent(side, ev, 0);
+  if (pre) pre(side);
+  auto after_between = [&]() {
+    if (!post) return;
+    hipEvent_t e2 = ev_pool[ev_next++ & 15];
+    (void)hipEventRecord(e2, s);
+    (void)hipStreamWaitEvent(side, e2, 0);
+    post(side);
+  };
   bool dK_done = false;
   if (batch_wgrads(ch, T, side, false, &dK_done)) {
     // every layer's dWp + column sums as three launches beside the chip-filling dK GEMMs, which stay on s one after the other
     if (between) between();
+    after_between();
     for (auto& R : ch)
       if (R.want_wgrads) layer_wgrads_gemms(R, 0, T, false, s, true, false);
   } else {
@@ -1164,6 +1178,7 @@ void Model::chain_wgrads(Chain& ch, int T, hipStream_t s, const std::function<vo
       layer_wgrads(R, T, side);
     }
     if (between) between();
+    after_between();
     for (auto& R : ch)
       if (R.want_wgrads) { layer_wgrads(R, T, s); break; }
   }
@@ -1599,6 +1614,15 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     bw_chains = std::vector<Chain>{dch, gch};
   };
   if (wave_bwd) build_bw_chains();                // host-only bookkeeping (bufA after the loop = d(h0))
+  // Without gradient buckets (rsrgan_g_step) and with the generator's BPTT as a persistent launch, the two FCs' parameter gradients --
+  // eight short launches that used to FOLLOW the dK GEMMs -- ride the side stream beside them.  Decided here, on the host: a
+  // replayed segment does not run its body.
+  static const bool fc_side_env = [] {
+    const char* e = getenv("RSRGAN_WGRAD_STREAMS"); const char* f = getenv("RSRGAN_FC_SIDE");
+    return (!e || atoi(e) >= 2) && (!f || atoi(f) != 0);
+  }();
+  const bool fcs_inside = wave_bwd && !bucketed && side && fc_side_env && cfg.g_type == RSRGAN_G_LSTM && dl[0].ldI == ldDout &&
+                          persist_backward_g(bw_chains[1], T, s, true);
 
   run_seg(seg_key(SEG_G_MAIN, T, kbits), s, [&]() {
   bool g_done = false;
@@ -1664,14 +1688,29 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
       const int H4d = 4 * dl[0].H;
       gemm(d_st[0].gates, H4d, true, D.W(dl[0].tK), H4d, true, dy, ldDout, R, dl[0].I, H4d, nullptr, 0, 0.f, true, s);
       gemm(dy, ldDout, true, G.W(g_fc_out_w), ldDout, true, g_dA, ldP, R, P, Dout, nullptr, 0, 0.f, false, s);
-      persist_backward_g(bw_chains[1], T, s);
+      // (fcs_inside: the output FC's parameter gradients need dy, complete here; the input FC's the d(h0) GEMM)
+      StreamFn pre, post;
+      if (fcs_inside) {
+        pre = [&](hipStream_t q) {
+          gemm(g_ins[Lg], ldP, false, dy, ldDout, false, G.Gd(g_fc_out_w), ldDout, P, Dout, R, nullptr, 0, 0.f, false, q);
+          launch_colsum(dy, ldDout, nullptr, 0, G.Gd(g_fc_out_b), R, Dout, (side && q == side) ? scratch2 : scratch, q);
+        };
+        post = [&](hipStream_t q) {        // through leakyrelu and the input FC (models/lstm.py:82-87); bufA holds d(h0)
+          launch_lrelu_bwd(g_h0, bufA, (size_t)R, P, ldP, cfg.lrelu_alpha, q);
+          gemm(x_tm, ldDin, false, bufA, ldP, false, G.Gd(g_fc_in_w), ldP, Din, P, R, nullptr, 0, 0.f, false, q);
+          launch_colsum(bufA, ldP, nullptr, 0, G.Gd(g_fc_in_b), R, P, (side && q == side) ? scratch2 : scratch, q);
+        };
+      }
+      persist_backward_g(bw_chains[1], T, s, false, pre, post);
     } else {
       rnn_backward(bw_chains, T, s, &offs, &fcs);
     }
     defer_wgrads = false;
     // output FC parameter gradients (batched over time, dy is complete now)
-    gemm(g_ins[Lg], ldP, false, dy, ldDout, false, G.Gd(g_fc_out_w), ldDout, P, Dout, R, nullptr, 0, 0.f, false, s);
-    launch_colsum(dy, ldDout, nullptr, 0, G.Gd(g_fc_out_b), R, Dout, scratch, s);
+    if (!fcs_inside) {
+      gemm(g_ins[Lg], ldP, false, dy, ldDout, false, G.Gd(g_fc_out_w), ldDout, P, Dout, R, nullptr, 0, 0.f, false, s);
+      launch_colsum(dy, ldDout, nullptr, 0, G.Gd(g_fc_out_b), R, Dout, scratch, s);
+    }
   } else if (want_grads) {
     d_backward_pass(B, T, false, true, dlogits, s, g_head);
     float* dyd = last_dx0;                        // d g_adv / d y
@@ -1685,7 +1724,7 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   if (wave_bwd) {
     int bi = 0;
     if (bucketed) mark_bucket(RSRGAN_NET_G, bi++, s);
-    if (cfg.g_type == RSRGAN_G_LSTM) {
+    if (cfg.g_type == RSRGAN_G_LSTM && !fcs_inside) {
       run_seg(seg_key(SEG_G_FCIN, T, kbits), s, [&]() {
         // through leakyrelu and the input FC (models/lstm.py:82-87); bufA holds d(h0)
         launch_lrelu_bwd(g_h0, bufA, (size_t)R, P, ldP, cfg.lrelu_alpha, s);

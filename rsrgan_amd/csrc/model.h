@@ -162,7 +162,8 @@ struct Model {
   bool gpersist_args(GPersistArgs& a, int T) const;       // false: not applicable
   void gpersist_rearm();                                  // the "not written" pattern in every ring slot (after allocation, after a failed launch)
   bool persist_forward_g(int T, hipStream_t s);           // layer 0's x-part batched first; fills the complete stash of every layer
-  bool persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only = false);   // BPTT of the generator chain (k_glstm_bwd), layer 0's input gradient as a GEMM, the weight gradients unless deferred
+  typedef std::function<void(hipStream_t)> StreamFn;
+  bool persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only = false, const StreamFn& pre = nullptr, const StreamFn& post = nullptr);   // BPTT of the generator chain (k_glstm_bwd), layer 0's input gradient as a GEMM, the weight gradients unless deferred
   // fully-connected stacks: models/dnn.py generator and models/discriminator_dnn.py discriminator
   std::vector<FcLayer> gfc, dfc;
   std::vector<float*> g_act, d_act;        // act[l] = input of FC layer l, act[L] = output of the stack
@@ -264,7 +265,7 @@ struct Model {
   void rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const std::vector<int>* offsets = nullptr,
                     const std::vector<FcStage>* fcs = nullptr);
   void layer_wgrads(const LayerRun& R, int T, hipStream_t s);
-  void chain_wgrads(Chain& ch, int T, hipStream_t s, const std::function<void()>& between);   // all layers of a finished BPTT, on two streams
+  void chain_wgrads(Chain& ch, int T, hipStream_t s, const std::function<void()>& between, const StreamFn& pre = nullptr, const StreamFn& post = nullptr);   // all layers of a finished BPTT, on two streams
   void layer_wgrads_gemms(const LayerRun& R, int t0, int t1, bool accumulate, hipStream_t s, bool do_dK = true, bool do_dWp = true);
   bool batch_wgrads(Chain& ch, int T, hipStream_t s, bool dK_too, bool* dK_done);      // all layers of one shape: one launch per kind
   void layer_wgrads_colsums(const LayerRun& R, int T, hipStream_t s, float* scr);
