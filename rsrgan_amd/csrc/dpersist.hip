@@ -32,7 +32,7 @@ constexpr int DP_HS = 72;           // LDS row stride of the h tile (floats): 18
 __device__ unsigned g_dp_trace[64][128][12];
 // (stamps go to LDS and leave at the end: a global store behind the write-through granule stores would itself stall at issue)
 #define DPT(i) do { if (threadIdx.x == 0 && t < 128) dp_tr[t][i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
-#define DPG(i) do { if (threadIdx.x == 256 && t < 128) dp_tr[t][8 + (i)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#define DPG(i) do { if (threadIdx.x == (blockDim.x == 768 ? 512u : 256u) && t < 128) dp_tr[t][8 + (i)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
 #define DPT_DECL __shared__ unsigned dp_tr[128][12];
 #define DPT_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x < 64) for (int t_ = 0; t_ < 128; ++t_) for (int i_ = 0; i_ < 12; ++i_) g_dp_trace[blockIdx.x][t_][i_] = dp_tr[t_][i_]; } while (0)
 #else
@@ -133,9 +133,11 @@ __device__ __forceinline__ bool dp_sweep2(const gu64* gm_, unsigned tm, float (&
   }
 }
 
-// 8 waves: 0-3 compute (wave w: all four gates of cells [16w, 16w+16) of the quarter; waves 0-2 also one 16-column tile of the
-// partial projection), 4-7 gather (wave 4+j polls quarter j's granules and hands them over through LDS).  The gather waves issue
-// no global stores: vmcnt retires in order, so a wave that has just published would wait for the acknowledgements of its own
+// 12 waves: 0-7 compute (wave w: TWO of the four gates -- i, j for w < 4, f, o for w >= 4 -- of cells [16 (w & 3), + 16) of the quarter;
+// the two waves of a cell group swap their gate tiles through LDS behind the MFMAs and each runs the cell for two of a lane's four cells:
+// the serial compute of a step, 48 gate MFMAs + a 4-cell cell phase on one wave = 3.2 k cycles of an 8.3 k period, is halved),
+// 8-11 gather (wave 8+j polls quarter j's granules and hands them over through LDS; waves 8-10 also one 16-column tile of the partial
+// projection).  The gather waves issue no global stores (beside the granules): vmcnt retires in order, so a wave that has just published would wait for the acknowledgements of its own
 // write-through stores before the first polled granule returns (measured: 1.2 us for a sweep of data that was long there).
 __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigned gen) {
   __shared__ __attribute__((aligned(16))) float part_m[DP_NQ][DP_KB][64][4];      // swept partials of m_{t-1}
@@ -144,6 +146,7 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
   __shared__ __attribute__((aligned(16))) float stage[6][16 * DP_HS];
   __shared__ __attribute__((aligned(16))) float kx_lds[4][4][DP_KB][64][4];       // K_x fragments of the compute waves (off the recurrent path: not worth 48 VGPRs)
   __shared__ __attribute__((aligned(16))) float wp_lds[4][4][64][4];               // W_p fragments of the projecting waves
+  __shared__ __attribute__((aligned(16))) float xch[4][4][64][4];                  // pre-activations of a cell group [group][gate][lane][cell]: the gate halves' exchange
   __shared__ int dead;
   DPT_DECL
   const int RTn = a.N >> 4, ncl = a.nl * RTn;
@@ -159,10 +162,10 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
   const size_t slot_stride_t = (size_t)DP_NQ * DP_SLOT;
   __syncthreads();
 
-  if (w >= 4) {
+  if (w >= 8) {
     // ---------------- gather waves ----------------
     __builtin_amdgcn_s_setprio(3);                                 // the hand-off is the critical path: ahead of the compute waves' run-ahead work
-    const int j = w - 4;
+    const int j = w - 8;
     const gu64* gm = (const gu64*)a.gran + ((size_t)(l * RTn + r) * T) * slot_stride_t + (size_t)j * DP_SLOT;          // quarter j of my tile
     const gu64* gx = (const gu64*)a.gran + ((size_t)(max(l - 1, 0) * RTn + r) * T) * slot_stride_t + (size_t)j * DP_SLOT;
     gu64* gout = (gu64*)a.gran + ((size_t)(l * RTn + r) * T) * slot_stride_t + (size_t)cq * DP_SLOT;
@@ -194,6 +197,7 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
       __syncthreads();                                             // A(t)
       if (dead) return;
       if (t < T) {
+        __syncthreads();                                           // X(t): the compute waves' exchange of gate tiles
         __syncthreads();                                           // B(t): the h tile of step t is in LDS
         DPG(2);
         // Partial projection of this quarter's 64 cells, on the gather waves: the write-through granule stores must not sit in the
@@ -240,13 +244,15 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
   }
 
   // ---------------- compute waves ----------------
-  const int cell = cq * 64 + 16 * w + lr;
+  const int cg = w & 3, gh = w >> 2;                                // cell group (16 cells), gate half: gates 2 gh, 2 gh + 1 (i, j | f, o)
+  const int cell = cq * 64 + 16 * cg + lr;
   // gate kernels: B fragment of gate g, k-block kb: lane (q, lr) holds K[k0 + 16kb + 4q + u][g*H + cell], u = 0..3 (zero beyond the width)
-  float4 kh[4][DP_KB];
+  float4 kh[2][DP_KB];
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
+  for (int gg = 0; gg < 2; ++gg)
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb) {
+      const int g = 2 * gh + gg;
       float vh[4], vx[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {                                 // all eight loads in flight, then the selects (the asm pins the loads
@@ -261,11 +267,11 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
         vh[u] = k < P ? vh[u] : 0.f;
         vx[u] = k < I ? vx[u] : 0.f;
       }
-      kh[g][kb] = make_float4(vh[0], vh[1], vh[2], vh[3]);
-      *reinterpret_cast<float4*>(&kx_lds[w][g][kb][lane][0]) = make_float4(vx[0], vx[1], vx[2], vx[3]);
+      kh[gg][kb] = make_float4(vh[0], vh[1], vh[2], vh[3]);
+      *reinterpret_cast<float4*>(&kx_lds[cg][g][kb][lane][0]) = make_float4(vx[0], vx[1], vx[2], vx[3]);
     }
-  // projection: wave w < 3 owns output columns [16w, 16w+16): B[k = cell 16kb + 4q + u of this quarter][col 16w + lr]
-  {
+  // projection: gather wave j < 3 owns output columns [16j, 16j+16): B[k = cell 16kb + 4q + u of this quarter][col 16j + lr]; loaded by compute waves 0-2
+  if (w < 3) {
     const int col = 16 * w + lr;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
@@ -280,21 +286,20 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
   }
   // The gate products run TRANSPOSED (K^T as the A operand, m^T as B; the 16x16x4 fragments of A[row][k] and B[k][col] sit in the
   // same lanes, so the resident registers serve either way): lane (q, lr) gets z[row lr][cells cb .. cb+3] -- four consecutive cells
-  // of ONE row, so zx, the gates, c and h move as 16-byte accesses (6 stores per step instead of 24: a scattered dword store costs
-  // ~125 cycles of issue, 3000 per step in profiles/r3_dpersist_trace.txt) and the masks are one comparison.
-  const int cb = cq * 64 + 16 * w + 4 * q;
-  const float4 pwi = *reinterpret_cast<const float4*>(L.wi + cb), pwf = *reinterpret_cast<const float4*>(L.wf + cb);
-  const float4 pwo = *reinterpret_cast<const float4*>(L.wo + cb);
-  f32x4 bs[4];
+  // of ONE row; this wave runs the cell for two of them, cb + 2 gh and cb + 2 gh + 1.
+  const int cb = cq * 64 + 16 * cg + 4 * q, ce = cb + 2 * gh;
+  const float2 pwi = *reinterpret_cast<const float2*>(L.wi + ce), pwf = *reinterpret_cast<const float2*>(L.wf + ce);
+  const float2 pwo = *reinterpret_cast<const float2*>(L.wo + ce);
+  f32x4 bs[2];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) bs[g] = *reinterpret_cast<const f32x4*>(L.bias + g * H + cb);
+  for (int gg = 0; gg < 2; ++gg) bs[gg] = *reinterpret_cast<const f32x4*>(L.bias + (2 * gh + gg) * H + cb);
   const int lenF = a.len[r0 + lr];
-  float cp[4] = {0.f, 0.f, 0.f, 0.f};
+  float cp[2] = {0.f, 0.f};
   float4 mf[DP_KB];
 #pragma unroll
   for (int kb = 0; kb < DP_KB; ++kb) mf[kb] = make_float4(0.f, 0.f, 0.f, 0.f);
   // slot 0 of the carried states is zero (cell.zero_state)
-  *reinterpret_cast<float4*>(L.c + (size_t)(r0 + lr) * H + cb) = make_float4(0.f, 0.f, 0.f, 0.f);
+  *reinterpret_cast<float2*>(L.c + (size_t)(r0 + lr) * H + ce) = make_float2(0.f, 0.f);
   if (cq == 0 && w == 0) {
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb)
@@ -304,7 +309,7 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
   // acc init of the next step: bias + x . K_x.  Layer 0's x is the stack's input, in memory before the launch: its rows travel as
   // plain 16-byte loads issued a whole step before their product (until round 4 that product was a time-batched GEMM in front of
   // the launch, 43 us for 12800 rows, whose 52 MB of output these waves then read back).
-  f32x4 accn[4];
+  f32x4 accn[2];
   float4 xn[DP_KB];
   auto load_x = [&](int t) {
     const float* xr = L.in + ((size_t)t * N + r0 + lr) * L.ldI;
@@ -322,24 +327,24 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
                                  ((p0.w + p1.w) + p2.w) + p3.w), make_float4(0.f, 0.f, 0.f, 0.f));
     }
   };
-  auto mma_part = [&](f32x4 (&acc)[4], const float4 (&af)[DP_KB], const float4 (&bf)[4][DP_KB]) {     // acc[g] += (af . bf[g])^T
+  auto mma_part = [&](f32x4 (&acc)[2], const float4 (&af)[DP_KB], const float4 (&bf)[2][DP_KB]) {     // acc[gg] += (af . bf[gg])^T
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].x, af[kb].x, acc[g], 0, 0, 0);
+      for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].x, af[kb].x, acc[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].y, af[kb].y, acc[g], 0, 0, 0);
+      for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].y, af[kb].y, acc[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].z, af[kb].z, acc[g], 0, 0, 0);
+      for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].z, af[kb].z, acc[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].w, af[kb].w, acc[g], 0, 0, 0);
+      for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].w, af[kb].w, acc[g], 0, 0, 0);
     }
   };
   // x-part of step t of a layer above 0 from the handed-over partials of the layer below: accn = bias + mask(x_t) . K_x;
   // layer 0: from the rows load_x fetched (dynamic_rnn does not mask its inputs; the cell discards what lies past a row's length)
   auto next_x = [&](int t) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) accn[g] = bs[g];
+    for (int g = 0; g < 2; ++g) accn[g] = bs[g];
     float4 xs[DP_KB];
     if (l > 0) {
       sum_parts(part_x[t & 1], I, xs);
@@ -352,17 +357,17 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
     }
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb) {
-      float4 bf[4];
+      float4 bf[2];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) bf[g] = *reinterpret_cast<const float4*>(&kx_lds[w][g][kb][lane][0]);
+      for (int g = 0; g < 2; ++g) bf[g] = *reinterpret_cast<const float4*>(&kx_lds[cg][2 * gh + g][kb][lane][0]);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].x, xs[kb].x, accn[g], 0, 0, 0);
+      for (int g = 0; g < 2; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].x, xs[kb].x, accn[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].y, xs[kb].y, accn[g], 0, 0, 0);
+      for (int g = 0; g < 2; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].y, xs[kb].y, accn[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].z, xs[kb].z, accn[g], 0, 0, 0);
+      for (int g = 0; g < 2; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].z, xs[kb].z, accn[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].w, xs[kb].w, accn[g], 0, 0, 0);
+      for (int g = 0; g < 2; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].w, xs[kb].w, accn[g], 0, 0, 0);
     }
   };
   // the full m of step t-1 (tile leader only): carried state -> mst[t], masked output -> out[t-1]
@@ -383,15 +388,14 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
   next_x(0);
   if (l == 0) load_x(min(1, T - 1));
 
-  float hv[4] = {0.f, 0.f, 0.f, 0.f}, sg[4][4] = {};
   for (int t = 0; t < T; ++t) {
-    f32x4 acc[4];
+    f32x4 acc[2];
     DPT(0);
     __syncthreads();                                               // A(t): m_{t-1} and x_{t+1} are in LDS
     if (dead) return;
     DPT(1);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = accn[g];
+    for (int g = 0; g < 2; ++g) acc[g] = accn[g];
     if (t > 0) {
       float4 ms[DP_KB];
       sum_parts(part_m, P, ms);
@@ -401,29 +405,38 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
       store_m(t, ms, live_prev);
     }
     mma_part(acc, mf, kh);
-    DPT(2);
-    // the cell, in the accumulator layout: lane = row lr, cells cb .. cb+3
-    const bool live = t < lenF;
-    const float pi_[4] = {pwi.x, pwi.y, pwi.z, pwi.w}, pf_[4] = {pwf.x, pwf.y, pwf.z, pwf.w}, po_[4] = {pwo.x, pwo.y, pwo.z, pwo.w};
+    // this wave's two gate tiles to its partner (the other gate half of the same cell group), the partner's two from it
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float cpv = cp[i];
-      const float gi = dp_sigmoid(acc[0][i] + pi_[i] * cpv);
-      const float gf = dp_sigmoid(acc[2][i] + a.forget_bias + pf_[i] * cpv);
-      const float gj = dp_tanh(acc[1][i]);
+    for (int g = 0; g < 2; ++g) *reinterpret_cast<f32x4*>(&xch[cg][2 * gh + g][lane][0]) = acc[g];
+    DPT(2);
+    __syncthreads();                                               // X(t)
+    f32x4 z[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) z[g] = (g >> 1) == gh ? acc[g & 1] : *reinterpret_cast<const f32x4*>(&xch[cg][g][lane][0]);
+    // the cell, in the accumulator layout: lane = row lr, this wave's cells ce, ce + 1 (elements 2 gh, 2 gh + 1 of the lane's four)
+    const bool live = t < lenF;
+    const float pi_[2] = {pwi.x, pwi.y}, pf_[2] = {pwf.x, pwf.y}, po_[2] = {pwo.x, pwo.y};
+    float hv[2], sg[4][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int i = 2 * gh + e;
+      const float cpv = cp[e];
+      const float gi = dp_sigmoid(z[0][i] + pi_[e] * cpv);
+      const float gf = dp_sigmoid(z[2][i] + a.forget_bias + pf_[e] * cpv);
+      const float gj = dp_tanh(z[1][i]);
       const float cn = gf * cpv + gi * gj;
-      const float go = dp_sigmoid(acc[3][i] + po_[i] * cn);
+      const float go = dp_sigmoid(z[3][i] + po_[e] * cn);
       const float hh = go * dp_tanh(cn);
-      hv[i] = live ? hh : 0.f;
-      sg[0][i] = live ? gi : 0.f; sg[1][i] = live ? gj : 0.f; sg[2][i] = live ? gf : 0.f; sg[3][i] = live ? go : 0.f;
-      cp[i] = live ? cn : cpv;
+      hv[e] = live ? hh : 0.f;
+      sg[0][e] = live ? gi : 0.f; sg[1][e] = live ? gj : 0.f; sg[2][e] = live ? gf : 0.f; sg[3][e] = live ? go : 0.f;
+      cp[e] = live ? cn : cpv;
     }
     {
-      const int so = lr * DP_HS + 16 * w + 4 * q;
+      const int so = lr * DP_HS + 16 * cg + 4 * q + 2 * gh;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(&stage[g][so]) = make_float4(sg[g][0], sg[g][1], sg[g][2], sg[g][3]);
-      *reinterpret_cast<float4*>(&stage[4][so]) = make_float4(cp[0], cp[1], cp[2], cp[3]);
-      *reinterpret_cast<float4*>(&stage[5][so]) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<float2*>(&stage[g][so]) = make_float2(sg[g][0], sg[g][1]);
+      *reinterpret_cast<float2*>(&stage[4][so]) = make_float2(cp[0], cp[1]);
+      *reinterpret_cast<float2*>(&stage[5][so]) = make_float2(hv[0], hv[1]);
     }
     DPT(3);
     __syncthreads();                                               // B(t): the h tile is in LDS
@@ -449,7 +462,7 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
   }
 }
 
-__global__ __launch_bounds__(512, 1) void k_dlstm_fwd(const DPersistArgs a) {
+__global__ __launch_bounds__(768, 1) void k_dlstm_fwd(const DPersistArgs a) {
   gu32* ctl = (gu32*)a.ctl;
   // every wave reads the generation itself: it only changes when ALL workgroups have passed their epilogue
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -797,7 +810,7 @@ void launch_dlstm_bwd(const DPersistArgs& a, hipStream_t s) {
 
 void launch_dlstm_fwd(const DPersistArgs& a, hipStream_t s) {
   const int blocks = a.nl * (a.N / 16) * DP_NQ;
-  hipLaunchKernelGGL(k_dlstm_fwd, dim3(blocks), dim3(512), 0, s, a);
+  hipLaunchKernelGGL(k_dlstm_fwd, dim3(blocks), dim3(768), 0, s, a);
   ++g_chain_launches;
 }
 
