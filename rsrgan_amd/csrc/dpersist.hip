@@ -442,8 +442,9 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
     __syncthreads();                                               // B(t): the h tile is in LDS
     DPT(4);
     DPT(7);
-    // run ahead while the gather waves poll: the x-part of step t+1 (after their projection and publish, see the backward kernel)
-    __builtin_amdgcn_s_sleep(12);
+    // run ahead while the gather waves poll: the x-part of step t+1
+    // (until the compute was split over eight waves an s_sleep(12) stood here, to keep the x-part's MFMA burst off the gather waves'
+    //  projection; with 24 MFMAs per wave it only costs: 336 -> 307 us per launch without it)
     if (t + 1 < T) next_x(t + 1);
     if (l == 0) load_x(min(t + 2, T - 1));                         // (consumed a step from now; not right behind barrier B: see the backward kernel)
     DPT(5);
