@@ -13,6 +13,8 @@
 // launch from earlier ones): no memset per launch, nothing frozen into a captured graph.  Every spin is bounded (wall-clock) and
 // reports through the sticky `err` word of the control block (Model::check_persist reads and clears it); a failed launch also
 // poisons the top layer's output with NaN so the step's losses cannot look healthy.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace rsr {
@@ -497,7 +499,7 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
   __shared__ __attribute__((aligned(16))) float part_m[DP_NQ][DP_KB][64][4];      // swept partials of dm_state (from step t+1)
   __shared__ __attribute__((aligned(16))) float part_x[2][DP_NQ][DP_KB][64][4];   // ... of dout (dx of the layer above), by parity of the step
   __shared__ __attribute__((aligned(16))) float stage[4][16 * DP_HS];             // dz of the step, staged for gather wave 3
-  __shared__ __attribute__((aligned(16))) float psum[4][DP_KB][64][4];            // the compute waves' partial dm_state tiles
+  __shared__ __attribute__((aligned(16))) float psum[8][DP_KB][64][4];            // the compute waves' partial dm_state tiles
   __shared__ __attribute__((aligned(16))) float psum_x[2][4][DP_KB][64][4];       // ... partial dx tiles, by parity of the step
   __shared__ __attribute__((aligned(16))) float kx_lds[4][DP_KB][4][64][4];       // K_x fragments (A operand of the dx product)
   __shared__ int dead;
@@ -513,6 +515,10 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
   const bool top = l == a.nl - 1;
   gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
   if (tid == 0) dead = 0;
+  // (twelve waves, as in the forward kernel: the two compute waves of a cell group each take two of a lane's four cells -- the cell
+  //  gradient and the k-steps of the state-gradient product those cells feed: eight partial tiles in psum; the input-gradient product
+  //  runs behind barrier B from the complete dz in `stage`, its three output tiles split 2 + 1 between the two waves.  LDS float adds
+  //  into shared tiles were tried first: 12 ds_add_f32 per lane took 7.9 k cycles, 1.79 ms per launch.)
   const size_t slot_stride_t = (size_t)DP_NQ * DP_SLOT;
   // edge 0: dm_state partials of this layer; edge 1: dx partials of this layer = dout of the layer below
   auto edge = [&](int layer, int e) -> gu64* {
@@ -520,10 +526,10 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
   };
   __syncthreads();
 
-  if (w >= 4) {
+  if (w >= 8) {
     // ---------------- gather waves ----------------
     __builtin_amdgcn_s_setprio(3);
-    const int j = w - 4;
+    const int j = w - 8;
     const gu64* gm = edge(l, 0) + (size_t)j * DP_SLOT;
     const gu64* gx = edge(min(l + 1, a.nl - 1), 1) + (size_t)j * DP_SLOT;
     gu64* gout_m = edge(l, 0) + (size_t)cq * DP_SLOT;
@@ -535,13 +541,18 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
         *reinterpret_cast<float4*>(&part[j][kb][lane][0]) = make_float4(v[kb * 4], v[kb * 4 + 1], v[kb * 4 + 2], v[kb * 4 + 3]);
     };
     auto fail = [&]() { if (lane == 0) { dead = 1; __hip_atomic_store(err, 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } };
-    // the sum of the four compute waves' tile j, published as this quarter's partial
-    auto publish = [&](float (*ps)[DP_KB][64][4], gu64* dst) {
-      const float4 p0 = *reinterpret_cast<const float4*>(&ps[0][j][lane][0]), p1 = *reinterpret_cast<const float4*>(&ps[1][j][lane][0]);
-      const float4 p2 = *reinterpret_cast<const float4*>(&ps[2][j][lane][0]), p3 = *reinterpret_cast<const float4*>(&ps[3][j][lane][0]);
+    // the sum of the compute waves' tiles j (NW of them, in wave order), published as this quarter's partial
+    auto publish = [&](float (*ps)[DP_KB][64][4], gu64* dst, auto nw) {
+      constexpr int NW = decltype(nw)::value;
+      float4 p = *reinterpret_cast<const float4*>(&ps[0][j][lane][0]);
+#pragma unroll
+      for (int c = 1; c < NW; ++c) {
+        const float4 v = *reinterpret_cast<const float4*>(&ps[c][j][lane][0]);
+        p = make_float4(p.x + v.x, p.y + v.y, p.z + v.z, p.w + v.w);
+      }
       gu64* go_ = dst + ((size_t)j * 64 + lane) * 4;
-      dp_store2(go_, gen, ((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y);
-      dp_store2(go_ + 2, gen, ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
+      dp_store2(go_, gen, p.x, p.y);
+      dp_store2(go_ + 2, gen, p.z, p.w);
     };
     if (!top) {                                                    // dout of step T-1 for the prologue
       if (!dp_sweep2(nullptr, gen, vm, gx + (size_t)(T - 1) * slot_stride_t, gen, vx, lane, err)) fail();
@@ -564,11 +575,11 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
       if (dead) return;
       // dx of step t+1 (in LDS since before A(t)) leaves while the compute waves work: its write-through stores are acknowledged
       // before the dm_state publish below (two publishes back to back cost the second one, and the poll behind it, ~0.75 us)
-      if (j < 3 && l > 0 && t < T - 1) publish(psum_x[(t + 1) & 1], gout_x + (size_t)(t + 1) * slot_stride_t);
+      if (j < 3 && l > 0 && t < T - 1) publish(psum_x[(t + 1) & 1], gout_x + (size_t)(t + 1) * slot_stride_t, std::integral_constant<int, 4>{});
       __syncthreads();                                             // B(t): psum(t) and the dz stage are in LDS
       DPG(2);
       if (j < 3) {
-        publish(psum, gout_m + (size_t)t * slot_stride_t);
+        publish(psum, gout_m + (size_t)t * slot_stride_t, std::integral_constant<int, 8>{});
       } else {
         // gather wave 3 writes the step's dz over the gate activations: whole 256-byte rows from the LDS stage
         const int c4 = (lane & 15) * 4, rr = lane >> 4;
@@ -585,17 +596,19 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
     }
     if (l > 0) {                                                   // dx of step 0, computed after barrier B(0)
       __syncthreads();                                             // C
-      if (j < 3) publish(psum_x[0], gout_x);
+      if (j < 3) publish(psum_x[0], gout_x, std::integral_constant<int, 4>{});
     }
     return;
   }
 
   // ---------------- compute waves ----------------
-  const int cb = cq * 64 + 16 * w + 4 * q;                          // this lane's four cells
-  // A operands, resident.  dh: W_p[cell 16w + lr][p = 16kb + 4q + u]; dm_state: K[I + p][g*H + cells cb .. cb+3], p = 16pt + lr
-  float4 wpA[DP_KB], khA[DP_KB][4];
+  const int cg = w & 3, hh = w >> 2;                                // cell group; this wave's cells of a lane's four: 2 hh, 2 hh + 1
+  const int cb = cq * 64 + 16 * cg + 4 * q, ce = cb + 2 * hh;       // this lane's four cells; the two this wave differentiates
+  // A operands, resident.  dh: W_p[cell 16 cg + lr][p = 16kb + 4q + u]; dm_state: K[I + p][g*H + cells ce, ce + 1], p = 16pt + lr
+  float4 wpA[DP_KB];
+  float2 khA[DP_KB][4];
   {
-    const float* wrow = L.Wp + (size_t)(cq * 64 + 16 * w + lr) * ldP;
+    const float* wrow = L.Wp + (size_t)(cq * 64 + 16 * cg + lr) * ldP;
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb) {
       const int k = 16 * kb + 4 * q;
@@ -609,29 +622,30 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
       for (int g = 0; g < 4; ++g) {
         const float4 vh = *reinterpret_cast<const float4*>(L.K + (size_t)(I + min(p, P - 1)) * H4 + g * H + cb);
         const float4 vx = *reinterpret_cast<const float4*>(L.K + (size_t)min(p, I - 1) * H4 + g * H + cb);
-        khA[pt][g] = dp_sel(p < P, vh, make_float4(0.f, 0.f, 0.f, 0.f));
-        *reinterpret_cast<float4*>(&kx_lds[w][pt][g][lane][0]) = dp_sel(l > 0 && p < I, vx, make_float4(0.f, 0.f, 0.f, 0.f));
+        const float4 sh = dp_sel(p < P, vh, make_float4(0.f, 0.f, 0.f, 0.f));
+        khA[pt][g] = hh ? make_float2(sh.z, sh.w) : make_float2(sh.x, sh.y);
+        if (hh == 0) *reinterpret_cast<float4*>(&kx_lds[cg][pt][g][lane][0]) = dp_sel(l > 0 && p < I, vx, make_float4(0.f, 0.f, 0.f, 0.f));
       }
     }
   }
-  const float4 pwi = *reinterpret_cast<const float4*>(L.wi + cb), pwf = *reinterpret_cast<const float4*>(L.wf + cb);
-  const float4 pwo = *reinterpret_cast<const float4*>(L.wo + cb);
-  const float pi_[4] = {pwi.x, pwi.y, pwi.z, pwi.w}, pf_[4] = {pwf.x, pwf.y, pwf.z, pwf.w}, po_[4] = {pwo.x, pwo.y, pwo.z, pwo.w};
+  const float2 pwi = *reinterpret_cast<const float2*>(L.wi + ce), pwf = *reinterpret_cast<const float2*>(L.wf + ce);
+  const float2 pwo = *reinterpret_cast<const float2*>(L.wo + ce);
+  const float pi_[2] = {pwi.x, pwi.y}, pf_[2] = {pwf.x, pwf.y}, po_[2] = {pwo.x, pwo.y};
   const int lenF = a.len[r0 + lr];
 
-  float dc[4] = {0.f, 0.f, 0.f, 0.f};
+  float dc[2] = {0.f, 0.f};
   float4 mf[DP_KB];                                                 // dm_state of this lane's row: [k = 16kb + 4q + u]
 #pragma unroll
   for (int kb = 0; kb < DP_KB; ++kb) mf[kb] = make_float4(0.f, 0.f, 0.f, 0.f);
   // operands of a step, requested one step ahead: the gate activations, c_{t-1} (c_t is last step's c_{t-1}) and the top layer's dout
-  f32x4 gn[4], cpn;
+  float2 gn[4], cpn;
   float4 don[DP_KB];
-  f32x4 ccur;
+  float2 ccur;
   auto prefetch = [&](int t) {
     const size_t row = (size_t)t * N + r0 + lr;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) gn[g] = *reinterpret_cast<const f32x4*>(L.gates + row * H4 + g * H + cb);
-    cpn = *reinterpret_cast<const f32x4*>(L.c + row * H + cb);
+    for (int g = 0; g < 4; ++g) gn[g] = *reinterpret_cast<const float2*>(L.gates + row * H4 + g * H + ce);
+    cpn = *reinterpret_cast<const float2*>(L.c + row * H + ce);
     if (top) {
 #pragma unroll
       for (int kb = 0; kb < DP_KB; ++kb)
@@ -648,7 +662,7 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
                                  ((p0.w + p1.w) + p2.w) + p3.w), make_float4(0.f, 0.f, 0.f, 0.f));
     }
   };
-  ccur = *reinterpret_cast<const f32x4*>(L.c + ((size_t)T * N + r0 + lr) * H + cb);      // c_T
+  ccur = *reinterpret_cast<const float2*>(L.c + ((size_t)T * N + r0 + lr) * H + ce);      // c_T
   prefetch(T - 1);
   __syncthreads();                                                 // P
   if (dead) return;
@@ -660,10 +674,10 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
     DPT(1);
     const bool live = t < lenF;
     // this step's operands out of the prefetch registers, the next step's requested
-    f32x4 gt[4];
+    float2 gt[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) gt[g] = gn[g];
-    const f32x4 cprev = cpn;
+    const float2 cprev = cpn;
     float4 dout[DP_KB];
     if (top) {
 #pragma unroll
@@ -691,7 +705,7 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
       for (int kb = 0; kb < DP_KB; ++kb)
         if (16 * kb + 4 * q < P) *reinterpret_cast<float4*>(L.dmt + ((size_t)t * N + r0 + lr) * ldP + 16 * kb + 4 * q) = dm[kb];
     }
-    // dh^T[cell][row] = W_p[cell][:] . dm^T
+    // dh^T[cell][row] = W_p[cell][:] . dm^T  (all four cells of the lane: both waves of the group run these 12 MFMAs)
     f32x4 dh = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb) {
@@ -701,28 +715,31 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
       dh = __builtin_amdgcn_mfma_f32_16x16x4f32(wpA[kb].w, dm[kb].w, dh, 0, 0, 0);
     }
     DPT(2);
-    // gate / cell gradients (kernels.hip k_bwd_a2): lane = row lr, cells cb + i
-    float dz[4][4];
+    // gate / cell gradients (kernels.hip k_bwd_a2): lane = row lr, cells ce + e
+    const float dh2[2] = {hh ? dh[2] : dh[0], hh ? dh[3] : dh[1]};
+    const float gt_[4][2] = {{gt[0].x, gt[0].y}, {gt[1].x, gt[1].y}, {gt[2].x, gt[2].y}, {gt[3].x, gt[3].y}};
+    const float cc_[2] = {ccur.x, ccur.y}, cp_[2] = {cprev.x, cprev.y};
+    float dz[4][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float gi = gt[0][i], gj = gt[1][i], gf = gt[2][i], go = gt[3][i];
-      const float tc = dp_tanh(ccur[i]);
-      const float dao = dh[i] * tc * go * (1.f - go);
-      const float dcn = dc[i] + dh[i] * go * (1.f - tc * tc) + dao * po_[i];
-      const float daf = dcn * cprev[i] * gf * (1.f - gf);
+    for (int e = 0; e < 2; ++e) {
+      const float gi = gt_[0][e], gj = gt_[1][e], gf = gt_[2][e], go = gt_[3][e];
+      const float tc = dp_tanh(cc_[e]);
+      const float dao = dh2[e] * tc * go * (1.f - go);
+      const float dcn = dc[e] + dh2[e] * go * (1.f - tc * tc) + dao * po_[e];
+      const float daf = dcn * cp_[e] * gf * (1.f - gf);
       const float dai = dcn * gj * gi * (1.f - gi);
       const float dj = dcn * gi * (1.f - gj * gj);
-      dz[0][i] = live ? dai : 0.f; dz[1][i] = live ? dj : 0.f; dz[2][i] = live ? daf : 0.f; dz[3][i] = live ? dao : 0.f;
-      dc[i] = live ? dcn * gf + dai * pi_[i] + daf * pf_[i] : dc[i];
+      dz[0][e] = live ? dai : 0.f; dz[1][e] = live ? dj : 0.f; dz[2][e] = live ? daf : 0.f; dz[3][e] = live ? dao : 0.f;
+      dc[e] = live ? dcn * gf + dai * pi_[e] + daf * pf_[e] : dc[e];
     }
     ccur = cprev;
     {
-      const int so = lr * DP_HS + 16 * w + 4 * q;
+      const int so = lr * DP_HS + 16 * cg + 4 * q + 2 * hh;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(&stage[g][so]) = make_float4(dz[g][0], dz[g][1], dz[g][2], dz[g][3]);
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<float2*>(&stage[g][so]) = make_float2(dz[g][0], dz[g][1]);
     }
     DPT(3);
-    // partial dm_state^T over this wave's 64 gate columns: the lane's dz[g][0..3] is the B fragment of k-block (gate g)
+    // partial dm_state^T over this wave's 32 gate columns (2 cells x 4 gates): the lane's dz[g][e] is the B fragment of a k-step
     f32x4 pa[DP_KB];
 #pragma unroll
     for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -732,10 +749,6 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
       for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(khA[pt][g].x, dz[g][0], pa[pt], 0, 0, 0);
 #pragma unroll
       for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(khA[pt][g].y, dz[g][1], pa[pt], 0, 0, 0);
-#pragma unroll
-      for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(khA[pt][g].z, dz[g][2], pa[pt], 0, 0, 0);
-#pragma unroll
-      for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(khA[pt][g].w, dz[g][3], pa[pt], 0, 0, 0);
     }
 #pragma unroll
     for (int pt = 0; pt < DP_KB; ++pt) *reinterpret_cast<f32x4*>(&psum[w][pt][lane][0]) = pa[pt];
@@ -743,27 +756,26 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
     __syncthreads();                                               // B(t)
     DPT(5);
     if (l > 0) {                                                   // dx partial^T of this step: published by the gather waves after B(t-1)
-      // (first let the gather waves publish: this burst of LDS reads and MFMAs right behind the barrier held their ~350-cycle
-      // publish back by 1500 cycles on the shared SIMDs, s_setprio notwithstanding -- profiles/r3_dpersist_trace.txt)
-      __builtin_amdgcn_s_sleep(8);
+      // from the COMPLETE dz of the cell group (both waves' cells: in `stage` since barrier B; this wave overwrites it only behind
+      // A(t-1)); output tiles pt = 0, 1 on the first wave of the group, pt = 2 on the second: whole tiles, no partial sums
+      float4 dzs[4];
 #pragma unroll
-      for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < 4; ++g) dzs[g] = *reinterpret_cast<const float4*>(&stage[g][lr * DP_HS + 16 * cg + 4 * q]);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4 af[DP_KB];
+      for (int pp = 0; pp < 2; ++pp) {
+        const int pt = hh ? 2 : pp;
+        if (hh && pp) break;
+        f32x4 px = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int pt = 0; pt < DP_KB; ++pt) af[pt] = *reinterpret_cast<const float4*>(&kx_lds[w][pt][g][lane][0]);
-#pragma unroll
-        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt].x, dz[g][0], pa[pt], 0, 0, 0);
-#pragma unroll
-        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt].y, dz[g][1], pa[pt], 0, 0, 0);
-#pragma unroll
-        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt].z, dz[g][2], pa[pt], 0, 0, 0);
-#pragma unroll
-        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt].w, dz[g][3], pa[pt], 0, 0, 0);
+        for (int g = 0; g < 4; ++g) {
+          const float4 af = *reinterpret_cast<const float4*>(&kx_lds[cg][pt][g][lane][0]);
+          px = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, dzs[g].x, px, 0, 0, 0);
+          px = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, dzs[g].y, px, 0, 0, 0);
+          px = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, dzs[g].z, px, 0, 0, 0);
+          px = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, dzs[g].w, px, 0, 0, 0);
+        }
+        *reinterpret_cast<f32x4*>(&psum_x[t & 1][cg][pt][lane][0]) = px;
       }
-#pragma unroll
-      for (int pt = 0; pt < DP_KB; ++pt) *reinterpret_cast<f32x4*>(&psum_x[t & 1][w][pt][lane][0]) = pa[pt];
     }
     DPT(6);
   }
@@ -771,7 +783,7 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
   if (l > 0) __syncthreads();                                      // C: dx of step 0 is in LDS
 }
 
-__global__ __launch_bounds__(512, 1) void k_dlstm_bwd(const DPersistArgs a) {
+__global__ __launch_bounds__(768, 1) void k_dlstm_bwd(const DPersistArgs a) {
   gu32* ctl = (gu32*)a.ctl;
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   dp_bwd_body(a, gen);
@@ -805,7 +817,7 @@ bool dpersist_supported(const DPersistArgs& a) {
 // a.gran: zeroed ONCE at allocation (tag 0 is never a generation); a.ctl: {1, 0, 0, 0} at allocation
 void launch_dlstm_bwd(const DPersistArgs& a, hipStream_t s) {
   const int blocks = a.nl * (a.N / 16) * DP_NQ;
-  hipLaunchKernelGGL(k_dlstm_bwd, dim3(blocks), dim3(512), 0, s, a);
+  hipLaunchKernelGGL(k_dlstm_bwd, dim3(blocks), dim3(768), 0, s, a);
   ++g_chain_launches;
 }
 
