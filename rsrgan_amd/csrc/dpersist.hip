@@ -13,8 +13,6 @@
 // launch from earlier ones): no memset per launch, nothing frozen into a captured graph.  Every spin is bounded (wall-clock) and
 // reports through the sticky `err` word of the control block (Model::check_persist reads and clears it); a failed launch also
 // poisons the top layer's output with NaN so the step's losses cannot look healthy.
-#include <type_traits>
-
 #include "kernels.h"
 
 namespace rsr {
@@ -34,7 +32,7 @@ constexpr int DP_HS = 72;           // LDS row stride of the h tile (floats): 18
 __device__ unsigned g_dp_trace[64][128][12];
 // (stamps go to LDS and leave at the end: a global store behind the write-through granule stores would itself stall at issue)
 #define DPT(i) do { if (threadIdx.x == 0 && t < 128) dp_tr[t][i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
-#define DPG(i) do { if (threadIdx.x == (blockDim.x == 768 ? 512u : 256u) && t < 128) dp_tr[t][8 + (i)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#define DPG(i) do { if (threadIdx.x == 256 && t < 128) dp_tr[t][8 + (i)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
 #define DPT_DECL __shared__ unsigned dp_tr[128][12];
 #define DPT_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x < 64) for (int t_ = 0; t_ < 128; ++t_) for (int i_ = 0; i_ < 12; ++i_) g_dp_trace[blockIdx.x][t_][i_] = dp_tr[t_][i_]; } while (0)
 #else
@@ -135,11 +133,9 @@ __device__ __forceinline__ bool dp_sweep2(const gu64* gm_, unsigned tm, float (&
   }
 }
 
-// 12 waves: 0-7 compute (wave w: TWO of the four gates -- i, j for w < 4, f, o for w >= 4 -- of cells [16 (w & 3), + 16) of the quarter;
-// the two waves of a cell group swap their gate tiles through LDS behind the MFMAs and each runs the cell for two of a lane's four cells:
-// the serial compute of a step, 48 gate MFMAs + a 4-cell cell phase on one wave = 3.2 k cycles of an 8.3 k period, is halved),
-// 8-11 gather (wave 8+j polls quarter j's granules and hands them over through LDS; waves 8-10 also one 16-column tile of the partial
-// projection).  The gather waves issue no global stores (beside the granules): vmcnt retires in order, so a wave that has just published would wait for the acknowledgements of its own
+// 8 waves: 0-3 compute (wave w: all four gates of cells [16w, 16w+16) of the quarter; waves 0-2 also one 16-column tile of the
+// partial projection), 4-7 gather (wave 4+j polls quarter j's granules and hands them over through LDS).  The gather waves issue
+// no global stores: vmcnt retires in order, so a wave that has just published would wait for the acknowledgements of its own
 // write-through stores before the first polled granule returns (measured: 1.2 us for a sweep of data that was long there).
 __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigned gen) {
   __shared__ __attribute__((aligned(16))) float part_m[DP_NQ][DP_KB][64][4];      // swept partials of m_{t-1}
@@ -148,7 +144,6 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
   __shared__ __attribute__((aligned(16))) float stage[6][16 * DP_HS];
   __shared__ __attribute__((aligned(16))) float kx_lds[4][4][DP_KB][64][4];       // K_x fragments of the compute waves (off the recurrent path: not worth 48 VGPRs)
   __shared__ __attribute__((aligned(16))) float wp_lds[4][4][64][4];               // W_p fragments of the projecting waves
-  __shared__ __attribute__((aligned(16))) float xch[4][4][64][4];                  // pre-activations of a cell group [group][gate][lane][cell]: the gate halves' exchange
   __shared__ int dead;
   DPT_DECL
   const int RTn = a.N >> 4, ncl = a.nl * RTn;
@@ -164,10 +159,10 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
   const size_t slot_stride_t = (size_t)DP_NQ * DP_SLOT;
   __syncthreads();
 
-  if (w >= 8) {
+  if (w >= 4) {
     // ---------------- gather waves ----------------
     __builtin_amdgcn_s_setprio(3);                                 // the hand-off is the critical path: ahead of the compute waves' run-ahead work
-    const int j = w - 8;
+    const int j = w - 4;
     const gu64* gm = (const gu64*)a.gran + ((size_t)(l * RTn + r) * T) * slot_stride_t + (size_t)j * DP_SLOT;          // quarter j of my tile
     const gu64* gx = (const gu64*)a.gran + ((size_t)(max(l - 1, 0) * RTn + r) * T) * slot_stride_t + (size_t)j * DP_SLOT;
     gu64* gout = (gu64*)a.gran + ((size_t)(l * RTn + r) * T) * slot_stride_t + (size_t)cq * DP_SLOT;
@@ -199,7 +194,6 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
       __syncthreads();                                             // A(t)
       if (dead) return;
       if (t < T) {
-        __syncthreads();                                           // X(t): the compute waves' exchange of gate tiles
         __syncthreads();                                           // B(t): the h tile of step t is in LDS
         DPG(2);
         // Partial projection of this quarter's 64 cells, on the gather waves: the write-through granule stores must not sit in the
@@ -246,15 +240,13 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
   }
 
   // ---------------- compute waves ----------------
-  const int cg = w & 3, gh = w >> 2;                                // cell group (16 cells), gate half: gates 2 gh, 2 gh + 1 (i, j | f, o)
-  const int cell = cq * 64 + 16 * cg + lr;
+  const int cell = cq * 64 + 16 * w + lr;
   // gate kernels: B fragment of gate g, k-block kb: lane (q, lr) holds K[k0 + 16kb + 4q + u][g*H + cell], u = 0..3 (zero beyond the width)
-  float4 kh[2][DP_KB];
+  float4 kh[4][DP_KB];
 #pragma unroll
-  for (int gg = 0; gg < 2; ++gg)
+  for (int g = 0; g < 4; ++g)
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb) {
-      const int g = 2 * gh + gg;
       float vh[4], vx[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {                                 // all eight loads in flight, then the selects (the asm pins the loads
@@ -269,11 +261,11 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
         vh[u] = k < P ? vh[u] : 0.f;
         vx[u] = k < I ? vx[u] : 0.f;
       }
-      kh[gg][kb] = make_float4(vh[0], vh[1], vh[2], vh[3]);
-      *reinterpret_cast<float4*>(&kx_lds[cg][g][kb][lane][0]) = make_float4(vx[0], vx[1], vx[2], vx[3]);
+      kh[g][kb] = make_float4(vh[0], vh[1], vh[2], vh[3]);
+      *reinterpret_cast<float4*>(&kx_lds[w][g][kb][lane][0]) = make_float4(vx[0], vx[1], vx[2], vx[3]);
     }
-  // projection: gather wave j < 3 owns output columns [16j, 16j+16): B[k = cell 16kb + 4q + u of this quarter][col 16j + lr]; loaded by compute waves 0-2
-  if (w < 3) {
+  // projection: wave w < 3 owns output columns [16w, 16w+16): B[k = cell 16kb + 4q + u of this quarter][col 16w + lr]
+  {
     const int col = 16 * w + lr;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
@@ -288,20 +280,21 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
   }
   // The gate products run TRANSPOSED (K^T as the A operand, m^T as B; the 16x16x4 fragments of A[row][k] and B[k][col] sit in the
   // same lanes, so the resident registers serve either way): lane (q, lr) gets z[row lr][cells cb .. cb+3] -- four consecutive cells
-  // of ONE row; this wave runs the cell for two of them, cb + 2 gh and cb + 2 gh + 1.
-  const int cb = cq * 64 + 16 * cg + 4 * q, ce = cb + 2 * gh;
-  const float2 pwi = *reinterpret_cast<const float2*>(L.wi + ce), pwf = *reinterpret_cast<const float2*>(L.wf + ce);
-  const float2 pwo = *reinterpret_cast<const float2*>(L.wo + ce);
-  f32x4 bs[2];
+  // of ONE row, so zx, the gates, c and h move as 16-byte accesses (6 stores per step instead of 24: a scattered dword store costs
+  // ~125 cycles of issue, 3000 per step in profiles/r3_dpersist_trace.txt) and the masks are one comparison.
+  const int cb = cq * 64 + 16 * w + 4 * q;
+  const float4 pwi = *reinterpret_cast<const float4*>(L.wi + cb), pwf = *reinterpret_cast<const float4*>(L.wf + cb);
+  const float4 pwo = *reinterpret_cast<const float4*>(L.wo + cb);
+  f32x4 bs[4];
 #pragma unroll
-  for (int gg = 0; gg < 2; ++gg) bs[gg] = *reinterpret_cast<const f32x4*>(L.bias + (2 * gh + gg) * H + cb);
+  for (int g = 0; g < 4; ++g) bs[g] = *reinterpret_cast<const f32x4*>(L.bias + g * H + cb);
   const int lenF = a.len[r0 + lr];
-  float cp[2] = {0.f, 0.f};
+  float cp[4] = {0.f, 0.f, 0.f, 0.f};
   float4 mf[DP_KB];
 #pragma unroll
   for (int kb = 0; kb < DP_KB; ++kb) mf[kb] = make_float4(0.f, 0.f, 0.f, 0.f);
   // slot 0 of the carried states is zero (cell.zero_state)
-  *reinterpret_cast<float2*>(L.c + (size_t)(r0 + lr) * H + ce) = make_float2(0.f, 0.f);
+  *reinterpret_cast<float4*>(L.c + (size_t)(r0 + lr) * H + cb) = make_float4(0.f, 0.f, 0.f, 0.f);
   if (cq == 0 && w == 0) {
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb)
@@ -311,7 +304,7 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
   // acc init of the next step: bias + x . K_x.  Layer 0's x is the stack's input, in memory before the launch: its rows travel as
   // plain 16-byte loads issued a whole step before their product (until round 4 that product was a time-batched GEMM in front of
   // the launch, 43 us for 12800 rows, whose 52 MB of output these waves then read back).
-  f32x4 accn[2];
+  f32x4 accn[4];
   float4 xn[DP_KB];
   auto load_x = [&](int t) {
     const float* xr = L.in + ((size_t)t * N + r0 + lr) * L.ldI;
@@ -329,24 +322,24 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
                                  ((p0.w + p1.w) + p2.w) + p3.w), make_float4(0.f, 0.f, 0.f, 0.f));
     }
   };
-  auto mma_part = [&](f32x4 (&acc)[2], const float4 (&af)[DP_KB], const float4 (&bf)[2][DP_KB]) {     // acc[gg] += (af . bf[gg])^T
+  auto mma_part = [&](f32x4 (&acc)[4], const float4 (&af)[DP_KB], const float4 (&bf)[4][DP_KB]) {     // acc[g] += (af . bf[g])^T
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb) {
 #pragma unroll
-      for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].x, af[kb].x, acc[g], 0, 0, 0);
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].x, af[kb].x, acc[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].y, af[kb].y, acc[g], 0, 0, 0);
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].y, af[kb].y, acc[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].z, af[kb].z, acc[g], 0, 0, 0);
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].z, af[kb].z, acc[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].w, af[kb].w, acc[g], 0, 0, 0);
+      for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g][kb].w, af[kb].w, acc[g], 0, 0, 0);
     }
   };
   // x-part of step t of a layer above 0 from the handed-over partials of the layer below: accn = bias + mask(x_t) . K_x;
   // layer 0: from the rows load_x fetched (dynamic_rnn does not mask its inputs; the cell discards what lies past a row's length)
   auto next_x = [&](int t) {
 #pragma unroll
-    for (int g = 0; g < 2; ++g) accn[g] = bs[g];
+    for (int g = 0; g < 4; ++g) accn[g] = bs[g];
     float4 xs[DP_KB];
     if (l > 0) {
       sum_parts(part_x[t & 1], I, xs);
@@ -359,17 +352,17 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
     }
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb) {
-      float4 bf[2];
+      float4 bf[4];
 #pragma unroll
-      for (int g = 0; g < 2; ++g) bf[g] = *reinterpret_cast<const float4*>(&kx_lds[cg][2 * gh + g][kb][lane][0]);
+      for (int g = 0; g < 4; ++g) bf[g] = *reinterpret_cast<const float4*>(&kx_lds[w][g][kb][lane][0]);
 #pragma unroll
-      for (int g = 0; g < 2; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].x, xs[kb].x, accn[g], 0, 0, 0);
+      for (int g = 0; g < 4; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].x, xs[kb].x, accn[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 2; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].y, xs[kb].y, accn[g], 0, 0, 0);
+      for (int g = 0; g < 4; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].y, xs[kb].y, accn[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 2; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].z, xs[kb].z, accn[g], 0, 0, 0);
+      for (int g = 0; g < 4; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].z, xs[kb].z, accn[g], 0, 0, 0);
 #pragma unroll
-      for (int g = 0; g < 2; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].w, xs[kb].w, accn[g], 0, 0, 0);
+      for (int g = 0; g < 4; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g].w, xs[kb].w, accn[g], 0, 0, 0);
     }
   };
   // the full m of step t-1 (tile leader only): carried state -> mst[t], masked output -> out[t-1]
@@ -390,14 +383,15 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
   next_x(0);
   if (l == 0) load_x(min(1, T - 1));
 
+  float hv[4] = {0.f, 0.f, 0.f, 0.f}, sg[4][4] = {};
   for (int t = 0; t < T; ++t) {
-    f32x4 acc[2];
+    f32x4 acc[4];
     DPT(0);
     __syncthreads();                                               // A(t): m_{t-1} and x_{t+1} are in LDS
     if (dead) return;
     DPT(1);
 #pragma unroll
-    for (int g = 0; g < 2; ++g) acc[g] = accn[g];
+    for (int g = 0; g < 4; ++g) acc[g] = accn[g];
     if (t > 0) {
       float4 ms[DP_KB];
       sum_parts(part_m, P, ms);
@@ -407,46 +401,36 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
       store_m(t, ms, live_prev);
     }
     mma_part(acc, mf, kh);
-    // this wave's two gate tiles to its partner (the other gate half of the same cell group), the partner's two from it
-#pragma unroll
-    for (int g = 0; g < 2; ++g) *reinterpret_cast<f32x4*>(&xch[cg][2 * gh + g][lane][0]) = acc[g];
     DPT(2);
-    __syncthreads();                                               // X(t)
-    f32x4 z[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) z[g] = (g >> 1) == gh ? acc[g & 1] : *reinterpret_cast<const f32x4*>(&xch[cg][g][lane][0]);
-    // the cell, in the accumulator layout: lane = row lr, this wave's cells ce, ce + 1 (elements 2 gh, 2 gh + 1 of the lane's four)
+    // the cell, in the accumulator layout: lane = row lr, cells cb .. cb+3
     const bool live = t < lenF;
-    const float pi_[2] = {pwi.x, pwi.y}, pf_[2] = {pwf.x, pwf.y}, po_[2] = {pwo.x, pwo.y};
-    float hv[2], sg[4][2];
+    const float pi_[4] = {pwi.x, pwi.y, pwi.z, pwi.w}, pf_[4] = {pwf.x, pwf.y, pwf.z, pwf.w}, po_[4] = {pwo.x, pwo.y, pwo.z, pwo.w};
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int i = 2 * gh + e;
-      const float cpv = cp[e];
-      const float gi = dp_sigmoid(z[0][i] + pi_[e] * cpv);
-      const float gf = dp_sigmoid(z[2][i] + a.forget_bias + pf_[e] * cpv);
-      const float gj = dp_tanh(z[1][i]);
+    for (int i = 0; i < 4; ++i) {
+      const float cpv = cp[i];
+      const float gi = dp_sigmoid(acc[0][i] + pi_[i] * cpv);
+      const float gf = dp_sigmoid(acc[2][i] + a.forget_bias + pf_[i] * cpv);
+      const float gj = dp_tanh(acc[1][i]);
       const float cn = gf * cpv + gi * gj;
-      const float go = dp_sigmoid(z[3][i] + po_[e] * cn);
+      const float go = dp_sigmoid(acc[3][i] + po_[i] * cn);
       const float hh = go * dp_tanh(cn);
-      hv[e] = live ? hh : 0.f;
-      sg[0][e] = live ? gi : 0.f; sg[1][e] = live ? gj : 0.f; sg[2][e] = live ? gf : 0.f; sg[3][e] = live ? go : 0.f;
-      cp[e] = live ? cn : cpv;
+      hv[i] = live ? hh : 0.f;
+      sg[0][i] = live ? gi : 0.f; sg[1][i] = live ? gj : 0.f; sg[2][i] = live ? gf : 0.f; sg[3][i] = live ? go : 0.f;
+      cp[i] = live ? cn : cpv;
     }
     {
-      const int so = lr * DP_HS + 16 * cg + 4 * q + 2 * gh;
+      const int so = lr * DP_HS + 16 * w + 4 * q;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) *reinterpret_cast<float2*>(&stage[g][so]) = make_float2(sg[g][0], sg[g][1]);
-      *reinterpret_cast<float2*>(&stage[4][so]) = make_float2(cp[0], cp[1]);
-      *reinterpret_cast<float2*>(&stage[5][so]) = make_float2(hv[0], hv[1]);
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(&stage[g][so]) = make_float4(sg[g][0], sg[g][1], sg[g][2], sg[g][3]);
+      *reinterpret_cast<float4*>(&stage[4][so]) = make_float4(cp[0], cp[1], cp[2], cp[3]);
+      *reinterpret_cast<float4*>(&stage[5][so]) = make_float4(hv[0], hv[1], hv[2], hv[3]);
     }
     DPT(3);
     __syncthreads();                                               // B(t): the h tile is in LDS
     DPT(4);
     DPT(7);
-    // run ahead while the gather waves poll: the x-part of step t+1
-    // (until the compute was split over eight waves an s_sleep(12) stood here, to keep the x-part's MFMA burst off the gather waves'
-    //  projection; with 24 MFMAs per wave it only costs: 336 -> 307 us per launch without it)
+    // run ahead while the gather waves poll: the x-part of step t+1 (after their projection and publish, see the backward kernel)
+    __builtin_amdgcn_s_sleep(12);
     if (t + 1 < T) next_x(t + 1);
     if (l == 0) load_x(min(t + 2, T - 1));                         // (consumed a step from now; not right behind barrier B: see the backward kernel)
     DPT(5);
@@ -465,7 +449,7 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
   }
 }
 
-__global__ __launch_bounds__(768, 1) void k_dlstm_fwd(const DPersistArgs a) {
+__global__ __launch_bounds__(512, 1) void k_dlstm_fwd(const DPersistArgs a) {
   gu32* ctl = (gu32*)a.ctl;
   // every wave reads the generation itself: it only changes when ALL workgroups have passed their epilogue
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -499,7 +483,7 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
   __shared__ __attribute__((aligned(16))) float part_m[DP_NQ][DP_KB][64][4];      // swept partials of dm_state (from step t+1)
   __shared__ __attribute__((aligned(16))) float part_x[2][DP_NQ][DP_KB][64][4];   // ... of dout (dx of the layer above), by parity of the step
   __shared__ __attribute__((aligned(16))) float stage[4][16 * DP_HS];             // dz of the step, staged for gather wave 3
-  __shared__ __attribute__((aligned(16))) float psum[8][DP_KB][64][4];            // the compute waves' partial dm_state tiles
+  __shared__ __attribute__((aligned(16))) float psum[4][DP_KB][64][4];            // the compute waves' partial dm_state tiles
   __shared__ __attribute__((aligned(16))) float psum_x[2][4][DP_KB][64][4];       // ... partial dx tiles, by parity of the step
   __shared__ __attribute__((aligned(16))) float kx_lds[4][DP_KB][4][64][4];       // K_x fragments (A operand of the dx product)
   __shared__ int dead;
@@ -515,10 +499,6 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
   const bool top = l == a.nl - 1;
   gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
   if (tid == 0) dead = 0;
-  // (twelve waves, as in the forward kernel: the two compute waves of a cell group each take two of a lane's four cells -- the cell
-  //  gradient and the k-steps of the state-gradient product those cells feed: eight partial tiles in psum; the input-gradient product
-  //  runs behind barrier B from the complete dz in `stage`, its three output tiles split 2 + 1 between the two waves.  LDS float adds
-  //  into shared tiles were tried first: 12 ds_add_f32 per lane took 7.9 k cycles, 1.79 ms per launch.)
   const size_t slot_stride_t = (size_t)DP_NQ * DP_SLOT;
   // edge 0: dm_state partials of this layer; edge 1: dx partials of this layer = dout of the layer below
   auto edge = [&](int layer, int e) -> gu64* {
@@ -526,10 +506,10 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
   };
   __syncthreads();
 
-  if (w >= 8) {
+  if (w >= 4) {
     // ---------------- gather waves ----------------
     __builtin_amdgcn_s_setprio(3);
-    const int j = w - 8;
+    const int j = w - 4;
     const gu64* gm = edge(l, 0) + (size_t)j * DP_SLOT;
     const gu64* gx = edge(min(l + 1, a.nl - 1), 1) + (size_t)j * DP_SLOT;
     gu64* gout_m = edge(l, 0) + (size_t)cq * DP_SLOT;
@@ -541,18 +521,13 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
         *reinterpret_cast<float4*>(&part[j][kb][lane][0]) = make_float4(v[kb * 4], v[kb * 4 + 1], v[kb * 4 + 2], v[kb * 4 + 3]);
     };
     auto fail = [&]() { if (lane == 0) { dead = 1; __hip_atomic_store(err, 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } };
-    // the sum of the compute waves' tiles j (NW of them, in wave order), published as this quarter's partial
-    auto publish = [&](float (*ps)[DP_KB][64][4], gu64* dst, auto nw) {
-      constexpr int NW = decltype(nw)::value;
-      float4 p = *reinterpret_cast<const float4*>(&ps[0][j][lane][0]);
-#pragma unroll
-      for (int c = 1; c < NW; ++c) {
-        const float4 v = *reinterpret_cast<const float4*>(&ps[c][j][lane][0]);
-        p = make_float4(p.x + v.x, p.y + v.y, p.z + v.z, p.w + v.w);
-      }
+    // the sum of the four compute waves' tile j, published as this quarter's partial
+    auto publish = [&](float (*ps)[DP_KB][64][4], gu64* dst) {
+      const float4 p0 = *reinterpret_cast<const float4*>(&ps[0][j][lane][0]), p1 = *reinterpret_cast<const float4*>(&ps[1][j][lane][0]);
+      const float4 p2 = *reinterpret_cast<const float4*>(&ps[2][j][lane][0]), p3 = *reinterpret_cast<const float4*>(&ps[3][j][lane][0]);
       gu64* go_ = dst + ((size_t)j * 64 + lane) * 4;
-      dp_store2(go_, gen, p.x, p.y);
-      dp_store2(go_ + 2, gen, p.z, p.w);
+      dp_store2(go_, gen, ((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y);
+      dp_store2(go_ + 2, gen, ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
     };
     if (!top) {                                                    // dout of step T-1 for the prologue
       if (!dp_sweep2(nullptr, gen, vm, gx + (size_t)(T - 1) * slot_stride_t, gen, vx, lane, err)) fail();
@@ -575,11 +550,11 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
       if (dead) return;
       // dx of step t+1 (in LDS since before A(t)) leaves while the compute waves work: its write-through stores are acknowledged
       // before the dm_state publish below (two publishes back to back cost the second one, and the poll behind it, ~0.75 us)
-      if (j < 3 && l > 0 && t < T - 1) publish(psum_x[(t + 1) & 1], gout_x + (size_t)(t + 1) * slot_stride_t, std::integral_constant<int, 4>{});
+      if (j < 3 && l > 0 && t < T - 1) publish(psum_x[(t + 1) & 1], gout_x + (size_t)(t + 1) * slot_stride_t);
       __syncthreads();                                             // B(t): psum(t) and the dz stage are in LDS
       DPG(2);
       if (j < 3) {
-        publish(psum, gout_m + (size_t)t * slot_stride_t, std::integral_constant<int, 8>{});
+        publish(psum, gout_m + (size_t)t * slot_stride_t);
       } else {
         // gather wave 3 writes the step's dz over the gate activations: whole 256-byte rows from the LDS stage
         const int c4 = (lane & 15) * 4, rr = lane >> 4;
@@ -596,19 +571,17 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
     }
     if (l > 0) {                                                   // dx of step 0, computed after barrier B(0)
       __syncthreads();                                             // C
-      if (j < 3) publish(psum_x[0], gout_x, std::integral_constant<int, 4>{});
+      if (j < 3) publish(psum_x[0], gout_x);
     }
     return;
   }
 
   // ---------------- compute waves ----------------
-  const int cg = w & 3, hh = w >> 2;                                // cell group; this wave's cells of a lane's four: 2 hh, 2 hh + 1
-  const int cb = cq * 64 + 16 * cg + 4 * q, ce = cb + 2 * hh;       // this lane's four cells; the two this wave differentiates
-  // A operands, resident.  dh: W_p[cell 16 cg + lr][p = 16kb + 4q + u]; dm_state: K[I + p][g*H + cells ce, ce + 1], p = 16pt + lr
-  float4 wpA[DP_KB];
-  float2 khA[DP_KB][4];
+  const int cb = cq * 64 + 16 * w + 4 * q;                          // this lane's four cells
+  // A operands, resident.  dh: W_p[cell 16w + lr][p = 16kb + 4q + u]; dm_state: K[I + p][g*H + cells cb .. cb+3], p = 16pt + lr
+  float4 wpA[DP_KB], khA[DP_KB][4];
   {
-    const float* wrow = L.Wp + (size_t)(cq * 64 + 16 * cg + lr) * ldP;
+    const float* wrow = L.Wp + (size_t)(cq * 64 + 16 * w + lr) * ldP;
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb) {
       const int k = 16 * kb + 4 * q;
@@ -622,30 +595,29 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
       for (int g = 0; g < 4; ++g) {
         const float4 vh = *reinterpret_cast<const float4*>(L.K + (size_t)(I + min(p, P - 1)) * H4 + g * H + cb);
         const float4 vx = *reinterpret_cast<const float4*>(L.K + (size_t)min(p, I - 1) * H4 + g * H + cb);
-        const float4 sh = dp_sel(p < P, vh, make_float4(0.f, 0.f, 0.f, 0.f));
-        khA[pt][g] = hh ? make_float2(sh.z, sh.w) : make_float2(sh.x, sh.y);
-        if (hh == 0) *reinterpret_cast<float4*>(&kx_lds[cg][pt][g][lane][0]) = dp_sel(l > 0 && p < I, vx, make_float4(0.f, 0.f, 0.f, 0.f));
+        khA[pt][g] = dp_sel(p < P, vh, make_float4(0.f, 0.f, 0.f, 0.f));
+        *reinterpret_cast<float4*>(&kx_lds[w][pt][g][lane][0]) = dp_sel(l > 0 && p < I, vx, make_float4(0.f, 0.f, 0.f, 0.f));
       }
     }
   }
-  const float2 pwi = *reinterpret_cast<const float2*>(L.wi + ce), pwf = *reinterpret_cast<const float2*>(L.wf + ce);
-  const float2 pwo = *reinterpret_cast<const float2*>(L.wo + ce);
-  const float pi_[2] = {pwi.x, pwi.y}, pf_[2] = {pwf.x, pwf.y}, po_[2] = {pwo.x, pwo.y};
+  const float4 pwi = *reinterpret_cast<const float4*>(L.wi + cb), pwf = *reinterpret_cast<const float4*>(L.wf + cb);
+  const float4 pwo = *reinterpret_cast<const float4*>(L.wo + cb);
+  const float pi_[4] = {pwi.x, pwi.y, pwi.z, pwi.w}, pf_[4] = {pwf.x, pwf.y, pwf.z, pwf.w}, po_[4] = {pwo.x, pwo.y, pwo.z, pwo.w};
   const int lenF = a.len[r0 + lr];
 
-  float dc[2] = {0.f, 0.f};
+  float dc[4] = {0.f, 0.f, 0.f, 0.f};
   float4 mf[DP_KB];                                                 // dm_state of this lane's row: [k = 16kb + 4q + u]
 #pragma unroll
   for (int kb = 0; kb < DP_KB; ++kb) mf[kb] = make_float4(0.f, 0.f, 0.f, 0.f);
   // operands of a step, requested one step ahead: the gate activations, c_{t-1} (c_t is last step's c_{t-1}) and the top layer's dout
-  float2 gn[4], cpn;
+  f32x4 gn[4], cpn;
   float4 don[DP_KB];
-  float2 ccur;
+  f32x4 ccur;
   auto prefetch = [&](int t) {
     const size_t row = (size_t)t * N + r0 + lr;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) gn[g] = *reinterpret_cast<const float2*>(L.gates + row * H4 + g * H + ce);
-    cpn = *reinterpret_cast<const float2*>(L.c + row * H + ce);
+    for (int g = 0; g < 4; ++g) gn[g] = *reinterpret_cast<const f32x4*>(L.gates + row * H4 + g * H + cb);
+    cpn = *reinterpret_cast<const f32x4*>(L.c + row * H + cb);
     if (top) {
 #pragma unroll
       for (int kb = 0; kb < DP_KB; ++kb)
@@ -662,7 +634,7 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
                                  ((p0.w + p1.w) + p2.w) + p3.w), make_float4(0.f, 0.f, 0.f, 0.f));
     }
   };
-  ccur = *reinterpret_cast<const float2*>(L.c + ((size_t)T * N + r0 + lr) * H + ce);      // c_T
+  ccur = *reinterpret_cast<const f32x4*>(L.c + ((size_t)T * N + r0 + lr) * H + cb);      // c_T
   prefetch(T - 1);
   __syncthreads();                                                 // P
   if (dead) return;
@@ -674,10 +646,10 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
     DPT(1);
     const bool live = t < lenF;
     // this step's operands out of the prefetch registers, the next step's requested
-    float2 gt[4];
+    f32x4 gt[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) gt[g] = gn[g];
-    const float2 cprev = cpn;
+    const f32x4 cprev = cpn;
     float4 dout[DP_KB];
     if (top) {
 #pragma unroll
@@ -705,7 +677,7 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
       for (int kb = 0; kb < DP_KB; ++kb)
         if (16 * kb + 4 * q < P) *reinterpret_cast<float4*>(L.dmt + ((size_t)t * N + r0 + lr) * ldP + 16 * kb + 4 * q) = dm[kb];
     }
-    // dh^T[cell][row] = W_p[cell][:] . dm^T  (all four cells of the lane: both waves of the group run these 12 MFMAs)
+    // dh^T[cell][row] = W_p[cell][:] . dm^T
     f32x4 dh = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb) {
@@ -715,31 +687,28 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
       dh = __builtin_amdgcn_mfma_f32_16x16x4f32(wpA[kb].w, dm[kb].w, dh, 0, 0, 0);
     }
     DPT(2);
-    // gate / cell gradients (kernels.hip k_bwd_a2): lane = row lr, cells ce + e
-    const float dh2[2] = {hh ? dh[2] : dh[0], hh ? dh[3] : dh[1]};
-    const float gt_[4][2] = {{gt[0].x, gt[0].y}, {gt[1].x, gt[1].y}, {gt[2].x, gt[2].y}, {gt[3].x, gt[3].y}};
-    const float cc_[2] = {ccur.x, ccur.y}, cp_[2] = {cprev.x, cprev.y};
-    float dz[4][2];
+    // gate / cell gradients (kernels.hip k_bwd_a2): lane = row lr, cells cb + i
+    float dz[4][4];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const float gi = gt_[0][e], gj = gt_[1][e], gf = gt_[2][e], go = gt_[3][e];
-      const float tc = dp_tanh(cc_[e]);
-      const float dao = dh2[e] * tc * go * (1.f - go);
-      const float dcn = dc[e] + dh2[e] * go * (1.f - tc * tc) + dao * po_[e];
-      const float daf = dcn * cp_[e] * gf * (1.f - gf);
+    for (int i = 0; i < 4; ++i) {
+      const float gi = gt[0][i], gj = gt[1][i], gf = gt[2][i], go = gt[3][i];
+      const float tc = dp_tanh(ccur[i]);
+      const float dao = dh[i] * tc * go * (1.f - go);
+      const float dcn = dc[i] + dh[i] * go * (1.f - tc * tc) + dao * po_[i];
+      const float daf = dcn * cprev[i] * gf * (1.f - gf);
       const float dai = dcn * gj * gi * (1.f - gi);
       const float dj = dcn * gi * (1.f - gj * gj);
-      dz[0][e] = live ? dai : 0.f; dz[1][e] = live ? dj : 0.f; dz[2][e] = live ? daf : 0.f; dz[3][e] = live ? dao : 0.f;
-      dc[e] = live ? dcn * gf + dai * pi_[e] + daf * pf_[e] : dc[e];
+      dz[0][i] = live ? dai : 0.f; dz[1][i] = live ? dj : 0.f; dz[2][i] = live ? daf : 0.f; dz[3][i] = live ? dao : 0.f;
+      dc[i] = live ? dcn * gf + dai * pi_[i] + daf * pf_[i] : dc[i];
     }
     ccur = cprev;
     {
-      const int so = lr * DP_HS + 16 * cg + 4 * q + 2 * hh;
+      const int so = lr * DP_HS + 16 * w + 4 * q;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) *reinterpret_cast<float2*>(&stage[g][so]) = make_float2(dz[g][0], dz[g][1]);
+      for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(&stage[g][so]) = make_float4(dz[g][0], dz[g][1], dz[g][2], dz[g][3]);
     }
     DPT(3);
-    // partial dm_state^T over this wave's 32 gate columns (2 cells x 4 gates): the lane's dz[g][e] is the B fragment of a k-step
+    // partial dm_state^T over this wave's 64 gate columns: the lane's dz[g][0..3] is the B fragment of k-block (gate g)
     f32x4 pa[DP_KB];
 #pragma unroll
     for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -749,6 +718,10 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
       for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(khA[pt][g].x, dz[g][0], pa[pt], 0, 0, 0);
 #pragma unroll
       for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(khA[pt][g].y, dz[g][1], pa[pt], 0, 0, 0);
+#pragma unroll
+      for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(khA[pt][g].z, dz[g][2], pa[pt], 0, 0, 0);
+#pragma unroll
+      for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(khA[pt][g].w, dz[g][3], pa[pt], 0, 0, 0);
     }
 #pragma unroll
     for (int pt = 0; pt < DP_KB; ++pt) *reinterpret_cast<f32x4*>(&psum[w][pt][lane][0]) = pa[pt];
@@ -756,26 +729,27 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
     __syncthreads();                                               // B(t)
     DPT(5);
     if (l > 0) {                                                   // dx partial^T of this step: published by the gather waves after B(t-1)
-      // from the COMPLETE dz of the cell group (both waves' cells: in `stage` since barrier B; this wave overwrites it only behind
-      // A(t-1)); output tiles pt = 0, 1 on the first wave of the group, pt = 2 on the second: whole tiles, no partial sums
-      float4 dzs[4];
+      // (first let the gather waves publish: this burst of LDS reads and MFMAs right behind the barrier held their ~350-cycle
+      // publish back by 1500 cycles on the shared SIMDs, s_setprio notwithstanding -- profiles/r3_dpersist_trace.txt)
+      __builtin_amdgcn_s_sleep(8);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) dzs[g] = *reinterpret_cast<const float4*>(&stage[g][lr * DP_HS + 16 * cg + 4 * q]);
+      for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int pp = 0; pp < 2; ++pp) {
-        const int pt = hh ? 2 : pp;
-        if (hh && pp) break;
-        f32x4 px = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < 4; ++g) {
+        float4 af[DP_KB];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 af = *reinterpret_cast<const float4*>(&kx_lds[cg][pt][g][lane][0]);
-          px = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, dzs[g].x, px, 0, 0, 0);
-          px = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, dzs[g].y, px, 0, 0, 0);
-          px = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, dzs[g].z, px, 0, 0, 0);
-          px = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, dzs[g].w, px, 0, 0, 0);
-        }
-        *reinterpret_cast<f32x4*>(&psum_x[t & 1][cg][pt][lane][0]) = px;
+        for (int pt = 0; pt < DP_KB; ++pt) af[pt] = *reinterpret_cast<const float4*>(&kx_lds[w][pt][g][lane][0]);
+#pragma unroll
+        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt].x, dz[g][0], pa[pt], 0, 0, 0);
+#pragma unroll
+        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt].y, dz[g][1], pa[pt], 0, 0, 0);
+#pragma unroll
+        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt].z, dz[g][2], pa[pt], 0, 0, 0);
+#pragma unroll
+        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt].w, dz[g][3], pa[pt], 0, 0, 0);
       }
+#pragma unroll
+      for (int pt = 0; pt < DP_KB; ++pt) *reinterpret_cast<f32x4*>(&psum_x[t & 1][w][pt][lane][0]) = pa[pt];
     }
     DPT(6);
   }
@@ -783,7 +757,7 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
   if (l > 0) __syncthreads();                                      // C: dx of step 0 is in LDS
 }
 
-__global__ __launch_bounds__(768, 1) void k_dlstm_bwd(const DPersistArgs a) {
+__global__ __launch_bounds__(512, 1) void k_dlstm_bwd(const DPersistArgs a) {
   gu32* ctl = (gu32*)a.ctl;
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   dp_bwd_body(a, gen);
@@ -817,13 +791,13 @@ bool dpersist_supported(const DPersistArgs& a) {
 // a.gran: zeroed ONCE at allocation (tag 0 is never a generation); a.ctl: {1, 0, 0, 0} at allocation
 void launch_dlstm_bwd(const DPersistArgs& a, hipStream_t s) {
   const int blocks = a.nl * (a.N / 16) * DP_NQ;
-  hipLaunchKernelGGL(k_dlstm_bwd, dim3(blocks), dim3(768), 0, s, a);
+  hipLaunchKernelGGL(k_dlstm_bwd, dim3(blocks), dim3(512), 0, s, a);
   ++g_chain_launches;
 }
 
 void launch_dlstm_fwd(const DPersistArgs& a, hipStream_t s) {
   const int blocks = a.nl * (a.N / 16) * DP_NQ;
-  hipLaunchKernelGGL(k_dlstm_fwd, dim3(blocks), dim3(768), 0, s, a);
+  hipLaunchKernelGGL(k_dlstm_fwd, dim3(blocks), dim3(512), 0, s, a);
   ++g_chain_launches;
 }
 
