@@ -1391,7 +1391,8 @@ bool Model::d_head(int N, int T, int n_real, const float* t_real, const float* t
                    hipStream_t s) {
   static const bool on = [] { const char* e = getenv("RSRGAN_DHEAD"); return !e || atoi(e) != 0; }();
   const int ldPd = pad4(dR), nb = (T * N + 63) / 64;
-  if (!on || d_dnn() || dl.empty() || dR % 4 != 0 || dR > DH_MAXR || (size_t)nb * (DH_MAXR + 3) > scratch_floats) return false;
+  if (!on || d_dnn() || dl.empty() || dR % 4 != 0 || dR + 3 > 64 ||       // (k_dhead2 sums 64 quantities: 3 + dR)
+      (size_t)nb * (DH_MAXR + 3) > scratch_floats) return false;
   DHeadArgs a{};
   a.top = d_st[dl.size() - 1].out; a.ldt = ldPd; a.w = D.W(d_fc_w); a.ldw = 4; a.b = D.W(d_fc_b);
   a.logits = logits; a.ldl = 4; a.dlogits = dlogits; a.dout = d_dB; a.ldo = ldPd; a.gw = D.Gd(d_fc_w); a.gb = D.Gd(d_fc_b);
