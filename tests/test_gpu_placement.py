@@ -139,6 +139,23 @@ def test_persistent_generator_recurrence_agrees(B, T, mode):
     assert a["vars_sha"] == c["vars_sha"]          # fixed summation order: reproducible bits
 
 
+@pytest.mark.parametrize("switch", ["RSRGAN_WGRAD_BATCH", "RSRGAN_DHEAD", "RSRGAN_FC_SIDE", "RSRGAN_WGRAD_STREAMS", "RSRGAN_LAZY_SWIZZLE",
+                                    "RSRGAN_FUSED_SEG"])
+def test_round4_launch_fusions_agree(switch):
+    """Round 4 replaced launch sequences around the persistent recurrences by fewer launches: the weight gradients of same-shaped layers
+    as one launch per kind (k_gemm16_b, k_lstm_colsums*_b), discriminator_lstm's head as one pass (k_dhead1/2), the FCs' parameter
+    gradients and the layers' dWp / column sums on a side stream beside the dK GEMMs, weight copies rebuilt where they are read, the
+    G-run as one graph segment.  Each has a switch that restores the launch sequence it replaced: same arithmetic, other summation
+    orders at most -- three updates of each net must agree to fp32 rounding."""
+    size = {"RSRGAN_TEST_B": "32", "RSRGAN_TEST_T": "9"}
+    a = _run(dict(size))
+    b = _run(dict(size, **{switch: "1" if switch == "RSRGAN_WGRAD_STREAMS" else "0"}))
+    assert a["device_status"] == 0 and b["device_status"] == 0
+    for k in ("d0", "g0", "d1", "g1"):
+        assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-7), (k, a[k], b[k])
+    assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
+
+
 def test_persistent_launches_survive_a_busy_side_stream():
     """The persistent recurrences (csrc/gpersist.hip, dpersist.hip) wait for each other inside a launch, so every workgroup must become
     resident -- without a cooperative launch.  With foreign kernels on another stream holding CUs (a spin kernel, streaming adds:
