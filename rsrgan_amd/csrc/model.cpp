@@ -46,7 +46,7 @@ int ParamSet::add(const std::string& name, int rows, int cols, bool is_vector) {
 
 // ------------------------------------------------------------------------------------------ hipGraph segments
 static inline uint64_t seg_key(int seg, int T, unsigned bits) { return ((uint64_t)seg << 48) | ((uint64_t)(unsigned)T << 16) | (bits & 0xffffu); }
-enum { SEG_D = 1, SEG_G_MAIN = 2, SEG_G_FCIN = 3, SEG_G_LAYER0 = 4 /* .. + MAXJ */, SEG_G_L2 = 20, SEG_G_TAIL = 21, SEG_APPLY_D = 22, SEG_APPLY_G = 23 };
+enum { SEG_D = 1, SEG_G_MAIN = 2, SEG_G_FCIN = 3, SEG_G_LAYER0 = 4 /* .. + MAXJ */, SEG_G_L2 = 20, SEG_G_TAIL = 21, SEG_APPLY_D = 22, SEG_APPLY_G = 23, SEG_G_BATCH = 24 };
 
 template <class F>
 void Model::run_seg(uint64_t key, hipStream_t s, F&& body) {
@@ -1080,7 +1080,7 @@ void Model::layer_wgrads_gemms(const LayerRun& R, int t0, int t1, bool accumulat
 // their kernel gradients [x | m]^T dZ run as one launch per kind for all layers (blockIdx.z = layer) instead of one per layer: these
 // launches are latency-bound (the discriminator's six per layer left the chip idle for 0.26 ms per D-run).  Returns whether dWp and
 // the column sums are done (*dK_done: the kernel gradients as well); the caller runs per layer what is not.
-bool Model::batch_wgrads(Chain& ch, int T, hipStream_t s, bool dK_too, bool* dK_done) {
+bool Model::batch_wgrads(Chain& ch, int T, hipStream_t s, bool dK_too, bool* dK_done, bool check_only) {
   static const bool on = [] { const char* e = getenv("RSRGAN_WGRAD_BATCH"); return !e || atoi(e) != 0; }();
   *dK_done = false;
   std::vector<const LayerRun*> rs;
@@ -1099,6 +1099,7 @@ bool Model::batch_wgrads(Chain& ch, int T, hipStream_t s, bool dK_too, bool* dK_
   float* scr = (side && s == side) ? scratch2 : scratch;
   // (the rule of launch_gemm_mapped: only products with little work per tile run on k_gemm16)
   auto small = [&](int M, int N, int K) { const double outs = (double)M * N; return !(K >= 256 && outs >= 4.0e6) && !(K >= 2048 && outs >= 1.5e6); };
+  if (check_only) { *dK_done = dK_too && small(L0.I + L0.P, H4, Rws); return small(H, L0.P, Rws); }      // (host-only: what a call would do)
   if (dK_too && small(L0.I + L0.P, H4, Rws)) {
     Gemm16Batch bt{}; bt.n = (int)rs.size();
     for (int p = 0; p < bt.n; ++p) { bt.A[p] = rs[p]->in; bt.A2[p] = rs[p]->S->mst; bt.B[p] = rs[p]->S->gates; bt.C[p] = rs[p]->ps->Gd(rs[p]->L->tK); }
@@ -1735,9 +1736,14 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
       if (bucketed) mark_bucket(RSRGAN_NET_G, bi++, s);
     }
     if (bucketed) {        // LSTM weight gradients layer by layer: each completes one bucket (all-reduced while the next runs)
+      // (same-shaped layers: every layer's dWp and column sums first, as one launch per kind -- decided on the host, a replayed
+      //  segment does not run its body -- then a layer's bucket is complete behind its dK GEMM)
+      bool dkd = false;
+      const bool gb = batch_wgrads(bw_chains[1], T, s, false, &dkd, true);
+      if (gb) run_seg(seg_key(SEG_G_BATCH, T, kbits), s, [&]() { bool d_ = false; (void)batch_wgrads(bw_chains[1], T, s, false, &d_); });
       int li = 0;
       for (auto& Rr : bw_chains[1]) {
-        run_seg(seg_key(SEG_G_LAYER0 + li, T, kbits), s, [&]() { layer_wgrads(Rr, T, s); });
+        run_seg(seg_key(SEG_G_LAYER0 + li, T, kbits), s, [&]() { if (gb) layer_wgrads_gemms(Rr, 0, T, false, s, true, false); else layer_wgrads(Rr, T, s); });
         mark_bucket(RSRGAN_NET_G, bi++, s);
         ++li;
       }
