@@ -215,14 +215,18 @@ int rsrgan_grad_bucket_wait(rsrgan_handle h, int32_t net, int32_t i, void* strea
 int rsrgan_profile_begin(rsrgan_handle h);
 int rsrgan_profile_read(rsrgan_handle h, int32_t* launches, double* total_us, double* alg_flops);
 /* the same window for another kernel class: kind 0 = k_fwd_gates (as above), kind 1 = k_glstm_fwd, the persistent launch that runs the
- * generator's whole forward recurrence (csrc/gpersist.hip; algorithmic FLOP = every layer's recurrent product and projection + the
- * input product above layer 0), kind 2 = k_glstm_bwd, its BPTT (state-gradient product, dh = dm . W_p^T, the input-gradient product
+ * generator's whole forward recurrence (csrc/gpersist.hip; algorithmic FLOP = every layer's input product -- layer 0's included: it runs
+ * inside the launch since round 4 --, recurrent product and projection, over the CALLER's rows: padding rows of a row-padded model do
+ * not count), kind 2 = k_glstm_bwd, its BPTT (state-gradient product, dh = dm . W_p^T, the input-gradient product
  * above layer 0).  Call before rsrgan_profile_read (which closes the window). */
 int rsrgan_profile_read_kind(rsrgan_handle h, int32_t kind, int32_t* launches, double* total_us, double* alg_flops);
 
-/* Health of the persistent recurrence kernels (csrc/dpersist.hip): synchronises the handle's stream, returns in *code 0 or
- * 1 + the first workgroup whose bounded wait for another workgroup's partials expired, and clears the (sticky) device word.
- * A failed launch has already poisoned its step's losses with NaN; nothing in the reference corresponds to this. */
+/* Health of the persistent recurrence kernels (csrc/dpersist.hip, csrc/gpersist.hip): synchronises the handle's stream and returns in
+ * *code 0, or 1 + the first workgroup whose bounded wait for another workgroup's partials expired -- of a discriminator launch as is,
+ * of a generator launch (k_glstm_fwd / k_glstm_bwd) with 0x10000 added -- and clears the (sticky) device word.  A failed launch has
+ * already poisoned its step's losses with NaN.  A failure means the launch's workgroups were not all resident at once (CUs taken
+ * away after rsrgan_create, which asks the device how many it can hold: csrc/gpersist.hip resident_probe): the handle re-arms its
+ * hand-off rings and takes the launch-per-phase path for that recurrence from then on.  Nothing in the reference corresponds to this. */
 int rsrgan_device_status(rsrgan_handle h, int32_t* code);
 
 /* tf.nn.dropout(h, keep_prob) after every hidden ReLU of the frame-level nets (models/dnn.py:86,99,116-121 and

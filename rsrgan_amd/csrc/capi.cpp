@@ -211,7 +211,7 @@ int rsrgan_forward_g(rsrgan_handle h, const float* x, const int32_t* lengths, in
     m.bn_eval_call = false;     // the graph of THIS model: is_training unless it was built with cross_validation
     m.g_forward(T, s);
     m.g_fwd_valid = false;      // labels were not packed: the stash is not a valid training forward
-    launch_unpack_bm(m.y_tm, m.ldDout, y, m.B, T, m.Dout, s);
+    launch_unpack_bm(m.y_tm, m.ldDout, y, m.B, T, m.Dout, s, m.Bt);      // (the caller's Bt rows of a padded model)
     if (hipGetLastError() != hipSuccess) { set_error("kernel launch failed in forward_g"); return RSRGAN_ERR_HIP; }
     return RSRGAN_OK;
   });
@@ -336,6 +336,7 @@ int rsrgan_device_status(rsrgan_handle h, int32_t* code) {
       const unsigned z[2] = {0u, 0u};
       if (hipMemcpy(blocks[k] + DP_CTL_DONE, z, sizeof(z), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed"); return RSRGAN_ERR_HIP; }
       if (k == 1) m.gpersist_rearm();                               // (an aborted generator launch leaves ring slots written: arm them again)
+      if (ctl[DP_CTL_ERR] != 0) m.persist_disable(k);                // (its workgroups were not all resident: this handle stops trying)
     }
   }
   return RSRGAN_OK;

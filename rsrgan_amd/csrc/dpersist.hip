@@ -775,10 +775,18 @@ __global__ __launch_bounds__(512, 1) void k_dlstm_bwd(const DPersistArgs a) {
 // (the backward launch uses two edges per layer: dm_state partials and the dx partials for the layer below)
 size_t dpersist_granule_bytes(int nl, int N, int T) { return (size_t)2 * nl * (N / 16) * T * DP_NQ * DP_SLOT * sizeof(unsigned long long); }
 
+int dpersist_grid(int nl, int N) { return nl * (N / 16) * DP_NQ; }
+size_t dpersist_lds_bytes() {
+  hipFuncAttributes f{}, b{};
+  if (hipFuncGetAttributes(&f, (const void*)k_dlstm_fwd) != hipSuccess || hipFuncGetAttributes(&b, (const void*)k_dlstm_bwd) != hipSuccess) return 0;
+  return f.sharedSizeBytes > b.sharedSizeBytes ? f.sharedSizeBytes : b.sharedSizeBytes;
+}
+
 bool dpersist_supported(const DPersistArgs& a) {
   if (a.nl < 1 || a.nl > DP_MAXL || a.N % 16 != 0 || a.H != 64 * DP_NQ || a.T < 1) return false;
-  // every workgroup must be resident at once (they wait for each other): at most half of the 256 CUs, one workgroup per CU
-  if (a.nl * (a.N / 16) * DP_NQ > 128) return false;
+  // every workgroup must be resident at once (they wait for each other), one workgroup per CU: at most 128, and no more than the
+  // device has (the static half; Model::init asks the device itself, resident_probe)
+  if (dpersist_grid(a.nl, a.N) > 128 || dpersist_grid(a.nl, a.N) > device_cu_count()) return false;
   for (int l = 0; l < a.nl; ++l) {
     const DPersistLayer& L = a.L[l];
     if (L.P > 16 * DP_KB || L.P % 4 != 0 || L.ldP % 4 != 0 || L.P < 4) return false;
@@ -790,13 +798,13 @@ bool dpersist_supported(const DPersistArgs& a) {
 
 // a.gran: zeroed ONCE at allocation (tag 0 is never a generation); a.ctl: {1, 0, 0, 0} at allocation
 void launch_dlstm_bwd(const DPersistArgs& a, hipStream_t s) {
-  const int blocks = a.nl * (a.N / 16) * DP_NQ;
+  const int blocks = dpersist_grid(a.nl, a.N);
   hipLaunchKernelGGL(k_dlstm_bwd, dim3(blocks), dim3(512), 0, s, a);
   ++g_chain_launches;
 }
 
 void launch_dlstm_fwd(const DPersistArgs& a, hipStream_t s) {
-  const int blocks = a.nl * (a.N / 16) * DP_NQ;
+  const int blocks = dpersist_grid(a.nl, a.N);
   hipLaunchKernelGGL(k_dlstm_fwd, dim3(blocks), dim3(512), 0, s, a);
   ++g_chain_launches;
 }

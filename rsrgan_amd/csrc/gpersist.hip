@@ -1136,9 +1136,60 @@ static int gp_grid(const GPersistArgs& a) {
   const int ngr = a.N / GP_ROWS, xpg = 8 / ngr, nwg = a.nl * a.NC;
   return 8 * ((nwg + xpg - 1) / xpg);
 }
+int gpersist_grid(const GPersistArgs& a) { return gp_grid(a); }
+size_t gpersist_lds_bytes() { return sizeof(GpLdsB<5>) > sizeof(GpLds<5>) ? sizeof(GpLdsB<5>) : sizeof(GpLds<5>); }
+
+// ---- how many workgroups of a persistent launch can be resident at once ----
+// The persistent recurrences (this file, dpersist.hip) wait for each other inside the launch: every workgroup must be on a CU at the
+// same time.  Nothing static tells that: multiProcessorCount is the whole device, a CU mask (HSA_CU_MASK / ROC_GLOBAL_CU_MASK), a
+// compute partition or a neighbour process take CUs away silently -- and a launch that does not fit spins into its time-out on every
+// step.  So the library ASKS, once per shape at rsrgan_create: `grid` workgroups of the same block size and LDS footprint (one per CU)
+// count themselves in and wait until all have arrived or 5 ms have passed.
+__global__ void k_resident_probe(unsigned* ctl, unsigned want) {
+  extern __shared__ unsigned gp_probe_lds[];
+  if (threadIdx.x == 0) {
+    gp_probe_lds[0] = 1u;                                              // (the dynamic allocation is what keeps a second workgroup off this CU)
+    __hip_atomic_fetch_add(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 500000ull) {         // 5 ms at 100 MHz
+        __hip_atomic_store(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+}
+int device_cu_count() {
+  static const int n = [] {
+    int dev = 0; hipDeviceProp_t p{};
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    return p.multiProcessorCount;
+  }();
+  return n;
+}
+bool resident_probe(int grid, int threads, size_t lds_bytes) {
+  static const bool off = [] { const char* e = getenv("RSRGAN_RESIDENT_PROBE"); return e && atoi(e) == 0; }();
+  if (grid < 1) return false;
+  if (grid > device_cu_count()) return false;                          // (one workgroup per CU at these footprints)
+  if (off) return true;
+  if (lds_bytes < (size_t)82 * 1024) lds_bytes = (size_t)82 * 1024;    // (more than half a CU's LDS: one probe workgroup per CU, whatever the real kernel's registers allow)
+  unsigned* ctl = nullptr;
+  if (hipMalloc(&ctl, 2 * sizeof(unsigned)) != hipSuccess) return false;
+  bool ok = hipMemset(ctl, 0, 2 * sizeof(unsigned)) == hipSuccess &&
+            hipFuncSetAttribute((const void*)k_resident_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(k_resident_probe, dim3(grid), dim3(threads), lds_bytes, 0, ctl, (unsigned)grid);
+    unsigned h[2] = {0u, 1u};
+    ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(h, ctl, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[1] == 0u && h[0] == (unsigned)grid;
+  }
+  (void)hipGetLastError();
+  (void)hipFree(ctl);
+  return ok;
+}
 
 bool gpersist_plan(GPersistArgs& a) {
-  if (a.nl < 1 || a.nl > GP_MAXL || a.T < 1 || a.T > 2046 || a.H % 4 != 0) return false;
+  if (a.nl < 1 || a.nl > GP_MAXL || a.T < 1 || a.T > GP_TMAX || a.H % 4 != 0) return false;
   const int ngr = a.N / GP_ROWS;
   if (a.N % GP_ROWS != 0 || (ngr != 1 && ngr != 2 && ngr != 4 && ngr != 8)) return false;
   a.NT = 5;
@@ -1151,8 +1202,9 @@ bool gpersist_plan(GPersistArgs& a) {
     if (((L.P + 15) / 16) * 2 > a.NC) return false;                // every 8-column half of a chunk needs its reducer
     if (a.NC > 40) return false;                                    // a G wave sums at most 10 producers
   }
-  // every workgroup must be resident at once (they wait for each other): one 12-wave workgroup per CU
-  return gp_grid(a) <= 256;
+  // every workgroup must be resident at once (they wait for each other): one 12-wave workgroup per CU.  (The static half of the
+  // answer; Model::init asks the device itself, resident_probe, before it allocates the hand-off rings.)
+  return gp_grid(a) <= device_cu_count();
 }
 size_t gpersist_gran1_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * GP_R1 * GP_NCH * a.NC * GP_SLOT; }
 size_t gpersist_gran2_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * a.T * GP_NCH * GP_SLOT; }

@@ -161,11 +161,14 @@ struct DPersistArgs {
 };
 size_t dpersist_granule_bytes(int nl, int N, int T);
 bool dpersist_supported(const DPersistArgs& a);
+int dpersist_grid(int nl, int N);                 // workgroups of a launch over N rows
+size_t dpersist_lds_bytes();
 void launch_dlstm_fwd(const DPersistArgs& a, hipStream_t s);
 void launch_dlstm_bwd(const DPersistArgs& a, hipStream_t s);      // gates: activations in, dz out; needs c, dmt, dout_top
 // ---- persistent generator recurrence (gpersist.hip): the forward pass of a stack of large projected LSTM cells ----
 constexpr int GP_MAXL = 4;
 constexpr int GP_ROWS = 32;                       // batch rows per row group (two 16-row MFMA tiles)
+constexpr int GP_THREADS = 768;                   // 12 waves per workgroup
 struct GPersistLayer {
   const float *KxT, *KhT;                         // k-contiguous transposed copies of the kernel: [4H][ldI], [4H][ldP] (zero padding)
   const float *bias, *wi, *wf, *wo, *Wp;          // bias [4H], peepholes [H], projection [H][ldP]
@@ -188,7 +191,14 @@ struct GPersistArgs {
   float* din0;                                    // backward: [T][N][ld_din0] gradient of the stack's input (null: not wanted)
   int ld_din0;
 };
+constexpr int GP_TMAX = 2046;                     // longest launch (slot offsets are 32-bit; a longer batch takes the launch-per-phase path)
 bool gpersist_plan(GPersistArgs& a);              // fills NT / NC; false: shape not supported
+int gpersist_grid(const GPersistArgs& a);         // workgroups of a launch (all must be resident at once)
+size_t gpersist_lds_bytes();                      // LDS of a workgroup (the larger of the two kernels')
+int device_cu_count();                            // hipDeviceProp_t::multiProcessorCount of the current device (queried once)
+// true when `grid` workgroups of `threads` threads and `lds_bytes` of LDS are on the device AT THE SAME TIME (asked of the device itself:
+// a probe launch; RSRGAN_RESIDENT_PROBE=0 trusts multiProcessorCount alone)
+bool resident_probe(int grid, int threads, size_t lds_bytes);
 size_t gpersist_gran1_bytes(const GPersistArgs& a);
 size_t gpersist_gran2_bytes(const GPersistArgs& a);
 size_t gpersist_gran3_bytes(const GPersistArgs& a);
@@ -225,10 +235,10 @@ void launch_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bo
 // ---------------------------------------------------------------- layout / pointwise
 struct StagePack { const float* src; float* dst; int D, ld; };              // [B][T][D] -> [T][B][ld]
 struct StageCopy { const void* src; void* dst; int n; };                     // n 32-bit words
-struct StageJobs { StagePack pack[2]; StageCopy copy[4]; int B, T; };
+struct StageJobs { StagePack pack[2]; StageCopy copy[4]; int B, T; int Bt; };      // Bt > 0: the caller has Bt <= B rows (destination stride B)
 void launch_stage_inputs(const StageJobs& j, hipStream_t s);
 void launch_pack_tm(const float* src_bm, float* dst_tm, int B, int T, int D, int ld, hipStream_t s);      // [B,T,D] -> [T][B][ld]
-void launch_unpack_bm(const float* src_tm, int ld, float* dst_bm, int B, int T, int D, hipStream_t s);    // [T][B][ld] -> [B,T,D]
+void launch_unpack_bm(const float* src_tm, int ld, float* dst_bm, int B, int T, int D, hipStream_t s, int Bt = 0);    // [T][B][ld] -> [Bt or B,T,D]
 // xd[t][b] = labels[t][b] + noise_r[b]   (b <  B)   (only when with_real)
 // xd[t][B+b or b] = y[t][b] + noise_f[b]
 void launch_build_d_input(const float* lab_tm, const float* y_tm, const float* noise_r, const float* noise_f,
@@ -316,17 +326,18 @@ struct DHeadArgs {
   const float* top; int ldt; const float* w; int ldw; const float* b;
   float* logits; int ldl; float* dlogits; float* dout; int ldo; float* gw; float* gb;
   int T, Nd, n_real, dR; const float* t_real; const float* t_fake; float* loss3; float* part; int want_grads, want_wgrads;
+  int Bp, Bt;                       // Bp > 0: every Bp rows of a frame are Bt utterances + padding rows that count in no mean
 };
 void launch_dhead(const DHeadArgs& a, hipStream_t s);
 void launch_lsgan(const float* logits, int ldl, float* dlogits, int T, int Nd, int n_real,
                   const float* target_real, const float* target_fake, float* loss3, hipStream_t s,
-                  bool clip_on = false, float clip_lo = 0.f, float clip_hi = 0.f);
+                  bool clip_on = false, float clip_lo = 0.f, float clip_hi = 0.f, int Bp = 0, int Bt = 0);
 void launch_build_joint(const float* x, int ldx, int off, int dim, const float* tail, int ldt, int Dt, float* joint, int ldj,
                         int row0, int R, hipStream_t s);
 void launch_slice_cols(const float* src, int lds, int off, float* dst, int ldd, int R, int C, hipStream_t s);
 // g_mse = 0.5*D*mean((y-lab)^2) ; dy (+)= lambda*(y-lab)/(B*T)   (dy nullptr = loss only)
 void launch_mse(const float* y, const float* lab, int ld, float* dy, int rows, int D, const float* lambda,
-                bool accumulate, float* loss_out, float* scratch /* >= 1024 floats */, hipStream_t s);
+                bool accumulate, float* loss_out, float* scratch /* >= 1024 floats */, hipStream_t s, int Bp = 0, int Bt = 0);   // Bp > 0: rows [Bt, Bp) of every Bp are padding
 // losses[3] = adv + lambda*mse + l2
 void launch_g_total(float* l4 /* adv,mse,l2,total */, const float* lambda, hipStream_t s);
 void launch_copy_f(const float* src, float* dst, int n, hipStream_t s);

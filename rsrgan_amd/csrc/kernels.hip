@@ -1160,13 +1160,14 @@ __global__ void k_stage_inputs(const StageJobs j) {
   }
 }
 void launch_stage_inputs(const StageJobs& j, hipStream_t s) {
-  hipLaunchKernelGGL(k_stage_inputs, dim3(j.T, j.B, 3), dim3(128), 0, s, j);
+  // (Bt < B: the model pads its row count for the persistent recurrences; rows [Bt, B) of the packs stay zero, their lengths 0)
+  hipLaunchKernelGGL(k_stage_inputs, dim3(j.T, j.Bt > 0 ? j.Bt : j.B, 3), dim3(128), 0, s, j);
 }
 void launch_pack_tm(const float* src, float* dst, int B, int T, int D, int ld, hipStream_t s) {
   hipLaunchKernelGGL(k_pack_tm, dim3(T, B), dim3(D >= 128 ? 128 : 64), 0, s, src, dst, B, T, D, ld);
 }
-void launch_unpack_bm(const float* src, int ld, float* dst, int B, int T, int D, hipStream_t s) {
-  hipLaunchKernelGGL(k_unpack_bm, dim3(T, B), dim3(D >= 128 ? 128 : 64), 0, s, src, ld, dst, B, T, D);
+void launch_unpack_bm(const float* src, int ld, float* dst, int B, int T, int D, hipStream_t s, int Bt) {
+  hipLaunchKernelGGL(k_unpack_bm, dim3(T, Bt > 0 ? Bt : B), dim3(D >= 128 ? 128 : 64), 0, s, src, ld, dst, B, T, D);
 }
 
 // discriminator input (gan_rnn_placeholder.py:205-213 + utils/ops.py:19-30): rows [0,B) real
@@ -1643,18 +1644,21 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red) {
 __global__ __launch_bounds__(1024) void k_lsgan(const float* __restrict__ logits, int ldl, float* __restrict__ dlogits,
                                                 int T, int Nd, int n_real, const float* __restrict__ t_real,
                                                 const float* __restrict__ t_fake, float* __restrict__ loss3,
-                                                int clip_on, float clip_lo, float clip_hi) {
+                                                int clip_on, float clip_lo, float clip_hi, int Bp, int Bt) {
   __shared__ float red[16];
   const int rows = T * Nd;
   const float tr = *t_real, tf = *t_fake;
-  const float cr = (float)T * (float)n_real, cf = (float)T * (float)(Nd - n_real);
+  // (Bp > 0: each half of Bp rows per frame holds Bt utterances and Bp - Bt padding rows, which are no part of any mean)
+  const int nr_ = Bp > 0 ? n_real / Bp * Bt : n_real, nf_ = Bp > 0 ? (Nd - n_real) / Bp * Bt : Nd - n_real;
+  const float cr = (float)T * (float)nr_, cf = (float)T * (float)nf_;
   float sr = 0.f, sf = 0.f;
   for (int r = threadIdx.x; r < rows; r += blockDim.x) {
     const bool real = (r % Nd) < n_real;
+    const bool valid = Bp <= 0 || ((r % Nd) % Bp) < Bt;
     const float raw = logits[(size_t)r * ldl];
     // discriminator_dnn.py:93 tf.clip_by_value(y, -0.5, 1.5): value clipped, gradient passes where lo <= y <= hi
     const float val = clip_on ? fminf(fmaxf(raw, clip_lo), clip_hi) : raw;
-    const float d = val - (real ? tr : tf);
+    const float d = valid ? val - (real ? tr : tf) : 0.f;
     if (real) sr += d * d; else sf += d * d;
     if (dlogits) dlogits[(size_t)r * ldl] = (clip_on && (raw < clip_lo || raw > clip_hi)) ? 0.f : 2.f * d / (real ? cr : cf);
   }
@@ -1667,9 +1671,10 @@ __global__ __launch_bounds__(1024) void k_lsgan(const float* __restrict__ logits
   }
 }
 void launch_lsgan(const float* logits, int ldl, float* dlogits, int T, int Nd, int n_real,
-                  const float* t_real, const float* t_fake, float* loss3, hipStream_t s, bool clip_on, float clip_lo, float clip_hi) {
+                  const float* t_real, const float* t_fake, float* loss3, hipStream_t s, bool clip_on, float clip_lo, float clip_hi,
+                  int Bp, int Bt) {
   hipLaunchKernelGGL(k_lsgan, dim3(1), dim3(1024), 0, s, logits, ldl, dlogits, T, Nd, n_real, t_real, t_fake, loss3,
-                     clip_on ? 1 : 0, clip_lo, clip_hi);
+                     clip_on ? 1 : 0, clip_lo, clip_hi, Bp, Bt);
 }
 
 // The head of discriminator_lstm in ONE pass over its top layer's outputs (models/discriminator_lstm.py:93-104: fully_connected to one
@@ -1688,7 +1693,8 @@ __global__ __launch_bounds__(64) void k_dhead1(const DHeadArgs a) {
   const int r = blockIdx.x * 64 + lane;
   const bool on = r < rows;
   const float tr = *a.t_real, tf = *a.t_fake;
-  const float cr = (float)a.T * (float)a.n_real, cf = (float)a.T * (float)(a.Nd - a.n_real);
+  const int nr_ = a.Bp > 0 ? a.n_real / a.Bp * a.Bt : a.n_real, nf_ = a.Bp > 0 ? (a.Nd - a.n_real) / a.Bp * a.Bt : a.Nd - a.n_real;
+  const float cr = (float)a.T * (float)nr_, cf = (float)a.T * (float)nf_;
   float x[DH_MAXR];
   float logit = wsh[DH_MAXR];
   const float* xr = a.top + (size_t)(on ? r : 0) * a.ldt;
@@ -1701,7 +1707,8 @@ __global__ __launch_bounds__(64) void k_dhead1(const DHeadArgs a) {
 #pragma unroll
   for (int c = 0; c < DH_MAXR; ++c) if (c < dR) logit += x[c] * wsh[c];
   const bool real = on && (r % a.Nd) < a.n_real;
-  const float d = logit - (real ? tr : tf);
+  const bool valid = a.Bp <= 0 || ((r % a.Nd) % a.Bp) < a.Bt;          // (padding rows of a row-padded model: no part of any mean)
+  const float d = valid ? logit - (real ? tr : tf) : 0.f;
   float sr = (on && real) ? d * d : 0.f, sf = (on && !real) ? d * d : 0.f;
   const float dl = on ? 2.f * d / (real ? cr : cf) : 0.f;
   if (on) {
@@ -1745,7 +1752,8 @@ __global__ __launch_bounds__(1024) void k_dhead2(const DHeadArgs a, int nblocks)
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float cr = (float)a.T * (float)a.n_real, cf = (float)a.T * (float)(a.Nd - a.n_real);
+    const int nr_ = a.Bp > 0 ? a.n_real / a.Bp * a.Bt : a.n_real, nf_ = a.Bp > 0 ? (a.Nd - a.n_real) / a.Bp * a.Bt : a.Nd - a.n_real;
+    const float cr = (float)a.T * (float)nr_, cf = (float)a.T * (float)nf_;
     const float lr_ = a.n_real > 0 ? tot[0] / cr : 0.f;
     const float lf_ = (a.Nd - a.n_real) > 0 ? tot[1] / cf : 0.f;
     a.loss3[0] = lr_; a.loss3[1] = lf_; a.loss3[2] = lr_ + lf_;
@@ -1789,15 +1797,17 @@ void launch_slice_cols(const float* src, int lds_, int off, float* dst, int ldd,
 constexpr int MSE_BLOCKS = 256;
 __global__ __launch_bounds__(256) void k_mse1(const float* __restrict__ y, const float* __restrict__ lab, int ld,
                                               float* __restrict__ dy, int rows, int D, const float* __restrict__ lambda,
-                                              int accumulate, float* __restrict__ scratch) {
+                                              int accumulate, float* __restrict__ scratch, int Bp, int Bt) {
   __shared__ float red[16];
   const size_t total = (size_t)rows * D;
-  const float scale = dy ? (*lambda) / (float)rows : 0.f;
+  const int rows_eff = Bp > 0 ? rows / Bp * Bt : rows;                  // (Bp > 0: rows [Bt, Bp) of every frame are padding)
+  const float scale = dy ? (*lambda) / (float)rows_eff : 0.f;
   float s = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t r = i / D; const int c = (int)(i % D);
     const size_t o = r * ld + c;
-    const float d = y[o] - lab[o];
+    const bool valid = Bp <= 0 || (int)(r % Bp) < Bt;
+    const float d = valid ? y[o] - lab[o] : 0.f;
     s += d * d;
     if (dy) dy[o] = (accumulate ? dy[o] : 0.f) + scale * d;
   }
@@ -1812,9 +1822,9 @@ __global__ void k_mse2(const float* __restrict__ scratch, int rows, float* __res
   }
 }
 void launch_mse(const float* y, const float* lab, int ld, float* dy, int rows, int D, const float* lambda,
-                bool accumulate, float* loss_out, float* scratch, hipStream_t s) {
-  hipLaunchKernelGGL(k_mse1, dim3(MSE_BLOCKS), dim3(256), 0, s, y, lab, ld, dy, rows, D, lambda, accumulate ? 1 : 0, scratch);
-  hipLaunchKernelGGL(k_mse2, dim3(1), dim3(64), 0, s, scratch, rows, loss_out);
+                bool accumulate, float* loss_out, float* scratch, hipStream_t s, int Bp, int Bt) {
+  hipLaunchKernelGGL(k_mse1, dim3(MSE_BLOCKS), dim3(256), 0, s, y, lab, ld, dy, rows, D, lambda, accumulate ? 1 : 0, scratch, Bp, Bt);
+  hipLaunchKernelGGL(k_mse2, dim3(1), dim3(64), 0, s, scratch, Bp > 0 ? rows / Bp * Bt : rows, loss_out);
 }
 
 __global__ void k_g_total(float* l4, const float* lambda) {

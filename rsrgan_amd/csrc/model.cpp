@@ -87,7 +87,7 @@ void Model::leave(hipStream_t caller, hipStream_t work) {
 }
 const float* Model::stage_noise(const float* src, float* buf, hipStream_t s) {
   if (!src) return nullptr;
-  (void)hipMemcpyAsync(buf, src, (size_t)B * Dout * sizeof(float), hipMemcpyDeviceToDevice, s);
+  (void)hipMemcpyAsync(buf, src, (size_t)Bt * Dout * sizeof(float), hipMemcpyDeviceToDevice, s);
   return buf;
 }
 
@@ -157,7 +157,7 @@ static void alloc_stash(Model& M, LstmStash& S, const LstmLayer& L, int N, int T
 
 int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   cfg = c;
-  B = c.batch_size; Tmax = c.max_frames; Din = c.input_dim; Dout = c.output_dim;
+  B = Bt = c.batch_size; Tmax = c.max_frames; Din = c.input_dim; Dout = c.output_dim;
   ldDin = pad4(Din); ldDout = pad4(Dout);
   if (B <= 0 || Tmax <= 0 || Din <= 0 || Dout <= 0 || c.g_layers <= 0 || c.d_layers <= 0 || c.g_cells <= 0 ||
       c.d_cells <= 0 || (c.g_layers > MAXJ && !g_dnn()) || c.d_layers > MAXJ) {
@@ -271,6 +271,17 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     }
     d_fc_w = D.add("d_model/fully_connected/weights", dR, 1, false);
     d_fc_b = D.add("d_model/fully_connected/biases", 1, 1, true);
+  }
+  // ---- row padding for the persistent generator recurrences (model.h Bt) ----
+  if (const char* e = getenv("RSRGAN_GPERSIST")) gp_env = atoi(e);        // bit 0: the generator's forward recurrence, bit 1: its BPTT
+  {
+    static const bool pad_env = [] { const char* e = getenv("RSRGAN_PAD_ROWS"); return !e || atoi(e) != 0; }();
+    const int Bp = (Bt + GP_ROWS - 1) / GP_ROWS * GP_ROWS;
+    if (pad_env && gp_env && Bp != Bt && !g_dnn() && !d_dnn() && wavefront()) {
+      B = Bp;
+      GPersistArgs ga{};
+      if (!gpersist_shape(ga, std::min(Tmax, (int)GP_TMAX))) B = Bt;     // (only where the padded batch does take the persistent path)
+    }
   }
   // ---- device buffers ----
   const bool ema_on = c.ema_decay > 0.f;
@@ -420,16 +431,25 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   }
   if (const char* e = getenv("RSRGAN_DPERSIST")) dp_env = atoi(e);        // bit 0: forward, bit 1: backward
   if (dp_env && !dl.empty() && dl.size() <= (size_t)DP_MAXL && B % 16 == 0) {
+    // every workgroup of a launch waits for the others: ask the device whether the stacked (2B rows) or at least the single (B rows)
+    // launch is resident at once -- a CU mask, a partition or a neighbour can take CUs away without multiProcessorCount knowing
+    const int nl_ = (int)dl.size();
+    for (int rows : {2 * B, B}) {
+      const int g_ = dpersist_grid(nl_, rows);
+      if (g_ <= 128 && resident_probe(g_, 512, dpersist_lds_bytes())) { dp_max_grid = g_; break; }
+    }
+  }
+  if (dp_max_grid > 0) {
     dp_gran_bytes = dpersist_granule_bytes((int)dl.size(), 2 * B, Tmax);
     dp_gran = (unsigned long long*)alloc<float>(dp_gran_bytes / sizeof(float));
     dp_ctl = (unsigned*)alloc<float>(16);
     const unsigned ctl0[DP_CTL_WORDS] = {1u, 0u, 0u, 0u};
     HIPC(hipMemcpy(dp_ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice));
   }
-  if (const char* e = getenv("RSRGAN_GPERSIST")) gp_env = atoi(e);        // bit 0: the generator's forward recurrence, bit 1: its BPTT
   if (gp_env && !g_dnn()) {
     GPersistArgs ga{};
-    if (gpersist_args(ga, Tmax)) {
+    gp_Tcap = std::min(Tmax, (int)GP_TMAX);
+    if (gpersist_args(ga, gp_Tcap) && resident_probe(gpersist_grid(ga), GP_THREADS, gpersist_lds_bytes())) {
       gp_gran1 = (unsigned long long*)alloc<float>(gpersist_gran1_bytes(ga) / sizeof(float));
       gp_gran2_bytes = gpersist_gran2_bytes(ga);
       gp_gran2 = (unsigned long long*)alloc<float>(gp_gran2_bytes / sizeof(float));
@@ -922,32 +942,52 @@ bool Model::persist_forward(Chain& ch, int T, hipStream_t s) {
     D_.I = L.I; D_.P = L.P; D_.ldP = L.ldP; D_.ldH = L.ldH; D_.ldI = L.ldI;
     D_.in = l == 0 ? R.in : nullptr;                   // (layer 0's input product runs inside the launch as well)
   }
-  if (!dpersist_supported(a) || dpersist_granule_bytes(a.nl, a.N, a.T) > dp_gran_bytes) return false;
+  if (!dpersist_supported(a) || dpersist_grid(a.nl, a.N) > dp_max_grid || dpersist_granule_bytes(a.nl, a.N, a.T) > dp_gran_bytes) return false;
   launch_dlstm_fwd(a, s);
   return true;
 }
 
 // The generator's stack as ONE persistent launch (gpersist.hip).  Same stash as the wavefront launches leave (gates, c, h, mst, out of
 // every layer), so the backward pass does not know which forward ran.
-bool Model::gpersist_args(GPersistArgs& a, int T) const {
+bool Model::gpersist_shape(GPersistArgs& a, int T) const {              // (sizes only: usable before any buffer exists)
   if (!gp_env || gl.empty() || gl.size() > (size_t)GP_MAXL || cfg.g_type != RSRGAN_G_LSTM) return false;
   a = GPersistArgs{};
-  a.nl = (int)gl.size(); a.N = B; a.T = T; a.H = gl[0].H; a.len = len_dev;
-  a.gran1 = gp_gran1; a.gran2 = gp_gran2; a.gran3 = gp_gran3; a.ctl = gp_ctl; a.forget_bias = cfg.forget_bias;
+  a.nl = (int)gl.size(); a.N = B; a.T = T; a.H = gl[0].H;
   for (size_t l = 0; l < gl.size(); ++l) {
-    const LstmLayer& L = gl[l]; const LstmStash& S = g_st[l];
+    const LstmLayer& L = gl[l];
     if (!L.has_proj || L.H != a.H) return false;
     GPersistLayer& G_ = a.L[l];
-    G_.KxT = L.KxT; G_.KhT = L.KhT; G_.bias = G.W(L.tb); G_.wi = G.W(L.twi); G_.wf = G.W(L.twf); G_.wo = G.W(L.two); G_.Wp = G.W(L.tWp);
-    G_.gates = S.gates; G_.c = S.c; G_.h = S.h; G_.mst = S.mst; G_.out = S.out; G_.dmt = S.dmt;
     G_.I = L.I; G_.P = L.P; G_.ldI = L.ldI; G_.ldP = L.ldP; G_.ldH = L.ldH;
   }
   return gpersist_plan(a);
 }
+bool Model::gpersist_args(GPersistArgs& a, int T) const {
+  if (!gpersist_shape(a, T)) return false;
+  a.len = len_dev;
+  a.gran1 = gp_gran1; a.gran2 = gp_gran2; a.gran3 = gp_gran3; a.ctl = gp_ctl; a.forget_bias = cfg.forget_bias;
+  for (size_t l = 0; l < gl.size(); ++l) {
+    const LstmLayer& L = gl[l]; const LstmStash& S = g_st[l];
+    GPersistLayer& G_ = a.L[l];
+    G_.KxT = L.KxT; G_.KhT = L.KhT; G_.bias = G.W(L.tb); G_.wi = G.W(L.twi); G_.wf = G.W(L.twf); G_.wo = G.W(L.two); G_.Wp = G.W(L.tWp);
+    G_.gates = S.gates; G_.c = S.c; G_.h = S.h; G_.mst = S.mst; G_.out = S.out; G_.dmt = S.dmt;
+  }
+  return true;
+}
+
+// A persistent launch reported a failed bounded wait (rsrgan_device_status): its workgroups were not all resident -- somebody else's
+// work on the device, CUs taken away after rsrgan_create.  Another attempt would spin into the same time-out on every step: this
+// handle takes the launch-per-phase path from now on (the captured graphs hold the persistent launches: dropped).
+void Model::persist_disable(int which) {
+  if (which == 1) gp_env = 0; else dp_env = 0;
+  lazy_sw = false;
+  drop_graphs();
+  refresh_swizzles(RSRGAN_NET_G, nullptr);
+  refresh_swizzles(RSRGAN_NET_D, nullptr);
+}
 
 void Model::gpersist_rearm() {
   GPersistArgs a{};
-  if (!gp_gran1 || !gpersist_args(a, Tmax)) return;
+  if (!gp_gran1 || !gpersist_args(a, gp_Tcap)) return;
   gpersist_arm(a, 0);
   (void)hipDeviceSynchronize();
 }
@@ -965,7 +1005,7 @@ bool Model::persist_forward_g(int T, hipStream_t s) {
     }
     // algorithmic FLOP of the launch: every layer's input and recurrent product and its projection
     for (size_t l = 0; l < gl.size(); ++l)
-      prof_gp_flops += 2.0 * B * T * ((double)(gl[l].I + gl[l].P) * 4.0 * gl[l].H + (double)gl[l].H * gl[l].P);
+      prof_gp_flops += 2.0 * Bt * T * ((double)(gl[l].I + gl[l].P) * 4.0 * gl[l].H + (double)gl[l].H * gl[l].P);
     (void)hipEventRecord(prof_gp_ev[2 * prof_gp_n], s);
     launch_glstm_fwd(a, s);
     (void)hipEventRecord(prof_gp_ev[2 * prof_gp_n + 1], s);
@@ -1007,7 +1047,7 @@ bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only,
     // algorithmic FLOP of the launch: every layer's state-gradient product and dh = dm . W_p^T, the input-gradient product (layer 0's
     // only when it runs inside the launch)
     for (size_t l = 0; l < gl.size(); ++l)
-      prof_gb_flops += 2.0 * B * T * ((double)((l || din_inside ? gl[l].I : 0) + gl[l].P) * 4.0 * gl[l].H + (double)gl[l].H * gl[l].P);
+      prof_gb_flops += 2.0 * Bt * T * ((double)((l || din_inside ? gl[l].I : 0) + gl[l].P) * 4.0 * gl[l].H + (double)gl[l].H * gl[l].P);
     (void)hipEventRecord(prof_gb_ev[2 * prof_gb_n], s);
     launch_glstm_bwd(a, s);
     (void)hipEventRecord(prof_gb_ev[2 * prof_gb_n + 1], s);
@@ -1043,7 +1083,7 @@ bool Model::persist_backward(Chain& ch, int T, hipStream_t s) {
     D_.I = L.I; D_.P = L.P; D_.ldP = L.ldP; D_.ldH = L.ldH;
   }
   a.dout_top = ch.back().dout; a.ld_dout = dl.back().ldP;
-  if (!a.dout_top || !dpersist_supported(a) || dpersist_granule_bytes(a.nl, a.N, a.T) > dp_gran_bytes) return false;
+  if (!a.dout_top || !dpersist_supported(a) || dpersist_grid(a.nl, a.N) > dp_max_grid || dpersist_granule_bytes(a.nl, a.N, a.T) > dp_gran_bytes) return false;
   launch_dlstm_bwd(a, s);
   if (!defer_wgrads) {           // (on one stream: the discriminator's sequences are short launches, two streams cost them 0.04 ms)
     bool dK_done = false;
@@ -1318,12 +1358,14 @@ int Model::prepare_batch(const float* x, const float* labels, const int32_t* len
   if (T <= 0 || T > Tmax) { set_error("T=%d outside (0, max_frames=%d]", T, Tmax); return RSRGAN_ERR_INVALID; }
   if (!x || (!lengths && !g_dnn())) { set_error("null input pointer"); return RSRGAN_ERR_INVALID; }
   // one launch: both packs, the lengths (twice: the stacked discriminator batch reads rows [B, 2B) as well) and the callers' noise
-  StageJobs j{}; j.B = B; j.T = T;
+  // (a padded model, Bt < B: the caller's Bt rows land in rows [0, Bt) of every frame; rows [Bt, B) of the packs, their lengths and
+  // their noise stay at the zeros of the allocation)
+  StageJobs j{}; j.B = B; j.T = T; j.Bt = Bt;
   j.pack[0] = StagePack{x, x_tm, Din, ldDin};
   if (labels) j.pack[1] = StagePack{labels, lab_tm, Dout, ldDout};
-  if (lengths) { j.copy[0] = StageCopy{lengths, len_dev, B}; j.copy[1] = StageCopy{lengths, len_dev + B, B}; }
-  if (nr && *nr) { j.copy[2] = StageCopy{*nr, noise_r_buf, B * Dout}; *nr = noise_r_buf; }
-  if (nf && *nf) { j.copy[3] = StageCopy{*nf, noise_f_buf, B * Dout}; *nf = noise_f_buf; }
+  if (lengths) { j.copy[0] = StageCopy{lengths, len_dev, Bt}; j.copy[1] = StageCopy{lengths, len_dev + B, Bt}; }
+  if (nr && *nr) { j.copy[2] = StageCopy{*nr, noise_r_buf, Bt * Dout}; *nr = noise_r_buf; }
+  if (nf && *nf) { j.copy[3] = StageCopy{*nf, noise_f_buf, Bt * Dout}; *nf = noise_f_buf; }
   launch_stage_inputs(j, s);
   cur_T = T;
   g_fwd_valid = false;
@@ -1399,6 +1441,7 @@ bool Model::d_head(int N, int T, int n_real, const float* t_real, const float* t
   a.logits = logits; a.ldl = 4; a.dlogits = dlogits; a.dout = d_dB; a.ldo = ldPd; a.gw = D.Gd(d_fc_w); a.gb = D.Gd(d_fc_b);
   a.T = T; a.Nd = N; a.n_real = n_real; a.dR = dR; a.t_real = t_real; a.t_fake = t_fake; a.loss3 = loss3; a.part = scratch;
   a.want_grads = want_grads ? 1 : 0; a.want_wgrads = want_wgrads ? 1 : 0;
+  a.Bp = pad_Bp(); a.Bt = Bt;
   launch_dhead(a, s);
   return true;
 }
@@ -1529,7 +1572,7 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
     const bool head = d_head(2 * B, T, B, dyn + DYN_D_REAL, dyn + DYN_D_FAKE, losses, want_grads, want_grads, s);
     if (!head) {
       d_logits(2 * B, T, s);
-      launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, 2 * B, B, dyn + DYN_D_REAL, dyn + DYN_D_FAKE, losses, s);
+      launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, 2 * B, B, dyn + DYN_D_REAL, dyn + DYN_D_FAKE, losses, s, false, 0.f, 0.f, pad_Bp(), Bt);
     }
     if (want_grads) d_backward_pass(2 * B, T, true, false, dlogits, s, head);
   }
@@ -1556,7 +1599,7 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     HIPC(hipMemsetAsync(losses + 3, 0, sizeof(float), s));
     if (want_grads) {
       float* dy = g_dC;                            // g_backward_pass ping-pongs g_dA / g_dB
-      launch_mse(y_tm, lab_tm, ldDout, dy, T * B, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s);
+      launch_mse(y_tm, lab_tm, ldDout, dy, T * B, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s, pad_Bp(), Bt);
       g_backward_pass(T, dy, s);
       if (l2s) {
         launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
@@ -1564,7 +1607,7 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
       }
       { finish_buckets(RSRGAN_NET_G, s); g_grads_ready = true; }
     } else {
-      launch_mse(y_tm, lab_tm, ldDout, nullptr, T * B, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s);
+      launch_mse(y_tm, lab_tm, ldDout, nullptr, T * B, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s, pad_Bp(), Bt);
     }
     if (!(want_grads && l2s)) HIPC(hipMemsetAsync(losses + 5, 0, sizeof(float), s));
     launch_g_total(losses + 3, dyn + DYN_LAMBDA, s);
@@ -1661,20 +1704,20 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     g_head = d_head(B, T, 0, dyn + DYN_D_REAL, dyn + DYN_D_REAL, tmp3, want_grads, false, s);
     if (!g_head) {
       d_logits(B, T, s);
-      launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, B, 0, dyn + DYN_D_REAL, dyn + DYN_D_REAL, tmp3, s);
+      launch_lsgan(logits, 4, want_grads ? dlogits : nullptr, T, B, 0, dyn + DYN_D_REAL, dyn + DYN_D_REAL, tmp3, s, false, 0.f, 0.f, pad_Bp(), Bt);
     }
   }
   launch_copy_f(tmp3 + 1, losses + 3, 1, s);
   if (want_grads && d_dnn()) {
     // discriminator_dnn: data gradient through the FC stack (time-batched GEMMs), then the generator's BPTT wave
     float* dyd = fc_backward(D, dfc, d_act, T * B, dlogits, false, true, s);      // [T*B][ldDout] (d_joint_dim == 0)
-    launch_mse(y_tm, lab_tm, ldDout, dyd, T * B, Dout, dyn + DYN_LAMBDA, true, losses + 4, scratch, s);
+    launch_mse(y_tm, lab_tm, ldDout, dyd, T * B, Dout, dyn + DYN_LAMBDA, true, losses + 4, scratch, s, pad_Bp(), Bt);
     g_backward_pass(T, dyd, s);
   } else if (wave_bwd) {
     // ONE backward wave: D's layers (data gradient only) | per-step output-FC backward | G's layers.
     // dy[t] = lambda*(y-lab)/(B*T) (written first) + d g_adv/d y[t] (accumulated by D layer 0's phase B)
     if (!g_head) gemm(dlogits, 4, true, D.W(d_fc_w), 4, true, d_dB, ldPd, R, dR, 1, nullptr, 0, 0.f, false, s);      // d(D outputs) = dlogits . W^T
-    launch_mse(y_tm, lab_tm, ldDout, dy, R, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s);
+    launch_mse(y_tm, lab_tm, ldDout, dy, R, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s, pad_Bp(), Bt);
     FcStage F;                                     // d(ins[L])[t] = dy[t] . W_out^T
     F.offset = Ld; F.N = B; F.K = Dout; F.D = P;
     F.in = dy; F.ld_in = ldDout; F.WT = G.W(g_fc_out_w); F.y = g_dA; F.ldy = ldP; F.accumulate = false;
@@ -1716,10 +1759,10 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   } else if (want_grads) {
     d_backward_pass(B, T, false, true, dlogits, s, g_head);
     float* dyd = last_dx0;                        // d g_adv / d y
-    launch_mse(y_tm, lab_tm, ldDout, dyd, T * B, Dout, dyn + DYN_LAMBDA, true, losses + 4, scratch, s);
+    launch_mse(y_tm, lab_tm, ldDout, dyd, T * B, Dout, dyn + DYN_LAMBDA, true, losses + 4, scratch, s, pad_Bp(), Bt);
     g_backward_pass(T, dyd, s);
   } else {
-    launch_mse(y_tm, lab_tm, ldDout, nullptr, T * B, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s);
+    launch_mse(y_tm, lab_tm, ldDout, nullptr, T * B, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s, pad_Bp(), Bt);
   }
   });
   if (!reuse) g_fwd_valid = true;

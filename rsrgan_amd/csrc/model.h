@@ -118,6 +118,12 @@ struct FcStage {
 struct Model {
   rsrgan_cfg cfg{};
   int B = 0, Tmax = 0, Din = 0, Dout = 0, ldDin = 0, ldDout = 0;
+  // B = rows per frame of every internal buffer; Bt = the caller's batch_size.  They differ when the batch is PADDED up to a multiple
+  // of the persistent generator kernels' 32-row group (run_gan_rnn_placeholder.sh:126 ships batch_size=8, decode feeds 1): the
+  // padding rows have length 0 -- dynamic_rnn's masking makes them inert (zero outputs, zero gradients) -- and the loss kernels leave
+  // them out of every mean (pad_Bp() / Bt).  RSRGAN_PAD_ROWS=0: off.
+  int Bt = 0;
+  int pad_Bp() const { return Bt != B ? B : 0; }
   int gR = 0, dR = 0;            // output width of the generator / discriminator LSTM stacks (num_proj, or cells when None)
   ParamSet G, D;
   std::vector<LstmLayer> gl, dl;
@@ -158,7 +164,11 @@ struct Model {
   unsigned* gp_ctl = nullptr;
   size_t gp_gran2_bytes = 0;
   int gp_env = 3;                                         // RSRGAN_GPERSIST: bit 0 the forward launch, bit 1 the backward launch (0: the launch-per-phase wavefront)
+  int gp_Tcap = 0;                                        // the rings are sized for min(max_frames, GP_TMAX) steps; longer batches take the launch path
+  int dp_max_grid = 0;                                    // largest discriminator launch the device proved it can hold (resident_probe)
+  void persist_disable(int which);                        // after a reported failure: 0 = discriminator, 1 = generator launches off for this handle
   bool gp_fwd_on() const { return gp_gran1 && (gp_env & 1); }
+  bool gpersist_shape(GPersistArgs& a, int T) const;      // sizes + plan only (no buffers)
   bool gpersist_args(GPersistArgs& a, int T) const;       // false: not applicable
   void gpersist_rearm();                                  // the "not written" pattern in every ring slot (after allocation, after a failed launch)
   bool persist_forward_g(int T, hipStream_t s);           // layer 0's x-part batched first; fills the complete stash of every layer

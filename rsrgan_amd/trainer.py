@@ -27,19 +27,25 @@ class RNNTrainer(GAN_RNN):
     """models/rnn_trainer.py:66 -- g_type in {lstm, res_lstm_l, res_lstm_base} (bnlstm / res_lstm_i are not built)."""
 
     def __init__(self, sess, args, devices, inputs=None, labels=None, lengths=None, cross_validation=False,
-                 name="RNNTrainer", *, max_frames: Optional[int] = None, process_group=None, seed: int = 4321,
+                 name="RNNTrainer", *, max_frames: Optional[int] = None, engine=None, process_group=None, seed: int = 4321,
                  net_overrides: Optional[dict] = None, share_engine_from=None):
         ov = dict(net_overrides or {})
         ov["flags"] = ov.get("flags", FLAG_WAVEFRONT) | FLAG_SUPERVISED
         super(RNNTrainer, self).__init__(sess, _Args(args, init_mse_weight=1.0), devices, cross_validation=cross_validation,
-                                         name=name, max_frames=max_frames, process_group=process_group, seed=seed,
+                                         name=name, max_frames=max_frames, engine=engine, process_group=process_group, seed=seed,
                                          net_overrides=ov, share_engine_from=share_engine_from)
 
     def d_step(self, *a, **k):
         raise RuntimeError("RNNTrainer has no discriminator (models/rnn_trainer.py)")
 
-    def _summary_fetch(self, inputs, labels, lengths):          # no discriminator: the three d_* scalars are 0
-        return ([0.0], [0.0], [0.0]), self.g_step(inputs, labels, lengths, train=False), self.forward(inputs, lengths)
+    def _summary_fetch(self, inputs, labels, lengths):
+        """Model.run_summaries' five-value contract (d, g, x, labels, y) on THIS rank's rows: the engine directly, no collective
+        (only the writer's rank gets here; g_step would all-gather the towers).  No discriminator: the three d_* scalars are 0."""
+        x, lab, ln = self._shard(inputs), self._shard(labels), self._shard(lengths)
+        with self.on_stream():
+            g = self.engine.g_backward(x, lab, ln, None, train=False, reuse=False, apply=False)
+            y = self.engine.forward_g(x, ln)
+        return [0.0, 0.0, 0.0], g, x, lab, y
 
     def step(self, inputs, labels, lengths, train=True, sync=True):
         """sess.run([model.g_opt, model.g_mse_losses, model.g_l2_losses, model.g_losses])."""
@@ -53,17 +59,19 @@ class DNNTrainer(GAN):
     G_TYPES = ("dnn", "rced")
 
     def __init__(self, sess, args, devices, inputs=None, labels=None, cross_validation=False, name="DNNTrainer", *,
-                 process_group=None, seed: int = 4321, net_overrides: Optional[dict] = None):
+                 engine=None, process_group=None, seed: int = 4321, net_overrides: Optional[dict] = None):
         ov = dict(net_overrides or {})
         ov["flags"] = ov.get("flags", FLAG_WAVEFRONT) | FLAG_SUPERVISED
         super(DNNTrainer, self).__init__(sess, _Args(args, init_mse_weight=1.0), devices, cross_validation=cross_validation,
-                                         name=name, process_group=process_group, seed=seed, net_overrides=ov)
+                                         name=name, engine=engine, process_group=process_group, seed=seed, net_overrides=ov)
 
     def d_step(self, *a, **k):
         raise RuntimeError("DNNTrainer has no discriminator (models/dnn_trainer.py)")
 
     def _summary_fetch(self, inputs, labels, lengths=None):
-        return ([0.0], [0.0], [0.0]), self.g_step(inputs, labels, train=False), self.forward(inputs)
+        """as RNNTrainer's: (d, g, x, labels, y) of the batch this rank drew, collective-free"""
+        g = self.engine.g_backward(self._frames(inputs), self._frames(labels), None, train=False, reuse=False, apply=False)
+        return [0.0, 0.0, 0.0], g, inputs, labels, self.forward(inputs)
 
     def step(self, inputs, labels, train=True, sync=True):
         out = self.g_step(inputs, labels, train=train, sync=sync)

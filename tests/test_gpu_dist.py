@@ -87,7 +87,7 @@ def test_nccl_world1_dp_path_equals_fused_step():
         dist.destroy_process_group()
 
 
-def _two_rank_worker(rank, world, port, out):
+def _two_rank_worker(rank, world, port, out, ref_size=False):
     """Two processes share cuda:0; gradients travel through gloo (RCCL refuses two ranks on one device), everything else is the
     real HIP engine: sharding, per-bucket events + communication stream, average, clip, apply."""
     import torch.distributed as dist
@@ -98,25 +98,38 @@ def _two_rank_worker(rank, world, port, out):
     try:
         from rsrgan_amd import GAN_RNN, train_one_iteration
         from tests.helpers import args_for, overrides, rand_params
-        cfg = small_cfg("lstm")
-        B, T = 3, 7
+        cfg, B, T = _two_rank_case(ref_size)
         g, d = rand_params(cfg, 5)
         m = GAN_RNN(None, args_for(cfg, B, num_gpu=world, g_learning_rate=8e-5 * world, d_learning_rate=1e-3 * world, gen_updates=2),
                     ["gpu:0"], max_frames=T, net_overrides=dict(overrides(cfg), flags=3))
         m.set_vars(g, d)
         assert len(m.engine.grad_buckets(NET_G)) > 1                 # the bucketed path is the one under test
         batches = [rand_batch(cfg, B * world, T, 60 + i, ragged=True) for i in range(3)]
+        if ref_size:
+            m.engine.profile_launches()
         res = train_one_iteration(None, m, len(batches) * world, 0, [[None] + list(b) for b in batches])
+        status = m.engine.device_status()
         gv, dv = m.get_vars()
-        out[rank] = (res, {k: v.copy() for k, v in gv.items()}, {k: v.copy() for k, v in dv.items()})
+        out[rank] = (res, {k: v.copy() for k, v in gv.items()}, {k: v.copy() for k, v in dv.items()}, status)
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_equal_two_towers():
+def _two_rank_case(ref_size):
+    if not ref_size:
+        return small_cfg("lstm"), 3, 7
+    from oracle import rsrgan_oracle as O
+    return O.NetCfg(), 32, 9            # the reference's networks, one 32-row group per rank: every recurrence a persistent launch
+
+
+@pytest.mark.parametrize("ref_size", [False, True])
+def test_two_ranks_on_one_gpu_equal_two_towers(ref_size):
     """SURVEY 8e determinism check on the HIP engine with world_size 2: must equal the oracle run as 2 in-graph towers and the
     1-rank HIP run on the concatenated batch (tower mean of tower-mean gradients = gradient of the overall mean), replicas
-    bit-identical (models/gan_rnn_placeholder.py:157-184)."""
+    bit-identical (models/gan_rnn_placeholder.py:157-184).  ref_size: the reference's networks at B = 32 per rank -- the size at
+    which the generator's recurrences are the persistent launches of csrc/gpersist.hip, so the multi-rank sequence g_backward(apply
+    =False) -> bucket events -> communication stream -> join -> apply runs around k_glstm_bwd and the bucket order behind it; the two
+    processes' launches (2 x 114 + the discriminator's workgroups) share one device and no bounded wait may expire."""
     import torch.multiprocessing as mp
     from oracle import rsrgan_oracle as O
     from rsrgan_amd import GAN_RNN, train_one_iteration
@@ -125,18 +138,23 @@ def test_two_ranks_on_one_gpu_equal_two_towers():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_two_rank_worker, args=(world, port, out), nprocs=world, join=True)
-    cfg = small_cfg("lstm")
-    B, T = 3, 7
+    mp.spawn(_two_rank_worker, args=(world, port, out, ref_size), nprocs=world, join=True)
+    cfg, B, T = _two_rank_case(ref_size)
     g, d = rand_params(cfg, 5)
     batches = [rand_batch(cfg, B * world, T, 60 + i, ragged=True) for i in range(3)]
     ref = O.GanRnnOracle(cfg, g, d, batch_size=B, num_towers=world,
                          g_learning_rate=float(np.float32(8e-5 * world)), d_learning_rate=float(np.float32(1e-3 * world)))
     want = O.train_one_iteration(ref, batches, 1, 2)
     for r in range(world):
-        res, gv, dv = out[r]
-        assert np.allclose(res, want, rtol=1e-4), (r, res, want)
+        res, gv, dv, status = out[r]
+        assert status == 0, (r, status)
+        assert np.allclose(res, want, rtol=1e-3 if ref_size else 1e-4), (r, res, want)
         for k in ref.g:
+            # (Adam moves an element by ~lr whatever its gradient's size: at the reference's sizes a few of the 5.8 M elements have
+            #  gradients below fp32 noise and step the other way -- bounded by the steps taken, rare in the mean)
+            if ref_size:
+                assert np.abs(gv[k] - ref.g[k]).max() <= 6 * 2 * 8e-5 * world and np.abs(gv[k] - ref.g[k]).mean() <= 2e-6, k
+                continue
             assert np.abs(gv[k] - ref.g[k]).max() <= 1e-5 * max(1.0, np.abs(ref.g[k]).max()), k
         for k in ref.d:
             assert np.abs(dv[k] - ref.d[k]).max() <= 1e-5 * max(1.0, np.abs(ref.d[k]).max()), k
@@ -147,7 +165,80 @@ def test_two_ranks_on_one_gpu_equal_two_towers():
                   ["gpu:0"], max_frames=T, net_overrides=dict(overrides(cfg), flags=3))
     one.set_vars(g, d)
     res1 = train_one_iteration(None, one, len(batches), 0, [[None] + list(b) for b in batches])
-    assert np.allclose(res1, out[0][0], rtol=1e-4)
+    assert np.allclose(res1, out[0][0], rtol=1e-3 if ref_size else 1e-4)
+    assert one.engine.device_status() == 0
     gv1, dv1 = one.get_vars()
     for k in gv1:
+        if ref_size:
+            assert np.abs(gv1[k] - out[0][1][k]).max() <= 6 * 2 * 8e-5 * world and np.abs(gv1[k] - out[0][1][k]).mean() <= 2e-6, k
+            continue
         assert np.abs(gv1[k] - out[0][1][k]).max() <= 2e-6 * max(1.0, np.abs(gv1[k]).max()), k
+
+
+@pytest.mark.parametrize("B,T", [(32, 9), (64, 100)])
+def test_dp_sequence_around_the_persistent_launches(B, T):
+    """VERDICT r4 item 4.  At the reference's sizes the generator's BPTT is ONE persistent launch (csrc/gpersist.hip k_glstm_bwd) and
+    the gradient buckets complete behind it in another order than on the launch-per-phase path.  The multi-rank sequence
+    g_backward(apply=False) -> per-bucket events -> all-reduce on the communication stream -> join -> apply must give the bits of
+    the fused single-rank g_step for three updates -- with NOTHING else on the device, and with collectives of a 24 MB buffer looping on
+    a second stream for the whole run (world 1: RCCL's out-of-place all-reduce is a device copy kernel; the reductions of a real
+    multi-rank run cannot be had on one GPU: RCCL refuses two ranks per device).  No bounded wait may expire either way."""
+    import threading
+    import torch.distributed as dist
+    from oracle import rsrgan_oracle as O
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    stop = threading.Event()
+    try:
+        cfg = O.NetCfg()
+        fused, _ = build_hip_pair(cfg, B, T, seed=81, flags=3)
+        dp, _ = build_hip_pair(cfg, B, T, seed=81, flags=3)
+        busy, _ = build_hip_pair(cfg, B, T, seed=81, flags=3)
+        assert len(dp.engine.grad_buckets(NET_G)) == cfg.g_layers + 2
+
+        def run(m, mode):
+            m.engine.profile_launches()
+            for it in range(3):
+                x, lab, ln = rand_batch(cfg, B, T, seed=90 + it, ragged=True)
+                if mode == "fused":
+                    m.d_step(x, lab, ln); m.g_step(x, lab, ln, reuse_g_forward=True)
+                else:
+                    m.engine.d_backward(x, lab, ln, train=True, apply=False)
+                    m.engine.all_reduce_grads(NET_D, force=True); m.engine.apply(NET_D)
+                    m.engine.g_backward(x, lab, ln, train=True, reuse=True, apply=False)
+                    m.engine.all_reduce_grads(NET_G, force=True); m.engine.apply(NET_G)
+            assert m.engine.device_status() == 0
+            return m.get_vars()
+
+        va = run(fused, "fused")
+        vb = run(dp, "dp")
+
+        def comm_load():
+            st = torch.cuda.Stream()
+            src = torch.ones(6 << 20, device="cuda"); dst = torch.empty_like(src)
+            with torch.cuda.stream(st):
+                while not stop.is_set():
+                    for _ in range(16):
+                        dist.all_reduce(src); dist.all_gather_into_tensor(dst, src); dst.add_(src)
+                    st.synchronize()
+        th = threading.Thread(target=comm_load, daemon=True); th.start()
+        import time; time.sleep(0.2)
+        vc = run(busy, "dp")
+        stop.set(); th.join(timeout=20)
+        for p_, q_, r_ in zip(va, vb, vc):
+            for k in p_:
+                assert np.array_equal(p_[k], q_[k]), ("dp", k)
+                assert np.array_equal(p_[k], r_[k]), ("dp, busy communication stream", k)
+        # the persistent launches are what ran: one k_glstm_fwd + one k_glstm_bwd per iteration
+        dp.engine.profile_begin()
+        x, lab, ln = rand_batch(cfg, B, T, seed=99, ragged=True)
+        dp.engine.d_backward(x, lab, ln, train=True, apply=False)
+        dp.engine.g_backward(x, lab, ln, train=True, reuse=True, apply=False)
+        n = dp.engine.profile_read_kind(1)[0] + dp.engine.profile_read_kind(2)[0]
+        dp.engine.profile_read()
+        assert n == 2, n
+    finally:
+        stop.set()
+        dist.destroy_process_group()

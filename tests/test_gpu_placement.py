@@ -65,7 +65,9 @@ print("RESULT " + json.dumps(out))
 
 
 def _run(env):
-    e = dict(os.environ); e.update(env)
+    e = dict(os.environ)
+    e.setdefault("RSRGAN_PAD_ROWS", "0")      # (these cases choose B to pick a path: no silent padding up to the persistent kernels' 32 rows)
+    e.update(env)
     p = subprocess.run([sys.executable, "-c", WORKER], capture_output=True, text=True, env=e, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]

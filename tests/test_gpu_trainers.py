@@ -126,8 +126,9 @@ def test_dnn_trainer_matches_oracle(case):
     gv, _ = m.get_vars()
     for k in o.g:
         # (Adam divides by sqrt(v): an element whose gradient is a few ulps of noise still moves by ~lr per step, so after three
-        # updates a small tensor such as a bias row differs by rounding-sized gradients times 1 / sqrt(v): 1.0e-3 was observed)
-        assert rel_err(gv[k], o.g[k]) < 2e-3, k
+        # updates a small tensor such as a bias row differs by rounding-sized gradients times 1 / sqrt(v): 1.0e-3 was observed at the
+        # configs[0] size only -- the toy cases keep the tighter bound)
+        assert rel_err(gv[k], o.g[k]) < (2e-3 if case.startswith("configs0") else 1e-3), k
 
 
 def test_training_converges_on_a_learnable_task():

@@ -104,3 +104,56 @@ def test_frame_level_loops_write_train_and_eval_events(tmp_path):
     m2 = _Model(None); m2._open_writer(SimpleNamespace())
     m3 = _Model(str(tmp_path / "x")); m3._open_writer(SimpleNamespace(write_summaries=False))
     assert m2.writer is None and m3.writer is None and not os.path.exists(tmp_path / "x")
+
+
+class _FrameEngine:
+    """the slice of the engine protocol a frame-level trainer's summary fetch touches (recording stand-in, CPU)"""
+    ema_enabled = False
+    device = "cpu"
+
+    def __init__(self):
+        self.calls = []
+
+    def set_scalar(self, k, v):
+        pass
+
+    def g_backward(self, x, lab, ln, noise_fake=None, train=True, reuse=False, apply=False):
+        import torch
+        self.calls.append(("g_backward", train, apply))
+        return torch.tensor([0.0, 2.0, 0.5, 2.5])
+
+    def forward_g(self, x, ln):
+        import torch
+        return torch.as_tensor(np.asarray(x))[:, :, :1] * 2
+
+
+def test_trainers_fetch_summaries_without_a_collective(tmp_path):
+    """Model.run_summaries unpacks (d, g, x, labels, y); RNNTrainer / DNNTrainer must honour that contract and fetch
+    through the engine directly (g_step all-gathers the towers' losses: a rank-0-only call would hang the other ranks)."""
+    import torch
+    from tests.helpers import OracleEngine, args_for, rand_batch, rand_params, small_cfg
+    from rsrgan_amd.trainer import DNNTrainer, RNNTrainer
+    cfg = small_cfg("lstm")
+    g, d = rand_params(cfg, 3)
+    eng = OracleEngine(cfg, g, d, 4)
+    m = RNNTrainer(None, args_for(cfg, 4, save_dir=str(tmp_path / "rnn")), ["cpu"], engine=eng, max_frames=6)
+    m._towers = None                                            # any gather in the fetch would blow up here
+    x, lab, ln = rand_batch(cfg, 4, 6, seed=5, ragged=True)
+    blob = m.run_summaries(x, lab, ln)
+    m.writer.add_summary(blob, 7); m.writer.close()
+    ev = S.read_events(m.writer.path)
+    assert ev[1][1] == 7 and [ev[1][2][t] for t in S.LOSS_TAGS[:3]] == [0.0, 0.0, 0.0]
+    assert ev[1][2]["g_loss"] > 0 and ev[1][2]["real_clean"]["num"] == x.size and ev[1][2]["real_noise"]["num"] == lab.size and ev[1][2]["g_clean"]["num"] == 4 * 6 * cfg.output_dim
+    fe = _FrameEngine()
+    from types import SimpleNamespace
+    a = SimpleNamespace(batch_size=4, input_dim=3, output_dim=1, g_type="dnn", save_dir=str(tmp_path / "dnn"))
+    t = DNNTrainer(None, a, ["cpu"], engine=fe)
+    xb = np.arange(12, dtype=np.float32).reshape(4, 3)
+    blob = t.run_summaries(xb, np.zeros((4, 1), np.float32))
+    t.writer.add_summary(blob, 3); t.writer.close()
+    ev = S.read_events(t.writer.path)
+    assert fe.calls == [("g_backward", False, False)]
+    assert ev[1][2]["g_loss"] == 2.5 and ev[1][2]["d_loss"] == 0.0 and ev[1][2]["g_clean"]["max"] == 18.0
+    with np.testing.assert_raises(RuntimeError):
+        t.d_step(xb, xb)
+    del torch
