@@ -48,6 +48,14 @@ constexpr int GP_R1 = 3;                 // steps in the hop-1 ring: a slot is s
 constexpr int GP_NCH = GP_NKB * GP_NR;   // chunk slots per layer and step (the layout's stride; a layer uses its first nkb * NR)
 constexpr unsigned GP_SC1 = 16u;         // aux of the raw-buffer builtins: sc1 (agent scope: write-through store / L1-bypassing load)
 constexpr unsigned GP_VOL = 1u << 31;    // ... compiler-only: volatile (a polled load must not be hoisted out of its loop)
+#ifndef GP_GATE_NUM                      // progressive sweeps start reading when GP_GATE_NUM / GP_GATE_DEN of the awaited sentinel pieces are there
+#define GP_GATE_NUM 1
+#define GP_GATE_DEN 2
+#endif
+#ifndef GP_HB10                          // pieces per round trip of a progressive pass (hop 1: 10 per lane, hop 2: 9)
+#define GP_HB10 10
+#define GP_HB9 9
+#endif
 
 #ifdef GP_TRACE
 __device__ unsigned g_gp_cnt[8];          // (GP_COUNT builds only: the atomics distort the timeline)          // [0] cached first reads, [1] of them with a stale / missing tag; [2], [3] the same for write-through first reads
@@ -205,6 +213,68 @@ __device__ __forceinline__ bool gp_sweep(const GpBuf& b, const unsigned (&lo)[NL
   }
 }
 
+// The PROGRESSIVE form of a sweep (round 5).  gp_sweep above costs a hand-off two round trips after the last piece has landed -- the
+// poll that notices it, then the full read (10 pieces per lane: ~4.5 k cycles of the forward period for hop 1, ~2.5 k for hop 2,
+// profiles/r4_gpersist_trace.txt "sentinels only") -- although most of the pieces arrived long before the last one (the producers
+// finish 7-9 k cycles apart).  Here the data is its own flag all the way: once `gate` of the awaited sentinel pieces are there (cheap
+// polling until then: a lane per producer, as before -- a wave that arrives early must not spin on full reads, that is what
+// saturated the fabric in the first version), every pass reads the pieces that are still PENDING, keeps the ones that came back
+// valid in registers, and asks again for the rest only: a finished piece's load is sent to an out-of-range offset (a raw-buffer load
+// beyond num_records returns zeros without a memory access).  What is left behind the last arrival is one round trip of the one or
+// two pieces that were missing.  out[] is complete and in slot order when the function returns, so the caller's sum keeps its fixed
+// order whatever the arrival order was.  nlw: wave-uniform number of pieces (>= every lane's nl).
+template <int NL, int HB>
+__device__ __forceinline__ bool gp_sweep_prog(const GpBuf& b, const unsigned (&lo)[NL], int nl, int nlw, unsigned lane_off, unsigned so, bool son,
+                                              int gate, gu32* err, f32x4 (&out)[NL]) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  unsigned of[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) of[k] = (unsigned)__builtin_amdgcn_readfirstlane((int)lo[k]);
+  if (gate > 0) {
+    for (unsigned polls = 0;; ++polls) {
+      const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(b.rs, so, 0, GP_SC1 | GP_VOL);
+      if (__popcll(__ballot(son && gp_valid(y))) >= gate) break;
+      asm volatile("" ::: "memory");
+      if ((polls & 63) == 63) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  unsigned pend = (unsigned)__builtin_amdgcn_readfirstlane((int)((1u << nlw) - 1u));
+  for (unsigned pass = 0;; ++pass) {
+#pragma unroll
+    for (int k0 = 0; k0 < NL; k0 += HB) {
+      if (((pend >> k0) & ((1u << HB) - 1u)) == 0u) continue;                       // (uniform)
+      u32x4 t[HB];
+#pragma unroll
+      for (int j = 0; j < HB; ++j) {
+        const int k = k0 + j < NL ? k0 + j : NL - 1;
+        const bool want = k0 + j < NL && ((pend >> k) & 1u) && k < nl;
+        t[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, want ? of[k] + lane_off : OOB, 0, GP_SC1 | GP_VOL);   // (unconditional)
+      }
+#pragma unroll
+      for (int j = 0; j < HB; ++j) {
+        const int k = k0 + j;
+        if (k < NL) {
+          const bool ok = __all(k >= nl || gp_valid(t[j]));
+          if (((pend >> k) & 1u) && ok) {                                              // (uniform)
+            out[k] = f32x4{__uint_as_float(t[j][0]), __uint_as_float(t[j][1]), __uint_as_float(t[j][2]), __uint_as_float(t[j][3])};
+            pend &= ~(1u << k);
+          }
+        }
+      }
+    }
+    if (pend == 0u) return true;
+    asm volatile("" ::: "memory");
+    if ((pass & 31) == 31) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 // LDS of a workgroup (NT = 5: 129 KB)
 template <int NT>
 struct GpLds {
@@ -219,7 +289,8 @@ struct GpLds {
   unsigned cnt_x[GP_NR][4], cnt_p[GP_NR], cnt_h[GP_NR], cnt_m[GP_NR], cnt_g[GP_NR], cnt_s[GP_NR], dead, pad_[13];
 };
 
-template <int NT>
+// PROG: bit 0 the reducers' hop-1 sweeps, bit 1 the gathers of hop 2 in the progressive form (gp_sweep_prog); RSRGAN_GP_PROG
+template <int NT, int PROG>
 __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S) {
   constexpr int NR = GP_NR, NU = NT * NR, CW = 4 * NT;
   GPT_DECL
@@ -550,7 +621,13 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
 #pragma unroll
       for (int k = 0; k < 10; ++k) lo[k] = slot1(par1, r, jbr, min(pp0 + 2 * k, NC - 1)) + (unsigned)hh * 512u;
       f32x4 sa = {0.f, 0.f, 0.f, 0.f};
-      if (!gp_sweep<10, true, 10, false>(b1, lo, nlr, pair_off, slot1(par1, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
+      if (PROG & 1) {
+        f32x4 pv[10];
+        if (!gp_sweep_prog<10, GP_HB10>(b1, lo, nlr, (pn + 1) >> 1, pair_off, slot1(par1, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn,
+                                  (pn * GP_GATE_NUM) / GP_GATE_DEN, err, pv)) { fail(); return; }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) { if (k == 0) sa = k < nlr ? pv[0] : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) sa += pv[k]; }      // (slot order: the same bits as the other form)
+      } else if (!gp_sweep<10, true, 10, false>(b1, lo, nlr, pair_off, slot1(par1, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
                                   [&](int k, const f32x4& v) { if (k == 0) sa = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) sa += v; })) { fail(); return; }
       GPT(15);
       *reinterpret_cast<f32x4*>(&S.gs[par][r][gp][lane][0]) = sa;
@@ -573,7 +650,10 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
 #pragma unroll
       for (int n = 0; n < 9; ++n) lo[n] = slot2(t, r, min(gp + 2 * n, nkb - 1));
       f32x4 mv[9];
-      if (!gp_sweep<9, true, 9, true>(b2, lo, nvg, frag_off, slot2(t, r, min(gp + 2 * (lane >> 1), nkb - 1)) + (unsigned)(lane & 1) * 512u + 496u,
+      if (PROG & 2) {
+        if (!gp_sweep_prog<9, GP_HB9>(b2, lo, nvg, nvg, frag_off, slot2(t, r, min(gp + 2 * (lane >> 1), nkb - 1)) + (unsigned)(lane & 1) * 512u + 496u,
+                                 lane < 2 * nvg, (2 * nvg * GP_GATE_NUM) / GP_GATE_DEN, err, mv)) { fail(); return; }
+      } else if (!gp_sweep<9, true, 9, true>(b2, lo, nvg, frag_off, slot2(t, r, min(gp + 2 * (lane >> 1), nkb - 1)) + (unsigned)(lane & 1) * 512u + 496u,
                                  lane < 2 * nvg, err, [&](int k, const f32x4& v) { mv[k] = v; })) { fail(); return; }
       GPT(17);
       const bool live = t < lenr;
@@ -597,12 +677,12 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
 #endif
 }
 
-template <int NT>
+template <int NT, int PROG>
 __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_fwd(const GPersistArgs a) {
   __shared__ __attribute__((aligned(16))) GpLds<NT> S;
   gu32* ctl = (gu32*)a.ctl;
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (counts launches; nothing depends on it)
-  gp_fwd_body<NT>(a, S);
+  gp_fwd_body<NT, PROG>(a, S);
   __syncthreads();                                                 // (every wave leaves the body on every path)
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -666,7 +746,7 @@ __device__ __forceinline__ bool gp_poll(const GpBuf& b, unsigned so, bool son, g
   }
 }
 
-template <int NT>
+template <int NT, int PROG>
 __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S) {
   constexpr int NR = GP_NR, CW = 4 * NT;
   GPT_DECL
@@ -1072,7 +1152,13 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
 #pragma unroll
         for (int k = 0; k < 10; ++k) lo[k] = slot1((s + GP_R1 - 1) % GP_R1, r, jbr, min(pp0 + 2 * k, NC - 1)) + (unsigned)hh * 512u;
         f32x4 ua = {0.f, 0.f, 0.f, 0.f};
-        if (!gp_sweep<10, true, 10, false>(b1, lo, nlr, pair_off, slot1((s + GP_R1 - 1) % GP_R1, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
+        if (PROG & 1) {
+          f32x4 pv[10];
+          if (!gp_sweep_prog<10, GP_HB10>(b1, lo, nlr, (pn + 1) >> 1, pair_off, slot1((s + GP_R1 - 1) % GP_R1, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn,
+                                    (pn * GP_GATE_NUM) / GP_GATE_DEN, err, pv)) { fail(); return; }
+#pragma unroll
+          for (int k = 0; k < 10; ++k) { if (k == 0) ua = k < nlr ? pv[0] : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) ua += pv[k]; }
+        } else if (!gp_sweep<10, true, 10, false>(b1, lo, nlr, pair_off, slot1((s + GP_R1 - 1) % GP_R1, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
                                     [&](int k, const f32x4& v) { if (k == 0) ua = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) ua += v; })) { fail(); return; }
         sa += ua;
       }
@@ -1095,7 +1181,10 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
 #pragma unroll
       for (int n = 0; n < 9; ++n) lo[n] = slot2(t, r, min(gp + 2 * n, nkb - 1));
       f32x4 mv[9];
-      if (!gp_sweep<9, true, 9, true>(b2, lo, nvg, frag_off, slot2(t, r, min(gp + 2 * (lane >> 1), nkb - 1)) + (unsigned)(lane & 1) * 512u + 496u,
+      if (PROG & 2) {
+        if (!gp_sweep_prog<9, GP_HB9>(b2, lo, nvg, nvg, frag_off, slot2(t, r, min(gp + 2 * (lane >> 1), nkb - 1)) + (unsigned)(lane & 1) * 512u + 496u,
+                                 lane < 2 * nvg, (2 * nvg * GP_GATE_NUM) / GP_GATE_DEN, err, mv)) { fail(); return; }
+      } else if (!gp_sweep<9, true, 9, true>(b2, lo, nvg, frag_off, slot2(t, r, min(gp + 2 * (lane >> 1), nkb - 1)) + (unsigned)(lane & 1) * 512u + 496u,
                                  lane < 2 * nvg, err, [&](int k, const f32x4& v) { mv[k] = v; })) { fail(); return; }
       GPTSG(16);
 #pragma unroll
@@ -1113,12 +1202,12 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
 #endif
 }
 
-template <int NT>
+template <int NT, int PROG>
 __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_bwd(const GPersistArgs a) {
   __shared__ __attribute__((aligned(16))) GpLdsB<NT> S;
   gu32* ctl = (gu32*)a.ctl;
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (counts launches)
-  gp_bwd_body<NT>(a, S);
+  gp_bwd_body<NT, PROG>(a, S);
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1215,14 +1304,18 @@ void gpersist_arm(const GPersistArgs& a, hipStream_t s) {
   (void)hipMemsetAsync(a.gran1, 0xFF, gpersist_gran1_bytes(a), s);
   if (a.gran3) (void)hipMemsetAsync(a.gran3, 0xFF, gpersist_gran3_bytes(a), s);
 }
+// (-DGP_PROG_ONLY=mask: the progressive sweeps, gp_sweep_prog -- the harness only: measured slower, profiles/r5_gpersist_progressive_sweep_negative.txt)
+#ifndef GP_PROG_ONLY
+#define GP_PROG_ONLY 0
+#endif
 void launch_glstm_fwd(const GPersistArgs& a, hipStream_t s) {
   (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_gran2_bytes(a), s);
-  hipLaunchKernelGGL(k_glstm_fwd<5>, dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
+  hipLaunchKernelGGL((k_glstm_fwd<5, GP_PROG_ONLY>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
   ++g_chain_launches;
 }
 void launch_glstm_bwd(const GPersistArgs& a, hipStream_t s) {
   (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_gran2_bytes(a), s);
-  hipLaunchKernelGGL(k_glstm_bwd<5>, dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
+  hipLaunchKernelGGL((k_glstm_bwd<5, GP_PROG_ONLY>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
   ++g_chain_launches;
 }
 
