@@ -290,7 +290,11 @@ struct GpLds {
 };
 
 // PROG: bit 0 the reducers' hop-1 sweeps, bit 1 the gathers of hop 2 in the progressive form (gp_sweep_prog); RSRGAN_GP_PROG
-template <int NT, int PROG>
+// RES: a residual stack (models/res_lstm_l.py:101-194): layer l + 1 reads s_l = out_l + s_{l-1} instead of out_l (s_{-1} = the stack's
+// input).  The reducer of a half chunk is also the owner of that half chunk of the running sum: it adds its masked m(t) to the half
+// chunk of s_{l-1}(t) (layer 0: the input rows in memory; above: what the same-numbered reducer of the layer below published a step
+// ago), writes it to res_out and publishes it in the second region of gran2, where the layer above's X waves gather their x(t).
+template <int NT, int PROG, bool RES>
 __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S) {
   constexpr int NR = GP_NR, NU = NT * NR, CW = 4 * NT;
   GPT_DECL
@@ -314,7 +318,10 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
   const size_t g1_per = (size_t)GP_NCH * NC * GP_SLOT, g2_per = (size_t)GP_NCH * GP_SLOT;
   const GpBuf b1 = gp_buf((const char*)a.gran1 + (size_t)(grp * a.nl + l) * GP_R1 * g1_per, GP_R1 * g1_per);
   const GpBuf b2 = gp_buf((const char*)a.gran2 + (size_t)(grp * a.nl + l) * T * g2_per, (size_t)T * g2_per);
-  const GpBuf b2x = gp_buf((const char*)a.gran2 + (size_t)(grp * a.nl + (l > 0 ? l - 1 : 0)) * T * g2_per, (size_t)T * g2_per);
+  // what the layer above gathers as its x(t): the m chunks themselves, or (RES) the running sums in the second region
+  const char* const g2x = RES ? (const char*)a.gran2 + (size_t)ngr * a.nl * T * g2_per : (const char*)a.gran2;
+  const GpBuf b2x = gp_buf(g2x + (size_t)(grp * a.nl + (l > 0 ? l - 1 : 0)) * T * g2_per, (size_t)T * g2_per);
+  const GpBuf b2s = gp_buf(g2x + (size_t)(grp * a.nl + l) * T * g2_per, (size_t)T * g2_per);      // (RES: where this layer publishes s_l)
   const unsigned frag_off = (unsigned)lane * 16u;                     // a fragment lane's bytes in a chunk slot
   const unsigned pair_off = (unsigned)((lane >> 5) * GP_SLOT + (lane & 31) * 16);   // reducer: lanes 0..31 read producer p's half chunk, lanes 32..63 producer p + 1's
   auto slot1 = [&](int par, int r, int jb, int p) { return (unsigned)((((size_t)(par * NR + r) * GP_NKB + jb) * NC + p) * GP_SLOT); };
@@ -514,13 +521,14 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
           // time-batched GEMM in front of the launch, 136 us; these waves and 60 % of the MFMA pipe were idle.)
           const float* xr = L.in + ((size_t)t * N + row0 + 16 * r + lr) * L.ldI;
 #pragma unroll
+          // (rows are zero beyond column I up to ldI, kernels.h layout rule: a piece may straddle I -- res_lstm_l's 257 columns)
           for (int jj = 0; jj < GP_KBW; ++jj)                            // (all five in flight, unconditional)
-            xv[jj] = *reinterpret_cast<const f32x4*>(xr + min(16 * min(xw + 4 * jj, nkbx - 1) + 4 * q, I - 4));
+            xv[jj] = *reinterpret_cast<const f32x4*>(xr + min(16 * min(xw + 4 * jj, nkbx - 1) + 4 * q, L.ldI - 4));
           asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]));
           static_assert(GP_KBW == 5, "the five pieces above");
 #pragma unroll
           for (int jj = 0; jj < GP_KBW; ++jj)
-            if (16 * min(xw + 4 * jj, nkbx - 1) + 4 * q >= I) xv[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (16 * min(xw + 4 * jj, nkbx - 1) + 4 * q >= L.ldI) xv[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
         } else if (!gp_sweep<GP_KBW, false, GP_KBW, true>(b2x, lo, nsx, frag_off, slot2(t, r, min(xw + 4 * (lane >> 1), nkbx - 1)) + (unsigned)(lane & 1) * 512u + 496u,
                                                     lane < 2 * nsx, err, [&](int k, const f32x4& v) { xv[k] = v; })) { fail(); return; }
         GPT(19 + 2 * r);
@@ -671,18 +679,43 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
         *reinterpret_cast<float4*>(L.out + ((size_t)t * N + rrow) * ldP + rcol) = live ? make_float4(tot[0], tot[1], tot[2], tot[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+    if (RES && reducer && gp == 1) {
+      // s_l(t) = out_l(t) + s_{l-1}(t) of this half chunk (res_lstm_l.py:111,121,131,190); the layer above is a step behind, so this
+      // sits behind the hand-offs as well.  s_{l-1}(t) was published before this layer's X waves could gather x(t): no real wait.
+      const bool act = lane < 32;
+      const unsigned off = slot2(t, r, jbr) + (unsigned)hh * 512u + (unsigned)(lane & 31) * 16u;
+      f32x4 sb;
+      if (l == 0) {
+        const float4 v = *reinterpret_cast<const float4*>(L.in + ((size_t)t * N + rrow) * L.ldI + min(rcol, L.ldI - 4));
+        sb = rcol < L.ldI ? f32x4{v.x, v.y, v.z, v.w} : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        u32x4 y;
+        for (unsigned polls = 0;; ++polls) {
+          y = __builtin_amdgcn_raw_buffer_load_b128(b2x.rs, off, 0, GP_SC1 | GP_VOL);
+          if (__all(!act || gp_valid(y))) break;
+          asm volatile("" ::: "memory");
+          if ((polls & 63) == 63 && (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { fail(); return; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        sb = f32x4{__uint_as_float(y[0]), __uint_as_float(y[1]), __uint_as_float(y[2]), __uint_as_float(y[3])};
+      }
+      const f32x4 s4 = (t < rlen ? tot : f32x4{0.f, 0.f, 0.f, 0.f}) + sb;
+      if (act && rcol < ldP) *reinterpret_cast<float4*>(L.res_out + ((size_t)t * N + rrow) * ldP + rcol) = make_float4(s4[0], s4[1], s4[2], s4[3]);
+      if (act && l + 1 < a.nl) gp_store(b2s, off, s4);
+    }
   }
 #ifdef GP_TRACE
   if (gw == 0) { const int i0_ = 12, i1_ = 18; GPT_FLUSH(); }
 #endif
 }
 
-template <int NT, int PROG>
+template <int NT, int PROG, bool RES>
 __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_fwd(const GPersistArgs a) {
   __shared__ __attribute__((aligned(16))) GpLds<NT> S;
   gu32* ctl = (gu32*)a.ctl;
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (counts launches; nothing depends on it)
-  gp_fwd_body<NT, PROG>(a, S);
+  gp_fwd_body<NT, PROG, RES>(a, S);
   __syncthreads();                                                 // (every wave leaves the body on every path)
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -746,7 +779,46 @@ __device__ __forceinline__ bool gp_poll(const GpBuf& b, unsigned so, bool son, g
   }
 }
 
-template <int NT, int PROG>
+// One wave sums the half chunks of ALL NC producers at base + p * GP_SLOT (off the critical path: a plain loop, four loads in flight --
+// the unrolled gp_sweep over 20 pieces cost the backward kernel 8 spilled registers): even producers in lanes 0..31, odd ones in
+// 32..63, then the two halves (even first); every lane ends with the total of its (lane & 31) piece.  false: time-out / peer failure.
+__device__ __forceinline__ bool gp_sum_all(const GpBuf& b, unsigned base, int NC, int lane, gu32* err, f32x4& out) {
+  if (!gp_poll(b, base + (unsigned)min(lane, NC - 1) * GP_SLOT + 496u, lane < NC, err)) return false;
+  f32x4 sa = {0.f, 0.f, 0.f, 0.f};
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (int k0 = 0; 2 * k0 < NC; k0 += 4) {
+    for (;;) {
+      u32x4 x[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        x[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, base + (unsigned)min(2 * (k0 + j) + (lane >> 5), NC - 1) * GP_SLOT + (unsigned)(lane & 31) * 16u, 0, GP_SC1 | GP_VOL);
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ok &= (2 * (k0 + j) + (lane >> 5) >= NC) || gp_valid(x[j]);
+      if (__all(ok)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (2 * (k0 + j) + (lane >> 5) < NC) sa += f32x4{__uint_as_float(x[j][0]), __uint_as_float(x[j][1]), __uint_as_float(x[j][2]), __uint_as_float(x[j][3])};
+        break;
+      }
+      asm volatile("" ::: "memory");
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  f32x4 sb;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sb[i] = __shfl_xor(sa[i], 32);
+  out = lane < 32 ? sa + sb : sb + sa;                                   // (even-producer half first, in both halves of the wave)
+  return true;
+}
+
+// RES (residual stack, see gp_fwd_body): the gradient of the running sum s_l is what layer l's outputs AND, unchanged, the layer
+// below receive: D_l(t) = D_{l+1}(t) + dz_{l+1}(t) . K_x^T, D_top = d(outputs of the stack).  The reducer of a half chunk owns that half
+// chunk of D: its second G wave sums ALL input-gradient partials of the layer above (alone: the sum is needed on its own), adds the
+// D_{l+1}(t) piece the same-numbered reducer above published a step ago, hands D_l(t) into the state-gradient sum and publishes it
+// for the layer below in the second region of gran2 (one slot per step, behind the hand-offs).
+template <int NT, int PROG, bool RES>
 __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S) {
   constexpr int NR = GP_NR, CW = 4 * NT;
   GPT_DECL
@@ -773,6 +845,10 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
   // gran3 holds nl + 1 rings per row group: ring l + 1 = what layer l + 1 hands to layer l, ring 0 = what layer 0 hands to its OWN reducers
   const GpBuf b3 = gp_buf((const char*)a.gran3 + (size_t)(grp * (a.nl + 1) + l + 1) * GP_XR * g1_per, GP_XR * g1_per);      // what the layer above hands to this one
   const GpBuf b3x = gp_buf((const char*)a.gran3 + (size_t)(grp * (a.nl + 1) + l) * GP_XR * g1_per, GP_XR * g1_per);         // what this layer hands down
+  // (RES) the gradients of the running sums, second region of gran2: this layer's D_l for the layer below, D_{l+1} from the layer above
+  const char* const g2d = (const char*)a.gran2 + (size_t)ngr * a.nl * T * g2_per;
+  const GpBuf b2d = gp_buf(g2d + (size_t)(grp * a.nl + l) * T * g2_per, (size_t)T * g2_per);
+  const GpBuf b2du = gp_buf(g2d + (size_t)(grp * a.nl + (top ? l : l + 1)) * T * g2_per, (size_t)T * g2_per);
   // Layer 0's input gradient dz_0 . K_x^T (the input FC's d(h0): until round 4 a time-batched GEMM behind the launch, 126 us): its X
   // waves -- idle otherwise -- run the same product as every other layer's and publish it to a ring of their own (ring 0); the
   // layer's reducers, which spend most of a step waiting for the layers above, sum it one step late and write it to din0.
@@ -1094,36 +1170,8 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
   // layer 0's input gradient of step sx (time T-1-sx): all NC partials of this half chunk, tile r, by ONE wave (gp == 0; off the
   // critical path, no exchange with the other G wave), even producers in lanes 0..31, odd ones in 32..63, then the two halves
   auto sum_dx0 = [&](int sx) -> bool {
-    // (a plain loop, four loads in flight: the unrolled gp_sweep over 20 pieces cost the kernel 8 spilled registers, and this sum has
-    // a whole step of slack)
-    const unsigned base = slot1(sx % GP_XR, r, jbr, 0) + (unsigned)hh * 512u;
-    if (!gp_poll(b3x, base + (unsigned)min(lane, NC - 1) * GP_SLOT + 496u, lane < NC, err)) return false;
-    f32x4 sa = {0.f, 0.f, 0.f, 0.f};
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (int k0 = 0; 2 * k0 < NC; k0 += 4) {
-      for (;;) {
-        u32x4 x[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          x[j] = __builtin_amdgcn_raw_buffer_load_b128(b3x.rs, base + (unsigned)min(2 * (k0 + j) + (lane >> 5), NC - 1) * GP_SLOT + (unsigned)(lane & 31) * 16u, 0, GP_SC1 | GP_VOL);
-        bool ok = true;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ok &= (2 * (k0 + j) + (lane >> 5) >= NC) || gp_valid(x[j]);
-        if (__all(ok)) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (2 * (k0 + j) + (lane >> 5) < NC) sa += f32x4{__uint_as_float(x[j][0]), __uint_as_float(x[j][1]), __uint_as_float(x[j][2]), __uint_as_float(x[j][3])};
-          break;
-        }
-        asm volatile("" ::: "memory");
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-        __builtin_amdgcn_s_sleep(4);
-      }
-    }
-    f32x4 sb;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) sb[i] = __shfl_xor(sa[i], 32);
-    const f32x4 tt = lane < 32 ? sa + sb : sb + sa;                      // (even-producer half first, in both halves of the wave)
+    f32x4 tt;
+    if (!gp_sum_all(b3x, slot1(sx % GP_XR, r, jbr, 0) + (unsigned)hh * 512u, NC, lane, err, tt)) return false;
     if (lane < 32 && rcol < a.ld_din0)
       *reinterpret_cast<float4*>(a.din0 + ((size_t)(T - 1 - sx) * N + rrow) * a.ld_din0 + rcol) = make_float4(tt[0], tt[1], tt[2], tt[3]);
     gp_signal(cnt + C_D + r, lane);
@@ -1133,11 +1181,36 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
     const int t = T - 1 - s;
     GPTSG(12);
     f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+    f32x4 Dl = {0.f, 0.f, 0.f, 0.f};                                     // (RES, second G wave) D_l(t) of this lane's four columns
     if (reducer) {
       float4 dtop = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (top && rcol < a.ld_dout) dtop = *reinterpret_cast<const float4*>(a.dout_top + ((size_t)t * N + rrow) * a.ld_dout + rcol);
+      if (top && rcol < a.ld_dout) {
+        dtop = *reinterpret_cast<const float4*>(a.dout_top + ((size_t)t * N + rrow) * a.ld_dout + rcol);
+        // (columns between P and ld_dout of a shared gradient buffer are whatever its last user left there: 0 x NaN would poison dh)
+        dtop = make_float4(rcol < P ? dtop.x : 0.f, rcol + 1 < P ? dtop.y : 0.f, rcol + 2 < P ? dtop.z : 0.f, rcol + 3 < P ? dtop.w : 0.f);
+      }
       f32x4 sa = {0.f, 0.f, 0.f, 0.f};
-      if (!top) {
+      if (RES) {
+        if (gp == 1) {
+          if (top) Dl = f32x4{dtop.x, dtop.y, dtop.z, dtop.w};
+          else {
+            f32x4 dxt;
+            if (!gp_sum_all(b3, slot1(s % GP_XR, r, jbr, 0) + (unsigned)hh * 512u, NC, lane, err, dxt)) { fail(); return; }
+            const unsigned off = slot2(t, r, jbr) + (unsigned)hh * 512u + (unsigned)(lane & 31) * 16u;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            u32x4 y;
+            for (unsigned polls = 0;; ++polls) {
+              y = __builtin_amdgcn_raw_buffer_load_b128(b2du.rs, off, 0, GP_SC1 | GP_VOL);
+              if (__all(gp_valid(y))) break;
+              asm volatile("" ::: "memory");
+              if ((polls & 63) == 63 && (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { fail(); return; }
+              __builtin_amdgcn_s_sleep(1);
+            }
+            Dl = dxt + f32x4{__uint_as_float(y[0]), __uint_as_float(y[1]), __uint_as_float(y[2]), __uint_as_float(y[3])};
+          }
+        }
+        dtop = make_float4(0.f, 0.f, 0.f, 0.f);                          // (it travels inside D_l)
+      } else if (!top) {
         // the input-gradient partials of the layer above at time t (published a diagonal ago as a rule: read first, poll if not there)
         unsigned lo[10];
 #pragma unroll
@@ -1162,6 +1235,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
                                     [&](int k, const f32x4& v) { if (k == 0) ua = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) ua += v; })) { fail(); return; }
         sa += ua;
       }
+      if (RES && gp == 1 && lane < 32) sa += Dl;                          // (once: with this wave's even-producer half)
       GPTSG(14);
       *reinterpret_cast<f32x4*>(&S.gs[s & 1][r][gp][lane][0]) = sa;
       gp_signal(cnt + C_G + r, lane);
@@ -1194,6 +1268,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
       GPTSG(17);
     }
     if (reducer && gp == 1 && lane < 32 && rcol < ldP) *reinterpret_cast<float4*>(L.dmt + ((size_t)t * N + rrow) * ldP + rcol) = make_float4(tot[0], tot[1], tot[2], tot[3]);
+    if (RES && reducer && gp == 1 && l > 0 && lane < 32) gp_store(b2d, slot2(t, r, jbr) + (unsigned)hh * 512u + (unsigned)lane * 16u, Dl);   // (the layer below is a step behind)
     if (dxr && gp == 0 && s > 0) { if (!sum_dx0(s - 1)) { fail(); return; } }
   }
   if (dxr && gp == 0 && !sum_dx0(T - 1)) { fail(); return; }
@@ -1202,12 +1277,12 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
 #endif
 }
 
-template <int NT, int PROG>
+template <int NT, int PROG, bool RES>
 __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_bwd(const GPersistArgs a) {
   __shared__ __attribute__((aligned(16))) GpLdsB<NT> S;
   gu32* ctl = (gu32*)a.ctl;
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (counts launches)
-  gp_bwd_body<NT, PROG>(a, S);
+  gp_bwd_body<NT, PROG, RES>(a, S);
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1285,9 +1360,11 @@ bool gpersist_plan(GPersistArgs& a) {
   a.NC = (a.H / 4 + a.NT - 1) / a.NT;
   for (int l = 0; l < a.nl; ++l) {
     const GPersistLayer& L = a.L[l];
-    if (L.P < 4 || L.P > 16 * GP_NKB || L.P % 4 != 0 || L.ldP % 4 != 0 || L.I > 16 * GP_NKB || L.ldH % 4 != 0) return false;
-    if (l == 0 && (L.I < 4 || L.I % 4 != 0 || L.ldI % 4 != 0)) return false;       // (16-byte pieces of the input rows)
+    // (P, I need not be multiples of 4 -- res_lstm_l: 257 --: every row is zero-padded to its ld, and 16-byte pieces stop at the ld)
+    if (L.P < 4 || L.P > 16 * GP_NKB || L.ldP % 4 != 0 || L.ldP < L.P || L.ldP - L.P > 3 || L.I > 16 * GP_NKB || L.ldH % 4 != 0) return false;
+    if (l == 0 && (L.I < 4 || L.ldI % 4 != 0 || L.ldI < L.I || L.ldI - L.I > 3)) return false;       // (16-byte pieces of the input rows)
     if (l > 0 && L.I != a.L[l - 1].P) return false;
+    if (a.res && (L.I != L.P || L.ldI != L.ldP)) return false;          // a running sum: every layer as wide as the stack's input
     if (((L.P + 15) / 16) * 2 > a.NC) return false;                // every 8-column half of a chunk needs its reducer
     if (a.NC > 40) return false;                                    // a G wave sums at most 10 producers
   }
@@ -1296,7 +1373,7 @@ bool gpersist_plan(GPersistArgs& a) {
   return gp_grid(a) <= device_cu_count();
 }
 size_t gpersist_gran1_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * GP_R1 * GP_NCH * a.NC * GP_SLOT; }
-size_t gpersist_gran2_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * a.T * GP_NCH * GP_SLOT; }
+size_t gpersist_gran2_bytes(const GPersistArgs& a) { return (size_t)(a.res ? 2 : 1) * (a.N / GP_ROWS) * a.nl * a.T * GP_NCH * GP_SLOT; }      // (res: + the running sums' region)
 size_t gpersist_gran3_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * (a.nl + 1) * GP_XR * GP_NCH * a.NC * GP_SLOT; }
 
 // (the memset arms the launch's hop-2 slots; gran1 / gran3 are armed once, gpersist_arm, and re-armed by the kernels themselves)
@@ -1310,12 +1387,14 @@ void gpersist_arm(const GPersistArgs& a, hipStream_t s) {
 #endif
 void launch_glstm_fwd(const GPersistArgs& a, hipStream_t s) {
   (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_gran2_bytes(a), s);
-  hipLaunchKernelGGL((k_glstm_fwd<5, GP_PROG_ONLY>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
+  if (a.res) hipLaunchKernelGGL((k_glstm_fwd<5, GP_PROG_ONLY, true>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
+  else hipLaunchKernelGGL((k_glstm_fwd<5, GP_PROG_ONLY, false>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
   ++g_chain_launches;
 }
 void launch_glstm_bwd(const GPersistArgs& a, hipStream_t s) {
   (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_gran2_bytes(a), s);
-  hipLaunchKernelGGL((k_glstm_bwd<5, GP_PROG_ONLY>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
+  if (a.res) hipLaunchKernelGGL((k_glstm_bwd<5, GP_PROG_ONLY, true>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
+  else hipLaunchKernelGGL((k_glstm_bwd<5, GP_PROG_ONLY, false>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
   ++g_chain_launches;
 }
 

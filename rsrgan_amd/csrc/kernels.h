@@ -176,6 +176,7 @@ struct GPersistLayer {
   const float* in;                                // layer 0: the stack's input [T][N][ldI] (forward)
   float* dmt;                                     // backward: [T][N][ldP] total dm per step (the projection's weight gradient reads it)
   int I, P, ldI, ldP, ldH;
+  float* res_out;                                 // residual stacks (GPersistArgs::res): [T][N][ldP] s_l = out_l + s_{l-1}: the next layer's input, the output FC's for the top layer
 };
 struct GPersistArgs {
   GPersistLayer L[GP_MAXL];
@@ -190,6 +191,9 @@ struct GPersistArgs {
   int ld_dout;
   float* din0;                                    // backward: [T][N][ld_din0] gradient of the stack's input (null: not wanted)
   int ld_din0;
+  // models/res_lstm_l.py:101-194: inputs_{l+1} = outputs_l + inputs_l (inputs_1 = the stack's input, L[0].in; needs I == P everywhere).
+  // gran2 then holds a second region of the same size: the running sums s_l (forward) / their gradients (backward), one slot per step.
+  int res;
 };
 constexpr int GP_TMAX = 2046;                     // longest launch (slot offsets are 32-bit; a longer batch takes the launch-per-phase path)
 bool gpersist_plan(GPersistArgs& a);              // fills NT / NC; false: shape not supported

@@ -950,9 +950,11 @@ bool Model::persist_forward(Chain& ch, int T, hipStream_t s) {
 // The generator's stack as ONE persistent launch (gpersist.hip).  Same stash as the wavefront launches leave (gates, c, h, mst, out of
 // every layer), so the backward pass does not know which forward ran.
 bool Model::gpersist_shape(GPersistArgs& a, int T) const {              // (sizes only: usable before any buffer exists)
-  if (!gp_env || gl.empty() || gl.size() > (size_t)GP_MAXL || cfg.g_type != RSRGAN_G_LSTM) return false;
+  static const bool res_env = [] { const char* e = getenv("RSRGAN_GP_RES"); return !e || atoi(e) != 0; }();
+  const bool res = cfg.g_type == RSRGAN_G_RES_LSTM_L && res_env;          // the running residual sum rides the hand-offs (gpersist.hip RES)
+  if (!gp_env || gl.empty() || gl.size() > (size_t)GP_MAXL || (cfg.g_type != RSRGAN_G_LSTM && !res)) return false;
   a = GPersistArgs{};
-  a.nl = (int)gl.size(); a.N = B; a.T = T; a.H = gl[0].H;
+  a.nl = (int)gl.size(); a.N = B; a.T = T; a.H = gl[0].H; a.res = res ? 1 : 0;
   for (size_t l = 0; l < gl.size(); ++l) {
     const LstmLayer& L = gl[l];
     if (!L.has_proj || L.H != a.H) return false;
@@ -970,6 +972,7 @@ bool Model::gpersist_args(GPersistArgs& a, int T) const {
     GPersistLayer& G_ = a.L[l];
     G_.KxT = L.KxT; G_.KhT = L.KhT; G_.bias = G.W(L.tb); G_.wi = G.W(L.twi); G_.wf = G.W(L.twf); G_.wo = G.W(L.two); G_.Wp = G.W(L.tWp);
     G_.gates = S.gates; G_.c = S.c; G_.h = S.h; G_.mst = S.mst; G_.out = S.out; G_.dmt = S.dmt;
+    G_.res_out = a.res ? g_res[l] : nullptr;
   }
   return true;
 }
@@ -1024,10 +1027,18 @@ bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only,
   if (!gpersist_args(a, T) || gpersist_gran2_bytes(a) > gp_gran2_bytes) return false;
   for (size_t l = 0; l < ch.size(); ++l) {
     const LayerRun& R = ch[l];
-    if (R.L != &gl[l] || R.S != &g_st[l] || R.res_in || R.res_out || R.row0 != 0 || R.Ns != R.N || R.N != a.N || R.len != a.len) return false;
-    if (l > 0 && (R.din_accumulate || ch[l].din != ch[l - 1].dout)) return false;
+    if (R.L != &gl[l] || R.S != &g_st[l] || R.row0 != 0 || R.Ns != R.N || R.N != a.N || R.len != a.len) return false;
+    if (!a.res) {
+      if (R.res_in || R.res_out) return false;
+      if (l > 0 && (R.din_accumulate || ch[l].din != ch[l - 1].dout)) return false;
+    } else {
+      // res_lstm_l: the callers keep d(inputs_l) = dx_l + d(inputs_{l+1}) accumulated in ONE buffer (dout == din, accumulate); inside the
+      // launch that sum travels from reducer to reducer, the buffer is only read as the top layer's d(outputs)
+      if (R.res_in != g_ins[l] || R.res_out != g_res[l] || R.dout != ch.back().dout) return false;
+      if (l > 0 ? (!R.din_accumulate || R.din != R.dout) : R.din != nullptr) return false;
+    }
   }
-  if (ch[0].din && ch[0].din_accumulate) return false;
+  if (!a.res && ch[0].din && ch[0].din_accumulate) return false;
   a.dout_top = ch.back().dout; a.ld_dout = gl.back().ldP;
   if (!a.dout_top) return false;
   if (check_only) return true;
@@ -1501,7 +1512,7 @@ void Model::g_backward_pass(int T, float* dy, hipStream_t s) {
     for (int l = (int)Lg - 1; l >= 0; --l) {
       ch[l].dout = cur; ch[l].din = l > 0 ? cur : nullptr; ch[l].din_accumulate = true;
     }
-    rnn_backward(chains, T, s);
+    if (!persist_backward_g(ch, T, s)) rnn_backward(chains, T, s);
   } else {
     for (int l = (int)Lg - 1; l >= 0; --l) {
       ch[l].dout = cur; ch[l].din = l > 0 ? other : nullptr; ch[l].din_accumulate = false;

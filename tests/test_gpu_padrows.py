@@ -24,6 +24,24 @@ def test_padded_batch_against_oracle(B, T, flags):
     _step_against_oracle(O.NetCfg(), B, T, flags, seed=500 + B)
 
 
+@pytest.mark.parametrize("B,T,flags", [(8, 100, 3), (8, 12, 1), (1, 30, 1)])
+def test_shipped_recipe_batch_against_oracle(B, T, flags):
+    """run_gan_rnn_placeholder.sh:124,126: --g_type res_lstm_l --batch_size 8 -- the residual stack, padded to one 32-row group, on the
+    persistent launches (csrc/gpersist.hip RES)."""
+    cfg = O.NetCfg.res_lstm_l()
+    _step_against_oracle(cfg, B, T, flags, seed=600 + B)
+    if flags == 1:
+        model, _ = build_hip_pair(cfg, B, T, seed=600 + B, flags=1)
+        x, lab, ln = rand_batch(cfg, B, T, seed=700 + B, ragged=True)
+        model.engine.profile_begin()
+        model.engine.d_backward(x, lab, ln, None, None, train=True, apply=False)
+        model.engine.g_backward(x, lab, ln, None, train=True, reuse=True, apply=False)
+        n = (model.engine.profile_read_kind(1)[0], model.engine.profile_read_kind(2)[0])
+        model.engine.profile_read()
+        assert n == (1, 1), "res_lstm_l did not take the persistent launches: %r" % (n,)
+        assert model.engine.device_status() == 0
+
+
 def test_padded_batch_runs_the_persistent_launches_and_takes_noise():
     cfg = O.NetCfg()
     B, T = 8, 12

@@ -21,7 +21,7 @@ sys.path.insert(0, %r)
 from oracle import rsrgan_oracle as O
 from tests.helpers import NET_D, NET_G, build_hip_pair, rand_batch
 import os
-cfg = O.NetCfg()                      # the reference's sizes: G 3x760/p280, D 2x256/p40
+cfg = O.NetCfg.res_lstm_l() if os.environ.get("RSRGAN_TEST_NET") == "res_lstm_l" else O.NetCfg()      # the reference's sizes: G 3x760/p280 (or the shipped 4x760/p257 residual stack), D 2x256/p40
 B, T = int(os.environ.get("RSRGAN_TEST_B", "8")), int(os.environ.get("RSRGAN_TEST_T", "7"))
 model, _ = build_hip_pair(cfg, B, T, seed=5, flags=3)
 x, lab, ln = rand_batch(cfg, B, T, seed=6, ragged=True)
@@ -138,6 +138,25 @@ def test_persistent_generator_recurrence_agrees(B, T, mode):
         assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-7), (k, a[k], b[k])
     assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
     c = _run(dict(size, RSRGAN_GPERSIST=str(mode)))
+    assert a["vars_sha"] == c["vars_sha"]          # fixed summation order: reproducible bits
+
+
+@pytest.mark.parametrize("B,T", [(32, 9), (32, 50), (32, 1), (32, 2), (8, 7)])
+def test_persistent_residual_generator_agrees(B, T):
+    """Round 5: res_lstm_l (the g_type run_gan_rnn_placeholder.sh:124 ships; models/res_lstm_l.py:101-194: four LSTMCell(760, num_proj=257)
+    with inputs_{l+1} = outputs_l + inputs_l) on the persistent launches: the running sum and its gradient travel from reducer to
+    reducer inside k_glstm_fwd / k_glstm_bwd (csrc/gpersist.hip RES) -- against the launch-per-phase wavefront (RSRGAN_GP_RES=0).  P = 257
+    is no multiple of 4: the 16-byte pieces straddle the last column.  (8, 7): padded to one 32-row group."""
+    size = {"RSRGAN_TEST_B": str(B), "RSRGAN_TEST_T": str(T), "RSRGAN_TEST_NET": "res_lstm_l", "RSRGAN_PAD_ROWS": "1"}
+    a = _run(dict(size))
+    b = _run(dict(size, RSRGAN_GP_RES="0", RSRGAN_PAD_ROWS="0"))
+    if T > 2:
+        assert b["chain_launches"] - a["chain_launches"] >= 2 * (T - 1), (a["chain_launches"], b["chain_launches"])
+    assert a["device_status"] == 0 and b["device_status"] == 0
+    for k in ("d0", "g0", "d1", "g1"):
+        assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-7), (k, a[k], b[k])
+    assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
+    c = _run(dict(size))
     assert a["vars_sha"] == c["vars_sha"]          # fixed summation order: reproducible bits
 
 
