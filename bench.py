@@ -646,6 +646,15 @@ def main():
                                 "value": round(B * T * n2 / v2["dt"], 1), "unit": "frames/s", "ms_per_step": round(v2["dt"] * 1e3 / n2, 4)})
         del v2
         torch.cuda.empty_cache()
+        # the shipped RECIPE as a whole (run_gan_rnn_placeholder.sh:124,126,129-130): res_lstm_l, batch_size 8, 1 D-run + 2 G-runs -- the
+        # batch is padded to one 32-row group of the persistent kernels (csrc/model.h Bt); and the same network at BASELINE configs[1]'s batch
+        for (bb, gu, tag) in ((8, 2, "shipped recipe: G=res_lstm_l, batch_size 8, 1D+2G"), (32, 1, "shipped network at B=32 (one row group: persistent launches), 1D+1G")):
+            a5 = argparse.Namespace(**vars(a)); a5.gen_updates = gu
+            v5 = measure_sequence(a5, "res_lstm_l", "lstm", bb, T, n2, 2, rank, local, world, dev)
+            out["variants"].append({"workload": "%s, T=%d" % (tag, T), "value": round(bb * T * n2 / v5["dt"], 1), "unit": "frames/s",
+                                    "ms_per_step": round(v5["dt"] * 1e3 / n2, 4)})
+            del v5
+            torch.cuda.empty_cache()
         try:           # BASELINE.json configs[3]: R-CED (257 x 11) + discriminator_dnn, N = 6400 frames (bench.py --net rced --rced-gan)
             import contextlib, io
             a3 = argparse.Namespace(**vars(a)); a3.net = "rced"; a3.rced_gan = True; a3.rced_width = 257; a3.batch = 6400; a3.steps = 3; a3.warmup = 1

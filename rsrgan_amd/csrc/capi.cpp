@@ -246,6 +246,7 @@ int rsrgan_d_step(rsrgan_handle h, const float* x, const float* labels, const in
   CHECK_H(h);
   return guard("rsrgan_d_step", [&]() -> int {
     StreamScope sc(h->m, stream);
+    struct Fused { Model& m; Fused(Model& m_, bool on) : m(m_) { m.fused_apply = on; } ~Fused() { m.fused_apply = false; m.apply_inlined = 0; } } fused(h->m, train != 0);
     int rc = h->m.d_backward(x, labels, lengths, T, nr, nf, out_losses, train != 0, sc.work);
     if (rc || !train) return rc;
     return h->m.apply(RSRGAN_NET_D, sc.work);
@@ -256,7 +257,7 @@ int rsrgan_g_step(rsrgan_handle h, const float* x, const float* labels, const in
   CHECK_H(h);
   return guard("rsrgan_g_step", [&]() -> int {
     StreamScope sc(h->m, stream);
-    struct Fused { Model& m; Fused(Model& m_, bool on) : m(m_) { m.fused_apply = on; } ~Fused() { m.fused_apply = false; } } fused(h->m, train != 0);
+    struct Fused { Model& m; Fused(Model& m_, bool on) : m(m_) { m.fused_apply = on; } ~Fused() { m.fused_apply = false; m.apply_inlined = 0; } } fused(h->m, train != 0);
     int rc = h->m.g_backward(x, labels, lengths, T, nf, out_losses, train != 0, reuse != 0, sc.work);
     if (rc || !train) return rc;
     return h->m.apply(RSRGAN_NET_G, sc.work);

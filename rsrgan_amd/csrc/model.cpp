@@ -1532,7 +1532,11 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
   if (rc) return rc;
   bn_eval_call = !want_grads;                      // (is_training of this fetch: the DropoutWrapper masks)
   if (seq_drop_on()) launch_drop_tick(drop_ctr, s);     // a new training run: new masks (read from device memory: graph-safe)
-  const unsigned kbits = (want_grads ? 1u : 0u) | (nr ? 2u : 0u) | (nf ? 4u : 0u);
+  // rsrgan_d_step: the update follows in the same call -- its launches close this segment (one graph: no launch boundary in front
+  // of the clip / SGD / weight-copy kernels); RSRGAN_FUSED_SEG=0 keeps them in a segment of their own
+  static const bool fused_seg_d = [] { const char* e = getenv("RSRGAN_FUSED_SEG"); return !e || atoi(e) != 0; }();
+  const bool inl = fused_apply && fused_seg_d && want_grads && !d_dnn() && graphs_on();
+  const unsigned kbits = (want_grads ? 1u : 0u) | (nr ? 2u : 0u) | (nf ? 4u : 0u) | (inl ? 8u : 0u);
   run_seg(seg_key(SEG_D, T, kbits), s, [&]() {
   // discriminator input rows [0,B) = labels + noise_real (gan_rnn_placeholder.py:207,212; utils/ops.py:19-30)
   launch_add_noise_rows(lab_tm, nr, xd, B, T, Dout, ldDout, 2 * B, 0, s);
@@ -1587,8 +1591,10 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
     }
     if (want_grads) d_backward_pass(2 * B, T, true, false, dlogits, s, head);
   }
+  if (inl) apply_body(RSRGAN_NET_D, s);
   });
   g_fwd_valid = true;
+  if (inl) apply_inlined |= 2;
   if (want_grads) { finish_buckets(RSRGAN_NET_D, s); d_grads_ready = true; }
   if (out_losses) launch_copy_f(losses, out_losses, 3, s);
   HIPC(hipGetLastError());
@@ -1640,7 +1646,6 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   // nothing can run between the backward pass and the optimizer: one segment, no graph boundaries between the layers)
   static const bool fused_seg = [] { const char* e = getenv("RSRGAN_FUSED_SEG"); return !e || atoi(e) != 0; }();
   const bool bucketed = wave_bwd && gbk[RSRGAN_NET_G].size() > 1 && !overlap() && !(fused_apply && fused_seg);
-  const unsigned kbits = (want_grads ? 1u : 0u) | (nf ? 2u : 0u) | (reuse ? 4u : 0u) | (l2_on ? 8u : 0u) | (bucketed ? 16u : 0u);
   const int R = T * B, Ld = (int)dl.size(), Lg = (int)gl.size();
   const int ldPd = pad4(dR), P = gR, ldP = pad4(P);
   float* dy = g_dB;                               // [T*B][ldDout] (wavefront backward)
@@ -1679,6 +1684,19 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   }();
   const bool fcs_inside = wave_bwd && !bucketed && side && fc_side_env && cfg.g_type == RSRGAN_G_LSTM && dl[0].ldI == ldDout &&
                           persist_backward_g(bw_chains[1], T, s, true);
+  // rsrgan_g_step with nothing left between the backward segment and the update (no input-FC segment, no buckets): the loss
+  // tail and the update's launches close the main segment -- ONE graph per G-run instead of three
+  const bool inl = fused_apply && fused_seg && wave_bwd && !bucketed && graphs_on() && !(cfg.g_type == RSRGAN_G_LSTM && !fcs_inside);
+  const unsigned kbits = (want_grads ? 1u : 0u) | (nf ? 2u : 0u) | (reuse ? 4u : 0u) | (l2_on ? 8u : 0u) | (bucketed ? 16u : 0u) | (inl ? 32u : 0u);
+  auto tail_body = [&]() {
+    if (want_grads && l2_on) {
+      launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
+      launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);
+    } else {
+      (void)hipMemsetAsync(losses + 5, 0, sizeof(float), s);
+    }
+    launch_g_total(losses + 3, dyn + DYN_LAMBDA, s);
+  };
 
   run_seg(seg_key(SEG_G_MAIN, T, kbits), s, [&]() {
   bool g_done = false;
@@ -1775,7 +1793,9 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   } else {
     launch_mse(y_tm, lab_tm, ldDout, nullptr, T * B, Dout, dyn + DYN_LAMBDA, false, losses + 4, scratch, s, pad_Bp(), Bt);
   }
+  if (inl) { tail_body(); apply_body(RSRGAN_NET_G, s); }
   });
+  if (inl) apply_inlined |= 1;
   if (!reuse) g_fwd_valid = true;
   if (wave_bwd) {
     int bi = 0;
@@ -1803,15 +1823,7 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
       }
     }
   }
-  run_seg(seg_key(SEG_G_TAIL, T, kbits), s, [&]() {
-    if (want_grads && l2_on) {
-      launch_l2(G.w, G.g, G.ct, dyn + DYN_L2, G.partial, s);
-      launch_l2_total(G.partial, G.ct.n_chunks, dyn + DYN_L2, losses + 5, s);
-    } else {
-      (void)hipMemsetAsync(losses + 5, 0, sizeof(float), s);
-    }
-    launch_g_total(losses + 3, dyn + DYN_LAMBDA, s);
-  });
+  if (!inl) run_seg(seg_key(SEG_G_TAIL, T, kbits), s, tail_body);
   if (want_grads) {
     if (l2_on) for (auto& bk : gbk[RSRGAN_NET_G]) bk.marked = false;      // the L2 term touches every tensor: all buckets final only now
     finish_buckets(RSRGAN_NET_G, s);
@@ -1822,29 +1834,37 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   return RSRGAN_OK;
 }
 
+// per-tensor clip_by_norm + the optimizer + EMA + the weight copies (gan_rnn_placeholder.py:177-189): the launches of one update
+void Model::apply_body(int net, hipStream_t s) {
+  if (net == RSRGAN_NET_D) {
+    launch_sumsq(D.g, D.ct, D.partial, s);
+    if (d_adam()) {                              // models/gan.py:125: d_opt = AdamOptimizer(d_learning_rate)
+      launch_adam_tick(dyn, adam_t_dev_d, (double)cfg.adam_beta1, (double)cfg.adam_beta2, s, DYN_D_LR, DYN_ADAM_LRT_D);
+      launch_apply_adam(D.w, D.g, D.m, D.v, D.ema, D.ct, D.partial, dyn, s, DYN_ADAM_LRT_D);
+    } else {
+      launch_apply_sgd(D.w, D.g, D.ema, D.ct, D.partial, dyn, s);
+    }
+    refresh_transposes(RSRGAN_NET_D, s);
+  } else {
+    launch_sumsq(G.g, G.ct, G.partial, s);
+    launch_adam_tick(dyn, adam_t_dev, (double)cfg.adam_beta1, (double)cfg.adam_beta2, s);
+    launch_apply_adam(G.w, G.g, G.m, G.v, G.ema, G.ct, G.partial, dyn, s);
+    refresh_transposes(RSRGAN_NET_G, s);
+  }
+}
+
 int Model::apply(int net, hipStream_t s) {
   if (net == RSRGAN_NET_D) {
     if (!d_grads_ready) { set_error("apply(D) without gradients"); return RSRGAN_ERR_STATE; }
-    run_seg(seg_key(SEG_APPLY_D, 0, 0), s, [&]() {
-      launch_sumsq(D.g, D.ct, D.partial, s);
-      if (d_adam()) {                              // models/gan.py:125: d_opt = AdamOptimizer(d_learning_rate)
-        launch_adam_tick(dyn, adam_t_dev_d, (double)cfg.adam_beta1, (double)cfg.adam_beta2, s, DYN_D_LR, DYN_ADAM_LRT_D);
-        launch_apply_adam(D.w, D.g, D.m, D.v, D.ema, D.ct, D.partial, dyn, s, DYN_ADAM_LRT_D);
-      } else {
-        launch_apply_sgd(D.w, D.g, D.ema, D.ct, D.partial, dyn, s);
-      }
-      refresh_transposes(RSRGAN_NET_D, s);
-    });
+    // (apply_inlined: rsrgan_d_step's backward segment already ran / replayed these launches at its end -- one graph, no boundary)
+    if (!(apply_inlined & 2)) run_seg(seg_key(SEG_APPLY_D, 0, 0), s, [&]() { apply_body(RSRGAN_NET_D, s); });
+    apply_inlined &= ~2;
     if (d_adam()) scal[RSRGAN_ADAM_STEP_D] += 1;
     d_grads_ready = false;
   } else if (net == RSRGAN_NET_G) {
     if (!g_grads_ready) { set_error("apply(G) without gradients"); return RSRGAN_ERR_STATE; }
-    run_seg(seg_key(SEG_APPLY_G, 0, 0), s, [&]() {
-      launch_sumsq(G.g, G.ct, G.partial, s);
-      launch_adam_tick(dyn, adam_t_dev, (double)cfg.adam_beta1, (double)cfg.adam_beta2, s);
-      launch_apply_adam(G.w, G.g, G.m, G.v, G.ema, G.ct, G.partial, dyn, s);
-      refresh_transposes(RSRGAN_NET_G, s);
-    });
+    if (!(apply_inlined & 1)) run_seg(seg_key(SEG_APPLY_G, 0, 0), s, [&]() { apply_body(RSRGAN_NET_G, s); });
+    apply_inlined &= ~1;
     scal[RSRGAN_ADAM_STEP] += 1;
     g_grads_ready = false;
     g_fwd_valid = false;

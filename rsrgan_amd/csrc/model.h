@@ -265,6 +265,8 @@ struct Model {
   int g_backward(const float* x, const float* labels, const int32_t* lengths, int T, const float* nf,
                  float* out_losses, bool want_grads, bool reuse, hipStream_t s);
   int apply(int net, hipStream_t s);
+  void apply_body(int net, hipStream_t s);     // the update's launches (clip, optimizer, EMA, weight copies)
+  int apply_inlined = 0;                       // bit 0 (G) / bit 1 (D): the backward segment of this call already contains them (fused steps)
   void refresh_transposes(int net, hipStream_t s);
   void refresh_swizzles(int net, hipStream_t s);
   bool lazy_sw = false;            // the fragment-tiled copies are rebuilt where they are read (rnn_forward / rnn_backward), not after every update
