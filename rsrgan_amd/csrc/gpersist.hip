@@ -93,6 +93,20 @@ __device__ __forceinline__ float gp_tanh(float x) {          // (dpersist.hip dp
   return fabsf(x) < 0.1f ? ser : big;
 }
 
+// The stash (gate activations, c, h, dz: written once per launch, read by the NEXT launch at the earliest) streams through the
+// memory system beside the hand-off rings, which want to stay in the Infinity Cache.  GP_STASH_NT = 1: non-temporal stores / loads
+// for it (measured: profiles/r5_hbm_phases.txt).
+#ifndef GP_STASH_NT
+#define GP_STASH_NT 0
+#endif
+__device__ __forceinline__ void gp_stash_store(float* dst, const float4& v) {
+#if GP_STASH_NT
+  __builtin_nontemporal_store(v.x, dst); __builtin_nontemporal_store(v.y, dst + 1); __builtin_nontemporal_store(v.z, dst + 2); __builtin_nontemporal_store(v.w, dst + 3);
+#else
+  *reinterpret_cast<float4*>(dst) = v;
+#endif
+}
+
 // ---- intra-workgroup synchronisation: monotonic LDS counters ----
 __device__ __forceinline__ void gp_signal(unsigned* cnt, int lane) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // this wave's LDS writes have landed
@@ -461,7 +475,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
           const float4 v = *reinterpret_cast<const float4*>(&S.st[k][row][4 * cq]);
           const size_t rowg = (size_t)t * N + row0 + row;
           float* dst = (k < 4 ? L.gates + rowg * H4 + k * H : k == 4 ? L.c + (rowg + N) * H : L.h + rowg * L.ldH) + cell0 + 4 * cq;
-          if (e < 6 * 16 * NT && cell0 + 4 * cq < H) *reinterpret_cast<float4*>(dst) = v;
+          if (e < 6 * 16 * NT && cell0 + 4 * cq < H) gp_stash_store(dst, v);
         }
         gp_signal(&S.cnt_s[r], lane);
         // This workgroup's G waves summed the partial projections of step t-1 before they gathered m(t-1) (the wait at the top):
@@ -1130,7 +1144,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
           const int cq = e % NT, pr = e / NT, row = 16 * r + (pr & 15), k = min(pr >> 4, 3);
           const float4 v = *reinterpret_cast<const float4*>(&S.st[k][row][4 * cq]);
           float* dst = L.gates + ((size_t)t * N + row0 + row) * H4 + k * H + cell0 + 4 * cq;
-          if (e < 4 * 16 * NT && cell0 + 4 * cq < H) *reinterpret_cast<float4*>(dst) = v;
+          if (e < 4 * 16 * NT && cell0 + 4 * cq < H) gp_stash_store(dst, v);
         }
         // This workgroup's G waves summed this step's partials before they gathered dm(t) (the wait at the top): re-arm their slots of
         // both rings.  Acknowledged before the wave signals its cells of the next step, i.e. before this workgroup's partials of that

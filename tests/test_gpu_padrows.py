@@ -127,11 +127,14 @@ def test_half_the_device_falls_back_without_time_outs(mask):
 
 
 def test_a_failed_persistent_launch_disables_the_path_for_the_handle():
-    """after a reported failure the handle must stop trying (every further step would spin into the same time-out).  The
-    probe is switched off and the capacity lied about (RSRGAN_RESIDENT_PROBE=0 trusts multiProcessorCount) under a CU mask: the first
-    step fails loudly (NaN losses, device_status != 0), the following ones run on the launch path and are right."""
+    """after a reported failure the handle must stop trying (every further step would spin into the same time-out).  With
+    the probe switched off (RSRGAN_RESIDENT_PROBE=0 trusts multiProcessorCount, which a CU mask does not change) a masked device
+    accepts the launches at rsrgan_create and one of them reports a failed bounded wait (on this pool: k_glstm_bwd of the first
+    training pass, code 0x10000 + workgroup); every pass after the report must run on the launch path, status 0, finite losses."""
     r = _worker({"HSA_CU_MASK": "0:0-127", "RSRGAN_RESIDENT_PROBE": "0", "RSRGAN_TEST_FLAGS": "3"})
-    if r["status"][0] == 0:
-        pytest.skip("the CU mask is not honoured in this environment")
-    assert r["status"][1:] == [0, 0] and r["ok"], r
+    bad = [i for i, v in enumerate(r["status"]) if v != 0]
+    if not bad:
+        pytest.skip("the CU mask is not honoured in this environment (no launch failed)")
+    assert bad[0] < 2 and r["status"][bad[0]] >= 0x10000, r["status"]
+    assert all(v == 0 for v in r["status"][bad[0] + 1:]), r["status"]
     assert all(np.isfinite(v) for v in r["d"][2] + r["g"][2]), r

@@ -230,6 +230,16 @@ int main(int argc, char** argv) {
     printf("ablation mask %d\n", RSR_GEMM_ABL);
     time_one(4096, 4096, 4096, false, false); time_one(4096, 4096, 4096, true, false); time_one(560, 3040, 6400, false, false);
   }
+  for (int i = 1; i < argc; ++i)
+    if (!strcmp(argv[i], "explore")) {
+      // what does the weight-gradient product [x | m]^T dZ (560 x 3040 x 6400, both operands row-major over time) wait for?  The same
+      // product with a longer reduction (longer runs per stream-K worker), with three layers' columns side by side (what a batched
+      // launch of the stack's three products would be), with M a whole number of tiles, and one 800-deep slab of it
+      const int shapes[][3] = {{560, 3040, 6400}, {560, 3040, 19200}, {560, 9120, 6400}, {640, 3072, 6400}, {512, 3072, 6400}, {576, 3040, 6400},
+                               {560, 3040, 800}, {560, 3040, 1600}, {1120, 3040, 6400}, {6400, 280, 3040}, {6400, 280, 9120}};
+      for (auto& sh : shapes) time_one(sh[0], sh[1], sh[2], false, false);
+      time_one(6400, 280, 3040, true, true);
+    }
   if (do_time) {
     const int shapes[][3] = {{4096, 4096, 4096}, {560, 3040, 6400}, {6400, 3040, 280}, {6400, 1024, 1024}, {6400, 1024, 2828}, {1024, 1024, 6400},
                              {760, 280, 6400}, {6400, 280, 257}, {32768, 1024, 1024}, {80, 1024, 12800}};

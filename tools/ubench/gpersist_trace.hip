@@ -66,6 +66,18 @@ int main(int argc, char** argv) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     best = ms < best ? ms : best;
   }
+  if (const char* ls = getenv("GP_LOOP_SECONDS")) {                 // keep launching for that long (memory-controller activity is sampled from outside: tools/hbm_phase.sh)
+    const double secs = atof(ls);
+    hipEvent_t l0, l1; CK(hipEventCreate(&l0)); CK(hipEventCreate(&l1));
+    CK(hipEventRecord(l0, s));
+    long n = 0; float ms = 0.f;
+    do {
+      for (int i = 0; i < 20; ++i) { if (bwd) launch_glstm_bwd(a, s); else launch_glstm_fwd(a, s); }
+      n += 20;
+      CK(hipEventRecord(l1, s)); CK(hipStreamSynchronize(s)); CK(hipEventElapsedTime(&ms, l0, l1));
+    } while (ms < secs * 1e3);
+    printf("loop: %ld launches in %.1f ms = %.1f us per launch\n", n, ms, ms * 1e3 / n);
+  }
   unsigned ctl[4]; CK(hipMemcpy(ctl, a.ctl, 16, hipMemcpyDeviceToHost));
   printf(bwd ? "k_glstm_bwd N=%d T=%d layers=%d (NT=%d NC=%d, %zu + %zu MB of granule slots): %.1f us per launch = %.2f us per step (err word %u, generation %u)\n" : "k_glstm_fwd N=%d T=%d layers=%d (NT=%d NC=%d, %zu + %zu MB of granule slots): %.1f us per launch = %.2f us per step (err word %u, generation %u)\n",
          N, T, nl, a.NT, a.NC, g1 >> 20, g2 >> 20, best * 1e3f, best * 1e3f / T, ctl[2], ctl[0]);
