@@ -54,6 +54,10 @@ struct GemmArgs {
   int tiles_m, tiles_n, NT, NK, W, n_dp;     // tile grid, tiles, k-tiles, workers, tiles of the data-parallel rounds
   int Uq, Ur;                                // units of the stream-K region = Uq * W + Ur (all unit arithmetic is 32-bit)
   GemmRowMap ma;                             // row map of A (kernels.h), used by the MAP instantiations only
+  // a BATCH of nb same-shaped products in one launch (round 5: the three layers' weight gradients [x | m]^T dZ): tile column
+  // tn belongs to problem tn / tn1, whose operands replace A / A2 / B / C -- one stream-K unit space over all problems' tiles
+  int nb, tn1;
+  const float* Ab[GEMM_MAXB]; const float* A2b[GEMM_MAXB]; const float* Bb[GEMM_MAXB]; float* Cb[GEMM_MAXB];
 };
 // first unit of worker w: floor(w * U / W)
 __device__ __forceinline__ int worker_lo(const GemmArgs& g, int w) { return w * g.Uq + (w * g.Ur) / g.W; }
@@ -153,7 +157,7 @@ struct Stage {
 
 // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 template <int RT, int CT>
-__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[RT][CT], int m_base, int n_base, int l31, int lh, const GemmArgs& g) {
+__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[RT][CT], int m_base, int n_base, int l31, int lh, const GemmArgs& g, float* __restrict__ C) {
 #pragma unroll
   for (int j = 0; j < CT; ++j) {
     const int col = n_base + j * 32 + l31;
@@ -177,13 +181,13 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[RT][CT], int m
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = min(row0 + (r & 3) + 8 * (r >> 2), g.M - 1);
-          v[r] += g.C[(size_t)row * g.ldc + cc];
+          v[r] += C[(size_t)row * g.ldc + cc];
         }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2);
-        if (cok && row < g.M) g.C[(size_t)row * g.ldc + col] = v[r];
+        if (cok && row < g.M) C[(size_t)row * g.ldc + col] = v[r];
       }
     }
   }
@@ -225,6 +229,8 @@ __global__ __launch_bounds__(64 * (4 + NL), RSR_GEMM_MINW) void k_gemm(const Gem
     }
     int tm, tn;
     tile_rc(g, t, tm, tn);
+    const float* pA = g.A; const float* pA2 = g.A2; const float* pB = g.B; float* pC = g.C;
+    if (g.nb > 1) { const int b = tn / g.tn1; tn -= b * g.tn1; pA = g.Ab[b]; pA2 = g.A2b[b]; pB = g.Bb[b]; pC = g.Cb[b]; }
     const int m0 = tm * BM, n0 = tn * BN;
     if (wid >= 4) {
       // ---- loader wave: runs NBUF-1 k-tiles ahead of the MFMA waves through a ring of NBUF LDS buffers.  One barrier per k-tile:
@@ -233,13 +239,13 @@ __global__ __launch_bounds__(64 * (4 + NL), RSR_GEMM_MINW) void k_gemm(const Gem
       // HBM / MALL: with one k-tile = 1.7 us of prefetch distance the MFMA waves waited on every tile)
       const int lw = wid - 4;
       SA sa; SB sb;
-      sa.init(g.A, g.lda, g.A2, g.lda2, g.M1, m0, g.M, i0 * GK, lane, lw, g.ma);
-      sb.init(g.B, g.ldb, nullptr, 0, 0, n0, g.N, i0 * GK, lane, lw, g.ma);
+      sa.init(pA, g.lda, pA2, g.lda2, g.M1, m0, g.M, i0 * GK, lane, lw, g.ma);
+      sb.init(pB, g.ldb, nullptr, 0, 0, n0, g.N, i0 * GK, lane, lw, g.ma);
       constexpr int NIT = SA::NI + SB::NI;                 // DMA instructions per k-tile of this wave
       static_assert((NBUF - 2) * NIT < 64, "vmcnt is a 6-bit counter");
 #pragma unroll
       for (int d = 0; d < NBUF - 1; ++d) {
-        sa.issue((i0 + d) * GK, g.K, i0 + d < i1, smem + d * BUF, lane, lw, g.lda, g.lda2, g.M1, m0, g.M, g.A2, g.ma);
+        sa.issue((i0 + d) * GK, g.K, i0 + d < i1, smem + d * BUF, lane, lw, g.lda, g.lda2, g.M1, m0, g.M, pA2, g.ma);
         sb.issue((i0 + d) * GK, g.K, i0 + d < i1, smem + d * BUF + SA::FLOATS, lane, lw, g.ldb, 0, 0, n0, g.N, nullptr, g.ma);
       }
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * NIT) : "memory");
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(64 * (4 + NL), RSR_GEMM_MINW) void k_gemm(const Gem
         float* bn = smem + slot * BUF;
         const int kn = kt + NBUF - 1;
         if (!(RSR_GEMM_ABL & 1)) {
-          sa.issue(kn * GK, g.K, kn < i1, bn, lane, lw, g.lda, g.lda2, g.M1, m0, g.M, g.A2, g.ma);
+          sa.issue(kn * GK, g.K, kn < i1, bn, lane, lw, g.lda, g.lda2, g.M1, m0, g.M, pA2, g.ma);
           sb.issue(kn * GK, g.K, kn < i1, bn + SA::FLOATS, lane, lw, g.ldb, 0, 0, n0, g.N, nullptr, g.ma);
         }
         slot = slot + 1 == NBUF ? 0 : slot + 1;
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(64 * (4 + NL), RSR_GEMM_MINW) void k_gemm(const Gem
       }
 
       if (i0 == 0 && i1 == g.NK) {
-        gemm_epilogue<RT, CT>(acc, m0 + wr * RT * 32, n0 + wc * CT * 32, l31, lh, g);
+        gemm_epilogue<RT, CT>(acc, m0 + wr * RT * 32, n0 + wc * CT * 32, l31, lh, g, pC);
       } else {
         // a piece of a tile: raw accumulators, lane-native order ([tile][quad][thread] float4: coalesced)
         const int slot = 2 * w + (u == u_lo ? 0 : 1);
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_s(const GemmArgs g) {
       __builtin_amdgcn_s_barrier();                        // ... everybody's; and k-tile kt has been read by every wave
     }
     if (i0 == 0 && i1 == g.NK) {
-      gemm_epilogue<RT, CT>(acc, m0 + wr * RT * 32, n0 + wc * CT * 32, l31, lh, g);
+      gemm_epilogue<RT, CT>(acc, m0 + wr * RT * 32, n0 + wc * CT * 32, l31, lh, g, g.C);
     } else {
       const int pslot = 2 * w + (u == u_lo ? 0 : 1);
       float4* q = reinterpret_cast<float4*>(g.ws) + (size_t)pslot * (RT * CT * 4 * 256) + tid;
@@ -556,7 +562,9 @@ __global__ __launch_bounds__(256) void k_gemm_fixup(const GemmArgs g) {
   const int t = g.n_dp + ts;
   int tm, tn;
   tile_rc(g, t, tm, tn);
-  gemm_epilogue<RT, CT>(acc, tm * BM + wr * RT * 32, tn * BN + wc * CT * 32, l31, lh, g);
+  float* pC = g.C;
+  if (g.nb > 1) { const int b = tn / g.tn1; tn -= b * g.tn1; pC = g.Cb[b]; }
+  gemm_epilogue<RT, CT>(acc, tm * BM + wr * RT * 32, tn * BN + wc * CT * 32, l31, lh, g, pC);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -900,7 +908,8 @@ void launch_cfg(GemmArgs& g, const Plan& pl, hipStream_t s, float* ws) {
     attr = true;
   }
   g.tiles_m = (g.M + BM - 1) / BM;
-  g.tiles_n = (g.N + BN - 1) / BN;
+  g.tn1 = (g.N + BN - 1) / BN;
+  g.tiles_n = g.tn1 * std::max(1, g.nb);                     // (a batch: every problem's tile columns side by side)
   g.NT = g.tiles_m * g.tiles_n;
   g.NK = (g.K + GK - 1) / GK;
   if ((long long)g.NT * g.NK >= (1LL << 30)) { fprintf(stderr, "rsrgan: GEMM beyond the 32-bit (tile, k-tile) unit arithmetic\n"); abort(); }
@@ -1071,6 +1080,29 @@ void launch_gemm_mapped(const float* A, int lda, const GemmRowMap& ma, const flo
   else if (a_kc && b_kc) launch_layout<true, true, false>(g, s, ws, ws_floats);
   else if (!a_kc && !b_kc) launch_layout<false, false, false>(g, s, ws, ws_floats);
   else launch_layout<false, true, false>(g, s, ws, ws_floats);
+}
+
+// nb same-shaped products C_b = [A_b | A2_b]^T-style (x-contiguous operands, no bias / activation) as ONE stream-K launch of k_gemm
+// at 128 x 128 tiles: the unit space runs over all problems' tiles, so a worker's run is nb times longer and one fix-up launch
+// serves them all (round 5: the generator's three dK products, 120 tiles each: 3 x 259 us -> 703 us in tools/ubench/gemm_bench explore).
+// false: not applicable (the caller launches the products one by one).
+bool launch_gemm_batch(int nb, const float* const* A, int lda, const float* const* A2, int lda2, int M1, const float* const* B, int ldb,
+                       float* const* C, int ldc, int M, int N, int K, bool accumulate, hipStream_t s, float* ws, size_t ws_floats) {
+  static const bool on = [] { const char* e = getenv("RSRGAN_GEMM_BATCH"); return !e || atoi(e) != 0; }();
+  if (!on || nb < 2 || nb > GEMM_MAXB || M <= 0 || N <= 0 || K <= 0 || !ws) return false;
+  const double outs = (double)M * N;
+  if (!(K >= 256 && outs >= 4.0e6) && !(K >= 2048 && outs >= 1.5e6)) return false;      // (k_gemm16's products: launch_gemm16_batch)
+  GemmArgs g{};
+  g.A = A[0]; g.A2 = A2 ? A2[0] : nullptr; g.B = B[0]; g.bias = nullptr; g.C = C[0];
+  g.lda = lda; g.lda2 = lda2; g.M1 = M1; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+  g.act = 0; g.accumulate = accumulate ? 1 : 0; g.alpha = 0.f;
+  g.ma = GemmRowMap{0, 0, 0};
+  g.nb = nb;
+  for (int b = 0; b < nb; ++b) { g.Ab[b] = A[b]; g.A2b[b] = A2 ? A2[b] : nullptr; g.Bb[b] = B[b]; g.Cb[b] = C[b]; }
+  const int tn1 = (N + 127) / 128;
+  const Plan pl = plan_cfg(M, nb * tn1 * 128, K, 128, 128, g_gemm_workers, ws, ws_floats);
+  launch_cfg<false, false, 2, 2, 2, false>(g, pl, s, ws);
+  return true;
 }
 
 void launch_gemm2(const float* A, int lda, const float* A2, int lda2, int M1, bool a_kc, const float* B, int ldb, bool b_kc,

@@ -231,6 +231,9 @@ void launch_gemm16_batch(const Gemm16Batch& bt, int lda, int lda2, int M1, int l
 void launch_gemm2(const float* A, int lda, const float* A2, int lda2, int M1, bool a_kc, const float* B, int ldb, bool b_kc,
                   float* C, int ldc, int M, int N, int K, const float* bias, int act, float alpha, bool accumulate,
                   hipStream_t s, float* ws, size_t ws_floats);   // rows >= M1 of an m-contiguous A come from A2
+constexpr int GEMM_MAXB = 4;
+bool launch_gemm_batch(int nb, const float* const* A, int lda, const float* const* A2, int lda2, int M1, const float* const* B, int ldb,
+                       float* const* C, int ldc, int M, int N, int K, bool accumulate, hipStream_t s, float* ws, size_t ws_floats);
 void launch_gemm(const float* A, int lda, bool a_kc, const float* B, int ldb, bool b_kc,
                  float* C, int ldc, int M, int N, int K,
                  const float* bias, int act, float alpha, bool accumulate, hipStream_t s,

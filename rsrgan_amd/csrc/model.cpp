@@ -1220,8 +1220,20 @@ void Model::chain_wgrads(Chain& ch, int T, hipStream_t s, const std::function<vo
     // every layer's dWp + column sums as three launches beside the chip-filling dK GEMMs, which stay on s one after the other
     if (between) between();
     after_between();
-    for (auto& R : ch)
-      if (R.want_wgrads) layer_wgrads_gemms(R, 0, T, false, s, true, false);
+    // the layers' kernel gradients [x | m]^T dZ: same shapes (batch_wgrads checked that) -> one stream-K launch over all of them
+    std::vector<const LayerRun*> rs;
+    for (auto& R : ch) if (R.want_wgrads) rs.push_back(&R);
+    bool batched = false;
+    if (rs.size() >= 2 && rs.size() <= (size_t)GEMM_MAXB) {
+      const float *A_[GEMM_MAXB], *A2_[GEMM_MAXB], *B_[GEMM_MAXB]; float* C_[GEMM_MAXB];
+      const LstmLayer& L0 = *rs[0]->L;
+      for (size_t i = 0; i < rs.size(); ++i) { A_[i] = rs[i]->in; A2_[i] = rs[i]->S->mst; B_[i] = rs[i]->S->gates; C_[i] = rs[i]->ps->Gd(rs[i]->L->tK); }
+      batched = launch_gemm_batch((int)rs.size(), A_, L0.ldI, A2_, L0.ldP, L0.I, B_, 4 * L0.H, C_, 4 * L0.H, L0.I + L0.P, 4 * L0.H, T * rs[0]->N, false, s,
+                                  (side && s == side) ? gemm_ws2 : gemm_ws, gemm_ws_floats);
+    }
+    if (!batched)
+      for (auto& R : ch)
+        if (R.want_wgrads) layer_wgrads_gemms(R, 0, T, false, s, true, false);
   } else {
     bool first = true;
     for (auto& R : ch) {

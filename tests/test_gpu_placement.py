@@ -160,6 +160,21 @@ def test_persistent_residual_generator_agrees(B, T):
     assert a["vars_sha"] == c["vars_sha"]          # fixed summation order: reproducible bits
 
 
+def test_batched_kernel_gradient_gemm_agrees():
+    """Round 5: the three generator layers' kernel gradients [x | m]^T dZ (560 x 3040 x 6400 each) as ONE stream-K launch of k_gemm
+    (csrc/gemm.hip launch_gemm_batch: the unit space runs over all problems' tiles) against one launch per layer: the same products,
+    cut at other k positions -- fp32 rounding apart, and reproducible."""
+    size = {"RSRGAN_TEST_B": "64", "RSRGAN_TEST_T": "100"}
+    a = _run(dict(size))
+    b = _run(dict(size, RSRGAN_GEMM_BATCH="0"))
+    assert a["device_status"] == 0 and b["device_status"] == 0
+    for k in ("d0", "g0", "d1", "g1"):
+        assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-7), (k, a[k], b[k])
+    assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
+    c = _run(dict(size))
+    assert a["vars_sha"] == c["vars_sha"]
+
+
 @pytest.mark.parametrize("switch", ["RSRGAN_WGRAD_BATCH", "RSRGAN_DHEAD", "RSRGAN_FC_SIDE", "RSRGAN_WGRAD_STREAMS", "RSRGAN_LAZY_SWIZZLE",
                                     "RSRGAN_FUSED_SEG"])
 def test_round4_launch_fusions_agree(switch):
