@@ -1065,15 +1065,15 @@ bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only,
     ++prof_gb_n;
   } else
     launch_glstm_bwd(a, s);
-  auto din0 = [&]() {
+  auto din0 = [&](hipStream_t q) {
     if (ch[0].din && !din_inside) {
       const LayerRun& R = ch[0];
       const int H4 = 4 * R.L->H;
-      gemm(R.S->gates, H4, true, R.ps->W(R.L->tK), H4, true, R.din, R.L->ldI, T * R.N, R.L->I, H4, nullptr, 0, 0.f, false, s);
+      gemm(R.S->gates, H4, true, R.ps->W(R.L->tK), H4, true, R.din, R.L->ldI, T * R.N, R.L->I, H4, nullptr, 0, 0.f, false, q);
     }
   };
   if (!defer_wgrads) chain_wgrads(ch, T, s, din0, pre, post);
-  else { if (pre) pre(s); din0(); if (post) post(s); }
+  else { if (pre) pre(s); din0(s); if (post) post(s); }
   return true;
 }
 
@@ -1192,18 +1192,21 @@ void Model::layer_wgrads(const LayerRun& R, int T, hipStream_t s) {
 // `pre` / `post` (optional): launches of the caller that only need the BPTT's inputs / only `between`'s result (the output and input
 // FCs' parameter gradients: short launches that used to follow the dK GEMMs): they ride the side stream too, `post` behind an event
 // recorded on s right after `between`.
-void Model::chain_wgrads(Chain& ch, int T, hipStream_t s, const std::function<void()>& between, const StreamFn& pre, const StreamFn& post) {
+void Model::chain_wgrads(Chain& ch, int T, hipStream_t s, const StreamFn& between, const StreamFn& pre, const StreamFn& post) {
   static const int streams = [] { const char* e = getenv("RSRGAN_WGRAD_STREAMS"); return e ? atoi(e) : 2; }();
   int nw = 0;
   for (auto& R : ch) nw += R.want_wgrads ? 1 : 0;
   if (!side || streams < 2 || nw < 2) {
     if (pre) pre(s);
-    if (between) between();
+    if (between) between(s);
     if (post) post(s);
     for (auto& R : ch)
       if (R.want_wgrads) layer_wgrads(R, T, s);
     return;
   }
+  // RSRGAN_DIN0_SIDE=1: `between` (the input gradient of layer 0 and what hangs on it) rides the side stream as well, the chip-filling
+  // kernel-gradient GEMMs start at once on s
+  static const bool between_side = [] { const char* e = getenv("RSRGAN_DIN0_SIDE"); return e && atoi(e) != 0; }();
   hipEvent_t ev = ev_pool[ev_next++ & 15];
   (void)hipEventRecord(ev, s);
   (void)hipStreamWaitEvent(side, ev, 0);
@@ -1216,9 +1219,26 @@ void Model::chain_wgrads(Chain& ch, int T, hipStream_t s, const std::function<vo
     post(side);
   };
   bool dK_done = false;
-  if (batch_wgrads(ch, T, side, false, &dK_done)) {
+  if (between_side && between && post) {
+    between(side); post(side);                                  // (first on the side stream: what hangs on it is the longest chain there)
+    const bool rest = batch_wgrads(ch, T, side, false, &dK_done);
+    std::vector<const LayerRun*> rs;
+    for (auto& R : ch) if (R.want_wgrads) rs.push_back(&R);
+    bool batched = false;
+    if (rest && rs.size() >= 2 && rs.size() <= (size_t)GEMM_MAXB) {
+      const float *A_[GEMM_MAXB], *A2_[GEMM_MAXB], *B_[GEMM_MAXB]; float* C_[GEMM_MAXB];
+      const LstmLayer& L0 = *rs[0]->L;
+      for (size_t i = 0; i < rs.size(); ++i) { A_[i] = rs[i]->in; A2_[i] = rs[i]->S->mst; B_[i] = rs[i]->S->gates; C_[i] = rs[i]->ps->Gd(rs[i]->L->tK); }
+      batched = launch_gemm_batch((int)rs.size(), A_, L0.ldI, A2_, L0.ldP, L0.I, B_, 4 * L0.H, C_, 4 * L0.H, L0.I + L0.P, 4 * L0.H, T * rs[0]->N, false, s, gemm_ws, gemm_ws_floats);
+    }
+    for (auto& R : ch)
+      if (R.want_wgrads) {
+        if (!batched || !rest) layer_wgrads_gemms(R, 0, T, false, s, !batched, !rest);
+        if (!rest) layer_wgrads_colsums(R, T, s, scratch);
+      }
+  } else if (batch_wgrads(ch, T, side, false, &dK_done)) {
     // every layer's dWp + column sums as three launches beside the chip-filling dK GEMMs, which stay on s one after the other
-    if (between) between();
+    if (between) between(s);
     after_between();
     // the layers' kernel gradients [x | m]^T dZ: same shapes (batch_wgrads checked that) -> one stream-K launch over all of them
     std::vector<const LayerRun*> rs;
@@ -1241,7 +1261,7 @@ void Model::chain_wgrads(Chain& ch, int T, hipStream_t s, const std::function<vo
       if (first) { first = false; continue; }                  // (the lowest layer with weight gradients stays on s)
       layer_wgrads(R, T, side);
     }
-    if (between) between();
+    if (between) between(s);
     after_between();
     for (auto& R : ch)
       if (R.want_wgrads) { layer_wgrads(R, T, s); break; }
