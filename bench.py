@@ -533,7 +533,12 @@ def main():
         k_traffic = None
         k_rocprof_us = None
         headline = a.net == "lstm" and a.d_type == "lstm" and (B, T, a.gen_updates) == (64, 100, 1)
-        tf_path = os.path.join(ROOT, "profiles", "r4_final_traffic.json")
+        # the newest committed set of final profiles (profiles/r<N>_final_*)
+        import glob, re
+        rounds = sorted({int(m.group(1)) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_final_traffic.json"))
+                         for m in [re.search(r"r(\d+)_final_traffic", f)] if m})
+        ptag = "r%d" % rounds[-1] if rounds else "r4"
+        tf_path = os.path.join(ROOT, "profiles", "%s_final_traffic.json" % ptag)
         if headline and os.path.exists(tf_path):
             # HBM-side bytes from the committed PMC passes of this workload (tools/traffic.sh: separate FETCH_SIZE / WRITE_SIZE
             # passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); refused when the kernels have changed
@@ -546,7 +551,7 @@ def main():
                 w = [v for v in tj.get("top_write", []) if res["prof"][0] in v[0]]
                 if f and w and f[0][2] == w[0][2]:
                     k_traffic = int((2 * f[0][1] + w[0][1]) * 1024 / f[0][2])
-        cs_path = os.path.join(ROOT, "profiles", "r4_final_rocprofv3_kernel_stats.csv")
+        cs_path = os.path.join(ROOT, "profiles", "%s_final_rocprofv3_kernel_stats.csv" % ptag)
         if headline and os.path.exists(cs_path):
             import csv
             for row in csv.DictReader(open(cs_path)):
@@ -558,10 +563,19 @@ def main():
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "scope": "all launches of one (1D+1G) step on one GPU; algorithmic %d FLOP/frame x %d frames "
                              "(SURVEY 8d: 3*F_G+8*F_D, F_G=%d, F_D=%d) / HIP-event step time; traffic = HBM-side bytes "
-                             "per step from profiles/r4_final_traffic.json (null when that file is absent or stale)" % (fpf, B * T, fg, fd)}
+                             "per step from profiles/%s_final_traffic.json (null when that file is absent or stale)" % (fpf, B * T, fg, fd, ptag)}
+            ALG_BYTES = 1.3e9          # ~1.1 GB activation stash write + read, 164 MB Adam, 24 MB parameters, 7.6 MB inputs
+            ratio = {"algorithmic_bytes_per_step": int(ALG_BYTES)}
+            if traffic:
+                ratio["pmc"] = round(traffic / ALG_BYTES, 2)
             if res.get("hbm"):
                 roof["traffic_is"] = "L2 fabric requests of serialised cold-L2 dispatches incl. Infinity-Cache hits (PMC): an upper bound"
                 roof["hbm_activity"] = res["hbm"]
+                ratio["memory_controllers"] = round(res["hbm"]["hbm_bytes_per_step_estimate"] / ALG_BYTES, 2)
+                ratio["note"] = ("the two persistent generator launches alone keep the memory controllers 23 / 26 % busy (2.4 / 3.5 GB per "
+                                 "launch, profiles/r5_hbm_phases.txt): their write-through hand-off pieces DO reach DRAM -- about three "
+                                 "quarters of the step's memory-controller bytes; the step is at ~16 % of the HBM roof")
+            roof["traffic_ratio"] = ratio
             if res.get("chain"):
                 # the third bound: the recurrence is a chain of dependent launches; each costs at least a kernel boundary
                 # plus one dependent operand round trip, whatever its FLOPs
@@ -592,8 +606,8 @@ def main():
                            "input product above layer 0) or, with RSRGAN_GPERSIST=0, the k_fwd_gates launches of the wavefront.  avg_us: "
                            "every launch of one extra step bracketed by HIP events on its stream (rsrgan_profile_begin / read_kind / read; "
                            "includes the event records and the memset that arms the launch's hop-2 slots, an upper bound); "
-                           "rocprofv3_avg_us: AverageNs of the same kernel in the committed profiles/r4_final_rocprofv3_kernel_stats.csv "
-                           "of this command"}
+                           "rocprofv3_avg_us: AverageNs of the same kernel in the committed profiles/%s_final_rocprofv3_kernel_stats.csv "
+                           "of this command" % ptag}
         out = {"metric": "GAN train frames/sec (G+D step), 257-dim LPS->40-dim MFCC", "value": round(value, 1),
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt * 1e3 / a.steps, 4), "ms_per_step_median": round(res["med_ms"], 4),
