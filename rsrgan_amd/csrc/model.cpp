@@ -952,7 +952,8 @@ bool Model::persist_forward(Chain& ch, int T, hipStream_t s) {
 bool Model::gpersist_shape(GPersistArgs& a, int T) const {              // (sizes only: usable before any buffer exists)
   static const bool res_env = [] { const char* e = getenv("RSRGAN_GP_RES"); return !e || atoi(e) != 0; }();
   const bool res = cfg.g_type == RSRGAN_G_RES_LSTM_L && res_env;          // the running residual sum rides the hand-offs (gpersist.hip RES)
-  if (!gp_env || gl.empty() || gl.size() > (size_t)GP_MAXL || (cfg.g_type != RSRGAN_G_LSTM && !res)) return false;
+  // (res_lstm_base, models/res_lstm_base.py:101-139: the same stack of projected cells fed the input frames directly, no sums)
+  if (!gp_env || gl.empty() || gl.size() > (size_t)GP_MAXL || (cfg.g_type != RSRGAN_G_LSTM && cfg.g_type != RSRGAN_G_RES_LSTM_BASE && !res)) return false;
   a = GPersistArgs{};
   a.nl = (int)gl.size(); a.N = B; a.T = T; a.H = gl[0].H; a.res = res ? 1 : 0;
   for (size_t l = 0; l < gl.size(); ++l) {
@@ -1550,7 +1551,7 @@ void Model::g_backward_pass(int T, float* dy, hipStream_t s) {
       ch[l].dout = cur; ch[l].din = l > 0 ? other : nullptr; ch[l].din_accumulate = false;
       std::swap(cur, other);
     }
-    rnn_backward(chains, T, s);
+    if (!persist_backward_g(ch, T, s)) rnn_backward(chains, T, s);
   }
 }
 

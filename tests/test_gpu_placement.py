@@ -21,7 +21,8 @@ sys.path.insert(0, %r)
 from oracle import rsrgan_oracle as O
 from tests.helpers import NET_D, NET_G, build_hip_pair, rand_batch
 import os
-cfg = O.NetCfg.res_lstm_l() if os.environ.get("RSRGAN_TEST_NET") == "res_lstm_l" else O.NetCfg()      # the reference's sizes: G 3x760/p280 (or the shipped 4x760/p257 residual stack), D 2x256/p40
+_net = os.environ.get("RSRGAN_TEST_NET")
+cfg = O.NetCfg.res_lstm_l() if _net == "res_lstm_l" else O.NetCfg.res_lstm_l(g_type="res_lstm_base") if _net == "res_lstm_base" else O.NetCfg()      # the reference's sizes: G 3x760/p280 (or the shipped 4x760/p257 residual stack), D 2x256/p40
 B, T = int(os.environ.get("RSRGAN_TEST_B", "8")), int(os.environ.get("RSRGAN_TEST_T", "7"))
 model, _ = build_hip_pair(cfg, B, T, seed=5, flags=3)
 x, lab, ln = rand_batch(cfg, B, T, seed=6, ragged=True)
@@ -158,6 +159,19 @@ def test_persistent_residual_generator_agrees(B, T):
     assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
     c = _run(dict(size))
     assert a["vars_sha"] == c["vars_sha"]          # fixed summation order: reproducible bits
+
+
+def test_persistent_base_generator_agrees():
+    """res_lstm_base (models/res_lstm_base.py: the same four projected cells without the residual sums, fed the input frames
+    directly): the persistent launches' plain form with a 257-wide layer 0 input read from memory, against the launch path."""
+    size = {"RSRGAN_TEST_B": "32", "RSRGAN_TEST_T": "9", "RSRGAN_TEST_NET": "res_lstm_base"}
+    a = _run(dict(size))
+    b = _run(dict(size, RSRGAN_GPERSIST="0"))
+    assert b["chain_launches"] - a["chain_launches"] >= 2 * 8, (a["chain_launches"], b["chain_launches"])
+    assert a["device_status"] == 0 and b["device_status"] == 0
+    for k in ("d0", "g0", "d1", "g1"):
+        assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-7), (k, a[k], b[k])
+    assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
 
 
 def test_batched_kernel_gradient_gemm_agrees():
