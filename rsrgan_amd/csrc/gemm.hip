@@ -23,6 +23,7 @@
 //     through the epilogue; pieces go to a work space in the accumulator layout (coalesced 16-byte stores) and k_gemm_fixup
 //     sums the pieces of a tile in k order (fixed order: deterministic, no float atomics) and runs the same epilogue.
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 
@@ -54,11 +55,13 @@ struct GemmArgs {
   int tiles_m, tiles_n, NT, NK, W, n_dp;     // tile grid, tiles, k-tiles, workers, tiles of the data-parallel rounds
   int Uq, Ur;                                // units of the stream-K region = Uq * W + Ur (all unit arithmetic is 32-bit)
   GemmRowMap ma;                             // row map of A (kernels.h), used by the MAP instantiations only
-  // a BATCH of nb same-shaped products in one launch (round 5: the three layers' weight gradients [x | m]^T dZ): tile column
-  // tn belongs to problem tn / tn1, whose operands replace A / A2 / B / C -- one stream-K unit space over all problems' tiles
-  int nb, tn1;
-  const float* Ab[GEMM_MAXB]; const float* A2b[GEMM_MAXB]; const float* Bb[GEMM_MAXB]; float* Cb[GEMM_MAXB];
 };
+// a BATCH of nb same-shaped products in one launch (round 5: the three layers' weight gradients [x | m]^T dZ): tile column tn
+// belongs to problem tn / tn1, whose operands replace A / A2 / B / C -- one stream-K unit space over all problems' tiles.  A second
+// kernel argument of the batched instantiation only (NoBatch elsewhere: the other kernels' argument block and code stay as they were --
+// with the table inside GemmArgs every k_gemm lost ~5-10 %: d(h0) 141 -> 156 us, the SEGAN step 19.7 -> 20.8 ms)
+struct GemmBatch { int nb, tn1; const float* Ab[GEMM_MAXB]; const float* A2b[GEMM_MAXB]; const float* Bb[GEMM_MAXB]; float* Cb[GEMM_MAXB]; };
+struct NoBatch { int nb; };
 // first unit of worker w: floor(w * U / W)
 __device__ __forceinline__ int worker_lo(const GemmArgs& g, int w) { return w * g.Uq + (w * g.Ur) / g.W; }
 // tile index -> (tile row, tile column): groups of 4 tile rows, column-major inside a group, so that the ~32 tiles an XCD works on
@@ -197,8 +200,9 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[RT][CT], int m
 // for 64: with the DMA in the MFMA waves' own instruction stream (round 3 first form, one chunk behind every fourth MFMA) the pipe
 // idled behind every DMA -- 112 TFLOP/s at 4096^3 with one wave per SIMD against 133 with the DMA ablated and 143 with DMA and
 // fragment reads ablated (tools/ubench/gemm_bench.hip `abl`).  A loader wave stalls on its own; the SIMD issues the MFMA wave next to it.
-template <bool AKC, bool BKC, int RT, int CT, int WM, bool MAPA>
-__global__ __launch_bounds__(64 * (4 + NL), RSR_GEMM_MINW) void k_gemm(const GemmArgs g) {
+template <bool AKC, bool BKC, int RT, int CT, int WM, bool MAPA, class BT = NoBatch>
+__global__ __launch_bounds__(64 * (4 + NL), RSR_GEMM_MINW) void k_gemm(const GemmArgs g, const BT bt) {
+  constexpr bool BATCH = std::is_same<BT, GemmBatch>::value;
   constexpr int WN = 4 / WM, BM = WM * RT * 32, BN = WN * CT * 32;
   typedef Stage<AKC, BM, MAPA> SA;
   typedef Stage<BKC, BN, false> SB;
@@ -230,7 +234,10 @@ __global__ __launch_bounds__(64 * (4 + NL), RSR_GEMM_MINW) void k_gemm(const Gem
     int tm, tn;
     tile_rc(g, t, tm, tn);
     const float* pA = g.A; const float* pA2 = g.A2; const float* pB = g.B; float* pC = g.C;
-    if (g.nb > 1) { const int b = tn / g.tn1; tn -= b * g.tn1; pA = g.Ab[b]; pA2 = g.A2b[b]; pB = g.Bb[b]; pC = g.Cb[b]; }
+    if constexpr (BATCH) {
+      const GemmBatch& gb = reinterpret_cast<const GemmBatch&>(bt);
+      const int b = tn / gb.tn1; tn -= b * gb.tn1; pA = gb.Ab[b]; pA2 = gb.A2b[b]; pB = gb.Bb[b]; pC = gb.Cb[b];
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     if (wid >= 4) {
       // ---- loader wave: runs NBUF-1 k-tiles ahead of the MFMA waves through a ring of NBUF LDS buffers.  One barrier per k-tile:
@@ -499,8 +506,9 @@ __global__ __launch_bounds__(256, 1) void k_gemm_s(const GemmArgs g) {
 }
 
 // tile `ts` of the stream-K region: the workers whose runs cut it, in k order; first run of a worker -> slot 2w, last -> 2w+1
-template <int RT, int CT, int WM>
-__global__ __launch_bounds__(256) void k_gemm_fixup(const GemmArgs g) {
+template <int RT, int CT, int WM, class BT = NoBatch>
+__global__ __launch_bounds__(256) void k_gemm_fixup(const GemmArgs g, const BT bt) {
+  constexpr bool BATCH = std::is_same<BT, GemmBatch>::value;
   constexpr int WN = 4 / WM, BM = WM * RT * 32, BN = WN * CT * 32;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   const int wid = tid >> 6, wr = wid / WN, wc = wid - wr * WN;
@@ -563,7 +571,7 @@ __global__ __launch_bounds__(256) void k_gemm_fixup(const GemmArgs g) {
   int tm, tn;
   tile_rc(g, t, tm, tn);
   float* pC = g.C;
-  if (g.nb > 1) { const int b = tn / g.tn1; tn -= b * g.tn1; pC = g.Cb[b]; }
+  if constexpr (BATCH) { const GemmBatch& gb = reinterpret_cast<const GemmBatch&>(bt); const int b = tn / gb.tn1; tn -= b * gb.tn1; pC = gb.Cb[b]; }
   gemm_epilogue<RT, CT>(acc, tm * BM + wr * RT * 32, tn * BN + wc * CT * 32, l31, lh, g, pC);
 }
 
@@ -899,7 +907,7 @@ Plan plan_cfg(int M, int N, int K, int bm, int bn, int workers, float* ws, size_
 }
 
 template <bool AKC, bool BKC, int RT, int CT, int WM, bool MAPA>
-void launch_cfg(GemmArgs& g, const Plan& pl, hipStream_t s, float* ws) {
+void launch_cfg(GemmArgs& g, const Plan& pl, hipStream_t s, float* ws, GemmBatch* bt = nullptr) {
   constexpr int WN = 4 / WM, BM = WM * RT * 32, BN = WN * CT * 32;
   constexpr size_t lds = (size_t)ring_depth(BM, BN) * (BM + BN) * GK * sizeof(float);
   static bool attr = false;
@@ -908,17 +916,26 @@ void launch_cfg(GemmArgs& g, const Plan& pl, hipStream_t s, float* ws) {
     attr = true;
   }
   g.tiles_m = (g.M + BM - 1) / BM;
-  g.tn1 = (g.N + BN - 1) / BN;
-  g.tiles_n = g.tn1 * std::max(1, g.nb);                     // (a batch: every problem's tile columns side by side)
+  g.tiles_n = ((g.N + BN - 1) / BN) * (bt ? bt->nb : 1);     // (a batch: every problem's tile columns side by side)
   g.NT = g.tiles_m * g.tiles_n;
   g.NK = (g.K + GK - 1) / GK;
   if ((long long)g.NT * g.NK >= (1LL << 30)) { fprintf(stderr, "rsrgan: GEMM beyond the 32-bit (tile, k-tile) unit arithmetic\n"); abort(); }
   g.ws = ws; g.W = pl.W; g.n_dp = pl.n_dp;
   const int U = (g.NT - g.n_dp) * g.NK;
   g.Uq = U / g.W; g.Ur = U % g.W;
-  hipLaunchKernelGGL((k_gemm<AKC, BKC, RT, CT, WM, MAPA>), dim3(g.W), dim3(64 * (4 + NL)), lds, s, g);
-  if (U > 0 && !(U % g.W == 0 && (U / g.W) % g.NK == 0))     // some tile is cut: sum its pieces
-    hipLaunchKernelGGL((k_gemm_fixup<RT, CT, WM>), dim3(g.NT - g.n_dp), dim3(256), 0, s, g);
+  const bool cut = U > 0 && !(U % g.W == 0 && (U / g.W) % g.NK == 0);      // some tile is cut: sum its pieces
+  if (bt) {
+    if constexpr (!AKC && !BKC && !MAPA && RT == 2 && CT == 2 && WM == 2) {
+      static bool attr_b = false;
+      if (!attr_b) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<AKC, BKC, RT, CT, WM, MAPA, GemmBatch>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_b = true; }
+      bt->tn1 = (g.N + BN - 1) / BN;
+      hipLaunchKernelGGL((k_gemm<AKC, BKC, RT, CT, WM, MAPA, GemmBatch>), dim3(g.W), dim3(64 * (4 + NL)), lds, s, g, *bt);
+      if (cut) hipLaunchKernelGGL((k_gemm_fixup<RT, CT, WM, GemmBatch>), dim3(g.NT - g.n_dp), dim3(256), 0, s, g, *bt);
+    }
+    return;
+  }
+  hipLaunchKernelGGL((k_gemm<AKC, BKC, RT, CT, WM, MAPA>), dim3(g.W), dim3(64 * (4 + NL)), lds, s, g, NoBatch{0});
+  if (cut) hipLaunchKernelGGL((k_gemm_fixup<RT, CT, WM>), dim3(g.NT - g.n_dp), dim3(256), 0, s, g, NoBatch{0});
 }
 
 template <bool AKC, bool BKC, int RT, int CT, int WM, bool MAPA>
@@ -940,7 +957,7 @@ void launch_cfg_s(GemmArgs& g, const Plan& pl, hipStream_t s, float* ws) {
   g.Uq = U / g.W; g.Ur = U % g.W;
   hipLaunchKernelGGL((k_gemm_s<AKC, BKC, RT, CT, WM, MAPA>), dim3(g.W), dim3(256), lds, s, g);
   if (U > 0 && !(U % g.W == 0 && (U / g.W) % g.NK == 0))
-    hipLaunchKernelGGL((k_gemm_fixup<RT, CT, WM>), dim3(g.NT - g.n_dp), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((k_gemm_fixup<RT, CT, WM>), dim3(g.NT - g.n_dp), dim3(256), 0, s, g, NoBatch{0});
 }
 
 template <bool AKC, bool BKC, bool MAPA>
@@ -1097,11 +1114,12 @@ bool launch_gemm_batch(int nb, const float* const* A, int lda, const float* cons
   g.lda = lda; g.lda2 = lda2; g.M1 = M1; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
   g.act = 0; g.accumulate = accumulate ? 1 : 0; g.alpha = 0.f;
   g.ma = GemmRowMap{0, 0, 0};
-  g.nb = nb;
-  for (int b = 0; b < nb; ++b) { g.Ab[b] = A[b]; g.A2b[b] = A2 ? A2[b] : nullptr; g.Bb[b] = B[b]; g.Cb[b] = C[b]; }
+  GemmBatch bt{};
+  bt.nb = nb;
+  for (int b = 0; b < nb; ++b) { bt.Ab[b] = A[b]; bt.A2b[b] = A2 ? A2[b] : nullptr; bt.Bb[b] = B[b]; bt.Cb[b] = C[b]; }
   const int tn1 = (N + 127) / 128;
   const Plan pl = plan_cfg(M, nb * tn1 * 128, K, 128, 128, g_gemm_workers, ws, ws_floats);
-  launch_cfg<false, false, 2, 2, 2, false>(g, pl, s, ws);
+  launch_cfg<false, false, 2, 2, 2, false>(g, pl, s, ws, &bt);
   return true;
 }
 
