@@ -227,10 +227,18 @@ def test_dp_sequence_around_the_persistent_launches(B, T):
         import time; time.sleep(0.2)
         vc = run(busy, "dp")
         stop.set(); th.join(timeout=20)
+        # the fused step hands the three layers' kernel gradients to ONE batched stream-K launch where the product is large enough
+        # (csrc/gemm.hip launch_gemm_batch: T = 100), the bucketed sequence needs them layer by layer: same products cut at other k
+        # positions, so fused and bucketed agree to fp32 rounding there (Adam then moves an element by ~lr whatever its gradient's
+        # size) and bit for bit where the batch is not taken (T = 9); a busy communication stream must never change a bit
+        batched = T * B >= 2048
         for p_, q_, r_ in zip(va, vb, vc):
             for k in p_:
-                assert np.array_equal(p_[k], q_[k]), ("dp", k)
-                assert np.array_equal(p_[k], r_[k]), ("dp, busy communication stream", k)
+                if batched:
+                    assert np.abs(p_[k] - q_[k]).max() <= 6 * 2 * 8e-5 and np.abs(p_[k] - q_[k]).mean() <= 2e-6, ("dp", k)
+                else:
+                    assert np.array_equal(p_[k], q_[k]), ("dp", k)
+                assert np.array_equal(q_[k], r_[k]), ("dp, busy communication stream", k)
         # the persistent launches are what ran: one k_glstm_fwd + one k_glstm_bwd per iteration
         dp.engine.profile_begin()
         x, lab, ln = rand_batch(cfg, B, T, seed=99, ragged=True)

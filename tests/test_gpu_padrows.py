@@ -94,6 +94,15 @@ for it in range(3):      # (the first pass without the updates: a failed launch 
     out.setdefault("status", []).append(int(model.engine.device_status()))
 if os.environ.get("RSRGAN_TEST_FLAGS") == "1":
     out["n_gp"] = int(model.engine.profile_read_kind(1)[0] + model.engine.profile_read_kind(2)[0]); model.engine.profile_read()
+# after the passes: the variables put back (a failed launch's update has poisoned them), one evaluation on whatever path the handle
+# is on now against the oracle at the same variables
+from tests.helpers import rand_params
+g0, d0 = rand_params(cfg, 31)
+model.set_vars(g0, d0)
+ev_d = np.ravel(model.d_step(x, lab, ln, train=False)); ev_g = np.ravel(model.g_step(x, lab, ln, train=False))
+out["status"].append(int(model.engine.device_status()))
+out["recovered"] = bool(np.allclose(ev_d, np.ravel(oracle.d_step(x, lab, ln, train=False)), rtol=1e-3) and
+                        np.allclose(ev_g, np.ravel(oracle.g_step(x, lab, ln, train=False)), rtol=1e-3))
 want_d = np.ravel(oracle.d_step(x, lab, ln)); want_g = np.ravel(oracle.g_step(x, lab, ln))
 out["ok"] = bool(np.allclose(out["d"][1], want_d, rtol=1e-3) and np.allclose(out["g"][1], want_g, rtol=1e-3))
 import torch
@@ -118,9 +127,9 @@ def test_half_the_device_falls_back_without_time_outs(mask):
     t0 = time.time()
     r = _worker(dict(mask, RSRGAN_TEST_FLAGS="1"))
     dt = time.time() - t0
-    assert r["ok"] and r["status"] == [0, 0, 0], r
+    assert r["ok"] and r["recovered"] and r["status"] == [0, 0, 0, 0], r
     full = _worker({"RSRGAN_TEST_FLAGS": "1"})
-    assert full["ok"] and full["status"] == [0, 0, 0] and full["n_gp"] == 6, full      # (two forwards in the first pass, then forward + BPTT per iteration)
+    assert full["ok"] and full["recovered"] and full["status"] == [0, 0, 0, 0] and full["n_gp"] == 6, full      # (two forwards in the first pass, then forward + BPTT per iteration)
     if r["n_gp"] != 0:
         pytest.skip("the CU mask %r is not honoured in this environment (the persistent launches ran: %d)" % (mask, r["n_gp"]))
     assert dt < 120, dt
@@ -136,5 +145,7 @@ def test_a_failed_persistent_launch_disables_the_path_for_the_handle():
     if not bad:
         pytest.skip("the CU mask is not honoured in this environment (no launch failed)")
     assert bad[0] < 2 and r["status"][bad[0]] >= 0x10000, r["status"]
-    assert all(v == 0 for v in r["status"][bad[0] + 1:]), r["status"]
-    assert all(np.isfinite(v) for v in r["d"][2] + r["g"][2]), r
+    assert all(v == 0 for v in r["status"][bad[0] + 1:]), r["status"]          # no further time-outs: the handle has left the path
+    # (the failed pass was a training pass: its update ran on the poisoned gradients, as the header says of a failed launch; with the
+    #  variables put back the handle computes the oracle's values on the launch path)
+    assert r["recovered"], r
