@@ -373,8 +373,9 @@ __global__ __launch_bounds__(64 * (4 + NL), RSR_GEMM_MINW) void k_gemm(const Gem
 // vmcnt(0) + barrier per k-tile.  k_gemm at 128 x 128 is ingest-bound (8 B/clk/CU against ~6.8); a 256 x 256 x 32 k-tile needs
 // 64 KB per 16384 MFMA cycles = 4 B/clk, 128 x 256 needs 6 (section 6-R3: the design point of the vendor library's kernels).
 // ------------------------------------------------------------------------------------------------------------------------
-template <bool AKC, bool BKC, int RT, int CT, int WM, bool MAPA>
-__global__ __launch_bounds__(256, 1) void k_gemm_s(const GemmArgs g) {
+template <bool AKC, bool BKC, int RT, int CT, int WM, bool MAPA, class BT = NoBatch>
+__global__ __launch_bounds__(256, 1) void k_gemm_s(const GemmArgs g, const BT bt) {
+  constexpr bool BATCH = std::is_same<BT, GemmBatch>::value;
   constexpr int WN = 4 / WM, BM = WM * RT * 32, BN = WN * CT * 32;
   typedef Stage<AKC, BM, MAPA, 4> SA;
   typedef Stage<BKC, BN, false, 4> SB;
@@ -400,13 +401,18 @@ __global__ __launch_bounds__(256, 1) void k_gemm_s(const GemmArgs g) {
     }
     int tm, tn;
     tile_rc(g, t, tm, tn);
+    const float* pA = g.A; const float* pA2 = g.A2; const float* pB = g.B; float* pC = g.C;
+    if constexpr (BATCH) {
+      const GemmBatch& gb = reinterpret_cast<const GemmBatch&>(bt);
+      const int b = tn / gb.tn1; tn -= b * gb.tn1; pA = gb.Ab[b]; pA2 = gb.A2b[b]; pB = gb.Bb[b]; pC = gb.Cb[b];
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     SA sa; SB sb;
-    sa.init(g.A, g.lda, g.A2, g.lda2, g.M1, m0, g.M, i0 * GK, lane, wid, g.ma);
-    sb.init(g.B, g.ldb, nullptr, 0, 0, n0, g.N, i0 * GK, lane, wid, g.ma);
+    sa.init(pA, g.lda, pA2, g.lda2, g.M1, m0, g.M, i0 * GK, lane, wid, g.ma);
+    sb.init(pB, g.ldb, nullptr, 0, 0, n0, g.N, i0 * GK, lane, wid, g.ma);
     constexpr int NIT = SA::NI + SB::NI;                   // DMA instructions per wave and k-tile
     __builtin_amdgcn_s_barrier();                          // the previous tile's last k-tile has been read by every wave
-    sa.issue(i0 * GK, g.K, true, smem, lane, wid, g.lda, g.lda2, g.M1, m0, g.M, g.A2, g.ma);
+    sa.issue(i0 * GK, g.K, true, smem, lane, wid, g.lda, g.lda2, g.M1, m0, g.M, pA2, g.ma);
     sb.issue(i0 * GK, g.K, true, smem + SA::FLOATS, lane, wid, g.ldb, 0, 0, n0, g.N, nullptr, g.ma);
     f32x16 acc[RT][CT];
 #pragma unroll
@@ -473,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_s(const GemmArgs g) {
               __builtin_amdgcn_sched_barrier(0);
               const int d = (gm * NIT) / NM;
               if (gm == ((2 * d + 1) * NM) / (2 * NIT) && more) {      // behind an MFMA: the matrix pipe has work while the DMA issues
-                if (d < SA::NI) sa.issue_one(d, (kt + 1) * GK, g.K, true, bnx, lane, wid, g.lda, g.lda2, g.M1, m0, g.M, g.A2, g.ma);
+                if (d < SA::NI) sa.issue_one(d, (kt + 1) * GK, g.K, true, bnx, lane, wid, g.lda, g.lda2, g.M1, m0, g.M, pA2, g.ma);
                 else sb.issue_one(d - SA::NI, (kt + 1) * GK, g.K, true, bnx + SA::FLOATS, lane, wid, g.ldb, 0, 0, n0, g.N, nullptr, g.ma);
                 __builtin_amdgcn_sched_barrier(0);
               }
@@ -489,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_s(const GemmArgs g) {
       __builtin_amdgcn_s_barrier();                        // ... everybody's; and k-tile kt has been read by every wave
     }
     if (i0 == 0 && i1 == g.NK) {
-      gemm_epilogue<RT, CT>(acc, m0 + wr * RT * 32, n0 + wc * CT * 32, l31, lh, g, g.C);
+      gemm_epilogue<RT, CT>(acc, m0 + wr * RT * 32, n0 + wc * CT * 32, l31, lh, g, pC);
     } else {
       const int pslot = 2 * w + (u == u_lo ? 0 : 1);
       float4* q = reinterpret_cast<float4*>(g.ws) + (size_t)pslot * (RT * CT * 4 * 256) + tid;
@@ -523,31 +529,37 @@ __global__ __launch_bounds__(256) void k_gemm_fixup(const GemmArgs g, const BT b
   };
   const int wa = owner(ua), wb = owner(ub);
   if (wa == wb) return;                                   // one worker owned the whole tile and wrote it
-  f32x16 acc[RT][CT];
+  // Large tiles (k_gemm_s: up to 4 x 4 sub-tiles per wave = 64 float4 per thread and piece): one block per ROW of sub-tiles
+  // (blockIdx.y) -- RT times the blocks, and a piece row is small enough to keep two pieces in flight (round 5: the 192 x 256
+  // tiles of the batched dK launch have 108 tiles for 256 CUs: 83 us as one block per tile)
+  constexpr bool SPLITI = RT * CT * 4 > 16;
+  constexpr int RTL = SPLITI ? 1 : RT;
+  const int isel = SPLITI ? blockIdx.y : 0;
+  f32x16 acc[RTL][CT];
 #pragma unroll
-  for (int i = 0; i < RT; ++i)
+  for (int i = 0; i < RTL; ++i)
 #pragma unroll
     for (int j = 0; j < CT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   // pieces in k order, TWO in flight when the tile is small enough to hold them in registers (a tile of a long-K product is cut into
   // 3-10 pieces: one dependent round trip per piece made this launch 20 us in the SEGAN step); the sums keep their order
-  constexpr int NQ4 = RT * CT * 4;
-  constexpr bool PAIR = NQ4 <= 16;
+  constexpr int NQ4 = RT * CT * 4, NQL = RTL * CT * 4;
+  constexpr bool PAIR = NQL <= 16;
   auto slot_of = [&](int w) { return 2 * w + (worker_lo(g, w) / g.NK == ts ? 0 : 1); };
   for (int w = wa; w <= wb; w += PAIR ? 2 : 1) {
-    const float4* q0 = reinterpret_cast<const float4*>(g.ws) + (size_t)slot_of(w) * (NQ4 * 256) + tid;
+    const float4* q0 = reinterpret_cast<const float4*>(g.ws) + (size_t)slot_of(w) * (NQ4 * 256) + (size_t)isel * (CT * 4 * 256) + tid;
     const bool two = PAIR && w + 1 <= wb;
-    const float4* q1 = reinterpret_cast<const float4*>(g.ws) + (size_t)slot_of(two ? w + 1 : w) * (NQ4 * 256) + tid;
-    float4 v0[NQ4], v1[PAIR ? NQ4 : 1];
+    const float4* q1 = reinterpret_cast<const float4*>(g.ws) + (size_t)slot_of(two ? w + 1 : w) * (NQ4 * 256) + (size_t)isel * (CT * 4 * 256) + tid;
+    float4 v0[NQL], v1[PAIR ? NQL : 1];
 #pragma unroll
-    for (int x = 0; x < NQ4; ++x) v0[x] = q0[x * 256];
+    for (int x = 0; x < NQL; ++x) v0[x] = q0[x * 256];
     if (PAIR) {
 #pragma unroll
-      for (int x = 0; x < NQ4; ++x) v1[x] = q1[x * 256];             // (unconditional: the last odd piece is read twice, added once)
+      for (int x = 0; x < NQL; ++x) v1[x] = q1[x * 256];             // (unconditional: the last odd piece is read twice, added once)
     }
 #pragma unroll
-    for (int i = 0; i < RT; ++i)
+    for (int i = 0; i < RTL; ++i)
 #pragma unroll
       for (int j = 0; j < CT; ++j)
 #pragma unroll
@@ -557,7 +569,7 @@ __global__ __launch_bounds__(256) void k_gemm_fixup(const GemmArgs g, const BT b
         }
     if (PAIR && two) {
 #pragma unroll
-      for (int i = 0; i < RT; ++i)
+      for (int i = 0; i < RTL; ++i)
 #pragma unroll
         for (int j = 0; j < CT; ++j)
 #pragma unroll
@@ -572,7 +584,7 @@ __global__ __launch_bounds__(256) void k_gemm_fixup(const GemmArgs g, const BT b
   tile_rc(g, t, tm, tn);
   float* pC = g.C;
   if constexpr (BATCH) { const GemmBatch& gb = reinterpret_cast<const GemmBatch&>(bt); const int b = tn / gb.tn1; tn -= b * gb.tn1; pC = gb.Cb[b]; }
-  gemm_epilogue<RT, CT>(acc, tm * BM + wr * RT * 32, tn * BN + wc * CT * 32, l31, lh, g, pC);
+  gemm_epilogue<RTL, CT>(acc, tm * BM + wr * RT * 32 + isel * 32, tn * BN + wc * CT * 32, l31, lh, g, pC);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -930,34 +942,36 @@ void launch_cfg(GemmArgs& g, const Plan& pl, hipStream_t s, float* ws, GemmBatch
       if (!attr_b) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<AKC, BKC, RT, CT, WM, MAPA, GemmBatch>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_b = true; }
       bt->tn1 = (g.N + BN - 1) / BN;
       hipLaunchKernelGGL((k_gemm<AKC, BKC, RT, CT, WM, MAPA, GemmBatch>), dim3(g.W), dim3(64 * (4 + NL)), lds, s, g, *bt);
-      if (cut) hipLaunchKernelGGL((k_gemm_fixup<RT, CT, WM, GemmBatch>), dim3(g.NT - g.n_dp), dim3(256), 0, s, g, *bt);
+      if (cut) hipLaunchKernelGGL((k_gemm_fixup<RT, CT, WM, GemmBatch>), dim3(g.NT - g.n_dp, RT * CT * 4 > 16 ? RT : 1), dim3(256), 0, s, g, *bt);
     }
     return;
   }
   hipLaunchKernelGGL((k_gemm<AKC, BKC, RT, CT, WM, MAPA>), dim3(g.W), dim3(64 * (4 + NL)), lds, s, g, NoBatch{0});
-  if (cut) hipLaunchKernelGGL((k_gemm_fixup<RT, CT, WM>), dim3(g.NT - g.n_dp), dim3(256), 0, s, g, NoBatch{0});
+  if (cut) hipLaunchKernelGGL((k_gemm_fixup<RT, CT, WM>), dim3(g.NT - g.n_dp, RT * CT * 4 > 16 ? RT : 1), dim3(256), 0, s, g, NoBatch{0});
 }
 
-template <bool AKC, bool BKC, int RT, int CT, int WM, bool MAPA>
-void launch_cfg_s(GemmArgs& g, const Plan& pl, hipStream_t s, float* ws) {
+template <bool AKC, bool BKC, int RT, int CT, int WM, bool MAPA, class BT = NoBatch>
+void launch_cfg_s(GemmArgs& g, const Plan& pl, hipStream_t s, float* ws, BT* bt = nullptr) {
   constexpr int WN = 4 / WM, BM = WM * RT * 32, BN = WN * CT * 32;
   constexpr size_t lds = (size_t)2 * (BM + BN) * GK * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_s<AKC, BKC, RT, CT, WM, MAPA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_s<AKC, BKC, RT, CT, WM, MAPA, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
   g.tiles_m = (g.M + BM - 1) / BM;
-  g.tiles_n = (g.N + BN - 1) / BN;
+  g.tiles_n = ((g.N + BN - 1) / BN) * (bt ? bt->nb : 1);
   g.NT = g.tiles_m * g.tiles_n;
   g.NK = (g.K + GK - 1) / GK;
   if ((long long)g.NT * g.NK >= (1LL << 30)) { fprintf(stderr, "rsrgan: GEMM beyond the 32-bit (tile, k-tile) unit arithmetic\n"); abort(); }
   g.ws = ws; g.W = pl.W; g.n_dp = pl.n_dp;
   const int U = (g.NT - g.n_dp) * g.NK;
   g.Uq = U / g.W; g.Ur = U % g.W;
-  hipLaunchKernelGGL((k_gemm_s<AKC, BKC, RT, CT, WM, MAPA>), dim3(g.W), dim3(256), lds, s, g);
+  BT btv{}; if (bt) { btv = *bt; }
+  if constexpr (std::is_same<BT, GemmBatch>::value) btv.tn1 = (g.N + BN - 1) / BN;
+  hipLaunchKernelGGL((k_gemm_s<AKC, BKC, RT, CT, WM, MAPA, BT>), dim3(g.W), dim3(256), lds, s, g, btv);
   if (U > 0 && !(U % g.W == 0 && (U / g.W) % g.NK == 0))
-    hipLaunchKernelGGL((k_gemm_fixup<RT, CT, WM>), dim3(g.NT - g.n_dp), dim3(256), 0, s, g, NoBatch{0});
+    hipLaunchKernelGGL((k_gemm_fixup<RT, CT, WM, BT>), dim3(g.NT - g.n_dp, RT * CT * 4 > 16 ? RT : 1), dim3(256), 0, s, g, btv);
 }
 
 template <bool AKC, bool BKC, bool MAPA>
@@ -1117,6 +1131,18 @@ bool launch_gemm_batch(int nb, const float* const* A, int lda, const float* cons
   GemmBatch bt{};
   bt.nb = nb;
   for (int b = 0; b < nb; ++b) { bt.Ab[b] = A[b]; bt.A2b[b] = A2 ? A2[b] : nullptr; bt.Bb[b] = B[b]; bt.Cb[b] = C[b]; }
+  // 192 x 256 tiles on the four self-loading waves of k_gemm_s (accumulators in AGPRs): 0.018 B/FLOP of operand ingest instead of
+  // 0.031 at 128 x 128, and M = 560 is 2.9 tiles of 192 (2.8 % padding) against 4.4 of 128 (12.5 %).  RSRGAN_GEMM_BATCH=2: the 128 x 128 form.
+  static const int form = [] { const char* e = getenv("RSRGAN_GEMM_BATCH"); return e ? atoi(e) : 1; }();
+  const int pad192 = (M + 191) / 192 * 192, pad128 = (M + 127) / 128 * 128;
+  if (form == 1 && pad192 < pad128 && 2 * (size_t)g_gemm_workers * 192 * 256 <= ws_floats) {
+    const int tn1 = (N + 255) / 256;
+    // k_gemm_s fills a CU's register file: nothing of the side stream (dWp, column sums, the FCs' gradients) co-resides with it, and
+    // behind the launch that work is exposed.  RSRGAN_GEMM_BATCH_W workers (a multiple of 8) leave the other CUs to the side stream.
+    static const int bw = [] { const char* e = getenv("RSRGAN_GEMM_BATCH_W"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 256 ? v & ~7 : 0; }();
+    const Plan pl = plan_cfg(M, nb * tn1 * 256, K, 192, 256, bw ? std::min(bw, g_gemm_workers) : g_gemm_workers, ws, ws_floats);
+    if (!pl.whole) { launch_cfg_s<false, false, 3, 4, 2, false, GemmBatch>(g, pl, s, ws, &bt); return true; }
+  }
   const int tn1 = (N + 127) / 128;
   const Plan pl = plan_cfg(M, nb * tn1 * 128, K, 128, 128, g_gemm_workers, ws, ws_floats);
   launch_cfg<false, false, 2, 2, 2, false>(g, pl, s, ws, &bt);

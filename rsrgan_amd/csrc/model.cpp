@@ -491,7 +491,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     for (auto& e : ev_pool)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { side = nullptr; break; }
   }
-  gemm_ws_floats = (size_t)16 << 20;          // 64 MiB of split-K partial tiles
+  gemm_ws_floats = (size_t)32 << 20;          // 128 MiB of split-K partial tiles / stream-K pieces (two 192 x 256 pieces per worker: 100 MB)
   gemm_ws = alloc<float>(gemm_ws_floats);
   if (!gemm_ws) gemm_ws_floats = 0;
   bwdb_ws_floats = (size_t)8 << 20;
