@@ -239,6 +239,9 @@ int main(int argc, char** argv) {
                                {560, 3040, 800}, {560, 3040, 1600}, {1120, 3040, 6400}, {6400, 280, 3040}, {6400, 280, 9120}};
       for (auto& sh : shapes) time_one(sh[0], sh[1], sh[2], false, false);
       time_one(6400, 280, 3040, true, true);
+      // d(h0) = dZ_0 . K_x^T: 150 tiles of 128 x 96 -- stream-K over 256 workers + fix-up, or one round of whole tiles on fewer workers?
+      for (int wk : {256, 152, 200}) { rsr::g_gemm_workers = wk; printf("workers=%d: ", wk); time_one(6400, 280, 3040, true, true); }
+      rsr::g_gemm_workers = 256;
     }
   if (do_time) {
     const int shapes[][3] = {{4096, 4096, 4096}, {560, 3040, 6400}, {6400, 3040, 280}, {6400, 1024, 1024}, {6400, 1024, 2828}, {1024, 1024, 6400},
