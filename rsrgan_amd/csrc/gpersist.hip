@@ -1310,6 +1310,313 @@ __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_bwd(const GPersistAr
   }
 }
 
+
+// =====================================================================================================================================
+// UNPROJECTED cells (num_proj=None: the state m IS h; BASELINE.json's "2-layer 512-unit LSTM generator") -- round 5.
+// Without a projection there is nothing to reduce: the workgroup that owns 16 cells owns k-block c of the state, so a step has ONE
+// hand-off, the all-gather of h(t) (every workgroup publishes its 16 x 16 tile as one chunk, every workgroup of the layer and of the
+// layer above gathers all H / 16 of them).  Same decomposition otherwise: workgroup = (row group of 32 rows, layer, slice of 16 cells =
+// 64 gate columns = NT 4 gate tiles), two tile lanes, 12 waves -- R: K_h slice (H x 64) resident, recurrent product + cell + stash;
+// X: K_x slice, the input product a step ahead; G: publish, gather.  H <= 512 (32 k-blocks: 8 per R / X wave, seven of them in VGPRs,
+// the eighth -- the X waves' seventh and eighth -- in LDS), H % 16 == 0.  Cell arithmetic, masking and the stash exactly as gp_fwd_body /
+// kernels.hip k_fwd_gates with np_m_out (mst = carried h, out = masked h).
+constexpr int NP_NT = 4, NP_NKB = 32, NP_KBW = 8, NP_NCH = NP_NKB * GP_NR;
+struct NpLds {
+  float mB[GP_NR][NP_NKB][64][4];           // carried h(t-1) as B fragments [row tile][k-block][lane][4]                 64 KB
+  float pb[4][NP_NT][GP_NR][64][4];         // accumulator tiles: x-part (X wave w -> R wave w), then the R waves' partial sums   32 KB
+  float st[6][GP_ROWS][4 * NP_NT];          // the step's stash: gates i, j, f, o | c | h                                  12 KB
+  float khl[4][NP_NT][64][4];               // the eighth K_h k-block of R wave w                                           16 KB
+  float kxl[4][2][NP_NT][64][4];            // the seventh and eighth K_x k-block of X wave w                               32 KB
+  float peep[4 * NP_NT][4], bias[4 * NP_NT][4];
+  unsigned cnt_x[GP_NR][4], cnt_p[GP_NR], cnt_h[GP_NR], cnt_m[GP_NR], cnt_s[GP_NR], dead, pad_[15];
+};
+static_assert(sizeof(NpLds) <= 160 * 1024, "LDS of the unprojected forward kernel");
+
+__device__ __forceinline__ void np_fwd_body(const GPersistArgs& a, NpLds& S) {
+  constexpr int NT = NP_NT, NR = GP_NR, NU = NT * NR, CW = 4 * NT;
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ngr = a.N / GP_ROWS, xpg = 8 / ngr;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int grp = xcd / xpg, idx = slot * xpg + (xcd % xpg);
+  if (idx >= a.nl * a.NC) return;
+  const int l = idx / a.NC, c = idx - l * a.NC;
+  const GPersistLayer L = a.L[l];
+  const int H = a.H, H4 = 4 * H, T = a.T, N = a.N, P = L.P, ldP = L.ldP, I = L.I;
+  const int nkb = (P + 15) >> 4, nkbx = (I + 15) >> 4;
+  const int row0 = grp * GP_ROWS, cell0 = c * CW;
+  gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
+  const size_t g2_per = (size_t)NP_NCH * GP_SLOT;                      // [group][layer][t][tile][k-block] slots
+  const GpBuf b2 = gp_buf((const char*)a.gran2 + (size_t)(grp * a.nl + l) * T * g2_per, (size_t)T * g2_per);
+  const GpBuf b2x = gp_buf((const char*)a.gran2 + (size_t)(grp * a.nl + (l > 0 ? l - 1 : 0)) * T * g2_per, (size_t)T * g2_per);
+  const unsigned frag_off = (unsigned)lane * 16u;
+  auto slot2 = [&](int t, int r, int jb) { return (unsigned)((((size_t)t * NR + r) * NP_NKB + jb) * GP_SLOT); };
+
+  for (int e = tid; e < 7 * CW; e += GP_WAVES * 64) {
+    const int k = e / CW, cl = e - k * CW, cell = min(cell0 + cl, H - 1);
+    if (k < 3) S.peep[cl][k] = (k == 0 ? L.wi : k == 1 ? L.wf : L.wo)[cell];
+    else S.bias[cl][k - 3] = L.bias[(k - 3) * H + cell];
+  }
+  for (int e = tid; e < GP_NR * NP_NKB * 64; e += GP_WAVES * 64)       // the carried state h(-1) is zero (cell.zero_state)
+    *reinterpret_cast<f32x4*>(&S.mB[0][0][0][0] + 4 * e) = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tid < 32) (&S.cnt_x[0][0])[tid] = 0u;
+  __syncthreads();
+  const unsigned* dead = &S.dead;
+  auto fail = [&]() {
+    if (lane == 0) {
+      __hip_atomic_store(&S.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(err, 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  const int len0 = a.len[row0 + lr], len1 = a.len[row0 + 16 + lr];
+
+  if (w < 4) {
+    // =============================== R waves ===============================
+    // resident K_h fragments: A[row lr = 4 * cell + gate][k = 16 jb + 4 q + u], jb = w + 4 jj; jj = 7 in LDS
+    float4 kh[NT][NP_KBW - 1];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int cell = cell0 + 4 * i + (lr >> 2);
+      const float* kr = L.KhT + (size_t)((lr & 3) * H + min(cell, H - 1)) * ldP;
+#pragma unroll
+      for (int jj = 0; jj < NP_KBW; ++jj) {
+        const int k = 16 * (w + 4 * jj) + 4 * q;
+        float4 v = *reinterpret_cast<const float4*>(kr + min(k, ldP - 4));
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+        const bool ok = k < P && cell < H;
+        const float4 f = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        if (jj < NP_KBW - 1) kh[i][jj < NP_KBW - 1 ? jj : 0] = f;
+        else *reinterpret_cast<float4*>(&S.khl[w][i][lane][0]) = f;
+      }
+    }
+    float cprev[NR] = {0.f, 0.f};
+    float* const pbw = &S.pb[w][0][0][lane][0];                        // + (i * NR + r) * 256
+    const float* const mbw = &S.mB[0][w][lane][0];                     // + (r * NP_NKB + 4 jj) * 256
+    const float* const khw = &S.khl[w][0][lane][0];                    // + i * 256
+    const float* const pbc = &S.pb[0][w][0][lane][0];                  // + (k * NU + r) * 256   (gate tile w)
+    const float* const pwc = &S.peep[4 * w + q][0];
+    float* const stc = &S.st[0][lr][4 * w + q];                        // + k * GP_ROWS * CW + r * 16 * CW
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (!gp_wait(&S.cnt_x[r][w], (unsigned)t + 1u, dead)) return;         // x-part (+ bias) of step t, tile r
+        if (t > 0 && !gp_wait(&S.cnt_m[r], 2u * (unsigned)t, dead)) return;   // h(t-1) of the tile is in LDS
+        {
+          f32x4 acc[NT];
+#pragma unroll
+          for (int i = 0; i < NT; ++i) acc[i] = *reinterpret_cast<const f32x4*>(pbw + (i * NR + r) * 256);
+          if (t > 0) {
+            __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+            for (int jj = 0; jj < NP_KBW; ++jj) {
+              if (w + 4 * jj < nkb) {
+                const float4 b = *reinterpret_cast<const float4*>(mbw + (r * NP_NKB + 4 * jj) * 256);
+                float4 ka[NT];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) ka[i] = jj < NP_KBW - 1 ? kh[i][jj < NP_KBW - 1 ? jj : 0] : *reinterpret_cast<const float4*>(khw + i * 256);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].x, b.x, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].y, b.y, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].z, b.z, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].w, b.w, acc[i], 0, 0, 0);
+              }
+            }
+            __builtin_amdgcn_s_setprio(0);
+          }
+#pragma unroll
+          for (int i = 0; i < NT; ++i) *reinterpret_cast<f32x4*>(pbw + (i * NR + r) * 256) = acc[i];
+        }
+        gp_signal(&S.cnt_p[r], lane);
+        if (!gp_wait(&S.cnt_p[r], 4u * ((unsigned)t + 1u), dead)) return;
+        if (t > 0 && !gp_wait(&S.cnt_s[r], 4u * (unsigned)t, dead)) return;  // the stash of step t-1 has left the stage
+        // the cell of gate tile w: lane (q, lr) = row 16 r + lr, cell 4 w + q, gates i j f o
+        const bool live = t < (r ? len1 : len0);
+        {
+          const f32x4 p0 = *reinterpret_cast<const f32x4*>(pbc + (0 * NU + r) * 256), p1 = *reinterpret_cast<const f32x4*>(pbc + (1 * NU + r) * 256);
+          const f32x4 p2 = *reinterpret_cast<const f32x4*>(pbc + (2 * NU + r) * 256), p3 = *reinterpret_cast<const f32x4*>(pbc + (3 * NU + r) * 256);
+          const f32x4 z = ((p0 + p1) + p2) + p3;
+          const float cpv = cprev[r];
+          const f32x4 pw = *reinterpret_cast<const f32x4*>(pwc);
+          const float gi = gp_sigmoid(z[0] + pw[0] * cpv);
+          const float gf = gp_sigmoid(z[2] + a.forget_bias + pw[1] * cpv);
+          const float gj = gp_tanh(z[1]);
+          const float cn = gf * cpv + gi * gj;
+          const float go = gp_sigmoid(z[3] + pw[2] * cn);
+          const float hh = go * gp_tanh(cn);
+          cprev[r] = live ? cn : cpv;
+          float* const d = stc + r * 16 * CW;
+          d[0 * GP_ROWS * CW] = live ? gi : 0.f; d[1 * GP_ROWS * CW] = live ? gj : 0.f;
+          d[2 * GP_ROWS * CW] = live ? gf : 0.f; d[3 * GP_ROWS * CW] = live ? go : 0.f;
+          d[4 * GP_ROWS * CW] = cprev[r];
+          d[5 * GP_ROWS * CW] = live ? hh : 0.f;
+        }
+        gp_signal(&S.cnt_h[r], lane);
+        if (!gp_wait(&S.cnt_h[r], 4u * ((unsigned)t + 1u), dead)) return;     // every cell of the tile is in the stage
+        // the tile's stash (gate activations, c, h) from the LDS stage, a quarter per R wave: 4 lanes write one 64-byte row piece
+#pragma unroll
+        for (int it = 0; it < (6 * 16 * NT + 255) / 256; ++it) {
+          const int e = it * 256 + w * 64 + lane;
+          const int cq = e % NT, pr = e / NT, row = 16 * r + (pr & 15), k = min(pr >> 4, 5);
+          const float4 v = *reinterpret_cast<const float4*>(&S.st[k][row][4 * cq]);
+          const size_t rowg = (size_t)t * N + row0 + row;
+          float* dst = (k < 4 ? L.gates + rowg * H4 + k * H : k == 4 ? L.c + (rowg + N) * H : L.h + rowg * L.ldH) + cell0 + 4 * cq;
+          if (e < 6 * 16 * NT && cell0 + 4 * cq < H) gp_stash_store(dst, v);
+        }
+        gp_signal(&S.cnt_s[r], lane);
+      }
+    }
+    return;
+  }
+
+  if (w < 8) {
+    // =============================== X waves: ahead of the R waves ===============================
+    const int xw = w - 4;
+    float* const pbx = &S.pb[xw][0][0][lane][0];                       // + (i * NR + r) * 256
+    float4 kx[NT][NP_KBW - 2];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int cell = cell0 + 4 * i + (lr >> 2);
+      const float* kr = L.KxT + (size_t)((lr & 3) * H + min(cell, H - 1)) * L.ldI;
+#pragma unroll
+      for (int jj = 0; jj < NP_KBW; ++jj) {
+        const int k = 16 * (xw + 4 * jj) + 4 * q;
+        float4 v = *reinterpret_cast<const float4*>(kr + min(k, L.ldI - 4));
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+        const bool ok = k < I && cell < H;                             // (the copy is zero beyond column I)
+        const float4 f = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+        if (jj < NP_KBW - 2) kx[i][jj < NP_KBW - 2 ? jj : 0] = f;
+        else *reinterpret_cast<float4*>(&S.kxl[xw][jj - (NP_KBW - 2)][i][lane][0]) = f;
+      }
+    }
+    const float* const kxw = &S.kxl[xw][0][0][lane][0];                // + ((jj - 6) * NT + i) * 256
+    const int nsx = (nkbx - xw + 3) >> 2;                              // this wave's k-blocks: xw, xw + 4, ...
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const bool live = t < (r ? len1 : len0);
+        f32x4 acc[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+          acc[i] = xw == 0 ? *reinterpret_cast<const f32x4*>(&S.bias[q][0] + 16 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        // x(t) in two halves of four k-blocks (eight pieces at once would not leave the registers for the weights)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          if (xw + 16 * half >= nkbx) break;                           // (uniform)
+          unsigned lo[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) lo[jj] = slot2(t, r, min(xw + 4 * (4 * half + jj), nkbx - 1));
+          f32x4 xv[4];
+          const int nh = max(0, min(4, nsx - 4 * half));               // pieces of this half
+          if (l == 0) {
+            const float* xr = L.in + ((size_t)t * N + row0 + 16 * r + lr) * L.ldI;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+              xv[jj] = *reinterpret_cast<const f32x4*>(xr + min(16 * min(xw + 4 * (4 * half + jj), nkbx - 1) + 4 * q, L.ldI - 4));
+            asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]));
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+              if (16 * min(xw + 4 * (4 * half + jj), nkbx - 1) + 4 * q >= L.ldI) xv[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+          } else if (!gp_sweep<4, false, 4, true>(b2x, lo, nh, frag_off, slot2(t, r, min(xw + 4 * (4 * half + (lane >> 1)), nkbx - 1)) + (unsigned)(lane & 1) * 512u + 496u,
+                                                  lane < 2 * nh, err, [&](int k, const f32x4& v) { xv[k] = v; })) { fail(); return; }
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int jg = 4 * half + jj;                              // (compile-time after unrolling)
+            if (xw + 4 * jg < nkbx) {
+              const float b0 = live ? xv[jj][0] : 0.f, b1 = live ? xv[jj][1] : 0.f, b2_ = live ? xv[jj][2] : 0.f, b3 = live ? xv[jj][3] : 0.f;
+              float4 ka[NT];
+#pragma unroll
+              for (int i = 0; i < NT; ++i) ka[i] = jg < NP_KBW - 2 ? kx[i][jg < NP_KBW - 2 ? jg : 0] : *reinterpret_cast<const float4*>(kxw + ((jg - (NP_KBW - 2)) * NT + i) * 256);
+#pragma unroll
+              for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].x, b0, acc[i], 0, 0, 0);
+#pragma unroll
+              for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].y, b1, acc[i], 0, 0, 0);
+#pragma unroll
+              for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].z, b2_, acc[i], 0, 0, 0);
+#pragma unroll
+              for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].w, b3, acc[i], 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_s_setprio(0);
+        }
+        if (t > 0 && !gp_wait(&S.cnt_h[r], 4u * (unsigned)t, dead)) return;       // the cells of step t-1 have read the tiles
+#pragma unroll
+        for (int i = 0; i < NT; ++i) *reinterpret_cast<f32x4*>(pbx + (i * NR + r) * 256) = acc[i];
+        gp_signal(&S.cnt_x[r][xw], lane);
+      }
+    }
+    return;
+  }
+
+  // =============================== G waves: publish, gather (tile gw & 1) ===============================
+  __builtin_amdgcn_s_setprio(3);
+  const int gw = w - 8, r = gw & 1, gp = gw >> 1;
+  const int lenr = r ? len1 : len0;
+  const int nvg = (nkb - gp + 1) >> 1;                                 // this wave's k-blocks of the gather: gp, gp + 2, ...
+  float* const mbg = &S.mB[r][gp][lane][0];                            // + 2 n * 256
+  // this workgroup's own chunk: lane (q, lr) = row 16 r + lr, its cells 4 q .. 4 q + 3
+  const float* const sth4 = &S.st[5][16 * r + lr][4 * q];
+  const int srow = row0 + 16 * r + lr, scol = cell0 + 4 * q;
+  f32x4 mcar = {0.f, 0.f, 0.f, 0.f};                                   // carried state of this lane's four cells (the stash's mst)
+  for (int e = gw * 64 + lane; e < GP_ROWS * NT; e += 256) {           // slot 0 of the carried states is zero (cell.zero_state)
+    const int row = e / NT, cq = e - row * NT;
+    if (cell0 + 4 * cq < H) {
+      *reinterpret_cast<float4*>(L.c + (size_t)(row0 + row) * H + cell0 + 4 * cq) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(L.mst + (size_t)(row0 + row) * ldP + cell0 + 4 * cq) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  for (int t = 0; t < T; ++t) {
+    if (!gp_wait(&S.cnt_h[r], 4u * ((unsigned)t + 1u), dead)) return;  // the cells of step t, tile r: h is in LDS
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(sth4);
+    if (gp == 0) gp_store(b2, slot2(t, r, c) + frag_off, hv);          // the hand-off: this workgroup's chunk of h(t)
+    if (t + 1 < T) {
+      // gather h(t) of the tile for the recurrent product of step t+1; dynamic_rnn carries the state of a finished row through
+      // unchanged (the carried state lives in mB itself: a finished row's lanes are not written)
+      const bool live = t < lenr;
+      // (two sweeps of eight chunks: sixteen pieces in flight per lane cost the kernel 40 spilled registers; the second half's
+      //  sentinels have landed by the time the first half is read)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (8 * half >= nvg) break;                                    // (uniform)
+        unsigned lo[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) lo[n] = slot2(t, r, min(gp + 2 * (8 * half + n), nkb - 1));
+        const int nh = min(8, nvg - 8 * half);
+        if (!gp_sweep<8, true, 8, true>(b2, lo, nh, frag_off, slot2(t, r, min(gp + 2 * (8 * half + (lane >> 1)), nkb - 1)) + (unsigned)(lane & 1) * 512u + 496u,
+                                        lane < 2 * nh, err, [&](int k, const f32x4& v) { if (k < nh && live) *reinterpret_cast<f32x4*>(mbg + 2 * (8 * half + k) * 256) = v; })) { fail(); return; }
+      }
+    }
+    gp_signal(&S.cnt_m[r], lane);
+    if (gp == 1 && scol < H) {                                         // this workgroup's columns of the carried state / masked output, behind the hand-off
+      const bool live = t < lenr;
+      mcar = live ? hv : mcar;
+      *reinterpret_cast<float4*>(L.mst + ((size_t)(t + 1) * N + srow) * ldP + scol) = make_float4(mcar[0], mcar[1], mcar[2], mcar[3]);
+      if (L.out) *reinterpret_cast<float4*>(L.out + ((size_t)t * N + srow) * ldP + scol) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_np_fwd(const GPersistArgs a) {
+  __shared__ __attribute__((aligned(16))) NpLds S;
+  gu32* ctl = (gu32*)a.ctl;
+  const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  np_fwd_body(a, S);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == gridDim.x - 1) {
+      if (__hip_atomic_load(ctl + DP_CTL_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        a.L[a.nl - 1].h[0] = __builtin_nanf("");
+      __hip_atomic_store(ctl + DP_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned g1 = gen + 1u;
+      __hip_atomic_store(ctl + DP_CTL_GEN, g1 >= (1u << 21) ? 1u : g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 static int gp_grid(const GPersistArgs& a) {
   const int ngr = a.N / GP_ROWS, xpg = 8 / ngr, nwg = a.nl * a.NC;
   return 8 * ((nwg + xpg - 1) / xpg);
@@ -1403,6 +1710,27 @@ void launch_glstm_fwd(const GPersistArgs& a, hipStream_t s) {
   (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_gran2_bytes(a), s);
   if (a.res) hipLaunchKernelGGL((k_glstm_fwd<5, GP_PROG_ONLY, true>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
   else hipLaunchKernelGGL((k_glstm_fwd<5, GP_PROG_ONLY, false>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
+  ++g_chain_launches;
+}
+// ---- the unprojected form: plan, sizes, launch ----
+bool gpersist_np_plan(GPersistArgs& a) {
+  if (a.nl < 1 || a.nl > GP_MAXL || a.T < 1 || a.T > GP_TMAX || a.H % 16 != 0 || a.H > 16 * NP_NKB) return false;
+  const int ngr = a.N / GP_ROWS;
+  if (a.N % GP_ROWS != 0 || (ngr != 1 && ngr != 2 && ngr != 4 && ngr != 8)) return false;
+  a.NT = NP_NT;
+  a.NC = a.H / (4 * NP_NT);
+  for (int l = 0; l < a.nl; ++l) {
+    const GPersistLayer& L = a.L[l];
+    if (L.P != a.H || L.ldP % 4 != 0 || L.ldP < L.P || L.ldH % 4 != 0 || L.I < 4 || L.I > 16 * NP_NKB || L.ldI % 4 != 0 || L.ldI < L.I || L.ldI - L.I > 3) return false;
+    if (l > 0 && L.I != a.H) return false;
+  }
+  return gp_grid(a) <= device_cu_count();
+}
+size_t gpersist_np_gran2_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * a.T * NP_NCH * GP_SLOT; }
+size_t gpersist_np_lds_bytes() { return sizeof(NpLds); }
+void launch_glstm_np_fwd(const GPersistArgs& a, hipStream_t s) {
+  (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_np_gran2_bytes(a), s);
+  hipLaunchKernelGGL(k_glstm_np_fwd, dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
   ++g_chain_launches;
 }
 void launch_glstm_bwd(const GPersistArgs& a, hipStream_t s) {

@@ -208,6 +208,11 @@ size_t gpersist_gran2_bytes(const GPersistArgs& a);
 size_t gpersist_gran3_bytes(const GPersistArgs& a);
 void gpersist_arm(const GPersistArgs& a, hipStream_t s);          // once after allocation: the "not written" pattern in every slot of gran1 / gran3
 void launch_glstm_fwd(const GPersistArgs& a, hipStream_t s);
+// the unprojected form (num_proj=None: P == H <= 512, H % 16 == 0): one hand-off per step, the all-gather of h (round 5)
+bool gpersist_np_plan(GPersistArgs& a);
+size_t gpersist_np_gran2_bytes(const GPersistArgs& a);
+size_t gpersist_np_lds_bytes();
+void launch_glstm_np_fwd(const GPersistArgs& a, hipStream_t s);
 void launch_glstm_bwd(const GPersistArgs& a, hipStream_t s);      // gates: activations in, dz out; needs c, dmt, dout_top; no input gradient for layer 0
 extern long long g_chain_launches;
 void launch_floor_chain(float* a, float* b, int n, int mode, hipStream_t s);

@@ -449,7 +449,19 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   if (gp_env && !g_dnn()) {
     GPersistArgs ga{};
     gp_Tcap = std::min(Tmax, (int)GP_TMAX);
-    if (gpersist_args(ga, gp_Tcap) && resident_probe(gpersist_grid(ga), GP_THREADS, gpersist_lds_bytes())) {
+    gp_noproj = !gl.empty() && !gl[0].has_proj;
+    if (gp_noproj) {
+      if (gpersist_shape(ga, gp_Tcap) && resident_probe(gpersist_grid(ga), GP_THREADS, gpersist_np_lds_bytes())) {
+        gp_gran2_bytes = gpersist_np_gran2_bytes(ga);
+        gp_gran2 = (unsigned long long*)alloc<float>(gp_gran2_bytes / sizeof(float));
+        gp_ctl = (unsigned*)alloc<float>(16);
+        gp_gran1 = gp_gran2;                                      // (no hop-1 ring: the pointer only says "the forward path is on")
+        if (gp_gran2 && gp_ctl) {
+          const unsigned ctl0[DP_CTL_WORDS] = {1u, 0u, 0u, 0u};
+          HIPC(hipMemcpy(gp_ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice));
+        } else { gp_gran1 = gp_gran2 = nullptr; gp_ctl = nullptr; }
+      }
+    } else if (gpersist_args(ga, gp_Tcap) && resident_probe(gpersist_grid(ga), GP_THREADS, gpersist_lds_bytes())) {
       gp_gran1 = (unsigned long long*)alloc<float>(gpersist_gran1_bytes(ga) / sizeof(float));
       gp_gran2_bytes = gpersist_gran2_bytes(ga);
       gp_gran2 = (unsigned long long*)alloc<float>(gp_gran2_bytes / sizeof(float));
@@ -956,12 +968,16 @@ bool Model::gpersist_shape(GPersistArgs& a, int T) const {              // (size
   if (!gp_env || gl.empty() || gl.size() > (size_t)GP_MAXL || (cfg.g_type != RSRGAN_G_LSTM && cfg.g_type != RSRGAN_G_RES_LSTM_BASE && !res)) return false;
   a = GPersistArgs{};
   a.nl = (int)gl.size(); a.N = B; a.T = T; a.H = gl[0].H; a.res = res ? 1 : 0;
+  bool noproj = !gl[0].has_proj;
   for (size_t l = 0; l < gl.size(); ++l) {
     const LstmLayer& L = gl[l];
-    if (!L.has_proj || L.H != a.H) return false;
+    if (L.has_proj == noproj || L.H != a.H) return false;
     GPersistLayer& G_ = a.L[l];
     G_.I = L.I; G_.P = L.P; G_.ldI = L.ldI; G_.ldP = L.ldP; G_.ldH = L.ldH;
   }
+  // num_proj=None (BASELINE.json's 2 x 512 generator): the single-hop form, forward only (gpersist.hip np_fwd_body)
+  static const bool np_env = [] { const char* e = getenv("RSRGAN_GP_NOPROJ"); return !e || atoi(e) != 0; }();
+  if (noproj) return np_env && !res && (gp_env & 1) && gpersist_np_plan(a);
   return gpersist_plan(a);
 }
 bool Model::gpersist_args(GPersistArgs& a, int T) const {
@@ -971,7 +987,7 @@ bool Model::gpersist_args(GPersistArgs& a, int T) const {
   for (size_t l = 0; l < gl.size(); ++l) {
     const LstmLayer& L = gl[l]; const LstmStash& S = g_st[l];
     GPersistLayer& G_ = a.L[l];
-    G_.KxT = L.KxT; G_.KhT = L.KhT; G_.bias = G.W(L.tb); G_.wi = G.W(L.twi); G_.wf = G.W(L.twf); G_.wo = G.W(L.two); G_.Wp = G.W(L.tWp);
+    G_.KxT = L.KxT; G_.KhT = L.KhT; G_.bias = G.W(L.tb); G_.wi = G.W(L.twi); G_.wf = G.W(L.twf); G_.wo = G.W(L.two); G_.Wp = L.has_proj ? G.W(L.tWp) : nullptr;
     G_.gates = S.gates; G_.c = S.c; G_.h = S.h; G_.mst = S.mst; G_.out = S.out; G_.dmt = S.dmt;
     G_.res_out = a.res ? g_res[l] : nullptr;
   }
@@ -991,7 +1007,7 @@ void Model::persist_disable(int which) {
 
 void Model::gpersist_rearm() {
   GPersistArgs a{};
-  if (!gp_gran1 || !gpersist_args(a, gp_Tcap)) return;
+  if (!gp_gran1 || gp_noproj || !gpersist_args(a, gp_Tcap)) return;       // (the unprojected form has no rings: every launch arms its own slots)
   gpersist_arm(a, 0);
   (void)hipDeviceSynchronize();
 }
@@ -999,8 +1015,13 @@ void Model::gpersist_rearm() {
 bool Model::persist_forward_g(int T, hipStream_t s) {
   if (!gp_fwd_on() || !wavefront() || seq_drop_on()) return false;
   GPersistArgs a{};
-  if (!gpersist_args(a, T) || gpersist_gran2_bytes(a) > gp_gran2_bytes) return false;
+  if (!gpersist_args(a, T) || (gp_noproj ? gpersist_np_gran2_bytes(a) : gpersist_gran2_bytes(a)) > gp_gran2_bytes) return false;
   a.L[0].in = g_ins[0];                                // (layer 0's input product runs inside the launch as well)
+  if (gp_noproj) {                                     // num_proj=None: the single-hop form (no event bracket: bench.py's dominant-kernel timing is the projected form's)
+    for (size_t l = 0; l < gl.size(); ++l) a.L[l].Wp = nullptr;
+    launch_glstm_np_fwd(a, s);
+    return true;
+  }
   if (prof_on) {
     if ((size_t)(2 * prof_gp_n + 2) > prof_gp_ev.size()) {
       const size_t old = prof_gp_ev.size();
@@ -1023,7 +1044,7 @@ bool Model::persist_forward_g(int T, hipStream_t s) {
 // BPTT through the generator's stack as ONE persistent launch (gpersist.hip k_glstm_bwd): dz over the gate activations of every
 // layer's stash, dm per step in dmt.  Layer 0's input gradient (the input FC's d(h0)) is one GEMM over the dz stash afterwards.
 bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only, const StreamFn& pre, const StreamFn& post) {
-  if (!gp_gran1 || !gp_gran3 || !(gp_env & 2) || !wavefront() || seq_drop_on() || ch.size() != gl.size()) return false;
+  if (!gp_gran1 || !gp_gran3 || gp_noproj || !(gp_env & 2) || !wavefront() || seq_drop_on() || ch.size() != gl.size()) return false;
   GPersistArgs a{};
   if (!gpersist_args(a, T) || gpersist_gran2_bytes(a) > gp_gran2_bytes) return false;
   for (size_t l = 0; l < ch.size(); ++l) {

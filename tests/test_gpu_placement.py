@@ -22,7 +22,8 @@ from oracle import rsrgan_oracle as O
 from tests.helpers import NET_D, NET_G, build_hip_pair, rand_batch
 import os
 _net = os.environ.get("RSRGAN_TEST_NET")
-cfg = O.NetCfg.res_lstm_l() if _net == "res_lstm_l" else O.NetCfg.res_lstm_l(g_type="res_lstm_base") if _net == "res_lstm_base" else O.NetCfg()      # the reference's sizes: G 3x760/p280 (or the shipped 4x760/p257 residual stack), D 2x256/p40
+cfg = (O.NetCfg.res_lstm_l() if _net == "res_lstm_l" else O.NetCfg.res_lstm_l(g_type="res_lstm_base") if _net == "res_lstm_base" else
+       O.NetCfg(g_type="res_lstm_base", g_layers=2, g_cells=512, g_proj=0) if _net == "noproj" else O.NetCfg())      # the reference's sizes: G 3x760/p280 (or the shipped 4x760/p257 residual stack), D 2x256/p40
 B, T = int(os.environ.get("RSRGAN_TEST_B", "8")), int(os.environ.get("RSRGAN_TEST_T", "7"))
 model, _ = build_hip_pair(cfg, B, T, seed=5, flags=3)
 x, lab, ln = rand_batch(cfg, B, T, seed=6, ragged=True)
@@ -172,6 +173,24 @@ def test_persistent_base_generator_agrees():
     for k in ("d0", "g0", "d1", "g1"):
         assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-7), (k, a[k], b[k])
     assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
+
+
+@pytest.mark.parametrize("B,T", [(32, 9), (64, 50), (32, 1), (32, 2)])
+def test_persistent_unprojected_generator_forward_agrees(B, T):
+    """Round 5: num_proj=None cells (BASELINE.json's "2-layer 512-unit LSTM generator": the state is h itself) -- the forward recurrence
+    as ONE persistent launch with a single hand-off per step, the all-gather of h (csrc/gpersist.hip k_glstm_np_fwd), against the
+    launch-per-phase wavefront (RSRGAN_GP_NOPROJ=0).  The backward pass is the launch path in both runs."""
+    size = {"RSRGAN_TEST_B": str(B), "RSRGAN_TEST_T": str(T), "RSRGAN_TEST_NET": "noproj"}
+    a = _run(dict(size))
+    b = _run(dict(size, RSRGAN_GP_NOPROJ="0"))
+    if T > 2:
+        assert b["chain_launches"] - a["chain_launches"] >= T - 1, (a["chain_launches"], b["chain_launches"])
+    assert a["device_status"] == 0 and b["device_status"] == 0
+    for k in ("d0", "g0", "d1", "g1"):
+        assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-7), (k, a[k], b[k])
+    assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
+    c = _run(dict(size))
+    assert a["vars_sha"] == c["vars_sha"]
 
 
 def test_batched_kernel_gradient_gemm_agrees():
