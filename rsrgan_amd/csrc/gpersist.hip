@@ -1320,20 +1320,25 @@ __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_bwd(const GPersistAr
 // X: K_x slice, the input product a step ahead; G: publish, gather.  H <= 512 (32 k-blocks: 8 per R / X wave, seven of them in VGPRs,
 // the eighth -- the X waves' seventh and eighth -- in LDS), H % 16 == 0.  Cell arithmetic, masking and the stash exactly as gp_fwd_body /
 // kernels.hip k_fwd_gates with np_m_out (mst = carried h, out = masked h).
-constexpr int NP_NT = 4, NP_NKB = 32, NP_KBW = 8, NP_NCH = NP_NKB * GP_NR;
+constexpr int NP_NKB = 32, NP_KBW = 8, NP_NCH = NP_NKB * GP_NR;
+// NT gate tiles (4 NT cells) per workgroup; KR / KX of an R / X wave's eight k-blocks live in VGPRs, the others in LDS.
+//   NT = 4 (16 cells = one whole chunk, H / 16 workgroups per row group and layer), KR = 7, KX = 6: 168 VGPRs and ~55 spilled
+//   NT = 2 (8 cells = a half chunk, H / 8 workgroups), KR = KX = 8: every weight in registers, twice the workgroups
+template <int NT, int KR, int KX>
 struct NpLds {
   float mB[GP_NR][NP_NKB][64][4];           // carried h(t-1) as B fragments [row tile][k-block][lane][4]                 64 KB
-  float pb[4][NP_NT][GP_NR][64][4];         // accumulator tiles: x-part (X wave w -> R wave w), then the R waves' partial sums   32 KB
-  float st[6][GP_ROWS][4 * NP_NT];          // the step's stash: gates i, j, f, o | c | h                                  12 KB
-  float khl[4][NP_NT][64][4];               // the eighth K_h k-block of R wave w                                           16 KB
-  float kxl[4][2][NP_NT][64][4];            // the seventh and eighth K_x k-block of X wave w                               32 KB
-  float peep[4 * NP_NT][4], bias[4 * NP_NT][4];
+  float pb[4][NT][GP_NR][64][4];         // accumulator tiles: x-part (X wave w -> R wave w), then the R waves' partial sums   32 KB
+  float st[6][GP_ROWS][4 * NT];          // the step's stash: gates i, j, f, o | c | h                                  12 KB
+  float khl[4][NP_KBW - KR > 0 ? NP_KBW - KR : 1][NT][64][4];      // the K_h k-blocks of R wave w that are not in registers
+  float kxl[4][NP_KBW - KX > 0 ? NP_KBW - KX : 1][NT][64][4];      // ... K_x, X wave w
+  float peep[4 * NT][4], bias[4 * NT][4];
   unsigned cnt_x[GP_NR][4], cnt_p[GP_NR], cnt_h[GP_NR], cnt_m[GP_NR], cnt_s[GP_NR], dead, pad_[15];
 };
-static_assert(sizeof(NpLds) <= 160 * 1024, "LDS of the unprojected forward kernel");
 
-__device__ __forceinline__ void np_fwd_body(const GPersistArgs& a, NpLds& S) {
-  constexpr int NT = NP_NT, NR = GP_NR, NU = NT * NR, CW = 4 * NT;
+template <int NT, int KR, int KX>
+__device__ __forceinline__ void np_fwd_body(const GPersistArgs& a, NpLds<NT, KR, KX>& S) {
+  static_assert(sizeof(NpLds<NT, KR, KX>) <= 160 * 1024, "LDS of the unprojected forward kernel");
+  constexpr int NR = GP_NR, NU = NT * NR, CW = 4 * NT;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ngr = a.N / GP_ROWS, xpg = 8 / ngr;
@@ -1373,7 +1378,7 @@ __device__ __forceinline__ void np_fwd_body(const GPersistArgs& a, NpLds& S) {
   if (w < 4) {
     // =============================== R waves ===============================
     // resident K_h fragments: A[row lr = 4 * cell + gate][k = 16 jb + 4 q + u], jb = w + 4 jj; jj = 7 in LDS
-    float4 kh[NT][NP_KBW - 1];
+    float4 kh[NT][KR];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int cell = cell0 + 4 * i + (lr >> 2);
@@ -1385,17 +1390,18 @@ __device__ __forceinline__ void np_fwd_body(const GPersistArgs& a, NpLds& S) {
         asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
         const bool ok = k < P && cell < H;
         const float4 f = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-        if (jj < NP_KBW - 1) kh[i][jj < NP_KBW - 1 ? jj : 0] = f;
-        else *reinterpret_cast<float4*>(&S.khl[w][i][lane][0]) = f;
+        if (jj < KR) kh[i][jj < KR ? jj : 0] = f;
+        else *reinterpret_cast<float4*>(&S.khl[w][jj - KR < 0 ? 0 : jj - KR][i][lane][0]) = f;
       }
     }
     float cprev[NR] = {0.f, 0.f};
+    const bool cellw = w < NT;                                        // this wave owns gate tile w (NT = 2: waves 0, 1)
     float* const pbw = &S.pb[w][0][0][lane][0];                        // + (i * NR + r) * 256
     const float* const mbw = &S.mB[0][w][lane][0];                     // + (r * NP_NKB + 4 jj) * 256
-    const float* const khw = &S.khl[w][0][lane][0];                    // + i * 256
-    const float* const pbc = &S.pb[0][w][0][lane][0];                  // + (k * NU + r) * 256   (gate tile w)
-    const float* const pwc = &S.peep[4 * w + q][0];
-    float* const stc = &S.st[0][lr][4 * w + q];                        // + k * GP_ROWS * CW + r * 16 * CW
+    const float* const khw = &S.khl[w][0][0][lane][0];                 // + ((jj - KR) * NT + i) * 256
+    const float* const pbc = &S.pb[0][cellw ? w : 0][0][lane][0];      // + (k * NU + r) * 256   (gate tile w)
+    const float* const pwc = &S.peep[4 * (cellw ? w : 0) + q][0];
+    float* const stc = &S.st[0][lr][4 * (cellw ? w : 0) + q];          // + k * GP_ROWS * CW + r * 16 * CW
     for (int t = 0; t < T; ++t) {
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
@@ -1413,7 +1419,7 @@ __device__ __forceinline__ void np_fwd_body(const GPersistArgs& a, NpLds& S) {
                 const float4 b = *reinterpret_cast<const float4*>(mbw + (r * NP_NKB + 4 * jj) * 256);
                 float4 ka[NT];
 #pragma unroll
-                for (int i = 0; i < NT; ++i) ka[i] = jj < NP_KBW - 1 ? kh[i][jj < NP_KBW - 1 ? jj : 0] : *reinterpret_cast<const float4*>(khw + i * 256);
+                for (int i = 0; i < NT; ++i) ka[i] = jj < KR ? kh[i][jj < KR ? jj : 0] : *reinterpret_cast<const float4*>(khw + ((jj - KR < 0 ? 0 : jj - KR) * NT + i) * 256);
 #pragma unroll
                 for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].x, b.x, acc[i], 0, 0, 0);
 #pragma unroll
@@ -1434,7 +1440,7 @@ __device__ __forceinline__ void np_fwd_body(const GPersistArgs& a, NpLds& S) {
         if (t > 0 && !gp_wait(&S.cnt_s[r], 4u * (unsigned)t, dead)) return;  // the stash of step t-1 has left the stage
         // the cell of gate tile w: lane (q, lr) = row 16 r + lr, cell 4 w + q, gates i j f o
         const bool live = t < (r ? len1 : len0);
-        {
+        if (cellw) {
           const f32x4 p0 = *reinterpret_cast<const f32x4*>(pbc + (0 * NU + r) * 256), p1 = *reinterpret_cast<const f32x4*>(pbc + (1 * NU + r) * 256);
           const f32x4 p2 = *reinterpret_cast<const f32x4*>(pbc + (2 * NU + r) * 256), p3 = *reinterpret_cast<const f32x4*>(pbc + (3 * NU + r) * 256);
           const f32x4 z = ((p0 + p1) + p2) + p3;
@@ -1475,7 +1481,7 @@ __device__ __forceinline__ void np_fwd_body(const GPersistArgs& a, NpLds& S) {
     // =============================== X waves: ahead of the R waves ===============================
     const int xw = w - 4;
     float* const pbx = &S.pb[xw][0][0][lane][0];                       // + (i * NR + r) * 256
-    float4 kx[NT][NP_KBW - 2];
+    float4 kx[NT][KX];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int cell = cell0 + 4 * i + (lr >> 2);
@@ -1487,11 +1493,11 @@ __device__ __forceinline__ void np_fwd_body(const GPersistArgs& a, NpLds& S) {
         asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
         const bool ok = k < I && cell < H;                             // (the copy is zero beyond column I)
         const float4 f = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-        if (jj < NP_KBW - 2) kx[i][jj < NP_KBW - 2 ? jj : 0] = f;
-        else *reinterpret_cast<float4*>(&S.kxl[xw][jj - (NP_KBW - 2)][i][lane][0]) = f;
+        if (jj < KX) kx[i][jj < KX ? jj : 0] = f;
+        else *reinterpret_cast<float4*>(&S.kxl[xw][jj - KX < 0 ? 0 : jj - KX][i][lane][0]) = f;
       }
     }
-    const float* const kxw = &S.kxl[xw][0][0][lane][0];                // + ((jj - 6) * NT + i) * 256
+    const float* const kxw = &S.kxl[xw][0][0][lane][0];                // + ((jj - KX) * NT + i) * 256
     const int nsx = (nkbx - xw + 3) >> 2;                              // this wave's k-blocks: xw, xw + 4, ...
     for (int t = 0; t < T; ++t) {
 #pragma unroll
@@ -1529,7 +1535,7 @@ __device__ __forceinline__ void np_fwd_body(const GPersistArgs& a, NpLds& S) {
               const float b0 = live ? xv[jj][0] : 0.f, b1 = live ? xv[jj][1] : 0.f, b2_ = live ? xv[jj][2] : 0.f, b3 = live ? xv[jj][3] : 0.f;
               float4 ka[NT];
 #pragma unroll
-              for (int i = 0; i < NT; ++i) ka[i] = jg < NP_KBW - 2 ? kx[i][jg < NP_KBW - 2 ? jg : 0] : *reinterpret_cast<const float4*>(kxw + ((jg - (NP_KBW - 2)) * NT + i) * 256);
+              for (int i = 0; i < NT; ++i) ka[i] = jg < KX ? kx[i][jg < KX ? jg : 0] : *reinterpret_cast<const float4*>(kxw + ((jg - KX < 0 ? 0 : jg - KX) * NT + i) * 256);
 #pragma unroll
               for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[i].x, b0, acc[i], 0, 0, 0);
 #pragma unroll
@@ -1557,9 +1563,13 @@ __device__ __forceinline__ void np_fwd_body(const GPersistArgs& a, NpLds& S) {
   const int lenr = r ? len1 : len0;
   const int nvg = (nkb - gp + 1) >> 1;                                 // this wave's k-blocks of the gather: gp, gp + 2, ...
   float* const mbg = &S.mB[r][gp][lane][0];                            // + 2 n * 256
-  // this workgroup's own chunk: lane (q, lr) = row 16 r + lr, its cells 4 q .. 4 q + 3
-  const float* const sth4 = &S.st[5][16 * r + lr][4 * q];
+  // this workgroup's own piece of the state: 4 NT cells = quads q < NT of chunk (4 NT c) / 16 (NT = 4: the whole chunk, NT = 2: one
+  // half); lane (q, lr), q < NT = row 16 r + lr, its cells 4 q .. 4 q + 3
+  const bool pubq = q < NT;
+  const float* const sth4 = &S.st[5][16 * r + lr][4 * (pubq ? q : 0)];
   const int srow = row0 + 16 * r + lr, scol = cell0 + 4 * q;
+  const int pjb = (CW * c) >> 4;                                       // the chunk this workgroup writes into
+  const unsigned poff = (unsigned)(((CW * c) & 15) >> 2) * 256u + (unsigned)lane * 16u;      // ... and its quads' offset inside it (quad-major: 256 bytes per quad)
   f32x4 mcar = {0.f, 0.f, 0.f, 0.f};                                   // carried state of this lane's four cells (the stash's mst)
   for (int e = gw * 64 + lane; e < GP_ROWS * NT; e += 256) {           // slot 0 of the carried states is zero (cell.zero_state)
     const int row = e / NT, cq = e - row * NT;
@@ -1571,26 +1581,19 @@ __device__ __forceinline__ void np_fwd_body(const GPersistArgs& a, NpLds& S) {
   for (int t = 0; t < T; ++t) {
     if (!gp_wait(&S.cnt_h[r], 4u * ((unsigned)t + 1u), dead)) return;  // the cells of step t, tile r: h is in LDS
     const f32x4 hv = *reinterpret_cast<const f32x4*>(sth4);
-    if (gp == 0) gp_store(b2, slot2(t, r, c) + frag_off, hv);          // the hand-off: this workgroup's chunk of h(t)
+    if (gp == 0 && pubq) gp_store(b2, slot2(t, r, pjb) + poff, hv);    // the hand-off: this workgroup's quads of h(t)
     if (t + 1 < T) {
       // gather h(t) of the tile for the recurrent product of step t+1; dynamic_rnn carries the state of a finished row through
       // unchanged (the carried state lives in mB itself: a finished row's lanes are not written)
+      unsigned lo[16];
+#pragma unroll
+      for (int n = 0; n < 16; ++n) lo[n] = slot2(t, r, min(gp + 2 * n, nkb - 1));
       const bool live = t < lenr;
-      // (two sweeps of eight chunks: sixteen pieces in flight per lane cost the kernel 40 spilled registers; the second half's
-      //  sentinels have landed by the time the first half is read)
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        if (8 * half >= nvg) break;                                    // (uniform)
-        unsigned lo[8];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) lo[n] = slot2(t, r, min(gp + 2 * (8 * half + n), nkb - 1));
-        const int nh = min(8, nvg - 8 * half);
-        if (!gp_sweep<8, true, 8, true>(b2, lo, nh, frag_off, slot2(t, r, min(gp + 2 * (8 * half + (lane >> 1)), nkb - 1)) + (unsigned)(lane & 1) * 512u + 496u,
-                                        lane < 2 * nh, err, [&](int k, const f32x4& v) { if (k < nh && live) *reinterpret_cast<f32x4*>(mbg + 2 * (8 * half + k) * 256) = v; })) { fail(); return; }
-      }
+      if (!gp_sweep<16, true, 16, true>(b2, lo, nvg, frag_off, slot2(t, r, min(gp + 2 * (lane >> 1), nkb - 1)) + (unsigned)(lane & 1) * 512u + 496u,
+                                        lane < 2 * nvg, err, [&](int k, const f32x4& v) { if (k < nvg && live) *reinterpret_cast<f32x4*>(mbg + 2 * k * 256) = v; })) { fail(); return; }
     }
     gp_signal(&S.cnt_m[r], lane);
-    if (gp == 1 && scol < H) {                                         // this workgroup's columns of the carried state / masked output, behind the hand-off
+    if (gp == 1 && pubq && scol < H) {                                 // this workgroup's columns of the carried state / masked output, behind the hand-off
       const bool live = t < lenr;
       mcar = live ? hv : mcar;
       *reinterpret_cast<float4*>(L.mst + ((size_t)(t + 1) * N + srow) * ldP + scol) = make_float4(mcar[0], mcar[1], mcar[2], mcar[3]);
@@ -1599,11 +1602,12 @@ __device__ __forceinline__ void np_fwd_body(const GPersistArgs& a, NpLds& S) {
   }
 }
 
+template <int NT, int KR, int KX>
 __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_np_fwd(const GPersistArgs a) {
-  __shared__ __attribute__((aligned(16))) NpLds S;
+  __shared__ __attribute__((aligned(16))) NpLds<NT, KR, KX> S;
   gu32* ctl = (gu32*)a.ctl;
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  np_fwd_body(a, S);
+  np_fwd_body<NT, KR, KX>(a, S);
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1713,24 +1717,30 @@ void launch_glstm_fwd(const GPersistArgs& a, hipStream_t s) {
   ++g_chain_launches;
 }
 // ---- the unprojected form: plan, sizes, launch ----
-bool gpersist_np_plan(GPersistArgs& a) {
+bool gpersist_np_plan(GPersistArgs& a, int nt_force) {
   if (a.nl < 1 || a.nl > GP_MAXL || a.T < 1 || a.T > GP_TMAX || a.H % 16 != 0 || a.H > 16 * NP_NKB) return false;
   const int ngr = a.N / GP_ROWS;
   if (a.N % GP_ROWS != 0 || (ngr != 1 && ngr != 2 && ngr != 4 && ngr != 8)) return false;
-  a.NT = NP_NT;
-  a.NC = a.H / (4 * NP_NT);
   for (int l = 0; l < a.nl; ++l) {
     const GPersistLayer& L = a.L[l];
     if (L.P != a.H || L.ldP % 4 != 0 || L.ldP < L.P || L.ldH % 4 != 0 || L.I < 4 || L.I > 16 * NP_NKB || L.ldI % 4 != 0 || L.ldI < L.I || L.ldI - L.I > 3) return false;
     if (l > 0 && L.I != a.H) return false;
   }
-  return gp_grid(a) <= device_cu_count();
+  // 8 cells per workgroup (every weight in registers) where that many workgroups are resident at once, else 16
+  static const int nt_env = [] { const char* e = getenv("RSRGAN_GP_NP_NT"); return e ? atoi(e) : 0; }();
+  for (int nt : {2, 4}) {
+    if ((nt_env && nt != nt_env) || (nt_force && nt != nt_force)) continue;
+    a.NT = nt; a.NC = a.H / (4 * nt);
+    if (gp_grid(a) <= device_cu_count()) return true;
+  }
+  return false;
 }
 size_t gpersist_np_gran2_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * a.T * NP_NCH * GP_SLOT; }
-size_t gpersist_np_lds_bytes() { return sizeof(NpLds); }
+size_t gpersist_np_lds_bytes() { return sizeof(NpLds<4, 7, 6>); }
 void launch_glstm_np_fwd(const GPersistArgs& a, hipStream_t s) {
   (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_np_gran2_bytes(a), s);
-  hipLaunchKernelGGL(k_glstm_np_fwd, dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
+  if (a.NT == 2) hipLaunchKernelGGL((k_glstm_np_fwd<2, 8, 8>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
+  else hipLaunchKernelGGL((k_glstm_np_fwd<4, 7, 6>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
   ++g_chain_launches;
 }
 void launch_glstm_bwd(const GPersistArgs& a, hipStream_t s) {

@@ -209,7 +209,7 @@ size_t gpersist_gran3_bytes(const GPersistArgs& a);
 void gpersist_arm(const GPersistArgs& a, hipStream_t s);          // once after allocation: the "not written" pattern in every slot of gran1 / gran3
 void launch_glstm_fwd(const GPersistArgs& a, hipStream_t s);
 // the unprojected form (num_proj=None: P == H <= 512, H % 16 == 0): one hand-off per step, the all-gather of h (round 5)
-bool gpersist_np_plan(GPersistArgs& a);
+bool gpersist_np_plan(GPersistArgs& a, int nt_force = 0);      // nt_force: 2 / 4 = that many gate tiles per workgroup only (0: the smaller one that fits the device)
 size_t gpersist_np_gran2_bytes(const GPersistArgs& a);
 size_t gpersist_np_lds_bytes();
 void launch_glstm_np_fwd(const GPersistArgs& a, hipStream_t s);

@@ -451,7 +451,15 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     gp_Tcap = std::min(Tmax, (int)GP_TMAX);
     gp_noproj = !gl.empty() && !gl[0].has_proj;
     if (gp_noproj) {
-      if (gpersist_shape(ga, gp_Tcap) && resident_probe(gpersist_grid(ga), GP_THREADS, gpersist_np_lds_bytes())) {
+      // 8 cells per workgroup (all weights in registers) needs twice the workgroups of 16: B = 64 with two layers is the whole
+      // device -- ask it; if it cannot hold them, try the 16-cell form
+      bool fits = false;
+      for (int nt : {2, 4}) {
+        gp_np_nt = nt;
+        if (gpersist_shape(ga, gp_Tcap) && resident_probe(gpersist_grid(ga), GP_THREADS, gpersist_np_lds_bytes())) { fits = true; break; }
+      }
+      if (!fits) gp_np_nt = 0;
+      if (fits) {
         gp_gran2_bytes = gpersist_np_gran2_bytes(ga);
         gp_gran2 = (unsigned long long*)alloc<float>(gp_gran2_bytes / sizeof(float));
         gp_ctl = (unsigned*)alloc<float>(16);
@@ -977,7 +985,7 @@ bool Model::gpersist_shape(GPersistArgs& a, int T) const {              // (size
   }
   // num_proj=None (BASELINE.json's 2 x 512 generator): the single-hop form, forward only (gpersist.hip np_fwd_body)
   static const bool np_env = [] { const char* e = getenv("RSRGAN_GP_NOPROJ"); return !e || atoi(e) != 0; }();
-  if (noproj) return np_env && !res && (gp_env & 1) && gpersist_np_plan(a);
+  if (noproj) return np_env && !res && (gp_env & 1) && gpersist_np_plan(a, gp_np_nt);
   return gpersist_plan(a);
 }
 bool Model::gpersist_args(GPersistArgs& a, int T) const {

@@ -169,6 +169,7 @@ struct Model {
   void persist_disable(int which);                        // after a reported failure: 0 = discriminator, 1 = generator launches off for this handle
   bool gp_fwd_on() const { return gp_gran1 && (gp_env & 1); }
   bool gpersist_shape(GPersistArgs& a, int T) const;      // sizes + plan only (no buffers)
+  int gp_np_nt = 0;                                       // ... its gate tiles per workgroup, fixed at init by the resident probe (0: not decided)
   bool gp_noproj = false;                                 // the generator's cells are unprojected (num_proj=None): the single-hop form (k_glstm_np_fwd; forward only)
   bool gpersist_args(GPersistArgs& a, int T) const;       // false: not applicable
   void gpersist_rearm();                                  // the "not written" pattern in every ring slot (after allocation, after a failed launch)
