@@ -1621,6 +1621,307 @@ __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_np_fwd(const GPersis
   }
 }
 
+
+// -------------------------------------------------------------------------------------------------------------------------------------
+// BPTT through unprojected cells as ONE persistent launch: the mirror of k_glstm_np_fwd, again with a single hand-off per step.  The
+// state gradient of a cell slice needs every workgroup's dz(t+1) . K_h^T restricted to ITS columns, so each workgroup publishes its
+// partial over all H state columns (R waves; X waves: dz(t) . K_x^T for the layer below) and the OWNER of 8 cells sums the 512-byte
+// pieces of the H / 8 producers in slice order (a reduce-scatter with the owner as reducer); nothing is gathered back -- the owner is
+// the only consumer of its dh.  8 cells per workgroup (NT = 2: the K_h^T / K_x^T slices, 64 registers per wave, stay in VGPRs).
+// Rings as in k_glstm_bwd: the state-gradient ring GP_R1 steps deep (its re-use is ordered by the recurrence itself), the
+// input-gradient ring between two layers GP_XR deep with an explicit check that the slot about to be written has been re-armed
+// by its consumer.  Cell gradient, masking, the dz stash: kernels.hip k_bwd_a2 / gp_bwd_body.
+constexpr int NPB_NT = 2;
+struct NpLdsB {
+  float dhS[GP_NR][16][4 * NPB_NT];         // dh(t) of a tile [row][cell]: the reducing G waves -> the cells
+  float dzB[GP_NR][NPB_NT][64][4];          // dz(t) as B fragments of both gradient products [tile][gate tile][lane (cell q, row lr)][gate]
+  float st[4][GP_ROWS][4 * NPB_NT];         // dz(t) in stash order [gate][row][cell]
+  float gs[2][GP_NR][2][64][4];             // the two reducing G waves' sums [step parity][tile][wave][half wave, piece lane]
+  float pfs[GP_NR][5][16][4 * NPB_NT];      // the stash of the NEXT step of a tile: gate activations i, j, f, o and c(t-1)
+  float peep[4 * NPB_NT][4];
+  unsigned cnt_h[GP_NR], cnt_m[GP_NR], cnt_g[GP_NR], cnt_z[GP_NR], cnt_f[GP_NR], cnt_q[GP_NR], dead, pad_[3];
+};
+
+__device__ __forceinline__ void np_bwd_body(const GPersistArgs& a, NpLdsB& S) {
+  constexpr int NT = NPB_NT, NR = GP_NR, CW = 4 * NT;
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ngr = a.N / GP_ROWS, xpg = 8 / ngr;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int grp = xcd / xpg, idx = slot * xpg + (xcd % xpg);
+  if (idx >= a.nl * a.NC) return;
+  const int l = idx / a.NC, c = idx - l * a.NC;
+  const GPersistLayer L = a.L[l];
+  const int H = a.H, H4 = 4 * H, T = a.T, N = a.N, P = L.P, ldP = L.ldP, I = L.I, NC = a.NC;
+  const int nkb = (P + 15) >> 4, nkbx = (I + 15) >> 4;
+  const int row0 = grp * GP_ROWS, cell0 = c * CW;
+  const bool top = l == a.nl - 1;
+  gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
+  // rings: [group][layer][ring step][tile][k-block][producer] slots of 1 KB
+  const size_t g1_per = (size_t)NP_NCH * NC * GP_SLOT;
+  const GpBuf b1 = gp_buf((const char*)a.gran1 + (size_t)(grp * a.nl + l) * GP_R1 * g1_per, GP_R1 * g1_per);
+  const GpBuf b3 = gp_buf((const char*)a.gran3 + (size_t)(grp * (a.nl + 1) + l + 1) * GP_XR * g1_per, GP_XR * g1_per);      // what the layer above hands to this one
+  const GpBuf b3x = gp_buf((const char*)a.gran3 + (size_t)(grp * (a.nl + 1) + l) * GP_XR * g1_per, GP_XR * g1_per);         // what this layer hands down
+  const unsigned pair_off = (unsigned)((lane >> 5) * GP_SLOT + (lane & 31) * 16);   // reducer: lanes 0..31 read producer p's half chunk, lanes 32..63 producer p + 1's
+  auto slot1 = [&](int par, int r, int jb, int p) { return (unsigned)((((size_t)(par * NR + r) * NP_NKB + jb) * NC + p) * GP_SLOT); };
+  // this workgroup OWNS the 8 columns (k-block jbr, half hh) of its layer's state: it sums their pieces of every producer
+  const int jbr = (CW * c) >> 4, hh = ((CW * c) & 15) >> 3;
+
+  for (int e = tid; e < 3 * CW; e += GP_WAVES * 64) {
+    const int k = e / CW, cl = e - k * CW, cell = min(cell0 + cl, H - 1);
+    S.peep[cl][k] = (k == 0 ? L.wi : k == 1 ? L.wf : L.wo)[cell];
+  }
+  if (tid < 16) (&S.cnt_h[0])[tid] = 0u;                                 // (all counters, dead)
+  __syncthreads();
+  const unsigned* dead = &S.dead;
+  auto fail = [&]() {
+    if (lane == 0) {
+      __hip_atomic_store(&S.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(err, 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  const int len0 = a.len[row0 + lr], len1 = a.len[row0 + 16 + lr];
+
+  if (w < 8) {
+    // R waves (w < 4): K_h, the state-gradient product and the cell.  X waves: K_x, the input-gradient product for the layer below.
+    // Resident weights: output tile pt = ww + 4 jj of the product's P (or I) columns, gate tile i:
+    //   A[row lr = column 16 pt + lr][k = cell 4 i + q] for the four k-steps gate 0..3
+    const bool isx = w >= 4;
+    const int ww = w & 3;
+    const bool noprod = isx && l == 0;                                   // (layer 0 feeds nobody: its input is the data)
+    const float* KT = isx ? L.KxT : L.KhT;
+    const int ldK = isx ? L.ldI : ldP, PW = isx ? I : P, nkw = isx ? nkbx : nkb;
+    float4 kw[NP_KBW][NT];
+#pragma unroll
+    for (int jj = 0; jj < NP_KBW; ++jj) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int col = 16 * (ww + 4 * jj) + lr, cell = cell0 + 4 * i + q;
+        const float* kr = KT + (size_t)min(cell, H - 1) * ldK + min(col, ldK - 1);
+        const size_t gs_ = (size_t)H * ldK;
+        float4 v = make_float4(kr[0], kr[gs_], kr[2 * gs_], kr[3 * gs_]);
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+        const bool ok = col < PW && cell < H && !noprod;
+        kw[jj][i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+      }
+    }
+    const float* const dzr = &S.dzB[0][0][lane][0];                     // + (r * NT + i) * 256
+    const GpBuf& bpub = isx ? b3x : b1;
+    // the product of one row tile and its publication: three output tiles in flight, a tile leaves as soon as its 4 NT products are done
+    auto product = [&](int r, int ring) {
+      const unsigned ln_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      const unsigned fo = ln_ << 4;
+      if (isx) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+      for (int j0 = 0; j0 < NP_KBW; j0 += 3) {
+        f32x4 acc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          const float4 b = *reinterpret_cast<const float4*>(dzr + (r * NT + i) * 256);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) if (j0 + j < NP_KBW) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kw[j0 + j < NP_KBW ? j0 + j : 0][i].x, b.x, acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) if (j0 + j < NP_KBW) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kw[j0 + j < NP_KBW ? j0 + j : 0][i].y, b.y, acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) if (j0 + j < NP_KBW) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kw[j0 + j < NP_KBW ? j0 + j : 0][i].z, b.z, acc[j], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) if (j0 + j < NP_KBW) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(kw[j0 + j < NP_KBW ? j0 + j : 0][i].w, b.w, acc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int jj = j0 + j;
+          if (jj < NP_KBW && ww + 4 * jj < nkw) gp_store(bpub, slot1(ring, r, ww + 4 * jj, c) + fo, acc[j]);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+    };
+
+    if (isx) {
+      // =============================== X waves ===============================
+      // the stash of step t-1 (gate activations, c(t-2): 16 rows x 4 NT cells x 5 values per tile) travels through these waves into LDS a step ahead
+      float4 pv;
+      auto fetch = [&](int t, int r) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int e = ww * 64 + ln;
+        const int cq = e % NT, pr = min(e / NT, 79), row = pr & 15, k = pr >> 4;
+        const size_t rowg = (size_t)t * N + row0 + 16 * r + row;
+        const int cell = min(cell0 + 4 * cq, H - 4);
+        pv = *reinterpret_cast<const float4*>((k < 4 ? L.gates + rowg * H4 + k * H : L.c + rowg * H) + cell);
+      };
+      auto stage = [&](int r) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int e = ww * 64 + ln;
+        const int cq = e % NT, pr = e / NT, row = pr & 15, k = min(pr >> 4, 4);
+        if (e < 5 * 16 * NT) *reinterpret_cast<float4*>(&S.pfs[r][k][row][4 * cq]) = pv;
+        gp_signal(&S.cnt_f[r], lane);
+      };
+#pragma unroll
+      for (int r = 0; r < NR; ++r) { fetch(T - 1, r); stage(r); }
+      for (int s = 0; s < T; ++s) {
+        const int t = T - 1 - s;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          // back-pressure: the slots of ring step s % GP_XR this wave is about to write (its 8 output chunks, both halves) must have
+          // been re-armed by their consumers in the layer below: every word of their last 16 bytes carries the sentinel again
+          if (!noprod && s >= GP_XR) {
+            const unsigned so = slot1(s % GP_XR, r, min(ww + 4 * (lane >> 1), nkbx - 1), c) + (unsigned)(lane & 1) * 512u + 496u;
+            const bool son = lane < 16 && ww + 4 * (lane >> 1) < nkbx;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (unsigned polls = 0;; ++polls) {
+              const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(b3x.rs, so, 0, GP_SC1 | GP_VOL);
+              const bool armed = (y[0] == GP_SENT) & (y[1] == GP_SENT) & (y[2] == GP_SENT) & (y[3] == GP_SENT);
+              if (__all(!son || armed)) break;
+              asm volatile("" ::: "memory");
+              if ((polls & 63) == 63 && (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { fail(); return; }
+              __builtin_amdgcn_s_sleep(2);
+            }
+          }
+          if (!gp_wait(&S.cnt_h[r], 4u * ((unsigned)s + 1u), dead)) return;       // dz(t) of the tile is in LDS (and the cells have read the stage)
+          if (t > 0) { fetch(t - 1, r); stage(r); }
+          if (!noprod) {
+            if (t > 0 && !gp_wait(&S.cnt_q[r], 4u * ((unsigned)s + 1u), dead)) return;      // (the R waves' product first: it is on the recurrence's critical path)
+            product(r, s % GP_XR);
+          }
+          gp_signal(&S.cnt_z[r], lane);                                     // (dzB of the tile may be overwritten)
+        }
+      }
+      return;
+    }
+
+    // =============================== R waves ===============================
+    const bool cellw = w < NT;                                             // this wave owns gate tile w
+    float ccur[NR], dcar[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      ccur[r] = L.c[((size_t)T * N + row0 + 16 * r + lr) * H + min(cell0 + 4 * (cellw ? w : 0) + q, H - 1)];
+      dcar[r] = 0.f;
+    }
+    const float* const pfc = &S.pfs[0][0][lr][4 * (cellw ? w : 0) + q];  // + ((r * 5 + k) * 16) * CW
+    const float* const pwc = &S.peep[4 * (cellw ? w : 0) + q][0];
+    float* const dzw = &S.dzB[0][cellw ? w : 0][lane][0];                 // + r * NT * 256
+    float* const stc = &S.st[0][lr][4 * (cellw ? w : 0) + q];             // + g * GP_ROWS * CW + r * 16 * CW
+    // this workgroup's pieces of both rings are re-armed by its R waves once its G waves have summed them
+    for (int s = 0; s < T; ++s) {
+      const int t = T - 1 - s;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        if (!gp_wait(&S.cnt_m[r], (unsigned)s + 1u, dead)) return;         // dh(t) of the tile is in LDS
+        if (s > 0 && !gp_wait(&S.cnt_z[r], 4u * (unsigned)s, dead)) return;  // the X waves have taken dz(t+1)
+        if (!gp_wait(&S.cnt_f[r], 4u * ((unsigned)s + 1u), dead)) return;  // the stash of step t is in LDS
+        const bool live = t < (r ? len1 : len0);
+        if (cellw) {
+          const float dh = S.dhS[r][lr][4 * w + q];
+          const f32x4 pw = *reinterpret_cast<const f32x4*>(pwc);
+          const float* const pq = pfc + r * 5 * 16 * CW;
+          const float gi = pq[0], gj = pq[16 * CW], gf = pq[2 * 16 * CW], go = pq[3 * 16 * CW], cp = pq[4 * 16 * CW];
+          const float cc = ccur[r], dcv = dcar[r];
+          const float tc = gp_tanh(cc);
+          const float dao = dh * tc * go * (1.f - go);
+          const float dcn = dcv + dh * go * (1.f - tc * tc) + dao * pw[2];
+          const float daf = dcn * cp * gf * (1.f - gf);
+          const float dai = dcn * gj * gi * (1.f - gi);
+          const float dj = dcn * gi * (1.f - gj * gj);
+          dcar[r] = live ? dcn * gf + dai * pw[0] + daf * pw[1] : dcv;
+          ccur[r] = cp;
+          const f32x4 dz = {live ? dai : 0.f, live ? dj : 0.f, live ? daf : 0.f, live ? dao : 0.f};
+          *reinterpret_cast<f32x4*>(dzw + r * NT * 256) = dz;
+          float* const d = stc + r * 16 * CW;
+          d[0 * GP_ROWS * CW] = dz[0]; d[1 * GP_ROWS * CW] = dz[1]; d[2 * GP_ROWS * CW] = dz[2]; d[3 * GP_ROWS * CW] = dz[3];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // (the re-arming stores of the step before)
+        gp_signal(&S.cnt_h[r], lane);
+        if (!gp_wait(&S.cnt_h[r], 4u * ((unsigned)s + 1u), dead)) return; // every cell's dz of the tile is in LDS
+        if (t > 0) { product(r, s % GP_R1); }                             // (dh(-1) has no consumer)
+        gp_signal(&S.cnt_q[r], lane);
+        // dz(t) over the gate activations of the stash, a quarter of the tile per R wave
+        {
+          int ln = lane;
+          asm volatile("" : "+v"(ln));
+          const int e = w * 64 + ln;
+          const int cq = e % NT, pr = e / NT, row = 16 * r + (pr & 15), k = min(pr >> 4, 3);
+          const float4 v = *reinterpret_cast<const float4*>(&S.st[k][row][4 * cq]);
+          float* dst = L.gates + ((size_t)t * N + row0 + row) * H4 + k * H + cell0 + 4 * cq;
+          if (e < 4 * 16 * NT && cell0 + 4 * cq < H) gp_stash_store(dst, v);
+        }
+        // re-arm what this workgroup's G waves have summed for this step (they did before they handed dh(t) over: the wait at the top)
+        if (s > 0) gp_rearm(b1, slot1((s - 1) % GP_R1, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
+        if (!top) gp_rearm(b3, slot1(s % GP_XR, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
+      }
+    }
+    return;
+  }
+
+  // =============================== G waves: sum this workgroup's pieces (tile gw & 1) ===============================
+  __builtin_amdgcn_s_setprio(3);
+  const int gw = w - 8, r = gw & 1, gp = gw >> 1;
+  const int ppw = (NC + 1) >> 1, pp0 = gp * ppw, pn = max(0, min(ppw, NC - pp0));
+  const int nlr = (pn + 1 - (lane >> 5)) >> 1;                           // (two producers per load: lanes 0..31 the even ones, 32..63 the odd ones)
+  // reducer lane L holds piece lane L & 31: row (L & 15), cells 4 ((L & 31) >> 4) .. + 3 of this workgroup
+  const int rrow = row0 + 16 * r + (lane & 15), rq = (lane & 31) >> 4, rcol = cell0 + 4 * rq;
+  const int rlen = a.len[rrow];
+  for (int s = 0; s < T; ++s) {
+    const int t = T - 1 - s;
+    float4 dtop = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (top && rcol < a.ld_dout) {
+      dtop = *reinterpret_cast<const float4*>(a.dout_top + ((size_t)t * N + rrow) * a.ld_dout + rcol);
+      dtop = make_float4(rcol < P ? dtop.x : 0.f, rcol + 1 < P ? dtop.y : 0.f, rcol + 2 < P ? dtop.z : 0.f, rcol + 3 < P ? dtop.w : 0.f);
+    }
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f};
+    if (!top) {
+      // the input-gradient partials of the layer above at time t (published a diagonal ago as a rule: read first, poll if not there)
+      unsigned lo[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) lo[k] = slot1(s % GP_XR, r, jbr, min(pp0 + 2 * k, NC - 1)) + (unsigned)hh * 512u;
+      if (!gp_sweep<16, false, 16, false>(b3, lo, nlr, pair_off, slot1(s % GP_XR, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
+                                   [&](int k, const f32x4& v) { if (k == 0) sa = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) sa += v; })) { fail(); return; }
+    }
+    if (s > 0) {
+      // the state-gradient partials of this layer from time t + 1
+      unsigned lo[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) lo[k] = slot1((s + GP_R1 - 1) % GP_R1, r, jbr, min(pp0 + 2 * k, NC - 1)) + (unsigned)hh * 512u;
+      f32x4 ua = {0.f, 0.f, 0.f, 0.f};
+      if (!gp_sweep<16, true, 16, false>(b1, lo, nlr, pair_off, slot1((s + GP_R1 - 1) % GP_R1, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
+                                  [&](int k, const f32x4& v) { if (k == 0) ua = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) ua += v; })) { fail(); return; }
+      sa += ua;
+    }
+    *reinterpret_cast<f32x4*>(&S.gs[s & 1][r][gp][lane][0]) = sa;
+    gp_signal(&S.cnt_g[r], lane);
+    if (!gp_wait(&S.cnt_g[r], 2u * ((unsigned)s + 1u), dead)) return;
+    if (gp == 0) {
+      const float* const gsr = &S.gs[s & 1][r][0][lane & 31][0];
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(gsr), a1 = *reinterpret_cast<const f32x4*>(gsr + 32 * 4);
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(gsr + 64 * 4), c1 = *reinterpret_cast<const f32x4*>(gsr + 96 * 4);
+      f32x4 tot = (((a0 + a1) + c0) + c1) + f32x4{dtop.x, dtop.y, dtop.z, dtop.w};
+      if (!(t < rlen)) tot = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (lane < 32) *reinterpret_cast<f32x4*>(&S.dhS[r][lane & 15][4 * rq]) = tot;
+      gp_signal(&S.cnt_m[r], lane);
+    }
+  }
+}
+
+__global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_np_bwd(const GPersistArgs a) {
+  __shared__ __attribute__((aligned(16))) NpLdsB S;
+  gu32* ctl = (gu32*)a.ctl;
+  const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  np_bwd_body(a, S);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == gridDim.x - 1) {
+      if (__hip_atomic_load(ctl + DP_CTL_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        a.L[0].gates[0] = __builtin_nanf("");
+      __hip_atomic_store(ctl + DP_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned g1 = gen + 1u;
+      __hip_atomic_store(ctl + DP_CTL_GEN, g1 >= (1u << 21) ? 1u : g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 static int gp_grid(const GPersistArgs& a) {
   const int ngr = a.N / GP_ROWS, xpg = 8 / ngr, nwg = a.nl * a.NC;
   return 8 * ((nwg + xpg - 1) / xpg);
@@ -1741,6 +2042,17 @@ void launch_glstm_np_fwd(const GPersistArgs& a, hipStream_t s) {
   (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_np_gran2_bytes(a), s);
   if (a.NT == 2) hipLaunchKernelGGL((k_glstm_np_fwd<2, 8, 8>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
   else hipLaunchKernelGGL((k_glstm_np_fwd<4, 7, 6>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
+  ++g_chain_launches;
+}
+// (the unprojected BPTT: 8 cells per workgroup only; gran1 / gran3 = its two rings, armed once)
+size_t gpersist_np_gran1_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * GP_R1 * NP_NCH * a.NC * GP_SLOT; }
+size_t gpersist_np_gran3_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * (a.nl + 1) * GP_XR * NP_NCH * a.NC * GP_SLOT; }
+void gpersist_np_arm(const GPersistArgs& a, hipStream_t s) {
+  (void)hipMemsetAsync(a.gran1, 0xFF, gpersist_np_gran1_bytes(a), s);
+  (void)hipMemsetAsync(a.gran3, 0xFF, gpersist_np_gran3_bytes(a), s);
+}
+void launch_glstm_np_bwd(const GPersistArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_glstm_np_bwd, dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
   ++g_chain_launches;
 }
 void launch_glstm_bwd(const GPersistArgs& a, hipStream_t s) {

@@ -213,6 +213,10 @@ bool gpersist_np_plan(GPersistArgs& a, int nt_force = 0);      // nt_force: 2 / 
 size_t gpersist_np_gran2_bytes(const GPersistArgs& a);
 size_t gpersist_np_lds_bytes();
 void launch_glstm_np_fwd(const GPersistArgs& a, hipStream_t s);
+size_t gpersist_np_gran1_bytes(const GPersistArgs& a);            // the unprojected BPTT (NT == 2 only): state-gradient ring, input-gradient rings
+size_t gpersist_np_gran3_bytes(const GPersistArgs& a);
+void gpersist_np_arm(const GPersistArgs& a, hipStream_t s);
+void launch_glstm_np_bwd(const GPersistArgs& a, hipStream_t s);   // gates: activations in, dz out; needs c, dout_top; no input gradient for layer 0
 void launch_glstm_bwd(const GPersistArgs& a, hipStream_t s);      // gates: activations in, dz out; needs c, dmt, dout_top; no input gradient for layer 0
 extern long long g_chain_launches;
 void launch_floor_chain(float* a, float* b, int n, int mode, hipStream_t s);

@@ -463,11 +463,19 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
         gp_gran2_bytes = gpersist_np_gran2_bytes(ga);
         gp_gran2 = (unsigned long long*)alloc<float>(gp_gran2_bytes / sizeof(float));
         gp_ctl = (unsigned*)alloc<float>(16);
-        gp_gran1 = gp_gran2;                                      // (no hop-1 ring: the pointer only says "the forward path is on")
+        // the BPTT form exists for 8 cells per workgroup only: its two rings (state gradient, input gradient between layers)
+        static const bool npb_env = [] { const char* e = getenv("RSRGAN_GP_NP_BWD"); return !e || atoi(e) != 0; }();
+        if (gp_np_nt == 2 && (gp_env & 2) && npb_env) {
+          gp_gran1 = (unsigned long long*)alloc<float>(gpersist_np_gran1_bytes(ga) / sizeof(float));
+          gp_gran3 = (unsigned long long*)alloc<float>(gpersist_np_gran3_bytes(ga) / sizeof(float));
+          if (!gp_gran1 || !gp_gran3) { gp_gran1 = gp_gran3 = nullptr; }
+        }
+        if (!gp_gran1) gp_gran1 = gp_gran2;                       // (forward only: the pointer just says "the forward path is on")
         if (gp_gran2 && gp_ctl) {
           const unsigned ctl0[DP_CTL_WORDS] = {1u, 0u, 0u, 0u};
           HIPC(hipMemcpy(gp_ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice));
-        } else { gp_gran1 = gp_gran2 = nullptr; gp_ctl = nullptr; }
+          gpersist_rearm();
+        } else { gp_gran1 = gp_gran2 = gp_gran3 = nullptr; gp_ctl = nullptr; }
       }
     } else if (gpersist_args(ga, gp_Tcap) && resident_probe(gpersist_grid(ga), GP_THREADS, gpersist_lds_bytes())) {
       gp_gran1 = (unsigned long long*)alloc<float>(gpersist_gran1_bytes(ga) / sizeof(float));
@@ -1015,7 +1023,11 @@ void Model::persist_disable(int which) {
 
 void Model::gpersist_rearm() {
   GPersistArgs a{};
-  if (!gp_gran1 || gp_noproj || !gpersist_args(a, gp_Tcap)) return;       // (the unprojected form has no rings: every launch arms its own slots)
+  if (!gp_gran1 || !gpersist_args(a, gp_Tcap)) return;
+  if (gp_noproj) {                                                       // (the unprojected form: only its BPTT has rings)
+    if (gp_gran3) { gpersist_np_arm(a, 0); (void)hipDeviceSynchronize(); }
+    return;
+  }
   gpersist_arm(a, 0);
   (void)hipDeviceSynchronize();
 }
@@ -1052,9 +1064,26 @@ bool Model::persist_forward_g(int T, hipStream_t s) {
 // BPTT through the generator's stack as ONE persistent launch (gpersist.hip k_glstm_bwd): dz over the gate activations of every
 // layer's stash, dm per step in dmt.  Layer 0's input gradient (the input FC's d(h0)) is one GEMM over the dz stash afterwards.
 bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only, const StreamFn& pre, const StreamFn& post) {
-  if (!gp_gran1 || !gp_gran3 || gp_noproj || !(gp_env & 2) || !wavefront() || seq_drop_on() || ch.size() != gl.size()) return false;
+  if (!gp_gran1 || !gp_gran3 || !(gp_env & 2) || !wavefront() || seq_drop_on() || ch.size() != gl.size()) return false;
   GPersistArgs a{};
-  if (!gpersist_args(a, T) || gpersist_gran2_bytes(a) > gp_gran2_bytes) return false;
+  if (!gpersist_args(a, T) || (gp_noproj ? gpersist_np_gran2_bytes(a) : gpersist_gran2_bytes(a)) > gp_gran2_bytes) return false;
+  if (gp_noproj) {
+    // num_proj=None (gpersist.hip k_glstm_np_bwd): dz over the gate activations of every layer's stash; no input gradient for layer 0
+    if (a.NT != 2 || a.res) return false;
+    for (size_t l = 0; l < ch.size(); ++l) {
+      const LayerRun& R = ch[l];
+      if (R.L != &gl[l] || R.S != &g_st[l] || R.res_in || R.res_out || R.row0 != 0 || R.Ns != R.N || R.N != a.N || R.len != a.len) return false;
+      if (l > 0 && (R.din_accumulate || ch[l].din != ch[l - 1].dout)) return false;
+    }
+    if (ch[0].din) return false;
+    a.dout_top = ch.back().dout; a.ld_dout = gl.back().ldP;
+    if (!a.dout_top) return false;
+    if (check_only) return true;
+    launch_glstm_np_bwd(a, s);
+    if (!defer_wgrads) chain_wgrads(ch, T, s, nullptr, pre, post);
+    else { if (pre) pre(s); if (post) post(s); }
+    return true;
+  }
   for (size_t l = 0; l < ch.size(); ++l) {
     const LayerRun& R = ch[l];
     if (R.L != &gl[l] || R.S != &g_st[l] || R.row0 != 0 || R.Ns != R.N || R.N != a.N || R.len != a.len) return false;
