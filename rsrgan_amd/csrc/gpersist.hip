@@ -44,7 +44,10 @@ constexpr int GP_NKB = 18;               // k-blocks of 16 of the recurrent / in
 constexpr int GP_KBW = 5;                // k-blocks per R / X wave (k-block jb belongs to wave jb & 3)
 constexpr int GP_SLOT = 1024;            // bytes per chunk slot: a 16 x 16 tile of floats, 16 bytes (four columns of one row) per fragment lane
 constexpr unsigned GP_SENT = 0xFFFFFFFFu; // a word of a slot nobody has written yet
-constexpr int GP_R1 = 3;                 // steps in the hop-1 ring: a slot is summed in step t, re-armed at the end of step t + 1, written again in step t + 3
+#ifndef GP_R1_STEPS
+#define GP_R1_STEPS 3
+#endif
+constexpr int GP_R1 = GP_R1_STEPS;                 // steps in the hop-1 ring: a slot is summed in step t, re-armed at the end of step t + 1, written again in step t + 3
 constexpr int GP_NCH = GP_NKB * GP_NR;   // chunk slots per layer and step (the layout's stride; a layer uses its first nkb * NR)
 constexpr unsigned GP_SC1 = 16u;         // aux of the raw-buffer builtins: sc1 (agent scope: write-through store / L1-bypassing load)
 constexpr unsigned GP_VOL = 1u << 31;    // ... compiler-only: volatile (a polled load must not be hoisted out of its loop)
@@ -145,9 +148,35 @@ __device__ __forceinline__ void gp_store(const GpBuf& b, unsigned off, const f32
   __builtin_amdgcn_raw_buffer_store_b128(x, b.rs, off, 0, GP_SC1);
 }
 __device__ __forceinline__ bool gp_valid(const u32x4& x) { return (x[0] != GP_SENT) & (x[1] != GP_SENT) & (x[2] != GP_SENT) & (x[3] != GP_SENT); }
+// TAGGED ring slots (round 5): the lowest mantissa bit of every published word carries the PARITY OF THE RING PASS that wrote it
+// ((step counter / ring depth) & 1, the counter carried from launch to launch in the control block, GP_CTL_C1 / _C3), so what the
+// previous pass left in a slot is told from this pass's data without anybody putting sentinels back: the re-arming stores were half
+// of the launches' write-through traffic (profiles/r5_gpersist_trace.txt "no re-arming").  A 32-bit word lands whole, so a torn piece
+// is a piece with mixed parities = not valid yet.  The value gives up its last bit: the producer rounds it to a 22-bit mantissa (ties
+// to even: <= 1 ulp, unbiased), the consumer clears the tag again (gp_untag), so what is summed does not depend on the pass parity --
+// the same inputs give the same bits whatever was launched before.
+__device__ __forceinline__ void gp_store_t(const GpBuf& b, unsigned off, const f32x4& v, unsigned tag) {
+  u32x4 x = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] = ((x[i] + ((x[i] >> 1) & 1u)) & ~1u) | tag;
+  __builtin_amdgcn_raw_buffer_store_b128(x, b.rs, off, 0, GP_SC1);
+}
+template <bool TAGGED>
+__device__ __forceinline__ f32x4 gp_untag(const u32x4& x) {
+  const unsigned m = TAGGED ? ~1u : ~0u;
+  return f32x4{__uint_as_float(x[0] & m), __uint_as_float(x[1] & m), __uint_as_float(x[2] & m), __uint_as_float(x[3] & m)};
+}
+__device__ __forceinline__ bool gp_valid_t(const u32x4& x, unsigned tag) {
+  const unsigned all1 = x[0] & x[1] & x[2] & x[3] & 1u, any1 = (x[0] | x[1] | x[2] | x[3]) & 1u;
+  return tag ? all1 != 0u : any1 == 0u;
+}
+constexpr int GP_CTL_C1 = 4, GP_CTL_C3 = 5;      // control-block words: steps written so far to the hop-1 ring (mod 2 GP_R1) / the input-gradient rings (mod 2 GP_XR)
 // Re-arm the NP producers' 512-byte half chunks at base + p * GP_SLOT (p = 0 .. NP-1): one store covers two producers (a half
 // wave each); wave w of the four R waves takes every fourth store.
 __device__ __forceinline__ void gp_rearm(const GpBuf& b, unsigned base, int NP, int w, int lane) {
+#ifdef GP_NOREARM                   // (harness experiment: rings as deep as the launch is long, armed by a memset in front of every launch)
+  return;
+#endif
   const u32x4 sent = {GP_SENT, GP_SENT, GP_SENT, GP_SENT};
   for (int k = w; 2 * k < NP; k += 4) {
     const int p = 2 * k + (lane >> 5);
@@ -166,9 +195,11 @@ __device__ __forceinline__ void gp_rearm(const GpBuf& b, unsigned base, int NP, 
 // L2s are invalidated at the kernel boundary behind the memset), i.e. it is detected like a store that has not landed, and the retry
 // reads past the caches (sc1).
 // false on time-out / peer failure.
-template <int NL, bool POLL_FIRST, int BATCH, bool CACHED, class F>
+template <int NL, bool POLL_FIRST, int BATCH, bool CACHED, bool TAGGED = false, class F>
 __device__ __forceinline__ bool gp_sweep(const GpBuf& b, const unsigned (&lo)[NL], int nl, unsigned lane_off, unsigned so, bool son,
-                                         gu32* err, F&& consume) {
+                                         gu32* err, F&& consume, unsigned tag = 0u) {
+  static_assert(!(TAGGED && CACHED), "tagged ring slots are read past the caches");
+  auto valid = [&](const u32x4& x) { return TAGGED ? gp_valid_t(x, tag) : gp_valid(x); };
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   // (the offsets as scalar VALUES first: hipcc turns `c ? lo[k] : lo[0]` into a load through a selected pointer, which keeps the
   // array in scratch / LDS)
@@ -190,8 +221,8 @@ __device__ __forceinline__ bool gp_sweep(const GpBuf& b, const unsigned (&lo)[NL
       for (int j = 0; j < BATCH; ++j) {
         const int k = k0 + j;
         if (k < NL) {
-          ok &= (k >= nl) || gp_valid(x[j]);
-          consume(k, f32x4{__uint_as_float(x[j][0]), __uint_as_float(x[j][1]), __uint_as_float(x[j][2]), __uint_as_float(x[j][3])});
+          ok &= (k >= nl) || valid(x[j]);
+          consume(k, gp_untag<TAGGED>(x[j]));
         }
       }
     }
@@ -216,7 +247,7 @@ __device__ __forceinline__ bool gp_sweep(const GpBuf& b, const unsigned (&lo)[NL
     read_now = true;
     for (unsigned polls = 0;; ++polls) {
       const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(b.rs, so, 0, GP_SC1 | GP_VOL);
-      if (__all(!son || gp_valid(y))) break;
+      if (__all(!son || valid(y))) break;
       asm volatile("" ::: "memory");
       if ((polls & 63) == 63) {
         if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull ||          // 1 s at 100 MHz
@@ -308,8 +339,9 @@ struct GpLds {
 // input).  The reducer of a half chunk is also the owner of that half chunk of the running sum: it adds its masked m(t) to the half
 // chunk of s_{l-1}(t) (layer 0: the input rows in memory; above: what the same-numbered reducer of the layer below published a step
 // ago), writes it to res_out and publishes it in the second region of gran2, where the layer above's X waves gather their x(t).
-template <int NT, int PROG, bool RES>
-__device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S) {
+template <int NT, int PROG, bool RES, bool TAG>
+__device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S, const unsigned c1) {
+  static_assert(!(TAG && PROG), "the progressive sweeps know the sentinel form only");
   constexpr int NR = GP_NR, NU = NT * NR, CW = 4 * NT;
   GPT_DECL
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
@@ -482,10 +514,10 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
         // re-arm those ring slots, here, where the wave has nothing urgent to do.  The stores are acknowledged before the wave
         // signals its cells of step t+1, i.e. before this workgroup's partials of step t+1 leave, without which no m(t+1) and
         // hence no partial of step t+2 -- the next write to these slots -- exists.
-        if (reducer && t > 0) gp_rearm(b1, slot1((t - 1) % GP_R1, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
+        if (!TAG && reducer && t > 0) gp_rearm(b1, slot1((t - 1) % GP_R1, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
       }
     }
-    if (reducer) {                                                       // the last step's partials: leave every ring slot armed for the next launch
+    if (!TAG && reducer) {                                               // the last step's partials: leave every ring slot armed for the next launch
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         if (!gp_wait(&S.cnt_m[r], 2u * (unsigned)T, dead)) return;
@@ -609,7 +641,8 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
   }
   if (reducer && gp == 1 && lane < 32 && rcol < ldP) *reinterpret_cast<float4*>(L.mst + (size_t)rrow * ldP + rcol) = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int t = 0; t < T; ++t) {
-    const int par = t & 1, par1 = t % GP_R1;
+    const int par = t & 1, par1 = (int)((c1 + (unsigned)t) % GP_R1);      // (c1 = 0 without tags)
+    const unsigned tag1 = ((c1 + (unsigned)t) / GP_R1) & 1u;
     GPT(12);
     if (!gp_wait(&S.cnt_h[r], 4u * ((unsigned)t + 1u), dead)) return;  // the cells of step t, tile r: h is in LDS
     GPT(13);
@@ -631,7 +664,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
           for (int j = 0; j < 3; ++j) pm[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpw[(2 * (n0 + j) * NT + ks) * 64], hv[ks], pm[j], 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-          if (n0 + j < nvg) gp_store(b1, pub0 + (unsigned)(2 * (n0 + j)) * (unsigned)NC * GP_SLOT, pm[j]);
+          if (n0 + j < nvg) { if (TAG) gp_store_t(b1, pub0 + (unsigned)(2 * (n0 + j)) * (unsigned)NC * GP_SLOT, pm[j], tag1); else gp_store(b1, pub0 + (unsigned)(2 * (n0 + j)) * (unsigned)NC * GP_SLOT, pm[j]); }
       }
     }
     GPT(14);
@@ -649,8 +682,8 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
                                   (pn * GP_GATE_NUM) / GP_GATE_DEN, err, pv)) { fail(); return; }
 #pragma unroll
         for (int k = 0; k < 10; ++k) { if (k == 0) sa = k < nlr ? pv[0] : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) sa += pv[k]; }      // (slot order: the same bits as the other form)
-      } else if (!gp_sweep<10, true, 10, false>(b1, lo, nlr, pair_off, slot1(par1, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
-                                  [&](int k, const f32x4& v) { if (k == 0) sa = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) sa += v; })) { fail(); return; }
+      } else if (!gp_sweep<10, true, 10, false, TAG>(b1, lo, nlr, pair_off, slot1(par1, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
+                                  [&](int k, const f32x4& v) { if (k == 0) sa = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) sa += v; }, tag1)) { fail(); return; }
       GPT(15);
       *reinterpret_cast<f32x4*>(&S.gs[par][r][gp][lane][0]) = sa;
       gp_signal(&S.cnt_g[r], lane);
@@ -724,16 +757,19 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S)
 #endif
 }
 
-template <int NT, int PROG, bool RES>
+template <int NT, int PROG, bool RES, bool TAG>
 __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_fwd(const GPersistArgs a) {
   __shared__ __attribute__((aligned(16))) GpLds<NT> S;
   gu32* ctl = (gu32*)a.ctl;
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (counts launches; nothing depends on it)
-  gp_fwd_body<NT, PROG, RES>(a, S);
+  // (TAG) steps written to the hop-1 ring by the launches so far, mod 2 GP_R1: every workgroup reads it here, the last one to finish moves it on
+  const unsigned c1 = TAG ? __hip_atomic_load(ctl + GP_CTL_C1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  gp_fwd_body<NT, PROG, RES, TAG>(a, S, c1);
   __syncthreads();                                                 // (every wave leaves the body on every path)
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == gridDim.x - 1) {
+      if (TAG) __hip_atomic_store(ctl + GP_CTL_C1, (c1 + (unsigned)a.T) % (2u * GP_R1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (__hip_atomic_load(ctl + DP_CTL_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
         a.L[a.nl - 1].out[0] = __builtin_nanf("");
       __hip_atomic_store(ctl + DP_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -761,7 +797,10 @@ __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_fwd(const GPersistAr
 // is a time-batched GEMM over the dz stash afterwards.
 // Cell gradient: kernels.hip k_bwd_a2 (peepholes, o's peephole on the new c, dynamic_rnn masking: a finished row has dz = 0 and
 // carries dc through).
-constexpr int GP_XR = 6;   // (a slot is re-armed, acknowledged, two steps after it was summed: four steps of slack)
+#ifndef GP_XR_STEPS
+#define GP_XR_STEPS 6
+#endif
+constexpr int GP_XR = GP_XR_STEPS;   // (a slot is re-armed, acknowledged, two steps after it was summed: four steps of slack)
 
 template <int NT>
 struct GpLdsB {
@@ -796,10 +835,22 @@ __device__ __forceinline__ bool gp_poll(const GpBuf& b, unsigned so, bool son, g
 // One wave sums the half chunks of ALL NC producers at base + p * GP_SLOT (off the critical path: a plain loop, four loads in flight --
 // the unrolled gp_sweep over 20 pieces cost the backward kernel 8 spilled registers): even producers in lanes 0..31, odd ones in
 // 32..63, then the two halves (even first); every lane ends with the total of its (lane & 31) piece.  false: time-out / peer failure.
-__device__ __forceinline__ bool gp_sum_all(const GpBuf& b, unsigned base, int NC, int lane, gu32* err, f32x4& out) {
-  if (!gp_poll(b, base + (unsigned)min(lane, NC - 1) * GP_SLOT + 496u, lane < NC, err)) return false;
-  f32x4 sa = {0.f, 0.f, 0.f, 0.f};
+template <bool TAGGED = false>
+__device__ __forceinline__ bool gp_sum_all(const GpBuf& b, unsigned base, int NC, int lane, gu32* err, f32x4& out, unsigned tag = 0u) {
+  auto valid = [&](const u32x4& x) { return TAGGED ? gp_valid_t(x, tag) : gp_valid(x); };
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  if (!TAGGED) { if (!gp_poll(b, base + (unsigned)min(lane, NC - 1) * GP_SLOT + 496u, lane < NC, err)) return false; }
+  else {
+    const unsigned so = base + (unsigned)min(lane, NC - 1) * GP_SLOT + 496u;
+    for (unsigned polls = 0;; ++polls) {
+      const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(b.rs, so, 0, GP_SC1 | GP_VOL);
+      if (__all(lane >= NC || valid(y))) break;
+      asm volatile("" ::: "memory");
+      if ((polls & 63) == 63 && (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) return false;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  f32x4 sa = {0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; 2 * k0 < NC; k0 += 4) {
     for (;;) {
       u32x4 x[4];
@@ -808,11 +859,11 @@ __device__ __forceinline__ bool gp_sum_all(const GpBuf& b, unsigned base, int NC
         x[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, base + (unsigned)min(2 * (k0 + j) + (lane >> 5), NC - 1) * GP_SLOT + (unsigned)(lane & 31) * 16u, 0, GP_SC1 | GP_VOL);
       bool ok = true;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ok &= (2 * (k0 + j) + (lane >> 5) >= NC) || gp_valid(x[j]);
+      for (int j = 0; j < 4; ++j) ok &= (2 * (k0 + j) + (lane >> 5) >= NC) || valid(x[j]);
       if (__all(ok)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (2 * (k0 + j) + (lane >> 5) < NC) sa += f32x4{__uint_as_float(x[j][0]), __uint_as_float(x[j][1]), __uint_as_float(x[j][2]), __uint_as_float(x[j][3])};
+          if (2 * (k0 + j) + (lane >> 5) < NC) sa += gp_untag<TAGGED>(x[j]);
         break;
       }
       asm volatile("" ::: "memory");
@@ -832,8 +883,9 @@ __device__ __forceinline__ bool gp_sum_all(const GpBuf& b, unsigned base, int NC
 // chunk of D: its second G wave sums ALL input-gradient partials of the layer above (alone: the sum is needed on its own), adds the
 // D_{l+1}(t) piece the same-numbered reducer above published a step ago, hands D_l(t) into the state-gradient sum and publishes it
 // for the layer below in the second region of gran2 (one slot per step, behind the hand-offs).
-template <int NT, int PROG, bool RES>
-__device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S) {
+template <int NT, int PROG, bool RES, bool TAG>
+__device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S, const unsigned c1, const unsigned c3) {
+  static_assert(!(TAG && PROG), "the progressive sweeps know the sentinel form only");
   constexpr int NR = GP_NR, CW = 4 * NT;
   GPT_DECL
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
@@ -944,7 +996,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
     const float* const dzr = &S.dzB[0][0][lane][0];                     // + (r * NT + i) * 256
     const GpBuf& bpub = isx ? b3x : b1;
     // the product of one row tile and its publication: three output tiles in flight, a tile leaves as soon as its 4 NT products are done
-    auto product = [&](int r, int ring) {
+    auto product = [&](int r, int ring, unsigned tag) {
       // (opaque copies: hipcc otherwise computes every slot offset and row address of the step loop once, in front of it, and
       // spills them -- a scratch reload behind the write-through stores below waits for their acknowledgement)
       const unsigned ln_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // (the lane id again: two VALU instructions, no register kept, no spill)
@@ -980,7 +1032,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const int jj = j0 + j;
-          if (jj < GP_KBW && ww + 4 * jj < nkw && (jj < GP_KBW - 1 || five)) gp_store(bpub, slot1(ring, r, ww + 4 * jj, c) + fo, acc[j]);
+          if (jj < GP_KBW && ww + 4 * jj < nkw && (jj < GP_KBW - 1 || five)) { if (TAG) gp_store_t(bpub, slot1(ring, r, ww + 4 * jj, c) + fo, acc[j], tag); else gp_store(bpub, slot1(ring, r, ww + 4 * jj, c) + fo, acc[j]); }
         }
       }
       __builtin_amdgcn_s_setprio(0);
@@ -1036,7 +1088,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
             // path; this one only feeds the layer below, which runs a ring's worth of steps behind: let theirs go first (side by
             // side both took 6-7.6 k cycles for 3.2 k of MFMA issue each, s_setprio notwithstanding).
             if (t > 0 && !gp_wait(cnt + C_Q + r, 4u * ((unsigned)s + 1u), dead)) return;
-            product(r, s % GP_XR);
+            product(r, (int)((c3 + (unsigned)s) % GP_XR), ((c3 + (unsigned)s) / GP_XR) & 1u);
             gp_signal(cnt + C_Z + r, lane);                                 // (the product has read dzB)
           }
         }
@@ -1133,7 +1185,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
         gp_signal(cnt + C_H + r, lane);
         GPTSR(6 * r + 4);
         if (!gp_wait(cnt + C_H + r, 4u * ((unsigned)s + 1u), dead)) return;       // every cell's dz of the tile is in LDS
-        if (t > 0) { product(r, s % GP_R1); gp_signal(cnt + C_Q + r, lane); }     // (dm(-1) has no consumer)
+        if (t > 0) { product(r, (int)((c1 + (unsigned)s) % GP_R1), ((c1 + (unsigned)s) / GP_R1) & 1u); gp_signal(cnt + C_Q + r, lane); }     // (dm(-1) has no consumer)
         GPTSR(6 * r + 5);
         // dz(t) over the gate activations of the stash, a quarter of the tile per R wave: NT consecutive lanes write one 16 NT-byte row piece
         int ln = lane;
@@ -1149,7 +1201,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
         // This workgroup's G waves summed this step's partials before they gathered dm(t) (the wait at the top): re-arm their slots of
         // both rings.  Acknowledged before the wave signals its cells of the next step, i.e. before this workgroup's partials of that
         // step leave, without which no dm of the step after -- and no later write to these slots -- exists.
-        if (reducer) {
+        if (!TAG && reducer) {
           if (s > 0) gp_rearm(b1, slot1((s - 1) % GP_R1, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
           if (!top) gp_rearm(b3, slot1(s % GP_XR, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
           if (dxr && s > 0) {                                              // (the G wave summed layer 0's input gradient of step s-1 long ago)
@@ -1159,7 +1211,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
         }
       }
     }
-    if (dxr) {                                                             // the last step's slots: leave the ring armed for the next launch
+    if (!TAG && dxr) {                                                     // the last step's slots: leave the ring armed for the next launch
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         if (!gp_wait(cnt + C_D + r, (unsigned)T, dead)) return;
@@ -1185,7 +1237,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
   // critical path, no exchange with the other G wave), even producers in lanes 0..31, odd ones in 32..63, then the two halves
   auto sum_dx0 = [&](int sx) -> bool {
     f32x4 tt;
-    if (!gp_sum_all(b3x, slot1(sx % GP_XR, r, jbr, 0) + (unsigned)hh * 512u, NC, lane, err, tt)) return false;
+    if (!gp_sum_all<TAG>(b3x, slot1((int)((c3 + (unsigned)sx) % GP_XR), r, jbr, 0) + (unsigned)hh * 512u, NC, lane, err, tt, ((c3 + (unsigned)sx) / GP_XR) & 1u)) return false;
     if (lane < 32 && rcol < a.ld_din0)
       *reinterpret_cast<float4*>(a.din0 + ((size_t)(T - 1 - sx) * N + rrow) * a.ld_din0 + rcol) = make_float4(tt[0], tt[1], tt[2], tt[3]);
     gp_signal(cnt + C_D + r, lane);
@@ -1193,6 +1245,9 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
   };
   for (int s = 0; s < T; ++s) {
     const int t = T - 1 - s;
+    // ring positions of this step (c1 = c3 = 0 without tags): what the layer above wrote at step s, what this layer wrote at step s - 1
+    const int rx = (int)((c3 + (unsigned)s) % GP_XR), r1 = (int)((c1 + (unsigned)s + 2u * GP_R1 - 1u) % GP_R1);
+    const unsigned tagx = ((c3 + (unsigned)s) / GP_XR) & 1u, tag1 = ((c1 + (unsigned)s + 2u * GP_R1 - 1u) / GP_R1) & 1u;
     GPTSG(12);
     f32x4 tot = {0.f, 0.f, 0.f, 0.f};
     f32x4 Dl = {0.f, 0.f, 0.f, 0.f};                                     // (RES, second G wave) D_l(t) of this lane's four columns
@@ -1209,7 +1264,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
           if (top) Dl = f32x4{dtop.x, dtop.y, dtop.z, dtop.w};
           else {
             f32x4 dxt;
-            if (!gp_sum_all(b3, slot1(s % GP_XR, r, jbr, 0) + (unsigned)hh * 512u, NC, lane, err, dxt)) { fail(); return; }
+            if (!gp_sum_all<TAG>(b3, slot1(rx, r, jbr, 0) + (unsigned)hh * 512u, NC, lane, err, dxt, tagx)) { fail(); return; }
             const unsigned off = slot2(t, r, jbr) + (unsigned)hh * 512u + (unsigned)(lane & 31) * 16u;
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             u32x4 y;
@@ -1228,16 +1283,16 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
         // the input-gradient partials of the layer above at time t (published a diagonal ago as a rule: read first, poll if not there)
         unsigned lo[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) lo[k] = slot1(s % GP_XR, r, jbr, min(pp0 + 2 * k, NC - 1)) + (unsigned)hh * 512u;
-        if (!gp_sweep<10, false, 10, false>(b3, lo, nlr, pair_off, slot1(s % GP_XR, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
-                                     [&](int k, const f32x4& v) { if (k == 0) sa = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) sa += v; })) { fail(); return; }
+        for (int k = 0; k < 10; ++k) lo[k] = slot1(rx, r, jbr, min(pp0 + 2 * k, NC - 1)) + (unsigned)hh * 512u;
+        if (!gp_sweep<10, false, 10, false, TAG>(b3, lo, nlr, pair_off, slot1(rx, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
+                                     [&](int k, const f32x4& v) { if (k == 0) sa = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) sa += v; }, tagx)) { fail(); return; }
       }
       GPTSG(13);
       if (s > 0) {
         // the state-gradient partials of this layer from time t + 1
         unsigned lo[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) lo[k] = slot1((s + GP_R1 - 1) % GP_R1, r, jbr, min(pp0 + 2 * k, NC - 1)) + (unsigned)hh * 512u;
+        for (int k = 0; k < 10; ++k) lo[k] = slot1(r1, r, jbr, min(pp0 + 2 * k, NC - 1)) + (unsigned)hh * 512u;
         f32x4 ua = {0.f, 0.f, 0.f, 0.f};
         if (PROG & 1) {
           f32x4 pv[10];
@@ -1245,8 +1300,8 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
                                     (pn * GP_GATE_NUM) / GP_GATE_DEN, err, pv)) { fail(); return; }
 #pragma unroll
           for (int k = 0; k < 10; ++k) { if (k == 0) ua = k < nlr ? pv[0] : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) ua += pv[k]; }
-        } else if (!gp_sweep<10, true, 10, false>(b1, lo, nlr, pair_off, slot1((s + GP_R1 - 1) % GP_R1, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
-                                    [&](int k, const f32x4& v) { if (k == 0) ua = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) ua += v; })) { fail(); return; }
+        } else if (!gp_sweep<10, true, 10, false, TAG>(b1, lo, nlr, pair_off, slot1(r1, r, jbr, min(pp0 + lane, NC - 1)) + (unsigned)hh * 512u + 496u, lane < pn, err,
+                                    [&](int k, const f32x4& v) { if (k == 0) ua = k < nlr ? v : f32x4{0.f, 0.f, 0.f, 0.f}; else if (k < nlr) ua += v; }, tag1)) { fail(); return; }
         sa += ua;
       }
       if (RES && gp == 1 && lane < 32) sa += Dl;                          // (once: with this wave's even-producer half)
@@ -1291,16 +1346,23 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
 #endif
 }
 
-template <int NT, int PROG, bool RES>
+template <int NT, int PROG, bool RES, bool TAG>
 __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_bwd(const GPersistArgs a) {
   __shared__ __attribute__((aligned(16))) GpLdsB<NT> S;
   gu32* ctl = (gu32*)a.ctl;
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (counts launches)
-  gp_bwd_body<NT, PROG, RES>(a, S);
+  // (TAG) the ring step counters: T - 1 state-gradient steps and T input-gradient steps are written per launch
+  const unsigned c1 = TAG ? __hip_atomic_load(ctl + GP_CTL_C1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  const unsigned c3 = TAG ? __hip_atomic_load(ctl + GP_CTL_C3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  gp_bwd_body<NT, PROG, RES, TAG>(a, S, c1, c3);
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == gridDim.x - 1) {
+      if (TAG) {
+        __hip_atomic_store(ctl + GP_CTL_C1, (c1 + (unsigned)a.T - 1u) % (2u * GP_R1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ctl + GP_CTL_C3, (c3 + (unsigned)a.T) % (2u * GP_XR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       if (__hip_atomic_load(ctl + DP_CTL_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
         a.L[0].gates[0] = __builtin_nanf("");
       __hip_atomic_store(ctl + DP_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2006,6 +2068,7 @@ size_t gpersist_gran3_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_RO
 void gpersist_arm(const GPersistArgs& a, hipStream_t s) {
   (void)hipMemsetAsync(a.gran1, 0xFF, gpersist_gran1_bytes(a), s);
   if (a.gran3) (void)hipMemsetAsync(a.gran3, 0xFF, gpersist_gran3_bytes(a), s);
+  (void)hipMemsetAsync(a.ctl + GP_CTL_C1, 0, 2 * sizeof(unsigned), s);          // (tagged rings: every word's parity bit is 1 now, pass 0 writes 0)
 }
 // (-DGP_PROG_ONLY=mask: the progressive sweeps, gp_sweep_prog -- the harness only: measured slower, profiles/r5_gpersist_progressive_sweep_negative.txt)
 #ifndef GP_PROG_ONLY
@@ -2013,8 +2076,12 @@ void gpersist_arm(const GPersistArgs& a, hipStream_t s) {
 #endif
 void launch_glstm_fwd(const GPersistArgs& a, hipStream_t s) {
   (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_gran2_bytes(a), s);
-  if (a.res) hipLaunchKernelGGL((k_glstm_fwd<5, GP_PROG_ONLY, true>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
-  else hipLaunchKernelGGL((k_glstm_fwd<5, GP_PROG_ONLY, false>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
+  const dim3 g(gp_grid(a)), b(GP_WAVES * 64);
+  if (a.tags && !GP_PROG_ONLY) {
+    if (a.res) hipLaunchKernelGGL((k_glstm_fwd<5, 0, true, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_glstm_fwd<5, 0, false, true>), g, b, 0, s, a);
+  } else if (a.res) hipLaunchKernelGGL((k_glstm_fwd<5, GP_PROG_ONLY, true, false>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((k_glstm_fwd<5, GP_PROG_ONLY, false, false>), g, b, 0, s, a);
   ++g_chain_launches;
 }
 // ---- the unprojected form: plan, sizes, launch ----
@@ -2057,8 +2124,12 @@ void launch_glstm_np_bwd(const GPersistArgs& a, hipStream_t s) {
 }
 void launch_glstm_bwd(const GPersistArgs& a, hipStream_t s) {
   (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_gran2_bytes(a), s);
-  if (a.res) hipLaunchKernelGGL((k_glstm_bwd<5, GP_PROG_ONLY, true>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
-  else hipLaunchKernelGGL((k_glstm_bwd<5, GP_PROG_ONLY, false>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
+  const dim3 g(gp_grid(a)), b(GP_WAVES * 64);
+  if (a.tags && !GP_PROG_ONLY) {
+    if (a.res) hipLaunchKernelGGL((k_glstm_bwd<5, 0, true, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_glstm_bwd<5, 0, false, true>), g, b, 0, s, a);
+  } else if (a.res) hipLaunchKernelGGL((k_glstm_bwd<5, GP_PROG_ONLY, true, false>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((k_glstm_bwd<5, GP_PROG_ONLY, false, false>), g, b, 0, s, a);
   ++g_chain_launches;
 }
 

@@ -194,6 +194,9 @@ struct GPersistArgs {
   // models/res_lstm_l.py:101-194: inputs_{l+1} = outputs_l + inputs_l (inputs_1 = the stack's input, L[0].in; needs I == P everywhere).
   // gran2 then holds a second region of the same size: the running sums s_l (forward) / their gradients (backward), one slot per step.
   int res;
+  // ring slots told apart by the parity of the ring pass in every word's lowest bit instead of sentinels that somebody has to put back
+  // (gpersist.hip gp_store_t; the projected kernels only): no re-arming stores
+  int tags;
 };
 constexpr int GP_TMAX = 2046;                     // longest launch (slot offsets are 32-bit; a longer batch takes the launch-per-phase path)
 bool gpersist_plan(GPersistArgs& a);              // fills NT / NC; false: shape not supported

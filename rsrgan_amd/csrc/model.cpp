@@ -985,6 +985,9 @@ bool Model::gpersist_shape(GPersistArgs& a, int T) const {              // (size
   a = GPersistArgs{};
   a.nl = (int)gl.size(); a.N = B; a.T = T; a.H = gl[0].H; a.res = res ? 1 : 0;
   bool noproj = !gl[0].has_proj;
+  // ring slots tagged with the parity of the ring pass instead of re-armed with sentinels (gpersist.hip gp_store_t); RSRGAN_GP_TAGS=0: the sentinel form
+  static const bool tags_env = [] { const char* e = getenv("RSRGAN_GP_TAGS"); return !e || atoi(e) != 0; }();
+  a.tags = tags_env && !noproj ? 1 : 0;
   for (size_t l = 0; l < gl.size(); ++l) {
     const LstmLayer& L = gl[l];
     if (L.has_proj == noproj || L.H != a.H) return false;

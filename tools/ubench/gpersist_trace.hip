@@ -46,6 +46,7 @@ int main(int argc, char** argv) {
   }
   if (bwd) { a.dout_top = dal((size_t)T * N * P, 0.01f); a.ld_dout = P; }
   if (!gpersist_plan(a)) { printf("unsupported shape\n"); return 1; }
+  if (const char* e = getenv("GP_TAGS")) a.tags = atoi(e);
   const size_t g1 = gpersist_gran1_bytes(a), g2 = gpersist_gran2_bytes(a);
   CK(hipMalloc(&a.gran1, g1)); CK(hipMalloc(&a.gran2, g2)); CK(hipMalloc(&a.ctl, 64));
   if (bwd) {
@@ -59,6 +60,9 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e9f;
   for (int it = 0; it < 5; ++it) {
+#ifdef GP_NOREARM
+    gpersist_arm(a, s);
+#endif
     CK(hipEventRecord(e0, s));
     if (bwd) launch_glstm_bwd(a, s); else launch_glstm_fwd(a, s);
     CK(hipEventRecord(e1, s));
