@@ -49,6 +49,12 @@ if os.environ.get("RSRGAN_TEST_SIDELOAD") == "1":
 for it in range(2):
     d = np.ravel(model.d_step(x, lab, ln)); g = np.ravel(model.g_step(x, lab, ln, reuse_g_forward=True))
     out["d%%d" %% it] = [float(v) for v in d]; out["g%%d" %% it] = [float(v) for v in g]
+for i, Ti in enumerate(int(v) for v in os.environ.get("RSRGAN_TEST_TSEQ", "").split(",") if v):
+    # batches of other lengths on the same handle (the outer loop's buckets): the ring positions of the persistent launches carry on
+    # from wherever the previous launch stopped
+    xi, labi, lni = rand_batch(cfg, B, Ti, seed=20 + i, ragged=True)
+    d = np.ravel(model.d_step(xi, labi, lni)); g = np.ravel(model.g_step(xi, labi, lni, reuse_g_forward=True))
+    out["sd%%d" %% i] = [float(v) for v in d]; out["sg%%d" %% i] = [float(v) for v in g]
 model.engine.profile_begin()
 model.d_step(x, lab, ln); model.g_step(x, lab, ln, reuse_g_forward=True)
 model.engine.profile_read()
@@ -141,6 +147,29 @@ def test_persistent_generator_recurrence_agrees(B, T, mode):
     assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
     c = _run(dict(size, RSRGAN_GPERSIST=str(mode)))
     assert a["vars_sha"] == c["vars_sha"]          # fixed summation order: reproducible bits
+
+
+@pytest.mark.parametrize("net", ["lstm", "res_lstm_l"])
+def test_tagged_ring_slots_across_batches_of_different_lengths(net):
+    """Round 5: the hop-1 / input-gradient ring slots of k_glstm_fwd / k_glstm_bwd carry the parity of the ring pass in every word's
+    lowest mantissa bit (csrc/gpersist.hip gp_store_t) instead of being re-armed with sentinels; the ring position is a counter in the
+    control block that runs on from launch to launch (T steps forward, T - 1 / T backward).  One handle, batches of 9, 4, 7, 1, 2, 5,
+    9 frames in turn (every residue of the ring depths 3 and 6, a one-step launch that writes nothing to the state-gradient ring):
+    against the sentinel form (RSRGAN_GP_TAGS=0; the values differ by the 23rd mantissa bit of the partial sums) and against the
+    launch path, no failed wait, and the same bits when the whole sequence is run again in a fresh process."""
+    size = {"RSRGAN_TEST_B": "32", "RSRGAN_TEST_T": "9", "RSRGAN_TEST_TSEQ": "4,7,1,2,5,9,3,9", "RSRGAN_TEST_NET": net}
+    a = _run(dict(size))
+    b = _run(dict(size, RSRGAN_GP_TAGS="0"))
+    c = _run(dict(size, RSRGAN_GPERSIST="0"))
+    assert a["device_status"] == 0 and b["device_status"] == 0 and c["device_status"] == 0
+    assert c["chain_launches"] - a["chain_launches"] >= 2 * 8
+    keys = ["d0", "g0", "d1", "g1"] + ["s%s%d" % (n, i) for i in range(8) for n in "dg"]
+    for k in keys:
+        assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-7), (k, a[k], b[k])
+        assert np.allclose(a[k], c[k], rtol=5e-5, atol=1e-7), (k, a[k], c[k])
+    assert abs(a["g_norm"] - c["g_norm"]) <= 1e-5 * c["g_norm"]
+    d = _run(dict(size))
+    assert a["vars_sha"] == d["vars_sha"]
 
 
 @pytest.mark.parametrize("B,T", [(32, 9), (32, 50), (32, 1), (32, 2), (8, 7)])
