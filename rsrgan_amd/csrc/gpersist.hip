@@ -915,6 +915,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
   const char* const g2d = (const char*)a.gran2 + (size_t)ngr * a.nl * T * g2_per;
   const GpBuf b2d = gp_buf(g2d + (size_t)(grp * a.nl + l) * T * g2_per, (size_t)T * g2_per);
   const GpBuf b2du = gp_buf(g2d + (size_t)(grp * a.nl + (top ? l : l + 1)) * T * g2_per, (size_t)T * g2_per);
+  const GpBuf btop = gp_buf(a.dout_top, (size_t)T * N * a.ld_dout * sizeof(float));      // (dout_trail: the top layer's polled reads)
   // Layer 0's input gradient dz_0 . K_x^T (the input FC's d(h0): until round 4 a time-batched GEMM behind the launch, 126 us): its X
   // waves -- idle otherwise -- run the same product as every other layer's and publish it to a ring of their own (ring 0); the
   // layer's reducers, which spend most of a step waiting for the layers above, sum it one step late and write it to din0.
@@ -1254,7 +1255,23 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
     if (reducer) {
       float4 dtop = make_float4(0.f, 0.f, 0.f, 0.f);
       if (top && rcol < a.ld_dout) {
-        dtop = *reinterpret_cast<const float4*>(a.dout_top + ((size_t)t * N + rrow) * a.ld_dout + rcol);
+        if (a.dout_trail) {
+          // the discriminator's trailing BPTT (dpersist.hip k_dlstm_bwd_trail) is writing d(outputs) while this launch runs: this
+          // lane's piece of step t, past the caches, until none of its words carries the armed pattern (it is there as a rule: that
+          // launch runs three times as fast as this one)
+          const unsigned off = (unsigned)((((size_t)t * N + rrow) * a.ld_dout + rcol) * sizeof(float));
+          const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+          u32x4 y;
+          for (unsigned polls = 0;; ++polls) {
+            y = __builtin_amdgcn_raw_buffer_load_b128(btop.rs, off, 0, GP_SC1 | GP_VOL);
+            if (__all(gp_valid(y))) break;
+            asm volatile("" ::: "memory");
+            if ((polls & 63) == 63 && (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { fail(); return; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          dtop = make_float4(__uint_as_float(y[0]), __uint_as_float(y[1]), __uint_as_float(y[2]), __uint_as_float(y[3]));
+        } else
+          dtop = *reinterpret_cast<const float4*>(a.dout_top + ((size_t)t * N + rrow) * a.ld_dout + rcol);
         // (columns between P and ld_dout of a shared gradient buffer are whatever its last user left there: 0 x NaN would poison dh)
         dtop = make_float4(rcol < P ? dtop.x : 0.f, rcol + 1 < P ? dtop.y : 0.f, rcol + 2 < P ? dtop.z : 0.f, rcol + 3 < P ? dtop.w : 0.f);
       }

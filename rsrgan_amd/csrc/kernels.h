@@ -158,8 +158,19 @@ struct DPersistArgs {
   float forget_bias;
   const float* dout_top;                          // backward: [T][N][ld_dout] gradient of the top layer's masked outputs
   int ld_dout;
+  // the trailing form of the backward launch (k_dlstm_bwd_trail: the G-run, no weight gradients): layer 0's input gradient is added
+  // to dy [T][N][ld_dy] step by step, and d(generator outputs)(t) = dy(t) . fc_w^T (fc_w: the generator's output FC [fc_P][ld_fcw])
+  // lands in dtop [T][N][ld_dtop], armed with 0xFF bytes by the caller, where k_glstm_bwd's top layer polls it
+  float* dy;
+  const float* fc_w;
+  float* dtop;
+  int ld_dy, ld_fcw, ld_dtop, fc_P;
 };
 size_t dpersist_granule_bytes(int nl, int N, int T);
+int dpersist_trail_grid(int nl, int N);
+size_t dpersist_trail_lds_bytes();
+bool dpersist_trail_supported(const DPersistArgs& a);
+void launch_dlstm_bwd_trail(const DPersistArgs& a, hipStream_t s);
 bool dpersist_supported(const DPersistArgs& a);
 int dpersist_grid(int nl, int N);                 // workgroups of a launch over N rows
 size_t dpersist_lds_bytes();
@@ -197,6 +208,9 @@ struct GPersistArgs {
   // ring slots told apart by the parity of the ring pass in every word's lowest bit instead of sentinels that somebody has to put back
   // (gpersist.hip gp_store_t; the projected kernels only): no re-arming stores
   int tags;
+  // dout_top is being written WHILE this launch runs (dpersist.hip k_dlstm_bwd_trail, the G-run): armed with 0xFF bytes, the top
+  // layer's reducers poll their 16-byte piece of a step past the caches until no word carries that pattern
+  int dout_trail;
 };
 constexpr int GP_TMAX = 2046;                     // longest launch (slot offsets are 32-bit; a longer batch takes the launch-per-phase path)
 bool gpersist_plan(GPersistArgs& a);              // fills NT / NC; false: shape not supported

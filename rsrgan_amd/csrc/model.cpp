@@ -491,6 +491,14 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     }
   }
   {
+    // the trailing discriminator BPTT beside k_glstm_bwd (the G-run): both launches' workgroups resident at once -- ask the device
+    static const bool trail_env = [] { const char* e = getenv("RSRGAN_TRAIL"); return !e || atoi(e) != 0; }();
+    GPersistArgs ga{};
+    if (trail_env && dp_gran && (dp_env & 2) && gp_gran1 && gp_gran3 && !gp_noproj && (gp_env & 2) && B % 32 == 0 && gpersist_args(ga, gp_Tcap))
+      trail_fits = resident_probe(gpersist_grid(ga) + dpersist_trail_grid((int)dl.size(), B), GP_THREADS,
+                                  std::max(gpersist_lds_bytes(), dpersist_trail_lds_bytes()));
+  }
+  {
     static const bool lazy_env = [] { const char* e = getenv("RSRGAN_LAZY_SWIZZLE"); return !e || atoi(e) != 0; }();
     lazy_sw = lazy_env && wavefront() && gp_gran1 && gp_gran3 && (gp_env & 3) == 3 && dp_gran && (dp_env & 3) == 3;
   }
@@ -1019,6 +1027,7 @@ bool Model::gpersist_args(GPersistArgs& a, int T) const {
 void Model::persist_disable(int which) {
   if (which == 1) gp_env = 0; else dp_env = 0;
   lazy_sw = false;
+  trail_fits = false;
   drop_graphs();
   refresh_swizzles(RSRGAN_NET_G, nullptr);
   refresh_swizzles(RSRGAN_NET_D, nullptr);
@@ -1111,6 +1120,7 @@ bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only,
   static const bool din0_env = [] { const char* e = getenv("RSRGAN_GP_DIN0"); return e && atoi(e) != 0; }();
   const bool din_inside = ch[0].din && din0_env && (gl[0].I + 15) / 16 <= (gl[0].P + 15) / 16 && gl[0].ldI % 4 == 0;
   if (din_inside) { a.din0 = ch[0].din; a.ld_din0 = gl[0].ldI; }
+  a.dout_trail = gp_trail_next ? 1 : 0;
   if (prof_on) {
     if ((size_t)(2 * prof_gb_n + 2) > prof_gb_ev.size()) {
       const size_t old = prof_gb_ev.size();
@@ -1127,6 +1137,11 @@ bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only,
     ++prof_gb_n;
   } else
     launch_glstm_bwd(a, s);
+  if (gp_trail_next) {                                 // the discriminator's trailing launch on the side stream: dy is complete behind it
+    hipEvent_t ev = ev_pool[ev_next++ & 15];
+    (void)hipEventRecord(ev, side);
+    (void)hipStreamWaitEvent(s, ev, 0);
+  }
   auto din0 = [&](hipStream_t q) {
     if (ch[0].din && !din_inside) {
       const LayerRun& R = ch[0];
@@ -1167,6 +1182,31 @@ bool Model::persist_backward(Chain& ch, int T, hipStream_t s) {
         if (!rest) layer_wgrads_colsums(R, T, s, (side && s == side) ? scratch2 : scratch);
       }
   }
+  return true;
+}
+
+bool Model::persist_backward_trail(Chain& ch, int T, hipStream_t s, float* dy, int ld_dy, float* dtop, int ld_dtop, bool check_only) {
+  if (!trail_fits || !side || !dp_gran || !(dp_env & 2) || !wavefront() || ch.size() != dl.size() || ch[0].din) return false;
+  DPersistArgs a{};
+  a.nl = (int)ch.size(); a.N = ch[0].N; a.T = T; a.H = dl[0].H; a.len = ch[0].len;
+  a.gran = dp_gran; a.ctl = dp_ctl; a.forget_bias = cfg.forget_bias;
+  for (size_t l = 0; l < ch.size(); ++l) {
+    const LayerRun& R = ch[l]; const LstmLayer& L = dl[l]; const LstmStash& S = d_st[l];
+    if (R.L != &L || R.S != &S || R.res_in || R.res_out || R.row0 != 0 || R.Ns != R.N || R.N != a.N || !L.has_proj || L.H != a.H || R.want_wgrads) return false;
+    if (l > 0 && R.in != d_st[l - 1].out) return false;
+    DPersistLayer& D_ = a.L[l];
+    D_.K = D.W(L.tK); D_.bias = D.W(L.tb); D_.wi = D.W(L.twi); D_.wf = D.W(L.twf); D_.wo = D.W(L.two); D_.Wp = D.W(L.tWp);
+    D_.gates = S.gates; D_.c = S.c; D_.h = S.h; D_.mst = S.mst; D_.out = S.out; D_.dmt = S.dmt;
+    D_.I = L.I; D_.P = L.P; D_.ldP = L.ldP; D_.ldH = L.ldH; D_.ldI = L.ldI;
+  }
+  a.dout_top = ch.back().dout; a.ld_dout = dl.back().ldP;
+  a.dy = dy; a.ld_dy = ld_dy; a.fc_w = G.W(g_fc_out_w); a.ld_fcw = ldDout; a.fc_P = gR; a.dtop = dtop; a.ld_dtop = ld_dtop;
+  if (!a.dout_top || a.N != B || dl[0].I != Dout || !dpersist_trail_supported(a) || dpersist_granule_bytes(a.nl, a.N, a.T) > dp_gran_bytes) return false;
+  if (check_only) return true;
+  hipEvent_t ev = ev_pool[ev_next++ & 15];
+  (void)hipEventRecord(ev, s);
+  (void)hipStreamWaitEvent(side, ev, 0);
+  launch_dlstm_bwd_trail(a, side);
   return true;
 }
 
@@ -1792,7 +1832,17 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     launch_g_total(losses + 3, dyn + DYN_LAMBDA, s);
   };
 
-  run_seg(seg_key(SEG_G_MAIN, T, kbits), s, [&]() {
+  // the discriminator's BPTT in its trailing form beside the generator's (persist_backward_trail): decided here, on the host
+  bool trail_plan = false;
+  if (wave_bwd && want_grads && !d_dnn() && dl[0].ldI == ldDout && persist_backward_g(bw_chains[1], T, s, true)) {
+    Chain dc0 = bw_chains[0];
+    dc0[0].din = nullptr;
+    trail_plan = persist_backward_trail(dc0, T, s, dy, ldDout, g_dA, ldP, true);
+  }
+  run_seg(seg_key(SEG_G_MAIN, T, kbits | (trail_plan ? 64u : 0u)), s, [&]() {
+  // (trailing form) the top layer's gradient buffer armed with the all-ones pattern HERE, at the head of the run: k_glstm_bwd polls it,
+  // and a fill in front of the fork would be the node both launches depend on (a fill node as the fork point serialized them)
+  if (trail_plan) (void)hipMemsetAsync(g_dA, 0xFF, (size_t)T * B * ldP * sizeof(float), s);
   bool g_done = false;
   if (!reuse && !wavefront()) g_forward(T, s);
   if (!reuse && wavefront() && gp_fwd_on()) {
@@ -1852,10 +1902,16 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
       // layer 0's input gradient as a GEMM on top of the mse term in dy), then the output FC's data gradient as one GEMM
       std::vector<Chain> dc1(1, bw_chains[0]);
       dc1[0][0].din = nullptr;
-      if (!persist_backward(dc1[0], T, s)) rnn_backward(dc1, T, s);
-      const int H4d = 4 * dl[0].H;
-      gemm(d_st[0].gates, H4d, true, D.W(dl[0].tK), H4d, true, dy, ldDout, R, dl[0].I, H4d, nullptr, 0, 0.f, true, s);
-      gemm(dy, ldDout, true, G.W(g_fc_out_w), ldDout, true, g_dA, ldP, R, P, Dout, nullptr, 0, 0.f, false, s);
+      // round 5: the discriminator's BPTT in its trailing form on the side stream, BESIDE the generator's (which polls its top
+      // layer's gradient step by step): dy and g_dA are completed inside that launch
+      const bool trailed = trail_plan && persist_backward_trail(dc1[0], T, s, dy, ldDout, g_dA, ldP);
+      if (!trailed) {
+        if (!persist_backward(dc1[0], T, s)) rnn_backward(dc1, T, s);
+        const int H4d = 4 * dl[0].H;
+        gemm(d_st[0].gates, H4d, true, D.W(dl[0].tK), H4d, true, dy, ldDout, R, dl[0].I, H4d, nullptr, 0, 0.f, true, s);
+        gemm(dy, ldDout, true, G.W(g_fc_out_w), ldDout, true, g_dA, ldP, R, P, Dout, nullptr, 0, 0.f, false, s);
+      }
+      gp_trail_next = trailed;
       // (fcs_inside: the output FC's parameter gradients need dy, complete here; the input FC's the d(h0) GEMM)
       StreamFn pre, post;
       if (fcs_inside) {
@@ -1870,6 +1926,7 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
         };
       }
       persist_backward_g(bw_chains[1], T, s, false, pre, post);
+      gp_trail_next = false;
     } else {
       rnn_backward(bw_chains, T, s, &offs, &fcs);
     }

@@ -149,6 +149,24 @@ def test_persistent_generator_recurrence_agrees(B, T, mode):
     assert a["vars_sha"] == c["vars_sha"]          # fixed summation order: reproducible bits
 
 
+@pytest.mark.parametrize("B,T,net", [(32, 9, "lstm"), (64, 100, "lstm"), (32, 1, "lstm"), (32, 2, "lstm"), (32, 9, "res_lstm_l"), (8, 7, "res_lstm_l")])
+def test_trailing_discriminator_bptt_agrees(B, T, net):
+    """Round 5: in the G-run (gan_rnn_placeholder.py:246-256: g_adv differentiated through D into G) the discriminator's BPTT runs in
+    its trailing form (csrc/dpersist.hip k_dlstm_bwd_trail: two row tiles per workgroup, FC workgroups that turn layer 0's input
+    gradient into dy(t) and d(outputs)(t) = dy(t) . W_out^T step by step) BESIDE the generator's BPTT, whose top layer polls that
+    gradient -- against the two launches one after the other with the two GEMMs between them (RSRGAN_TRAIL=0).  Same products, the
+    input gradient summed per cell quarter instead of per k-block of a GEMM: fp32 rounding apart; reproducible; no failed wait."""
+    size = {"RSRGAN_TEST_B": str(B), "RSRGAN_TEST_T": str(T), "RSRGAN_TEST_NET": net, "RSRGAN_PAD_ROWS": "1"}
+    a = _run(dict(size))
+    b = _run(dict(size, RSRGAN_TRAIL="0"))
+    assert a["device_status"] == 0 and b["device_status"] == 0
+    for k in ("d0", "g0", "d1", "g1"):
+        assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-7), (k, a[k], b[k])
+    assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
+    c = _run(dict(size))
+    assert a["vars_sha"] == c["vars_sha"]
+
+
 @pytest.mark.parametrize("net", ["lstm", "res_lstm_l"])
 def test_tagged_ring_slots_across_batches_of_different_lengths(net):
     """Round 5: the hop-1 / input-gradient ring slots of k_glstm_fwd / k_glstm_bwd carry the parity of the ring pass in every word's
