@@ -17,14 +17,7 @@
 
 namespace rsr {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) unsigned long long gu64;
-typedef __attribute__((address_space(1))) unsigned gu32;
-
-constexpr int DP_NQ = 4;            // cell quarters per row tile (H = 64 * DP_NQ)
-constexpr int DP_KB = 3;            // k-blocks of 16 of the recurrent / input width (P <= 48)
-constexpr int DP_SLOT = DP_KB * 64 * 4;     // granules per (layer, tile, step, quarter): the consumer's A-fragment order [kb][lane][u]
-constexpr int DP_HS = 72;           // LDS row stride of the h tile (floats): 18 float4, == 2 mod 16 (conflict-free fragment reads)
+#include "dpersist_dev.h"
 
 // tools/ubench/dpersist_trace.hip compiles this file with DP_TRACE: thread 0 of every workgroup stamps the 100 MHz counter at the
 // phase boundaries of every step; the product build has no such code
@@ -41,97 +34,6 @@ __device__ unsigned g_dp_trace[64][128][12];
 #define DPT_DECL
 #define DPT_FLUSH() do { } while (0)
 #endif
-
-__device__ __forceinline__ float4 dp_sel(bool c, const float4 a, const float4 b) {      // componentwise: a float4 ?: becomes a pointer select + scratch
-  return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
-}
-// Cell non-linearities on the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each): the cell phase of a workgroup is
-// 1024 elements x 5 transcendentals on ONE wave per SIMD, and libm's expf / tanhf / IEEE division made it 1.4 us of a step
-// (profiles/r3_dpersist_trace.txt).  |error| <= ~2e-7 absolute: tanh switches to its odd series below 0.1 where 1 - 2/(1+e^2x) cancels.
-__device__ __forceinline__ float dp_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
-__device__ __forceinline__ float dp_tanh(float x) {
-  const float x2 = x * x;
-  const float ser = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f - 0.05396825f * x2)));
-  const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008f * x));
-  return fabsf(x) < 0.1f ? ser : big;
-}
-
-// 16-byte write-through accesses carrying two granules each (8-byte scalar sc1 stores are one fabric write per lane: 2.7x the time
-// per byte, MI355X_MICROARCH.md "stores of each flavour"; the 8-byte halves of a 16-byte sc1 access are observed untorn).  Inline
-// asm: the compiler has no 16-byte agent-scope atomic.  (Its vmcnt bookkeeping does not see these: the loads wait inside the asm,
-// and an untracked store only makes a later compiler-placed wait stricter, vmcnt retiring in order.)
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void dp_store2(gu64* p, unsigned tag, float v0, float v1) {
-  const u32x4 x = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
-  // (s_nop: a store of more than 8 bytes followed by a write of its data registers needs a wait state; the compiler inserts it
-  // for its own stores, not behind an asm statement)
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
-}
-// the 12 granules of this lane in one slot: 6 loads in flight, one wait
-__device__ __forceinline__ void dp_load12(const gu64* g, int lane, u32x4 (&x)[6]) {
-  const gu64* p0 = g + (size_t)lane * 4;
-  asm volatile(
-      "global_load_dwordx4 %0, %6, off sc1\n\t"
-      "global_load_dwordx4 %1, %6, off offset:16 sc1\n\t"
-      "global_load_dwordx4 %2, %6, off offset:2048 sc1\n\t"
-      "global_load_dwordx4 %3, %6, off offset:2064 sc1\n\t"
-      "global_load_dwordx4 %4, %7, off sc1\n\t"
-      "global_load_dwordx4 %5, %7, off offset:16 sc1\n\t"
-      "s_waitcnt vmcnt(0)"
-      : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5])
-      : "v"(p0), "v"(p0 + 512)
-      : "memory");
-}
-// two slots in one round trip
-__device__ __forceinline__ void dp_load24(const gu64* g0, const gu64* g1, int lane, u32x4 (&x)[6], u32x4 (&y)[6]) {
-  const gu64* p0 = g0 + (size_t)lane * 4;
-  const gu64* p1 = g1 + (size_t)lane * 4;
-  asm volatile(
-      "global_load_dwordx4 %0, %12, off sc1\n\t"
-      "global_load_dwordx4 %1, %12, off offset:16 sc1\n\t"
-      "global_load_dwordx4 %2, %12, off offset:2048 sc1\n\t"
-      "global_load_dwordx4 %3, %12, off offset:2064 sc1\n\t"
-      "global_load_dwordx4 %4, %13, off sc1\n\t"
-      "global_load_dwordx4 %5, %13, off offset:16 sc1\n\t"
-      "global_load_dwordx4 %6, %14, off sc1\n\t"
-      "global_load_dwordx4 %7, %14, off offset:16 sc1\n\t"
-      "global_load_dwordx4 %8, %14, off offset:2048 sc1\n\t"
-      "global_load_dwordx4 %9, %14, off offset:2064 sc1\n\t"
-      "global_load_dwordx4 %10, %15, off sc1\n\t"
-      "global_load_dwordx4 %11, %15, off offset:16 sc1\n\t"
-      "s_waitcnt vmcnt(0)"
-      : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]),
-        "=&v"(y[4]), "=&v"(y[5])
-      : "v"(p0), "v"(p0 + 512), "v"(p1), "v"(p1 + 512)
-      : "memory");
-}
-__device__ __forceinline__ bool dp_take(const u32x4 (&x)[6], unsigned tag, float (&v)[DP_KB * 4]) {
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    v[2 * k] = __uint_as_float(x[k].x); v[2 * k + 1] = __uint_as_float(x[k].z);
-    ok &= x[k].y == tag && x[k].w == tag;
-  }
-  return __all(ok);
-}
-// One wave re-reads granules until all carry their tag: 12 of slot `gm_` (tag tm; skipped when null) and 12 of slot `gx_` (tag tx;
-// skipped when null).  false on time-out (or when another workgroup has failed).
-__device__ __forceinline__ bool dp_sweep2(const gu64* gm_, unsigned tm, float (&vm)[DP_KB * 4], const gu64* gx_, unsigned tx, float (&vx)[DP_KB * 4],
-                                          int lane, gu32* err) {
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  bool dm = gm_ == nullptr, dx = gx_ == nullptr;                   // (wave-uniform)
-  for (unsigned spins = 0;; ++spins) {
-    u32x4 x[6], y[6];
-    if (!dm && !dx) { dp_load24(gm_, gx_, lane, x, y); dm = dp_take(x, tm, vm); dx = dp_take(y, tx, vx); }
-    else if (!dm) { dp_load12(gm_, lane, x); dm = dp_take(x, tm, vm); }
-    else if (!dx) { dp_load12(gx_, lane, x); dx = dp_take(x, tx, vx); }
-    if (dm && dx) return true;
-    if ((spins & 63) == 63) {
-      if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull ||                     // 1 s at 100 MHz (a peer that is merely not scheduled yet must not fail the launch)
-          __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-    }
-  }
-}
 
 // 8 waves: 0-3 compute (wave w: all four gates of cells [16w, 16w+16) of the quarter; waves 0-2 also one 16-column tile of the
 // partial projection), 4-7 gather (wave 4+j polls quarter j's granules and hands them over through LDS).  The gather waves issue
@@ -773,370 +675,6 @@ __global__ __launch_bounds__(512, 1) void k_dlstm_bwd(const DPersistArgs a) {
 }
 
 
-// ------------------------------------------------------------------------------------------------------------------------
-// The TRAILING form of the backward launch (round 5; the G-run: gan_rnn_placeholder.py:246-256 differentiates g_adv through the
-// discriminator INTO the generator).  The generator's BPTT (gpersist.hip k_glstm_bwd) consumes d(outputs)(t) = dy(t) . W_out^T in the
-// same descending time order in which the discriminator's BPTT produces d g_adv / d y(t): launched one after the other the second
-// waits 0.38 ms for the first although it could start a few steps behind it.  Every workgroup of both launches must be resident at
-// once, and k_glstm_bwd holds 228 of the 256 CUs: this form runs the discriminator's BPTT on HALF the workgroups -- a workgroup
-// (layer, PAIR of 16-row tiles, cell quarter) keeps one copy of its weights and takes its two tiles in turn within a step (the
-// hand-off of one tile travels while the other computes), 16 workgroups for 64 rows -- plus one FC workgroup per row tile that turns
-// layer 0's input-gradient partials into the generator's top-layer gradient, step by step:
-//     dy(t) = [lambda-weighted mse term, written by k_mse1 before the launch] + sum of the four quarters' dx0 partials   (-> memory:
-//             the output FC's parameter gradients read it afterwards)
-//     d(outputs)(t) = dy(t) . W_out^T  (16 x Dout . Dout x P: 12 MFMAs per 16-column tile)  -> dtop, write-through
-// dtop is armed with the all-ones pattern in front of the launch; the reducers of k_glstm_bwd's top layer poll their own 16-byte
-// piece of step t (GPersistArgs::dout_trail).  No weight gradients here (the G-run takes none of the discriminator): no dz stash,
-// no dmt.  16 + 4 + 228 = 248 workgroups.
-// ------------------------------------------------------------------------------------------------------------------------
-constexpr int DP_TPW = 2;           // 16-row tiles per workgroup of the trailing form
-struct DpTrailLds {
-  float part_m[DP_TPW][DP_NQ][DP_KB][64][4];      // swept partials of dm_state (from step t+1), per tile
-  float part_x[DP_TPW][2][DP_NQ][DP_KB][64][4];   // ... of dout (dx of the layer above), per tile, by parity of the step
-  float psum[4][DP_KB][64][4];                    // the compute waves' partial dm_state tiles (one tile at a time)
-  float psum_x[DP_TPW][4][DP_KB][64][4];          // ... partial dx tiles (written behind barrier B(t), published behind A(t-1))
-  float kx_lds[4][DP_KB][4][64][4];               // K_x fragments (A operand of the dx product)
-  int dead;
-};
-
-__device__ __forceinline__ void dp_bwdt_body(const DPersistArgs& a, const unsigned gen, DpTrailLds& S, const int bid) {
-  const int RPn = a.N >> 5, RTn = a.N >> 4, ncl = a.nl * RPn;       // tile pairs
-  const int cl = bid % ncl, cq = bid / ncl;
-  const int l = cl / RPn, rp = cl - l * RPn;
-  const DPersistLayer L = a.L[l];
-  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int H = a.H, H4 = 4 * H, T = a.T, N = a.N, P = L.P, ldP = L.ldP, I = L.I;
-  const bool top = l == a.nl - 1;
-  gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
-  const size_t slot_stride_t = (size_t)DP_NQ * DP_SLOT;
-  auto edge = [&](int layer, int e, int r) -> gu64* {
-    return (gu64*)a.gran + ((size_t)((layer * 2 + e) * RTn + r) * T) * slot_stride_t;
-  };
-
-  if (w >= 4) {
-    // ---------------- gather waves ----------------
-    __builtin_amdgcn_s_setprio(3);
-    const int j = w - 4;
-    float vm[DP_KB * 4], vx[DP_KB * 4];
-    auto put = [&](float (*part)[DP_KB][64][4], const float (&v)[DP_KB * 4]) {
-#pragma unroll
-      for (int kb = 0; kb < DP_KB; ++kb)
-        *reinterpret_cast<float4*>(&part[j][kb][lane][0]) = make_float4(v[kb * 4], v[kb * 4 + 1], v[kb * 4 + 2], v[kb * 4 + 3]);
-    };
-    auto fail = [&]() { if (lane == 0) { S.dead = 1; __hip_atomic_store(err, 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } };
-    auto publish = [&](float (*ps)[DP_KB][64][4], gu64* dst) {
-      const float4 p0 = *reinterpret_cast<const float4*>(&ps[0][j][lane][0]), p1 = *reinterpret_cast<const float4*>(&ps[1][j][lane][0]);
-      const float4 p2 = *reinterpret_cast<const float4*>(&ps[2][j][lane][0]), p3 = *reinterpret_cast<const float4*>(&ps[3][j][lane][0]);
-      gu64* go_ = dst + ((size_t)j * 64 + lane) * 4;
-      dp_store2(go_, gen, ((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y);
-      dp_store2(go_ + 2, gen, ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
-    };
-    if (!top) {                                                    // dout of step T-1 for the prologue
-#pragma unroll
-      for (int i = 0; i < DP_TPW; ++i) {
-        const gu64* gx = edge(l + 1, 1, 2 * rp + i) + (size_t)j * DP_SLOT;
-        if (!dp_sweep2(nullptr, gen, vm, gx + (size_t)(T - 1) * slot_stride_t, gen, vx, lane, err)) fail();
-        put(S.part_x[i][(T - 1) & 1], vx);
-      }
-    }
-    __syncthreads();                                               // P
-    if (S.dead) return;
-    for (int t = T - 1; t >= 0; --t) {
-#pragma unroll
-      for (int i = 0; i < DP_TPW; ++i) {
-        const int r = 2 * rp + i;
-        const gu64* gm = edge(l, 0, r) + (size_t)j * DP_SLOT;
-        const gu64* gx = edge(min(l + 1, a.nl - 1), 1, r) + (size_t)j * DP_SLOT;
-        gu64* gout_m = edge(l, 0, r) + (size_t)cq * DP_SLOT;
-        gu64* gout_x = edge(l, 1, r) + (size_t)cq * DP_SLOT;
-        const bool wm = t < T - 1, wx = !top && t > 0;
-        if (wm || wx) {
-          if (!dp_sweep2(wm ? gm + (size_t)(t + 1) * slot_stride_t : nullptr, gen, vm,
-                         wx ? gx + (size_t)(t - 1) * slot_stride_t : nullptr, gen, vx, lane, err)) fail();
-          if (wm) put(S.part_m[i], vm);
-          if (wx) put(S.part_x[i][(t - 1) & 1], vx);
-        }
-        __syncthreads();                                           // A(t, i)
-        if (S.dead) return;
-        if (j < 3 && t < T - 1) publish(S.psum_x[i], gout_x + (size_t)(t + 1) * slot_stride_t);      // dx of step t+1 (in LDS since B(t+1, i))
-        __syncthreads();                                           // B(t, i): psum(t, i) is in LDS
-        if (j < 3) publish(S.psum, gout_m + (size_t)t * slot_stride_t);
-      }
-    }
-    __syncthreads();                                               // C: dx of step 0 is in LDS
-    if (j < 3) {
-#pragma unroll
-      for (int i = 0; i < DP_TPW; ++i) publish(S.psum_x[i], edge(l, 1, 2 * rp + i) + (size_t)cq * DP_SLOT);
-    }
-    return;
-  }
-
-  // ---------------- compute waves ----------------
-  const int cb = cq * 64 + 16 * w + 4 * q;                          // this lane's four cells
-  float4 wpA[DP_KB], khA[DP_KB][4];
-  {
-    const float* wrow = L.Wp + (size_t)(cq * 64 + 16 * w + lr) * ldP;
-#pragma unroll
-    for (int kb = 0; kb < DP_KB; ++kb) {
-      const int k = 16 * kb + 4 * q;
-      const float4 v = *reinterpret_cast<const float4*>(wrow + min(k, P - 4));
-      wpA[kb] = dp_sel(k < P, v, make_float4(0.f, 0.f, 0.f, 0.f));
-    }
-#pragma unroll
-    for (int pt = 0; pt < DP_KB; ++pt) {
-      const int p = 16 * pt + lr;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 vh = *reinterpret_cast<const float4*>(L.K + (size_t)(I + min(p, P - 1)) * H4 + g * H + cb);
-        const float4 vx = *reinterpret_cast<const float4*>(L.K + (size_t)min(p, I - 1) * H4 + g * H + cb);
-        khA[pt][g] = dp_sel(p < P, vh, make_float4(0.f, 0.f, 0.f, 0.f));
-        *reinterpret_cast<float4*>(&S.kx_lds[w][pt][g][lane][0]) = dp_sel(p < I, vx, make_float4(0.f, 0.f, 0.f, 0.f));      // (layer 0 too: its dx feeds the FC workgroups)
-      }
-    }
-  }
-  const float4 pwi = *reinterpret_cast<const float4*>(L.wi + cb), pwf = *reinterpret_cast<const float4*>(L.wf + cb);
-  const float4 pwo = *reinterpret_cast<const float4*>(L.wo + cb);
-  const float pi_[4] = {pwi.x, pwi.y, pwi.z, pwi.w}, pf_[4] = {pwf.x, pwf.y, pwf.z, pwf.w}, po_[4] = {pwo.x, pwo.y, pwo.z, pwo.w};
-  int lenF[DP_TPW];
-  float dc[DP_TPW][4];
-  float4 mf[DP_TPW][DP_KB];
-  f32x4 ccur[DP_TPW];
-  // operands of the NEXT (step, tile), requested while this one computes -- one set: a set per tile spilled 62 registers
-  f32x4 gn[4], cpn;
-  float4 don[DP_KB];
-  auto prefetch = [&](int i, int t) {
-    const size_t row = (size_t)t * N + 32 * rp + 16 * i + lr;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) gn[g] = *reinterpret_cast<const f32x4*>(L.gates + row * H4 + g * H + cb);
-    cpn = *reinterpret_cast<const f32x4*>(L.c + row * H + cb);
-    if (top) {
-#pragma unroll
-      for (int kb = 0; kb < DP_KB; ++kb)
-        don[kb] = *reinterpret_cast<const float4*>(a.dout_top + row * a.ld_dout + min(16 * kb + 4 * q, P - 4));
-    }
-  };
-  auto sum_parts = [&](float (*part)[DP_KB][64][4], int width, float4 (&s)[DP_KB]) {
-#pragma unroll
-    for (int kb = 0; kb < DP_KB; ++kb) {
-      const float4 p0 = *reinterpret_cast<const float4*>(&part[0][kb][lane][0]), p1 = *reinterpret_cast<const float4*>(&part[1][kb][lane][0]);
-      const float4 p2 = *reinterpret_cast<const float4*>(&part[2][kb][lane][0]), p3 = *reinterpret_cast<const float4*>(&part[3][kb][lane][0]);
-      s[kb] = dp_sel(16 * kb + 4 * q < width,
-                     make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
-                                 ((p0.w + p1.w) + p2.w) + p3.w), make_float4(0.f, 0.f, 0.f, 0.f));
-    }
-  };
-#pragma unroll
-  for (int i = 0; i < DP_TPW; ++i) {
-    const int row = 32 * rp + 16 * i + lr;
-    lenF[i] = a.len[row];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) dc[i][u] = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < DP_KB; ++kb) mf[i][kb] = make_float4(0.f, 0.f, 0.f, 0.f);
-    ccur[i] = *reinterpret_cast<const f32x4*>(L.c + ((size_t)T * N + row) * H + cb);      // c_T
-  }
-  prefetch(0, T - 1);
-  __syncthreads();                                                 // P
-  if (S.dead) return;
-
-  for (int t = T - 1; t >= 0; --t) {
-#pragma unroll
-    for (int i = 0; i < DP_TPW; ++i) {
-      __syncthreads();                                             // A(t, i)
-      if (S.dead) return;
-      const bool live = t < lenF[i];
-      f32x4 gt[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) gt[g] = gn[g];
-      const f32x4 cprev = cpn;
-      float4 dout[DP_KB];
-      if (top) {
-#pragma unroll
-        for (int kb = 0; kb < DP_KB; ++kb) dout[kb] = dp_sel(16 * kb + 4 * q < P, don[kb], make_float4(0.f, 0.f, 0.f, 0.f));
-      } else {
-        sum_parts(S.part_x[i][t & 1], P, dout);
-      }
-      if (i + 1 < DP_TPW) prefetch(i + 1, t); else prefetch(0, max(t - 1, 0));
-      if (t < T - 1) {
-        float4 ms[DP_KB];
-        sum_parts(S.part_m[i], P, ms);
-        const bool live_next = (t + 1) < lenF[i];                   // masked rows pass the carried gradient through
-#pragma unroll
-        for (int kb = 0; kb < DP_KB; ++kb) mf[i][kb] = dp_sel(live_next, ms[kb], mf[i][kb]);
-      }
-      float4 dm[DP_KB];
-#pragma unroll
-      for (int kb = 0; kb < DP_KB; ++kb)
-        dm[kb] = dp_sel(live, make_float4(dout[kb].x + mf[i][kb].x, dout[kb].y + mf[i][kb].y, dout[kb].z + mf[i][kb].z, dout[kb].w + mf[i][kb].w),
-                        make_float4(0.f, 0.f, 0.f, 0.f));
-      f32x4 dh = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kb = 0; kb < DP_KB; ++kb) {
-        dh = __builtin_amdgcn_mfma_f32_16x16x4f32(wpA[kb].x, dm[kb].x, dh, 0, 0, 0);
-        dh = __builtin_amdgcn_mfma_f32_16x16x4f32(wpA[kb].y, dm[kb].y, dh, 0, 0, 0);
-        dh = __builtin_amdgcn_mfma_f32_16x16x4f32(wpA[kb].z, dm[kb].z, dh, 0, 0, 0);
-        dh = __builtin_amdgcn_mfma_f32_16x16x4f32(wpA[kb].w, dm[kb].w, dh, 0, 0, 0);
-      }
-      // gate / cell gradients (kernels.hip k_bwd_a2): lane = row lr, cells cb + u
-      float dz[4][4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float gi = gt[0][u], gj = gt[1][u], gf = gt[2][u], go = gt[3][u];
-        const float tc = dp_tanh(ccur[i][u]);
-        const float dao = dh[u] * tc * go * (1.f - go);
-        const float dcn = dc[i][u] + dh[u] * go * (1.f - tc * tc) + dao * po_[u];
-        const float daf = dcn * cprev[u] * gf * (1.f - gf);
-        const float dai = dcn * gj * gi * (1.f - gi);
-        const float dj = dcn * gi * (1.f - gj * gj);
-        dz[0][u] = live ? dai : 0.f; dz[1][u] = live ? dj : 0.f; dz[2][u] = live ? daf : 0.f; dz[3][u] = live ? dao : 0.f;
-        dc[i][u] = live ? dcn * gf + dai * pi_[u] + daf * pf_[u] : dc[i][u];
-      }
-      ccur[i] = cprev;
-      f32x4 pa[DP_KB];
-#pragma unroll
-      for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-#pragma unroll
-        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(khA[pt][g].x, dz[g][0], pa[pt], 0, 0, 0);
-#pragma unroll
-        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(khA[pt][g].y, dz[g][1], pa[pt], 0, 0, 0);
-#pragma unroll
-        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(khA[pt][g].z, dz[g][2], pa[pt], 0, 0, 0);
-#pragma unroll
-        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(khA[pt][g].w, dz[g][3], pa[pt], 0, 0, 0);
-      }
-#pragma unroll
-      for (int pt = 0; pt < DP_KB; ++pt) *reinterpret_cast<f32x4*>(&S.psum[w][pt][lane][0]) = pa[pt];
-      __syncthreads();                                             // B(t, i)
-      // dx partial^T of this step and tile (every layer: layer 0's goes to the FC workgroups), published behind A(t-1, i)
-      __builtin_amdgcn_s_sleep(8);                                 // (first let the gather waves publish, see dp_bwd_body)
-#pragma unroll
-      for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4 af[DP_KB];
-#pragma unroll
-        for (int pt = 0; pt < DP_KB; ++pt) af[pt] = *reinterpret_cast<const float4*>(&S.kx_lds[w][pt][g][lane][0]);
-#pragma unroll
-        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt].x, dz[g][0], pa[pt], 0, 0, 0);
-#pragma unroll
-        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt].y, dz[g][1], pa[pt], 0, 0, 0);
-#pragma unroll
-        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt].z, dz[g][2], pa[pt], 0, 0, 0);
-#pragma unroll
-        for (int pt = 0; pt < DP_KB; ++pt) pa[pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[pt].w, dz[g][3], pa[pt], 0, 0, 0);
-      }
-#pragma unroll
-      for (int pt = 0; pt < DP_KB; ++pt) *reinterpret_cast<f32x4*>(&S.psum_x[i][w][pt][lane][0]) = pa[pt];
-    }
-  }
-  __syncthreads();                                                 // C
-}
-
-// The FC workgroup of row tile fr (see above): per step, the four gather waves take a quarter's dx0 partials each; then every wave
-// forms dy(t) of the tile and the 16-column tiles w, w + 8, w + 16 of dy(t) . W_out^T.
-constexpr int DP_FCT = 3;           // 16-column tiles of d(outputs) per wave: P_fc <= 16 * 8 * DP_FCT
-__device__ __forceinline__ void dp_fcb_body(const DPersistArgs& a, const unsigned gen, DpTrailLds& S, const int fr) {
-  const int RTn = a.N >> 4;
-  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int T = a.T, N = a.N, I = a.L[0].I, Pf = a.fc_P, ldt = a.ld_dtop;
-  gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
-  const size_t slot_stride_t = (size_t)DP_NQ * DP_SLOT;
-  const gu64* gx = (const gu64*)a.gran + ((size_t)((0 * 2 + 1) * RTn + fr) * T) * slot_stride_t + (size_t)(w & 3) * DP_SLOT;
-  float (*part)[DP_KB][64][4] = S.part_m[0];
-  // A operand: W_out[c = 16 ct + lr][p = 16 kb + 4 q + u] (zero beyond P_fc rows / I columns)
-  float4 wA[DP_FCT][DP_KB];
-#pragma unroll
-  for (int n = 0; n < DP_FCT; ++n)
-#pragma unroll
-    for (int kb = 0; kb < DP_KB; ++kb) {
-      const int c = 16 * (w + 8 * n) + lr, p = 16 * kb + 4 * q;
-      const float4 v = *reinterpret_cast<const float4*>(a.fc_w + (size_t)min(c, Pf - 1) * a.ld_fcw + min(p, I - 4));
-      wA[n][kb] = dp_sel(c < Pf && p < I, v, make_float4(0.f, 0.f, 0.f, 0.f));
-    }
-  const int row = 16 * fr + lr;
-  float4 dyn[DP_KB];
-  auto load_dy = [&](int t) {
-    const float* p_ = a.dy + ((size_t)t * N + row) * a.ld_dy;
-#pragma unroll
-    for (int kb = 0; kb < DP_KB; ++kb) dyn[kb] = *reinterpret_cast<const float4*>(p_ + min(16 * kb + 4 * q, I - 4));
-  };
-  load_dy(T - 1);
-  __syncthreads();                                                 // (dead = 0 is visible)
-  for (int t = T - 1; t >= 0; --t) {
-    if (w >= 4) {
-      float vm[DP_KB * 4], vx[DP_KB * 4];
-      if (!dp_sweep2(nullptr, gen, vm, gx + (size_t)t * slot_stride_t, gen, vx, lane, err)) {
-        if (lane == 0) { S.dead = 1; __hip_atomic_store(err, 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-      }
-#pragma unroll
-      for (int kb = 0; kb < DP_KB; ++kb)
-        *reinterpret_cast<float4*>(&part[w - 4][kb][lane][0]) = make_float4(vx[kb * 4], vx[kb * 4 + 1], vx[kb * 4 + 2], vx[kb * 4 + 3]);
-    }
-    __syncthreads();                                               // A: the four quarters' partials of step t are in LDS
-    if (S.dead) return;
-    float4 dyv[DP_KB];
-#pragma unroll
-    for (int kb = 0; kb < DP_KB; ++kb) {
-      const float4 p0 = *reinterpret_cast<const float4*>(&part[0][kb][lane][0]), p1 = *reinterpret_cast<const float4*>(&part[1][kb][lane][0]);
-      const float4 p2 = *reinterpret_cast<const float4*>(&part[2][kb][lane][0]), p3 = *reinterpret_cast<const float4*>(&part[3][kb][lane][0]);
-      const float4 dx = make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z, ((p0.w + p1.w) + p2.w) + p3.w);
-      dyv[kb] = dp_sel(16 * kb + 4 * q < I, make_float4(dyn[kb].x + dx.x, dyn[kb].y + dx.y, dyn[kb].z + dx.z, dyn[kb].w + dx.w), make_float4(0.f, 0.f, 0.f, 0.f));
-    }
-    if (w == 0) {
-      float* p_ = a.dy + ((size_t)t * N + row) * a.ld_dy;
-#pragma unroll
-      for (int kb = 0; kb < DP_KB; ++kb)
-        if (16 * kb + 4 * q < I) *reinterpret_cast<float4*>(p_ + 16 * kb + 4 * q) = dyv[kb];
-    }
-    load_dy(max(t - 1, 0));
-#pragma unroll
-    for (int n = 0; n < DP_FCT; ++n) {
-      const int c0 = 16 * (w + 8 * n) + 4 * q;                      // this lane's four columns of row `row`
-      if (16 * (w + 8 * n) < ldt) {                                 // (wave-uniform)
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < DP_KB; ++kb) {
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[n][kb].x, dyv[kb].x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[n][kb].y, dyv[kb].y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[n][kb].z, dyv[kb].z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[n][kb].w, dyv[kb].w, acc, 0, 0, 0);
-        }
-        if (c0 < ldt) {
-          u32x4 x = {__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3])};
-#pragma unroll
-          for (int u = 0; u < 4; ++u) x[u] = x[u] == 0xFFFFFFFFu ? 0x7FC00000u : x[u];      // (the armed pattern is nobody's value)
-          float* dst = a.dtop + ((size_t)t * N + row) * ldt + c0;
-          asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(x) : "memory");
-        }
-      }
-    }
-    __syncthreads();                                               // B: `part` may be overwritten
-  }
-}
-
-__global__ __launch_bounds__(512, 1) void k_dlstm_bwd_trail(const DPersistArgs a) {
-  __shared__ __attribute__((aligned(16))) DpTrailLds S;
-  gu32* ctl = (gu32*)a.ctl;
-  const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (threadIdx.x == 0) S.dead = 0;
-  __syncthreads();
-  const int nD = a.nl * (a.N >> 5) * DP_NQ;
-  if ((int)blockIdx.x < nD) dp_bwdt_body(a, gen, S, (int)blockIdx.x);
-  else dp_fcb_body(a, gen, S, (int)blockIdx.x - nD);
-  if (threadIdx.x == 0) {
-    const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == gridDim.x - 1) {
-      if (__hip_atomic_load(ctl + DP_CTL_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) a.dy[0] = __builtin_nanf("");
-      __hip_atomic_store(ctl + DP_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(ctl + DP_CTL_GEN, gen + 1u == 0u ? 1u : gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 // (the backward launch uses two edges per layer: dm_state partials and the dx partials for the layer below)
 size_t dpersist_granule_bytes(int nl, int N, int T) { return (size_t)2 * nl * (N / 16) * T * DP_NQ * DP_SLOT * sizeof(unsigned long long); }
 
@@ -1169,21 +707,12 @@ void launch_dlstm_bwd(const DPersistArgs& a, hipStream_t s) {
 }
 
 int dpersist_trail_grid(int nl, int N) { return nl * (N / 32) * DP_NQ + N / 16; }
-size_t dpersist_trail_lds_bytes() {
-  hipFuncAttributes f{};
-  return hipFuncGetAttributes(&f, (const void*)k_dlstm_bwd_trail) == hipSuccess ? f.sharedSizeBytes : 0;
-}
+size_t dpersist_trail_lds_bytes() { return sizeof(DpTrailLds); }
 bool dpersist_trail_supported(const DPersistArgs& a) {
   if (!dpersist_supported(a) || a.N % 32 != 0 || !a.dy || !a.fc_w || !a.dtop) return false;
   if (a.ld_dy % 4 != 0 || a.ld_fcw % 4 != 0 || a.ld_dtop % 4 != 0 || a.fc_P < 1 || a.fc_P > a.ld_dtop || a.ld_dtop > 16 * 8 * DP_FCT) return false;
   return a.L[0].I % 4 == 0 && a.L[0].I >= 4 && a.L[0].I <= a.ld_dy && a.L[0].I <= a.ld_fcw;
 }
-// a.dtop armed with 0xFF bytes by the caller, in front of this launch AND of the k_glstm_bwd that polls it
-void launch_dlstm_bwd_trail(const DPersistArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_dlstm_bwd_trail, dim3(dpersist_trail_grid(a.nl, a.N)), dim3(512), 0, s, a);
-  ++g_chain_launches;
-}
-
 void launch_dlstm_fwd(const DPersistArgs& a, hipStream_t s) {
   const int blocks = dpersist_grid(a.nl, a.N);
   hipLaunchKernelGGL(k_dlstm_fwd, dim3(blocks), dim3(512), 0, s, a);

@@ -36,6 +36,7 @@ namespace rsr {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned gu32;
+#include "dpersist_dev.h"            // (the trailing form of the discriminator's BPTT rides inside k_glstm_bwd_dt)
 
 constexpr int GP_NR = GP_ROWS / 16;      // row tiles per group
 constexpr int GP_WAVES = 12;             // R0..R3, X0..X3, G0..G3
@@ -884,7 +885,7 @@ __device__ __forceinline__ bool gp_sum_all(const GpBuf& b, unsigned base, int NC
 // D_{l+1}(t) piece the same-numbered reducer above published a step ago, hands D_l(t) into the state-gradient sum and publishes it
 // for the layer below in the second region of gran2 (one slot per step, behind the hand-offs).
 template <int NT, int PROG, bool RES, bool TAG>
-__device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S, const unsigned c1, const unsigned c3) {
+__device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S, const unsigned c1, const unsigned c3, const unsigned bid) {
   static_assert(!(TAG && PROG), "the progressive sweeps know the sentinel form only");
   constexpr int NR = GP_NR, CW = 4 * NT;
   GPT_DECL
@@ -894,7 +895,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
   if (tid == 0) gp_tr[0][23] = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
   const int ngr = a.N / GP_ROWS, xpg = 8 / ngr;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int xcd = bid & 7, slot = bid >> 3;
   const int grp = xcd / xpg, idx = slot * xpg + (xcd % xpg);
   if (idx >= a.nl * a.NC) return;
   const int l = idx / a.NC, c = idx - l * a.NC;
@@ -960,7 +961,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
   auto fail = [&]() {
     if (lane == 0) {
       __hip_atomic_store(cnt + C_DEAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_store(err, 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(err, 1u + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
   const int len0 = a.len[row0 + lr], len1 = a.len[row0 + 16 + lr];
@@ -1255,7 +1256,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
     if (reducer) {
       float4 dtop = make_float4(0.f, 0.f, 0.f, 0.f);
       if (top && rcol < a.ld_dout) {
-        if (a.dout_trail) {
+        if (a.dout_trail == 1) {
           // the discriminator's trailing BPTT (dpersist.hip k_dlstm_bwd_trail) is writing d(outputs) while this launch runs: this
           // lane's piece of step t, past the caches, until none of its words carries the armed pattern (it is there as a rule: that
           // launch runs three times as fast as this one)
@@ -1371,11 +1372,69 @@ __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_bwd(const GPersistAr
   // (TAG) the ring step counters: T - 1 state-gradient steps and T input-gradient steps are written per launch
   const unsigned c1 = TAG ? __hip_atomic_load(ctl + GP_CTL_C1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   const unsigned c3 = TAG ? __hip_atomic_load(ctl + GP_CTL_C3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-  gp_bwd_body<NT, PROG, RES, TAG>(a, S, c1, c3);
+  gp_bwd_body<NT, PROG, RES, TAG>(a, S, c1, c3, blockIdx.x);
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == gridDim.x - 1) {
+      if (TAG) {
+        __hip_atomic_store(ctl + GP_CTL_C1, (c1 + (unsigned)a.T - 1u) % (2u * GP_R1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ctl + GP_CTL_C3, (c3 + (unsigned)a.T) % (2u * GP_XR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (__hip_atomic_load(ctl + DP_CTL_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        a.L[0].gates[0] = __builtin_nanf("");
+      __hip_atomic_store(ctl + DP_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned g1 = gen + 1u;
+      __hip_atomic_store(ctl + DP_CTL_GEN, g1 >= (1u << 21) ? 1u : g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// The generator's BPTT AND the trailing form of the discriminator's (dpersist_dev.h dp_bwdt_body / dp_fcb_body) as ONE launch: the
+// first dt_pad workgroups (a multiple of 8: the generator's workgroups keep their XCDs) are the discriminator's, the rest run gp_bwd_body, whose top layer polls the
+// gradient the FC workgroups write (GPersistArgs::dout_trail).  Two launches on two streams did the same 0.45 ms faster than one
+// after the other -- when their queues let them run side by side: inside a replayed graph, or with other streams of the process
+// sharing a hardware queue with either, the generator's launch can be dispatched FIRST and waits a second for a launch that sits
+// behind it.  One launch has one dispatch order: the discriminator's workgroups first.
+template <int NT, bool RES, bool TAG>
+union GpDtLds { GpLdsB<NT> g; DpTrailLds d; };
+template <int NT, bool RES, bool TAG>
+__global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_bwd_dt(const GPersistArgs a, const DPersistArgs d) {
+  __shared__ __attribute__((aligned(16))) GpDtLds<NT, RES, TAG> S;
+  const int nD = d.nl * (d.N >> 5) * DP_NQ, nReal = nD + (d.N >> 4), dt_pad = (nReal + 7) & ~7;
+  // (a.dout_trail = 1; RSRGAN_TRAIL_DBG sets the timing experiments of DESIGN 6-R5: 2 the discriminator half alone, 3 both halves without
+  //  the generator's polls, 4 the generator half alone -- their results are meaningless)
+  const int mode = a.dout_trail;
+  const int dbid = (int)blockIdx.x;
+  const unsigned gbid = blockIdx.x - (unsigned)dt_pad;
+  if (dbid < dt_pad) {
+    if (dbid >= nReal || mode == 4) return;
+    gu32* dctl = (gu32*)d.ctl;
+    const unsigned dgen = __hip_atomic_load(dctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) S.d.dead = 0;
+    __syncthreads();
+    if (dbid < nD) dp_bwdt_body(d, dgen, S.d, dbid);
+    else dp_fcb_body(d, dgen, S.d, dbid - nD);
+    if (threadIdx.x == 0) {
+      const unsigned old = __hip_atomic_fetch_add(dctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == (unsigned)nReal - 1u) {
+        if (__hip_atomic_load(dctl + DP_CTL_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) d.dy[0] = __builtin_nanf("");
+        __hip_atomic_store(dctl + DP_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dctl + DP_CTL_GEN, dgen + 1u == 0u ? 1u : dgen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  }
+  gu32* ctl = (gu32*)a.ctl;
+  if (mode == 2) return;
+  const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned c1 = TAG ? __hip_atomic_load(ctl + GP_CTL_C1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  const unsigned c3 = TAG ? __hip_atomic_load(ctl + GP_CTL_C3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  gp_bwd_body<NT, 0, RES, TAG>(a, S.g, c1, c3, gbid);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == gridDim.x - (unsigned)dt_pad - 1u) {
       if (TAG) {
         __hip_atomic_store(ctl + GP_CTL_C1, (c1 + (unsigned)a.T - 1u) % (2u * GP_R1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(ctl + GP_CTL_C3, (c3 + (unsigned)a.T) % (2u * GP_XR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2138,6 +2197,18 @@ void gpersist_np_arm(const GPersistArgs& a, hipStream_t s) {
 void launch_glstm_np_bwd(const GPersistArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_glstm_np_bwd, dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
   ++g_chain_launches;
+}
+// ONE launch: the discriminator's trailing BPTT (d: DPersistArgs with the trailing fields) in front of the generator's (a.dout_trail = 1)
+int gpersist_dt_grid(const GPersistArgs& a, const DPersistArgs& d) { return gp_grid(a) + ((dpersist_trail_grid(d.nl, d.N) + 7) & ~7); }
+void launch_glstm_bwd_dt(const GPersistArgs& a, const DPersistArgs& d, hipStream_t s) {
+  (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_gran2_bytes(a), s);
+  const dim3 g(gpersist_dt_grid(a, d)), b(GP_WAVES * 64);
+  if (a.tags) {
+    if (a.res) hipLaunchKernelGGL((k_glstm_bwd_dt<5, true, true>), g, b, 0, s, a, d);
+    else hipLaunchKernelGGL((k_glstm_bwd_dt<5, false, true>), g, b, 0, s, a, d);
+  } else if (a.res) hipLaunchKernelGGL((k_glstm_bwd_dt<5, true, false>), g, b, 0, s, a, d);
+  else hipLaunchKernelGGL((k_glstm_bwd_dt<5, false, false>), g, b, 0, s, a, d);
+  g_chain_launches += 2;
 }
 void launch_glstm_bwd(const GPersistArgs& a, hipStream_t s) {
   (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_gran2_bytes(a), s);

@@ -158,7 +158,7 @@ struct DPersistArgs {
   float forget_bias;
   const float* dout_top;                          // backward: [T][N][ld_dout] gradient of the top layer's masked outputs
   int ld_dout;
-  // the trailing form of the backward launch (k_dlstm_bwd_trail: the G-run, no weight gradients): layer 0's input gradient is added
+  // the trailing form of the backward launch (dpersist_dev.h, inside gpersist.hip k_glstm_bwd_dt: the G-run, no weight gradients): layer 0's input gradient is added
   // to dy [T][N][ld_dy] step by step, and d(generator outputs)(t) = dy(t) . fc_w^T (fc_w: the generator's output FC [fc_P][ld_fcw])
   // lands in dtop [T][N][ld_dtop], armed with 0xFF bytes by the caller, where k_glstm_bwd's top layer polls it
   float* dy;
@@ -170,7 +170,6 @@ size_t dpersist_granule_bytes(int nl, int N, int T);
 int dpersist_trail_grid(int nl, int N);
 size_t dpersist_trail_lds_bytes();
 bool dpersist_trail_supported(const DPersistArgs& a);
-void launch_dlstm_bwd_trail(const DPersistArgs& a, hipStream_t s);
 bool dpersist_supported(const DPersistArgs& a);
 int dpersist_grid(int nl, int N);                 // workgroups of a launch over N rows
 size_t dpersist_lds_bytes();
@@ -215,6 +214,8 @@ struct GPersistArgs {
 constexpr int GP_TMAX = 2046;                     // longest launch (slot offsets are 32-bit; a longer batch takes the launch-per-phase path)
 bool gpersist_plan(GPersistArgs& a);              // fills NT / NC; false: shape not supported
 int gpersist_grid(const GPersistArgs& a);         // workgroups of a launch (all must be resident at once)
+int gpersist_dt_grid(const GPersistArgs& a, const DPersistArgs& d);      // ... of k_glstm_bwd_dt
+void launch_glstm_bwd_dt(const GPersistArgs& a, const DPersistArgs& d, hipStream_t s);   // the generator's BPTT with the discriminator's trailing BPTT in front (ONE launch; a.dout_trail = 1, d.dtop armed)
 size_t gpersist_lds_bytes();                      // LDS of a workgroup (the larger of the two kernels')
 int device_cu_count();                            // hipDeviceProp_t::multiProcessorCount of the current device (queried once)
 // true when `grid` workgroups of `threads` threads and `lds_bytes` of LDS are on the device AT THE SAME TIME (asked of the device itself:

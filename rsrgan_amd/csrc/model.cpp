@@ -492,10 +492,10 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   }
   {
     // the trailing discriminator BPTT beside k_glstm_bwd (the G-run): both launches' workgroups resident at once -- ask the device
-    static const bool trail_env = [] { const char* e = getenv("RSRGAN_TRAIL"); return !e || atoi(e) != 0; }();
+    if (const char* e = getenv("RSRGAN_TRAIL")) trail_mode = atoi(e);
     GPersistArgs ga{};
-    if (trail_env && dp_gran && (dp_env & 2) && gp_gran1 && gp_gran3 && !gp_noproj && (gp_env & 2) && B % 32 == 0 && gpersist_args(ga, gp_Tcap))
-      trail_fits = resident_probe(gpersist_grid(ga) + dpersist_trail_grid((int)dl.size(), B), GP_THREADS,
+    if (trail_mode && dp_gran && (dp_env & 2) && gp_gran1 && gp_gran3 && !gp_noproj && (gp_env & 2) && B % 32 == 0 && gpersist_args(ga, gp_Tcap))
+      trail_fits = resident_probe(gpersist_grid(ga) + ((dpersist_trail_grid((int)dl.size(), B) + 7) & ~7), GP_THREADS,
                                   std::max(gpersist_lds_bytes(), dpersist_trail_lds_bytes()));
   }
   {
@@ -1121,6 +1121,7 @@ bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only,
   const bool din_inside = ch[0].din && din0_env && (gl[0].I + 15) / 16 <= (gl[0].P + 15) / 16 && gl[0].ldI % 4 == 0;
   if (din_inside) { a.din0 = ch[0].din; a.ld_din0 = gl[0].ldI; }
   a.dout_trail = gp_trail_next ? 1 : 0;
+  if (gp_trail_next && getenv("RSRGAN_TRAIL_DBG")) a.dout_trail = atoi(getenv("RSRGAN_TRAIL_DBG"));
   if (prof_on) {
     if ((size_t)(2 * prof_gb_n + 2) > prof_gb_ev.size()) {
       const size_t old = prof_gb_ev.size();
@@ -1132,16 +1133,13 @@ bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only,
     for (size_t l = 0; l < gl.size(); ++l)
       prof_gb_flops += 2.0 * Bt * T * ((double)((l || din_inside ? gl[l].I : 0) + gl[l].P) * 4.0 * gl[l].H + (double)gl[l].H * gl[l].P);
     (void)hipEventRecord(prof_gb_ev[2 * prof_gb_n], s);
-    launch_glstm_bwd(a, s);
+    if (gp_trail_next) launch_glstm_bwd_dt(a, dt_args, s); else launch_glstm_bwd(a, s);
     (void)hipEventRecord(prof_gb_ev[2 * prof_gb_n + 1], s);
     ++prof_gb_n;
-  } else
+  } else if (gp_trail_next)
+    launch_glstm_bwd_dt(a, dt_args, s);
+  else
     launch_glstm_bwd(a, s);
-  if (gp_trail_next) {                                 // the discriminator's trailing launch on the side stream: dy is complete behind it
-    hipEvent_t ev = ev_pool[ev_next++ & 15];
-    (void)hipEventRecord(ev, side);
-    (void)hipStreamWaitEvent(s, ev, 0);
-  }
   auto din0 = [&](hipStream_t q) {
     if (ch[0].din && !din_inside) {
       const LayerRun& R = ch[0];
@@ -1186,7 +1184,7 @@ bool Model::persist_backward(Chain& ch, int T, hipStream_t s) {
 }
 
 bool Model::persist_backward_trail(Chain& ch, int T, hipStream_t s, float* dy, int ld_dy, float* dtop, int ld_dtop, bool check_only) {
-  if (!trail_fits || !side || !dp_gran || !(dp_env & 2) || !wavefront() || ch.size() != dl.size() || ch[0].din) return false;
+  if (!trail_fits || !dp_gran || !(dp_env & 2) || !wavefront() || ch.size() != dl.size() || ch[0].din) return false;
   DPersistArgs a{};
   a.nl = (int)ch.size(); a.N = ch[0].N; a.T = T; a.H = dl[0].H; a.len = ch[0].len;
   a.gran = dp_gran; a.ctl = dp_ctl; a.forget_bias = cfg.forget_bias;
@@ -1203,10 +1201,7 @@ bool Model::persist_backward_trail(Chain& ch, int T, hipStream_t s, float* dy, i
   a.dy = dy; a.ld_dy = ld_dy; a.fc_w = G.W(g_fc_out_w); a.ld_fcw = ldDout; a.fc_P = gR; a.dtop = dtop; a.ld_dtop = ld_dtop;
   if (!a.dout_top || a.N != B || dl[0].I != Dout || !dpersist_trail_supported(a) || dpersist_granule_bytes(a.nl, a.N, a.T) > dp_gran_bytes) return false;
   if (check_only) return true;
-  hipEvent_t ev = ev_pool[ev_next++ & 15];
-  (void)hipEventRecord(ev, s);
-  (void)hipStreamWaitEvent(side, ev, 0);
-  launch_dlstm_bwd_trail(a, side);
+  dt_args = a;                                           // (persist_backward_g launches k_glstm_bwd_dt with it)
   return true;
 }
 
@@ -1902,8 +1897,8 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
       // layer 0's input gradient as a GEMM on top of the mse term in dy), then the output FC's data gradient as one GEMM
       std::vector<Chain> dc1(1, bw_chains[0]);
       dc1[0][0].din = nullptr;
-      // round 5: the discriminator's BPTT in its trailing form on the side stream, BESIDE the generator's (which polls its top
-      // layer's gradient step by step): dy and g_dA are completed inside that launch
+      // round 5: the discriminator's BPTT in its trailing form INSIDE the generator's launch (k_glstm_bwd_dt; the generator's top layer
+      // polls its gradient step by step): dy and g_dA are completed there
       const bool trailed = trail_plan && persist_backward_trail(dc1[0], T, s, dy, ldDout, g_dA, ldP);
       if (!trailed) {
         if (!persist_backward(dc1[0], T, s)) rnn_backward(dc1, T, s);

@@ -158,11 +158,13 @@ struct Model {
   int dp_env = 3;                                         // RSRGAN_DPERSIST: bit 0 the forward launch, bit 1 the backward launch
   bool persist_forward(Chain& ch, int T, hipStream_t s);  // false: not applicable -> caller falls back to fold_forward
   bool persist_backward(Chain& ch, int T, hipStream_t s); // BPTT of the chain + its weight gradients; false: not applicable
-  // the G-run's discriminator BPTT in its trailing form (dpersist.hip k_dlstm_bwd_trail) on the side stream: dy += layer 0's input
-  // gradient, dtop = dy . W_out^T step by step; the k_glstm_bwd launched next on s polls dtop (gp_trail_next)
+  // the G-run's discriminator BPTT in its trailing form (dpersist_dev.h): fills dt_args for the k_glstm_bwd_dt launch that
+  // persist_backward_g makes next (gp_trail_next): dy += layer 0's input gradient, dtop = dy . W_out^T step by step
   bool persist_backward_trail(Chain& ch, int T, hipStream_t s, float* dy, int ld_dy, float* dtop, int ld_dtop, bool check_only = false);
   bool trail_fits = false;                                // both launches resident at once (resident_probe at init)
-  bool gp_trail_next = false;                             // the next k_glstm_bwd launch polls its top layer's d(outputs), then joins the side stream
+  bool gp_trail_next = false;                             // the next generator BPTT launch is k_glstm_bwd_dt (dt_args)
+  int trail_mode = 1;                                     // RSRGAN_TRAIL: 0 off
+  DPersistArgs dt_args{};                                 // (mode 1) the discriminator half of the next k_glstm_bwd_dt launch
   // ---- persistent GENERATOR recurrence (gpersist.hip): the forward pass of the generator's stack as ONE launch (weights resident
   // in VGPRs / LDS for all T steps); RSRGAN_GPERSIST bit 0.  Needs B % 32 == 0, projected cells, no residual sums, no dropout.
   unsigned long long *gp_gran1 = nullptr, *gp_gran2 = nullptr, *gp_gran3 = nullptr;
