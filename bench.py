@@ -602,7 +602,8 @@ def main():
                                                    if k_rocprof_us else None),
                     "how": "the kernel class with the largest total duration in the step: k_glstm_bwd (csrc/gpersist.hip: the generator's "
                            "whole BPTT as ONE persistent launch; algorithmic FLOP = every layer's state-gradient product and dh = dm.Wp^T "
-                           "+ the input-gradient product above layer 0), k_glstm_fwd (its forward recurrence: recurrent product, projection, "
+                           "+ the input-gradient product above layer 0; round 5: the launch is k_glstm_bwd_dt, which also carries the "
+                           "discriminator's trailing BPTT of the G-run -- its data-gradient products and dy.W_out^T are counted), k_glstm_fwd (its forward recurrence: recurrent product, projection, "
                            "input product above layer 0) or, with RSRGAN_GPERSIST=0, the k_fwd_gates launches of the wavefront.  avg_us: "
                            "every launch of one extra step bracketed by HIP events on its stream (rsrgan_profile_begin / read_kind / read; "
                            "includes the event records and the memset that arms the launch's hop-2 slots, an upper bound); "

@@ -1132,6 +1132,11 @@ bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only,
     // only when it runs inside the launch)
     for (size_t l = 0; l < gl.size(); ++l)
       prof_gb_flops += 2.0 * Bt * T * ((double)((l || din_inside ? gl[l].I : 0) + gl[l].P) * 4.0 * gl[l].H + (double)gl[l].H * gl[l].P);
+    if (gp_trail_next) {      // k_glstm_bwd_dt: + the discriminator's data gradient (every layer's state- and input-gradient product, dh = dm . W_p^T) and dy . W_out^T
+      for (size_t l = 0; l < dl.size(); ++l)
+        prof_gb_flops += 2.0 * Bt * T * ((double)(dl[l].I + dl[l].P) * 4.0 * dl[l].H + (double)dl[l].H * dl[l].P);
+      prof_gb_flops += 2.0 * Bt * T * (double)Dout * gR;
+    }
     (void)hipEventRecord(prof_gb_ev[2 * prof_gb_n], s);
     if (gp_trail_next) launch_glstm_bwd_dt(a, dt_args, s); else launch_glstm_bwd(a, s);
     (void)hipEventRecord(prof_gb_ev[2 * prof_gb_n + 1], s);
