@@ -218,12 +218,14 @@ int rsrgan_profile_read(rsrgan_handle h, int32_t* launches, double* total_us, do
  * generator's whole forward recurrence (csrc/gpersist.hip; algorithmic FLOP = every layer's input product -- layer 0's included: it runs
  * inside the launch since round 4 --, recurrent product and projection, over the CALLER's rows: padding rows of a row-padded model do
  * not count), kind 2 = k_glstm_bwd, its BPTT (state-gradient product, dh = dm . W_p^T, the input-gradient product
- * above layer 0).  Call before rsrgan_profile_read (which closes the window). */
+ * above layer 0; in the G-run the launch is k_glstm_bwd_dt, which also carries the discriminator's BPTT in its trailing form,
+ * csrc/dpersist_dev.h: that half's state- and input-gradient products, dh = dm . W_p^T and dy . W_out^T are counted too).  Call before
+ * rsrgan_profile_read (which closes the window). */
 int rsrgan_profile_read_kind(rsrgan_handle h, int32_t kind, int32_t* launches, double* total_us, double* alg_flops);
 
 /* Health of the persistent recurrence kernels (csrc/dpersist.hip, csrc/gpersist.hip): synchronises the handle's stream and returns in
  * *code 0, or 1 + the first workgroup whose bounded wait for another workgroup's partials expired -- of a discriminator launch as is,
- * of a generator launch (k_glstm_fwd / k_glstm_bwd) with 0x10000 added -- and clears the (sticky) device word.  A failed launch has
+ * of a generator launch (k_glstm_fwd / k_glstm_bwd; in k_glstm_bwd_dt each half reports as its own kind) with 0x10000 added -- and clears the (sticky) device word.  A failed launch has
  * already poisoned its step's losses with NaN.  A failure means the launch's workgroups were not all resident at once (CUs taken
  * away after rsrgan_create, which asks the device how many it can hold: csrc/gpersist.hip resident_probe): the handle re-arms its
  * hand-off rings and takes the launch-per-phase path for that recurrence from then on.  Nothing in the reference corresponds to this. */
