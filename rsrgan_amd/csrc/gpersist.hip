@@ -333,6 +333,7 @@ struct GpLds {
   float peep[4 * NT][4];                    // {w_i, w_f, w_o, -} per cell of this slice (one 16-byte read per cell)
   float bias[4 * NT][4];                    // {b_i, b_j, b_f, b_o} per cell: the accumulator registers of a lane
   unsigned cnt_x[GP_NR][4], cnt_p[GP_NR], cnt_h[GP_NR], cnt_m[GP_NR], cnt_g[GP_NR], cnt_s[GP_NR], dead, pad_[13];
+  int len[GP_ROWS];                         // the rows' lengths: read per step (a register that holds one for the whole launch was spilled, and a scratch reload sat in the cell phase and in front of the publication)
 };
 
 // PROG: bit 0 the reducers' hop-1 sweeps, bit 1 the gathers of hop 2 in the progressive form (gp_sweep_prog); RSRGAN_GP_PROG
@@ -392,6 +393,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
   for (int e = tid; e < GP_NR * GP_NKB * 64; e += GP_WAVES * 64)       // the carried state m(-1) is zero (cell.zero_state)
     *reinterpret_cast<f32x4*>(&S.mB[0][0][0][0] + 4 * e) = f32x4{0.f, 0.f, 0.f, 0.f};
   if (tid < 32) (&S.cnt_x[0][0])[tid] = 0u;
+  if (tid < GP_ROWS) S.len[tid] = a.len[row0 + tid];
   __syncthreads();
   const unsigned* dead = &S.dead;
   auto fail = [&]() {
@@ -400,7 +402,6 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
       __hip_atomic_store(err, 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
-  const int len0 = a.len[row0 + lr], len1 = a.len[row0 + 16 + lr];
 
   if (w < 4) {
     // =============================== R waves: the critical compute ===============================
@@ -471,7 +472,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
         if (t > 0 && !gp_wait(&S.cnt_s[r], 4u * (unsigned)t, dead)) return;  // the stash of step t-1 has left the stage (long ago)
         GPT(6 * r + 4);
         // the cell, on the accumulator layout: lane (q, lr) of (gate tile i, row tile r) = row 16 r + lr, cell 4 i + q, gates i j f o
-        const bool live = t < (r ? len1 : len0);
+        const bool live = t < S.len[16 * r + lr];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           if (s == 0 || two) {
@@ -579,7 +580,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
         } else if (!gp_sweep<GP_KBW, false, GP_KBW, true>(b2x, lo, nsx, frag_off, slot2(t, r, min(xw + 4 * (lane >> 1), nkbx - 1)) + (unsigned)(lane & 1) * 512u + 496u,
                                                     lane < 2 * nsx, err, [&](int k, const f32x4& v) { xv[k] = v; })) { fail(); return; }
         GPT(19 + 2 * r);
-        const bool live = t < (r ? len1 : len0);
+        const bool live = t < S.len[16 * r + lr];
         f32x4 acc[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i)
@@ -618,7 +619,6 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
   // =============================== G waves: project, publish, reduce, gather (tile gw & 1) ===============================
   __builtin_amdgcn_s_setprio(3);                                       // the hand-off is the critical path and these waves issue little (their polls sleep); R bursts run at 2, X bursts at 1
   const int gw = w - 8, r = gw & 1, gp = gw >> 1;                      // this wave's tile, and which of the tile's two G waves it is
-  const int lenr = r ? len1 : len0;
   // The partial projection of this slice's cells and its publication run HERE, not on the R waves: whatever vector-memory access
   // follows the write-through granule stores in a wave's queue waits for their acknowledgement (vmcnt retires in order).
   // Chunk n of this wave = k-block gp + 2 n of P, tile r:
@@ -712,7 +712,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
       } else if (!gp_sweep<9, true, 9, true>(b2, lo, nvg, frag_off, slot2(t, r, min(gp + 2 * (lane >> 1), nkb - 1)) + (unsigned)(lane & 1) * 512u + 496u,
                                  lane < 2 * nvg, err, [&](int k, const f32x4& v) { mv[k] = v; })) { fail(); return; }
       GPT(17);
-      const bool live = t < lenr;
+      const bool live = t < S.len[16 * r + lr];
 #pragma unroll
       for (int n = 0; n < 9; ++n)
         if (n < nvg && live) *reinterpret_cast<f32x4*>(mbg + 2 * n * 256) = mv[n];
@@ -1046,28 +1046,32 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
       // The stash of step t-1 (gate activations, c(t-2): 16 rows x 4 NT cells x 5 values per tile) travels through these waves into
       // LDS a step ahead, as 16-byte row pieces (the mirror of the R waves' stash store): the R waves keep 80 weight registers and
       // cannot hold it, and a load issued in front of the publication below does not wait for a write-through acknowledgement.
-      float4 pv[2];
+      // (two named values, not an array: indexed inside the lambdas the pair lived in SCRATCH -- the load waited for at once, stored,
+      //  reloaded a step later, every access a memory round trip beside the hand-off traffic)
+      float4 pv0, pv1;
+      auto fetch1 = [&](int t, int r, int it, int ln) -> float4 {
+        const int e = it * 256 + ww * 64 + ln;
+        const int cq = e % NT, pr = min(e / NT, 79), row = pr & 15, k = pr >> 4;
+        const size_t rowg = (size_t)t * N + row0 + 16 * r + row;
+        const int cell = min(cell0 + 4 * cq, H - 4);
+        return *reinterpret_cast<const float4*>((k < 4 ? L.gates + rowg * H4 + k * H : L.c + rowg * H) + cell);
+      };
       auto fetch = [&](int t, int r) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int e = it * 256 + ww * 64 + ln;
-          const int cq = e % NT, pr = min(e / NT, 79), row = pr & 15, k = pr >> 4;
-          const size_t rowg = (size_t)t * N + row0 + 16 * r + row;
-          const int cell = min(cell0 + 4 * cq, H - 4);
-          pv[it] = *reinterpret_cast<const float4*>((k < 4 ? L.gates + rowg * H4 + k * H : L.c + rowg * H) + cell);
-        }
+        pv0 = fetch1(t, r, 0, ln);
+        pv1 = fetch1(t, r, 1, ln);
+      };
+      auto stage1 = [&](int r, int it, int ln, const float4& v) {
+        const int e = it * 256 + ww * 64 + ln;
+        const int cq = e % NT, pr = e / NT, row = pr & 15, k = min(pr >> 4, 4);
+        if (e < 5 * 16 * NT) *reinterpret_cast<float4*>(&S.pfs[r][k][row][4 * cq]) = v;
       };
       auto stage = [&](int r) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-          const int e = it * 256 + ww * 64 + ln;
-          const int cq = e % NT, pr = e / NT, row = pr & 15, k = min(pr >> 4, 4);
-          if (e < 5 * 16 * NT) *reinterpret_cast<float4*>(&S.pfs[r][k][row][4 * cq]) = pv[it];
-        }
+        stage1(r, 0, ln, pv0);
+        stage1(r, 1, ln, pv1);
         gp_signal(cnt + C_F + r, lane);
       };
 #pragma unroll

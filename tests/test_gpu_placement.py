@@ -57,6 +57,7 @@ for i, Ti in enumerate(int(v) for v in os.environ.get("RSRGAN_TEST_TSEQ", "").sp
     out["sd%%d" %% i] = [float(v) for v in d]; out["sg%%d" %% i] = [float(v) for v in g]
 model.engine.profile_begin()
 model.d_step(x, lab, ln); model.g_step(x, lab, ln, reuse_g_forward=True)
+out["gb_flops"] = float(model.engine.profile_read_kind(2)[2])      # algorithmic FLOP of the generator's BPTT launch (k_glstm_bwd_dt counts the discriminator half too)
 model.engine.profile_read()
 out["chain_launches"] = int(model.engine.profile_launches())
 out["device_status"] = int(model.engine.device_status())
@@ -160,6 +161,7 @@ def test_trailing_discriminator_bptt_agrees(B, T, net):
     a = _run(dict(size))
     b = _run(dict(size, RSRGAN_TRAIL="0"))
     assert a["device_status"] == 0 and b["device_status"] == 0
+    assert a["gb_flops"] > b["gb_flops"] > 0, (a["gb_flops"], b["gb_flops"])      # the one launch carried the discriminator's products: that path ran
     for k in ("d0", "g0", "d1", "g1"):
         assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-7), (k, a[k], b[k])
     assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]

@@ -11,7 +11,7 @@
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
-namespace rsr { long long g_chain_launches = 0; }
+namespace rsr { long long g_chain_launches = 0; int dpersist_trail_grid(int nl, int N) { return nl * (N / 32) * 4 + N / 16; } }      // (dpersist.hip is not linked here)
 #ifndef GP_NOTRACE                 // -DGP_NOTRACE: the product's code (no stamps: the launch time only; the stamps cost the backward kernel 18 spilled registers)
 #define GP_TRACE 1
 #endif
