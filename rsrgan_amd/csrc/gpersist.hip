@@ -324,16 +324,17 @@ __device__ __forceinline__ bool gp_sweep_prog(const GpBuf& b, const unsigned (&l
 // LDS of a workgroup (NT = 5: 129 KB)
 template <int NT>
 struct GpLds {
+  // (small, hot arrays first: a DS immediate offset reaches 64 KB; see DpTrailLds)
+  unsigned cnt_x[GP_NR][4], cnt_p[GP_NR], cnt_h[GP_NR], cnt_m[GP_NR], cnt_g[GP_NR], cnt_s[GP_NR], dead, pad_[13];
+  int len[GP_ROWS];                         // the rows' lengths: read per step (a register that holds one for the whole launch was spilled, and a scratch reload sat in the cell phase and in front of the publication)
+  float peep[4 * NT][4];                    // {w_i, w_f, w_o, -} per cell of this slice (one 16-byte read per cell)
+  float bias[4 * NT][4];                    // {b_i, b_j, b_f, b_o} per cell: the accumulator registers of a lane
+  float gs[2][GP_NR][2][64][4];             // the two reducing G waves' partial sums of this workgroup's half chunk [step parity][tile][wave][half wave = even / odd producers, fragment lane]
+  float st[6][GP_ROWS][4 * NT];             // the step's stash: gates i, j, f, o | c | h   (h also feeds the projection)
+  float kx4[2][NT][64][4];                  // the fifth K_x k-block of X waves 0, 1 (k-blocks 16, 17): 100 weight registers do not fit beside the sweeps
   float wp[GP_NKB][NT][64];                 // W_p^T fragments: A operand of the partial projection [k-block of P][k-step of 4 cells][lane]
   float mB[GP_NR][GP_NKB][64][4];           // carried m(t-1) as B fragments [row tile][k-block][lane][4]
   float pb[4][NT][GP_NR][64][4];            // accumulator tiles: x-part (X wave w -> R wave w), then the R waves' partial sums
-  float st[6][GP_ROWS][4 * NT];             // the step's stash: gates i, j, f, o | c | h   (h also feeds the projection)
-  float gs[2][GP_NR][2][64][4];             // the two reducing G waves' partial sums of this workgroup's half chunk [step parity][tile][wave][half wave = even / odd producers, fragment lane]
-  float kx4[2][NT][64][4];                  // the fifth K_x k-block of X waves 0, 1 (k-blocks 16, 17): 100 weight registers do not fit beside the sweeps
-  float peep[4 * NT][4];                    // {w_i, w_f, w_o, -} per cell of this slice (one 16-byte read per cell)
-  float bias[4 * NT][4];                    // {b_i, b_j, b_f, b_o} per cell: the accumulator registers of a lane
-  unsigned cnt_x[GP_NR][4], cnt_p[GP_NR], cnt_h[GP_NR], cnt_m[GP_NR], cnt_g[GP_NR], cnt_s[GP_NR], dead, pad_[13];
-  int len[GP_ROWS];                         // the rows' lengths: read per step (a register that holds one for the whole launch was spilled, and a scratch reload sat in the cell phase and in front of the publication)
 };
 
 // PROG: bit 0 the reducers' hop-1 sweeps, bit 1 the gathers of hop 2 in the progressive form (gp_sweep_prog); RSRGAN_GP_PROG
@@ -805,18 +806,19 @@ constexpr int GP_XR = GP_XR_STEPS;   // (a slot is re-armed, acknowledged, two s
 
 template <int NT>
 struct GpLdsB {
-  float wpa[GP_NKB][64][4];                 // W_p fragments, A operand of dh^T = W_p . dm^T: [k-block of P][lane][4 k-steps]; row 4 q + i = cell 4 i + q (so that accumulator register i of lane (q, lr) is gate tile i's cell q)
-  float wpb[GP_NKB][16][4];                 // ... of the fifth gate tile: [k-block][4 (k quarter) + cell - 16][4 k-steps]; A row 4 q = cell 16 + q, the other rows of that product are never read (every lane of a row group reads the same entry)
-  float mB[GP_NR][GP_NKB][64][4];           // dm(t) as B fragments [row tile][k-block][lane][4]
-  float kl[8][NT][64][4];                   // weights that do not fit the register file [slot][gate tile][lane][gate]: slots 0..3 R wave w's output tile 12 + w, 4, 5 R waves' tiles 16, 17, 6, 7 X waves' tiles 16, 17
-  float pd[4][GP_NR][NT][64];               // dh partial sums [R wave = k-blocks w, w + 4, ..][row tile][gate tile][lane]
-  float dzB[GP_NR][NT][64][4];              // dz(t) as B fragments of both gradient products [row tile][gate tile][lane (cell q, row lr)][gate]
-  float st[4][GP_ROWS][4 * NT];             // dz(t) in stash order [gate][row][cell]
-  float gs[2][GP_NR][2][64][4];             // the two reducing G waves' sums [step parity][tile][wave][half wave, fragment lane]
-  float pfs[GP_NR][5][16][4 * NT];          // the stash of the NEXT step of a tile: gate activations i, j, f, o and c(t-1) (the X waves fetch it a step ahead)
+  // (small, hot arrays first: a DS immediate offset reaches 64 KB; see DpTrailLds)
+  unsigned cnt_p[GP_NR], cnt_h[GP_NR], cnt_m[GP_NR], cnt_g[GP_NR], cnt_z[GP_NR], cnt_f[GP_NR], cnt_q[GP_NR], cnt_d[GP_NR], dead, pad_[3];
   float peep[4 * NT][4];                    // {w_i, w_f, w_o, -} per cell
   float car[4][2][GP_NR][64][2];            // c(t) and the carried dc of an R wave's cells [wave][gate tile w | 4 + w][row tile][lane] (in registers they get spilled, and a scratch reload waits for the wave's write-through stores)
-  unsigned cnt_p[GP_NR], cnt_h[GP_NR], cnt_m[GP_NR], cnt_g[GP_NR], cnt_z[GP_NR], cnt_f[GP_NR], cnt_q[GP_NR], cnt_d[GP_NR], dead, pad_[3];
+  float gs[2][GP_NR][2][64][4];             // the two reducing G waves' sums [step parity][tile][wave][half wave, fragment lane]
+  float st[4][GP_ROWS][4 * NT];             // dz(t) in stash order [gate][row][cell]
+  float pfs[GP_NR][5][16][4 * NT];          // the stash of the NEXT step of a tile: gate activations i, j, f, o and c(t-1) (the X waves fetch it a step ahead)
+  float wpb[GP_NKB][16][4];                 // ... of the fifth gate tile: [k-block][4 (k quarter) + cell - 16][4 k-steps]; A row 4 q = cell 16 + q, the other rows of that product are never read (every lane of a row group reads the same entry)
+  float dzB[GP_NR][NT][64][4];              // dz(t) as B fragments of both gradient products [row tile][gate tile][lane (cell q, row lr)][gate]
+  float pd[4][GP_NR][NT][64];               // dh partial sums [R wave = k-blocks w, w + 4, ..][row tile][gate tile][lane]
+  float wpa[GP_NKB][64][4];                 // W_p fragments, A operand of dh^T = W_p . dm^T: [k-block of P][lane][4 k-steps]; row 4 q + i = cell 4 i + q (so that accumulator register i of lane (q, lr) is gate tile i's cell q)
+  float mB[GP_NR][GP_NKB][64][4];           // dm(t) as B fragments [row tile][k-block][lane][4]
+  float kl[8][NT][64][4];                   // weights that do not fit the register file [slot][gate tile][lane][gate]: slots 0..3 R wave w's output tile 12 + w, 4, 5 R waves' tiles 16, 17, 6, 7 X waves' tiles 16, 17
 };
 
 // one lane = one sentinel piece (16 bytes at `so` when son): wait until every one is valid
