@@ -706,6 +706,28 @@ void launch_dlstm_bwd(const DPersistArgs& a, hipStream_t s) {
   ++g_chain_launches;
 }
 
+// the 2-tile form of the forward launch, stand-alone (RSRGAN_DFWD_T=1: the body that k_glstm_fwd_dt hosts, on the generator's register budget)
+__global__ __launch_bounds__(768, 3) void k_dlstm_fwd_t(const DPersistArgs a) {
+  __shared__ __attribute__((aligned(16))) DpFwdTLds S;
+  gu32* ctl = (gu32*)a.ctl;
+  const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) S.dead = 0;
+  __syncthreads();
+  dp_fwdt_body(a, gen, S, (int)blockIdx.x, false);
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == gridDim.x - 1) {
+      if (__hip_atomic_load(ctl + DP_CTL_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) a.L[a.nl - 1].out[0] = __builtin_nanf("");
+      __hip_atomic_store(ctl + DP_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ctl + DP_CTL_GEN, gen + 1u == 0u ? 1u : gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+void launch_dlstm_fwd_t(const DPersistArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_dlstm_fwd_t, dim3(a.nl * (a.N / 32) * DP_NQ), dim3(768), 0, s, a);
+  ++g_chain_launches;
+}
+
 int dpersist_trail_grid(int nl, int N) { return nl * (N / 32) * DP_NQ + N / 16; }
 size_t dpersist_trail_lds_bytes() { return sizeof(DpTrailLds); }
 bool dpersist_trail_supported(const DPersistArgs& a) {

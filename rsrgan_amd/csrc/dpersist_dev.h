@@ -496,3 +496,315 @@ __device__ __forceinline__ void dp_fcb_body(const DPersistArgs& a, const unsigne
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The FORWARD twin of the trailing form: two 16-row tiles per workgroup, 12 waves, the 168-register budget of the generator's launches
+// (see above).  Waves 0-3 compute tile 0, 8-11 tile 1, 4-7 gather / project / publish / write the stash for both tiles in turn.  K_h
+// fragments in LDS; the x-part of a tile's next step (K_x fragments requested from memory, 12 KB per wave) runs in the OTHER tile's
+// phase; W_p fragments in the projecting waves' registers.  xin: layer 0 takes its input like the layers above take theirs -- four
+// partial sums published as granules by whoever produces it (edge nl: the FC workgroups that follow the generator's top layer) --
+// instead of reading rows from memory; such an input is not masked by the rows' lengths (dynamic_rnn does not mask its inputs).
+// ------------------------------------------------------------------------------------------------------------------------
+struct DpFwdTLds {
+  float bp[64][8];                                // per cell of the quarter: {b_i, b_j, b_f, b_o, w_i, w_f, w_o, -} (28 registers a compute wave does not have)
+  float stage[6][16 * DP_HS];                     // the phase's stash [gates i, j, f, o | c | h][row][cell of the quarter]; array 5 is the h tile the projection reads
+  float part_m[DP_TPW][DP_NQ][DP_KB][64][4];      // swept partials of m(t-1), per tile
+  float kh_lds[4][4][DP_KB][64][4];               // K_h fragments [compute wave][gate][k-block][lane]
+  float part_x[DP_TPW][2][DP_NQ][DP_KB][64][4];   // swept partials of x(t+1), per tile, by parity of the step
+  int dead;
+};
+
+__device__ __forceinline__ void dp_fwdt_body(const DPersistArgs& a, const unsigned gen, DpFwdTLds& S, const int bid, const bool xin) {
+  const int RPn = a.N >> 5, RTn = a.N >> 4, ncl = a.nl * RPn;
+  const int cl = bid % ncl, cq = bid / ncl;
+  const int l = cl / RPn, rp = cl - l * RPn;
+  const DPersistLayer L = a.L[l];
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, H4 = 4 * H, T = a.T, N = a.N, P = L.P, ldP = L.ldP, I = L.I;
+  const bool xg = l > 0 || xin;                                     // the input arrives as granules
+  gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
+  const size_t slot_stride_t = (size_t)DP_NQ * DP_SLOT;
+  auto edge = [&](int layer, int r) -> gu64* { return (gu64*)a.gran + ((size_t)(layer * RTn + r) * T) * slot_stride_t; };
+  const int lx = l > 0 ? l - 1 : a.nl;                              // whose granules are my input (edge nl: the producer of layer 0's input)
+
+  if (w >= 4 && w < 8) {
+    // ---------------- gather waves ----------------
+    __builtin_amdgcn_s_setprio(3);
+    const int j = w - 4;
+    float vm[DP_KB * 4], vx[DP_KB * 4];
+    auto put = [&](float (*part)[DP_KB][64][4], const float (&v)[DP_KB * 4]) {
+#pragma unroll
+      for (int kb = 0; kb < DP_KB; ++kb)
+        *reinterpret_cast<float4*>(&part[j][kb][lane][0]) = make_float4(v[kb * 4], v[kb * 4 + 1], v[kb * 4 + 2], v[kb * 4 + 3]);
+    };
+    auto fail = [&]() { if (lane == 0) { S.dead = 1; __hip_atomic_store(err, 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } };
+    // W_p^T fragments of this wave's 16 output columns (j < 3): A[col 16 j + lr][cell 16 kb + 4 q + u of the quarter]
+    float4 wpA[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int col = 16 * min(j, 2) + lr;
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = L.Wp[(size_t)(cq * 64 + 16 * kb + 4 * q + u) * ldP + min(col, P - 1)];
+      asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+      wpA[kb] = dp_sel(col < P, make_float4(v[0], v[1], v[2], v[3]), make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    if (xg) {                                                      // x_0 for the prologue
+#pragma unroll
+      for (int i = 0; i < DP_TPW; ++i) {
+        if (!dp_sweep2(nullptr, gen, vm, edge(lx, 2 * rp + i) + (size_t)j * DP_SLOT, gen, vx, lane, err)) fail();
+        put(S.part_x[i][0], vx);
+      }
+    }
+    __syncthreads();                                               // P
+    if (S.dead) return;
+    const int t_end = cq == 0 ? T + 1 : T;
+    for (int t = 0; t < t_end; ++t) {
+#pragma unroll
+      for (int i = 0; i < DP_TPW; ++i) {
+        const int r = 2 * rp + i, r0 = 16 * r;
+        const gu64* gm = edge(l, r) + (size_t)j * DP_SLOT;
+        const gu64* gx = edge(lx, r) + (size_t)j * DP_SLOT;
+        gu64* gout = edge(l, r) + (size_t)cq * DP_SLOT;
+        const bool wm = t > 0, wx = xg && t + 1 < T;
+        if (wm || wx) {
+          if (!dp_sweep2(wm ? gm + (size_t)(t - 1) * slot_stride_t : nullptr, gen, vm,
+                         wx ? gx + (size_t)(t + 1) * slot_stride_t : nullptr, gen, vx, lane, err)) fail();
+          if (wm) put(S.part_m[i], vm);
+          if (wx) put(S.part_x[i][(t + 1) & 1], vx);
+        }
+        __syncthreads();                                           // A(t, i)
+        if (S.dead) return;
+        if (t < T) {
+          __syncthreads();                                         // B(t, i): the h tile and the stash of (t, i) are in LDS
+          if (j < 3) {
+            f32x4 pm = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+              const float4 af = *reinterpret_cast<const float4*>(&S.stage[5][lr * DP_HS + 16 * kb + 4 * q]);
+              pm = __builtin_amdgcn_mfma_f32_16x16x4f32(wpA[kb].x, af.x, pm, 0, 0, 0);
+              pm = __builtin_amdgcn_mfma_f32_16x16x4f32(wpA[kb].y, af.y, pm, 0, 0, 0);
+              pm = __builtin_amdgcn_mfma_f32_16x16x4f32(wpA[kb].z, af.z, pm, 0, 0, 0);
+              pm = __builtin_amdgcn_mfma_f32_16x16x4f32(wpA[kb].w, af.w, pm, 0, 0, 0);
+            }
+            gu64* go_ = gout + (size_t)t * slot_stride_t + ((size_t)j * 64 + lane) * 4;
+            dp_store2(go_, gen, pm[0], pm[1]);
+            dp_store2(go_ + 2, gen, pm[2], pm[3]);
+          } else {
+            // gather wave 3 writes the phase's stash from its LDS stage: whole 256-byte rows (read before this wave arrives at the next barrier)
+            const int c4 = (lane & 15) * 4, rr = lane >> 4;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const int row = 4 * rg + rr;
+              const size_t grow = (size_t)t * N + r0 + row;
+#pragma unroll
+              for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(L.gates + grow * H4 + g * H + cq * 64 + c4) = *reinterpret_cast<const float4*>(&S.stage[g][row * DP_HS + c4]);
+              *reinterpret_cast<float4*>(L.c + (grow + N) * H + cq * 64 + c4) = *reinterpret_cast<const float4*>(&S.stage[4][row * DP_HS + c4]);
+              *reinterpret_cast<float4*>(L.h + grow * L.ldH + cq * 64 + c4) = *reinterpret_cast<const float4*>(&S.stage[5][row * DP_HS + c4]);
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  // ---------------- compute waves: 0-3 take tile 0, 8-11 tile 1 ----------------
+  const int wc = w & 3;
+  auto compute = [&](auto my_c) {
+  constexpr int my = decltype(my_c)::value;
+  const int cell = cq * 64 + 16 * wc + lr;                          // (fragment loads: the cell of this lane's A rows)
+  const int cb = cq * 64 + 16 * wc + 4 * q;                         // this lane's four cells in the accumulator layout
+  const int rowb = 32 * rp + 16 * my + lr;
+  if (my == 0) {                                                    // one copy of the K_h fragments serves both tiles
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int kb = 0; kb < DP_KB; ++kb) {
+        float vh[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vh[u] = L.K[(size_t)(I + min(16 * kb + 4 * q + u, P - 1)) * H4 + g * H + cell];
+        asm volatile("" : "+v"(vh[0]), "+v"(vh[1]), "+v"(vh[2]), "+v"(vh[3]));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vh[u] = 16 * kb + 4 * q + u < P ? vh[u] : 0.f;
+        *reinterpret_cast<float4*>(&S.kh_lds[wc][g][kb][lane][0]) = make_float4(vh[0], vh[1], vh[2], vh[3]);
+      }
+  }
+  if (my == 0 && lane < 16) {                                       // bias and peepholes of this wave's 16 cells -> LDS
+    const int c_ = cq * 64 + 16 * wc + lane;
+    *reinterpret_cast<float4*>(&S.bp[16 * wc + lane][0]) = make_float4(L.bias[c_], L.bias[H + c_], L.bias[2 * H + c_], L.bias[3 * H + c_]);
+    *reinterpret_cast<float4*>(&S.bp[16 * wc + lane][4]) = make_float4(L.wi[c_], L.wf[c_], L.wo[c_], 0.f);
+  }
+  const float* const bpl = &S.bp[16 * wc + 4 * q][0];               // + 8 u: cell cb + u
+  const int lenF = a.len[rowb];
+  float cp[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 mf[DP_KB];
+#pragma unroll
+  for (int kb = 0; kb < DP_KB; ++kb) mf[kb] = make_float4(0.f, 0.f, 0.f, 0.f);
+  *reinterpret_cast<float4*>(L.c + (size_t)rowb * H + cb) = make_float4(0.f, 0.f, 0.f, 0.f);       // slot 0 of the carried states is zero (cell.zero_state)
+  if (cq == 0 && wc == 0) {
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb)
+      if (16 * kb + 4 * q < P) *reinterpret_cast<float4*>(L.mst + (size_t)rowb * ldP + 16 * kb + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  f32x4 accn[4];
+  float4 xn[DP_KB];
+  auto load_x = [&](int t) {
+    const float* xr = L.in + ((size_t)t * N + rowb) * L.ldI;
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb) xn[kb] = *reinterpret_cast<const float4*>(xr + min(16 * kb + 4 * q, I - 4));
+  };
+  auto sum_parts = [&](float (*part)[DP_KB][64][4], int width, float4 (&s_)[DP_KB]) {
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb) {
+      const float4 p0 = *reinterpret_cast<const float4*>(&part[0][kb][lane][0]), p1 = *reinterpret_cast<const float4*>(&part[1][kb][lane][0]);
+      const float4 p2 = *reinterpret_cast<const float4*>(&part[2][kb][lane][0]), p3 = *reinterpret_cast<const float4*>(&part[3][kb][lane][0]);
+      s_[kb] = dp_sel(16 * kb + 4 * q < width,
+                      make_float4(((p0.x + p1.x) + p2.x) + p3.x, ((p0.y + p1.y) + p2.y) + p3.y, ((p0.z + p1.z) + p2.z) + p3.z,
+                                  ((p0.w + p1.w) + p2.w) + p3.w), make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+  };
+  // x-part of step t: accn = bias + x_t . K_x (the K_x fragments of this wave's cells: requested here, 12 KB out of the L2)
+  const float* const kxp = L.K + cell;                              // + (16 kb + 4 q + u) * H4 + g * H
+  auto next_x = [&](int t) {
+    const float* kq = kxp;
+    asm volatile("" : "+v"(kq));                                    // (opaque: hoisted out of the loop the fragments are 48 registers held forever)
+    float4 kx[DP_KB][4];
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = kq[(size_t)min(16 * kb + 4 * q + u, I - 1) * H4 + g * H];
+        kx[kb][g] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    float4 xs[DP_KB];
+    if (xg) {
+      sum_parts(S.part_x[my][t & 1], I, xs);
+      const bool livex = l == 0 || t < lenF;                        // dynamic_rnn's OUTPUT is zero past the row's length; the stack's input is not masked
+#pragma unroll
+      for (int kb = 0; kb < DP_KB; ++kb) xs[kb] = dp_sel(livex, xs[kb], make_float4(0.f, 0.f, 0.f, 0.f));
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < DP_KB; ++kb) xs[kb] = dp_sel(16 * kb + 4 * q < I, xn[kb], make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4 bq = *reinterpret_cast<const float4*>(bpl + 8 * u);
+      accn[0][u] = bq.x; accn[1][u] = bq.y; accn[2][u] = bq.z; accn[3][u] = bq.w;
+    }
+    // (rows k >= I of the fragments repeat row I - 1: the x values there are zero)
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(kx[kb][g].x, xs[kb].x, accn[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(kx[kb][g].y, xs[kb].y, accn[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(kx[kb][g].z, xs[kb].z, accn[g], 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) accn[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(kx[kb][g].w, xs[kb].w, accn[g], 0, 0, 0);
+    }
+  };
+  auto store_m = [&](int t, const float4 (&mnew)[DP_KB], bool live_prev) {
+    if (cq != 0 || wc != 0) return;
+#pragma unroll
+    for (int kb = 0; kb < DP_KB; ++kb)
+      if (16 * kb + 4 * q < P) {
+        *reinterpret_cast<float4*>(L.mst + ((size_t)t * N + rowb) * ldP + 16 * kb + 4 * q) = mf[kb];
+        *reinterpret_cast<float4*>(L.out + ((size_t)(t - 1) * N + rowb) * ldP + 16 * kb + 4 * q) =
+            dp_sel(live_prev, mnew[kb], make_float4(0.f, 0.f, 0.f, 0.f));
+      }
+  };
+
+  if (!xg) load_x(0);
+  __syncthreads();                                                 // P
+  if (S.dead) return;
+  next_x(0);
+  if (!xg) load_x(min(1, T - 1));
+
+  for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int i = 0; i < DP_TPW; ++i) {
+      __syncthreads();                                             // A(t, i)
+      if (S.dead) return;
+      if (i == my) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = accn[g];
+        if (t > 0) {
+          float4 ms[DP_KB];
+          sum_parts(S.part_m[my], P, ms);
+          const bool live_prev = (t - 1) < lenF;
+#pragma unroll
+          for (int kb = 0; kb < DP_KB; ++kb) mf[kb] = dp_sel(live_prev, ms[kb], mf[kb]);
+          store_m(t, ms, live_prev);
+        }
+#pragma unroll
+        for (int kb = 0; kb < DP_KB; ++kb) {
+          float4 kh[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) kh[g] = *reinterpret_cast<const float4*>(&S.kh_lds[wc][g][kb][lane][0]);
+          const float mv[4] = {mf[kb].x, mf[kb].y, mf[kb].z, mf[kb].w};
+          const float* khf = &kh[0].x;
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(khf[4 * g + u], mv[u], acc[g], 0, 0, 0);
+        }
+        // the cell, in the accumulator layout: lane = row lr, cells cb .. cb+3
+        const bool live = t < lenF;
+        float hv[4], sg[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float4 pw = *reinterpret_cast<const float4*>(bpl + 8 * u + 4);      // {w_i, w_f, w_o} of cell cb + u
+          const float cpv = cp[u];
+          const float gi = dp_sigmoid(acc[0][u] + pw.x * cpv);
+          const float gf = dp_sigmoid(acc[2][u] + a.forget_bias + pw.y * cpv);
+          const float gj = dp_tanh(acc[1][u]);
+          const float cn = gf * cpv + gi * gj;
+          const float go = dp_sigmoid(acc[3][u] + pw.z * cn);
+          const float hh = go * dp_tanh(cn);
+          hv[u] = live ? hh : 0.f;
+          sg[0][u] = live ? gi : 0.f; sg[1][u] = live ? gj : 0.f; sg[2][u] = live ? gf : 0.f; sg[3][u] = live ? go : 0.f;
+          cp[u] = live ? cn : cpv;
+        }
+        {
+          const int so = lr * DP_HS + 16 * wc + 4 * q;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(&S.stage[g][so]) = make_float4(sg[g][0], sg[g][1], sg[g][2], sg[g][3]);
+          *reinterpret_cast<float4*>(&S.stage[4][so]) = make_float4(cp[0], cp[1], cp[2], cp[3]);
+          *reinterpret_cast<float4*>(&S.stage[5][so]) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+        }
+        __syncthreads();                                           // B(t, i)
+      } else {
+        // the other tile's phase: my tile's x-part of the step it runs next -- step t + 1 behind my phase (t, 0), step t in front of my phase (t, 1)
+        const int tn = my == 0 ? t + 1 : t;
+        if (tn < T && (my == 0 || t > 0)) {
+          next_x(tn);
+          if (!xg) load_x(min(tn + 1, T - 1));
+        }
+        __syncthreads();                                           // B(t, i), the other tile's
+      }
+    }
+  }
+  if (cq == 0) {                                                   // the last step's m (block-uniform branch)
+#pragma unroll
+    for (int i = 0; i < DP_TPW; ++i) {
+      __syncthreads();                                             // A(T, i)
+      if (S.dead) return;
+      if (i == my) {
+        float4 ms[DP_KB];
+        sum_parts(S.part_m[my], P, ms);
+        const bool live_prev = (T - 1) < lenF;
+#pragma unroll
+        for (int kb = 0; kb < DP_KB; ++kb) mf[kb] = dp_sel(live_prev, ms[kb], mf[kb]);
+        store_m(T, ms, live_prev);
+      }
+    }
+  }
+  };
+  if (w < 4) compute(std::integral_constant<int, 0>{}); else compute(std::integral_constant<int, 1>{});
+}

@@ -174,6 +174,7 @@ bool dpersist_supported(const DPersistArgs& a);
 int dpersist_grid(int nl, int N);                 // workgroups of a launch over N rows
 size_t dpersist_lds_bytes();
 void launch_dlstm_fwd(const DPersistArgs& a, hipStream_t s);
+void launch_dlstm_fwd_t(const DPersistArgs& a, hipStream_t s);    // the 2-tile, 12-wave form (N % 32 == 0), stand-alone
 void launch_dlstm_bwd(const DPersistArgs& a, hipStream_t s);      // gates: activations in, dz out; needs c, dmt, dout_top
 // ---- persistent generator recurrence (gpersist.hip): the forward pass of a stack of large projected LSTM cells ----
 constexpr int GP_MAXL = 4;

@@ -979,7 +979,8 @@ bool Model::persist_forward(Chain& ch, int T, hipStream_t s) {
     D_.in = l == 0 ? R.in : nullptr;                   // (layer 0's input product runs inside the launch as well)
   }
   if (!dpersist_supported(a) || dpersist_grid(a.nl, a.N) > dp_max_grid || dpersist_granule_bytes(a.nl, a.N, a.T) > dp_gran_bytes) return false;
-  launch_dlstm_fwd(a, s);
+  static const bool fwd_t_env = [] { const char* e = getenv("RSRGAN_DFWD_T"); return e && atoi(e) != 0; }();
+  if (fwd_t_env && a.N % 32 == 0) launch_dlstm_fwd_t(a, s); else launch_dlstm_fwd(a, s);
   return true;
 }
 
