@@ -728,6 +728,7 @@ void launch_dlstm_fwd_t(const DPersistArgs& a, hipStream_t s) {
   ++g_chain_launches;
 }
 
+size_t dpersist_fwdt_lds_bytes() { return sizeof(DpFwdTLds); }
 int dpersist_trail_grid(int nl, int N) { return nl * (N / 32) * DP_NQ + N / 16; }
 size_t dpersist_trail_lds_bytes() { return sizeof(DpTrailLds); }
 bool dpersist_trail_supported(const DPersistArgs& a) {

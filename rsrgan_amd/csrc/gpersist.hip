@@ -343,7 +343,7 @@ struct GpLds {
 // chunk of s_{l-1}(t) (layer 0: the input rows in memory; above: what the same-numbered reducer of the layer below published a step
 // ago), writes it to res_out and publishes it in the second region of gran2, where the layer above's X waves gather their x(t).
 template <int NT, int PROG, bool RES, bool TAG>
-__device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S, const unsigned c1) {
+__device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S, const unsigned c1, const unsigned bid) {
   static_assert(!(TAG && PROG), "the progressive sweeps know the sentinel form only");
   constexpr int NR = GP_NR, NU = NT * NR, CW = 4 * NT;
   GPT_DECL
@@ -354,7 +354,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
 #endif
   // block -> (row group, layer, slice): block b runs on XCD b & 7 (observed; speed only) -- a row group owns 8 / groups XCDs
   const int ngr = a.N / GP_ROWS, xpg = 8 / ngr;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int xcd = bid & 7, slot = bid >> 3;
   const int grp = xcd / xpg, idx = slot * xpg + (xcd % xpg);
   if (idx >= a.nl * a.NC) return;
   const int l = idx / a.NC, c = idx - l * a.NC;
@@ -400,7 +400,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
   auto fail = [&]() {
     if (lane == 0) {
       __hip_atomic_store(&S.dead, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_store(err, 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(err, 1u + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   };
 
@@ -751,7 +751,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
       }
       const f32x4 s4 = (t < rlen ? tot : f32x4{0.f, 0.f, 0.f, 0.f}) + sb;
       if (act && rcol < ldP) *reinterpret_cast<float4*>(L.res_out + ((size_t)t * N + rrow) * ldP + rcol) = make_float4(s4[0], s4[1], s4[2], s4[3]);
-      if (act && l + 1 < a.nl) gp_store(b2s, off, s4);
+      if (act && (l + 1 < a.nl || a.fwd_trail)) gp_store(b2s, off, s4);      // (the top layer's: for the FC workgroups of k_glstm_fwd_dt)
     }
   }
 #ifdef GP_TRACE
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_fwd(const GPersistAr
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (counts launches; nothing depends on it)
   // (TAG) steps written to the hop-1 ring by the launches so far, mod 2 GP_R1: every workgroup reads it here, the last one to finish moves it on
   const unsigned c1 = TAG ? __hip_atomic_load(ctl + GP_CTL_C1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-  gp_fwd_body<NT, PROG, RES, TAG>(a, S, c1);
+  gp_fwd_body<NT, PROG, RES, TAG>(a, S, c1, blockIdx.x);
   __syncthreads();                                                 // (every wave leaves the body on every path)
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -799,6 +799,169 @@ __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_fwd(const GPersistAr
 // is a time-batched GEMM over the dz stash afterwards.
 // Cell gradient: kernels.hip k_bwd_a2 (peepholes, o's peephole on the new c, dynamic_rnn masking: a finished row has dz = 0 and
 // carries dc through).
+
+// ---- k_glstm_fwd_dt: the generator's forward recurrence with the discriminator's (D(G(x))) a few steps behind it, ONE launch ----
+// The FC workgroup of 16-row tile fr follows the generator's top layer: per step it takes the layer's 18 all-gathered chunks of m(t) (RES:
+// of the running sum s_top(t)) as they are published (hop-2 slots: valid when no word carries the armed pattern), forms
+// y(t) = m(t) . W_out + b (models/lstm.py:121-124) on four waves -- wave w the k-blocks w, w + 4, ..: a partial sum each, which is
+// exactly what layer 0 of the discriminator's stack expects from "the layer below" (dpersist_dev.h dp_fwdt_body, xin): four partials as
+// generation-tagged granules (bias on wave 0's, gaussian_noise_layer's row noise on wave 1's) -- and three more waves sum the partials
+// into y(t) for memory (the mse term, the output FC's gradients) and y(t) + noise (the discriminator's input rows).
+struct GpFcLds { float yp[2][4][DP_KB][64][4]; int dead; };
+__device__ __forceinline__ void gp_fcf_body(const GPersistArgs& a, const DPersistArgs& d, const unsigned dgen, GpFcLds& S, const int fr, const bool res) {
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (w >= 7) return;                                              // (seven waves; a barrier counts the surviving waves)
+  const int T = a.T, N = d.N, Dn = d.L[0].I, K = d.fc_P, RTn = N >> 4;
+  const int grp = fr >> 1, r = fr & 1, ltop = a.nl - 1, nkb = (K + 15) >> 4;
+  const int ngr = a.N / GP_ROWS;
+  gu32* err = (gu32*)d.ctl + DP_CTL_ERR;
+  gu32* gerr = (gu32*)a.ctl + DP_CTL_ERR;
+  const size_t g2_per = (size_t)GP_NCH * GP_SLOT;
+  const char* const g2 = res ? (const char*)a.gran2 + (size_t)ngr * a.nl * T * g2_per : (const char*)a.gran2;
+  const GpBuf b2 = gp_buf(g2 + (size_t)(grp * a.nl + ltop) * T * g2_per, (size_t)T * g2_per);
+  const size_t slot_stride_t = (size_t)DP_NQ * DP_SLOT;
+  gu64* const gout = (gu64*)d.gran + ((size_t)(d.nl * RTn + fr) * T) * slot_stride_t;      // edge nl: layer 0's input
+  const int row = 16 * fr + lr;
+  auto fail = [&]() { if (lane == 0) { S.dead = 1; __hip_atomic_store(err, 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } };
+  if (w < 4) {
+    // A operand: W_out[k = 16 jb + 4 q + u][p = 16 ct + lr], jb = w + 4 n (zero beyond K rows / Dn columns)
+    float4 wA[5][DP_KB];
+#pragma unroll
+    for (int n = 0; n < 5; ++n)
+#pragma unroll
+      for (int ct = 0; ct < DP_KB; ++ct) {
+        float v[4];
+        const int p = 16 * ct + lr;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = d.fc_w[(size_t)min(16 * (w + 4 * n) + 4 * q + u, K - 1) * d.ld_fcw + min(p, Dn - 1)];
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (16 * (w + 4 * n) + 4 * q + u < K && p < Dn) ? v[u] : 0.f;
+        wA[n][ct] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    // what this wave's partial carries beside the product: wave 0 the bias, wave 1 the row noise (p = 16 ct + 4 q + i of row lr)
+    float4 add[DP_KB];
+#pragma unroll
+    for (int ct = 0; ct < DP_KB; ++ct) {
+      const int p = min(16 * ct + 4 * q, Dn - 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (w == 0) v = *reinterpret_cast<const float4*>(d.fc_b + p);
+      if (w == 1 && d.noise) v = *reinterpret_cast<const float4*>(d.noise + (size_t)row * Dn + p);
+      add[ct] = dp_sel(16 * ct + 4 * q < Dn, v, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+      // this wave's chunks of step t: all in flight, valid when no word carries the armed pattern
+      u32x4 x[5];
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      for (unsigned polls = 0;; ++polls) {
+        bool ok = true;
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+          const int jb = min(w + 4 * n, nkb - 1);
+          x[n] = __builtin_amdgcn_raw_buffer_load_b128(b2.rs, (unsigned)((((size_t)t * GP_NR + r) * GP_NKB + jb) * GP_SLOT) + (unsigned)lane * 16u, 0, GP_SC1 | GP_VOL);
+        }
+#pragma unroll
+        for (int n = 0; n < 5; ++n) ok &= gp_valid(x[n]);
+        if (__all(ok)) break;
+        asm volatile("" ::: "memory");
+        if ((polls & 63) == 63 && (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                                   __hip_atomic_load(gerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { fail(); break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      f32x4 acc[DP_KB];
+#pragma unroll
+      for (int ct = 0; ct < DP_KB; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int n = 0; n < 5; ++n) {
+        if (w + 4 * n < nkb) {                                      // (wave-uniform)
+          const float bz[4] = {__uint_as_float(x[n][0]), __uint_as_float(x[n][1]), __uint_as_float(x[n][2]), __uint_as_float(x[n][3])};
+#pragma unroll
+          for (int ct = 0; ct < DP_KB; ++ct) {
+            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[n][ct].x, bz[0], acc[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[n][ct].y, bz[1], acc[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[n][ct].z, bz[2], acc[ct], 0, 0, 0);
+            acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[n][ct].w, bz[3], acc[ct], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int ct = 0; ct < DP_KB; ++ct) {
+        *reinterpret_cast<f32x4*>(&S.yp[t & 1][w][ct][lane][0]) = acc[ct];
+        gu64* go_ = gout + (size_t)t * slot_stride_t + (size_t)w * DP_SLOT + ((size_t)ct * 64 + lane) * 4;
+        dp_store2(go_, dgen, acc[ct][0] + add[ct].x, acc[ct][1] + add[ct].y);
+        dp_store2(go_ + 2, dgen, acc[ct][2] + add[ct].z, acc[ct][3] + add[ct].w);
+      }
+      __syncthreads();                                             // yp[t & 1] is complete (and the summing waves have left yp of step t - 1)
+      if (S.dead) return;
+    }
+    return;
+  }
+  // waves 4..6: column tile ct of y(t) for memory: p = 16 ct + 4 q + i of row lr
+  const int ct = w - 4, p0 = 16 * ct + 4 * q;
+  float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), nz = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p0 < Dn) {
+    bb = *reinterpret_cast<const float4*>(d.fc_b + p0);
+    if (d.noise) nz = *reinterpret_cast<const float4*>(d.noise + (size_t)row * Dn + p0);
+  }
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    __syncthreads();
+    if (S.dead) return;
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(&S.yp[t & 1][0][ct][lane][0]), s1 = *reinterpret_cast<const f32x4*>(&S.yp[t & 1][1][ct][lane][0]);
+    const f32x4 s2 = *reinterpret_cast<const f32x4*>(&S.yp[t & 1][2][ct][lane][0]), s3 = *reinterpret_cast<const f32x4*>(&S.yp[t & 1][3][ct][lane][0]);
+    const f32x4 y = (((s0 + s1) + s2) + s3) + f32x4{bb.x, bb.y, bb.z, bb.w};
+    if (p0 < Dn) {
+      *reinterpret_cast<float4*>(d.dy + ((size_t)t * N + row) * d.ld_dy + p0) = make_float4(y[0], y[1], y[2], y[3]);
+      *reinterpret_cast<float4*>(d.dtop + ((size_t)t * d.xd_Ns + d.xd_row0 + row) * d.ld_dtop + p0) = make_float4(y[0] + nz.x, y[1] + nz.y, y[2] + nz.z, y[3] + nz.w);
+    }
+  }
+}
+
+template <int NT>
+union GpFdtLds { GpLds<NT> g; DpFwdTLds d; GpFcLds f; };
+template <int NT, bool RES, bool TAG>
+__global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_fwd_dt(const GPersistArgs a, const DPersistArgs d) {
+  __shared__ __attribute__((aligned(16))) GpFdtLds<NT> S;
+  const int nD = d.nl * (d.N >> 5) * DP_NQ, nReal = nD + (d.N >> 4), dt_pad = (nReal + 7) & ~7;
+  const int dbid = (int)blockIdx.x;
+  if (dbid < dt_pad) {
+    if (dbid >= nReal) return;
+    gu32* dctl = (gu32*)d.ctl;
+    const unsigned dgen = __hip_atomic_load(dctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) { if (dbid < nD) S.d.dead = 0; else S.f.dead = 0; }
+    __syncthreads();
+    if (dbid < nD) dp_fwdt_body(d, dgen, S.d, dbid, true);
+    else gp_fcf_body(a, d, dgen, S.f, dbid - nD, RES);
+    if (threadIdx.x == 0) {
+      const unsigned old = __hip_atomic_fetch_add(dctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == (unsigned)nReal - 1u) {
+        if (__hip_atomic_load(dctl + DP_CTL_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) d.L[d.nl - 1].out[0] = __builtin_nanf("");
+        __hip_atomic_store(dctl + DP_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dctl + DP_CTL_GEN, dgen + 1u == 0u ? 1u : dgen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  }
+  gu32* ctl = (gu32*)a.ctl;
+  const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned c1 = TAG ? __hip_atomic_load(ctl + GP_CTL_C1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  gp_fwd_body<NT, 0, RES, TAG>(a, S.g, c1, blockIdx.x - (unsigned)dt_pad);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == gridDim.x - (unsigned)dt_pad - 1u) {
+      if (TAG) __hip_atomic_store(ctl + GP_CTL_C1, (c1 + (unsigned)a.T) % (2u * GP_R1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_load(ctl + DP_CTL_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        a.L[a.nl - 1].out[0] = __builtin_nanf("");
+      __hip_atomic_store(ctl + DP_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned g1 = gen + 1u;
+      __hip_atomic_store(ctl + DP_CTL_GEN, g1 >= (1u << 21) ? 1u : g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 #ifndef GP_XR_STEPS
 #define GP_XR_STEPS 6
 #endif
@@ -2214,6 +2377,16 @@ void launch_glstm_bwd_dt(const GPersistArgs& a, const DPersistArgs& d, hipStream
     else hipLaunchKernelGGL((k_glstm_bwd_dt<5, false, true>), g, b, 0, s, a, d);
   } else if (a.res) hipLaunchKernelGGL((k_glstm_bwd_dt<5, true, false>), g, b, 0, s, a, d);
   else hipLaunchKernelGGL((k_glstm_bwd_dt<5, false, false>), g, b, 0, s, a, d);
+  g_chain_launches += 2;
+}
+void launch_glstm_fwd_dt(const GPersistArgs& a, const DPersistArgs& d, hipStream_t s) {
+  (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_gran2_bytes(a), s);
+  const dim3 g(gpersist_dt_grid(a, d)), b(GP_WAVES * 64);
+  if (a.tags) {
+    if (a.res) hipLaunchKernelGGL((k_glstm_fwd_dt<5, true, true>), g, b, 0, s, a, d);
+    else hipLaunchKernelGGL((k_glstm_fwd_dt<5, false, true>), g, b, 0, s, a, d);
+  } else if (a.res) hipLaunchKernelGGL((k_glstm_fwd_dt<5, true, false>), g, b, 0, s, a, d);
+  else hipLaunchKernelGGL((k_glstm_fwd_dt<5, false, false>), g, b, 0, s, a, d);
   g_chain_launches += 2;
 }
 void launch_glstm_bwd(const GPersistArgs& a, hipStream_t s) {

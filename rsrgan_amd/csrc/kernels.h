@@ -165,6 +165,13 @@ struct DPersistArgs {
   const float* fc_w;
   float* dtop;
   int ld_dy, ld_fcw, ld_dtop, fc_P;
+  // the trailing form of the FORWARD launch (inside gpersist.hip k_glstm_fwd_dt: D(G(x)) a few steps behind the generator): the FC
+  // workgroups form y(t) = m_top(t) . fc_w + fc_b from the generator's top-layer chunks (fc_w [fc_P][ld_fcw], y -> dy [T][N][ld_dy]),
+  // hand y(t) + noise to layer 0 as four partial sums and write it to dtop [T][xd_Ns][ld_dtop] at rows xd_row0.. (the input rows the
+  // discriminator's weight gradients read); noise [N][I] or null
+  const float* fc_b;
+  const float* noise;
+  int xd_Ns, xd_row0;
 };
 size_t dpersist_granule_bytes(int nl, int N, int T);
 int dpersist_trail_grid(int nl, int N);
@@ -211,11 +218,15 @@ struct GPersistArgs {
   // dout_top is being written WHILE this launch runs (dpersist.hip k_dlstm_bwd_trail, the G-run): armed with 0xFF bytes, the top
   // layer's reducers poll their 16-byte piece of a step past the caches until no word carries that pattern
   int dout_trail;
+  // k_glstm_fwd_dt: the discriminator's forward recurrence follows inside this launch (RES: the top layer publishes its running sum too)
+  int fwd_trail;
 };
 constexpr int GP_TMAX = 2046;                     // longest launch (slot offsets are 32-bit; a longer batch takes the launch-per-phase path)
 bool gpersist_plan(GPersistArgs& a);              // fills NT / NC; false: shape not supported
 int gpersist_grid(const GPersistArgs& a);         // workgroups of a launch (all must be resident at once)
-int gpersist_dt_grid(const GPersistArgs& a, const DPersistArgs& d);      // ... of k_glstm_bwd_dt
+int gpersist_dt_grid(const GPersistArgs& a, const DPersistArgs& d);      // ... of k_glstm_bwd_dt / k_glstm_fwd_dt
+void launch_glstm_fwd_dt(const GPersistArgs& a, const DPersistArgs& d, hipStream_t s);   // the generator's forward recurrence with D(G(x)) trailing it (ONE launch; a.fwd_trail = 1)
+size_t dpersist_fwdt_lds_bytes();
 void launch_glstm_bwd_dt(const GPersistArgs& a, const DPersistArgs& d, hipStream_t s);   // the generator's BPTT with the discriminator's trailing BPTT in front (ONE launch; a.dout_trail = 1, d.dtop armed)
 size_t gpersist_lds_bytes();                      // LDS of a workgroup (the larger of the two kernels')
 int device_cu_count();                            // hipDeviceProp_t::multiProcessorCount of the current device (queried once)

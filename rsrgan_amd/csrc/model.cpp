@@ -1074,6 +1074,38 @@ bool Model::persist_forward_g(int T, hipStream_t s) {
   return true;
 }
 
+// The generator's forward recurrence with D(G(x)) a few steps behind it as ONE launch (gpersist.hip k_glstm_fwd_dt): the G-run of a
+// schedule that recomputes the generator's forward (gen_updates > 1: run_gan_rnn_placeholder.sh:130): y, the discriminator's input rows
+// (y + noise) and both stashes are complete behind it.  False: not applicable (the caller runs the launches one after the other).
+bool Model::persist_forward_g_trail(Chain& ch, int T, hipStream_t s, const float* nf) {
+  static const bool env = [] { const char* e = getenv("RSRGAN_TRAIL_FWD"); return !e || atoi(e) != 0; }();
+  if (!env || !trail_fits || !gp_fwd_on() || gp_noproj || !wavefront() || seq_drop_on() || !dp_gran || !(dp_env & 1) || ch.size() != dl.size()) return false;
+  GPersistArgs a{};
+  if (!gpersist_args(a, T) || gpersist_gran2_bytes(a) > gp_gran2_bytes) return false;
+  a.L[0].in = g_ins[0];
+  a.fwd_trail = 1;
+  DPersistArgs d{};
+  d.nl = (int)ch.size(); d.N = ch[0].N; d.T = T; d.H = dl[0].H; d.len = ch[0].len;
+  d.gran = dp_gran; d.ctl = dp_ctl; d.forget_bias = cfg.forget_bias;
+  for (size_t l = 0; l < ch.size(); ++l) {
+    const LayerRun& R = ch[l]; const LstmLayer& L = dl[l]; const LstmStash& S = d_st[l];
+    if (R.L != &L || R.S != &S || R.res_in || R.res_out || R.row0 != 0 || R.Ns != R.N || R.N != d.N || !L.has_proj || L.H != d.H) return false;
+    if (l > 0 && R.in != d_st[l - 1].out) return false;
+    DPersistLayer& D_ = d.L[l];
+    D_.K = D.W(L.tK); D_.bias = D.W(L.tb); D_.wi = D.W(L.twi); D_.wf = D.W(L.twf); D_.wo = D.W(L.two); D_.Wp = D.W(L.tWp);
+    D_.gates = S.gates; D_.c = S.c; D_.h = S.h; D_.mst = S.mst; D_.out = S.out;
+    D_.I = L.I; D_.P = L.P; D_.ldP = L.ldP; D_.ldH = L.ldH; D_.ldI = L.ldI;
+    D_.in = l == 0 ? R.in : nullptr;
+  }
+  if (ch[0].in != xd || d.N != B || B % 32 != 0 || dl[0].I != Dout || Dout % 4 != 0 || !dpersist_supported(d)) return false;
+  if (dpersist_granule_bytes(d.nl + 1, d.N, d.T) / 2 > dp_gran_bytes) return false;      // (one edge per layer and one for layer 0's input)
+  d.dy = y_tm; d.ld_dy = ldDout; d.fc_w = G.W(g_fc_out_w); d.ld_fcw = ldDout; d.fc_P = gR; d.fc_b = G.W(g_fc_out_b);
+  d.noise = nf; d.dtop = xd; d.ld_dtop = ldDout; d.xd_Ns = B; d.xd_row0 = 0;
+  launch_glstm_fwd_dt(a, d, s);
+  g_fwd_valid = true;
+  return true;
+}
+
 // BPTT through the generator's stack as ONE persistent launch (gpersist.hip k_glstm_bwd): dz over the gate activations of every
 // layer's stash, dm per step in dmt.  Layer 0's input gradient (the input FC's d(h0)) is one GEMM over the dz stash afterwards.
 bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only, const StreamFn& pre, const StreamFn& post) {
@@ -1846,12 +1878,20 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   if (trail_plan) (void)hipMemsetAsync(g_dA, 0xFF, (size_t)T * B * ldP * sizeof(float), s);
   bool g_done = false;
   if (!reuse && !wavefront()) g_forward(T, s);
+  bool d_trailed = false;      // D(G(x)) ran inside the generator's forward launch (k_glstm_fwd_dt): y, the discriminator's input rows and its stash are there
   if (!reuse && wavefront() && gp_fwd_on()) {
     g_forward_head(T, s);
-    g_done = persist_forward_g(T, s);
-    if (g_done) g_forward_tail(T, s);
+    if (!d_dnn()) {
+      Chain dch = d_chain(B, B, 0);
+      g_done = d_trailed = persist_forward_g_trail(dch, T, s, nf);
+    }
+    if (!g_done) {
+      g_done = persist_forward_g(T, s);
+      if (g_done) g_forward_tail(T, s);
+    }
   }
-  if (!reuse && wavefront() && !g_done) {
+  if (d_trailed) {
+  } else if (!reuse && wavefront() && !g_done) {
     // ONE forward wave: G's layers | per-step output FC (-> y_t and D's input rows, noise added) | D's layers
     if (!gp_fwd_on()) g_forward_head(T, s);
     std::vector<Chain> chains{g_chain(T)};

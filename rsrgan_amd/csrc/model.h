@@ -161,6 +161,7 @@ struct Model {
   // the G-run's discriminator BPTT in its trailing form (dpersist_dev.h): fills dt_args for the k_glstm_bwd_dt launch that
   // persist_backward_g makes next (gp_trail_next): dy += layer 0's input gradient, dtop = dy . W_out^T step by step
   bool persist_backward_trail(Chain& ch, int T, hipStream_t s, float* dy, int ld_dy, float* dtop, int ld_dtop, bool check_only = false);
+  bool persist_forward_g_trail(Chain& ch, int T, hipStream_t s, const float* nf);      // k_glstm_fwd_dt: the generator's forward recurrence + D(G(x)) behind it, one launch
   bool trail_fits = false;                                // both launches resident at once (resident_probe at init)
   bool gp_trail_next = false;                             // the next generator BPTT launch is k_glstm_bwd_dt (dt_args)
   int trail_mode = 1;                                     // RSRGAN_TRAIL: 0 off

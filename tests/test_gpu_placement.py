@@ -46,8 +46,9 @@ if os.environ.get("RSRGAN_TEST_SIDELOAD") == "1":
                 st.synchronize()
     side = threading.Thread(target=load, daemon=True); side.start()
     import time; time.sleep(0.3)
+_reuse = os.environ.get("RSRGAN_TEST_REUSE", "1") != "0"      # 0: the G-run recomputes the generator's forward (a second G-run of gen_updates = 2)
 for it in range(2):
-    d = np.ravel(model.d_step(x, lab, ln)); g = np.ravel(model.g_step(x, lab, ln, reuse_g_forward=True))
+    d = np.ravel(model.d_step(x, lab, ln)); g = np.ravel(model.g_step(x, lab, ln, reuse_g_forward=_reuse))
     out["d%%d" %% it] = [float(v) for v in d]; out["g%%d" %% it] = [float(v) for v in g]
 for i, Ti in enumerate(int(v) for v in os.environ.get("RSRGAN_TEST_TSEQ", "").split(",") if v):
     # batches of other lengths on the same handle (the outer loop's buckets): the ring positions of the persistent launches carry on
@@ -56,7 +57,8 @@ for i, Ti in enumerate(int(v) for v in os.environ.get("RSRGAN_TEST_TSEQ", "").sp
     d = np.ravel(model.d_step(xi, labi, lni)); g = np.ravel(model.g_step(xi, labi, lni, reuse_g_forward=True))
     out["sd%%d" %% i] = [float(v) for v in d]; out["sg%%d" %% i] = [float(v) for v in g]
 model.engine.profile_begin()
-model.d_step(x, lab, ln); model.g_step(x, lab, ln, reuse_g_forward=True)
+model.d_step(x, lab, ln); model.g_step(x, lab, ln, reuse_g_forward=_reuse)
+out["gp_n"] = int(model.engine.profile_read_kind(1)[0])           # k_glstm_fwd launches bracketed (k_glstm_fwd_dt is not)
 out["gb_flops"] = float(model.engine.profile_read_kind(2)[2])      # algorithmic FLOP of the generator's BPTT launch (k_glstm_bwd_dt counts the discriminator half too)
 model.engine.profile_read()
 out["chain_launches"] = int(model.engine.profile_launches())
@@ -162,6 +164,26 @@ def test_trailing_discriminator_bptt_agrees(B, T, net):
     b = _run(dict(size, RSRGAN_TRAIL="0"))
     assert a["device_status"] == 0 and b["device_status"] == 0
     assert a["gb_flops"] > b["gb_flops"] > 0, (a["gb_flops"], b["gb_flops"])      # the one launch carried the discriminator's products: that path ran
+    for k in ("d0", "g0", "d1", "g1"):
+        assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-7), (k, a[k], b[k])
+    assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
+    c = _run(dict(size))
+    assert a["vars_sha"] == c["vars_sha"]
+
+
+@pytest.mark.parametrize("B,T,net", [(32, 9, "lstm"), (64, 100, "lstm"), (32, 1, "lstm"), (32, 2, "lstm"), (32, 9, "res_lstm_l"), (8, 7, "res_lstm_l")])
+def test_trailing_discriminator_forward_agrees(B, T, net):
+    """Round 5: a G-run that recomputes the generator's forward (the second G-run of the shipped gen_updates = 2,
+    run_gan_rnn_placeholder.sh:130) runs D(G(x)) INSIDE the generator's forward launch (csrc/gpersist.hip k_glstm_fwd_dt: FC workgroups turn
+    the top layer's chunks into y(t) = m(t) . W_out + b step by step, the discriminator's recurrence -- two row tiles per workgroup,
+    csrc/dpersist_dev.h dp_fwdt_body -- follows a few steps behind) against generator launch, output-FC GEMM, noise kernel and
+    discriminator launch one after the other (RSRGAN_TRAIL_FWD=0).  The output FC is summed per quarter of its reduction: fp32 rounding
+    apart; reproducible; no failed wait; the stand-alone generator launch is gone from the G-run."""
+    size = {"RSRGAN_TEST_B": str(B), "RSRGAN_TEST_T": str(T), "RSRGAN_TEST_NET": net, "RSRGAN_PAD_ROWS": "1", "RSRGAN_TEST_REUSE": "0"}
+    a = _run(dict(size))
+    b = _run(dict(size, RSRGAN_TRAIL_FWD="0"))
+    assert a["device_status"] == 0 and b["device_status"] == 0
+    assert a["gp_n"] == b["gp_n"] - 1, (a["gp_n"], b["gp_n"])
     for k in ("d0", "g0", "d1", "g1"):
         assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-7), (k, a[k], b[k])
     assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
