@@ -460,6 +460,11 @@ def bench_segan(a, rank, local, world, dev):
 
 
 def main():
+    # The sequence benches keep their synthetic batch resident on the device (the contract: inputs in HBM when the timed region starts)
+    # and draw no discriminator noise (init_disc_noise_std = 0), so they can give the library the guarantee RSRGAN_DPIPE=1 asks for --
+    # labels and lengths of rsrgan_d_step are complete when the call is made: D(real) of the next D-run then runs beside the previous
+    # G-run's weight-gradient GEMMs and the D-run itself is one launch less on the chain.  RSRGAN_DPIPE=0 to compare.
+    os.environ.setdefault("RSRGAN_DPIPE", "1")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -617,7 +622,7 @@ def main():
                "config": {"workload": "gan_rnn_placeholder 1D+%dG step, G=%s(%dx%d/p%d)+D=%s(%dx%d/p%d), B=%d/GPU T=%d, "
                                       "257->40" % (a.gen_updates, g_type, c.g_layers, c.g_cells, c.g_proj, a.d_type, c.d_layers,
                                                    c.d_cells, c.d_proj, B, T),
-                          "schedule_flags": a.flags, "global_batch": B * world, "frames_per_step": B * T * world, "parallelism": "dp%d" % world,
+                          "schedule_flags": a.flags, "d_pipe": os.environ.get("RSRGAN_DPIPE", "0"), "global_batch": B * world, "frames_per_step": B * T * world, "parallelism": "dp%d" % world,
                           "losses_last_step": [round(float(v), 6) for v in losses]},
                "roofline": roof}
         if res.get("buckets"):

@@ -32,8 +32,14 @@ static int guard(const char* what, F&& body) {
 // against the caller's stream by events on both sides.
 struct StreamScope {
   Model& m; hipStream_t caller, work;
-  StreamScope(Model& m_, void* s) : m(m_), caller((hipStream_t)s), work(m_.enter((hipStream_t)s)) {}
-  ~StreamScope() { m.leave(caller, work); }
+  StreamScope(Model& m_, void* s) : m(m_), caller((hipStream_t)s), work(m_.enter((hipStream_t)s)) { m.last_work = work; }
+  ~StreamScope() {
+    // (RSRGAN_DPIPE) whatever this call did to the discriminator's weights, stash or input rows is complete behind this point -- unless
+    // the call has recorded the event itself, earlier (rsrgan_g_step / rsrgan_g_backward behind the fused backward launch)
+    if (m.dpipe && !m.dfree_inside) (void)hipEventRecord(m.ev_dfree, work);
+    m.dfree_inside = false;
+    m.leave(caller, work);
+  }
 };
 
 extern "C" {
@@ -322,9 +328,11 @@ int rsrgan_device_status(rsrgan_handle h, int32_t* code) {
   if (!code) { set_error("null output pointer"); return RSRGAN_ERR_INVALID; }
   Model& m = h->m;
   *code = 0;
-  if (m.main_s && hipStreamSynchronize(m.main_s) != hipSuccess) { set_error("hipStreamSynchronize failed"); return RSRGAN_ERR_HIP; }
+  // the streams this handle has worked on (not the whole device: other handles and other tenants are none of this call's business;
+  // see also gpersist.hip k_arm for what a device-wide synchronisation + blocking copy did to replayed fill nodes)
+  for (hipStream_t q : {m.main_s, m.last_work, m.side})
+    if (q && hipStreamSynchronize(q) != hipSuccess) { set_error("hipStreamSynchronize failed"); return RSRGAN_ERR_HIP; }
   if (!m.dp_ctl && !m.gp_ctl) return RSRGAN_OK;
-  if (hipDeviceSynchronize() != hipSuccess) { set_error("hipDeviceSynchronize failed"); return RSRGAN_ERR_HIP; }
   // the control blocks of the persistent recurrences (dpersist.hip, gpersist.hip): the first failure wins; a generator failure is
   // reported as 0x10000 + workgroup
   unsigned* blocks[2] = {m.dp_ctl, m.gp_ctl};

@@ -54,8 +54,9 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
   const DPersistLayer L = a.L[l];                                   // by value: the fields stay in SGPRs (a reference re-reads the kernarg every step)
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int H = a.H, H4 = 4 * H, T = a.T, N = a.N, P = L.P, ldP = L.ldP, I = L.I;
+  const int H = a.H, H4 = 4 * H, T = a.T, P = L.P, ldP = L.ldP, I = L.I;
   const int r0 = r * 16;
+  const int Ns = a.Ns ? a.Ns : a.N, rb = a.row0 + r0;      // (the rows of this launch inside a taller stash: stride Ns, first row row0; lengths are relative)
   gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
   if (tid == 0) dead = 0;
   const size_t slot_stride_t = (size_t)DP_NQ * DP_SLOT;
@@ -127,11 +128,11 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
 #pragma unroll
           for (int rg = 0; rg < 4; ++rg) {
             const int row = 4 * rg + rr;
-            const size_t grow = (size_t)t * N + r0 + row;
+            const size_t grow = (size_t)t * Ns + rb + row;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
               *reinterpret_cast<float4*>(L.gates + grow * H4 + g * H + cq * 64 + c4) = *reinterpret_cast<const float4*>(&stage[g][row * DP_HS + c4]);
-            *reinterpret_cast<float4*>(L.c + (grow + N) * H + cq * 64 + c4) = *reinterpret_cast<const float4*>(&stage[4][row * DP_HS + c4]);
+            *reinterpret_cast<float4*>(L.c + (grow + Ns) * H + cq * 64 + c4) = *reinterpret_cast<const float4*>(&stage[4][row * DP_HS + c4]);
             *reinterpret_cast<float4*>(L.h + grow * L.ldH + cq * 64 + c4) = *reinterpret_cast<const float4*>(&stage[5][row * DP_HS + c4]);
           }
         }
@@ -196,11 +197,11 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
 #pragma unroll
   for (int kb = 0; kb < DP_KB; ++kb) mf[kb] = make_float4(0.f, 0.f, 0.f, 0.f);
   // slot 0 of the carried states is zero (cell.zero_state)
-  *reinterpret_cast<float4*>(L.c + (size_t)(r0 + lr) * H + cb) = make_float4(0.f, 0.f, 0.f, 0.f);
+  *reinterpret_cast<float4*>(L.c + (size_t)(rb + lr) * H + cb) = make_float4(0.f, 0.f, 0.f, 0.f);
   if (cq == 0 && w == 0) {
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb)
-      if (16 * kb + 4 * q < P) *reinterpret_cast<float4*>(L.mst + (size_t)(r0 + lr) * ldP + 16 * kb + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (16 * kb + 4 * q < P) *reinterpret_cast<float4*>(L.mst + (size_t)(rb + lr) * ldP + 16 * kb + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
   // acc init of the next step: bias + x . K_x.  Layer 0's x is the stack's input, in memory before the launch: its rows travel as
@@ -209,7 +210,7 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
   f32x4 accn[4];
   float4 xn[DP_KB];
   auto load_x = [&](int t) {
-    const float* xr = L.in + ((size_t)t * N + r0 + lr) * L.ldI;
+    const float* xr = L.in + ((size_t)t * Ns + rb + lr) * L.ldI;
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb) xn[kb] = *reinterpret_cast<const float4*>(xr + min(16 * kb + 4 * q, I - 4));
   };
@@ -273,8 +274,8 @@ __device__ __forceinline__ void dp_fwd_body(const DPersistArgs& a, const unsigne
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb)
       if (16 * kb + 4 * q < P) {
-        *reinterpret_cast<float4*>(L.mst + ((size_t)t * N + r0 + lr) * ldP + 16 * kb + 4 * q) = mf[kb];
-        *reinterpret_cast<float4*>(L.out + ((size_t)(t - 1) * N + r0 + lr) * ldP + 16 * kb + 4 * q) =
+        *reinterpret_cast<float4*>(L.mst + ((size_t)t * Ns + rb + lr) * ldP + 16 * kb + 4 * q) = mf[kb];
+        *reinterpret_cast<float4*>(L.out + ((size_t)(t - 1) * Ns + rb + lr) * ldP + 16 * kb + 4 * q) =
             dp_sel(live_prev, mnew[kb], make_float4(0.f, 0.f, 0.f, 0.f));
       }
   };

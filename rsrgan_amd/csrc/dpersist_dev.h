@@ -520,8 +520,9 @@ __device__ __forceinline__ void dp_fwdt_body(const DPersistArgs& a, const unsign
   const DPersistLayer L = a.L[l];
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int H = a.H, H4 = 4 * H, T = a.T, N = a.N, P = L.P, ldP = L.ldP, I = L.I;
+  const int H = a.H, H4 = 4 * H, T = a.T, P = L.P, ldP = L.ldP, I = L.I;
   const bool xg = l > 0 || xin;                                     // the input arrives as granules
+  const int Ns = a.Ns ? a.Ns : a.N, rw0 = a.row0;                   // (the rows of this launch inside a taller stash: stride Ns, first row row0; lengths are relative)
   gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
   const size_t slot_stride_t = (size_t)DP_NQ * DP_SLOT;
   auto edge = [&](int layer, int r) -> gu64* { return (gu64*)a.gran + ((size_t)(layer * RTn + r) * T) * slot_stride_t; };
@@ -596,11 +597,11 @@ __device__ __forceinline__ void dp_fwdt_body(const DPersistArgs& a, const unsign
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
               const int row = 4 * rg + rr;
-              const size_t grow = (size_t)t * N + r0 + row;
+              const size_t grow = (size_t)t * Ns + rw0 + r0 + row;
 #pragma unroll
               for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<float4*>(L.gates + grow * H4 + g * H + cq * 64 + c4) = *reinterpret_cast<const float4*>(&S.stage[g][row * DP_HS + c4]);
-              *reinterpret_cast<float4*>(L.c + (grow + N) * H + cq * 64 + c4) = *reinterpret_cast<const float4*>(&S.stage[4][row * DP_HS + c4]);
+              *reinterpret_cast<float4*>(L.c + (grow + Ns) * H + cq * 64 + c4) = *reinterpret_cast<const float4*>(&S.stage[4][row * DP_HS + c4]);
               *reinterpret_cast<float4*>(L.h + grow * L.ldH + cq * 64 + c4) = *reinterpret_cast<const float4*>(&S.stage[5][row * DP_HS + c4]);
             }
           }
@@ -616,7 +617,7 @@ __device__ __forceinline__ void dp_fwdt_body(const DPersistArgs& a, const unsign
   constexpr int my = decltype(my_c)::value;
   const int cell = cq * 64 + 16 * wc + lr;                          // (fragment loads: the cell of this lane's A rows)
   const int cb = cq * 64 + 16 * wc + 4 * q;                         // this lane's four cells in the accumulator layout
-  const int rowb = 32 * rp + 16 * my + lr;
+  const int rowl = 32 * rp + 16 * my + lr, rowb = rw0 + rowl;      // the lane's row in the launch / in the stash
   if (my == 0) {                                                    // one copy of the K_h fragments serves both tiles
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -637,7 +638,7 @@ __device__ __forceinline__ void dp_fwdt_body(const DPersistArgs& a, const unsign
     *reinterpret_cast<float4*>(&S.bp[16 * wc + lane][4]) = make_float4(L.wi[c_], L.wf[c_], L.wo[c_], 0.f);
   }
   const float* const bpl = &S.bp[16 * wc + 4 * q][0];               // + 8 u: cell cb + u
-  const int lenF = a.len[rowb];
+  const int lenF = a.len[rowl];
   float cp[4] = {0.f, 0.f, 0.f, 0.f};
   float4 mf[DP_KB];
 #pragma unroll
@@ -651,7 +652,7 @@ __device__ __forceinline__ void dp_fwdt_body(const DPersistArgs& a, const unsign
   f32x4 accn[4];
   float4 xn[DP_KB];
   auto load_x = [&](int t) {
-    const float* xr = L.in + ((size_t)t * N + rowb) * L.ldI;
+    const float* xr = L.in + ((size_t)t * Ns + rowb) * L.ldI;
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb) xn[kb] = *reinterpret_cast<const float4*>(xr + min(16 * kb + 4 * q, I - 4));
   };
@@ -713,8 +714,8 @@ __device__ __forceinline__ void dp_fwdt_body(const DPersistArgs& a, const unsign
 #pragma unroll
     for (int kb = 0; kb < DP_KB; ++kb)
       if (16 * kb + 4 * q < P) {
-        *reinterpret_cast<float4*>(L.mst + ((size_t)t * N + rowb) * ldP + 16 * kb + 4 * q) = mf[kb];
-        *reinterpret_cast<float4*>(L.out + ((size_t)(t - 1) * N + rowb) * ldP + 16 * kb + 4 * q) =
+        *reinterpret_cast<float4*>(L.mst + ((size_t)t * Ns + rowb) * ldP + 16 * kb + 4 * q) = mf[kb];
+        *reinterpret_cast<float4*>(L.out + ((size_t)(t - 1) * Ns + rowb) * ldP + 16 * kb + 4 * q) =
             dp_sel(live_prev, mnew[kb], make_float4(0.f, 0.f, 0.f, 0.f));
       }
   };

@@ -2305,6 +2305,17 @@ bool gpersist_plan(GPersistArgs& a) {
   // answer; Model::init asks the device itself, resident_probe, before it allocates the hand-off rings.)
   return gp_grid(a) <= device_cu_count();
 }
+// The per-launch arming of sentinel slots as a KERNEL, not hipMemsetAsync: inside a replayed hipGraph a fill node in front of a persistent
+// launch is not a dependable predecessor (seen twice: as the fork point of two branches it serialised them; and after a device-wide
+// synchronisation followed by a blocking copy -- between the instantiation of a step's graphs and a replay -- the replayed launch waited
+// a second for pieces that had been overwritten).  16-byte stores, grid-stride.
+__global__ void k_arm(uint4* p, size_t n16) {
+  const uint4 v = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+void gpersist_arm_bytes(void* p, size_t bytes, hipStream_t s) {      // bytes: a multiple of 16
+  hipLaunchKernelGGL(k_arm, dim3(1024), dim3(256), 0, s, (uint4*)p, bytes / 16);
+}
 size_t gpersist_gran1_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * GP_R1 * GP_NCH * a.NC * GP_SLOT; }
 size_t gpersist_gran2_bytes(const GPersistArgs& a) { return (size_t)(a.res ? 2 : 1) * (a.N / GP_ROWS) * a.nl * a.T * GP_NCH * GP_SLOT; }      // (res: + the running sums' region)
 size_t gpersist_gran3_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * (a.nl + 1) * GP_XR * GP_NCH * a.NC * GP_SLOT; }
@@ -2320,7 +2331,7 @@ void gpersist_arm(const GPersistArgs& a, hipStream_t s) {
 #define GP_PROG_ONLY 0
 #endif
 void launch_glstm_fwd(const GPersistArgs& a, hipStream_t s) {
-  (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_gran2_bytes(a), s);
+  gpersist_arm_bytes(a.gran2, gpersist_gran2_bytes(a), s);
   const dim3 g(gp_grid(a)), b(GP_WAVES * 64);
   if (a.tags && !GP_PROG_ONLY) {
     if (a.res) hipLaunchKernelGGL((k_glstm_fwd<5, 0, true, true>), g, b, 0, s, a);
@@ -2351,7 +2362,7 @@ bool gpersist_np_plan(GPersistArgs& a, int nt_force) {
 size_t gpersist_np_gran2_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * a.T * NP_NCH * GP_SLOT; }
 size_t gpersist_np_lds_bytes() { return sizeof(NpLds<4, 7, 6>); }
 void launch_glstm_np_fwd(const GPersistArgs& a, hipStream_t s) {
-  (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_np_gran2_bytes(a), s);
+  gpersist_arm_bytes(a.gran2, gpersist_np_gran2_bytes(a), s);
   if (a.NT == 2) hipLaunchKernelGGL((k_glstm_np_fwd<2, 8, 8>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
   else hipLaunchKernelGGL((k_glstm_np_fwd<4, 7, 6>), dim3(gp_grid(a)), dim3(GP_WAVES * 64), 0, s, a);
   ++g_chain_launches;
@@ -2370,7 +2381,7 @@ void launch_glstm_np_bwd(const GPersistArgs& a, hipStream_t s) {
 // ONE launch: the discriminator's trailing BPTT (d: DPersistArgs with the trailing fields) in front of the generator's (a.dout_trail = 1)
 int gpersist_dt_grid(const GPersistArgs& a, const DPersistArgs& d) { return gp_grid(a) + ((dpersist_trail_grid(d.nl, d.N) + 7) & ~7); }
 void launch_glstm_bwd_dt(const GPersistArgs& a, const DPersistArgs& d, hipStream_t s) {
-  (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_gran2_bytes(a), s);
+  gpersist_arm_bytes(a.gran2, gpersist_gran2_bytes(a), s);
   const dim3 g(gpersist_dt_grid(a, d)), b(GP_WAVES * 64);
   if (a.tags) {
     if (a.res) hipLaunchKernelGGL((k_glstm_bwd_dt<5, true, true>), g, b, 0, s, a, d);
@@ -2380,7 +2391,7 @@ void launch_glstm_bwd_dt(const GPersistArgs& a, const DPersistArgs& d, hipStream
   g_chain_launches += 2;
 }
 void launch_glstm_fwd_dt(const GPersistArgs& a, const DPersistArgs& d, hipStream_t s) {
-  (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_gran2_bytes(a), s);
+  gpersist_arm_bytes(a.gran2, gpersist_gran2_bytes(a), s);
   const dim3 g(gpersist_dt_grid(a, d)), b(GP_WAVES * 64);
   if (a.tags) {
     if (a.res) hipLaunchKernelGGL((k_glstm_fwd_dt<5, true, true>), g, b, 0, s, a, d);
@@ -2390,7 +2401,7 @@ void launch_glstm_fwd_dt(const GPersistArgs& a, const DPersistArgs& d, hipStream
   g_chain_launches += 2;
 }
 void launch_glstm_bwd(const GPersistArgs& a, hipStream_t s) {
-  (void)hipMemsetAsync(a.gran2, 0xFF, gpersist_gran2_bytes(a), s);
+  gpersist_arm_bytes(a.gran2, gpersist_gran2_bytes(a), s);
   const dim3 g(gp_grid(a)), b(GP_WAVES * 64);
   if (a.tags && !GP_PROG_ONLY) {
     if (a.res) hipLaunchKernelGGL((k_glstm_bwd<5, 0, true, true>), g, b, 0, s, a);

@@ -172,6 +172,9 @@ struct DPersistArgs {
   const float* fc_b;
   const float* noise;
   int xd_Ns, xd_row0;
+  // forward launches over the rows [row0, row0 + N) of a stash that is Ns rows tall (0: N) -- the D-run's two discriminator calls write
+  // the two halves of the stacked stash its BPTT reads (model.cpp Model::d_backward); len points at the launch's first row
+  int Ns, row0;
 };
 size_t dpersist_granule_bytes(int nl, int N, int T);
 int dpersist_trail_grid(int nl, int N);
@@ -223,6 +226,8 @@ struct GPersistArgs {
 };
 constexpr int GP_TMAX = 2046;                     // longest launch (slot offsets are 32-bit; a longer batch takes the launch-per-phase path)
 bool gpersist_plan(GPersistArgs& a);              // fills NT / NC; false: shape not supported
+void gpersist_arm_bytes(void* p, size_t bytes, hipStream_t s);      // 0xFF-fill as a kernel (a fill node is no dependable predecessor of a persistent launch inside a replayed graph)
+extern int g_gemm_workers;                      // worker slots of a stream-K GEMM launch (gemm.hip)
 int gpersist_grid(const GPersistArgs& a);         // workgroups of a launch (all must be resident at once)
 int gpersist_dt_grid(const GPersistArgs& a, const DPersistArgs& d);      // ... of k_glstm_bwd_dt / k_glstm_fwd_dt
 void launch_glstm_fwd_dt(const GPersistArgs& a, const DPersistArgs& d, hipStream_t s);   // the generator's forward recurrence with D(G(x)) trailing it (ONE launch; a.fwd_trail = 1)

@@ -523,6 +523,20 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   scratch2 = alloc<float>(std::max<size_t>(4 * 64 * maxcols, 1024));
   g_fc_out_wT = g_dnn() ? nullptr : alloc<float>((size_t)Dout * ldP);
   if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) side = nullptr;
+  {
+    const char* e = getenv("RSRGAN_DPIPE");
+    if (e && atoi(e) != 0 && trail_fits && side && !d_dnn() && dp_max_grid >= dpersist_grid((int)dl.size(), B)) {
+      const size_t gb = dpersist_granule_bytes((int)dl.size(), B, Tmax) / 2;      // (a forward launch: one edge per layer)
+      dp_gran2 = (unsigned long long*)alloc<float>(gb / sizeof(float));
+      dp_ctl2 = (unsigned*)alloc<float>(16);
+      if (dp_gran2 && dp_ctl2 && hipEventCreateWithFlags(&ev_dfree, hipEventDisableTiming) == hipSuccess &&
+          hipEventCreateWithFlags(&ev_real, hipEventDisableTiming) == hipSuccess) {
+        const unsigned ctl0[DP_CTL_WORDS] = {1u, 0u, 0u, 0u};
+        HIPC(hipMemcpy(dp_ctl2, ctl0, sizeof(ctl0), hipMemcpyHostToDevice));
+        dpipe = true;
+      }
+    }
+  }
   if (side) {
     for (auto& e : ev_pool)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { side = nullptr; break; }
@@ -534,6 +548,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   bwdb_ws = alloc<float>(bwdb_ws_floats);
   gemm_ws2 = alloc<float>(gemm_ws_floats ? gemm_ws_floats : 1);
   if (!gemm_ws2) side = nullptr;
+  if (!side) dpipe = false;
   if (!scratch || !d_dB || !g_dB || !xd) { set_error("hipMalloc failed (activations)"); return RSRGAN_ERR_HIP; }
 
   // ---- initial values: xavier_initializer() uniform / zeros (models/lstm.py:86-87,93) ----
@@ -1029,6 +1044,7 @@ void Model::persist_disable(int which) {
   if (which == 1) gp_env = 0; else dp_env = 0;
   lazy_sw = false;
   trail_fits = false;
+  dpipe = false;
   drop_graphs();
   refresh_swizzles(RSRGAN_NET_G, nullptr);
   refresh_swizzles(RSRGAN_NET_D, nullptr);
@@ -1077,7 +1093,29 @@ bool Model::persist_forward_g(int T, hipStream_t s) {
 // The generator's forward recurrence with D(G(x)) a few steps behind it as ONE launch (gpersist.hip k_glstm_fwd_dt): the G-run of a
 // schedule that recomputes the generator's forward (gen_updates > 1: run_gan_rnn_placeholder.sh:130): y, the discriminator's input rows
 // (y + noise) and both stashes are complete behind it.  False: not applicable (the caller runs the launches one after the other).
-bool Model::persist_forward_g_trail(Chain& ch, int T, hipStream_t s, const float* nf) {
+// D(real) of the D-run as a launch of its own over rows [0, B) of the stacked stash (RSRGAN_DPIPE), with granules and control block of its own
+bool Model::persist_forward_real(int T, hipStream_t q, bool check_only) {
+  if (!dpipe || !dp_gran2 || !(dp_env & 1) || !wavefront()) return false;
+  Chain ch = d_chain(B, 2 * B, 0);
+  DPersistArgs a{};
+  a.nl = (int)ch.size(); a.N = B; a.T = T; a.H = dl[0].H; a.len = ch[0].len; a.Ns = 2 * B; a.row0 = 0;
+  a.gran = dp_gran2; a.ctl = dp_ctl2; a.forget_bias = cfg.forget_bias;
+  for (size_t l = 0; l < ch.size(); ++l) {
+    const LstmLayer& L = dl[l]; const LstmStash& S = d_st[l];
+    if (!L.has_proj || L.H != a.H) return false;
+    DPersistLayer& D_ = a.L[l];
+    D_.K = D.W(L.tK); D_.bias = D.W(L.tb); D_.wi = D.W(L.twi); D_.wf = D.W(L.twf); D_.wo = D.W(L.two); D_.Wp = D.W(L.tWp);
+    D_.gates = S.gates; D_.c = S.c; D_.h = S.h; D_.mst = S.mst; D_.out = S.out;
+    D_.I = L.I; D_.P = L.P; D_.ldP = L.ldP; D_.ldH = L.ldH; D_.ldI = L.ldI;
+    D_.in = l == 0 ? xd : nullptr;
+  }
+  if (!dpersist_supported(a) || dpersist_grid(a.nl, a.N) > dp_max_grid || T > Tmax) return false;
+  if (check_only) return true;
+  launch_dlstm_fwd(a, q);
+  return true;
+}
+
+bool Model::persist_forward_g_trail(Chain& ch, int T, hipStream_t s, const float* nf, bool check_only) {
   static const bool env = [] { const char* e = getenv("RSRGAN_TRAIL_FWD"); return !e || atoi(e) != 0; }();
   if (!env || !trail_fits || !gp_fwd_on() || gp_noproj || !wavefront() || seq_drop_on() || !dp_gran || !(dp_env & 1) || ch.size() != dl.size()) return false;
   GPersistArgs a{};
@@ -1089,7 +1127,8 @@ bool Model::persist_forward_g_trail(Chain& ch, int T, hipStream_t s, const float
   d.gran = dp_gran; d.ctl = dp_ctl; d.forget_bias = cfg.forget_bias;
   for (size_t l = 0; l < ch.size(); ++l) {
     const LayerRun& R = ch[l]; const LstmLayer& L = dl[l]; const LstmStash& S = d_st[l];
-    if (R.L != &L || R.S != &S || R.res_in || R.res_out || R.row0 != 0 || R.Ns != R.N || R.N != d.N || !L.has_proj || L.H != d.H) return false;
+    // (rows [row0, row0 + N) of a stash Ns rows tall: the D-run's D(G(x)) writes the second half of the stacked stash)
+    if (R.L != &L || R.S != &S || R.res_in || R.res_out || R.Ns != ch[0].Ns || R.row0 != ch[0].row0 || R.N != d.N || !L.has_proj || L.H != d.H) return false;
     if (l > 0 && R.in != d_st[l - 1].out) return false;
     DPersistLayer& D_ = d.L[l];
     D_.K = D.W(L.tK); D_.bias = D.W(L.tb); D_.wi = D.W(L.twi); D_.wf = D.W(L.twf); D_.wo = D.W(L.two); D_.Wp = D.W(L.tWp);
@@ -1097,10 +1136,12 @@ bool Model::persist_forward_g_trail(Chain& ch, int T, hipStream_t s, const float
     D_.I = L.I; D_.P = L.P; D_.ldP = L.ldP; D_.ldH = L.ldH; D_.ldI = L.ldI;
     D_.in = l == 0 ? R.in : nullptr;
   }
+  d.Ns = ch[0].Ns; d.row0 = ch[0].row0;
   if (ch[0].in != xd || d.N != B || B % 32 != 0 || dl[0].I != Dout || Dout % 4 != 0 || !dpersist_supported(d)) return false;
   if (dpersist_granule_bytes(d.nl + 1, d.N, d.T) / 2 > dp_gran_bytes) return false;      // (one edge per layer and one for layer 0's input)
   d.dy = y_tm; d.ld_dy = ldDout; d.fc_w = G.W(g_fc_out_w); d.ld_fcw = ldDout; d.fc_P = gR; d.fc_b = G.W(g_fc_out_b);
-  d.noise = nf; d.dtop = xd; d.ld_dtop = ldDout; d.xd_Ns = B; d.xd_row0 = 0;
+  d.noise = nf; d.dtop = xd; d.ld_dtop = ldDout; d.xd_Ns = ch[0].Ns; d.xd_row0 = ch[0].row0;
+  if (check_only) return true;
   launch_glstm_fwd_dt(a, d, s);
   g_fwd_valid = true;
   return true;
@@ -1155,7 +1196,8 @@ bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only,
   if (din_inside) { a.din0 = ch[0].din; a.ld_din0 = gl[0].ldI; }
   a.dout_trail = gp_trail_next ? 1 : 0;
   if (gp_trail_next && getenv("RSRGAN_TRAIL_DBG")) a.dout_trail = atoi(getenv("RSRGAN_TRAIL_DBG"));
-  if (prof_on) {
+  if (gp_phase == 2) {
+  } else if (prof_on) {
     if ((size_t)(2 * prof_gb_n + 2) > prof_gb_ev.size()) {
       const size_t old = prof_gb_ev.size();
       prof_gb_ev.resize(old + 8, nullptr);
@@ -1178,6 +1220,7 @@ bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only,
     launch_glstm_bwd_dt(a, dt_args, s);
   else
     launch_glstm_bwd(a, s);
+  if (gp_phase == 1) return true;
   auto din0 = [&](hipStream_t q) {
     if (ch[0].din && !din_inside) {
       const LayerRun& R = ch[0];
@@ -1532,7 +1575,7 @@ void Model::rnn_backward(std::vector<Chain>& chains, int T, hipStream_t s, const
 
 // ------------------------------------------------------------------------------------------
 int Model::prepare_batch(const float* x, const float* labels, const int32_t* lengths, int T, hipStream_t s, const float** nr,
-                         const float** nf) {
+                         const float** nf, hipStream_t early) {
   if (T <= 0 || T > Tmax) { set_error("T=%d outside (0, max_frames=%d]", T, Tmax); return RSRGAN_ERR_INVALID; }
   if (!x || (!lengths && !g_dnn())) { set_error("null input pointer"); return RSRGAN_ERR_INVALID; }
   // one launch: both packs, the lengths (twice: the stacked discriminator batch reads rows [B, 2B) as well) and the callers' noise
@@ -1544,6 +1587,15 @@ int Model::prepare_batch(const float* x, const float* labels, const int32_t* len
   if (lengths) { j.copy[0] = StageCopy{lengths, len_dev, Bt}; j.copy[1] = StageCopy{lengths, len_dev + B, Bt}; }
   if (nr && *nr) { j.copy[2] = StageCopy{*nr, noise_r_buf, Bt * Dout}; *nr = noise_r_buf; }
   if (nf && *nf) { j.copy[3] = StageCopy{*nf, noise_f_buf, Bt * Dout}; *nf = noise_f_buf; }
+  if (early) {
+    // (RSRGAN_DPIPE) what D(real) needs -- the labels, the lengths, its noise -- goes ahead on the side stream, behind the last use of
+    // the buffers it overwrites (ev_dfree); the input frames and D(G(x))'s noise stay in stream order
+    StageJobs e{}; e.B = B; e.T = T; e.Bt = Bt;
+    e.pack[1] = j.pack[1]; e.copy[0] = j.copy[0]; e.copy[1] = j.copy[1]; e.copy[2] = j.copy[2];
+    j.pack[1] = StagePack{}; j.copy[0] = StageCopy{}; j.copy[1] = StageCopy{}; j.copy[2] = StageCopy{};
+    (void)hipStreamWaitEvent(early, ev_dfree, 0);
+    launch_stage_inputs(e, early);
+  }
   launch_stage_inputs(j, s);
   cur_T = T;
   g_fwd_valid = false;
@@ -1695,20 +1747,42 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
   if (supervised()) { set_error("RSRGAN_FLAG_SUPERVISED: the trainer graph has no discriminator step"); return RSRGAN_ERR_STATE; }
   if (g_dnn()) return dnn_d_backward(x, labels, T, out_losses, want_grads, s);
   if (d_dnn()) { nr = nullptr; nf = nullptr; }    // discriminator_dnn.py:58: the noise layer is commented out
-  int rc = prepare_batch(x, labels, lengths, T, s, &nr, &nf);      // (stages the noise too: caller pointers never enter a graph)
+  // RSRGAN_DPIPE: D(real) on the side stream, ahead of this call's place in the stream; the run itself is k_glstm_fwd_dt (D(G(x)) trailing)
+  bool dsplit = false;
+  // (RSRGAN_DPIPE=1 covers labels and lengths; a noise_real tensor drawn on the caller's stream right before the call is covered by =2 only)
+  static const int dpipe_level = [] { const char* e = getenv("RSRGAN_DPIPE"); return e ? atoi(e) : 0; }();
+  static const int dpipe_dbg = [] { const char* e = getenv("RSRGAN_DPIPE_DBG"); return e ? atoi(e) : 0; }();
+  if (dpipe && !(dpipe_dbg & 1) && (!nr || dpipe_level >= 2) && wavefront() && gp_fwd_on() && !d_dnn() && !seq_drop_on() && T > 0 && T <= Tmax) {
+    Chain dchk = d_chain(B, 2 * B, B);
+    dsplit = persist_forward_real(T, side, true) && persist_forward_g_trail(dchk, T, s, nf, true);
+  }
+  int rc = prepare_batch(x, labels, lengths, T, s, &nr, &nf, dsplit ? side : nullptr);      // (stages the noise too: caller pointers never enter a graph)
   if (rc) return rc;
+  if (dsplit) {
+    // discriminator input rows [0,B) = labels + noise_real, D(real) over them; this stream waits for it in front of its own launches
+    // (the fused forward launch and the D(real) launch do not fit the device together)
+    launch_add_noise_rows(lab_tm, nr, xd, B, T, Dout, ldDout, 2 * B, 0, side);
+    (void)persist_forward_real(T, side);
+    (void)hipEventRecord(ev_real, side);
+    (void)hipStreamWaitEvent(s, ev_real, 0);
+  }
   bn_eval_call = !want_grads;                      // (is_training of this fetch: the DropoutWrapper masks)
   if (seq_drop_on()) launch_drop_tick(drop_ctr, s);     // a new training run: new masks (read from device memory: graph-safe)
   // rsrgan_d_step: the update follows in the same call -- its launches close this segment (one graph: no launch boundary in front
   // of the clip / SGD / weight-copy kernels); RSRGAN_FUSED_SEG=0 keeps them in a segment of their own
   static const bool fused_seg_d = [] { const char* e = getenv("RSRGAN_FUSED_SEG"); return !e || atoi(e) != 0; }();
   const bool inl = fused_apply && fused_seg_d && want_grads && !d_dnn() && graphs_on();
-  const unsigned kbits = (want_grads ? 1u : 0u) | (nr ? 2u : 0u) | (nf ? 4u : 0u) | (inl ? 8u : 0u);
+  const unsigned kbits = (want_grads ? 1u : 0u) | (nr ? 2u : 0u) | (nf ? 4u : 0u) | (inl ? 8u : 0u) | (dsplit ? 16u : 0u);
   run_seg(seg_key(SEG_D, T, kbits), s, [&]() {
   // discriminator input rows [0,B) = labels + noise_real (gan_rnn_placeholder.py:207,212; utils/ops.py:19-30)
-  launch_add_noise_rows(lab_tm, nr, xd, B, T, Dout, ldDout, 2 * B, 0, s);
+  if (!dsplit) launch_add_noise_rows(lab_tm, nr, xd, B, T, Dout, ldDout, 2 * B, 0, s);
   bool g_done = false;
-  if (wavefront() && gp_fwd_on()) {
+  if (dsplit) {
+    g_forward_head(T, s);
+    Chain dch = d_chain(B, 2 * B, B);
+    g_done = persist_forward_g_trail(dch, T, s, nf);
+  }
+  if (!g_done && wavefront() && gp_fwd_on()) {
     // the generator as ONE persistent launch, then both discriminator calls stacked (N = 2B) as another
     g_forward_head(T, s);
     g_done = persist_forward_g(T, s);
@@ -1872,10 +1946,43 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     dc0[0].din = nullptr;
     trail_plan = persist_backward_trail(dc0, T, s, dy, ldDout, g_dA, ldP, true);
   }
-  run_seg(seg_key(SEG_G_MAIN, T, kbits | (trail_plan ? 64u : 0u)), s, [&]() {
+  // RSRGAN_DPIPE: the next D-run's D(real) may start as soon as the fused backward launch has finished -- the event is recorded between
+  // two graph segments: the launch closes the first, the weight gradients (and the inlined update) are the second
+  static const int dpipe_dbg = [] { const char* e = getenv("RSRGAN_DPIPE_DBG"); return e ? atoi(e) : 0; }();
+  const bool gsplit = dpipe && trail_plan && !(dpipe_dbg & 2);
+  auto bwd_rest = [&]() {
+    const int ldP_ = pad4(gR);
+    StreamFn pre, post;
+    if (fcs_inside) {
+      pre = [&](hipStream_t q) {
+        gemm(g_ins[Lg], ldP_, false, dy, ldDout, false, G.Gd(g_fc_out_w), ldDout, gR, Dout, R, nullptr, 0, 0.f, false, q);
+        launch_colsum(dy, ldDout, nullptr, 0, G.Gd(g_fc_out_b), R, Dout, (side && q == side) ? scratch2 : scratch, q);
+      };
+      post = [&](hipStream_t q) {
+        launch_lrelu_bwd(g_h0, bufA, (size_t)R, gR, ldP_, cfg.lrelu_alpha, q);
+        gemm(x_tm, ldDin, false, bufA, ldP_, false, G.Gd(g_fc_in_w), ldP_, Din, gR, R, nullptr, 0, 0.f, false, q);
+        launch_colsum(bufA, ldP_, nullptr, 0, G.Gd(g_fc_in_b), R, gR, (side && q == side) ? scratch2 : scratch, q);
+      };
+    }
+    // the next D-run's D(real) (32 workgroups that own their CUs) runs beside these launches when the host is ahead: the chip-filling
+    // GEMMs leave it room (a persistent stream-K launch on all 256 CUs would wait for it with 32 of its workers, and it for them)
+    static const int pipe_w = [] { const char* e = getenv("RSRGAN_DPIPE_W"); const int v = e ? atoi(e) : 224; return v >= 64 && v <= 256 ? v & ~7 : 224; }();
+    const int saved_w = g_gemm_workers;
+    g_gemm_workers = std::min(saved_w, pipe_w);
+    defer_wgrads = bucketed;
+    gp_phase = 2; persist_backward_g(bw_chains[1], T, s, false, pre, post); gp_phase = 0;
+    defer_wgrads = false;
+    if (!fcs_inside) {
+      gemm(g_ins[Lg], ldP_, false, dy, ldDout, false, G.Gd(g_fc_out_w), ldDout, gR, Dout, R, nullptr, 0, 0.f, false, s);
+      launch_colsum(dy, ldDout, nullptr, 0, G.Gd(g_fc_out_b), R, Dout, scratch, s);
+    }
+    g_gemm_workers = saved_w;
+    if (inl) { tail_body(); apply_body(RSRGAN_NET_G, s); }
+  };
+  run_seg(seg_key(SEG_G_MAIN, T, kbits | (trail_plan ? 64u : 0u) | (gsplit ? 128u : 0u)), s, [&]() {
   // (trailing form) the top layer's gradient buffer armed with the all-ones pattern HERE, at the head of the run: k_glstm_bwd polls it,
   // and a fill in front of the fork would be the node both launches depend on (a fill node as the fork point serialized them)
-  if (trail_plan) (void)hipMemsetAsync(g_dA, 0xFF, (size_t)T * B * ldP * sizeof(float), s);
+  if (trail_plan) gpersist_arm_bytes(g_dA, (size_t)T * B * ldP * sizeof(float), s);
   bool g_done = false;
   if (!reuse && !wavefront()) g_forward(T, s);
   bool d_trailed = false;      // D(G(x)) ran inside the generator's forward launch (k_glstm_fwd_dt): y, the discriminator's input rows and its stash are there
@@ -1966,6 +2073,11 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
           launch_colsum(bufA, ldP, nullptr, 0, G.Gd(g_fc_in_b), R, P, (side && q == side) ? scratch2 : scratch, q);
         };
       }
+      if (gsplit) {      // (RSRGAN_DPIPE) the launch only: ev_dfree is recorded behind it, what follows is a segment of its own (bwd_rest)
+        gp_phase = 1; persist_backward_g(bw_chains[1], T, s, false, pre, post); gp_phase = 0;
+        gp_trail_next = false;
+        return;
+      }
       persist_backward_g(bw_chains[1], T, s, false, pre, post);
       gp_trail_next = false;
     } else {
@@ -1987,6 +2099,12 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   }
   if (inl) { tail_body(); apply_body(RSRGAN_NET_G, s); }
   });
+  if (gsplit) {
+    defer_wgrads = false;
+    (void)hipEventRecord(ev_dfree, s);
+    dfree_inside = true;
+    run_seg(seg_key(SEG_G_MAIN, T, kbits | 64u | 256u), s, bwd_rest);
+  }
   if (inl) apply_inlined |= 1;
   if (!reuse) g_fwd_valid = true;
   if (wave_bwd) {
@@ -2056,6 +2174,7 @@ int Model::apply(int net, hipStream_t s) {
   } else if (net == RSRGAN_NET_G) {
     if (!g_grads_ready) { set_error("apply(G) without gradients"); return RSRGAN_ERR_STATE; }
     if (!(apply_inlined & 1)) run_seg(seg_key(SEG_APPLY_G, 0, 0), s, [&]() { apply_body(RSRGAN_NET_G, s); });
+    dfree_inside = true;                         // (RSRGAN_DPIPE: the generator's update touches nothing the next D(real) reads or writes)
     apply_inlined &= ~1;
     scal[RSRGAN_ADAM_STEP] += 1;
     g_grads_ready = false;

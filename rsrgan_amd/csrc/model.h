@@ -161,7 +161,18 @@ struct Model {
   // the G-run's discriminator BPTT in its trailing form (dpersist_dev.h): fills dt_args for the k_glstm_bwd_dt launch that
   // persist_backward_g makes next (gp_trail_next): dy += layer 0's input gradient, dtop = dy . W_out^T step by step
   bool persist_backward_trail(Chain& ch, int T, hipStream_t s, float* dy, int ld_dy, float* dtop, int ld_dtop, bool check_only = false);
-  bool persist_forward_g_trail(Chain& ch, int T, hipStream_t s, const float* nf);      // k_glstm_fwd_dt: the generator's forward recurrence + D(G(x)) behind it, one launch
+  bool persist_forward_g_trail(Chain& ch, int T, hipStream_t s, const float* nf, bool check_only = false);      // k_glstm_fwd_dt: the generator's forward recurrence + D(G(x)) behind it, one launch
+  // RSRGAN_DPIPE=1 (the caller guarantees that labels, lengths and noise_real of rsrgan_d_step are complete when the call is made): the
+  // D-run's D(real) -- which depends on nothing of the generator -- leaves the chain: staged and run on the side stream as soon as the
+  // previous run no longer needs the discriminator's stash (ev_dfree), i.e. beside the previous G-run's weight-gradient GEMMs when the
+  // host runs ahead; the D-run itself is k_glstm_fwd_dt with D(G(x)) trailing + the stacked BPTT.
+  bool dpipe = false;
+  bool dfree_inside = false;                              // this call recorded ev_dfree itself (behind the fused backward launch)
+  int gp_phase = 0;                                       // persist_backward_g: 1 the launch only, 2 what follows it (the G-run split in two graph segments around ev_dfree)
+  hipEvent_t ev_dfree = nullptr, ev_real = nullptr;
+  unsigned long long* dp_gran2 = nullptr;                 // granules / control block of the D(real) launch (it may overlap another discriminator launch's epilogue)
+  unsigned* dp_ctl2 = nullptr;
+  bool persist_forward_real(int T, hipStream_t q, bool check_only = false);
   bool trail_fits = false;                                // both launches resident at once (resident_probe at init)
   bool gp_trail_next = false;                             // the next generator BPTT launch is k_glstm_bwd_dt (dt_args)
   int trail_mode = 1;                                     // RSRGAN_TRAIL: 0 off
@@ -262,7 +273,7 @@ struct Model {
 
   // steps
   int prepare_batch(const float* x, const float* labels, const int32_t* lengths, int T, hipStream_t s, const float** nr = nullptr,
-                    const float** nf = nullptr);      // nr / nf: callers' noise, staged in the same launch (in/out: the staged copy)
+                    const float** nf = nullptr, hipStream_t early = nullptr);      // nr / nf: callers' noise, staged in the same launch (in/out: the staged copy)
   void g_forward(int T, hipStream_t s, Chain* extra = nullptr);
   void g_forward_head(int T, hipStream_t s);
   void g_forward_tail(int T, hipStream_t s);
@@ -350,6 +361,7 @@ struct Model {
   std::unordered_map<uint64_t, GraphSlot> graphs;
   hipStream_t main_s = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  hipStream_t last_work = nullptr;                        // the stream the last call worked on (rsrgan_device_status waits for it)
   float *noise_r_buf = nullptr, *noise_f_buf = nullptr;      // staged gaussian_noise_layer draws [B][Dout]
   bool graphs_on() const { return (cfg.flags & RSRGAN_FLAG_GRAPH) != 0 && wavefront() && !overlap() && !prof_on && !g_dnn() && graphs_env; }
   bool graphs_env = true;

@@ -56,6 +56,19 @@ for i, Ti in enumerate(int(v) for v in os.environ.get("RSRGAN_TEST_TSEQ", "").sp
     xi, labi, lni = rand_batch(cfg, B, Ti, seed=20 + i, ragged=True)
     d = np.ravel(model.d_step(xi, labi, lni)); g = np.ravel(model.g_step(xi, labi, lni, reuse_g_forward=True))
     out["sd%%d" %% i] = [float(v) for v in d]; out["sg%%d" %% i] = [float(v) for v in g]
+_async = int(os.environ.get("RSRGAN_TEST_ASYNC", "0"))
+if _async:
+    # steps enqueued without waiting for their results (what bench.py and train_one_iteration do): the host runs ahead of the device
+    import torch
+    xs = [tuple(torch.from_numpy(v).cuda() for v in rand_batch(cfg, B, T, seed=40 + i, ragged=True)) for i in range(3)]
+    torch.cuda.synchronize()
+    with model.engine.on_stream():
+        for i in range(_async):
+            xi, labi, lni = xs[i %% 3]
+            model.d_step(xi, labi, lni, sync=False, gather=False)
+            last = model.g_step(xi, labi, lni, reuse_g_forward=True, sync=False, gather=False)
+    torch.cuda.synchronize()
+    out["async_last"] = [float(v) for v in np.ravel(last.cpu().numpy())]
 model.engine.profile_begin()
 model.d_step(x, lab, ln); model.g_step(x, lab, ln, reuse_g_forward=_reuse)
 out["gp_n"] = int(model.engine.profile_read_kind(1)[0])           # k_glstm_fwd launches bracketed (k_glstm_fwd_dt is not)
@@ -188,6 +201,26 @@ def test_trailing_discriminator_forward_agrees(B, T, net):
         assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-7), (k, a[k], b[k])
     assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
     c = _run(dict(size))
+    assert a["vars_sha"] == c["vars_sha"]
+
+
+@pytest.mark.parametrize("B,T,net", [(64, 100, "lstm"), (32, 9, "lstm"), (32, 1, "lstm"), (32, 9, "res_lstm_l")])
+def test_pipelined_discriminator_run_agrees(B, T, net):
+    """Round 5, RSRGAN_DPIPE=1 (the caller guarantees that labels and lengths of rsrgan_d_step are complete when the call is made): the
+    D-run's D(real) (gan_rnn_placeholder.py:207: it depends on nothing of the generator) is staged and run on the side stream as soon as
+    the previous run no longer needs the discriminator's stash -- beside the previous G-run's weight-gradient GEMMs when the host runs
+    ahead -- over rows [0, B) of the stacked stash, and the D-run itself is k_glstm_fwd_dt with D(G(x)) trailing over rows [B, 2B), then the
+    stacked BPTT.  24 steps enqueued without a host wait, three batches in turn: against RSRGAN_DPIPE=0 (fp32 rounding of the
+    output FC apart), the same bits when the whole sequence runs again, no failed wait."""
+    size = {"RSRGAN_TEST_B": str(B), "RSRGAN_TEST_T": str(T), "RSRGAN_TEST_NET": net, "RSRGAN_TEST_ASYNC": "24"}
+    a = _run(dict(size, RSRGAN_DPIPE="1"))
+    b = _run(dict(size, RSRGAN_DPIPE="0"))
+    assert a["device_status"] == 0 and b["device_status"] == 0
+    assert a["gp_n"] == b["gp_n"] - 1, (a["gp_n"], b["gp_n"])      # the D-run's stand-alone generator launch is gone: k_glstm_fwd_dt ran
+    for k in ("d0", "g0", "d1", "g1", "async_last"):
+        assert np.allclose(a[k], b[k], rtol=2e-4, atol=1e-6), (k, a[k], b[k])
+    assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
+    c = _run(dict(size, RSRGAN_DPIPE="1"))
     assert a["vars_sha"] == c["vars_sha"]
 
 
