@@ -166,7 +166,11 @@ int rsrgan_forward_g(rsrgan_handle h, const float* x, const int32_t* lengths, in
  * float[3] = {d_rl, d_fk, d_loss}.  For the frame-level GAN (g_type RSRGAN_G_DNN: models/gan.py,
  * scripts/train_gan_dnn.py) the same entry points are used with T = 1, x [N,1,Din*(L+1+R)], labels
  * [N,1,Dout]; lengths may be NULL there.  train=0 gives the eval fetch
- * (train_gan_rnn_placeholder.py:154-160): losses only, no update. */
+ * (train_gan_rnn_placeholder.py:154-160): losses only, no update.
+ * Every buffer is read in `stream` order -- unless the process runs with RSRGAN_DPIPE=1, by which the CALLER guarantees that
+ * `labels` and `lengths` (=2: `noise_real` too) are complete when the call is made: they are then read on a side stream, possibly
+ * before earlier work on `stream` has finished, so that D(real) of this call can run beside the previous call's tail
+ * (DESIGN.md 6-R5 (13)).  Results do not depend on it. */
 int rsrgan_d_step(rsrgan_handle h, const float* x, const float* labels, const int32_t* lengths,
                   int32_t T, const float* noise_real, const float* noise_fake,
                   float* out_losses, int32_t train, void* stream);
