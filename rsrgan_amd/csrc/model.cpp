@@ -1751,8 +1751,7 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
   bool dsplit = false;
   // (RSRGAN_DPIPE=1 covers labels and lengths; a noise_real tensor drawn on the caller's stream right before the call is covered by =2 only)
   static const int dpipe_level = [] { const char* e = getenv("RSRGAN_DPIPE"); return e ? atoi(e) : 0; }();
-  static const int dpipe_dbg = [] { const char* e = getenv("RSRGAN_DPIPE_DBG"); return e ? atoi(e) : 0; }();
-  if (dpipe && !(dpipe_dbg & 1) && (!nr || dpipe_level >= 2) && wavefront() && gp_fwd_on() && !d_dnn() && !seq_drop_on() && T > 0 && T <= Tmax) {
+  if (dpipe && (!nr || dpipe_level >= 2) && wavefront() && gp_fwd_on() && !d_dnn() && !seq_drop_on() && T > 0 && T <= Tmax) {
     Chain dchk = d_chain(B, 2 * B, B);
     dsplit = persist_forward_real(T, side, true) && persist_forward_g_trail(dchk, T, s, nf, true);
   }
@@ -1948,8 +1947,7 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   }
   // RSRGAN_DPIPE: the next D-run's D(real) may start as soon as the fused backward launch has finished -- the event is recorded between
   // two graph segments: the launch closes the first, the weight gradients (and the inlined update) are the second
-  static const int dpipe_dbg = [] { const char* e = getenv("RSRGAN_DPIPE_DBG"); return e ? atoi(e) : 0; }();
-  const bool gsplit = dpipe && trail_plan && !(dpipe_dbg & 2);
+  const bool gsplit = dpipe && trail_plan;
   auto bwd_rest = [&]() {
     const int ldP_ = pad4(gR);
     StreamFn pre, post;
