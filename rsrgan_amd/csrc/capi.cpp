@@ -335,15 +335,16 @@ int rsrgan_device_status(rsrgan_handle h, int32_t* code) {
   if (!m.dp_ctl && !m.gp_ctl) return RSRGAN_OK;
   // the control blocks of the persistent recurrences (dpersist.hip, gpersist.hip): the first failure wins; a generator failure is
   // reported as 0x10000 + workgroup
-  unsigned* blocks[2] = {m.dp_ctl, m.gp_ctl};
-  for (int k = 0; k < 2; ++k) {
-    if (!blocks[k]) continue;
+  unsigned* blocks[3] = {m.dp_ctl, m.gp_ctl, m.dp_ctl2};      // (dp_ctl2: the D(real) launches of RSRGAN_DPIPE; reported like the other discriminator launches)
+  for (int k_ = 0; k_ < 3; ++k_) {
+    const int k = k_ == 2 ? 0 : k_;
+    if (!blocks[k_]) continue;
     unsigned ctl[DP_CTL_WORDS];
-    if (hipMemcpy(ctl, blocks[k], sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess) { set_error("hipMemcpy failed"); return RSRGAN_ERR_HIP; }
+    if (hipMemcpy(ctl, blocks[k_], sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess) { set_error("hipMemcpy failed"); return RSRGAN_ERR_HIP; }
     if (*code == 0 && ctl[DP_CTL_ERR] != 0) *code = (int32_t)(ctl[DP_CTL_ERR] + (k ? 0x10000u : 0u));
     if (ctl[DP_CTL_ERR] != 0 || ctl[DP_CTL_DONE] != 0) {          // (an aborted launch can leave the arrival count behind)
       const unsigned z[2] = {0u, 0u};
-      if (hipMemcpy(blocks[k] + DP_CTL_DONE, z, sizeof(z), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed"); return RSRGAN_ERR_HIP; }
+      if (hipMemcpy(blocks[k_] + DP_CTL_DONE, z, sizeof(z), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy failed"); return RSRGAN_ERR_HIP; }
       if (k == 1) m.gpersist_rearm();                               // (an aborted generator launch leaves ring slots written: arm them again)
       if (ctl[DP_CTL_ERR] != 0) m.persist_disable(k);                // (its workgroups were not all resident: this handle stops trying)
     }
