@@ -601,6 +601,9 @@ void Model::destroy() {
     (void)hipStreamDestroy(side);
     side = nullptr;
   }
+  if (ev_dfree) { (void)hipEventDestroy(ev_dfree); ev_dfree = nullptr; }
+  if (ev_real) { (void)hipEventDestroy(ev_real); ev_real = nullptr; }
+  dpipe = false;
   for (auto& v : gbk) { for (auto& b : v) if (b.ev) (void)hipEventDestroy(b.ev); v.clear(); }
   for (auto& e : prof_ev) if (e) (void)hipEventDestroy(e);
   prof_ev.clear();
