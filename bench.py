@@ -666,6 +666,21 @@ def main():
                                 "value": round(B * T * n2 / v2["dt"], 1), "unit": "frames/s", "ms_per_step": round(v2["dt"] * 1e3 / n2, 4)})
         del v2
         torch.cuda.empty_cache()
+        # the headline workload WITHOUT the caller's guarantee behind RSRGAN_DPIPE (every buffer of rsrgan_d_step read in stream order:
+        # the D-run's two discriminator calls stacked behind the generator's forward launch) -- what a caller that uploads a batch
+        # right before the call gets
+        if os.environ.get("RSRGAN_DPIPE", "0") != "0":
+            keep = os.environ["RSRGAN_DPIPE"]; os.environ["RSRGAN_DPIPE"] = "0"
+            try:
+                v0 = measure_sequence(a, "lstm", "lstm", B, T, max(10, a.steps // 2), 4, rank, local, world, dev)
+                n0 = max(10, a.steps // 2)
+                out["variants"].append({"workload": "the headline step with RSRGAN_DPIPE=0 (no guarantee about the caller's buffers), B=%d T=%d" % (B, T),
+                                        "value": round(B * T * n0 / v0["dt"], 1), "unit": "frames/s", "ms_per_step": round(v0["dt"] * 1e3 / n0, 4),
+                                        "roofline_frac": round(fpf * B * T / (v0["dev_ms"] * 1e-3 / n0) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)})
+                del v0
+            finally:
+                os.environ["RSRGAN_DPIPE"] = keep
+            torch.cuda.empty_cache()
         # the shipped RECIPE as a whole (run_gan_rnn_placeholder.sh:124,126,129-130): res_lstm_l, batch_size 8, 1 D-run + 2 G-runs -- the
         # batch is padded to one 32-row group of the persistent kernels (csrc/model.h Bt); and the same network at BASELINE configs[1]'s batch
         for (bb, gu, tag) in ((8, 2, "shipped recipe: G=res_lstm_l, batch_size 8, 1D+2G"), (32, 1, "shipped network at B=32 (one row group: persistent launches), 1D+1G")):
