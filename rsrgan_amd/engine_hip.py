@@ -123,6 +123,24 @@ class HipEngine:
             raise ValueError("expected shape %s, got %s" % (tuple(shape), tuple(t.shape)))
         return t
 
+    def upload_ready(self, a, int32=False) -> torch.Tensor:
+        """Host array -> device tensor that is COMPLETE when this returns (copied on an upload stream of its own, which the host
+        waits for -- not for the compute stream): what RSRGAN_DPIPE=1 asks of the labels and lengths of a D-run (include/rsrgan.h
+        rsrgan_d_step), so that D(real) of the next step can run beside the previous step's tail.  Device tensors pass through: a
+        caller that hands them in under RSRGAN_DPIPE=1 vouches for them itself."""
+        if isinstance(a, torch.Tensor) and a.device == self.device:
+            return a.to(torch.int32).contiguous() if int32 else a.to(torch.float32).contiguous()
+        us = getattr(self, "_upload_stream", None)
+        if us is None:
+            us = self._upload_stream = torch.cuda.Stream(self.device)
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a) if int32 else np.ascontiguousarray(a, dtype=np.float32))
+        with torch.cuda.stream(us):
+            t = t.to(self.device, non_blocking=True)
+            t = (t.to(torch.int32) if int32 else t.to(torch.float32)).contiguous()
+        us.synchronize()
+        t.record_stream(torch.cuda.current_stream(self.device))
+        return t
+
     def _i32(self, a) -> torch.Tensor:
         t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
         return t.to(self.device).to(torch.int32).contiguous()       # placeholder is float32, cast like dynamic_rnn
@@ -256,6 +274,9 @@ class HipEngine:
         return y
 
     def d_backward(self, x, lab, lengths, noise_real=None, noise_fake=None, train=True, apply=False) -> torch.Tensor:
+        if os.environ.get("RSRGAN_DPIPE", "0") not in ("", "0"):      # the library reads labels / lengths ahead of the stream: hand it complete ones
+            lab = self.upload_ready(lab)
+            lengths = self.upload_ready(lengths, int32=True) if lengths is not None else None
         x, lab = self._f32(x), self._f32(lab)
         ln = self._i32(lengths) if lengths is not None else None
         nr, nf = self._noise(noise_real), self._noise(noise_fake)

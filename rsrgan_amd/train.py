@@ -3,6 +3,7 @@ from __future__ import annotations
 
 import math
 
+import os
 import numpy as np
 import torch
 
@@ -81,13 +82,20 @@ def _train_one_iteration(sess, model, tr_num_batch, iteration, train_queue, num_
         if queue_inputs.shape[0] != model.batch_size * num_gpu:   # :69-70
             continue
         x = model._shard(queue_inputs); lab = model._shard(queue_labels); ln = model._shard(queue_lengths)
+        ready = getattr(model.engine, "upload_ready", None) if os.environ.get("RSRGAN_DPIPE", "0") not in ("", "0") else None
+        if ready is not None and not (isinstance(lab, torch.Tensor) and lab.device == dev):
+            # RSRGAN_DPIPE=1: labels and lengths complete BEFORE the D-run is called (copied on the engine's upload stream while the
+            # previous step still runs): D(real) of this batch then runs beside the previous G-run's tail
+            lab = ready(lab); ln = ready(ln, int32=True)
         if not isinstance(x, torch.Tensor):
             x = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
-            lab = torch.from_numpy(np.ascontiguousarray(lab, np.float32)).to(dev)
-            ln = torch.from_numpy(np.ascontiguousarray(ln)).to(dev).to(torch.int32)
+            if not isinstance(lab, torch.Tensor):
+                lab = torch.from_numpy(np.ascontiguousarray(lab, np.float32)).to(dev)
+                ln = torch.from_numpy(np.ascontiguousarray(ln)).to(dev).to(torch.int32)
         elif x.device != dev:                                     # page-locked staging tensors from io.prefetch: asynchronous DMA
-            x = x.to(dev, non_blocking=True); lab = lab.to(dev, non_blocking=True)
-            ln = ln.to(dev, non_blocking=True).to(torch.int32)
+            x = x.to(dev, non_blocking=True)
+            if lab.device != dev:
+                lab = lab.to(dev, non_blocking=True); ln = ln.to(dev, non_blocking=True).to(torch.int32)
         for d_step in range(model.disc_updates):
             tw = model.d_step(x, lab, ln, sync=False, gather=False)   # this tower's [1, 3]; towers are averaged once, below
             m = tw.mean(0)                                        # np.mean over towers (:85-87)
