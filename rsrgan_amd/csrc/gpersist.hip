@@ -171,6 +171,7 @@ __device__ __forceinline__ bool gp_valid_t(const u32x4& x, unsigned tag) {
   const unsigned all1 = x[0] & x[1] & x[2] & x[3] & 1u, any1 = (x[0] | x[1] | x[2] | x[3]) & 1u;
   return tag ? all1 != 0u : any1 == 0u;
 }
+#define GP_CIDX(a) ((a).ngl ? 2 * (a).grp0 : 0)      // (a launch over some row groups only: their rings advance on their own counters)
 constexpr int GP_CTL_C1 = 4, GP_CTL_C3 = 5;      // control-block words: steps written so far to the hop-1 ring (mod 2 GP_R1) / the input-gradient rings (mod 2 GP_XR)
 // Re-arm the NP producers' 512-byte half chunks at base + p * GP_SLOT (p = 0 .. NP-1): one store covers two producers (a half
 // wave each); wave w of the four R waves takes every fourth store.
@@ -353,9 +354,10 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
   if (tid == 0) gp_tr[0][23] = (unsigned)__builtin_amdgcn_s_memtime();          // kernel entry -> [0][22]: the prologue (weights into VGPRs / LDS)
 #endif
   // block -> (row group, layer, slice): block b runs on XCD b & 7 (observed; speed only) -- a row group owns 8 / groups XCDs
-  const int ngr = a.N / GP_ROWS, xpg = 8 / ngr;
+  // (a.ngl row groups starting at a.grp0, or all of them: a stack whose workgroups do not fit the device at once runs one launch per row group)
+  const int ngr = a.N / GP_ROWS, ngl = a.ngl ? a.ngl : ngr, xpg = 8 / ngl;
   const int xcd = bid & 7, slot = bid >> 3;
-  const int grp = xcd / xpg, idx = slot * xpg + (xcd % xpg);
+  const int grp = a.grp0 + xcd / xpg, idx = slot * xpg + (xcd % xpg);
   if (idx >= a.nl * a.NC) return;
   const int l = idx / a.NC, c = idx - l * a.NC;
   const GPersistLayer L = a.L[l];
@@ -765,13 +767,13 @@ __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_fwd(const GPersistAr
   gu32* ctl = (gu32*)a.ctl;
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (counts launches; nothing depends on it)
   // (TAG) steps written to the hop-1 ring by the launches so far, mod 2 GP_R1: every workgroup reads it here, the last one to finish moves it on
-  const unsigned c1 = TAG ? __hip_atomic_load(ctl + GP_CTL_C1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  const unsigned c1 = TAG ? __hip_atomic_load(ctl + GP_CTL_C1 + GP_CIDX(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   gp_fwd_body<NT, PROG, RES, TAG>(a, S, c1, blockIdx.x);
   __syncthreads();                                                 // (every wave leaves the body on every path)
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == gridDim.x - 1) {
-      if (TAG) __hip_atomic_store(ctl + GP_CTL_C1, (c1 + (unsigned)a.T) % (2u * GP_R1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (TAG) __hip_atomic_store(ctl + GP_CTL_C1 + GP_CIDX(a), (c1 + (unsigned)a.T) % (2u * GP_R1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (__hip_atomic_load(ctl + DP_CTL_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
         a.L[a.nl - 1].out[0] = __builtin_nanf("");
       __hip_atomic_store(ctl + DP_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -946,13 +948,13 @@ __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_fwd_dt(const GPersis
   }
   gu32* ctl = (gu32*)a.ctl;
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned c1 = TAG ? __hip_atomic_load(ctl + GP_CTL_C1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  const unsigned c1 = TAG ? __hip_atomic_load(ctl + GP_CTL_C1 + GP_CIDX(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   gp_fwd_body<NT, 0, RES, TAG>(a, S.g, c1, blockIdx.x - (unsigned)dt_pad);
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == gridDim.x - (unsigned)dt_pad - 1u) {
-      if (TAG) __hip_atomic_store(ctl + GP_CTL_C1, (c1 + (unsigned)a.T) % (2u * GP_R1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (TAG) __hip_atomic_store(ctl + GP_CTL_C1 + GP_CIDX(a), (c1 + (unsigned)a.T) % (2u * GP_R1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (__hip_atomic_load(ctl + DP_CTL_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
         a.L[a.nl - 1].out[0] = __builtin_nanf("");
       __hip_atomic_store(ctl + DP_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1059,9 +1061,10 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
 #ifdef GP_TRACE
   if (tid == 0) gp_tr[0][23] = (unsigned)__builtin_amdgcn_s_memtime();
 #endif
-  const int ngr = a.N / GP_ROWS, xpg = 8 / ngr;
+  // (a.ngl row groups starting at a.grp0, or all of them: a stack whose workgroups do not fit the device at once runs one launch per row group)
+  const int ngr = a.N / GP_ROWS, ngl = a.ngl ? a.ngl : ngr, xpg = 8 / ngl;
   const int xcd = bid & 7, slot = bid >> 3;
-  const int grp = xcd / xpg, idx = slot * xpg + (xcd % xpg);
+  const int grp = a.grp0 + xcd / xpg, idx = slot * xpg + (xcd % xpg);
   if (idx >= a.nl * a.NC) return;
   const int l = idx / a.NC, c = idx - l * a.NC;
   const GPersistLayer L = a.L[l];
@@ -1539,16 +1542,16 @@ __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_bwd(const GPersistAr
   gu32* ctl = (gu32*)a.ctl;
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (counts launches)
   // (TAG) the ring step counters: T - 1 state-gradient steps and T input-gradient steps are written per launch
-  const unsigned c1 = TAG ? __hip_atomic_load(ctl + GP_CTL_C1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-  const unsigned c3 = TAG ? __hip_atomic_load(ctl + GP_CTL_C3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  const unsigned c1 = TAG ? __hip_atomic_load(ctl + GP_CTL_C1 + GP_CIDX(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  const unsigned c3 = TAG ? __hip_atomic_load(ctl + GP_CTL_C3 + GP_CIDX(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   gp_bwd_body<NT, PROG, RES, TAG>(a, S, c1, c3, blockIdx.x);
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == gridDim.x - 1) {
       if (TAG) {
-        __hip_atomic_store(ctl + GP_CTL_C1, (c1 + (unsigned)a.T - 1u) % (2u * GP_R1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(ctl + GP_CTL_C3, (c3 + (unsigned)a.T) % (2u * GP_XR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ctl + GP_CTL_C1 + GP_CIDX(a), (c1 + (unsigned)a.T - 1u) % (2u * GP_R1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ctl + GP_CTL_C3 + GP_CIDX(a), (c3 + (unsigned)a.T) % (2u * GP_XR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (__hip_atomic_load(ctl + DP_CTL_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
         a.L[0].gates[0] = __builtin_nanf("");
@@ -1597,16 +1600,16 @@ __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_bwd_dt(const GPersis
   gu32* ctl = (gu32*)a.ctl;
   if (mode == 2) return;
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned c1 = TAG ? __hip_atomic_load(ctl + GP_CTL_C1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-  const unsigned c3 = TAG ? __hip_atomic_load(ctl + GP_CTL_C3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  const unsigned c1 = TAG ? __hip_atomic_load(ctl + GP_CTL_C1 + GP_CIDX(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+  const unsigned c3 = TAG ? __hip_atomic_load(ctl + GP_CTL_C3 + GP_CIDX(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
   gp_bwd_body<NT, 0, RES, TAG>(a, S.g, c1, c3, gbid);
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == gridDim.x - (unsigned)dt_pad - 1u) {
       if (TAG) {
-        __hip_atomic_store(ctl + GP_CTL_C1, (c1 + (unsigned)a.T - 1u) % (2u * GP_R1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(ctl + GP_CTL_C3, (c3 + (unsigned)a.T) % (2u * GP_XR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ctl + GP_CTL_C1 + GP_CIDX(a), (c1 + (unsigned)a.T - 1u) % (2u * GP_R1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ctl + GP_CTL_C3 + GP_CIDX(a), (c3 + (unsigned)a.T) % (2u * GP_XR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (__hip_atomic_load(ctl + DP_CTL_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
         a.L[0].gates[0] = __builtin_nanf("");
@@ -2230,7 +2233,7 @@ __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_np_bwd(const GPersis
 }
 
 static int gp_grid(const GPersistArgs& a) {
-  const int ngr = a.N / GP_ROWS, xpg = 8 / ngr, nwg = a.nl * a.NC;
+  const int ngr = a.ngl ? a.ngl : a.N / GP_ROWS, xpg = 8 / ngr, nwg = a.nl * a.NC;
   return 8 * ((nwg + xpg - 1) / xpg);
 }
 int gpersist_grid(const GPersistArgs& a) { return gp_grid(a); }
@@ -2303,6 +2306,9 @@ bool gpersist_plan(GPersistArgs& a) {
   }
   // every workgroup must be resident at once (they wait for each other): one 12-wave workgroup per CU.  (The static half of the
   // answer; Model::init asks the device itself, resident_probe, before it allocates the hand-off rings.)
+  if (gp_grid(a) <= device_cu_count()) return true;
+  // one launch per row group (res_lstm_l at 64 rows: 4 layers x 38 slices x 2 row groups = 304 workgroups)
+  a.ngl = 1; a.grp0 = 0;
   return gp_grid(a) <= device_cu_count();
 }
 // The per-launch arming of sentinel slots as a KERNEL, not hipMemsetAsync: inside a replayed hipGraph a fill node in front of a persistent
@@ -2316,6 +2322,14 @@ __global__ void k_arm(uint4* p, size_t n16) {
 void gpersist_arm_bytes(void* p, size_t bytes, hipStream_t s) {      // bytes: a multiple of 16
   hipLaunchKernelGGL(k_arm, dim3(1024), dim3(256), 0, s, (uint4*)p, bytes / 16);
 }
+// the hop-2 slots of the row groups a launch covers (both regions of a residual stack): the other groups' chunks stay -- the FC workgroups
+// of k_glstm_fwd_dt read the first group's while the second group's launch runs
+static void gp_arm_gran2(const GPersistArgs& a, hipStream_t s) {
+  const int ngr = a.N / GP_ROWS, ngl = a.ngl ? a.ngl : ngr;
+  const size_t per_grp = (size_t)a.nl * a.T * GP_NCH * GP_SLOT, region = (size_t)ngr * per_grp;
+  for (int rg = 0; rg < (a.res ? 2 : 1); ++rg)
+    gpersist_arm_bytes((char*)a.gran2 + rg * region + (size_t)a.grp0 * per_grp, (size_t)ngl * per_grp, s);
+}
 size_t gpersist_gran1_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * a.nl * GP_R1 * GP_NCH * a.NC * GP_SLOT; }
 size_t gpersist_gran2_bytes(const GPersistArgs& a) { return (size_t)(a.res ? 2 : 1) * (a.N / GP_ROWS) * a.nl * a.T * GP_NCH * GP_SLOT; }      // (res: + the running sums' region)
 size_t gpersist_gran3_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_ROWS) * (a.nl + 1) * GP_XR * GP_NCH * a.NC * GP_SLOT; }
@@ -2324,14 +2338,14 @@ size_t gpersist_gran3_bytes(const GPersistArgs& a) { return (size_t)(a.N / GP_RO
 void gpersist_arm(const GPersistArgs& a, hipStream_t s) {
   (void)hipMemsetAsync(a.gran1, 0xFF, gpersist_gran1_bytes(a), s);
   if (a.gran3) (void)hipMemsetAsync(a.gran3, 0xFF, gpersist_gran3_bytes(a), s);
-  (void)hipMemsetAsync(a.ctl + GP_CTL_C1, 0, 2 * sizeof(unsigned), s);          // (tagged rings: every word's parity bit is 1 now, pass 0 writes 0)
+  (void)hipMemsetAsync(a.ctl + 4, 0, 12 * sizeof(unsigned), s);          // (tagged rings: every word's parity bit is 1 now, pass 0 writes 0)
 }
 // (-DGP_PROG_ONLY=mask: the progressive sweeps, gp_sweep_prog -- the harness only: measured slower, profiles/r5_gpersist_progressive_sweep_negative.txt)
 #ifndef GP_PROG_ONLY
 #define GP_PROG_ONLY 0
 #endif
 void launch_glstm_fwd(const GPersistArgs& a, hipStream_t s) {
-  gpersist_arm_bytes(a.gran2, gpersist_gran2_bytes(a), s);
+  gp_arm_gran2(a, s);
   const dim3 g(gp_grid(a)), b(GP_WAVES * 64);
   if (a.tags && !GP_PROG_ONLY) {
     if (a.res) hipLaunchKernelGGL((k_glstm_fwd<5, 0, true, true>), g, b, 0, s, a);
@@ -2381,7 +2395,7 @@ void launch_glstm_np_bwd(const GPersistArgs& a, hipStream_t s) {
 // ONE launch: the discriminator's trailing BPTT (d: DPersistArgs with the trailing fields) in front of the generator's (a.dout_trail = 1)
 int gpersist_dt_grid(const GPersistArgs& a, const DPersistArgs& d) { return gp_grid(a) + ((dpersist_trail_grid(d.nl, d.N) + 7) & ~7); }
 void launch_glstm_bwd_dt(const GPersistArgs& a, const DPersistArgs& d, hipStream_t s) {
-  gpersist_arm_bytes(a.gran2, gpersist_gran2_bytes(a), s);
+  gp_arm_gran2(a, s);
   const dim3 g(gpersist_dt_grid(a, d)), b(GP_WAVES * 64);
   if (a.tags) {
     if (a.res) hipLaunchKernelGGL((k_glstm_bwd_dt<5, true, true>), g, b, 0, s, a, d);
@@ -2391,7 +2405,7 @@ void launch_glstm_bwd_dt(const GPersistArgs& a, const DPersistArgs& d, hipStream
   g_chain_launches += 2;
 }
 void launch_glstm_fwd_dt(const GPersistArgs& a, const DPersistArgs& d, hipStream_t s) {
-  gpersist_arm_bytes(a.gran2, gpersist_gran2_bytes(a), s);
+  gp_arm_gran2(a, s);
   const dim3 g(gpersist_dt_grid(a, d)), b(GP_WAVES * 64);
   if (a.tags) {
     if (a.res) hipLaunchKernelGGL((k_glstm_fwd_dt<5, true, true>), g, b, 0, s, a, d);
@@ -2401,7 +2415,7 @@ void launch_glstm_fwd_dt(const GPersistArgs& a, const DPersistArgs& d, hipStream
   g_chain_launches += 2;
 }
 void launch_glstm_bwd(const GPersistArgs& a, hipStream_t s) {
-  gpersist_arm_bytes(a.gran2, gpersist_gran2_bytes(a), s);
+  gp_arm_gran2(a, s);
   const dim3 g(gp_grid(a)), b(GP_WAVES * 64);
   if (a.tags && !GP_PROG_ONLY) {
     if (a.res) hipLaunchKernelGGL((k_glstm_bwd<5, 0, true, true>), g, b, 0, s, a);

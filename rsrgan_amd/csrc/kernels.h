@@ -223,6 +223,8 @@ struct GPersistArgs {
   int dout_trail;
   // k_glstm_fwd_dt: the discriminator's forward recurrence follows inside this launch (RES: the top layer publishes its running sum too)
   int fwd_trail;
+  // a launch over ngl row groups starting at grp0 (0: all): gpersist_plan sets ngl = 1 when the whole stack's workgroups do not fit the device
+  int ngl, grp0;
 };
 constexpr int GP_TMAX = 2046;                     // longest launch (slot offsets are 32-bit; a longer batch takes the launch-per-phase path)
 bool gpersist_plan(GPersistArgs& a);              // fills NT / NC; false: shape not supported

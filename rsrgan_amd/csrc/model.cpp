@@ -1064,6 +1064,27 @@ void Model::gpersist_rearm() {
   (void)hipDeviceSynchronize();
 }
 
+// A stack planned as one launch per row group (GPersistArgs::ngl: res_lstm_l at 64 rows does not fit the device at once): the launches
+// one after the other; `fused` (k_glstm_fwd_dt / k_glstm_bwd_dt with the discriminator's half over ALL rows) rides the launch of group
+// `fused_at` -- the LAST forward launch (the FC workgroups read the earlier groups' chunks, which stay in their slots), the FIRST
+// backward launch (the later groups' launches find d(outputs) complete and do not poll).
+static void glstm_fwd_groups(GPersistArgs a, const DPersistArgs* d, hipStream_t s) {
+  const int ngr = a.N / GP_ROWS;
+  if (!a.ngl) { if (d) launch_glstm_fwd_dt(a, *d, s); else launch_glstm_fwd(a, s); return; }
+  for (int g = 0; g < ngr; ++g) {
+    a.grp0 = g;
+    if (d && g == ngr - 1) launch_glstm_fwd_dt(a, *d, s); else launch_glstm_fwd(a, s);
+  }
+}
+static void glstm_bwd_groups(GPersistArgs a, const DPersistArgs* d, hipStream_t s) {
+  const int ngr = a.N / GP_ROWS;
+  if (!a.ngl) { if (d) launch_glstm_bwd_dt(a, *d, s); else launch_glstm_bwd(a, s); return; }
+  for (int g = 0; g < ngr; ++g) {
+    a.grp0 = g;
+    if (d && g == 0) { a.dout_trail = 1; launch_glstm_bwd_dt(a, *d, s); } else { a.dout_trail = 0; launch_glstm_bwd(a, s); }
+  }
+}
+
 bool Model::persist_forward_g(int T, hipStream_t s) {
   if (!gp_fwd_on() || !wavefront() || seq_drop_on()) return false;
   GPersistArgs a{};
@@ -1084,12 +1105,12 @@ bool Model::persist_forward_g(int T, hipStream_t s) {
     for (size_t l = 0; l < gl.size(); ++l)
       prof_gp_flops += 2.0 * Bt * T * ((double)(gl[l].I + gl[l].P) * 4.0 * gl[l].H + (double)gl[l].H * gl[l].P);
     (void)hipEventRecord(prof_gp_ev[2 * prof_gp_n], s);
-    launch_glstm_fwd(a, s);
+    glstm_fwd_groups(a, nullptr, s);
     (void)hipEventRecord(prof_gp_ev[2 * prof_gp_n + 1], s);
     ++prof_gp_n;
     return true;
   }
-  launch_glstm_fwd(a, s);
+  glstm_fwd_groups(a, nullptr, s);
   return true;
 }
 
@@ -1145,7 +1166,7 @@ bool Model::persist_forward_g_trail(Chain& ch, int T, hipStream_t s, const float
   d.dy = y_tm; d.ld_dy = ldDout; d.fc_w = G.W(g_fc_out_w); d.ld_fcw = ldDout; d.fc_P = gR; d.fc_b = G.W(g_fc_out_b);
   d.noise = nf; d.dtop = xd; d.ld_dtop = ldDout; d.xd_Ns = ch[0].Ns; d.xd_row0 = ch[0].row0;
   if (check_only) return true;
-  launch_glstm_fwd_dt(a, d, s);
+  glstm_fwd_groups(a, &d, s);
   g_fwd_valid = true;
   return true;
 }
@@ -1216,13 +1237,11 @@ bool Model::persist_backward_g(Chain& ch, int T, hipStream_t s, bool check_only,
       prof_gb_flops += 2.0 * Bt * T * (double)Dout * gR;
     }
     (void)hipEventRecord(prof_gb_ev[2 * prof_gb_n], s);
-    if (gp_trail_next) launch_glstm_bwd_dt(a, dt_args, s); else launch_glstm_bwd(a, s);
+    glstm_bwd_groups(a, gp_trail_next ? &dt_args : nullptr, s);
     (void)hipEventRecord(prof_gb_ev[2 * prof_gb_n + 1], s);
     ++prof_gb_n;
-  } else if (gp_trail_next)
-    launch_glstm_bwd_dt(a, dt_args, s);
-  else
-    launch_glstm_bwd(a, s);
+  } else
+    glstm_bwd_groups(a, gp_trail_next ? &dt_args : nullptr, s);
   if (gp_phase == 1) return true;
   auto din0 = [&](hipStream_t q) {
     if (ch[0].din && !din_inside) {

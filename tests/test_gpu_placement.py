@@ -247,12 +247,14 @@ def test_tagged_ring_slots_across_batches_of_different_lengths(net):
     assert a["vars_sha"] == d["vars_sha"]
 
 
-@pytest.mark.parametrize("B,T", [(32, 9), (32, 50), (32, 1), (32, 2), (8, 7)])
+@pytest.mark.parametrize("B,T", [(32, 9), (32, 50), (32, 1), (32, 2), (8, 7), (64, 9), (64, 2)])
 def test_persistent_residual_generator_agrees(B, T):
     """Round 5: res_lstm_l (the g_type run_gan_rnn_placeholder.sh:124 ships; models/res_lstm_l.py:101-194: four LSTMCell(760, num_proj=257)
     with inputs_{l+1} = outputs_l + inputs_l) on the persistent launches: the running sum and its gradient travel from reducer to
     reducer inside k_glstm_fwd / k_glstm_bwd (csrc/gpersist.hip RES) -- against the launch-per-phase wavefront (RSRGAN_GP_RES=0).  P = 257
-    is no multiple of 4: the 16-byte pieces straddle the last column.  (8, 7): padded to one 32-row group."""
+    is no multiple of 4: the 16-byte pieces straddle the last column.  (8, 7): padded to one 32-row group.  (64, .): two row groups =
+    304 workgroups, more than the device holds at once: ONE LAUNCH PER ROW GROUP (GPersistArgs::ngl), the discriminator's half over all
+    rows riding the last forward / the first backward launch, the ring counters of the two groups advancing on their own."""
     size = {"RSRGAN_TEST_B": str(B), "RSRGAN_TEST_T": str(T), "RSRGAN_TEST_NET": "res_lstm_l", "RSRGAN_PAD_ROWS": "1"}
     a = _run(dict(size))
     b = _run(dict(size, RSRGAN_GP_RES="0", RSRGAN_PAD_ROWS="0"))
