@@ -547,6 +547,12 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   bwdb_ws_floats = (size_t)8 << 20;
   bwdb_ws = alloc<float>(bwdb_ws_floats);
   gemm_ws2 = alloc<float>(gemm_ws_floats ? gemm_ws_floats : 1);
+  static const bool dk_pad = [] { const char* e = getenv("RSRGAN_DK_PAD"); return !e || atoi(e) != 0; }();
+  if (dk_pad && !gl.empty() && gl[0].has_proj && gl[0].I % 4 != 0 && gl[0].ldI % 4 == 0 && gl.size() <= (size_t)GEMM_MAXB) {
+    dk_tmp_per = (size_t)(gl[0].ldI + gl[0].P) * 4 * gl[0].H;
+    dk_tmp = alloc<float>(dk_tmp_per * gl.size());
+    if (!dk_tmp) dk_tmp_per = 0;
+  }
   if (!gemm_ws2) side = nullptr;
   if (!side) dpipe = false;
   if (!scratch || !d_dB || !g_dB || !xd) { set_error("hipMalloc failed (activations)"); return RSRGAN_ERR_HIP; }
@@ -1340,9 +1346,12 @@ bool Model::batch_wgrads(Chain& ch, int T, hipStream_t s, bool dK_too, bool* dK_
   const LstmLayer& L0 = *rs[0]->L;
   for (auto* R : rs) {
     const LstmLayer& L = *R->L;
-    if (L.I != L0.I || L.P != L0.P || L.H != L0.H || L.ldI != L0.ldI || L.ldP != L0.ldP || L.ldH != L0.ldH || !L.has_proj || L.I % 4 != 0 ||
+    if (L.I != L0.I || L.P != L0.P || L.H != L0.H || L.ldI != L0.ldI || L.ldP != L0.ldP || L.ldH != L0.ldH || !L.has_proj ||
         R->N != rs[0]->N || R->Ns != R->N || R->row0 != 0)
       return false;
+    // (an input width that is no multiple of 4 -- res_lstm_l's 257: the kernel gradient is the caller's, over the zero-padded ld columns
+    //  into dk_tmp; the projection gradients and the column sums below do not care)
+    if (L.I % 4 != 0 && (dK_too || !dk_tmp || R->ps != &G)) return false;
   }
   const int H = L0.H, H4 = 4 * H, Rws = T * rs[0]->N;
   if ((size_t)rs.size() * 64 * 7 * H > scratch_floats) return false;
@@ -1428,8 +1437,16 @@ void Model::chain_wgrads(Chain& ch, int T, hipStream_t s, const StreamFn& betwee
     if (rest && rs.size() >= 2 && rs.size() <= (size_t)GEMM_MAXB) {
       const float *A_[GEMM_MAXB], *A2_[GEMM_MAXB], *B_[GEMM_MAXB]; float* C_[GEMM_MAXB];
       const LstmLayer& L0 = *rs[0]->L;
-      for (size_t i = 0; i < rs.size(); ++i) { A_[i] = rs[i]->in; A2_[i] = rs[i]->S->mst; B_[i] = rs[i]->S->gates; C_[i] = rs[i]->ps->Gd(rs[i]->L->tK); }
-      batched = launch_gemm_batch((int)rs.size(), A_, L0.ldI, A2_, L0.ldP, L0.I, B_, 4 * L0.H, C_, 4 * L0.H, L0.I + L0.P, 4 * L0.H, T * rs[0]->N, false, s, gemm_ws, gemm_ws_floats);
+      const bool padI = L0.I % 4 != 0;                     // (x over its ld columns into dk_tmp, rows copied behind: see model.h dk_tmp)
+      const int Ie = padI ? L0.ldI : L0.I;
+      for (size_t i = 0; i < rs.size(); ++i) { A_[i] = rs[i]->in; A2_[i] = rs[i]->S->mst; B_[i] = rs[i]->S->gates; C_[i] = padI ? dk_tmp + i * dk_tmp_per : rs[i]->ps->Gd(rs[i]->L->tK); }
+      batched = launch_gemm_batch((int)rs.size(), A_, L0.ldI, A2_, L0.ldP, Ie, B_, 4 * L0.H, C_, 4 * L0.H, Ie + L0.P, 4 * L0.H, T * rs[0]->N, false, s, gemm_ws, gemm_ws_floats);
+      if (batched && padI)
+        for (size_t i = 0; i < rs.size(); ++i) {
+          float* dK_ = rs[i]->ps->Gd(rs[i]->L->tK);
+          launch_copy_f(C_[i], dK_, L0.I * 4 * L0.H, s);
+          launch_copy_f(C_[i] + (size_t)Ie * 4 * L0.H, dK_ + (size_t)L0.I * 4 * L0.H, L0.P * 4 * L0.H, s);
+        }
     }
     for (auto& R : ch)
       if (R.want_wgrads) {
@@ -1447,9 +1464,17 @@ void Model::chain_wgrads(Chain& ch, int T, hipStream_t s, const StreamFn& betwee
     if (rs.size() >= 2 && rs.size() <= (size_t)GEMM_MAXB) {
       const float *A_[GEMM_MAXB], *A2_[GEMM_MAXB], *B_[GEMM_MAXB]; float* C_[GEMM_MAXB];
       const LstmLayer& L0 = *rs[0]->L;
-      for (size_t i = 0; i < rs.size(); ++i) { A_[i] = rs[i]->in; A2_[i] = rs[i]->S->mst; B_[i] = rs[i]->S->gates; C_[i] = rs[i]->ps->Gd(rs[i]->L->tK); }
-      batched = launch_gemm_batch((int)rs.size(), A_, L0.ldI, A2_, L0.ldP, L0.I, B_, 4 * L0.H, C_, 4 * L0.H, L0.I + L0.P, 4 * L0.H, T * rs[0]->N, false, s,
+      const bool padI = L0.I % 4 != 0;                     // (x over its ld columns into dk_tmp, rows copied behind: see model.h dk_tmp)
+      const int Ie = padI ? L0.ldI : L0.I;
+      for (size_t i = 0; i < rs.size(); ++i) { A_[i] = rs[i]->in; A2_[i] = rs[i]->S->mst; B_[i] = rs[i]->S->gates; C_[i] = padI ? dk_tmp + i * dk_tmp_per : rs[i]->ps->Gd(rs[i]->L->tK); }
+      batched = launch_gemm_batch((int)rs.size(), A_, L0.ldI, A2_, L0.ldP, Ie, B_, 4 * L0.H, C_, 4 * L0.H, Ie + L0.P, 4 * L0.H, T * rs[0]->N, false, s,
                                   (side && s == side) ? gemm_ws2 : gemm_ws, gemm_ws_floats);
+      if (batched && padI)
+        for (size_t i = 0; i < rs.size(); ++i) {
+          float* dK_ = rs[i]->ps->Gd(rs[i]->L->tK);
+          launch_copy_f(C_[i], dK_, L0.I * 4 * L0.H, s);
+          launch_copy_f(C_[i] + (size_t)Ie * 4 * L0.H, dK_ + (size_t)L0.I * 4 * L0.H, L0.P * 4 * L0.H, s);
+        }
     }
     if (!batched)
       for (auto& R : ch)

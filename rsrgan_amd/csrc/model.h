@@ -336,6 +336,10 @@ struct Model {
   hipEvent_t ev_pool[16] = {};
   int ev_next = 0;
   float* gemm_ws2 = nullptr;
+  // kernel gradients of layers whose input width is no multiple of 4 (res_lstm_l: 257): the stacked product [x (ld columns: the padding
+  // is zero) | m]^T dZ lands here, [ldI + P][4H] per layer, and its two row blocks are copied into dK behind it (chain_wgrads)
+  float* dk_tmp = nullptr;
+  size_t dk_tmp_per = 0;
   float* scratch2 = nullptr;
   bool overlap() const { return side != nullptr && (cfg.flags & RSRGAN_FLAG_OVERLAP) != 0; }
   Chain g_chain(int T);
