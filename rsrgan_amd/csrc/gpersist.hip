@@ -364,6 +364,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
   const int H = a.H, H4 = 4 * H, T = a.T, N = a.N, P = L.P, ldP = L.ldP, I = L.I, NC = a.NC;
   const int nkb = (P + 15) >> 4, nkbx = (I + 15) >> 4;
   const int row0 = grp * GP_ROWS, cell0 = c * CW;
+  const int nrt = a.nrt ? a.nrt : NR;                                 // live row tiles (GPersistArgs::nrt)
   gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
   // hop 1: [group][layer][parity][tile][k-block][producer] slots; hop 2: [group][layer][t][tile][k-block] slots
   const size_t g1_per = (size_t)GP_NCH * NC * GP_SLOT, g2_per = (size_t)GP_NCH * GP_SLOT;
@@ -439,6 +440,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
 #endif
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
+        if (r >= nrt) continue;
         GPT(6 * r + 0);
         if (!gp_wait(&S.cnt_x[r][w], (unsigned)t + 1u, dead)) return;     // x-part (+ bias) of step t, tile r
         GPT(6 * r + 1);
@@ -525,6 +527,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
     if (!TAG && reducer) {                                               // the last step's partials: leave every ring slot armed for the next launch
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
+        if (r >= nrt) continue;
         if (!gp_wait(&S.cnt_m[r], 2u * (unsigned)T, dead)) return;
         gp_rearm(b1, slot1((T - 1) % GP_R1, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
       }
@@ -560,6 +563,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
     for (int t = 0; t < T; ++t) {
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
+        if (r >= nrt) continue;
         // x(t) = the masked output of the layer below: fragments (k-block xw + 4 jj, tile r) of its m(t), two 16-byte pieces each
         unsigned lo[GP_KBW];
 #pragma unroll
@@ -644,6 +648,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
     if (cell0 + 4 * cq < H) *reinterpret_cast<float4*>(L.c + (size_t)(row0 + row) * H + cell0 + 4 * cq) = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (reducer && gp == 1 && lane < 32 && rcol < ldP) *reinterpret_cast<float4*>(L.mst + (size_t)rrow * ldP + rcol) = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r >= nrt) return;                                                // (a tile of padding rows: nothing to project, publish, sum or gather)
   for (int t = 0; t < T; ++t) {
     const int par = t & 1, par1 = (int)((c1 + (unsigned)t) % GP_R1);      // (c1 = 0 without tags)
     const unsigned tag1 = ((c1 + (unsigned)t) / GP_R1) & 1u;
@@ -825,6 +830,7 @@ __device__ __forceinline__ void gp_fcf_body(const GPersistArgs& a, const DPersis
   const size_t slot_stride_t = (size_t)DP_NQ * DP_SLOT;
   gu64* const gout = (gu64*)d.gran + ((size_t)(d.nl * RTn + fr) * T) * slot_stride_t;      // edge nl: layer 0's input
   const int row = 16 * fr + lr;
+  const bool deadt = a.nrt && r >= a.nrt;
   auto fail = [&]() { if (lane == 0) { S.dead = 1; __hip_atomic_store(err, 1u + (unsigned)blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } };
   if (w < 4) {
     // A operand: W_out[k = 16 jb + 4 q + u][p = 16 ct + lr], jb = w + 4 n (zero beyond K rows / Dn columns)
@@ -857,6 +863,10 @@ __device__ __forceinline__ void gp_fcf_body(const GPersistArgs& a, const DPersis
       // this wave's chunks of step t: all in flight, valid when no word carries the armed pattern
       u32x4 x[5];
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      if (deadt) {                                                 // (GPersistArgs::nrt: the generator publishes nothing for a tile of padding rows; m = 0)
+#pragma unroll
+        for (int n = 0; n < 5; ++n) x[n] = u32x4{0u, 0u, 0u, 0u};
+      } else
       for (unsigned polls = 0;; ++polls) {
         bool ok = true;
 #pragma unroll
@@ -1071,6 +1081,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
   const int H = a.H, H4 = 4 * H, T = a.T, N = a.N, P = L.P, ldP = L.ldP, I = L.I, NC = a.NC;
   const int nkb = (P + 15) >> 4, nkbx = (I + 15) >> 4;
   const int row0 = grp * GP_ROWS, cell0 = c * CW;
+  const int nrt = a.nrt ? a.nrt : NR;                                 // live row tiles (GPersistArgs::nrt)
   const bool top = l == a.nl - 1;
   gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
   const size_t g1_per = (size_t)GP_NCH * NC * GP_SLOT, g2_per = (size_t)GP_NCH * GP_SLOT;
@@ -1243,11 +1254,12 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
         gp_signal(cnt + C_F + r, lane);
       };
 #pragma unroll
-      for (int r = 0; r < NR; ++r) { fetch(T - 1, r); stage(r); }
+      for (int r = 0; r < NR; ++r) { if (r < nrt) { fetch(T - 1, r); stage(r); } }
       for (int s = 0; s < T; ++s) {
         const int t = T - 1 - s;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
+          if (r >= nrt) continue;
           GPTSR(18 + 2 * r);
           // back-pressure: ring slot s % GP_XR was summed AND re-armed by the layer below when it has published its dm(t + GP_XR - 2)
           // (its R waves re-arm a slot at the end of the step that summed it, acknowledged before the next step's partials leave,
@@ -1297,6 +1309,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
 #endif
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
+        if (r >= nrt) continue;
         GPTSR(6 * r + 0);
         if (!gp_wait(cnt + C_M + r, 2u * ((unsigned)s + 1u), dead)) return;      // dm(t) of the tile is in LDS
         GPTSR(6 * r + 1);
@@ -1388,6 +1401,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
     if (!TAG && dxr) {                                                     // the last step's slots: leave the ring armed for the next launch
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
+        if (r >= nrt) continue;
         if (!gp_wait(cnt + C_D + r, (unsigned)T, dead)) return;
         gp_rearm(b3x, slot1((T - 1) % GP_XR, r, jbr, 0) + (unsigned)hh * 512u, NC, w, lane);
       }
@@ -1417,6 +1431,7 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
     gp_signal(cnt + C_D + r, lane);
     return true;
   };
+  if (r >= nrt) return;                                                // (a tile of padding rows: no gradient to sum, publish or gather)
   for (int s = 0; s < T; ++s) {
     const int t = T - 1 - s;
     // ring positions of this step (c1 = c3 = 0 without tags): what the layer above wrote at step s, what this layer wrote at step s - 1

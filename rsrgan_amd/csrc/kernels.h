@@ -225,6 +225,10 @@ struct GPersistArgs {
   int fwd_trail;
   // a launch over ngl row groups starting at grp0 (0: all): gpersist_plan sets ngl = 1 when the whole stack's workgroups do not fit the device
   int ngl, grp0;
+  // live 16-row tiles of every row group (0: both).  1: rows 16..31 of the group are padding rows of a padded model (Bt <= 16: their length
+  // is 0 in every batch and everything they own in the stashes stays at the zeros of the allocation), so their tile lane does not run at
+  // all: no recurrent product, no cells, no hand-off pieces -- half the bytes of a step on the fabric
+  int nrt;
 };
 constexpr int GP_TMAX = 2046;                     // longest launch (slot offsets are 32-bit; a longer batch takes the launch-per-phase path)
 bool gpersist_plan(GPersistArgs& a);              // fills NT / NC; false: shape not supported

@@ -1030,7 +1030,13 @@ bool Model::gpersist_shape(GPersistArgs& a, int T) const {              // (size
   // num_proj=None (BASELINE.json's 2 x 512 generator): the single-hop form, forward only (gpersist.hip np_fwd_body)
   static const bool np_env = [] { const char* e = getenv("RSRGAN_GP_NOPROJ"); return !e || atoi(e) != 0; }();
   if (noproj) return np_env && !res && (gp_env & 1) && gpersist_np_plan(a, gp_np_nt);
-  return gpersist_plan(a);
+  if (!gpersist_plan(a)) return false;
+  // a padded model whose real rows fit one 16-row tile (the shipped batch_size = 8, decode's single utterance): the other tile of the
+  // row group holds padding rows only -- length 0 in every batch, zeros in every stash since the allocation -- and does not run
+  // (GPersistArgs::nrt).  RSRGAN_GP_NRT=0: both tiles run.
+  static const bool nrt_env = [] { const char* e = getenv("RSRGAN_GP_NRT"); return !e || atoi(e) != 0; }();
+  if (nrt_env && B == 32 && Bt <= 16) a.nrt = 1;
+  return true;
 }
 bool Model::gpersist_args(GPersistArgs& a, int T) const {
   if (!gpersist_shape(a, T)) return false;

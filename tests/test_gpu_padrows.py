@@ -38,7 +38,9 @@ def test_shipped_recipe_batch_against_oracle(B, T, flags):
         model.engine.g_backward(x, lab, ln, None, train=True, reuse=True, apply=False)
         n = (model.engine.profile_read_kind(1)[0], model.engine.profile_read_kind(2)[0])
         model.engine.profile_read()
-        assert n == (1, 1), "res_lstm_l did not take the persistent launches: %r" % (n,)
+        # (RSRGAN_DPIPE=1 in the environment: the D-run is k_glstm_fwd_dt, which the kind-1 bracket does not count)
+        want = ((0, 1), (1, 1)) if os.environ.get("RSRGAN_DPIPE", "0") != "0" else ((1, 1),)
+        assert n in want, "res_lstm_l did not take the persistent launches: %r" % (n,)
         assert model.engine.device_status() == 0
 
 

@@ -247,6 +247,24 @@ def test_tagged_ring_slots_across_batches_of_different_lengths(net):
     assert a["vars_sha"] == d["vars_sha"]
 
 
+@pytest.mark.parametrize("B,T,net,reuse", [(8, 100, "res_lstm_l", "0"), (8, 9, "res_lstm_l", "1"), (1, 30, "lstm", "1"), (16, 7, "lstm", "0"), (8, 1, "lstm", "1")])
+def test_single_tile_lane_for_padding_rows_changes_no_bit(B, T, net, reuse):
+    """Round 5: a padded model whose real rows fit ONE 16-row tile (the shipped batch_size = 8, run_gan_rnn_placeholder.sh:126; decode's
+    single utterance) runs one tile lane of the persistent generator launches (GPersistArgs::nrt = 1: the second tile of the row group
+    holds rows of length 0 -- dynamic_rnn's masking makes them inert, everything they own in the stashes is zero since the allocation
+    -- and neither computes nor publishes nor gathers; the FC workgroups of k_glstm_fwd_dt take zeros for its chunks) -- against both
+    lanes running (RSRGAN_GP_NRT=0).  The live tile's arithmetic and summation order are the same: the same bits, D-run, G-run (reusing
+    and recomputing the forward: k_glstm_fwd_dt) and the updated variables; no failed wait."""
+    size = {"RSRGAN_TEST_B": str(B), "RSRGAN_TEST_T": str(T), "RSRGAN_TEST_NET": net, "RSRGAN_PAD_ROWS": "1", "RSRGAN_TEST_REUSE": reuse}
+    a = _run(dict(size))
+    b = _run(dict(size, RSRGAN_GP_NRT="0"))
+    assert a["device_status"] == 0 and b["device_status"] == 0
+    assert a["gb_flops"] == b["gb_flops"] > 0, (a["gb_flops"], b["gb_flops"])      # the persistent launches ran
+    for k in ("d0", "g0", "d1", "g1"):
+        assert a[k] == b[k], (k, a[k], b[k])
+    assert a["vars_sha"] == b["vars_sha"]
+
+
 @pytest.mark.parametrize("B,T", [(32, 9), (32, 50), (32, 1), (32, 2), (8, 7), (64, 9), (64, 2)])
 def test_persistent_residual_generator_agrees(B, T):
     """Round 5: res_lstm_l (the g_type run_gan_rnn_placeholder.sh:124 ships; models/res_lstm_l.py:101-194: four LSTMCell(760, num_proj=257)
