@@ -326,7 +326,7 @@ __device__ __forceinline__ bool gp_sweep_prog(const GpBuf& b, const unsigned (&l
 template <int NT>
 struct GpLds {
   // (small, hot arrays first: a DS immediate offset reaches 64 KB; see DpTrailLds)
-  unsigned cnt_x[GP_NR][4], cnt_p[GP_NR], cnt_h[GP_NR], cnt_m[GP_NR], cnt_g[GP_NR], cnt_s[GP_NR], dead, pad_[13];
+  unsigned cnt_x[GP_NR][4], cnt_p[GP_NR], cnt_h[GP_NR], cnt_m[GP_NR], cnt_g[GP_NR], cnt_s[GP_NR], dead, cnt_j[GP_NR], pad_[11];
   int len[GP_ROWS];                         // the rows' lengths: read per step (a register that holds one for the whole launch was spilled, and a scratch reload sat in the cell phase and in front of the publication)
   float peep[4 * NT][4];                    // {w_i, w_f, w_o, -} per cell of this slice (one 16-byte read per cell)
   float bias[4 * NT][4];                    // {b_i, b_j, b_f, b_o} per cell: the accumulator registers of a lane
@@ -504,6 +504,7 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
         gp_signal(&S.cnt_h[r], lane);
         GPT(6 * r + 5);
         if (!gp_wait(&S.cnt_h[r], 4u * ((unsigned)t + 1u), dead)) return;     // every cell of the tile is in the stage
+        if ((a.sched & 2) && !gp_wait(&S.cnt_j[r], 2u * ((unsigned)t + 1u), dead)) return;   // (the lane's partial projections have left first)
         // the tile's stash (gate activations, c, h: 7.5 KB) from the LDS stage, a quarter per R wave: NT consecutive lanes write one
         // 16 NT-byte row piece.  The R waves do it: they have nothing in the vector-memory queue that it could delay (the X waves'
         // sweeps queued behind these stores, and a wave that publishes or polls must not have them in front of its hand-off traffic)
@@ -514,6 +515,9 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
           const float4 v = *reinterpret_cast<const float4*>(&S.st[k][row][4 * cq]);
           const size_t rowg = (size_t)t * N + row0 + row;
           float* dst = (k < 4 ? L.gates + rowg * H4 + k * H : k == 4 ? L.c + (rowg + N) * H : L.h + rowg * L.ldH) + cell0 + 4 * cq;
+#ifdef GP_ABL2
+          if (GP_ABL2 & 2) continue;                                     // timing ablation: no stash stores
+#endif
           if (e < 6 * 16 * NT && cell0 + 4 * cq < H) gp_stash_store(dst, v);
         }
         gp_signal(&S.cnt_s[r], lane);
@@ -587,6 +591,9 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
         } else if (!gp_sweep<GP_KBW, false, GP_KBW, true>(b2x, lo, nsx, frag_off, slot2(t, r, min(xw + 4 * (lane >> 1), nkbx - 1)) + (unsigned)(lane & 1) * 512u + 496u,
                                                     lane < 2 * nsx, err, [&](int k, const f32x4& v) { xv[k] = v; })) { fail(); return; }
         GPT(19 + 2 * r);
+        // (sched bit 0) not beside the lane's projection burst and publication: the product of step t starts when the G waves have issued
+        // the partial projections of step t - 1 (then the lane waits for its hand-off and the other lane's R burst is half a period away)
+        if ((a.sched & 1) && t > 0 && !gp_wait(&S.cnt_j[r], 2u * (unsigned)t, dead)) return;
         const bool live = t < S.len[16 * r + lr];
         f32x4 acc[NT];
 #pragma unroll
@@ -595,6 +602,9 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
         __builtin_amdgcn_s_setprio(1);                                 // (below the R waves' and the projection's bursts, above every spin loop)
 #pragma unroll
         for (int jj = 0; jj < GP_KBW; ++jj) {
+#ifdef GP_ABL2
+          if (GP_ABL2 & 1) continue;                                   // timing ablation: no x-part products
+#endif
           if (xw + 4 * jj < nkbx) {
             const float b0 = live ? xv[jj][0] : 0.f, b1 = live ? xv[jj][1] : 0.f, b2_ = live ? xv[jj][2] : 0.f, b3 = live ? xv[jj][3] : 0.f;
             float4 ka[NT];
@@ -670,12 +680,18 @@ __device__ __forceinline__ void gp_fwd_body(const GPersistArgs& a, GpLds<NT>& S,
 #pragma unroll
         for (int ks = 0; ks < NT; ++ks)
 #pragma unroll
-          for (int j = 0; j < 3; ++j) pm[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpw[(2 * (n0 + j) * NT + ks) * 64], hv[ks], pm[j], 0, 0, 0);
+          for (int j = 0; j < 3; ++j) {
+#ifdef GP_ABL2
+            if (GP_ABL2 & 4) continue;                                 // timing ablation: no projection products
+#endif
+            pm[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wpw[(2 * (n0 + j) * NT + ks) * 64], hv[ks], pm[j], 0, 0, 0);
+          }
 #pragma unroll
         for (int j = 0; j < 3; ++j)
           if (n0 + j < nvg) { if (TAG) gp_store_t(b1, pub0 + (unsigned)(2 * (n0 + j)) * (unsigned)NC * GP_SLOT, pm[j], tag1); else gp_store(b1, pub0 + (unsigned)(2 * (n0 + j)) * (unsigned)NC * GP_SLOT, pm[j]); }
       }
     }
+    if (a.sched & 3) gp_signal(&S.cnt_j[r], lane);
     GPT(14);
     f32x4 tot = {0.f, 0.f, 0.f, 0.f};
     if (reducer) {

@@ -229,6 +229,9 @@ struct GPersistArgs {
   // is 0 in every batch and everything they own in the stashes stays at the zeros of the allocation), so their tile lane does not run at
   // all: no recurrent product, no cells, no hand-off pieces -- half the bytes of a step on the fabric
   int nrt;
+  // bit 0: a lane's off-chain work waits for the lane's publication (gp_fwd_body: the X waves' product of step t + 1 and the R waves' stash
+  // store of step t start when the G waves have issued the partial projections of step t: LDS counter cnt_j) instead of colliding with it
+  int sched;
 };
 constexpr int GP_TMAX = 2046;                     // longest launch (slot offsets are 32-bit; a longer batch takes the launch-per-phase path)
 bool gpersist_plan(GPersistArgs& a);              // fills NT / NC; false: shape not supported

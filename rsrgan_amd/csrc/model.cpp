@@ -1036,6 +1036,10 @@ bool Model::gpersist_shape(GPersistArgs& a, int T) const {              // (size
   // (GPersistArgs::nrt).  RSRGAN_GP_NRT=0: both tiles run.
   static const bool nrt_env = [] { const char* e = getenv("RSRGAN_GP_NRT"); return !e || atoi(e) != 0; }();
   if (nrt_env && B == 32 && Bt <= 16) a.nrt = 1;
+  // the forward launch's off-chain work (the X waves' products, the stash stores) behind the lane's publication instead of beside it
+  // (GPersistArgs::sched; pays with two row groups on the fabric: 13.5 -> 13.0 us per step at 64 rows, nothing at 32).  RSRGAN_GP_SCHED=0..3
+  static const int sched_env = [] { const char* e = getenv("RSRGAN_GP_SCHED"); return e ? atoi(e) : -1; }();
+  a.sched = sched_env >= 0 ? sched_env : (B >= 64 ? 3 : 0);
   return true;
 }
 bool Model::gpersist_args(GPersistArgs& a, int T) const {

@@ -47,6 +47,7 @@ int main(int argc, char** argv) {
   if (bwd) { a.dout_top = dal((size_t)T * N * P, 0.01f); a.ld_dout = P; }
   if (!gpersist_plan(a)) { printf("unsupported shape\n"); return 1; }
   if (const char* e = getenv("GP_TAGS")) a.tags = atoi(e);
+  if (const char* e = getenv("GP_SCHED")) a.sched = atoi(e);
   if (const char* e = getenv("GP_NRT")) {                           // live row tiles per group (GPersistArgs::nrt): the rows of the dead tile get length 0
     a.nrt = atoi(e);
     if (a.nrt == 1) { for (int i = 0; i < N; ++i) if ((i & 31) >= 16) len[i] = 0; CK(hipMemcpy(dlen, len.data(), N * 4, hipMemcpyHostToDevice)); }
