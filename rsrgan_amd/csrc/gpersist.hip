@@ -1207,6 +1207,9 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
         for (int j = 0; j < 3; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
+#ifdef GP_ABL2
+          if ((GP_ABL2 & 8) && isx) continue;                           // timing ablation: no input-gradient products (zeros are published)
+#endif
           const float4 b = *reinterpret_cast<const float4*>(dzr + (r * NT + i) * 256);
           float4 ka[3];
 #pragma unroll
@@ -1252,6 +1255,9 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
         return *reinterpret_cast<const float4*>((k < 4 ? L.gates + rowg * H4 + k * H : L.c + rowg * H) + cell);
       };
       auto fetch = [&](int t, int r) {
+#ifdef GP_ABL2
+        if (GP_ABL2 & 32) { pv0 = pv1 = make_float4(0.3f, 0.3f, 0.3f, 0.3f); return; }      // timing ablation: no stash prefetch
+#endif
         int ln = lane;
         asm volatile("" : "+v"(ln));
         pv0 = fetch1(t, r, 0, ln);
@@ -1399,6 +1405,9 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
           const int cq = e % NT, pr = e / NT, row = 16 * r + (pr & 15), k = min(pr >> 4, 3);
           const float4 v = *reinterpret_cast<const float4*>(&S.st[k][row][4 * cq]);
           float* dst = L.gates + ((size_t)t * N + row0 + row) * H4 + k * H + cell0 + 4 * cq;
+#ifdef GP_ABL2
+          if (GP_ABL2 & 16) continue;                                    // timing ablation: no dz stores
+#endif
           if (e < 4 * 16 * NT && cell0 + 4 * cq < H) gp_stash_store(dst, v);
         }
         // This workgroup's G waves summed this step's partials before they gathered dm(t) (the wait at the top): re-arm their slots of
