@@ -650,7 +650,7 @@ def main():
         # running residual sum, models/res_lstm_l.py:101-194): 3*F_G + 8*F_D with F_G = 14 083 600
         del v
         torch.cuda.empty_cache()
-        vr = measure_sequence(a, "res_lstm_l", "lstm", B, T, n2, 2, rank, local, world, dev)
+        vr = measure_sequence(a, "res_lstm_l", "lstm", B, T, n2, 4, rank, local, world, dev)
         cr = vr["model"].engine.cfg
         fr, fgr, fdr = flop_per_frame(257, 40, vr["g_type"], cr.g_layers, cr.g_cells, cr.g_proj, cr.d_layers, cr.d_cells, cr.d_proj)
         out["variants"].append({"workload": "shipped network: G=res_lstm_l(4x760/p257) + D=lstm(2x256/p40), 1D+1G, B=%d T=%d" % (B, T),
@@ -661,7 +661,7 @@ def main():
         torch.cuda.empty_cache()
         # the shipped schedule: 1 D-run + 2 G-runs per batch (run_gan_rnn_placeholder.sh:129-130), reference-true networks
         a2 = argparse.Namespace(**vars(a)); a2.gen_updates = 2
-        v2 = measure_sequence(a2, "lstm", "lstm", B, T, n2, 2, rank, local, world, dev)
+        v2 = measure_sequence(a2, "lstm", "lstm", B, T, n2, 4, rank, local, world, dev)
         out["variants"].append({"workload": "shipped schedule 1D+2G per batch, reference-true networks, B=%d T=%d" % (B, T),
                                 "value": round(B * T * n2 / v2["dt"], 1), "unit": "frames/s", "ms_per_step": round(v2["dt"] * 1e3 / n2, 4)})
         del v2
@@ -685,7 +685,7 @@ def main():
         # batch is padded to one 32-row group of the persistent kernels (csrc/model.h Bt); and the same network at BASELINE configs[1]'s batch
         for (bb, gu, tag) in ((8, 2, "shipped recipe: G=res_lstm_l, batch_size 8, 1D+2G"), (32, 1, "shipped network at B=32 (one row group: persistent launches), 1D+1G")):
             a5 = argparse.Namespace(**vars(a)); a5.gen_updates = gu
-            v5 = measure_sequence(a5, "res_lstm_l", "lstm", bb, T, n2, 2, rank, local, world, dev)
+            v5 = measure_sequence(a5, "res_lstm_l", "lstm", bb, T, n2, 4, rank, local, world, dev)      # (4 warm-up steps: a segment is captured at its second use, replayed from the third)
             out["variants"].append({"workload": "%s, T=%d" % (tag, T), "value": round(bb * T * n2 / v5["dt"], 1), "unit": "frames/s",
                                     "ms_per_step": round(v5["dt"] * 1e3 / n2, 4)})
             del v5
