@@ -714,7 +714,7 @@ __global__ __launch_bounds__(768, 3) void k_dlstm_fwd_t(const DPersistArgs a) {
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 0) S.dead = 0;
   __syncthreads();
-  dp_fwdt_body(a, gen, S, (int)blockIdx.x, false);
+  dp_fwdt_body<false>(a, gen, S, (int)blockIdx.x, false);
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == gridDim.x - 1) {

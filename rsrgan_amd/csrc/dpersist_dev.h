@@ -140,6 +140,7 @@ struct DpTrailLds {
   int dead;
 };
 
+template <bool DEAD1>
 __device__ __forceinline__ void dp_bwdt_body(const DPersistArgs& a, const unsigned gen, DpTrailLds& S, const int bid) {
   const int RPn = a.N >> 5, RTn = a.N >> 4, ncl = a.nl * RPn;       // tile pairs
   const int cl = bid % ncl, cq = bid / ncl;
@@ -149,6 +150,7 @@ __device__ __forceinline__ void dp_bwdt_body(const DPersistArgs& a, const unsign
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = a.H, H4 = 4 * H, T = a.T, N = a.N, P = L.P, ldP = L.ldP, I = L.I;
   const bool top = l == a.nl - 1;
+  constexpr bool dead1 = DEAD1;                                     // tile 1 of the pair: padding rows only (DPersistArgs::nrt == 1: the caller picks the instantiation)
   gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
   const size_t slot_stride_t = (size_t)DP_NQ * DP_SLOT;
   auto edge = [&](int layer, int e, int r) -> gu64* {
@@ -214,6 +216,7 @@ __device__ __forceinline__ void dp_bwdt_body(const DPersistArgs& a, const unsign
     if (!top) {                                                    // dout of step T-1 for the prologue
 #pragma unroll
       for (int i = 0; i < DP_TPW; ++i) {
+        if (i == 1 && dead1) continue;
         const gu64* gx = edge(l + 1, 1, 2 * rp + i) + (size_t)j * DP_SLOT;
         if (!dp_sweep2(nullptr, gen, vm, gx + (size_t)(T - 1) * slot_stride_t, gen, vx, lane, err)) fail();
         put(S.part_x[i][(T - 1) & 1], vx);
@@ -230,6 +233,12 @@ __device__ __forceinline__ void dp_bwdt_body(const DPersistArgs& a, const unsign
         gu64* gout_m = edge(l, 0, r) + (size_t)cq * DP_SLOT;
         gu64* gout_x = edge(l, 1, r) + (size_t)cq * DP_SLOT;
         const bool wm = t < T - 1, wx = !top && t > 0;
+        if (i == 1 && dead1) {                                     // (the padding tile's phase: the two barriers)
+          __syncthreads();
+          if (S.dead) return;
+          __syncthreads();
+          continue;
+        }
         if (wm || wx) {
           if (!dp_sweep2(wm ? gm + (size_t)(t + 1) * slot_stride_t : nullptr, gen, vm,
                          wx ? gx + (size_t)(t - 1) * slot_stride_t : nullptr, gen, vx, lane, err)) fail();
@@ -250,7 +259,8 @@ __device__ __forceinline__ void dp_bwdt_body(const DPersistArgs& a, const unsign
     __syncthreads();                                               // C
     if (j < 3) {
 #pragma unroll
-      for (int i = 0; i < DP_TPW; ++i) publish_dx(dxacc[i], edge(l, 1, 2 * rp + i) + (size_t)cq * DP_SLOT);
+      for (int i = 0; i < DP_TPW; ++i)
+        if (!(i == 1 && dead1)) publish_dx(dxacc[i], edge(l, 1, 2 * rp + i) + (size_t)cq * DP_SLOT);
     }
     return;
   }
@@ -327,7 +337,7 @@ __device__ __forceinline__ void dp_bwdt_body(const DPersistArgs& a, const unsign
   for (int t = T - 1; t >= 0; --t) {
 #pragma unroll
     for (int i = 0; i < DP_TPW; ++i) {
-      if (i == my) {
+      if (i == my && !(my == 1 && dead1)) {
         __syncthreads();                                           // A(t, i)
         if (S.dead) return;
         const bool live = t < lenF;
@@ -424,6 +434,17 @@ __device__ __forceinline__ void dp_fcb_body(const DPersistArgs& a, const unsigne
   const size_t slot_stride_t = (size_t)DP_NQ * DP_SLOT;
   const gu64* gx = (const gu64*)a.gran + ((size_t)((0 * 2 + 1) * RTn + fr) * T) * slot_stride_t + (size_t)(w & 3) * DP_SLOT;
   float (*part)[DP_KB][64][4] = S.part_m[0];
+  if (a.nrt == 1 && (fr & 1)) {
+    // a tile of padding rows (DPersistArgs::nrt): nobody publishes an input gradient for it and the generator does not read its rows of
+    // d(outputs); they leave the armed pattern all the same (zeros: the gradient of rows of length 0), dy stays what the mse term left
+    for (int e = tid; e < T * 16 * (ldt >> 2); e += (int)blockDim.x) {
+      const int c4 = e % (ldt >> 2), rt = e / (ldt >> 2), rr = rt & 15, t = rt >> 4;
+      float* dst = a.dtop + ((size_t)t * N + 16 * fr + rr) * ldt + 4 * c4;
+      const f32x4 x = {0.f, 0.f, 0.f, 0.f};                          // (write-through like the live tiles': a generator lane that does run polls these rows past the caches)
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(x) : "memory");
+    }
+    return;
+  }
   if (w >= 8) return;                                              // (eight waves; a barrier counts the surviving waves)
   // A operand: W_out[c = 16 ct + lr][p = 16 kb + 4 q + u] (zero beyond P_fc rows / I columns)
   float4 wA[DP_FCT][DP_KB];
@@ -513,6 +534,7 @@ struct DpFwdTLds {
   int dead;
 };
 
+template <bool DEAD1>
 __device__ __forceinline__ void dp_fwdt_body(const DPersistArgs& a, const unsigned gen, DpFwdTLds& S, const int bid, const bool xin) {
   const int RPn = a.N >> 5, RTn = a.N >> 4, ncl = a.nl * RPn;
   const int cl = bid % ncl, cq = bid / ncl;
@@ -527,6 +549,7 @@ __device__ __forceinline__ void dp_fwdt_body(const DPersistArgs& a, const unsign
   const size_t slot_stride_t = (size_t)DP_NQ * DP_SLOT;
   auto edge = [&](int layer, int r) -> gu64* { return (gu64*)a.gran + ((size_t)(layer * RTn + r) * T) * slot_stride_t; };
   const int lx = l > 0 ? l - 1 : a.nl;                              // whose granules are my input (edge nl: the producer of layer 0's input)
+  constexpr bool dead1 = DEAD1;                                     // tile 1 of the pair: padding rows only (DPersistArgs::nrt == 1: the caller picks the instantiation)
 
   if (w >= 4 && w < 8) {
     // ---------------- gather waves ----------------
@@ -553,6 +576,7 @@ __device__ __forceinline__ void dp_fwdt_body(const DPersistArgs& a, const unsign
     if (xg) {                                                      // x_0 for the prologue
 #pragma unroll
       for (int i = 0; i < DP_TPW; ++i) {
+        if (i == 1 && dead1) continue;
         if (!dp_sweep2(nullptr, gen, vm, edge(lx, 2 * rp + i) + (size_t)j * DP_SLOT, gen, vx, lane, err)) fail();
         put(S.part_x[i][0], vx);
       }
@@ -568,6 +592,12 @@ __device__ __forceinline__ void dp_fwdt_body(const DPersistArgs& a, const unsign
         const gu64* gx = edge(lx, r) + (size_t)j * DP_SLOT;
         gu64* gout = edge(l, r) + (size_t)cq * DP_SLOT;
         const bool wm = t > 0, wx = xg && t + 1 < T;
+        if (i == 1 && dead1) {                                     // (the padding tile's phase: its barriers -- tile 0's x-part runs in it)
+          __syncthreads();
+          if (S.dead) return;
+          if (t < T) __syncthreads();
+          continue;
+        }
         if (wm || wx) {
           if (!dp_sweep2(wm ? gm + (size_t)(t - 1) * slot_stride_t : nullptr, gen, vm,
                          wx ? gx + (size_t)(t + 1) * slot_stride_t : nullptr, gen, vx, lane, err)) fail();
@@ -723,7 +753,8 @@ __device__ __forceinline__ void dp_fwdt_body(const DPersistArgs& a, const unsign
   if (!xg) load_x(0);
   __syncthreads();                                                 // P
   if (S.dead) return;
-  next_x(0);
+  constexpr bool idle = my == 1 && dead1;                           // this wave's tile is padding: barriers only
+  if (!idle) next_x(0);
   if (!xg) load_x(min(1, T - 1));
 
   for (int t = 0; t < T; ++t) {
@@ -731,7 +762,9 @@ __device__ __forceinline__ void dp_fwdt_body(const DPersistArgs& a, const unsign
     for (int i = 0; i < DP_TPW; ++i) {
       __syncthreads();                                             // A(t, i)
       if (S.dead) return;
-      if (i == my) {
+      if (idle) {
+        __syncthreads();                                           // B(t, i)
+      } else if (i == my) {
         f32x4 acc[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc[g] = accn[g];
@@ -796,7 +829,7 @@ __device__ __forceinline__ void dp_fwdt_body(const DPersistArgs& a, const unsign
     for (int i = 0; i < DP_TPW; ++i) {
       __syncthreads();                                             // A(T, i)
       if (S.dead) return;
-      if (i == my) {
+      if (i == my && !idle) {
         float4 ms[DP_KB];
         sum_parts(S.part_m[my], P, ms);
         const bool live_prev = (T - 1) < lenF;

@@ -960,7 +960,7 @@ __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_fwd_dt(const GPersis
     const unsigned dgen = __hip_atomic_load(dctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 0) { if (dbid < nD) S.d.dead = 0; else S.f.dead = 0; }
     __syncthreads();
-    if (dbid < nD) dp_fwdt_body(d, dgen, S.d, dbid, true);
+    if (dbid < nD) { if (d.nrt == 1) dp_fwdt_body<true>(d, dgen, S.d, dbid, true); else dp_fwdt_body<false>(d, dgen, S.d, dbid, true); }
     else gp_fcf_body(a, d, dgen, S.f, dbid - nD, RES);
     if (threadIdx.x == 0) {
       const unsigned old = __hip_atomic_fetch_add(dctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1625,7 +1625,7 @@ __global__ __launch_bounds__(GP_WAVES * 64, 3) void k_glstm_bwd_dt(const GPersis
     const unsigned dgen = __hip_atomic_load(dctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x == 0) S.d.dead = 0;
     __syncthreads();
-    if (dbid < nD) dp_bwdt_body(d, dgen, S.d, dbid);
+    if (dbid < nD) { if (d.nrt == 1) dp_bwdt_body<true>(d, dgen, S.d, dbid); else dp_bwdt_body<false>(d, dgen, S.d, dbid); }
     else dp_fcb_body(d, dgen, S.d, dbid - nD);
     if (threadIdx.x == 0) {
       const unsigned old = __hip_atomic_fetch_add(dctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

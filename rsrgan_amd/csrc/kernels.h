@@ -175,6 +175,9 @@ struct DPersistArgs {
   // forward launches over the rows [row0, row0 + N) of a stash that is Ns rows tall (0: N) -- the D-run's two discriminator calls write
   // the two halves of the stacked stash its BPTT reads (model.cpp Model::d_backward); len points at the launch's first row
   int Ns, row0;
+  // the trailing forms (dp_fwdt_body / dp_bwdt_body / dp_fcb_body): 1 = the second 16-row tile of every tile pair holds padding rows only
+  // (GPersistArgs::nrt): its phase is two barriers -- no sweep, no product, no publication, no stash rows
+  int nrt;
 };
 size_t dpersist_granule_bytes(int nl, int N, int T);
 int dpersist_trail_grid(int nl, int N);

@@ -1010,6 +1010,14 @@ bool Model::persist_forward(Chain& ch, int T, hipStream_t s) {
 
 // The generator's stack as ONE persistent launch (gpersist.hip).  Same stash as the wavefront launches leave (gates, c, h, mst, out of
 // every layer), so the backward pass does not know which forward ran.
+// the discriminator's halves of the fused launches: the second tile of the (only) tile pair is padding (DPersistArgs::nrt; RSRGAN_DP_NRT=0: it runs)
+int Model::trail_nrt() const {
+  static const bool on = [] {
+    const char* e = getenv("RSRGAN_DP_NRT"); const char* g = getenv("RSRGAN_GP_NRT");
+    return (!e || atoi(e) != 0) && (!g || atoi(g) != 0);             // (only beside a generator that drops the tile as well)
+  }();
+  return on && B == 32 && Bt <= 16 ? 1 : 0;
+}
 bool Model::gpersist_shape(GPersistArgs& a, int T) const {              // (sizes only: usable before any buffer exists)
   static const bool res_env = [] { const char* e = getenv("RSRGAN_GP_RES"); return !e || atoi(e) != 0; }();
   const bool res = cfg.g_type == RSRGAN_G_RES_LSTM_L && res_env;          // the running residual sum rides the hand-offs (gpersist.hip RES)
@@ -1181,6 +1189,7 @@ bool Model::persist_forward_g_trail(Chain& ch, int T, hipStream_t s, const float
   if (dpersist_granule_bytes(d.nl + 1, d.N, d.T) / 2 > dp_gran_bytes) return false;      // (one edge per layer and one for layer 0's input)
   d.dy = y_tm; d.ld_dy = ldDout; d.fc_w = G.W(g_fc_out_w); d.ld_fcw = ldDout; d.fc_P = gR; d.fc_b = G.W(g_fc_out_b);
   d.noise = nf; d.dtop = xd; d.ld_dtop = ldDout; d.xd_Ns = ch[0].Ns; d.xd_row0 = ch[0].row0;
+  d.nrt = trail_nrt();
   if (check_only) return true;
   glstm_fwd_groups(a, &d, s);
   g_fwd_valid = true;
@@ -1320,6 +1329,7 @@ bool Model::persist_backward_trail(Chain& ch, int T, hipStream_t s, float* dy, i
   a.dy = dy; a.ld_dy = ld_dy; a.fc_w = G.W(g_fc_out_w); a.ld_fcw = ldDout; a.fc_P = gR; a.dtop = dtop; a.ld_dtop = ld_dtop;
   if (!a.dout_top || a.N != B || dl[0].I != Dout || !dpersist_trail_supported(a) || dpersist_granule_bytes(a.nl, a.N, a.T) > dp_gran_bytes) return false;
   if (check_only) return true;
+  a.nrt = trail_nrt();
   dt_args = a;                                           // (persist_backward_g launches k_glstm_bwd_dt with it)
   return true;
 }

@@ -300,6 +300,7 @@ struct Model {
   void layer_wgrads(const LayerRun& R, int T, hipStream_t s);
   void chain_wgrads(Chain& ch, int T, hipStream_t s, const StreamFn& between, const StreamFn& pre = nullptr, const StreamFn& post = nullptr);   // all layers of a finished BPTT, on two streams
   void layer_wgrads_gemms(const LayerRun& R, int t0, int t1, bool accumulate, hipStream_t s, bool do_dK = true, bool do_dWp = true);
+  int trail_nrt() const;
   bool batch_wgrads(Chain& ch, int T, hipStream_t s, bool dK_too, bool* dK_done, bool check_only = false);      // all layers of one shape: one launch per kind
   void layer_wgrads_colsums(const LayerRun& R, int T, hipStream_t s, float* scr);
   // side stream: weight-gradient GEMMs (MFMA-bound) overlap the byte-bound backward wave

@@ -258,7 +258,9 @@ def test_single_tile_lane_for_padding_rows_changes_no_bit(B, T, net, reuse):
     size = {"RSRGAN_TEST_B": str(B), "RSRGAN_TEST_T": str(T), "RSRGAN_TEST_NET": net, "RSRGAN_PAD_ROWS": "1", "RSRGAN_TEST_REUSE": reuse}
     a = _run(dict(size))
     b = _run(dict(size, RSRGAN_GP_NRT="0"))
-    assert a["device_status"] == 0 and b["device_status"] == 0
+    c = _run(dict(size, RSRGAN_DP_NRT="0"))      # (the discriminator's halves of the fused launches drop the tile too: DPersistArgs::nrt)
+    assert a["device_status"] == 0 and b["device_status"] == 0 and c["device_status"] == 0
+    assert a["vars_sha"] == c["vars_sha"]
     assert a["gb_flops"] == b["gb_flops"] > 0, (a["gb_flops"], b["gb_flops"])      # the persistent launches ran
     for k in ("d0", "g0", "d1", "g1"):
         assert a[k] == b[k], (k, a[k], b[k])
