@@ -1026,14 +1026,19 @@ __device__ __forceinline__ bool gp_poll(const GpBuf& b, unsigned so, bool son, g
   }
 }
 
+#ifndef GP_RES_NB
+#define GP_RES_NB 10
+#endif
 // One wave sums the half chunks of ALL NC producers at base + p * GP_SLOT (off the critical path: a plain loop, four loads in flight --
 // the unrolled gp_sweep over 20 pieces cost the backward kernel 8 spilled registers): even producers in lanes 0..31, odd ones in
 // 32..63, then the two halves (even first); every lane ends with the total of its (lane & 31) piece.  false: time-out / peer failure.
-template <bool TAGGED = false>
+// NB loads in flight; POLL false: the pieces are there as a rule (the layer above is a diagonal ahead): read first, repeat a batch that is not complete.
+template <bool TAGGED = false, int NB = 4, bool POLL = true>
 __device__ __forceinline__ bool gp_sum_all(const GpBuf& b, unsigned base, int NC, int lane, gu32* err, f32x4& out, unsigned tag = 0u) {
   auto valid = [&](const u32x4& x) { return TAGGED ? gp_valid_t(x, tag) : gp_valid(x); };
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  if (!TAGGED) { if (!gp_poll(b, base + (unsigned)min(lane, NC - 1) * GP_SLOT + 496u, lane < NC, err)) return false; }
+  if (!POLL) {}
+  else if (!TAGGED) { if (!gp_poll(b, base + (unsigned)min(lane, NC - 1) * GP_SLOT + 496u, lane < NC, err)) return false; }
   else {
     const unsigned so = base + (unsigned)min(lane, NC - 1) * GP_SLOT + 496u;
     for (unsigned polls = 0;; ++polls) {
@@ -1045,18 +1050,18 @@ __device__ __forceinline__ bool gp_sum_all(const GpBuf& b, unsigned base, int NC
     }
   }
   f32x4 sa = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; 2 * k0 < NC; k0 += 4) {
+  for (int k0 = 0; 2 * k0 < NC; k0 += NB) {
     for (;;) {
-      u32x4 x[4];
+      u32x4 x[NB];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NB; ++j)
         x[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, base + (unsigned)min(2 * (k0 + j) + (lane >> 5), NC - 1) * GP_SLOT + (unsigned)(lane & 31) * 16u, 0, GP_SC1 | GP_VOL);
       bool ok = true;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ok &= (2 * (k0 + j) + (lane >> 5) >= NC) || valid(x[j]);
+      for (int j = 0; j < NB; ++j) ok &= (2 * (k0 + j) + (lane >> 5) >= NC) || valid(x[j]);
       if (__all(ok)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NB; ++j)
           if (2 * (k0 + j) + (lane >> 5) < NC) sa += gp_untag<TAGGED>(x[j]);
         break;
       }
@@ -1494,11 +1499,12 @@ __device__ __forceinline__ void gp_bwd_body(const GPersistArgs& a, GpLdsB<NT>& S
           if (top) Dl = f32x4{dtop.x, dtop.y, dtop.z, dtop.w};
           else {
             f32x4 dxt;
-            if (!gp_sum_all<TAG>(b3, slot1(rx, r, jbr, 0) + (unsigned)hh * 512u, NC, lane, err, dxt, tagx)) { fail(); return; }
             const unsigned off = slot2(t, r, jbr) + (unsigned)hh * 512u + (unsigned)(lane & 31) * 16u;
+            u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(b2du.rs, off, 0, GP_SC1 | GP_VOL);      // (D_{l+1}(t): in flight beside the partials; polled below if it was not there yet)
+            if (!gp_sum_all<TAG, GP_RES_NB, false>(b3, slot1(rx, r, jbr, 0) + (unsigned)hh * 512u, NC, lane, err, dxt, tagx)) { fail(); return; }      // (on the reducer's path: ten loads in flight, the same order of the sum)
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            u32x4 y;
             for (unsigned polls = 0;; ++polls) {
+              if (__all(gp_valid(y))) break;
               y = __builtin_amdgcn_raw_buffer_load_b128(b2du.rs, off, 0, GP_SC1 | GP_VOL);
               if (__all(gp_valid(y))) break;
               asm volatile("" ::: "memory");
