@@ -33,6 +33,35 @@ if ROOT not in sys.path:
 PEAK_FP32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
 
 
+ARITH_NOTE = ("fp32 MFMA (v_mfma_f32_16x16x4 / 32x32x2), fp32 accumulate; the ring hand-offs of the persistent generator launches "
+              "(the 38-way partial sums of every step and layer: projection / state-gradient / input-gradient partials) are rounded to "
+              "a 22-bit mantissa -- the lowest bit carries the ring pass's parity (RSRGAN_GP_TAGS=1, csrc/gpersist.hip gp_store_t); "
+              "everything else is IEEE fp32 like the reference (gan_rnn_placeholder.py:94-104)")
+
+
+def parity_margin(g_type, B, T):
+    """ACHIEVED error of the HIP path against the fp64 oracle for this workload as tests/test_gpu_fullsize.py
+    ::test_full_size_step_as_benched_against_oracle measured it on an MI355X (max relative error of the losses, worst gradient tensor's
+    relative L2 error, enhanced-MFCC L1), for RSRGAN_DPIPE on / off and tagged / untagged hand-offs; committed by
+    tools/mk_parity_margin.py.  The bounds are the north_star's 1e-3 (losses, MFCC) and the tests' 2e-3 (gradients)."""
+    path = os.path.join(ROOT, "profiles", "r6_parity_margin.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        doc = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    key = "%s_B%d_T%d" % (g_type, B, T)
+    rows = {k[len(key) + 1:]: v for k, v in doc.get("cases", {}).items() if k.startswith(key + "_")}
+    if not rows:
+        return None
+    cur = "dpipe%s_tags%s" % ("0" if os.environ.get("RSRGAN_DPIPE", "0") in ("", "0") else "1", "0" if os.environ.get("RSRGAN_GP_TAGS", "1") == "0" else "1")
+    sel = rows.get(cur)
+    return {"this_configuration": cur, "loss": sel and max(sel["loss"], sel["loss_after_updates"]), "grad": sel and max(sel["grad_d"], sel["grad_g"]),
+            "mfcc": sel and sel["mfcc_l1"], "bound": {"loss": 1e-3, "grad": 2e-3, "mfcc": 1e-3}, "all_configurations": rows,
+            "source": "profiles/r6_parity_margin.json (%s)" % doc.get("measured", "")}
+
+
 def flop_per_frame(din, dout, g_type, gl, gh, gp, dl_, dh, dp):
     lstmp = lambda i, h, p: 2 * ((i + p) * 4 * h + h * p) if p > 0 else 2 * (i + h) * 4 * h     # p == 0: num_proj=None
     gp_out = gp if gp > 0 else gh
@@ -459,6 +488,76 @@ def bench_segan(a, rank, local, world, dev):
     rdist.barrier()
 
 
+def spawn_ranks(n, backend):
+    """Re-run this command line as n ranks of one node under torch.distributed.run (rendezvous on 127.0.0.1: the container's hostname
+    may not resolve).  Fails loudly -- non-zero, nothing printed on stdout -- when the node has fewer GPUs than ranks."""
+    import socket
+    import subprocess
+    if backend == "nccl":
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print("bench.py: --gpus %d but %d GPU(s) visible: refusing to measure fewer devices than asked for" % (n, have), file=sys.stderr)
+            return 3
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, _usable_cpus() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def bench_plumbing(a, rank, world):
+    """--backend gloo: this script's rank plumbing on CPU, with an engine injected by the caller (RSRGAN_BENCH_ENGINE=module:factory,
+    factory(batch_size, max_frames, rank) -> engine speaking rsrgan_amd/engine_hip.py's protocol).  bench.py itself never imports the
+    oracle outside cpu_baseline; the product path has no CPU engine, so without an injected one this refuses."""
+    import importlib
+    from types import SimpleNamespace
+    from rsrgan_amd import GAN_RNN, dist as rdist
+    spec = os.environ.get("RSRGAN_BENCH_ENGINE")
+    if not spec:
+        raise SystemExit("bench.py --backend gloo: no GPU path on CPU (there is no CPU fallback); set RSRGAN_BENCH_ENGINE=module:factory")
+    mod, fn = spec.split(":")
+    B, T = min(a.batch, 2), min(a.frames, 4)
+    engine = getattr(importlib.import_module(mod), fn)(B, T, rank)
+    args = SimpleNamespace(batch_size=B, input_dim=engine.cfg.input_dim, output_dim=engine.cfg.output_dim, left_context=0, right_context=0,
+                           g_type=engine.cfg.g_type, keep_prob=1.0, batch_norm=False, num_gpu=world, save_dir=None, l2_scale=0.0,
+                           disc_updates=1, gen_updates=a.gen_updates, init_mse_weight=10.0, init_disc_noise_std=0.0,
+                           d_learning_rate=1e-3 * world, g_learning_rate=8e-5 * world)
+    model = GAN_RNN(None, args, ["cpu:%d" % rank], engine=engine, max_frames=T)
+    x, lab, ln = synthetic(B, T, engine.cfg.input_dim, engine.cfg.output_dim, seed=1234 + rank)
+
+    def step():
+        model.d_step(x, lab, ln, sync=False, gather=False)
+        out = None
+        for i in range(a.gen_updates):
+            out = model.g_step(x, lab, ln, reuse_g_forward=(i == 0), sync=False, gather=False)
+        return out
+    for _ in range(a.warmup):
+        step()
+    rdist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        last = step()
+    rdist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t[0])
+    if rank == 0:
+        print(json.dumps({"metric": "GAN train frames/sec (G+D step), 257-dim LPS->40-dim MFCC", "value": round(B * T * world * a.steps / dt, 1),
+                          "unit": "frames/s", "n_gpus": world, "rccl_ranks": rdist.world_size(), "backend": "gloo", "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": round(dt * 1e3 / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "n/a", "data": "synthetic",
+                          "config": {"workload": "PLUMBING TEST ONLY: injected CPU engine %s, B=%d T=%d per rank; no GPU, not a measurement" % (spec, B, T),
+                                     "global_batch": B * world, "parallelism": "dp%d" % world,
+                                     "losses_last_step": [round(float(v), 6) for v in last.mean(0)]},
+                          "roofline": None}), flush=True)
+    rdist.barrier()
+
+
 def main():
     # The sequence benches keep their synthetic batch resident on the device (the contract: inputs in HBM when the timed region starts)
     # and draw no discriminator noise (init_disc_noise_std = 0), so they can give the library the guarantee RSRGAN_DPIPE=1 asks for --
@@ -492,6 +591,10 @@ def main():
                     help="strong scaling (SURVEY 8d): --batch is the GLOBAL batch, split evenly over the ranks (default: weak, "
                          "--batch per GPU as the reference defines batch_size per tower)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)      # internal: net,B,T,threads -> one timed CPU-baseline leg
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the product).  gloo = no GPU: only the rank plumbing of this script (spawn, rendezvous, "
+                         "barriers, MAX over ranks, the one JSON line) runs, on an engine the CALLER injects through "
+                         "RSRGAN_BENCH_ENGINE=module:factory -- the tests' CPU stand-in; nothing is measured that means anything")
     a = ap.parse_args()
     if a.cpu_worker:
         net, B, T, th = a.cpu_worker.split(",")
@@ -499,11 +602,21 @@ def main():
         print(json.dumps({"steps": n, "seconds": dt}), flush=True)
         return
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU, models/gan_rnn_placeholder.py:152-175's
+        # tower loop; scripts/train_gan_rnn_placeholder.py:414-425,458-461) and hand their exit code on
+        sys.exit(spawn_ranks(a.gpus, a.backend))
+
     from rsrgan_amd import GAN_RNN, dist as rdist
-    rank, local, world = rdist.init_from_env("nccl")
+    rank, local, world = rdist.init_from_env(a.backend)
     if world != max(a.gpus, 1):
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
+        # never a silent one-GPU number under an N-GPU label (or the reverse)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch N ranks (torch.distributed.run --nproc-per-node N) with --gpus N, "
+                         "or run `python bench.py --gpus N` alone, which spawns them" % (a.gpus, world))
+    if a.backend == "gloo":
+        return bench_plumbing(a, rank, world)
+    if torch.cuda.device_count() <= local:
+        raise SystemExit("bench.py: rank %d needs GPU %d, %d visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if a.strong:
@@ -577,9 +690,6 @@ def main():
                 roof["traffic_is"] = "L2 fabric requests of serialised cold-L2 dispatches incl. Infinity-Cache hits (PMC): an upper bound"
                 roof["hbm_activity"] = res["hbm"]
                 ratio["memory_controllers"] = round(res["hbm"]["hbm_bytes_per_step_estimate"] / ALG_BYTES, 2)
-                ratio["note"] = ("the two persistent generator launches alone keep the memory controllers 23 / 26 % busy (2.4 / 3.5 GB per "
-                                 "launch, profiles/r5_hbm_phases.txt): their write-through hand-off pieces DO reach DRAM -- about three "
-                                 "quarters of the step's memory-controller bytes; the step is at ~16 % of the HBM roof")
             roof["traffic_ratio"] = ratio
             if res.get("chain"):
                 # the third bound: the recurrence is a chain of dependent launches; each costs at least a kernel boundary
@@ -618,7 +728,9 @@ def main():
                "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(dt * 1e3 / a.steps, 4), "ms_per_step_median": round(res["med_ms"], 4),
                "higher_is_better": True, "scaling": "strong" if a.strong else "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rccl_ranks": rdist.world_size(),
+               "arith": ARITH_NOTE if os.environ.get("RSRGAN_GP_TAGS", "1") != "0" else "fp32 MFMA / fp32 accumulate, untagged hand-offs (RSRGAN_GP_TAGS=0)",
+               "parity_margin": parity_margin(g_type, B, T),
                "config": {"workload": "gan_rnn_placeholder 1D+%dG step, G=%s(%dx%d/p%d)+D=%s(%dx%d/p%d), B=%d/GPU T=%d, "
                                       "257->40" % (a.gen_updates, g_type, c.g_layers, c.g_cells, c.g_proj, a.d_type, c.d_layers,
                                                    c.d_cells, c.d_proj, B, T),

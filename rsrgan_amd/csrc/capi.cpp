@@ -32,12 +32,15 @@ static int guard(const char* what, F&& body) {
 // against the caller's stream by events on both sides.
 struct StreamScope {
   Model& m; hipStream_t caller, work;
-  StreamScope(Model& m_, void* s) : m(m_), caller((hipStream_t)s), work(m_.enter((hipStream_t)s)) { m.last_work = work; }
+  StreamScope(Model& m_, void* s) : m(m_), caller((hipStream_t)s), work(m_.enter((hipStream_t)s)) {}
   ~StreamScope() {
     // (RSRGAN_DPIPE) whatever this call did to the discriminator's weights, stash or input rows is complete behind this point -- unless
     // the call has recorded the event itself, earlier (rsrgan_g_step / rsrgan_g_backward behind the fused backward launch)
-    if (m.dpipe && !m.dfree_inside) (void)hipEventRecord(m.ev_dfree, work);
+    if (m.dpipe && !m.dfree_inside) { (void)hipEventRecord(m.ev_dfree, work); m.dfree_current = true; }
     m.dfree_inside = false;
+    // rsrgan_device_status waits for THIS point of the caller's stream through an event of the handle's own: the stream itself may be
+    // gone by then (a raw copy of a destroyed stream is a dangling handle)
+    if (m.ev_last && hipEventRecord(m.ev_last, work) == hipSuccess) m.ev_last_set = true;
     m.leave(caller, work);
   }
 };
@@ -330,7 +333,8 @@ int rsrgan_device_status(rsrgan_handle h, int32_t* code) {
   *code = 0;
   // the streams this handle has worked on (not the whole device: other handles and other tenants are none of this call's business;
   // see also gpersist.hip k_arm for what a device-wide synchronisation + blocking copy did to replayed fill nodes)
-  for (hipStream_t q : {m.main_s, m.last_work, m.side})
+  if (m.ev_last_set && hipEventSynchronize(m.ev_last) != hipSuccess) { set_error("hipEventSynchronize failed"); return RSRGAN_ERR_HIP; }
+  for (hipStream_t q : {m.main_s, m.side})
     if (q && hipStreamSynchronize(q) != hipSuccess) { set_error("hipStreamSynchronize failed"); return RSRGAN_ERR_HIP; }
   if (!m.dp_ctl && !m.gp_ctl) return RSRGAN_OK;
   // the control blocks of the persistent recurrences (dpersist.hip, gpersist.hip): the first failure wins; a generator failure is

@@ -2316,8 +2316,11 @@ int device_cu_count() {
 }
 bool resident_probe(int grid, int threads, size_t lds_bytes) {
   static const bool off = [] { const char* e = getenv("RSRGAN_RESIDENT_PROBE"); return e && atoi(e) == 0; }();
+  // RSRGAN_RESIDENT_CAP=n: the verdict of a device that can hold n workgroups (what a CU mask or a compute partition makes the probe
+  // find; masks are not honoured in every environment, the cap always is -- tests/test_gpu_padrows.py)
+  static const int cap = [] { const char* e = getenv("RSRGAN_RESIDENT_CAP"); return e ? atoi(e) : 0; }();
   if (grid < 1) return false;
-  if (grid > device_cu_count()) return false;                          // (one workgroup per CU at these footprints)
+  if (grid > device_cu_count() || (cap > 0 && grid > cap)) return false;      // (one workgroup per CU at these footprints)
   if (off) return true;
   if (lds_bytes < (size_t)82 * 1024) lds_bytes = (size_t)82 * 1024;    // (more than half a CU's LDS: one probe workgroup per CU, whatever the real kernel's registers allow)
   unsigned* ctl = nullptr;

@@ -523,6 +523,7 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
   scratch2 = alloc<float>(std::max<size_t>(4 * 64 * maxcols, 1024));
   g_fc_out_wT = g_dnn() ? nullptr : alloc<float>((size_t)Dout * ldP);
   if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) side = nullptr;
+  if (hipEventCreateWithFlags(&ev_last, hipEventDisableTiming) != hipSuccess) ev_last = nullptr;
   {
     const char* e = getenv("RSRGAN_DPIPE");
     if (e && atoi(e) != 0 && trail_fits && side && !d_dnn() && dp_max_grid >= dpersist_grid((int)dl.size(), B)) {
@@ -607,6 +608,7 @@ void Model::destroy() {
     (void)hipStreamDestroy(side);
     side = nullptr;
   }
+  if (ev_last) { (void)hipEventDestroy(ev_last); ev_last = nullptr; ev_last_set = false; }
   if (ev_dfree) { (void)hipEventDestroy(ev_dfree); ev_dfree = nullptr; }
   if (ev_real) { (void)hipEventDestroy(ev_real); ev_real = nullptr; }
   dpipe = false;
@@ -1016,7 +1018,8 @@ int Model::trail_nrt() const {
     const char* e = getenv("RSRGAN_DP_NRT"); const char* g = getenv("RSRGAN_GP_NRT");
     return (!e || atoi(e) != 0) && (!g || atoi(g) != 0);             // (only beside a generator that drops the tile as well)
   }();
-  return on && B == 32 && Bt <= 16 ? 1 : 0;
+  // (and only when every recurrence of both nets runs persistent: see gpersist_shape's note on the padding rows of the stash)
+  return on && B == 32 && Bt <= 16 && (gp_env & 3) == 3 && (dp_env & 3) == 3 ? 1 : 0;
 }
 bool Model::gpersist_shape(GPersistArgs& a, int T) const {              // (sizes only: usable before any buffer exists)
   static const bool res_env = [] { const char* e = getenv("RSRGAN_GP_RES"); return !e || atoi(e) != 0; }();
@@ -1043,7 +1046,9 @@ bool Model::gpersist_shape(GPersistArgs& a, int T) const {              // (size
   // row group holds padding rows only -- length 0 in every batch, zeros in every stash since the allocation -- and does not run
   // (GPersistArgs::nrt).  RSRGAN_GP_NRT=0: both tiles run.
   static const bool nrt_env = [] { const char* e = getenv("RSRGAN_GP_NRT"); return !e || atoi(e) != 0; }();
-  if (nrt_env && B == 32 && Bt <= 16) a.nrt = 1;
+  // (only when BOTH recurrences run persistent: a launch-path forward writes gate activations into the padding rows of the stash,
+  // which a one-lane BPTT would never turn into dz = 0 -- the weight-gradient products would read them as dZ)
+  if (nrt_env && B == 32 && Bt <= 16 && (gp_env & 3) == 3) a.nrt = 1;
   // the forward launch's off-chain work (the X waves' products, the stash stores) behind the lane's publication instead of beside it
   // (GPersistArgs::sched; pays with two row groups on the fabric: 13.5 -> 13.0 us per step at 64 rows, nothing at 32).  RSRGAN_GP_SCHED=0..3
   static const int sched_env = [] { const char* e = getenv("RSRGAN_GP_SCHED"); return e ? atoi(e) : -1; }();
@@ -1814,6 +1819,8 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
   if (supervised()) { set_error("RSRGAN_FLAG_SUPERVISED: the trainer graph has no discriminator step"); return RSRGAN_ERR_STATE; }
   if (g_dnn()) return dnn_d_backward(x, labels, T, out_losses, want_grads, s);
   if (d_dnn()) { nr = nullptr; nf = nullptr; }    // discriminator_dnn.py:58: the noise layer is commented out
+  bn_eval_call = !want_grads;                      // (is_training of this fetch: the DropoutWrapper masks; read by seq_drop_on() below)
+  dfree_current = false;                           // this run writes the discriminator's stash and input rows
   // RSRGAN_DPIPE: D(real) on the side stream, ahead of this call's place in the stream; the run itself is k_glstm_fwd_dt (D(G(x)) trailing)
   bool dsplit = false;
   // (RSRGAN_DPIPE=1 covers labels and lengths; a noise_real tensor drawn on the caller's stream right before the call is covered by =2 only)
@@ -1832,7 +1839,6 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
     (void)hipEventRecord(ev_real, side);
     (void)hipStreamWaitEvent(s, ev_real, 0);
   }
-  bn_eval_call = !want_grads;                      // (is_training of this fetch: the DropoutWrapper masks)
   if (seq_drop_on()) launch_drop_tick(drop_ctr, s);     // a new training run: new masks (read from device memory: graph-safe)
   // rsrgan_d_step: the update follows in the same call -- its launches close this segment (one graph: no launch boundary in front
   // of the clip / SGD / weight-copy kernels); RSRGAN_FUSED_SEG=0 keeps them in a segment of their own
@@ -1913,6 +1919,7 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   if (!labels) { set_error("labels required"); return RSRGAN_ERR_INVALID; }
   if (g_dnn()) return dnn_g_backward(x, labels, T, out_losses, want_grads, reuse, s);
   bn_eval_call = !want_grads;                      // (is_training of this fetch)
+  dfree_current = false;                           // this run reads and writes the discriminator's stash
   if (seq_drop_on()) { reuse = false; launch_drop_tick(drop_ctr, s); }     // a new sess.run: new DropoutWrapper masks, a new forward
   if (supervised()) {
     // RNNTrainer (models/rnn_trainer.py:131-156): g_loss = 0.5*Dout*mse(G(x), labels) + l2; no discriminator in the graph
@@ -2167,7 +2174,7 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
   if (gsplit) {
     defer_wgrads = false;
     (void)hipEventRecord(ev_dfree, s);
-    dfree_inside = true;
+    dfree_inside = true; dfree_current = true;
     run_seg(seg_key(SEG_G_MAIN, T, kbits | 64u | 256u), s, bwd_rest);
   }
   if (inl) apply_inlined |= 1;
@@ -2239,7 +2246,10 @@ int Model::apply(int net, hipStream_t s) {
   } else if (net == RSRGAN_NET_G) {
     if (!g_grads_ready) { set_error("apply(G) without gradients"); return RSRGAN_ERR_STATE; }
     if (!(apply_inlined & 1)) run_seg(seg_key(SEG_APPLY_G, 0, 0), s, [&]() { apply_body(RSRGAN_NET_G, s); });
-    dfree_inside = true;                         // (RSRGAN_DPIPE: the generator's update touches nothing the next D(real) reads or writes)
+    // (RSRGAN_DPIPE: the generator's update touches nothing the next D(real) reads or writes, so the event stays where the G-run's
+    // backward launch -- or the previous call's end -- recorded it; a run that has used the discriminator's stash since and has NOT
+    // recorded it leaves the record to the end of this call)
+    if (dfree_current) dfree_inside = true;
     apply_inlined &= ~1;
     scal[RSRGAN_ADAM_STEP] += 1;
     g_grads_ready = false;

@@ -168,6 +168,7 @@ struct Model {
   // host runs ahead; the D-run itself is k_glstm_fwd_dt with D(G(x)) trailing + the stacked BPTT.
   bool dpipe = false;
   bool dfree_inside = false;                              // this call recorded ev_dfree itself (behind the fused backward launch)
+  bool dfree_current = false;                             // ev_dfree has been recorded behind the last run that touched the discriminator's stash / input rows
   int gp_phase = 0;                                       // persist_backward_g: 1 the launch only, 2 what follows it (the G-run split in two graph segments around ev_dfree)
   hipEvent_t ev_dfree = nullptr, ev_real = nullptr;
   unsigned long long* dp_gran2 = nullptr;                 // granules / control block of the D(real) launch (it may overlap another discriminator launch's epilogue)
@@ -366,7 +367,7 @@ struct Model {
   std::unordered_map<uint64_t, GraphSlot> graphs;
   hipStream_t main_s = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
-  hipStream_t last_work = nullptr;                        // the stream the last call worked on (rsrgan_device_status waits for it)
+  hipEvent_t ev_last = nullptr; bool ev_last_set = false; // recorded behind every call on the stream it worked on (rsrgan_device_status waits for it)
   float *noise_r_buf = nullptr, *noise_f_buf = nullptr;      // staged gaussian_noise_layer draws [B][Dout]
   bool graphs_on() const { return (cfg.flags & RSRGAN_FLAG_GRAPH) != 0 && wavefront() && !overlap() && !prof_on && !g_dnn() && graphs_env; }
   bool graphs_env = true;

@@ -128,11 +128,21 @@ class HipEngine:
         waits for -- not for the compute stream): what RSRGAN_DPIPE=1 asks of the labels and lengths of a D-run (include/rsrgan.h
         rsrgan_d_step), so that D(real) of the next step can run beside the previous step's tail.  Device tensors pass through: a
         caller that hands them in under RSRGAN_DPIPE=1 vouches for them itself."""
-        if isinstance(a, torch.Tensor) and a.device == self.device:
-            return a.to(torch.int32).contiguous() if int32 else a.to(torch.float32).contiguous()
         us = getattr(self, "_upload_stream", None)
         if us is None:
             us = self._upload_stream = torch.cuda.Stream(self.device)
+        if isinstance(a, torch.Tensor) and a.device == self.device:
+            want = torch.int32 if int32 else torch.float32
+            if a.dtype == want and a.is_contiguous():
+                return a
+            # an int64 `lengths`, a float64 or strided label: the conversion is a KERNEL.  Queued on the current stream it would sit
+            # behind that stream's backlog while D(real) on the library's side stream reads its output ahead of it -- so it runs on
+            # the upload stream (the caller vouches for `a` itself being complete) and the host waits for it, as for a host array.
+            with torch.cuda.stream(us):
+                t = a.to(want).contiguous()
+            us.synchronize()
+            t.record_stream(torch.cuda.current_stream(self.device))
+            return t
         t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a) if int32 else np.ascontiguousarray(a, dtype=np.float32))
         with torch.cuda.stream(us):
             t = t.to(self.device, non_blocking=True)

@@ -233,3 +233,11 @@ def _mask_of_tag(seed, run, tag, rows, cols, keep_prob):
         x = x ^ (x >> np.uint64(31))
     thr = int(float(np.float32(keep_prob)) * 16777216.0)
     return ((x >> np.uint64(40)) < np.uint64(thr)).reshape(rows, cols).astype(np.float64)
+
+
+def bench_engine(batch_size, max_frames, rank):
+    """RSRGAN_BENCH_ENGINE=tests.helpers:bench_engine -- the CPU stand-in bench.py's `--backend gloo` plumbing test runs on
+    (tests/test_bench_ranks.py).  Identical variables on every rank, like the replicas of the product."""
+    cfg = small_cfg()
+    g, d = rand_params(cfg, 5)
+    return OracleEngine(cfg, g, d, batch_size)

@@ -128,3 +128,150 @@ def test_full_size_schedules_agree_and_padding_is_inert():
     assert np.array_equal(y, y2)
     l2 = a.engine.g_backward(x2, lab, ln, None, train=True, reuse=False, apply=False).cpu().numpy()
     assert np.allclose(la, l2, rtol=1e-6)
+
+
+# ---- the configuration bench.py TIMES, against the fp64 oracle (round 6) ---------------------------------------------------------
+# bench.py enqueues steps without a host wait on one stream, device-resident batches, hipGraph replay (flags = 3), and gives the
+# library the guarantee RSRGAN_DPIPE=1 asks for (D(real) of the next D-run on the side stream beside the previous G-run's
+# weight-gradient GEMMs, the D-run itself = k_glstm_fwd_dt with D(G(x)) trailing over rows [B, 2B)); the ring hand-offs of the
+# persistent generator launches carry a pass-parity tag in the lowest mantissa bit of every partial sum (RSRGAN_GP_TAGS=1: a 22-bit
+# mantissa on those partials).  Each case below runs in a process of its own (the switches are read once per process) and compares
+# with the oracle -- NOT with another configuration of the library: losses 1e-3, every gradient tensor 2e-3, enhanced-MFCC L1 1e-3
+# (gan_rnn_placeholder.py:207-213,244-260; train_gan_rnn_placeholder.py:72-101).  The ACHIEVED errors are written to
+# gpurun_out/parity_margin/<case>.json; tools/mk_parity_margin.py folds them into profiles/r6_parity_margin.json, which bench.py
+# quotes in its JSON line ("parity_margin").
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_AS_BENCHED = r"""
+import json, os, sys, hashlib
+import numpy as np, torch
+sys.path.insert(0, %r)
+from oracle import rsrgan_oracle as O
+from tests.helpers import NET_D, NET_G, build_hip_pair, rand_batch, rel_err, split_flat
+net, B, T, seed = os.environ["RSRGAN_TEST_NET"], int(os.environ["RSRGAN_TEST_B"]), int(os.environ["RSRGAN_TEST_T"]), int(os.environ["RSRGAN_TEST_SEED"])
+cfg = O.NetCfg.res_lstm_l() if net == "res_lstm_l" else O.NetCfg()
+model, oracle = build_hip_pair(cfg, B, T, seed=seed, flags=3)
+host = [rand_batch(cfg, B, T, seed=seed + 100 + i, ragged=True) for i in range(3)]
+dev = [tuple(torch.from_numpy(v).cuda() for v in b) for b in host]
+torch.cuda.synchronize()
+eng = model.engine
+grads = lambda n: split_flat(eng.get_grads(n).cpu().numpy(), eng.tensor_table(n))
+
+# the oracle's side of the case depends on (net, B, T, seed) only: computed once, shared by the DPIPE / tag variants of the case
+cache = os.environ["RSRGAN_TEST_ORACLE_CACHE"]
+if os.path.exists(cache):
+    want = dict(np.load(cache))
+else:
+    want = {}
+    for i, (x, lab, ln) in enumerate(host):
+        x64, lab64 = x.astype(np.float64), lab.astype(np.float64)
+        l, gd = oracle.d_tower(x64, lab64, ln)
+        want["p1_d%%d" %% i] = np.asarray(l, np.float64)
+        l2, gg, y = oracle.g_tower(x64, lab64, ln)
+        want["p1_g%%d" %% i] = np.asarray(l2, np.float64)
+        if i == 2:
+            for k, v in gd.items(): want["gd/" + k] = v
+            for k, v in gg.items(): want["gg/" + k] = v
+            want["y"] = y
+    for i, (x, lab, ln) in enumerate(host):        # three full iterations (1 D + 1 G update each), one per batch
+        x64, lab64 = x.astype(np.float64), lab.astype(np.float64)
+        want["p2_d%%d" %% i] = np.ravel(np.asarray(oracle.d_step(x64, lab64, ln), np.float64))
+        want["p2_g%%d" %% i] = np.ravel(np.asarray(oracle.g_step(x64, lab64, ln), np.float64))
+    x, lab, ln = host[0]
+    want["p2_eval"] = np.ravel(np.asarray(oracle.g_step(x.astype(np.float64), lab.astype(np.float64), ln, train=False), np.float64))
+    tmp = cache + ".%%d.tmp.npz" %% os.getpid()
+    np.savez(tmp, **want); os.replace(tmp, cache)
+
+got = {}
+# phase 1: gradients at the injected variables.  D-run + G-run of the three batches in turn, nine pairs enqueued WITHOUT a host wait
+# (a segment runs eagerly on its first use, is captured on its second, replayed from the third on); nothing is applied
+outs = []
+with eng.on_stream():
+    for it in range(9):
+        x, lab, ln = dev[it %% 3]
+        d = eng.d_backward(x, lab, ln, None, None, train=True, apply=False)
+        g = eng.g_backward(x, lab, ln, None, train=True, reuse=True, apply=False)
+        outs.append((d, g))
+torch.cuda.synchronize()
+for i in range(3):
+    got["p1_d%%d" %% i] = outs[6 + i][0].cpu().numpy().astype(np.float64)
+    got["p1_g%%d" %% i] = outs[6 + i][1].cpu().numpy().astype(np.float64)
+gd, gg = grads(NET_D), grads(NET_G)           # of the last pair: batch 2
+y = model.forward(host[2][0], host[2][2])
+# phase 2: three full iterations as train_one_iteration / bench.py issue them (updates inside rsrgan_d_step / rsrgan_g_step)
+outs = []
+with eng.on_stream():
+    for i in range(3):
+        x, lab, ln = dev[i]
+        d = model.d_step(x, lab, ln, sync=False, gather=False)
+        g = model.g_step(x, lab, ln, reuse_g_forward=True, sync=False, gather=False)
+        outs.append((d, g))
+torch.cuda.synchronize()
+for i in range(3):
+    got["p2_d%%d" %% i] = np.ravel(outs[i][0].cpu().numpy()).astype(np.float64)
+    got["p2_g%%d" %% i] = np.ravel(outs[i][1].cpu().numpy()).astype(np.float64)
+got["p2_eval"] = np.ravel(np.asarray(model.g_step(host[0][0], host[0][1], host[0][2], train=False), np.float64))
+
+relmax = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b)) / np.maximum(np.abs(np.asarray(b)), 1e-30)))
+res = {"loss": 0.0, "loss_after_updates": 0.0, "grad_d": 0.0, "grad_g": 0.0, "worst": {}}
+for k in got:
+    # (g_l2 is exactly 0 with l2_scale = 0 on both sides: skipped by the mask)
+    m = np.abs(want[k]) > 0
+    e = relmax(got[k][m], want[k][m])
+    key = "loss" if k.startswith("p1_") else "loss_after_updates"
+    if e > res[key]:
+        res[key] = e; res["worst"][key] = k
+for k, v in gd.items():
+    e = rel_err(v, want["gd/" + k])
+    if e > res["grad_d"]: res["grad_d"] = e; res["worst"]["grad_d"] = k
+for k, v in gg.items():
+    e = rel_err(v, want["gg/" + k])
+    if e > res["grad_g"]: res["grad_g"] = e; res["worst"]["grad_g"] = k
+res["mfcc_l1"] = float(np.abs(y - want["y"]).mean() / np.abs(want["y"]).mean())
+res["device_status"] = int(eng.device_status())
+eng.profile_begin()
+x, lab, ln = dev[0]
+with eng.on_stream():
+    eng.d_backward(x, lab, ln, None, None, train=True, apply=False)
+res["standalone_g_forward_launches"] = int(eng.profile_read_kind(1)[0])      # 0 under RSRGAN_DPIPE=1: the D-run is k_glstm_fwd_dt
+eng.profile_read()
+res["case"] = {"net": net, "B": B, "T": T, "RSRGAN_DPIPE": os.environ.get("RSRGAN_DPIPE", "0"), "RSRGAN_GP_TAGS": os.environ.get("RSRGAN_GP_TAGS", "1"),
+               "flags": 3, "lengths": "ragged", "batches": 3, "enqueued_without_host_wait": True}
+print("RESULT " + json.dumps(res))
+""" % _ROOT
+
+
+def _as_benched(net, B, T, dpipe, tags):
+    env = dict(os.environ, RSRGAN_TEST_NET=net, RSRGAN_TEST_B=str(B), RSRGAN_TEST_T=str(T), RSRGAN_TEST_SEED=str(500 + B),
+               RSRGAN_DPIPE=str(dpipe), RSRGAN_GP_TAGS=str(tags),
+               RSRGAN_TEST_ORACLE_CACHE=os.path.join(tempfile.gettempdir(), "rsrgan_oracle_asbenched_%s_%d_%d.npz" % (net, B, T)))
+    p = subprocess.run([sys.executable, "-c", _AS_BENCHED], capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    out = os.path.join(_ROOT, "gpurun_out", "parity_margin")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "%s_B%d_T%d_dpipe%d_tags%d.json" % (net, B, T, dpipe, tags)), "w") as f:
+        json.dump(res, f, indent=1, sort_keys=True)
+    return res
+
+
+@pytest.mark.parametrize("tags", [1, 0])
+@pytest.mark.parametrize("dpipe", [1, 0])
+@pytest.mark.parametrize("net,B,T", [("lstm", 64, 100), ("lstm", 32, 50), ("res_lstm_l", 32, 50)])
+def test_full_size_step_as_benched_against_oracle(net, B, T, dpipe, tags):
+    """What bench.py times (RSRGAN_DPIPE=1, tagged ring hand-offs, graph replay, steps enqueued without a host wait over three
+    ragged batches in turn) and its three neighbours (DPIPE off, tags off) against the fp64 oracle."""
+    if tags == 0 and (net, B) != ("lstm", 64):
+        pytest.skip("the untagged hand-offs are compared at the headline size only")
+    r = _as_benched(net, B, T, dpipe, tags)
+    assert r["device_status"] == 0
+    assert r["standalone_g_forward_launches"] == (0 if dpipe else 1), r      # proves which D-run ran
+    assert r["loss"] < RTOL and r["loss_after_updates"] < RTOL, r
+    assert r["grad_d"] < 2e-3 and r["grad_g"] < 2e-3, r
+    assert r["mfcc_l1"] < RTOL, r

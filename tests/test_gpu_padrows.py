@@ -24,6 +24,18 @@ def test_padded_batch_against_oracle(B, T, flags):
     _step_against_oracle(O.NetCfg(), B, T, flags, seed=500 + B)
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
+@pytest.mark.parametrize("net", ["lstm", "res_lstm_l"])
+def test_padded_batch_with_one_persistent_direction_against_oracle(net, mode, monkeypatch):
+    """Round 6 (advisor): a padded batch (batch_size 8 -> one 32-row group) with only ONE of the generator's recurrences persistent
+    (RSRGAN_GPERSIST=1: forward only, =2: BPTT only; read at rsrgan_create).  The one-lane form of the persistent launches (GPersistArgs::
+    nrt = 1) relies on the padding rows of the stash never being written; a launch-path recurrence writes them, so the lane is dropped
+    only when both directions run persistent -- every gradient against the oracle either way."""
+    monkeypatch.setenv("RSRGAN_GPERSIST", mode)
+    cfg = O.NetCfg.res_lstm_l() if net == "res_lstm_l" else O.NetCfg()
+    _step_against_oracle(cfg, 8, 12, 3, seed=640)
+
+
 @pytest.mark.parametrize("B,T,flags", [(8, 100, 3), (8, 12, 1), (1, 30, 1)])
 def test_shipped_recipe_batch_against_oracle(B, T, flags):
     """run_gan_rnn_placeholder.sh:124,126: --g_type res_lstm_l --batch_size 8 -- the residual stack, padded to one 32-row group, on the
@@ -135,6 +147,18 @@ def test_half_the_device_falls_back_without_time_outs(mask):
     if r["n_gp"] != 0:
         pytest.skip("the CU mask %r is not honoured in this environment (the persistent launches ran: %d)" % (mask, r["n_gp"]))
     assert dt < 120, dt
+
+
+def test_probe_verdict_no_selects_the_launch_path():
+    """The fallback itself, independent of whether this environment honours CU masks: RSRGAN_RESIDENT_CAP=128 makes resident_probe
+    answer what it answers on half a device (128 workgroup slots < the 228 of the generator launches, the discriminator's 64 fit):
+    rsrgan_create leaves the generator's hand-off rings unallocated, the steps run on the launch-per-phase path (no persistent
+    generator launch is bracketed), agree with the oracle, and no bounded wait expires."""
+    r = _worker({"RSRGAN_RESIDENT_CAP": "128", "RSRGAN_TEST_FLAGS": "1"})
+    assert r["n_gp"] == 0, r
+    assert r["ok"] and r["recovered"] and r["status"] == [0, 0, 0, 0], r
+    r = _worker({"RSRGAN_RESIDENT_CAP": "16", "RSRGAN_TEST_FLAGS": "3"})        # neither net's persistent launches fit; graph replay
+    assert r["ok"] and r["recovered"] and r["status"] == [0, 0, 0, 0], r
 
 
 def test_a_failed_persistent_launch_disables_the_path_for_the_handle():

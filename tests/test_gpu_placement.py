@@ -61,6 +61,9 @@ if _async:
     # steps enqueued without waiting for their results (what bench.py and train_one_iteration do): the host runs ahead of the device
     import torch
     xs = [tuple(torch.from_numpy(v).cuda() for v in rand_batch(cfg, B, T, seed=40 + i, ragged=True)) for i in range(3)]
+    if os.environ.get("RSRGAN_TEST_LEN64") == "1":
+        # the common dtype of a device `lengths` tensor, and a strided label: their conversion to int32 / contiguous fp32 is a kernel
+        xs = [(x_, torch.stack([l_, l_], -1)[..., 0], n_.to(torch.int64)) for (x_, l_, n_) in xs]
     torch.cuda.synchronize()
     with model.engine.on_stream():
         for i in range(_async):
@@ -222,6 +225,21 @@ def test_pipelined_discriminator_run_agrees(B, T, net):
     assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
     c = _run(dict(size, RSRGAN_DPIPE="1"))
     assert a["vars_sha"] == c["vars_sha"]
+
+
+def test_pipelined_discriminator_run_converts_device_tensors_off_the_compute_stream():
+    """Round 6 (advisor, engine_hip.upload_ready): under RSRGAN_DPIPE=1 the library reads labels and lengths on its side stream AHEAD of
+    the caller's stream.  Device tensors that need a conversion (int64 lengths -- the common dtype --, a strided label) used to be
+    converted by a kernel queued on the compute stream behind its backlog, so D(real) could read the conversion's output before it was
+    written.  24 steps enqueued without a host wait over three ragged batches in turn, int64 lengths and strided labels: the same
+    losses as with int32 / contiguous tensors (bit for bit: the conversion changes no value) and as RSRGAN_DPIPE=0."""
+    size = {"RSRGAN_TEST_B": "32", "RSRGAN_TEST_T": "9", "RSRGAN_TEST_ASYNC": "24"}
+    a = _run(dict(size, RSRGAN_DPIPE="1", RSRGAN_TEST_LEN64="1"))
+    b = _run(dict(size, RSRGAN_DPIPE="1"))
+    c = _run(dict(size, RSRGAN_DPIPE="0", RSRGAN_TEST_LEN64="1"))
+    assert a["device_status"] == 0
+    assert a["async_last"] == b["async_last"] and a["vars_sha"] == b["vars_sha"], (a["async_last"], b["async_last"])
+    assert np.allclose(a["async_last"], c["async_last"], rtol=2e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("net", ["lstm", "res_lstm_l"])
