@@ -488,6 +488,76 @@ def bench_segan(a, rank, local, world, dev):
     rdist.barrier()
 
 
+def bench_host_loop(a, net, B, n_batches, gen_updates, local, via_reader, T=100):
+    """The loop a user runs (scripts/train_gan_rnn_placeholder.py:48-133): train_one_iteration over HOST numpy batches -- ragged lengths,
+    padded per batch -- fed through io.prefetch (the reference's Queue of 32) and uploaded per batch (labels / lengths through
+    HipEngine.upload_ready, which is what earns RSRGAN_DPIPE's guarantee); frames/s end to end, losses fetched once per iteration.
+    via_reader: synthetic Kaldi arks are written to a scratch directory and read back by the bucketing reader
+    (io.features.PaddedBatchReader: ark parsing, padding, length buckets) in the prefetch thread; otherwise the padded batches are
+    materialised beforehand (a reader that keeps up -- the reader's own rate is reported beside it).  One untimed pass first: a
+    graph segment exists per padded length T."""
+    import shutil
+    import tempfile
+    from types import SimpleNamespace
+    from rsrgan_amd import GAN_RNN, train_one_iteration
+    from rsrgan_amd.io import prefetch
+    from rsrgan_amd.io.features import PaddedBatchReader
+    from rsrgan_amd.io.kaldi_ark import ArkWriter
+    rng = np.random.default_rng(99)
+    tmp = tempfile.mkdtemp(prefix="rsrgan_bench_")
+    try:
+        wi, wl = ArkWriter(os.path.join(tmp, "in.scp")), ArkWriter(os.path.join(tmp, "lab.scp"))
+        n_utt = B * n_batches
+        # lengths in {0.6, 0.7, 0.8, 0.9, 1.0} T: ragged rows, yet only a few distinct padded lengths per run (one graph segment each);
+        # one length bucket (num_buckets = 1): get_padded_batch's buckets start at 200 frames, these utterances are shorter
+        lens = rng.choice([int(T * f) for f in (0.6, 0.7, 0.8, 0.9, 1.0)], size=n_utt)
+        for i, n in enumerate(lens):
+            u = "utt%06d" % i
+            wi.write_next_utt(os.path.join(tmp, "in.ark"), u, rng.standard_normal((n, 257)).astype(np.float32))
+            wl.write_next_utt(os.path.join(tmp, "lab.ark"), u, rng.standard_normal((n, 40)).astype(np.float32))
+        wi.close(); wl.close()
+        reader = PaddedBatchReader(os.path.join(tmp, "in.scp"), os.path.join(tmp, "lab.scp"), B, num_buckets=1, shuffle=True, seed=7)
+        t0 = time.perf_counter()
+        batches = list(reader)
+        reader_s = time.perf_counter() - t0
+        batches = [b for b in batches if b[1].shape[0] == B]
+        frames = sum(b[1].shape[0] * b[1].shape[1] for b in batches)
+        args = SimpleNamespace(batch_size=B, input_dim=257, output_dim=40, left_context=0, right_context=0, g_type=net, keep_prob=1.0,
+                               batch_norm=False, num_gpu=1, save_dir=None, l2_scale=0.0, disc_updates=1, gen_updates=gen_updates,
+                               init_mse_weight=10.0, init_disc_noise_std=0.0, d_learning_rate=1e-3, g_learning_rate=8e-5)
+        out = {}
+        for dpipe in ("1", "0"):
+            keep = os.environ.get("RSRGAN_DPIPE")
+            os.environ["RSRGAN_DPIPE"] = dpipe
+            try:
+                model = GAN_RNN(None, args, ["gpu:%d" % local], max_frames=T, seed=4321, net_overrides=dict(flags=a.flags))
+                feed = (lambda: prefetch(PaddedBatchReader(os.path.join(tmp, "in.scp"), os.path.join(tmp, "lab.scp"), B, num_buckets=1,
+                                                           shuffle=True, seed=7), capacity=32)) if via_reader else (lambda: prefetch(batches, capacity=32))
+                for _ in range(2):          # eager, then captured; the timed pass replays
+                    train_one_iteration(None, model, len(batches), 0, feed())
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = train_one_iteration(None, model, len(batches), 1, feed())      # (returns after the losses have reached the host)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                if not np.all(np.isfinite(res)):
+                    raise RuntimeError("non-finite losses %s" % (res,))
+                out["dpipe" + dpipe] = {"value": round(frames / dt, 1), "ms_per_iteration": round(dt * 1e3 / len(batches), 4)}
+                del model
+                torch.cuda.empty_cache()
+            finally:
+                if keep is None:
+                    os.environ.pop("RSRGAN_DPIPE", None)
+                else:
+                    os.environ["RSRGAN_DPIPE"] = keep
+        return {"unit": "frames/s", "batches": len(batches), "frames_per_batch_mean": round(frames / max(len(batches), 1), 1),
+                "padded_lengths": sorted({int(b[1].shape[1]) for b in batches}), "RSRGAN_DPIPE=1": out["dpipe1"], "RSRGAN_DPIPE=0": out["dpipe0"],
+                "reader_alone_frames_per_s": round(frames / reader_s, 1), "fed_by": "PaddedBatchReader in the prefetch thread" if via_reader
+                else "pre-materialised padded batches through io.prefetch"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def spawn_ranks(n, backend):
     """Re-run this command line as n ranks of one node under torch.distributed.run (rendezvous on 127.0.0.1: the container's hostname
     may not resolve).  Fails loudly -- non-zero, nothing printed on stdout -- when the node has fewer GPUs than ranks."""
@@ -559,10 +629,10 @@ def bench_plumbing(a, rank, world):
 
 
 def main():
-    # The sequence benches keep their synthetic batch resident on the device (the contract: inputs in HBM when the timed region starts)
-    # and draw no discriminator noise (init_disc_noise_std = 0), so they can give the library the guarantee RSRGAN_DPIPE=1 asks for --
-    # labels and lengths of rsrgan_d_step are complete when the call is made: D(real) of the next D-run then runs beside the previous
-    # G-run's weight-gradient GEMMs and the D-run itself is one launch less on the chain.  RSRGAN_DPIPE=0 to compare.
+    # RSRGAN_DPIPE=1 is the default of the Python host layer (rsrgan_amd/engine_hip.py: HipEngine hands every D-run's labels and lengths
+    # through upload_ready, which is the guarantee the switch asks for): D(real) of the next D-run runs beside the previous G-run's
+    # weight-gradient GEMMs and the D-run itself is one launch less on the chain.  Set here too so that the line's
+    # "d_pipe" field and the RSRGAN_DPIPE=0 variant read the same variable.  RSRGAN_DPIPE=0 to compare.
     os.environ.setdefault("RSRGAN_DPIPE", "1")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -801,6 +871,15 @@ def main():
             out["variants"].append({"workload": "%s, T=%d" % (tag, T), "value": round(bb * T * n2 / v5["dt"], 1), "unit": "frames/s",
                                     "ms_per_step": round(v5["dt"] * 1e3 / n2, 4)})
             del v5
+            torch.cuda.empty_cache()
+        # the loop a user runs: train_one_iteration fed from host batches (ragged, padded per batch) through io.prefetch + upload_ready
+        for (net_h, bb, gu, nb, rd, tag) in (("res_lstm_l", 8, 2, 50, True, "shipped recipe (res_lstm_l, batch_size 8, 1D+2G), 50 ragged host batches read from Kaldi arks by the bucketing reader"),
+                                             ("lstm", B, 1, 24, False, "headline networks, B=%d, 1D+1G, 24 ragged host batches" % B)):
+            try:
+                h = bench_host_loop(a, net_h, bb, nb, gu, local, rd, T)
+                out["variants"].append(dict({"workload": "train_one_iteration end to end: " + tag}, **h))
+            except Exception as e:      # never lose the headline line to a variant
+                out["variants"].append({"workload": "train_one_iteration end to end: " + tag, "error": str(e)[:200]})
             torch.cuda.empty_cache()
         try:           # BASELINE.json configs[3]: R-CED (257 x 11) + discriminator_dnn, N = 6400 frames (bench.py --net rced --rced-gan)
             import contextlib, io

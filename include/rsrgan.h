@@ -223,8 +223,9 @@ int rsrgan_profile_read(rsrgan_handle h, int32_t* launches, double* total_us, do
  * inside the launch since round 4 --, recurrent product and projection, over the CALLER's rows: padding rows of a row-padded model do
  * not count), kind 2 = k_glstm_bwd, its BPTT (state-gradient product, dh = dm . W_p^T, the input-gradient product
  * above layer 0; in the G-run the launch is k_glstm_bwd_dt, which also carries the discriminator's BPTT in its trailing form,
- * csrc/dpersist_dev.h: that half's state- and input-gradient products, dh = dm . W_p^T and dy . W_out^T are counted too).  Call before
- * rsrgan_profile_read (which closes the window). */
+ * csrc/dpersist_dev.h: that half's state- and input-gradient products, dh = dm . W_p^T and dy . W_out^T are counted too), kind 3 =
+ * k_glstm_fwd_dt, the forward launch with D(G(x)) trailing inside it (the D-run under RSRGAN_DPIPE, every G-run that recomputes the
+ * forward): the NUMBER of launches only (total_us and alg_flops come back 0).  Call before rsrgan_profile_read (which closes the window). */
 int rsrgan_profile_read_kind(rsrgan_handle h, int32_t kind, int32_t* launches, double* total_us, double* alg_flops);
 
 /* Health of the persistent recurrence kernels (csrc/dpersist.hip, csrc/gpersist.hip): synchronises the handle's stream and returns in

@@ -306,7 +306,7 @@ int rsrgan_grad_bucket_wait(rsrgan_handle h, int32_t net, int32_t i, void* strea
 
 int rsrgan_profile_begin(rsrgan_handle h) {
   CHECK_H(h);
-  h->m.prof_on = true; h->m.prof_n = 0; h->m.prof_flops = 0.0; h->m.prof_gp_n = 0; h->m.prof_gp_flops = 0.0; h->m.prof_gb_n = 0; h->m.prof_gb_flops = 0.0;
+  h->m.prof_on = true; h->m.prof_n = 0; h->m.prof_flops = 0.0; h->m.prof_gp_n = 0; h->m.prof_gp_flops = 0.0; h->m.prof_gb_n = 0; h->m.prof_gb_flops = 0.0; h->m.prof_fdt_n = 0;
   g_chain_launches = 0;
   return RSRGAN_OK;
 }
@@ -380,6 +380,10 @@ int rsrgan_profile_read_kind(rsrgan_handle h, int32_t kind, int32_t* launches, d
   CHECK_H(h);
   if (kind == 0) return rsrgan_profile_read(h, launches, total_us, alg_flops);
   Model& m = h->m;
+  if (kind == 3 && launches && total_us && alg_flops) {            // k_glstm_fwd_dt launches since profile_begin: a count only (not bracketed)
+    *launches = m.prof_fdt_n; *total_us = 0.0; *alg_flops = 0.0;
+    return RSRGAN_OK;
+  }
   if ((kind != 1 && kind != 2) || !launches || !total_us || !alg_flops) { set_error("profile_read_kind: bad argument"); return RSRGAN_ERR_INVALID; }
   std::vector<hipEvent_t>& ev = kind == 1 ? m.prof_gp_ev : m.prof_gb_ev;
   const int n = kind == 1 ? m.prof_gp_n : m.prof_gb_n;

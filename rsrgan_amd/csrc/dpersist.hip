@@ -417,6 +417,8 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
     const gu64* gx = edge(min(l + 1, a.nl - 1), 1) + (size_t)j * DP_SLOT;
     gu64* gout_m = edge(l, 0) + (size_t)cq * DP_SLOT;
     gu64* gout_x = edge(l, 1) + (size_t)cq * DP_SLOT;
+    // progress words of this workgroup for the trailing weight-gradient workgroups: [(layer, tile)][T + 1 steps][quarter]
+    gu32* dwf = a.dw_ws ? (gu32*)a.dw_flag + ((size_t)(l * RTn + r) * (T + 1)) * 4 + cq : nullptr;
     float vm[DP_KB * 4], vx[DP_KB * 4];
     auto put = [&](float (*part)[DP_KB][64][4], const float (&v)[DP_KB * 4]) {
 #pragma unroll
@@ -461,13 +463,29 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
       } else {
         // gather wave 3 writes the step's dz over the gate activations: whole 256-byte rows from the LDS stage
         const int c4 = (lane & 15) * 4, rr = lane >> 4;
+        if (dwf) {
+          // (the weight-gradient workgroups trail this launch, dp_dw_body: dz leaves write-through, and the step's progress word says
+          // "everything this workgroup stored up to step t + 1 (dz) / t + 2 (dm) has been acknowledged": this wave's sweep of iteration
+          // t ended in s_waitcnt vmcnt(0) behind the dz stores of iteration t + 1, and the compute wave that stores dm(t + 2) has since
+          // waited for loads it issued behind them.  No wait is added to the chain.)
+          if (lane == 0) __hip_atomic_store(dwf + (size_t)t * 4, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int row = 4 * rg + rr;
-          const size_t grow = (size_t)t * N + r0 + row;
+          for (int rg = 0; rg < 4; ++rg) {
+            const int row = 4 * rg + rr;
+            const size_t grow = (size_t)t * N + r0 + row;
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(L.gates + grow * H4 + g * H + cq * 64 + c4) = *reinterpret_cast<const float4*>(&stage[g][row * DP_HS + c4]);
+            for (int g = 0; g < 4; ++g)
+              dp_store4_wt(L.gates + grow * H4 + g * H + cq * 64 + c4, *reinterpret_cast<const float4*>(&stage[g][row * DP_HS + c4]));
+          }
+        } else {
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int row = 4 * rg + rr;
+            const size_t grow = (size_t)t * N + r0 + row;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4*>(L.gates + grow * H4 + g * H + cq * 64 + c4) = *reinterpret_cast<const float4*>(&stage[g][row * DP_HS + c4]);
+          }
         }
       }
       DPG(3);
@@ -576,9 +594,15 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
       dm[kb] = dp_sel(live, make_float4(dout[kb].x + mf[kb].x, dout[kb].y + mf[kb].y, dout[kb].z + mf[kb].z, dout[kb].w + mf[kb].w),
                       make_float4(0.f, 0.f, 0.f, 0.f));
     if (cq == 0 && w == 0) {                                       // dm_t for the projection's weight gradient
+      if (a.dw_ws) {                                               // (read by the trailing weight-gradient workgroups: write-through)
 #pragma unroll
-      for (int kb = 0; kb < DP_KB; ++kb)
-        if (16 * kb + 4 * q < P) *reinterpret_cast<float4*>(L.dmt + ((size_t)t * N + r0 + lr) * ldP + 16 * kb + 4 * q) = dm[kb];
+        for (int kb = 0; kb < DP_KB; ++kb)
+          if (16 * kb + 4 * q < P) dp_store4_wt(L.dmt + ((size_t)t * N + r0 + lr) * ldP + 16 * kb + 4 * q, dm[kb]);
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < DP_KB; ++kb)
+          if (16 * kb + 4 * q < P) *reinterpret_cast<float4*>(L.dmt + ((size_t)t * N + r0 + lr) * ldP + 16 * kb + 4 * q) = dm[kb];
+      }
     }
     // dh^T[cell][row] = W_p[cell][:] . dm^T
     f32x4 dh = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -660,10 +684,237 @@ __device__ __forceinline__ void dp_bwd_body(const DPersistArgs& a, const unsigne
   if (l > 0) __syncthreads();                                      // C: dx of step 0 is in LDS
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The discriminator's WEIGHT gradients inside the same launch (round 6).  The D-run's BPTT holds 64 of the 256 CUs; its weight
+// gradients used to follow it as twelve launches (split-K GEMMs + reductions + column sums: 0.2 ms for 188 k parameters) in front of
+// the update the G-run waits for.  Here 4 * nl * N/16 more workgroups ride the launch on idle CUs and TRAIL the recurrence by two
+// steps: workgroup (layer l, 16-row tile r, gate g), wave w owns the gate's cells [32w, 32w + 32) and accumulates over all T steps,
+// in registers,
+//   dK[k][col]   += in[row][k] . dz[row][col]      in = [x_t | m_{t-1} | 1]: the row of ones makes the bias gradient row I + P
+//                                                  (96 x 32 per wave: 12 MFMA tiles; rows = the tile's 16 batch rows = 4 MFMAs of k = 4)
+//   dw_{i,f,o}[cell] += dz_gate[row][cell] . c[row][cell]   (c_{t-1} for i and f, c_t for o: BNLSTMCell.py:176-207's peepholes)
+//   dWp[cell][p] += h[row][cell] . dm[row][p]       (the j gate's workgroup, which has no peephole: wave w owns cells [32w, 32w + 32))
+// straight from memory in the MFMA operand layouts (no LDS, no barrier: every wave is its own stream).  dz(t) and dm(t) are the
+// recurrence's write-through stores; the wave polls the four quarters' progress words of step t - 2 (see dp_bwd_body) and reads them
+// with sc1 loads.  The per-tile partial sums land in dw_ws; k_dw_reduce (kernels.hip) adds the N/16 tiles in a fixed order.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int DW_MT = 6;            // 16-row tiles of the [x | m | 1] operand: three of x (I <= 48), three of m and the ones row (P <= 47)
+__device__ __forceinline__ float dp_ld_sc1(const float* p) {
+  return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+template <bool proj>                                                // the j gate has no peephole: its workgroup takes dWp
+__device__ __forceinline__ void dp_dw_body(const DPersistArgs& a, const unsigned gen, const int bid) {
+  const int RTn = a.N >> 4;
+  const int g = bid & 3, cl = bid >> 2;                             // gate (i, j, f, o); (layer, row tile)
+  const int l = cl / RTn, r = cl - l * RTn;
+  const DPersistLayer L = a.L[l];
+  const int lane = threadIdx.x & 63, lr = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int H = a.H, H4 = 4 * H, T = a.T, N = a.N, I = L.I, P = L.P, ldP = L.ldP, ldI = L.ldI;
+  const int r0 = r * 16;
+  const int c0 = 32 * w, col0 = g * H + c0;                         // this wave's 32 cells / gate columns
+  gu32* err = (gu32*)a.ctl + DP_CTL_ERR;
+  const gu32* flags = (const gu32*)a.dw_flag + ((size_t)(l * RTn + r) * (T + 1)) * 4;
+
+  f32x4 acc[DW_MT][2];
+#pragma unroll
+  for (int mt = 0; mt < DW_MT; ++mt) { acc[mt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  f32x4 accp[2][DP_KB];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int nt = 0; nt < DP_KB; ++nt) accp[j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float pp[2] = {0.f, 0.f};
+  const size_t coff = g == 3 ? (size_t)N * H : 0;                   // w_o multiplies the NEW cell state: c_t lives one step further
+
+  // A step = one round trip of operand loads + 48 - 72 MFMAs.  The progress word of the NEXT step travels with the operands of this one
+  // (polled on its own, a step was two dependent round trips, ~5 us against the recurrence's 4.2 us per step: the launch ended 87 us
+  // after its recurrence); only a word that is not there yet -- the wave has caught up with the recurrence -- is polled in a loop.
+  struct Ops { float av[DW_MT][4], bv[2][4], ev[DP_KB][4], fv[2][4]; };
+  bool ok = true;
+  auto wait_for = [&](int t) {                                      // the recurrence is two steps further (or has drained: slot T)
+    const gu32* fp = flags + (size_t)(t >= 2 ? t - 2 : T) * 4;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned spins = 0;; ++spins) {
+      u32x4 v;
+      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(fp) : "memory");
+      if (v.x == gen && v.y == gen && v.z == gen && v.w == gen) return;
+      __builtin_amdgcn_s_sleep(32);
+      if ((spins & 63) == 63 && (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull ||
+                                 __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { ok = false; return; }
+    }
+  };
+  // Operand addresses = a wave-uniform base per (buffer, step, row quad s) + a per-lane offset that never changes: every load is
+  // unconditional (a clamped offset and a select afterwards: a load under a branch closes the branch with a full wait -- the first
+  // version of this loop ran 6 us per step on forty serialised round trips) and leaves in one batch.
+  // The [x | m | 1] operand as 3 + 3 tiles: tiles 0-2 = x features 16mt + lr (< I), tiles 3-5 = m features 16(mt-3) + lr (< P), the
+  // row of ones at m feature P (P < 48, checked by dpersist_dw_supported).
+  unsigned off_x[3], off_m[3], off_d[DP_KB];
+  float msk_x[3], msk_m[3], one_m[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int f = 16 * k + lr;
+    off_x[k] = (unsigned)((r0 + q) * ldI + min(f, I - 1)); msk_x[k] = f < I ? 1.f : 0.f;
+    off_m[k] = (unsigned)((r0 + q) * ldP + min(f, P - 1)); msk_m[k] = f < P ? 1.f : 0.f; one_m[k] = f == P ? 1.f : 0.f;
+    off_d[k] = off_m[k];
+  }
+  const unsigned off_b = (unsigned)((r0 + q) * H4 + col0 + lr);
+  const unsigned off_c = (unsigned)((r0 + q) * (proj ? L.ldH : H) + c0 + lr);
+  auto load = [&](Ops& o, int t) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const size_t rw = (size_t)t * N + 4 * s;                      // (wave-uniform: scalar arithmetic)
+      const float* gb = L.gates + rw * H4;
+      o.bv[0][s] = dp_ld_sc1(gb + off_b);
+      o.bv[1][s] = dp_ld_sc1(gb + off_b + 16);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const size_t rw = (size_t)t * N + 4 * s;
+      const float* xb = L.in + rw * ldI;
+      const float* mb = L.mst + rw * ldP;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { o.av[k][s] = xb[off_x[k]]; o.av[3 + k][s] = mb[off_m[k]]; }
+    }
+    if (proj) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const size_t rw = (size_t)t * N + 4 * s;
+        const float* hb = L.h + rw * L.ldH;
+        const float* db = L.dmt + rw * ldP;
+        o.fv[0][s] = hb[off_c]; o.fv[1][s] = hb[off_c + 16];
+#pragma unroll
+        for (int nt = 0; nt < DP_KB; ++nt) o.ev[nt][s] = dp_ld_sc1(db + off_d[nt]);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float* cb = L.c + coff + ((size_t)t * N + 4 * s) * H;
+        o.fv[0][s] = cb[off_c]; o.fv[1][s] = cb[off_c + 16];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                              // (all requests out before the first select)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { o.av[k][s] *= msk_x[k]; o.av[3 + k][s] = o.av[3 + k][s] * msk_m[k] + one_m[k]; }
+      if (proj) {
+#pragma unroll
+        for (int nt = 0; nt < DP_KB; ++nt) o.ev[nt][s] *= msk_m[nt];
+      }
+    }
+  };
+  auto compute = [&](const Ops& o) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int mt = 0; mt < DW_MT; ++mt) {
+        acc[mt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[mt][s], o.bv[0][s], acc[mt][0], 0, 0, 0);
+        acc[mt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[mt][s], o.bv[1][s], acc[mt][1], 0, 0, 0);
+      }
+    }
+    if (proj) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int nt = 0; nt < DP_KB; ++nt) accp[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.fv[j][s], o.ev[nt][s], accp[j][nt], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { pp[0] += o.bv[0][s] * o.fv[0][s]; pp[1] += o.bv[1][s] * o.fv[1][s]; }
+    }
+  };
+  // ONE wave of the workgroup polls (32 waves spinning on a tile's progress words -- every wave of its four workgroups -- slowed the
+  // recurrence itself: 423 -> 660 us per launch; the words share memory channels with its hand-offs): wave 0 hands what it has seen to
+  // the other seven through an LDS word, `prog` = the lowest step whose operands are known to be complete (T: none yet, -1: give up)
+  __shared__ int prog;
+  if (threadIdx.x == 0) prog = T;
+  __syncthreads();
+  Ops o;
+  if (w == 0) {
+    wait_for(T - 1);
+    if (lane == 0) __hip_atomic_store(&prog, ok ? T - 1 : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int t = T - 1; t >= 0 && ok; --t) {
+      u32x4 fl = {gen, gen, gen, gen};
+      if (t >= 1) {
+        const gu32* fp = flags + (size_t)(t >= 3 ? t - 3 : T) * 4;  // the word step t - 1 waits for
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(fl) : "v"(fp) : "memory");
+      }
+      load(o, t);
+      compute(o);
+      // (the operands above were requested behind the word and have arrived: so has the word; the statement ties its first use to this point)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(fl) : : "memory");
+      if (t >= 1) {
+        if (!(fl.x == gen && fl.y == gen && fl.z == gen && fl.w == gen)) { __builtin_amdgcn_s_sleep(32); wait_for(t - 1); }
+        if (lane == 0) __hip_atomic_store(&prog, ok ? t - 1 : -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  } else {
+    for (int t = T - 1; t >= 0 && ok; --t) {
+      for (;;) {
+        const int p_ = __hip_atomic_load(&prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (p_ < 0) { ok = false; break; }
+        if (p_ <= t) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
+      if (!ok) break;
+      load(o, t);
+      compute(o);
+    }
+  }
+  if (!ok) return;
+  // the tile's partial sums: [I + P + 1][4H] (kernel rows, then the bias row) | [3][H] peepholes w_i, w_f, w_o | [H][ldP] projection
+  float* wsb = a.dw_ws + (size_t)(l * RTn + r) * a.dw_stride;
+#pragma unroll
+  for (int mt = 0; mt < DW_MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = 16 * (mt % 3) + 4 * q + i;                     // x feature (tiles 0-2) / m feature, the row of ones at P (tiles 3-5)
+        const bool on = mt < 3 ? f < I : f <= P;
+        if (on) wsb[(size_t)(mt < 3 ? f : I + f) * H4 + col0 + 16 * nt + lr] = acc[mt][nt][i];
+      }
+  if (proj) {
+    float* pw = wsb + (size_t)(I + P + 1) * H4 + 3 * H;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int nt = 0; nt < DP_KB; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (16 * nt + lr < P) pw[(size_t)(c0 + 16 * j + 4 * q + i) * ldP + 16 * nt + lr] = accp[j][nt][i];
+  } else {
+    float* pw = wsb + (size_t)(I + P + 1) * H4 + (g == 0 ? 0 : g == 2 ? 1 : 2) * H + c0;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      float v = pp[nt];
+      v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);               // the four row groups of a column, fixed order
+      if (q == 0) pw[16 * nt + lr] = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(512, 1) void k_dlstm_bwd(const DPersistArgs a) {
   gu32* ctl = (gu32*)a.ctl;
   const unsigned gen = __hip_atomic_load(ctl + DP_CTL_GEN, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  dp_bwd_body(a, gen);
+  const int nchain = a.nl * (a.N >> 4) * DP_NQ;
+  if ((int)blockIdx.x >= nchain) {
+    const int bid = (int)blockIdx.x - nchain;
+    if ((bid & 3) == 1) dp_dw_body<true>(a, gen, bid); else dp_dw_body<false>(a, gen, bid);
+  } else {
+    dp_bwd_body(a, gen);
+    if (a.dw_ws) {
+      // the last progress word: every store of every wave of this workgroup has been acknowledged
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int RTn = a.N >> 4, ncl = a.nl * RTn, cl = blockIdx.x % ncl, cq = blockIdx.x / ncl;
+        __hip_atomic_store((gu32*)a.dw_flag + ((size_t)cl * (a.T + 1) + a.T) * 4 + cq, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(ctl + DP_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == gridDim.x - 1) {
@@ -702,9 +953,21 @@ bool dpersist_supported(const DPersistArgs& a) {
 
 // a.gran: zeroed ONCE at allocation (tag 0 is never a generation); a.ctl: {1, 0, 0, 0} at allocation
 void launch_dlstm_bwd(const DPersistArgs& a, hipStream_t s) {
-  const int blocks = dpersist_grid(a.nl, a.N);
+  const int blocks = dpersist_grid(a.nl, a.N) + (a.dw_ws ? dpersist_dw_grid(a.nl, a.N) : 0);
   hipLaunchKernelGGL(k_dlstm_bwd, dim3(blocks), dim3(512), 0, s, a);
   ++g_chain_launches;
+}
+// the trailing weight-gradient workgroups of the backward launch (dp_dw_body): their number, the floats of one (layer, tile) record of
+// dw_ws, the bytes of the progress words, and whether the shapes fit
+int dpersist_dw_grid(int nl, int N) { return 4 * nl * (N / 16); }
+size_t dpersist_dw_stride(const DPersistArgs& a) { return (size_t)(a.L[0].I + a.L[0].P + 1) * 4 * a.H + 3 * (size_t)a.H + (size_t)a.H * a.L[0].ldP; }
+size_t dpersist_dw_flag_bytes(int nl, int N, int T) { return (size_t)nl * (N / 16) * (T + 1) * 4 * sizeof(unsigned); }
+bool dpersist_dw_supported(const DPersistArgs& a) {
+  for (int l = 0; l < a.nl; ++l) {
+    const DPersistLayer& L = a.L[l];
+    if (L.I > 48 || L.P > 47 || L.I < 1 || L.I != a.L[0].I || L.P != a.L[0].P || L.ldP != a.L[0].ldP || L.ldI < L.I) return false;
+  }
+  return a.H == 64 * DP_NQ;
 }
 
 // the 2-tile form of the forward launch, stand-alone (RSRGAN_DFWD_T=1: the body that k_glstm_fwd_dt hosts, on the generator's register budget)

@@ -36,6 +36,11 @@ __device__ __forceinline__ void dp_store2(gu64* p, unsigned tag, float v0, float
   // for its own stores, not behind an asm statement)
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 }
+// 16 bytes of ordinary data write-through (what another workgroup of the SAME launch reads behind a progress word: sc1 stores + sc1 loads)
+__device__ __forceinline__ void dp_store4_wt(float* p, const float4 v) {
+  const u32x4 x = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+}
 // the 12 granules of this lane in one slot: 6 loads in flight, one wait
 __device__ __forceinline__ void dp_load12(const gu64* g, int lane, u32x4 (&x)[6]) {
   const gu64* p0 = g + (size_t)lane * 4;

@@ -178,7 +178,17 @@ struct DPersistArgs {
   // the trailing forms (dp_fwdt_body / dp_bwdt_body / dp_fcb_body): 1 = the second 16-row tile of every tile pair holds padding rows only
   // (GPersistArgs::nrt): its phase is two barriers -- no sweep, no product, no publication, no stash rows
   int nrt;
+  // the stand-alone backward launch with the weight gradients inside (dpersist.hip dp_dw_body; null: none): per (layer, 16-row tile)
+  // partial sums [dw_stride floats], progress words [(layer, tile)][T + 1][4] zeroed once at allocation.  Needs L[l].in / ldI of
+  // every layer (layer l > 0: the masked outputs of the layer below)
+  float* dw_ws;
+  unsigned* dw_flag;
+  size_t dw_stride;
 };
+int dpersist_dw_grid(int nl, int N);
+size_t dpersist_dw_stride(const DPersistArgs& a);
+size_t dpersist_dw_flag_bytes(int nl, int N, int T);
+bool dpersist_dw_supported(const DPersistArgs& a);
 size_t dpersist_granule_bytes(int nl, int N, int T);
 int dpersist_trail_grid(int nl, int N);
 size_t dpersist_trail_lds_bytes();
@@ -416,6 +426,10 @@ struct ChunkTable {          // device arrays, one entry per 4096-float chunk of
   int n_chunks, n_tensors;
 };
 void launch_sumsq(const float* g, const ChunkTable& ct, float* partial, hipStream_t s);
+// adds the N/16 per-tile records of dw_ws into the gradient buffer (fixed order) and leaves every chunk's sum of squares in `partial`
+// (k_sumsq's output: the update that follows in the same segment skips that launch); src[tensor] = the tensor's float offset inside a
+// layer-0-tile-0 record (+ layer * ntiles * stride), or -1 for tensors the launch did not compute (their gradient is only squared)
+void launch_dw_reduce(const float* ws, size_t stride, int ntiles, const long long* src, float* g, const ChunkTable& ct, float* partial, hipStream_t s);
 // l2: g += l2_scale*w on flagged tensors; partial[c] = sumsq(w) of flagged chunks (else 0)
 void launch_l2(const float* w, float* g, const ChunkTable& ct, const float* l2_scale, float* partial, hipStream_t s);
 void launch_l2_total(const float* partial, int n_chunks, const float* l2_scale, float* out, hipStream_t s);

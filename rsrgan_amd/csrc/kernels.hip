@@ -1864,6 +1864,41 @@ void launch_sumsq(const float* g, const ChunkTable& ct, float* partial, hipStrea
   hipLaunchKernelGGL(k_sumsq, dim3(ct.n_chunks), dim3(256), 0, s, g, ct, partial);
 }
 
+// The discriminator's weight gradients come out of k_dlstm_bwd as one record of partial sums per (layer, 16-row tile) (dpersist.hip
+// dp_dw_body).  One block per 4096-float chunk of the gradient buffer: the chunk's floats = the sum of the tiles' records in tile order
+// (deterministic), written to the buffer, and -- k_sumsq's job -- the chunk's sum of squares for the per-tensor clip.
+__global__ __launch_bounds__(256) void k_dw_reduce(const float* __restrict__ ws, size_t stride, int ntiles, const long long* __restrict__ src,
+                                                   float* __restrict__ g, ChunkTable ct, float* __restrict__ partial) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const int t = ct.tensor[c];
+  const int off = ct.off[c], n = ct.len[c];
+  const long long so = src[t];
+  float s = 0.f;
+  if (so < 0) {
+    for (int i = threadIdx.x * 4; i < n; i += 1024) {
+      const float4 v = *reinterpret_cast<const float4*>(g + off + i);
+      s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  } else {
+    const float* p = ws + so + (off - ct.off[ct.t_first[t]]);
+    for (int i = threadIdx.x * 4; i < n; i += 1024) {
+      float4 a = *reinterpret_cast<const float4*>(p + i);
+      for (int r = 1; r < ntiles; ++r) {
+        const float4 b = *reinterpret_cast<const float4*>(p + (size_t)r * stride + i);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      *reinterpret_cast<float4*>(g + off + i) = a;
+      s += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+    }
+  }
+  s = block_sum_1024(s, red);
+  if (threadIdx.x == 0) partial[c] = s;
+}
+void launch_dw_reduce(const float* ws, size_t stride, int ntiles, const long long* src, float* g, const ChunkTable& ct, float* partial, hipStream_t s) {
+  hipLaunchKernelGGL(k_dw_reduce, dim3(ct.n_chunks), dim3(256), 0, s, ws, stride, ntiles, src, g, ct, partial);
+}
+
 __global__ __launch_bounds__(256) void k_l2(const float* __restrict__ w, float* __restrict__ g, ChunkTable ct,
                                             const float* __restrict__ l2_scale, float* __restrict__ partial) {
   __shared__ float red[16];

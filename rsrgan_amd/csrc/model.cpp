@@ -445,6 +445,30 @@ int Model::init(const rsrgan_cfg& c, uint64_t seed) {
     dp_ctl = (unsigned*)alloc<float>(16);
     const unsigned ctl0[DP_CTL_WORDS] = {1u, 0u, 0u, 0u};
     HIPC(hipMemcpy(dp_ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice));
+    // the weight gradients inside the D-run's BPTT launch (the stacked call over 2B rows): shapes only here, pointers per call
+    static const bool dw_env = [] { const char* e = getenv("RSRGAN_DW_INKERNEL"); return !e || atoi(e) != 0; }();
+    DPersistArgs pa{};
+    pa.nl = (int)dl.size(); pa.N = 2 * B; pa.H = dl[0].H;
+    for (size_t l = 0; l < dl.size(); ++l) { pa.L[l].I = dl[l].I; pa.L[l].P = dl[l].P; pa.L[l].ldP = dl[l].ldP; pa.L[l].ldI = dl[l].ldI; }
+    bool shapes = dw_env && (dp_env & 2) && dpersist_dw_supported(pa) && !d_adam();
+    for (auto& L : dl) shapes = shapes && L.has_proj && L.H == dl[0].H && L.ldH == dl[0].ldH;
+    if (shapes && dpersist_grid(pa.nl, pa.N) == dp_max_grid) {
+      const int nt = pa.N / 16;
+      dw_stride = dpersist_dw_stride(pa);
+      dw_ws = alloc<float>((size_t)pa.nl * nt * dw_stride);
+      dw_flag = (unsigned*)alloc<float>(dpersist_dw_flag_bytes(pa.nl, pa.N, Tmax) / sizeof(float));
+      std::vector<long long> src(D.t.size(), -1);
+      const int IP = dl[0].I + dl[0].P, H4 = 4 * dl[0].H, H_ = dl[0].H;
+      for (size_t l = 0; l < dl.size(); ++l) {
+        const long long base = (long long)l * nt * (long long)dw_stride;
+        src[dl[l].tK] = base; src[dl[l].tb] = base + (long long)IP * H4;
+        const long long pp = base + (long long)(IP + 1) * H4;
+        src[dl[l].twi] = pp; src[dl[l].twf] = pp + H_; src[dl[l].two] = pp + 2 * H_; src[dl[l].tWp] = pp + 3 * H_;
+      }
+      dw_src = (long long*)alloc<float>(src.size() * 2);
+      if (dw_ws && dw_flag && dw_src) HIPC(hipMemcpy(dw_src, src.data(), src.size() * sizeof(long long), hipMemcpyHostToDevice));
+      else dw_ws = nullptr;
+    }
   }
   if (gp_env && !g_dnn()) {
     GPersistArgs ga{};
@@ -1196,6 +1220,7 @@ bool Model::persist_forward_g_trail(Chain& ch, int T, hipStream_t s, const float
   d.noise = nf; d.dtop = xd; d.ld_dtop = ldDout; d.xd_Ns = ch[0].Ns; d.xd_row0 = ch[0].row0;
   d.nrt = trail_nrt();
   if (check_only) return true;
+  if (prof_on) ++prof_fdt_n;
   glstm_fwd_groups(a, &d, s);
   g_fwd_valid = true;
   return true;
@@ -1299,11 +1324,20 @@ bool Model::persist_backward(Chain& ch, int T, hipStream_t s) {
     DPersistLayer& D_ = a.L[l];
     D_.K = D.W(L.tK); D_.bias = D.W(L.tb); D_.wi = D.W(L.twi); D_.wf = D.W(L.twf); D_.wo = D.W(L.two); D_.Wp = D.W(L.tWp);
     D_.gates = S.gates; D_.c = S.c; D_.h = S.h; D_.mst = S.mst; D_.out = S.out; D_.dmt = S.dmt;
-    D_.I = L.I; D_.P = L.P; D_.ldP = L.ldP; D_.ldH = L.ldH;
+    D_.I = L.I; D_.P = L.P; D_.ldP = L.ldP; D_.ldH = L.ldH; D_.ldI = L.ldI; D_.in = R.in;
   }
   a.dout_top = ch.back().dout; a.ld_dout = dl.back().ldP;
   if (!a.dout_top || !dpersist_supported(a) || dpersist_grid(a.nl, a.N) > dp_max_grid || dpersist_granule_bytes(a.nl, a.N, a.T) > dp_gran_bytes) return false;
+  // the weight gradients ride the launch (dp_dw_body) when every layer wants them, for the stacked call the records were sized for
+  bool dw = dw_ws && !defer_wgrads && a.N == 2 * B && T <= Tmax;
+  for (auto& R : ch) dw = dw && R.want_wgrads && R.in && R.ps == &D;
+  if (dw) { a.dw_ws = dw_ws; a.dw_flag = dw_flag; a.dw_stride = dw_stride; }
   launch_dlstm_bwd(a, s);
+  if (dw) {
+    launch_dw_reduce(dw_ws, dw_stride, a.N / 16, dw_src, D.g, D.ct, D.partial, s);
+    d_partial_fresh = true;
+    return true;
+  }
   if (!defer_wgrads) {           // (on one stream: the discriminator's sequences are short launches, two streams cost them 0.04 ms)
     bool dK_done = false;
     const bool rest = batch_wgrads(ch, T, s, true, &dK_done);
@@ -1906,6 +1940,7 @@ int Model::d_backward(const float* x, const float* labels, const int32_t* length
   }
   if (inl) apply_body(RSRGAN_NET_D, s);
   });
+  d_partial_fresh = false;        // (a later rsrgan_apply -- after the caller's all-reduce -- squares the gradients it finds)
   g_fwd_valid = true;
   if (inl) apply_inlined |= 2;
   if (want_grads) { finish_buckets(RSRGAN_NET_D, s); d_grads_ready = true; }
@@ -2219,7 +2254,8 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
 // per-tensor clip_by_norm + the optimizer + EMA + the weight copies (gan_rnn_placeholder.py:177-189): the launches of one update
 void Model::apply_body(int net, hipStream_t s) {
   if (net == RSRGAN_NET_D) {
-    launch_sumsq(D.g, D.ct, D.partial, s);
+    if (!d_partial_fresh) launch_sumsq(D.g, D.ct, D.partial, s);      // (k_dw_reduce of the same segment has left the sums of squares)
+    d_partial_fresh = false;
     if (d_adam()) {                              // models/gan.py:125: d_opt = AdamOptimizer(d_learning_rate)
       launch_adam_tick(dyn, adam_t_dev_d, (double)cfg.adam_beta1, (double)cfg.adam_beta2, s, DYN_D_LR, DYN_ADAM_LRT_D);
       launch_apply_adam(D.w, D.g, D.m, D.v, D.ema, D.ct, D.partial, dyn, s, DYN_ADAM_LRT_D);

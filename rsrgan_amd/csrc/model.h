@@ -185,6 +185,10 @@ struct Model {
   size_t gp_gran2_bytes = 0;
   int gp_env = 3;                                         // RSRGAN_GPERSIST: bit 0 the forward launch, bit 1 the backward launch (0: the launch-per-phase wavefront)
   int gp_Tcap = 0;                                        // the rings are sized for min(max_frames, GP_TMAX) steps; longer batches take the launch path
+  // the discriminator's weight gradients inside its stand-alone BPTT launch (dpersist.hip dp_dw_body; RSRGAN_DW_INKERNEL=0: the GEMM /
+  // column-sum launches behind it): per-(layer, tile) partial sums, progress words, the tensors' offsets inside a record (device)
+  float* dw_ws = nullptr; unsigned* dw_flag = nullptr; long long* dw_src = nullptr; size_t dw_stride = 0;
+  bool d_partial_fresh = false;                           // k_dw_reduce has just left D.partial (the clip's sums of squares): the inlined update skips k_sumsq
   int dp_max_grid = 0;                                    // largest discriminator launch the device proved it can hold (resident_probe)
   void persist_disable(int which);                        // after a reported failure: 0 = discriminator, 1 = generator launches off for this handle
   bool gp_fwd_on() const { return gp_gran1 && (gp_env & 1); }
@@ -329,6 +333,7 @@ struct Model {
   // ... and for the persistent generator BPTT (k_glstm_bwd: one launch per G-run): rsrgan_profile_read_kind(h, 2, ...)
   std::vector<hipEvent_t> prof_gb_ev;
   int prof_gb_n = 0;
+  int prof_fdt_n = 0;               // fused forward launches (k_glstm_fwd_dt) since profile_begin
   double prof_gb_flops = 0.0;
   void gates_launch(const FwdGateJobs& gj, int blocks, int kb, hipStream_t s);
   int gates_blocks(int H, int N) const;

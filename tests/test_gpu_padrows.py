@@ -48,11 +48,10 @@ def test_shipped_recipe_batch_against_oracle(B, T, flags):
         model.engine.profile_begin()
         model.engine.d_backward(x, lab, ln, None, None, train=True, apply=False)
         model.engine.g_backward(x, lab, ln, None, train=True, reuse=True, apply=False)
-        n = (model.engine.profile_read_kind(1)[0], model.engine.profile_read_kind(2)[0])
+        # (RSRGAN_DPIPE=1, the Python layer's default: the D-run's forward is k_glstm_fwd_dt = kind 3, else k_glstm_fwd = kind 1)
+        n = (model.engine.profile_read_kind(1)[0] + model.engine.profile_read_kind(3)[0], model.engine.profile_read_kind(2)[0])
         model.engine.profile_read()
-        # (RSRGAN_DPIPE=1 in the environment: the D-run is k_glstm_fwd_dt, which the kind-1 bracket does not count)
-        want = ((0, 1), (1, 1)) if os.environ.get("RSRGAN_DPIPE", "0") != "0" else ((1, 1),)
-        assert n in want, "res_lstm_l did not take the persistent launches: %r" % (n,)
+        assert n == (1, 1), "res_lstm_l did not take the persistent launches: %r" % (n,)
         assert model.engine.device_status() == 0
 
 
@@ -77,7 +76,7 @@ def test_padded_batch_runs_the_persistent_launches_and_takes_noise():
     gg = _grads(model, NET_G)
     for k in wg:
         assert rel_err(gg[k], wg[k]) < 2e-3, ("G", k, rel_err(gg[k], wg[k]))
-    n_fwd, n_bwd = model.engine.profile_read_kind(1)[0], model.engine.profile_read_kind(2)[0]
+    n_fwd, n_bwd = model.engine.profile_read_kind(1)[0] + model.engine.profile_read_kind(3)[0], model.engine.profile_read_kind(2)[0]
     model.engine.profile_read()
     assert (n_fwd, n_bwd) == (1, 1), "the persistent generator launches did not run on the padded batch (%d, %d)" % (n_fwd, n_bwd)
     assert model.engine.device_status() == 0
@@ -107,7 +106,7 @@ for it in range(3):      # (the first pass without the updates: a failed launch 
     out["g"].append([float(v) for v in np.ravel(model.g_step(x, lab, ln, train=it > 0, reuse_g_forward=it > 0))])
     out.setdefault("status", []).append(int(model.engine.device_status()))
 if os.environ.get("RSRGAN_TEST_FLAGS") == "1":
-    out["n_gp"] = int(model.engine.profile_read_kind(1)[0] + model.engine.profile_read_kind(2)[0]); model.engine.profile_read()
+    out["n_gp"] = int(model.engine.profile_read_kind(1)[0] + model.engine.profile_read_kind(2)[0] + model.engine.profile_read_kind(3)[0]); model.engine.profile_read()
 # after the passes: the variables put back (a failed launch's update has poisoned them), one evaluation on whatever path the handle
 # is on now against the oracle at the same variables
 from tests.helpers import rand_params
@@ -143,7 +142,7 @@ def test_half_the_device_falls_back_without_time_outs(mask):
     dt = time.time() - t0
     assert r["ok"] and r["recovered"] and r["status"] == [0, 0, 0, 0], r
     full = _worker({"RSRGAN_TEST_FLAGS": "1"})
-    assert full["ok"] and full["recovered"] and full["status"] == [0, 0, 0, 0] and full["n_gp"] == 5, full      # (a forward in the first D-run -- its G-run's recomputed forward is k_glstm_fwd_dt, round 5, not bracketed --, then forward + BPTT per iteration)
+    assert full["ok"] and full["recovered"] and full["status"] == [0, 0, 0, 0] and full["n_gp"] == 6, full      # (evaluation pass: the D-run's forward and the G-run's recomputed one; then forward + BPTT per training iteration)
     if r["n_gp"] != 0:
         pytest.skip("the CU mask %r is not honoured in this environment (the persistent launches ran: %d)" % (mask, r["n_gp"]))
     assert dt < 120, dt

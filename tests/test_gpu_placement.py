@@ -94,6 +94,7 @@ print("RESULT " + json.dumps(out))
 def _run(env):
     e = dict(os.environ)
     e.setdefault("RSRGAN_PAD_ROWS", "0")      # (these cases choose B to pick a path: no silent padding up to the persistent kernels' 32 rows)
+    e.setdefault("RSRGAN_DPIPE", "0")         # (one switch at a time against the stream-ordered D-run; the pipelined D-run -- the Python layer's default -- has its own cases)
     e.update(env)
     p = subprocess.run([sys.executable, "-c", WORKER], capture_output=True, text=True, env=e, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -240,6 +241,25 @@ def test_pipelined_discriminator_run_converts_device_tensors_off_the_compute_str
     assert a["device_status"] == 0
     assert a["async_last"] == b["async_last"] and a["vars_sha"] == b["vars_sha"], (a["async_last"], b["async_last"])
     assert np.allclose(a["async_last"], c["async_last"], rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,T,net", [(64, 100, "lstm"), (32, 9, "lstm"), (32, 1, "lstm"), (32, 2, "lstm"), (32, 3, "lstm"), (8, 7, "res_lstm_l"), (16, 5, "lstm")])
+def test_discriminator_weight_gradients_inside_the_bptt_launch_agree(B, T, net):
+    """Round 6: the D-run's weight gradients (discriminator_lstm.py:70-104; gan_rnn_placeholder.py:144,177-183) are accumulated by
+    workgroups that TRAIL the recurrence inside k_dlstm_bwd (csrc/dpersist.hip dp_dw_body: dz / dm read write-through behind progress
+    words, one record of partial sums per 16-row tile, k_dw_reduce adds the tiles in a fixed order and leaves the clip's sums of
+    squares) -- against the split-K GEMM / column-sum launches behind the recurrence (RSRGAN_DW_INKERNEL=0).  Same products summed in
+    another order: fp32 rounding apart; T = 1, 2, 3 the drained-launch progress word and the two-step lag; reproducible; no failed wait."""
+    size = {"RSRGAN_TEST_B": str(B), "RSRGAN_TEST_T": str(T), "RSRGAN_TEST_NET": net, "RSRGAN_PAD_ROWS": "1", "RSRGAN_TEST_TSEQ": "3,1,2" if T == 9 else ""}
+    a = _run(dict(size))
+    b = _run(dict(size, RSRGAN_DW_INKERNEL="0"))
+    assert a["device_status"] == 0 and b["device_status"] == 0
+    keys = ["d0", "g0", "d1", "g1"] + [k for k in a if k[:2] in ("sd", "sg")]
+    for k in keys:
+        assert np.allclose(a[k], b[k], rtol=5e-5, atol=1e-7), (k, a[k], b[k])
+    assert abs(a["g_norm"] - b["g_norm"]) <= 1e-5 * b["g_norm"]
+    c = _run(dict(size))
+    assert a["vars_sha"] == c["vars_sha"]
 
 
 @pytest.mark.parametrize("net", ["lstm", "res_lstm_l"])
