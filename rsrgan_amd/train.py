@@ -83,11 +83,18 @@ def _train_one_iteration(sess, model, tr_num_batch, iteration, train_queue, num_
             continue
         x = model._shard(queue_inputs); lab = model._shard(queue_labels); ln = model._shard(queue_lengths)
         ready = getattr(model.engine, "upload_ready", None) if os.environ.get("RSRGAN_DPIPE", "0") not in ("", "0") else None
+        later = getattr(model.engine, "upload_async", None)
         if ready is not None and not (isinstance(lab, torch.Tensor) and lab.device == dev):
             # RSRGAN_DPIPE=1: labels and lengths complete BEFORE the D-run is called (copied on the engine's upload stream while the
             # previous step still runs): D(real) of this batch then runs beside the previous G-run's tail
             lab = ready(lab); ln = ready(ln, int32=True)
-        if not isinstance(x, torch.Tensor):
+        if later is not None:
+            # everything else travels on the upload stream as well and is consumed in stream order (an event, no host wait): a copy
+            # queued on the compute stream would sit between the previous G-run and this D-run
+            x = later(x)
+            if not (isinstance(lab, torch.Tensor) and lab.device == dev):
+                lab = later(lab); ln = later(ln, int32=True)
+        elif not isinstance(x, torch.Tensor):
             x = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
             if not isinstance(lab, torch.Tensor):
                 lab = torch.from_numpy(np.ascontiguousarray(lab, np.float32)).to(dev)

@@ -94,7 +94,8 @@ print("RESULT " + json.dumps(out))
 def _run(env):
     e = dict(os.environ)
     e.setdefault("RSRGAN_PAD_ROWS", "0")      # (these cases choose B to pick a path: no silent padding up to the persistent kernels' 32 rows)
-    e.setdefault("RSRGAN_DPIPE", "0")         # (one switch at a time against the stream-ordered D-run; the pipelined D-run -- the Python layer's default -- has its own cases)
+    e["RSRGAN_DPIPE"] = "0"                   # (one switch at a time against the stream-ordered D-run; the pipelined D-run -- the Python layer's default, which an
+                                              #  engine created earlier in this process has written into os.environ -- has its own cases, which set it)
     e.update(env)
     p = subprocess.run([sys.executable, "-c", WORKER], capture_output=True, text=True, env=e, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
