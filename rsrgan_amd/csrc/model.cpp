@@ -2118,9 +2118,13 @@ int Model::g_backward(const float* x, const float* labels, const int32_t* length
     std::vector<FcStage> fcs{F};
     rnn_forward(chains, T, s, &offs, &fcs);
   } else {
-    launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, B, 0, s);
+    // D(G(x)) on y + noise (utils/ops.py:19-30).  Without a noise draw (init_disc_noise_std = 0, the shipped recipe) the discriminator
+    // reads y where it lies -- the same [T][B][ld] layout as its input rows --: one launch less in front of the recurrence
+    const bool direct = !nf && !d_dnn() && dl[0].ldI == ldDout;
+    if (!direct) launch_add_noise_rows(y_tm, nf, xd, B, T, Dout, ldDout, B, 0, s);
     if (!d_dnn()) {
       std::vector<Chain> chains(1, d_chain(B, B, 0));
+      if (direct) chains[0][0].in = y_tm;
       if (!persist_forward(chains[0], T, s) && !fold_forward(chains[0], T, s)) rnn_forward(chains, T, s);
     }
   }
