@@ -170,15 +170,15 @@ if os.path.exists(cache):
 else:
     want = {}
     for i, (x, lab, ln) in enumerate(host):
+        if i != 2: continue          # (gradients and losses at the injected variables: the LAST batch of the turn -- what a mixed-up or stale batch would break; all three batches are compared after the updates below)
         x64, lab64 = x.astype(np.float64), lab.astype(np.float64)
         l, gd = oracle.d_tower(x64, lab64, ln)
         want["p1_d%%d" %% i] = np.asarray(l, np.float64)
         l2, gg, y = oracle.g_tower(x64, lab64, ln)
         want["p1_g%%d" %% i] = np.asarray(l2, np.float64)
-        if i == 2:
-            for k, v in gd.items(): want["gd/" + k] = v
-            for k, v in gg.items(): want["gg/" + k] = v
-            want["y"] = y
+        for k, v in gd.items(): want["gd/" + k] = v
+        for k, v in gg.items(): want["gg/" + k] = v
+        want["y"] = y
     for i, (x, lab, ln) in enumerate(host):        # three full iterations (1 D + 1 G update each), one per batch
         x64, lab64 = x.astype(np.float64), lab.astype(np.float64)
         want["p2_d%%d" %% i] = np.ravel(np.asarray(oracle.d_step(x64, lab64, ln), np.float64))
@@ -199,7 +199,7 @@ with eng.on_stream():
         g = eng.g_backward(x, lab, ln, None, train=True, reuse=True, apply=False)
         outs.append((d, g))
 torch.cuda.synchronize()
-for i in range(3):
+for i in (2,):
     got["p1_d%%d" %% i] = outs[6 + i][0].cpu().numpy().astype(np.float64)
     got["p1_g%%d" %% i] = outs[6 + i][1].cpu().numpy().astype(np.float64)
 gd, gg = grads(NET_D), grads(NET_G)           # of the last pair: batch 2
@@ -250,7 +250,7 @@ print("RESULT " + json.dumps(res))
 def _as_benched(net, B, T, dpipe, tags):
     env = dict(os.environ, RSRGAN_TEST_NET=net, RSRGAN_TEST_B=str(B), RSRGAN_TEST_T=str(T), RSRGAN_TEST_SEED=str(500 + B),
                RSRGAN_DPIPE=str(dpipe), RSRGAN_GP_TAGS=str(tags),
-               RSRGAN_TEST_ORACLE_CACHE=os.path.join(tempfile.gettempdir(), "rsrgan_oracle_asbenched_%s_%d_%d.npz" % (net, B, T)))
+               RSRGAN_TEST_ORACLE_CACHE=os.path.join(tempfile.gettempdir(), "rsrgan_oracle_asbenched2_%s_%d_%d.npz" % (net, B, T)))
     p = subprocess.run([sys.executable, "-c", _AS_BENCHED], capture_output=True, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])

@@ -244,7 +244,7 @@ def test_pipelined_discriminator_run_converts_device_tensors_off_the_compute_str
     assert np.allclose(a["async_last"], c["async_last"], rtol=2e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("B,T,net", [(64, 100, "lstm"), (32, 9, "lstm"), (32, 1, "lstm"), (32, 2, "lstm"), (32, 3, "lstm"), (8, 7, "res_lstm_l"), (16, 5, "lstm")])
+@pytest.mark.parametrize("B,T,net", [(64, 100, "lstm"), (32, 9, "lstm"), (32, 1, "lstm"), (32, 2, "lstm"), (8, 7, "res_lstm_l")])
 def test_discriminator_weight_gradients_inside_the_bptt_launch_agree(B, T, net):
     """Round 6: the D-run's weight gradients (discriminator_lstm.py:70-104; gan_rnn_placeholder.py:144,177-183) are accumulated by
     workgroups that TRAIL the recurrence inside k_dlstm_bwd (csrc/dpersist.hip dp_dw_body: dz / dm read write-through behind progress
