@@ -884,7 +884,8 @@ static int pick_splits(int tiles, int nk, size_t out_bytes, int max_splits, doub
 }
 
 
-int g_gemm_workers = 256;     // worker slots of a launch = one block (4 MFMA + 2 loader waves, ring of LDS buffers) per CU
+thread_local int g_gemm_workers = 256;     // (per host thread: Model::g_backward narrows it around the launches that share the chip with the next D(real))
+                                            // worker slots of a launch = one block (4 MFMA + 2 loader waves, ring of LDS buffers) per CU
 namespace {
 
 struct Plan { int W, n_dp, whole; double cost; };

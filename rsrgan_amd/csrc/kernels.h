@@ -249,7 +249,7 @@ struct GPersistArgs {
 constexpr int GP_TMAX = 2046;                     // longest launch (slot offsets are 32-bit; a longer batch takes the launch-per-phase path)
 bool gpersist_plan(GPersistArgs& a);              // fills NT / NC; false: shape not supported
 void gpersist_arm_bytes(void* p, size_t bytes, hipStream_t s);      // 0xFF-fill as a kernel (a fill node is no dependable predecessor of a persistent launch inside a replayed graph)
-extern int g_gemm_workers;                      // worker slots of a stream-K GEMM launch (gemm.hip)
+extern thread_local int g_gemm_workers;                      // worker slots of a stream-K GEMM launch (gemm.hip)
 int gpersist_grid(const GPersistArgs& a);         // workgroups of a launch (all must be resident at once)
 int gpersist_dt_grid(const GPersistArgs& a, const DPersistArgs& d);      // ... of k_glstm_bwd_dt / k_glstm_fwd_dt
 void launch_glstm_fwd_dt(const GPersistArgs& a, const DPersistArgs& d, hipStream_t s);   // the generator's forward recurrence with D(G(x)) trailing it (ONE launch; a.fwd_trail = 1)

@@ -1104,6 +1104,9 @@ void Model::persist_disable(int which) {
   drop_graphs();
   refresh_swizzles(RSRGAN_NET_G, nullptr);
   refresh_swizzles(RSRGAN_NET_D, nullptr);
+  // (on the null stream, which orders nothing against the non-blocking streams the next call works on: rsrgan_device_status, the only
+  // caller, is a synchronising call anyway)
+  (void)hipStreamSynchronize(nullptr);
 }
 
 void Model::gpersist_rearm() {
