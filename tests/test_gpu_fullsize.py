@@ -275,3 +275,27 @@ def test_full_size_step_as_benched_against_oracle(net, B, T, dpipe, tags):
     assert r["loss"] < RTOL and r["loss_after_updates"] < RTOL, r
     assert r["grad_d"] < 2e-3 and r["grad_g"] < 2e-3, r
     assert r["mfcc_l1"] < RTOL, r
+
+
+def test_shipped_recipe_host_fed_iteration_against_oracle():
+    """The loop a user runs at the recipe the reference ships (run_gan_rnn_placeholder.sh:124,126,129-130: res_lstm_l, batch_size 8, 1 D-run +
+    2 G-runs per batch; scripts/train_gan_rnn_placeholder.py:48-133): train_one_iteration over HOST batches of different padded lengths,
+    ragged rows, through io.prefetch -- labels / lengths through upload_ready (the Python layer's RSRGAN_DPIPE=1 default), the inputs on
+    the upload stream in stream order, the second G-run recomputing the generator's forward (k_glstm_fwd_dt) -- against the oracle's
+    train_one_iteration on the same batches: the 7 averages within 1e-3, the updated variables of both nets after 5 x (1 + 2) updates."""
+    from rsrgan_amd import train_one_iteration
+    from rsrgan_amd.io import prefetch
+    cfg = O.NetCfg.res_lstm_l()
+    B = 8
+    model, oracle = build_hip_pair(cfg, B, 100, seed=810, flags=3, disc_updates=1, gen_updates=2)
+    batches = [rand_batch(cfg, B, T, seed=820 + i, ragged=True) for i, T in enumerate((60, 50, 60, 60, 40))]      # (T = 60: eager, captured, replayed)
+    batches.insert(2, rand_batch(cfg, 5, 60, seed=830))          # a partial window: skipped (train...py:69-70)
+    got = train_one_iteration(None, model, len(batches), 0, prefetch([[None, x, lab, ln] for x, lab, ln in batches], capacity=4))
+    want = O.train_one_iteration(oracle, [(x.astype(np.float64), lab.astype(np.float64), ln) for x, lab, ln in batches], 1, 2)
+    assert np.allclose(got, want, rtol=RTOL), (got, want)
+    gv, dv = model.get_vars()
+    for k, v in oracle.g.items():
+        assert rel_err(gv[k], v) < 1e-4, ("G", k, rel_err(gv[k], v))
+    for k, v in oracle.d.items():
+        assert rel_err(dv[k], v) < 1e-4, ("D", k, rel_err(dv[k], v))
+    assert model.engine.device_status() == 0
