@@ -818,12 +818,12 @@ def main():
         # in the reference); the same kernels run it, reported beside the reference-true headline.
         del model, res
         torch.cuda.empty_cache()
-        v = measure_sequence(a, "baseline_named", "dnn", B, T, max(3, a.steps // 4), 2, rank, local, world, dev)
+        v = measure_sequence(a, "baseline_named", "dnn", B, T, max(10, a.steps // 2), 5, rank, local, world, dev)      # (variants: >= 10 timed steps after 5)
         c2 = v["model"].engine.cfg
         f2, fg2, fd2 = flop_per_frame(257, 40, "res_lstm_base", 2, 512, 0, c2.d_layers, c2.d_cells, 0)
         fd2 = 2 * (40 * c2.d_cells + (c2.d_layers - 1) * c2.d_cells * c2.d_cells + c2.d_cells)
         f2 = 3 * fg2 + 8 * fd2
-        n2 = max(3, a.steps // 4)
+        n2 = max(10, a.steps // 2)
         out["variants"] = [{"workload": "BASELINE.json-named: G=2x512 LSTM (num_proj=None) + D=discriminator_dnn(4x1024), B=%d T=%d" % (B, T),
                             "value": round(B * T * n2 / v["dt"], 1), "unit": "frames/s", "ms_per_step": round(v["dt"] * 1e3 / n2, 4),
                             "roofline_frac": round(f2 * B * T / (v["dev_ms"] * 1e-3 / n2) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
@@ -832,7 +832,7 @@ def main():
         # running residual sum, models/res_lstm_l.py:101-194): 3*F_G + 8*F_D with F_G = 14 083 600
         del v
         torch.cuda.empty_cache()
-        vr = measure_sequence(a, "res_lstm_l", "lstm", B, T, n2, 4, rank, local, world, dev)
+        vr = measure_sequence(a, "res_lstm_l", "lstm", B, T, n2, 5, rank, local, world, dev)
         cr = vr["model"].engine.cfg
         fr, fgr, fdr = flop_per_frame(257, 40, vr["g_type"], cr.g_layers, cr.g_cells, cr.g_proj, cr.d_layers, cr.d_cells, cr.d_proj)
         out["variants"].append({"workload": "shipped network: G=res_lstm_l(4x760/p257) + D=lstm(2x256/p40), 1D+1G, B=%d T=%d" % (B, T),
@@ -843,7 +843,7 @@ def main():
         torch.cuda.empty_cache()
         # the shipped schedule: 1 D-run + 2 G-runs per batch (run_gan_rnn_placeholder.sh:129-130), reference-true networks
         a2 = argparse.Namespace(**vars(a)); a2.gen_updates = 2
-        v2 = measure_sequence(a2, "lstm", "lstm", B, T, n2, 4, rank, local, world, dev)
+        v2 = measure_sequence(a2, "lstm", "lstm", B, T, n2, 5, rank, local, world, dev)
         out["variants"].append({"workload": "shipped schedule 1D+2G per batch, reference-true networks, B=%d T=%d" % (B, T),
                                 "value": round(B * T * n2 / v2["dt"], 1), "unit": "frames/s", "ms_per_step": round(v2["dt"] * 1e3 / n2, 4)})
         del v2
@@ -867,7 +867,7 @@ def main():
         # batch is padded to one 32-row group of the persistent kernels (csrc/model.h Bt); and the same network at BASELINE configs[1]'s batch
         for (bb, gu, tag) in ((8, 2, "shipped recipe: G=res_lstm_l, batch_size 8, 1D+2G"), (32, 1, "shipped network at B=32 (one row group: persistent launches), 1D+1G")):
             a5 = argparse.Namespace(**vars(a)); a5.gen_updates = gu
-            v5 = measure_sequence(a5, "res_lstm_l", "lstm", bb, T, n2, 4, rank, local, world, dev)      # (4 warm-up steps: a segment is captured at its second use, replayed from the third)
+            v5 = measure_sequence(a5, "res_lstm_l", "lstm", bb, T, n2, 5, rank, local, world, dev)      # (warm-up steps: a segment is captured at its second use, replayed from the third)
             out["variants"].append({"workload": "%s, T=%d" % (tag, T), "value": round(bb * T * n2 / v5["dt"], 1), "unit": "frames/s",
                                     "ms_per_step": round(v5["dt"] * 1e3 / n2, 4)})
             del v5
@@ -883,7 +883,7 @@ def main():
             torch.cuda.empty_cache()
         try:           # BASELINE.json configs[3]: R-CED (257 x 11) + discriminator_dnn, N = 6400 frames (bench.py --net rced --rced-gan)
             import contextlib, io
-            a3 = argparse.Namespace(**vars(a)); a3.net = "rced"; a3.rced_gan = True; a3.rced_width = 257; a3.batch = 6400; a3.steps = 3; a3.warmup = 1
+            a3 = argparse.Namespace(**vars(a)); a3.net = "rced"; a3.rced_gan = True; a3.rced_width = 257; a3.batch = 6400; a3.steps = 5; a3.warmup = 2
             buf = io.StringIO()
             with contextlib.redirect_stdout(buf):
                 bench_rced(a3, rank, local, world, dev)
@@ -895,7 +895,7 @@ def main():
             out["variants"].append({"workload": "R-CED + discriminator_dnn (configs[3])", "error": str(e)[:200]})
         try:           # BASELINE.json configs[4]: SEGAN-style conv G/D, 16384-sample chunks, B = 32 (bench.py --net segan --batch 32)
             import contextlib, io
-            a4 = argparse.Namespace(**vars(a)); a4.net = "segan"; a4.batch = 32; a4.segan_len = 16384; a4.steps = 3; a4.warmup = 1
+            a4 = argparse.Namespace(**vars(a)); a4.net = "segan"; a4.batch = 32; a4.segan_len = 16384; a4.steps = 10; a4.warmup = 3
             buf = io.StringIO()
             with contextlib.redirect_stdout(buf):
                 bench_segan(a4, rank, local, world, dev)
